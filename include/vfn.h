@@ -1,0 +1,183 @@
+/*
+ * vfn.h — C ABI of the MI355X-native VF-NeRF volume-rendering hot path.
+ *
+ * This is the drop-in boundary: every entry point is stateless and stream-ordered, takes plain
+ * DEVICE pointers + sizes + a POD parameter struct + the hipStream_t to launch on (passed as
+ * void*), allocates nothing, and returns 0 on success or a negative vfn_status (message via
+ * vfn_last_error()).  All tensors are dense row-major fp32 unless stated.  The reference is pure
+ * Python, so there is no pre-existing FFI; each entry names the reference function it replaces
+ * (paths relative to the reference root) and INTEGRATION.md shows the ctypes binding the facade uses.
+ *
+ * Notation: N rays, S_c coarse samples, N_f fine samples, S_t = S_c + N_f, M points.
+ */
+#ifndef VFN_H
+#define VFN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VFN_ABI_VERSION 1
+
+typedef enum vfn_status {
+    VFN_OK = 0,
+    VFN_ERR_INVALID = -1,     /* bad argument / unsupported shape */
+    VFN_ERR_LAUNCH = -2,      /* HIP launch error */
+    VFN_ERR_UNSUPPORTED = -3  /* network geometry the kernels are not specialised for */
+} vfn_status;
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* vfn_last_error(void);
+int vfn_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Network geometry + packed weights.
+ *
+ * The kernels are specialised for the shipped architecture family (confs/vf_nerf.conf:13-37):
+ * hidden width 256 everywhere, ReLU between layers, eval-mode BatchNorm folded into each Linear,
+ * one optional skip layer that concatenates the positional encoding (vector_field_network.py:192-193),
+ * VF head = 3 vector columns + F feature columns with tanh, rendering head = 3 columns with sigmoid.
+ * ------------------------------------------------------------------------------------------- */
+#define VFN_MAX_LAYERS 16
+#define VFN_HIDDEN 256
+
+typedef struct vfn_net_geom {
+    int32_t n_layers;        /* number of Linear layers (VF: 9, render: 5 in the shipped conf)          */
+    int32_t multires;        /* positional-encoding octaves L (embedder.py:40-52); VF: 6, render: 4     */
+    int32_t skip_layer;      /* index of the layer whose input is cat([x, PE])/sqrt(2); -1 = none       */
+    int32_t feature_dims;    /* VF: F (256 or 0); render: width of the feature input (256 or 0)         */
+    int32_t in_dims[VFN_MAX_LAYERS];   /* reference in_features of each Linear                          */
+    int32_t out_dims[VFN_MAX_LAYERS];  /* reference out_features of each Linear                         */
+    int32_t has_bn[VFN_MAX_LAYERS];    /* 1 when the Linear is followed by BatchNorm1d                  */
+} vfn_net_geom;
+
+/* Raw (reference-layout) parameter pointers of one layer: Linear weight[out][in], bias[out], and the
+ * BatchNorm1d weight/bias/running_mean/running_var[out] (NULL when has_bn == 0). */
+typedef struct vfn_layer_params {
+    const float* weight;
+    const float* bias;
+    const float* bn_weight;
+    const float* bn_bias;
+    const float* bn_mean;
+    const float* bn_var;
+} vfn_layer_params;
+
+#define VFN_NET_VF 0
+#define VFN_NET_RENDER 1
+
+/* Number of floats of the packed-weight workspace for a network of this geometry (host-side, no GPU).
+ * Returns < 0 (vfn_status) when the geometry is unsupported. */
+int64_t vfn_packed_size(int32_t net_kind, const vfn_net_geom* geom);
+
+/* Fold eval-mode BatchNorm (eps 1e-5) and the skip 1/sqrt(2) into each Linear and re-order the result
+ * into the MFMA-fragment order the fused kernels stream (see DESIGN.md "packed weights").  Must be
+ * re-run after every optimizer step; reads the live parameter storage, writes `packed`.
+ * Replaces: the per-call nn.Linear/nn.BatchNorm1d parameter reads of vector_field_network.py:177-208
+ * and rendering_network.py:98-103. */
+int vfn_pack_weights(int32_t net_kind, const vfn_net_geom* geom, const vfn_layer_params* layers,
+                     float* packed, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1 — rays + coarse sampler.
+ * Replaces utils/rendering.py:12-60 (+ utils/pinhole_model.py:9-63) and
+ * models/samplers/ray_sampler.py:49-80,113-142.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vfn_raygen_params {
+    int32_t n_rays;
+    int32_t n_samples;       /* S_c */
+    int32_t pose_is_quat;    /* 0: pose[N,4,4]; 1: pose[N,7] = (qr,qi,qj,qk,tx,ty,tz) */
+    float near;
+    float far;               /* used when far_per_ray == NULL */
+} vfn_raygen_params;
+
+/* uv[N,2] (u = x, v = y), pose, intrinsics[N,4,4], t_vals[S_c] = linspace(0,1,S_c) (host supplied so
+ * that it is bit-identical to torch.linspace), far_per_ray[N] or NULL, u_coarse[N,S_c] uniforms in
+ * [0,1) or NULL for deterministic sampling.
+ * Outputs: directions[N,3] (un-normalised, Q7), ray_dirs[N,3] (unit), cam_loc[N,3], z_vals[N,S_c],
+ * points[N,S_c,3]. */
+int vfn_raygen_uniform(const vfn_raygen_params* p, const float* uv, const float* pose, const float* intrinsics,
+                       const float* t_vals, const float* far_per_ray, const float* u_coarse,
+                       float* directions, float* ray_dirs, float* cam_loc, float* z_vals, float* points,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2/K4 — fused MLPs (fp32 MFMA, weights from vfn_pack_weights).
+ * ------------------------------------------------------------------------------------------- */
+/* points[M,3] -> out.  out_cols == 3: only the vector columns [M,3] (proposal pass, grid queries:
+ * vector_field_nerf.py:253-256, evaluation/utils/mc_utils.py:100); out_cols == 3+F: the full
+ * [M,3+F] row (vector_field_network.py:140-208, eval mode). */
+int vfn_vf_mlp_fwd(const vfn_net_geom* geom, const float* packed, const float* points, int64_t n_points,
+                   int32_t out_cols, float* out, void* stream);
+
+/* Rendering MLP alone: rendering_network.py:62-108 (mode "idr").  view_dirs[M,3] per point. */
+int vfn_render_mlp_fwd(const vfn_net_geom* geom, const float* packed, const float* points, const float* normals,
+                       const float* view_dirs, const float* feats, int64_t n_points, float* colors,
+                       void* stream);
+
+/* Fine pass in one launch: VF MLP -> (features stay in LDS) -> rendering MLP.
+ * points[M,3] with M = N*S_t, ray_dirs[N,3]; row m uses ray_dirs[m / samples_per_ray].
+ * Outputs normals[M,3] (tanh'ed vector columns) and colors[M,3] (sigmoid); feats_out[M,F] optional
+ * (NULL to skip).  Replaces vector_field_nerf.py:294-297 + :315-318. */
+int vfn_vf_render_fused_fwd(const vfn_net_geom* vf_geom, const float* vf_packed,
+                            const vfn_net_geom* rn_geom, const float* rn_packed,
+                            const float* points, const float* ray_dirs, int64_t n_points,
+                            int32_t samples_per_ray, float* normals, float* colors, float* feats_out,
+                            void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3 — per-ray density -> VolSDF weights (-> argmax / composite).
+ * Replaces vector_field_nerf.py:442-474 (get_density), models/helpers/functions.py:41-72,
+ * models/helpers/density_functions.py:129-204, utils/rendering.py:122-148 and the sums at
+ * vector_field_nerf.py:322-323.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vfn_density_params {
+    int32_t n_rays;
+    int32_t n_samples;        /* S: samples per ray in this pass                                   */
+    int32_t n_window;         /* W = len(cos_sim_weights); uniform ones/W weights are used (Q6)     */
+    int32_t normalize;        /* normalize_rendering                                                */
+    float dir_to_normal_th;
+    float beta_min, beta_max; /* density_config.beta_bounds                                         */
+    float mean_min, mean_max; /* density_config.mean_bounds                                         */
+    float scale_min;
+    float cutoff;             /* -0.5: the reference drops the configured cutoff (Q5)               */
+} vfn_density_params;
+
+/* normals[N,S,3], ray_dirs[N,3], z_vals[N,S]; density_scalars = device pointer to {beta, mean, scale}
+ * (raw, un-clamped learnable values).  Outputs (any may be NULL): sigma[N,S], weights[N,S],
+ * argmax[N] int64 (first maximum of weights), and, when colors[N,S,3] is given, rgb[N,3] and
+ * depth[N] (= sum_s w c, sum_s w z). */
+int vfn_ray_density_weights(const vfn_density_params* p, const float* normals, const float* ray_dirs,
+                            const float* z_vals, const float* density_scalars, const float* colors,
+                            float* sigma, float* weights, int64_t* argmax, float* rgb, float* depth,
+                            void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3b — range fine sampler.  Replaces models/samplers/ray_sampler.py:264-302 + :77-78.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vfn_fine_params {
+    int32_t n_rays;
+    int32_t n_coarse;   /* S_c */
+    int32_t n_fine;     /* N_f = min(N_samples, max_samples) */
+    float near;
+    float far;          /* used when far_per_ray == NULL */
+    float half_range;   /* fine_range, as fp32 */
+    float window_step;  /* fp32(2*fine_range/(N_f-1)) evaluated in double by the host, as Python does */
+    float span;         /* fp32(far - near) evaluated in double by the host; ignored with far_per_ray */
+} vfn_fine_params;
+
+/* z_coarse[N,S_c], argmax[N] (from vfn_ray_density_weights), directions[N,3], cam_loc[N,3],
+ * u_fine[N,N_f] or NULL (deterministic window), u_add[N,N_f] (always consumed, Q9).
+ * Outputs z_vals[N,S_t] ascending, points[N,S_t,3]. */
+int vfn_range_fine_sample(const vfn_fine_params* p, const float* z_coarse, const int64_t* argmax,
+                          const float* directions, const float* cam_loc, const float* far_per_ray,
+                          const float* u_fine, const float* u_add, float* z_vals, float* points, void* stream);
+
+/* Counter-based uniforms in [0,1) for production sampling (Philox4x32-10, one 4-tuple per 4 outputs). */
+int vfn_fill_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFN_H */

@@ -1,0 +1,359 @@
+"""CPU oracle for the VF-NeRF volume-rendering hot path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a plain PyTorch-CPU (fp32) restatement of the
+reference algorithm behind ``VectorFieldNerf.render`` so that the HIP path can be
+checked on a box where ``/root/reference`` does not exist.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import it;
+the product package ``vf_nerf_amd`` never does.
+
+Parity pin: the reference has no tests / golden vectors of its own, so
+this oracle is pinned against outputs of the reference itself, captured in the build
+container by ``tests/golden/make_golden.py`` (imports ``/root/reference`` read-only) and
+committed as ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` replays them.
+
+Every function cites the reference lines it restates (paths relative to the reference
+root).  Weights are passed as state dicts using the reference's key names
+(``layers.{i}.0.weight`` … ``layers.8.bias``) so real checkpoints can be fed in.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------------------
+# a1: rays  (utils/rendering.py:12-60, utils/pinhole_model.py:9-63)
+# --------------------------------------------------------------------------------------
+def quaternion_pose_to_matrix(pose7: Tensor) -> Tensor:
+    """[N,7] (qr,qi,qj,qk,tx,ty,tz) -> [N,4,4].  utils/pinhole_model.py:9-33 and
+    utils/rendering.py:27-33 (the reference hard-codes .cuda() there, Q13; the math is
+    restated device-free)."""
+    q = F.normalize(pose7[:, :4], dim=1)
+    r, i, j, k = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    n = pose7.shape[0]
+    p = torch.eye(4, dtype=pose7.dtype).repeat(n, 1, 1)
+    p[:, 0, 0] = 1 - 2 * (j ** 2 + k ** 2)
+    p[:, 0, 1] = 2 * (j * i - k * r)
+    p[:, 0, 2] = 2 * (i * k + r * j)
+    p[:, 1, 0] = 2 * (j * i + k * r)
+    p[:, 1, 1] = 1 - 2 * (i ** 2 + k ** 2)
+    p[:, 1, 2] = 2 * (j * k - i * r)
+    p[:, 2, 0] = 2 * (k * i - j * r)
+    p[:, 2, 1] = 2 * (j * k + i * r)
+    p[:, 2, 2] = 1 - 2 * (i ** 2 + j ** 2)
+    p[:, :3, 3] = pose7[:, 4:]
+    return p
+
+
+def ray_directions(uv: Tensor, pose: Tensor, intrinsics: Tensor):
+    """uv[N,2], pose[N,4,4]|[N,7], K[N,4,4] -> directions[N,3] (un-normalised, camera z=±1),
+    ray_dirs[N,3] (unit), cam_loc[N,3].  utils/rendering.py:12-60 + pinhole_model.py:36-63.
+    The z sign is read from ray 0's fy only (rendering.py:42)."""
+    if pose.shape[1] == 7:
+        pose = quaternion_pose_to_matrix(pose)
+    cam_loc = pose[:, :3, 3]
+    fx, fy = intrinsics[:, 0, 0], intrinsics[:, 1, 1]
+    cx, cy = intrinsics[:, 0, 2], intrinsics[:, 1, 2]
+    sk = intrinsics[:, 0, 1]
+    u, v = uv[:, 0], uv[:, 1]
+    z = torch.ones(uv.shape[0], dtype=uv.dtype) * torch.sign(intrinsics[0, 1, 1])
+    x = (u - cx + cy * sk / fy - sk * v / fy) / fx * z.abs()
+    y = (v - cy) / fy * z.abs()
+    cam_h = torch.stack([x, y, z, torch.ones_like(z)], dim=-1).unsqueeze(-1)  # [N,4,1]
+    world = torch.bmm(pose, cam_h)[:, :3, 0]
+    directions = world - cam_loc
+    ray_dirs = F.normalize(directions, dim=1)
+    return directions, ray_dirs, cam_loc
+
+
+# --------------------------------------------------------------------------------------
+# a2: coarse sampler  (models/samplers/ray_sampler.py:49-80, 113-142)
+# --------------------------------------------------------------------------------------
+def stratify(z: Tensor, u: Tensor) -> Tensor:
+    """Stratified jitter inside the half-way intervals (ray_sampler.py:132-140, 282-289)."""
+    mids = 0.5 * (z[..., 1:] + z[..., :-1])
+    upper = torch.cat([mids, z[..., -1:]], -1)
+    lower = torch.cat([z[..., :1], mids], -1)
+    return lower + (upper - lower) * u
+
+
+def uniform_z_vals(n_rays: int, n_samples: int, near: float, far, u: Optional[Tensor] = None) -> Tensor:
+    """z[N,S_c].  ``far`` is a float or a per-ray [N,1] tensor (ray_sampler.py:126-127).
+    ``u`` = the torch.rand(N,S_c) draw when perturb is on, None when deterministic."""
+    near_t = near * torch.ones(n_rays, 1)
+    far_t = far * torch.ones(n_rays, 1) if isinstance(far, float) else far
+    t = torch.linspace(0.0, 1.0, steps=n_samples)
+    z = near_t * (1.0 - t) + far_t * t
+    if u is not None:
+        z = stratify(z, u)
+    return z
+
+
+def points_along_rays(cam_loc: Tensor, directions: Tensor, z: Tensor) -> Tensor:
+    """[N,S,3] = o + z * d with the UN-normalised d (ray_sampler.py:77-78; Q7)."""
+    return cam_loc.unsqueeze(1) + z.unsqueeze(2) * directions.unsqueeze(1)
+
+
+# --------------------------------------------------------------------------------------
+# a3: positional encoding  (models/helpers/embedder.py:11-37, 40-52)
+# --------------------------------------------------------------------------------------
+def positional_encoding(x: Tensor, n_freqs: int) -> Tensor:
+    """[M,3] -> [M, 3 + 6 L]: x, then per octave sin(2^k x), cos(2^k x) as 3-wide blocks."""
+    out = [x]
+    for k in range(n_freqs):
+        f = float(2.0 ** k)
+        out.append(torch.sin(x * f))
+        out.append(torch.cos(x * f))
+    return torch.cat(out, dim=-1)
+
+
+# --------------------------------------------------------------------------------------
+# a4 / a10: the two MLPs, eval mode  (vector_field_network.py:177-208,
+#           rendering_network.py:62-108)
+# --------------------------------------------------------------------------------------
+def _n_layers(sd: Dict[str, Tensor]) -> int:
+    idx = {int(k.split('.')[1]) for k in sd if k.startswith('layers.')}
+    return max(idx) + 1
+
+
+def _layer_eval(sd: Dict[str, Tensor], i: int, x: Tensor) -> Tensor:
+    """Linear (+ BatchNorm1d with running statistics, eps 1e-5) of layer i."""
+    if f'layers.{i}.0.weight' in sd:  # nn.Sequential(Linear, BatchNorm1d)
+        y = F.linear(x, sd[f'layers.{i}.0.weight'], sd[f'layers.{i}.0.bias'])
+        if f'layers.{i}.1.running_mean' in sd:
+            y = F.batch_norm(y, sd[f'layers.{i}.1.running_mean'], sd[f'layers.{i}.1.running_var'],
+                             sd[f'layers.{i}.1.weight'], sd[f'layers.{i}.1.bias'], False, 0.0, 1e-5)
+        return y
+    return F.linear(x, sd[f'layers.{i}.weight'], sd[f'layers.{i}.bias'])
+
+
+def vf_mlp(points: Tensor, sd: Dict[str, Tensor], multires: int = 6, skip_in=(4,)) -> Tensor:
+    """[M,3] -> [M, 3 + F] (cols 0:3 vector after tanh, 3: features after tanh).
+    vector_field_network.py:177-208: skip layers see cat([x, pe]) / sqrt(2); ReLU between
+    layers, tanh on the last."""
+    pe = positional_encoding(points, multires) if multires > 0 else points
+    n = _n_layers(sd)
+    x = pe.clone()
+    inv = torch.sqrt(torch.tensor([2.0]))
+    for i in range(n):
+        if i in skip_in:
+            x = torch.cat([x, pe], 1) / inv
+        x = _layer_eval(sd, i, x)
+        x = torch.relu(x) if i < n - 1 else torch.tanh(x)
+    return x
+
+
+def render_mlp(points: Tensor, normals: Tensor, view_dirs: Tensor, feats: Tensor,
+               sd: Dict[str, Tensor], multires: int = 4) -> Tensor:
+    """mode 'idr' (rendering_network.py:84-86): cat[p, PE(d), n, feat] -> ReLU MLP -> sigmoid."""
+    d = positional_encoding(view_dirs, multires) if multires > 0 else view_dirs
+    x = torch.cat([points, d, normals, feats], dim=-1)
+    n = _n_layers(sd)
+    for i in range(n):
+        x = _layer_eval(sd, i, x)
+        if i < n - 1:
+            x = torch.relu(x)
+    return torch.sigmoid(x)
+
+
+# --------------------------------------------------------------------------------------
+# a5: windowed cosine similarity  (models/helpers/functions.py:41-72)
+# --------------------------------------------------------------------------------------
+def window_cosine(normals: Tensor, weights: Tensor) -> Tensor:
+    """normals[N,S,3], weights[W] -> [N,S-1].  Entry j is cos(n_j, n_{j+1}); for the
+    interior j in [start, S-1-start) it becomes the weighted sum over n_{j+1..j+start-1}
+    (forward) and n_{j-1..j-(start-2)} (backward), weights normalised by sum |w|."""
+    w_n = weights.shape[0]
+    start = int((w_n + 1) / 2 + 1)
+    middle = int((w_n - 1) / 2)
+    norm = torch.tensor(0.0)
+    for i in range(w_n):
+        norm = norm + weights[i].abs()
+    x, y = normals[:, :-1, :], normals[:, 1:, :]
+    c = F.cosine_similarity(x, y, dim=2)
+    out = c.clone()
+    lo, hi = start, c.shape[1] - start
+    if hi > lo:
+        acc = c[:, lo:hi] * weights[middle] / norm
+        for i in range(1, start - 1):
+            fwd = F.cosine_similarity(x[:, lo:hi], y[:, lo + i:hi + i], dim=2)
+            bwd = F.cosine_similarity(x[:, lo:hi], y[:, lo - i - 1:hi - i - 1], dim=2)
+            acc = acc + fwd * weights[middle + i].abs() / norm + bwd * weights[middle - i].abs() / norm
+        out[:, lo:hi] = acc
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# a7: Laplace density  (models/helpers/density_functions.py:20-34, 129-204)
+# --------------------------------------------------------------------------------------
+@dataclass
+class DensityParams:
+    beta: float = 0.5
+    mean: float = 0.7
+    scale: float = 100.0
+    beta_bounds: tuple = (1e-4, 1e9)
+    mean_bounds: tuple = (0.6, 1.0)
+    scale_min: float = 1.0
+    # Density.forward drops ``cutoff`` (density_functions.py:34, Q5): always -0.5.
+    cutoff: float = -0.5
+
+    def tensors(self):
+        return (torch.tensor(self.beta), torch.tensor(self.mean), torch.tensor(self.scale))
+
+
+def laplace_cdf(x: Tensor, beta: Tensor, scale: Tensor, mean: Tensor) -> Tensor:
+    """density_functions.py:153-167."""
+    return scale * (0.5 + 0.5 * torch.sign(x - mean) * (1 - torch.exp(-torch.abs(x - mean) / beta)))
+
+
+def laplace_density(x: Tensor, p: DensityParams, beta=None, mean=None, scale=None) -> Tensor:
+    """relu(cdf(x) - cdf(cutoff)) with clamped parameters (density_functions.py:129-204).
+    beta/mean/scale may be passed as (autograd) tensors, else taken from ``p``."""
+    b0, m0, s0 = p.tensors()
+    beta = b0 if beta is None else beta
+    mean = m0 if mean is None else mean
+    scale = s0 if scale is None else scale
+    beta = torch.clamp(beta, torch.tensor(p.beta_bounds[0]), torch.tensor(p.beta_bounds[1]))
+    mean = torch.clamp(mean, torch.tensor(p.mean_bounds[0]), torch.tensor(p.mean_bounds[1]))
+    scale = torch.max(scale.abs(), torch.tensor(p.scale_min))
+    return torch.relu(laplace_cdf(x, beta, scale, mean) - laplace_cdf(torch.tensor([p.cutoff]), beta, scale, mean))
+
+
+# --------------------------------------------------------------------------------------
+# a6: density along a ray  (models/nerf/vector_field_nerf.py:442-474)
+# --------------------------------------------------------------------------------------
+def ray_density(normals: Tensor, ray_dirs: Tensor, n_window: int, dir_to_normal_th: float,
+                p: DensityParams, beta=None, mean=None, scale=None, return_parts: bool = False):
+    """normals[N,S,3], ray_dirs[N,3] (unit, one per ray) -> sigma[N,S] (last column 0).
+    Uniform window weights ones/W are used whatever the annealed config says (Q6)."""
+    n, s, _ = normals.shape
+    w = torch.ones(n_window) / n_window
+    c = window_cosine(normals, w)
+    rd = ray_dirs.unsqueeze(1).expand(n, s, 3)
+    c_ray = F.cosine_similarity(normals[:, :-1, :], rd[:, :-1, :], dim=2)
+    masked = torch.logical_and(c_ray < dir_to_normal_th, c < 0)
+    sigma = laplace_density(-c.reshape(-1, 1), p, beta, mean, scale).reshape(n, s - 1)
+    sigma = torch.where(masked, torch.zeros_like(sigma), sigma)
+    sigma = torch.cat([sigma, torch.zeros(n, 1)], dim=-1)
+    if return_parts:
+        return sigma, c, c_ray
+    return sigma
+
+
+# --------------------------------------------------------------------------------------
+# a8: VolSDF weights  (utils/rendering.py:122-148)
+# --------------------------------------------------------------------------------------
+def volsdf_weights(z: Tensor, sigma: Tensor, normalize: bool = True) -> Tensor:
+    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((z.shape[0], 1), 1e10)], dim=-1)
+    e = dists * sigma
+    shifted = torch.cat([torch.zeros(z.shape[0], 1), e[:, :-1]], dim=-1)
+    transmittance = torch.exp(-torch.cumsum(shifted, dim=-1))
+    w = (1.0 - torch.exp(-e)) * transmittance
+    if normalize:
+        w = w / (w.sum(dim=-1, keepdim=True) + 1e-5)
+    return w
+
+
+# --------------------------------------------------------------------------------------
+# a9: range fine sampler  (models/samplers/ray_sampler.py:264-302)
+# --------------------------------------------------------------------------------------
+def range_fine_z_vals(z_c: Tensor, w_c: Tensor, n_fine: int, near: float, far: float, half_range: float,
+                      u_add: Tensor, u_fine: Optional[Tensor] = None):
+    """-> (z[N,S_c+N_f] sorted, argmax[N] int64).  u_add = the always-drawn rand(N,N_f)
+    (Q9); u_fine = the stratification draw (None when deterministic).  Rays whose argmax
+    is 0 take the uniform u_add samples, the others a window of +-range (not clamped)."""
+    imax = torch.argmax(w_c, dim=-1)
+    z_star = z_c[torch.arange(z_c.shape[0]), imax]
+    window = z_star[:, None] - half_range + 2 * half_range / (n_fine - 1) * torch.arange(n_fine)
+    if u_fine is not None:
+        window = stratify(window, u_fine)
+    z_add = u_add * (far - near) + near
+    pick = (imax > 0).unsqueeze(1)
+    extra = torch.where(pick, window, z_add)
+    z = torch.sort(torch.cat([z_c, extra], dim=-1), dim=-1)[0]
+    return z, imax
+
+
+# --------------------------------------------------------------------------------------
+# a12: render()  (models/nerf/vector_field_nerf.py:216-338), eval-mode networks
+# --------------------------------------------------------------------------------------
+@dataclass
+class RenderSettings:
+    n_samples: int = 64
+    n_fine: int = 64            # min(fine_sampler.N_samples, max_samples) at call time (Q16)
+    near: float = 0.0
+    far: float = 1.0
+    fine_range: float = 0.3
+    perturb: bool = False
+    n_window: int = 11
+    dir_to_normal_th: float = -2.0
+    normalize: bool = True
+    vf_multires: int = 6
+    vf_skip_in: tuple = (4,)
+    render_multires: int = 4
+    feature_dims: int = 256
+    density: DensityParams = field(default_factory=DensityParams)
+
+
+def render(uv: Tensor, pose: Tensor, intrinsics: Tensor, vf_sd: Dict[str, Tensor], rn_sd: Dict[str, Tensor],
+           cfg: RenderSettings, u_coarse: Optional[Tensor] = None, u_fine: Optional[Tensor] = None,
+           u_add: Optional[Tensor] = None, far=None, beta=None, mean=None, scale=None) -> Dict[str, Tensor]:
+    """Full forward of the path; returns every stage so tests can compare stage-wise.
+    Random draws are explicit inputs, in the order the reference draws them
+    (ray_sampler.py:138, :287, :292).  The proposal ("coarse") pass only evaluates the VF
+    net (vector_field_nerf.py:252-277); the returned rgb/depth come from the S_c+N_f pass
+    (Q2)."""
+    out: Dict[str, Tensor] = {}
+    n = uv.shape[0]
+    far_v = cfg.far if far is None else far
+    directions, ray_dirs, cam_loc = ray_directions(uv, pose, intrinsics)
+    out.update(directions=directions, ray_dirs=ray_dirs, cam_loc=cam_loc)
+
+    z_c = uniform_z_vals(n, cfg.n_samples, cfg.near, far_v, u_coarse if cfg.perturb else None)
+    pts_c = points_along_rays(cam_loc, directions, z_c)
+    out.update(z_coarse=z_c, points_coarse=pts_c)
+
+    with torch.no_grad():
+        vf_c = vf_mlp(pts_c.reshape(-1, 3), vf_sd, cfg.vf_multires, cfg.vf_skip_in)
+        nrm_c = vf_c[:, :3].reshape(n, cfg.n_samples, 3)
+        sigma_c, cos_c, cosray_c = ray_density(nrm_c, ray_dirs, cfg.n_window, cfg.dir_to_normal_th, cfg.density,
+                                               beta, mean, scale, return_parts=True)
+        w_c = volsdf_weights(z_c, sigma_c, cfg.normalize)
+    out.update(normals_coarse=nrm_c, window_cos_coarse=cos_c, cos_ray_coarse=cosray_c,
+               sigma_coarse=sigma_c, weights_coarse=w_c)
+
+    far_f = cfg.far if far is None else far
+    if u_add is None:
+        raise ValueError('u_add (the rand(N,N_f) draw of ray_sampler.py:292) is required')
+    z_f, imax = range_fine_z_vals(z_c, w_c, cfg.n_fine, cfg.near, far_f, cfg.fine_range, u_add,
+                                  u_fine if cfg.perturb else None)
+    pts_f = points_along_rays(cam_loc, directions, z_f)
+    s_t = cfg.n_samples + cfg.n_fine
+    out.update(max_indices=imax, z_vals=z_f, points=pts_f)
+
+    vf_f = vf_mlp(pts_f.reshape(-1, 3), vf_sd, cfg.vf_multires, cfg.vf_skip_in)
+    nrm_flat = vf_f[:, :3]
+    feats = vf_f[:, 3:3 + cfg.feature_dims]
+    nrm_f = nrm_flat.reshape(n, s_t, 3)
+    sigma_f, cos_f, cosray_f = ray_density(nrm_f, ray_dirs, cfg.n_window, cfg.dir_to_normal_th, cfg.density,
+                                           beta, mean, scale, return_parts=True)
+    w_f = volsdf_weights(z_f, sigma_f, cfg.normalize)
+    rep_dirs = ray_dirs.unsqueeze(1).repeat(1, s_t, 1).reshape(-1, 3)
+    colors = render_mlp(pts_f.reshape(-1, 3), nrm_flat.detach(), rep_dirs, feats, rn_sd, cfg.render_multires)
+    rgb = torch.sum(w_f.unsqueeze(-1) * colors.reshape(n, s_t, 3), dim=1)
+    depth = torch.sum(w_f.unsqueeze(-1) * z_f.unsqueeze(-1), dim=1)
+    out.update(vf_out=vf_f, normals=nrm_f, window_cos=cos_f, cos_ray=cosray_f, sigma=sigma_f, weights=w_f,
+               colors=colors, rgb=rgb, depth=depth, ray_dirs_repeated=rep_dirs)
+    return out
+
+
+def psnr(a: Tensor, b: Tensor) -> float:
+    """-10 log10(mean((a-b)^2))  (utils/utils.py:235-245)."""
+    mse = torch.mean((a - b) ** 2).item()
+    return float('inf') if mse == 0 else -10.0 * math.log10(mse)

@@ -1,0 +1,70 @@
+"""Shared test helpers: golden fixtures and model construction from a fixture's recipe."""
+from __future__ import annotations
+
+import ast
+import os
+from typing import Dict
+
+import numpy as np
+import torch
+
+import vf_nerf_amd
+from vf_nerf_amd import synthetic
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FIXTURE_NAMES = ("c1_det", "c1_perturb", "odd_orbit", "w1_det")
+
+
+def load_fixture(name: str):
+    """-> (fx: dict of scalars, data: dict of torch tensors)."""
+    raw = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+    fx = ast.literal_eval(str(raw["fixture"]))
+    data = {k: torch.from_numpy(raw[k]) for k in raw.files if k != "fixture"}
+    return fx, data
+
+
+def build_model(fx: dict, data: Dict[str, torch.Tensor], device="cpu") -> "vf_nerf_amd.VectorFieldNerf":
+    """Rebuild the fixture's weights with this repo's own modules (seed + gain + stored head rows) and check the
+    fingerprint recorded when the reference produced the golden outputs."""
+    torch.manual_seed(fx["seed"])
+    cfg = vf_nerf_amd.shipped_config(torch.device("cpu"), n_samples=fx["n_samples"], n_importance=fx["n_importance"],
+                                     perturb=fx["perturb"], near=fx["near"], far=fx["far"],
+                                     fine_range=fx["fine_range"], dir_to_normal_th=fx["th"], n_window=fx["n_window"])
+    model = vf_nerf_amd.VectorFieldNerf(cfg)
+    synthetic.scale_hidden_weights(model.vector_field_network, model.rendering_network, fx["gain"])
+    with torch.no_grad():
+        last = model.vector_field_network.layers[8]
+        last.weight[:3] = data["head_weight"]
+        last.bias[:3] = data["head_bias"]
+    chk = synthetic.weights_checksum({"vf": model.vector_field_network.state_dict(),
+                                      "rn": model.rendering_network.state_dict(),
+                                      "density": model.density.state_dict()})
+    want = data["weights_checksum"].tolist()
+    got = [chk["sum"], chk["abs_sum"], chk["count"]]
+    assert got[2] == want[2] and abs(got[0] - want[0]) <= 1e-9 * abs(want[1]) and \
+        abs(got[1] - want[1]) <= 1e-9 * abs(want[1]), f"weights rebuilt from the recipe differ from the fixture: {got} vs {want}"
+    model.eval()
+    if device != "cpu":
+        dev = torch.device(device)
+        model.to(dev)
+        model.config.cuda_config.device = dev
+        model.config.cos_sim_weights = model.config.cos_sim_weights.to(dev)
+    if "far_per_ray" in data:
+        model.ray_sampler.far = data["far_per_ray"].to(device)
+        model.fine_sampler.far = data["far_per_ray"].to(device)
+    return model
+
+
+def oracle_settings(fx: dict):
+    from oracle import vfnerf_oracle as O
+    return O.RenderSettings(n_samples=fx["n_samples"], n_fine=fx["n_importance"], near=fx["near"], far=fx["far"],
+                            fine_range=fx["fine_range"], perturb=fx["perturb"], n_window=fx["n_window"],
+                            dir_to_normal_th=fx["th"], normalize=True,
+                            density=O.DensityParams(beta=0.5, mean=0.7, scale=100.0, beta_bounds=(1e-4, 1e9),
+                                                    mean_bounds=(0.6, 1.0), scale_min=1.0))
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """max |a-b| / max(1, max|b|): the '1e-4 rel fp32' yardstick, robust to near-zero entries."""
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / max(1.0, float(b.abs().max())))

@@ -1,0 +1,219 @@
+"""HIP kernels (through the C ABI / ctypes) against the CPU oracle and the reference's golden vectors.
+
+Stage tests inject the reference's own intermediates so that one stage's rounding cannot flip a
+discontinuity (argmax, mask, sort) of a later one; the end-to-end test then accounts for such flips per ray.
+Tolerances: bit-exact for sample indices and z values; 1e-4 relative (max|a-b| / max(1, max|b|)) for fp32
+values as BASELINE.json's north_star states — the observed errors are ~1e-6 and the tighter bounds below
+assert that."""
+import pytest
+import torch
+
+from helpers import FIXTURE_NAMES, build_model, load_fixture, oracle_settings, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4        # the contract
+TIGHT = 2e-5      # what exact-fp32 MFMA + fp32 transcendentals actually deliver
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def to_dev(d):
+    return {k: v.to(dev()) for k, v in d.items()}
+
+
+@pytest.fixture(scope="module", params=FIXTURE_NAMES)
+def case(request):
+    from vf_nerf_amd import lib
+    lib.load()
+    fx, d = load_fixture(request.param)
+    model = build_model(fx, d, device="cuda:0")
+    return fx, d, to_dev(d), model
+
+
+def test_library_is_the_hip_build():
+    from vf_nerf_amd import lib
+    l = lib.load()
+    assert l.vfn_abi_version() == 1
+    with open("/proc/self/maps") as f:
+        assert "libvfn.so" in f.read()
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    from vf_nerf_amd import lib
+    fx, d = load_fixture("w1_det")
+    model = build_model(fx, d, device="cuda:0")
+    vf = model.vector_field_network
+    with pytest.raises(lib.VfnError):
+        lib.vf_mlp_fwd(vf.geometry(), vf.packed_weights(), torch.zeros(8, 3), 3)
+
+
+def test_raygen_and_coarse_sampler(case):
+    from vf_nerf_amd import lib
+    fx, d, g, model = case
+    far_t = g["far_per_ray"].reshape(-1).contiguous() if "far_per_ray" in g else None
+    t_vals = torch.linspace(0., 1., steps=fx["n_samples"]).to(dev())
+    directions, ray_dirs, cam_loc, z, pts = lib.raygen_uniform(g["uv"], g["pose"], g["intrinsics"], t_vals,
+                                                               fx["n_samples"], fx["near"], fx["far"], far_t,
+                                                               g.get("u_coarse"))
+    assert torch.equal(cam_loc.cpu(), d["cam_loc"])
+    assert torch.equal(z.cpu(), d["z_coarse"]), "coarse z values must be bit-exact"
+    assert rel_err(directions, d["directions"]) < 1e-6
+    assert rel_err(ray_dirs, d["ray_dirs"]) < 1e-6
+    ref_pts = d["cam_loc"][:, None, :] + d["z_coarse"][:, :, None] * d["directions"][:, None, :]
+    assert rel_err(pts, ref_pts) < 1e-6
+
+
+def test_vf_mlp_vector_only(case):
+    from vf_nerf_amd import lib
+    fx, d, g, model = case
+    pts = (g["cam_loc"][:, None, :] + g["z_coarse"][:, :, None] * g["directions"][:, None, :]).reshape(-1, 3).contiguous()
+    vf = model.vector_field_network
+    out = lib.vf_mlp_fwd(vf.geometry(), vf.packed_weights(), pts, 3)
+    err = rel_err(out, d["normals_coarse"].reshape(-1, 3))
+    print(f"vf vector-only rel err {err:.3e}")
+    assert err < TIGHT
+
+
+def test_vf_mlp_full_row(case):
+    from oracle import vfnerf_oracle as O
+    fx, d, g, model = case
+    pts = g["points"].reshape(-1, 3).contiguous()
+    with torch.no_grad():
+        out = model.vector_field_network(pts)
+    cpu_sd = {k: v.cpu() for k, v in model.vector_field_network.state_dict().items()}
+    ref = O.vf_mlp(d["points"].reshape(-1, 3), cpu_sd)
+    assert out.shape == ref.shape == (pts.shape[0], 259)
+    err_n, err_f = rel_err(out[:, :3], ref[:, :3]), rel_err(out[:, 3:], ref[:, 3:])
+    print(f"vf full rel err normals {err_n:.3e} feats {err_f:.3e}")
+    assert err_n < TIGHT and err_f < TIGHT
+    assert rel_err(out[::8, 3:], d["feats_sub"]) < TIGHT     # the reference's own features
+    assert rel_err(out[:, :3], d["normals"].reshape(-1, 3)) < TIGHT
+
+
+def test_density_weights_argmax_coarse(case):
+    from vf_nerf_amd import lib
+    fx, d, g, model = case
+    sigma, w, imax, _, _ = lib.ray_density_weights(model._density_params(), g["normals_coarse"].contiguous(),
+                                                   g["ray_dirs"].contiguous(), g["z_coarse"].contiguous(),
+                                                   model.density.raw_scalars(), want_argmax=True)
+    es, ew = rel_err(sigma, d["sigma_coarse"]), rel_err(w, d["weights_coarse"])
+    print(f"coarse sigma rel err {es:.3e} weights {ew:.3e}")
+    assert es < TIGHT and ew < TIGHT
+    assert torch.equal(imax.cpu(), d["max_indices"]), "argmax of the proposal weights must be bit-exact"
+
+
+def test_range_fine_sampler_bit_exact(case):
+    from vf_nerf_amd import lib
+    fx, d, g, model = case
+    far_t = g["far_per_ray"].reshape(-1).contiguous() if "far_per_ray" in g else None
+    z, pts = lib.range_fine_sample(g["z_coarse"].contiguous(), g["max_indices"].contiguous(),
+                                   g["directions"].contiguous(), g["cam_loc"].contiguous(), fx["n_importance"],
+                                   fx["near"], fx["far"], fx["fine_range"], g["u_add"].contiguous(),
+                                   g.get("u_fine"), far_t)
+    assert torch.equal(z.cpu(), d["z_vals"]), "fine z values (sorted) must be bit-exact"
+    assert torch.equal(pts.cpu(), d["points"]), "fine points must be bit-exact given identical directions"
+
+
+def test_fused_fine_pass(case):
+    from vf_nerf_amd import lib
+    fx, d, g, model = case
+    vf, rn = model.vector_field_network, model.rendering_network
+    s_t = fx["n_samples"] + fx["n_importance"]
+    normals, colors, feats = lib.vf_render_fused_fwd(vf.geometry(), vf.packed_weights(), rn.geometry(),
+                                                     rn.packed_weights(), g["points"].reshape(-1, 3).contiguous(),
+                                                     g["ray_dirs"].contiguous(), s_t, want_feats=True)
+    en, ec = rel_err(normals, d["normals"].reshape(-1, 3)), rel_err(colors, d["colors"])
+    ef = rel_err(feats[::8], d["feats_sub"])
+    print(f"fused normals {en:.3e} colors {ec:.3e} feats {ef:.3e}")
+    assert en < TIGHT and ec < TIGHT and ef < TIGHT
+
+
+def test_render_mlp_alone(case):
+    from oracle import vfnerf_oracle as O
+    fx, d, g, model = case
+    s_t = fx["n_samples"] + fx["n_importance"]
+    cpu_vf = {k: v.cpu() for k, v in model.vector_field_network.state_dict().items()}
+    ref_vf = O.vf_mlp(d["points"].reshape(-1, 3), cpu_vf)
+    rep = d["ray_dirs"].unsqueeze(1).repeat(1, s_t, 1).reshape(-1, 3)
+    with torch.no_grad():
+        colors = model.rendering_network(g["points"].reshape(-1, 3), ref_vf[:, :3].to(dev()), rep.to(dev()),
+                                         ref_vf[:, 3:].contiguous().to(dev()))
+    err = rel_err(colors, d["colors"])
+    print(f"render-only colors rel err {err:.3e}")
+    assert err < TIGHT
+
+
+def test_composite_with_reference_inputs(case):
+    from vf_nerf_amd import lib
+    fx, d, g, model = case
+    sigma, w, _, rgb, depth = lib.ray_density_weights(model._density_params(), g["normals"].contiguous(),
+                                                      g["ray_dirs"].contiguous(), g["z_vals"].contiguous(),
+                                                      model.density.raw_scalars(), colors=g["colors"].contiguous())
+    errs = dict(sigma=rel_err(sigma, d["sigma"]), weights=rel_err(w, d["weights"]), rgb=rel_err(rgb, d["rgb"]),
+                depth=rel_err(depth, d["depth"]))
+    print("composite rel errs", {k: f"{v:.3e}" for k, v in errs.items()})
+    assert max(errs.values()) < TIGHT
+    assert depth.shape == (d["depth"].shape[0], 1)
+
+
+def test_render_end_to_end(case):
+    """Whole render() with the reference's random draws replayed.  A ray only counts as an outlier when a
+    discontinuity (argmax / mask threshold) flipped; such rays must be rare and everything else within 1e-4."""
+    from oracle import vfnerf_oracle as O
+    fx, d, g, model = case
+    uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add") if k in g}
+    with torch.no_grad():
+        out = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
+    n = d["uv"].shape[0]
+    s_t = fx["n_samples"] + fx["n_importance"]
+    assert out.points_coarse.shape == (n, s_t, 3) and out.coarse_normals.shape == (n, s_t, 3)
+    assert out.coarse_rgb_values.shape == (n, 3) and out.coarse_depth_map.shape == (n, 1)
+    assert out.z_vals.shape == (n, s_t) and out.ray_dirs.shape == (n * s_t, 3) and out.coarse_colors.shape == (n * s_t, 3)
+    assert out.fine_normals is None and out.directional_derivtives is None
+    same_z = (out.z_vals.cpu() == d["z_vals"]).all(dim=1)
+    frac = float(same_z.float().mean())
+    print(f"rays with bit-identical fine z: {frac:.3f}")
+    assert frac >= 0.9
+    good = same_z
+    rgb_err = (out.coarse_rgb_values.cpu() - d["rgb"]).abs().max(dim=1)[0]
+    dep_err = (out.coarse_depth_map.cpu() - d["depth"]).abs().reshape(-1)
+    print(f"max rgb err (matching rays) {float(rgb_err[good].max()):.3e}, depth {float(dep_err[good].max()):.3e}")
+    ok = (rgb_err < TOL) & (dep_err < TOL * max(1.0, float(d['depth'].abs().max())))
+    assert float(ok[good].float().mean()) >= 0.97, "fp32 noise may flip a density mask on a few rays, not more"
+    psnr = O.psnr(out.coarse_rgb_values.cpu()[good], d["rgb"][good])
+    print(f"PSNR vs reference (matching rays): {psnr:.1f} dB")
+    assert psnr > 60.0
+
+
+def test_white_background_adds_missing_opacity():
+    fx, d = load_fixture("w1_det")
+    model = build_model(fx, d, device="cuda:0")
+    g = to_dev(d)
+    with torch.no_grad():
+        a = model.render(g["pose"], g["uv"], g["intrinsics"], 0, False, uniforms={"u_add": g["u_add"]})
+        b = model.render(g["pose"], g["uv"], g["intrinsics"], 0, True, uniforms={"u_add": g["u_add"]})
+    assert float((b.coarse_rgb_values - a.coarse_rgb_values).min()) >= -1e-6
+
+
+def test_philox_uniforms():
+    from vf_nerf_amd import lib
+    out = torch.empty(1 << 20, device=dev())
+    lib.fill_uniform(out, seed=7, offset=0)
+    assert float(out.min()) >= 0.0 and float(out.max()) < 1.0
+    assert abs(float(out.mean()) - 0.5) < 2e-3 and abs(float(out.var()) - 1 / 12) < 2e-3
+    again = torch.empty_like(out)
+    lib.fill_uniform(again, seed=7, offset=0)
+    assert torch.equal(out, again)
+    lib.fill_uniform(again, seed=7, offset=1)
+    assert torch.equal(out[4:], again[:-4])     # offset counts Philox 4-tuples
+
+
+def test_get_density_api(case):
+    fx, d, g, model = case
+    n, s_t = d["z_vals"].shape
+    rep = g["ray_dirs"].unsqueeze(1).repeat(1, s_t, 1).reshape(-1, 3)
+    sigma = model.get_density(g["normals"], rep, True)
+    assert rel_err(sigma, d["sigma"]) < TIGHT

@@ -1,0 +1,65 @@
+"""The CPU oracle (oracle/vfnerf_oracle.py) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  This is what pins the oracle; the GPU tests then compare HIP vs oracle."""
+import pytest
+import torch
+
+from helpers import FIXTURE_NAMES, build_model, load_fixture, oracle_settings
+from oracle import vfnerf_oracle as O
+
+
+def _run(name):
+    fx, d = load_fixture(name)
+    model = build_model(fx, d)
+    far = d.get("far_per_ray")
+    out = O.render(d["uv"], d["pose"], d["intrinsics"], model.vector_field_network.state_dict(),
+                   model.rendering_network.state_dict(), oracle_settings(fx), u_coarse=d.get("u_coarse"),
+                   u_fine=d.get("u_fine"), u_add=d["u_add"], far=far)
+    return fx, d, out
+
+
+@pytest.mark.parametrize("name", FIXTURE_NAMES)
+def test_render_matches_reference_bitwise_stages(name):
+    """Sampling stages and indices are bit-exact; everything downstream of the MLPs within 1e-6."""
+    fx, d, out = _run(name)
+    for k in ("directions", "ray_dirs", "cam_loc", "z_coarse"):
+        assert torch.equal(out[k], d[k]), k
+    assert torch.equal(out["max_indices"], d["max_indices"])
+    assert torch.equal(out["z_vals"], d["z_vals"])
+    assert torch.equal(out["points"], d["points"])
+    tol = 1e-6
+    for k in ("normals_coarse", "window_cos_coarse", "sigma_coarse", "weights_coarse", "normals", "window_cos",
+              "sigma", "weights", "colors", "rgb", "depth"):
+        scale = max(1.0, float(d[k].abs().max()))
+        assert float((out[k] - d[k]).abs().max()) <= tol * scale, (k, float((out[k] - d[k]).abs().max()))
+    assert float((out["vf_out"][::8, 3:] - d["feats_sub"]).abs().max()) <= tol
+
+
+def test_fixture_covers_edge_cases():
+    """At least one fixture has rays whose proposal weights are all zero (argmax 0 -> uniform extras, Q9),
+    an odd S_t, a per-ray far and a non-default window."""
+    _, d = load_fixture("odd_orbit")
+    assert int((d["max_indices"] == 0).sum()) > 0 and int((d["max_indices"] > 0).sum()) > 0
+    assert d["z_vals"].shape[1] % 2 == 1 and "far_per_ray" in d
+
+
+def test_window_cosine_short_rays():
+    """Rays shorter than two window halves leave the adjacent cosine untouched (functions.py:59-70)."""
+    torch.manual_seed(0)
+    n = torch.randn(3, 9, 3)
+    w = torch.ones(11) / 11
+    c = O.window_cosine(n, w)
+    assert torch.allclose(c, torch.nn.functional.cosine_similarity(n[:, :-1], n[:, 1:], dim=2))
+
+
+def test_density_is_zero_above_half_cosine():
+    """sigma > 0 only where the (negated) cosine is below the dropped cutoff -0.5, i.e. cos < 0.5 (Q5)."""
+    p = O.DensityParams()
+    x = torch.linspace(-1, 1, 201).reshape(-1, 1)
+    s = O.laplace_density(-x, p)
+    assert float(s[x > 0.5].abs().max()) == 0.0 and float(s[x < 0.49].min()) > 0.0
+
+
+def test_psnr_definition():
+    a = torch.zeros(10, 3)
+    b = torch.full((10, 3), 0.1)
+    assert abs(O.psnr(a, b) - 20.0) < 1e-4

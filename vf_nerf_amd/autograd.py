@@ -1,0 +1,49 @@
+"""Dispatch of the MLP forwards to the HIP kernels (and, when gradients are required, to the
+``torch.autograd.Function`` wrappers of the backward kernels)."""
+from __future__ import annotations
+
+import torch
+
+from . import lib
+
+
+def _wants_grad(net, *tensors) -> bool:
+    if not torch.is_grad_enabled():
+        return False
+    return any(t is not None and t.requires_grad for t in tensors) or any(p.requires_grad for p in net.parameters())
+
+
+def _flat3(t: torch.Tensor) -> torch.Tensor:
+    return t.reshape(-1, t.shape[-1]).contiguous().float()
+
+
+def vf_forward(net, points: torch.Tensor, vector_only: bool = False) -> torch.Tensor:
+    if _wants_grad(net, points):
+        from .backward import vf_forward_autograd
+        return vf_forward_autograd(net, points, vector_only)
+    pts = _flat3(points)
+    cols = 3 if vector_only else 3 + net._feature_dims()
+    return lib.vf_mlp_fwd(net.geometry(), net.packed_weights(), pts, cols)
+
+
+def render_forward(net, points, normals, view_dirs, feats) -> torch.Tensor:
+    if _wants_grad(net, points, normals, view_dirs, feats):
+        from .backward import render_forward_autograd
+        return render_forward_autograd(net, points, normals, view_dirs, feats)
+    return lib.render_mlp_fwd(net.geometry(), net.packed_weights(), _flat3(points), _flat3(normals),
+                              _flat3(view_dirs), _flat3(feats))
+
+
+def fine_pass(model, pts: torch.Tensor, z: torch.Tensor, ray_dirs: torch.Tensor):
+    """Steps (7)-(11) of render(): fused VF + rendering MLPs, then density / weights / composite per ray.
+    Returns (normals[M,3], colors[M,3], rgb[N,3], depth[N,1], weights[N,S_t])."""
+    vf, rn = model.vector_field_network, model.rendering_network
+    n, s_t = z.shape
+    if torch.is_grad_enabled() and any(p.requires_grad for p in model.unique_parameters()):
+        from .backward import fine_pass_autograd
+        return fine_pass_autograd(model, pts, z, ray_dirs)
+    normals, colors, _ = lib.vf_render_fused_fwd(vf.geometry(), vf.packed_weights(), rn.geometry(),
+                                                 rn.packed_weights(), pts.view(-1, 3), ray_dirs, s_t)
+    _, weights, _, rgb, depth = lib.ray_density_weights(model._density_params(), normals, ray_dirs, z,
+                                                        model.density.raw_scalars(), colors=colors, want_sigma=False)
+    return normals, colors, rgb, depth, weights

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Builds libvfn.so (HIP kernels + C ABI) for gfx950, in-tree.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+cd "$(dirname "$0")"
+ARCH=${VFN_ARCH:-gfx950}
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=${ARCH} -Wall -Wno-unused-function"
+hipcc $FLAGS -c vfn_pack.hip -o vfn_pack.o &
+hipcc $FLAGS -c vfn_mlp.hip -o vfn_mlp.o ${VFN_MLP_EXTRA:-} &
+hipcc $FLAGS -ffp-contract=off -c vfn_rays.hip -o vfn_rays.o &
+wait
+hipcc -shared -fPIC --offload-arch=${ARCH} -o libvfn.so vfn_pack.o vfn_mlp.o vfn_rays.o
+echo "built $(pwd)/libvfn.so"

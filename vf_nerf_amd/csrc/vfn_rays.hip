@@ -1,0 +1,434 @@
+// vfn_rays.hip — the per-ray (HBM / latency bound) kernels of the VF-NeRF hot path:
+//   K1  pinhole ray generation + stratified uniform sampler
+//   K3  windowed cosine -> Laplace density -> VolSDF weights (wavefront scan) -> argmax / composite
+//   K3b range fine sampler (window / uniform extras, rank sort, points)
+//   Philox uniform fill for production sampling.
+//
+// One wavefront owns one ray end to end (window stencil, scan, argmax, sort are all wave-local:
+// LDS + cross-lane shuffles, no inter-workgroup traffic).  Arithmetic follows the reference's
+// operation order with FMA contraction disabled so that z values / sample indices reproduce the
+// PyTorch CPU path bit for bit on identical inputs (tests/test_rays_gpu.py).
+#pragma clang fp contract(off)
+#include <string.h>
+#include "vfn_common.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int RAYS_PER_BLOCK = 4;   // one wave per ray, 256 threads
+constexpr int MAX_SAMPLES = 512;    // per-ray samples supported by the LDS carve-up (<= 40 KiB dynamic LDS)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: rays + coarse z + points
+//   utils/rendering.py:12-60, utils/pinhole_model.py:9-63, models/samplers/ray_sampler.py:49-80,113-142
+// ------------------------------------------------------------------------------------------------
+constexpr int K1_RAYS = 16;
+
+struct RaygenArgs {
+    vfn_raygen_params p;
+    const float* uv;
+    const float* pose;
+    const float* K;
+    const float* t_vals;
+    const float* far_per_ray;
+    const float* u;
+    float* directions;
+    float* ray_dirs;
+    float* cam_loc;
+    float* z_vals;
+    float* points;
+};
+
+__device__ __forceinline__ float coarse_z(float near, float far, float t) { return near * (1.0f - t) + far * t; }
+
+__global__ __launch_bounds__(256) void vfn_raygen_kernel(const RaygenArgs a) {
+    __shared__ float s_ray[K1_RAYS][8];  // dir(3), cam(3), far, pad
+    const int tid = threadIdx.x;
+    const int ray0 = blockIdx.x * K1_RAYS;
+    const int n = a.p.n_rays;
+    if (tid < K1_RAYS && ray0 + tid < n) {
+        const int r = ray0 + tid;
+        float P[3][4];
+        if (a.p.pose_is_quat) {
+            const float* q7 = a.pose + (size_t)r * 7;
+            float q0 = q7[0], q1 = q7[1], q2 = q7[2], q3 = q7[3];
+            const float nq = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);
+            const float qr = q0 / nq, qi = q1 / nq, qj = q2 / nq, qk = q3 / nq;
+            P[0][0] = 1 - 2 * (qj * qj + qk * qk); P[0][1] = 2 * (qj * qi - qk * qr); P[0][2] = 2 * (qi * qk + qr * qj);
+            P[1][0] = 2 * (qj * qi + qk * qr); P[1][1] = 1 - 2 * (qi * qi + qk * qk); P[1][2] = 2 * (qj * qk - qi * qr);
+            P[2][0] = 2 * (qk * qi - qj * qr); P[2][1] = 2 * (qj * qk + qi * qr); P[2][2] = 1 - 2 * (qi * qi + qj * qj);
+            P[0][3] = q7[4]; P[1][3] = q7[5]; P[2][3] = q7[6];
+        } else {
+            const float* m = a.pose + (size_t)r * 16;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) P[i][j] = m[i * 4 + j];
+        }
+        const float* Kr = a.K + (size_t)r * 16;
+        const float fx = Kr[0], sk = Kr[1], cx = Kr[2], fy = Kr[5], cy = Kr[6];
+        const float fy0 = a.K[5];  // sign is read from ray 0 only (utils/rendering.py:42)
+        const float zs = (fy0 > 0.f) ? 1.f : ((fy0 < 0.f) ? -1.f : 0.f);
+        const float u = a.uv[(size_t)r * 2 + 0], v = a.uv[(size_t)r * 2 + 1];
+        const float za = fabsf(zs);
+        const float x = (u - cx + cy * sk / fy - sk * v / fy) / fx * za;
+        const float y = (v - cy) / fy * za;
+        float w[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w[i] = ((P[i][0] * x + P[i][1] * y) + P[i][2] * zs) + P[i][3];
+        const float cam[3] = {P[0][3], P[1][3], P[2][3]};
+        float d[3] = {w[0] - cam[0], w[1] - cam[1], w[2] - cam[2]};
+        const float nd = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            a.directions[(size_t)r * 3 + i] = d[i];
+            a.ray_dirs[(size_t)r * 3 + i] = d[i] / nd;
+            a.cam_loc[(size_t)r * 3 + i] = cam[i];
+            s_ray[tid][i] = d[i];
+            s_ray[tid][3 + i] = cam[i];
+        }
+        s_ray[tid][6] = a.far_per_ray ? a.far_per_ray[r] : a.p.far;
+    }
+    __syncthreads();
+    const int S = a.p.n_samples;
+    const int total = K1_RAYS * S;
+    for (int idx = tid; idx < total; idx += blockDim.x) {
+        const int lr = idx / S, s = idx - lr * S;
+        const int r = ray0 + lr;
+        if (r >= n) break;
+        const float near = a.p.near, far = s_ray[lr][6];
+        float z = coarse_z(near, far, a.t_vals[s]);
+        if (a.u) {
+            const float zl = (s > 0) ? coarse_z(near, far, a.t_vals[s - 1]) : z;
+            const float zu = (s < S - 1) ? coarse_z(near, far, a.t_vals[s + 1]) : z;
+            const float upper = (s < S - 1) ? 0.5f * (zu + z) : z;
+            const float lower = (s > 0) ? 0.5f * (z + zl) : z;
+            z = lower + (upper - lower) * a.u[(size_t)r * S + s];
+        }
+        const size_t o = (size_t)r * S + s;
+        a.z_vals[o] = z;
+        a.points[o * 3 + 0] = s_ray[lr][3] + z * s_ray[lr][0];
+        a.points[o * 3 + 1] = s_ray[lr][4] + z * s_ray[lr][1];
+        a.points[o * 3 + 2] = s_ray[lr][5] + z * s_ray[lr][2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: density -> weights -> argmax / composite, one wave per ray
+//   models/nerf/vector_field_nerf.py:442-474, models/helpers/functions.py:41-72,
+//   models/helpers/density_functions.py:129-204, utils/rendering.py:122-148,
+//   models/nerf/vector_field_nerf.py:322-323
+// ------------------------------------------------------------------------------------------------
+struct DensityArgs {
+    vfn_density_params p;
+    const float* normals;
+    const float* ray_dirs;
+    const float* z_vals;
+    const float* scalars;  // beta, mean, scale (raw)
+    const float* colors;
+    float* sigma;
+    float* weights;
+    long long* argmax;
+    float* rgb;
+    float* depth;
+};
+
+__device__ __forceinline__ float laplace_cdf(float x, float beta, float scale, float mean) {
+    const float a = x - mean;
+    const float sg = (a > 0.f) ? 1.f : ((a < 0.f) ? -1.f : 0.f);
+    const float t = 1.0f - expf(-fabsf(a) / beta);
+    return scale * (0.5f + (0.5f * sg) * t);
+}
+
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+
+__global__ __launch_bounds__(256) void vfn_density_kernel(const DensityArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int S = a.p.n_samples;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (ray >= a.p.n_rays) return;  // whole wave exits together; no block-level barriers below
+    float* su = dsm + (size_t)wv * S * 5;  // unit normals [S][3]
+    float* sz = su + (size_t)S * 3;        // z [S]
+    float* se = sz + S;                    // free energy / weights [S]
+
+    const float* nrm = a.normals + (size_t)ray * S * 3;
+    for (int j = lane; j < S; j += WAVE) {
+        const float x = nrm[j * 3 + 0], y = nrm[j * 3 + 1], z = nrm[j * 3 + 2];
+        const float nn = fmaxf(sqrtf((x * x + y * y) + z * z), 1e-8f);
+        su[j * 3 + 0] = x / nn; su[j * 3 + 1] = y / nn; su[j * 3 + 2] = z / nn;
+        sz[j] = a.z_vals[(size_t)ray * S + j];
+    }
+    float d[3] = {a.ray_dirs[(size_t)ray * 3 + 0], a.ray_dirs[(size_t)ray * 3 + 1], a.ray_dirs[(size_t)ray * 3 + 2]};
+    {
+        const float nd = fmaxf(sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]), 1e-8f);
+        d[0] /= nd; d[1] /= nd; d[2] /= nd;
+    }
+    const float beta = fminf(fmaxf(a.scalars[0], a.p.beta_min), a.p.beta_max);
+    const float mean = fminf(fmaxf(a.scalars[1], a.p.mean_min), a.p.mean_max);
+    const float scale = fmaxf(fabsf(a.scalars[2]), a.p.scale_min);
+    const float cdf_cut = laplace_cdf(a.p.cutoff, beta, scale, mean);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+    const int W = a.p.n_window;
+    const int start = (int)((W + 1) / 2.0 + 1);
+    const float wgt = 1.0f / (float)W;  // torch.ones(W) / W
+    float wnorm = 0.f;
+    for (int i = 0; i < W; ++i) wnorm += fabsf(wgt);
+    const int L = S - 1;
+    const int lo = start, hi = L - start;  // interior [lo, hi)
+
+    // sigma and free energy
+    for (int j = lane; j < S; j += WAVE) {
+        float sg = 0.f;
+        if (j < L) {
+            const float* uj = su + j * 3;
+            float c = dot3(uj, su + (j + 1) * 3);
+            if (j >= lo && j < hi) {
+                c = c * wgt / wnorm;
+                for (int i = 1; i < start - 1; ++i) {
+                    const float f = dot3(uj, su + (j + 1 + i) * 3);
+                    const float b = dot3(uj, su + (j - i) * 3);
+                    c = (c + f * wgt / wnorm) + b * wgt / wnorm;
+                }
+            }
+            const float c_ray = dot3(uj, d);
+            sg = fmaxf(laplace_cdf(-c, beta, scale, mean) - cdf_cut, 0.f);
+            if (c_ray < a.p.dir_to_normal_th && c < 0.f) sg = 0.f;
+        }
+        if (a.sigma) a.sigma[(size_t)ray * S + j] = sg;
+        const float delta = (j < L) ? (sz[j + 1] - sz[j]) : 1e10f;
+        se[j] = delta * sg;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    // exclusive scan of the free energy along the ray: each lane owns C consecutive samples, lane
+    // totals are scanned across the wavefront (fp64 like torch.cumsum's CPU accumulator).
+    const int C = (S + WAVE - 1) / WAVE;
+    const int j0 = lane * C;
+    double tot = 0.0;
+    for (int i = 0; i < C; ++i) { const int j = j0 + i; if (j < S) tot += (double)se[j]; }
+    double incl = tot;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const double up = __shfl_up(incl, o, WAVE);
+        if (lane >= o) incl += up;
+    }
+    double run = incl - tot;  // exclusive prefix of this lane's first sample
+    float wsum_l = 0.f;
+    for (int i = 0; i < C; ++i) {
+        const int j = j0 + i;
+        if (j < S) {
+            const float e = se[j];
+            const float T = expf(-(float)run);
+            const float w = (1.0f - expf(-e)) * T;
+            run += (double)e;
+            se[j] = w;
+            wsum_l += w;
+        }
+    }
+    const float wsum = wave_sum(wsum_l);
+    const float den = wsum + 1e-5f;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* col = a.colors ? a.colors + (size_t)ray * S * 3 : nullptr;
+    for (int j = lane; j < S; j += WAVE) {
+        float w = se[j];
+        if (a.p.normalize) w = w / den;
+        if (a.weights) a.weights[(size_t)ray * S + j] = w;
+        if (w > best) { best = w; besti = j; }
+        if (col) {
+            acc[0] += w * col[j * 3 + 0]; acc[1] += w * col[j * 3 + 1]; acc[2] += w * col[j * 3 + 2];
+            acc[3] += w * sz[j];
+        }
+    }
+    if (a.argmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, WAVE);
+            const int oi = __shfl_xor(besti, o, WAVE);
+            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        if (lane == 0) a.argmax[ray] = (besti == 0x7fffffff) ? 0 : besti;
+    }
+    if (col) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = wave_sum(acc[c]);
+        if (lane == 0) {
+            a.rgb[(size_t)ray * 3 + 0] = acc[0]; a.rgb[(size_t)ray * 3 + 1] = acc[1]; a.rgb[(size_t)ray * 3 + 2] = acc[2];
+            a.depth[ray] = acc[3];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3b: range fine sampler, one wave per ray   (models/samplers/ray_sampler.py:264-302, :77-78)
+// ------------------------------------------------------------------------------------------------
+struct FineArgs {
+    vfn_fine_params p;
+    const float* z_coarse;
+    const long long* argmax;
+    const float* directions;
+    const float* cam_loc;
+    const float* far_per_ray;
+    const float* u_fine;
+    const float* u_add;
+    float* z_vals;
+    float* points;
+};
+
+__global__ __launch_bounds__(256) void vfn_fine_kernel(const FineArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    const int Sc = a.p.n_coarse, Nf = a.p.n_fine, St = Sc + Nf;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (ray >= a.p.n_rays) return;
+    float* sv = fsm + (size_t)wv * St * 2;  // unsorted values [St]
+    float* so = sv + St;                    // sorted values [St]
+
+    const long long imax = a.argmax[ray];
+    const float* zc = a.z_coarse + (size_t)ray * Sc;
+    for (int j = lane; j < Sc; j += WAVE) sv[j] = zc[j];
+    const float near = a.p.near;
+    const float far = a.far_per_ray ? a.far_per_ray[ray] : a.p.far;
+    if (imax > 0) {
+        const float zstar = zc[imax];
+        const float base = zstar - a.p.half_range;
+        const float step = a.p.window_step;
+        for (int k = lane; k < Nf; k += WAVE) {
+            float z = base + step * (float)k;
+            if (a.u_fine) {
+                const float zl = base + step * (float)(k - 1);
+                const float zu = base + step * (float)(k + 1);
+                const float upper = (k < Nf - 1) ? 0.5f * (zu + z) : z;
+                const float lower = (k > 0) ? 0.5f * (z + zl) : z;
+                z = lower + (upper - lower) * a.u_fine[(size_t)ray * Nf + k];
+            }
+            sv[Sc + k] = z;
+        }
+    } else {
+        const float span = a.far_per_ray ? (far - near) : a.p.span;
+        for (int k = lane; k < Nf; k += WAVE) sv[Sc + k] = a.u_add[(size_t)ray * Nf + k] * span + near;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // rank sort: position = #smaller + #equal-with-lower-index (stable)
+    for (int i = lane; i < St; i += WAVE) {
+        const float v = sv[i];
+        int rank = 0;
+        for (int j = 0; j < St; ++j) {
+            const float o = sv[j];
+            rank += (o < v || (o == v && j < i)) ? 1 : 0;
+        }
+        so[rank] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const float dx = a.directions[(size_t)ray * 3 + 0], dy = a.directions[(size_t)ray * 3 + 1], dz = a.directions[(size_t)ray * 3 + 2];
+    const float ox = a.cam_loc[(size_t)ray * 3 + 0], oy = a.cam_loc[(size_t)ray * 3 + 1], oz = a.cam_loc[(size_t)ray * 3 + 2];
+    for (int j = lane; j < St; j += WAVE) {
+        const float z = so[j];
+        const size_t o = (size_t)ray * St + j;
+        a.z_vals[o] = z;
+        a.points[o * 3 + 0] = ox + z * dx;
+        a.points[o * 3 + 1] = oy + z * dy;
+        a.points[o * 3 + 2] = oz + z * dz;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 uniforms in [0,1)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+
+__global__ void vfn_uniform_kernel(float* out, long long n, unsigned long long seed, unsigned long long offset) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one Philox block per 4 outputs
+    const long long base = g * 4;
+    if (base >= n) return;
+    const unsigned long long ctr = offset + (unsigned long long)g;
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (base + i < n) out[base + i] = (float)(c[i] >> 8) * (1.0f / 16777216.0f);
+}
+
+}  // namespace
+
+extern "C" int vfn_raygen_uniform(const vfn_raygen_params* p, const float* uv, const float* pose, const float* intrinsics,
+                                  const float* t_vals, const float* far_per_ray, const float* u_coarse, float* directions,
+                                  float* ray_dirs, float* cam_loc, float* z_vals, float* points, void* stream) {
+    VFN_REQUIRE(p && uv && pose && intrinsics && t_vals && directions && ray_dirs && cam_loc && z_vals && points,
+                "vfn_raygen_uniform: NULL argument");
+    VFN_REQUIRE(p->n_rays >= 0 && p->n_samples >= 1, "vfn_raygen_uniform: bad sizes (n_rays=%d, n_samples=%d)", p->n_rays,
+                p->n_samples);
+    if (p->n_rays == 0) return VFN_OK;
+    RaygenArgs a{*p, uv, pose, intrinsics, t_vals, far_per_ray, u_coarse, directions, ray_dirs, cam_loc, z_vals, points};
+    const unsigned blocks = (unsigned)((p->n_rays + K1_RAYS - 1) / K1_RAYS);
+    hipLaunchKernelGGL(vfn_raygen_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return vfn_check_launch("vfn_raygen_uniform");
+}
+
+extern "C" int vfn_ray_density_weights(const vfn_density_params* p, const float* normals, const float* ray_dirs,
+                                       const float* z_vals, const float* density_scalars, const float* colors, float* sigma,
+                                       float* weights, int64_t* argmax, float* rgb, float* depth, void* stream) {
+    VFN_REQUIRE(p && normals && ray_dirs && z_vals && density_scalars, "vfn_ray_density_weights: NULL argument");
+    VFN_REQUIRE(p->n_samples >= 2 && p->n_samples <= MAX_SAMPLES, "vfn_ray_density_weights: n_samples=%d outside [2,%d]",
+                p->n_samples, MAX_SAMPLES);
+    VFN_REQUIRE(p->n_window >= 1, "vfn_ray_density_weights: n_window must be >= 1");
+    VFN_REQUIRE(!colors || (rgb && depth), "vfn_ray_density_weights: colors given but rgb/depth NULL");
+    if (p->n_rays <= 0) return VFN_OK;
+    DensityArgs a{*p, normals, ray_dirs, z_vals, density_scalars, colors, sigma, weights, (long long*)argmax, rgb, depth};
+    const unsigned blocks = (unsigned)((p->n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
+    const size_t shmem = (size_t)RAYS_PER_BLOCK * p->n_samples * 5 * sizeof(float);
+    hipLaunchKernelGGL(vfn_density_kernel, dim3(blocks), dim3(256), shmem, (hipStream_t)stream, a);
+    return vfn_check_launch("vfn_ray_density_weights");
+}
+
+extern "C" int vfn_range_fine_sample(const vfn_fine_params* p, const float* z_coarse, const int64_t* argmax,
+                                     const float* directions, const float* cam_loc, const float* far_per_ray,
+                                     const float* u_fine, const float* u_add, float* z_vals, float* points, void* stream) {
+    VFN_REQUIRE(p && z_coarse && argmax && directions && cam_loc && u_add && z_vals && points,
+                "vfn_range_fine_sample: NULL argument (u_add is always required, ray_sampler.py:292)");
+    VFN_REQUIRE(p->n_coarse >= 1 && p->n_fine >= 2 && p->n_coarse + p->n_fine <= MAX_SAMPLES,
+                "vfn_range_fine_sample: bad sizes (n_coarse=%d, n_fine=%d)", p->n_coarse, p->n_fine);
+    if (p->n_rays <= 0) return VFN_OK;
+    FineArgs a{*p, z_coarse, (const long long*)argmax, directions, cam_loc, far_per_ray, u_fine, u_add, z_vals, points};
+    const unsigned blocks = (unsigned)((p->n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
+    const size_t shmem = (size_t)RAYS_PER_BLOCK * (p->n_coarse + p->n_fine) * 2 * sizeof(float);
+    hipLaunchKernelGGL(vfn_fine_kernel, dim3(blocks), dim3(256), shmem, (hipStream_t)stream, a);
+    return vfn_check_launch("vfn_range_fine_sample");
+}
+
+extern "C" int vfn_fill_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+    VFN_REQUIRE(out || n == 0, "vfn_fill_uniform: NULL output");
+    if (n <= 0) return VFN_OK;
+    const long long groups = (n + 3) / 4;
+    const unsigned blocks = (unsigned)((groups + 255) / 256);
+    hipLaunchKernelGGL(vfn_uniform_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, (long long)n,
+                       (unsigned long long)seed, (unsigned long long)offset);
+    return vfn_check_launch("vfn_fill_uniform");
+}

@@ -1,0 +1,228 @@
+"""ctypes binding of ``libvfn.so`` (the C ABI declared in ``include/vfn.h``).
+
+There is no CPU fallback: if the shared library is missing, or a tensor is not a contiguous fp32
+CUDA(HIP) tensor, the call raises.  ``import torch`` must come first so that the HIP runtime the
+library binds to is the one PyTorch already loaded (same ``libamdhip64.so.7`` SONAME).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvfn.so")
+
+MAX_LAYERS = 16
+HIDDEN = 256
+NET_VF, NET_RENDER = 0, 1
+
+EXPORTS = (
+    "vfn_last_error", "vfn_abi_version", "vfn_packed_size", "vfn_pack_weights", "vfn_raygen_uniform",
+    "vfn_vf_mlp_fwd", "vfn_render_mlp_fwd", "vfn_vf_render_fused_fwd", "vfn_ray_density_weights",
+    "vfn_range_fine_sample", "vfn_fill_uniform",
+)
+
+
+class VfnError(RuntimeError):
+    pass
+
+
+class NetGeom(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("multires", C.c_int32), ("skip_layer", C.c_int32),
+                ("feature_dims", C.c_int32), ("in_dims", C.c_int32 * MAX_LAYERS),
+                ("out_dims", C.c_int32 * MAX_LAYERS), ("has_bn", C.c_int32 * MAX_LAYERS)]
+
+
+class LayerParams(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p), ("bn_weight", C.c_void_p),
+                ("bn_bias", C.c_void_p), ("bn_mean", C.c_void_p), ("bn_var", C.c_void_p)]
+
+
+class RaygenParams(C.Structure):
+    _fields_ = [("n_rays", C.c_int32), ("n_samples", C.c_int32), ("pose_is_quat", C.c_int32),
+                ("near", C.c_float), ("far", C.c_float)]
+
+
+class DensityParams(C.Structure):
+    _fields_ = [("n_rays", C.c_int32), ("n_samples", C.c_int32), ("n_window", C.c_int32),
+                ("normalize", C.c_int32), ("dir_to_normal_th", C.c_float),
+                ("beta_min", C.c_float), ("beta_max", C.c_float), ("mean_min", C.c_float),
+                ("mean_max", C.c_float), ("scale_min", C.c_float), ("cutoff", C.c_float)]
+
+
+class FineParams(C.Structure):
+    _fields_ = [("n_rays", C.c_int32), ("n_coarse", C.c_int32), ("n_fine", C.c_int32),
+                ("near", C.c_float), ("far", C.c_float), ("half_range", C.c_float),
+                ("window_step", C.c_float), ("span", C.c_float)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libvfn.so once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VfnError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       f"or vf_nerf_amd/csrc/build.sh (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    lib.vfn_last_error.restype = C.c_char_p
+    lib.vfn_packed_size.restype = C.c_int64
+    lib.vfn_packed_size.argtypes = [C.c_int32, C.POINTER(NetGeom)]
+    for name in EXPORTS:
+        getattr(lib, name)  # raises AttributeError if the ABI lost a symbol
+    if lib.vfn_abi_version() != 1:
+        raise VfnError(f"libvfn.so ABI {lib.vfn_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise VfnError(f"{what} failed (status {rc}): {load().vfn_last_error().decode()}")
+
+
+def _ptr(t: Optional[torch.Tensor], name: str, dtype=torch.float32) -> C.c_void_p:
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise VfnError(f"{name}: expected a CUDA/HIP tensor, got {t.device} (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise VfnError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise VfnError(f"{name}: tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ------------------------------------------------------------------------------------------------
+# geometry / packing
+# ------------------------------------------------------------------------------------------------
+def make_geom(n_layers: int, multires: int, skip_layer: int, feature_dims: int, in_dims: Sequence[int],
+              out_dims: Sequence[int], has_bn: Sequence[bool]) -> NetGeom:
+    if n_layers > MAX_LAYERS:
+        raise VfnError(f"{n_layers} layers > {MAX_LAYERS}")
+    g = NetGeom()
+    g.n_layers, g.multires, g.skip_layer, g.feature_dims = n_layers, multires, skip_layer, feature_dims
+    for i in range(n_layers):
+        g.in_dims[i], g.out_dims[i], g.has_bn[i] = int(in_dims[i]), int(out_dims[i]), int(bool(has_bn[i]))
+    return g
+
+
+def packed_size(kind: int, geom: NetGeom) -> int:
+    n = load().vfn_packed_size(kind, C.byref(geom))
+    if n < 0:
+        raise VfnError(f"unsupported network geometry: {load().vfn_last_error().decode()}")
+    return int(n)
+
+
+def pack_weights(kind: int, geom: NetGeom, layers: Sequence[dict], packed: torch.Tensor) -> None:
+    """layers[i] = dict(weight=, bias=, bn_weight=, bn_bias=, bn_mean=, bn_var=) of live tensors."""
+    arr = (LayerParams * geom.n_layers)()
+    for i, lp in enumerate(layers):
+        arr[i].weight = _ptr(lp["weight"], f"layer{i}.weight")
+        arr[i].bias = _ptr(lp["bias"], f"layer{i}.bias")
+        for k in ("bn_weight", "bn_bias", "bn_mean", "bn_var"):
+            setattr(arr[i], k, _ptr(lp.get(k), f"layer{i}.{k}"))
+    _check(load().vfn_pack_weights(kind, C.byref(geom), arr, _ptr(packed, "packed"), _stream()), "vfn_pack_weights")
+
+
+# ------------------------------------------------------------------------------------------------
+# kernels
+# ------------------------------------------------------------------------------------------------
+def raygen_uniform(uv, pose, intrinsics, t_vals, n_samples, near, far, far_per_ray=None, u_coarse=None):
+    n = uv.shape[0]
+    dev = uv.device
+    p = RaygenParams(n, n_samples, int(pose.dim() == 2 and pose.shape[1] == 7), float(near), float(far))
+    directions = torch.empty(n, 3, device=dev)
+    ray_dirs = torch.empty(n, 3, device=dev)
+    cam_loc = torch.empty(n, 3, device=dev)
+    z = torch.empty(n, n_samples, device=dev)
+    pts = torch.empty(n, n_samples, 3, device=dev)
+    _check(load().vfn_raygen_uniform(C.byref(p), _ptr(uv, "uv"), _ptr(pose, "pose"), _ptr(intrinsics, "intrinsics"),
+                                     _ptr(t_vals, "t_vals"), _ptr(far_per_ray, "far_per_ray"),
+                                     _ptr(u_coarse, "u_coarse"), _ptr(directions, "directions"),
+                                     _ptr(ray_dirs, "ray_dirs"), _ptr(cam_loc, "cam_loc"), _ptr(z, "z"),
+                                     _ptr(pts, "points"), _stream()), "vfn_raygen_uniform")
+    return directions, ray_dirs, cam_loc, z, pts
+
+
+def vf_mlp_fwd(geom: NetGeom, packed, points, out_cols: int):
+    m = points.shape[0]
+    out = torch.empty(m, out_cols, device=points.device)
+    _check(load().vfn_vf_mlp_fwd(C.byref(geom), _ptr(packed, "packed"), _ptr(points, "points"), C.c_int64(m),
+                                 C.c_int32(out_cols), _ptr(out, "out"), _stream()), "vfn_vf_mlp_fwd")
+    return out
+
+
+def render_mlp_fwd(geom: NetGeom, packed, points, normals, view_dirs, feats):
+    m = points.shape[0]
+    colors = torch.empty(m, 3, device=points.device)
+    _check(load().vfn_render_mlp_fwd(C.byref(geom), _ptr(packed, "packed"), _ptr(points, "points"),
+                                     _ptr(normals, "normals"), _ptr(view_dirs, "view_dirs"), _ptr(feats, "feats"),
+                                     C.c_int64(m), _ptr(colors, "colors"), _stream()), "vfn_render_mlp_fwd")
+    return colors
+
+
+def vf_render_fused_fwd(vf_geom, vf_packed, rn_geom, rn_packed, points, ray_dirs, samples_per_ray: int,
+                        want_feats: bool = False):
+    m = points.shape[0]
+    dev = points.device
+    normals = torch.empty(m, 3, device=dev)
+    colors = torch.empty(m, 3, device=dev)
+    feats = torch.empty(m, HIDDEN, device=dev) if want_feats else None
+    _check(load().vfn_vf_render_fused_fwd(C.byref(vf_geom), _ptr(vf_packed, "vf_packed"), C.byref(rn_geom),
+                                          _ptr(rn_packed, "rn_packed"), _ptr(points, "points"),
+                                          _ptr(ray_dirs, "ray_dirs"), C.c_int64(m), C.c_int32(samples_per_ray),
+                                          _ptr(normals, "normals"), _ptr(colors, "colors"), _ptr(feats, "feats"),
+                                          _stream()), "vfn_vf_render_fused_fwd")
+    return normals, colors, feats
+
+
+def ray_density_weights(dp: DensityParams, normals, ray_dirs, z_vals, scalars, colors=None, want_sigma=True,
+                        want_weights=True, want_argmax=False):
+    n, s = z_vals.shape
+    dev = z_vals.device
+    dp.n_rays, dp.n_samples = n, s
+    sigma = torch.empty(n, s, device=dev) if want_sigma else None
+    weights = torch.empty(n, s, device=dev) if want_weights else None
+    argmax = torch.empty(n, dtype=torch.int64, device=dev) if want_argmax else None
+    rgb = torch.empty(n, 3, device=dev) if colors is not None else None
+    depth = torch.empty(n, 1, device=dev) if colors is not None else None
+    _check(load().vfn_ray_density_weights(C.byref(dp), _ptr(normals, "normals"), _ptr(ray_dirs, "ray_dirs"),
+                                          _ptr(z_vals, "z_vals"), _ptr(scalars, "density_scalars"),
+                                          _ptr(colors, "colors"), _ptr(sigma, "sigma"), _ptr(weights, "weights"),
+                                          _ptr(argmax, "argmax", torch.int64), _ptr(rgb, "rgb"),
+                                          _ptr(depth, "depth"), _stream()), "vfn_ray_density_weights")
+    return sigma, weights, argmax, rgb, depth
+
+
+def range_fine_sample(z_coarse, argmax, directions, cam_loc, n_fine, near, far, fine_range, u_add, u_fine=None,
+                      far_per_ray=None):
+    n, sc = z_coarse.shape
+    dev = z_coarse.device
+    step = 2 * fine_range / (n_fine - 1)            # Python double arithmetic, as ray_sampler.py:279
+    span = (far - near) if far_per_ray is None else 0.0
+    p = FineParams(n, sc, n_fine, float(near), float(far) if far_per_ray is None else 0.0, float(fine_range),
+                   float(step), float(span))
+    z = torch.empty(n, sc + n_fine, device=dev)
+    pts = torch.empty(n, sc + n_fine, 3, device=dev)
+    _check(load().vfn_range_fine_sample(C.byref(p), _ptr(z_coarse, "z_coarse"), _ptr(argmax, "argmax", torch.int64),
+                                        _ptr(directions, "directions"), _ptr(cam_loc, "cam_loc"),
+                                        _ptr(far_per_ray, "far_per_ray"), _ptr(u_fine, "u_fine"), _ptr(u_add, "u_add"),
+                                        _ptr(z, "z_vals"), _ptr(pts, "points"), _stream()), "vfn_range_fine_sample")
+    return z, pts
+
+
+def fill_uniform(out: torch.Tensor, seed: int, offset: int) -> torch.Tensor:
+    _check(load().vfn_fill_uniform(_ptr(out, "out"), C.c_int64(out.numel()), C.c_uint64(seed & (2 ** 64 - 1)),
+                                   C.c_uint64(offset & (2 ** 64 - 1)), _stream()), "vfn_fill_uniform")
+    return out

@@ -1,0 +1,305 @@
+"""``VectorFieldNerf``: the model facade the reference trainer / evaluator talk to, with ``render`` running on
+hand-written HIP kernels (csrc/*.hip) through the C ABI of ``include/vfn.h``.
+
+Mirrors ``models/nerf/vector_field_nerf.py:23-474`` of the reference: same constructor argument
+(``VFNerfConfig``), same attributes (``vector_field_network``, ``fine_vector_field_network`` — the same
+object, Q4 —, ``rendering_network``, ``ray_sampler``, ``fine_sampler``, ``density``, ``optimizer``,
+``scheduler``, ``config``), same methods and checkpoint keys.  Differences, all deliberate:
+
+* ``nn.DataParallel`` (vector_field_nerf.py:70-75) is replaced by one process per GPU (``distributed.py``);
+* random numbers come from a counter-based Philox stream on the device, or from explicitly supplied
+  uniforms (``uniforms=`` keyword) so a CPU reference run can be replayed exactly;
+* ``render`` needs ``n_importance > 0`` exactly like the reference (it raises NameError there, Q1; a
+  ValueError here).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import lib
+from .density import LaplaceDensity
+from .networks import RenderingNetwork, VectorFieldNetwork
+from .output import NerfOutput
+from .samplers import RangeFineSampler, UniformSampler
+
+
+class _WindowSchedule:
+    """Tent-shaped window weights that narrow linearly with the epoch (reference:
+    utils/weight_annealing.py:32-74).  Kept because the trainer logs ``config.cos_sim_weights_dict()``;
+    the density itself always uses uniform weights (vector_field_nerf.py:453-455, Q6)."""
+
+    def __init__(self, n_weights: int, n_epochs: int, soft: bool) -> None:
+        self.n, self.epochs, self.soft = n_weights, n_epochs, soft
+        self.mid = (n_weights - 1) / 2
+
+    def get_weights(self, epoch: int, device) -> torch.Tensor:
+        if epoch < 0:
+            return torch.ones(self.n, device=device).float() / self.n
+        offs = (torch.arange(self.n, device=device) - int(self.mid)).float().abs()
+        tent = torch.relu(-self.mid / self.epochs * epoch * offs + self.mid)
+        w = tent / tent.sum()
+        m = int(self.mid)
+        if self.soft and w[m] >= 0.8:
+            w[m - 2:m + 3] = 0.05
+            w[m] = 0.8
+        return w
+
+
+class VectorFieldNerf:
+    def __init__(self, config) -> None:
+        self.config = config
+        rs = config.ray_sampler_config
+        self.vector_field_network = VectorFieldNetwork(config.vf_net_config)
+        if rs.fine_sampling():
+            self.fine_vector_field_network = self.vector_field_network  # alias, as in the reference (Q4)
+        self.rendering_network = RenderingNetwork(config.rendering_net_config)
+
+        self.ray_sampler = UniformSampler(rs.n_samples, rs.near, rs.far, not rs.perturb)
+        if rs.fine_sampling():
+            self.fine_sampler = RangeFineSampler(rs.n_importance, rs.near, rs.far, not rs.perturb,
+                                                 range=rs.fine_range, max_samples=rs.max_samples)
+        self.density = LaplaceDensity(**config.density_config.todict())
+        if config.cos_sim_weights_anneal != "none":
+            self.annealing = _WindowSchedule(config.cos_sim_weights.shape[0],
+                                             config.anneal_end - config.anneal_start,
+                                             config.cos_sim_weights_anneal == "soft")
+        sc = config.scheduler_config
+        self.optimizer = torch.optim.Adam(self.parameters(), lr=sc.lr, weight_decay=sc.weight_decay)
+        self.scheduler = torch.optim.lr_scheduler.ExponentialLR(
+            self.optimizer, sc.lr_decay_factor ** (1. / sc.lr_decay_steps))
+        self.to(config.cuda_config.device)
+
+        # device RNG stream (Philox counter); every render() advances the offset
+        self.rng_seed = 0
+        self._rng_offset = 0
+        self._t_vals: Dict[Tuple[int, str], torch.Tensor] = {}
+
+    # ---------------------------------------------------------------------------------------------
+    # module plumbing
+    # ---------------------------------------------------------------------------------------------
+    def _modules(self):
+        return (self.vector_field_network, self.rendering_network, self.density)
+
+    def cpu(self) -> None:
+        for m in self._modules():
+            m.cpu()
+
+    def to(self, device) -> None:
+        for m in self._modules():
+            m.to(device)
+
+    def parameters(self) -> List[nn.Parameter]:
+        """VF parameters appear twice when fine sampling is on, exactly like the reference
+        (vector_field_nerf.py:127-137): the trainer's Adam / clip_grad_norm_ semantics depend on it (Q4)."""
+        params = list(self.vector_field_network.parameters()) + list(self.rendering_network.parameters()) + \
+            list(self.density.parameters())
+        if self.config.ray_sampler_config.fine_sampling():
+            params += list(self.fine_vector_field_network.parameters())
+        return params
+
+    def unique_parameters(self) -> List[nn.Parameter]:
+        seen, out = set(), []
+        for p in self.parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+        return out
+
+    def train(self) -> None:
+        if self.config.numerical_jacobian:
+            self.vector_field_network.eval()
+        else:
+            self.vector_field_network.train()
+        self.rendering_network.train()
+        self.density.train()
+
+    def eval(self) -> None:
+        for m in self._modules():
+            m.eval()
+
+    def _new_schedule(self, num_steps: int) -> None:
+        sc = self.config.scheduler_config
+        self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, sc.lr_decay_factor ** (1. / num_steps))
+        self.optimizer = torch.optim.Adam(self.parameters(), lr=sc.lr)
+
+    def new_scheduler(self, num_steps: int) -> None:
+        self._new_schedule(num_steps)
+
+    def reset_scheduler(self, num_steps: Optional[int] = None) -> None:
+        self._new_schedule(self.config.scheduler_config.lr_decay_steps if num_steps is None else num_steps)
+
+    def load(self, path: str) -> int:
+        ckpt = torch.load(path, map_location=self.config.cuda_config.device)
+        self.vector_field_network.load_state_dict(ckpt['vf_net'])
+        self.rendering_network.load_state_dict(ckpt['rendering_net'])
+        self.density.load_state_dict(ckpt['density'])
+        self.optimizer.load_state_dict(ckpt['optimizer'])
+        self.scheduler.load_state_dict(ckpt['scheduler'])
+        if self.config.ray_sampler_config.fine_sampling() and 'fine_vf_net' in ckpt:
+            self.fine_vector_field_network.load_state_dict(ckpt['fine_vf_net'])
+        return ckpt['epoch'] + 1
+
+    def save(self, epoch: int, path: str) -> None:
+        state = {'vf_net': self.vector_field_network.state_dict(),
+                 'rendering_net': self.rendering_network.state_dict(),
+                 'density': self.density.state_dict(),
+                 'epoch': epoch,
+                 'optimizer': self.optimizer.state_dict(),
+                 'scheduler': self.scheduler.state_dict()}
+        if self.config.ray_sampler_config.fine_sampling():
+            state['fine_vf_net'] = self.fine_vector_field_network.state_dict()
+        torch.save(state, os.path.join(path, f"{epoch}.pth"))
+        torch.save(state, os.path.join(path, "latest.pth"))
+
+    # ---------------------------------------------------------------------------------------------
+    # helpers
+    # ---------------------------------------------------------------------------------------------
+    def _anneal(self, epoch: int, device) -> None:
+        if self.config.cos_sim_weights_anneal != "none" and epoch > self.config.anneal_start:
+            self.config.cos_sim_weights = self.annealing.get_weights(epoch - self.config.anneal_start, device)
+
+    def _linspace(self, n: int, device) -> torch.Tensor:
+        key = (n, str(device))
+        if key not in self._t_vals:
+            # computed by torch on the host so that it is bit-identical to ray_sampler.py:129
+            self._t_vals[key] = torch.linspace(0., 1., steps=n).to(device)
+        return self._t_vals[key]
+
+    def _uniform(self, shape, device) -> torch.Tensor:
+        out = torch.empty(shape, device=device)
+        lib.fill_uniform(out, self.rng_seed, self._rng_offset)
+        self._rng_offset += (out.numel() + 3) // 4
+        return out
+
+    def _density_params(self) -> lib.DensityParams:
+        d, c = self.density, self.config
+        return lib.DensityParams(0, 0, int(c.cos_sim_weights.shape[0]), int(bool(c.normalize_rendering)),
+                                 float(c.dir_to_normal_th), float(d.beta_bounds[0]), float(d.beta_bounds[1]),
+                                 float(d.mean_bounds[0]), float(d.mean_bounds[1]), float(d.scale_min), float(d.cutoff))
+
+    @staticmethod
+    def _far_args(far):
+        """``far`` may be a float or a per-ray tensor (ray_sampler.py:126-127)."""
+        if isinstance(far, torch.Tensor):
+            return 0.0, far.reshape(-1).float().contiguous()
+        return float(far), None
+
+    def _rays(self, pose, pixels, intrinsics, u_coarse):
+        far, far_t = self._far_args(self.ray_sampler.far)
+        s_c = self.ray_sampler.N_samples
+        return lib.raygen_uniform(pixels.float().contiguous(), pose.float().contiguous(),
+                                  intrinsics.float().contiguous(), self._linspace(s_c, pose.device), s_c,
+                                  self.ray_sampler.near, far, far_t, u_coarse)
+
+    # ---------------------------------------------------------------------------------------------
+    # the hot path
+    # ---------------------------------------------------------------------------------------------
+    def render(self, pose: torch.Tensor, pixels: torch.Tensor, intrinsics: torch.Tensor, epoch: int,
+               white: bool = False, uniforms: Optional[Dict[str, torch.Tensor]] = None) -> NerfOutput:
+        """pose[N,4,4]|[N,7], pixels[N,2] (u,v), intrinsics[N,4,4] -> NerfOutput (vector_field_nerf.py:216-338).
+
+        ``uniforms`` optionally supplies the three torch.rand draws of the reference in call order
+        (``u_coarse[N,S_c]``, ``u_fine[N,N_f]``, ``u_add[N,N_f]``); otherwise the device Philox stream is used."""
+        cfg = self.config
+        if cfg.rendering != "volsdf":
+            raise NotImplementedError("rendering='nerf' calls nerf_volume_rendering with swapped arguments in the "
+                                      "reference (Q11); only 'volsdf' is implemented")
+        if not cfg.ray_sampler_config.fine_sampling():
+            raise ValueError("render() needs n_importance > 0 (the reference raises NameError without it, Q1)")
+        if self.vector_field_network.training or cfg.numerical_jacobian:
+            raise NotImplementedError("train-mode VF forward / directional derivatives (vector_field_nerf.py:258-264) "
+                                      "are not on the HIP path; use model.eval() as the shipped trainer does (Q8)")
+        from .autograd import fine_pass  # differentiable or plain, depending on torch.is_grad_enabled()
+
+        dev = pose.device
+        self._anneal(epoch, dev)
+        n = pixels.shape[0]
+        s_c = self.ray_sampler.N_samples
+        n_f = min(self.fine_sampler.N_samples, self.fine_sampler.max_samples)
+        perturb_c = not self.ray_sampler.deterministic
+        perturb_f = not self.fine_sampler.deterministic
+        uniforms = uniforms or {}
+
+        def draw(name, shape, needed):
+            if not needed:
+                return None
+            if name in uniforms:
+                return uniforms[name].to(dev).float().contiguous()
+            return self._uniform(shape, dev)
+
+        with torch.no_grad():
+            # (1)-(2) rays + proposal samples
+            u_coarse = draw("u_coarse", (n, s_c), perturb_c)
+            directions, ray_dirs, cam_loc, z_c, pts_c = self._rays(pose, pixels, intrinsics, u_coarse)
+            # (3) VF net, vector columns only
+            vf = self.vector_field_network
+            normals_c = lib.vf_mlp_fwd(vf.geometry(), vf.packed_weights(), pts_c.view(-1, 3), 3)
+            # (4)-(5) density -> weights -> argmax
+            scal = self.density.raw_scalars()
+            _, _, imax, _, _ = lib.ray_density_weights(self._density_params(), normals_c, ray_dirs, z_c, scal,
+                                                       want_sigma=False, want_weights=False, want_argmax=True)
+            # (6) fine samples
+            u_fine = draw("u_fine", (n, n_f), perturb_f)
+            u_add = draw("u_add", (n, n_f), True)
+            far, far_t = self._far_args(self.fine_sampler.far)
+            z, pts = lib.range_fine_sample(z_c, imax, directions, cam_loc, n_f, self.fine_sampler.near, far,
+                                           self.fine_sampler.range, u_add, u_fine, far_t)
+        s_t = s_c + n_f
+        # (7)-(11) fine pass: VF net + rendering net + density + composite
+        normals, colors, rgb, depth, weights = fine_pass(self, pts, z, ray_dirs)
+        if white:
+            rgb = rgb + (1. - weights.sum(-1)[..., None])
+        rep_dirs = ray_dirs.unsqueeze(1).expand(n, s_t, 3).reshape(-1, 3)
+        return NerfOutput(points_coarse=pts, points_fine=None, coarse_normals=normals.view(n, s_t, 3),
+                          coarse_rgb_values=rgb, coarse_depth_map=depth, fine_normals=None, fine_rgb_values=None,
+                          fine_depth_map=None, z_vals=z, directional_derivtives=None, ray_dirs=rep_dirs,
+                          coarse_colors=colors)
+
+    # ---------------------------------------------------------------------------------------------
+    # secondary entry points (vector_field_nerf.py:341-474)
+    # ---------------------------------------------------------------------------------------------
+    def get_density(self, normals: torch.Tensor, ray_dirs: torch.Tensor, fine: bool = False) -> torch.Tensor:
+        """normals[N,S,3], ray_dirs[N*S,3] (repeated per sample, as the reference passes them) -> sigma[N,S]."""
+        n, s, _ = normals.shape
+        rd = ray_dirs.reshape(n, s, 3)[:, 0, :].contiguous()
+        z = torch.zeros(n, s, device=normals.device)
+        sigma, _, _, _, _ = lib.ray_density_weights(self._density_params(), normals.detach().float().contiguous(), rd,
+                                                    z, self.density.raw_scalars(), want_weights=False)
+        return sigma
+
+    def get_vector_field(self, pose, pixels, intrinsics) -> torch.Tensor:
+        u = None if self.ray_sampler.deterministic else self._uniform((pixels.shape[0], self.ray_sampler.N_samples),
+                                                                        pose.device)
+        _, _, _, _, pts = self._rays(pose, pixels, intrinsics, u)
+        return self.vector_field_network(pts.view(-1, 3), vector_only=True)
+
+    def get_colors(self, pose, pixels, intrinsics, epoch: int):
+        self._anneal(epoch, pose.device)
+        u = None if self.ray_sampler.deterministic else self._uniform((pixels.shape[0], self.ray_sampler.N_samples),
+                                                                        pose.device)
+        _, ray_dirs, _, _, pts = self._rays(pose, pixels, intrinsics, u)
+        s_c = self.ray_sampler.N_samples
+        flat = pts.view(-1, 3)
+        rep = ray_dirs.unsqueeze(1).expand(-1, s_c, 3).reshape(-1, 3)
+        out = self.vector_field_network(flat)
+        f = self.config.vf_net_config.feature_vector_dims
+        colors = self.rendering_network(flat, out[:, :3], rep, out[:, 3:3 + f])
+        return colors, flat, rep
+
+    def get_weights_and_color(self, points, repeated_ray_dirs, z_vals, epoch: int):
+        self._anneal(epoch, points.device)
+        n, s = z_vals.shape
+        flat = points.reshape(-1, 3)
+        out = self.vector_field_network(flat)
+        f = self.config.vf_net_config.feature_vector_dims
+        normals = out[:, :3].contiguous()
+        rd = repeated_ray_dirs.reshape(n, s, 3)[:, 0, :].contiguous()
+        _, weights, _, _, _ = lib.ray_density_weights(self._density_params(), normals.detach(), rd,
+                                                      z_vals.float().contiguous(), self.density.raw_scalars(),
+                                                      want_sigma=False)
+        colors = self.rendering_network(flat, normals, repeated_ray_dirs.reshape(-1, 3), out[:, 3:3 + f])
+        return weights, colors
