@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/s of ``VectorFieldNerf.render`` (forward, eval mode) on 4096-ray chunks with
+128 samples per ray (S_c = N_f = 64), synthetic random-weight scene, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps 20 --warmup 3
+
+A step = one render() of one 4096-ray chunk per rank (rays shard embarrassingly: no data-path collective,
+weak scaling).  The timed region is bracketed by barrier + torch.cuda.synchronize() on both sides; the time is
+the max over ranks; rank 0 prints ONE JSON line.  Inputs (uv / pose / intrinsics) are resident in HBM before
+the timed region; random numbers come from the device Philox stream inside the timed region.
+
+Extra objects on the line:
+  roofline      the dominant kernel (fused VF+rendering MLP, fp32 MFMA): algorithmic FLOPs per launch
+                (2*S_t*(525056+271360) per ray) / its average duration measured with HIP
+                events on the launch stream inside the timed region; peak = 157.3 TFLOP/s fp32 matrix.
+  cpu_baseline  the CPU oracle (torch fp32, all host cores) on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+VF_MACS, RN_MACS = 525056, 271360          # per point
+PEAK_F32_MFMA = 157.3                      # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def build_scene(dev, n_rays, s_c, n_f, seed):
+    import vf_nerf_amd
+    from vf_nerf_amd import synthetic
+    torch.manual_seed(0)
+    cfg = vf_nerf_amd.shipped_config(dev, n_samples=s_c, n_importance=n_f, perturb=True, dir_to_normal_th=-0.2)
+    model = vf_nerf_amd.VectorFieldNerf(cfg)
+    model.eval()
+    model.rng_seed = seed
+    synthetic.scale_hidden_weights(model.vector_field_network, model.rendering_network, 2.0)
+    with torch.no_grad():
+        pts = synthetic.frustum_points(20000, seed=1234).to(dev)
+        mean, std = synthetic.vector_head_stats_from_tanh(model.vector_field_network(pts, vector_only=True))
+        synthetic.recentre_vector_head(model.vector_field_network, mean, std)
+    # Replica-like pinhole: 1200x680, f = 600
+    uv, pose, K = synthetic.pinhole_batch(n_rays, 1200, 680, 600.0, seed=100 + seed, device=dev)
+    return model, uv, pose, K
+
+
+def cpu_baseline(model, uv, pose, K, s_c, n_f, sample_rays=1024, budget_s=12.0):
+    """Oracle render() on the host cores, bounded to ~10-30 s.  torch's intra-op pool stops scaling on these
+    small per-layer GEMMs well before the box's 256 hardware threads (measured on the GPU box, rays/s at
+    8/16/32/64/128 threads: 505/568/602/406/213), so 32 threads are used and reported."""
+    from oracle import vfnerf_oracle as O
+    threads = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    vf_sd = {k: v.detach().cpu() for k, v in model.vector_field_network.state_dict().items()}
+    rn_sd = {k: v.detach().cpu() for k, v in model.rendering_network.state_dict().items()}
+    settings = O.RenderSettings(n_samples=s_c, n_fine=n_f, perturb=True, dir_to_normal_th=-0.2, fine_range=0.3,
+                                density=O.DensityParams(scale_min=1.0))
+    uv_c, pose_c, K_c = uv[:sample_rays].cpu(), pose[:sample_rays].cpu(), K[:sample_rays].cpu()
+    g = torch.Generator().manual_seed(5)
+    uni = dict(u_coarse=torch.rand(sample_rays, s_c, generator=g), u_fine=torch.rand(sample_rays, n_f, generator=g),
+               u_add=torch.rand(sample_rays, n_f, generator=g))
+    with torch.no_grad():
+        O.render(uv_c, pose_c, K_c, vf_sd, rn_sd, settings, **uni)  # warm-up
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            O.render(uv_c, pose_c, K_c, vf_sd, rn_sd, settings, **uni)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or reps >= 50:
+                break
+    return {"value": round(sample_rays * reps / el, 1), "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} x oracle render() of {sample_rays} rays x {s_c + n_f} samples, torch fp32 CPU, "
+                      f"{threads} threads, {el:.1f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--coarse", type=int, default=64)
+    ap.add_argument("--fine", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from vf_nerf_amd import lib
+    lib.load()  # fail loudly when the HIP extension is missing
+    s_c, n_f = args.coarse, args.fine
+    s_t = s_c + n_f
+    model, uv, pose, K = build_scene(dev, args.rays, s_c, n_f, seed=rank)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            model.render(pose, uv, K, epoch=0)
+        model._kernel_events = []
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model.render(pose, uv, K, epoch=0)
+        sync()
+        elapsed = time.perf_counter() - t0
+    events = model._kernel_events
+    model._kernel_events = None
+    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
+
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        rays_per_s = args.rays * args.steps * world / elapsed
+        flops_launch = 2.0 * s_t * (VF_MACS + RN_MACS) * args.rays
+        achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
+        hits = float((out.coarse_depth_map > 0).float().mean())
+        line = {
+            "metric": "rays/sec (4096-ray chunk, 128 samples/ray)",
+            "value": round(rays_per_s, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"VectorFieldNerf.render forward, {args.rays}-ray chunk x {s_t} samples/ray "
+                                   f"(S_c={s_c} + N_f={n_f}), shipped 9x256 VF + 5x256 rendering MLPs, eval-mode BN, "
+                                   f"stratified sampling on device Philox, Replica-like 1200x680 pinhole",
+                       "rays_per_chunk_per_gpu": args.rays, "samples_per_ray": s_t, "parallelism": f"rays x{world}",
+                       "rays_with_nonzero_depth": round(hits, 3)},
+            "roofline": {"bound": "mfma", "kernel": "vfn_mlp_kernel<MODE_FUSED> (VF MLP + rendering MLP, fine pass)",
+                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": None,
+                         "flops_per_launch": flops_launch, "avg_launch_ms": round(kernel_ms, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(model, uv, pose, K, s_c, n_f)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+"""Host-side logic that needs no GPU: C-ABI exports, layer planning, facade plumbing, checkpoint keys,
+ray sharding and the gloo world_size-2 gradient all-reduce."""
+import os
+import re
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import vf_nerf_amd
+from vf_nerf_amd import distributed as vdist
+from vf_nerf_amd import lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cpu_model(**kw):
+    torch.manual_seed(0)
+    m = vf_nerf_amd.VectorFieldNerf(vf_nerf_amd.shipped_config(torch.device("cpu"), **kw))
+    return m
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, "include", "vfn.h")).read()
+    declared = set(re.findall(r"\b(vfn_[a-z0-9_]+)\s*\(", header))
+    declared -= {"vfn_status"}
+    assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
+    handle = lib.load()
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert handle.vfn_abi_version() == 1
+
+
+def test_packed_size_and_plan_errors():
+    m = _cpu_model(n_samples=8, n_importance=8)
+    vf, rn = m.vector_field_network, m.rendering_network
+    vf_hidden = 8 * 256 * (5 + 32 + 32) + 7 * 256 * 32 + 8 * 256 * 33 + 8 * 256 * 32 * 3 + 8 * 256 * 32
+    vf_bias = 8 * 32 * 8 + 7 * 32
+    assert lib.packed_size(lib.NET_VF, vf.geometry()) == vf_hidden + vf_bias + 16 * 256 + 16
+    rn_hidden = 8 * 256 * 37 + 3 * 8 * 256 * 32
+    assert lib.packed_size(lib.NET_RENDER, rn.geometry()) == rn_hidden + 4 * 256 + 16 * 256 + 16
+    bad = lib.make_geom(3, 6, -1, 256, [39, 128, 128], [128, 128, 259], [1, 1, 0])
+    with pytest.raises(lib.VfnError, match="out_features=128"):
+        lib.packed_size(lib.NET_VF, bad)
+
+
+def test_cpu_tensor_is_refused_without_fallback():
+    m = _cpu_model(n_samples=8, n_importance=8)
+    m.eval()
+    with torch.no_grad(), pytest.raises(lib.VfnError, match="no CPU fallback"):
+        m.vector_field_network(torch.zeros(4, 3))
+
+
+def test_facade_surface_and_checkpoint_roundtrip():
+    m = _cpu_model(n_samples=16, n_importance=8)
+    assert m.fine_vector_field_network is m.vector_field_network          # alias (Q4)
+    assert len(m.parameters()) == 89 and sum(p.numel() for p in m.unique_parameters()) == 805780
+    assert sum(p.numel() for p in m.parameters()) == 1337122
+    assert m.ray_sampler.N_samples == 16 and m.fine_sampler.N_samples == 8 and m.fine_sampler.max_samples == 100
+    m.fine_sampler.N_samples += 5
+    assert m.fine_sampler.N_samples == 13
+    assert float(m.density.get_beta()) == 0.5 and abs(float(m.density.get_mean()) - 0.7) < 1e-7
+    assert float(m.density.get_scale()) == 100.0
+    assert set(m.config.cos_sim_weights_dict()) == {f"w_{i}" for i in range(11)}
+    keys = list(m.vector_field_network.state_dict())
+    assert keys[0] == "layers.0.0.weight" and "layers.3.1.running_mean" in keys
+    assert keys[-2:] == ["layers.8.weight", "layers.8.bias"]
+    with tempfile.TemporaryDirectory() as d:
+        m.save(7, d)
+        ck = torch.load(os.path.join(d, "latest.pth"))
+        assert set(ck) == {"vf_net", "rendering_net", "density", "epoch", "optimizer", "scheduler", "fine_vf_net"}
+        m2 = _cpu_model(n_samples=16, n_importance=8)
+        assert m2.load(os.path.join(d, "7.pth")) == 8
+    with pytest.raises(ValueError):
+        vf_nerf_amd.shipped_config(torch.device("cpu"), anneal="bogus")
+
+
+def test_render_requires_fine_sampling_and_eval_mode():
+    m = _cpu_model(n_samples=8, n_importance=0)
+    z = torch.zeros(2, 4, 4)
+    with pytest.raises(ValueError):
+        m.render(z, torch.zeros(2, 2), z, 0)
+    m = _cpu_model(n_samples=8, n_importance=8)
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m.render(z, torch.zeros(2, 2), z, 0)
+
+
+def test_window_schedule_is_a_normalised_tent():
+    m = _cpu_model(n_samples=8, n_importance=8)
+    w = m.annealing.get_weights(350, "cpu")
+    assert abs(float(w.sum()) - 1) < 1e-6 and int(torch.argmax(w)) == 5 and float(w[0]) < float(w[4])
+    assert torch.allclose(m.annealing.get_weights(-1, "cpu"), torch.full((11,), 1 / 11))
+
+
+def test_shard_bounds_cover_everything_once():
+    for n in (0, 1, 7, 4096, 8191):
+        for world in (1, 2, 3, 8):
+            spans = [vdist.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _ddp_worker(rank, world, port, result_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    r, w, _ = vdist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(rank)                      # different initial weights per rank on purpose
+    model = vf_nerf_amd.VectorFieldNerf(vf_nerf_amd.shipped_config(torch.device("cpu"), n_samples=8, n_importance=8))
+    vdist.broadcast_parameters(model, src=0)
+    bucket = vdist.GradientBucket(model)
+    assert bucket.numel() == 805780              # the alias must not double the bucket (Q4)
+    model.optimizer.zero_grad(set_to_none=True)  # a trainer that drops the views...
+    for i, p in enumerate(model.unique_parameters()):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    bucket.all_reduce_mean()                     # ...is re-bound, then ONE collective
+    expect = sum(range(1, world + 1)) / world
+    ok = all(torch.allclose(p.grad, torch.full_like(p, expect * (i + 1)))
+             for i, p in enumerate(model.unique_parameters()))
+    first = model.vector_field_network.layers[0][0].weight.detach().clone()
+    lo, hi = vdist.shard_bounds(7, rank, world)
+    gathered = vdist.gather_rows(torch.full((hi - lo, 2), float(rank)), 7)
+    torch.save({"ok": ok, "w": first, "rows": gathered}, os.path.join(result_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_gradient_allreduce_and_broadcast():
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_ddp_worker, args=(world, port, d), nprocs=world, join=True)
+        res = [torch.load(os.path.join(d, f"r{r}.pt")) for r in range(world)]
+    assert all(r["ok"] for r in res)
+    assert torch.equal(res[0]["w"], res[1]["w"])          # broadcast made the replicas identical
+    rows = res[0]["rows"]
+    assert rows.shape[0] == 7 and torch.equal(rows[:, 0], torch.tensor([0., 0, 0, 0, 1, 1, 1]))
+
+
+def test_dropin_aliases_reference_import_paths():
+    import importlib
+    import sys
+    saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in ("models", "evaluation")}
+    try:
+        import vf_nerf_amd.dropin  # noqa: F401
+        mod = importlib.import_module("models.nerf.vector_field_nerf")
+        assert mod.VectorFieldNerf is vf_nerf_amd.VectorFieldNerf
+        from models.vector_field.vector_field_network import VectorFieldNetwork
+        from models.samplers.ray_sampler import RangeFineSampler, UniformSampler  # noqa: F401
+        from models.helpers.density_functions import LaplaceDensity  # noqa: F401
+        assert VectorFieldNetwork is vf_nerf_amd.networks.VectorFieldNetwork
+    finally:
+        for k in [k for k in sys.modules if k.split(".")[0] in ("models", "evaluation")]:
+            del sys.modules[k]
+        sys.modules.update(saved)

@@ -42,8 +42,15 @@ def fine_pass(model, pts: torch.Tensor, z: torch.Tensor, ray_dirs: torch.Tensor)
     if torch.is_grad_enabled() and any(p.requires_grad for p in model.unique_parameters()):
         from .backward import fine_pass_autograd
         return fine_pass_autograd(model, pts, z, ray_dirs)
-    normals, colors, _ = lib.vf_render_fused_fwd(vf.geometry(), vf.packed_weights(), rn.geometry(),
-                                                 rn.packed_weights(), pts.view(-1, 3), ray_dirs, s_t)
+    vf_w, rn_w = vf.packed_weights(), rn.packed_weights()
+    events = getattr(model, "_kernel_events", None)  # bench.py: HIP events around the dominant kernel
+    if events is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    normals, colors, _ = lib.vf_render_fused_fwd(vf.geometry(), vf_w, rn.geometry(), rn_w, pts.view(-1, 3), ray_dirs, s_t)
+    if events is not None:
+        e1.record()
+        events.append((e0, e1))
     _, weights, _, rgb, depth = lib.ray_density_weights(model._density_params(), normals, ray_dirs, z,
                                                         model.density.raw_scalars(), colors=colors, want_sigma=False)
     return normals, colors, rgb, depth, weights
