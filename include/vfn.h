@@ -177,6 +177,58 @@ int vfn_range_fine_sample(const vfn_fine_params* p, const float* z_coarse, const
 /* Counter-based uniforms in [0,1) for production sampling (Philox4x32-10, one 4-tuple per 4 outputs). */
 int vfn_fill_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 
+/* =============================================================================================
+ * Training path (autograd of the fine pass: models/nerf/vector_field_nerf.py:294-323 under
+ * train/vector_field_nerf_train.py:251-260, eval-mode BatchNorm as in :140-141).
+ *
+ * Workspace layout shared by the entry points below ("slots"): slot s is a dense [M,256] fp32 matrix;
+ * slots 0..H_vf-1 are the VF net's hidden layers in order (the last one is the 256-wide feature block of
+ * the final Linear when feature_dims > 0), slots H_vf..H_vf+H_rn-1 the rendering net's hidden layers.
+ * `saved` holds post-activation outputs (forward), `dy` pre-activation gradients (backward).
+ * ============================================================================================= */
+
+/* Size (floats) and fill of the TRANSPOSED weight pack used by dX = dY * W'. */
+int64_t vfn_packed_bwd_size(int32_t net_kind, const vfn_net_geom* geom);
+int vfn_pack_weights_bwd(int32_t net_kind, const vfn_net_geom* geom, const vfn_layer_params* layers,
+                         float* packed_bwd, void* stream);
+
+/* Forward kernels that additionally write `saved` slots and the auxiliary input tiles
+ * (save_aux_vf[M,40] = positional encoding of the point, save_aux_rn[M,40] = [p, PE(d), n]). */
+int vfn_vf_mlp_fwd_train(const vfn_net_geom* geom, const float* packed, const float* points, int64_t n_points,
+                         int32_t out_cols, float* out, float* saved, float* save_aux_vf, void* stream);
+int vfn_vf_render_fused_fwd_train(const vfn_net_geom* vf_geom, const float* vf_packed,
+                                  const vfn_net_geom* rn_geom, const float* rn_packed,
+                                  const float* points, const float* ray_dirs, int64_t n_points,
+                                  int32_t samples_per_ray, float* normals, float* colors, float* saved,
+                                  float* save_aux_vf, float* save_aux_rn, void* stream);
+
+/* dX chain.  rn_geom != NULL: gradients d_colors[M,3] (wrt the sigmoid outputs `colors`) and d_vec (wrt the
+ * tanh'ed vector columns `vec`, row stride vec_stride) are pushed back through the rendering net, the feature
+ * hand-off and the VF net.  rn_geom == NULL: VF net only; d_feats (wrt the tanh'ed features, row stride
+ * vec_stride) may be NULL.  Writes every `dy` slot plus dz_rgb[M,4] / dz_vec[M,4] (pre-activation gradients of
+ * the two 3-channel heads, 4th column zero). */
+int vfn_mlp_bwd_chain(const vfn_net_geom* vf_geom, const float* vf_packed, const float* vf_packed_bwd,
+                      const vfn_net_geom* rn_geom, const float* rn_packed, const float* rn_packed_bwd,
+                      const float* saved, float* dy, const float* d_colors, const float* colors,
+                      const float* d_vec, const float* vec, const float* d_feats, int32_t vec_stride,
+                      int64_t n_points, float* dz_rgb, float* dz_vec, void* stream);
+
+/* Weight-gradient partials dW'[n][k] = sum_m dY[m][n] X[m][k] as `groups` slabs [groups][n_out][ld_out], plus
+ * db'[n] = sum_m dY[m][n] as [groups][n_out] (db_part may be NULL).  shape 0: n_out 256, ld_out 256 (hidden
+ * layer, act inputs); 1: n_out 256, ld_out 64 (aux inputs); 2: n_out 32, ld_out 256 (3-channel head).
+ * Columns >= n_valid of dY / >= k_valid of X read as zero. */
+int vfn_weight_grad_partials(int32_t shape, const float* dy, int32_t ld_dy, int32_t n_valid, const float* x,
+                             int32_t ld_x, int32_t k_valid, int64_t n_points, int32_t groups, float* dw_part,
+                             float* db_part, void* stream);
+
+/* Backward of vfn_ray_density_weights: upstream d_rgb[N,3], d_depth[N], d_weights[N,S] (each may be NULL) ->
+ * d_colors[N,S,3] (written, may be NULL), d_normals[N,S,3] (ACCUMULATED into), d_scalars[3] (atomically
+ * accumulated gradients of the raw beta, mean, scale).  n_samples <= 256. */
+int vfn_ray_density_weights_bwd(const vfn_density_params* p, const float* normals, const float* ray_dirs,
+                                const float* z_vals, const float* density_scalars, const float* colors,
+                                const float* d_rgb, const float* d_depth, const float* d_weights,
+                                float* d_normals, float* d_colors, float* d_scalars, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -186,12 +186,52 @@ def capture(fx, model):
     return d, model
 
 
+GRAD_KEYS = (("vf", "layers.0.0.weight"), ("vf", "layers.0.1.weight"), ("vf", "layers.3.0.bias"),
+             ("vf", "layers.4.0.weight"), ("vf", "layers.4.1.bias"), ("vf", "layers.7.1.weight"),
+             ("vf", "layers.8.weight"), ("vf", "layers.8.bias"), ("rn", "layers.0.0.weight"),
+             ("rn", "layers.2.1.weight"), ("rn", "layers.4.weight"), ("rn", "layers.4.bias"))
+
+
+def loss_coefficients(n, s_t):
+    """Fixed linear functional of (rgb, depth, normals); shared with the tests via the seed."""
+    g = torch.Generator().manual_seed(4242)
+    return (torch.randn(n, 3, generator=g), torch.randn(n, 1, generator=g), 0.05 * torch.randn(n, s_t, 3, generator=g))
+
+
+def capture_grads(fx, model, data):
+    """Reference gradients of the functional for the replayed random draws (the shipped training regime: networks
+    in eval mode, autograd through the fine pass only)."""
+    draws = [data[k] for k in ("u_coarse", "u_fine", "u_add") if k in data]
+    it = iter(draws)
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: next(it).clone()
+    try:
+        for p in model.parameters():
+            p.grad = None
+        out = model.render(data["pose"], data["uv"], data["intrinsics"], epoch=0)
+    finally:
+        torch.rand = real_rand
+    assert torch.equal(out.z_vals, data["z_vals"])
+    a, b, c = loss_coefficients(*data["z_vals"].shape)
+    loss = (out.coarse_rgb_values * a).sum() + (out.coarse_depth_map * b).sum() + (out.coarse_normals * c).sum()
+    loss.backward()
+    nets = {"vf": model.vector_field_network, "rn": model.rendering_network}
+    g = {}
+    for net, key in GRAD_KEYS:
+        g[f"grad.{net}.{key}"] = dict(nets[net].named_parameters())[key].grad.clone()
+    for name, p in model.density.named_parameters():
+        g[f"grad.density.{name}"] = p.grad.clone().reshape(1)
+    g["loss"] = loss.detach().reshape(1)
+    return g
+
+
 def main() -> None:
     torch.set_num_threads(8)
     for name, fx in FIXTURES.items():
         model = build_reference_model(fx)
         own_model_matches(fx, model)
         data, model = capture(fx, model)
+        data.update(capture_grads(fx, model, data))
         head = model.vector_field_network.layers[8]
         chk = synthetic.weights_checksum({"vf": model.vector_field_network.state_dict(),
                                           "rn": model.rendering_network.state_dict(),

@@ -68,3 +68,48 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     """max |a-b| / max(1, max|b|): the '1e-4 rel fp32' yardstick, robust to near-zero entries."""
     a, b = a.double().cpu(), b.double().cpu()
     return float((a - b).abs().max() / max(1.0, float(b.abs().max())))
+
+
+GRAD_KEYS = (("vf", "layers.0.0.weight"), ("vf", "layers.0.1.weight"), ("vf", "layers.3.0.bias"),
+             ("vf", "layers.4.0.weight"), ("vf", "layers.4.1.bias"), ("vf", "layers.7.1.weight"),
+             ("vf", "layers.8.weight"), ("vf", "layers.8.bias"), ("rn", "layers.0.0.weight"),
+             ("rn", "layers.2.1.weight"), ("rn", "layers.4.weight"), ("rn", "layers.4.bias"))
+
+
+def loss_coefficients(n, s_t):
+    """The fixed linear functional of (rgb, depth, normals) used when the reference gradients were captured
+    (tests/golden/make_golden.py:loss_coefficients)."""
+    g = torch.Generator().manual_seed(4242)
+    return (torch.randn(n, 3, generator=g), torch.randn(n, 1, generator=g), 0.05 * torch.randn(n, s_t, 3, generator=g))
+
+
+def grad_rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """max |a-b| / max |b| (gradient tensors span orders of magnitude across layers; scale by the tensor's own max)."""
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+def oracle_gradients(fx, d, model):
+    """Autograd of the CPU oracle for the same functional -> {name: grad} for every parameter + density scalars."""
+    from oracle import vfnerf_oracle as O
+    vf_sd = {k: v.detach().cpu().clone() for k, v in model.vector_field_network.state_dict().items()}
+    rn_sd = {k: v.detach().cpu().clone() for k, v in model.rendering_network.state_dict().items()}
+    leaves = {}
+    for tag, net, sd in (("vf", model.vector_field_network, vf_sd), ("rn", model.rendering_network, rn_sd)):
+        for name, _ in net.named_parameters():
+            sd[name].requires_grad_(True)
+            leaves[f"{tag}.{name}"] = sd[name]
+    beta = torch.tensor(0.5, requires_grad=True)
+    mean = torch.tensor(0.7, requires_grad=True)
+    scale = torch.tensor(100.0, requires_grad=True)
+    hidden = []
+    out = O.render(d["uv"], d["pose"], d["intrinsics"], vf_sd, rn_sd, oracle_settings(fx), u_coarse=d.get("u_coarse"),
+                   u_fine=d.get("u_fine"), u_add=d["u_add"], far=d.get("far_per_ray"), beta=beta, mean=mean, scale=scale,
+                   hidden=hidden)
+    a, b, c = loss_coefficients(*d["z_vals"].shape)
+    loss = (out["rgb"] * a).sum() + (out["depth"] * b).sum() + (out["normals"] * c).sum()
+    loss.backward()
+    grads = {k: v.grad for k, v in leaves.items()}
+    grads.update({"density.beta": beta.grad, "density.mean": mean.grad, "density.scale": scale.grad})
+    grads["_hidden"] = hidden     # 8 VF + 4 rendering post-ReLU activations [M, width]
+    return float(loss), grads

@@ -1,0 +1,140 @@
+"""Training path on the GPU: gradients of a fixed linear functional of (rgb, depth, normals) from the HIP backward
+kernels against the CPU oracle's autograd and against gradients captured from the reference's own backward pass.
+Tolerance: 1e-3 of each gradient tensor's max magnitude (sums over thousands of points in a different order);
+observed errors are printed."""
+import pytest
+import torch
+
+from helpers import (FIXTURE_NAMES, GRAD_KEYS, build_model, grad_rel_err, load_fixture, loss_coefficients,
+                     oracle_gradients)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _hip_gradients(fx, d, model):
+    g = {k: v.to("cuda:0") for k, v in d.items() if isinstance(v, torch.Tensor)}
+    uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add") if k in g}
+    for p in model.unique_parameters():
+        p.grad = None
+    model._keep_saved = True
+    out = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
+    a, b, c = (t.to("cuda:0") for t in loss_coefficients(*d["z_vals"].shape))
+    loss = (out.coarse_rgb_values * a).sum() + (out.coarse_depth_map * b).sum() + (out.coarse_normals * c).sum()
+    loss.backward()
+    return float(loss), out
+
+
+@pytest.mark.parametrize("name", FIXTURE_NAMES)
+def test_render_gradients(name):
+    fx, d = load_fixture(name)
+    model = build_model(fx, d, device="cuda:0")
+    loss, out = _hip_gradients(fx, d, model)
+    assert (out.z_vals.cpu() == d["z_vals"]).all(), "sampling must replay exactly for the comparison to be meaningful"
+    ref_loss, ref = oracle_gradients(fx, d, build_model(fx, d))
+    assert abs(loss - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss))
+    # ReLU kinks: two fp32 implementations can disagree on the sign of a pre-activation that is ~1e-7 from zero,
+    # which legitimately changes the gradient of everything below.  Count such flips from the saved activations.
+    saved = model._debug_saved.cpu()
+    slots = list(range(8)) + list(range(9, 13))          # VF hidden 0..7, rendering hidden 0..3 (slot 8 = features)
+    flips = 0
+    for slot, act in zip(slots, ref["_hidden"]):
+        w = act.shape[1]
+        flips += int(((saved[slot][:, :w] > 0) != (act > 0)).sum())
+    tol = TOL if flips == 0 else 3e-2
+    print(f"{name}: ReLU sign flips between HIP and CPU activations: {flips} -> tolerance {tol:g}")
+    assert flips <= 3
+    worst = ("", 0.0)
+    errs = []
+    nets = {"vf": model.vector_field_network, "rn": model.rendering_network}
+    for tag, net in nets.items():
+        for pname, p in net.named_parameters():
+            assert p.grad is not None, (tag, pname)
+            err = grad_rel_err(p.grad, ref[f"{tag}.{pname}"])
+            if err > worst[1]:
+                worst = (f"{tag}.{pname}", err)
+            if err > 1e-4:
+                print(f"   {tag}.{pname}: err {err:.3e} (|ref|max {float(ref[f'{tag}.{pname}'].abs().max()):.3e})")
+            errs.append((tag, pname, err))
+    for pname, p in model.density.named_parameters():
+        err = grad_rel_err(p.grad.reshape(1), ref[f"density.{pname}"].reshape(1))
+        print(f"density.{pname}: hip {float(p.grad):.6e} ref {float(ref['density.' + pname]):.6e}")
+        assert err < tol, (pname, err)
+    print(f"{name}: worst parameter-gradient error {worst[1]:.3e} at {worst[0]}")
+    assert all(e < tol for _, _, e in errs), [x for x in errs if x[2] >= tol]
+    # and against the reference's own backward pass
+    for tag, key in GRAD_KEYS:
+        err = grad_rel_err(dict(nets[tag].named_parameters())[key].grad, d[f"grad.{tag}.{key}"])
+        assert err < tol, ("vs reference", tag, key, err)
+    for k in ("beta", "mean", "scale"):
+        assert grad_rel_err(getattr(model.density, k).grad.reshape(1), d[f"grad.density.{k}"]) < tol
+
+
+def test_supervision_forward_gradients():
+    """vector_field_network(points)[:, :3] as the trainer uses it for border / centre supervision
+    (train/vector_field_nerf_train.py:191,203,215), full-row and vector-only variants."""
+    from oracle import vfnerf_oracle as O
+    fx, d = load_fixture("odd_orbit")
+    model = build_model(fx, d, device="cuda:0")
+    vf = model.vector_field_network
+    gen = torch.Generator().manual_seed(3)
+    pts = (torch.rand(333, 3, generator=gen) - 0.5) * 2
+    coef = torch.randn(333, 3, generator=gen)
+    cpu_sd = {k: v.detach().cpu().clone() for k, v in vf.state_dict().items()}
+    for name, _ in vf.named_parameters():
+        cpu_sd[name].requires_grad_(True)
+    (O.vf_mlp(pts, cpu_sd)[:, :3] * coef).sum().backward()
+    for variant in ("full", "vector_only"):
+        for p in vf.parameters():
+            p.grad = None
+        out = vf(pts.to("cuda:0")) if variant == "full" else vf(pts.to("cuda:0"), vector_only=True)
+        (out[:, :3] * coef.to("cuda:0")).sum().backward()
+        worst = 0.0
+        for name, p in vf.named_parameters():
+            ref = cpu_sd[name].grad
+            if variant == "vector_only" and name.startswith("layers.8"):
+                err = grad_rel_err(p.grad[:3], ref[:3])
+            else:
+                err = grad_rel_err(p.grad, ref)
+            worst = max(worst, err)
+            assert err < TOL, (variant, name, err)
+        print(f"supervision forward ({variant}): worst gradient error {worst:.3e}")
+
+
+def test_one_adam_step_matches_oracle_step():
+    """zero_grad -> backward -> clip_grad_norm_ (with the duplicated parameter list, Q4) -> Adam.step, as
+    train/vector_field_nerf_train.py:251-260 does, against the same sequence driven by the oracle's gradients."""
+    fx, d = load_fixture("w1_det")
+    model = build_model(fx, d, device="cuda:0")
+    ref_model = build_model(fx, d)
+    # torch's multi-tensor ("foreach") Adam / clip update duplicated parameters concurrently on the GPU, which makes
+    # the reference's double update (Q4) racy there; pin the sequential semantics on both sides for the comparison.
+    lr = model.config.scheduler_config.lr
+    model.optimizer = torch.optim.Adam(model.parameters(), lr=lr, foreach=False)
+    ref_model.optimizer = torch.optim.Adam(ref_model.parameters(), lr=lr, foreach=False)
+    _hip_gradients(fx, d, model)
+    torch.nn.utils.clip_grad_norm_(model.parameters(), model.config.scheduler_config.clip_norm, foreach=False)
+    model.optimizer.step()
+    _, ref = oracle_gradients(fx, d, ref_model)
+    for tag, net in (("vf", ref_model.vector_field_network), ("rn", ref_model.rendering_network)):
+        for pname, p in net.named_parameters():
+            p.grad = ref[f"{tag}.{pname}"].clone()
+    for pname, p in ref_model.density.named_parameters():
+        p.grad = ref[f"density.{pname}"].reshape(p.shape).clone()
+    torch.nn.utils.clip_grad_norm_(ref_model.parameters(), ref_model.config.scheduler_config.clip_norm, foreach=False)
+    ref_model.optimizer.step()
+    # Adam's first step is lr * g / (|g| + 1e-8) = +-lr per application (twice for the aliased VF net, Q4): it is
+    # ill-conditioned where |g| is at rounding-noise level, so compare where the gradient is significant.
+    worst = 0.0
+    for tag, net_a, net_b in (("vf", model.vector_field_network, ref_model.vector_field_network),
+                              ("rn", model.rendering_network, ref_model.rendering_network)):
+        for (n1, p1), (n2, p2) in zip(net_a.named_parameters(), net_b.named_parameters()):
+            gref = ref[f"{tag}.{n1}"]
+            sig = gref.abs() > 1e-3 * gref.abs().max()
+            diff = (p1.detach().cpu() - p2.detach()).abs()
+            worst = max(worst, float(diff[sig].max()))
+    print(f"max parameter difference after one clipped Adam step (significant gradients): {worst:.3e}")
+    assert worst < 2e-5
+    w0 = build_model(fx, d).vector_field_network.layers[8].weight.detach()
+    step = (ref_model.vector_field_network.layers[8].weight.detach() - w0).abs().max()
+    assert abs(float(step) - 2 * lr) < 0.1 * lr, "the aliased VF parameters receive two Adam updates per step (Q4)"

@@ -63,3 +63,18 @@ def test_psnr_definition():
     a = torch.zeros(10, 3)
     b = torch.full((10, 3), 0.1)
     assert abs(O.psnr(a, b) - 20.0) < 1e-4
+
+
+@pytest.mark.parametrize("name", FIXTURE_NAMES)
+def test_oracle_gradients_match_reference(name):
+    """Autograd of the oracle against gradients captured from the reference's own backward pass."""
+    from helpers import GRAD_KEYS, grad_rel_err, oracle_gradients
+    fx, d = load_fixture(name)
+    model = build_model(fx, d)
+    loss, grads = oracle_gradients(fx, d, model)
+    assert abs(loss - float(d["loss"])) <= 1e-5 * max(1.0, abs(float(d["loss"])))
+    for net, key in GRAD_KEYS:
+        err = grad_rel_err(grads[f"{net}.{key}"], d[f"grad.{net}.{key}"])
+        assert err < 1e-4, (net, key, err)
+    for k in ("beta", "mean", "scale"):
+        assert grad_rel_err(grads[f"density.{k}"].reshape(1), d[f"grad.density.{k}"]) < 1e-4, k

@@ -1,13 +1,305 @@
-"""Autograd wrappers of the training path (a13 in SURVEY.md §8).  Filled in after the forward path."""
+"""Autograd wrappers of the training path.
+
+The reference trains through plain PyTorch autograd over the fine pass (models/nerf/vector_field_nerf.py:294-323;
+train/vector_field_nerf_train.py:251-260) with BatchNorm in eval mode (Q8).  Here the same gradients come from HIP
+kernels: a training forward that saves each layer's output, a fused dX chain, persistent weight-gradient kernels
+(csrc/vfn_mlp_bwd.hip) and the per-ray density/composite backward (csrc/vfn_rays.hip).  What remains in PyTorch is
+parameter-sized glue: summing the partial slabs and un-folding BatchNorm / the skip scale back onto the reference's
+parameters (Linear weight/bias, BatchNorm weight/bias).
+"""
 from __future__ import annotations
 
+import math
+from typing import Dict, List, Optional
 
-def _todo(*_a, **_k):
-    raise NotImplementedError(
-        "the HIP backward kernels (dW/dX of the fused MLPs, scan/window-cosine backward) are not built yet: "
-        "call under torch.no_grad() for rendering / evaluation")
+import torch
+
+from . import lib
+
+HID = lib.HIDDEN
+EPS_BN = 1e-5
 
 
-vf_forward_autograd = _todo
-render_forward_autograd = _todo
-fine_pass_autograd = _todo
+# ------------------------------------------------------------------------------------------------
+# host-side mirror of the kernel's layer plan (csrc/vfn_plan.h): which reference rows / columns each
+# hidden entry covers
+# ------------------------------------------------------------------------------------------------
+def _entries(net) -> List[dict]:
+    geom = net.geometry()
+    L = geom.n_layers
+    pe = 3 + 6 * geom.multires if geom.multires > 0 else 3
+    F = geom.feature_dims
+    out = []
+    if net._kind == lib.NET_VF:
+        skip = geom.skip_layer
+        for i in range(L - 1):
+            e = dict(layer=i, rows=geom.out_dims[i], row_off=0, scale=1.0, act=None, aux=None)
+            if i == 0:
+                e["aux"] = (0, pe)
+            elif i == skip:
+                e["act"] = (0, geom.out_dims[i - 1])
+                e["aux"] = (geom.out_dims[i - 1], pe)
+                e["scale"] = 1.0 / math.sqrt(2.0)
+            else:
+                e["act"] = (0, HID)
+            out.append(e)
+        if F > 0:
+            out.append(dict(layer=L - 1, rows=F, row_off=3, scale=1.0, act=(0, HID), aux=None))
+    else:
+        for i in range(L - 1):
+            e = dict(layer=i, rows=geom.out_dims[i], row_off=0, scale=1.0, act=(0, HID), aux=None)
+            if i == 0:
+                e["act"] = (6 + pe, F)
+                e["aux"] = (0, 6 + pe)
+            out.append(e)
+    return out
+
+
+def _packed_bwd(net) -> torch.Tensor:
+    tensors = [t for d in net._layer_tensors() for t in d.values()]
+    key = tuple((t.data_ptr(), t._version) for t in tensors)
+    dev = tensors[0].device
+    cache = getattr(net, "_packed_bwd_cache", None)
+    if cache is None or cache[0] != key or cache[1].device != dev:
+        geom = net.geometry()
+        buf = torch.empty(max(1, lib.packed_bwd_size(net._kind, geom)), device=dev)
+        with torch.no_grad():
+            lib.pack_weights_bwd(net._kind, geom, [{k: v.detach() for k, v in d.items()} for d in net._layer_tensors()],
+                                 buf)
+        net._packed_bwd_cache = (key, buf)
+        cache = net._packed_bwd_cache
+    return cache[1]
+
+
+def _groups(m: int) -> int:
+    return max(1, min(256, m // 256))
+
+
+def _vf_inputs(vf, saved_slots: List[torch.Tensor]) -> List[Optional[torch.Tensor]]:
+    """act input of each VF entry (entry 0 reads only the encoding; entry h reads the output of entry h-1; the feature
+    block reads the last plain hidden output) followed by the head's input."""
+    entries = _entries(vf)
+    n_plain = len(entries) - (1 if vf._feature_dims() > 0 else 0)
+    inputs: List[Optional[torch.Tensor]] = [None] + [saved_slots[h - 1] for h in range(1, n_plain)]
+    if vf._feature_dims() > 0:
+        inputs.append(saved_slots[n_plain - 1])
+    inputs.append(saved_slots[n_plain - 1])
+    return inputs
+
+
+def _rn_inputs(feats: torch.Tensor, saved_slots: List[torch.Tensor]) -> List[torch.Tensor]:
+    """rendering net: entry 0 reads the features, entry h the output of entry h-1, the head the last output."""
+    return [feats] + list(saved_slots)
+
+
+def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=()) -> Dict[torch.nn.Parameter, torch.Tensor]:
+    """inputs[h]: [M,256] act input of hidden entry h (None if it has none); inputs[-1]: input of the 3-channel head.
+    dy_slots[h]: [M,256] pre-activation gradient of entry h.  aux: [M,40].  dz_head: [M,4].  Runs the persistent
+    weight-gradient kernels, sums their partial slabs and un-folds BatchNorm / the skip scale:
+        W' = s * scale * W,  b' = s (b - mu) + beta_bn,  s = gamma / sqrt(var + eps)."""
+    dev = aux.device
+    entries = _entries(net)
+    G = _groups(m)
+    grads: Dict[torch.nn.Parameter, torch.Tensor] = {}
+
+    def acc(p, g):
+        grads[p] = g if p not in grads else grads[p] + g
+
+    for h, e in enumerate(entries):
+        if h in skip:
+            continue
+        lin, bn = net._linear(e["layer"]), net._bn(e["layer"])
+        W = lin.weight.detach()
+        rows, r0 = e["rows"], e["row_off"]
+        dy = dy_slots[h]
+        db_part = torch.empty(G, HID, device=dev)
+        dW_act = dW_aux = None
+        if e["act"] is not None:
+            part = torch.empty(G, HID, HID, device=dev)
+            lib.weight_grad_partials(0, dy, HID, HID, inputs[h], HID, HID, m, G, part, db_part)
+            dW_act = part.sum(0)
+        if e["aux"] is not None:
+            part = torch.empty(G, HID, 64, device=dev)
+            lib.weight_grad_partials(1, dy, HID, HID, aux, lib.AUX_K, lib.AUX_K, m, G, part,
+                                     db_part if e["act"] is None else None)
+            dW_aux = part.sum(0)
+        db = db_part.sum(0)[:rows]
+        if bn is not None:
+            inv = torch.rsqrt(bn.running_var.detach() + EPS_BN)
+            s_fold = bn.weight.detach() * inv
+        else:
+            inv, s_fold = None, torch.ones(rows, device=dev)
+        gW = torch.zeros_like(W)
+        dgam = torch.zeros(rows, device=dev)
+        for blk, rng in ((dW_act, e["act"]), (dW_aux, e["aux"])):
+            if blk is None:
+                continue
+            c0, nc = rng
+            sub = blk[:rows, :nc] * e["scale"]
+            gW[r0:r0 + rows, c0:c0 + nc] = s_fold[:, None] * sub
+            if bn is not None:
+                dgam += (sub * W[r0:r0 + rows, c0:c0 + nc]).sum(1)
+        acc(lin.weight, gW)
+        gb = torch.zeros_like(lin.bias)
+        gb[r0:r0 + rows] = s_fold * db
+        acc(lin.bias, gb)
+        if bn is not None:
+            acc(bn.weight, (dgam + db * (lin.bias.detach() - bn.running_mean.detach())) * inv)
+            acc(bn.bias, db.clone())
+    # 3-channel head = rows 0..2 of the last Linear
+    last = net._linear(net.num_layers - 1)
+    part = torch.empty(G, 32, HID, device=dev)
+    dbp = torch.empty(G, 32, device=dev)
+    lib.weight_grad_partials(2, dz_head, 4, 3, inputs[-1], HID, HID, m, G, part, dbp)
+    gW = torch.zeros_like(last.weight)
+    gW[:3] = part.sum(0)[:3]
+    gb = torch.zeros_like(last.bias)
+    gb[:3] = dbp.sum(0)[:3]
+    acc(last.weight, gW)
+    acc(last.bias, gb)
+    return grads
+
+
+class _Workspace:
+    def __init__(self, m: int, n_slots: int, dev) -> None:
+        self.saved = torch.empty(n_slots, m, HID, device=dev)
+        self.aux_vf = torch.empty(m, lib.AUX_K, device=dev)
+        self.aux_rn = torch.empty(m, lib.AUX_K, device=dev)
+
+
+# ------------------------------------------------------------------------------------------------
+# fine pass of render()
+# ------------------------------------------------------------------------------------------------
+class _FinePass(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, pts, z, ray_dirs, *params):
+        vf, rn = model.vector_field_network, model.rendering_network
+        n, s_t = z.shape
+        m = n * s_t
+        dev = pts.device
+        vf_h, rn_h = len(_entries(vf)), len(_entries(rn))
+        ws = _Workspace(m, vf_h + rn_h, dev)
+        scal = model.density.raw_scalars()
+        normals, colors = lib.vf_render_fused_fwd_train(vf.geometry(), vf.packed_weights(), rn.geometry(),
+                                                        rn.packed_weights(), pts.reshape(-1, 3), ray_dirs, s_t,
+                                                        ws.saved, ws.aux_vf, ws.aux_rn)
+        dp = model._density_params()
+        _, weights, _, rgb, depth = lib.ray_density_weights(dp, normals, ray_dirs, z, scal, colors=colors,
+                                                            want_sigma=False)
+        if getattr(model, "_keep_saved", False):   # test hook: expose the saved activations
+            model._debug_saved = ws.saved
+        ctx.model, ctx.ws, ctx.dims, ctx.param_order = model, ws, (n, s_t, m, vf_h, rn_h), list(params)
+        ctx.save_for_backward(normals, colors, z, ray_dirs, scal)
+        return normals, colors, rgb, depth, weights
+
+    @staticmethod
+    def backward(ctx, d_normals, d_colors_direct, d_rgb, d_depth, d_weights):
+        model, ws = ctx.model, ctx.ws
+        n, s_t, m, vf_h, rn_h = ctx.dims
+        normals, colors, z, ray_dirs, scal = ctx.saved_tensors
+        vf, rn = model.vector_field_network, model.rendering_network
+        dev = normals.device
+
+        def cont(t, shape):
+            return None if t is None else t.reshape(shape).float().contiguous()
+
+        # (1) per-ray backward: d rgb / d depth / d weights -> d colours, d normals (density path), d scalars
+        dn = torch.zeros(m, 3, device=dev) if d_normals is None else d_normals.reshape(m, 3).float().clone()
+        dc = torch.empty(m, 3, device=dev)
+        dscal = torch.zeros(3, device=dev)
+        lib.ray_density_weights_bwd(model._density_params(), normals, ray_dirs, z, scal, colors, cont(d_rgb, (n, 3)),
+                                    cont(d_depth, (n,)), cont(d_weights, (n, s_t)), dn, dc, dscal)
+        if d_colors_direct is not None:
+            dc = dc + d_colors_direct.reshape(m, 3)
+        # (2) dX chain through the rendering net, the feature hand-off and the VF net
+        dy = torch.empty(vf_h + rn_h, m, HID, device=dev)
+        dz_rgb = torch.empty(m, 4, device=dev)
+        dz_vec = torch.empty(m, 4, device=dev)
+        lib.mlp_bwd_chain(vf.geometry(), vf.packed_weights(), _packed_bwd(vf), rn.geometry(), rn.packed_weights(),
+                          _packed_bwd(rn), ws.saved, dy, dc, colors, dn, normals, None, 3, m, dz_rgb, dz_vec)
+        # (3) weight gradients
+        g_vf = _weight_grads(vf, _vf_inputs(vf, [ws.saved[h] for h in range(vf_h)]), [dy[h] for h in range(vf_h)],
+                             ws.aux_vf, dz_vec, m)
+        g_rn = _weight_grads(rn, _rn_inputs(ws.saved[vf_h - 1], [ws.saved[vf_h + h] for h in range(rn_h)]),
+                             [dy[vf_h + h] for h in range(rn_h)], ws.aux_rn, dz_rgb, m)
+        # density scalars in density.parameters() order
+        by_name = {"beta": dscal[0], "mean": dscal[1], "scale": dscal[2]}
+        g_den = {p: by_name[name].reshape(p.shape) for name, p in model.density.named_parameters()}
+        ctx.ws = None
+        out = []
+        for p in ctx.param_order:
+            out.append(g_vf.get(p, g_rn.get(p, g_den.get(p))))
+        return (None, None, None, None, *out)
+
+
+def fine_pass_autograd(model, pts, z, ray_dirs):
+    params = list(model.vector_field_network.parameters()) + list(model.rendering_network.parameters()) + \
+        list(model.density.parameters())
+    return _FinePass.apply(model, pts, z, ray_dirs, *params)
+
+
+# ------------------------------------------------------------------------------------------------
+# standalone VF forward (supervision points: train/vector_field_nerf_train.py:191,203,215)
+# ------------------------------------------------------------------------------------------------
+class _VFForward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, points, vector_only, *params):
+        pts = points.reshape(-1, 3).float().contiguous()
+        m = pts.shape[0]
+        dev = pts.device
+        has_feat = net._feature_dims() > 0
+        vf_h = len(_entries(net))
+        ws = _Workspace(m, vf_h, dev)
+        cols = 3 if (vector_only or not has_feat) else 3 + net._feature_dims()
+        out = lib.vf_mlp_fwd_train(net.geometry(), net.packed_weights(), pts, cols, ws.saved, ws.aux_vf)
+        ctx.net, ctx.ws, ctx.dims, ctx.param_order = net, ws, (m, vf_h, cols), list(params)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        net, ws = ctx.net, ctx.ws
+        m, vf_h, cols = ctx.dims
+        (out,) = ctx.saved_tensors
+        dev = out.device
+        d_out = d_out.float().contiguous()
+        dy = torch.empty(vf_h, m, HID, device=dev)
+        dz_vec = torch.empty(m, 4, device=dev)
+        d_feats = None
+        if cols > 3:
+            d_feats = _offset_view(d_out, 3)
+        lib.mlp_bwd_chain(net.geometry(), net.packed_weights(), _packed_bwd(net), None, None, None, ws.saved, dy,
+                          None, None, d_out, out, d_feats, cols, m, None, dz_vec)
+        # vector-only forward: the feature block of the last Linear was never evaluated -> no gradient for it
+        skip = (vf_h - 1,) if (net._feature_dims() > 0 and cols == 3) else ()
+        grads = _weight_grads(net, _vf_inputs(net, [ws.saved[h] for h in range(vf_h)]), [dy[h] for h in range(vf_h)],
+                              ws.aux_vf, dz_vec, m, skip=skip)
+        ctx.ws = None
+        return (None, None, None, *[grads.get(p) for p in ctx.param_order])
+
+
+class _RawPointer:
+    """A (tensor, element offset) pair accepted by lib._ptr-style marshalling for strided column views."""
+
+    def __init__(self, base: torch.Tensor, offset: int) -> None:
+        self.base, self.offset = base, offset
+        self.is_cuda, self.dtype = base.is_cuda, base.dtype
+
+    def is_contiguous(self) -> bool:
+        return True
+
+    def data_ptr(self) -> int:
+        return self.base.data_ptr() + 4 * self.offset
+
+
+def _offset_view(t: torch.Tensor, col0: int) -> _RawPointer:
+    return _RawPointer(t, col0)
+
+
+def vf_forward_autograd(net, points, vector_only):
+    return _VFForward.apply(net, points, vector_only, *list(net.parameters()))
+
+
+def render_forward_autograd(net, points, normals, view_dirs, feats):
+    raise NotImplementedError("gradients through a stand-alone RenderingNetwork.forward are not wired yet; the "
+                              "training path differentiates the fused fine pass of render() instead")

@@ -54,10 +54,15 @@ int vfn_make_plan(int net_kind, const vfn_net_geom* g, VfnNetPlan* plan, char* e
     plan->multires = g->multires;
     plan->pe_dim = pe_dim;
 
-    uint32_t off = 0;
+    uint32_t off = 0, boff = 0;
     int nh = 0;
     auto add_hidden = [&](int ref_layer, uint32_t nkb_act, uint32_t nkb_aux, uint32_t n_tiles) {
         VfnLayerPlan& lp = plan->hidden[nh++];
+        lp.bw_off = VFN_NO_BWD;
+        if (nkb_act > 0) {  // act inputs carry gradient; aux inputs (encodings of points / dirs) never do
+            lp.bw_off = boff;
+            boff += (nkb_act / 4) * (4 * n_tiles) * 256u;
+        }
         lp.ref_layer = (uint16_t)ref_layer;
         lp.nkb_act = (uint16_t)nkb_act;
         lp.nkb_aux = (uint16_t)nkb_aux;
@@ -83,6 +88,7 @@ int vfn_make_plan(int net_kind, const vfn_net_geom* g, VfnNetPlan* plan, char* e
             if (i == 0) { nkb_act = 0; nkb_aux = cdiv(pe_dim, 8); }
             else if (i == skip) { nkb_act = cdiv(g->out_dims[i - 1], 8); nkb_aux = cdiv(pe_dim, 8); }
             else { nkb_act = VFN_HIDDEN / 8; nkb_aux = 0; }
+            if (nkb_act % 4) nkb_act += 4 - nkb_act % 4;  // act K is consumed/produced in 32-column tiles
             add_hidden(i, nkb_act, nkb_aux, cdiv(expect_out, 32));
         }
         if (g->in_dims[L - 1] != VFN_HIDDEN || g->out_dims[L - 1] != 3 + F)
@@ -117,6 +123,7 @@ int vfn_make_plan(int net_kind, const vfn_net_geom* g, VfnNetPlan* plan, char* e
     plan->head_b_off = off;
     off += 16u;
     plan->total_floats = off;
+    plan->total_bwd_floats = boff;
     return VFN_OK;
 }
 
@@ -149,6 +156,7 @@ struct PackEntry {
     int32_t act_col_off, act_valid;
     int32_t aux_col_off, aux_valid;
     int32_t is_head;
+    int32_t transposed;    // backward pack: tileT[kt][nb][lane][j] = W'[8nb+4h+j][32kt+(lane&31)]
     float scale;
 };
 
@@ -174,7 +182,12 @@ __global__ void vfn_pack_kernel(PackArgs a) {
         const uint32_t blk = local >> 8;
         int n, kk;
         uint32_t kb;
-        if (e.is_head) {
+        if (e.transposed) {
+            const uint32_t nb = blk % e.kb_total, kt = blk / e.kb_total;
+            n = (int)(8u * nb + 4u * (lane >> 5) + j);
+            kk = (int)(32u * kt + (lane & 31u));
+            kb = 0;
+        } else if (e.is_head) {
             kb = blk;
             n = (int)(lane & 15u);
             kk = (int)(16u * kb + 4u * (lane >> 4) + j);
@@ -185,7 +198,7 @@ __global__ void vfn_pack_kernel(PackArgs a) {
             kk = (int)(8u * kb + 4u * (lane >> 5) + j);
         }
         int col = -1;
-        const int act_k = (int)(e.nkb_act * (e.is_head ? 16u : 8u));
+        const int act_k = e.transposed ? 0x7fffffff : (int)(e.nkb_act * (e.is_head ? 16u : 8u));
         if (kk < act_k) {
             if (kk < e.act_valid) col = e.act_col_off + kk;
         } else {
@@ -210,15 +223,9 @@ __global__ void vfn_pack_kernel(PackArgs a) {
     a.out[idx] = val;
 }
 
-extern "C" int vfn_pack_weights(int32_t net_kind, const vfn_net_geom* geom, const vfn_layer_params* layers,
-                                float* packed, void* stream) {
-    VfnNetPlan plan;
-    char err[256] = {0};
-    int rc = vfn_make_plan(net_kind, geom, &plan, err, sizeof(err));
-    if (rc != VFN_OK) { vfn_set_error("vfn_pack_weights: %s", err); return rc; }
-    VFN_REQUIRE(layers && packed, "vfn_pack_weights: NULL argument");
-
-    PackArgs a;
+// Builds the PackArgs entry list.  bwd == false: forward tiles + biases + head; bwd == true: transposed tiles.
+static int build_pack_args(int32_t net_kind, const vfn_net_geom* geom, const vfn_layer_params* layers,
+                           const VfnNetPlan& plan, bool bwd, PackArgs& a) {
     memset(&a, 0, sizeof(a));
     const int L = geom->n_layers;
     const int pe_dim = plan.pe_dim;
@@ -240,15 +247,23 @@ extern "C" int vfn_pack_weights(int32_t net_kind, const vfn_net_geom* geom, cons
 
     for (int h = 0; h < plan.n_hidden; ++h) {
         const VfnLayerPlan& lp = plan.hidden[h];
+        if (bwd && lp.bw_off == VFN_NO_BWD) continue;
         const int i = lp.ref_layer;
         PackEntry& e = a.e[a.n_entries++];
-        rc = fill_params(e, i);
+        int rc = fill_params(e, i);
         if (rc != VFN_OK) return rc;
-        e.w_off = lp.w_off; e.b_off = lp.b_off;
-        e.kb_total = lp.nkb_act + lp.nkb_aux;
+        if (bwd) {
+            e.w_off = lp.bw_off; e.b_off = 0;
+            e.kb_total = 4u * lp.n_tiles;                  // nb blocks of 8 n's
+            e.n_w = (lp.nkb_act / 4u) * e.kb_total * 256u;
+            e.n_b = 0; e.transposed = 1;
+        } else {
+            e.w_off = lp.w_off; e.b_off = lp.b_off;
+            e.kb_total = lp.nkb_act + lp.nkb_aux;
+            e.n_w = lp.n_tiles * e.kb_total * 256u;
+            e.n_b = lp.n_tiles * 32u;
+        }
         e.nkb_act = lp.nkb_act;
-        e.n_w = lp.n_tiles * e.kb_total * 256u;
-        e.n_b = lp.n_tiles * 32u;
         e.is_head = 0;
         const bool feat = plan.feat_layer && h == plan.n_hidden - 1;
         e.row_off = feat ? 3 : 0;
@@ -265,9 +280,9 @@ extern "C" int vfn_pack_weights(int32_t net_kind, const vfn_net_geom* geom, cons
             else { e.act_col_off = 0; e.act_valid = VFN_HIDDEN; e.aux_valid = 0; }
         }
     }
-    {   // head: reference rows 0..2 of the last Linear
+    if (!bwd) {   // head: reference rows 0..2 of the last Linear
         PackEntry& e = a.e[a.n_entries++];
-        rc = fill_params(e, L - 1);
+        int rc = fill_params(e, L - 1);
         if (rc != VFN_OK) return rc;
         e.w_off = plan.head_w_off; e.b_off = plan.head_b_off;
         e.kb_total = plan.head_nkb16; e.nkb_act = plan.head_nkb16;
@@ -275,9 +290,41 @@ extern "C" int vfn_pack_weights(int32_t net_kind, const vfn_net_geom* geom, cons
         e.is_head = 1; e.row_off = 0; e.n_rows = 3;
         e.act_col_off = 0; e.act_valid = VFN_HIDDEN; e.aux_valid = 0;
     }
-    a.total = plan.total_floats;
+    a.total = bwd ? plan.total_bwd_floats : plan.total_floats;
+    return VFN_OK;
+}
+
+static int pack_common(int32_t net_kind, const vfn_net_geom* geom, const vfn_layer_params* layers, float* packed,
+                       void* stream, bool bwd, const char* what) {
+    VfnNetPlan plan;
+    char err[256] = {0};
+    int rc = vfn_make_plan(net_kind, geom, &plan, err, sizeof(err));
+    if (rc != VFN_OK) { vfn_set_error("%s: %s", what, err); return rc; }
+    VFN_REQUIRE(layers && packed, "%s: NULL argument", what);
+    PackArgs a;
+    rc = build_pack_args(net_kind, geom, layers, plan, bwd, a);
+    if (rc != VFN_OK) return rc;
     a.out = packed;
+    if (a.total == 0) return VFN_OK;
     const uint32_t threads = 256, blocks = (a.total + threads - 1) / threads;
     hipLaunchKernelGGL(vfn_pack_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, a);
-    return vfn_check_launch("vfn_pack_weights");
+    return vfn_check_launch(what);
+}
+
+extern "C" int vfn_pack_weights(int32_t net_kind, const vfn_net_geom* geom, const vfn_layer_params* layers,
+                                float* packed, void* stream) {
+    return pack_common(net_kind, geom, layers, packed, stream, false, "vfn_pack_weights");
+}
+
+extern "C" int64_t vfn_packed_bwd_size(int32_t net_kind, const vfn_net_geom* geom) {
+    VfnNetPlan plan;
+    char err[256] = {0};
+    int rc = vfn_make_plan(net_kind, geom, &plan, err, sizeof(err));
+    if (rc != VFN_OK) { vfn_set_error("vfn_packed_bwd_size: %s", err); return rc; }
+    return (int64_t)plan.total_bwd_floats;
+}
+
+extern "C" int vfn_pack_weights_bwd(int32_t net_kind, const vfn_net_geom* geom, const vfn_layer_params* layers,
+                                    float* packed_bwd, void* stream) {
+    return pack_common(net_kind, geom, layers, packed_bwd, stream, true, "vfn_pack_weights_bwd");
 }

@@ -12,6 +12,10 @@
 //   followed by bias'[32*n_tiles].
 // Head:  w[kb16][lane][j] = W'[n = lane & 15][k = 16*kb16 + 4*(lane >> 4) + j], then bias'[16].
 // W', bias' = Linear with eval-mode BatchNorm (eps 1e-5) folded in, and 1/sqrt(2) for the skip layer.
+//
+// Backward pack (dX = dY * W'), per hidden layer that has an "act" input:
+//   tileT[kt][nb][lane][j] = W'[n = 8*nb + 4*(lane >> 5) + j][k = 32*kt + (lane & 31)]
+//   kt < nkb_act/4 (output = act columns of the layer input), nb < 4*n_tiles (reduction over n).
 #pragma once
 #include <stdint.h>
 #include "../../include/vfn.h"
@@ -26,7 +30,9 @@ struct VfnLayerPlan {
     uint16_t nkb_aux;    // K blocks taken from the aux tile
     uint16_t n_tiles;    // 32-column output tiles (1..8)
     uint16_t ref_layer;  // index of the reference Linear
+    uint32_t bw_off;     // float offset of the transposed ("backward") tiles in the bwd pack; VFN_NO_BWD if none
 };
+#define VFN_NO_BWD 0xffffffffu
 
 struct VfnNetPlan {
     int32_t n_hidden;            // number of hidden (tile) layers
@@ -37,6 +43,7 @@ struct VfnNetPlan {
     uint32_t head_b_off;
     uint32_t head_nkb16;         // K/16 blocks of the head (always 16: K = 256)
     uint32_t total_floats;
+    uint32_t total_bwd_floats;   // size of the backward pack
     VfnLayerPlan hidden[VFN_MAX_LAYERS];
 };
 

@@ -274,6 +274,247 @@ __global__ __launch_bounds__(256) void vfn_density_kernel(const DensityArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// K3-bwd: gradient of (rgb, depth, weights) wrt colours, normals and the three density scalars.
+// Recomputes the forward quantities of the ray in LDS, then walks the chain backwards:
+//   w = what / (sum what + 1e-5),  what_j = (1 - exp(-e_j)) T_j,  T_j = exp(-sum_{i<j} e_i),  e_j = delta_j sigma_j,
+//   sigma_j = relu(s F(-c_j) - s F(cutoff)) (0 where masked),  c_j = windowed cosine of unit normals.
+// One wave per ray; prefix / suffix sums are wavefront scans; scalar gradients leave by one atomicAdd per ray.
+// ------------------------------------------------------------------------------------------------
+constexpr int MAX_SAMPLES_BWD = 256;
+
+struct DensityBwdArgs {
+    vfn_density_params p;
+    const float* normals;
+    const float* ray_dirs;
+    const float* z_vals;
+    const float* scalars;
+    const float* colors;    // may be NULL
+    const float* d_rgb;     // [N,3] may be NULL
+    const float* d_depth;   // [N]   may be NULL
+    const float* d_weights; // [N,S] may be NULL
+    float* d_normals;       // [N,S,3] accumulated into (+=)
+    float* d_colors;        // [N,S,3] written (may be NULL)
+    float* d_scalars;       // [3] atomically accumulated: raw beta, mean, scale
+};
+
+__device__ __forceinline__ double wave_excl_scan_d(double v, int lane) {
+    double incl = v;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const double up = __shfl_up(incl, o, WAVE);
+        if (lane >= o) incl += up;
+    }
+    return incl - v;
+}
+
+__global__ __launch_bounds__(256) void vfn_density_bwd_kernel(const DensityBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float bsm[];
+    const int S = a.p.n_samples;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (ray >= a.p.n_rays) return;
+    float* su = bsm + (size_t)wv * S * 12;  // unit normals [S][3]
+    float* sinv = su + (size_t)S * 3;       // 1 / max(|n|, eps)
+    float* sz = sinv + S;
+    float* sc = sz + S;                     // windowed cosine
+    float* se = sc + S;                     // free energy
+    float* sT = se + S;                     // transmittance
+    float* sw = sT + S;                     // un-normalised weight
+    float* sg = sw + S;                     // dL/d what, later dL/d c (gc)
+    float* sact = sg + S;                   // 1 where sigma is on its differentiable branch
+    float* sdl = sact + S;                  // delta
+
+    const float* nrm = a.normals + (size_t)ray * S * 3;
+    for (int j = lane; j < S; j += WAVE) {
+        const float x = nrm[j * 3 + 0], y = nrm[j * 3 + 1], z = nrm[j * 3 + 2];
+        const float nn = fmaxf(sqrtf((x * x + y * y) + z * z), 1e-8f);
+        su[j * 3 + 0] = x / nn; su[j * 3 + 1] = y / nn; su[j * 3 + 2] = z / nn;
+        sinv[j] = 1.0f / nn;
+        sz[j] = a.z_vals[(size_t)ray * S + j];
+    }
+    float d[3] = {a.ray_dirs[(size_t)ray * 3 + 0], a.ray_dirs[(size_t)ray * 3 + 1], a.ray_dirs[(size_t)ray * 3 + 2]};
+    {
+        const float nd = fmaxf(sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]), 1e-8f);
+        d[0] /= nd; d[1] /= nd; d[2] /= nd;
+    }
+    const float braw = a.scalars[0], mraw = a.scalars[1], sraw = a.scalars[2];
+    const float beta = fminf(fmaxf(braw, a.p.beta_min), a.p.beta_max);
+    const float mean = fminf(fmaxf(mraw, a.p.mean_min), a.p.mean_max);
+    const float scale = fmaxf(fabsf(sraw), a.p.scale_min);
+    const float cdf_cut = laplace_cdf(a.p.cutoff, beta, scale, mean);
+    __builtin_amdgcn_wave_barrier();
+
+    const int W = a.p.n_window;
+    const int start = (int)((W + 1) / 2.0 + 1);
+    const float wgt = 1.0f / (float)W;
+    float wnorm = 0.f;
+    for (int i = 0; i < W; ++i) wnorm += fabsf(wgt);
+    const float coef = wgt / wnorm;
+    const int L = S - 1;
+    const int lo = start, hi = L - start;
+
+    for (int j = lane; j < S; j += WAVE) {
+        float sgm = 0.f, c = 1.f, act = 0.f;
+        if (j < L) {
+            const float* uj = su + j * 3;
+            c = dot3(uj, su + (j + 1) * 3);
+            if (j >= lo && j < hi) {
+                c = c * wgt / wnorm;
+                for (int i = 1; i < start - 1; ++i) {
+                    const float f = dot3(uj, su + (j + 1 + i) * 3);
+                    const float b = dot3(uj, su + (j - i) * 3);
+                    c = (c + f * wgt / wnorm) + b * wgt / wnorm;
+                }
+            }
+            const float c_ray = dot3(uj, d);
+            const float raw = laplace_cdf(-c, beta, scale, mean) - cdf_cut;
+            const bool masked = (c_ray < a.p.dir_to_normal_th && c < 0.f);
+            if (raw > 0.f && !masked) { sgm = raw; act = 1.f; }
+        }
+        sc[j] = c;
+        sact[j] = act;
+        const float delta = (j < L) ? (sz[j + 1] - sz[j]) : 1e10f;
+        sdl[j] = delta;
+        se[j] = delta * sgm;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // forward scan: transmittance, weights
+    const int C = (S + WAVE - 1) / WAVE;
+    const int j0 = lane * C;
+    double tot = 0.0;
+    for (int i = 0; i < C; ++i) { const int j = j0 + i; if (j < S) tot += (double)se[j]; }
+    double run = wave_excl_scan_d(tot, lane);
+    float wsum_l = 0.f;
+    for (int i = 0; i < C; ++i) {
+        const int j = j0 + i;
+        if (j < S) {
+            const float e = se[j];
+            const float T = expf(-(float)run);
+            const float w = (1.0f - expf(-e)) * T;
+            run += (double)e;
+            sT[j] = T; sw[j] = w;
+            wsum_l += w;
+        }
+    }
+    const float wsum = wave_sum(wsum_l);
+    const float den = a.p.normalize ? (wsum + 1e-5f) : 1.0f;
+    __builtin_amdgcn_wave_barrier();
+
+    // upstream gradient of the weights
+    float drgb[3] = {0.f, 0.f, 0.f}, ddep = 0.f;
+    if (a.d_rgb) { drgb[0] = a.d_rgb[(size_t)ray * 3 + 0]; drgb[1] = a.d_rgb[(size_t)ray * 3 + 1]; drgb[2] = a.d_rgb[(size_t)ray * 3 + 2]; }
+    if (a.d_depth) ddep = a.d_depth[ray];
+    const float* col = a.colors ? a.colors + (size_t)ray * S * 3 : nullptr;
+    float dot_l = 0.f;
+    for (int j = lane; j < S; j += WAVE) {
+        const float w = sw[j] / den;
+        float g = ddep * sz[j];
+        if (col) g += (drgb[0] * col[j * 3 + 0] + drgb[1] * col[j * 3 + 1]) + drgb[2] * col[j * 3 + 2];
+        if (a.d_weights) g += a.d_weights[(size_t)ray * S + j];
+        if (a.d_colors) {
+            float* dc = a.d_colors + ((size_t)ray * S + j) * 3;
+            dc[0] = w * drgb[0]; dc[1] = w * drgb[1]; dc[2] = w * drgb[2];
+        }
+        sg[j] = g;
+        dot_l += g * w;
+    }
+    const float gdot = wave_sum(dot_l);
+    __builtin_amdgcn_wave_barrier();
+    // dL/d what_j ; q_j = ghat_j * what_j ; suffix (exclusive) sums of q
+    double qtot = 0.0;
+    for (int i = 0; i < C; ++i) {
+        const int j = j0 + i;
+        if (j < S) {
+            const float gh = a.p.normalize ? (sg[j] - gdot) / den : sg[j];
+            sg[j] = gh;
+            qtot += (double)(gh * sw[j]);
+        }
+    }
+    const double qpre = wave_excl_scan_d(qtot, lane);
+    double qall = qtot;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qall += __shfl_xor(qall, o, WAVE);
+    // suffix_excl(j) = qall - prefix_incl(j)
+    double qrun = qpre;
+    float gb = 0.f, gm = 0.f, gs = 0.f;  // partial scalar gradients (effective beta, mean, scale)
+    const float Ec = expf(-fabsf(a.p.cutoff - mean) / beta);
+    const float ac = a.p.cutoff - mean;
+    const float Fcut = cdf_cut / scale;
+    for (int i = 0; i < C; ++i) {
+        const int j = j0 + i;
+        if (j < S) {
+            const float gh = sg[j];
+            qrun += (double)(gh * sw[j]);
+            const float suffix = (float)(qall - qrun);
+            float gc = 0.f;
+            if (j < L && sact[j] != 0.f) {
+                const float e = se[j];
+                const float de = gh * sT[j] * expf(-e) - suffix;
+                const float dsig = sdl[j] * de;
+                const float x = -sc[j];
+                const float ax = x - mean;
+                const float E = expf(-fabsf(ax) / beta);
+                const float sgx = (ax > 0.f) ? 1.f : ((ax < 0.f) ? -1.f : 0.f);
+                const float Fx = 0.5f + 0.5f * sgx * (1.0f - E);
+                gc = -dsig * scale * 0.5f * E / beta;                                     // d sigma / d c = -d sigma / d x
+                gs += dsig * (Fx - Fcut);
+                gm += dsig * scale * (-0.5f * E / beta + 0.5f * Ec / beta);
+                gb += dsig * scale * (-0.5f * ax * E + 0.5f * ac * Ec) / (beta * beta);
+            }
+            sg[j] = gc;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    gb = wave_sum(gb); gm = wave_sum(gm); gs = wave_sum(gs);
+    if (lane == 0 && a.d_scalars) {
+        if (braw >= a.p.beta_min && braw <= a.p.beta_max) atomicAdd(a.d_scalars + 0, gb);
+        if (mraw >= a.p.mean_min && mraw <= a.p.mean_max) atomicAdd(a.d_scalars + 1, gm);
+        if (fabsf(sraw) >= a.p.scale_min) atomicAdd(a.d_scalars + 2, (sraw >= 0.f) ? gs : -gs);
+    }
+    // gather dL/d u_j from every cosine it takes part in, then project through the normalisation
+    for (int j = lane; j < S; j += WAVE) {
+        float du[3] = {0.f, 0.f, 0.f};
+        // as centre
+        if (j < L) {
+            const float gcj = sg[j];
+            if (gcj != 0.f) {
+                if (j >= lo && j < hi) {
+                    for (int t = 1; t <= start - 1; ++t) { const float* un = su + (j + t) * 3; du[0] += coef * gcj * un[0]; du[1] += coef * gcj * un[1]; du[2] += coef * gcj * un[2]; }
+                    for (int t = 1; t <= start - 2; ++t) { const float* un = su + (j - t) * 3; du[0] += coef * gcj * un[0]; du[1] += coef * gcj * un[1]; du[2] += coef * gcj * un[2]; }
+                } else {
+                    const float* un = su + (j + 1) * 3;
+                    du[0] += gcj * un[0]; du[1] += gcj * un[1]; du[2] += gcj * un[2];
+                }
+            }
+        }
+        // as neighbour of centre i
+        for (int i = max(0, j - (start - 1)); i <= min(L - 1, j + (start - 2)); ++i) {
+            if (i == j) continue;
+            const float gci = sg[i];
+            if (gci == 0.f) continue;
+            const bool interior = (i >= lo && i < hi);
+            const int off = j - i;
+            float wgt_ij = 0.f;
+            if (interior) { if ((off >= 1 && off <= start - 1) || (off <= -1 && off >= -(start - 2))) wgt_ij = coef; }
+            else if (off == 1) wgt_ij = 1.f;
+            if (wgt_ij != 0.f) { const float* ui = su + i * 3; du[0] += wgt_ij * gci * ui[0]; du[1] += wgt_ij * gci * ui[1]; du[2] += wgt_ij * gci * ui[2]; }
+        }
+        const float* uj = su + j * 3;
+        const float inv = sinv[j];
+        float dn[3];
+        if (inv >= 1e8f * 0.999f) {  // |n| clamped to eps: u = n / eps
+            dn[0] = du[0] * inv; dn[1] = du[1] * inv; dn[2] = du[2] * inv;
+        } else {
+            const float pr = (du[0] * uj[0] + du[1] * uj[1]) + du[2] * uj[2];
+            dn[0] = (du[0] - pr * uj[0]) * inv; dn[1] = (du[1] - pr * uj[1]) * inv; dn[2] = (du[2] - pr * uj[2]) * inv;
+        }
+        float* o = a.d_normals + ((size_t)ray * S + j) * 3;
+        o[0] += dn[0]; o[1] += dn[1]; o[2] += dn[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K3b: range fine sampler, one wave per ray   (models/samplers/ray_sampler.py:264-302, :77-78)
 // ------------------------------------------------------------------------------------------------
 struct FineArgs {
@@ -431,4 +672,20 @@ extern "C" int vfn_fill_uniform(float* out, int64_t n, uint64_t seed, uint64_t o
     hipLaunchKernelGGL(vfn_uniform_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, (long long)n,
                        (unsigned long long)seed, (unsigned long long)offset);
     return vfn_check_launch("vfn_fill_uniform");
+}
+
+extern "C" int vfn_ray_density_weights_bwd(const vfn_density_params* p, const float* normals, const float* ray_dirs,
+                                           const float* z_vals, const float* density_scalars, const float* colors,
+                                           const float* d_rgb, const float* d_depth, const float* d_weights,
+                                           float* d_normals, float* d_colors, float* d_scalars, void* stream) {
+    VFN_REQUIRE(p && normals && ray_dirs && z_vals && density_scalars && d_normals, "vfn_ray_density_weights_bwd: NULL argument");
+    VFN_REQUIRE(p->n_samples >= 2 && p->n_samples <= MAX_SAMPLES_BWD,
+                "vfn_ray_density_weights_bwd: n_samples=%d outside [2,%d]", p->n_samples, MAX_SAMPLES_BWD);
+    VFN_REQUIRE(!(d_rgb && !colors), "vfn_ray_density_weights_bwd: d_rgb given without colors");
+    if (p->n_rays <= 0) return VFN_OK;
+    DensityBwdArgs a{*p, normals, ray_dirs, z_vals, density_scalars, colors, d_rgb, d_depth, d_weights, d_normals, d_colors, d_scalars};
+    const unsigned blocks = (unsigned)((p->n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
+    const size_t shmem = (size_t)RAYS_PER_BLOCK * p->n_samples * 12 * sizeof(float);
+    hipLaunchKernelGGL(vfn_density_bwd_kernel, dim3(blocks), dim3(256), shmem, (hipStream_t)stream, a);
+    return vfn_check_launch("vfn_ray_density_weights_bwd");
 }

@@ -22,7 +22,9 @@ NET_VF, NET_RENDER = 0, 1
 EXPORTS = (
     "vfn_last_error", "vfn_abi_version", "vfn_packed_size", "vfn_pack_weights", "vfn_raygen_uniform",
     "vfn_vf_mlp_fwd", "vfn_render_mlp_fwd", "vfn_vf_render_fused_fwd", "vfn_ray_density_weights",
-    "vfn_range_fine_sample", "vfn_fill_uniform",
+    "vfn_range_fine_sample", "vfn_fill_uniform", "vfn_packed_bwd_size", "vfn_pack_weights_bwd",
+    "vfn_vf_mlp_fwd_train", "vfn_vf_render_fused_fwd_train", "vfn_mlp_bwd_chain", "vfn_weight_grad_partials",
+    "vfn_ray_density_weights_bwd",
 )
 
 
@@ -74,6 +76,8 @@ def load() -> C.CDLL:
     lib.vfn_last_error.restype = C.c_char_p
     lib.vfn_packed_size.restype = C.c_int64
     lib.vfn_packed_size.argtypes = [C.c_int32, C.POINTER(NetGeom)]
+    lib.vfn_packed_bwd_size.restype = C.c_int64
+    lib.vfn_packed_bwd_size.argtypes = [C.c_int32, C.POINTER(NetGeom)]
     for name in EXPORTS:
         getattr(lib, name)  # raises AttributeError if the ABI lost a symbol
     if lib.vfn_abi_version() != 1:
@@ -124,15 +128,32 @@ def packed_size(kind: int, geom: NetGeom) -> int:
     return int(n)
 
 
-def pack_weights(kind: int, geom: NetGeom, layers: Sequence[dict], packed: torch.Tensor) -> None:
-    """layers[i] = dict(weight=, bias=, bn_weight=, bn_bias=, bn_mean=, bn_var=) of live tensors."""
+def _layer_array(geom: NetGeom, layers: Sequence[dict]):
     arr = (LayerParams * geom.n_layers)()
     for i, lp in enumerate(layers):
         arr[i].weight = _ptr(lp["weight"], f"layer{i}.weight")
         arr[i].bias = _ptr(lp["bias"], f"layer{i}.bias")
         for k in ("bn_weight", "bn_bias", "bn_mean", "bn_var"):
             setattr(arr[i], k, _ptr(lp.get(k), f"layer{i}.{k}"))
-    _check(load().vfn_pack_weights(kind, C.byref(geom), arr, _ptr(packed, "packed"), _stream()), "vfn_pack_weights")
+    return arr
+
+
+def pack_weights(kind: int, geom: NetGeom, layers: Sequence[dict], packed: torch.Tensor) -> None:
+    """layers[i] = dict(weight=, bias=, bn_weight=, bn_bias=, bn_mean=, bn_var=) of live tensors."""
+    _check(load().vfn_pack_weights(kind, C.byref(geom), _layer_array(geom, layers), _ptr(packed, "packed"), _stream()),
+           "vfn_pack_weights")
+
+
+def packed_bwd_size(kind: int, geom: NetGeom) -> int:
+    n = load().vfn_packed_bwd_size(kind, C.byref(geom))
+    if n < 0:
+        raise VfnError(f"unsupported network geometry: {load().vfn_last_error().decode()}")
+    return int(n)
+
+
+def pack_weights_bwd(kind: int, geom: NetGeom, layers: Sequence[dict], packed_bwd: torch.Tensor) -> None:
+    _check(load().vfn_pack_weights_bwd(kind, C.byref(geom), _layer_array(geom, layers), _ptr(packed_bwd, "packed_bwd"),
+                                       _stream()), "vfn_pack_weights_bwd")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -226,3 +247,64 @@ def fill_uniform(out: torch.Tensor, seed: int, offset: int) -> torch.Tensor:
     _check(load().vfn_fill_uniform(_ptr(out, "out"), C.c_int64(out.numel()), C.c_uint64(seed & (2 ** 64 - 1)),
                                    C.c_uint64(offset & (2 ** 64 - 1)), _stream()), "vfn_fill_uniform")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# training path
+# ------------------------------------------------------------------------------------------------
+AUX_K = 40
+
+
+def vf_mlp_fwd_train(geom: NetGeom, packed, points, out_cols: int, saved, aux_vf):
+    m = points.shape[0]
+    out = torch.empty(m, out_cols, device=points.device)
+    _check(load().vfn_vf_mlp_fwd_train(C.byref(geom), _ptr(packed, "packed"), _ptr(points, "points"), C.c_int64(m),
+                                       C.c_int32(out_cols), _ptr(out, "out"), _ptr(saved, "saved"),
+                                       _ptr(aux_vf, "aux_vf"), _stream()), "vfn_vf_mlp_fwd_train")
+    return out
+
+
+def vf_render_fused_fwd_train(vf_geom, vf_packed, rn_geom, rn_packed, points, ray_dirs, samples_per_ray, saved, aux_vf,
+                              aux_rn):
+    m = points.shape[0]
+    dev = points.device
+    normals = torch.empty(m, 3, device=dev)
+    colors = torch.empty(m, 3, device=dev)
+    _check(load().vfn_vf_render_fused_fwd_train(C.byref(vf_geom), _ptr(vf_packed, "vf_packed"), C.byref(rn_geom),
+                                                _ptr(rn_packed, "rn_packed"), _ptr(points, "points"),
+                                                _ptr(ray_dirs, "ray_dirs"), C.c_int64(m), C.c_int32(samples_per_ray),
+                                                _ptr(normals, "normals"), _ptr(colors, "colors"), _ptr(saved, "saved"),
+                                                _ptr(aux_vf, "aux_vf"), _ptr(aux_rn, "aux_rn"), _stream()),
+           "vfn_vf_render_fused_fwd_train")
+    return normals, colors
+
+
+def mlp_bwd_chain(vf_geom, vf_packed, vf_packed_bwd, rn_geom, rn_packed, rn_packed_bwd, saved, dy, d_colors, colors,
+                  d_vec, vec, d_feats, vec_stride: int, n_points: int, dz_rgb, dz_vec):
+    rn = C.byref(rn_geom) if rn_geom is not None else None
+    _check(load().vfn_mlp_bwd_chain(C.byref(vf_geom), _ptr(vf_packed, "vf_packed"), _ptr(vf_packed_bwd, "vf_packed_bwd"),
+                                    rn, _ptr(rn_packed, "rn_packed"), _ptr(rn_packed_bwd, "rn_packed_bwd"),
+                                    _ptr(saved, "saved"), _ptr(dy, "dy"), _ptr(d_colors, "d_colors"),
+                                    _ptr(colors, "colors"), _ptr(d_vec, "d_vec"), _ptr(vec, "vec"),
+                                    _ptr(d_feats, "d_feats"), C.c_int32(vec_stride), C.c_int64(n_points),
+                                    _ptr(dz_rgb, "dz_rgb"), _ptr(dz_vec, "dz_vec"), _stream()), "vfn_mlp_bwd_chain")
+
+
+def weight_grad_partials(shape: int, dy, ld_dy: int, n_valid: int, x, ld_x: int, k_valid: int, n_points: int,
+                         groups: int, dw_part, db_part=None):
+    _check(load().vfn_weight_grad_partials(C.c_int32(shape), _ptr(dy, "dy"), C.c_int32(ld_dy), C.c_int32(n_valid),
+                                           _ptr(x, "x"), C.c_int32(ld_x), C.c_int32(k_valid), C.c_int64(n_points),
+                                           C.c_int32(groups), _ptr(dw_part, "dw_part"), _ptr(db_part, "db_part"),
+                                           _stream()), "vfn_weight_grad_partials")
+
+
+def ray_density_weights_bwd(dp: DensityParams, normals, ray_dirs, z_vals, scalars, colors, d_rgb, d_depth, d_weights,
+                            d_normals, d_colors, d_scalars):
+    n, s = z_vals.shape
+    dp.n_rays, dp.n_samples = n, s
+    _check(load().vfn_ray_density_weights_bwd(C.byref(dp), _ptr(normals, "normals"), _ptr(ray_dirs, "ray_dirs"),
+                                              _ptr(z_vals, "z_vals"), _ptr(scalars, "scalars"), _ptr(colors, "colors"),
+                                              _ptr(d_rgb, "d_rgb"), _ptr(d_depth, "d_depth"),
+                                              _ptr(d_weights, "d_weights"), _ptr(d_normals, "d_normals"),
+                                              _ptr(d_colors, "d_colors"), _ptr(d_scalars, "d_scalars"), _stream()),
+           "vfn_ray_density_weights_bwd")

@@ -68,7 +68,7 @@ class VectorFieldNerf:
                                              config.anneal_end - config.anneal_start,
                                              config.cos_sim_weights_anneal == "soft")
         sc = config.scheduler_config
-        self.optimizer = torch.optim.Adam(self.parameters(), lr=sc.lr, weight_decay=sc.weight_decay)
+        self.optimizer = self._adam(sc.lr, sc.weight_decay)
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(
             self.optimizer, sc.lr_decay_factor ** (1. / sc.lr_decay_steps))
         self.to(config.cuda_config.device)
@@ -121,10 +121,17 @@ class VectorFieldNerf:
         for m in self._modules():
             m.eval()
 
+    def _adam(self, lr: float, weight_decay: float = 0.0) -> torch.optim.Adam:
+        """Adam over ``parameters()`` — duplicates included, as the reference builds it (vector_field_nerf.py:63).
+        ``foreach=False``: the reference's double update of the aliased VF parameters (Q4) is a property of the
+        sequential per-parameter loop of the PyTorch it was written for; the multi-tensor implementation that newer
+        PyTorch picks on GPUs updates duplicated tensors concurrently (racy).  The sequential form keeps Q4 exact."""
+        return torch.optim.Adam(self.parameters(), lr=lr, weight_decay=weight_decay, foreach=False)
+
     def _new_schedule(self, num_steps: int) -> None:
         sc = self.config.scheduler_config
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, sc.lr_decay_factor ** (1. / num_steps))
-        self.optimizer = torch.optim.Adam(self.parameters(), lr=sc.lr)
+        self.optimizer = self._adam(sc.lr)
 
     def new_scheduler(self, num_steps: int) -> None:
         self._new_schedule(num_steps)
