@@ -82,6 +82,63 @@ def cpu_baseline(model, uv, pose, K, s_c, n_f, sample_rays=1024, budget_s=12.0):
                       f"{threads} threads, {el:.1f} s"}
 
 
+def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync):
+    """One step = what the reference trainer does per batch, with synthetic targets (config 3 of BASELINE.json)."""
+    from vf_nerf_amd import distributed as vdist
+    s_t = args.coarse + args.fine
+    g = torch.Generator().manual_seed(7 + rank)
+    rgb_gt = torch.rand(args.rays, 3, generator=g).to(dev)
+    depth_gt = (0.2 + 0.6 * torch.rand(args.rays, 1, generator=g)).to(dev)
+    n_sup = (args.rays * s_t) // 10
+    bucket = vdist.GradientBucket(model) if world > 1 else None
+    clip = model.config.scheduler_config.clip_norm
+
+    def step():
+        out = model.render(pose, uv, K, epoch=0)
+        sup = torch.rand(2 * n_sup, 3, device=dev) * 2 - 1            # border + centre supervision points
+        sup_n = model.vector_field_network(sup)[:, :3]
+        normals = out.coarse_normals.reshape(-1, 3)
+        loss = 2.0 * (out.coarse_rgb_values - rgb_gt).abs().mean() + \
+            0.5 * torch.clamp((out.coarse_depth_map - depth_gt).abs(), max=0.5).mean() + \
+            0.1 * ((normals.norm(dim=-1) - 1.0) ** 2).mean() + 1.0 * ((sup_n - 0.5) ** 2).mean()
+        if bucket is not None:
+            bucket.zero()
+        else:
+            model.optimizer.zero_grad()
+        loss.backward()
+        if bucket is not None:
+            bucket.all_reduce_mean()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), clip, foreach=False)
+        model.optimizer.step()
+        model.scheduler.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "training rays/sec (4096-ray batch, 128 samples/ray, fwd+bwd+clip+Adam)",
+                          "value": round(args.rays * args.steps * world / elapsed, 1), "unit": "rays/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "final_loss": round(float(loss), 5),
+                          "config": {"workload": f"train step: render({args.rays} rays x {s_t}) + 2x{n_sup} supervision "
+                                                 f"points through the VF net + L1/depth/unit-norm/supervision loss + "
+                                                 f"backward + clip_grad_norm_ + Adam (sequential)"}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +148,9 @@ def main() -> None:
     ap.add_argument("--coarse", type=int, default=64)
     ap.add_argument("--fine", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train", action="store_true",
+                    help="time a training step instead (render with autograd + 2 supervision VF forwards + loss + "
+                         "backward + clip + Adam, train/vector_field_nerf_train.py:177-260); not the headline metric")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +178,10 @@ def main() -> None:
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.train:
+        train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync)
+        return
 
     with torch.no_grad():
         for _ in range(args.warmup):

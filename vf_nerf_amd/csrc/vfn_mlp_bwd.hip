@@ -46,70 +46,92 @@ struct BwdArgs {
     int fused;              // 1: rendering net + VF net; 0: VF net only
 };
 
-__device__ __forceinline__ float head_weight(const float* __restrict__ wbase, const VfnNetPlan& np, int n, int col) {
+__device__ __forceinline__ float head_weight(const float* __restrict__ wbase, uint32_t head_w_off, int n, int col) {
     // forward head pack: w[kb16][lane = 16*q + n][j], k = 16*kb16 + 4*q + j
-    return wbase[np.head_w_off + ((((col >> 4) * 64) + (((col & 15) >> 2) * 16) + n) << 2) + (col & 3)];
+    return wbase[head_w_off + ((((col >> 4) * 64) + (((col & 15) >> 2) * 16) + n) << 2) + (col & 3)];
 }
 
 // One backward step for this wave's output tiles:
 //   v[row][col] = (DO_MMA ? sum_n tile[row][n] * W'[n][col] : 0) + (head ? sum_{c<3} s_dz[row][c] * Whead[c][col] : 0)
 //   dy = v * f'(saved[mask_slot][row][col]);  dY[mask_slot] <- dy;  tile <- dy
 template <int NT>
-__device__ __forceinline__ void bwd_step_t(bool do_mma, const VfnLayerPlan* lp, const float* __restrict__ wb,
-                                           const VfnNetPlan* head_np, const float* __restrict__ head_w,
+__device__ __forceinline__ void bwd_step_t(bool do_mma, int n_red_tiles, uint32_t bw_off, const float* __restrict__ wb,
+                                           bool head_np, uint32_t head_w_off, const float* __restrict__ head_w,
                                            const float* s_dz, float* s_tile, const float* __restrict__ saved_slot,
                                            float* __restrict__ dy_slot, int mask_kind, long long row0, long long n_rows,
                                            int tile0, int lane) {
     f32x16 acc[2][2];
     acc[0][0] = splat16(0.f); acc[0][1] = splat16(0.f); acc[1][0] = splat16(0.f); acc[1][1] = splat16(0.f);
     if (do_mma) {
-        const int nb = 4 * (int)lp->n_tiles;
-        const f32x4* w0 = reinterpret_cast<const f32x4*>(wb + lp->bw_off) + (size_t)tile0 * nb * 64;
+        const int nb = 4 * n_red_tiles;
+        const f32x4* w0 = reinterpret_cast<const f32x4*>(wb + bw_off) + (size_t)tile0 * nb * 64;
         const f32x4* w1 = w0 + (size_t)nb * 64;
         mma_segment<NT, true>(acc, s_tile, nb, w0, w1, lane);
     }
-    const int c = lane & 31, h = lane >> 5;
+    int c = lane & 31, h = lane >> 5;
+    // make the lane coordinates opaque here: otherwise hipcc hoists the ~190 lane-constant LDS / global offsets of
+    // this epilogue out of the layer loop and spills them around every MFMA phase
+    asm volatile("" : "+v"(c), "+v"(h));
     float hw[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     if (head_np) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) hw[nt][ch] = head_weight(head_w, *head_np, ch, 32 * (tile0 + nt) + c);
+            for (int ch = 0; ch < 3; ++ch) hw[nt][ch] = head_weight(head_w, head_w_off, ch, 32 * (tile0 + nt) + c);
     }
+    // the saved activations of this tile through a bounds-checked buffer descriptor: rows past the end of the
+    // batch read as 0 without branches (a guarded plain load makes hipcc serialise every element)
+    const int rows_in = (int)min((long long)TM, n_rows - row0);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(saved_slot + (size_t)row0 * ACT_LD), 0, rows_in * ACT_LD * 4, 0x00020000);
+    float* dy_tile = dy_slot + (size_t)row0 * ACT_LD;
     __syncthreads();  // every wave has finished reading the tile
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt) {
+        float xs[NT][16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                xs[nt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rs, (row * ACT_LD + 32 * (tile0 + nt) + c) * 4, 0, 0));
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
             float dz0 = 0.f, dz1 = 0.f, dz2 = 0.f;
             if (head_np) { dz0 = s_dz[row * 4 + 0]; dz1 = s_dz[row * 4 + 1]; dz2 = s_dz[row * 4 + 2]; }
-            const bool in = row0 + row < n_rows;
+            const bool in = row < rows_in;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int col = 32 * (tile0 + nt) + c;
                 float v = acc[mt][nt][r];
                 if (head_np) v += dz0 * hw[nt][0] + dz1 * hw[nt][1] + dz2 * hw[nt][2];
-                const size_t g = (size_t)(row0 + row) * ACT_LD + col;
-                const float x = in ? saved_slot[g] : 0.f;
+                const float x = xs[nt][r];
                 const float dyv = (mask_kind == MASK_RELU) ? (x > 0.f ? v : 0.f) : v * (1.0f - x * x);
-                if (in) dy_slot[g] = dyv;
+                if (in) dy_tile[row * ACT_LD + col] = dyv;
                 s_tile[act_idx(row, col)] = in ? dyv : 0.f;
             }
         }
+    }
     __syncthreads();
 }
 
-__device__ __forceinline__ void bwd_step(bool do_mma, const VfnLayerPlan* lp, const float* wb, const VfnNetPlan* head_np,
-                                         const float* head_w, const float* s_dz, float* s_tile, const float* saved_slot,
-                                         float* dy_slot, int mask_kind, long long row0, long long n_rows, int n_out_tiles,
-                                         int wave, int lane) {
+// lp (by value: taking addresses of kernel-argument members would force a private-memory copy of the plans)
+// supplies the reduction width (n_tiles) and the transposed tiles; has_head adds the rank-3 head update.
+__device__ __forceinline__ void bwd_step(bool do_mma, const VfnLayerPlan lp, const float* wb, bool has_head,
+                                         uint32_t head_w_off, const float* head_w, const float* s_dz, float* s_tile,
+                                         const float* saved_slot, float* dy_slot, int mask_kind, long long row0,
+                                         long long n_rows, int n_out_tiles, int wave, int lane) {
     const int tile0 = 2 * wave;
     const int nt = min(2, max(0, n_out_tiles - tile0));  // wave-uniform
     if (nt == 2)
-        bwd_step_t<2>(do_mma, lp, wb, head_np, head_w, s_dz, s_tile, saved_slot, dy_slot, mask_kind, row0, n_rows, tile0, lane);
+        bwd_step_t<2>(do_mma, lp.n_tiles, lp.bw_off, wb, has_head, head_w_off, head_w, s_dz, s_tile, saved_slot, dy_slot,
+                      mask_kind, row0, n_rows, tile0, lane);
     else if (nt == 1)
-        bwd_step_t<1>(do_mma, lp, wb, head_np, head_w, s_dz, s_tile, saved_slot, dy_slot, mask_kind, row0, n_rows, tile0, lane);
+        bwd_step_t<1>(do_mma, lp.n_tiles, lp.bw_off, wb, has_head, head_w_off, head_w, s_dz, s_tile, saved_slot, dy_slot,
+                      mask_kind, row0, n_rows, tile0, lane);
     else { __syncthreads(); __syncthreads(); }
 }
 
@@ -145,14 +167,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void vfn_mlp_bwd_kernel(const BwdArgs 
         }
         __syncthreads();
         // (b) gradient wrt the last hidden output of the rendering net = rank-3 update, ReLU-masked
-        bwd_step(false, nullptr, nullptr, &a.rn, a.rn_w, s_dz, s_tile, a.saved + (size_t)(vfH + rnH - 1) * slot,
+        bwd_step(false, a.rn.hidden[0], nullptr, true, a.rn.head_w_off, a.rn_w, s_dz, s_tile, a.saved + (size_t)(vfH + rnH - 1) * slot,
                  a.dy + (size_t)(vfH + rnH - 1) * slot, MASK_RELU, row0, n_rows, VFN_HIDDEN / 32, wave, lane);
         // (c) hidden layers rnH-1 .. 1
         for (int hh = rnH - 1; hh >= 1; --hh)
-            bwd_step(true, &a.rn.hidden[hh], a.rn_wb, nullptr, nullptr, s_dz, s_tile, a.saved + (size_t)(vfH + hh - 1) * slot,
+            bwd_step(true, a.rn.hidden[hh], a.rn_wb, false, 0u, nullptr, s_dz, s_tile, a.saved + (size_t)(vfH + hh - 1) * slot,
                      a.dy + (size_t)(vfH + hh - 1) * slot, MASK_RELU, row0, n_rows, a.rn.hidden[hh].nkb_act / 4, wave, lane);
         // (d) layer 0: gradient wrt the features, through tanh -> feature slot of the VF net
-        bwd_step(true, &a.rn.hidden[0], a.rn_wb, nullptr, nullptr, s_dz, s_tile, a.saved + (size_t)(vfH - 1) * slot,
+        bwd_step(true, a.rn.hidden[0], a.rn_wb, false, 0u, nullptr, s_dz, s_tile, a.saved + (size_t)(vfH - 1) * slot,
                  a.dy + (size_t)(vfH - 1) * slot, MASK_TANH, row0, n_rows, a.rn.hidden[0].nkb_act / 4, wave, lane);
         have_feat_grad = true;
     } else if (a.d_feats && a.vf.feat_layer) {
@@ -190,12 +212,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void vfn_mlp_bwd_kernel(const BwdArgs 
     }
     __syncthreads();
     // (e) last Linear of the VF net: feature block (MFMA) + vector head (rank 3) -> last plain hidden output
-    bwd_step(have_feat_grad, &a.vf.hidden[vfH - 1], a.vf_wb, &a.vf, a.vf_w, s_dz, s_tile,
+    bwd_step(have_feat_grad, a.vf.hidden[vfH - 1], a.vf_wb, true, a.vf.head_w_off, a.vf_w, s_dz, s_tile,
              a.saved + (size_t)(n_plain - 1) * slot, a.dy + (size_t)(n_plain - 1) * slot, MASK_RELU, row0, n_rows,
              VFN_HIDDEN / 32, wave, lane);
     // (f) plain hidden layers n_plain-1 .. 1 (layer 0 consumes only the encoding: no dX)
     for (int hh = n_plain - 1; hh >= 1; --hh)
-        bwd_step(true, &a.vf.hidden[hh], a.vf_wb, nullptr, nullptr, s_dz, s_tile, a.saved + (size_t)(hh - 1) * slot,
+        bwd_step(true, a.vf.hidden[hh], a.vf_wb, false, 0u, nullptr, s_dz, s_tile, a.saved + (size_t)(hh - 1) * slot,
                  a.dy + (size_t)(hh - 1) * slot, MASK_RELU, row0, n_rows, a.vf.hidden[hh].nkb_act / 4, wave, lane);
 }
 
@@ -238,46 +260,56 @@ __global__ __launch_bounds__(256, 1) void vfn_dw_kernel(const DwArgs a) {
 #pragma unroll
     for (int i = 0; i < NN; ++i) bsum[i] = 0.f;
 
-    int ncol[NN], kcol[KK];
-    bool nok[NN], kok[KK];
+    // Slab-relative, bounds-checked buffer descriptors: rows past the slab / batch end and columns past
+    // n_valid / k_valid get an out-of-range offset and read as 0 — no branches, no per-element waits.
+    const long long r_base = 2 * p0;
+    const long long rows_slab = max(0LL, min(2 * (p1 - p0), a.n_points - r_base));
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.dy + (size_t)r_base * a.ld_dy), 0, (int)(rows_slab * a.ld_dy * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x + (size_t)r_base * a.ld_x), 0, (int)(rows_slab * a.ld_x * 4), 0x00020000);
+    constexpr unsigned OOB = 0x7fffffffu;
+    int ncol[NN];
+    unsigned noff[NN], koff[KK];
 #pragma unroll
-    for (int i = 0; i < NN; ++i) { ncol[i] = 32 * (wn * NN + i) + c; nok[i] = ncol[i] < a.n_valid; }
+    for (int i = 0; i < NN; ++i) { ncol[i] = 32 * (wn * NN + i) + c; noff[i] = ncol[i] < a.n_valid ? (unsigned)ncol[i] * 4u : OOB; }
 #pragma unroll
-    for (int t = 0; t < KK; ++t) { kcol[t] = 32 * (wk * KK + t) + c; kok[t] = kcol[t] < a.k_valid; }
+    for (int t = 0; t < KK; ++t) { const int kc = 32 * (wk * KK + t) + c; koff[t] = kc < a.k_valid ? (unsigned)kc * 4u : OOB; }
 
-    float av[U][NN], bv[U][KK];
-    auto load_group = [&](long long p) {
+    float a0v[U][NN], b0v[U][KK], a1v[U][NN], b1v[U][KK];
+    auto load_group = [&](long long p, float (&av)[U][NN], float (&bv)[U][KK]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long long m = 2 * (p + u) + h;
-            const bool in = (p + u) < p1 && m < a.n_points;
+            const unsigned r = (unsigned)(2 * (p - p0 + u) + h);
+            const unsigned ra = r * (unsigned)a.ld_dy * 4u, rb = r * (unsigned)a.ld_x * 4u;
 #pragma unroll
-            for (int i = 0; i < NN; ++i) av[u][i] = (in && nok[i]) ? a.dy[(size_t)m * a.ld_dy + ncol[i]] : 0.f;
+            for (int i = 0; i < NN; ++i)
+                av[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dy, noff[i] == OOB ? OOB : ra + noff[i], 0, 0));
 #pragma unroll
-            for (int t = 0; t < KK; ++t) bv[u][t] = (in && kok[t]) ? a.x[(size_t)m * a.ld_x + kcol[t]] : 0.f;
+            for (int t = 0; t < KK; ++t)
+                bv[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, koff[t] == OOB ? OOB : rb + koff[t], 0, 0));
         }
     };
-    if (p0 < p1) load_group(p0);
-    for (long long p = p0; p < p1; p += U) {
-        float ca[U][NN], cb[U][KK];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int i = 0; i < NN; ++i) ca[u][i] = av[u][i];
-#pragma unroll
-            for (int t = 0; t < KK; ++t) cb[u][t] = bv[u][t];
-        }
-        if (p + U < p1) load_group(p + U);
+    auto compute = [&](const float (&av)[U][NN], const float (&bv)[U][KK]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int i = 0; i < NN; ++i) {
-                bsum[i] += ca[u][i];
+                bsum[i] += av[u][i];
 #pragma unroll
                 for (int t = 0; t < KK; ++t)
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[u][i], cb[u][t], acc[i][t], 0, 0, 0);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][t], acc[i][t], 0, 0, 0);
             }
         }
+    };
+    // two named register sets, no copies: the loads of one set stay in flight under the MFMAs of the other
+    // (rows past the slab end have out-of-range offsets -> zeros, so over-running the slab is harmless)
+    load_group(p0, a0v, b0v);
+    for (long long p = p0; p < p1; p += 2 * U) {
+        load_group(p + U, a1v, b1v);
+        compute(a0v, b0v);
+        load_group(p + 2 * U, a0v, b0v);
+        compute(a1v, b1v);
     }
     // partial slab: D row = n (MFMA i index), col = k (j index)
     float* out = a.dw_part + (size_t)g * a.n_out * a.ld_out;

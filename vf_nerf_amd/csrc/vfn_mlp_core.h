@@ -96,7 +96,8 @@ __device__ __forceinline__ float act_fn(float v, int kind) {
 // col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 template <int NT>
 __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[2][2], float* s_act, int tile0, int lane, int kind) {
-    const int c = lane & 31, h = lane >> 5;
+    int c = lane & 31, h = lane >> 5;
+    asm volatile("" : "+v"(c), "+v"(h));  // keep the lane-constant offsets from being hoisted out of the layer loop
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -112,7 +113,8 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[2][2], float*
 template <int NT>
 __device__ __forceinline__ void store_tile_global(const f32x16 (&acc)[2][2], float* out, long long row0, long long n_rows,
                                                   int stride, int col_off, int tile0, int lane, int kind) {
-    const int c = lane & 31, h = lane >> 5;
+    int c = lane & 31, h = lane >> 5;
+    asm volatile("" : "+v"(c), "+v"(h));
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
