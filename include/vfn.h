@@ -229,6 +229,26 @@ int vfn_ray_density_weights_bwd(const vfn_density_params* p, const float* normal
                                 const float* d_rgb, const float* d_depth, const float* d_weights,
                                 float* d_normals, float* d_colors, float* d_scalars, void* stream);
 
+/* =============================================================================================
+ * "f16x3" inference kernels: the same MLPs on the f16 matrix cores with fp32-equivalent accuracy.
+ * Every value is carried as two halves (hi + lo, 22 significant bits) and each product is evaluated as
+ * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation: 3 f16 MFMAs per K=16
+ * block instead of 8 fp32 MFMAs.  Weights come from vfn_pack16_weights (BatchNorm folded, scaled by 2^6, split,
+ * fragment order; re-run after every optimizer step).  Specialised for the shipped layer shapes
+ * (confs/vf_nerf.conf:13-37); other geometries return VFN_ERR_UNSUPPORTED and callers use the fp32 kernels.
+ * ============================================================================================= */
+int64_t vfn_pack16_size(int32_t net_kind, const vfn_net_geom* geom);           /* bytes */
+int vfn_pack16_weights(int32_t net_kind, const vfn_net_geom* geom, const vfn_layer_params* layers,
+                       void* packed16, void* stream);
+/* points[M,3] -> the 3 tanh'ed vector columns [M,3] (proposal pass / grid queries). */
+int vfn_vf_mlp16_fwd(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
+                     float* out_vec, void* stream);
+/* Fine pass: VF MLP -> rendering MLP, features stay in registers; normals[M,3], colors[M,3]. */
+int vfn_vf_render_fused16_fwd(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
+                              const void* rn_packed16, const float* points, const float* ray_dirs,
+                              int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

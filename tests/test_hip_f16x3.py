@@ -1,0 +1,72 @@
+"""The f16x3 (split-half, fp32-accumulate) inference kernels against the reference's golden vectors, and the
+exact-fp32 kernels as a second opinion.  Same tolerances as the fp32 path: the split carries 22 significant bits
+per operand and the products of halves are exact in fp32."""
+import pytest
+import torch
+
+from helpers import FIXTURE_NAMES, build_model, load_fixture, rel_err
+
+pytestmark = pytest.mark.gpu
+TIGHT = 2e-5
+
+
+@pytest.fixture(scope="module", params=FIXTURE_NAMES)
+def case(request):
+    fx, d = load_fixture(request.param)
+    model = build_model(fx, d, device="cuda:0")
+    return fx, d, {k: v.to("cuda:0") for k, v in d.items()}, model
+
+
+def test_vector_only_f16x3(case):
+    from vf_nerf_amd import lib
+    fx, d, g, model = case
+    pts = (g["cam_loc"][:, None, :] + g["z_coarse"][:, :, None] * g["directions"][:, None, :]).reshape(-1, 3).contiguous()
+    vf = model.vector_field_network
+    out = lib.vf_mlp16_fwd(vf.geometry(), vf.packed16_weights(), pts)
+    ref32 = lib.vf_mlp_fwd(vf.geometry(), vf.packed_weights(), pts, 3)
+    e_gold, e_32 = rel_err(out, d["normals_coarse"].reshape(-1, 3)), rel_err(out, ref32)
+    print(f"f16x3 vector-only: vs reference {e_gold:.3e}, vs exact-fp32 kernel {e_32:.3e}")
+    assert e_gold < TIGHT and e_32 < TIGHT
+
+
+def test_fused_fine_pass_f16x3(case):
+    from vf_nerf_amd import lib
+    fx, d, g, model = case
+    vf, rn = model.vector_field_network, model.rendering_network
+    s_t = fx["n_samples"] + fx["n_importance"]
+    normals, colors = lib.vf_render_fused16_fwd(vf.geometry(), vf.packed16_weights(), rn.geometry(),
+                                                rn.packed16_weights(), g["points"].reshape(-1, 3).contiguous(),
+                                                g["ray_dirs"].contiguous(), s_t)
+    en, ec = rel_err(normals, d["normals"].reshape(-1, 3)), rel_err(colors, d["colors"])
+    print(f"f16x3 fused: normals {en:.3e} colors {ec:.3e}")
+    assert en < TIGHT and ec < TIGHT
+
+
+def test_precision_switch_end_to_end(case):
+    fx, d, g, model = case
+    uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add") if k in g}
+    outs = {}
+    for prec in ("fp32", "f16x3"):
+        model.precision = prec
+        with torch.no_grad():
+            outs[prec] = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
+    model.precision = "f16x3"
+    same = (outs["f16x3"].z_vals == outs["fp32"].z_vals).all(dim=1)
+    assert float(same.float().mean()) >= 0.9
+    err = (outs["f16x3"].coarse_rgb_values - outs["fp32"].coarse_rgb_values).abs().max(dim=1)[0]
+    print(f"f16x3 vs fp32 render: identical sampling on {float(same.float().mean()):.3f} of rays, max rgb diff {float(err[same].max()):.3e}")
+    assert float(err[same].max()) < 1e-4
+
+
+def test_partial_tile_and_large_batch():
+    """Point counts that are not multiples of the 128-point workgroup, and a batch spanning many workgroups."""
+    from vf_nerf_amd import lib
+    fx, d = load_fixture("w1_det")
+    model = build_model(fx, d, device="cuda:0")
+    vf = model.vector_field_network
+    gen = torch.Generator().manual_seed(1)
+    for m in (1, 31, 129, 5000):
+        pts = (torch.rand(m, 3, generator=gen) * 2 - 1).to("cuda:0")
+        a = lib.vf_mlp16_fwd(vf.geometry(), vf.packed16_weights(), pts)
+        b = lib.vf_mlp_fwd(vf.geometry(), vf.packed_weights(), pts, 3)
+        assert rel_err(a, b) < TIGHT, m

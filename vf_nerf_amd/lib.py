@@ -24,7 +24,8 @@ EXPORTS = (
     "vfn_vf_mlp_fwd", "vfn_render_mlp_fwd", "vfn_vf_render_fused_fwd", "vfn_ray_density_weights",
     "vfn_range_fine_sample", "vfn_fill_uniform", "vfn_packed_bwd_size", "vfn_pack_weights_bwd",
     "vfn_vf_mlp_fwd_train", "vfn_vf_render_fused_fwd_train", "vfn_mlp_bwd_chain", "vfn_weight_grad_partials",
-    "vfn_ray_density_weights_bwd",
+    "vfn_ray_density_weights_bwd", "vfn_pack16_size", "vfn_pack16_weights", "vfn_vf_mlp16_fwd",
+    "vfn_vf_render_fused16_fwd",
 )
 
 
@@ -78,6 +79,8 @@ def load() -> C.CDLL:
     lib.vfn_packed_size.argtypes = [C.c_int32, C.POINTER(NetGeom)]
     lib.vfn_packed_bwd_size.restype = C.c_int64
     lib.vfn_packed_bwd_size.argtypes = [C.c_int32, C.POINTER(NetGeom)]
+    lib.vfn_pack16_size.restype = C.c_int64
+    lib.vfn_pack16_size.argtypes = [C.c_int32, C.POINTER(NetGeom)]
     for name in EXPORTS:
         getattr(lib, name)  # raises AttributeError if the ABI lost a symbol
     if lib.vfn_abi_version() != 1:
@@ -308,3 +311,39 @@ def ray_density_weights_bwd(dp: DensityParams, normals, ray_dirs, z_vals, scalar
                                               _ptr(d_weights, "d_weights"), _ptr(d_normals, "d_normals"),
                                               _ptr(d_colors, "d_colors"), _ptr(d_scalars, "d_scalars"), _stream()),
            "vfn_ray_density_weights_bwd")
+
+
+# ------------------------------------------------------------------------------------------------
+# f16x3 inference kernels
+# ------------------------------------------------------------------------------------------------
+def pack16_size(kind: int, geom: NetGeom) -> int:
+    n = load().vfn_pack16_size(kind, C.byref(geom))
+    if n < 0:
+        raise VfnError(f"unsupported network geometry: {load().vfn_last_error().decode()}")
+    return int(n)
+
+
+def pack16_weights(kind: int, geom: NetGeom, layers: Sequence[dict], packed16: torch.Tensor) -> None:
+    _check(load().vfn_pack16_weights(kind, C.byref(geom), _layer_array(geom, layers), _ptr(packed16, "packed16", torch.uint8),
+                                     _stream()), "vfn_pack16_weights")
+
+
+def vf_mlp16_fwd(geom: NetGeom, packed16, points):
+    m = points.shape[0]
+    out = torch.empty(m, 3, device=points.device)
+    _check(load().vfn_vf_mlp16_fwd(C.byref(geom), _ptr(packed16, "packed16", torch.uint8), _ptr(points, "points"),
+                                   C.c_int64(m), _ptr(out, "out"), _stream()), "vfn_vf_mlp16_fwd")
+    return out
+
+
+def vf_render_fused16_fwd(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, samples_per_ray: int):
+    m = points.shape[0]
+    dev = points.device
+    normals = torch.empty(m, 3, device=dev)
+    colors = torch.empty(m, 3, device=dev)
+    _check(load().vfn_vf_render_fused16_fwd(C.byref(vf_geom), _ptr(vf_packed16, "vf_packed16", torch.uint8),
+                                            C.byref(rn_geom), _ptr(rn_packed16, "rn_packed16", torch.uint8),
+                                            _ptr(points, "points"), _ptr(ray_dirs, "ray_dirs"), C.c_int64(m),
+                                            C.c_int32(samples_per_ray), _ptr(normals, "normals"),
+                                            _ptr(colors, "colors"), _stream()), "vfn_vf_render_fused16_fwd")
+    return normals, colors

@@ -73,6 +73,10 @@ class VectorFieldNerf:
             self.optimizer, sc.lr_decay_factor ** (1. / sc.lr_decay_steps))
         self.to(config.cuda_config.device)
 
+        # arithmetic of the inference MLP kernels: "f16x3" = split-half products on the f16 matrix cores with
+        # fp32 accumulation (fp32-equivalent accuracy, see csrc/vfn_mlp16.hip); "fp32" = exact fp32 MFMA.
+        # Gradient-carrying calls always use the fp32 kernels.
+        self.precision = "f16x3"
         # device RNG stream (Philox counter); every render() advances the offset
         self.rng_seed = 0
         self._rng_offset = 0
@@ -244,7 +248,10 @@ class VectorFieldNerf:
             directions, ray_dirs, cam_loc, z_c, pts_c = self._rays(pose, pixels, intrinsics, u_coarse)
             # (3) VF net, vector columns only
             vf = self.vector_field_network
-            normals_c = lib.vf_mlp_fwd(vf.geometry(), vf.packed_weights(), pts_c.view(-1, 3), 3)
+            if self.precision == "f16x3":
+                normals_c = lib.vf_mlp16_fwd(vf.geometry(), vf.packed16_weights(), pts_c.view(-1, 3))
+            else:
+                normals_c = lib.vf_mlp_fwd(vf.geometry(), vf.packed_weights(), pts_c.view(-1, 3), 3)
             # (4)-(5) density -> weights -> argmax
             scal = self.density.raw_scalars()
             _, _, imax, _, _ = lib.ray_density_weights(self._density_params(), normals_c, ray_dirs, z_c, scal,

@@ -86,6 +86,22 @@ class _PackedMLP(nn.Module):
             self._packed_key = key
         return self._packed
 
+    def packed16_weights(self) -> torch.Tensor:
+        """f16x3 pack (hi/lo halves, 2^6 scale, fragment order) for the current parameter values."""
+        tensors = [t for d in self._layer_tensors() for t in d.values()]
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        dev = tensors[0].device
+        cache = getattr(self, "_packed16_cache", None)
+        if cache is None or cache[0] != key or cache[1].device != dev:
+            geom = self.geometry()
+            buf = cache[1] if (cache is not None and cache[1].device == dev) else \
+                torch.empty(lib.pack16_size(self._kind, geom), dtype=torch.uint8, device=dev)
+            with torch.no_grad():
+                lib.pack16_weights(self._kind, geom, [{k: v.detach() for k, v in d.items()}
+                                                      for d in self._layer_tensors()], buf)
+            self._packed16_cache = (key, buf)
+        return self._packed16_cache[1]
+
     def _require_eval_bn(self) -> None:
         if self.training and any(self._bn(i) is not None for i in range(self.num_layers)):
             raise NotImplementedError(
