@@ -10,15 +10,16 @@
 //
 // Structure (different from the fp32 kernel — activations never touch LDS):
 //  * the GEMM is transposed, Y^T[n][m] = W'[n][k] X^T[k][m]: the MFMA's A operand is the weight tile, B is the
-//    activation; a wave owns 32 points (the lane's column m) end to end.  The 32x32 accumulator of output tile t
-//    IS, register for register, the B operand of k-blocks 2t and 2t+1 of the next layer (accumulator row
-//    (r&3) + 8(r>>2) + 4(lane>>5) <-> fragment element order, absorbed into the weight packing), so a layer's output
-//    is split to (hi, lo) halves in registers and consumed in place: no LDS round trip, no cross-lane traffic,
-//    no barrier on the activation path;
-//  * weights (A fragments, hi and lo planes, lane-linear 1 KiB blocks) are shared by the workgroup's 4 waves
-//    through a double-buffered LDS chunk (one 32-row output tile x all K = 33 KiB): the next chunk is fetched
-//    from L2 into registers while the current one feeds the MFMAs and written to the other buffer mid-tile —
-//    one barrier per chunk;
+//    activation; a wave owns 16 points (the lane's column m = lane & 15) end to end, on v_mfma_f32_16x16x32_f16.
+//    The 16x16 accumulators of output tiles 2s and 2s+1 ARE, register for register, the B operand of K-block s of
+//    the next layer (accumulator row 4*(lane>>4) + reg <-> fragment element order, absorbed into the weight
+//    packing), so a layer's output is split to (hi, lo) halves in registers and consumed in place: no LDS round
+//    trip, no cross-lane traffic, no barrier on the activation path.  16 points per wave keep the two activation
+//    sets at 128 VGPRs, so 8 waves (two per SIMD) fit and one wave's epilogue / LDS waits hide under its
+//    partner's MFMAs;
+//  * weights (A fragments, hi and lo planes, lane-linear 1 KiB blocks) are shared by the workgroup's 8 waves
+//    through a three-slot LDS ring of chunks (32 output rows x all K = 33 KiB) filled by LDS-DMA two chunks ahead,
+//    tracked with counted vmcnt waits and one raw s_barrier per chunk;
 //  * the weights are pre-scaled by 2^6 at pack time (exact), so the low halves stay normal f16 numbers; the
 //    epilogue multiplies by 2^-6.
 #include <string.h>
@@ -33,8 +34,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define VFN16_WSCALE 64.0f
 #define VFN16_INV_WSCALE 0.015625f
-#define VFN16_MAX_CHUNK_KB 40     // 2 * 19 K-blocks + 1 bias block
-#define VFN16_STAGE 10            // ceil(40 / 4 waves)
+#define VFN16_MAX_CHUNK_KB 42     // 2 tiles x 10 K-blocks x 2 planes + 1 bias block
 
 // ------------------------------------------------------------------------------------------------
 // plan: where each hidden entry's chunks live in the f16 pack
@@ -46,9 +46,9 @@ struct Plan16 {
     uint32_t total_kb;
     uint32_t head_off_kb;
     uint32_t off_kb[VFN_MAX_LAYERS];   // first chunk of hidden entry h (KiB from the pack base)
-    uint8_t act16[VFN_MAX_LAYERS];     // K blocks of 16 taken from the activation registers
-    uint8_t aux16[VFN_MAX_LAYERS];     // K blocks of 16 taken from the auxiliary (encoding) registers
-    uint8_t n_tiles[VFN_MAX_LAYERS];
+    uint8_t act16[VFN_MAX_LAYERS];     // K blocks of 32 taken from the activation registers
+    uint8_t aux16[VFN_MAX_LAYERS];     // K blocks of 32 taken from the auxiliary (encoding) registers
+    uint8_t n_tiles[VFN_MAX_LAYERS];   // chunks = pairs of 16-row output tiles
 };
 
 static int make_plan16(int kind, const vfn_net_geom* g, VfnNetPlan* p32, Plan16* p, const char* what) {
@@ -60,29 +60,30 @@ static int make_plan16(int kind, const vfn_net_geom* g, VfnNetPlan* p32, Plan16*
     uint32_t off = 0;
     for (int h = 0; h < p32->n_hidden; ++h) {
         const VfnLayerPlan& lp = p32->hidden[h];
-        p->act16[h] = (uint8_t)(lp.nkb_act / 2);
-        p->aux16[h] = lp.nkb_aux ? 3 : 0;     // 39 / 33 encoding columns -> 48
+        p->act16[h] = (uint8_t)(lp.nkb_act / 4);
+        p->aux16[h] = lp.nkb_aux ? 2 : 0;     // 39 / 33 encoding columns -> 64
         p->n_tiles[h] = (uint8_t)lp.n_tiles;
-        if (lp.nkb_act % 2) { vfn_set_error("%s: act width not a multiple of 16", what); return VFN_ERR_UNSUPPORTED; }
+        if (lp.nkb_act % 4) { vfn_set_error("%s: act width not a multiple of 32", what); return VFN_ERR_UNSUPPORTED; }
         p->off_kb[h] = off;
-        off += lp.n_tiles * (2u * (p->act16[h] + p->aux16[h]) + 1u);
+        off += lp.n_tiles * (4u * (p->act16[h] + p->aux16[h]) + 1u);
     }
     p->head_off_kb = off;
-    off += 2u * 16u + 1u;
+    off += 2u * 8u + 1u;                      // head: ONE 16-row tile
     p->total_kb = off;
     return VFN_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
 // pack: fold BatchNorm / skip scale, scale by 2^6, split to halves, fragment order
-//   chunk(nt) = [kb][part hi|lo][lane][8 halves] ++ bias block [h][16 floats] (1 KiB, 128 B used)
-//   element j of lane (r = lane & 31, h = lane >> 5) of K-block kb:
-//     act blocks:  k = 32*(kb>>1) + 16*(kb&1) + 8*(j>>2) + 4*h + (j&3)     (accumulator-as-operand order)
-//     aux blocks:  k_aux = 16*(kb - act16) + 8*h + j
+//   chunk = [tile t16 of the pair][kb][plane hi|lo][lane][8 halves] ++ bias block [t16][g][4 floats] (1 KiB)
+//   element j of lane (r = lane & 15, g = lane >> 4) of K-block kb (32 wide), output row n = 32*chunk + 16*t16 + r:
+//     act blocks:  k = 32*kb + 16*(j>>2) + 4*g + (j&3)           (accumulator-pair-as-operand order)
+//     aux blocks:  k_aux = 32*(kb - act) + 8*g + j
+//   the head is a single tile (n_tiles16 == 1).
 // ------------------------------------------------------------------------------------------------
 struct Pack16Entry {
     const float* w; const float* b; const float* bn_w; const float* bn_b; const float* bn_mean; const float* bn_var;
-    uint32_t off_kb, n_tiles, act16, aux16;
+    uint32_t off_kb, n_chunks, tiles16, act16, aux16;
     int32_t in_dim, row_off, n_rows, act_col_off, act_valid, aux_col_off, aux_valid;
     float scale;
 };
@@ -109,23 +110,25 @@ __global__ void vfn_pack16_kernel(Pack16Args a) {
         if (idx >= a.e[i].off_kb * 256u) ei = i;
     const Pack16Entry& e = a.e[ei];
     const uint32_t nkb = e.act16 + e.aux16;
-    const uint32_t chunk_words = (2u * nkb + 1u) * 256u;
+    const uint32_t wblocks = e.tiles16 * nkb * 2u;             // 1 KiB weight blocks per chunk
+    const uint32_t chunk_words = (wblocks + 1u) * 256u;
     const uint32_t local = idx - e.off_kb * 256u;
-    const uint32_t nt = local / chunk_words, cw = local % chunk_words;
+    const uint32_t ck = local / chunk_words, cw = local % chunk_words;
     uint32_t word = 0;
-    if (cw < 2u * nkb * 256u) {
+    if (cw < wblocks * 256u) {
         const uint32_t blk = cw >> 8, lane = (cw >> 2) & 63u, jp = cw & 3u;   // word jp holds elements 2jp, 2jp+1
-        const uint32_t kb = blk >> 1, part = blk & 1u;
-        const int n = (int)(32u * nt + (lane & 31u)), h = (int)(lane >> 5);
+        const uint32_t part = blk & 1u, kb = (blk >> 1) % nkb, t16 = (blk >> 1) / nkb;
+        const int g = (int)(lane >> 4);
+        const int n = (int)(32u * ck + 16u * t16 + (lane & 15u));
         _Float16 halves[2];
         for (int q = 0; q < 2; ++q) {
             const int j = (int)(2u * jp) + q;
             int col = -1;
             if (kb < e.act16) {
-                const int k = 32 * (int)(kb >> 1) + 16 * (int)(kb & 1u) + 8 * (j >> 2) + 4 * h + (j & 3);
+                const int k = 32 * (int)kb + 16 * (j >> 2) + 4 * g + (j & 3);
                 if (k < e.act_valid) col = e.act_col_off + k;
             } else {
-                const int k = 16 * (int)(kb - e.act16) + 8 * h + j;
+                const int k = 32 * (int)(kb - e.act16) + 8 * g + j;
                 if (k < e.aux_valid) col = e.aux_col_off + k;
             }
             const float w = folded_weight(e, n, col);
@@ -135,12 +138,12 @@ __global__ void vfn_pack16_kernel(Pack16Args a) {
         word = (uint32_t)__builtin_bit_cast(unsigned short, halves[0]) |
                ((uint32_t)__builtin_bit_cast(unsigned short, halves[1]) << 16);
     } else {
-        const uint32_t bi = cw - 2u * nkb * 256u;   // bias block: [h][16] floats in accumulator-row order
+        const uint32_t bi = cw - wblocks * 256u;   // bias block: [t16][g][4] floats in accumulator-row order
         if (bi < 32u) {
-            const int h = (int)(bi >> 4), r = (int)(bi & 15u);
-            const int n = (int)(32u * nt) + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int t16 = (int)(bi >> 4), g = (int)((bi >> 2) & 3u), r = (int)(bi & 3u);
+            const int n = (int)(32u * ck) + 16 * t16 + 4 * g + r;
             float b = 0.f;
-            if (n < e.n_rows) {
+            if (n < e.n_rows && (uint32_t)t16 < e.tiles16) {
                 const int row = e.row_off + n;
                 b = e.b[row];
                 if (e.bn_w) b = (b - e.bn_mean[row]) * (e.bn_w[row] / sqrtf(e.bn_var[row] + 1e-5f)) + e.bn_b[row];
@@ -183,7 +186,7 @@ extern "C" int vfn_pack16_weights(int32_t net_kind, const vfn_net_geom* geom, co
         Pack16Entry& e = a.e[a.n_entries++];
         rc = fill(e, i);
         if (rc != VFN_OK) return rc;
-        e.off_kb = p.off_kb[h]; e.n_tiles = p.n_tiles[h]; e.act16 = p.act16[h]; e.aux16 = p.aux16[h];
+        e.off_kb = p.off_kb[h]; e.n_chunks = p.n_tiles[h]; e.tiles16 = 2; e.act16 = p.act16[h]; e.aux16 = p.aux16[h];
         const bool feat = p.feat_layer && h == p.n_hidden - 1;
         e.row_off = feat ? 3 : 0;
         e.n_rows = feat ? F : geom->out_dims[i];
@@ -203,7 +206,7 @@ extern "C" int vfn_pack16_weights(int32_t net_kind, const vfn_net_geom* geom, co
         Pack16Entry& e = a.e[a.n_entries++];
         rc = fill(e, L - 1);
         if (rc != VFN_OK) return rc;
-        e.off_kb = p.head_off_kb; e.n_tiles = 1; e.act16 = 16; e.aux16 = 0;
+        e.off_kb = p.head_off_kb; e.n_chunks = 1; e.tiles16 = 1; e.act16 = 8; e.aux16 = 0;
         e.row_off = 0; e.n_rows = 3; e.act_col_off = 0; e.act_valid = VFN_HIDDEN;
     }
     a.total_words = p.total_kb * 256u;
@@ -222,7 +225,10 @@ enum : int { M16_VF_VEC = 0, M16_FUSED = 1 };
 
 #define VFN16_MAX_CHUNKS 160
 #define VFN16_SLOT (VFN16_MAX_CHUNK_KB * 64)   // uint4 elements per LDS ring slot
+#define VFN16_WAVES 8
+#define VFN16_PTS 128                          // points per workgroup (16 per wave)
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
@@ -238,20 +244,25 @@ struct Mlp16Args {
     int dirs_div;
     int n_chunks;
     // the weight chunks in the order the kernel consumes them: bit 31 = rendering net, bits 30..8 = KiB offset in that
-    // net's pack, bits 7..0 = KiB size
+    // net's pack, bits 7..0 = KiB size.  Copied to LDS at kernel start (dynamic indexing of a by-value argument would
+    // be lowered to a private-memory copy, and scratch traffic would break the counted vmcnt waits).
     uint32_t chunk[VFN16_MAX_CHUNKS];
 };
 
-struct X16 { half8 hi[16]; half8 lo[16]; };     // 256 activation columns of this lane's point, split
-struct A16 { half8 hi[3]; half8 lo[3]; };       // 48 auxiliary (encoding) columns
+struct X16 { half8 hi[8]; half8 lo[8]; };      // 256 activation columns of this lane's point, split (8 K-blocks of 32)
+struct A16 { half8 hi[2]; half8 lo[2]; };      // 64 auxiliary (encoding) columns
 
 // Three-slot LDS ring fed by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction): while chunk c feeds the
 // MFMAs, chunk c+1 is landing and chunk c+2 is being issued.  Completion is tracked with COUNTED vmcnt waits and a
 // raw s_barrier (a __syncthreads() would drain the DMA in flight); nothing else in the loop touches vector memory.
 struct Pipe {
-    uint4* lds;
-    int slot;     // ring slot of the chunk being consumed
-    int c;        // index of that chunk in the chunk list
+    uint4* lds;            // ring
+    const uint32_t* tab;   // chunk list (LDS)
+    const uint4* vf_w;
+    const uint4* rn_w;
+    int n_chunks;
+    int slot;              // ring slot of the chunk being consumed
+    int c;                 // index of that chunk in the chunk list
 };
 
 __device__ __forceinline__ void split2(float a, float b, _Float16& h0, _Float16& h1, _Float16& l0, _Float16& l1) {
@@ -262,21 +273,24 @@ __device__ __forceinline__ void split2(float a, float b, _Float16& h0, _Float16&
     h0 = hi[0]; h1 = hi[1]; l0 = lo[0]; l1 = lo[1];
 }
 
+__device__ __forceinline__ uint32_t chunk_entry(const Pipe& p, int idx) {
+    return __builtin_amdgcn_readfirstlane(p.tab[idx]);
+}
 __device__ __forceinline__ int dma_count(uint32_t entry, int wave) {   // DMA instructions this wave issues for a chunk
     const int kb = (int)(entry & 0xffu);
-    return kb > wave ? (kb - wave + 3) >> 2 : 0;
+    return kb > wave ? (kb - wave + VFN16_WAVES - 1) / VFN16_WAVES : 0;
 }
 
-__device__ __forceinline__ void dma_issue(const Mlp16Args& a, const Pipe& p, int chunk_idx, int slot, int wave, int lane) {
-    const uint32_t e = a.chunk[chunk_idx];
-    const uint4* src = ((e >> 31) ? a.rn_w : a.vf_w) + (size_t)((e >> 8) & 0x7fffffu) * 64;
+__device__ __forceinline__ void dma_issue(const Pipe& p, int chunk_idx, int slot, int wave, int lane) {
+    const uint32_t e = chunk_entry(p, chunk_idx);
+    const uint4* src = ((e >> 31) ? p.rn_w : p.vf_w) + (size_t)((e >> 8) & 0x7fffffu) * 64;
     const int kb = (int)(e & 0xffu);
     uint4* dst = p.lds + slot * VFN16_SLOT;
-    for (int b = wave; b < kb; b += 4)
+    for (int b = wave; b < kb; b += VFN16_WAVES)
         __builtin_amdgcn_global_load_lds((glb_void*)(src + b * 64 + lane), (lds_void*)(dst + b * 64), 16, 0, 0);
 }
 
-__device__ __forceinline__ void wait_all_but(int n) {   // s_waitcnt vmcnt(n), n wave-uniform in 0..10
+__device__ __forceinline__ void wait_all_but(int n) {   // s_waitcnt vmcnt(n), n wave-uniform in 0..6
     switch (n) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
@@ -284,95 +298,76 @@ __device__ __forceinline__ void wait_all_but(int n) {   // s_waitcnt vmcnt(n), n
         case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
         case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
         case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     }
 }
 
-// End of a tile: chunk c+1 must have landed (ours: counted wait leaving chunk c+2's DMA in flight; everyone's: barrier).
-__device__ __forceinline__ void pipe_next(const Mlp16Args& a, Pipe& p, int wave) {
-    if (p.c + 1 < a.n_chunks) {
-        wait_all_but(p.c + 2 < a.n_chunks ? dma_count(a.chunk[p.c + 2], wave) : 0);
+// End of a chunk: chunk c+1 must have landed (ours: counted wait leaving chunk c+2's DMA in flight; everyone's: barrier).
+__device__ __forceinline__ void pipe_next(Pipe& p, int wave) {
+    if (p.c + 1 < p.n_chunks) {
+        wait_all_but(p.c + 2 < p.n_chunks ? dma_count(chunk_entry(p, p.c + 2), wave) : 0);
         __builtin_amdgcn_s_barrier();
     }
     p.c += 1;
     p.slot = p.slot == 2 ? 0 : p.slot + 1;
 }
 
-// One layer: xout <- f(W' [xin ; aux] + b') for NT output tiles.
-template <int ACT16, int AUX16, int NT, int EPI>
-__device__ __forceinline__ void layer16(const Mlp16Args& a, const X16& xin, const A16& aux, X16& xout, float (&head)[3],
-                                        Pipe& p, int wave, int lane) {
-    constexpr int NKB = ACT16 + AUX16;
-    const int h = lane >> 5;
+// One layer: xout <- f(W' [xin ; aux] + b') — NCH chunks of TPC 16-row output tiles each.
+// D layout of v_mfma_f32_16x16x32_f16: column = lane & 15 (the point), row = 4 * (lane >> 4) + reg.
+template <int ACT, int AUX, int NCH, int TPC, int EPI>
+__device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xout, float (&head)[3], Pipe& p, int wave,
+                                        int lane) {
+    constexpr int NKB = ACT + AUX;
+    const int g = lane >> 4;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    for (int ch = 0; ch < NCH; ++ch) {
         // (1) keep the ring two chunks ahead
-        if (p.c + 2 < a.n_chunks) dma_issue(a, p, p.c + 2, p.slot == 0 ? 2 : p.slot - 1, wave, lane);
-        // (2) this tile
+        if (p.c + 2 < p.n_chunks) dma_issue(p, p.c + 2, p.slot == 0 ? 2 : p.slot - 1, wave, lane);
+        // (2) the chunk's tiles
         const uint4* cb = p.lds + p.slot * VFN16_SLOT;
-        const f32x4* bias = reinterpret_cast<const f32x4*>(cb + 2 * NKB * 64) + h * 4;
-        f32x16 acc;
+        f32x4v acc[TPC];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 bq = bias[q];
-            acc[4 * q + 0] = bq[0]; acc[4 * q + 1] = bq[1]; acc[4 * q + 2] = bq[2]; acc[4 * q + 3] = bq[3];
-        }
-        // A fragments are read two K-blocks ahead of the MFMAs that consume them (one wave per SIMD: nothing
-        // else hides the LDS latency)
-        half8 fa[3], fb[3];   // fa = hi plane, fb = lo plane, rotating over kb % 3
-        fa[0] = __builtin_bit_cast(half8, cb[0 * 64 + lane]);
-        fb[0] = __builtin_bit_cast(half8, cb[1 * 64 + lane]);
-        if (NKB > 1) {
-            fa[1] = __builtin_bit_cast(half8, cb[2 * 64 + lane]);
-            fb[1] = __builtin_bit_cast(half8, cb[3 * 64 + lane]);
-        }
+        for (int t = 0; t < TPC; ++t) {
+            acc[t] = reinterpret_cast<const f32x4v*>(cb + TPC * NKB * 2 * 64)[t * 4 + g];
+            const uint4* tb = cb + t * NKB * 2 * 64;
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-            if (kb + 2 < NKB) {
-                fa[(kb + 2) % 3] = __builtin_bit_cast(half8, cb[(2 * (kb + 2)) * 64 + lane]);
-                fb[(kb + 2) % 3] = __builtin_bit_cast(half8, cb[(2 * (kb + 2) + 1) * 64 + lane]);
+            for (int kb = 0; kb < NKB; ++kb) {
+                const half8 a_hi = __builtin_bit_cast(half8, tb[(2 * kb) * 64 + lane]);
+                const half8 a_lo = __builtin_bit_cast(half8, tb[(2 * kb + 1) * 64 + lane]);
+                const half8 x_hi = kb < ACT ? xin.hi[kb < ACT ? kb : 0] : aux.hi[kb >= ACT ? kb - ACT : 0];
+                const half8 x_lo = kb < ACT ? xin.lo[kb < ACT ? kb : 0] : aux.lo[kb >= ACT ? kb - ACT : 0];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, x_hi, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, x_lo, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, x_hi, acc[t], 0, 0, 0);
             }
-            const half8 a_hi = fa[kb % 3], a_lo = fb[kb % 3];
-            const half8 x_hi = kb < ACT16 ? xin.hi[kb < ACT16 ? kb : 0] : aux.hi[kb >= ACT16 ? kb - ACT16 : 0];
-            const half8 x_lo = kb < ACT16 ? xin.lo[kb < ACT16 ? kb : 0] : aux.lo[kb >= ACT16 ? kb - ACT16 : 0];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, x_hi, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, x_lo, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, x_hi, acc, 0, 0, 0);
         }
-        // (3) epilogue
+        // (3) epilogue: the tile pair becomes K-block `ch` of the next layer's operand
         if (EPI == EPI_RELU || EPI == EPI_TANH) {
+            half8 hi, lo;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                half8 hi, lo;
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    float v0 = acc[8 * s + j] * VFN16_INV_WSCALE, v1 = acc[8 * s + j + 1] * VFN16_INV_WSCALE;
-                    if (EPI == EPI_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                    else { v0 = tanhf(v0); v1 = tanhf(v1); }
-                    _Float16 h0, h1, l0, l1;
-                    split2(v0, v1, h0, h1, l0, l1);
-                    hi[j] = h0; hi[j + 1] = h1; lo[j] = l0; lo[j + 1] = l1;
-                }
-                xout.hi[2 * nt + s] = hi; xout.lo[2 * nt + s] = lo;
+            for (int j = 0; j < 8; j += 2) {
+                float v0 = acc[j >> 2][j & 3] * VFN16_INV_WSCALE, v1 = acc[j >> 2][(j & 3) + 1] * VFN16_INV_WSCALE;
+                if (EPI == EPI_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                else { v0 = tanhf(v0); v1 = tanhf(v1); }
+                _Float16 h0, h1, l0, l1;
+                split2(v0, v1, h0, h1, l0, l1);
+                hi[j] = h0; hi[j + 1] = h1; lo[j] = l0; lo[j + 1] = l1;
             }
+            xout.hi[ch] = hi; xout.lo[ch] = lo;
         } else {
-            // 3-channel head: rows 0..2 of the tile live in registers 0..2 of the h == 0 half
+            // 3-channel head: rows 0..2 of the tile are registers 0..2 of the g == 0 lanes
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float v = acc[c] * VFN16_INV_WSCALE;
+                const float v = acc[0][c] * VFN16_INV_WSCALE;
                 head[c] = (EPI == EPI_HEAD_TANH) ? tanhf(v) : 1.0f / (1.0f + expf(-v));
             }
         }
         // (4) hand over to the next chunk
-        pipe_next(a, p, wave);
+        pipe_next(p, wave);
     }
 }
 
-// encoding columns [x(3), sin/cos(2^k x)...] of one 3-vector: column k of the 48-wide aux operand
+// encoding columns [x(3), sin/cos(2^k x)...] of one 3-vector: column k of the aux operand
 __device__ __forceinline__ float enc_value(const float (&x)[3], const float (&sn)[18], const float (&cs)[18], int multires, int k) {
     if (k < 3) return x[k];
     const int idx = k - 3, oct = idx / 6, rem = idx - 6 * oct;
@@ -380,18 +375,41 @@ __device__ __forceinline__ float enc_value(const float (&x)[3], const float (&sn
     return rem < 3 ? sn[3 * oct + rem] : cs[3 * oct + rem - 3];
 }
 
+// aux operand from a column generator: element j of lane group g of K-block s <-> column 32 s + 8 g + j
+template <typename F>
+__device__ __forceinline__ void build_aux(A16& aux, int g, F col) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            float v0, v1;
+            if (g == 0) { v0 = col(32 * s + j); v1 = col(32 * s + j + 1); }
+            else if (g == 1) { v0 = col(32 * s + 8 + j); v1 = col(32 * s + 8 + j + 1); }
+            else if (g == 2) { v0 = col(32 * s + 16 + j); v1 = col(32 * s + 16 + j + 1); }
+            else { v0 = col(32 * s + 24 + j); v1 = col(32 * s + 24 + j + 1); }
+            _Float16 h0, h1, l0, l1;
+            split2(v0, v1, h0, h1, l0, l1);
+            hi[j] = h0; hi[j + 1] = h1; lo[j] = l0; lo[j + 1] = l1;
+        }
+        aux.hi[s] = hi; aux.lo[s] = lo;
+    }
+}
+
 template <int MODE>
-__global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
+__global__ __launch_bounds__(512, 2) void vfn_mlp16_kernel(const Mlp16Args a) {
     __shared__ __attribute__((aligned(16))) uint4 s_ring[3 * VFN16_SLOT];
+    __shared__ uint32_t s_tab[VFN16_MAX_CHUNKS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5;
-    const long long m = (long long)blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const int g = lane >> 4;
+    const long long m = (long long)blockIdx.x * VFN16_PTS + wave * 16 + (lane & 15);
     const bool in = m < a.n_points;
 
-    // this lane's point (both halves of the wave share a point); loaded BEFORE any DMA so that the counted
-    // vmcnt waits of the ring only ever see DMA instructions
+    if (tid < VFN16_MAX_CHUNKS) s_tab[tid] = a.chunk[tid];
+    // this lane's point (the four lane groups of a wave share the 16 points); loaded BEFORE any DMA so that the
+    // counted vmcnt waits of the ring only ever see DMA instructions
     float x[3] = {0.f, 0.f, 0.f};
     if (in) { x[0] = a.points[m * 3 + 0]; x[1] = a.points[m * 3 + 1]; x[2] = a.points[m * 3 + 2]; }
     float d[3] = {0.f, 0.f, 0.f};
@@ -400,14 +418,15 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
         d[0] = a.ray_dirs[di * 3 + 0]; d[1] = a.ray_dirs[di * 3 + 1]; d[2] = a.ray_dirs[di * 3 + 2];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // chunk list visible
 
     Pipe p;
-    p.lds = s_ring; p.slot = 0; p.c = 0;
-    dma_issue(a, p, 0, 0, wave, lane);
-    if (a.n_chunks > 1) dma_issue(a, p, 1, 1, wave, lane);
+    p.lds = s_ring; p.tab = s_tab; p.vf_w = a.vf_w; p.rn_w = a.rn_w; p.n_chunks = a.n_chunks; p.slot = 0; p.c = 0;
+    dma_issue(p, 0, 0, wave, lane);
+    if (p.n_chunks > 1) dma_issue(p, 1, 1, wave, lane);
 
-    // ---- positional encoding of the point -> aux operand (element j of K-block s <-> column 16 s + 8 h + j) ----
-    const Plan16& vf = a.vf;
+    // ---- positional encoding of the point -> aux operand ------------------------------------------------
+    const int vf_multires = a.vf.multires, rn_multires = a.rn.multires;
     A16 aux;
     {
         float sn[18], cs[18];
@@ -415,66 +434,53 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
         for (int o = 0; o < 6; ++o)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                if (o < vf.multires) sincosf(x[c] * (float)(1 << o), &sn[3 * o + c], &cs[3 * o + c]);
+                if (o < vf_multires) sincosf(x[c] * (float)(1 << o), &sn[3 * o + c], &cs[3 * o + c]);
                 else { sn[3 * o + c] = 0.f; cs[3 * o + c] = 0.f; }
             }
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            half8 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                const float v0 = h ? enc_value(x, sn, cs, vf.multires, 16 * s + 8 + j) : enc_value(x, sn, cs, vf.multires, 16 * s + j);
-                const float v1 = h ? enc_value(x, sn, cs, vf.multires, 16 * s + 8 + j + 1) : enc_value(x, sn, cs, vf.multires, 16 * s + j + 1);
-                _Float16 h0, h1, l0, l1;
-                split2(v0, v1, h0, h1, l0, l1);
-                hi[j] = h0; hi[j + 1] = h1; lo[j] = l0; lo[j + 1] = l1;
-            }
-            aux.hi[s] = hi; aux.lo[s] = lo;
-        }
+        build_aux(aux, g, [&](int k) { return enc_value(x, sn, cs, vf_multires, k); });
     }
     // chunk 0 landed (chunk 1 may still be in flight)
-    wait_all_but(a.n_chunks > 1 ? dma_count(a.chunk[1], wave) : 0);
+    wait_all_but(p.n_chunks > 1 ? dma_count(chunk_entry(p, 1), wave) : 0);
     __builtin_amdgcn_s_barrier();
 
     // ---- VF net (shipped family: L0 | plain... | narrow | skip | plain... | [features] + head) ------------
     X16 xa, xb;
     float vec[3] = {0.f, 0.f, 0.f};
-    const int n_plain = vf.n_hidden - vf.feat_layer;
-    layer16<0, 3, 8, EPI_RELU>(a, xa, aux, xb, vec, p, wave, lane);   // layer 0: encoding only
+    const int n_plain = a.vf.n_hidden - a.vf.feat_layer;
+    layer16<0, 2, 8, 2, EPI_RELU>(xa, aux, xb, vec, p, wave, lane);   // layer 0: encoding only
     bool in_b = true;                                                 // current activations live in xb
     for (int hh = 1; hh < n_plain; ++hh) {
-        const int shape = (vf.aux16[hh] ? 2 : 0) | (vf.n_tiles[hh] == 7 ? 1 : 0);
+        const int shape = (a.vf.aux16[hh] ? 2 : 0) | (a.vf.n_tiles[hh] == 7 ? 1 : 0);
         if (in_b) {
-            if (shape == 0) layer16<16, 0, 8, EPI_RELU>(a, xb, aux, xa, vec, p, wave, lane);
-            else if (shape == 1) layer16<16, 0, 7, EPI_RELU>(a, xb, aux, xa, vec, p, wave, lane);
-            else layer16<14, 3, 8, EPI_RELU>(a, xb, aux, xa, vec, p, wave, lane);
+            if (shape == 0) layer16<8, 0, 8, 2, EPI_RELU>(xb, aux, xa, vec, p, wave, lane);
+            else if (shape == 1) layer16<8, 0, 7, 2, EPI_RELU>(xb, aux, xa, vec, p, wave, lane);
+            else layer16<7, 2, 8, 2, EPI_RELU>(xb, aux, xa, vec, p, wave, lane);
         } else {
-            if (shape == 0) layer16<16, 0, 8, EPI_RELU>(a, xa, aux, xb, vec, p, wave, lane);
-            else if (shape == 1) layer16<16, 0, 7, EPI_RELU>(a, xa, aux, xb, vec, p, wave, lane);
-            else layer16<14, 3, 8, EPI_RELU>(a, xa, aux, xb, vec, p, wave, lane);
+            if (shape == 0) layer16<8, 0, 8, 2, EPI_RELU>(xa, aux, xb, vec, p, wave, lane);
+            else if (shape == 1) layer16<8, 0, 7, 2, EPI_RELU>(xa, aux, xb, vec, p, wave, lane);
+            else layer16<7, 2, 8, 2, EPI_RELU>(xa, aux, xb, vec, p, wave, lane);
         }
         in_b = !in_b;
     }
     if (MODE == M16_VF_VEC) {
-        if (in_b) layer16<16, 0, 1, EPI_HEAD_TANH>(a, xb, aux, xa, vec, p, wave, lane);
-        else layer16<16, 0, 1, EPI_HEAD_TANH>(a, xa, aux, xb, vec, p, wave, lane);
-        if (in && h == 0) { a.out_vec[m * 3 + 0] = vec[0]; a.out_vec[m * 3 + 1] = vec[1]; a.out_vec[m * 3 + 2] = vec[2]; }
+        if (in_b) layer16<8, 0, 1, 1, EPI_HEAD_TANH>(xb, aux, xa, vec, p, wave, lane);
+        else layer16<8, 0, 1, 1, EPI_HEAD_TANH>(xa, aux, xb, vec, p, wave, lane);
+        if (in && g == 0) { a.out_vec[m * 3 + 0] = vec[0]; a.out_vec[m * 3 + 1] = vec[1]; a.out_vec[m * 3 + 2] = vec[2]; }
         return;
     }
     // fused: feature block (tanh) then the vector head, both from the same input
-    const Plan16& rn = a.rn;
     if (in_b) {
-        layer16<16, 0, 8, EPI_TANH>(a, xb, aux, xa, vec, p, wave, lane);
-        layer16<16, 0, 1, EPI_HEAD_TANH>(a, xb, aux, xb, vec, p, wave, lane);
+        layer16<8, 0, 8, 2, EPI_TANH>(xb, aux, xa, vec, p, wave, lane);
+        layer16<8, 0, 1, 1, EPI_HEAD_TANH>(xb, aux, xb, vec, p, wave, lane);
     } else {
-        layer16<16, 0, 8, EPI_TANH>(a, xa, aux, xb, vec, p, wave, lane);
-        layer16<16, 0, 1, EPI_HEAD_TANH>(a, xa, aux, xa, vec, p, wave, lane);
+        layer16<8, 0, 8, 2, EPI_TANH>(xa, aux, xb, vec, p, wave, lane);
+        layer16<8, 0, 1, 1, EPI_HEAD_TANH>(xa, aux, xa, vec, p, wave, lane);
     }
     in_b = !in_b;   // the features are in the other set now
-    // the head's outputs sit in the h == 0 half; the h == 1 half of the same point needs them for the aux operand
+    // the head's outputs sit in the g == 0 lanes; the other lane groups of the same point need them for the aux operand
     float nrm[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) nrm[c] = __shfl(vec[c], lane & 31, 64);
+    for (int c = 0; c < 3; ++c) nrm[c] = __shfl(vec[c], lane & 15, 64);
 
     // ---- rendering net: aux = [p(3), d(3), sin/cos(2^k d)(6L), n(3)] -------------------------------------
     {
@@ -483,44 +489,32 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
         for (int o = 0; o < 6; ++o)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                if (o < rn.multires) sincosf(d[c] * (float)(1 << o), &sn[3 * o + c], &cs[3 * o + c]);
+                if (o < rn_multires) sincosf(d[c] * (float)(1 << o), &sn[3 * o + c], &cs[3 * o + c]);
                 else { sn[3 * o + c] = 0.f; cs[3 * o + c] = 0.f; }
             }
-        const int ncol = 6 + 6 * rn.multires;   // first normal column
-        auto rn_aux = [&](int k) -> float {
+        const int ncol = 6 + 6 * rn_multires;   // first normal column
+        build_aux(aux, g, [&](int k) -> float {
             if (k < 3) return x[k];
             if (k >= ncol) return k < ncol + 3 ? nrm[k - ncol] : 0.f;
-            return enc_value(d, sn, cs, rn.multires, k - 3);
-        };
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            half8 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                const float v0 = h ? rn_aux(16 * s + 8 + j) : rn_aux(16 * s + j);
-                const float v1 = h ? rn_aux(16 * s + 8 + j + 1) : rn_aux(16 * s + j + 1);
-                _Float16 h0, h1, l0, l1;
-                split2(v0, v1, h0, h1, l0, l1);
-                hi[j] = h0; hi[j + 1] = h1; lo[j] = l0; lo[j + 1] = l1;
-            }
-            aux.hi[s] = hi; aux.lo[s] = lo;
-        }
+            return enc_value(d, sn, cs, rn_multires, k - 3);
+        });
     }
     float rgb[3] = {0.f, 0.f, 0.f};
-    for (int hh = 0; hh < rn.n_hidden; ++hh) {
+    const int rn_hidden = a.rn.n_hidden;
+    for (int hh = 0; hh < rn_hidden; ++hh) {
         if (in_b) {
-            if (hh == 0) layer16<16, 3, 8, EPI_RELU>(a, xb, aux, xa, rgb, p, wave, lane);
-            else layer16<16, 0, 8, EPI_RELU>(a, xb, aux, xa, rgb, p, wave, lane);
+            if (hh == 0) layer16<8, 2, 8, 2, EPI_RELU>(xb, aux, xa, rgb, p, wave, lane);
+            else layer16<8, 0, 8, 2, EPI_RELU>(xb, aux, xa, rgb, p, wave, lane);
         } else {
-            if (hh == 0) layer16<16, 3, 8, EPI_RELU>(a, xa, aux, xb, rgb, p, wave, lane);
-            else layer16<16, 0, 8, EPI_RELU>(a, xa, aux, xb, rgb, p, wave, lane);
+            if (hh == 0) layer16<8, 2, 8, 2, EPI_RELU>(xa, aux, xb, rgb, p, wave, lane);
+            else layer16<8, 0, 8, 2, EPI_RELU>(xa, aux, xb, rgb, p, wave, lane);
         }
         in_b = !in_b;
     }
-    if (in_b) layer16<16, 0, 1, EPI_HEAD_SIGMOID>(a, xb, aux, xa, rgb, p, wave, lane);
-    else layer16<16, 0, 1, EPI_HEAD_SIGMOID>(a, xa, aux, xb, rgb, p, wave, lane);
+    if (in_b) layer16<8, 0, 1, 1, EPI_HEAD_SIGMOID>(xb, aux, xa, rgb, p, wave, lane);
+    else layer16<8, 0, 1, 1, EPI_HEAD_SIGMOID>(xa, aux, xb, rgb, p, wave, lane);
     // outputs last: the only vector-memory stores of the kernel come after the last counted wait
-    if (in && h == 0) {
+    if (in && g == 0) {
         a.out_vec[m * 3 + 0] = nrm[0]; a.out_vec[m * 3 + 1] = nrm[1]; a.out_vec[m * 3 + 2] = nrm[2];
         a.out_colors[m * 3 + 0] = rgb[0]; a.out_colors[m * 3 + 1] = rgb[1]; a.out_colors[m * 3 + 2] = rgb[2];
     }
@@ -528,27 +522,27 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
 
 // chunk list in consumption order
 int push_chunks(Mlp16Args& a, const Plan16& pl, int net, int h) {
-    const uint32_t kb = 2u * (pl.act16[h] + pl.aux16[h]) + 1u;
-    for (uint32_t nt = 0; nt < pl.n_tiles[h]; ++nt) {
+    const uint32_t kb = 4u * (pl.act16[h] + pl.aux16[h]) + 1u;
+    for (uint32_t ck = 0; ck < pl.n_tiles[h]; ++ck) {
         if (a.n_chunks >= VFN16_MAX_CHUNKS) return VFN_ERR_UNSUPPORTED;
-        a.chunk[a.n_chunks++] = ((uint32_t)net << 31) | ((pl.off_kb[h] + nt * kb) << 8) | kb;
+        a.chunk[a.n_chunks++] = ((uint32_t)net << 31) | ((pl.off_kb[h] + ck * kb) << 8) | kb;
     }
     return VFN_OK;
 }
 int push_head(Mlp16Args& a, const Plan16& pl, int net) {
     if (a.n_chunks >= VFN16_MAX_CHUNKS) return VFN_ERR_UNSUPPORTED;
-    a.chunk[a.n_chunks++] = ((uint32_t)net << 31) | (pl.head_off_kb << 8) | 33u;
+    a.chunk[a.n_chunks++] = ((uint32_t)net << 31) | (pl.head_off_kb << 8) | 17u;
     return VFN_OK;
 }
 
 int check_family(const Plan16& vf, const char* what) {
     // the f16x3 kernel is specialised for the shipped layer shapes: first layer encoding-only, optional narrow layer
-    // (7 tiles) before a skip layer (14 + 3 K-blocks), everything else 256 x 256
-    if (vf.act16[0] != 0 || vf.aux16[0] != 3 || vf.n_tiles[0] != 8) { vfn_set_error("%s: unsupported first layer", what); return VFN_ERR_UNSUPPORTED; }
+    // (7 chunks) before a skip layer (7 + 2 K-blocks), everything else 256 x 256
+    if (vf.act16[0] != 0 || vf.aux16[0] != 2 || vf.n_tiles[0] != 8) { vfn_set_error("%s: unsupported first layer", what); return VFN_ERR_UNSUPPORTED; }
     const int n_plain = vf.n_hidden - vf.feat_layer;
     for (int h = 1; h < n_plain; ++h) {
         const bool skip = vf.aux16[h] != 0;
-        if ((skip && vf.act16[h] != 14) || (!skip && vf.act16[h] != 16) || (vf.n_tiles[h] != 8 && vf.n_tiles[h] != 7) ||
+        if ((skip && vf.act16[h] != 7) || (!skip && vf.act16[h] != 8) || (vf.n_tiles[h] != 8 && vf.n_tiles[h] != 7) ||
             (skip && vf.n_tiles[h] != 8)) {
             vfn_set_error("%s: hidden layer %d has a shape the f16x3 kernel is not specialised for", what, h);
             return VFN_ERR_UNSUPPORTED;
@@ -574,8 +568,8 @@ extern "C" int vfn_vf_mlp16_fwd(const vfn_net_geom* geom, const void* packed16, 
     for (int h = 0; h < n_plain; ++h)
         if ((rc = push_chunks(a, a.vf, 0, h)) != VFN_OK) { vfn_set_error("vfn_vf_mlp16_fwd: too many weight chunks"); return rc; }
     if ((rc = push_head(a, a.vf, 0)) != VFN_OK) { vfn_set_error("vfn_vf_mlp16_fwd: too many weight chunks"); return rc; }
-    const long long blocks = (n_points + 127) / 128;
-    hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_VEC>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
+    hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_VEC>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_mlp16_fwd");
 }
 
@@ -593,7 +587,7 @@ extern "C" int vfn_vf_render_fused16_fwd(const vfn_net_geom* vf_geom, const void
     if (rc != VFN_OK) return rc;
     VFN_REQUIRE(a.vf.feat_layer && vf_geom->feature_dims == VFN_HIDDEN && rn_geom->feature_dims == VFN_HIDDEN,
                 "vfn_vf_render_fused16_fwd: both nets need feature_dims == %d", VFN_HIDDEN);
-    VFN_REQUIRE(a.rn.act16[0] == 16 && a.rn.aux16[0] == 3, "vfn_vf_render_fused16_fwd: unsupported rendering layer 0");
+    VFN_REQUIRE(a.rn.act16[0] == 8 && a.rn.aux16[0] == 2, "vfn_vf_render_fused16_fwd: unsupported rendering layer 0");
     VFN_REQUIRE(vf_packed16 && rn_packed16 && points && ray_dirs && normals && colors, "vfn_vf_render_fused16_fwd: NULL argument");
     VFN_REQUIRE(samples_per_ray > 0, "vfn_vf_render_fused16_fwd: samples_per_ray must be > 0");
     if (n_points <= 0) return VFN_OK;
@@ -604,7 +598,7 @@ extern "C" int vfn_vf_render_fused16_fwd(const vfn_net_geom* vf_geom, const void
     for (int h = 0; h < a.rn.n_hidden && rc == VFN_OK; ++h) rc = push_chunks(a, a.rn, 1, h);
     if (rc == VFN_OK) rc = push_head(a, a.rn, 1);
     if (rc != VFN_OK) { vfn_set_error("vfn_vf_render_fused16_fwd: too many weight chunks"); return rc; }
-    const long long blocks = (n_points + 127) / 128;
-    hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
+    hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_render_fused16_fwd");
 }
