@@ -304,10 +304,12 @@ __device__ __forceinline__ void wait_all_but(int n) {   // s_waitcnt vmcnt(n), n
 
 // End of a chunk: chunk c+1 must have landed (ours: counted wait leaving chunk c+2's DMA in flight; everyone's: barrier).
 __device__ __forceinline__ void pipe_next(Pipe& p, int wave) {
+#ifndef ABL_NOSYNC
     if (p.c + 1 < p.n_chunks) {
         wait_all_but(p.c + 2 < p.n_chunks ? dma_count(chunk_entry(p, p.c + 2), wave) : 0);
         __builtin_amdgcn_s_barrier();
     }
+#endif
     p.c += 1;
     p.slot = p.slot == 2 ? 0 : p.slot + 1;
 }
@@ -322,26 +324,53 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         // (1) keep the ring two chunks ahead
+#ifndef ABL_NODMA
         if (p.c + 2 < p.n_chunks) dma_issue(p, p.c + 2, p.slot == 0 ? 2 : p.slot - 1, wave, lane);
-        // (2) the chunk's tiles
+#endif
+        // (2) the chunk's tiles as one flat sequence of TPC * NKB steps (one K-block of one tile each).  The A
+        // fragments of step s+2 are read while the MFMAs of step s run; the order is pinned with
+        // sched_group_barrier because hipcc otherwise sinks every ds_read to just before its use and the LDS
+        // latency is paid on every step.
         const uint4* cb = p.lds + p.slot * VFN16_SLOT;
+        constexpr int STEPS = TPC * NKB;
         f32x4v acc[TPC];
 #pragma unroll
-        for (int t = 0; t < TPC; ++t) {
-            acc[t] = reinterpret_cast<const f32x4v*>(cb + TPC * NKB * 2 * 64)[t * 4 + g];
-            const uint4* tb = cb + t * NKB * 2 * 64;
+        for (int t = 0; t < TPC; ++t) acc[t] = reinterpret_cast<const f32x4v*>(cb + STEPS * 2 * 64)[t * 4 + g];
+        half8 fh[3], fl[3];
+        fh[0] = __builtin_bit_cast(half8, cb[0 * 64 + lane]);
+        fl[0] = __builtin_bit_cast(half8, cb[1 * 64 + lane]);
+        if (STEPS > 1) {
+            fh[1] = __builtin_bit_cast(half8, cb[2 * 64 + lane]);
+            fl[1] = __builtin_bit_cast(half8, cb[3 * 64 + lane]);
+        }
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb) {
-                const half8 a_hi = __builtin_bit_cast(half8, tb[(2 * kb) * 64 + lane]);
-                const half8 a_lo = __builtin_bit_cast(half8, tb[(2 * kb + 1) * 64 + lane]);
-                const half8 x_hi = kb < ACT ? xin.hi[kb < ACT ? kb : 0] : aux.hi[kb >= ACT ? kb - ACT : 0];
-                const half8 x_lo = kb < ACT ? xin.lo[kb < ACT ? kb : 0] : aux.lo[kb >= ACT ? kb - ACT : 0];
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, x_hi, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, x_lo, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, x_hi, acc[t], 0, 0, 0);
+        for (int st = 0; st < STEPS; ++st) {
+            if (st + 2 < STEPS) {
+                fh[(st + 2) % 3] = __builtin_bit_cast(half8, cb[(2 * (st + 2)) * 64 + lane]);
+                fl[(st + 2) % 3] = __builtin_bit_cast(half8, cb[(2 * (st + 2) + 1) * 64 + lane]);
             }
+            const int t = st / NKB, kb = st % NKB;
+            const half8 a_hi = fh[st % 3], a_lo = fl[st % 3];
+            const half8 x_hi = kb < ACT ? xin.hi[kb < ACT ? kb : 0] : aux.hi[kb >= ACT ? kb - ACT : 0];
+            const half8 x_lo = kb < ACT ? xin.lo[kb < ACT ? kb : 0] : aux.lo[kb >= ACT ? kb - ACT : 0];
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, x_hi, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, x_lo, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, x_hi, acc[t], 0, 0, 0);
+        }
+        // schedule: bias + the first two steps' reads, then per step [2 reads for step s+2 | 3 MFMAs of step s]
+        __builtin_amdgcn_sched_group_barrier(0x100, TPC + (STEPS > 1 ? 4 : 2), 0);
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            if (st + 2 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
         }
         // (3) epilogue: the tile pair becomes K-block `ch` of the next layer's operand
+#ifdef ABL_NOEPI
+        if (EPI == EPI_RELU || EPI == EPI_TANH) {
+            asm volatile("" :: "v"(acc[0]), "v"(acc[TPC - 1]));
+            xout.hi[ch] = xin.hi[0]; xout.lo[ch] = xin.lo[0];
+        } else
+#endif
         if (EPI == EPI_RELU || EPI == EPI_TANH) {
             half8 hi, lo;
 #pragma unroll
@@ -398,8 +427,10 @@ __device__ __forceinline__ void build_aux(A16& aux, int g, F col) {
 
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void vfn_mlp16_kernel(const Mlp16Args a) {
-    __shared__ __attribute__((aligned(16))) uint4 s_ring[3 * VFN16_SLOT];
-    __shared__ uint32_t s_tab[VFN16_MAX_CHUNKS];
+    // ONE __shared__ object: a second one beside an LDS-DMA destination makes hipcc drain vmcnt(0) before every
+    // first ds_read after a DMA issue (cdna_hip_programming.md, "three .s-level traps")
+    __shared__ __attribute__((aligned(16))) uint4 s_ring[3 * VFN16_SLOT + VFN16_MAX_CHUNKS / 4];
+    uint32_t* s_tab = reinterpret_cast<uint32_t*>(s_ring + 3 * VFN16_SLOT);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
