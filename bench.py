@@ -33,6 +33,7 @@ import torch  # noqa: E402
 
 VF_MACS, RN_MACS = 525056, 271360          # per point
 PEAK_F32_MFMA = 157.3                      # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_F16_MFMA = 2500.0                     # TFLOP/s dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 
 
 def build_scene(dev, n_rays, s_c, n_f, seed):
@@ -148,6 +149,9 @@ def main() -> None:
     ap.add_argument("--coarse", type=int, default=64)
     ap.add_argument("--fine", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=("f16x3", "fp32"), default="f16x3",
+                    help="MLP kernels: f16x3 = split-half products on the f16 matrix cores, fp32 accumulate (default, "
+                         "fp32-equivalent accuracy); fp32 = exact fp32 MFMA")
     ap.add_argument("--train", action="store_true",
                     help="time a training step instead (render with autograd + 2 supervision VF forwards + loss + "
                          "backward + clip + Adam, train/vector_field_nerf_train.py:177-260); not the headline metric")
@@ -173,6 +177,7 @@ def main() -> None:
     s_c, n_f = args.coarse, args.fine
     s_t = s_c + n_f
     model, uv, pose, K = build_scene(dev, args.rays, s_c, n_f, seed=rank)
+    model.precision = args.precision
 
     def sync():
         if dist is not None:
@@ -207,20 +212,31 @@ def main() -> None:
         flops_launch = 2.0 * s_t * (VF_MACS + RN_MACS) * args.rays
         achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
         hits = float((out.coarse_depth_map > 0).float().mean())
+        f16 = args.precision == "f16x3"
+        roof = {"bound": "mfma",
+                "kernel": ("vfn_mlp16_kernel<M16_FUSED>" if f16 else "vfn_mlp_kernel<MODE_FUSED>") +
+                          " (VF MLP + rendering MLP, fine pass)",
+                # peak / frac follow BASELINE.md §3: the fp32-matrix roofline the north star is stated against
+                "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": None,
+                "flops_per_launch": flops_launch, "avg_launch_ms": round(kernel_ms, 4)}
+        if f16:
+            # the f16x3 kernel spends 3 f16 MFMA products per fp32-equivalent product: its own matrix-pipe ceiling
+            roof.update({"mfma_dtype": "f16 (3 products per fp32-equivalent product, fp32 accumulate)",
+                         "f16_dense_peak": PEAK_F16_MFMA,
+                         "frac_of_f16x3_ceiling": round(achieved / (PEAK_F16_MFMA / 3.0), 4),
+                         "frac_of_f16_dense_peak": round(achieved / PEAK_F16_MFMA, 4)})
         line = {
             "metric": "rays/sec (4096-ray chunk, 128 samples/ray)",
             "value": round(rays_per_s, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16x3+f32acc" if f16 else "f32", "data": "synthetic",
             "config": {"workload": f"VectorFieldNerf.render forward, {args.rays}-ray chunk x {s_t} samples/ray "
                                    f"(S_c={s_c} + N_f={n_f}), shipped 9x256 VF + 5x256 rendering MLPs, eval-mode BN, "
                                    f"stratified sampling on device Philox, Replica-like 1200x680 pinhole",
                        "rays_per_chunk_per_gpu": args.rays, "samples_per_ray": s_t, "parallelism": f"rays x{world}",
                        "rays_with_nonzero_depth": round(hits, 3)},
-            "roofline": {"bound": "mfma", "kernel": "vfn_mlp_kernel<MODE_FUSED> (VF MLP + rendering MLP, fine pass)",
-                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": None,
-                         "flops_per_launch": flops_launch, "avg_launch_ms": round(kernel_ms, 4)},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, uv, pose, K, s_c, n_f)
