@@ -273,6 +273,11 @@ __device__ __forceinline__ void split2(float a, float b, _Float16& h0, _Float16&
     h0 = hi[0]; h1 = hi[1]; l0 = lo[0]; l1 = lo[1];
 }
 
+// tanh through one exp: 1 - 2 / (1 + e^{2v}).  Absolute error ~1e-7 (the subtraction rounds at 1 ulp of 1), which is
+// what matters for values that feed the next layer in fp32-equivalent arithmetic; saturates correctly to +-1.
+// The ocml tanhf expands to a long two-branch sequence whose temporaries spilled to scratch in the unrolled epilogue.
+__device__ __forceinline__ float tanh_exp(float v) { return 1.0f - 2.0f / (1.0f + expf(2.0f * v)); }
+
 __device__ __forceinline__ uint32_t chunk_entry(const Pipe& p, int idx) {
     return __builtin_amdgcn_readfirstlane(p.tab[idx]);
 }
@@ -377,7 +382,7 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
             for (int j = 0; j < 8; j += 2) {
                 float v0 = acc[j >> 2][j & 3] * VFN16_INV_WSCALE, v1 = acc[j >> 2][(j & 3) + 1] * VFN16_INV_WSCALE;
                 if (EPI == EPI_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                else { v0 = tanhf(v0); v1 = tanhf(v1); }
+                else { v0 = tanh_exp(v0); v1 = tanh_exp(v1); }
                 _Float16 h0, h1, l0, l1;
                 split2(v0, v1, h0, h1, l0, l1);
                 hi[j] = h0; hi[j + 1] = h1; lo[j] = l0; lo[j + 1] = l1;
@@ -388,7 +393,7 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float v = acc[0][c] * VFN16_INV_WSCALE;
-                head[c] = (EPI == EPI_HEAD_TANH) ? tanhf(v) : 1.0f / (1.0f + expf(-v));
+                head[c] = (EPI == EPI_HEAD_TANH) ? tanh_exp(v) : 1.0f / (1.0f + expf(-v));
             }
         }
         // (4) hand over to the next chunk
@@ -429,8 +434,12 @@ template <int MODE>
 __global__ __launch_bounds__(512, 2) void vfn_mlp16_kernel(const Mlp16Args a) {
     // ONE __shared__ object: a second one beside an LDS-DMA destination makes hipcc drain vmcnt(0) before every
     // first ds_read after a DMA issue (cdna_hip_programming.md, "three .s-level traps")
-    __shared__ __attribute__((aligned(16))) uint4 s_ring[3 * VFN16_SLOT + VFN16_MAX_CHUNKS / 4];
+    __shared__ __attribute__((aligned(16))) uint4 s_ring[3 * VFN16_SLOT + VFN16_MAX_CHUNKS / 4 + 512 * 2];
     uint32_t* s_tab = reinterpret_cast<uint32_t*>(s_ring + 3 * VFN16_SLOT);
+    // per-thread parking space for the point and its view direction (8 floats): they are needed again only when
+    // the rendering net's aux operand is built, ~100 chunks later, and would otherwise be spilled to scratch —
+    // private-memory traffic that shows up as ~0.7 GB of HBM reads+writes per launch and perturbs the vmcnt waits
+    float* s_park = reinterpret_cast<float*>(s_ring + 3 * VFN16_SLOT + VFN16_MAX_CHUNKS / 4) + threadIdx.x * 8;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -449,6 +458,10 @@ __global__ __launch_bounds__(512, 2) void vfn_mlp16_kernel(const Mlp16Args a) {
         d[0] = a.ray_dirs[di * 3 + 0]; d[1] = a.ray_dirs[di * 3 + 1]; d[2] = a.ray_dirs[di * 3 + 2];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (MODE == M16_FUSED) {
+        s_park[0] = x[0]; s_park[1] = x[1]; s_park[2] = x[2];
+        s_park[4] = d[0]; s_park[5] = d[1]; s_park[6] = d[2];
+    }
     __syncthreads();   // chunk list visible
 
     Pipe p;
@@ -515,19 +528,21 @@ __global__ __launch_bounds__(512, 2) void vfn_mlp16_kernel(const Mlp16Args a) {
 
     // ---- rendering net: aux = [p(3), d(3), sin/cos(2^k d)(6L), n(3)] -------------------------------------
     {
+        float xr[3] = {s_park[0], s_park[1], s_park[2]};
+        float dr[3] = {s_park[4], s_park[5], s_park[6]};
         float sn[18], cs[18];
 #pragma unroll
         for (int o = 0; o < 6; ++o)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                if (o < rn_multires) sincosf(d[c] * (float)(1 << o), &sn[3 * o + c], &cs[3 * o + c]);
+                if (o < rn_multires) sincosf(dr[c] * (float)(1 << o), &sn[3 * o + c], &cs[3 * o + c]);
                 else { sn[3 * o + c] = 0.f; cs[3 * o + c] = 0.f; }
             }
         const int ncol = 6 + 6 * rn_multires;   // first normal column
         build_aux(aux, g, [&](int k) -> float {
-            if (k < 3) return x[k];
+            if (k < 3) return xr[k];
             if (k >= ncol) return k < ncol + 3 ? nrm[k - ncol] : 0.f;
-            return enc_value(d, sn, cs, rn_multires, k - 3);
+            return enc_value(dr, sn, cs, rn_multires, k - 3);
         });
     }
     float rgb[3] = {0.f, 0.f, 0.f};
