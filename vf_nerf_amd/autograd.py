@@ -42,7 +42,7 @@ def fine_pass(model, pts: torch.Tensor, z: torch.Tensor, ray_dirs: torch.Tensor)
     if torch.is_grad_enabled() and any(p.requires_grad for p in model.unique_parameters()):
         from .backward import fine_pass_autograd
         return fine_pass_autograd(model, pts, z, ray_dirs)
-    f16 = getattr(model, "precision", "fp32") == "f16x3"
+    f16 = model.uses_f16x3()
     vf_w, rn_w = (vf.packed16_weights(), rn.packed16_weights()) if f16 else (vf.packed_weights(), rn.packed_weights())
     events = getattr(model, "_kernel_events", None)  # bench.py: HIP events around the dominant kernel
     if events is not None:

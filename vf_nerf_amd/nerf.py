@@ -169,6 +169,13 @@ class VectorFieldNerf:
     # ---------------------------------------------------------------------------------------------
     # helpers
     # ---------------------------------------------------------------------------------------------
+    def uses_f16x3(self) -> bool:
+        """f16x3 inference kernels are used when requested AND specialised for both networks' geometry."""
+        if self.precision not in ("f16x3", "fp32"):
+            raise ValueError(f"precision must be 'f16x3' or 'fp32', got {self.precision!r}")
+        return self.precision == "f16x3" and self.vector_field_network.supports_f16x3() and \
+            self.rendering_network.supports_f16x3()
+
     def _anneal(self, epoch: int, device) -> None:
         if self.config.cos_sim_weights_anneal != "none" and epoch > self.config.anneal_start:
             self.config.cos_sim_weights = self.annealing.get_weights(epoch - self.config.anneal_start, device)
@@ -248,7 +255,7 @@ class VectorFieldNerf:
             directions, ray_dirs, cam_loc, z_c, pts_c = self._rays(pose, pixels, intrinsics, u_coarse)
             # (3) VF net, vector columns only
             vf = self.vector_field_network
-            if self.precision == "f16x3":
+            if self.uses_f16x3():
                 normals_c = lib.vf_mlp16_fwd(vf.geometry(), vf.packed16_weights(), pts_c.view(-1, 3))
             else:
                 normals_c = lib.vf_mlp_fwd(vf.geometry(), vf.packed_weights(), pts_c.view(-1, 3), 3)

@@ -102,6 +102,19 @@ class _PackedMLP(nn.Module):
             self._packed16_cache = (key, buf)
         return self._packed16_cache[1]
 
+    def supports_f16x3(self) -> bool:
+        """True when the f16x3 kernels are specialised for this geometry (the shipped layer shapes); otherwise the
+        facade uses the exact-fp32 HIP kernels (never a CPU path)."""
+        ok = getattr(self, "_f16x3_ok", None)
+        if ok is None:
+            try:
+                lib.pack16_size(self._kind, self.geometry())
+                ok = True
+            except lib.VfnError:
+                ok = False
+            self._f16x3_ok = ok
+        return ok
+
     def _require_eval_bn(self) -> None:
         if self.training and any(self._bn(i) is not None for i in range(self.num_layers)):
             raise NotImplementedError(
