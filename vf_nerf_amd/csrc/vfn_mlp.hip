@@ -254,6 +254,7 @@ extern "C" int vfn_vf_mlp_fwd(const vfn_net_geom* geom, const float* packed, con
     MlpArgs a = {};
     int rc = plan_or_error(VFN_NET_VF, geom, &a.vf, "vfn_vf_mlp_fwd");
     if (rc != VFN_OK) return rc;
+    if (n_points <= 0) return VFN_OK;
     VFN_REQUIRE(packed && points && out, "vfn_vf_mlp_fwd: NULL argument");
     VFN_REQUIRE(out_cols == 3 || (geom->feature_dims > 0 && out_cols == 3 + geom->feature_dims),
                 "vfn_vf_mlp_fwd: out_cols=%d must be 3 or 3+feature_dims", out_cols);
@@ -269,6 +270,7 @@ extern "C" int vfn_render_mlp_fwd(const vfn_net_geom* geom, const float* packed,
     int rc = plan_or_error(VFN_NET_RENDER, geom, &a.rn, "vfn_render_mlp_fwd");
     if (rc != VFN_OK) return rc;
     VFN_REQUIRE(geom->feature_dims == VFN_HIDDEN, "vfn_render_mlp_fwd: feature_dims must be %d", VFN_HIDDEN);
+    if (n_points <= 0) return VFN_OK;
     VFN_REQUIRE(packed && points && normals && view_dirs && feats && colors, "vfn_render_mlp_fwd: NULL argument");
     a.rn_w = packed; a.points = points; a.normals_in = normals; a.view_dirs = view_dirs; a.feats_in = feats;
     a.out_colors = colors; a.n_points = n_points; a.dirs_div = 1;
@@ -286,6 +288,7 @@ extern "C" int vfn_vf_render_fused_fwd(const vfn_net_geom* vf_geom, const float*
     if (rc != VFN_OK) return rc;
     VFN_REQUIRE(vf_geom->feature_dims == VFN_HIDDEN && rn_geom->feature_dims == VFN_HIDDEN,
                 "vfn_vf_render_fused_fwd: both nets need feature_dims == %d", VFN_HIDDEN);
+    if (n_points <= 0) return VFN_OK;
     VFN_REQUIRE(vf_packed && rn_packed && points && ray_dirs && normals && colors, "vfn_vf_render_fused_fwd: NULL argument");
     VFN_REQUIRE(samples_per_ray > 0, "vfn_vf_render_fused_fwd: samples_per_ray must be > 0");
     a.vf_w = vf_packed; a.rn_w = rn_packed; a.points = points; a.view_dirs = ray_dirs; a.out_vec = normals;
@@ -299,6 +302,7 @@ extern "C" int vfn_vf_mlp_fwd_train(const vfn_net_geom* geom, const float* packe
     MlpArgs a = {};
     int rc = plan_or_error(VFN_NET_VF, geom, &a.vf, "vfn_vf_mlp_fwd_train");
     if (rc != VFN_OK) return rc;
+    if (n_points <= 0) return VFN_OK;
     VFN_REQUIRE(packed && points && out && save_act && save_aux_vf, "vfn_vf_mlp_fwd_train: NULL argument");
     VFN_REQUIRE(out_cols == 3 || (geom->feature_dims > 0 && out_cols == 3 + geom->feature_dims),
                 "vfn_vf_mlp_fwd_train: out_cols=%d must be 3 or 3+feature_dims", out_cols);
@@ -320,6 +324,7 @@ extern "C" int vfn_vf_render_fused_fwd_train(const vfn_net_geom* vf_geom, const 
     if (rc != VFN_OK) return rc;
     VFN_REQUIRE(vf_geom->feature_dims == VFN_HIDDEN && rn_geom->feature_dims == VFN_HIDDEN,
                 "vfn_vf_render_fused_fwd_train: both nets need feature_dims == %d", VFN_HIDDEN);
+    if (n_points <= 0) return VFN_OK;
     VFN_REQUIRE(vf_packed && rn_packed && points && ray_dirs && normals && colors && save_act && save_aux_vf && save_aux_rn,
                 "vfn_vf_render_fused_fwd_train: NULL argument");
     VFN_REQUIRE(samples_per_ray > 0, "vfn_vf_render_fused_fwd_train: samples_per_ray must be > 0");

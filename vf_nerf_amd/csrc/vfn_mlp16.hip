@@ -607,8 +607,8 @@ extern "C" int vfn_vf_mlp16_fwd(const vfn_net_geom* geom, const void* packed16, 
     if (rc != VFN_OK) return rc;
     rc = check_family(a.vf, "vfn_vf_mlp16_fwd");
     if (rc != VFN_OK) return rc;
-    VFN_REQUIRE(packed16 && points && out_vec, "vfn_vf_mlp16_fwd: NULL argument");
     if (n_points <= 0) return VFN_OK;
+    VFN_REQUIRE(packed16 && points && out_vec, "vfn_vf_mlp16_fwd: NULL argument");
     a.vf_w = (const uint4*)packed16; a.points = points; a.out_vec = out_vec; a.n_points = n_points; a.dirs_div = 1;
     const int n_plain = a.vf.n_hidden - a.vf.feat_layer;
     for (int h = 0; h < n_plain; ++h)
@@ -634,9 +634,9 @@ extern "C" int vfn_vf_render_fused16_fwd(const vfn_net_geom* vf_geom, const void
     VFN_REQUIRE(a.vf.feat_layer && vf_geom->feature_dims == VFN_HIDDEN && rn_geom->feature_dims == VFN_HIDDEN,
                 "vfn_vf_render_fused16_fwd: both nets need feature_dims == %d", VFN_HIDDEN);
     VFN_REQUIRE(a.rn.act16[0] == 8 && a.rn.aux16[0] == 2, "vfn_vf_render_fused16_fwd: unsupported rendering layer 0");
+    if (n_points <= 0) return VFN_OK;
     VFN_REQUIRE(vf_packed16 && rn_packed16 && points && ray_dirs && normals && colors, "vfn_vf_render_fused16_fwd: NULL argument");
     VFN_REQUIRE(samples_per_ray > 0, "vfn_vf_render_fused16_fwd: samples_per_ray must be > 0");
-    if (n_points <= 0) return VFN_OK;
     a.vf_w = (const uint4*)vf_packed16; a.rn_w = (const uint4*)rn_packed16; a.points = points; a.ray_dirs = ray_dirs;
     a.out_vec = normals; a.out_colors = colors; a.n_points = n_points; a.dirs_div = samples_per_ray;
     for (int h = 0; h < a.vf.n_hidden && rc == VFN_OK; ++h) rc = push_chunks(a, a.vf, 0, h);

@@ -355,9 +355,9 @@ extern "C" int vfn_mlp_bwd_chain(const vfn_net_geom* vf_geom, const float* vf_pa
         VFN_REQUIRE(rn_packed && rn_packed_bwd && d_colors && colors && dz_rgb, "vfn_mlp_bwd_chain: NULL rendering-net argument");
         VFN_REQUIRE(vf_geom->feature_dims == VFN_HIDDEN, "vfn_mlp_bwd_chain: fused mode needs feature_dims == %d", VFN_HIDDEN);
     }
+    if (n_points <= 0) return VFN_OK;
     VFN_REQUIRE(vf_packed && vf_packed_bwd && saved && dy && d_vec && vec && dz_vec, "vfn_mlp_bwd_chain: NULL argument");
     VFN_REQUIRE(vec_stride >= 3, "vfn_mlp_bwd_chain: vec_stride must be >= 3");
-    if (n_points <= 0) return VFN_OK;
     a.vf_w = vf_packed; a.vf_wb = vf_packed_bwd; a.rn_w = rn_packed; a.rn_wb = rn_packed_bwd;
     a.saved = saved; a.dy = dy; a.d_colors = d_colors; a.colors = colors; a.d_vec = d_vec; a.vec = vec;
     a.d_feats = d_feats; a.dz_rgb = dz_rgb; a.dz_vec = dz_vec; a.n_points = n_points; a.vec_stride = vec_stride;

@@ -622,6 +622,7 @@ __global__ void vfn_uniform_kernel(float* out, long long n, unsigned long long s
 extern "C" int vfn_raygen_uniform(const vfn_raygen_params* p, const float* uv, const float* pose, const float* intrinsics,
                                   const float* t_vals, const float* far_per_ray, const float* u_coarse, float* directions,
                                   float* ray_dirs, float* cam_loc, float* z_vals, float* points, void* stream) {
+    if (p && p->n_rays == 0) return VFN_OK;   // empty batch: nothing to launch (device pointers may be NULL)
     VFN_REQUIRE(p && uv && pose && intrinsics && t_vals && directions && ray_dirs && cam_loc && z_vals && points,
                 "vfn_raygen_uniform: NULL argument");
     VFN_REQUIRE(p->n_rays >= 0 && p->n_samples >= 1, "vfn_raygen_uniform: bad sizes (n_rays=%d, n_samples=%d)", p->n_rays,
@@ -636,6 +637,7 @@ extern "C" int vfn_raygen_uniform(const vfn_raygen_params* p, const float* uv, c
 extern "C" int vfn_ray_density_weights(const vfn_density_params* p, const float* normals, const float* ray_dirs,
                                        const float* z_vals, const float* density_scalars, const float* colors, float* sigma,
                                        float* weights, int64_t* argmax, float* rgb, float* depth, void* stream) {
+    if (p && p->n_rays <= 0) return VFN_OK;
     VFN_REQUIRE(p && normals && ray_dirs && z_vals && density_scalars, "vfn_ray_density_weights: NULL argument");
     VFN_REQUIRE(p->n_samples >= 2 && p->n_samples <= MAX_SAMPLES, "vfn_ray_density_weights: n_samples=%d outside [2,%d]",
                 p->n_samples, MAX_SAMPLES);
@@ -652,6 +654,7 @@ extern "C" int vfn_ray_density_weights(const vfn_density_params* p, const float*
 extern "C" int vfn_range_fine_sample(const vfn_fine_params* p, const float* z_coarse, const int64_t* argmax,
                                      const float* directions, const float* cam_loc, const float* far_per_ray,
                                      const float* u_fine, const float* u_add, float* z_vals, float* points, void* stream) {
+    if (p && p->n_rays <= 0) return VFN_OK;
     VFN_REQUIRE(p && z_coarse && argmax && directions && cam_loc && u_add && z_vals && points,
                 "vfn_range_fine_sample: NULL argument (u_add is always required, ray_sampler.py:292)");
     VFN_REQUIRE(p->n_coarse >= 1 && p->n_fine >= 2 && p->n_coarse + p->n_fine <= MAX_SAMPLES,
@@ -678,6 +681,7 @@ extern "C" int vfn_ray_density_weights_bwd(const vfn_density_params* p, const fl
                                            const float* z_vals, const float* density_scalars, const float* colors,
                                            const float* d_rgb, const float* d_depth, const float* d_weights,
                                            float* d_normals, float* d_colors, float* d_scalars, void* stream) {
+    if (p && p->n_rays <= 0) return VFN_OK;
     VFN_REQUIRE(p && normals && ray_dirs && z_vals && density_scalars && d_normals, "vfn_ray_density_weights_bwd: NULL argument");
     VFN_REQUIRE(p->n_samples >= 2 && p->n_samples <= MAX_SAMPLES_BWD,
                 "vfn_ray_density_weights_bwd: n_samples=%d outside [2,%d]", p->n_samples, MAX_SAMPLES_BWD);
