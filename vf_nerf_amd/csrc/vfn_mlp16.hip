@@ -281,8 +281,17 @@ __device__ __forceinline__ float tanh_exp(float v) { return 1.0f - 2.0f / (1.0f 
 __device__ __forceinline__ uint32_t chunk_entry(const Pipe& p, int idx) {
     return __builtin_amdgcn_readfirstlane(p.tab[idx]);
 }
+// The DMA is issued by the first VFN16_DMA_WAVES waves only, and AFTER their MFMAs: those are the older waves, which
+// win matrix-pipe arbitration, finish each chunk's MFMAs first and would otherwise idle at the barrier; issuing an
+// LDS-DMA piece blocks a wave for ~70 cycles, so the younger (critical) waves issue none.  Interleaved A/B on one
+// GPU: -5 % kernel time vs. all eight waves issuing at the start of the chunk.
+#ifndef VFN16_DMA_WAVES
+#define VFN16_DMA_WAVES 4
+#endif
+#define EXP_DMA_WAVES VFN16_DMA_WAVES
 __device__ __forceinline__ int dma_count(uint32_t entry, int wave) {   // DMA instructions this wave issues for a chunk
     const int kb = (int)(entry & 0xffu);
+    if (EXP_DMA_WAVES != VFN16_WAVES) return (wave < EXP_DMA_WAVES && kb > wave) ? (kb - wave + EXP_DMA_WAVES - 1) / EXP_DMA_WAVES : 0;
     return kb > wave ? (kb - wave + VFN16_WAVES - 1) / VFN16_WAVES : 0;
 }
 
@@ -311,8 +320,12 @@ __device__ __forceinline__ void wait_all_but(int n) {   // s_waitcnt vmcnt(n), n
 __device__ __forceinline__ void pipe_next(Pipe& p, int wave) {
 #ifndef ABL_NOSYNC
     if (p.c + 1 < p.n_chunks) {
+#ifndef ABL_NOWAIT
         wait_all_but(p.c + 2 < p.n_chunks ? dma_count(chunk_entry(p, p.c + 2), wave) : 0);
+#endif
+#ifndef ABL_NOBARRIER
         __builtin_amdgcn_s_barrier();
+#endif
     }
 #endif
     p.c += 1;
@@ -326,11 +339,12 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
                                         int lane) {
     constexpr int NKB = ACT + AUX;
     const int g = lane >> 4;
+    const bool late_dma = wave < VFN16_DMA_WAVES;   // wave-uniform; see VFN16_DMA_WAVES
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        // (1) keep the ring two chunks ahead
+        // (1) keep the ring two chunks ahead (issued after the MFMAs, by the older waves only: see VFN16_DMA_WAVES)
 #ifndef ABL_NODMA
-        if (p.c + 2 < p.n_chunks) dma_issue(p, p.c + 2, p.slot == 0 ? 2 : p.slot - 1, wave, lane);
+        if (!late_dma && p.c + 2 < p.n_chunks) dma_issue(p, p.c + 2, p.slot == 0 ? 2 : p.slot - 1, wave, lane);
 #endif
         // (2) the chunk's tiles as one flat sequence of TPC * NKB steps (one K-block of one tile each).  The A
         // fragments of step s+2 are read while the MFMAs of step s run; the order is pinned with
@@ -396,6 +410,9 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
                 head[c] = (EPI == EPI_HEAD_TANH) ? tanh_exp(v) : 1.0f / (1.0f + expf(-v));
             }
         }
+#ifndef ABL_NODMA
+        if (late_dma && p.c + 2 < p.n_chunks) dma_issue(p, p.c + 2, p.slot == 0 ? 2 : p.slot - 1, wave, lane);
+#endif
         // (4) hand over to the next chunk
         pipe_next(p, wave);
     }
