@@ -395,7 +395,9 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
                 float v0 = acc[j >> 2][j & 3] * VFN16_INV_WSCALE, v1 = acc[j >> 2][(j & 3) + 1] * VFN16_INV_WSCALE;
-                if (EPI == EPI_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                // ReLU, saturated below the f16 range so that an out-of-family activation degrades instead of turning
+                // into inf - inf = NaN in the split (activations of BatchNorm'ed layers are O(1..100))
+                if (EPI == EPI_RELU) { v0 = fminf(fmaxf(v0, 0.f), 60000.f); v1 = fminf(fmaxf(v1, 0.f), 60000.f); }
                 else { v0 = tanh_exp(v0); v1 = tanh_exp(v1); }
                 _Float16 h0, h1, l0, l1;
                 split2(v0, v1, h0, h1, l0, l1);
