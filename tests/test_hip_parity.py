@@ -235,3 +235,45 @@ def test_grid_query_matches_full_forward():
     parts = [grid.get_set_predictions(dec, samples, 3000, dev(), rank=r, world_size=2) for r in range(2)]
     assert rel_err(parts[0] + parts[1], want) < 1e-6
     assert float(parts[0][3000:6000].abs().max()) == 0.0 and float(parts[1][:3000].abs().max()) == 0.0
+
+
+def test_quaternion_pose_rays():
+    """pose[N,7] = (qr,qi,qj,qk,tx,ty,tz): utils/rendering.py:27-33 + pinhole_model.quat_to_rot (CUDA-only in the
+    reference, Q13), against the oracle's device-free restatement."""
+    from oracle import vfnerf_oracle as O
+    from vf_nerf_amd import lib
+    gen = torch.Generator().manual_seed(2)
+    n = 77
+    q = torch.randn(n, 4, generator=gen)
+    t = torch.randn(n, 3, generator=gen)
+    pose7 = torch.cat([q, t], dim=1)
+    uv = torch.rand(n, 2, generator=gen) * 64
+    K = torch.eye(4).repeat(n, 1, 1)
+    K[:, 0, 0] = 60.0; K[:, 1, 1] = -55.0; K[:, 0, 2] = 31.5; K[:, 1, 2] = 31.5; K[:, 0, 1] = 0.3   # negative fy: z = -1
+    d_ref, rd_ref, c_ref = O.ray_directions(uv, pose7, K)
+    t_vals = torch.linspace(0., 1., steps=8).to(dev())
+    directions, ray_dirs, cam_loc, z, pts = lib.raygen_uniform(uv.to(dev()), pose7.to(dev()), K.to(dev()), t_vals, 8, 0.0, 1.0)
+    assert torch.equal(cam_loc.cpu(), c_ref)
+    assert rel_err(directions, d_ref) < 2e-6 and rel_err(ray_dirs, rd_ref) < 2e-6
+    assert float(directions.cpu()[:, :].abs().max()) > 0 and float((ray_dirs.norm(dim=1) - 1).abs().max()) < 1e-5
+
+
+def test_secondary_entry_points(case):
+    """get_vector_field / get_colors / get_weights_and_color (vector_field_nerf.py:341-440) against the oracle."""
+    from oracle import vfnerf_oracle as O
+    fx, d, g, model = case
+    n, s_t = d["z_vals"].shape
+    cpu_vf = {k: v.cpu() for k, v in model.vector_field_network.state_dict().items()}
+    cpu_rn = {k: v.cpu() for k, v in model.rendering_network.state_dict().items()}
+    rep = d["ray_dirs"].unsqueeze(1).repeat(1, s_t, 1).reshape(-1, 3)
+    with torch.no_grad():
+        w, c = model.get_weights_and_color(g["points"], rep.to(dev()), g["z_vals"], epoch=0)
+    assert rel_err(w, d["weights"]) < TIGHT and rel_err(c, d["colors"]) < TIGHT
+    if not fx["perturb"]:
+        with torch.no_grad():
+            vec = model.get_vector_field(g["pose"], g["uv"], g["intrinsics"])
+            colors, flat, rep_c = model.get_colors(g["pose"], g["uv"], g["intrinsics"], epoch=0)
+        assert rel_err(vec, d["normals_coarse"].reshape(-1, 3)) < TIGHT
+        ref_vf = O.vf_mlp(flat.cpu(), cpu_vf)
+        ref_c = O.render_mlp(flat.cpu(), ref_vf[:, :3], rep_c.cpu(), ref_vf[:, 3:], cpu_rn)
+        assert rel_err(colors, ref_c) < TIGHT
