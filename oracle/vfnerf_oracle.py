@@ -359,6 +359,37 @@ def render(uv: Tensor, pose: Tensor, intrinsics: Tensor, vf_sd: Dict[str, Tensor
     return out
 
 
+# --------------------------------------------------------------------------------------
+# training-side restatement used by the loop-parity test: VFLoss  (models/losses/vf_loss.py:34-87)
+# --------------------------------------------------------------------------------------
+@dataclass
+class LossWeights:      # confs/vf_nerf.conf:82-96
+    rgb: float = 2.0
+    depth: float = 0.5
+    unit_norm: float = 0.1
+    supervision: float = 1.0
+    norm_smaller_than_one: float = 0.1
+    directional_derivatives: float = 0.0
+    norm_smaller_than_one_start: int = 11000
+    depth_loss_clamp: float = 0.5
+
+
+def vf_loss(rgb: Tensor, depth: Tensor, normals: Tensor, supervised: Tensor, rgb_gt: Tensor, depth_gt: Tensor,
+            supervised_gt: Tensor, w: LossWeights, epoch: int = 0) -> Tensor:
+    """L1 rgb + clamped-L1 depth + unit-norm + supervision MSE (+ norm<1 after its start epoch); the
+    directional-derivative term is absent in the shipped regime (weight 0, derivatives None; Q8)."""
+    loss = w.rgb * F.l1_loss(rgb, rgb_gt)
+    if depth_gt.nelement() > 0:
+        loss = loss + w.depth * F.l1_loss(depth, depth_gt, reduction="none").clamp(max=w.depth_loss_clamp).mean()
+    flat = normals.reshape(-1, 3)
+    loss = loss + w.unit_norm * torch.mean((torch.norm(flat, dim=1) - 1) ** 2)
+    if supervised.nelement() > 0:
+        loss = loss + w.supervision * F.mse_loss(supervised, supervised_gt)
+    if epoch >= w.norm_smaller_than_one_start:
+        loss = loss + w.norm_smaller_than_one * torch.mean(torch.pow(F.relu(torch.norm(flat, dim=1) - 1), 2))
+    return loss
+
+
 def psnr(a: Tensor, b: Tensor) -> float:
     """-10 log10(mean((a-b)^2))  (utils/utils.py:235-245)."""
     mse = torch.mean((a - b) ** 2).item()
