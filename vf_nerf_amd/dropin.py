@@ -13,11 +13,11 @@ import importlib
 import sys
 import types
 
-from . import density, grid, nerf, networks, output, samplers
+from . import density, grid, nerf, networks, render_output, samplers
 
 _ALIASES = {
     "models.nerf.vector_field_nerf": nerf,
-    "models.nerf.output": output,
+    "models.nerf.output": render_output,
     "models.vector_field.vector_field_network": networks,
     "models.vector_field.rendering_network": networks,
     "models.samplers.ray_sampler": samplers,

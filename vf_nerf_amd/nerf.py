@@ -23,7 +23,7 @@ from torch import nn
 from . import lib
 from .density import LaplaceDensity
 from .networks import RenderingNetwork, VectorFieldNetwork
-from .output import NerfOutput
+from .render_output import NerfOutput
 from .samplers import RangeFineSampler, UniformSampler
 
 

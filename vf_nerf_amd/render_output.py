@@ -1,0 +1,44 @@
+"""``NerfOutput``: what ``VectorFieldNerf.render`` returns (interface of the reference's models/nerf/output.py:7-70).
+
+The attribute names are the reference's, including its quirk that every ``*_coarse`` / ``coarse_*`` attribute holds
+the result of the S_c+N_f ("fine") pass while the ``*_fine`` / ``fine_*`` attributes stay ``None``.
+The class is generated from the two name tables below: four mandatory tensors, then the optional ones.
+"""
+from __future__ import annotations
+
+from dataclasses import field, make_dataclass
+from typing import Optional
+
+import torch
+
+_MANDATORY = "points_coarse coarse_normals coarse_rgb_values coarse_depth_map".split()
+_OPTIONAL = ("mask z_vals points_fine fine_normals fine_rgb_values fine_depth_map fine_mask "
+             "directional_derivtives ray_dirs coarse_colors").split()   # "derivtives": the reference's spelling
+_DICT_KEYS = _MANDATORY + ["mask"] + [k for k in _OPTIONAL if k.startswith(("points_", "fine_"))]
+
+
+def _adjacent(t: torch.Tensor, n_rays: int, per_ray: int):
+    """[n_rays*per_ray, 3] -> (sample j, sample j+1) for j < per_ray-1, each flattened to [*, 3]."""
+    t = t.reshape(n_rays, per_ray, 3)
+    return t[:, :-1].reshape(-1, 3), t[:, 1:].reshape(-1, 3)
+
+
+def _fine_active(self) -> bool:
+    return self.fine_normals is not None
+
+
+def _get_normals(self, N_rays: int, N_coarse: int, N_fine: int):
+    """Adjacent-sample normal pairs per pass: (coarse_j, coarse_j+1, fine_j | None, fine_j+1 | None)."""
+    first = _adjacent(self.coarse_normals, N_rays, N_coarse)
+    second = _adjacent(self.fine_normals, N_rays, N_fine) if self.fine_active() else (None, None)
+    return first + second
+
+
+def _to_dict(self):
+    return {k: getattr(self, k) for k in _DICT_KEYS}
+
+
+NerfOutput = make_dataclass(
+    "NerfOutput",
+    [(n, torch.Tensor) for n in _MANDATORY] + [(n, Optional[torch.Tensor], field(default=None)) for n in _OPTIONAL],
+    namespace=dict(fine_active=_fine_active, get_normals=_get_normals, to_dict=_to_dict, __module__=__name__))
