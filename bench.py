@@ -47,11 +47,11 @@ def hbm_traffic(f16: bool):
     return int((2.0 * t["FETCH_SIZE_KB_per_launch"] + t["WRITE_SIZE_KB_per_launch"]) * 1024)
 
 
-def build_scene(dev, n_rays, s_c, n_f, seed):
+def build_scene(dev, n_rays, s_c, n_f, seed, perturb=True):
     import vf_nerf_amd
     from vf_nerf_amd import synthetic
     torch.manual_seed(0)
-    cfg = vf_nerf_amd.shipped_config(dev, n_samples=s_c, n_importance=n_f, perturb=True, dir_to_normal_th=-0.2)
+    cfg = vf_nerf_amd.shipped_config(dev, n_samples=s_c, n_importance=n_f, perturb=perturb, dir_to_normal_th=-0.2)
     model = vf_nerf_amd.VectorFieldNerf(cfg)
     model.eval()
     model.rng_seed = seed
@@ -84,14 +84,146 @@ def cpu_baseline(model, uv, pose, K, s_c, n_f, sample_rays=1024, budget_s=12.0):
         O.render(uv_c, pose_c, K_c, vf_sd, rn_sd, settings, **uni)  # warm-up
         reps, t0 = 0, time.perf_counter()
         while True:
-            O.render(uv_c, pose_c, K_c, vf_sd, rn_sd, settings, **uni)
+            ref = O.render(uv_c, pose_c, K_c, vf_sd, rn_sd, settings, **uni)
             reps += 1
             el = time.perf_counter() - t0
             if el >= budget_s or reps >= 50:
                 break
+        # the "PSNR vs ref" half of the metric: the HIP path on the same rays with the same uniforms, checked
+        # against the oracle's output (the oracle is the checker here, never the thing measured as `value`)
+        out = model.render(pose[:sample_rays], uv[:sample_rays], K[:sample_rays], epoch=0, uniforms=uni)
+    rgb, depth = out.coarse_rgb_values.cpu(), out.coarse_depth_map.cpu()
+    same = (out.z_vals.cpu() == ref["z_vals"]).all(dim=1)
+    parity = {"rays": sample_rays, "psnr_rgb_db": round(min(O.psnr(rgb, ref["rgb"]), 200.0), 2),
+              "mean_abs_depth_err": float((depth - ref["depth"].reshape(depth.shape)).abs().mean()),
+              "max_abs_rgb_err_identically_sampled_rays": float((rgb - ref["rgb"]).abs().max(dim=1)[0][same].max()),
+              "rays_sampled_bit_identically": round(float(same.float().mean()), 4)}
     return {"value": round(sample_rays * reps / el, 1), "unit": "rays/s", "cores": threads, "kind": "port",
             "sample": f"{reps} x oracle render() of {sample_rays} rays x {s_c + n_f} samples, torch fp32 CPU, "
-                      f"{threads} threads, {el:.1f} s"}
+                      f"{threads} threads, {el:.1f} s"}, parity
+
+
+def _oracle_inputs(model):
+    vf_sd = {k: v.detach().cpu() for k, v in model.vector_field_network.state_dict().items()}
+    rn_sd = {k: v.detach().cpu() for k, v in model.rendering_network.state_dict().items()}
+    return vf_sd, rn_sd
+
+
+def view_bench(args, dev):
+    """BASELINE.json configs[1]: one full Replica-like view (1200x680 = 816 000 rays) rendered in 1024-ray chunks x 128
+    samples, perturb off, forward only.  A step = one full view.  The PSNR / depth error is taken against the oracle's
+    image of the same camera at 1/8 resolution (150x85, intrinsics scaled), which the CPU finishes in ~20 s."""
+    from vf_nerf_amd import synthetic
+    from oracle import vfnerf_oracle as O
+    chunk, (w, h, f) = args.rays if args.rays != 4096 else 1024, (1200, 680, 600.0)
+    s_c, n_f = args.coarse, args.fine
+    model, _, _, _ = build_scene(dev, 16, s_c, n_f, seed=0, perturb=False)
+    model.precision = args.precision
+    uv, pose, K = synthetic.pinhole_image(w, h, f, device=dev)
+    n = uv.shape[0]
+
+    def full_view():
+        rgb = torch.empty(n, 3, device=dev)
+        depth = torch.empty(n, 1, device=dev)
+        for lo in range(0, n, chunk):
+            hi = min(lo + chunk, n)
+            o = model.render(pose[lo:hi], uv[lo:hi], K[lo:hi], epoch=0)
+            rgb[lo:hi], depth[lo:hi] = o.coarse_rgb_values, o.coarse_depth_map
+        return rgb, depth
+
+    with torch.no_grad():
+        for _ in range(max(1, args.warmup // 3)):
+            full_view()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            full_view()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+
+        # parity image: same camera at 1/8 resolution on both sides, identical u_add draw (Q9)
+        ws, hs = w // 8, h // 8
+        uv_s, pose_s, K_s = synthetic.pinhole_image(ws, hs, f / 8.0, device=dev)
+        g = torch.Generator().manual_seed(21)
+        uni = {"u_add": torch.rand(ws * hs, n_f, generator=g)}
+        o = model.render(pose_s, uv_s, K_s, epoch=0, uniforms=uni)
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        settings = O.RenderSettings(n_samples=s_c, n_fine=n_f, perturb=False, dir_to_normal_th=-0.2, fine_range=0.3,
+                                    density=O.DensityParams(scale_min=1.0))
+        vf_sd, rn_sd = _oracle_inputs(model)
+        t1 = time.perf_counter()
+        ref = O.render(uv_s.cpu(), pose_s.cpu(), K_s.cpu(), vf_sd, rn_sd, settings, **uni)
+        cpu_s = time.perf_counter() - t1
+    rgb, depth = o.coarse_rgb_values.cpu(), o.coarse_depth_map.cpu()
+    print(json.dumps({
+        "metric": "rays/sec (full 1200x680 view, 1024-ray chunks, 128 samples/ray) + PSNR/depth vs ref",
+        "value": round(n * args.steps / elapsed, 1), "unit": "rays/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": max(1, args.warmup // 3), "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16x3+f32acc" if args.precision == "f16x3" else "f32", "data": "synthetic",
+        "config": {"workload": f"full view {w}x{h} = {n} rays in {chunk}-ray chunks x {s_c + n_f} samples, perturb off, "
+                               f"forward only (BASELINE.json configs[1])"},
+        "parity_vs_oracle": {"image": f"{ws}x{hs} (same camera, intrinsics / 8), {ws * hs} rays",
+                             "psnr_rgb_db": round(min(O.psnr(rgb, ref["rgb"]), 200.0), 2),
+                             "mean_abs_depth_err": float((depth - ref["depth"].reshape(depth.shape)).abs().mean()),
+                             "max_abs_rgb_err": float((rgb - ref["rgb"]).abs().max()),
+                             "argmax_indices_equal": bool((o.z_vals.cpu() == ref["z_vals"]).all()),
+                             "oracle_seconds": round(cpu_s, 1)}}), flush=True)
+
+
+def grid_bench(args, dev, rank, world, dist, sync):
+    """BASELINE.json configs[4]: dense-grid queries of the vector field (marching-cubes input): res^3 points of one
+    quadrant through ``grid.get_set_predictions`` (host grid -> pinned upload -> vector-only VF kernel -> pinned
+    download), blocks of 100 000 points dealt round-robin to the ranks.  A step = one res^3 quadrant."""
+    from vf_nerf_amd import grid
+    from oracle import vfnerf_oracle as O
+    model, _, _, _ = build_scene(dev, 16, 64, 64, seed=0)
+    model.precision = args.precision
+    dec = model.fine_vector_field_network
+    res = args.grid_res
+    ax = torch.linspace(-1.0, 1.0, res)
+    samples = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1).reshape(-1, 3).contiguous()
+    n = samples.shape[0]
+    for _ in range(max(1, args.warmup // 3)):
+        grid.get_set_predictions(dec, samples, 100000, dev, rank=rank, world_size=world)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        got = grid.get_set_predictions(dec, samples, 100000, dev, rank=rank, world_size=world)
+    sync()
+    elapsed = time.perf_counter() - t0
+    # device-resident rate (grid already in HBM, no host copies): what the kernel itself sustains
+    dsamples = samples[: min(n, 1 << 24)].to(dev)
+    grid.get_set_predictions(dec, dsamples, 100000, dev)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    grid.get_set_predictions(dec, dsamples, 100000, dev)
+    torch.cuda.synchronize()
+    resident = dsamples.shape[0] / (time.perf_counter() - t1)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        vf_sd, _ = _oracle_inputs(model)
+        idx = torch.arange(0, n, max(1, n // 4096))[:4096]
+        idx = idx[(idx // 100000) % world == 0]                      # rows this rank evaluated
+        ref = O.vf_mlp(samples[idx], vf_sd, 6, (4,))[:, :3]
+        err = float((got[idx] - ref).abs().max())
+        print(json.dumps({
+            "metric": "grid points/sec (vector-field queries for quadrant marching cubes)",
+            "value": round(n * args.steps / elapsed, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps,
+            "warmup": max(1, args.warmup // 3), "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f16x3+f32acc" if args.precision == "f16x3" else "f32", "data": "synthetic",
+            "config": {"workload": f"{res}^3 = {n} grid points per quadrant, host grid in, host [n,3] out, "
+                                   f"max_batch 100000 (BASELINE.json configs[4], one quadrant)",
+                       "parallelism": f"blocks x{world}"},
+            "device_resident_points_per_s": round(resident, 1),
+            "max_abs_err_vs_oracle_4096_points": err}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync):
@@ -163,6 +295,10 @@ def main() -> None:
     ap.add_argument("--precision", choices=("f16x3", "fp32"), default="f16x3",
                     help="MLP kernels: f16x3 = split-half products on the f16 matrix cores, fp32 accumulate (default, "
                          "fp32-equivalent accuracy); fp32 = exact fp32 MFMA")
+    ap.add_argument("--workload", choices=("render", "view", "grid", "train"), default="render",
+                    help="render = the headline line (default); view = BASELINE configs[1] full view in 1024-ray chunks + "
+                         "PSNR/depth vs the oracle image; grid = configs[4] dense grid queries; train = configs[2] step")
+    ap.add_argument("--grid-res", type=int, default=256)
     ap.add_argument("--train", action="store_true",
                     help="time a training step instead (render with autograd + 2 supervision VF forwards + loss + "
                          "backward + clip + Adam, train/vector_field_nerf_train.py:177-260); not the headline metric")
@@ -185,6 +321,20 @@ def main() -> None:
 
     from vf_nerf_amd import lib
     lib.load()  # fail loudly when the HIP extension is missing
+    if args.train:
+        args.workload = "train"
+    if args.workload in ("view", "grid"):
+        def sync0():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+        if args.workload == "view":
+            if world > 1:
+                raise SystemExit("--workload view is a single-GPU configuration")
+            view_bench(args, dev)
+        else:
+            grid_bench(args, dev, rank, world, dist, sync0)
+        return
     s_c, n_f = args.coarse, args.fine
     s_t = s_c + n_f
     model, uv, pose, K = build_scene(dev, args.rays, s_c, n_f, seed=rank)
@@ -195,7 +345,7 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.train:
+    if args.workload == "train":
         train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync)
         return
 
@@ -238,7 +388,7 @@ def main() -> None:
                 # BASELINE.md §3 states the path's roofline against the fp32 matrix peak:
                 "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA, 4)}
         line = {
-            "metric": "rays/sec (4096-ray chunk, 128 samples/ray)",
+            "metric": "rays/sec (4096-ray chunk, 128 samples/ray) + PSNR vs ref",
             "value": round(rays_per_s, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16x3+f32acc" if f16 else "f32", "data": "synthetic",
@@ -250,7 +400,7 @@ def main() -> None:
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(model, uv, pose, K, s_c, n_f)
+            line["cpu_baseline"], line["parity_vs_oracle"] = cpu_baseline(model, uv, pose, K, s_c, n_f)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -230,10 +230,15 @@ def test_grid_query_matches_full_forward():
     samples = torch.rand(10000, 3, generator=gen) * 2 - 1
     with torch.no_grad():
         want = dec(samples.to(dev()))[:, :3].cpu()
-    got = grid.get_set_predictions(dec, samples, 3000, dev())
-    assert got.shape == (10000, 3) and rel_err(got, want) < 1e-6
+    for precision, tol in (("fp32", 1e-6), ("f16x3", 2e-5)):     # f16x3: split-half products, fp32-equivalent
+        model.precision = precision
+        got = grid.get_set_predictions(dec, samples, 3000, dev())
+        assert got.shape == (10000, 3) and rel_err(got, want) < tol, precision
     parts = [grid.get_set_predictions(dec, samples, 3000, dev(), rank=r, world_size=2) for r in range(2)]
-    assert rel_err(parts[0] + parts[1], want) < 1e-6
+    assert rel_err(parts[0] + parts[1], want) < 2e-5
+    # device-resident grid (no staging) and a 4-column sample tensor (xyz + value, as mc_utils builds it)
+    four = torch.cat([samples, torch.zeros(10000, 1)], dim=1).to(dev())
+    assert rel_err(grid.get_set_predictions(dec, four, 3000, dev()).cpu(), want) < 2e-5
     assert float(parts[0][3000:6000].abs().max()) == 0.0 and float(parts[1][:3000].abs().max()) == 0.0
 
 

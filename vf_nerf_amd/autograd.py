@@ -22,6 +22,8 @@ def vf_forward(net, points: torch.Tensor, vector_only: bool = False) -> torch.Te
         from .backward import vf_forward_autograd
         return vf_forward_autograd(net, points, vector_only)
     pts = _flat3(points)
+    if vector_only and getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3():
+        return lib.vf_mlp16_fwd(net.geometry(), net.packed16_weights(), pts)
     cols = 3 if vector_only else 3 + net._feature_dims()
     return lib.vf_mlp_fwd(net.geometry(), net.packed_weights(), pts, cols)
 

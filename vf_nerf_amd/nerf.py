@@ -75,7 +75,8 @@ class VectorFieldNerf:
 
         # arithmetic of the inference MLP kernels: "f16x3" = split-half products on the f16 matrix cores with
         # fp32 accumulation (fp32-equivalent accuracy, see csrc/vfn_mlp16.hip); "fp32" = exact fp32 MFMA.
-        # Gradient-carrying calls always use the fp32 kernels.
+        # Gradient-carrying calls always use the fp32 kernels.  The setting is shared with the networks so that
+        # gradient-free vector queries made on them directly (grid extraction) follow it.
         self.precision = "f16x3"
         # device RNG stream (Philox counter); every render() advances the offset
         self.rng_seed = 0
@@ -169,6 +170,17 @@ class VectorFieldNerf:
     # ---------------------------------------------------------------------------------------------
     # helpers
     # ---------------------------------------------------------------------------------------------
+    @property
+    def precision(self) -> str:
+        return self._precision
+
+    @precision.setter
+    def precision(self, value: str) -> None:
+        if value not in ("f16x3", "fp32"):
+            raise ValueError(f"precision must be 'f16x3' or 'fp32', got {value!r}")
+        self._precision = value
+        self.vector_field_network.precision = value
+
     def uses_f16x3(self) -> bool:
         """f16x3 inference kernels are used when requested AND specialised for both networks' geometry."""
         if self.precision not in ("f16x3", "fp32"):

@@ -129,6 +129,9 @@ class VectorFieldNetwork(_PackedMLP):
     def __init__(self, config) -> None:
         super().__init__()
         self.config = config
+        # arithmetic of gradient-free vector-only queries: "f16x3" (split-half f16 MFMA, fp32-equivalent) or "fp32";
+        # the facade's ``precision`` setter writes it.  Full-width and gradient-carrying forwards are always fp32.
+        self.precision = "f16x3"
         pe = _pe_dim(config.embedder_multires, config.input_dims)
         dims = [pe if config.embedder_multires > 0 else config.input_dims] + list(config.dimensions) + \
                [config.output_dims + config.feature_vector_dims]

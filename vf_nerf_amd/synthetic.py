@@ -33,6 +33,20 @@ def pinhole_batch(n_rays: int, width: int, height: int, focal: float, seed: int,
     return (uv.to(device), P.repeat(n_rays, 1, 1).contiguous().to(device), K.repeat(n_rays, 1, 1).contiguous().to(device))
 
 
+def pinhole_image(width: int, height: int, focal: float, device="cpu", pose: torch.Tensor = None
+                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Every pixel of one pinhole view in row-major order -> (uv[W*H,2], pose[W*H,4,4], intrinsics[W*H,4,4]);
+    the principal point is the image centre, so a 1/k-resolution image of the same camera uses focal/k."""
+    v, u = torch.meshgrid(torch.arange(height).float(), torch.arange(width).float(), indexing="ij")
+    uv = torch.stack([u.reshape(-1), v.reshape(-1)], dim=1)
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = focal
+    K[0, 2], K[1, 2] = (width - 1) / 2, (height - 1) / 2
+    P = torch.eye(4) if pose is None else pose.float()
+    n = width * height
+    return uv.to(device), P.repeat(n, 1, 1).contiguous().to(device), K.repeat(n, 1, 1).contiguous().to(device)
+
+
 def orbit_pose(azimuth_deg: float, elevation_deg: float, radius: float, target=(0.0, 0.0, 0.6)) -> torch.Tensor:
     """Camera-to-world 4x4 looking at ``target`` from a sphere around it (+z forward, OpenCV style)."""
     az, el = math.radians(azimuth_deg), math.radians(elevation_deg)
