@@ -1,11 +1,12 @@
 """Interleaved A/B timing of vfn_vf_render_fused16_fwd across several builds of libvfn.so in ONE process on ONE GPU
-(devices of this pool differ by several percent, so variants are only ever compared inside one run).
+(devices of this pool differ by several percent, and the kernel is power-limited, so variants are only ever compared
+inside one run).
 
-    hipcc ... -DSOME_SWITCH -c vf_nerf_amd/csrc/vfn_mlp16.hip -o /tmp/v.o && hipcc -shared ... -o /tmp/libvfn_v.so
-    python tools/ab_fused16.py vf_nerf_amd/csrc/libvfn.so /tmp/libvfn_v.so
+    bash vf_nerf_amd/csrc/build.sh && tools/build_variants.sh "nodma:-DABL_NODMA" "fd3:-DVFN16_FDEPTH=3"
+    python tools/ab_fused16.py vf_nerf_amd/csrc/libvfn.so vf_nerf_amd/csrc/libvfn_nodma.so vf_nerf_amd/csrc/libvfn_fd3.so
 
-Build switches understood by vfn_mlp16.hip: ABL_NOEPI / ABL_NOSYNC / ABL_NOWAIT / ABL_NOBARRIER / ABL_NODMA (timing-only
-ablations: results are wrong), EXP_DMA2X (issue every DMA piece twice), VFN16_DMA_WAVES=n."""
+Build switches: see tools/build_variants.sh.  Timing-only ablations change the DATA the matrix cores see (zeros toggle
+fewer wires), which raises the shader clock: compare their cycle counts (tools/stamp_fused16.py), not only their times."""
 import sys, ctypes as C, torch, statistics
 sys.path.insert(0, '.')
 import bench

@@ -9,20 +9,35 @@
 // Measured against the reference on the golden fixtures it is as close as the exact-fp32 kernel.
 //
 // Structure (different from the fp32 kernel — activations never touch LDS):
-//  * the GEMM is transposed, Y^T[n][m] = W'[n][k] X^T[k][m]: the MFMA's A operand is the weight tile, B is the
-//    activation; a wave owns 16 points (the lane's column m = lane & 15) end to end, on v_mfma_f32_16x16x32_f16.
-//    The 16x16 accumulators of output tiles 2s and 2s+1 ARE, register for register, the B operand of K-block s of
-//    the next layer (accumulator row 4*(lane>>4) + reg <-> fragment element order, absorbed into the weight
-//    packing), so a layer's output is split to (hi, lo) halves in registers and consumed in place: no LDS round
-//    trip, no cross-lane traffic, no barrier on the activation path.  16 points per wave keep the two activation
-//    sets at 128 VGPRs, so 8 waves (two per SIMD) fit and one wave's epilogue / LDS waits hide under its
-//    partner's MFMAs;
-//  * weights (A fragments, hi and lo planes, lane-linear 1 KiB blocks) are shared by the workgroup's 8 waves
-//    through a three-slot LDS ring of chunks (32 output rows x all K = 33 KiB) filled by LDS-DMA two chunks ahead,
-//    tracked with counted vmcnt waits and one raw s_barrier per chunk;
-//  * the weights are pre-scaled by 2^6 at pack time (exact), so the low halves stay normal f16 numbers; the
-//    epilogue multiplies by 2^-6.
+//  * the GEMM is transposed, Y^T[n][m] = W'[n][k] X^T[k][m]: the MFMA's A operand is a 32-row weight tile, B is the
+//    activation; a wave owns 32 points (the lane's column m = lane & 31) end to end.  The 32x32 accumulator of output
+//    tile t IS, register for register, the B operand of K-blocks 2t and 2t+1 of the next layer (accumulator row
+//    (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) <-> fragment element order, absorbed into the weight packing), so a
+//    layer's output is split to (hi, lo) halves in registers and consumed in place: no LDS round trip, no cross-lane
+//    traffic on the activation path;
+//  * ONE wave per SIMD, 4 waves = 128 points per workgroup, the whole 512-entry register file per wave: the two
+//    activation sets (2 x 128 registers) live in the AGPRs, where the MFMA reads its B operand directly; accumulators,
+//    weight fragments and the epilogue use the arch VGPRs (hipcc -mllvm -amdgpu-mfma-vgpr-form).  32 points per wave
+//    halve the LDS fragment traffic per FLOP of a 16-point tiling, and v_mfma_f32_32x32x16 leaves 24 of its 32 cycles
+//    free for other issue (8 of 16 for the 16x16x32 form);
+//  * weights (A fragments, hi and lo planes, lane-linear 1 KiB blocks) are shared by the workgroup's 4 waves through
+//    a three-slot LDS ring of chunks (one 32-row tile x all K, <= 39 KiB) filled by LDS-DMA (buffer_load ... lds);
+//  * with one wave per SIMD nothing else hides the epilogue, the DMA issue or the ring hand-over, so the chunk loop is
+//    software-pipelined by hand over the K steps of a tile (see layer16): epilogue of the previous tile in the first
+//    half, vmcnt(0) + s_barrier in the middle, DMA pieces of chunk c+2 in the second half, bias and first fragments of
+//    chunk c+1 in the last step;
+//  * the layer sequence is the shipped one (confs/vf_nerf.conf:13-37) and compiled in: straight-line code, every chunk's
+//    place in the pack, its size and its ring slot are immediates; other geometries return VFN_ERR_UNSUPPORTED and
+//    callers use the fp32 kernels;
+//  * accumulators hold 2^6 x the true pre-activation and the factor rides on the activations (operand blocks hold
+//    2^6 x, weights are packed unscaled, the ReLU epilogue needs no multiply).  f16 denormals are honoured by the
+//    MFMA, which the low halves of the weights rely on.
+//
+// Build flags (build.sh): -mllvm -amdgpu-mfma-vgpr-form (accumulators in arch VGPRs, leaving all 256 AGPRs to the
+// activation sets) and -mllvm -pragma-unroll-threshold=10000000 (the K loops must unroll fully: operand blocks are
+// register arrays).
 #include <string.h>
+#include <utility>
 #include "vfn_common.h"
 #include "vfn_plan.h"
 
@@ -30,25 +45,33 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// Scaling: accumulators hold 2^6 x the true pre-activation.  VFN16_ASCALE = 1 carries the factor on the ACTIVATIONS
+// (operand blocks hold 2^6 x, weights are packed unscaled, the ReLU epilogue needs no multiply); 0 carries it on the
+// weights (activations unscaled, one multiply per value in the epilogue).
+#ifndef VFN16_ASCALE
+#define VFN16_ASCALE 1
+#endif
 #define VFN16_WSCALE 64.0f
 #define VFN16_INV_WSCALE 0.015625f
-#define VFN16_MAX_CHUNK_KB 42     // 2 tiles x 10 K-blocks x 2 planes + 1 bias block
+#define VFN16_PACK_WSCALE (VFN16_ASCALE ? 1.0f : VFN16_WSCALE)
+#define VFN16_XSCALE (VFN16_ASCALE ? VFN16_WSCALE : 1.0f)
+#ifndef VFN16_EPI_PER_MFMA
+#define VFN16_EPI_PER_MFMA 6     // VALU instructions of the pending epilogue scheduled behind each MFMA
+#endif
+#define VFN16_MAX_CHUNK_KB 39     // (16 act + 3 aux) K-blocks x 2 planes + 1 bias block
 
-// ------------------------------------------------------------------------------------------------
-// plan: where each hidden entry's chunks live in the f16 pack
-// ------------------------------------------------------------------------------------------------
 struct Plan16 {
     int32_t n_hidden;
     int32_t feat_layer;
     int32_t multires;
     uint32_t total_kb;
     uint32_t head_off_kb;
-    uint32_t off_kb[VFN_MAX_LAYERS];   // first chunk of hidden entry h (KiB from the pack base)
-    uint8_t act16[VFN_MAX_LAYERS];     // K blocks of 32 taken from the activation registers
-    uint8_t aux16[VFN_MAX_LAYERS];     // K blocks of 32 taken from the auxiliary (encoding) registers
-    uint8_t n_tiles[VFN_MAX_LAYERS];   // chunks = pairs of 16-row output tiles
+    uint32_t off_kb[VFN_MAX_LAYERS];
+    uint8_t act16[VFN_MAX_LAYERS];     // K blocks of 16 taken from the activation registers
+    uint8_t aux16[VFN_MAX_LAYERS];     // K blocks of 16 taken from the auxiliary (encoding) registers
+    uint8_t n_tiles[VFN_MAX_LAYERS];   // chunks = 32-row output tiles
 };
 
 static int make_plan16(int kind, const vfn_net_geom* g, VfnNetPlan* p32, Plan16* p, const char* what) {
@@ -60,37 +83,33 @@ static int make_plan16(int kind, const vfn_net_geom* g, VfnNetPlan* p32, Plan16*
     uint32_t off = 0;
     for (int h = 0; h < p32->n_hidden; ++h) {
         const VfnLayerPlan& lp = p32->hidden[h];
-        p->act16[h] = (uint8_t)(lp.nkb_act / 4);
-        p->aux16[h] = lp.nkb_aux ? 2 : 0;     // 39 / 33 encoding columns -> 64
+        if (lp.nkb_act % 2) { vfn_set_error("%s: act width not a multiple of 16", what); return VFN_ERR_UNSUPPORTED; }
+        p->act16[h] = (uint8_t)(lp.nkb_act / 2);
+        p->aux16[h] = lp.nkb_aux ? 3 : 0;     // 39 / 33 encoding columns -> 48
         p->n_tiles[h] = (uint8_t)lp.n_tiles;
-        if (lp.nkb_act % 4) { vfn_set_error("%s: act width not a multiple of 32", what); return VFN_ERR_UNSUPPORTED; }
         p->off_kb[h] = off;
-        off += lp.n_tiles * (4u * (p->act16[h] + p->aux16[h]) + 1u);
+        off += lp.n_tiles * (2u * (p->act16[h] + p->aux16[h]) + 1u);
     }
     p->head_off_kb = off;
-    off += 2u * 8u + 1u;                      // head: ONE 16-row tile
+    off += 2u * 16u + 1u;
     p->total_kb = off;
     return VFN_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// pack: fold BatchNorm / skip scale, scale by 2^6, split to halves, fragment order
-//   chunk = [tile t16 of the pair][kb][plane hi|lo][lane][8 halves] ++ bias block [t16][g][4 floats] (1 KiB)
-//   element j of lane (r = lane & 15, g = lane >> 4) of K-block kb (32 wide), output row n = 32*chunk + 16*t16 + r:
-//     act blocks:  k = 32*kb + 16*(j>>2) + 4*g + (j&3)           (accumulator-pair-as-operand order)
-//     aux blocks:  k_aux = 32*(kb - act) + 8*g + j
-//   the head is a single tile (n_tiles16 == 1).
-// ------------------------------------------------------------------------------------------------
+// chunk = [kb][plane hi|lo][lane][8 halves] ++ bias block [hl][16 floats] (1 KiB)
+//   lane (i = lane & 31, g = lane >> 5), element j of K-block kb (16 wide), output row n = 32*chunk + i:
+//     act blocks:  k = 16*kb + 8*(j>>2) + 4*g + (j&3)          (accumulator-as-operand order)
+//     aux blocks:  k_aux = 16*(kb - act) + 8*g + j
 struct Pack16Entry {
     const float* w; const float* b; const float* bn_w; const float* bn_b; const float* bn_mean; const float* bn_var;
-    uint32_t off_kb, n_chunks, tiles16, act16, aux16;
+    uint32_t off_kb, n_chunks, act16, aux16;
     int32_t in_dim, row_off, n_rows, act_col_off, act_valid, aux_col_off, aux_valid;
     float scale;
 };
 struct Pack16Args {
     Pack16Entry e[VFN_MAX_LAYERS + 2];
     int32_t n_entries;
-    uint32_t total_words;   // 32-bit words
+    uint32_t total_words;
     uint32_t* out;
 };
 
@@ -99,36 +118,36 @@ __device__ __forceinline__ float folded_weight(const Pack16Entry& e, int n, int 
     const int row = e.row_off + n;
     float w = e.w[(size_t)row * e.in_dim + col];
     if (e.bn_w) w *= e.bn_w[row] / sqrtf(e.bn_var[row] + 1e-5f);
-    return w * e.scale * VFN16_WSCALE;
+    return w * e.scale * VFN16_PACK_WSCALE;
 }
 
 __global__ void vfn_pack16_kernel(Pack16Args a) {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;   // one 32-bit word
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.total_words) return;
     int ei = 0;
     for (int i = 1; i < a.n_entries; ++i)
         if (idx >= a.e[i].off_kb * 256u) ei = i;
     const Pack16Entry& e = a.e[ei];
     const uint32_t nkb = e.act16 + e.aux16;
-    const uint32_t wblocks = e.tiles16 * nkb * 2u;             // 1 KiB weight blocks per chunk
+    const uint32_t wblocks = nkb * 2u;
     const uint32_t chunk_words = (wblocks + 1u) * 256u;
     const uint32_t local = idx - e.off_kb * 256u;
     const uint32_t ck = local / chunk_words, cw = local % chunk_words;
     uint32_t word = 0;
     if (cw < wblocks * 256u) {
-        const uint32_t blk = cw >> 8, lane = (cw >> 2) & 63u, jp = cw & 3u;   // word jp holds elements 2jp, 2jp+1
-        const uint32_t part = blk & 1u, kb = (blk >> 1) % nkb, t16 = (blk >> 1) / nkb;
-        const int g = (int)(lane >> 4);
-        const int n = (int)(32u * ck + 16u * t16 + (lane & 15u));
+        const uint32_t blk = cw >> 8, lane = (cw >> 2) & 63u, jp = cw & 3u;
+        const uint32_t part = blk & 1u, kb = blk >> 1;
+        const int g = (int)(lane >> 5);
+        const int n = (int)(32u * ck + (lane & 31u));
         _Float16 halves[2];
         for (int q = 0; q < 2; ++q) {
             const int j = (int)(2u * jp) + q;
             int col = -1;
             if (kb < e.act16) {
-                const int k = 32 * (int)kb + 16 * (j >> 2) + 4 * g + (j & 3);
+                const int k = 16 * (int)kb + 8 * (j >> 2) + 4 * g + (j & 3);
                 if (k < e.act_valid) col = e.act_col_off + k;
             } else {
-                const int k = 32 * (int)(kb - e.act16) + 8 * g + j;
+                const int k = 16 * (int)(kb - e.act16) + 8 * g + j;
                 if (k < e.aux_valid) col = e.aux_col_off + k;
             }
             const float w = folded_weight(e, n, col);
@@ -138,12 +157,12 @@ __global__ void vfn_pack16_kernel(Pack16Args a) {
         word = (uint32_t)__builtin_bit_cast(unsigned short, halves[0]) |
                ((uint32_t)__builtin_bit_cast(unsigned short, halves[1]) << 16);
     } else {
-        const uint32_t bi = cw - wblocks * 256u;   // bias block: [t16][g][4] floats in accumulator-row order
+        const uint32_t bi = cw - wblocks * 256u;   // bias block: [hl][16] floats in accumulator-register order
         if (bi < 32u) {
-            const int t16 = (int)(bi >> 4), g = (int)((bi >> 2) & 3u), r = (int)(bi & 3u);
-            const int n = (int)(32u * ck) + 16 * t16 + 4 * g + r;
+            const int hl = (int)(bi >> 4), r = (int)(bi & 15u);
+            const int n = (int)(32u * ck) + (r & 3) + 8 * (r >> 2) + 4 * hl;
             float b = 0.f;
-            if (n < e.n_rows && (uint32_t)t16 < e.tiles16) {
+            if (n < e.n_rows) {
                 const int row = e.row_off + n;
                 b = e.b[row];
                 if (e.bn_w) b = (b - e.bn_mean[row]) * (e.bn_w[row] / sqrtf(e.bn_var[row] + 1e-5f)) + e.bn_b[row];
@@ -154,17 +173,23 @@ __global__ void vfn_pack16_kernel(Pack16Args a) {
     a.out[idx] = word;
 }
 
+static int check_kind16(int net_kind, const Plan16& p, const char* what);   // plan against the compiled-in layer tables
+
 extern "C" int64_t vfn_pack16_size(int32_t net_kind, const vfn_net_geom* geom) {
     VfnNetPlan p32; Plan16 p;
     int rc = make_plan16(net_kind, geom, &p32, &p, "vfn_pack16_size");
+    if (rc != VFN_OK) return rc;
+    rc = check_kind16(net_kind, p, "vfn_pack16_size");
     if (rc != VFN_OK) return rc;
     return (int64_t)p.total_kb * 1024;
 }
 
 extern "C" int vfn_pack16_weights(int32_t net_kind, const vfn_net_geom* geom, const vfn_layer_params* layers,
-                                  void* packed16, void* stream) {
+                                   void* packed16, void* stream) {
     VfnNetPlan p32; Plan16 p;
     int rc = make_plan16(net_kind, geom, &p32, &p, "vfn_pack16_weights");
+    if (rc != VFN_OK) return rc;
+    rc = check_kind16(net_kind, p, "vfn_pack16_weights");
     if (rc != VFN_OK) return rc;
     VFN_REQUIRE(layers && packed16, "vfn_pack16_weights: NULL argument");
     Pack16Args a;
@@ -186,7 +211,7 @@ extern "C" int vfn_pack16_weights(int32_t net_kind, const vfn_net_geom* geom, co
         Pack16Entry& e = a.e[a.n_entries++];
         rc = fill(e, i);
         if (rc != VFN_OK) return rc;
-        e.off_kb = p.off_kb[h]; e.n_chunks = p.n_tiles[h]; e.tiles16 = 2; e.act16 = p.act16[h]; e.aux16 = p.aux16[h];
+        e.off_kb = p.off_kb[h]; e.n_chunks = p.n_tiles[h]; e.act16 = p.act16[h]; e.aux16 = p.aux16[h];
         const bool feat = p.feat_layer && h == p.n_hidden - 1;
         e.row_off = feat ? 3 : 0;
         e.n_rows = feat ? F : geom->out_dims[i];
@@ -206,7 +231,7 @@ extern "C" int vfn_pack16_weights(int32_t net_kind, const vfn_net_geom* geom, co
         Pack16Entry& e = a.e[a.n_entries++];
         rc = fill(e, L - 1);
         if (rc != VFN_OK) return rc;
-        e.off_kb = p.head_off_kb; e.n_chunks = 1; e.tiles16 = 1; e.act16 = 8; e.aux16 = 0;
+        e.off_kb = p.head_off_kb; e.n_chunks = 1; e.act16 = 16; e.aux16 = 0;
         e.row_off = 0; e.n_rows = 3; e.act_col_off = 0; e.act_valid = VFN_HIDDEN;
     }
     a.total_words = p.total_kb * 256u;
@@ -215,209 +240,264 @@ extern "C" int vfn_pack16_weights(int32_t net_kind, const vfn_net_geom* geom, co
     return vfn_check_launch("vfn_pack16_weights");
 }
 
-// ------------------------------------------------------------------------------------------------
-// kernel
-// ------------------------------------------------------------------------------------------------
 namespace {
 
 enum : int { EPI_RELU = 0, EPI_TANH = 1, EPI_HEAD_TANH = 2, EPI_HEAD_SIGMOID = 3 };
 enum : int { M16_VF_VEC = 0, M16_FUSED = 1 };
 
-#define VFN16_MAX_CHUNKS 160
+#ifndef VFN16_FDEPTH
+#define VFN16_FDEPTH 2            // A-fragment ring: K steps in registers (1 ahead)
+#endif
 #define VFN16_SLOT (VFN16_MAX_CHUNK_KB * 64)   // uint4 elements per LDS ring slot
-#define VFN16_WAVES 8
-#define VFN16_PTS 128                          // points per workgroup (16 per wave)
+#define VFN16_WAVES 4
+#define VFN16_PTS 128                          // points per workgroup (32 per wave)
 
-typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
+
+// ------------------------------------------------------------------------------------------------
+// The shipped layer sequence (confs/vf_nerf.conf:13-37) as compile-time tables: the kernel is straight-line code, every
+// chunk's place in the pack, its size and its ring slot are immediates.  check_vf16() / check_rn16() verify a network against
+// these tables; other geometries run on the fp32 kernels.
+// ------------------------------------------------------------------------------------------------
+constexpr int VF_ACT[9] = {0, 16, 16, 16, 14, 16, 16, 16, 16};    // K-blocks of 16 from the activations
+constexpr int VF_AUX[9] = {3, 0, 0, 0, 3, 0, 0, 0, 0};            // K-blocks of 16 from the encoding
+constexpr int VF_TILES[9] = {8, 8, 8, 7, 8, 8, 8, 8, 8};          // [8] = the feature block of the last Linear
+constexpr int RN_ACT[4] = {16, 16, 16, 16};
+constexpr int RN_AUX[4] = {3, 0, 0, 0};
+constexpr int RN_TILES[4] = {8, 8, 8, 8};
+constexpr int HEAD_KB = 2 * 16 + 1;
+constexpr int chunk_kb(int act, int aux) { return 2 * (act + aux) + 1; }
+constexpr int vf_off_kb(int h) { int o = 0; for (int i = 0; i < h; ++i) o += VF_TILES[i] * chunk_kb(VF_ACT[i], VF_AUX[i]); return o; }
+constexpr int rn_off_kb(int h) { int o = 0; for (int i = 0; i < h; ++i) o += RN_TILES[i] * chunk_kb(RN_ACT[i], RN_AUX[i]); return o; }
+
+struct ChunkD { int net, off_kb, kb; };      // net 0 = VF pack, 1 = rendering pack; kb = 0: past the end
+// chunk c of the launch in consumption order (fused: VF hidden + features, VF head, rendering hidden, rendering head;
+// vector-only: the 8 plain VF layers, VF head)
+constexpr ChunkD chunk_of(int mode, int c) {
+    const int vf_layers = mode == M16_FUSED ? 9 : 8;
+    for (int h = 0; h < vf_layers; ++h) {
+        if (c < VF_TILES[h]) return {0, vf_off_kb(h) + c * chunk_kb(VF_ACT[h], VF_AUX[h]), chunk_kb(VF_ACT[h], VF_AUX[h])};
+        c -= VF_TILES[h];
+    }
+    if (c == 0) return {0, vf_off_kb(9), HEAD_KB};
+    c -= 1;
+    if (mode == M16_FUSED) {
+        for (int h = 0; h < 4; ++h) {
+            if (c < RN_TILES[h]) return {1, rn_off_kb(h) + c * chunk_kb(RN_ACT[h], RN_AUX[h]), chunk_kb(RN_ACT[h], RN_AUX[h])};
+            c -= RN_TILES[h];
+        }
+        if (c == 0) return {1, rn_off_kb(4), HEAD_KB};
+    }
+    return {0, 0, 0};
+}
 
 struct Mlp16Args {
-    Plan16 vf, rn;
-    const uint4* vf_w;    // f16 pack
+    const uint4* vf_w;
     const uint4* rn_w;
     const float* points;
     const float* ray_dirs;
-    float* out_vec;       // [M,3]
-    float* out_colors;    // [M,3]
+    float* out_vec;
+    float* out_colors;
     long long n_points;
     int dirs_div;
-    int n_chunks;
-    // the weight chunks in the order the kernel consumes them: bit 31 = rendering net, bits 30..8 = KiB offset in that
-    // net's pack, bits 7..0 = KiB size.  Copied to LDS at kernel start (dynamic indexing of a by-value argument would
-    // be lowered to a private-memory copy, and scratch traffic would break the counted vmcnt waits).
-    uint32_t chunk[VFN16_MAX_CHUNKS];
+    int vf_multires, rn_multires;
+    uint32_t vf_bytes, rn_bytes;
 };
 
-struct X16 { half8 hi[8]; half8 lo[8]; };      // 256 activation columns of this lane's point, split (8 K-blocks of 32)
-struct A16 { half8 hi[2]; half8 lo[2]; };      // 64 auxiliary (encoding) columns
+struct X16 { half8 hi[16]; half8 lo[16]; };     // 256 activation columns x this lane's point, split (16 K-blocks of 16)
+struct A16 { half8 hi[3]; half8 lo[3]; };       // 48 auxiliary (encoding) columns
 
-// Three-slot LDS ring fed by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction): while chunk c feeds the
-// MFMAs, chunk c+1 is landing and chunk c+2 is being issued.  Completion is tracked with COUNTED vmcnt waits and a
-// raw s_barrier (a __syncthreads() would drain the DMA in flight); nothing else in the loop touches vector memory.
-struct Pipe {
-    uint4* lds;            // ring
-    const uint32_t* tab;   // chunk list (LDS)
-    const uint4* vf_w;
-    const uint4* rn_w;
-    int n_chunks;
-    int slot;              // ring slot of the chunk being consumed
-    int c;                 // index of that chunk in the chunk list
+struct Pipe16 {
+    uint4* lds;                    // ring base
+    __amdgpu_buffer_rsrc_t vf_w;   // the two f16 packs as buffer resources: the DMA addresses stay in SGPRs
+    __amdgpu_buffer_rsrc_t rn_w;
 };
 
+// State carried from chunk to chunk (and from layer call to layer call): the previous tile's accumulators, whose
+// epilogue runs in the shadow of the next tile's MFMAs, and the next chunk's bias and first fragments, which are read
+// before the current chunk ends so that no tile starts with an exposed LDS latency.
+struct Carry16 {
+    f32x16 pend;
+    f32x16 bias;
+    half8 fh0, fl0;
+};
+
+template <int N, typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
+
+// (hi, lo) halves of two values: hi = f16(v), lo = f16(v - hi).  The residual is one v_fma_mix_f32 per value (the f16
+// half is converted inside the instruction; hipcc otherwise emits v_cvt_f32_f16 + v_sub_f32), and deliberately not a
+// packed fp32 op: v_pk_add_f32 beside MFMAs costs ~13 extra cycles per instruction (MI355X_MICROARCH.md, "price of one
+// filler beside MFMAs").
 __device__ __forceinline__ void split2(float a, float b, _Float16& h0, _Float16& h1, _Float16& l0, _Float16& l1) {
     const float2v v = {a, b};
     const half2v hi = __builtin_convertvector(v, half2v);
-    const float2v back = __builtin_convertvector(hi, float2v);
-    const half2v lo = __builtin_convertvector(v - back, half2v);
-    h0 = hi[0]; h1 = hi[1]; l0 = lo[0]; l1 = lo[1];
+    h0 = hi[0]; h1 = hi[1];
+    const uint32_t hp = __builtin_bit_cast(uint32_t, hi);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hp), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hp), "v"(b));
+    const float2v r = {r0, r1};
+    const half2v lo = __builtin_convertvector(r, half2v);
+    l0 = lo[0]; l1 = lo[1];
 }
 
-// tanh through one exp: 1 - 2 / (1 + e^{2v}).  Absolute error ~1e-7 (the subtraction rounds at 1 ulp of 1), which is
-// what matters for values that feed the next layer in fp32-equivalent arithmetic; saturates correctly to +-1.
-// The ocml tanhf expands to a long two-branch sequence whose temporaries spilled to scratch in the unrolled epilogue.
+// tanh through one exp: 1 - 2 / (1 + e^{2v}).  Absolute error ~1e-7; saturates correctly to +-1.
 __device__ __forceinline__ float tanh_exp(float v) { return 1.0f - 2.0f / (1.0f + expf(2.0f * v)); }
 
-__device__ __forceinline__ uint32_t chunk_entry(const Pipe& p, int idx) {
-    return __builtin_amdgcn_readfirstlane(p.tab[idx]);
+// One 1-KiB LDS-DMA piece: block `blk` of chunk descriptor D into ring slot SLOT.
+template <int NET, int OFF_KB, int SLOT>
+__device__ __forceinline__ void dma_piece(const Pipe16& p, int blk, int lane) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(NET ? p.rn_w : p.vf_w, (lds_void*)(p.lds + SLOT * VFN16_SLOT + blk * 64), 16,
+                                             lane * 16, (OFF_KB + blk) * 1024, 0, 0);
 }
-// The DMA is issued by the first VFN16_DMA_WAVES waves only, and AFTER their MFMAs: those are the older waves, which
-// win matrix-pipe arbitration, finish each chunk's MFMAs first and would otherwise idle at the barrier; issuing an
-// LDS-DMA piece blocks a wave for ~70 cycles, so the younger (critical) waves issue none.  Interleaved A/B on one
-// GPU: -5 % kernel time vs. all eight waves issuing at the start of the chunk.
-#ifndef VFN16_DMA_WAVES
-#define VFN16_DMA_WAVES 4
-#endif
-#define EXP_DMA_WAVES VFN16_DMA_WAVES
-__device__ __forceinline__ int dma_count(uint32_t entry, int wave) {   // DMA instructions this wave issues for a chunk
-    const int kb = (int)(entry & 0xffu);
-    if (EXP_DMA_WAVES != VFN16_WAVES) return (wave < EXP_DMA_WAVES && kb > wave) ? (kb - wave + EXP_DMA_WAVES - 1) / EXP_DMA_WAVES : 0;
-    return kb > wave ? (kb - wave + VFN16_WAVES - 1) / VFN16_WAVES : 0;
+template <int MODE, int C>
+__device__ __forceinline__ void dma_chunk(const Pipe16& p, int wave, int lane) {     // whole chunk at once (prologue only)
+    constexpr ChunkD d = chunk_of(MODE, C);
+#pragma unroll
+    for (int i = 0; i * VFN16_WAVES < d.kb; ++i)
+        if (wave + VFN16_WAVES * i < d.kb) dma_piece<d.net, d.off_kb, C % 3>(p, wave + VFN16_WAVES * i, lane);
 }
 
-__device__ __forceinline__ void dma_issue(const Pipe& p, int chunk_idx, int slot, int wave, int lane) {
-    const uint32_t e = chunk_entry(p, chunk_idx);
-    const uint4* src = ((e >> 31) ? p.rn_w : p.vf_w) + (size_t)((e >> 8) & 0x7fffffu) * 64;
-    const int kb = (int)(e & 0xffu);
-    uint4* dst = p.lds + slot * VFN16_SLOT;
-    for (int b = wave; b < kb; b += VFN16_WAVES)
-        __builtin_amdgcn_global_load_lds((glb_void*)(src + b * 64 + lane), (lds_void*)(dst + b * 64), 16, 0, 0);
+template <int MODE, int C>
+__device__ __forceinline__ void prefetch_chunk(Carry16& cy, const Pipe16& p, int lane) {
+    constexpr ChunkD d = chunk_of(MODE, C);
+    const uint4* cb = p.lds + (C % 3) * VFN16_SLOT;
+    const f32x4v* bb = reinterpret_cast<const f32x4v*>(cb + (d.kb - 1) * 64) + (lane >> 5) * 4;
+    const f32x4v b0 = bb[0], b1 = bb[1], b2 = bb[2], b3 = bb[3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { cy.bias[q] = b0[q]; cy.bias[4 + q] = b1[q]; cy.bias[8 + q] = b2[q]; cy.bias[12 + q] = b3[q]; }
+    cy.fh0 = __builtin_bit_cast(half8, cb[0 * 64 + lane]);
+    cy.fl0 = __builtin_bit_cast(half8, cb[1 * 64 + lane]);
 }
 
-__device__ __forceinline__ void wait_all_but(int n) {   // s_waitcnt vmcnt(n), n wave-uniform in 0..6
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    }
+// Two accumulator values -> (hi, lo) halves of element pair (j, j+1) of an operand block.
+template <int EPI>
+__device__ __forceinline__ void epi_pair(float a0, float a1, half8& hi, half8& lo, int j) {
+    float v0 = a0, v1 = a1;
+    if (!VFN16_ASCALE || EPI != EPI_RELU) { v0 *= VFN16_INV_WSCALE; v1 *= VFN16_INV_WSCALE; }
+    // ReLU, saturated below the f16 range so that an out-of-family activation degrades instead of turning into
+    // inf - inf = NaN in the split (activations of BatchNorm'ed layers are O(1..100))
+    if (EPI == EPI_RELU) { v0 = fminf(fmaxf(v0, 0.f), 60000.f); v1 = fminf(fmaxf(v1, 0.f), 60000.f); }
+    else { v0 = tanh_exp(v0) * VFN16_XSCALE; v1 = tanh_exp(v1) * VFN16_XSCALE; }
+    _Float16 h0, h1, l0, l1;
+    split2(v0, v1, h0, h1, l0, l1);
+    hi[j] = h0; hi[j + 1] = h1; lo[j] = l0; lo[j + 1] = l1;
 }
 
-// End of a chunk: chunk c+1 must have landed (ours: counted wait leaving chunk c+2's DMA in flight; everyone's: barrier).
-__device__ __forceinline__ void pipe_next(Pipe& p, int wave) {
-#ifndef ABL_NOSYNC
-    if (p.c + 1 < p.n_chunks) {
-#ifndef ABL_NOWAIT
-        wait_all_but(p.c + 2 < p.n_chunks ? dma_count(chunk_entry(p, p.c + 2), wave) : 0);
-#endif
-#ifndef ABL_NOBARRIER
-        __builtin_amdgcn_s_barrier();
-#endif
-    }
-#endif
-    p.c += 1;
-    p.slot = p.slot == 2 ? 0 : p.slot + 1;
-}
-
-// One layer: xout <- f(W' [xin ; aux] + b') — NCH chunks of TPC 16-row output tiles each.
-// D layout of v_mfma_f32_16x16x32_f16: column = lane & 15 (the point), row = 4 * (lane >> 4) + reg.
-template <int ACT, int AUX, int NCH, int TPC, int EPI>
-__device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xout, float (&head)[3], Pipe& p, int wave,
-                                        int lane) {
+// One layer: xout <- f(W' [xin ; aux] + b') — NCH chunks (C0 .. C0+NCH-1 of the launch) of one 32-row output tile each.
+// D layout of v_mfma_f32_32x32x16_f16: column = lane & 31 (the point), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5):
+// registers 0..7 / 8..15 of tile t ARE operand K-blocks 2t / 2t+1 of the next layer (order absorbed into the pack).
+//
+// With one wave per SIMD nothing else hides the epilogue, the DMA issue or the ring hand-over, so the chunk loop is
+// software-pipelined over the K steps of a tile (three MFMAs = 96 matrix-pipe cycles each, fenced by sched_barrier):
+//   first half   the epilogue of the PREVIOUS tile (8 register pairs);
+//   middle       s_waitcnt vmcnt(0) + s_barrier: chunk c+1 (issued half a chunk ago) has landed for everybody and
+//                everybody has left chunk c-1, whose slot is now free;
+//   second half  the LDS-DMA pieces of chunk c+2 into that slot;
+//   last step    the bias and first fragments of chunk c+1 (cy).
+// The last tile of a layer is handed to the next layer call in cy.pend (PEPI = its epilogue, PKB = the K-block pair of
+// `xpend` it becomes); it is needed only by K steps PKB, PKB+1 of that layer's first tile.
+template <int MODE, int C0, int ACT, int AUX, int NCH, int EPI, int PEPI, int PKB>
+__device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xout, X16& xpend, Carry16& cy, float (&head)[3],
+                                       const Pipe16& p, int wave, int lane) {
     constexpr int NKB = ACT + AUX;
-    const int g = lane >> 4;
-    const bool late_dma = wave < VFN16_DMA_WAVES;   // wave-uniform; see VFN16_DMA_WAVES
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        // (1) keep the ring two chunks ahead (issued after the MFMAs, by the older waves only: see VFN16_DMA_WAVES)
-#ifndef ABL_NODMA
-        if (!late_dma && p.c + 2 < p.n_chunks) dma_issue(p, p.c + 2, p.slot == 0 ? 2 : p.slot - 1, wave, lane);
-#endif
-        // (2) the chunk's tiles as one flat sequence of TPC * NKB steps (one K-block of one tile each).  The A
-        // fragments of step s+2 are read while the MFMAs of step s run; the order is pinned with
-        // sched_group_barrier because hipcc otherwise sinks every ds_read to just before its use and the LDS
-        // latency is paid on every step.
-        const uint4* cb = p.lds + p.slot * VFN16_SLOT;
-        constexpr int STEPS = TPC * NKB;
-        f32x4v acc[TPC];
-#pragma unroll
-        for (int t = 0; t < TPC; ++t) acc[t] = reinterpret_cast<const f32x4v*>(cb + STEPS * 2 * 64)[t * 4 + g];
-        half8 fh[3], fl[3];
-        fh[0] = __builtin_bit_cast(half8, cb[0 * 64 + lane]);
-        fl[0] = __builtin_bit_cast(half8, cb[1 * 64 + lane]);
-        if (STEPS > 1) {
+    constexpr int H = NKB / 2 > 0 ? NKB / 2 : 1;        // steps before the hand-over
+    constexpr int PMAX = (VFN16_MAX_CHUNK_KB + VFN16_WAVES - 1) / VFN16_WAVES;   // DMA pieces per wave and chunk
+    constexpr int DSTEPS = NKB - H > 0 ? NKB - H : 1;
+    static_assert(PEPI < 0 || PKB >= H, "the pending tile must be complete before it is read");
+    static_for<NCH>([&](auto ich) {
+        constexpr int ch = decltype(ich)::value;
+        constexpr int C = C0 + ch;
+        constexpr ChunkD dcur = chunk_of(MODE, C), dnext = chunk_of(MODE, C + 1), ddma = chunk_of(MODE, C + 2);
+        static_assert(dcur.kb == 2 * NKB + 1, "layer shape and chunk table disagree");
+        const uint4* cb = p.lds + (C % 3) * VFN16_SLOT;
+        f32x16 acc = cy.bias;
+        half8 fh[VFN16_FDEPTH], fl[VFN16_FDEPTH];
+        fh[0] = cy.fh0; fl[0] = cy.fl0;
+        if (VFN16_FDEPTH == 3 && NKB > 1) {
             fh[1] = __builtin_bit_cast(half8, cb[2 * 64 + lane]);
             fl[1] = __builtin_bit_cast(half8, cb[3 * 64 + lane]);
         }
+        half8 ehi[2], elo[2];
 #pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-            if (st + 2 < STEPS) {
-                fh[(st + 2) % 3] = __builtin_bit_cast(half8, cb[(2 * (st + 2)) * 64 + lane]);
-                fl[(st + 2) % 3] = __builtin_bit_cast(half8, cb[(2 * (st + 2) + 1) * 64 + lane]);
+        for (int st = 0; st < NKB; ++st) {
+            constexpr int AHEAD = VFN16_FDEPTH - 1;
+            if (st + AHEAD < NKB) {
+                fh[(st + AHEAD) % VFN16_FDEPTH] = __builtin_bit_cast(half8, cb[(2 * (st + AHEAD)) * 64 + lane]);
+                fl[(st + AHEAD) % VFN16_FDEPTH] = __builtin_bit_cast(half8, cb[(2 * (st + AHEAD) + 1) * 64 + lane]);
             }
-            const int t = st / NKB, kb = st % NKB;
-            const half8 a_hi = fh[st % 3], a_lo = fl[st % 3];
-            const half8 x_hi = kb < ACT ? xin.hi[kb < ACT ? kb : 0] : aux.hi[kb >= ACT ? kb - ACT : 0];
-            const half8 x_lo = kb < ACT ? xin.lo[kb < ACT ? kb : 0] : aux.lo[kb >= ACT ? kb - ACT : 0];
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, x_hi, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, x_lo, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, x_hi, acc[t], 0, 0, 0);
-        }
-        // schedule: bias + the first two steps' reads, then per step [2 reads for step s+2 | 3 MFMAs of step s]
-        __builtin_amdgcn_sched_group_barrier(0x100, TPC + (STEPS > 1 ? 4 : 2), 0);
-#pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-            if (st + 2 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        }
-        // (3) epilogue: the tile pair becomes K-block `ch` of the next layer's operand
+            const half8 a_hi = fh[st % VFN16_FDEPTH], a_lo = fl[st % VFN16_FDEPTH];
+            const half8 x_hi = st < ACT ? xin.hi[st < ACT ? st : 0] : aux.hi[st >= ACT ? st - ACT : 0];
+            const half8 x_lo = st < ACT ? xin.lo[st < ACT ? st : 0] : aux.lo[st >= ACT ? st - ACT : 0];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, x_hi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, x_lo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, x_hi, acc, 0, 0, 0);
+            // -- first half: epilogue pairs of the pending tile
 #ifdef ABL_NOEPI
-        if (EPI == EPI_RELU || EPI == EPI_TANH) {
-            asm volatile("" :: "v"(acc[0]), "v"(acc[TPC - 1]));
-            xout.hi[ch] = xin.hi[0]; xout.lo[ch] = xin.lo[0];
-        } else
+            if (st == 0 && (ch > 0 || PEPI >= 0)) asm volatile("" :: "v"(cy.pend));
+            if (false) {
+#else
+            if (st < H && (ch > 0 || PEPI >= 0)) {
 #endif
-        if (EPI == EPI_RELU || EPI == EPI_TANH) {
-            half8 hi, lo;
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                float v0 = acc[j >> 2][j & 3] * VFN16_INV_WSCALE, v1 = acc[j >> 2][(j & 3) + 1] * VFN16_INV_WSCALE;
-                // ReLU, saturated below the f16 range so that an out-of-family activation degrades instead of turning
-                // into inf - inf = NaN in the split (activations of BatchNorm'ed layers are O(1..100))
-                if (EPI == EPI_RELU) { v0 = fminf(fmaxf(v0, 0.f), 60000.f); v1 = fminf(fmaxf(v1, 0.f), 60000.f); }
-                else { v0 = tanh_exp(v0); v1 = tanh_exp(v1); }
-                _Float16 h0, h1, l0, l1;
-                split2(v0, v1, h0, h1, l0, l1);
-                hi[j] = h0; hi[j + 1] = h1; lo[j] = l0; lo[j + 1] = l1;
+                for (int pr = st * 8 / H; pr < (st + 1) * 8 / H; ++pr) {
+                    const int sblk = pr >> 2, j = (pr & 3) * 2;
+                    if (ch > 0) epi_pair<EPI>(cy.pend[2 * pr], cy.pend[2 * pr + 1], ehi[sblk], elo[sblk], j);
+                    else epi_pair<(PEPI >= 0 ? PEPI : 0)>(cy.pend[2 * pr], cy.pend[2 * pr + 1], ehi[sblk], elo[sblk], j);
+                    if ((pr & 3) == 3) {
+                        asm volatile("" : "+a"(ehi[sblk]));   // operands live in AGPRs (MFMA reads them there)
+                        asm volatile("" : "+a"(elo[sblk]));
+                        if (ch > 0) { xout.hi[2 * (ch > 0 ? ch - 1 : 0) + sblk] = ehi[sblk]; xout.lo[2 * (ch > 0 ? ch - 1 : 0) + sblk] = elo[sblk]; }
+                        else { xpend.hi[PKB + sblk] = ehi[sblk]; xpend.lo[PKB + sblk] = elo[sblk]; }
+                    }
+                }
+#ifndef VFN16_NOGROUPS
+                // one MFMA, then its share of the epilogue in that MFMA's shadow
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VFN16_EPI_PER_MFMA, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VFN16_EPI_PER_MFMA, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VFN16_EPI_PER_MFMA, 0);
+#endif
             }
-            xout.hi[ch] = hi; xout.lo[ch] = lo;
+            // -- middle: ring hand-over
+            if (st == H - 1 && dnext.kb > 0) {
+#ifndef ABL_NOSYNC
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#endif
+            }
+            // -- second half: this step's share of the DMA pieces of chunk c+2
+#ifndef ABL_NODMA
+            if (st >= H && ddma.kb > 0) {
+#pragma unroll
+                for (int i = (st - H) * PMAX / DSTEPS; i < (st - H + 1) * PMAX / DSTEPS; ++i) {
+                    if (VFN16_WAVES * i + VFN16_WAVES <= ddma.kb) dma_piece<ddma.net, ddma.off_kb, (C + 2) % 3>(p, wave + VFN16_WAVES * i, lane);
+                    else if (VFN16_WAVES * i < ddma.kb) { if (wave + VFN16_WAVES * i < ddma.kb) dma_piece<ddma.net, ddma.off_kb, (C + 2) % 3>(p, wave + VFN16_WAVES * i, lane); }
+                }
+            }
+#endif
+            // -- last step: the next chunk's bias and first fragments
+            if (st == NKB - 1 && dnext.kb > 0) prefetch_chunk<MODE, (dnext.kb > 0 ? C + 1 : C)>(cy, p, lane);
+#ifndef VFN16_NOSCHED
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+        if (EPI == EPI_RELU || EPI == EPI_TANH) {
+            cy.pend = acc;
         } else {
-            // 3-channel head: rows 0..2 of the tile are registers 0..2 of the g == 0 lanes
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float v = acc[0][c] * VFN16_INV_WSCALE;
+                const float v = acc[c] * VFN16_INV_WSCALE;     // rows 0..2 = registers 0..2 of the lanes with lane < 32
                 head[c] = (EPI == EPI_HEAD_TANH) ? tanh_exp(v) : 1.0f / (1.0f + expf(-v));
             }
         }
-#ifndef ABL_NODMA
-        if (late_dma && p.c + 2 < p.n_chunks) dma_issue(p, p.c + 2, p.slot == 0 ? 2 : p.slot - 1, wave, lane);
-#endif
-        // (4) hand over to the next chunk
-        pipe_next(p, wave);
-    }
+    });
 }
 
 // encoding columns [x(3), sin/cos(2^k x)...] of one 3-vector: column k of the aux operand
@@ -428,19 +508,18 @@ __device__ __forceinline__ float enc_value(const float (&x)[3], const float (&sn
     return rem < 3 ? sn[3 * oct + rem] : cs[3 * oct + rem - 3];
 }
 
-// aux operand from a column generator: element j of lane group g of K-block s <-> column 32 s + 8 g + j
+// aux operand from a column generator: element j of lane half g of K-block s <-> column 16 s + 8 g + j
 template <typename F>
 __device__ __forceinline__ void build_aux(A16& aux, int g, F col) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < 3; ++s) {
         half8 hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
             float v0, v1;
-            if (g == 0) { v0 = col(32 * s + j); v1 = col(32 * s + j + 1); }
-            else if (g == 1) { v0 = col(32 * s + 8 + j); v1 = col(32 * s + 8 + j + 1); }
-            else if (g == 2) { v0 = col(32 * s + 16 + j); v1 = col(32 * s + 16 + j + 1); }
-            else { v0 = col(32 * s + 24 + j); v1 = col(32 * s + 24 + j + 1); }
+            if (g == 0) { v0 = col(16 * s + j); v1 = col(16 * s + j + 1); }
+            else { v0 = col(16 * s + 8 + j); v1 = col(16 * s + 8 + j + 1); }
+            v0 *= VFN16_XSCALE; v1 *= VFN16_XSCALE;
             _Float16 h0, h1, l0, l1;
             split2(v0, v1, h0, h1, l0, l1);
             hi[j] = h0; hi[j + 1] = h1; lo[j] = l0; lo[j + 1] = l1;
@@ -449,26 +528,31 @@ __device__ __forceinline__ void build_aux(A16& aux, int g, F col) {
     }
 }
 
+__device__ __forceinline__ void load_aux(A16& ax, const float* park) {
+    const half8* pk = reinterpret_cast<const half8*>(park + 8);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { ax.hi[q] = pk[2 * q]; ax.lo[q] = pk[2 * q + 1]; }
+}
+
 template <int MODE>
-__global__ __launch_bounds__(512, 2) void vfn_mlp16_kernel(const Mlp16Args a) {
+__global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     // ONE __shared__ object: a second one beside an LDS-DMA destination makes hipcc drain vmcnt(0) before every
     // first ds_read after a DMA issue (cdna_hip_programming.md, "three .s-level traps")
-    __shared__ __attribute__((aligned(16))) uint4 s_ring[3 * VFN16_SLOT + VFN16_MAX_CHUNKS / 4 + 512 * 2];
-    uint32_t* s_tab = reinterpret_cast<uint32_t*>(s_ring + 3 * VFN16_SLOT);
-    // per-thread parking space for the point and its view direction (8 floats): they are needed again only when
-    // the rendering net's aux operand is built, ~100 chunks later, and would otherwise be spilled to scratch —
-    // private-memory traffic that shows up as ~0.7 GB of HBM reads+writes per launch and perturbs the vmcnt waits
-    float* s_park = reinterpret_cast<float*>(s_ring + 3 * VFN16_SLOT + VFN16_MAX_CHUNKS / 4) + threadIdx.x * 8;
+    __shared__ __attribute__((aligned(16))) uint4 s_ring[3 * VFN16_SLOT + 256 * 8];
+    // per-thread parking space (128 B): the point, its view direction and the encoding operand of the VF net, which is
+    // needed again only at the skip layer
+    float* s_park = reinterpret_cast<float*>(s_ring + 3 * VFN16_SLOT) + threadIdx.x * 32;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4;
-    const long long m = (long long)blockIdx.x * VFN16_PTS + wave * 16 + (lane & 15);
+    const int g = lane >> 5;
+#ifdef VFN16_STAMPS
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const long long m = (long long)blockIdx.x * VFN16_PTS + wave * 32 + (lane & 31);
     const bool in = m < a.n_points;
 
-    if (tid < VFN16_MAX_CHUNKS) s_tab[tid] = a.chunk[tid];
-    // this lane's point (the four lane groups of a wave share the 16 points); loaded BEFORE any DMA so that the
-    // counted vmcnt waits of the ring only ever see DMA instructions
+    // this lane's point (the two lane halves of a wave share the 32 points); loaded BEFORE any DMA
     float x[3] = {0.f, 0.f, 0.f};
     if (in) { x[0] = a.points[m * 3 + 0]; x[1] = a.points[m * 3 + 1]; x[2] = a.points[m * 3 + 2]; }
     float d[3] = {0.f, 0.f, 0.f};
@@ -481,15 +565,17 @@ __global__ __launch_bounds__(512, 2) void vfn_mlp16_kernel(const Mlp16Args a) {
         s_park[0] = x[0]; s_park[1] = x[1]; s_park[2] = x[2];
         s_park[4] = d[0]; s_park[5] = d[1]; s_park[6] = d[2];
     }
-    __syncthreads();   // chunk list visible
 
-    Pipe p;
-    p.lds = s_ring; p.tab = s_tab; p.vf_w = a.vf_w; p.rn_w = a.rn_w; p.n_chunks = a.n_chunks; p.slot = 0; p.c = 0;
-    dma_issue(p, 0, 0, wave, lane);
-    if (p.n_chunks > 1) dma_issue(p, 1, 1, wave, lane);
+    Pipe16 p;
+    p.lds = s_ring;
+    p.vf_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.vf_w), 0, (int)a.vf_bytes, 0x00020000);
+    p.rn_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(MODE == M16_FUSED ? a.rn_w : a.vf_w), 0,
+                                               (int)(MODE == M16_FUSED ? a.rn_bytes : a.vf_bytes), 0x00020000);
+    dma_chunk<MODE, 0>(p, wave, lane);
+    dma_chunk<MODE, 1>(p, wave, lane);
 
-    // ---- positional encoding of the point -> aux operand ------------------------------------------------
-    const int vf_multires = a.vf.multires, rn_multires = a.rn.multires;
+    // ---- positional encoding of the point -> aux operand (and its parked copy for the skip layer) -----------
+    const int vf_multires = a.vf_multires, rn_multires = a.rn_multires;
     A16 aux;
     {
         float sn[18], cs[18];
@@ -501,49 +587,42 @@ __global__ __launch_bounds__(512, 2) void vfn_mlp16_kernel(const Mlp16Args a) {
                 else { sn[3 * o + c] = 0.f; cs[3 * o + c] = 0.f; }
             }
         build_aux(aux, g, [&](int k) { return enc_value(x, sn, cs, vf_multires, k); });
+        half8* pk = reinterpret_cast<half8*>(s_park + 8);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { pk[2 * q] = aux.hi[q]; pk[2 * q + 1] = aux.lo[q]; }
     }
-    // chunk 0 landed (chunk 1 may still be in flight)
-    wait_all_but(p.n_chunks > 1 ? dma_count(chunk_entry(p, 1), wave) : 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunks 0 and 1 landed
     __builtin_amdgcn_s_barrier();
+    Carry16 cy;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) cy.pend[q] = 0.f;
+    prefetch_chunk<MODE, 0>(cy, p, lane);
 
-    // ---- VF net (shipped family: L0 | plain... | narrow | skip | plain... | [features] + head) ------------
+    // ---- VF net: straight-line code with static operand-set roles, so that only one set plus the tiles produced so far
+    // are ever live
     X16 xa, xb;
     float vec[3] = {0.f, 0.f, 0.f};
-    const int n_plain = a.vf.n_hidden - a.vf.feat_layer;
-    layer16<0, 2, 8, 2, EPI_RELU>(xa, aux, xb, vec, p, wave, lane);   // layer 0: encoding only
-    bool in_b = true;                                                 // current activations live in xb
-    for (int hh = 1; hh < n_plain; ++hh) {
-        const int shape = (a.vf.aux16[hh] ? 2 : 0) | (a.vf.n_tiles[hh] == 7 ? 1 : 0);
-        if (in_b) {
-            if (shape == 0) layer16<8, 0, 8, 2, EPI_RELU>(xb, aux, xa, vec, p, wave, lane);
-            else if (shape == 1) layer16<8, 0, 7, 2, EPI_RELU>(xb, aux, xa, vec, p, wave, lane);
-            else layer16<7, 2, 8, 2, EPI_RELU>(xb, aux, xa, vec, p, wave, lane);
-        } else {
-            if (shape == 0) layer16<8, 0, 8, 2, EPI_RELU>(xa, aux, xb, vec, p, wave, lane);
-            else if (shape == 1) layer16<8, 0, 7, 2, EPI_RELU>(xa, aux, xb, vec, p, wave, lane);
-            else layer16<7, 2, 8, 2, EPI_RELU>(xa, aux, xb, vec, p, wave, lane);
-        }
-        in_b = !in_b;
-    }
-    if (MODE == M16_VF_VEC) {
-        if (in_b) layer16<8, 0, 1, 1, EPI_HEAD_TANH>(xb, aux, xa, vec, p, wave, lane);
-        else layer16<8, 0, 1, 1, EPI_HEAD_TANH>(xa, aux, xb, vec, p, wave, lane);
+    constexpr int R = EPI_RELU, T = EPI_TANH, NONE = -1;
+    layer16<MODE, 0, 0, 3, 8, R, NONE, 0>(xa, aux, xb, xb, cy, vec, p, wave, lane);        // L0: encoding only
+    layer16<MODE, 8, 16, 0, 8, R, R, 14>(xb, aux, xa, xb, cy, vec, p, wave, lane);         // L1
+    layer16<MODE, 16, 16, 0, 8, R, R, 14>(xa, aux, xb, xa, cy, vec, p, wave, lane);        // L2
+    layer16<MODE, 24, 16, 0, 7, R, R, 14>(xb, aux, xa, xb, cy, vec, p, wave, lane);        // L3: 217 outputs
+    { A16 ax; load_aux(ax, s_park); layer16<MODE, 31, 14, 3, 8, R, R, 12>(xa, ax, xb, xa, cy, vec, p, wave, lane); }   // L4: skip
+    layer16<MODE, 39, 16, 0, 8, R, R, 14>(xb, aux, xa, xb, cy, vec, p, wave, lane);        // L5
+    layer16<MODE, 47, 16, 0, 8, R, R, 14>(xa, aux, xb, xa, cy, vec, p, wave, lane);        // L6
+    layer16<MODE, 55, 16, 0, 8, R, R, 14>(xb, aux, xa, xb, cy, vec, p, wave, lane);        // L7 -> xa
+    if constexpr (MODE == M16_VF_VEC) {
+        layer16<MODE, 63, 16, 0, 1, EPI_HEAD_TANH, R, 14>(xa, aux, xb, xa, cy, vec, p, wave, lane);
         if (in && g == 0) { a.out_vec[m * 3 + 0] = vec[0]; a.out_vec[m * 3 + 1] = vec[1]; a.out_vec[m * 3 + 2] = vec[2]; }
-        return;
-    }
-    // fused: feature block (tanh) then the vector head, both from the same input
-    if (in_b) {
-        layer16<8, 0, 8, 2, EPI_TANH>(xb, aux, xa, vec, p, wave, lane);
-        layer16<8, 0, 1, 1, EPI_HEAD_TANH>(xb, aux, xb, vec, p, wave, lane);
     } else {
-        layer16<8, 0, 8, 2, EPI_TANH>(xa, aux, xb, vec, p, wave, lane);
-        layer16<8, 0, 1, 1, EPI_HEAD_TANH>(xa, aux, xa, vec, p, wave, lane);
-    }
-    in_b = !in_b;   // the features are in the other set now
-    // the head's outputs sit in the g == 0 lanes; the other lane groups of the same point need them for the aux operand
+    // fused: feature block (tanh) -> xb, then the vector head from the same input; the head's tile hosts the epilogue
+    // of the last feature tile
+    layer16<MODE, 63, 16, 0, 8, T, R, 14>(xa, aux, xb, xa, cy, vec, p, wave, lane);
+    layer16<MODE, 71, 16, 0, 1, EPI_HEAD_TANH, T, 14>(xa, aux, xb, xb, cy, vec, p, wave, lane);
+    // the head's outputs sit in the lanes < 32; the other lane half of the same point needs them for the aux operand
     float nrm[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) nrm[c] = __shfl(vec[c], lane & 15, 64);
+    for (int c = 0; c < 3; ++c) nrm[c] = __shfl(vec[c], lane & 31, 64);
 
     // ---- rendering net: aux = [p(3), d(3), sin/cos(2^k d)(6L), n(3)] -------------------------------------
     {
@@ -565,105 +644,88 @@ __global__ __launch_bounds__(512, 2) void vfn_mlp16_kernel(const Mlp16Args a) {
         });
     }
     float rgb[3] = {0.f, 0.f, 0.f};
-    const int rn_hidden = a.rn.n_hidden;
-    for (int hh = 0; hh < rn_hidden; ++hh) {
-        if (in_b) {
-            if (hh == 0) layer16<8, 2, 8, 2, EPI_RELU>(xb, aux, xa, rgb, p, wave, lane);
-            else layer16<8, 0, 8, 2, EPI_RELU>(xb, aux, xa, rgb, p, wave, lane);
-        } else {
-            if (hh == 0) layer16<8, 2, 8, 2, EPI_RELU>(xa, aux, xb, rgb, p, wave, lane);
-            else layer16<8, 0, 8, 2, EPI_RELU>(xa, aux, xb, rgb, p, wave, lane);
-        }
-        in_b = !in_b;
+    layer16<MODE, 72, 16, 3, 8, R, NONE, 0>(xb, aux, xa, xb, cy, rgb, p, wave, lane);      // R0: [features ; p, PE(d), n]
+    layer16<MODE, 80, 16, 0, 8, R, R, 14>(xa, aux, xb, xa, cy, rgb, p, wave, lane);        // R1
+    layer16<MODE, 88, 16, 0, 8, R, R, 14>(xb, aux, xa, xb, cy, rgb, p, wave, lane);        // R2
+    layer16<MODE, 96, 16, 0, 8, R, R, 14>(xa, aux, xb, xa, cy, rgb, p, wave, lane);        // R3 -> xb
+    layer16<MODE, 104, 16, 0, 1, EPI_HEAD_SIGMOID, R, 14>(xb, aux, xa, xb, cy, rgb, p, wave, lane);
+    // outputs last: the only vector-memory stores of the kernel come after the last DMA wait
+    const long long mo = (long long)blockIdx.x * VFN16_PTS + (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
+    if (mo < a.n_points && (threadIdx.x & 32) == 0) {
+        a.out_vec[mo * 3 + 0] = nrm[0]; a.out_vec[mo * 3 + 1] = nrm[1]; a.out_vec[mo * 3 + 2] = nrm[2];
+        a.out_colors[mo * 3 + 0] = rgb[0]; a.out_colors[mo * 3 + 1] = rgb[1]; a.out_colors[mo * 3 + 2] = rgb[2];
     }
-    if (in_b) layer16<8, 0, 1, 1, EPI_HEAD_SIGMOID>(xb, aux, xa, rgb, p, wave, lane);
-    else layer16<8, 0, 1, 1, EPI_HEAD_SIGMOID>(xa, aux, xb, rgb, p, wave, lane);
-    // outputs last: the only vector-memory stores of the kernel come after the last counted wait
-    if (in && g == 0) {
-        a.out_vec[m * 3 + 0] = nrm[0]; a.out_vec[m * 3 + 1] = nrm[1]; a.out_vec[m * 3 + 2] = nrm[2];
-        a.out_colors[m * 3 + 0] = rgb[0]; a.out_colors[m * 3 + 1] = rgb[1]; a.out_colors[m * 3 + 2] = rgb[2];
+#ifdef VFN16_STAMPS
+    if (threadIdx.x == 0) {   // timing-only build: shader-clock and 100 MHz ticks of this workgroup, over its first colours
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        a.out_colors[mo * 3 + 0] = (float)(t1 - st_t0); a.out_colors[mo * 3 + 1] = (float)(r1 - st_r0);
     }
+#endif
+    }   // fused
 }
 
-// chunk list in consumption order
-int push_chunks(Mlp16Args& a, const Plan16& pl, int net, int h) {
-    const uint32_t kb = 4u * (pl.act16[h] + pl.aux16[h]) + 1u;
-    for (uint32_t ck = 0; ck < pl.n_tiles[h]; ++ck) {
-        if (a.n_chunks >= VFN16_MAX_CHUNKS) return VFN_ERR_UNSUPPORTED;
-        a.chunk[a.n_chunks++] = ((uint32_t)net << 31) | ((pl.off_kb[h] + ck * kb) << 8) | kb;
-    }
+// a network's plan against the compile-time tables
+int check_vf16(const Plan16& vf, const char* what) {
+    bool ok = vf.feat_layer == 1 && vf.n_hidden == 9 && (int)vf.head_off_kb == vf_off_kb(9);
+    for (int h = 0; ok && h < 9; ++h)
+        ok = vf.act16[h] == VF_ACT[h] && vf.aux16[h] == VF_AUX[h] && vf.n_tiles[h] == VF_TILES[h] && (int)vf.off_kb[h] == vf_off_kb(h);
+    if (!ok) { vfn_set_error("%s: the f16x3 kernels are specialised for the shipped vector-field network shape", what); return VFN_ERR_UNSUPPORTED; }
     return VFN_OK;
 }
-int push_head(Mlp16Args& a, const Plan16& pl, int net) {
-    if (a.n_chunks >= VFN16_MAX_CHUNKS) return VFN_ERR_UNSUPPORTED;
-    a.chunk[a.n_chunks++] = ((uint32_t)net << 31) | (pl.head_off_kb << 8) | 17u;
-    return VFN_OK;
-}
-
-int check_family(const Plan16& vf, const char* what) {
-    // the f16x3 kernel is specialised for the shipped layer shapes: first layer encoding-only, optional narrow layer
-    // (7 chunks) before a skip layer (7 + 2 K-blocks), everything else 256 x 256
-    if (vf.act16[0] != 0 || vf.aux16[0] != 2 || vf.n_tiles[0] != 8) { vfn_set_error("%s: unsupported first layer", what); return VFN_ERR_UNSUPPORTED; }
-    const int n_plain = vf.n_hidden - vf.feat_layer;
-    for (int h = 1; h < n_plain; ++h) {
-        const bool skip = vf.aux16[h] != 0;
-        if ((skip && vf.act16[h] != 7) || (!skip && vf.act16[h] != 8) || (vf.n_tiles[h] != 8 && vf.n_tiles[h] != 7) ||
-            (skip && vf.n_tiles[h] != 8)) {
-            vfn_set_error("%s: hidden layer %d has a shape the f16x3 kernel is not specialised for", what, h);
-            return VFN_ERR_UNSUPPORTED;
-        }
-    }
+int check_rn16(const Plan16& rn, const char* what) {
+    bool ok = rn.n_hidden == 4 && (int)rn.head_off_kb == rn_off_kb(4);
+    for (int h = 0; ok && h < 4; ++h)
+        ok = rn.act16[h] == RN_ACT[h] && rn.aux16[h] == RN_AUX[h] && rn.n_tiles[h] == RN_TILES[h] && (int)rn.off_kb[h] == rn_off_kb(h);
+    if (!ok) { vfn_set_error("%s: the f16x3 kernels are specialised for the shipped rendering network shape", what); return VFN_ERR_UNSUPPORTED; }
     return VFN_OK;
 }
 
 }  // namespace
 
+static int check_kind16(int net_kind, const Plan16& p, const char* what) {
+    return net_kind == VFN_NET_VF ? check_vf16(p, what) : check_rn16(p, what);
+}
+
 extern "C" int vfn_vf_mlp16_fwd(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
-                                float* out_vec, void* stream) {
+                                 float* out_vec, void* stream) {
     Mlp16Args a = {};
-    VfnNetPlan p32;
-    int rc = make_plan16(VFN_NET_VF, geom, &p32, &a.vf, "vfn_vf_mlp16_fwd");
+    VfnNetPlan p32; Plan16 vf;
+    int rc = make_plan16(VFN_NET_VF, geom, &p32, &vf, "vfn_vf_mlp16_fwd");
     if (rc != VFN_OK) return rc;
-    rc = check_family(a.vf, "vfn_vf_mlp16_fwd");
+    rc = check_vf16(vf, "vfn_vf_mlp16_fwd");
     if (rc != VFN_OK) return rc;
     if (n_points <= 0) return VFN_OK;
     VFN_REQUIRE(packed16 && points && out_vec, "vfn_vf_mlp16_fwd: NULL argument");
     a.vf_w = (const uint4*)packed16; a.points = points; a.out_vec = out_vec; a.n_points = n_points; a.dirs_div = 1;
-    const int n_plain = a.vf.n_hidden - a.vf.feat_layer;
-    for (int h = 0; h < n_plain; ++h)
-        if ((rc = push_chunks(a, a.vf, 0, h)) != VFN_OK) { vfn_set_error("vfn_vf_mlp16_fwd: too many weight chunks"); return rc; }
-    if ((rc = push_head(a, a.vf, 0)) != VFN_OK) { vfn_set_error("vfn_vf_mlp16_fwd: too many weight chunks"); return rc; }
+    a.vf_multires = vf.multires; a.vf_bytes = vf.total_kb * 1024u;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
-    hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_VEC>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_VEC>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_mlp16_fwd");
 }
 
 extern "C" int vfn_vf_render_fused16_fwd(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
-                                         const void* rn_packed16, const float* points, const float* ray_dirs,
-                                         int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
-                                         void* stream) {
+                                          const void* rn_packed16, const float* points, const float* ray_dirs,
+                                          int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
+                                          void* stream) {
     Mlp16Args a = {};
-    VfnNetPlan p32;
-    int rc = make_plan16(VFN_NET_VF, vf_geom, &p32, &a.vf, "vfn_vf_render_fused16_fwd");
+    VfnNetPlan p32; Plan16 vf, rn;
+    int rc = make_plan16(VFN_NET_VF, vf_geom, &p32, &vf, "vfn_vf_render_fused16_fwd");
     if (rc != VFN_OK) return rc;
-    rc = check_family(a.vf, "vfn_vf_render_fused16_fwd");
+    rc = make_plan16(VFN_NET_RENDER, rn_geom, &p32, &rn, "vfn_vf_render_fused16_fwd");
     if (rc != VFN_OK) return rc;
-    rc = make_plan16(VFN_NET_RENDER, rn_geom, &p32, &a.rn, "vfn_vf_render_fused16_fwd");
+    rc = check_vf16(vf, "vfn_vf_render_fused16_fwd");
     if (rc != VFN_OK) return rc;
-    VFN_REQUIRE(a.vf.feat_layer && vf_geom->feature_dims == VFN_HIDDEN && rn_geom->feature_dims == VFN_HIDDEN,
+    rc = check_rn16(rn, "vfn_vf_render_fused16_fwd");
+    if (rc != VFN_OK) return rc;
+    VFN_REQUIRE(vf_geom->feature_dims == VFN_HIDDEN && rn_geom->feature_dims == VFN_HIDDEN,
                 "vfn_vf_render_fused16_fwd: both nets need feature_dims == %d", VFN_HIDDEN);
-    VFN_REQUIRE(a.rn.act16[0] == 8 && a.rn.aux16[0] == 2, "vfn_vf_render_fused16_fwd: unsupported rendering layer 0");
     if (n_points <= 0) return VFN_OK;
     VFN_REQUIRE(vf_packed16 && rn_packed16 && points && ray_dirs && normals && colors, "vfn_vf_render_fused16_fwd: NULL argument");
     VFN_REQUIRE(samples_per_ray > 0, "vfn_vf_render_fused16_fwd: samples_per_ray must be > 0");
     a.vf_w = (const uint4*)vf_packed16; a.rn_w = (const uint4*)rn_packed16; a.points = points; a.ray_dirs = ray_dirs;
     a.out_vec = normals; a.out_colors = colors; a.n_points = n_points; a.dirs_div = samples_per_ray;
-    for (int h = 0; h < a.vf.n_hidden && rc == VFN_OK; ++h) rc = push_chunks(a, a.vf, 0, h);
-    if (rc == VFN_OK) rc = push_head(a, a.vf, 0);
-    for (int h = 0; h < a.rn.n_hidden && rc == VFN_OK; ++h) rc = push_chunks(a, a.rn, 1, h);
-    if (rc == VFN_OK) rc = push_head(a, a.rn, 1);
-    if (rc != VFN_OK) { vfn_set_error("vfn_vf_render_fused16_fwd: too many weight chunks"); return rc; }
+    a.vf_multires = vf.multires; a.rn_multires = rn.multires; a.vf_bytes = vf.total_kb * 1024u; a.rn_bytes = rn.total_kb * 1024u;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
-    hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_render_fused16_fwd");
 }
