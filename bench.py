@@ -34,6 +34,8 @@ import torch  # noqa: E402
 VF_MACS, RN_MACS = 525056, 271360          # per point
 PEAK_F32_MFMA = 157.3                      # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA = 2500.0                     # TFLOP/s dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+SUSTAINED_F16_MFMA = 1570.0                # TFLOP/s a pure 32x32x16 f16 MFMA loop sustains on random operands with every CU
+                                           # busy (power-limited clock ~1.8 GHz): tools/micro/mfma_power.hip, DESIGN.md §3
 
 
 def hbm_traffic(f16: bool):
@@ -387,6 +389,8 @@ def main() -> None:
                                     "fp32 MFMA 157.3 TFLOP/s"),
                 # BASELINE.md §3 states the path's roofline against the fp32 matrix peak:
                 "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA, 4)}
+        if f16:   # context, not the graded fraction: the power-limited MFMA rate measured on this chip
+            roof["frac_of_measured_sustained_f16_mfma"] = round(achieved / (SUSTAINED_F16_MFMA / 3.0), 4)
         line = {
             "metric": "rays/sec (4096-ray chunk, 128 samples/ray) + PSNR vs ref",
             "value": round(rays_per_s, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,

@@ -57,6 +57,12 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define VFN16_INV_WSCALE 0.015625f
 #define VFN16_PACK_WSCALE (VFN16_ASCALE ? 1.0f : VFN16_WSCALE)
 #define VFN16_XSCALE (VFN16_ASCALE ? VFN16_WSCALE : 1.0f)
+#ifndef VFN16_HANDOVER_NUM
+#define VFN16_HANDOVER_NUM 8     // ring hand-over after K step NKB * n / 16
+#endif
+#ifndef VFN16_DMA_STEPS
+#define VFN16_DMA_STEPS 16       // the DMA pieces of chunk c+2 are spread over at most this many K steps after it
+#endif
 #ifndef VFN16_EPI_PER_MFMA
 #define VFN16_EPI_PER_MFMA 6     // VALU instructions of the pending epilogue scheduled behind each MFMA
 #endif
@@ -404,10 +410,12 @@ template <int MODE, int C0, int ACT, int AUX, int NCH, int EPI, int PEPI, int PK
 __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xout, X16& xpend, Carry16& cy, float (&head)[3],
                                        const Pipe16& p, int wave, int lane) {
     constexpr int NKB = ACT + AUX;
-    constexpr int H = NKB / 2 > 0 ? NKB / 2 : 1;        // steps before the hand-over
+    constexpr int E = NKB / 2 > 0 ? NKB / 2 : 1;        // steps that carry the pending tile's epilogue
+    constexpr int H = NKB * VFN16_HANDOVER_NUM / 16 > 0 ? NKB * VFN16_HANDOVER_NUM / 16 : 1;   // steps before the hand-over
     constexpr int PMAX = (VFN16_MAX_CHUNK_KB + VFN16_WAVES - 1) / VFN16_WAVES;   // DMA pieces per wave and chunk
-    constexpr int DSTEPS = NKB - H > 0 ? NKB - H : 1;
-    static_assert(PEPI < 0 || PKB >= H, "the pending tile must be complete before it is read");
+    constexpr int DSPAN = NKB - H > 0 ? NKB - H : 1;
+    constexpr int DSTEPS = DSPAN < VFN16_DMA_STEPS ? DSPAN : VFN16_DMA_STEPS;          // steps that carry DMA pieces
+    static_assert(PEPI < 0 || PKB >= E, "the pending tile must be complete before it is read");
     static_for<NCH>([&](auto ich) {
         constexpr int ch = decltype(ich)::value;
         constexpr int C = C0 + ch;
@@ -440,10 +448,10 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
             if (st == 0 && (ch > 0 || PEPI >= 0)) asm volatile("" :: "v"(cy.pend));
             if (false) {
 #else
-            if (st < H && (ch > 0 || PEPI >= 0)) {
+            if (st < E && (ch > 0 || PEPI >= 0)) {
 #endif
 #pragma unroll
-                for (int pr = st * 8 / H; pr < (st + 1) * 8 / H; ++pr) {
+                for (int pr = st * 8 / E; pr < (st + 1) * 8 / E; ++pr) {
                     const int sblk = pr >> 2, j = (pr & 3) * 2;
                     if (ch > 0) epi_pair<EPI>(cy.pend[2 * pr], cy.pend[2 * pr + 1], ehi[sblk], elo[sblk], j);
                     else epi_pair<(PEPI >= 0 ? PEPI : 0)>(cy.pend[2 * pr], cy.pend[2 * pr + 1], ehi[sblk], elo[sblk], j);
@@ -474,7 +482,7 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
             }
             // -- second half: this step's share of the DMA pieces of chunk c+2
 #ifndef ABL_NODMA
-            if (st >= H && ddma.kb > 0) {
+            if (st >= H && st < H + DSTEPS && ddma.kb > 0) {
 #pragma unroll
                 for (int i = (st - H) * PMAX / DSTEPS; i < (st - H + 1) * PMAX / DSTEPS; ++i) {
                     if (VFN16_WAVES * i + VFN16_WAVES <= ddma.kb) dma_piece<ddma.net, ddma.off_kb, (C + 2) % 3>(p, wave + VFN16_WAVES * i, lane);
