@@ -248,6 +248,17 @@ int vfn_vf_render_fused16_fwd(const vfn_net_geom* vf_geom, const void* vf_packed
                               const void* rn_packed16, const float* points, const float* ray_dirs,
                               int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
                               void* stream);
+/* The same forwards under autograd (train/vector_field_nerf_train.py:177,191,203,215): they additionally fill the
+ * workspace the backward entry points read (`saved` slots, save_aux_vf[M,40], save_aux_rn[M,40]; see "slots" above),
+ * exactly like vfn_vf_mlp_fwd_train / vfn_vf_render_fused_fwd_train.  with_features = 0 evaluates only the vector head
+ * (the feature slot is not written); with_features = 1 also writes the 256 tanh'ed features into their slot, from which
+ * the caller assembles [M, 3+F].  n_points < 2^22 per launch. */
+int vfn_vf_mlp16_fwd_train(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
+                           int32_t with_features, float* out_vec, float* saved, float* save_aux_vf, void* stream);
+int vfn_vf_render_fused16_fwd_train(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
+                                    const void* rn_packed16, const float* points, const float* ray_dirs,
+                                    int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
+                                    float* saved, float* save_aux_vf, float* save_aux_rn, void* stream);
 
 #ifdef __cplusplus
 }

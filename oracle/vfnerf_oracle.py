@@ -133,11 +133,22 @@ def _layer_eval(sd: Dict[str, Tensor], i: int, x: Tensor) -> Tensor:
     return F.linear(x, sd[f'layers.{i}.weight'], sd[f'layers.{i}.bias'])
 
 
-def vf_mlp(points: Tensor, sd: Dict[str, Tensor], multires: int = 6, skip_in=(4,), hidden: Optional[list] = None) -> Tensor:
+def _relu(x: Tensor, masks: Optional[list]) -> Tensor:
+    """ReLU; with ``masks`` (a list consumed front to back) the unit is open where the given boolean mask says so
+    instead of where x > 0.  Tests pass the masks of the implementation under test: a pre-activation that is ~1e-7 from
+    zero may legitimately land on either side in two fp32 implementations, and with the masks pinned the gradients of
+    both can be compared tightly."""
+    if masks is None:
+        return torch.relu(x)
+    return x * masks.pop(0).to(x.dtype)
+
+
+def vf_mlp(points: Tensor, sd: Dict[str, Tensor], multires: int = 6, skip_in=(4,), hidden: Optional[list] = None,
+           masks: Optional[list] = None) -> Tensor:
     """[M,3] -> [M, 3 + F] (cols 0:3 vector after tanh, 3: features after tanh).
     vector_field_network.py:177-208: skip layers see cat([x, pe]) / sqrt(2); ReLU between
     layers, tanh on the last.  ``hidden`` (a list) receives every post-ReLU activation (tests use it to
-    detect ReLU-kink flips between two fp32 implementations)."""
+    detect ReLU-kink flips between two fp32 implementations); ``masks``: see _relu."""
     pe = positional_encoding(points, multires) if multires > 0 else points
     n = _n_layers(sd)
     x = pe.clone()
@@ -146,14 +157,14 @@ def vf_mlp(points: Tensor, sd: Dict[str, Tensor], multires: int = 6, skip_in=(4,
         if i in skip_in:
             x = torch.cat([x, pe], 1) / inv
         x = _layer_eval(sd, i, x)
-        x = torch.relu(x) if i < n - 1 else torch.tanh(x)
+        x = _relu(x, masks) if i < n - 1 else torch.tanh(x)
         if hidden is not None and i < n - 1:
             hidden.append(x.detach())
     return x
 
 
 def render_mlp(points: Tensor, normals: Tensor, view_dirs: Tensor, feats: Tensor,
-               sd: Dict[str, Tensor], multires: int = 4, hidden: Optional[list] = None) -> Tensor:
+               sd: Dict[str, Tensor], multires: int = 4, hidden: Optional[list] = None, masks: Optional[list] = None) -> Tensor:
     """mode 'idr' (rendering_network.py:84-86): cat[p, PE(d), n, feat] -> ReLU MLP -> sigmoid."""
     d = positional_encoding(view_dirs, multires) if multires > 0 else view_dirs
     x = torch.cat([points, d, normals, feats], dim=-1)
@@ -161,7 +172,7 @@ def render_mlp(points: Tensor, normals: Tensor, view_dirs: Tensor, feats: Tensor
     for i in range(n):
         x = _layer_eval(sd, i, x)
         if i < n - 1:
-            x = torch.relu(x)
+            x = _relu(x, masks)
             if hidden is not None:
                 hidden.append(x.detach())
     return torch.sigmoid(x)
@@ -309,7 +320,7 @@ class RenderSettings:
 def render(uv: Tensor, pose: Tensor, intrinsics: Tensor, vf_sd: Dict[str, Tensor], rn_sd: Dict[str, Tensor],
            cfg: RenderSettings, u_coarse: Optional[Tensor] = None, u_fine: Optional[Tensor] = None,
            u_add: Optional[Tensor] = None, far=None, beta=None, mean=None, scale=None,
-           hidden: Optional[list] = None) -> Dict[str, Tensor]:
+           hidden: Optional[list] = None, masks: Optional[list] = None) -> Dict[str, Tensor]:
     """Full forward of the path; returns every stage so tests can compare stage-wise.
     Random draws are explicit inputs, in the order the reference draws them
     (ray_sampler.py:138, :287, :292).  The proposal ("coarse") pass only evaluates the VF
@@ -343,7 +354,7 @@ def render(uv: Tensor, pose: Tensor, intrinsics: Tensor, vf_sd: Dict[str, Tensor
     s_t = cfg.n_samples + cfg.n_fine
     out.update(max_indices=imax, z_vals=z_f, points=pts_f)
 
-    vf_f = vf_mlp(pts_f.reshape(-1, 3), vf_sd, cfg.vf_multires, cfg.vf_skip_in, hidden=hidden)
+    vf_f = vf_mlp(pts_f.reshape(-1, 3), vf_sd, cfg.vf_multires, cfg.vf_skip_in, hidden=hidden, masks=masks)
     nrm_flat = vf_f[:, :3]
     feats = vf_f[:, 3:3 + cfg.feature_dims]
     nrm_f = nrm_flat.reshape(n, s_t, 3)
@@ -351,7 +362,8 @@ def render(uv: Tensor, pose: Tensor, intrinsics: Tensor, vf_sd: Dict[str, Tensor
                                            beta, mean, scale, return_parts=True)
     w_f = volsdf_weights(z_f, sigma_f, cfg.normalize)
     rep_dirs = ray_dirs.unsqueeze(1).repeat(1, s_t, 1).reshape(-1, 3)
-    colors = render_mlp(pts_f.reshape(-1, 3), nrm_flat.detach(), rep_dirs, feats, rn_sd, cfg.render_multires, hidden=hidden)
+    colors = render_mlp(pts_f.reshape(-1, 3), nrm_flat.detach(), rep_dirs, feats, rn_sd, cfg.render_multires, hidden=hidden,
+                        masks=masks)
     rgb = torch.sum(w_f.unsqueeze(-1) * colors.reshape(n, s_t, 3), dim=1)
     depth = torch.sum(w_f.unsqueeze(-1) * z_f.unsqueeze(-1), dim=1)
     out.update(vf_out=vf_f, normals=nrm_f, window_cos=cos_f, cos_ray=cosray_f, sigma=sigma_f, weights=w_f,

@@ -89,8 +89,9 @@ def grad_rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
 
 
-def oracle_gradients(fx, d, model):
-    """Autograd of the CPU oracle for the same functional -> {name: grad} for every parameter + density scalars."""
+def oracle_gradients(fx, d, model, masks=None):
+    """Autograd of the CPU oracle for the same functional -> {name: grad} for every parameter + density scalars.
+    ``masks``: ReLU masks of the fine pass (8 VF + 4 rendering layers, [M, width] bool) to pin, see oracle._relu."""
     from oracle import vfnerf_oracle as O
     vf_sd = {k: v.detach().cpu().clone() for k, v in model.vector_field_network.state_dict().items()}
     rn_sd = {k: v.detach().cpu().clone() for k, v in model.rendering_network.state_dict().items()}
@@ -105,7 +106,7 @@ def oracle_gradients(fx, d, model):
     hidden = []
     out = O.render(d["uv"], d["pose"], d["intrinsics"], vf_sd, rn_sd, oracle_settings(fx), u_coarse=d.get("u_coarse"),
                    u_fine=d.get("u_fine"), u_add=d["u_add"], far=d.get("far_per_ray"), beta=beta, mean=mean, scale=scale,
-                   hidden=hidden)
+                   hidden=hidden, masks=None if masks is None else list(masks))
     a, b, c = loss_coefficients(*d["z_vals"].shape)
     loss = (out["rgb"] * a).sum() + (out["depth"] * b).sum() + (out["normals"] * c).sum()
     loss.backward()

@@ -25,25 +25,34 @@ def _hip_gradients(fx, d, model):
     return float(loss), out
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
 @pytest.mark.parametrize("name", FIXTURE_NAMES)
-def test_render_gradients(name):
+def test_render_gradients(name, precision):
+    """``precision`` selects the arithmetic of the activation-saving forward (split-half f16 products or exact fp32
+    MFMA); the backward kernels are fp32 either way."""
     fx, d = load_fixture(name)
     model = build_model(fx, d, device="cuda:0")
+    model.precision = precision
     loss, out = _hip_gradients(fx, d, model)
     assert (out.z_vals.cpu() == d["z_vals"]).all(), "sampling must replay exactly for the comparison to be meaningful"
     ref_loss, ref = oracle_gradients(fx, d, build_model(fx, d))
     assert abs(loss - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss))
-    # ReLU kinks: two fp32 implementations can disagree on the sign of a pre-activation that is ~1e-7 from zero,
-    # which legitimately changes the gradient of everything below.  Count such flips from the saved activations.
+    # ReLU kinks: two fp32-accurate implementations can disagree on the sign of a pre-activation that is ~1e-7 from
+    # zero, which legitimately changes the gradient of everything below (one unit of a 64-ray fixture moves a layer's
+    # gradient by percents).  Count such flips from the saved activations; when there are any, the tight comparison is
+    # made against the oracle re-run with THIS implementation's masks pinned.
     saved = model._debug_saved.cpu()
     slots = list(range(8)) + list(range(9, 13))          # VF hidden 0..7, rendering hidden 0..3 (slot 8 = features)
-    flips = 0
+    masks, flips = [], 0
     for slot, act in zip(slots, ref["_hidden"]):
         w = act.shape[1]
-        flips += int(((saved[slot][:, :w] > 0) != (act > 0)).sum())
-    tol = TOL if flips == 0 else 3e-2
-    print(f"{name}: ReLU sign flips between HIP and CPU activations: {flips} -> tolerance {tol:g}")
-    assert flips <= 3
+        masks.append(saved[slot][:, :w] > 0)
+        flips += int((masks[-1] != (act > 0)).sum())
+    print(f"{name}/{precision}: ReLU sign flips between HIP and CPU activations: {flips}")
+    assert flips <= 4
+    if flips:
+        ref_loss, ref = oracle_gradients(fx, d, build_model(fx, d), masks=masks)
+        assert abs(loss - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss))
     worst = ("", 0.0)
     errs = []
     nets = {"vf": model.vector_field_network, "rn": model.rendering_network}
@@ -53,21 +62,60 @@ def test_render_gradients(name):
             err = grad_rel_err(p.grad, ref[f"{tag}.{pname}"])
             if err > worst[1]:
                 worst = (f"{tag}.{pname}", err)
-            if err > 1e-4:
-                print(f"   {tag}.{pname}: err {err:.3e} (|ref|max {float(ref[f'{tag}.{pname}'].abs().max()):.3e})")
             errs.append((tag, pname, err))
     for pname, p in model.density.named_parameters():
         err = grad_rel_err(p.grad.reshape(1), ref[f"density.{pname}"].reshape(1))
         print(f"density.{pname}: hip {float(p.grad):.6e} ref {float(ref['density.' + pname]):.6e}")
-        assert err < tol, (pname, err)
-    print(f"{name}: worst parameter-gradient error {worst[1]:.3e} at {worst[0]}")
-    assert all(e < tol for _, _, e in errs), [x for x in errs if x[2] >= tol]
-    # and against the reference's own backward pass
+        assert err < TOL, (pname, err)
+    print(f"{name}/{precision}: worst parameter-gradient error {worst[1]:.3e} at {worst[0]}")
+    assert all(e < TOL for _, _, e in errs), [x for x in errs if x[2] >= TOL]
+    # and against the reference's own backward pass (captured in the fixture): tight when no unit flipped, a sanity
+    # bound otherwise
+    tol_ref = TOL if flips == 0 else 1e-1
     for tag, key in GRAD_KEYS:
         err = grad_rel_err(dict(nets[tag].named_parameters())[key].grad, d[f"grad.{tag}.{key}"])
-        assert err < tol, ("vs reference", tag, key, err)
+        assert err < tol_ref, ("vs reference", tag, key, err)
     for k in ("beta", "mean", "scale"):
-        assert grad_rel_err(getattr(model.density, k).grad.reshape(1), d[f"grad.density.{k}"]) < tol
+        assert grad_rel_err(getattr(model.density, k).grad.reshape(1), d[f"grad.density.{k}"]) < tol_ref
+
+
+def test_training_forward_workspace_f16x3_matches_fp32():
+    """The two activation-saving forwards (vfn_vf_render_fused16_fwd_train / vfn_vf_render_fused_fwd_train and the VF-only
+    pair) fill the same workspace: every hidden layer's output, both encoding tiles, normals and colours."""
+    from vf_nerf_amd import lib
+    from vf_nerf_amd.backward import _Workspace, _entries
+    fx, d = load_fixture("c1_perturb")
+    model = build_model(fx, d, device="cuda:0")
+    vf, rn = model.vector_field_network, model.rendering_network
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(5)
+    n, s_t = 37, 12                                    # 444 points: ragged last workgroup
+    pts = (torch.rand(n * s_t, 3, generator=gen) * 2 - 1).to(dev)
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=1).to(dev)
+    m, slots = n * s_t, len(_entries(vf)) + len(_entries(rn))
+    ws32, ws16 = _Workspace(m, slots, dev), _Workspace(m, slots, dev)
+    n32, c32 = lib.vf_render_fused_fwd_train(vf.geometry(), vf.packed_weights(), rn.geometry(), rn.packed_weights(), pts,
+                                             dirs, s_t, ws32.saved, ws32.aux_vf, ws32.aux_rn)
+    n16, c16 = lib.vf_render_fused16_fwd_train(vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(),
+                                               pts, dirs, s_t, ws16.saved, ws16.aux_vf, ws16.aux_rn)
+    assert float((n16 - n32).abs().max()) < 2e-5 and float((c16 - c32).abs().max()) < 2e-5
+    assert float((ws16.aux_vf[:, :39] - ws32.aux_vf[:, :39]).abs().max()) < 1e-6
+    assert float((ws16.aux_rn[:, :33] - ws32.aux_rn[:, :33]).abs().max()) < 2e-5      # holds the normals
+    widths = [256, 256, 256, 217, 256, 256, 256, 256, 256, 256, 256, 256, 256]
+    for slot, w in enumerate(widths):
+        a, b = ws16.saved[slot][:, :w], ws32.saved[slot][:, :w]
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) < 2e-5 * scale, (slot, float((a - b).abs().max()), scale)
+    # VF-only variants (supervision points), with and without the feature block
+    for with_feat in (False, True):
+        w32, w16 = _Workspace(m, len(_entries(vf)), dev), _Workspace(m, len(_entries(vf)), dev)
+        o32 = lib.vf_mlp_fwd_train(vf.geometry(), vf.packed_weights(), pts, 259 if with_feat else 3, w32.saved, w32.aux_vf)
+        o16 = lib.vf_mlp16_fwd_train(vf.geometry(), vf.packed16_weights(), pts, with_feat, w16.saved, w16.aux_vf)
+        assert float((o16 - o32[:, :3]).abs().max()) < 2e-5
+        for slot in range(9 if with_feat else 8):
+            w = widths[slot]
+            scale = max(1.0, float(w32.saved[slot][:, :w].abs().max()))
+            assert float((w16.saved[slot][:, :w] - w32.saved[slot][:, :w]).abs().max()) < 2e-5 * scale, (with_feat, slot)
 
 
 def test_supervision_forward_gradients():
@@ -106,6 +154,9 @@ def test_one_adam_step_matches_oracle_step():
     train/vector_field_nerf_train.py:251-260 does, against the same sequence driven by the oracle's gradients."""
     fx, d = load_fixture("w1_det")
     model = build_model(fx, d, device="cuda:0")
+    # exact-fp32 forward: this test is about the optimizer sequence; a ReLU unit landing on the other side of zero
+    # (which the split-f16 forward does on this fixture, see test_render_gradients) would change the gradients by percents
+    model.precision = "fp32"
     ref_model = build_model(fx, d)
     # torch's multi-tensor ("foreach") Adam / clip update duplicated parameters concurrently on the GPU, which makes
     # the reference's double update (Q4) racy there; pin the sequential semantics on both sides for the comparison.
@@ -164,6 +215,8 @@ def test_training_loop_tracks_the_cpu_path():
 
     def run(device):
         model = build_model(fx, d, device=device)
+        if device != "cpu":
+            model.precision = "fp32"     # a trajectory comparison: keep every discrete event (ReLU kinks) on the CPU's side
         lr = model.config.scheduler_config.lr
         model.optimizer = torch.optim.Adam(model.parameters(), lr=lr, foreach=False)      # sequential on both sides
         model.scheduler = torch.optim.lr_scheduler.ExponentialLR(model.optimizer, 0.1 ** (1. / 50000))

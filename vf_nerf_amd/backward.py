@@ -160,6 +160,9 @@ def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=()) -> Dict[
     return grads
 
 
+_F16_TRAIN_MAX_POINTS = 1 << 22   # the f16x3 training kernels address a workspace slot with 32-bit offsets
+
+
 class _Workspace:
     def __init__(self, m: int, n_slots: int, dev) -> None:
         self.saved = torch.empty(n_slots, m, HID, device=dev)
@@ -180,9 +183,14 @@ class _FinePass(torch.autograd.Function):
         vf_h, rn_h = len(_entries(vf)), len(_entries(rn))
         ws = _Workspace(m, vf_h + rn_h, dev)
         scal = model.density.raw_scalars()
-        normals, colors = lib.vf_render_fused_fwd_train(vf.geometry(), vf.packed_weights(), rn.geometry(),
-                                                        rn.packed_weights(), pts.reshape(-1, 3), ray_dirs, s_t,
-                                                        ws.saved, ws.aux_vf, ws.aux_rn)
+        if model.uses_f16x3() and m < _F16_TRAIN_MAX_POINTS:   # split-half products, fp32-equivalent (csrc/vfn_mlp16.hip)
+            normals, colors = lib.vf_render_fused16_fwd_train(vf.geometry(), vf.packed16_weights(), rn.geometry(),
+                                                              rn.packed16_weights(), pts.reshape(-1, 3), ray_dirs, s_t,
+                                                              ws.saved, ws.aux_vf, ws.aux_rn)
+        else:
+            normals, colors = lib.vf_render_fused_fwd_train(vf.geometry(), vf.packed_weights(), rn.geometry(),
+                                                            rn.packed_weights(), pts.reshape(-1, 3), ray_dirs, s_t,
+                                                            ws.saved, ws.aux_vf, ws.aux_rn)
         dp = model._density_params()
         _, weights, _, rgb, depth = lib.ray_density_weights(dp, normals, ray_dirs, z, scal, colors=colors,
                                                             want_sigma=False)
@@ -251,7 +259,12 @@ class _VFForward(torch.autograd.Function):
         vf_h = len(_entries(net))
         ws = _Workspace(m, vf_h, dev)
         cols = 3 if (vector_only or not has_feat) else 3 + net._feature_dims()
-        out = lib.vf_mlp_fwd_train(net.geometry(), net.packed_weights(), pts, cols, ws.saved, ws.aux_vf)
+        if getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3() and m < _F16_TRAIN_MAX_POINTS:
+            out = lib.vf_mlp16_fwd_train(net.geometry(), net.packed16_weights(), pts, cols > 3, ws.saved, ws.aux_vf)
+            if cols > 3:   # [vector | features]: the kernel left the features in their workspace slot
+                out = torch.cat([out, ws.saved[vf_h - 1]], dim=1)
+        else:
+            out = lib.vf_mlp_fwd_train(net.geometry(), net.packed_weights(), pts, cols, ws.saved, ws.aux_vf)
         ctx.net, ctx.ws, ctx.dims, ctx.param_order = net, ws, (m, vf_h, cols), list(params)
         ctx.save_for_backward(out)
         return out

@@ -249,7 +249,11 @@ extern "C" int vfn_pack16_weights(int32_t net_kind, const vfn_net_geom* geom, co
 namespace {
 
 enum : int { EPI_RELU = 0, EPI_TANH = 1, EPI_HEAD_TANH = 2, EPI_HEAD_SIGMOID = 3 };
-enum : int { M16_VF_VEC = 0, M16_FUSED = 1 };
+// launch modes: bit 0 = the VF feature block is evaluated, bit 1 = the rendering net follows, bit 2 = training (every
+// hidden layer's post-activation output and the encoding tiles are written out for the backward kernels)
+enum : int { M16_FEAT = 1, M16_RENDER = 2, M16_TRAIN = 4,
+             M16_VF_VEC = 0, M16_FUSED = M16_FEAT | M16_RENDER,
+             M16_VF_VEC_TRAIN = M16_TRAIN, M16_VF_FULL_TRAIN = M16_FEAT | M16_TRAIN, M16_FUSED_TRAIN = M16_FUSED | M16_TRAIN };
 
 #ifndef VFN16_FDEPTH
 #define VFN16_FDEPTH 2            // A-fragment ring: K steps in registers (1 ahead)
@@ -280,14 +284,14 @@ struct ChunkD { int net, off_kb, kb; };      // net 0 = VF pack, 1 = rendering p
 // chunk c of the launch in consumption order (fused: VF hidden + features, VF head, rendering hidden, rendering head;
 // vector-only: the 8 plain VF layers, VF head)
 constexpr ChunkD chunk_of(int mode, int c) {
-    const int vf_layers = mode == M16_FUSED ? 9 : 8;
+    const int vf_layers = (mode & M16_FEAT) ? 9 : 8;
     for (int h = 0; h < vf_layers; ++h) {
         if (c < VF_TILES[h]) return {0, vf_off_kb(h) + c * chunk_kb(VF_ACT[h], VF_AUX[h]), chunk_kb(VF_ACT[h], VF_AUX[h])};
         c -= VF_TILES[h];
     }
     if (c == 0) return {0, vf_off_kb(9), HEAD_KB};
     c -= 1;
-    if (mode == M16_FUSED) {
+    if (mode & M16_RENDER) {
         for (int h = 0; h < 4; ++h) {
             if (c < RN_TILES[h]) return {1, rn_off_kb(h) + c * chunk_kb(RN_ACT[h], RN_AUX[h]), chunk_kb(RN_ACT[h], RN_AUX[h])};
             c -= RN_TILES[h];
@@ -308,6 +312,11 @@ struct Mlp16Args {
     int dirs_div;
     int vf_multires, rn_multires;
     uint32_t vf_bytes, rn_bytes;
+    // training modes: saved[slot][M][256] (slots: VF hidden 0..8 incl. the feature block, rendering hidden 9..12),
+    // save_aux_vf / save_aux_rn [M][40]
+    float* saved;
+    float* save_aux_vf;
+    float* save_aux_rn;
 };
 
 struct X16 { half8 hi[16]; half8 lo[16]; };     // 256 activation columns x this lane's point, split (16 K-blocks of 16)
@@ -317,6 +326,11 @@ struct Pipe16 {
     uint4* lds;                    // ring base
     __amdgpu_buffer_rsrc_t vf_w;   // the two f16 packs as buffer resources: the DMA addresses stay in SGPRs
     __amdgpu_buffer_rsrc_t rn_w;
+    // training modes
+    float* saved;
+    long long slot_floats;         // M * 256
+    uint32_t slot_bytes;           // M * 1024 (the host checks that it fits)
+    uint32_t save_voff;            // byte offset of this lane's 16-byte column group in a slot row; out of range for m >= M
 };
 
 // State carried from chunk to chunk (and from layer call to layer call): the previous tile's accumulators, whose
@@ -380,9 +394,9 @@ __device__ __forceinline__ void prefetch_chunk(Carry16& cy, const Pipe16& p, int
 }
 
 // Two accumulator values -> (hi, lo) halves of element pair (j, j+1) of an operand block.
-template <int EPI>
-__device__ __forceinline__ void epi_pair(float a0, float a1, half8& hi, half8& lo, int j) {
-    float v0 = a0, v1 = a1;
+template <int EPI, bool KEEP>
+__device__ __forceinline__ void epi_pair(f32x16& pend, int pr, half8& hi, half8& lo, int j) {
+    float v0 = pend[2 * pr], v1 = pend[2 * pr + 1];
     if (!VFN16_ASCALE || EPI != EPI_RELU) { v0 *= VFN16_INV_WSCALE; v1 *= VFN16_INV_WSCALE; }
     // ReLU, saturated below the f16 range so that an out-of-family activation degrades instead of turning into
     // inf - inf = NaN in the split (activations of BatchNorm'ed layers are O(1..100))
@@ -391,6 +405,18 @@ __device__ __forceinline__ void epi_pair(float a0, float a1, half8& hi, half8& l
     _Float16 h0, h1, l0, l1;
     split2(v0, v1, h0, h1, l0, l1);
     hi[j] = h0; hi[j + 1] = h1; lo[j] = l0; lo[j + 1] = l1;
+    if (KEEP) { pend[2 * pr] = v0 * (1.0f / VFN16_XSCALE); pend[2 * pr + 1] = v1 * (1.0f / VFN16_XSCALE); }   // training: the value the backward reads
+}
+
+// Training: registers 4q..4q+3 of a finished tile = 4 consecutive columns (32 TILE + 8 q + 4 (lane >> 5)) of this lane's
+// point -> one 16-byte buffer store into slot SLOT (rows beyond M are dropped by the range check).
+template <int SLOT, int TILE>
+__device__ __forceinline__ void save_group(const Pipe16& p, const f32x16& v, int q) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.saved + (long long)SLOT * p.slot_floats, 0,
+                                                                        (int)p.slot_bytes, 0x00020000);
+    const f32x4v g = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)p.save_voff, (32 * TILE + 8 * q) * 4, 0);
 }
 
 // One layer: xout <- f(W' [xin ; aux] + b') — NCH chunks (C0 .. C0+NCH-1 of the launch) of one 32-row output tile each.
@@ -406,7 +432,7 @@ __device__ __forceinline__ void epi_pair(float a0, float a1, half8& hi, half8& l
 //   last step    the bias and first fragments of chunk c+1 (cy).
 // The last tile of a layer is handed to the next layer call in cy.pend (PEPI = its epilogue, PKB = the K-block pair of
 // `xpend` it becomes); it is needed only by K steps PKB, PKB+1 of that layer's first tile.
-template <int MODE, int C0, int ACT, int AUX, int NCH, int EPI, int PEPI, int PKB>
+template <int MODE, int C0, int ACT, int AUX, int NCH, int EPI, int PEPI, int PKB, int SLOT = -1, int PSLOT = -1>
 __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xout, X16& xpend, Carry16& cy, float (&head)[3],
                                        const Pipe16& p, int wave, int lane) {
     constexpr int NKB = ACT + AUX;
@@ -416,6 +442,8 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
     constexpr int DSPAN = NKB - H > 0 ? NKB - H : 1;
     constexpr int DSTEPS = DSPAN < VFN16_DMA_STEPS ? DSPAN : VFN16_DMA_STEPS;          // steps that carry DMA pieces
     static_assert(PEPI < 0 || PKB >= E, "the pending tile must be complete before it is read");
+    constexpr bool TRAIN = (MODE & M16_TRAIN) != 0;
+    constexpr int SSTEPS = DSPAN < 4 ? DSPAN : 4;      // training: steps after the hand-over that carry the 4 stores of a tile
     static_for<NCH>([&](auto ich) {
         constexpr int ch = decltype(ich)::value;
         constexpr int C = C0 + ch;
@@ -453,8 +481,8 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
 #pragma unroll
                 for (int pr = st * 8 / E; pr < (st + 1) * 8 / E; ++pr) {
                     const int sblk = pr >> 2, j = (pr & 3) * 2;
-                    if (ch > 0) epi_pair<EPI>(cy.pend[2 * pr], cy.pend[2 * pr + 1], ehi[sblk], elo[sblk], j);
-                    else epi_pair<(PEPI >= 0 ? PEPI : 0)>(cy.pend[2 * pr], cy.pend[2 * pr + 1], ehi[sblk], elo[sblk], j);
+                    if (ch > 0) epi_pair<EPI, TRAIN>(cy.pend, pr, ehi[sblk], elo[sblk], j);
+                    else epi_pair<(PEPI >= 0 ? PEPI : 0), TRAIN>(cy.pend, pr, ehi[sblk], elo[sblk], j);
                     if ((pr & 3) == 3) {
                         asm volatile("" : "+a"(ehi[sblk]));   // operands live in AGPRs (MFMA reads them there)
                         asm volatile("" : "+a"(elo[sblk]));
@@ -490,6 +518,15 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
                 }
             }
 #endif
+            // -- training: the finished (activated) pending tile goes out after the hand-over, so that the stores have
+            // half a chunk to retire before the next vmcnt(0)
+            if (TRAIN && st >= H && st < H + SSTEPS && (ch > 0 || PEPI >= 0)) {
+#pragma unroll
+                for (int q = (st - H) * 4 / SSTEPS; q < (st - H + 1) * 4 / SSTEPS; ++q) {
+                    if (ch > 0) save_group<(SLOT >= 0 ? SLOT : 0), (ch > 0 ? ch - 1 : 0)>(p, cy.pend, q);
+                    else save_group<(PSLOT >= 0 ? PSLOT : 0), PKB / 2>(p, cy.pend, q);
+                }
+            }
             // -- last step: the next chunk's bias and first fragments
             if (st == NKB - 1 && dnext.kb > 0) prefetch_chunk<MODE, (dnext.kb > 0 ? C + 1 : C)>(cy, p, lane);
 #ifndef VFN16_NOSCHED
@@ -536,6 +573,23 @@ __device__ __forceinline__ void build_aux(A16& aux, int g, F col) {
     }
 }
 
+// training: this lane's columns of the encoding tile -> dst[m][40] (column 16 s + 8 g + j; 16-byte groups below 40)
+template <typename F>
+__device__ __forceinline__ void save_aux(float* dst, long long m, int g, F col) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c0 = 16 * s + 8 * g + 4 * h;
+            if (c0 + 4 <= VFN_AUX_K) {
+                f32x4v v;
+                if (g == 0) { v = f32x4v{col(16 * s + 4 * h), col(16 * s + 4 * h + 1), col(16 * s + 4 * h + 2), col(16 * s + 4 * h + 3)}; }
+                else { v = f32x4v{col(16 * s + 8 + 4 * h), col(16 * s + 8 + 4 * h + 1), col(16 * s + 8 + 4 * h + 2), col(16 * s + 8 + 4 * h + 3)}; }
+                *reinterpret_cast<f32x4v*>(dst + m * VFN_AUX_K + c0) = v;
+            }
+        }
+}
+
 __device__ __forceinline__ void load_aux(A16& ax, const float* park) {
     const half8* pk = reinterpret_cast<const half8*>(park + 8);
 #pragma unroll
@@ -564,12 +618,12 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     float x[3] = {0.f, 0.f, 0.f};
     if (in) { x[0] = a.points[m * 3 + 0]; x[1] = a.points[m * 3 + 1]; x[2] = a.points[m * 3 + 2]; }
     float d[3] = {0.f, 0.f, 0.f};
-    if (MODE == M16_FUSED && in) {
+    if ((MODE & M16_RENDER) && in) {
         const long long di = m / a.dirs_div;
         d[0] = a.ray_dirs[di * 3 + 0]; d[1] = a.ray_dirs[di * 3 + 1]; d[2] = a.ray_dirs[di * 3 + 2];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (MODE == M16_FUSED) {
+    if (MODE & M16_RENDER) {
         s_park[0] = x[0]; s_park[1] = x[1]; s_park[2] = x[2];
         s_park[4] = d[0]; s_park[5] = d[1]; s_park[6] = d[2];
     }
@@ -577,8 +631,10 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     Pipe16 p;
     p.lds = s_ring;
     p.vf_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.vf_w), 0, (int)a.vf_bytes, 0x00020000);
-    p.rn_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(MODE == M16_FUSED ? a.rn_w : a.vf_w), 0,
-                                               (int)(MODE == M16_FUSED ? a.rn_bytes : a.vf_bytes), 0x00020000);
+    p.rn_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>((MODE & M16_RENDER) ? a.rn_w : a.vf_w), 0,
+                                               (int)((MODE & M16_RENDER) ? a.rn_bytes : a.vf_bytes), 0x00020000);
+    p.saved = a.saved; p.slot_floats = a.n_points * 256; p.slot_bytes = (uint32_t)(a.n_points * 1024);
+    p.save_voff = in ? (uint32_t)(m * 1024 + g * 16) : 0xfffffff0u;
     dma_chunk<MODE, 0>(p, wave, lane);
     dma_chunk<MODE, 1>(p, wave, lane);
 
@@ -595,6 +651,7 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
                 else { sn[3 * o + c] = 0.f; cs[3 * o + c] = 0.f; }
             }
         build_aux(aux, g, [&](int k) { return enc_value(x, sn, cs, vf_multires, k); });
+        if ((MODE & M16_TRAIN) && in) save_aux(a.save_aux_vf, m, g, [&](int k) { return enc_value(x, sn, cs, vf_multires, k); });
         half8* pk = reinterpret_cast<half8*>(s_park + 8);
 #pragma unroll
         for (int q = 0; q < 3; ++q) { pk[2 * q] = aux.hi[q]; pk[2 * q + 1] = aux.lo[q]; }
@@ -611,22 +668,25 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     X16 xa, xb;
     float vec[3] = {0.f, 0.f, 0.f};
     constexpr int R = EPI_RELU, T = EPI_TANH, NONE = -1;
-    layer16<MODE, 0, 0, 3, 8, R, NONE, 0>(xa, aux, xb, xb, cy, vec, p, wave, lane);        // L0: encoding only
-    layer16<MODE, 8, 16, 0, 8, R, R, 14>(xb, aux, xa, xb, cy, vec, p, wave, lane);         // L1
-    layer16<MODE, 16, 16, 0, 8, R, R, 14>(xa, aux, xb, xa, cy, vec, p, wave, lane);        // L2
-    layer16<MODE, 24, 16, 0, 7, R, R, 14>(xb, aux, xa, xb, cy, vec, p, wave, lane);        // L3: 217 outputs
-    { A16 ax; load_aux(ax, s_park); layer16<MODE, 31, 14, 3, 8, R, R, 12>(xa, ax, xb, xa, cy, vec, p, wave, lane); }   // L4: skip
-    layer16<MODE, 39, 16, 0, 8, R, R, 14>(xb, aux, xa, xb, cy, vec, p, wave, lane);        // L5
-    layer16<MODE, 47, 16, 0, 8, R, R, 14>(xa, aux, xb, xa, cy, vec, p, wave, lane);        // L6
-    layer16<MODE, 55, 16, 0, 8, R, R, 14>(xb, aux, xa, xb, cy, vec, p, wave, lane);        // L7 -> xa
-    if constexpr (MODE == M16_VF_VEC) {
-        layer16<MODE, 63, 16, 0, 1, EPI_HEAD_TANH, R, 14>(xa, aux, xb, xa, cy, vec, p, wave, lane);
+    layer16<MODE, 0, 0, 3, 8, R, NONE, 0, 0, -1>(xa, aux, xb, xb, cy, vec, p, wave, lane);        // L0: encoding only
+    layer16<MODE, 8, 16, 0, 8, R, R, 14, 1, 0>(xb, aux, xa, xb, cy, vec, p, wave, lane);         // L1
+    layer16<MODE, 16, 16, 0, 8, R, R, 14, 2, 1>(xa, aux, xb, xa, cy, vec, p, wave, lane);        // L2
+    layer16<MODE, 24, 16, 0, 7, R, R, 14, 3, 2>(xb, aux, xa, xb, cy, vec, p, wave, lane);        // L3: 217 outputs
+    { A16 ax; load_aux(ax, s_park); layer16<MODE, 31, 14, 3, 8, R, R, 12, 4, 3>(xa, ax, xb, xa, cy, vec, p, wave, lane); }   // L4: skip
+    layer16<MODE, 39, 16, 0, 8, R, R, 14, 5, 4>(xb, aux, xa, xb, cy, vec, p, wave, lane);        // L5
+    layer16<MODE, 47, 16, 0, 8, R, R, 14, 6, 5>(xa, aux, xb, xa, cy, vec, p, wave, lane);        // L6
+    layer16<MODE, 55, 16, 0, 8, R, R, 14, 7, 6>(xb, aux, xa, xb, cy, vec, p, wave, lane);        // L7 -> xa
+    if constexpr (!(MODE & M16_FEAT)) {
+        layer16<MODE, 63, 16, 0, 1, EPI_HEAD_TANH, R, 14, -1, 7>(xa, aux, xb, xa, cy, vec, p, wave, lane);
         if (in && g == 0) { a.out_vec[m * 3 + 0] = vec[0]; a.out_vec[m * 3 + 1] = vec[1]; a.out_vec[m * 3 + 2] = vec[2]; }
     } else {
     // fused: feature block (tanh) -> xb, then the vector head from the same input; the head's tile hosts the epilogue
     // of the last feature tile
-    layer16<MODE, 63, 16, 0, 8, T, R, 14>(xa, aux, xb, xa, cy, vec, p, wave, lane);
-    layer16<MODE, 71, 16, 0, 1, EPI_HEAD_TANH, T, 14>(xa, aux, xb, xb, cy, vec, p, wave, lane);
+    layer16<MODE, 63, 16, 0, 8, T, R, 14, 8, 7>(xa, aux, xb, xa, cy, vec, p, wave, lane);
+    layer16<MODE, 71, 16, 0, 1, EPI_HEAD_TANH, T, 14, -1, 8>(xa, aux, xb, xb, cy, vec, p, wave, lane);
+    if constexpr (!(MODE & M16_RENDER)) {
+        if (in && g == 0) { a.out_vec[m * 3 + 0] = vec[0]; a.out_vec[m * 3 + 1] = vec[1]; a.out_vec[m * 3 + 2] = vec[2]; }
+    } else {
     // the head's outputs sit in the lanes < 32; the other lane half of the same point needs them for the aux operand
     float nrm[3];
 #pragma unroll
@@ -645,18 +705,20 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
                 else { sn[3 * o + c] = 0.f; cs[3 * o + c] = 0.f; }
             }
         const int ncol = 6 + 6 * rn_multires;   // first normal column
-        build_aux(aux, g, [&](int k) -> float {
+        auto rn_col = [&](int k) -> float {
             if (k < 3) return xr[k];
             if (k >= ncol) return k < ncol + 3 ? nrm[k - ncol] : 0.f;
             return enc_value(dr, sn, cs, rn_multires, k - 3);
-        });
+        };
+        build_aux(aux, g, rn_col);
+        if ((MODE & M16_TRAIN) && in) save_aux(a.save_aux_rn, m, g, rn_col);
     }
     float rgb[3] = {0.f, 0.f, 0.f};
-    layer16<MODE, 72, 16, 3, 8, R, NONE, 0>(xb, aux, xa, xb, cy, rgb, p, wave, lane);      // R0: [features ; p, PE(d), n]
-    layer16<MODE, 80, 16, 0, 8, R, R, 14>(xa, aux, xb, xa, cy, rgb, p, wave, lane);        // R1
-    layer16<MODE, 88, 16, 0, 8, R, R, 14>(xb, aux, xa, xb, cy, rgb, p, wave, lane);        // R2
-    layer16<MODE, 96, 16, 0, 8, R, R, 14>(xa, aux, xb, xa, cy, rgb, p, wave, lane);        // R3 -> xb
-    layer16<MODE, 104, 16, 0, 1, EPI_HEAD_SIGMOID, R, 14>(xb, aux, xa, xb, cy, rgb, p, wave, lane);
+    layer16<MODE, 72, 16, 3, 8, R, NONE, 0, 9, -1>(xb, aux, xa, xb, cy, rgb, p, wave, lane);      // R0: [features ; p, PE(d), n]
+    layer16<MODE, 80, 16, 0, 8, R, R, 14, 10, 9>(xa, aux, xb, xa, cy, rgb, p, wave, lane);        // R1
+    layer16<MODE, 88, 16, 0, 8, R, R, 14, 11, 10>(xb, aux, xa, xb, cy, rgb, p, wave, lane);        // R2
+    layer16<MODE, 96, 16, 0, 8, R, R, 14, 12, 11>(xa, aux, xb, xa, cy, rgb, p, wave, lane);        // R3 -> xb
+    layer16<MODE, 104, 16, 0, 1, EPI_HEAD_SIGMOID, R, 14, -1, 12>(xb, aux, xa, xb, cy, rgb, p, wave, lane);
     // outputs last: the only vector-memory stores of the kernel come after the last DMA wait
     const long long mo = (long long)blockIdx.x * VFN16_PTS + (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
     if (mo < a.n_points && (threadIdx.x & 32) == 0) {
@@ -669,7 +731,8 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
         a.out_colors[mo * 3 + 0] = (float)(t1 - st_t0); a.out_colors[mo * 3 + 1] = (float)(r1 - st_r0);
     }
 #endif
-    }   // fused
+    }   // rendering net
+    }   // feature block
 }
 
 // a network's plan against the compile-time tables
@@ -736,4 +799,54 @@ extern "C" int vfn_vf_render_fused16_fwd(const vfn_net_geom* vf_geom, const void
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_render_fused16_fwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// training forwards: same arithmetic, plus the workspace the backward kernels read (include/vfn.h, "slots")
+// ------------------------------------------------------------------------------------------------
+extern "C" int vfn_vf_mlp16_fwd_train(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
+                                      int32_t with_features, float* out_vec, float* saved, float* save_aux_vf, void* stream) {
+    Mlp16Args a = {};
+    VfnNetPlan p32; Plan16 vf;
+    int rc = make_plan16(VFN_NET_VF, geom, &p32, &vf, "vfn_vf_mlp16_fwd_train");
+    if (rc != VFN_OK) return rc;
+    rc = check_vf16(vf, "vfn_vf_mlp16_fwd_train");
+    if (rc != VFN_OK) return rc;
+    if (n_points <= 0) return VFN_OK;
+    VFN_REQUIRE(packed16 && points && out_vec && saved && save_aux_vf, "vfn_vf_mlp16_fwd_train: NULL argument");
+    VFN_REQUIRE(n_points < (1ll << 22), "vfn_vf_mlp16_fwd_train: at most 4194303 points per launch (32-bit slot offsets)");
+    a.vf_w = (const uint4*)packed16; a.points = points; a.out_vec = out_vec; a.n_points = n_points; a.dirs_div = 1;
+    a.vf_multires = vf.multires; a.vf_bytes = vf.total_kb * 1024u; a.saved = saved; a.save_aux_vf = save_aux_vf;
+    const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
+    if (with_features) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_FULL_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_VEC_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return vfn_check_launch("vfn_vf_mlp16_fwd_train");
+}
+
+extern "C" int vfn_vf_render_fused16_fwd_train(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
+                                               const void* rn_packed16, const float* points, const float* ray_dirs,
+                                               int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
+                                               float* saved, float* save_aux_vf, float* save_aux_rn, void* stream) {
+    Mlp16Args a = {};
+    VfnNetPlan p32; Plan16 vf, rn;
+    int rc = make_plan16(VFN_NET_VF, vf_geom, &p32, &vf, "vfn_vf_render_fused16_fwd_train");
+    if (rc != VFN_OK) return rc;
+    rc = make_plan16(VFN_NET_RENDER, rn_geom, &p32, &rn, "vfn_vf_render_fused16_fwd_train");
+    if (rc != VFN_OK) return rc;
+    rc = check_vf16(vf, "vfn_vf_render_fused16_fwd_train");
+    if (rc != VFN_OK) return rc;
+    rc = check_rn16(rn, "vfn_vf_render_fused16_fwd_train");
+    if (rc != VFN_OK) return rc;
+    if (n_points <= 0) return VFN_OK;
+    VFN_REQUIRE(vf_packed16 && rn_packed16 && points && ray_dirs && normals && colors && saved && save_aux_vf && save_aux_rn,
+                "vfn_vf_render_fused16_fwd_train: NULL argument");
+    VFN_REQUIRE(samples_per_ray > 0, "vfn_vf_render_fused16_fwd_train: samples_per_ray must be > 0");
+    VFN_REQUIRE(n_points < (1ll << 22), "vfn_vf_render_fused16_fwd_train: at most 4194303 points per launch (32-bit slot offsets)");
+    a.vf_w = (const uint4*)vf_packed16; a.rn_w = (const uint4*)rn_packed16; a.points = points; a.ray_dirs = ray_dirs;
+    a.out_vec = normals; a.out_colors = colors; a.n_points = n_points; a.dirs_div = samples_per_ray;
+    a.vf_multires = vf.multires; a.rn_multires = rn.multires; a.vf_bytes = vf.total_kb * 1024u; a.rn_bytes = rn.total_kb * 1024u;
+    a.saved = saved; a.save_aux_vf = save_aux_vf; a.save_aux_rn = save_aux_rn;
+    const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
+    hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return vfn_check_launch("vfn_vf_render_fused16_fwd_train");
 }

@@ -25,7 +25,7 @@ EXPORTS = (
     "vfn_range_fine_sample", "vfn_fill_uniform", "vfn_packed_bwd_size", "vfn_pack_weights_bwd",
     "vfn_vf_mlp_fwd_train", "vfn_vf_render_fused_fwd_train", "vfn_mlp_bwd_chain", "vfn_weight_grad_partials",
     "vfn_ray_density_weights_bwd", "vfn_pack16_size", "vfn_pack16_weights", "vfn_vf_mlp16_fwd",
-    "vfn_vf_render_fused16_fwd",
+    "vfn_vf_render_fused16_fwd", "vfn_vf_mlp16_fwd_train", "vfn_vf_render_fused16_fwd_train",
 )
 
 
@@ -334,6 +334,33 @@ def vf_mlp16_fwd(geom: NetGeom, packed16, points):
     _check(load().vfn_vf_mlp16_fwd(C.byref(geom), _ptr(packed16, "packed16", torch.uint8), _ptr(points, "points"),
                                    C.c_int64(m), _ptr(out, "out"), _stream()), "vfn_vf_mlp16_fwd")
     return out
+
+
+def vf_mlp16_fwd_train(geom: NetGeom, packed16, points, with_features: bool, saved, aux_vf):
+    """f16x3 VF forward that fills the backward workspace; returns the vector columns [M,3] (the features, when
+    evaluated, are in their ``saved`` slot)."""
+    m = points.shape[0]
+    out = torch.empty(m, 3, device=points.device)
+    _check(load().vfn_vf_mlp16_fwd_train(C.byref(geom), _ptr(packed16, "packed16", torch.uint8), _ptr(points, "points"),
+                                         C.c_int64(m), C.c_int32(1 if with_features else 0), _ptr(out, "out"),
+                                         _ptr(saved, "saved"), _ptr(aux_vf, "aux_vf"), _stream()),
+           "vfn_vf_mlp16_fwd_train")
+    return out
+
+
+def vf_render_fused16_fwd_train(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, samples_per_ray, saved,
+                                aux_vf, aux_rn):
+    m = points.shape[0]
+    dev = points.device
+    normals = torch.empty(m, 3, device=dev)
+    colors = torch.empty(m, 3, device=dev)
+    _check(load().vfn_vf_render_fused16_fwd_train(C.byref(vf_geom), _ptr(vf_packed16, "vf_packed16", torch.uint8),
+                                                  C.byref(rn_geom), _ptr(rn_packed16, "rn_packed16", torch.uint8),
+                                                  _ptr(points, "points"), _ptr(ray_dirs, "ray_dirs"), C.c_int64(m),
+                                                  C.c_int32(samples_per_ray), _ptr(normals, "normals"),
+                                                  _ptr(colors, "colors"), _ptr(saved, "saved"), _ptr(aux_vf, "aux_vf"),
+                                                  _ptr(aux_rn, "aux_rn"), _stream()), "vfn_vf_render_fused16_fwd_train")
+    return normals, colors
 
 
 def vf_render_fused16_fwd(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, samples_per_ray: int):
