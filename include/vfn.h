@@ -248,6 +248,12 @@ int vfn_vf_render_fused16_fwd(const vfn_net_geom* vf_geom, const void* vf_packed
                               const void* rn_packed16, const float* points, const float* ray_dirs,
                               int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
                               void* stream);
+/* vfn_weight_grad_partials(shape 0, ld 256, all 256 columns valid) on the bf16 matrix cores: operands split into two
+ * bf16 halves (16 significant bits, fp32 exponent range), three products per K-block, fp32 accumulation; same outputs
+ * (`groups` slabs [groups][256][256] and [groups][256]).  ~2^-16 relative error per product under the sum over points. */
+int vfn_weight_grad_partials_bf16(const float* dy, const float* x, int64_t n_points, int32_t groups, float* dw_part,
+                                  float* db_part, void* stream);
+
 /* The same forwards under autograd (train/vector_field_nerf_train.py:177,191,203,215): they additionally fill the
  * workspace the backward entry points read (`saved` slots, save_aux_vf[M,40], save_aux_rn[M,40]; see "slots" above),
  * exactly like vfn_vf_mlp_fwd_train / vfn_vf_render_fused_fwd_train.  with_features = 0 evaluates only the vector head

@@ -257,3 +257,35 @@ def test_training_loop_tracks_the_cpu_path():
     drift = max(float((p.detach().cpu() - q.detach()).abs().max())
                 for p, q in zip(hip_model.unique_parameters(), cpu_model.unique_parameters()))
     print(f"max parameter drift after {steps} steps: {drift:.3e} (each step moves a weight by <= 2 lr = 1e-3)")
+
+
+def test_weight_gradient_bf16_split_matches_fp32():
+    """vfn_weight_grad_partials_bf16 against the exact-fp32 kernel on the same operands: exact on small integers (which
+    pins the transposed-read operand maps), ~2^-16 per product on random data spanning gradient-like magnitudes, ragged
+    point counts and more groups than steps."""
+    from vf_nerf_amd import lib
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(9)
+    for m, groups, kind in ((64, 1, "int"), (1000, 3, "int"), (4099, 7, "rand"), (50, 4, "rand"), (70000, 64, "rand")):
+        if kind == "int":
+            dy = torch.randint(-3, 4, (m, 256), generator=gen).float()
+            x = torch.randint(-3, 4, (m, 256), generator=gen).float()
+        else:
+            dy = torch.randn(m, 256, generator=gen) * torch.logspace(-9, -3, 256)[None, :]     # columns of very different scale
+            x = torch.relu(torch.randn(m, 256, generator=gen)) * 30.0
+        dy, x = dy.to(dev), x.to(dev)
+        p32, b32 = torch.empty(groups, 256, 256, device=dev), torch.empty(groups, 256, device=dev)
+        p16, b16 = torch.empty(groups, 256, 256, device=dev), torch.empty(groups, 256, device=dev)
+        lib.weight_grad_partials(0, dy, 256, 256, x, 256, 256, m, groups, p32, b32)
+        lib.weight_grad_partials_bf16(dy, x, m, groups, p16, b16)
+        g32, g16 = p32.sum(0), p16.sum(0)
+        ref = (dy.double().t() @ x.double()).float()
+        if kind == "int":
+            assert torch.equal(g16, ref) and torch.equal(g32, ref), (m, groups)
+        else:
+            row_scale = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)      # per output row: rows differ by 1e6
+            err16 = float(((g16 - ref).abs() / row_scale).max())
+            err32 = float(((g32 - ref).abs() / row_scale).max())
+            print(f"m={m} groups={groups}: bf16-split err {err16:.2e}, fp32 kernel err {err32:.2e} (relative to each row's max)")
+            assert err16 < 2e-4, (m, groups, err16)
+        assert float((b16.sum(0) - dy.sum(0)).abs().max()) <= 1e-5 * max(1.0, float(dy.abs().sum(0).max()))

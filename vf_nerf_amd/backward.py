@@ -92,7 +92,8 @@ def _rn_inputs(feats: torch.Tensor, saved_slots: List[torch.Tensor]) -> List[tor
     return [feats] + list(saved_slots)
 
 
-def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=()) -> Dict[torch.nn.Parameter, torch.Tensor]:
+def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=(), fast: bool = False
+                  ) -> Dict[torch.nn.Parameter, torch.Tensor]:
     """inputs[h]: [M,256] act input of hidden entry h (None if it has none); inputs[-1]: input of the 3-channel head.
     dy_slots[h]: [M,256] pre-activation gradient of entry h.  aux: [M,40].  dz_head: [M,4].  Runs the persistent
     weight-gradient kernels, sums their partial slabs and un-folds BatchNorm / the skip scale:
@@ -116,7 +117,10 @@ def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=()) -> Dict[
         dW_act = dW_aux = None
         if e["act"] is not None:
             part = torch.empty(G, HID, HID, device=dev)
-            lib.weight_grad_partials(0, dy, HID, HID, inputs[h], HID, HID, m, G, part, db_part)
+            if fast:
+                lib.weight_grad_partials_bf16(dy, inputs[h], m, G, part, db_part)
+            else:
+                lib.weight_grad_partials(0, dy, HID, HID, inputs[h], HID, HID, m, G, part, db_part)
             dW_act = part.sum(0)
         if e["aux"] is not None:
             part = torch.empty(G, HID, 64, device=dev)
@@ -227,9 +231,9 @@ class _FinePass(torch.autograd.Function):
                           _packed_bwd(rn), ws.saved, dy, dc, colors, dn, normals, None, 3, m, dz_rgb, dz_vec)
         # (3) weight gradients
         g_vf = _weight_grads(vf, _vf_inputs(vf, [ws.saved[h] for h in range(vf_h)]), [dy[h] for h in range(vf_h)],
-                             ws.aux_vf, dz_vec, m)
+                             ws.aux_vf, dz_vec, m, fast=model.uses_f16x3())
         g_rn = _weight_grads(rn, _rn_inputs(ws.saved[vf_h - 1], [ws.saved[vf_h + h] for h in range(rn_h)]),
-                             [dy[vf_h + h] for h in range(rn_h)], ws.aux_rn, dz_rgb, m)
+                             [dy[vf_h + h] for h in range(rn_h)], ws.aux_rn, dz_rgb, m, fast=model.uses_f16x3())
         # density scalars in density.parameters() order
         by_name = {"beta": dscal[0], "mean": dscal[1], "scale": dscal[2]}
         g_den = {p: by_name[name].reshape(p.shape) for name, p in model.density.named_parameters()}
@@ -286,7 +290,8 @@ class _VFForward(torch.autograd.Function):
         # vector-only forward: the feature block of the last Linear was never evaluated -> no gradient for it
         skip = (vf_h - 1,) if (net._feature_dims() > 0 and cols == 3) else ()
         grads = _weight_grads(net, _vf_inputs(net, [ws.saved[h] for h in range(vf_h)]), [dy[h] for h in range(vf_h)],
-                              ws.aux_vf, dz_vec, m, skip=skip)
+                              ws.aux_vf, dz_vec, m, skip=skip,
+                              fast=getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3())
         ctx.ws = None
         return (None, None, None, *[grads.get(p) for p in ctx.param_order])
 

@@ -26,6 +26,7 @@ EXPORTS = (
     "vfn_vf_mlp_fwd_train", "vfn_vf_render_fused_fwd_train", "vfn_mlp_bwd_chain", "vfn_weight_grad_partials",
     "vfn_ray_density_weights_bwd", "vfn_pack16_size", "vfn_pack16_weights", "vfn_vf_mlp16_fwd",
     "vfn_vf_render_fused16_fwd", "vfn_vf_mlp16_fwd_train", "vfn_vf_render_fused16_fwd_train",
+    "vfn_weight_grad_partials_bf16",
 )
 
 
@@ -299,6 +300,13 @@ def weight_grad_partials(shape: int, dy, ld_dy: int, n_valid: int, x, ld_x: int,
                                            _ptr(x, "x"), C.c_int32(ld_x), C.c_int32(k_valid), C.c_int64(n_points),
                                            C.c_int32(groups), _ptr(dw_part, "dw_part"), _ptr(db_part, "db_part"),
                                            _stream()), "vfn_weight_grad_partials")
+
+
+def weight_grad_partials_bf16(dy, x, n_points: int, groups: int, dw_part, db_part=None):
+    """shape-0 weight_grad_partials (256 x 256, every column valid) on the bf16 matrix cores (split operands)."""
+    _check(load().vfn_weight_grad_partials_bf16(_ptr(dy, "dy"), _ptr(x, "x"), C.c_int64(n_points), C.c_int32(groups),
+                                                _ptr(dw_part, "dw_part"), _ptr(db_part, "db_part"), _stream()),
+           "vfn_weight_grad_partials_bf16")
 
 
 def ray_density_weights_bwd(dp: DensityParams, normals, ray_dirs, z_vals, scalars, colors, d_rgb, d_depth, d_weights,
