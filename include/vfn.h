@@ -254,6 +254,19 @@ int vfn_vf_render_fused16_fwd(const vfn_net_geom* vf_geom, const void* vf_packed
 int vfn_weight_grad_partials_bf16(const float* dy, const float* x, int64_t n_points, int32_t groups, float* dw_part,
                                   float* db_part, void* stream);
 
+/* vfn_mlp_bwd_chain on the bf16 matrix cores (split operands, three products per K-block, fp32 accumulation; shipped layer
+ * shapes only, others return VFN_ERR_UNSUPPORTED).  Takes its own TRANSPOSED bf16 packs (vfn_pack_weights_bwd16; re-run
+ * after every optimizer step) and the raw rows 0..2 of each net's last Linear ([3][256] fp32) for the 3-channel heads.
+ * Same outputs as vfn_mlp_bwd_chain.  n_points < 2^22 per launch. */
+int64_t vfn_packed_bwd16_size(int32_t net_kind, const vfn_net_geom* geom);                      /* bytes */
+int vfn_pack_weights_bwd16(int32_t net_kind, const vfn_net_geom* geom, const vfn_layer_params* layers, void* packed,
+                           void* stream);
+int vfn_mlp_bwd_chain_bf16(const vfn_net_geom* vf_geom, const void* vf_packed_bwd16, const float* vf_head_w,
+                           const vfn_net_geom* rn_geom, const void* rn_packed_bwd16, const float* rn_head_w,
+                           const float* saved, float* dy, const float* d_colors, const float* colors,
+                           const float* d_vec, const float* vec, const float* d_feats, int32_t vec_stride,
+                           int64_t n_points, float* dz_rgb, float* dz_vec, void* stream);
+
 /* The same forwards under autograd (train/vector_field_nerf_train.py:177,191,203,215): they additionally fill the
  * workspace the backward entry points read (`saved` slots, save_aux_vf[M,40], save_aux_rn[M,40]; see "slots" above),
  * exactly like vfn_vf_mlp_fwd_train / vfn_vf_render_fused_fwd_train.  with_features = 0 evaluates only the vector head

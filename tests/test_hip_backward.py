@@ -289,3 +289,58 @@ def test_weight_gradient_bf16_split_matches_fp32():
             print(f"m={m} groups={groups}: bf16-split err {err16:.2e}, fp32 kernel err {err32:.2e} (relative to each row's max)")
             assert err16 < 2e-4, (m, groups, err16)
         assert float((b16.sum(0) - dy.sum(0)).abs().max()) <= 1e-5 * max(1.0, float(dy.abs().sum(0).max()))
+
+
+def test_dx_chain_bf16_split_matches_fp32():
+    """vfn_mlp_bwd_chain_bf16 against the exact-fp32 chain on the same workspace: every dY slot and both head gradients,
+    in the fused mode and the two VF-only modes (with / without a gradient on the features).  Tolerance 2e-4 of each
+    slot's largest entry (16-bit operands under 256-term sums; observed ~3e-5)."""
+    from vf_nerf_amd import lib
+    from vf_nerf_amd.backward import _Workspace, _entries, _packed_bwd, _packed_bwd16, _head_rows
+    fx, d = load_fixture("c1_perturb")
+    model = build_model(fx, d, device="cuda:0")
+    vf, rn = model.vector_field_network, model.rendering_network
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(11)
+    n, s_t = 41, 13                                    # 533 points: ragged last workgroup
+    m = n * s_t
+    pts = (torch.rand(m, 3, generator=gen) * 2 - 1).to(dev)
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=1).to(dev)
+    vf_h, rn_h = len(_entries(vf)), len(_entries(rn))
+    ws = _Workspace(m, vf_h + rn_h, dev)
+    normals, colors = lib.vf_render_fused_fwd_train(vf.geometry(), vf.packed_weights(), rn.geometry(), rn.packed_weights(), pts,
+                                                    dirs, s_t, ws.saved, ws.aux_vf, ws.aux_rn)
+    dc = (torch.randn(m, 3, generator=gen) * 1e-4).to(dev)
+    dn = (torch.randn(m, 3, generator=gen) * 1e-5).to(dev)
+
+    def compare(tag, a, b, slots):
+        for sl in slots:
+            scale = float(b[sl].abs().max())
+            err = float((a[sl] - b[sl]).abs().max())
+            assert err <= 2e-4 * scale + 1e-30, (tag, sl, err, scale)
+
+    dy32, dy16 = torch.zeros(vf_h + rn_h, m, 256, device=dev), torch.zeros(vf_h + rn_h, m, 256, device=dev)
+    zr32, zv32, zr16, zv16 = (torch.empty(m, 4, device=dev) for _ in range(4))
+    lib.mlp_bwd_chain(vf.geometry(), vf.packed_weights(), _packed_bwd(vf), rn.geometry(), rn.packed_weights(), _packed_bwd(rn),
+                      ws.saved, dy32, dc, colors, dn, normals, None, 3, m, zr32, zv32)
+    lib.mlp_bwd_chain_bf16(vf.geometry(), _packed_bwd16(vf), _head_rows(vf), rn.geometry(), _packed_bwd16(rn), _head_rows(rn),
+                           ws.saved, dy16, dc, colors, dn, normals, None, 3, m, zr16, zv16)
+    assert torch.equal(zr16, zr32) and torch.equal(zv16, zv32)
+    widths = [256, 256, 256, 217, 256, 256, 256, 256, 256, 256, 256, 256, 256]
+    compare("fused", [dy16[s][:, :w] for s, w in enumerate(widths)], [dy32[s][:, :w] for s, w in enumerate(widths)], range(13))
+    # VF-only: full rows (gradient on vector + features) and vector-only
+    out = torch.cat([normals, ws.saved[vf_h - 1]], dim=1).contiguous()
+    d_out = (torch.randn(m, 259, generator=gen) * 1e-3).to(dev)
+    for cols in (259, 3):
+        dy32, dy16 = torch.zeros(vf_h, m, 256, device=dev), torch.zeros(vf_h, m, 256, device=dev)
+        o = out if cols == 259 else normals
+        g = d_out if cols == 259 else d_out[:, :3].contiguous()
+        from vf_nerf_amd.backward import _offset_view
+        dfe = _offset_view(g, 3) if cols == 259 else None
+        lib.mlp_bwd_chain(vf.geometry(), vf.packed_weights(), _packed_bwd(vf), None, None, None, ws.saved, dy32, None, None, g, o,
+                          dfe, cols, m, None, zv32)
+        lib.mlp_bwd_chain_bf16(vf.geometry(), _packed_bwd16(vf), _head_rows(vf), None, None, None, ws.saved, dy16, None, None, g, o,
+                               dfe, cols, m, None, zv16)
+        assert torch.equal(zv16, zv32)
+        slots = range(9) if cols == 259 else range(8)
+        compare(f"vf-only/{cols}", [dy16[s][:, :w] for s, w in enumerate(widths[:9])], [dy32[s][:, :w] for s, w in enumerate(widths[:9])], slots)

@@ -71,6 +71,27 @@ def _packed_bwd(net) -> torch.Tensor:
     return cache[1]
 
 
+def _packed_bwd16(net) -> torch.Tensor:
+    """Transposed bf16-split pack for the bf16 dX chain (csrc/vfn_bwd16.hip), cached on the parameter versions."""
+    tensors = [t for d in net._layer_tensors() for t in d.values()]
+    key = tuple((t.data_ptr(), t._version) for t in tensors)
+    dev = tensors[0].device
+    cache = getattr(net, "_packed_bwd16_cache", None)
+    if cache is None or cache[0] != key or cache[1].device != dev:
+        geom = net.geometry()
+        buf = torch.empty(lib.packed_bwd16_size(net._kind, geom), dtype=torch.uint8, device=dev)
+        with torch.no_grad():
+            lib.pack_weights_bwd16(net._kind, geom, [{k: v.detach() for k, v in d.items()} for d in net._layer_tensors()], buf)
+        net._packed_bwd16_cache = (key, buf)
+        cache = net._packed_bwd16_cache
+    return cache[1]
+
+
+def _head_rows(net) -> torch.Tensor:
+    """Rows 0..2 of the last Linear ([3][256], contiguous view): the 3-channel head."""
+    return net._linear(net.num_layers - 1).weight.detach()[:3]
+
+
 def _groups(m: int) -> int:
     return max(1, min(256, m // 256))
 
@@ -227,8 +248,13 @@ class _FinePass(torch.autograd.Function):
         dy = torch.empty(vf_h + rn_h, m, HID, device=dev)
         dz_rgb = torch.empty(m, 4, device=dev)
         dz_vec = torch.empty(m, 4, device=dev)
-        lib.mlp_bwd_chain(vf.geometry(), vf.packed_weights(), _packed_bwd(vf), rn.geometry(), rn.packed_weights(),
-                          _packed_bwd(rn), ws.saved, dy, dc, colors, dn, normals, None, 3, m, dz_rgb, dz_vec)
+        fast = model.uses_f16x3() and m < _F16_TRAIN_MAX_POINTS
+        if fast:
+            lib.mlp_bwd_chain_bf16(vf.geometry(), _packed_bwd16(vf), _head_rows(vf), rn.geometry(), _packed_bwd16(rn),
+                                   _head_rows(rn), ws.saved, dy, dc, colors, dn, normals, None, 3, m, dz_rgb, dz_vec)
+        else:
+            lib.mlp_bwd_chain(vf.geometry(), vf.packed_weights(), _packed_bwd(vf), rn.geometry(), rn.packed_weights(),
+                              _packed_bwd(rn), ws.saved, dy, dc, colors, dn, normals, None, 3, m, dz_rgb, dz_vec)
         # (3) weight gradients
         g_vf = _weight_grads(vf, _vf_inputs(vf, [ws.saved[h] for h in range(vf_h)]), [dy[h] for h in range(vf_h)],
                              ws.aux_vf, dz_vec, m, fast=model.uses_f16x3())
@@ -285,13 +311,17 @@ class _VFForward(torch.autograd.Function):
         d_feats = None
         if cols > 3:
             d_feats = _offset_view(d_out, 3)
-        lib.mlp_bwd_chain(net.geometry(), net.packed_weights(), _packed_bwd(net), None, None, None, ws.saved, dy,
-                          None, None, d_out, out, d_feats, cols, m, None, dz_vec)
+        fast = getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3() and m < _F16_TRAIN_MAX_POINTS
+        if fast:
+            lib.mlp_bwd_chain_bf16(net.geometry(), _packed_bwd16(net), _head_rows(net), None, None, None, ws.saved, dy,
+                                   None, None, d_out, out, d_feats, cols, m, None, dz_vec)
+        else:
+            lib.mlp_bwd_chain(net.geometry(), net.packed_weights(), _packed_bwd(net), None, None, None, ws.saved, dy,
+                              None, None, d_out, out, d_feats, cols, m, None, dz_vec)
         # vector-only forward: the feature block of the last Linear was never evaluated -> no gradient for it
         skip = (vf_h - 1,) if (net._feature_dims() > 0 and cols == 3) else ()
         grads = _weight_grads(net, _vf_inputs(net, [ws.saved[h] for h in range(vf_h)]), [dy[h] for h in range(vf_h)],
-                              ws.aux_vf, dz_vec, m, skip=skip,
-                              fast=getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3())
+                              ws.aux_vf, dz_vec, m, skip=skip, fast=fast)
         ctx.ws = None
         return (None, None, None, *[grads.get(p) for p in ctx.param_order])
 

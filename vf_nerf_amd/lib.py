@@ -26,7 +26,7 @@ EXPORTS = (
     "vfn_vf_mlp_fwd_train", "vfn_vf_render_fused_fwd_train", "vfn_mlp_bwd_chain", "vfn_weight_grad_partials",
     "vfn_ray_density_weights_bwd", "vfn_pack16_size", "vfn_pack16_weights", "vfn_vf_mlp16_fwd",
     "vfn_vf_render_fused16_fwd", "vfn_vf_mlp16_fwd_train", "vfn_vf_render_fused16_fwd_train",
-    "vfn_weight_grad_partials_bf16",
+    "vfn_weight_grad_partials_bf16", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
 )
 
 
@@ -82,6 +82,8 @@ def load() -> C.CDLL:
     lib.vfn_packed_bwd_size.argtypes = [C.c_int32, C.POINTER(NetGeom)]
     lib.vfn_pack16_size.restype = C.c_int64
     lib.vfn_pack16_size.argtypes = [C.c_int32, C.POINTER(NetGeom)]
+    lib.vfn_packed_bwd16_size.restype = C.c_int64
+    lib.vfn_packed_bwd16_size.argtypes = [C.c_int32, C.POINTER(NetGeom)]
     for name in EXPORTS:
         getattr(lib, name)  # raises AttributeError if the ABI lost a symbol
     if lib.vfn_abi_version() != 1:
@@ -300,6 +302,30 @@ def weight_grad_partials(shape: int, dy, ld_dy: int, n_valid: int, x, ld_x: int,
                                            _ptr(x, "x"), C.c_int32(ld_x), C.c_int32(k_valid), C.c_int64(n_points),
                                            C.c_int32(groups), _ptr(dw_part, "dw_part"), _ptr(db_part, "db_part"),
                                            _stream()), "vfn_weight_grad_partials")
+
+
+def packed_bwd16_size(kind: int, geom: NetGeom) -> int:
+    n = load().vfn_packed_bwd16_size(kind, C.byref(geom))
+    if n < 0:
+        raise VfnError(f"vfn_packed_bwd16_size failed (status {n}): {load().vfn_last_error().decode()}")
+    return int(n)
+
+
+def pack_weights_bwd16(kind: int, geom: NetGeom, layers: Sequence[dict], packed: torch.Tensor) -> None:
+    _check(load().vfn_pack_weights_bwd16(kind, C.byref(geom), _layer_array(geom, layers), _ptr(packed, "packed", torch.uint8),
+                                         _stream()), "vfn_pack_weights_bwd16")
+
+
+def mlp_bwd_chain_bf16(vf_geom, vf_packed_bwd16, vf_head_w, rn_geom, rn_packed_bwd16, rn_head_w, saved, dy, d_colors, colors,
+                       d_vec, vec, d_feats, vec_stride: int, n_points: int, dz_rgb, dz_vec):
+    rn = C.byref(rn_geom) if rn_geom is not None else None
+    _check(load().vfn_mlp_bwd_chain_bf16(C.byref(vf_geom), _ptr(vf_packed_bwd16, "vf_packed_bwd16", torch.uint8),
+                                         _ptr(vf_head_w, "vf_head_w"), rn,
+                                         _ptr(rn_packed_bwd16, "rn_packed_bwd16", torch.uint8), _ptr(rn_head_w, "rn_head_w"),
+                                         _ptr(saved, "saved"), _ptr(dy, "dy"), _ptr(d_colors, "d_colors"),
+                                         _ptr(colors, "colors"), _ptr(d_vec, "d_vec"), _ptr(vec, "vec"),
+                                         _ptr(d_feats, "d_feats"), C.c_int32(vec_stride), C.c_int64(n_points),
+                                         _ptr(dz_rgb, "dz_rgb"), _ptr(dz_vec, "dz_vec"), _stream()), "vfn_mlp_bwd_chain_bf16")
 
 
 def weight_grad_partials_bf16(dy, x, n_points: int, groups: int, dw_part, db_part=None):
