@@ -230,7 +230,7 @@ def grid_bench(args, dev, rank, world, dist, sync):
 
 def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync):
     """One step = what the reference trainer does per batch, with synthetic targets (config 3 of BASELINE.json)."""
-    from vf_nerf_amd import distributed as vdist
+    from vf_nerf_amd import distributed as vdist, optim as voptim
     s_t = args.coarse + args.fine
     g = torch.Generator().manual_seed(7 + rank)
     rgb_gt = torch.rand(args.rays, 3, generator=g).to(dev)
@@ -254,7 +254,7 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync):
         loss.backward()
         if bucket is not None:
             bucket.all_reduce_mean()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), clip, foreach=False)
+        voptim.clip_grad_norm_(model.parameters(), clip)       # = torch's clip_grad_norm_(..., foreach=False), Q4-exact
         model.optimizer.step()
         model.scheduler.step()
         return loss
@@ -279,7 +279,7 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync):
                           "data": "synthetic", "final_loss": round(float(loss), 5),
                           "config": {"workload": f"train step: render({args.rays} rays x {s_t}) + 2x{n_sup} supervision "
                                                  f"points through the VF net + L1/depth/unit-norm/supervision loss + "
-                                                 f"backward + clip_grad_norm_ + Adam (sequential)"}}), flush=True)
+                                                 f"backward + clip_grad_norm_ + Adam (sequential semantics over the duplicated parameter list)"}}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

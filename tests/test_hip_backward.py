@@ -158,13 +158,14 @@ def test_one_adam_step_matches_oracle_step():
     # (which the split-f16 forward does on this fixture, see test_render_gradients) would change the gradients by percents
     model.precision = "fp32"
     ref_model = build_model(fx, d)
-    # torch's multi-tensor ("foreach") Adam / clip update duplicated parameters concurrently on the GPU, which makes
-    # the reference's double update (Q4) racy there; pin the sequential semantics on both sides for the comparison.
+    # GPU side: the facade's own optimizer (optim.SequentialAdam) and optim.clip_grad_norm_ — multi-tensor kernels, one
+    # pass per multiplicity; CPU side: PyTorch's sequential per-entry loops, i.e. the semantics the reference ran with.
+    from vf_nerf_amd import optim
     lr = model.config.scheduler_config.lr
-    model.optimizer = torch.optim.Adam(model.parameters(), lr=lr, foreach=False)
+    assert isinstance(model.optimizer, optim.SequentialAdam)
     ref_model.optimizer = torch.optim.Adam(ref_model.parameters(), lr=lr, foreach=False)
     _hip_gradients(fx, d, model)
-    torch.nn.utils.clip_grad_norm_(model.parameters(), model.config.scheduler_config.clip_norm, foreach=False)
+    optim.clip_grad_norm_(model.parameters(), model.config.scheduler_config.clip_norm)
     model.optimizer.step()
     _, ref = oracle_gradients(fx, d, ref_model)
     for tag, net in (("vf", ref_model.vector_field_network), ("rn", ref_model.rendering_network)):
@@ -218,7 +219,9 @@ def test_training_loop_tracks_the_cpu_path():
         if device != "cpu":
             model.precision = "fp32"     # a trajectory comparison: keep every discrete event (ReLU kinks) on the CPU's side
         lr = model.config.scheduler_config.lr
-        model.optimizer = torch.optim.Adam(model.parameters(), lr=lr, foreach=False)      # sequential on both sides
+        if device == "cpu":
+            model.optimizer = torch.optim.Adam(model.parameters(), lr=lr, foreach=False)  # PyTorch's sequential loop
+        # (the GPU side keeps the facade's optim.SequentialAdam)
         model.scheduler = torch.optim.lr_scheduler.ExponentialLR(model.optimizer, 0.1 ** (1. / 50000))
         losses = []
         for t in range(steps):
@@ -239,7 +242,11 @@ def test_training_loop_tracks_the_cpu_path():
             loss = O.vf_loss(rgb, depth, normals, sup, tgt[0], tgt[1], tgt[2], w, epoch=0)
             model.optimizer.zero_grad()
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), model.config.scheduler_config.clip_norm, foreach=False)
+            if device == "cpu":
+                torch.nn.utils.clip_grad_norm_(model.parameters(), model.config.scheduler_config.clip_norm, foreach=False)
+            else:
+                from vf_nerf_amd import optim
+                optim.clip_grad_norm_(model.parameters(), model.config.scheduler_config.clip_norm)
             model.optimizer.step()
             model.scheduler.step()
             losses.append(float(loss))

@@ -157,3 +157,43 @@ def test_dropin_aliases_reference_import_paths():
         for k in [k for k in sys.modules if k.split(".")[0] in ("models", "evaluation")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_sequential_adam_and_clip_match_torch_sequential_loops():
+    """optim.SequentialAdam / optim.clip_grad_norm_ against torch.optim.Adam(foreach=False) /
+    torch.nn.utils.clip_grad_norm_(foreach=False) on a parameter list that names some tensors twice (Q4): identical
+    parameters, moments and step counters after several steps, identical state_dict layout."""
+    from vf_nerf_amd import optim
+    torch.manual_seed(3)
+    shapes = [(7, 5), (5,), (3, 3), (4,)]
+
+    def make():
+        torch.manual_seed(4)
+        ps = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+        return ps, ps + ps[:2]                 # the first two are listed twice
+
+    pa, la = make()
+    pb, lb = make()
+    oa = torch.optim.Adam(la, lr=3e-3, foreach=False)
+    ob = optim.SequentialAdam(lb, lr=3e-3)
+    for it in range(5):
+        g = [torch.randn(*s) * (10.0 if it == 2 else 0.1) for s in shapes]
+        for plist in (pa, pb):
+            for p, gg in zip(plist, g):
+                p.grad = gg.clone()
+        na = torch.nn.utils.clip_grad_norm_(la, 0.5, foreach=False)
+        nb = optim.clip_grad_norm_(lb, 0.5)
+        assert abs(float(na) - float(nb)) <= 1e-6 * float(na)
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=0)
+            b.grad.copy_(a.grad)               # remove the norm's summation-order rounding from the Adam comparison
+        oa.step(); ob.step()
+        for a, b in zip(pa, pb):
+            assert torch.equal(a, b), it
+    for a, b in zip(pa, pb):
+        sa, sb = oa.state[a], ob.state[b]
+        assert float(sa["step"]) == float(sb["step"]) and torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+    assert float(oa.state[pa[0]]["step"]) == 10.0 and float(oa.state[pa[2]]["step"]) == 5.0
+    sda, sdb = oa.state_dict(), ob.state_dict()
+    assert sda["param_groups"][0]["params"] == sdb["param_groups"][0]["params"] and sda["state"].keys() == sdb["state"].keys()
+    ob.load_state_dict(sda)                    # reference checkpoints load

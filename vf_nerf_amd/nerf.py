@@ -130,8 +130,10 @@ class VectorFieldNerf:
         """Adam over ``parameters()`` — duplicates included, as the reference builds it (vector_field_nerf.py:63).
         ``foreach=False``: the reference's double update of the aliased VF parameters (Q4) is a property of the
         sequential per-parameter loop of the PyTorch it was written for; the multi-tensor implementation that newer
-        PyTorch picks on GPUs updates duplicated tensors concurrently (racy).  The sequential form keeps Q4 exact."""
-        return torch.optim.Adam(self.parameters(), lr=lr, weight_decay=weight_decay, foreach=False)
+        PyTorch picks on GPUs updates duplicated tensors concurrently (racy).  ``optim.SequentialAdam`` keeps the
+        sequential semantics (and torch.optim.Adam's state / state_dict) at ~20 launches per step."""
+        from .optim import SequentialAdam   # the same update, multi-tensor kernels over distinct tensors per pass
+        return SequentialAdam(self.parameters(), lr=lr, weight_decay=weight_decay)
 
     def _new_schedule(self, num_steps: int) -> None:
         sc = self.config.scheduler_config
