@@ -44,7 +44,7 @@ enum : int { MASK_RELU = 0, MASK_TANH = 1 };
 // ------------------------------------------------------------------------------------------------
 constexpr int ST_NB[12] = {16, 16, 16, 16, 16, 16, 16, 16, 16, 14, 16, 16};
 constexpr int ST_TILES[12] = {8, 8, 8, 8, 8, 8, 8, 8, 7, 8, 8, 8};
-constexpr int ST_SLOT[12] = {11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0};       // rendering hidden 2,1,0 | features | VF hidden 7..0
+// (workspace slot written by step s: 11, 10, 9 rendering hidden 2, 1, 0 | 8 features | 7 .. 0 VF hidden 7 .. 0)
 constexpr int ST_NET[12] = {1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0};
 constexpr int ST_LAYER[12] = {3, 2, 1, 0, 8, 7, 6, 5, 4, 3, 2, 1};        // reference Linear index inside its net
 constexpr int chunk_kb(int nb) { return 2 * nb; }
@@ -387,7 +387,6 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
 
     // ---- the tiles the chain starts from: no matrix product, just the head update / the caller's gradient ----
     X16 xa, xb;
-    constexpr int S0 = first_step(MODE);
     if constexpr (MODE == BM_FUSED) {
         // gradient wrt the last hidden output of the rendering net = rank-3 update from the rgb head, ReLU-masked (slot 12)
         static_for<8>([&](auto it) {
