@@ -38,7 +38,7 @@ SUSTAINED_F16_MFMA = 1570.0                # TFLOP/s a pure 32x32x16 f16 MFMA lo
                                            # busy (power-limited clock ~1.8 GHz): tools/micro/mfma_power.hip, DESIGN.md §3
 
 
-def hbm_traffic(f16: bool):
+def hbm_traffic(f16: bool, kernel_class: str = "fused16"):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside the
     benchmark): FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md §HBM) + WRITE_SIZE, in bytes."""
     path = os.path.join(REPO, "profiles", "r01", "traffic_f16x3.json")
@@ -46,7 +46,11 @@ def hbm_traffic(f16: bool):
         return None
     with open(path) as fh:
         t = json.load(fh)
-    return int((2.0 * t["FETCH_SIZE_KB_per_launch"] + t["WRITE_SIZE_KB_per_launch"]) * 1024)
+    sym = {"vf_feat16": "vfn_mlp16_kernel<9>", "render16": "vfn_mlp16_kernel<18>", "fused16": "vfn_mlp16_kernel<3>"}.get(kernel_class)
+    fetch, write = t["all_kernels"].get(f"FETCH_SIZE|{sym}"), t["all_kernels"].get(f"WRITE_SIZE|{sym}")
+    if fetch is None or write is None:
+        return None
+    return int((2.0 * fetch + write) * 1024)
 
 
 def build_scene(dev, n_rays, s_c, n_f, seed, perturb=True):
@@ -297,6 +301,9 @@ def main() -> None:
     ap.add_argument("--precision", choices=("f16x3", "fp32"), default="f16x3",
                     help="MLP kernels: f16x3 = split-half products on the f16 matrix cores, fp32 accumulate (default, "
                          "fp32-equivalent accuracy); fp32 = exact fp32 MFMA")
+    ap.add_argument("--no-reuse", action="store_true",
+                    help="evaluate the VF net on the proposal samples twice, as the reference does (one fused VF+rendering "
+                         "launch over all S_c+N_f samples), instead of once")
     ap.add_argument("--workload", choices=("render", "view", "grid", "train"), default="render",
                     help="render = the headline line (default); view = BASELINE configs[1] full view in 1024-ray chunks + "
                          "PSNR/depth vs the oracle image; grid = configs[4] dense grid queries; train = configs[2] step")
@@ -341,6 +348,7 @@ def main() -> None:
     s_t = s_c + n_f
     model, uv, pose, K = build_scene(dev, args.rays, s_c, n_f, seed=rank)
     model.precision = args.precision
+    model.reuse_proposal = not args.no_reuse
 
     def sync():
         if dist is not None:
@@ -363,7 +371,13 @@ def main() -> None:
         elapsed = time.perf_counter() - t0
     events = model._kernel_events
     model._kernel_events = None
-    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
+    # dominant kernel class = the one with the largest share of the timed region (HIP events on the launch stream)
+    per_class = {}
+    for name, e0, e1 in events:
+        per_class.setdefault(name, []).append(e0.elapsed_time(e1))
+    dom = max(per_class, key=lambda k: sum(per_class[k]))
+    kernel_ms = sum(per_class[dom]) / len(per_class[dom])
+    launches_per_step = len(per_class[dom]) / max(1, args.steps)
 
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -372,7 +386,10 @@ def main() -> None:
 
     if rank == 0:
         rays_per_s = args.rays * args.steps * world / elapsed
-        flops_launch = 2.0 * s_t * (VF_MACS + RN_MACS) * args.rays
+        # ALGORITHMIC fp32-equivalent FLOPs of one launch of that kernel (SURVEY.md §8d per-point figures x its points)
+        points = {"vf_feat16": args.rays * s_c, "render16": args.rays * s_t}.get(dom, args.rays * s_t)
+        macs = {"vf_feat16": VF_MACS, "render16": RN_MACS}.get(dom, VF_MACS + RN_MACS)
+        flops_launch = 2.0 * macs * points
         achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
         hits = float((out.coarse_depth_map > 0).float().mean())
         f16 = args.precision == "f16x3"
@@ -380,10 +397,14 @@ def main() -> None:
         # f16 MFMA products per fp32-equivalent product, so its matrix-pipe ceiling is the dense f16 peak / 3.
         peak = PEAK_F16_MFMA / 3.0 if f16 else PEAK_F32_MFMA
         roof = {"bound": "mfma",
-                "kernel": ("vfn_mlp16_kernel<M16_FUSED>" if f16 else "vfn_mlp_kernel<MODE_FUSED>") +
-                          " (VF MLP + rendering MLP, fine pass)",
+                "kernel": {"vf_feat16": "vfn_mlp16_kernel<M16_VF_BLK> (VF MLP, once per distinct sample: proposal samples, then the new fine samples)",
+                           "render16": "vfn_mlp16_kernel<M16_RN_BLK> (rendering MLP on gathered feature blocks)",
+                           "fused16": "vfn_mlp16_kernel<M16_FUSED> (VF MLP + rendering MLP, fine pass)",
+                           "fused32": "vfn_mlp_kernel<MODE_FUSED> (VF MLP + rendering MLP, fine pass)"}[dom],
+                "launches_per_step": launches_per_step,
+                "kernel_ms_per_step_by_class": {k: round(sum(v) / max(1, args.steps), 4) for k, v in per_class.items()},
                 "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": hbm_traffic(f16),
+                "frac": round(achieved / peak, 4), "traffic": hbm_traffic(f16, dom),
                 "flops_per_launch": flops_launch, "avg_launch_ms": round(kernel_ms, 4),
                 "peak_definition": ("dense f16 MFMA 2500 TFLOP/s / 3 products per fp32-equivalent product" if f16 else
                                     "fp32 MFMA 157.3 TFLOP/s"),
@@ -400,6 +421,7 @@ def main() -> None:
                                    f"(S_c={s_c} + N_f={n_f}), shipped 9x256 VF + 5x256 rendering MLPs, eval-mode BN, "
                                    f"stratified sampling on device Philox, Replica-like 1200x680 pinhole",
                        "rays_per_chunk_per_gpu": args.rays, "samples_per_ray": s_t, "parallelism": f"rays x{world}",
+                       "vf_evaluations_per_ray": s_t if getattr(model, "reuse_proposal", False) and f16 else s_c + s_t,
                        "rays_with_nonzero_depth": round(hits, 3)},
             "roofline": roof,
         }

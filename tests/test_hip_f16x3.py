@@ -70,3 +70,52 @@ def test_partial_tile_and_large_batch():
         a = lib.vf_mlp16_fwd(vf.geometry(), vf.packed16_weights(), pts)
         b = lib.vf_mlp_fwd(vf.geometry(), vf.packed_weights(), pts, 3)
         assert rel_err(a, b) < TIGHT, m
+
+
+def test_proposal_reuse_equals_fused_pass():
+    """render() with the VF net evaluated once per distinct sample (vfn_vf_feat16_fwd on the proposal samples, again on the
+    N_f new ones, vfn_render16_from_blocks on the gathered features) against the single fused launch over all S_c+N_f
+    samples: same per-sample arithmetic, so every output must agree to the last bit — including ragged ray counts, the
+    all-zero-weights branch (argmax 0 -> uniform extra samples) and per-ray far."""
+    import torch
+    from helpers import build_model, load_fixture
+    for name in ("c1_perturb", "odd_orbit", "w1_det"):
+        fx, d = load_fixture(name)
+        model = build_model(fx, d, device="cuda:0")
+        g = {k: v.to("cuda:0") for k, v in d.items() if isinstance(v, torch.Tensor)}
+        uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add") if k in g}
+        outs = []
+        for reuse in (True, False):
+            model.reuse_proposal = reuse
+            with torch.no_grad():
+                outs.append(model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni))
+        a, b = outs
+        assert torch.equal(a.z_vals, b.z_vals) and torch.equal(a.points_coarse, b.points_coarse)
+        for f in ("coarse_normals", "coarse_colors", "coarse_rgb_values", "coarse_depth_map"):
+            x, y = getattr(a, f), getattr(b, f)
+            assert torch.equal(x, y), (name, f, float((x - y).abs().max()))
+
+
+def test_fine_sampler_provenance_index():
+    """vfn_range_fine_sample_indexed: src maps every sorted sample back to its proposal / new sample, new_points are the
+    new samples in generation order; z and points equal the plain sampler's."""
+    import torch
+    from vf_nerf_amd import lib
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(4)
+    n, s_c, n_f = 37, 16, 9
+    z_c = torch.sort(torch.rand(n, s_c, generator=gen), dim=1)[0].to(dev)
+    imax = torch.randint(0, s_c, (n,), generator=gen).to(dev)
+    imax[::5] = 0
+    dirs = torch.randn(n, 3, generator=gen).to(dev)
+    cam = torch.randn(n, 3, generator=gen).to(dev)
+    u_add, u_fine = torch.rand(n, n_f, generator=gen).to(dev), torch.rand(n, n_f, generator=gen).to(dev)
+    z0, p0 = lib.range_fine_sample(z_c, imax, dirs, cam, n_f, 0.0, 1.0, 0.3, u_add, u_fine)
+    z1, p1, src, newp = lib.range_fine_sample_indexed(z_c, imax, dirs, cam, n_f, 0.0, 1.0, 0.3, u_add, u_fine)
+    assert torch.equal(z0, z1) and torch.equal(p0, p1)
+    allp = torch.cat([(cam[:, None, :] + z_c[..., None] * dirs[:, None, :]).reshape(-1, 3), newp.reshape(-1, 3)])
+    assert torch.equal(allp[src.reshape(-1).long()].view(n, s_c + n_f, 3), p1)
+    rows = torch.sort(src, dim=1)[0].cpu()
+    expect = torch.cat([torch.arange(n)[:, None] * s_c + torch.arange(s_c)[None, :],
+                        n * s_c + torch.arange(n)[:, None] * n_f + torch.arange(n_f)[None, :]], dim=1).int()
+    assert torch.equal(rows, expect)

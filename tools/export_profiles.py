@@ -32,10 +32,10 @@ for counter, sub, stem in (("FETCH_SIZE", "prof_fetch", "pf"), ("WRITE_SIZE", "p
     for name, val, n in c.execute(q, (counter,)):
         if "vfn_" in name:
             traffic["all_kernels"][f"{counter}|{short(name)}"] = round(val, 2)
-fused = "vfn_mlp16_kernel<1>"
-traffic["kernel"] = f"{fused} (fused fine pass, 4096 rays x 128 samples)"
-traffic["FETCH_SIZE_KB_per_launch"] = traffic["all_kernels"].get(f"FETCH_SIZE|{fused}")
-traffic["WRITE_SIZE_KB_per_launch"] = traffic["all_kernels"].get(f"WRITE_SIZE|{fused}")
+# template arguments are the launch modes of csrc/vfn_mlp16.hip: <0> vector-only VF (grid queries), <3> fused VF + rendering,
+# <9> VF with feature blocks out (once per distinct sample), <18> rendering net on gathered blocks
+traffic["modes"] = {"vfn_mlp16_kernel<0>": "VF, vector columns only", "vfn_mlp16_kernel<3>": "fused VF + rendering (fine pass)",
+                    "vfn_mlp16_kernel<9>": "VF + feature blocks out", "vfn_mlp16_kernel<18>": "rendering net on gathered blocks"}
 with open(os.path.join(out, f"traffic_{tag}.json"), "w") as fh:
     json.dump(traffic, fh, indent=1)
 print(open(os.path.join(out, f"traffic_{tag}.json")).read())

@@ -46,17 +46,11 @@ def fine_pass(model, pts: torch.Tensor, z: torch.Tensor, ray_dirs: torch.Tensor)
         return fine_pass_autograd(model, pts, z, ray_dirs)
     f16 = model.uses_f16x3()
     vf_w, rn_w = (vf.packed16_weights(), rn.packed16_weights()) if f16 else (vf.packed_weights(), rn.packed_weights())
-    events = getattr(model, "_kernel_events", None)  # bench.py: HIP events around the dominant kernel
-    if events is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    if f16:
-        normals, colors = lib.vf_render_fused16_fwd(vf.geometry(), vf_w, rn.geometry(), rn_w, pts.view(-1, 3), ray_dirs, s_t)
-    else:
-        normals, colors, _ = lib.vf_render_fused_fwd(vf.geometry(), vf_w, rn.geometry(), rn_w, pts.view(-1, 3), ray_dirs, s_t)
-    if events is not None:
-        e1.record()
-        events.append((e0, e1))
+    with model._timed("fused16" if f16 else "fused32"):   # bench.py: HIP events around the dominant kernel
+        if f16:
+            normals, colors = lib.vf_render_fused16_fwd(vf.geometry(), vf_w, rn.geometry(), rn_w, pts.view(-1, 3), ray_dirs, s_t)
+        else:
+            normals, colors, _ = lib.vf_render_fused_fwd(vf.geometry(), vf_w, rn.geometry(), rn_w, pts.view(-1, 3), ray_dirs, s_t)
     _, weights, _, rgb, depth = lib.ray_density_weights(model._density_params(), normals, ray_dirs, z,
                                                         model.density.raw_scalars(), colors=colors, want_sigma=False)
     return normals, colors, rgb, depth, weights

@@ -251,8 +251,10 @@ namespace {
 enum : int { EPI_RELU = 0, EPI_TANH = 1, EPI_HEAD_TANH = 2, EPI_HEAD_SIGMOID = 3 };
 // launch modes: bit 0 = the VF feature block is evaluated, bit 1 = the rendering net follows, bit 2 = training (every
 // hidden layer's post-activation output and the encoding tiles are written out for the backward kernels)
-enum : int { M16_FEAT = 1, M16_RENDER = 2, M16_TRAIN = 4,
-             M16_VF_VEC = 0, M16_FUSED = M16_FEAT | M16_RENDER,
+//   bit 3 = the feature block leaves the kernel as operand blocks (for a later rendering-net launch), bit 4 = rendering net
+//   only, its feature operand gathered from such blocks
+enum : int { M16_FEAT = 1, M16_RENDER = 2, M16_TRAIN = 4, M16_BLKOUT = 8, M16_BLKIN = 16,
+             M16_VF_VEC = 0, M16_FUSED = M16_FEAT | M16_RENDER, M16_VF_BLK = M16_FEAT | M16_BLKOUT, M16_RN_BLK = M16_RENDER | M16_BLKIN,
              M16_VF_VEC_TRAIN = M16_TRAIN, M16_VF_FULL_TRAIN = M16_FEAT | M16_TRAIN, M16_FUSED_TRAIN = M16_FUSED | M16_TRAIN };
 
 #ifndef VFN16_FDEPTH
@@ -284,13 +286,15 @@ struct ChunkD { int net, off_kb, kb; };      // net 0 = VF pack, 1 = rendering p
 // chunk c of the launch in consumption order (fused: VF hidden + features, VF head, rendering hidden, rendering head;
 // vector-only: the 8 plain VF layers, VF head)
 constexpr ChunkD chunk_of(int mode, int c) {
-    const int vf_layers = (mode & M16_FEAT) ? 9 : 8;
-    for (int h = 0; h < vf_layers; ++h) {
-        if (c < VF_TILES[h]) return {0, vf_off_kb(h) + c * chunk_kb(VF_ACT[h], VF_AUX[h]), chunk_kb(VF_ACT[h], VF_AUX[h])};
-        c -= VF_TILES[h];
+    if (!(mode & M16_BLKIN)) {
+        const int vf_layers = (mode & M16_FEAT) ? 9 : 8;
+        for (int h = 0; h < vf_layers; ++h) {
+            if (c < VF_TILES[h]) return {0, vf_off_kb(h) + c * chunk_kb(VF_ACT[h], VF_AUX[h]), chunk_kb(VF_ACT[h], VF_AUX[h])};
+            c -= VF_TILES[h];
+        }
+        if (c == 0) return {0, vf_off_kb(9), HEAD_KB};
+        c -= 1;
     }
-    if (c == 0) return {0, vf_off_kb(9), HEAD_KB};
-    c -= 1;
     if (mode & M16_RENDER) {
         for (int h = 0; h < 4; ++h) {
             if (c < RN_TILES[h]) return {1, rn_off_kb(h) + c * chunk_kb(RN_ACT[h], RN_AUX[h]), chunk_kb(RN_ACT[h], RN_AUX[h])};
@@ -300,6 +304,8 @@ constexpr ChunkD chunk_of(int mode, int c) {
     }
     return {0, 0, 0};
 }
+
+constexpr int rn_first_chunk(int mode) { return (mode & M16_BLKIN) ? 0 : 72; }
 
 struct Mlp16Args {
     const uint4* vf_w;
@@ -317,6 +323,11 @@ struct Mlp16Args {
     float* saved;
     float* save_aux_vf;
     float* save_aux_rn;
+    // split launches: feature operand blocks, 1 KiB per point: [tile t][lane half g][hi 2t | lo 2t | hi 2t+1 | lo 2t+1] x 16 B
+    uint4* blk_out;           // M16_BLKOUT: written for rows 0 .. n_points-1
+    const uint4* blk_in;      // M16_BLKIN: row src[m] feeds point m
+    const float* vec_in;      // M16_BLKIN: [rows,3] vector outputs of the feature launches (gathered like blk_in)
+    const int* src;           // M16_BLKIN: [M]
 };
 
 struct X16 { half8 hi[16]; half8 lo[16]; };     // 256 activation columns x this lane's point, split (16 K-blocks of 16)
@@ -331,6 +342,9 @@ struct Pipe16 {
     long long slot_floats;         // M * 256
     uint32_t slot_bytes;           // M * 1024 (the host checks that it fits)
     uint32_t save_voff;            // byte offset of this lane's 16-byte column group in a slot row; out of range for m >= M
+    // feature operand blocks
+    uint4* blk_out;
+    uint32_t blk_bytes, blk_voff;  // rows * 1024; m * 1024 + 64 * (lane >> 5), out of range for m >= M
 };
 
 // State carried from chunk to chunk (and from layer call to layer call): the previous tile's accumulators, whose
@@ -432,7 +446,21 @@ __device__ __forceinline__ void save_group(const Pipe16& p, const f32x16& v, int
 //   last step    the bias and first fragments of chunk c+1 (cy).
 // The last tile of a layer is handed to the next layer call in cy.pend (PEPI = its epilogue, PKB = the K-block pair of
 // `xpend` it becomes); it is needed only by K steps PKB, PKB+1 of that layer's first tile.
-template <int MODE, int C0, int ACT, int AUX, int NCH, int EPI, int PEPI, int PKB, int SLOT = -1, int PSLOT = -1>
+// Operand blocks 2 TILE, 2 TILE + 1 of `x` (one finished feature tile) -> this point's row of the block buffer.
+template <int TILE>
+__device__ __forceinline__ void store_blocks(const Pipe16& p, const X16& x) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.blk_out, 0, (int)p.blk_bytes, 0x00020000);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x.hi[2 * TILE + s]), rs, (int)p.blk_voff, TILE * 128 + s * 32, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x.lo[2 * TILE + s]), rs, (int)p.blk_voff, TILE * 128 + s * 32 + 16, 0);
+    }
+}
+
+// BLK: the tiles this layer produces (and a pending tile it finishes, PBLK) are feature tiles that also go to the block buffer
+template <int MODE, int C0, int ACT, int AUX, int NCH, int EPI, int PEPI, int PKB, int SLOT = -1, int PSLOT = -1, bool BLK = false,
+          bool PBLK = false>
 __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xout, X16& xpend, Carry16& cy, float (&head)[3],
                                        const Pipe16& p, int wave, int lane) {
     constexpr int NKB = ACT + AUX;
@@ -527,6 +555,11 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
                     else save_group<(PSLOT >= 0 ? PSLOT : 0), PKB / 2>(p, cy.pend, q);
                 }
             }
+            // -- split launches: a finished feature tile leaves as operand blocks, after the hand-over like the stores above
+            if (st == H && ((BLK && ch > 0) || (PBLK && ch == 0))) {
+                if (ch > 0) store_blocks<(ch > 0 ? ch - 1 : 0)>(p, xout);
+                else store_blocks<PKB / 2>(p, xpend);
+            }
             // -- last step: the next chunk's bias and first fragments
             if (st == NKB - 1 && dnext.kb > 0) prefetch_chunk<MODE, (dnext.kb > 0 ? C + 1 : C)>(cy, p, lane);
 #ifndef VFN16_NOSCHED
@@ -596,6 +629,47 @@ __device__ __forceinline__ void load_aux(A16& ax, const float* park) {
     for (int q = 0; q < 3; ++q) { ax.hi[q] = pk[2 * q]; ax.lo[q] = pk[2 * q + 1]; }
 }
 
+// The rendering net on a feature operand that is already in `xb` (fused launches: straight from the VF net's epilogue;
+// M16_RN_BLK: gathered from the block buffer): aux = [p(3), d(3), sin/cos(2^k d)(6L), n(3)], four hidden layers, rgb head.
+template <int MODE>
+__device__ __forceinline__ void render_tail(const Mlp16Args& a, const Pipe16& p, Carry16& cy, X16& xa, X16& xb, const float (&xr)[3],
+                                            const float (&dr)[3], const float (&nrm)[3], long long m, bool in, int g, int wave, int lane) {
+    constexpr int R = EPI_RELU, NONE = -1;
+    constexpr int C0 = rn_first_chunk(MODE);
+    const int rn_multires = a.rn_multires;
+    A16 aux;
+    {
+        float sn[18], cs[18];
+#pragma unroll
+        for (int o = 0; o < 6; ++o)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (o < rn_multires) sincosf(dr[c] * (float)(1 << o), &sn[3 * o + c], &cs[3 * o + c]);
+                else { sn[3 * o + c] = 0.f; cs[3 * o + c] = 0.f; }
+            }
+        const int ncol = 6 + 6 * rn_multires;   // first normal column
+        auto rn_col = [&](int k) -> float {
+            if (k < 3) return xr[k];
+            if (k >= ncol) return k < ncol + 3 ? nrm[k - ncol] : 0.f;
+            return enc_value(dr, sn, cs, rn_multires, k - 3);
+        };
+        build_aux(aux, g, rn_col);
+        if ((MODE & M16_TRAIN) && in) save_aux(a.save_aux_rn, m, g, rn_col);
+    }
+    float rgb[3] = {0.f, 0.f, 0.f};
+    layer16<MODE, C0 + 0, 16, 3, 8, R, NONE, 0, 9, -1>(xb, aux, xa, xb, cy, rgb, p, wave, lane);      // R0: [features ; p, PE(d), n]
+    layer16<MODE, C0 + 8, 16, 0, 8, R, R, 14, 10, 9>(xa, aux, xb, xa, cy, rgb, p, wave, lane);        // R1
+    layer16<MODE, C0 + 16, 16, 0, 8, R, R, 14, 11, 10>(xb, aux, xa, xb, cy, rgb, p, wave, lane);      // R2
+    layer16<MODE, C0 + 24, 16, 0, 8, R, R, 14, 12, 11>(xa, aux, xb, xa, cy, rgb, p, wave, lane);      // R3 -> xb
+    layer16<MODE, C0 + 32, 16, 0, 1, EPI_HEAD_SIGMOID, R, 14, -1, 12>(xb, aux, xa, xb, cy, rgb, p, wave, lane);
+    // outputs last: the only vector-memory stores of the kernel come after the last DMA wait
+    const long long mo = (long long)blockIdx.x * VFN16_PTS + (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
+    if (mo < a.n_points && (threadIdx.x & 32) == 0) {
+        a.out_vec[mo * 3 + 0] = nrm[0]; a.out_vec[mo * 3 + 1] = nrm[1]; a.out_vec[mo * 3 + 2] = nrm[2];
+        a.out_colors[mo * 3 + 0] = rgb[0]; a.out_colors[mo * 3 + 1] = rgb[1]; a.out_colors[mo * 3 + 2] = rgb[2];
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     // ONE __shared__ object: a second one beside an LDS-DMA destination makes hipcc drain vmcnt(0) before every
@@ -614,6 +688,44 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     const long long m = (long long)blockIdx.x * VFN16_PTS + wave * 32 + (lane & 31);
     const bool in = m < a.n_points;
 
+    if constexpr ((MODE & M16_BLKIN) != 0) {
+        // ---- rendering net only: this point's feature operand, normal, position and view direction come from memory ----
+        const int srow = in ? a.src[m] : 0;
+        float xr[3] = {0.f, 0.f, 0.f}, dr[3] = {0.f, 0.f, 0.f}, nrm[3] = {0.f, 0.f, 0.f};
+        if (in) {
+            const long long di = m / a.dirs_div;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { xr[c] = a.points[m * 3 + c]; dr[c] = a.ray_dirs[di * 3 + c]; nrm[c] = a.vec_in[(long long)srow * 3 + c]; }
+        }
+        X16 xa, xb;
+        {
+            const uint4* row = a.blk_in + (size_t)srow * 64 + g * 4;      // 64 uint4 per point, 4 per (tile, lane half)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                uint4 q0 = row[t * 8 + 0], q1 = row[t * 8 + 1], q2 = row[t * 8 + 2], q3 = row[t * 8 + 3];
+                if (!in) { q0 = uint4{0, 0, 0, 0}; q1 = q0; q2 = q0; q3 = q0; }
+                half8 h0 = __builtin_bit_cast(half8, q0), l0 = __builtin_bit_cast(half8, q1);
+                half8 h1 = __builtin_bit_cast(half8, q2), l1 = __builtin_bit_cast(half8, q3);
+                asm volatile("" : "+a"(h0)); asm volatile("" : "+a"(l0)); asm volatile("" : "+a"(h1)); asm volatile("" : "+a"(l1));
+                xb.hi[2 * t] = h0; xb.lo[2 * t] = l0; xb.hi[2 * t + 1] = h1; xb.lo[2 * t + 1] = l1;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        Pipe16 p;
+        p.lds = s_ring;
+        p.vf_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.rn_w), 0, (int)a.rn_bytes, 0x00020000);
+        p.rn_w = p.vf_w;
+        p.saved = nullptr; p.slot_floats = 0; p.slot_bytes = 0; p.save_voff = 0; p.blk_out = nullptr; p.blk_bytes = 0; p.blk_voff = 0;
+        dma_chunk<MODE, 0>(p, wave, lane);
+        dma_chunk<MODE, 1>(p, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunks 0 and 1 landed
+        __builtin_amdgcn_s_barrier();
+        Carry16 cy;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) cy.pend[q] = 0.f;
+        prefetch_chunk<MODE, 0>(cy, p, lane);
+        render_tail<MODE>(a, p, cy, xa, xb, xr, dr, nrm, m, in, g, wave, lane);
+    } else {
     // this lane's point (the two lane halves of a wave share the 32 points); loaded BEFORE any DMA
     float x[3] = {0.f, 0.f, 0.f};
     if (in) { x[0] = a.points[m * 3 + 0]; x[1] = a.points[m * 3 + 1]; x[2] = a.points[m * 3 + 2]; }
@@ -635,11 +747,12 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
                                                (int)((MODE & M16_RENDER) ? a.rn_bytes : a.vf_bytes), 0x00020000);
     p.saved = a.saved; p.slot_floats = a.n_points * 256; p.slot_bytes = (uint32_t)(a.n_points * 1024);
     p.save_voff = in ? (uint32_t)(m * 1024 + g * 16) : 0xfffffff0u;
+    p.blk_out = a.blk_out; p.blk_bytes = (uint32_t)(a.n_points * 1024); p.blk_voff = in ? (uint32_t)(m * 1024 + g * 64) : 0xfffffff0u;
     dma_chunk<MODE, 0>(p, wave, lane);
     dma_chunk<MODE, 1>(p, wave, lane);
 
     // ---- positional encoding of the point -> aux operand (and its parked copy for the skip layer) -----------
-    const int vf_multires = a.vf_multires, rn_multires = a.rn_multires;
+    const int vf_multires = a.vf_multires;
     A16 aux;
     {
         float sn[18], cs[18];
@@ -682,8 +795,9 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     } else {
     // fused: feature block (tanh) -> xb, then the vector head from the same input; the head's tile hosts the epilogue
     // of the last feature tile
-    layer16<MODE, 63, 16, 0, 8, T, R, 14, 8, 7>(xa, aux, xb, xa, cy, vec, p, wave, lane);
-    layer16<MODE, 71, 16, 0, 1, EPI_HEAD_TANH, T, 14, -1, 8>(xa, aux, xb, xb, cy, vec, p, wave, lane);
+    constexpr bool BO = (MODE & M16_BLKOUT) != 0;
+    layer16<MODE, 63, 16, 0, 8, T, R, 14, 8, 7, BO, false>(xa, aux, xb, xa, cy, vec, p, wave, lane);
+    layer16<MODE, 71, 16, 0, 1, EPI_HEAD_TANH, T, 14, -1, 8, false, BO>(xa, aux, xb, xb, cy, vec, p, wave, lane);
     if constexpr (!(MODE & M16_RENDER)) {
         if (in && g == 0) { a.out_vec[m * 3 + 0] = vec[0]; a.out_vec[m * 3 + 1] = vec[1]; a.out_vec[m * 3 + 2] = vec[2]; }
     } else {
@@ -691,40 +805,11 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     float nrm[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) nrm[c] = __shfl(vec[c], lane & 31, 64);
-
-    // ---- rendering net: aux = [p(3), d(3), sin/cos(2^k d)(6L), n(3)] -------------------------------------
-    {
-        float xr[3] = {s_park[0], s_park[1], s_park[2]};
-        float dr[3] = {s_park[4], s_park[5], s_park[6]};
-        float sn[18], cs[18];
-#pragma unroll
-        for (int o = 0; o < 6; ++o)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                if (o < rn_multires) sincosf(dr[c] * (float)(1 << o), &sn[3 * o + c], &cs[3 * o + c]);
-                else { sn[3 * o + c] = 0.f; cs[3 * o + c] = 0.f; }
-            }
-        const int ncol = 6 + 6 * rn_multires;   // first normal column
-        auto rn_col = [&](int k) -> float {
-            if (k < 3) return xr[k];
-            if (k >= ncol) return k < ncol + 3 ? nrm[k - ncol] : 0.f;
-            return enc_value(dr, sn, cs, rn_multires, k - 3);
-        };
-        build_aux(aux, g, rn_col);
-        if ((MODE & M16_TRAIN) && in) save_aux(a.save_aux_rn, m, g, rn_col);
-    }
-    float rgb[3] = {0.f, 0.f, 0.f};
-    layer16<MODE, 72, 16, 3, 8, R, NONE, 0, 9, -1>(xb, aux, xa, xb, cy, rgb, p, wave, lane);      // R0: [features ; p, PE(d), n]
-    layer16<MODE, 80, 16, 0, 8, R, R, 14, 10, 9>(xa, aux, xb, xa, cy, rgb, p, wave, lane);        // R1
-    layer16<MODE, 88, 16, 0, 8, R, R, 14, 11, 10>(xb, aux, xa, xb, cy, rgb, p, wave, lane);        // R2
-    layer16<MODE, 96, 16, 0, 8, R, R, 14, 12, 11>(xa, aux, xb, xa, cy, rgb, p, wave, lane);        // R3 -> xb
-    layer16<MODE, 104, 16, 0, 1, EPI_HEAD_SIGMOID, R, 14, -1, 12>(xb, aux, xa, xb, cy, rgb, p, wave, lane);
-    // outputs last: the only vector-memory stores of the kernel come after the last DMA wait
+    const float xr[3] = {s_park[0], s_park[1], s_park[2]};
+    const float dr[3] = {s_park[4], s_park[5], s_park[6]};
+    render_tail<MODE>(a, p, cy, xa, xb, xr, dr, nrm, m, in, g, wave, lane);
     const long long mo = (long long)blockIdx.x * VFN16_PTS + (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
-    if (mo < a.n_points && (threadIdx.x & 32) == 0) {
-        a.out_vec[mo * 3 + 0] = nrm[0]; a.out_vec[mo * 3 + 1] = nrm[1]; a.out_vec[mo * 3 + 2] = nrm[2];
-        a.out_colors[mo * 3 + 0] = rgb[0]; a.out_colors[mo * 3 + 1] = rgb[1]; a.out_colors[mo * 3 + 2] = rgb[2];
-    }
+    (void)mo;
 #ifdef VFN16_STAMPS
     if (threadIdx.x == 0) {   // timing-only build: shader-clock and 100 MHz ticks of this workgroup, over its first colours
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -733,6 +818,7 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
 #endif
     }   // rendering net
     }   // feature block
+    }   // not M16_BLKIN
 }
 
 // a network's plan against the compile-time tables
@@ -799,6 +885,48 @@ extern "C" int vfn_vf_render_fused16_fwd(const vfn_net_geom* vf_geom, const void
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_render_fused16_fwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// split inference launches: the VF net once per distinct sample, the rendering net on gathered feature blocks
+// ------------------------------------------------------------------------------------------------
+extern "C" int vfn_vf_feat16_fwd(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
+                                 float* out_vec, void* out_blocks, void* stream) {
+    Mlp16Args a = {};
+    VfnNetPlan p32; Plan16 vf;
+    int rc = make_plan16(VFN_NET_VF, geom, &p32, &vf, "vfn_vf_feat16_fwd");
+    if (rc != VFN_OK) return rc;
+    rc = check_vf16(vf, "vfn_vf_feat16_fwd");
+    if (rc != VFN_OK) return rc;
+    if (n_points <= 0) return VFN_OK;
+    VFN_REQUIRE(packed16 && points && out_vec && out_blocks, "vfn_vf_feat16_fwd: NULL argument");
+    VFN_REQUIRE(n_points < (1ll << 22), "vfn_vf_feat16_fwd: at most 4194303 points per launch (32-bit block offsets)");
+    a.vf_w = (const uint4*)packed16; a.points = points; a.out_vec = out_vec; a.n_points = n_points; a.dirs_div = 1;
+    a.vf_multires = vf.multires; a.vf_bytes = vf.total_kb * 1024u; a.blk_out = (uint4*)out_blocks;
+    const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
+    hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_BLK>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return vfn_check_launch("vfn_vf_feat16_fwd");
+}
+
+extern "C" int vfn_render16_from_blocks(const vfn_net_geom* rn_geom, const void* rn_packed16, const void* blocks, const float* vecs,
+                                        const int32_t* src, const float* points, const float* ray_dirs, int64_t n_points,
+                                        int32_t samples_per_ray, float* normals, float* colors, void* stream) {
+    Mlp16Args a = {};
+    VfnNetPlan p32; Plan16 rn;
+    int rc = make_plan16(VFN_NET_RENDER, rn_geom, &p32, &rn, "vfn_render16_from_blocks");
+    if (rc != VFN_OK) return rc;
+    rc = check_rn16(rn, "vfn_render16_from_blocks");
+    if (rc != VFN_OK) return rc;
+    VFN_REQUIRE(rn_geom->feature_dims == VFN_HIDDEN, "vfn_render16_from_blocks: feature_dims must be %d", VFN_HIDDEN);
+    if (n_points <= 0) return VFN_OK;
+    VFN_REQUIRE(rn_packed16 && blocks && vecs && src && points && ray_dirs && normals && colors, "vfn_render16_from_blocks: NULL argument");
+    VFN_REQUIRE(samples_per_ray > 0, "vfn_render16_from_blocks: samples_per_ray must be > 0");
+    a.rn_w = (const uint4*)rn_packed16; a.vf_w = a.rn_w; a.points = points; a.ray_dirs = ray_dirs; a.out_vec = normals; a.out_colors = colors;
+    a.n_points = n_points; a.dirs_div = samples_per_ray; a.rn_multires = rn.multires; a.rn_bytes = rn.total_kb * 1024u; a.vf_bytes = a.rn_bytes;
+    a.blk_in = (const uint4*)blocks; a.vec_in = vecs; a.src = src;
+    const long long nblocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
+    hipLaunchKernelGGL(vfn_mlp16_kernel<M16_RN_BLK>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, a);
+    return vfn_check_launch("vfn_render16_from_blocks");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -528,6 +528,9 @@ struct FineArgs {
     const float* u_add;
     float* z_vals;
     float* points;
+    // optional (vfn_range_fine_sample_indexed): where each sorted sample comes from, and the new samples on their own
+    int* src;            // [N,S_t]: coarse sample j of the ray -> ray*S_c + j; new sample k -> N*S_c + ray*N_f + k
+    float* new_points;   // [N,N_f,3] in generation order
 };
 
 __global__ __launch_bounds__(256) void vfn_fine_kernel(const FineArgs a) {
@@ -574,6 +577,7 @@ __global__ __launch_bounds__(256) void vfn_fine_kernel(const FineArgs a) {
             rank += (o < v || (o == v && j < i)) ? 1 : 0;
         }
         so[rank] = v;
+        if (a.src) a.src[(size_t)ray * St + rank] = i < Sc ? ray * Sc + i : a.p.n_rays * Sc + ray * Nf + (i - Sc);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -586,6 +590,15 @@ __global__ __launch_bounds__(256) void vfn_fine_kernel(const FineArgs a) {
         a.points[o * 3 + 0] = ox + z * dx;
         a.points[o * 3 + 1] = oy + z * dy;
         a.points[o * 3 + 2] = oz + z * dz;
+    }
+    if (a.new_points) {
+        for (int k = lane; k < Nf; k += WAVE) {
+            const float z = sv[Sc + k];
+            const size_t o = (size_t)ray * Nf + k;
+            a.new_points[o * 3 + 0] = ox + z * dx;
+            a.new_points[o * 3 + 1] = oy + z * dy;
+            a.new_points[o * 3 + 2] = oz + z * dz;
+        }
     }
 }
 
@@ -654,13 +667,21 @@ extern "C" int vfn_ray_density_weights(const vfn_density_params* p, const float*
 extern "C" int vfn_range_fine_sample(const vfn_fine_params* p, const float* z_coarse, const int64_t* argmax,
                                      const float* directions, const float* cam_loc, const float* far_per_ray,
                                      const float* u_fine, const float* u_add, float* z_vals, float* points, void* stream) {
+    return vfn_range_fine_sample_indexed(p, z_coarse, argmax, directions, cam_loc, far_per_ray, u_fine, u_add, z_vals, points,
+                                         nullptr, nullptr, stream);
+}
+
+extern "C" int vfn_range_fine_sample_indexed(const vfn_fine_params* p, const float* z_coarse, const int64_t* argmax,
+                                             const float* directions, const float* cam_loc, const float* far_per_ray,
+                                             const float* u_fine, const float* u_add, float* z_vals, float* points,
+                                             int32_t* src, float* new_points, void* stream) {
     if (p && p->n_rays <= 0) return VFN_OK;
     VFN_REQUIRE(p && z_coarse && argmax && directions && cam_loc && u_add && z_vals && points,
                 "vfn_range_fine_sample: NULL argument (u_add is always required, ray_sampler.py:292)");
     VFN_REQUIRE(p->n_coarse >= 1 && p->n_fine >= 2 && p->n_coarse + p->n_fine <= MAX_SAMPLES,
                 "vfn_range_fine_sample: bad sizes (n_coarse=%d, n_fine=%d)", p->n_coarse, p->n_fine);
-    if (p->n_rays <= 0) return VFN_OK;
-    FineArgs a{*p, z_coarse, (const long long*)argmax, directions, cam_loc, far_per_ray, u_fine, u_add, z_vals, points};
+    VFN_REQUIRE((long long)p->n_rays * (p->n_coarse + p->n_fine) < (1ll << 31), "vfn_range_fine_sample: more than 2^31 samples");
+    FineArgs a{*p, z_coarse, (const long long*)argmax, directions, cam_loc, far_per_ray, u_fine, u_add, z_vals, points, src, new_points};
     const unsigned blocks = (unsigned)((p->n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
     const size_t shmem = (size_t)RAYS_PER_BLOCK * (p->n_coarse + p->n_fine) * 2 * sizeof(float);
     hipLaunchKernelGGL(vfn_fine_kernel, dim3(blocks), dim3(256), shmem, (hipStream_t)stream, a);

@@ -22,11 +22,11 @@ NET_VF, NET_RENDER = 0, 1
 EXPORTS = (
     "vfn_last_error", "vfn_abi_version", "vfn_packed_size", "vfn_pack_weights", "vfn_raygen_uniform",
     "vfn_vf_mlp_fwd", "vfn_render_mlp_fwd", "vfn_vf_render_fused_fwd", "vfn_ray_density_weights",
-    "vfn_range_fine_sample", "vfn_fill_uniform", "vfn_packed_bwd_size", "vfn_pack_weights_bwd",
+    "vfn_range_fine_sample", "vfn_range_fine_sample_indexed", "vfn_fill_uniform", "vfn_packed_bwd_size", "vfn_pack_weights_bwd",
     "vfn_vf_mlp_fwd_train", "vfn_vf_render_fused_fwd_train", "vfn_mlp_bwd_chain", "vfn_weight_grad_partials",
     "vfn_ray_density_weights_bwd", "vfn_pack16_size", "vfn_pack16_weights", "vfn_vf_mlp16_fwd",
     "vfn_vf_render_fused16_fwd", "vfn_vf_mlp16_fwd_train", "vfn_vf_render_fused16_fwd_train",
-    "vfn_weight_grad_partials_bf16", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
+    "vfn_vf_feat16_fwd", "vfn_render16_from_blocks", "vfn_weight_grad_partials_bf16", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
 )
 
 
@@ -249,6 +249,28 @@ def range_fine_sample(z_coarse, argmax, directions, cam_loc, n_fine, near, far, 
     return z, pts
 
 
+def range_fine_sample_indexed(z_coarse, argmax, directions, cam_loc, n_fine, near, far, fine_range, u_add, u_fine=None,
+                              far_per_ray=None):
+    """range_fine_sample plus src[N,S_t] (int32 provenance of every sorted sample) and new_points[N,N_f,3]."""
+    n, sc = z_coarse.shape
+    dev = z_coarse.device
+    step = 2 * fine_range / (n_fine - 1)
+    span = (far - near) if far_per_ray is None else 0.0
+    p = FineParams(n, sc, n_fine, float(near), float(far) if far_per_ray is None else 0.0, float(fine_range),
+                   float(step), float(span))
+    z = torch.empty(n, sc + n_fine, device=dev)
+    pts = torch.empty(n, sc + n_fine, 3, device=dev)
+    src = torch.empty(n, sc + n_fine, dtype=torch.int32, device=dev)
+    new_pts = torch.empty(n, n_fine, 3, device=dev)
+    _check(load().vfn_range_fine_sample_indexed(C.byref(p), _ptr(z_coarse, "z_coarse"), _ptr(argmax, "argmax", torch.int64),
+                                                _ptr(directions, "directions"), _ptr(cam_loc, "cam_loc"),
+                                                _ptr(far_per_ray, "far_per_ray"), _ptr(u_fine, "u_fine"),
+                                                _ptr(u_add, "u_add"), _ptr(z, "z_vals"), _ptr(pts, "points"),
+                                                _ptr(src, "src", torch.int32), _ptr(new_pts, "new_points"), _stream()),
+           "vfn_range_fine_sample_indexed")
+    return z, pts, src, new_pts
+
+
 def fill_uniform(out: torch.Tensor, seed: int, offset: int) -> torch.Tensor:
     _check(load().vfn_fill_uniform(_ptr(out, "out"), C.c_int64(out.numel()), C.c_uint64(seed & (2 ** 64 - 1)),
                                    C.c_uint64(offset & (2 ** 64 - 1)), _stream()), "vfn_fill_uniform")
@@ -368,6 +390,30 @@ def vf_mlp16_fwd(geom: NetGeom, packed16, points):
     _check(load().vfn_vf_mlp16_fwd(C.byref(geom), _ptr(packed16, "packed16", torch.uint8), _ptr(points, "points"),
                                    C.c_int64(m), _ptr(out, "out"), _stream()), "vfn_vf_mlp16_fwd")
     return out
+
+
+BLOCK_BYTES = 1024   # one point's 256 features as split-f16 operand blocks
+
+
+def vf_feat16_fwd(geom: NetGeom, packed16, points, out_vec, out_blocks) -> None:
+    """VF net on points[M,3]; writes out_vec[M,3] and out_blocks[M, 1024] (uint8) — slices of larger buffers are fine."""
+    m = points.shape[0]
+    _check(load().vfn_vf_feat16_fwd(C.byref(geom), _ptr(packed16, "packed16", torch.uint8), _ptr(points, "points"),
+                                    C.c_int64(m), _ptr(out_vec, "out_vec"), _ptr(out_blocks, "out_blocks", torch.uint8),
+                                    _stream()), "vfn_vf_feat16_fwd")
+
+
+def render16_from_blocks(rn_geom: NetGeom, rn_packed16, blocks, vecs, src, points, ray_dirs, samples_per_ray: int):
+    m = points.shape[0]
+    dev = points.device
+    normals = torch.empty(m, 3, device=dev)
+    colors = torch.empty(m, 3, device=dev)
+    _check(load().vfn_render16_from_blocks(C.byref(rn_geom), _ptr(rn_packed16, "rn_packed16", torch.uint8),
+                                           _ptr(blocks, "blocks", torch.uint8), _ptr(vecs, "vecs"),
+                                           _ptr(src, "src", torch.int32), _ptr(points, "points"), _ptr(ray_dirs, "ray_dirs"),
+                                           C.c_int64(m), C.c_int32(samples_per_ray), _ptr(normals, "normals"),
+                                           _ptr(colors, "colors"), _stream()), "vfn_render16_from_blocks")
+    return normals, colors
 
 
 def vf_mlp16_fwd_train(geom: NetGeom, packed16, points, with_features: bool, saved, aux_vf):

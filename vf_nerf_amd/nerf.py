@@ -49,6 +49,24 @@ class _WindowSchedule:
         return w
 
 
+class _EventScope:
+    def __init__(self, sink, name: str) -> None:
+        self.sink, self.name = sink, name
+
+    def __enter__(self):
+        if self.sink is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.sink is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.sink.append((self.name, self.e0, e1))
+        return False
+
+
 class VectorFieldNerf:
     def __init__(self, config) -> None:
         self.config = config
@@ -78,6 +96,11 @@ class VectorFieldNerf:
         # Gradient-carrying calls always use the fp32 kernels.  The setting is shared with the networks so that
         # gradient-free vector queries made on them directly (grid extraction) follow it.
         self.precision = "f16x3"
+        # Inference with the f16x3 kernels evaluates the VF net once per distinct sample: the proposal samples keep their
+        # vector columns and feature operand blocks, only the N_f new samples are evaluated after the fine sampler, and the
+        # rendering net gathers (the reference evaluates the proposal samples twice; same per-sample arithmetic, identical
+        # outputs).  False: one fused VF+rendering launch over all S_c+N_f samples.
+        self.reuse_proposal = True
         # device RNG stream (Philox counter); every render() advances the offset
         self.rng_seed = 0
         self._rng_offset = 0
@@ -190,6 +213,13 @@ class VectorFieldNerf:
         return self.precision == "f16x3" and self.vector_field_network.supports_f16x3() and \
             self.rendering_network.supports_f16x3()
 
+    def _needs_grad(self) -> bool:
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.unique_parameters())
+
+    def _timed(self, name: str):
+        """bench.py hook: HIP events around a launch when ``_kernel_events`` is a list (no-op otherwise)."""
+        return _EventScope(getattr(self, "_kernel_events", None), name)
+
     def _anneal(self, epoch: int, device) -> None:
         if self.config.cos_sim_weights_anneal != "none" and epoch > self.config.anneal_start:
             self.config.cos_sim_weights = self.annealing.get_weights(epoch - self.config.anneal_start, device)
@@ -263,13 +293,22 @@ class VectorFieldNerf:
                 return uniforms[name].to(dev).float().contiguous()
             return self._uniform(shape, dev)
 
+        # inference with the f16x3 kernels: evaluate the VF net once per distinct sample (see ``reuse_proposal``)
+        reuse = self.reuse_proposal and self.uses_f16x3() and not self._needs_grad() and n * (s_c + n_f) < (1 << 22)
         with torch.no_grad():
             # (1)-(2) rays + proposal samples
             u_coarse = draw("u_coarse", (n, s_c), perturb_c)
             directions, ray_dirs, cam_loc, z_c, pts_c = self._rays(pose, pixels, intrinsics, u_coarse)
-            # (3) VF net, vector columns only
+            # (3) VF net on the proposal samples: vector columns (and, when they will be reused, the feature blocks)
             vf = self.vector_field_network
-            if self.uses_f16x3():
+            if reuse:
+                m_c, m_n = n * s_c, n * n_f
+                blocks = torch.empty(m_c + m_n, lib.BLOCK_BYTES, dtype=torch.uint8, device=dev)
+                vecs = torch.empty(m_c + m_n, 3, device=dev)
+                with self._timed("vf_feat16"):
+                    lib.vf_feat16_fwd(vf.geometry(), vf.packed16_weights(), pts_c.view(-1, 3), vecs[:m_c], blocks[:m_c])
+                normals_c = vecs[:m_c]
+            elif self.uses_f16x3():
                 normals_c = lib.vf_mlp16_fwd(vf.geometry(), vf.packed16_weights(), pts_c.view(-1, 3))
             else:
                 normals_c = lib.vf_mlp_fwd(vf.geometry(), vf.packed_weights(), pts_c.view(-1, 3), 3)
@@ -281,11 +320,27 @@ class VectorFieldNerf:
             u_fine = draw("u_fine", (n, n_f), perturb_f)
             u_add = draw("u_add", (n, n_f), True)
             far, far_t = self._far_args(self.fine_sampler.far)
-            z, pts = lib.range_fine_sample(z_c, imax, directions, cam_loc, n_f, self.fine_sampler.near, far,
-                                           self.fine_sampler.range, u_add, u_fine, far_t)
+            if reuse:
+                z, pts, src, new_pts = lib.range_fine_sample_indexed(z_c, imax, directions, cam_loc, n_f, self.fine_sampler.near,
+                                                                     far, self.fine_sampler.range, u_add, u_fine, far_t)
+            else:
+                z, pts = lib.range_fine_sample(z_c, imax, directions, cam_loc, n_f, self.fine_sampler.near, far,
+                                               self.fine_sampler.range, u_add, u_fine, far_t)
         s_t = s_c + n_f
-        # (7)-(11) fine pass: VF net + rendering net + density + composite
-        normals, colors, rgb, depth, weights = fine_pass(self, pts, z, ray_dirs)
+        if reuse:
+            # (7)-(11) VF net on the new samples only, rendering net on gathered features, density + composite
+            with torch.no_grad():
+                rn = self.rendering_network
+                with self._timed("vf_feat16"):
+                    lib.vf_feat16_fwd(vf.geometry(), vf.packed16_weights(), new_pts.view(-1, 3), vecs[m_c:], blocks[m_c:])
+                with self._timed("render16"):
+                    normals, colors = lib.render16_from_blocks(rn.geometry(), rn.packed16_weights(), blocks, vecs, src.view(-1),
+                                                               pts.view(-1, 3), ray_dirs, s_t)
+                _, weights, _, rgb, depth = lib.ray_density_weights(self._density_params(), normals, ray_dirs, z, scal,
+                                                                    colors=colors, want_sigma=False)
+        else:
+            # (7)-(11) fine pass: VF net + rendering net + density + composite
+            normals, colors, rgb, depth, weights = fine_pass(self, pts, z, ray_dirs)
         if white:
             rgb = rgb + (1. - weights.sum(-1)[..., None])
         rep_dirs = ray_dirs.unsqueeze(1).expand(n, s_t, 3).reshape(-1, 3)
