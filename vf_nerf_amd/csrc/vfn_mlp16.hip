@@ -57,6 +57,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define VFN16_INV_WSCALE 0.015625f
 #define VFN16_PACK_WSCALE (VFN16_ASCALE ? 1.0f : VFN16_WSCALE)
 #define VFN16_XSCALE (VFN16_ASCALE ? VFN16_WSCALE : 1.0f)
+#ifndef VFN16_SAVE_AUX
+#define VFN16_SAVE_AUX 0         // cache policy bits of the training-mode workspace stores (0 = default write-back)
+#endif
 #ifndef VFN16_HANDOVER_NUM
 #define VFN16_HANDOVER_NUM 8     // ring hand-over after K step NKB * n / 16
 #endif
@@ -430,7 +433,11 @@ __device__ __forceinline__ void save_group(const Pipe16& p, const f32x16& v, int
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.saved + (long long)SLOT * p.slot_floats, 0,
                                                                         (int)p.slot_bytes, 0x00020000);
     const f32x4v g = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)p.save_voff, (32 * TILE + 8 * q) * 4, 0);
+#ifndef ABL_NOSAVE
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)p.save_voff, (32 * TILE + 8 * q) * 4, VFN16_SAVE_AUX);
+#else
+    asm volatile("" :: "v"(g));
+#endif
 }
 
 // One layer: xout <- f(W' [xin ; aux] + b') — NCH chunks (C0 .. C0+NCH-1 of the launch) of one 32-row output tile each.
@@ -532,6 +539,10 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
             // -- middle: ring hand-over
             if (st == H - 1 && dnext.kb > 0) {
 #ifndef ABL_NOSYNC
+#ifdef ABL_LOOSE_WAIT      // timing-only: leave the four stores of a training tile in flight (not safe: see DESIGN.md)
+                if ((MODE & M16_TRAIN) != 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else
+#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
 #endif
