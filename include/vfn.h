@@ -292,6 +292,21 @@ int vfn_render16_from_blocks(const vfn_net_geom* rn_geom, const void* rn_packed1
                              const int32_t* src, const float* points, const float* ray_dirs, int64_t n_points,
                              int32_t samples_per_ray, float* normals, float* colors, void* stream);
 
+/* From partial slabs to parameter gradients, all layer entries of a net in one launch: sums the `groups` slabs written
+ * by vfn_weight_grad_partials(_bf16) and un-folds eval-mode BatchNorm and the skip scale (W' = s scale W,
+ * b' = s (b - mu) + beta, s = gamma / sqrt(var + 1e-5)) onto the parameters the optimizer holds:
+ * rows [row_off, row_off + rows) of g_w[out][in_dim] (columns act_c0.. and aux_c0..), g_b, and, with BatchNorm, g_bn_w, g_bn_b.
+ * slab_rows = rows per slab group (256, or 32 for the 3-channel head).  At most 12 entries. */
+typedef struct {
+    const float* dw_act; const float* dw_aux; const float* db;
+    const float* w; const float* b_lin; const float* bn_w; const float* bn_var; const float* bn_mean;
+    float* g_w; float* g_b; float* g_bn_w; float* g_bn_b;
+    int32_t rows, row_off, in_dim, slab_rows;
+    int32_t act_c0, act_nc, aux_c0, aux_nc;
+    float scale;
+} vfn_unfold_entry;
+int vfn_unfold_weight_grads(const vfn_unfold_entry* entries, int32_t n_entries, int32_t groups, void* stream);
+
 /* The same forwards under autograd (train/vector_field_nerf_train.py:177,191,203,215): they additionally fill the
  * workspace the backward entry points read (`saved` slots, save_aux_vf[M,40], save_aux_rn[M,40]; see "slots" above),
  * exactly like vfn_vf_mlp_fwd_train / vfn_vf_render_fused_fwd_train.  with_features = 0 evaluates only the vector head

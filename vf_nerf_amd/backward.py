@@ -117,71 +117,57 @@ def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=(), fast: bo
                   ) -> Dict[torch.nn.Parameter, torch.Tensor]:
     """inputs[h]: [M,256] act input of hidden entry h (None if it has none); inputs[-1]: input of the 3-channel head.
     dy_slots[h]: [M,256] pre-activation gradient of entry h.  aux: [M,40].  dz_head: [M,4].  Runs the persistent
-    weight-gradient kernels, sums their partial slabs and un-folds BatchNorm / the skip scale:
+    weight-gradient kernels (``fast``: the 256 x 256 products on the bf16 matrix cores, csrc/vfn_dw16.hip), then ONE
+    launch (csrc/vfn_unfold.hip) sums their partial slabs and un-folds BatchNorm / the skip scale onto the parameters:
         W' = s * scale * W,  b' = s (b - mu) + beta_bn,  s = gamma / sqrt(var + eps)."""
     dev = aux.device
     entries = _entries(net)
     G = _groups(m)
     grads: Dict[torch.nn.Parameter, torch.Tensor] = {}
+    unfold = []
 
-    def acc(p, g):
-        grads[p] = g if p not in grads else grads[p] + g
+    def out_for(p):
+        if p not in grads:
+            grads[p] = torch.empty_like(p)
+        return grads[p]
 
     for h, e in enumerate(entries):
         if h in skip:
             continue
         lin, bn = net._linear(e["layer"]), net._bn(e["layer"])
-        W = lin.weight.detach()
-        rows, r0 = e["rows"], e["row_off"]
         dy = dy_slots[h]
         db_part = torch.empty(G, HID, device=dev)
-        dW_act = dW_aux = None
+        u = dict(db=db_part, w=lin.weight.detach(), b_lin=lin.bias.detach(), g_w=out_for(lin.weight), g_b=out_for(lin.bias),
+                 rows=e["rows"], row_off=e["row_off"], in_dim=lin.in_features, slab_rows=HID, scale=e["scale"])
         if e["act"] is not None:
             part = torch.empty(G, HID, HID, device=dev)
             if fast:
                 lib.weight_grad_partials_bf16(dy, inputs[h], m, G, part, db_part)
             else:
                 lib.weight_grad_partials(0, dy, HID, HID, inputs[h], HID, HID, m, G, part, db_part)
-            dW_act = part.sum(0)
+            u.update(dw_act=part, act_c0=e["act"][0], act_nc=e["act"][1])
         if e["aux"] is not None:
             part = torch.empty(G, HID, 64, device=dev)
             lib.weight_grad_partials(1, dy, HID, HID, aux, lib.AUX_K, lib.AUX_K, m, G, part,
                                      db_part if e["act"] is None else None)
-            dW_aux = part.sum(0)
-        db = db_part.sum(0)[:rows]
+            u.update(dw_aux=part, aux_c0=e["aux"][0], aux_nc=e["aux"][1])
         if bn is not None:
-            inv = torch.rsqrt(bn.running_var.detach() + EPS_BN)
-            s_fold = bn.weight.detach() * inv
-        else:
-            inv, s_fold = None, torch.ones(rows, device=dev)
-        gW = torch.zeros_like(W)
-        dgam = torch.zeros(rows, device=dev)
-        for blk, rng in ((dW_act, e["act"]), (dW_aux, e["aux"])):
-            if blk is None:
-                continue
-            c0, nc = rng
-            sub = blk[:rows, :nc] * e["scale"]
-            gW[r0:r0 + rows, c0:c0 + nc] = s_fold[:, None] * sub
-            if bn is not None:
-                dgam += (sub * W[r0:r0 + rows, c0:c0 + nc]).sum(1)
-        acc(lin.weight, gW)
-        gb = torch.zeros_like(lin.bias)
-        gb[r0:r0 + rows] = s_fold * db
-        acc(lin.bias, gb)
-        if bn is not None:
-            acc(bn.weight, (dgam + db * (lin.bias.detach() - bn.running_mean.detach())) * inv)
-            acc(bn.bias, db.clone())
-    # 3-channel head = rows 0..2 of the last Linear
+            u.update(bn_w=bn.weight.detach(), bn_var=bn.running_var.detach(), bn_mean=bn.running_mean.detach(),
+                     g_bn_w=out_for(bn.weight), g_bn_b=out_for(bn.bias))
+        unfold.append(u)
+    # 3-channel head = rows 0..2 of the last Linear (no BatchNorm)
     last = net._linear(net.num_layers - 1)
     part = torch.empty(G, 32, HID, device=dev)
     dbp = torch.empty(G, 32, device=dev)
     lib.weight_grad_partials(2, dz_head, 4, 3, inputs[-1], HID, HID, m, G, part, dbp)
-    gW = torch.zeros_like(last.weight)
-    gW[:3] = part.sum(0)[:3]
-    gb = torch.zeros_like(last.bias)
-    gb[:3] = dbp.sum(0)[:3]
-    acc(last.weight, gW)
-    acc(last.bias, gb)
+    fresh = last.weight not in grads          # the feature rows of the last Linear were skipped (vector-only forward)
+    unfold.append(dict(dw_act=part, db=dbp, w=last.weight.detach(), b_lin=last.bias.detach(), g_w=out_for(last.weight),
+                       g_b=out_for(last.bias), rows=3, row_off=0, in_dim=last.in_features, slab_rows=32, act_c0=0,
+                       act_nc=HID, scale=1.0))
+    if fresh and last.out_features > 3:
+        grads[last.weight][3:].zero_()
+        grads[last.bias][3:].zero_()
+    lib.unfold_weight_grads(unfold, G)
     return grads
 
 

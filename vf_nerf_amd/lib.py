@@ -26,7 +26,7 @@ EXPORTS = (
     "vfn_vf_mlp_fwd_train", "vfn_vf_render_fused_fwd_train", "vfn_mlp_bwd_chain", "vfn_weight_grad_partials",
     "vfn_ray_density_weights_bwd", "vfn_pack16_size", "vfn_pack16_weights", "vfn_vf_mlp16_fwd",
     "vfn_vf_render_fused16_fwd", "vfn_vf_mlp16_fwd_train", "vfn_vf_render_fused16_fwd_train",
-    "vfn_vf_feat16_fwd", "vfn_render16_from_blocks", "vfn_weight_grad_partials_bf16", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
+    "vfn_vf_feat16_fwd", "vfn_render16_from_blocks", "vfn_weight_grad_partials_bf16", "vfn_unfold_weight_grads", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
 )
 
 
@@ -348,6 +348,26 @@ def mlp_bwd_chain_bf16(vf_geom, vf_packed_bwd16, vf_head_w, rn_geom, rn_packed_b
                                          _ptr(colors, "colors"), _ptr(d_vec, "d_vec"), _ptr(vec, "vec"),
                                          _ptr(d_feats, "d_feats"), C.c_int32(vec_stride), C.c_int64(n_points),
                                          _ptr(dz_rgb, "dz_rgb"), _ptr(dz_vec, "dz_vec"), _stream()), "vfn_mlp_bwd_chain_bf16")
+
+
+class UnfoldEntry(C.Structure):
+    """mirrors vfn_unfold_entry"""
+    _fields_ = [(n, C.c_void_p) for n in ("dw_act", "dw_aux", "db", "w", "b_lin", "bn_w", "bn_var", "bn_mean", "g_w", "g_b",
+                                          "g_bn_w", "g_bn_b")] + \
+               [(n, C.c_int32) for n in ("rows", "row_off", "in_dim", "slab_rows", "act_c0", "act_nc", "aux_c0", "aux_nc")] + \
+               [("scale", C.c_float)]
+
+
+def unfold_weight_grads(entries: Sequence[dict], groups: int) -> None:
+    """entries: dicts with the tensors / ints of vfn_unfold_entry (missing tensors = NULL)."""
+    arr = (UnfoldEntry * len(entries))()
+    for i, e in enumerate(entries):
+        for name, _ in UnfoldEntry._fields_[:12]:
+            setattr(arr[i], name, _ptr(e.get(name), name))
+        for name, _ in UnfoldEntry._fields_[12:20]:
+            setattr(arr[i], name, int(e.get(name, 0)))
+        arr[i].scale = float(e.get("scale", 1.0))
+    _check(load().vfn_unfold_weight_grads(arr, C.c_int32(len(entries)), C.c_int32(groups), _stream()), "vfn_unfold_weight_grads")
 
 
 def weight_grad_partials_bf16(dy, x, n_points: int, groups: int, dw_part, db_part=None):
