@@ -234,7 +234,8 @@ def grid_bench(args, dev, rank, world, dist, sync):
 
 def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync):
     """One step = what the reference trainer does per batch, with synthetic targets (config 3 of BASELINE.json)."""
-    from vf_nerf_amd import distributed as vdist, optim as voptim
+    from vf_nerf_amd import distributed as vdist, optim as voptim, supervision
+    centroid = torch.tensor([0.0, 0.0, 0.6], device=dev)
     s_t = args.coarse + args.fine
     g = torch.Generator().manual_seed(7 + rank)
     rgb_gt = torch.rand(args.rays, 3, generator=g).to(dev)
@@ -245,12 +246,15 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync):
 
     def step():
         out = model.render(pose, uv, K, epoch=0)
-        sup = torch.rand(2 * n_sup, 3, device=dev) * 2 - 1            # border + centre supervision points
-        sup_n = model.vector_field_network(sup)[:, :3]
+        # border + centre supervision points, as the trainer draws them (train/vector_field_nerf_train.py:198-214)
+        bp, b_gt = supervision.sample_border_points(0.75, 1.0, n_sup, centroid, dev)
+        cp, c_gt = supervision.sample_center_points(centroid, 0.05, n_sup, dev)
+        sup_n = model.vector_field_network(torch.cat([bp, cp]))[:, :3]
+        sup_gt = torch.cat([b_gt, c_gt])
         normals = out.coarse_normals.reshape(-1, 3)
         loss = 2.0 * (out.coarse_rgb_values - rgb_gt).abs().mean() + \
             0.5 * torch.clamp((out.coarse_depth_map - depth_gt).abs(), max=0.5).mean() + \
-            0.1 * ((normals.norm(dim=-1) - 1.0) ** 2).mean() + 1.0 * ((sup_n - 0.5) ** 2).mean()
+            0.1 * ((normals.norm(dim=-1) - 1.0) ** 2).mean() + 1.0 * ((sup_n - sup_gt) ** 2).mean()
         if bucket is not None:
             bucket.zero()
         else:

@@ -307,6 +307,13 @@ typedef struct {
 } vfn_unfold_entry;
 int vfn_unfold_weight_grads(const vfn_unfold_entry* entries, int32_t n_entries, int32_t groups, void* stream);
 
+/* Supervision points of the trainer (train/vector_field_nerf_train.py:186-214): n uniform samples in the spherical
+ * shell r_min <= |p - centroid| <= r_max (models/samplers/sampler.py:160-193) and their radial unit ground truth
+ * (models/helpers/functions.py:100-135): inward = 1 -> normalize(centroid - p) (sample_border_points), 0 -> normalize(p -
+ * centroid) (sample_center_points).  u[n,3] supplies the three uniforms per sample (parity runs) or is NULL (Philox). */
+int vfn_sample_sphere_shell(int64_t n, float r_min, float r_max, const float* centroid, int32_t inward, const float* u,
+                            uint64_t seed, uint64_t offset, float* points, float* gt, void* stream);
+
 /* The same forwards under autograd (train/vector_field_nerf_train.py:177,191,203,215): they additionally fill the
  * workspace the backward entry points read (`saved` slots, save_aux_vf[M,40], save_aux_rn[M,40]; see "slots" above),
  * exactly like vfn_vf_mlp_fwd_train / vfn_vf_render_fused_fwd_train.  with_features = 0 evaluates only the vector head

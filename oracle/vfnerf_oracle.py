@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass, field
-from typing import Dict, Optional
+from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -406,3 +406,21 @@ def psnr(a: Tensor, b: Tensor) -> float:
     """-10 log10(mean((a-b)^2))  (utils/utils.py:235-245)."""
     mse = torch.mean((a - b) ** 2).item()
     return float('inf') if mse == 0 else -10.0 * math.log10(mse)
+
+
+
+# --------------------------------------------------------------------------------------
+# supervision points  (models/samplers/sampler.py:160-193, models/helpers/functions.py:100-135)
+# --------------------------------------------------------------------------------------
+def sphere_shell_points(u: Tensor, r_min: float, r_max: float, centroid: Tensor, inward: bool) -> Tuple[Tensor, Tensor]:
+    """u[n,3] = the three uniform draws per sample in the reference's order (phi, cos(theta), radius).  The sampler
+    works in float64 numpy and casts to float32 before adding the centroid; gt = normalize(+-(p - c), eps 1e-12)."""
+    u64 = u.double()
+    phi = 2.0 * math.pi * u64[:, 0]
+    cos_t = 2.0 * u64[:, 1] - 1.0
+    theta = torch.arccos(cos_t)
+    r = torch.pow(u64[:, 2], 1.0 / 3.0) * (r_max - r_min) + r_min
+    local = torch.stack([r * torch.sin(theta) * torch.cos(phi), r * torch.sin(theta) * torch.sin(phi), r * torch.cos(theta)], dim=1)
+    points = local.float() + centroid.float()
+    d = (centroid - points) if inward else (points - centroid)
+    return points, F.normalize(d, dim=1)

@@ -282,3 +282,31 @@ def test_secondary_entry_points(case):
         ref_vf = O.vf_mlp(flat.cpu(), cpu_vf)
         ref_c = O.render_mlp(flat.cpu(), ref_vf[:, :3], rep_c.cpu(), ref_vf[:, 3:], cpu_rn)
         assert rel_err(colors, ref_c) < TIGHT
+
+
+def test_supervision_sphere_shell_sampler():
+    """vfn_sample_sphere_shell / vf_nerf_amd.supervision against the oracle's restatement of SphereSampler +
+    sample_border_points / sample_center_points on the same uniforms, and the device Philox stream's statistics."""
+    from oracle import vfnerf_oracle as O
+    from vf_nerf_amd import lib, supervision
+    gen = torch.Generator().manual_seed(8)
+    n = 5000
+    u = torch.rand(n, 3, generator=gen)
+    c = torch.tensor([0.1, -0.2, 0.6])
+    for r_min, r_max, inward in ((0.75, 1.0, True), (0.0, 0.05, False), (0.3, 0.3, True)):
+        want_p, want_g = O.sphere_shell_points(u, r_min, r_max, c, inward)
+        got_p, got_g = lib.sample_sphere_shell(n, r_min, r_max, c.to(dev()), inward, u=u.to(dev()))
+        assert float((got_p.cpu() - want_p).abs().max()) < 2e-6
+        big = (want_p - c).norm(dim=1) > 1e-3            # the direction of a point ~1e-7 from the centroid is all rounding
+        assert float((got_g.cpu() - want_g)[big].abs().max()) < 2e-4 if r_max < 0.1 else float((got_g.cpu() - want_g).abs().max()) < 2e-5
+    supervision.manual_seed(11)
+    bp, bg = supervision.sample_border_points(0.75, 1.0, 20000, c, dev())
+    cp, cg = supervision.sample_center_points(c, 0.05, 20000, dev())
+    rb, rc = (bp.cpu() - c).norm(dim=1), (cp.cpu() - c).norm(dim=1)
+    assert float(rb.min()) >= 0.75 - 1e-6 and float(rb.max()) <= 1.0 + 1e-6 and float(rc.max()) <= 0.05 + 1e-6
+    assert float(((bp.cpu() - c) / rb[:, None]).mean(0).abs().max()) < 0.02        # directions uniform on the sphere
+    assert abs(float(((rc / 0.05) ** 3).mean()) - 0.5) < 0.02                        # cbrt(u) radius law
+    assert float((bg.cpu() + (bp.cpu() - c) / rb[:, None]).abs().max()) < 1e-5      # border gt points at the centroid
+    assert float((cg.cpu() - (cp.cpu() - c) / rc[:, None]).abs().max()) < 1e-3      # centre gt points away from it
+    again = supervision.sample_border_points(0.75, 1.0, 20000, c, dev())[0]
+    assert not torch.equal(again, bp), "the stream advances"

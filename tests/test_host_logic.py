@@ -197,3 +197,30 @@ def test_sequential_adam_and_clip_match_torch_sequential_loops():
     sda, sdb = oa.state_dict(), ob.state_dict()
     assert sda["param_groups"][0]["params"] == sdb["param_groups"][0]["params"] and sda["state"].keys() == sdb["state"].keys()
     ob.load_state_dict(sda)                    # reference checkpoints load
+
+
+def test_vfloss_matches_oracle_restatement():
+    """vf_nerf_amd.loss.VFLoss (reference interface, one read-back) against the oracle's restatement of
+    models/losses/vf_loss.py:34-87 — before and after the norm<1 term switches on, with and without depth / supervision."""
+    from types import SimpleNamespace
+    from oracle import vfnerf_oracle as O
+    from vf_nerf_amd.loss import VFLoss
+    gen = torch.Generator().manual_seed(2)
+    n, s = 16, 8
+    cfg = SimpleNamespace(depth_loss_clamp=0.5, norm_smaller_than_one_start=5, directional_derivatives_start=0)
+    wts = SimpleNamespace(rgb=2.0, depth=0.5, unit_norm=0.1, supervision=1.0, norm_smaller_than_one=0.1, directional_derivatives=0.0)
+    crit = VFLoss(cfg, wts)
+    ow = O.LossWeights(norm_smaller_than_one_start=5)
+    for epoch, with_depth, with_sup in ((0, True, True), (7, True, True), (0, False, False)):
+        pred = dict(rgb=torch.rand(n, 3, generator=gen), depth=torch.rand(n, 1, generator=gen),
+                    normals=torch.randn(n * s, 3, generator=gen), directional_derivatives=None,
+                    supervised_normals=torch.randn(10, 3, generator=gen) if with_sup else torch.empty(0, 3))
+        gt = dict(rgb=torch.rand(n, 3, generator=gen), depth=torch.rand(n, 1, generator=gen) * 2 if with_depth else torch.empty(0),
+                  supervised_normals=torch.randn(10, 3, generator=gen) if with_sup else torch.empty(0))
+        loss, logs = crit(pred, gt, epoch)
+        want = O.vf_loss(pred["rgb"], pred["depth"], pred["normals"], pred["supervised_normals"], gt["rgb"], gt["depth"],
+                         gt["supervised_normals"], ow, epoch=epoch)
+        assert abs(float(loss) - float(want)) < 1e-6 * max(1.0, abs(float(want)))
+        assert set(logs) == {"rgb_loss", "depth_loss", "unit_norm_loss", "supervision_loss", "norm_smaller_than_one_loss",
+                             "directional_derivatives_loss"} and all(isinstance(v, float) for v in logs.values())
+        assert (logs["norm_smaller_than_one_loss"] > 0) == (epoch >= 5)

@@ -630,6 +630,54 @@ __global__ void vfn_uniform_kernel(float* out, long long n, unsigned long long s
         if (base + i < n) out[base + i] = (float)(c[i] >> 8) * (1.0f / 16777216.0f);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Supervision points: uniform samples in a spherical shell around the scene centroid + their radial ground-truth
+// directions (models/samplers/sampler.py:160-193 SphereSampler.sample; models/helpers/functions.py:100-135
+// sample_border_points / sample_center_points, which the trainer calls with numpy on the host every step).
+//   phi = 2 pi u0, cos(theta) = 2 u1 - 1, r = cbrt(u2) (r_max - r_min) + r_min,
+//   p = c + r (sin(theta) cos(phi), sin(theta) sin(phi), cos(theta)),   gt = normalize(+-(p - c))  (eps 1e-12)
+// ------------------------------------------------------------------------------------------------
+struct ShellArgs {
+    const float* u;          // [n,3] explicit uniforms, or NULL -> Philox(seed, offset + sample)
+    const float* centroid;   // [3]
+    float* points;           // [n,3]
+    float* gt;               // [n,3]
+    long long n;
+    float r_min, r_max;
+    int inward;              // 1: gt points at the centroid (border supervision); 0: away from it (centre supervision)
+    unsigned long long seed, offset;
+};
+
+__global__ void vfn_sphere_shell_kernel(const ShellArgs a) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    float u0, u1, u2;
+    if (a.u) { u0 = a.u[i * 3 + 0]; u1 = a.u[i * 3 + 1]; u2 = a.u[i * 3 + 2]; }
+    else {
+        const unsigned long long ctr = a.offset + (unsigned long long)i;
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+        uint32_t k[2] = {(uint32_t)a.seed, (uint32_t)(a.seed >> 32)};
+#pragma unroll
+        for (int r = 0; r < 10; ++r) philox_round(c, k);
+        u0 = (float)(c[0] >> 8) * (1.0f / 16777216.0f);
+        u1 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);
+        u2 = (float)(c[2] >> 8) * (1.0f / 16777216.0f);
+    }
+    const float phi = 6.283185307179586f * u0;
+    const float ct = 2.0f * u1 - 1.0f;
+    const float st = sqrtf(fmaxf(0.f, 1.0f - ct * ct));
+    const float r = cbrtf(u2) * (a.r_max - a.r_min) + a.r_min;
+    float sp, cp;
+    sincosf(phi, &sp, &cp);
+    const float cx = a.centroid[0], cy = a.centroid[1], cz = a.centroid[2];
+    const float px = r * st * cp + cx, py = r * st * sp + cy, pz = r * ct + cz;
+    a.points[i * 3 + 0] = px; a.points[i * 3 + 1] = py; a.points[i * 3 + 2] = pz;
+    float dx = px - cx, dy = py - cy, dz = pz - cz;
+    if (a.inward) { dx = -dx; dy = -dy; dz = -dz; }
+    const float inv = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+    a.gt[i * 3 + 0] = dx * inv; a.gt[i * 3 + 1] = dy * inv; a.gt[i * 3 + 2] = dz * inv;
+}
+
 }  // namespace
 
 extern "C" int vfn_raygen_uniform(const vfn_raygen_params* p, const float* uv, const float* pose, const float* intrinsics,
@@ -713,4 +761,14 @@ extern "C" int vfn_ray_density_weights_bwd(const vfn_density_params* p, const fl
     const size_t shmem = (size_t)RAYS_PER_BLOCK * p->n_samples * 12 * sizeof(float);
     hipLaunchKernelGGL(vfn_density_bwd_kernel, dim3(blocks), dim3(256), shmem, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_ray_density_weights_bwd");
+}
+
+extern "C" int vfn_sample_sphere_shell(int64_t n, float r_min, float r_max, const float* centroid, int32_t inward, const float* u,
+                                       uint64_t seed, uint64_t offset, float* points, float* gt, void* stream) {
+    if (n <= 0) return VFN_OK;
+    VFN_REQUIRE(centroid && points && gt, "vfn_sample_sphere_shell: NULL argument");
+    VFN_REQUIRE(r_max >= r_min && r_min >= 0.f, "vfn_sample_sphere_shell: need 0 <= r_min <= r_max (got %g, %g)", (double)r_min, (double)r_max);
+    ShellArgs a{u, centroid, points, gt, (long long)n, r_min, r_max, inward ? 1 : 0, (unsigned long long)seed, (unsigned long long)offset};
+    hipLaunchKernelGGL(vfn_sphere_shell_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return vfn_check_launch("vfn_sample_sphere_shell");
 }

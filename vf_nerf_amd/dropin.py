@@ -13,7 +13,7 @@ import importlib
 import sys
 import types
 
-from . import density, grid, nerf, networks, render_output, samplers
+from . import density, grid, loss, nerf, networks, render_output, samplers, supervision
 
 _ALIASES = {
     "models.nerf.vector_field_nerf": nerf,
@@ -48,6 +48,19 @@ def install() -> None:
     try:
         mc = importlib.import_module("evaluation.utils.mc_utils")
         mc.get_set_predictions = grid.get_set_predictions
+    except Exception:
+        pass
+    # models.helpers.functions stays the reference's module (the trainer uses more of it); only the two host-side numpy
+    # samplers the trainer calls every step are replaced by the device-side ones
+    try:
+        fn = importlib.import_module("models.helpers.functions")
+        fn.sample_border_points = supervision.sample_border_points
+        fn.sample_center_points = supervision.sample_center_points
+    except Exception:
+        pass
+    # the loss with one device read-back per step instead of six
+    try:
+        importlib.import_module("models.losses.vf_loss").VFLoss = loss.VFLoss
     except Exception:
         pass
 

@@ -22,7 +22,7 @@ NET_VF, NET_RENDER = 0, 1
 EXPORTS = (
     "vfn_last_error", "vfn_abi_version", "vfn_packed_size", "vfn_pack_weights", "vfn_raygen_uniform",
     "vfn_vf_mlp_fwd", "vfn_render_mlp_fwd", "vfn_vf_render_fused_fwd", "vfn_ray_density_weights",
-    "vfn_range_fine_sample", "vfn_range_fine_sample_indexed", "vfn_fill_uniform", "vfn_packed_bwd_size", "vfn_pack_weights_bwd",
+    "vfn_range_fine_sample", "vfn_range_fine_sample_indexed", "vfn_fill_uniform", "vfn_sample_sphere_shell", "vfn_packed_bwd_size", "vfn_pack_weights_bwd",
     "vfn_vf_mlp_fwd_train", "vfn_vf_render_fused_fwd_train", "vfn_mlp_bwd_chain", "vfn_weight_grad_partials",
     "vfn_ray_density_weights_bwd", "vfn_pack16_size", "vfn_pack16_weights", "vfn_vf_mlp16_fwd",
     "vfn_vf_render_fused16_fwd", "vfn_vf_mlp16_fwd_train", "vfn_vf_render_fused16_fwd_train",
@@ -275,6 +275,18 @@ def fill_uniform(out: torch.Tensor, seed: int, offset: int) -> torch.Tensor:
     _check(load().vfn_fill_uniform(_ptr(out, "out"), C.c_int64(out.numel()), C.c_uint64(seed & (2 ** 64 - 1)),
                                    C.c_uint64(offset & (2 ** 64 - 1)), _stream()), "vfn_fill_uniform")
     return out
+
+
+def sample_sphere_shell(n: int, r_min: float, r_max: float, centroid: torch.Tensor, inward: bool, seed: int = 0, offset: int = 0,
+                        u: Optional[torch.Tensor] = None):
+    dev = centroid.device
+    pts = torch.empty(n, 3, device=dev)
+    gt = torch.empty(n, 3, device=dev)
+    _check(load().vfn_sample_sphere_shell(C.c_int64(n), C.c_float(r_min), C.c_float(r_max), _ptr(centroid, "centroid"),
+                                          C.c_int32(1 if inward else 0), _ptr(u, "u"), C.c_uint64(seed & (2 ** 64 - 1)),
+                                          C.c_uint64(offset & (2 ** 64 - 1)), _ptr(pts, "points"), _ptr(gt, "gt"), _stream()),
+           "vfn_sample_sphere_shell")
+    return pts, gt
 
 
 # ------------------------------------------------------------------------------------------------

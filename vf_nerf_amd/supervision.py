@@ -1,0 +1,64 @@
+"""Device-side supervision points of the trainer.
+
+The reference draws them with numpy on the host and uploads them every step
+(train/vector_field_nerf_train.py:186-214 -> models/helpers/functions.py:100-135 -> models/samplers/sampler.py:160-193).
+Same function names, arguments and return values here; the samples come from the library's Philox stream on the device
+(csrc/vfn_rays.hip: vfn_sphere_shell_kernel), so there is no host work and no upload.  The random STREAM necessarily
+differs from numpy's; the distribution and the ground truth are the reference's (tests replay explicit uniforms through
+both).  ``vf_nerf_amd.dropin`` installs the two samplers into ``models.helpers.functions``.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import lib
+
+_seed = 0x5eed
+_offset = 0
+
+
+def manual_seed(seed: int) -> None:
+    """Seed of the supervision stream (independent of the render() sampling stream)."""
+    global _seed, _offset
+    _seed, _offset = int(seed), 0
+
+
+def _shell(r_min: float, r_max: float, num_samples: int, centroid: torch.Tensor, device, inward: bool):
+    global _offset
+    c = torch.as_tensor(centroid, dtype=torch.float32, device=device).reshape(3).contiguous()
+    pts, gt = lib.sample_sphere_shell(int(num_samples), float(r_min), float(r_max), c, inward, _seed, _offset)
+    _offset += int(num_samples)
+    return pts, gt
+
+
+def sample_border_points(r_min: float, r_max: float, num_samples: int, centroid: torch.Tensor,
+                         device: torch.device = "cuda") -> Tuple[torch.Tensor, torch.Tensor]:
+    """Points in the shell r_min..r_max around the centroid and unit vectors pointing at the centroid
+    (functions.py:100-117)."""
+    return _shell(r_min, r_max, num_samples, centroid, device, inward=True)
+
+
+def sample_center_points(centroid: torch.Tensor, radius: float, num_samples: int,
+                         device: torch.device = "cuda") -> Tuple[torch.Tensor, torch.Tensor]:
+    """Points in the ball of the given radius around the centroid and unit vectors pointing away from it
+    (functions.py:119-135)."""
+    return _shell(0.0, radius, num_samples, centroid, device, inward=False)
+
+
+def get_border_indices_and_gt(points: torch.Tensor, normals: torch.Tensor, far: float, radius: float,
+                              centroid: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Normals of the ray samples farther than far/2 - radius from the centroid, and unit vectors from those samples to
+    the centroid (functions.py:75-98).  points / normals: [N,S,3]."""
+    keep = torch.linalg.vector_norm(points - centroid, dim=2) > (far / 2 - radius)
+    return normals.reshape(points.shape)[keep], F.normalize(centroid - points[keep], dim=1)
+
+
+def get_center_indices_and_gt(points: torch.Tensor, normals: torch.Tensor, centroid: torch.Tensor,
+                              radius: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Normals of the ray samples closer than ``radius`` to the centroid, and unit vectors from the centroid to them
+    (functions.py:137-157)."""
+    keep = torch.linalg.vector_norm(points - centroid, dim=2) < radius
+    return normals.reshape(points.shape)[keep], F.normalize(points[keep] - centroid, dim=1)
