@@ -307,6 +307,7 @@ class RenderSettings:
     far: float = 1.0
     fine_range: float = 0.3
     perturb: bool = False
+    numerical_jacobian: bool = False   # vector_field_nerf.py:258-262,299-301
     n_window: int = 11
     dir_to_normal_th: float = -2.0
     normalize: bool = True
@@ -342,6 +343,10 @@ def render(uv: Tensor, pose: Tensor, intrinsics: Tensor, vf_sd: Dict[str, Tensor
         sigma_c, cos_c, cosray_c = ray_density(nrm_c, ray_dirs, cfg.n_window, cfg.dir_to_normal_th, cfg.density,
                                                beta, mean, scale, return_parts=True)
         w_c = volsdf_weights(z_c, sigma_c, cfg.normalize)
+        dd_c = None
+        if cfg.numerical_jacobian:
+            dd_c = numerical_directional_derivatives(pts_c.reshape(-1, 3), vf_c[:, :3],
+                                                     lambda q: vf_mlp(q, vf_sd, cfg.vf_multires, cfg.vf_skip_in), fine=False).reshape(-1, 3)
     out.update(normals_coarse=nrm_c, window_cos_coarse=cos_c, cos_ray_coarse=cosray_c,
                sigma_coarse=sigma_c, weights_coarse=w_c)
 
@@ -366,6 +371,10 @@ def render(uv: Tensor, pose: Tensor, intrinsics: Tensor, vf_sd: Dict[str, Tensor
                         masks=masks)
     rgb = torch.sum(w_f.unsqueeze(-1) * colors.reshape(n, s_t, 3), dim=1)
     depth = torch.sum(w_f.unsqueeze(-1) * z_f.unsqueeze(-1), dim=1)
+    if cfg.numerical_jacobian:
+        dd_f = numerical_directional_derivatives(pts_f.reshape(-1, 3), nrm_flat,
+                                                 lambda q: vf_mlp(q, vf_sd, cfg.vf_multires, cfg.vf_skip_in), fine=True).reshape(-1, 3)
+        out["directional_derivatives"] = torch.cat([dd_c, dd_f], dim=0).norm(dim=-1)
     out.update(vf_out=vf_f, normals=nrm_f, window_cos=cos_f, cos_ray=cosray_f, sigma=sigma_f, weights=w_f,
                colors=colors, rgb=rgb, depth=depth, ray_dirs_repeated=rep_dirs)
     return out
@@ -407,6 +416,41 @@ def psnr(a: Tensor, b: Tensor) -> float:
     mse = torch.mean((a - b) ** 2).item()
     return float('inf') if mse == 0 else -10.0 * math.log10(mse)
 
+
+
+# --------------------------------------------------------------------------------------
+# directional derivatives  (models/nerf/vector_field_nerf.py:476-526; only reached with numerical_jacobian=True or a
+# train-mode VF net — not in the shipped regime)
+# --------------------------------------------------------------------------------------
+def directional_derivatives(normals: Tensor, jac: Tensor) -> Tensor:
+    """jac[M,3,3] (or [M,9]) applied to two unit tangents of every normal: t1 = normalize((n_y, -n_x, 0)),
+    t2 = normalize(n x (n_y, -n_x, 0)) -> [M,2,3]  (vector_field_nerf.py:476-498)."""
+    jac = jac.reshape(-1, 3, 3)
+    n1 = torch.zeros_like(normals)
+    n1[:, 0] = normals[:, 1]
+    n1[:, 1] = -normals[:, 0]
+    n2 = torch.cross(normals, n1, dim=-1)
+    out = torch.zeros(normals.shape[0], 2, 3, dtype=normals.dtype)
+    out[:, 0, :] = torch.bmm(jac, F.normalize(n1, dim=-1).unsqueeze(-1)).squeeze(-1)
+    out[:, 1, :] = torch.bmm(jac, F.normalize(n2, dim=-1).unsqueeze(-1)).squeeze(-1)
+    return out
+
+
+def numerical_directional_derivatives(points: Tensor, normals: Tensor, vf, fine: bool, epsilon: float = 1e-5) -> Tensor:
+    """Central differences of the 3 vector outputs (vector_field_nerf.py:500-526).  ``vf``: points[M,3] -> [M,>=3].
+    The reference fills the Jacobian by COLUMNS in the proposal pass (J[:, :, i] = d f / d x_i) and by ROWS in the fine
+    pass (J[:, i] = d f / d x_i, i.e. the transposed Jacobian) — kept."""
+    jac = torch.zeros(points.shape[0], 3, 3, dtype=points.dtype)
+    for i in range(3):
+        pos, neg = points.clone(), points.clone()
+        pos[:, i] += epsilon
+        neg[:, i] -= epsilon
+        col = (vf(pos)[:, :3] - vf(neg)[:, :3]) / (2.0 * epsilon)
+        if fine:
+            jac[:, i] = col
+        else:
+            jac[:, :, i] = col
+    return directional_derivatives(normals, jac)
 
 
 # --------------------------------------------------------------------------------------

@@ -46,6 +46,10 @@ FIXTURES = {
     "odd_orbit": dict(seed=3, gain=2.0, n_rays=24, n_samples=24, n_importance=17, perturb=True, th=-0.2, n_window=5,
                       near=0.1, far=1.5, fine_range=0.25, width=80, height=60, focal=70.0, cam_seed=5,
                       pose="orbit", skew=0.5, far_per_ray=True),
+    # numerical_jacobian=True (vector_field_nerf.py:258-262,299-301,500-526): 6 extra VF forwards per pass
+    "numjac_det": dict(seed=5, gain=2.0, n_rays=10, n_samples=14, n_importance=9, perturb=False, th=-0.2, n_window=5,
+                       near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=9, pose="identity",
+                       skew=0.0, far_per_ray=False, numjac=True),
     "w1_det": dict(seed=4, gain=2.0, n_rays=16, n_samples=20, n_importance=12, perturb=False, th=-2.0, n_window=1,
                    near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=7, pose="identity",
                    skew=0.0, far_per_ray=False),
@@ -71,7 +75,8 @@ def ref_config(fx) -> "rcfg.VFNerfConfig":
         density_config=rcfg.DensityConfig(beta_bounds=[1e-4, 1e9], mean_bounds=[0.6, 1.0], scale_min=1.0,
                                           params_init={'beta': 0.5, 'scale': 100.0, 'mean': 0.7}, cutoff=-2.0),
         cos_sim_weights=[0.09] * fx["n_window"], cos_sim_weights_anneal="hard", anneal_start=700, anneal_end=1400,
-        rendering="volsdf", normalize_rendering=True, dir_to_normal_th=fx["th"], numerical_jacobian=False,
+        rendering="volsdf", normalize_rendering=True, dir_to_normal_th=fx["th"],
+        numerical_jacobian=bool(fx.get("numjac", False)),
         border_supervision=True, center_supervision=True)
 
 
@@ -171,6 +176,10 @@ def capture(fx, model):
         assert len(draws) == 1
     if fx["far_per_ray"]:
         d["far_per_ray"] = model.ray_sampler.far
+    if fx.get("numjac"):      # each pass = the main VF forward + 6 offset forwards of the numerical Jacobian
+        assert len(rec["vf"]) == 14
+        rec["vf"] = [rec["vf"][0], rec["vf"][7]]
+        d["directional_derivatives"] = out.directional_derivtives
     assert len(rec["vf"]) == 2 and len(rec["vol_out"]) == 2 and len(rec["wcos"]) == 2 and len(rec["colors"]) == 1
     (z_c, sigma_c), (z_f, sigma_f) = rec["vol_in"]
     d.update(directions=directions.reshape(-1, 3), ray_dirs=ray_dirs.reshape(-1, 3), cam_loc=cam_loc.reshape(-1, 3),
@@ -198,6 +207,11 @@ def loss_coefficients(n, s_t):
     return (torch.randn(n, 3, generator=g), torch.randn(n, 1, generator=g), 0.05 * torch.randn(n, s_t, 3, generator=g))
 
 
+def dd_coefficients(m):
+    g = torch.Generator().manual_seed(4343)
+    return 1e-3 * torch.rand(m, generator=g)
+
+
 def capture_grads(fx, model, data):
     """Reference gradients of the functional for the replayed random draws (the shipped training regime: networks
     in eval mode, autograd through the fine pass only)."""
@@ -214,6 +228,8 @@ def capture_grads(fx, model, data):
     assert torch.equal(out.z_vals, data["z_vals"])
     a, b, c = loss_coefficients(*data["z_vals"].shape)
     loss = (out.coarse_rgb_values * a).sum() + (out.coarse_depth_map * b).sum() + (out.coarse_normals * c).sum()
+    if out.directional_derivtives is not None:     # fixed positive weights on the directional-derivative norms
+        loss = loss + (out.directional_derivtives * dd_coefficients(out.directional_derivtives.shape[0])).sum()
     loss.backward()
     nets = {"vf": model.vector_field_network, "rn": model.rendering_network}
     g = {}
@@ -227,7 +243,10 @@ def capture_grads(fx, model, data):
 
 def main() -> None:
     torch.set_num_threads(8)
+    only = set(sys.argv[1:])          # optional: fixture names to (re)generate
     for name, fx in FIXTURES.items():
+        if only and name not in only:
+            continue
         model = build_reference_model(fx)
         own_model_matches(fx, model)
         data, model = capture(fx, model)

@@ -30,6 +30,7 @@ def build_model(fx: dict, data: Dict[str, torch.Tensor], device="cpu") -> "vf_ne
     cfg = vf_nerf_amd.shipped_config(torch.device("cpu"), n_samples=fx["n_samples"], n_importance=fx["n_importance"],
                                      perturb=fx["perturb"], near=fx["near"], far=fx["far"],
                                      fine_range=fx["fine_range"], dir_to_normal_th=fx["th"], n_window=fx["n_window"])
+    cfg.numerical_jacobian = bool(fx.get("numjac", False))
     model = vf_nerf_amd.VectorFieldNerf(cfg)
     synthetic.scale_hidden_weights(model.vector_field_network, model.rendering_network, fx["gain"])
     with torch.no_grad():
@@ -57,7 +58,7 @@ def build_model(fx: dict, data: Dict[str, torch.Tensor], device="cpu") -> "vf_ne
 
 def oracle_settings(fx: dict):
     from oracle import vfnerf_oracle as O
-    return O.RenderSettings(n_samples=fx["n_samples"], n_fine=fx["n_importance"], near=fx["near"], far=fx["far"],
+    return O.RenderSettings(numerical_jacobian=bool(fx.get("numjac", False)), n_samples=fx["n_samples"], n_fine=fx["n_importance"], near=fx["near"], far=fx["far"],
                             fine_range=fx["fine_range"], perturb=fx["perturb"], n_window=fx["n_window"],
                             dir_to_normal_th=fx["th"], normalize=True,
                             density=O.DensityParams(beta=0.5, mean=0.7, scale=100.0, beta_bounds=(1e-4, 1e9),

@@ -310,3 +310,42 @@ def test_supervision_sphere_shell_sampler():
     assert float((cg.cpu() - (cp.cpu() - c) / rc[:, None]).abs().max()) < 1e-3      # centre gt points away from it
     again = supervision.sample_border_points(0.75, 1.0, 20000, c, dev())[0]
     assert not torch.equal(again, bp), "the stream advances"
+
+
+def test_numerical_directional_derivatives_on_hip():
+    """numerical_jacobian=True end to end on the HIP path against the reference's golden output.  The quantity is a central
+    difference with epsilon = 1e-5 of fp32 network outputs, so a forward difference of 1e-7 between two implementations
+    shows up as 5e-3 in a Jacobian entry — the tolerance is that noise floor, not the 1e-4 of the smooth outputs."""
+    fx, d = load_fixture("numjac_det")
+    model = build_model(fx, d, device="cuda:0")
+    g = {k: v.to(dev()) for k, v in d.items() if isinstance(v, torch.Tensor)}
+    with torch.no_grad():
+        out = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms={"u_add": g["u_add"]})
+    assert torch.equal(out.z_vals.cpu(), d["z_vals"])
+    assert rel_err(out.coarse_rgb_values, d["rgb"]) < 2e-5
+    dd, ref = out.directional_derivtives.cpu(), d["directional_derivatives"]
+    assert dd.shape == ref.shape
+    err = (dd - ref).abs()
+    # yardstick: the same quantity from the oracle evaluated in float64 (no cancellation noise).  The reference's own fp32
+    # output deviates from it by the noise floor; the HIP path must sit on the same floor.
+    from oracle import vfnerf_oracle as O
+    from helpers import oracle_settings
+    f64 = lambda sd: {k: v.double() for k, v in sd.items()}
+    cpu_model = build_model(fx, d)
+    o64 = O.render(d["uv"].double(), d["pose"].double(), d["intrinsics"].double(), f64(cpu_model.vector_field_network.state_dict()),
+                   f64(cpu_model.rendering_network.state_dict()), oracle_settings(fx), u_add=d["u_add"].double())
+    exact = o64["directional_derivatives"].float()
+    e_ref, e_hip = (ref - exact).abs(), (dd - exact).abs()
+    print(f"directional derivatives (max |value| {float(ref.abs().max()):.1f}): vs reference max {float(err.max()):.3e} median "
+          f"{float(err.median()):.3e}; vs float64: reference median {float(e_ref.median()):.3e} max {float(e_ref.max()):.3e}, "
+          f"HIP median {float(e_hip.median()):.3e} max {float(e_hip.max()):.3e}")
+    assert float(e_hip.median()) <= 3.0 * float(e_ref.median()) + 1e-3 and float(e_hip.max()) <= 3.0 * float(e_ref.max()) + 1e-2
+    assert float(err.max()) < 1e-2 * float(ref.abs().max()) + 0.5
+    # with gradients: the fine-pass half of the derivatives carries autograd history through six more VF forwards
+    for p in model.unique_parameters():
+        p.grad = None
+    out = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms={"u_add": g["u_add"]})
+    assert out.directional_derivtives.requires_grad
+    out.directional_derivtives.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.vector_field_network.parameters() if p.grad is not None)
+    assert float(model.vector_field_network.layers[0][0].weight.grad.abs().max()) > 0

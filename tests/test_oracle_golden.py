@@ -78,3 +78,18 @@ def test_oracle_gradients_match_reference(name):
         assert err < 1e-4, (net, key, err)
     for k in ("beta", "mean", "scale"):
         assert grad_rel_err(grads[f"density.{k}"].reshape(1), d[f"grad.density.{k}"]) < 1e-4, k
+
+
+def test_numerical_directional_derivatives_golden():
+    """numerical_jacobian=True (vector_field_nerf.py:258-262,299-301,476-526): the oracle's restatement against the
+    reference's own output, including the transposed Jacobian of the fine pass."""
+    from helpers import build_model, load_fixture, oracle_settings
+    from oracle import vfnerf_oracle as O
+    fx, d = load_fixture("numjac_det")
+    model = build_model(fx, d)
+    out = O.render(d["uv"], d["pose"], d["intrinsics"], model.vector_field_network.state_dict(),
+                   model.rendering_network.state_dict(), oracle_settings(fx), u_add=d["u_add"])
+    n, s_c, n_f = fx["n_rays"], fx["n_samples"], fx["n_importance"]
+    assert out["directional_derivatives"].shape == (2 * n * (s_c + s_c + n_f),)
+    assert float((out["directional_derivatives"] - d["directional_derivatives"]).abs().max()) <= 1e-4 * float(d["directional_derivatives"].abs().max())
+    assert float((out["rgb"] - d["rgb"]).abs().max()) < 1e-6

@@ -272,9 +272,10 @@ class VectorFieldNerf:
                                       "reference (Q11); only 'volsdf' is implemented")
         if not cfg.ray_sampler_config.fine_sampling():
             raise ValueError("render() needs n_importance > 0 (the reference raises NameError without it, Q1)")
-        if self.vector_field_network.training or cfg.numerical_jacobian:
-            raise NotImplementedError("train-mode VF forward / directional derivatives (vector_field_nerf.py:258-264) "
-                                      "are not on the HIP path; use model.eval() as the shipped trainer does (Q8)")
+        if self.vector_field_network.training:
+            raise NotImplementedError("the train-mode VF forward (batch-statistics BatchNorm + autograd Jacobian, "
+                                      "vector_field_network.py:146-173) is not on the HIP path; use model.eval() as the shipped "
+                                      "trainer does (Q8) — directional derivatives are available with numerical_jacobian=True")
         from .autograd import fine_pass  # differentiable or plain, depending on torch.is_grad_enabled()
 
         dev = pose.device
@@ -312,6 +313,9 @@ class VectorFieldNerf:
                 normals_c = lib.vf_mlp16_fwd(vf.geometry(), vf.packed16_weights(), pts_c.view(-1, 3))
             else:
                 normals_c = lib.vf_mlp_fwd(vf.geometry(), vf.packed_weights(), pts_c.view(-1, 3), 3)
+            dd_c = None
+            if cfg.numerical_jacobian:      # vector_field_nerf.py:258-262
+                dd_c = self.compute_numerical_directional_derivatives(pts_c.view(-1, 3), normals_c).reshape(-1, 3)
             # (4)-(5) density -> weights -> argmax
             scal = self.density.raw_scalars()
             _, _, imax, _, _ = lib.ray_density_weights(self._density_params(), normals_c, ray_dirs, z_c, scal,
@@ -341,13 +345,50 @@ class VectorFieldNerf:
         else:
             # (7)-(11) fine pass: VF net + rendering net + density + composite
             normals, colors, rgb, depth, weights = fine_pass(self, pts, z, ray_dirs)
+        dd = None
+        if cfg.numerical_jacobian:          # vector_field_nerf.py:299-301 (differentiable: six more VF forwards)
+            dd_f = self.compute_numerical_directional_derivatives(pts.view(-1, 3), normals.reshape(-1, 3), fine=True)
+            dd = torch.cat([dd_c, dd_f.reshape(-1, 3)], dim=0).norm(dim=-1)
         if white:
             rgb = rgb + (1. - weights.sum(-1)[..., None])
         rep_dirs = ray_dirs.unsqueeze(1).expand(n, s_t, 3).reshape(-1, 3)
         return NerfOutput(points_coarse=pts, points_fine=None, coarse_normals=normals.view(n, s_t, 3),
                           coarse_rgb_values=rgb, coarse_depth_map=depth, fine_normals=None, fine_rgb_values=None,
-                          fine_depth_map=None, z_vals=z, directional_derivtives=None, ray_dirs=rep_dirs,
+                          fine_depth_map=None, z_vals=z, directional_derivtives=dd, ray_dirs=rep_dirs,
                           coarse_colors=colors)
+
+    # ---------------------------------------------------------------------------------------------
+    # directional derivatives (vector_field_nerf.py:476-526)
+    # ---------------------------------------------------------------------------------------------
+    def compute_directional_derivatives(self, points: torch.Tensor, normals: torch.Tensor, jac: torch.Tensor) -> torch.Tensor:
+        """jac[M,3,3] | [M,9] applied to two unit tangents of every normal, t1 = normalize((n_y, -n_x, 0)) and
+        t2 = normalize(n x (n_y, -n_x, 0)) -> [M,2,3]."""
+        jac = jac.reshape(-1, 3, 3)
+        zeros = torch.zeros_like(normals[:, 0])
+        n1 = torch.stack([normals[:, 1], -normals[:, 0], zeros], dim=1)
+        n2 = torch.linalg.cross(normals, n1, dim=-1)
+        t1 = torch.nn.functional.normalize(n1, dim=-1)
+        t2 = torch.nn.functional.normalize(n2, dim=-1)
+        return torch.stack([torch.bmm(jac, t1.unsqueeze(-1)).squeeze(-1), torch.bmm(jac, t2.unsqueeze(-1)).squeeze(-1)], dim=1)
+
+    def compute_numerical_directional_derivatives(self, points: torch.Tensor, normals: torch.Tensor, epsilon: float = 1e-5,
+                                                  fine: bool = False) -> torch.Tensor:
+        """Central differences of the vector columns: six more VF forwards (vector-only kernels; exact-fp32 arithmetic,
+        because a forward error d becomes d / epsilon in the quotient).  As in the reference the Jacobian is filled by
+        columns in the proposal pass and by rows (transposed) in the fine pass."""
+        net = self.fine_vector_field_network if fine else self.vector_field_network
+        keep = net.precision
+        net.precision = "fp32"
+        try:
+            cols = []
+            for i in range(3):
+                step = torch.zeros(3, device=points.device, dtype=points.dtype)
+                step[i] = epsilon
+                cols.append((net(points + step, vector_only=True) - net(points - step, vector_only=True)) / (2.0 * epsilon))
+        finally:
+            net.precision = keep
+        jac = torch.stack(cols, dim=1) if fine else torch.stack(cols, dim=2)     # fine: jac[:, i] = column i (Q: transposed)
+        return self.compute_directional_derivatives(points, normals, jac)
 
     # ---------------------------------------------------------------------------------------------
     # secondary entry points (vector_field_nerf.py:341-474)
