@@ -12,10 +12,17 @@ the max over ranks; rank 0 prints ONE JSON line.  Inputs (uv / pose / intrinsics
 the timed region; random numbers come from the device Philox stream inside the timed region.
 
 Extra objects on the line:
-  roofline      the dominant kernel (fused VF+rendering MLP, fp32 MFMA): algorithmic FLOPs per launch
-                (2*S_t*(525056+271360) per ray) / its average duration measured with HIP
-                events on the launch stream inside the timed region; peak = 157.3 TFLOP/s fp32 matrix.
-  cpu_baseline  the CPU oracle (torch fp32, all host cores) on a bounded sample of the same workload.
+  roofline          the dominant kernel class of the step (largest share of the timed region; with the defaults the VF
+                    MLP launch of the split inference pipeline, two launches per step): ALGORITHMIC fp32-equivalent FLOPs
+                    of one launch (SURVEY.md §8d per-point figures x its points) / its average duration measured with
+                    HIP events on the launch stream inside the timed region; peak = dense f16 MFMA 2500 TFLOP/s / 3 (three
+                    f16 products per fp32-equivalent product), or 157.3 TFLOP/s fp32 matrix with --precision fp32;
+                    traffic from the committed PMC passes (profiles/).
+  cpu_baseline      the CPU oracle (torch fp32, 32 host threads) on a bounded sample of the same workload.
+  parity_vs_oracle  the "PSNR vs ref" half of the metric: the HIP path against the oracle on those sample rays.
+
+Other workloads (not the headline line): --workload view | grid | train (BASELINE.json configs[1], [4], [2]);
+--no-reuse evaluates the VF net on the proposal samples twice, as the reference does (one fused launch).
 """
 from __future__ import annotations
 
