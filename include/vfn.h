@@ -326,6 +326,26 @@ int vfn_vf_render_fused16_fwd_train(const vfn_net_geom* vf_geom, const void* vf_
                                     int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
                                     float* saved, float* save_aux_vf, float* save_aux_rn, void* stream);
 
+/* =============================================================================================
+ * Dense-grid stages between the vector-field queries and the mesh triangulation (evaluation/utils/mc_utils.py,
+ * evaluation/utils/guassian_smoothing.py).  Grid cell (i,j,k) -> (i n + j) n + k; field vt[n^3,3]; n <= 1024.
+ * ============================================================================================= */
+/* mc_utils.py:34-86: out[n^3] = 1 where the flux of the normalised field through the cell's 8 corners is <= threshold
+ * (-0.5 in the reference), else 0; cells of the last planes are 0. */
+int vfn_grid_divergence(const float* vt, int32_t n, float threshold, float* out, void* stream);
+/* guassian_smoothing.py:81-97: one axis of the separable Gaussian (k odd, <= 15 host weights), replicate padding;
+ * three calls (axis 0, 1, 2) = smooth_vf.  Out of place. */
+int vfn_grid_smooth_axis(const float* in, float* out, int32_t n, int32_t axis, const float* weights_host, int32_t k,
+                         void* stream);
+/* mc_utils.py:107-167: for cells with divergence == 1, which of the cell's two most opposed corner vectors each of the 8
+ * corners sides with (0/1; corner order (0,0,0) (0,1,0) (1,1,0) (1,0,0) (0,0,1) (0,1,1) (1,1,1) (1,0,1)); other cells 0.
+ * vt is the normalised field [n^3,3]. */
+int vfn_grid_unify_direction(const float* divergence, const float* vt, int32_t n, int64_t* choice, void* stream);
+/* mc_utils.py:170-223: for the 28 corner pairs (a<b) of every cell: different_side[n^3,28] = choice_a != choice_b,
+ * pair_norms[n^3,28,2] = (norms at corner a, norms at corner b), corners outside the grid read as 0. */
+int vfn_grid_comb_format(const int64_t* choice, const float* norms, int32_t n, float* different_side, float* pair_norms,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -468,3 +468,73 @@ def sphere_shell_points(u: Tensor, r_min: float, r_max: float, centroid: Tensor,
     points = local.float() + centroid.float()
     d = (centroid - points) if inward else (points - centroid)
     return points, F.normalize(d, dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# dense-grid stages of the mesh extraction (evaluation/utils/mc_utils.py:34-86,107-223;
+# evaluation/utils/guassian_smoothing.py:9-97).  Direct gathers instead of the reference's conv3d chains.
+# --------------------------------------------------------------------------------------
+_CORNERS = ((0, 0, 0), (0, 1, 0), (1, 1, 0), (1, 0, 0), (0, 0, 1), (0, 1, 1), (1, 1, 1), (1, 0, 1))   # selection-filter order
+
+
+def _corner_gather(grid: Tensor, n: int) -> Tensor:
+    """grid[n,n,n,C] -> [n,n,n,8,C]: the 8 corners of every cell, zero beyond the grid (conv3d padding=1, then [1:,1:,1:])."""
+    padded = F.pad(grid, (0, 0, 0, 1, 0, 1, 0, 1))
+    return torch.stack([padded[a:a + n, b:b + n, c:c + n] for a, b, c in _CORNERS], dim=3)
+
+
+def grid_divergence(vt_values: Tensor, n: int, threshold: float = -0.5) -> Tensor:
+    """mc_utils.py:34-86: flux of the normalised field through the 2x2x2 corners of every cell (outward unit diagonals),
+    sum_c x_c |x_c| (sqrt(3)/4) / (sqrt(2)/3); 1 where <= threshold; the last planes stay 0."""
+    v = F.normalize(vt_values, dim=1).reshape(n, n, n, 3)
+    s = torch.zeros(n - 1, n - 1, n - 1, dtype=v.dtype)
+    for c in range(8):
+        a, b, cc = c >> 2, (c >> 1) & 1, c & 1
+        d = F.normalize(torch.tensor([2.0 * a - 1, 2.0 * b - 1, 2.0 * cc - 1], dtype=v.dtype), dim=0)
+        x = (v[a:a + n - 1, b:b + n - 1, cc:cc + n - 1] * d).sum(-1)
+        s = s + x * x.abs() * (math.sqrt(3.0) / 4.0)
+    s = s / (math.sqrt(2.0) / 3.0)
+    out = torch.zeros(n, n, n, dtype=v.dtype)
+    out[:-1, :-1, :-1] = s
+    return torch.where(out > threshold, torch.zeros_like(out), torch.ones_like(out))
+
+
+def smooth_field(vf: Tensor, k: int = 3, sigma: float = 1.0) -> Tensor:
+    """guassian_smoothing.py:9-97: depthwise k^3 kernel, the product over the axes of exp(-((x - mean) / (2 sigma))^2)
+    — the reference's exponent, i.e. a Gaussian of standard deviation sigma sqrt(2) — normalised to sum 1; replicate
+    padding.  vf[n,n,n,3]."""
+    ax = torch.arange(k, dtype=torch.float32)
+    mean = (k - 1) / 2.0
+    g = 1.0 / (sigma * math.sqrt(2 * math.pi)) * torch.exp(-(((ax - mean) / (2 * sigma)) ** 2))
+    kern = g[:, None, None] * g[None, :, None] * g[None, None, :]
+    kern = (kern / kern.sum()).to(vf.dtype)
+    x = F.pad(vf.permute(3, 0, 1, 2).unsqueeze(0), (k // 2,) * 6, mode="replicate")
+    w = kern.view(1, 1, k, k, k).repeat(3, 1, 1, 1, 1)
+    return F.conv3d(x, w, groups=3).squeeze(0).permute(1, 2, 3, 0)
+
+
+def grid_unify_direction(divergence_grid: Tensor, vt_grid: Tensor, n: int) -> Tensor:
+    """mc_utils.py:107-167.  vt_grid[3,n,n,n] (normalised field).  For surface cells: the most opposed corner pair
+    (argmax of 1 - <v_a, v_b> over the 64 ordered pairs, first maximum), then per corner the nearer of the two."""
+    corners = _corner_gather(vt_grid.permute(1, 2, 3, 0), n)                      # [n,n,n,8,3]
+    sel = divergence_grid == 1
+    sv = corners[sel]                                                              # [m,8,3]
+    dots = (sv[:, :, None, 0] * sv[:, None, :, 0] + sv[:, :, None, 1] * sv[:, None, :, 1]) + sv[:, :, None, 2] * sv[:, None, :, 2]
+    far = torch.argmax((1.0 - dots).reshape(-1, 64), dim=-1)
+    first = sv[torch.arange(sv.shape[0]), far // 8]
+    second = sv[torch.arange(sv.shape[0]), far % 8]
+    d1 = torch.norm(first[:, None, :] - sv, dim=-1)
+    d2 = torch.norm(second[:, None, :] - sv, dim=-1)
+    choice = torch.argmin(torch.stack((d1, d2), dim=-1), dim=-1)
+    out = torch.zeros(n, n, n, 8, dtype=choice.dtype)
+    out[sel] = choice
+    return out.reshape(-1, 8)
+
+
+def grid_comb_format(choice_side: Tensor, norms: Tensor, n: int):
+    """mc_utils.py:170-223: the 28 corner pairs (a < b) of every cell."""
+    nr = _corner_gather(norms.reshape(n, n, n, 1), n).reshape(n ** 3, 8)
+    pairs = [(a, b) for a in range(7) for b in range(a + 1, 8)]
+    different = torch.stack([(choice_side[:, a] != choice_side[:, b]).to(norms.dtype) for a, b in pairs], dim=1)
+    pair_norms = torch.stack([torch.stack((nr[:, a], nr[:, b]), dim=-1) for a, b in pairs], dim=1)
+    return different, pair_norms

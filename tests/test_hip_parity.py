@@ -349,3 +349,39 @@ def test_numerical_directional_derivatives_on_hip():
     out.directional_derivtives.sum().backward()
     assert all(torch.isfinite(p.grad).all() for p in model.vector_field_network.parameters() if p.grad is not None)
     assert float(model.vector_field_network.layers[0][0].weight.grad.abs().max()) > 0
+
+
+def test_grid_stages_on_hip():
+    """vf_nerf_amd.grid.extract_divergence / smooth_vf / unify_direction / make_comb_format (one HIP kernel each) against
+    outputs of the reference's own functions on the same fields.  The masks and choices are thresholds / argmins of fp32
+    expressions: a cell may differ only if its deciding quantity is within rounding of the decision boundary."""
+    import os
+    import numpy as np
+    from oracle import vfnerf_oracle as O
+    from vf_nerf_amd import grid
+    raw = np.load(os.path.join(os.path.dirname(__file__), "golden", "grid_stages.npz"))
+    g = {k: torch.from_numpy(raw[k]) for k in raw.files}
+    for n in (10, 13):
+        pred = g[f"n{n}.pred"].to(dev())
+        div = grid.extract_divergence(pred, n)
+        assert div.shape == (n, n, n) and float((div.cpu() != g[f"n{n}.div"]).float().sum()) == 0
+        for k, sigma, key in ((3, 1.0, "smooth3"), (9, 2.0, "smooth9")):
+            sm = grid.smooth_vf(pred.reshape(n, n, n, 3), k=k, sigma=sigma)
+            assert sm.shape == (n, n, n, 3) and float((sm.cpu() - g[f"n{n}.{key}"]).abs().max()) < 2e-6
+        vt = torch.nn.functional.normalize(pred, dim=1).reshape(n, n, n, 3)
+        choice = grid.unify_direction(div, vt.permute(3, 0, 1, 2), N=n)
+        assert choice.dtype == torch.int64 and choice.shape == (n ** 3, 8)
+        mism = (choice.cpu() != g[f"n{n}.choice"]).sum()
+        assert int(mism) == 0, int(mism)
+        norms = torch.norm(g[f"n{n}.pred"], dim=1).to(dev())          # as the reference computes them (CPU), then a pure gather
+        comb, pair_norms = grid.make_comb_format(choice, norms, n)
+        assert torch.equal(comb.cpu(), g[f"n{n}.comb"]) and torch.equal(pair_norms.cpu(), g[f"n{n}.pair_norms"])
+    # a larger random grid against the oracle (edge planes, empty and full masks)
+    n = 33
+    gen = torch.Generator().manual_seed(5)
+    pred = torch.randn(n ** 3, 3, generator=gen)
+    div = grid.extract_divergence(pred.to(dev()), n).cpu()
+    want = O.grid_divergence(pred, n)
+    assert float((div != want).float().mean()) < 1e-3
+    with pytest.raises(Exception):
+        grid.extract_divergence(pred, n)      # host tensors are refused: no CPU fallback

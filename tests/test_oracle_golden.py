@@ -93,3 +93,28 @@ def test_numerical_directional_derivatives_golden():
     assert out["directional_derivatives"].shape == (2 * n * (s_c + s_c + n_f),)
     assert float((out["directional_derivatives"] - d["directional_derivatives"]).abs().max()) <= 1e-4 * float(d["directional_derivatives"].abs().max())
     assert float((out["rgb"] - d["rgb"]).abs().max()) < 1e-6
+
+
+def _grid_golden():
+    import os
+    import numpy as np
+    raw = np.load(os.path.join(os.path.dirname(__file__), "golden", "grid_stages.npz"))
+    return {k: torch.from_numpy(raw[k]) for k in raw.files}
+
+
+def test_grid_stages_oracle_vs_reference_golden():
+    """The oracle's restatement of extract_divergence / smooth_vf / unify_direction / make_comb_format
+    (evaluation/utils/mc_utils.py, guassian_smoothing.py) against outputs of the reference's own functions."""
+    from oracle import vfnerf_oracle as O
+    g = _grid_golden()
+    for n in (10, 13):
+        pred = g[f"n{n}.pred"]
+        div = O.grid_divergence(pred, n)
+        assert torch.equal(div, g[f"n{n}.div"])
+        assert float((O.smooth_field(pred.reshape(n, n, n, 3), 3, 1.0) - g[f"n{n}.smooth3"]).abs().max()) < 1e-6
+        assert float((O.smooth_field(pred.reshape(n, n, n, 3), 9, 2.0) - g[f"n{n}.smooth9"]).abs().max()) < 1e-6
+        vt = torch.nn.functional.normalize(pred, dim=1).reshape(n, n, n, 3).permute(3, 0, 1, 2)
+        choice = O.grid_unify_direction(div, vt, n)
+        assert torch.equal(choice, g[f"n{n}.choice"])
+        comb, pair_norms = O.grid_comb_format(choice, torch.norm(pred, dim=1), n)
+        assert torch.equal(comb, g[f"n{n}.comb"]) and torch.equal(pair_norms, g[f"n{n}.pair_norms"])

@@ -48,6 +48,11 @@ def install() -> None:
     try:
         mc = importlib.import_module("evaluation.utils.mc_utils")
         mc.get_set_predictions = grid.get_set_predictions
+        # the conv3d / gather stages after the queries, as device kernels (they expect the grid on the GPU)
+        mc.extract_divergence = grid.extract_divergence
+        mc.unify_direction = grid.unify_direction
+        mc.make_comb_format = grid.make_comb_format
+        importlib.import_module("evaluation.utils.guassian_smoothing").smooth_vf = grid.smooth_vf
     except Exception:
         pass
     # models.helpers.functions stays the reference's module (the trainer uses more of it); only the two host-side numpy

@@ -21,6 +21,8 @@ from typing import List, Tuple
 
 import torch
 
+from . import lib
+
 DEVICE_CHUNK = 1 << 22      # points per launch group: 48 MiB in + 48 MiB out of HBM
 
 
@@ -85,3 +87,56 @@ def get_set_predictions(decoder, samples: torch.Tensor, max_batch: int, device, 
 def _accepts_vector_only(decoder) -> bool:
     from .networks import VectorFieldNetwork
     return isinstance(decoder, VectorFieldNetwork)
+
+
+# ------------------------------------------------------------------------------------------------
+# the stages between the queries and the triangulation, on the device.  Same names, arguments and
+# results as evaluation/utils/mc_utils.py:34-86,107-223 and evaluation/utils/guassian_smoothing.py:81-97, but the res^3
+# grids stay in HBM: pass the (device-resident) output of get_set_predictions along.
+# ------------------------------------------------------------------------------------------------
+def _dev_f32(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda:
+        raise lib.VfnError("the dense-grid stages run on the device: move the grid to the GPU first (no CPU fallback)")
+    return t.float().contiguous()
+
+
+def extract_divergence(vt_values: torch.Tensor, N: int) -> torch.Tensor:
+    """vt_values[N^3,3] -> [N,N,N] mask (1.0 where the normalised field converges onto the cell, threshold -0.5)."""
+    return lib.grid_divergence(_dev_f32(vt_values.reshape(-1, 3)), N, -0.5)
+
+
+def gaussian_weights(k: int, sigma: float):
+    """The 1-D factor of the reference's k^3 kernel: exp(-((x - mean) / (2 sigma))^2) per axis (its exponent: a Gaussian of
+    standard deviation sigma sqrt(2)), the product normalised to sum 1 — which factorises into normalised 1-D factors."""
+    import math
+    mean = (k - 1) / 2.0
+    w = [math.exp(-(((i - mean) / (2 * sigma)) ** 2)) for i in range(k)]
+    tot = sum(w)
+    return [x / tot for x in w]
+
+
+def smooth_vf(vf: torch.Tensor, k: int = 3, sigma: float = 1.0) -> torch.Tensor:
+    """vf[N,N,N,3] -> Gaussian-smoothed field, replicate padding; three separable passes."""
+    n = vf.shape[0]
+    a = _dev_f32(vf.reshape(-1, 3))
+    if a.data_ptr() == vf.data_ptr():
+        a = a.clone()
+    b = torch.empty_like(a)
+    w = gaussian_weights(k, sigma)
+    lib.grid_smooth_axis(a, b, n, 0, w)
+    lib.grid_smooth_axis(b, a, n, 1, w)
+    lib.grid_smooth_axis(a, b, n, 2, w)
+    return b.view(n, n, n, 3)
+
+
+def unify_direction(divergence_grid: torch.Tensor, vt_grid: torch.Tensor, N: int = 64) -> torch.Tensor:
+    """divergence_grid[N,N,N], vt_grid[3,N,N,N] (normalised field, channel first as the reference passes it) -> [N^3,8]."""
+    vt = _dev_f32(vt_grid.permute(1, 2, 3, 0).reshape(-1, 3))
+    return lib.grid_unify_direction(_dev_f32(divergence_grid.reshape(-1)), vt, N)
+
+
+def make_comb_format(choice_side: torch.Tensor, norms: torch.Tensor, N: int):
+    """choice_side[N^3,8], norms[N^3] -> (different_side[N^3,28], different_side_norms[N^3,28,2])."""
+    if not choice_side.is_cuda:
+        raise lib.VfnError("the dense-grid stages run on the device")
+    return lib.grid_comb_format(choice_side.to(torch.int64).contiguous(), _dev_f32(norms.reshape(-1)), N)

@@ -26,7 +26,8 @@ EXPORTS = (
     "vfn_vf_mlp_fwd_train", "vfn_vf_render_fused_fwd_train", "vfn_mlp_bwd_chain", "vfn_weight_grad_partials",
     "vfn_ray_density_weights_bwd", "vfn_pack16_size", "vfn_pack16_weights", "vfn_vf_mlp16_fwd",
     "vfn_vf_render_fused16_fwd", "vfn_vf_mlp16_fwd_train", "vfn_vf_render_fused16_fwd_train",
-    "vfn_vf_feat16_fwd", "vfn_render16_from_blocks", "vfn_weight_grad_partials_bf16", "vfn_unfold_weight_grads", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
+    "vfn_vf_feat16_fwd", "vfn_render16_from_blocks", "vfn_grid_divergence", "vfn_grid_smooth_axis",
+    "vfn_grid_unify_direction", "vfn_grid_comb_format", "vfn_weight_grad_partials_bf16", "vfn_unfold_weight_grads", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
 )
 
 
@@ -486,3 +487,36 @@ def vf_render_fused16_fwd(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ra
                                             C.c_int32(samples_per_ray), _ptr(normals, "normals"),
                                             _ptr(colors, "colors"), _stream()), "vfn_vf_render_fused16_fwd")
     return normals, colors
+
+
+# ------------------------------------------------------------------------------------------------
+# dense-grid stages (mesh extraction)
+# ------------------------------------------------------------------------------------------------
+def grid_divergence(vt: torch.Tensor, n: int, threshold: float = -0.5) -> torch.Tensor:
+    out = torch.empty(n, n, n, device=vt.device)
+    _check(load().vfn_grid_divergence(_ptr(vt, "vt"), C.c_int32(n), C.c_float(threshold), _ptr(out, "out"), _stream()),
+           "vfn_grid_divergence")
+    return out
+
+
+def grid_smooth_axis(src: torch.Tensor, dst: torch.Tensor, n: int, axis: int, weights: Sequence[float]) -> None:
+    w = (C.c_float * len(weights))(*[float(x) for x in weights])
+    _check(load().vfn_grid_smooth_axis(_ptr(src, "in"), _ptr(dst, "out"), C.c_int32(n), C.c_int32(axis), w,
+                                       C.c_int32(len(weights)), _stream()), "vfn_grid_smooth_axis")
+
+
+def grid_unify_direction(divergence: torch.Tensor, vt: torch.Tensor, n: int) -> torch.Tensor:
+    choice = torch.empty(n * n * n, 8, dtype=torch.int64, device=vt.device)
+    _check(load().vfn_grid_unify_direction(_ptr(divergence, "divergence"), _ptr(vt, "vt"), C.c_int32(n),
+                                           _ptr(choice, "choice", torch.int64), _stream()), "vfn_grid_unify_direction")
+    return choice
+
+
+def grid_comb_format(choice: torch.Tensor, norms: torch.Tensor, n: int):
+    dev = norms.device
+    different = torch.empty(n * n * n, 28, device=dev)
+    pair_norms = torch.empty(n * n * n, 28, 2, device=dev)
+    _check(load().vfn_grid_comb_format(_ptr(choice, "choice", torch.int64), _ptr(norms, "norms"), C.c_int32(n),
+                                       _ptr(different, "different_side"), _ptr(pair_norms, "pair_norms"), _stream()),
+           "vfn_grid_comb_format")
+    return different, pair_norms
