@@ -385,3 +385,14 @@ def test_grid_stages_on_hip():
     assert float((div != want).float().mean()) < 1e-3
     with pytest.raises(Exception):
         grid.extract_divergence(pred, n)      # host tensors are refused: no CPU fallback
+
+
+def test_shared_pose_and_intrinsics():
+    """One pose / intrinsics matrix per image instead of the per-ray replicas the reference's datasets upload."""
+    fx, d = load_fixture("c1_det")
+    model = build_model(fx, d, device="cuda:0")
+    g = {k: v.to(dev()) for k, v in d.items() if isinstance(v, torch.Tensor)}
+    with torch.no_grad():
+        a = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms={"u_add": g["u_add"]})
+        b = model.render(g["pose"][0], g["uv"], g["intrinsics"][:1], epoch=0, uniforms={"u_add": g["u_add"]})
+    assert torch.equal(a.coarse_rgb_values, b.coarse_rgb_values) and torch.equal(a.z_vals, b.z_vals)

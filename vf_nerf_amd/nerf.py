@@ -253,6 +253,18 @@ class VectorFieldNerf:
     def _rays(self, pose, pixels, intrinsics, u_coarse):
         far, far_t = self._far_args(self.ray_sampler.far)
         s_c = self.ray_sampler.N_samples
+        n = pixels.shape[0]
+        # the reference's datasets replicate the image's pose and intrinsics per ray (128 B/ray of upload,
+        # replica_dataset.py:146-212); one copy per image ([4,4] / [7] / leading dimension 1) is accepted as well and
+        # replicated here, on the device
+        if pose.dim() == 1 or (pose.dim() == 2 and pose.shape == (4, 4)):
+            pose = pose.unsqueeze(0)
+        if intrinsics.dim() == 2:
+            intrinsics = intrinsics.unsqueeze(0)
+        if pose.shape[0] == 1 and n != 1:
+            pose = pose.expand(n, *pose.shape[1:])
+        if intrinsics.shape[0] == 1 and n != 1:
+            intrinsics = intrinsics.expand(n, 4, 4)
         return lib.raygen_uniform(pixels.float().contiguous(), pose.float().contiguous(),
                                   intrinsics.float().contiguous(), self._linspace(s_c, pose.device), s_c,
                                   self.ray_sampler.near, far, far_t, u_coarse)
@@ -262,7 +274,8 @@ class VectorFieldNerf:
     # ---------------------------------------------------------------------------------------------
     def render(self, pose: torch.Tensor, pixels: torch.Tensor, intrinsics: torch.Tensor, epoch: int,
                white: bool = False, uniforms: Optional[Dict[str, torch.Tensor]] = None) -> NerfOutput:
-        """pose[N,4,4]|[N,7], pixels[N,2] (u,v), intrinsics[N,4,4] -> NerfOutput (vector_field_nerf.py:216-338).
+        """pose[N,4,4]|[N,7], pixels[N,2] (u,v), intrinsics[N,4,4] -> NerfOutput (vector_field_nerf.py:216-338); a single
+        pose / intrinsics for the whole batch ([4,4], [7], or leading dimension 1) is accepted too.
 
         ``uniforms`` optionally supplies the three torch.rand draws of the reference in call order
         (``u_coarse[N,S_c]``, ``u_fine[N,N_f]``, ``u_add[N,N_f]``); otherwise the device Philox stream is used."""
