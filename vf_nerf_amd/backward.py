@@ -56,8 +56,7 @@ def _entries(net) -> List[dict]:
 
 
 def _packed_bwd(net) -> torch.Tensor:
-    tensors = [t for d in net._layer_tensors() for t in d.values()]
-    key = tuple((t.data_ptr(), t._version) for t in tensors)
+    tensors, key = net._pack_key()
     dev = tensors[0].device
     cache = getattr(net, "_packed_bwd_cache", None)
     if cache is None or cache[0] != key or cache[1].device != dev:
@@ -73,8 +72,7 @@ def _packed_bwd(net) -> torch.Tensor:
 
 def _packed_bwd16(net) -> torch.Tensor:
     """Transposed bf16-split pack for the bf16 dX chain (csrc/vfn_bwd16.hip), cached on the parameter versions."""
-    tensors = [t for d in net._layer_tensors() for t in d.values()]
-    key = tuple((t.data_ptr(), t._version) for t in tensors)
+    tensors, key = net._pack_key()
     dev = tensors[0].device
     cache = getattr(net, "_packed_bwd16_cache", None)
     if cache is None or cache[0] != key or cache[1].device != dev:

@@ -71,10 +71,26 @@ class _PackedMLP(nn.Module):
                 [self._bn(i) is not None for i in range(self.num_layers)])
         return self._geom
 
+    def _apply(self, fn, *args, **kwargs):
+        """.to() / .cuda() / .float() replace buffer tensors: drop the cached tensor list and the packs built from it."""
+        out = super()._apply(fn, *args, **kwargs)
+        for name in ("_pack_tensors", "_packed16_cache", "_packed_bwd_cache", "_packed_bwd16_cache"):
+            if hasattr(self, name):
+                delattr(self, name)
+        self._packed, self._packed_key = None, None
+        return out
+
+    def _pack_key(self):
+        """(data_ptr, version) of every tensor the packs are built from; the tensor list itself is collected once (the
+        module tree is fixed after construction — walking it on every call costs more than a kernel launch)."""
+        tensors = getattr(self, "_pack_tensors", None)
+        if tensors is None:
+            tensors = self._pack_tensors = [t for d in self._layer_tensors() for t in d.values()]
+        return tensors, tuple([(t.data_ptr(), t._version) for t in tensors])
+
     def packed_weights(self) -> torch.Tensor:
         """Packed (BN-folded, fragment-ordered) weights for the current parameter values."""
-        tensors = [t for d in self._layer_tensors() for t in d.values()]
-        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        tensors, key = self._pack_key()
         dev = tensors[0].device
         if self._packed is None or self._packed.device != dev or key != self._packed_key:
             geom = self.geometry()
@@ -87,9 +103,8 @@ class _PackedMLP(nn.Module):
         return self._packed
 
     def packed16_weights(self) -> torch.Tensor:
-        """f16x3 pack (hi/lo halves, 2^6 scale, fragment order) for the current parameter values."""
-        tensors = [t for d in self._layer_tensors() for t in d.values()]
-        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        """f16x3 pack (hi/lo halves, fragment order) for the current parameter values."""
+        tensors, key = self._pack_key()
         dev = tensors[0].device
         cache = getattr(self, "_packed16_cache", None)
         if cache is None or cache[0] != key or cache[1].device != dev:
