@@ -122,13 +122,23 @@ def _n_layers(sd: Dict[str, Tensor]) -> int:
     return max(idx) + 1
 
 
-def _layer_eval(sd: Dict[str, Tensor], i: int, x: Tensor) -> Tensor:
-    """Linear (+ BatchNorm1d with running statistics, eps 1e-5) of layer i."""
+def _layer_eval(sd: Dict[str, Tensor], i: int, x: Tensor, train: bool = False) -> Tensor:
+    """Linear (+ BatchNorm1d, eps 1e-5) of layer i.  Eval mode normalises with the running statistics.  ``train`` is
+    nn.BatchNorm1d in training mode (the state of the modules after ``VectorFieldNerf.train()``,
+    vector_field_nerf.py:139-150): the batch mean and the biased batch variance over the rows of this call normalise, and
+    the running statistics in ``sd`` are updated IN PLACE with momentum 0.1 (the unbiased variance goes into
+    running_var) and ``num_batches_tracked`` advances, as torch does."""
     if f'layers.{i}.0.weight' in sd:  # nn.Sequential(Linear, BatchNorm1d)
         y = F.linear(x, sd[f'layers.{i}.0.weight'], sd[f'layers.{i}.0.bias'])
         if f'layers.{i}.1.running_mean' in sd:
-            y = F.batch_norm(y, sd[f'layers.{i}.1.running_mean'], sd[f'layers.{i}.1.running_var'],
-                             sd[f'layers.{i}.1.weight'], sd[f'layers.{i}.1.bias'], False, 0.0, 1e-5)
+            if train:      # y_hat = (y - mean_batch) / sqrt(var_batch_biased + eps); running stats <- 0.9 old + 0.1 batch (unbiased var)
+                y = F.batch_norm(y, sd[f'layers.{i}.1.running_mean'], sd[f'layers.{i}.1.running_var'],
+                                 sd[f'layers.{i}.1.weight'], sd[f'layers.{i}.1.bias'], True, 0.1, 1e-5)
+                if f'layers.{i}.1.num_batches_tracked' in sd:
+                    sd[f'layers.{i}.1.num_batches_tracked'] += 1
+            else:
+                y = F.batch_norm(y, sd[f'layers.{i}.1.running_mean'], sd[f'layers.{i}.1.running_var'],
+                                 sd[f'layers.{i}.1.weight'], sd[f'layers.{i}.1.bias'], False, 0.0, 1e-5)
         return y
     return F.linear(x, sd[f'layers.{i}.weight'], sd[f'layers.{i}.bias'])
 
@@ -144,7 +154,7 @@ def _relu(x: Tensor, masks: Optional[list]) -> Tensor:
 
 
 def vf_mlp(points: Tensor, sd: Dict[str, Tensor], multires: int = 6, skip_in=(4,), hidden: Optional[list] = None,
-           masks: Optional[list] = None) -> Tensor:
+           masks: Optional[list] = None, train: bool = False) -> Tensor:
     """[M,3] -> [M, 3 + F] (cols 0:3 vector after tanh, 3: features after tanh).
     vector_field_network.py:177-208: skip layers see cat([x, pe]) / sqrt(2); ReLU between
     layers, tanh on the last.  ``hidden`` (a list) receives every post-ReLU activation (tests use it to
@@ -156,21 +166,36 @@ def vf_mlp(points: Tensor, sd: Dict[str, Tensor], multires: int = 6, skip_in=(4,
     for i in range(n):
         if i in skip_in:
             x = torch.cat([x, pe], 1) / inv
-        x = _layer_eval(sd, i, x)
+        x = _layer_eval(sd, i, x, train)
         x = _relu(x, masks) if i < n - 1 else torch.tanh(x)
         if hidden is not None and i < n - 1:
             hidden.append(x.detach())
     return x
 
 
+def vf_mlp_train(points: Tensor, sd: Dict[str, Tensor], multires: int = 6, skip_in=(4,), masks: Optional[list] = None) -> Tensor:
+    """Train-mode forward of the VF net (vector_field_network.py:146-173): [M,3] -> [M, 3 + F + 9].  Batch-statistics
+    BatchNorm, then one ``autograd.grad`` per vector column with ``grad_outputs = 1`` for every row, concatenated as
+    [d y0 / d p, d y1 / d p, d y2 / d p].  With batch statistics the rows are coupled, so row m of that "Jacobian" is
+    sum_r d y_c[r] / d p[m] — the backward of train-mode BatchNorm, not the per-row Jacobian of an eval-mode net.
+    ``points`` gets requires_grad in place, as the reference does; the running statistics in ``sd`` advance once."""
+    with torch.enable_grad():
+        points.requires_grad_(True)
+        y = vf_mlp(points, sd, multires, skip_in, masks=masks, train=True)
+        ones = torch.ones_like(y[:, 0])
+        rows = [torch.autograd.grad(y[:, c], points, ones, create_graph=True, retain_graph=True)[0] for c in range(3)]
+        return torch.cat([y] + rows, dim=-1)
+
+
 def render_mlp(points: Tensor, normals: Tensor, view_dirs: Tensor, feats: Tensor,
-               sd: Dict[str, Tensor], multires: int = 4, hidden: Optional[list] = None, masks: Optional[list] = None) -> Tensor:
+               sd: Dict[str, Tensor], multires: int = 4, hidden: Optional[list] = None, masks: Optional[list] = None,
+               train: bool = False) -> Tensor:
     """mode 'idr' (rendering_network.py:84-86): cat[p, PE(d), n, feat] -> ReLU MLP -> sigmoid."""
     d = positional_encoding(view_dirs, multires) if multires > 0 else view_dirs
     x = torch.cat([points, d, normals, feats], dim=-1)
     n = _n_layers(sd)
     for i in range(n):
-        x = _layer_eval(sd, i, x)
+        x = _layer_eval(sd, i, x, train)
         if i < n - 1:
             x = _relu(x, masks)
             if hidden is not None:
@@ -308,6 +333,7 @@ class RenderSettings:
     fine_range: float = 0.3
     perturb: bool = False
     numerical_jacobian: bool = False   # vector_field_nerf.py:258-262,299-301
+    train_mode: bool = False           # networks after VectorFieldNerf.train(): batch-statistics BatchNorm, Jacobian columns
     n_window: int = 11
     dir_to_normal_th: float = -2.0
     normalize: bool = True
@@ -337,16 +363,20 @@ def render(uv: Tensor, pose: Tensor, intrinsics: Tensor, vf_sd: Dict[str, Tensor
     pts_c = points_along_rays(cam_loc, directions, z_c)
     out.update(z_coarse=z_c, points_coarse=pts_c)
 
+    vf_call = (lambda q, **kw: vf_mlp_train(q, vf_sd, cfg.vf_multires, cfg.vf_skip_in, masks=kw.get("masks"))) if cfg.train_mode \
+        else (lambda q, **kw: vf_mlp(q, vf_sd, cfg.vf_multires, cfg.vf_skip_in, **kw))
+    nf = 3 + cfg.feature_dims
     with torch.no_grad():
-        vf_c = vf_mlp(pts_c.reshape(-1, 3), vf_sd, cfg.vf_multires, cfg.vf_skip_in)
+        vf_c = vf_call(pts_c.reshape(-1, 3))          # train mode: enable_grad inside, the result is used without grad
         nrm_c = vf_c[:, :3].reshape(n, cfg.n_samples, 3)
         sigma_c, cos_c, cosray_c = ray_density(nrm_c, ray_dirs, cfg.n_window, cfg.dir_to_normal_th, cfg.density,
                                                beta, mean, scale, return_parts=True)
         w_c = volsdf_weights(z_c, sigma_c, cfg.normalize)
         dd_c = None
         if cfg.numerical_jacobian:
-            dd_c = numerical_directional_derivatives(pts_c.reshape(-1, 3), vf_c[:, :3],
-                                                     lambda q: vf_mlp(q, vf_sd, cfg.vf_multires, cfg.vf_skip_in), fine=False).reshape(-1, 3)
+            dd_c = numerical_directional_derivatives(pts_c.reshape(-1, 3), vf_c[:, :3], vf_call, fine=False).reshape(-1, 3)
+        elif cfg.train_mode:       # vector_field_nerf.py:260-261
+            dd_c = directional_derivatives(vf_c[:, :3], vf_c[:, nf:nf + 9]).reshape(-1, 3)
     out.update(normals_coarse=nrm_c, window_cos_coarse=cos_c, cos_ray_coarse=cosray_c,
                sigma_coarse=sigma_c, weights_coarse=w_c)
 
@@ -359,7 +389,8 @@ def render(uv: Tensor, pose: Tensor, intrinsics: Tensor, vf_sd: Dict[str, Tensor
     s_t = cfg.n_samples + cfg.n_fine
     out.update(max_indices=imax, z_vals=z_f, points=pts_f)
 
-    vf_f = vf_mlp(pts_f.reshape(-1, 3), vf_sd, cfg.vf_multires, cfg.vf_skip_in, hidden=hidden, masks=masks)
+    vf_f = vf_call(pts_f.reshape(-1, 3), masks=masks) if cfg.train_mode else \
+        vf_mlp(pts_f.reshape(-1, 3), vf_sd, cfg.vf_multires, cfg.vf_skip_in, hidden=hidden, masks=masks)
     nrm_flat = vf_f[:, :3]
     feats = vf_f[:, 3:3 + cfg.feature_dims]
     nrm_f = nrm_flat.reshape(n, s_t, 3)
@@ -368,13 +399,14 @@ def render(uv: Tensor, pose: Tensor, intrinsics: Tensor, vf_sd: Dict[str, Tensor
     w_f = volsdf_weights(z_f, sigma_f, cfg.normalize)
     rep_dirs = ray_dirs.unsqueeze(1).repeat(1, s_t, 1).reshape(-1, 3)
     colors = render_mlp(pts_f.reshape(-1, 3), nrm_flat.detach(), rep_dirs, feats, rn_sd, cfg.render_multires, hidden=hidden,
-                        masks=masks)
+                        masks=masks, train=cfg.train_mode)
     rgb = torch.sum(w_f.unsqueeze(-1) * colors.reshape(n, s_t, 3), dim=1)
     depth = torch.sum(w_f.unsqueeze(-1) * z_f.unsqueeze(-1), dim=1)
     if cfg.numerical_jacobian:
-        dd_f = numerical_directional_derivatives(pts_f.reshape(-1, 3), nrm_flat,
-                                                 lambda q: vf_mlp(q, vf_sd, cfg.vf_multires, cfg.vf_skip_in), fine=True).reshape(-1, 3)
+        dd_f = numerical_directional_derivatives(pts_f.reshape(-1, 3), nrm_flat, vf_call, fine=True).reshape(-1, 3)
         out["directional_derivatives"] = torch.cat([dd_c, dd_f], dim=0).norm(dim=-1)
+    elif cfg.train_mode:           # vector_field_nerf.py:303-305: the fine-pass values are computed and dropped (Q10)
+        out["directional_derivatives"] = torch.cat([dd_c, dd_c], dim=0).norm(dim=-1)
     out.update(vf_out=vf_f, normals=nrm_f, window_cos=cos_f, cos_ray=cosray_f, sigma=sigma_f, weights=w_f,
                colors=colors, rgb=rgb, depth=depth, ray_dirs_repeated=rep_dirs)
     return out

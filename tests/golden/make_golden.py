@@ -50,6 +50,11 @@ FIXTURES = {
     "numjac_det": dict(seed=5, gain=2.0, n_rays=10, n_samples=14, n_importance=9, perturb=False, th=-0.2, n_window=5,
                        near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=9, pose="identity",
                        skew=0.0, far_per_ray=False, numjac=True),
+    # networks in TRAIN mode (model.train(), vector_field_nerf.py:139-150): batch-statistics BatchNorm in both nets, the VF
+    # forward appends the three autograd.grad rows, analytic directional derivatives (:260-261,303-305,476-498)
+    "train_mode": dict(seed=6, gain=2.0, n_rays=12, n_samples=16, n_importance=10, perturb=True, th=-0.2, n_window=5,
+                       near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=11, pose="identity",
+                       skew=0.0, far_per_ray=False, train=True),
     "w1_det": dict(seed=4, gain=2.0, n_rays=16, n_samples=20, n_importance=12, perturb=False, th=-2.0, n_window=1,
                    near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=7, pose="identity",
                    skew=0.0, far_per_ray=False),
@@ -241,6 +246,59 @@ def capture_grads(fx, model, data):
     return g
 
 
+BN_KEYS = (("vf", 0), ("vf", 3), ("vf", 7), ("rn", 0), ("rn", 3))
+
+
+def capture_train(fx, model):
+    """One render() of the reference with the networks in train mode, gradients enabled: draws, the two VF outputs
+    ([M,268]), outputs, gradients of the fixed functional, and the BatchNorm running statistics afterwards (each VF
+    BatchNorm has seen two batches, each rendering-net BatchNorm one)."""
+    model.train()
+    assert model.vector_field_network.training and model.rendering_network.training
+    uv, pose, K = synthetic.pinhole_batch(fx["n_rays"], fx["width"], fx["height"], fx["focal"], fx["cam_seed"], skew=fx["skew"])
+    rec = {"rand": [], "vf": [], "colors": []}
+    real_rand = torch.rand
+
+    def rand_spy(*a, **k):
+        out = real_rand(*a, **k)
+        rec["rand"].append(out.clone())
+        return out
+
+    h1 = model.vector_field_network.register_forward_hook(lambda m, i, o: rec["vf"].append(o.detach().clone()))
+    h2 = model.rendering_network.register_forward_hook(lambda m, i, o: rec["colors"].append(o.detach().clone()))
+    torch.rand = rand_spy
+    try:
+        torch.manual_seed(1000 + fx["seed"])
+        for p in model.parameters():
+            p.grad = None
+        out = model.render(pose, uv, K, epoch=0)
+    finally:
+        torch.rand = real_rand
+        h1.remove()
+        h2.remove()
+    assert len(rec["rand"]) == 3 and len(rec["vf"]) == 2 and rec["vf"][0].shape[1] == 268
+    assert not out.directional_derivtives.requires_grad       # computed under no_grad: the loss term has no gradient
+    d = {"uv": uv, "pose": pose, "intrinsics": K, "u_coarse": rec["rand"][0], "u_fine": rec["rand"][1], "u_add": rec["rand"][2],
+         "vf_out_coarse": rec["vf"][0], "vf_out": rec["vf"][1], "z_vals": out.z_vals, "points": out.points_coarse,
+         "normals": out.coarse_normals.detach(), "colors": out.coarse_colors.detach(), "rgb": out.coarse_rgb_values.detach(),
+         "depth": out.coarse_depth_map.detach(), "directional_derivatives": out.directional_derivtives}
+    a, b, c = loss_coefficients(*out.z_vals.shape)
+    loss = (out.coarse_rgb_values * a).sum() + (out.coarse_depth_map * b).sum() + (out.coarse_normals * c).sum()
+    loss.backward()
+    nets = {"vf": model.vector_field_network, "rn": model.rendering_network}
+    for net, key in GRAD_KEYS:
+        d[f"grad.{net}.{key}"] = dict(nets[net].named_parameters())[key].grad.clone()
+    for name, p in model.density.named_parameters():
+        d[f"grad.density.{name}"] = p.grad.clone().reshape(1)
+    d["loss"] = loss.detach().reshape(1)
+    for net, i in BN_KEYS:
+        bn = nets[net].layers[i][1]
+        d[f"bn.{net}.{i}.running_mean"] = bn.running_mean.clone()
+        d[f"bn.{net}.{i}.running_var"] = bn.running_var.clone()
+        d[f"bn.{net}.{i}.num_batches_tracked"] = bn.num_batches_tracked.clone().reshape(1)
+    return d
+
+
 def main() -> None:
     torch.set_num_threads(8)
     only = set(sys.argv[1:])          # optional: fixture names to (re)generate
@@ -249,12 +307,15 @@ def main() -> None:
             continue
         model = build_reference_model(fx)
         own_model_matches(fx, model)
-        data, model = capture(fx, model)
-        data.update(capture_grads(fx, model, data))
         head = model.vector_field_network.layers[8]
         chk = synthetic.weights_checksum({"vf": model.vector_field_network.state_dict(),
                                           "rn": model.rendering_network.state_dict(),
                                           "density": model.density.state_dict()})
+        if fx.get("train"):
+            data = capture_train(fx, model)
+        else:
+            data, model = capture(fx, model)
+            data.update(capture_grads(fx, model, data))
         arrays = {k: v.detach().cpu().numpy() for k, v in data.items()}
         arrays["head_weight"] = head.weight[:3].detach().numpy()
         arrays["head_bias"] = head.bias[:3].detach().numpy()
@@ -262,6 +323,10 @@ def main() -> None:
         arrays["fixture"] = np.array(repr(fx))
         path = os.path.join(HERE, f"{name}.npz")
         np.savez_compressed(path, **arrays)
+        if fx.get("train"):
+            print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); rays with colour: "
+                  f"{float((data['rgb'].abs().sum(-1) > 1e-3).float().mean()):.2f}")
+            continue
         nz = float((data["weights"].sum(-1) > 0.5).float().mean())
         print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); rays with surface hits: {nz:.2f}; "
               f"argmax>0: {float((data['max_indices'] > 0).float().mean()):.2f}")

@@ -58,7 +58,7 @@ def build_model(fx: dict, data: Dict[str, torch.Tensor], device="cpu") -> "vf_ne
 
 def oracle_settings(fx: dict):
     from oracle import vfnerf_oracle as O
-    return O.RenderSettings(numerical_jacobian=bool(fx.get("numjac", False)), n_samples=fx["n_samples"], n_fine=fx["n_importance"], near=fx["near"], far=fx["far"],
+    return O.RenderSettings(numerical_jacobian=bool(fx.get("numjac", False)), train_mode=bool(fx.get("train", False)), n_samples=fx["n_samples"], n_fine=fx["n_importance"], near=fx["near"], far=fx["far"],
                             fine_range=fx["fine_range"], perturb=fx["perturb"], n_window=fx["n_window"],
                             dir_to_normal_th=fx["th"], normalize=True,
                             density=O.DensityParams(beta=0.5, mean=0.7, scale=100.0, beta_bounds=(1e-4, 1e9),
@@ -114,4 +114,6 @@ def oracle_gradients(fx, d, model, masks=None):
     grads = {k: v.grad for k, v in leaves.items()}
     grads.update({"density.beta": beta.grad, "density.mean": mean.grad, "density.scale": scale.grad})
     grads["_hidden"] = hidden     # 8 VF + 4 rendering post-ReLU activations [M, width]
+    grads["_out"] = out           # every stage of the oracle's forward
+    grads["_state"] = {"vf": vf_sd, "rn": rn_sd}      # train mode: running statistics advanced in place
     return float(loss), grads

@@ -3,7 +3,7 @@
 import pytest
 import torch
 
-from helpers import FIXTURE_NAMES, build_model, load_fixture, oracle_settings
+from helpers import FIXTURE_NAMES, GRAD_KEYS, build_model, grad_rel_err, load_fixture, oracle_gradients, oracle_settings
 from oracle import vfnerf_oracle as O
 
 
@@ -118,3 +118,37 @@ def test_grid_stages_oracle_vs_reference_golden():
         assert torch.equal(choice, g[f"n{n}.choice"])
         comb, pair_norms = O.grid_comb_format(choice, torch.norm(pred, dim=1), n)
         assert torch.equal(comb, g[f"n{n}.comb"]) and torch.equal(pair_norms, g[f"n{n}.pair_norms"])
+
+
+def test_train_mode_matches_reference():
+    """Networks in train mode (model.train(), vector_field_nerf.py:139-150): batch-statistics BatchNorm in both nets, the
+    VF forward's three autograd.grad rows, analytic directional derivatives (coarse values twice, Q10), gradients through the
+    batch statistics, running statistics after two VF batches / one rendering-net batch."""
+    fx, d = load_fixture("train_mode")
+    model = build_model(fx, d)
+    loss, g = oracle_gradients(fx, d, model)
+    out = g["_out"]
+    assert torch.equal(out["z_vals"], d["z_vals"]) and torch.equal(out["points"], d["points"])
+    for k in ("normals", "colors", "rgb", "depth"):
+        assert float((out[k].reshape(d[k].shape) - d[k]).abs().max()) <= 2e-6, k
+    assert float((out["vf_out"][:, :259] - d["vf_out"][:, :259]).abs().max()) <= 2e-6
+    jac, want = out["vf_out"][:, 259:].detach(), d["vf_out"][:, 259:]
+    assert jac.shape == want.shape == (d["z_vals"].numel(), 9)
+    assert float((jac - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    dd, dd_want = out["directional_derivatives"], d["directional_derivatives"]
+    assert dd.shape == dd_want.shape and float((dd - dd_want).abs().max()) <= 2e-5 * float(dd_want.abs().max())
+    assert abs(loss - float(d["loss"])) <= 1e-5 * max(1.0, abs(float(d["loss"])))
+    for net, key in GRAD_KEYS:
+        want = d[f"grad.{net}.{key}"]
+        if key.endswith(".0.bias"):        # Linear bias in front of batch statistics: the gradient is exactly 0 up to rounding
+            assert float(g[f"{net}.{key}"].abs().max()) <= 1e-4 and float(want.abs().max()) <= 1e-4
+            continue
+        assert grad_rel_err(g[f"{net}.{key}"], want) <= 2e-4, (net, key, grad_rel_err(g[f"{net}.{key}"], want))
+    for name in ("beta", "mean", "scale"):
+        assert grad_rel_err(g[f"density.{name}"].reshape(1), d[f"grad.density.{name}"]) <= 2e-4, name
+    for net, i in (("vf", 0), ("vf", 3), ("vf", 7), ("rn", 0), ("rn", 3)):
+        sd = g["_state"][net]
+        for stat in ("running_mean", "running_var"):
+            got, want = sd[f"layers.{i}.1.{stat}"], d[f"bn.{net}.{i}.{stat}"]
+            assert float((got - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max())), (net, i, stat)
+        assert int(sd[f"layers.{i}.1.num_batches_tracked"]) == int(d[f"bn.{net}.{i}.num_batches_tracked"])
