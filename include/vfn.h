@@ -346,6 +346,57 @@ int vfn_grid_unify_direction(const float* divergence, const float* vt, int32_t n
 int vfn_grid_comb_format(const int64_t* choice, const float* norms, int32_t n, float* different_side, float* pair_norms,
                          void* stream);
 
+/* =============================================================================================
+ * Networks in TRAINING mode: nn.BatchNorm1d with batch statistics (vector_field_network.py:146-208 and
+ * rendering_network.py:62-108 after VectorFieldNerf.train(), vector_field_nerf.py:139-150; the trainer enters it when the
+ * directional-derivative loss weight is non-zero, train/vector_field_nerf_train.py:140-141).  Batch statistics couple all
+ * rows of a layer, so the layers run one launch at a time on row-major fp32 matrices in HBM.  Leading dimensions are
+ * multiples of 4 floats, rows 16-byte aligned, pad columns hold zeros.
+ * ============================================================================================= */
+/* transpose_w = 0: C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]), W = nn.Linear weight [n_out][ldw], k_in columns
+ *                  (torch.nn.functional.linear); act 0 none / 1 tanh / 2 sigmoid.
+ * transpose_w = 1: C[m][j] = sum_k A[m][k] W[k][j], W [k_in][ldw], j < n_out  (the input gradient dX = dZ W).
+ * A is read over k rounded up to a multiple of 8 (lda must cover it, pad columns zero).  Exact fp32 (v_mfma_f32_32x32x2f32).
+ * stats_part (or NULL): [vfn_linear_rows_stat_parts(m)][2][n_out] per-workgroup column sums of the pre-activation z and
+ * of z^2 — the batch statistics, finished by vfn_colsum_finish. */
+int vfn_linear_rows(int32_t transpose_w, const float* a, int32_t lda, const float* w, int32_t ldw, const float* bias,
+                    int64_t m, int32_t n_out, int32_t k_in, int32_t act, float* c, int32_t ldc, float* stats_part,
+                    void* stream);
+int64_t vfn_linear_rows_stat_parts(int64_t m);
+/* Partials per workgroup of the row-wise kernels below (vfn_bstat_relu_bwd_sums). */
+int64_t vfn_bstat_row_parts(int64_t m);
+/* part[n_parts][width] fp32 -> sums[width] double. */
+int vfn_colsum_finish(const float* part, int64_t n_parts, int32_t width, double* sums, void* stream);
+/* sums[2][n] (sum z, sum z^2 over m rows) -> coef[4][n] = scale (gamma rstd), shift (beta - mean scale), mean, rstd with
+ * rstd = 1 / sqrt(biased variance + eps); running_mean / running_var (may be NULL) <- (1 - momentum) old + momentum batch,
+ * the variance unbiased (m / (m - 1)), as torch.nn.BatchNorm1d does in training mode. */
+int vfn_bstat_finalize(const double* sums, int64_t m, int32_t n, const float* gamma, const float* beta, float eps,
+                       float momentum, float* running_mean, float* running_var, float* coef, void* stream);
+/* h[m][c] = post_scale * relu(z[m][c] * scale[c] + shift[c]), c < n. */
+int vfn_bstat_relu_rows(const float* z, int32_t ldz, const float* coef, int64_t m, int32_t n, float post_scale, float* h,
+                        int32_t ldh, void* stream);
+/* Backward of the above through the batch statistics.  g = gradient wrt h.  With g' = post_scale g [h > 0] and
+ * x_hat = (z - mean) rstd:  part[vfn_bstat_row_parts(m)][2][n] = per-workgroup sums of g' and g' x_hat (= d beta, d gamma
+ * after vfn_colsum_finish);  dz = gamma rstd (g' - sum g' / m - x_hat sum(g' x_hat) / m). */
+int vfn_bstat_relu_bwd_sums(const float* g, int32_t ldg, const float* h, int32_t ldh, const float* z, int32_t ldz,
+                            const float* coef, int64_t m, int32_t n, float post_scale, float* part, void* stream);
+int vfn_bstat_relu_bwd_rows(const float* g, int32_t ldg, const float* h, int32_t ldh, const float* z, int32_t ldz,
+                            const float* coef, const double* sums, int64_t m, int32_t n, float post_scale, float* dz,
+                            int32_t lddz, void* stream);
+/* dz = dy (1 - y^2) (act 1, tanh) or dy y (1 - y) (act 2, sigmoid) or dy (act 0).  dy == NULL: dy is 1 in column
+ * onehot_col and 0 elsewhere — the grad_outputs of the three autograd.grad calls of vector_field_network.py:150-171. */
+int vfn_act_bwd_rows(int32_t act, const float* dy, int32_t lddy, const float* y, int32_t ldy, int64_t m, int32_t n,
+                     int32_t onehot_col, float* dz, int32_t lddz, void* stream);
+/* dst[row][col0 + j] = scale * PE(src3[row / rows_per_src])[j], j < 3 + 6 multires (models/helpers/embedder.py:11-37;
+ * multires 0 copies the 3 values). */
+int vfn_embed_rows(const float* src3, int32_t ld_src, int32_t rows_per_src, int64_t m, int32_t multires, float scale,
+                   float* dst, int32_t ld_dst, int32_t col0, void* stream);
+/* d_src3[m][3] (+)= sum over the (up to two) places the encoding was used of scale * dPE/dx applied to the gradient
+ * rows d[row][col..col+3+6 multires) (d_b may be NULL). */
+int vfn_embed_rows_bwd(const float* src3, int64_t m, int32_t multires, const float* d_a, int32_t ld_a, int32_t col_a,
+                       float scale_a, const float* d_b, int32_t ld_b, int32_t col_b, float scale_b, float* d_src3,
+                       int32_t accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -173,7 +173,8 @@ def vf_mlp(points: Tensor, sd: Dict[str, Tensor], multires: int = 6, skip_in=(4,
     return x
 
 
-def vf_mlp_train(points: Tensor, sd: Dict[str, Tensor], multires: int = 6, skip_in=(4,), masks: Optional[list] = None) -> Tensor:
+def vf_mlp_train(points: Tensor, sd: Dict[str, Tensor], multires: int = 6, skip_in=(4,), masks: Optional[list] = None,
+                 hidden: Optional[list] = None) -> Tensor:
     """Train-mode forward of the VF net (vector_field_network.py:146-173): [M,3] -> [M, 3 + F + 9].  Batch-statistics
     BatchNorm, then one ``autograd.grad`` per vector column with ``grad_outputs = 1`` for every row, concatenated as
     [d y0 / d p, d y1 / d p, d y2 / d p].  With batch statistics the rows are coupled, so row m of that "Jacobian" is
@@ -181,7 +182,7 @@ def vf_mlp_train(points: Tensor, sd: Dict[str, Tensor], multires: int = 6, skip_
     ``points`` gets requires_grad in place, as the reference does; the running statistics in ``sd`` advance once."""
     with torch.enable_grad():
         points.requires_grad_(True)
-        y = vf_mlp(points, sd, multires, skip_in, masks=masks, train=True)
+        y = vf_mlp(points, sd, multires, skip_in, masks=masks, hidden=hidden, train=True)
         ones = torch.ones_like(y[:, 0])
         rows = [torch.autograd.grad(y[:, c], points, ones, create_graph=True, retain_graph=True)[0] for c in range(3)]
         return torch.cat([y] + rows, dim=-1)
@@ -363,7 +364,8 @@ def render(uv: Tensor, pose: Tensor, intrinsics: Tensor, vf_sd: Dict[str, Tensor
     pts_c = points_along_rays(cam_loc, directions, z_c)
     out.update(z_coarse=z_c, points_coarse=pts_c)
 
-    vf_call = (lambda q, **kw: vf_mlp_train(q, vf_sd, cfg.vf_multires, cfg.vf_skip_in, masks=kw.get("masks"))) if cfg.train_mode \
+    vf_call = (lambda q, **kw: vf_mlp_train(q, vf_sd, cfg.vf_multires, cfg.vf_skip_in, masks=kw.get("masks"),
+                                            hidden=kw.get("hidden"))) if cfg.train_mode \
         else (lambda q, **kw: vf_mlp(q, vf_sd, cfg.vf_multires, cfg.vf_skip_in, **kw))
     nf = 3 + cfg.feature_dims
     with torch.no_grad():
@@ -389,7 +391,7 @@ def render(uv: Tensor, pose: Tensor, intrinsics: Tensor, vf_sd: Dict[str, Tensor
     s_t = cfg.n_samples + cfg.n_fine
     out.update(max_indices=imax, z_vals=z_f, points=pts_f)
 
-    vf_f = vf_call(pts_f.reshape(-1, 3), masks=masks) if cfg.train_mode else \
+    vf_f = vf_call(pts_f.reshape(-1, 3), masks=masks, hidden=hidden) if cfg.train_mode else \
         vf_mlp(pts_f.reshape(-1, 3), vf_sd, cfg.vf_multires, cfg.vf_skip_in, hidden=hidden, masks=masks)
     nrm_flat = vf_f[:, :3]
     feats = vf_f[:, 3:3 + cfg.feature_dims]

@@ -1,0 +1,214 @@
+"""Networks in TRAINING mode on the GPU (``VectorFieldNerf.train()``: batch-statistics BatchNorm, the VF forward's three
+autograd.grad rows, analytic directional derivatives) against the CPU oracle and against vectors the
+reference itself produced (tests/golden/train_mode.npz).  Tolerances are written at each comparison; fp32 throughout."""
+import pytest
+import torch
+
+from helpers import GRAD_KEYS, build_model, grad_rel_err, load_fixture, loss_coefficients, oracle_gradients, rel_err
+from oracle import vfnerf_oracle as O
+from vf_nerf_amd import lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("m,k,n", [(1, 39, 256), (130, 256, 217), (257, 256, 259), (1000, 289, 256), (77, 256, 3), (4096, 256, 256)])
+@pytest.mark.parametrize("transpose", [False, True])
+def test_linear_rows_against_float64(m, k, n, transpose):
+    """C = tanh(A W^T + b) / C = A W on the fp32 matrix cores vs float64 on the CPU: 1e-6 of the largest |z| (products are
+    exact fp32, the sums of k terms round in fp32); column sums of z and z^2 within 1e-5."""
+    torch.manual_seed(m + k + n)
+    kp, ldc = (k + 7) & ~7, (n + 7) & ~7
+    a = torch.zeros(m, kp)
+    a[:, :k] = torch.randn(m, k)
+    w = torch.randn(k, n) if transpose else torch.randn(n, k)
+    b = None if transpose else torch.randn(n)
+    c = torch.full((m, ldc), 7.0, device=DEV)
+    parts = lib.linear_rows_stat_parts(m)
+    part = torch.empty(parts, 2, n, device=DEV)
+    lib.linear_rows(a.to(DEV), w.to(DEV), None if b is None else b.to(DEV), m, n, k, c, act=lib.ACT_NONE if transpose else lib.ACT_TANH,
+                    transpose_w=transpose, stats_part=part)
+    z = a[:, :k].double() @ (w.double() if transpose else w.double().t()) + (0 if b is None else b.double())
+    want = z if transpose else torch.tanh(z)
+    got = c.cpu()
+    assert float((got[:, :n].double() - want).abs().max()) <= 1e-6 * max(1.0, float(z.abs().max()))
+    assert bool((got[:, n:] == 7.0).all()), "columns past n_out must not be written"
+    sums = torch.empty(2 * n, dtype=torch.float64, device=DEV)
+    lib.colsum_finish(part, parts, 2 * n, sums)
+    s = sums.cpu().view(2, n)
+    assert float((s[0] - z.sum(0)).abs().max()) <= 1e-5 * float(z.abs().sum(0).max())
+    assert float((s[1] - (z * z).sum(0)).abs().max()) <= 1e-5 * float((z * z).sum(0).max())
+
+
+def test_embed_rows_and_its_derivative():
+    """Positional encoding rows (and the scaled copy the skip layer reads) bit-match the oracle's; the backward is the
+    analytic derivative (checked against float64 autograd, 1e-5 of the largest entry)."""
+    torch.manual_seed(3)
+    m, L = 300, 6
+    pts = torch.rand(m, 3) * 2 - 1
+    dst = torch.zeros(m, 48, device=DEV)
+    lib.embed_rows(pts.to(DEV), m, L, lib.Cols(dst, 4))
+    want = O.positional_encoding(pts, L)
+    assert float((dst.cpu()[:, 4:43] - want).abs().max()) <= 1e-6
+    assert float(dst.cpu()[:, :4].abs().max()) == 0.0 and float(dst.cpu()[:, 43:].abs().max()) == 0.0
+    ga, gb = torch.randn(m, 40), torch.randn(m, 256)
+    p64 = pts.double().requires_grad_(True)
+    pe = O.positional_encoding(p64, L)
+    (pe * ga[:, :39].double()).sum().backward(retain_graph=True)
+    g1 = p64.grad.clone()
+    p64.grad = None
+    (pe * 0.5 * gb[:, 217:256].double()).sum().backward()
+    d = torch.empty(m, 3, device=DEV)
+    lib.embed_rows_bwd(pts.to(DEV), m, L, ga.to(DEV), 1.0, lib.Cols(gb.to(DEV), 217), 0.5, d)
+    want_d = g1 + p64.grad
+    assert float((d.cpu().double() - want_d).abs().max()) <= 1e-5 * float(want_d.abs().max())
+
+
+def _train_model(fx, d):
+    model = build_model(fx, d, device=DEV)
+    model.train()
+    assert model.vector_field_network.training and model.rendering_network.training
+    return model
+
+
+def test_vf_forward_training_mode_against_oracle_and_reference():
+    """[M, 3 + 256 + 9] of the VF net on the fixture's proposal samples: network columns within 1e-4 (the '1e-4 rel fp32'
+    bar), Jacobian rows within 1e-3 of their largest entry (sums of M per-row terms through 8 BatchNorm backwards), both vs
+    the reference's own output; running statistics after one batch vs the oracle's."""
+    fx, d = load_fixture("train_mode")
+    model = _train_model(fx, d)
+    cpu = build_model(fx, d)
+    sd = {k: v.clone() for k, v in cpu.vector_field_network.state_dict().items()}
+    cfg = O.RenderSettings(n_samples=fx["n_samples"], near=fx["near"], far=fx["far"], perturb=True)
+    directions, _, cam_loc = O.ray_directions(d["uv"], d["pose"], d["intrinsics"])
+    z_c = O.uniform_z_vals(fx["n_rays"], cfg.n_samples, cfg.near, cfg.far, d["u_coarse"])
+    pts = O.points_along_rays(cam_loc, directions, z_c).reshape(-1, 3)
+    orc = O.vf_mlp_train(pts.clone(), sd).detach()       # the oracle on THIS host's CPU (it advances sd's running statistics)
+    want = d["vf_out_coarse"]                            # the reference's output, captured in the build container
+    e_orc = float((orc - want).abs().max() / want.abs().max())
+    print(f"oracle on this host vs reference fixture: {e_orc:.2e}")
+    assert e_orc <= 1e-4
+    got = model.vector_field_network(pts.to(DEV)).detach().cpu()
+    assert got.shape == want.shape == (pts.shape[0], 268)
+    e_net = float((got[:, :259] - want[:, :259]).abs().max())
+    e_jac = float((got[:, 259:] - want[:, 259:]).abs().max()) / float(want[:, 259:].abs().max())
+    print(f"train-mode VF forward: network columns max abs err {e_net:.2e}, Jacobian rows rel err {e_jac:.2e}")
+    assert e_net <= 1e-4 and e_jac <= 1e-3
+    for i in (0, 3, 7):
+        bn = model.vector_field_network.layers[i][1]
+        assert int(bn.num_batches_tracked) == 1
+        for stat in ("running_mean", "running_var"):
+            w = sd[f"layers.{i}.1.{stat}"]
+            assert float((getattr(bn, stat).cpu() - w).abs().max()) <= 1e-5 * max(1.0, float(w.abs().max())), (i, stat)
+
+
+def test_render_training_mode_against_reference():
+    """render() after train(): outputs, directional derivatives (proposal values listed twice, Q10), gradients of the fixed
+    functional through the batch statistics of both networks, running statistics (VF: two batches, rendering net: one) —
+    against what the reference produced for the same draws."""
+    fx, d = load_fixture("train_mode")
+    model = _train_model(fx, d)
+    g = {k: v.to(DEV) for k, v in d.items() if isinstance(v, torch.Tensor)}
+    uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add")}
+    for p in model.unique_parameters():
+        p.grad = None
+    out = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
+    assert torch.equal(out.z_vals.cpu(), d["z_vals"]), "sampling must replay exactly (argmax of the proposal weights)"
+    errs = {}
+    for name, got in (("normals", out.coarse_normals), ("colors", out.coarse_colors), ("rgb", out.coarse_rgb_values),
+                      ("depth", out.coarse_depth_map)):
+        errs[name] = rel_err(got.detach().reshape(d[name].shape), d[name])
+    dd, dd_want = out.directional_derivtives.cpu(), d["directional_derivatives"]
+    assert dd.shape == dd_want.shape and not out.directional_derivtives.requires_grad
+    errs["dd"] = float((dd - dd_want).abs().max()) / float(dd_want.abs().max())
+    print("train-mode render vs reference:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs[k] for k in ("normals", "colors", "rgb", "depth")) <= 1e-4 and errs["dd"] <= 1e-3
+    a, b, c = (t.to(DEV) for t in loss_coefficients(*d["z_vals"].shape))
+    loss = (out.coarse_rgb_values * a).sum() + (out.coarse_depth_map * b).sum() + (out.coarse_normals * c).sum()
+    loss.backward()
+    assert abs(float(loss) - float(d["loss"])) <= 1e-4 * max(1.0, abs(float(d["loss"])))
+    nets = {"vf": model.vector_field_network, "rn": model.rendering_network}
+    worst = 0.0
+    for net, key in GRAD_KEYS:
+        got, want = dict(nets[net].named_parameters())[key].grad.cpu(), d[f"grad.{net}.{key}"]
+        if key.endswith(".0.bias"):          # a bias in front of batch statistics: exactly zero gradient up to rounding
+            assert float(got.abs().max()) <= 1e-4
+            continue
+        e = grad_rel_err(got, want)
+        worst = max(worst, e)
+        assert e <= 2e-3, (net, key, e)
+    for name, p in model.density.named_parameters():
+        e = grad_rel_err(p.grad.cpu().reshape(1), d[f"grad.density.{name}"])
+        worst = max(worst, e)
+        assert e <= 2e-3, (name, e)
+    print(f"train-mode gradients vs reference: worst rel err {worst:.2e}")
+    for net, i in (("vf", 0), ("vf", 3), ("vf", 7), ("rn", 0), ("rn", 3)):
+        bn = nets[net].layers[i][1]
+        assert int(bn.num_batches_tracked) == int(d[f"bn.{net}.{i}.num_batches_tracked"])
+        for stat in ("running_mean", "running_var"):
+            want = d[f"bn.{net}.{i}.{stat}"]
+            assert float((getattr(bn, stat).cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())), (net, i, stat)
+
+
+def test_training_mode_gradients_against_oracle_all_parameters():
+    """Every parameter's gradient (not only the sampled keys of the fixture) vs the oracle's autograd, 2e-3 of each tensor's
+    largest entry.  A pre-activation ~1e-7 from zero may land on either side of the ReLU in two fp32 implementations, and in a
+    312-row batch one such unit moves a layer's gradient by percents: flips are counted, and when there are any the oracle is
+    re-run with THIS implementation's ReLU masks pinned (oracle._relu), as the eval-mode gradient tests do."""
+    fx, d = load_fixture("train_mode")
+    model = _train_model(fx, d)
+    vf, rn = model.vector_field_network, model.rendering_network
+    vf._keep_state = rn._keep_state = True
+    g = {k: v.to(DEV) for k, v in d.items() if isinstance(v, torch.Tensor)}
+    out = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms={k: g[k] for k in ("u_coarse", "u_fine", "u_add")})
+    a, b, c = (t.to(DEV) for t in loss_coefficients(*d["z_vals"].shape))
+    loss = (out.coarse_rgb_values * a).sum() + (out.coarse_depth_map * b).sum() + (out.coarse_normals * c).sum()
+    loss.backward()
+    ref_loss, ref = oracle_gradients(fx, d, build_model(fx, d))
+    masks = []
+    for net in (vf, rn):
+        st = net._debug_state
+        for i in range(1, net.num_layers):
+            width = net._linear(i - 1).out_features
+            masks.append((st.x[i][:, :width] > 0).cpu())
+    flips = sum(int((mk != (act > 0)).sum()) for mk, act in zip(masks, ref["_hidden"]))
+    print(f"train mode: ReLU sign flips between HIP and CPU activations: {flips} of {sum(mk.numel() for mk in masks)}")
+    assert len(masks) == len(ref["_hidden"]) == 12 and flips <= 8
+    if flips:
+        ref_loss, ref = oracle_gradients(fx, d, build_model(fx, d), masks=masks)
+    assert abs(float(loss) - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss))
+    worst = ("", 0.0)
+    for tag, net in (("vf", vf), ("rn", rn)):
+        for name, p in net.named_parameters():
+            want = ref[f"{tag}.{name}"]
+            if float(want.abs().max()) <= 1e-5:      # Linear biases in front of BatchNorm: zero
+                assert float(p.grad.abs().max()) <= 1e-4, (tag, name)
+                continue
+            e = grad_rel_err(p.grad, want)
+            worst = max(worst, (f"{tag}.{name}", e), key=lambda t: t[1])
+            assert e <= 2e-3, (tag, name, e)
+    for name, p in model.density.named_parameters():
+        assert grad_rel_err(p.grad.reshape(1), ref[f"density.{name}"].reshape(1)) <= 2e-3, name
+    print("train-mode gradients vs oracle: worst", worst)
+
+
+def test_supervision_forward_in_training_mode_is_differentiable():
+    """The trainer's extra calls ``vector_field_network(points)[:, :3]`` (train/vector_field_nerf_train.py:191,203,215) in
+    training mode: gradient of sum(out[:, :3] * c) wrt two parameters vs the oracle."""
+    fx, d = load_fixture("train_mode")
+    model = _train_model(fx, d)
+    torch.manual_seed(1)
+    pts = torch.rand(500, 3) * 2 - 1
+    coef = torch.randn(500, 3)
+    out = model.vector_field_network(pts.to(DEV))
+    assert out.shape == (500, 268)
+    (out[:, :3] * coef.to(DEV)).sum().backward()
+    cpu = build_model(fx, d)
+    sd = {k: v.clone() for k, v in cpu.vector_field_network.state_dict().items()}
+    for k in ("layers.2.0.weight", "layers.8.weight", "layers.5.1.weight"):
+        sd[k].requires_grad_(True)
+    y = O.vf_mlp(pts, sd, train=True)
+    (y[:, :3] * coef).sum().backward()
+    for k in ("layers.2.0.weight", "layers.8.weight", "layers.5.1.weight"):
+        got = dict(model.vector_field_network.named_parameters())[k].grad
+        assert grad_rel_err(got, sd[k].grad) <= 2e-3, (k, grad_rel_err(got, sd[k].grad))

@@ -77,15 +77,18 @@ def test_facade_surface_and_checkpoint_roundtrip():
         vf_nerf_amd.shipped_config(torch.device("cpu"), anneal="bogus")
 
 
-def test_render_requires_fine_sampling_and_eval_mode():
+def test_render_requires_fine_sampling_and_a_device():
     m = _cpu_model(n_samples=8, n_importance=0)
     z = torch.zeros(2, 4, 4)
     with pytest.raises(ValueError):
         m.render(z, torch.zeros(2, 2), z, 0)
-    m = _cpu_model(n_samples=8, n_importance=8)
-    m.train()
-    with pytest.raises(NotImplementedError):
-        m.render(z, torch.zeros(2, 2), z, 0)
+    from vf_nerf_amd.lib import VfnError
+    for mode in ("eval", "train"):          # either way the arithmetic is on the device: CPU tensors are refused, loudly
+        m = _cpu_model(n_samples=8, n_importance=8)
+        getattr(m, mode)()
+        assert m.vector_field_network.training == (mode == "train") == m.rendering_network.training
+        with pytest.raises(VfnError):
+            m.render(z, torch.zeros(2, 2), z, 0)
 
 
 def test_window_schedule_is_a_normalised_tent():

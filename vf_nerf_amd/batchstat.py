@@ -1,0 +1,379 @@
+"""The two MLPs with their BatchNorm layers in TRAINING mode (batch statistics), on the layer-at-a-time HIP kernels of
+``csrc/vfn_bstat.hip``.
+
+Reference: ``VectorFieldNerf.train()`` (models/nerf/vector_field_nerf.py:139-150) puts both networks in training mode;
+the trainer does so when the directional-derivative loss weight is non-zero (train/vector_field_nerf_train.py:140-141).
+Then ``nn.BatchNorm1d`` normalises with the statistics of the batch (and updates the running ones), and the VF forward
+appends three ``autograd.grad`` rows (vector_field_network.py:146-173).  Batch statistics couple all rows of a batch:
+
+* forward: per layer Linear -> column sums -> (scale, shift) -> ReLU, one launch each;
+* the three "Jacobian" rows are backward passes through those batch statistics (``grad_outputs = 1`` on every row of one
+  output column): row m of the result is sum_r d y_c[r] / d p[m], not the per-point Jacobian of an eval-mode network;
+* backward: per layer the two column sums of the BatchNorm backward, dZ, dX = dZ W and the weight-gradient partials.
+
+Everything here is orchestration: buffers from torch, arithmetic in the kernels.  Gradients flow to the parameters and to
+the feature / normal hand-off between the networks; the Jacobian rows are returned without a graph (the reference builds
+one with ``create_graph=True`` but never differentiates it: render() uses them under ``no_grad`` or drops them, Q10).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import lib
+from .lib import Cols
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+INV_SQRT2 = 1.0 / math.sqrt(2.0)
+
+
+def _up8(n: int) -> int:
+    return (n + 7) & ~7
+
+
+class _State:
+    """What one forward leaves behind for the Jacobian rows and the backward."""
+
+    def __init__(self) -> None:
+        self.x: List[torch.Tensor] = []        # input matrix of every Linear (post-activation of the previous layer)
+        self.z: List[torch.Tensor] = []        # pre-BatchNorm output of every BatchNorm'ed Linear
+        self.coef: List[torch.Tensor] = []     # [4][n]: scale, shift, mean, rstd
+        self.y: Optional[torch.Tensor] = None  # activated output of the last Linear
+        self.m = 0
+
+
+def _bn_layers(net) -> int:
+    return sum(1 for i in range(net.num_layers) if net._bn(i) is not None)
+
+
+def _require_shape(net) -> None:
+    L = net.num_layers
+    if any(net._bn(i) is None for i in range(L - 1)) or net._bn(L - 1) is not None:
+        raise NotImplementedError("the training-mode path expects BatchNorm after every Linear but the last (confs/vf_nerf.conf)")
+
+
+def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, update_running: bool = True) -> _State:
+    """x0[M, ld] = input matrix of layer 0 (pad columns zero).  ``fill_skip(dst: Cols, scale)`` writes the skip layer's
+    re-injected input (the positional encoding) next to the previous layer's output."""
+    _require_shape(net)
+    dev = x0.device
+    st = _State()
+    st.m = m
+    L = net.num_layers
+    skip = net._skip_layer()
+    x = x0
+    for i in range(L - 1):
+        lin, bn = net._linear(i), net._bn(i)
+        n, k = lin.out_features, lin.in_features
+        st.x.append(x)
+        z = torch.empty(m, _up8(n), device=dev) if n % 8 == 0 else torch.zeros(m, _up8(n), device=dev)
+        parts = lib.linear_rows_stat_parts(m)
+        part = torch.empty(parts, 2, n, device=dev)
+        lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, stats_part=part)
+        sums = torch.empty(2, n, dtype=torch.float64, device=dev)
+        lib.colsum_finish(part, parts, 2 * n, sums)
+        coef = torch.empty(4, n, device=dev)
+        lib.bstat_finalize(sums, m, n, bn.weight.detach(), bn.bias.detach(), BN_EPS, BN_MOMENTUM,
+                           bn.running_mean if update_running else None, bn.running_var if update_running else None, coef)
+        if update_running:
+            bn.num_batches_tracked += 1
+        st.z.append(z)
+        st.coef.append(coef)
+        nxt_k = net._linear(i + 1).in_features
+        if i + 1 == skip:        # next input = cat([h, pe]) / sqrt(2)  (vector_field_network.py:192-193)
+            x = torch.zeros(m, _up8(nxt_k), device=dev)
+            lib.bstat_relu_rows(z, coef, m, n, INV_SQRT2, x)
+            fill_skip(Cols(x, n), INV_SQRT2)
+        else:
+            x = torch.empty(m, _up8(nxt_k), device=dev) if (nxt_k % 8 == 0 and nxt_k == n) else torch.zeros(m, _up8(nxt_k), device=dev)
+            lib.bstat_relu_rows(z, coef, m, n, 1.0, x)
+    last = net._linear(L - 1)
+    st.x.append(x)
+    y = torch.zeros(m, _up8(last.out_features), device=dev)
+    lib.linear_rows(x, last.weight.detach(), last.bias.detach(), m, last.out_features, last.in_features, y, act=final_act)
+    st.y = y
+    if getattr(net, "_keep_state", False):     # test hook: expose the activations of the latest forward
+        net._debug_state = st
+    return st
+
+
+def _groups(m: int) -> int:
+    return max(1, min(256, m // 256))
+
+
+class _ParamGrads:
+    """Weight-gradient partial slabs of every layer, un-folded (summed) in one launch at the end."""
+
+    def __init__(self, net, m: int) -> None:
+        self.net, self.m, self.G = net, m, _groups(m)
+        self.grads: Dict[torch.nn.Parameter, torch.Tensor] = {}
+        self.unfold: List[dict] = []
+
+    def _out(self, p):
+        if p not in self.grads:
+            self.grads[p] = torch.empty_like(p)
+        return self.grads[p]
+
+    def linear(self, i: int, dz: torch.Tensor, x: torch.Tensor) -> None:
+        """dW_i = dZ^T X, db_i = column sums of dZ, in pieces the weight-gradient kernel has shapes for: output rows in
+        blocks of 256 (or one 32-row block for a narrow head), input columns in blocks of 256 with a tail of <= 64."""
+        lin = self.net._linear(i)
+        n, k = lin.out_features, lin.in_features
+        dev, G, m = dz.device, self.G, self.m
+        row_blocks = []
+        if n % 256 != 0 and n % 256 <= 32 and n > 32:     # 259 = 3 + 256: rows 0..2 as the narrow head, the rest as one block
+            row_blocks.append((0, n % 256, 2))
+            row_blocks += [(r, 256, 0) for r in range(n % 256, n, 256)]
+        elif n <= 32:
+            row_blocks.append((0, n, 2))
+        else:
+            row_blocks += [(r, min(256, n - r), 0) for r in range(0, n, 256)]
+        # input columns: a 256-wide "act" block when there is one, and a <= 64-wide "aux" block for the rest
+        if k <= 64:
+            col_blocks = [("aux", 0, k)]
+        elif k == 256:
+            col_blocks = [("act", 0, 256)]
+        elif 256 < k <= 320:
+            col_blocks = [("aux", 0, k - 256), ("act", k - 256, 256)]      # rendering net: [p, PE(d), n | 256 features]
+        else:
+            raise NotImplementedError(f"weight gradients for in_features={k}")
+        for r0, rows, head in row_blocks:
+            slab_rows = 32 if head else 256
+            u = dict(w=lin.weight.detach(), b_lin=lin.bias.detach(), g_w=self._out(lin.weight), g_b=self._out(lin.bias),
+                     rows=rows, row_off=r0, in_dim=k, slab_rows=slab_rows, scale=1.0)
+            db_part = torch.empty(G, slab_rows, device=dev)
+            u["db"] = db_part
+            first = True
+            for kind, c0, nc in col_blocks:
+                dzv, xv = Cols(dz, r0), Cols(x, c0)
+                if head:
+                    if kind != "act":
+                        raise NotImplementedError("a narrow head reading fewer than 256 inputs")
+                    part = torch.empty(G, 32, 256, device=dev)
+                    lib.weight_grad_partials(2, dzv, dzv.ld, rows, xv, xv.ld, nc, m, G, part, db_part if first else None)
+                    u.update(dw_act=part, act_c0=c0, act_nc=nc)
+                elif kind == "act":
+                    part = torch.empty(G, 256, 256, device=dev)
+                    lib.weight_grad_partials(0, dzv, dzv.ld, rows, xv, xv.ld, nc, m, G, part, db_part if first else None)
+                    u.update(dw_act=part, act_c0=c0, act_nc=nc)
+                else:
+                    part = torch.empty(G, 256, 64, device=dev)
+                    lib.weight_grad_partials(1, dzv, dzv.ld, rows, xv, xv.ld, nc, m, G, part, db_part if first else None)
+                    u.update(dw_aux=part, aux_c0=c0, aux_nc=nc)
+                first = False
+            self.unfold.append(u)
+
+    def batchnorm(self, i: int, sums: torch.Tensor) -> None:
+        bn = self.net._bn(i)
+        self.grads[bn.bias] = sums[0].float()        # d beta = sum g', d gamma = sum g' x_hat
+        self.grads[bn.weight] = sums[1].float()
+
+    def finish(self) -> Dict[torch.nn.Parameter, torch.Tensor]:
+        if self.unfold:
+            lib.unfold_weight_grads(self.unfold, self.G)
+        return self.grads
+
+
+def _backward(net, st: _State, dz_last: torch.Tensor, pg: Optional[_ParamGrads], want_dx0: bool):
+    """dz_last[M, up8(n_L)]: gradient wrt the pre-activation of the last Linear (pad columns zero).
+    -> (dX_0 or None, skip piece (Cols of the gradient wrt the re-injected encoding, scale) or None)."""
+    m, L = st.m, net.num_layers
+    dev = dz_last.device
+    skip = net._skip_layer()
+    dz = dz_last
+    skip_piece = None
+    for i in range(L - 1, -1, -1):
+        lin = net._linear(i)
+        n, k = lin.out_features, lin.in_features
+        if pg is not None:
+            pg.linear(i, dz, st.x[i])
+        if i == 0 and not want_dx0:
+            return None, skip_piece
+        g = torch.zeros(m, _up8(k), device=dev) if k % 8 else torch.empty(m, _up8(k), device=dev)
+        lib.linear_rows(dz, lin.weight.detach(), None, m, k, n, g, transpose_w=True)      # dX = dZ W
+        if i == 0:
+            return g, skip_piece
+        # BatchNorm + ReLU of layer i-1, whose (scaled) output is columns [0, n_prev) of x[i]
+        n_prev = net._linear(i - 1).out_features
+        post = INV_SQRT2 if i == skip else 1.0
+        if i == skip:
+            skip_piece = (Cols(g, n_prev), INV_SQRT2)
+        parts = lib.bstat_row_parts(m)
+        part = torch.empty(parts, 2, n_prev, device=dev)
+        z, coef = st.z[i - 1], st.coef[i - 1]
+        lib.bstat_relu_bwd_sums(g, st.x[i], z, coef, m, n_prev, post, part)
+        sums = torch.empty(2, n_prev, dtype=torch.float64, device=dev)
+        lib.colsum_finish(part, parts, 2 * n_prev, sums)
+        if pg is not None:
+            pg.batchnorm(i - 1, sums)
+        dz = torch.zeros(m, _up8(n_prev), device=dev) if n_prev % 8 else torch.empty(m, _up8(n_prev), device=dev)
+        lib.bstat_relu_bwd_rows(g, st.x[i], z, coef, sums, m, n_prev, post, dz)
+    raise AssertionError("unreachable")
+
+
+# ------------------------------------------------------------------------------------------------
+# vector-field network
+# ------------------------------------------------------------------------------------------------
+def _vf_forward_state(net, pts: torch.Tensor) -> _State:
+    m = pts.shape[0]
+    L_pe = net._multires()
+    k0 = net._linear(0).in_features
+    x0 = torch.zeros(m, _up8(k0), device=pts.device)
+    lib.embed_rows(pts, m, L_pe, x0)
+    return _forward(net, x0, m, lib.ACT_TANH, fill_skip=lambda dst, scale: lib.embed_rows(pts, m, L_pe, dst, scale))
+
+
+def _vf_point_grads(net, st: _State, pts: torch.Tensor, dz_last: torch.Tensor, pg: Optional[_ParamGrads]) -> torch.Tensor:
+    """Backward from dz_last down to the points -> [M,3]."""
+    m = st.m
+    dx0, piece = _backward(net, st, dz_last, pg, want_dx0=True)
+    d_pts = torch.empty(m, 3, device=pts.device)
+    lib.embed_rows_bwd(pts, m, net._multires(), dx0, 1.0, piece[0] if piece else None, piece[1] if piece else 0.0, d_pts)
+    return d_pts
+
+
+def vf_jacobian_rows(net, st: _State, pts: torch.Tensor) -> torch.Tensor:
+    """[M,9] = [d y_0 / d p, d y_1 / d p, d y_2 / d p] with grad_outputs = 1 on every row (vector_field_network.py:150-172)."""
+    m = st.m
+    n_out = net._linear(net.num_layers - 1).out_features
+    rows = []
+    for c in range(3):
+        dz = torch.zeros(m, _up8(n_out), device=pts.device)
+        lib.act_bwd_rows(lib.ACT_TANH, None, st.y, m, n_out, dz, onehot_col=c)
+        rows.append(_vf_point_grads(net, st, pts, dz, None))
+    return torch.cat(rows, dim=1)
+
+
+class _VFTrainMode(torch.autograd.Function):
+    """points[M,3] -> [M, 3 + F (+ 9)] with batch-statistics BatchNorm; gradients to the parameters (and the points)."""
+
+    @staticmethod
+    def forward(ctx, net, points, want_jacobian, *params):
+        pts = points.detach().reshape(-1, 3).float().contiguous()
+        m = pts.shape[0]
+        st = _vf_forward_state(net, pts)
+        n_out = net._linear(net.num_layers - 1).out_features
+        cols = [st.y[:, :n_out]]
+        if want_jacobian:
+            cols.append(vf_jacobian_rows(net, st, pts))
+        out = torch.cat(cols, dim=1) if len(cols) > 1 else st.y[:, :n_out].contiguous()
+        ctx.net, ctx.st, ctx.pts, ctx.n_out, ctx.param_order = net, st, pts, n_out, list(params)
+        ctx.points_grad = points.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        net, st, pts, n_out = ctx.net, ctx.st, ctx.pts, ctx.n_out
+        m = st.m
+        if d_out.shape[1] > n_out and bool((d_out[:, n_out:] != 0).any()):
+            raise NotImplementedError("gradients through the Jacobian columns of the train-mode VF forward (a double backward) "
+                                      "are not implemented; the reference's render() never requests them (Q10)")
+        dy = d_out[:, :n_out].float().contiguous()
+        dz = torch.zeros(m, _up8(n_out), device=dy.device)
+        lib.act_bwd_rows(lib.ACT_TANH, dy, st.y, m, n_out, dz)
+        pg = _ParamGrads(net, m)
+        d_pts = None
+        if ctx.points_grad:
+            d_pts = _vf_point_grads(net, st, pts, dz, pg)
+        else:
+            _backward(net, st, dz, pg, want_dx0=False)
+        grads = pg.finish()
+        ctx.st = None
+        return (None, d_pts, None, *[grads.get(p) for p in ctx.param_order])
+
+
+def vf_forward_train_mode(net, points: torch.Tensor, want_jacobian: bool = True) -> torch.Tensor:
+    """``VectorFieldNetwork.forward`` in training mode: [M, 3 + F + 9] (or [M, 3 + F] with ``want_jacobian=False``, for
+    callers that drop the Jacobian columns).  Unlike the reference (vector_field_network.py:148) the caller's ``points`` are
+    not switched to ``requires_grad`` in place: the gradient wrt the points is produced only when they already ask for it."""
+    if not points.is_cuda:
+        raise lib.VfnError("the training-mode forward runs on the device (no CPU fallback)")
+    return _VFTrainMode.apply(net, points, want_jacobian, *list(net.parameters()))
+
+
+# ------------------------------------------------------------------------------------------------
+# rendering network
+# ------------------------------------------------------------------------------------------------
+class _RenderTrainMode(torch.autograd.Function):
+    """cat[p, PE(d), n, feat] -> ReLU MLP with batch-statistics BatchNorm -> sigmoid (rendering_network.py:62-108, mode idr);
+    gradients to the parameters and the features."""
+
+    @staticmethod
+    def forward(ctx, net, points, normals, view_dirs, feats, *params):
+        m = points.shape[0]
+        dev = points.device
+        pe = 3 + 6 * net._multires() if net._multires() > 0 else 3
+        k0 = net._linear(0).in_features
+        f = feats.shape[1]
+        if k0 != 3 + pe + 3 + f:
+            raise lib.VfnError(f"rendering net: first layer reads {k0} columns, inputs give {3 + pe + 3 + f}")
+        x0 = torch.zeros(m, _up8(k0), device=dev)
+        lib.embed_rows(points.detach().reshape(-1, 3).float().contiguous(), m, 0, Cols(x0, 0))
+        lib.embed_rows(view_dirs.detach().reshape(-1, 3).float().contiguous(), m, net._multires(), Cols(x0, 3))
+        lib.embed_rows(normals.detach().reshape(-1, 3).float().contiguous(), m, 0, Cols(x0, 3 + pe))
+        x0[:, 6 + pe:6 + pe + f].copy_(feats.detach())
+        st = _forward(net, x0, m, lib.ACT_SIGMOID)
+        ctx.net, ctx.st, ctx.cols, ctx.param_order = net, st, (6 + pe, f), list(params)
+        return st.y[:, :3].contiguous()
+
+    @staticmethod
+    def backward(ctx, d_colors):
+        net, st = ctx.net, ctx.st
+        m = st.m
+        c0, f = ctx.cols
+        dz = torch.zeros(m, 8, device=d_colors.device)
+        lib.act_bwd_rows(lib.ACT_SIGMOID, d_colors.float().contiguous(), st.y, m, 3, dz)
+        pg = _ParamGrads(net, m)
+        dx0, _ = _backward(net, st, dz, pg, want_dx0=True)
+        grads = pg.finish()
+        ctx.st = None
+        return (None, None, None, None, dx0[:, c0:c0 + f], *[grads.get(p) for p in ctx.param_order])
+
+
+def render_forward_train_mode(net, points, normals, view_dirs, feats) -> torch.Tensor:
+    if not points.is_cuda:
+        raise lib.VfnError("the training-mode forward runs on the device (no CPU fallback)")
+    return _RenderTrainMode.apply(net, points, normals, view_dirs, feats.float(), *list(net.parameters()))
+
+
+# ------------------------------------------------------------------------------------------------
+# per-ray density / weights / composite under autograd, for render() paths that call the networks one by one
+# ------------------------------------------------------------------------------------------------
+class _RayComposite(torch.autograd.Function):
+    """(normals[M,3], colors[M,3]) -> (rgb[N,3], depth[N,1], weights[N,S]) through vfn_ray_density_weights; gradients to the
+    normals, the colours and the three density scalars (vector_field_nerf.py:308-323,442-474)."""
+
+    @staticmethod
+    def forward(ctx, model, normals, colors, z, ray_dirs, *density_params):
+        scal = model.density.raw_scalars()
+        normals = normals.detach().float().contiguous()
+        colors = colors.detach().float().contiguous()
+        _, weights, _, rgb, depth = lib.ray_density_weights(model._density_params(), normals, ray_dirs, z, scal, colors=colors,
+                                                            want_sigma=False)
+        ctx.model, ctx.names = model, [n for n, _ in model.density.named_parameters()]
+        ctx.save_for_backward(normals, colors, z, ray_dirs, scal)
+        return rgb, depth, weights
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth, d_weights):
+        normals, colors, z, ray_dirs, scal = ctx.saved_tensors
+        n, s = z.shape
+        dev = z.device
+
+        def cont(t, shape):
+            return None if t is None else t.reshape(shape).float().contiguous()
+
+        dn = torch.zeros(n * s, 3, device=dev)
+        dc = torch.empty(n * s, 3, device=dev)
+        dscal = torch.zeros(3, device=dev)
+        lib.ray_density_weights_bwd(ctx.model._density_params(), normals, ray_dirs, z, scal, colors, cont(d_rgb, (n, 3)),
+                                    cont(d_depth, (n,)), cont(d_weights, (n, s)), dn, dc, dscal)
+        by_name = {"beta": dscal[0], "mean": dscal[1], "scale": dscal[2]}
+        dens = [by_name[name].reshape(p.shape) for name, p in ctx.model.density.named_parameters()]
+        return (None, dn, dc, None, None, *dens)
+
+
+def ray_composite(model, normals, colors, z, ray_dirs):
+    return _RayComposite.apply(model, normals, colors, z, ray_dirs, *list(model.density.parameters()))

@@ -14,6 +14,7 @@ hipcc $FLAGS -mllvm -amdgpu-mfma-vgpr-form -mllvm -pragma-unroll-threshold=10000
 hipcc $FLAGS -mllvm -amdgpu-mfma-vgpr-form -mllvm -pragma-unroll-threshold=10000000 -c vfn_mlp16.hip -o vfn_mlp16.o ${VFN_MLP16_EXTRA:-} &
 hipcc $FLAGS -ffp-contract=off -c vfn_rays.hip -o vfn_rays.o &
 hipcc $FLAGS -ffp-contract=off -c vfn_grid.hip -o vfn_grid.o &
+hipcc $FLAGS -c vfn_bstat.hip -o vfn_bstat.o &
 wait
-hipcc -shared -fPIC --offload-arch=${ARCH} -o libvfn.so vfn_pack.o vfn_mlp.o vfn_mlp_bwd.o vfn_dw16.o vfn_unfold.o vfn_bwd16.o vfn_mlp16.o vfn_rays.o vfn_grid.o
+hipcc -shared -fPIC --offload-arch=${ARCH} -o libvfn.so vfn_pack.o vfn_mlp.o vfn_mlp_bwd.o vfn_dw16.o vfn_unfold.o vfn_bwd16.o vfn_mlp16.o vfn_rays.o vfn_grid.o vfn_bstat.o
 echo "built $(pwd)/libvfn.so"

@@ -1,0 +1,414 @@
+// vfn_bstat.hip — the two MLPs with nn.BatchNorm1d in TRAINING mode (batch statistics), layer at a time.
+//
+// Reference: models/vector_field/vector_field_network.py:146-208 and rendering_network.py:62-108 after
+// VectorFieldNerf.train() (models/nerf/vector_field_nerf.py:139-150) — the regime the trainer enters when the
+// directional-derivative loss weight is non-zero (train/vector_field_nerf_train.py:140-141).  Batch statistics couple
+// every row of a layer's output, so — unlike the eval-mode path, where BatchNorm folds into the weights and all layers
+// fuse into one launch — each layer needs the column means / variances of the whole batch before the next one can
+// start, and its backward needs two more column sums before dZ exists.  The path is therefore a sequence of
+//   * vfn_linear_rows          C = act(A W^T + b) or C = A W, exact fp32 on v_mfma_f32_32x32x2f32, optional per-block
+//                              column sums of z and z^2 (the batch statistics, no atomics),
+//   * vfn_colsum_finish        per-block partial sums -> double column sums,
+//   * vfn_bstat_finalize       sums -> mean / biased variance -> scale, shift, mean, rstd; running statistics update,
+//   * vfn_bstat_relu_rows      h = post * relu(z * scale + shift),
+//   * vfn_bstat_relu_bwd_sums  per-block partials of sum g', sum g' x_hat  (g' = post * g * [h > 0]),
+//   * vfn_bstat_relu_bwd_rows  dz = gamma rstd (g' - mean g' - x_hat mean(g' x_hat)),
+//   * vfn_act_bwd_rows         tanh / sigmoid backward (or a one-hot seed for the autograd.grad rows),
+//   * vfn_embed_rows(_bwd)     positional encoding and its derivative wrt the point,
+// and the weight gradients reuse vfn_weight_grad_partials + vfn_unfold_weight_grads.  Activations live in HBM as
+// row-major fp32 matrices whose leading dimensions are multiples of 4 floats and whose pad columns hold zeros.
+//
+// Roofline: the fp32 matrix pipe (32x32x2: 64 cycles per MFMA per SIMD, 157 TFLOP/s nominal) bounds the GEMM; all other
+// kernels are one pass over [M, n] fp32 and HBM-bound.
+#include "vfn_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GM_ROWS = 128;    // rows per workgroup (4 waves x 32)
+constexpr int GM_KC = 32;       // contraction chunk staged in LDS
+constexpr int GM_LD = 36;       // LDS row stride (floats): 16-byte aligned, conflict-free b128 reads
+constexpr int ACT_NONE = 0, ACT_TANH = 1, ACT_SIGMOID = 2;
+
+struct GemmArgs {
+    const float* a; const float* w; const float* bias; float* c; float* stats_part;
+    long long m;
+    int lda, ldw, ldc;
+    int n_out;      // output columns (all launches together)
+    int k_in;       // contraction length actually present in W
+    int k_pad;      // contraction length to run over A (multiple of 8, pad columns of A are zero)
+    int n0;         // first output column of this launch
+    int act;
+    int stats_ld;   // = n_out
+};
+
+// TRANS = false: B(k, n) = W[n][k]  (nn.Linear weight, C = A W^T);  TRANS = true: B(k, n) = W[k][n]  (C = A W).
+template <int NT, bool TRANS>
+__global__ __launch_bounds__(256, 2) void vfn_linear_rows_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_b[NT * 32 * GM_LD];
+    __shared__ float s_red[2][4][NT * 32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, g = lane >> 5;
+    const long long row_a = (long long)blockIdx.x * GM_ROWS + 32 * wave + c;     // A-operand row of this lane
+    const bool row_ok = row_a < a.m;
+    const float* arow = a.a + (size_t)(row_ok ? row_a : 0) * a.lda;
+    constexpr int NCOL = NT * 32;
+    constexpr int PER = NCOL * GM_KC / 256;      // W elements each thread stages per chunk
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // element e of the [NCOL][32] chunk -> (column n, contraction index kk).  Plain: consecutive lanes walk k (coalesced
+    // rows of W[n][k]).  Transposed: a wave covers 16 columns x 4 k (coalesced rows of W[k][n], and the LDS stores of its 64
+    // lanes fall on distinct banks: 36 n + kk = 4 (e>>2 & 15) + (e & 3) mod 32).
+    auto stage_index = [&](int e, int& n, int& kk) {
+        if (!TRANS) { kk = e & 31; n = e >> 5; }
+        else { const int rest = e >> 6; kk = (e & 3) + 4 * (rest & 7); n = ((e >> 2) & 15) + 16 * (rest >> 3); }
+    };
+    float wreg[PER];
+    auto fetch_w = [&](int kc) {
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            int n, kk;
+            stage_index(tid + 256 * r, n, kk);
+            const int col = a.n0 + n, k = kc + kk;
+            float v = 0.f;
+            if (n < NCOL && col < a.n_out && k < a.k_in)
+                v = TRANS ? a.w[(size_t)k * a.ldw + col] : a.w[(size_t)col * a.ldw + k];
+            wreg[r] = v;
+        }
+    };
+    auto stage_w = [&]() {
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            int n, kk;
+            stage_index(tid + 256 * r, n, kk);
+            if (n < NCOL) s_b[n * GM_LD + kk] = wreg[r];
+        }
+    };
+
+    fetch_w(0);
+    for (int kc = 0; kc < a.k_pad; kc += GM_KC) {
+        __syncthreads();               // every wave is done with the previous chunk
+        stage_w();
+        __syncthreads();
+        if (kc + GM_KC < a.k_pad) fetch_w(kc + GM_KC);
+        f32x4 av[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const int k = kc + 8 * kb + 4 * g;
+            av[kb] = (row_ok && k < a.k_pad) ? *reinterpret_cast<const f32x4*>(arow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            if (kc + 8 * kb >= a.k_pad) break;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(s_b + (32 * j + c) * GM_LD + 8 * kb + 4 * g);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb][t], bv[t], acc[j], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: D row = (r&3) + 8 (r>>2) + 4 g, col = c
+    const long long row0 = (long long)blockIdx.x * GM_ROWS + 32 * wave;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = a.n0 + 32 * j + c;
+        const bool col_ok = col < a.n_out;
+        const float b = (a.bias && col_ok) ? a.bias[col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            const float z = acc[j][r] + b;
+            if (row < a.m && col_ok) {
+                s1 += z;
+                s2 += z * z;
+                float y = z;
+                if (a.act == ACT_TANH) y = tanhf(z);
+                else if (a.act == ACT_SIGMOID) y = 1.0f / (1.0f + expf(-z));
+                a.c[(size_t)row * a.ldc + col] = y;
+            }
+        }
+        if (a.stats_part) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (g == 0) { s_red[0][wave][32 * j + c] = s1; s_red[1][wave][32 * j + c] = s2; }
+        }
+    }
+    if (a.stats_part) {
+        __syncthreads();
+        for (int i = tid; i < 2 * NCOL; i += 256) {
+            const int which = i / NCOL, n = i - which * NCOL;
+            const int col = a.n0 + n;
+            if (col < a.n_out) {
+                const float s = s_red[which][0][n] + s_red[which][1][n] + s_red[which][2][n] + s_red[which][3][n];
+                a.stats_part[((size_t)blockIdx.x * 2 + which) * a.stats_ld + col] = s;
+            }
+        }
+    }
+}
+
+template <bool TRANS>
+void launch_gemm(GemmArgs a, hipStream_t s) {
+    const unsigned blocks = (unsigned)((a.m + GM_ROWS - 1) / GM_ROWS);
+    for (int n0 = 0; n0 < a.n_out; n0 += 256) {
+        a.n0 = n0;
+        const int tiles = (min(a.n_out - n0, 256) + 31) / 32;
+        if (tiles > 4) hipLaunchKernelGGL((vfn_linear_rows_kernel<8, TRANS>), dim3(blocks), dim3(256), 0, s, a);
+        else if (tiles > 2) hipLaunchKernelGGL((vfn_linear_rows_kernel<4, TRANS>), dim3(blocks), dim3(256), 0, s, a);
+        else if (tiles > 1) hipLaunchKernelGGL((vfn_linear_rows_kernel<2, TRANS>), dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((vfn_linear_rows_kernel<1, TRANS>), dim3(blocks), dim3(256), 0, s, a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums: per-block partials [P][n_sets][n] (fp32) -> double [n_sets][n]
+// ------------------------------------------------------------------------------------------------
+__global__ void vfn_colsum_finish_kernel(const float* part, int n_parts, int width, double* sums) {
+    __shared__ double s_acc[256];
+    const int col = blockIdx.x;
+    double acc = 0.0;
+    for (int p = threadIdx.x; p < n_parts; p += 256) acc += (double)part[(size_t)p * width + col];
+    s_acc[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s_acc[threadIdx.x] += s_acc[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[col] = s_acc[0];
+}
+
+// sums[0][c] = sum z, sums[1][c] = sum z^2 over m rows -> coef[0..3][n] = scale, shift, mean, rstd; running stats
+__global__ void vfn_bstat_finalize_kernel(const double* sums, long long m, int n, const float* gamma, const float* beta,
+                                          float eps, float momentum, float* running_mean, float* running_var, float* coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const double mean = sums[c] / (double)m;
+    double var = sums[n + c] / (double)m - mean * mean;      // biased (what normalises)
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float scale = gamma[c] * rstd;
+    coef[c] = scale;
+    coef[n + c] = beta[c] - (float)mean * scale;
+    coef[2 * n + c] = (float)mean;
+    coef[3 * n + c] = rstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        const double unbiased = m > 1 ? var * ((double)m / (double)(m - 1)) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// row-wise kernels: one thread per column (consecutive lanes = consecutive columns), EW_ROWS rows per workgroup
+// ------------------------------------------------------------------------------------------------
+constexpr int EW_ROWS = 64;
+
+__global__ __launch_bounds__(256) void vfn_bstat_relu_rows_kernel(const float* z, int ldz, const float* coef, long long m, int n,
+                                                                   float post, float* h, int ldh) {
+    const long long r0 = (long long)blockIdx.x * EW_ROWS, r1 = min(m, r0 + EW_ROWS);
+    for (int c = threadIdx.x; c < n; c += 256) {
+        const float sc = coef[c], sh = coef[n + c];
+        for (long long r = r0; r < r1; ++r) h[(size_t)r * ldh + c] = post * fmaxf(z[(size_t)r * ldz + c] * sc + sh, 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void vfn_bstat_relu_bwd_sums_kernel(const float* gr, int ldg, const float* h, int ldh, const float* z,
+                                                                       int ldz, const float* coef, long long m, int n, float post,
+                                                                       float* part) {
+    const long long r0 = (long long)blockIdx.x * EW_ROWS, r1 = min(m, r0 + EW_ROWS);
+    for (int c = threadIdx.x; c < n; c += 256) {
+        const float mean = coef[2 * n + c], rstd = coef[3 * n + c];
+        float s1 = 0.f, s2 = 0.f;
+        for (long long r = r0; r < r1; ++r) {
+            const float g1 = h[(size_t)r * ldh + c] > 0.f ? post * gr[(size_t)r * ldg + c] : 0.f;
+            s1 += g1;
+            s2 += g1 * ((z[(size_t)r * ldz + c] - mean) * rstd);
+        }
+        part[((size_t)blockIdx.x * 2) * n + c] = s1;
+        part[((size_t)blockIdx.x * 2 + 1) * n + c] = s2;
+    }
+}
+
+__global__ __launch_bounds__(256) void vfn_bstat_relu_bwd_rows_kernel(const float* gr, int ldg, const float* h, int ldh, const float* z,
+                                                                       int ldz, const float* coef, const double* sums, long long m,
+                                                                       int n, float post, float* dz, int lddz) {
+    const long long r0 = (long long)blockIdx.x * EW_ROWS, r1 = min(m, r0 + EW_ROWS);
+    for (int c = threadIdx.x; c < n; c += 256) {
+        const float mean = coef[2 * n + c], rstd = coef[3 * n + c], scale = coef[c];     // scale = gamma * rstd
+        const float ga = (float)(sums[c] / (double)m), gb = (float)(sums[n + c] / (double)m);
+        for (long long r = r0; r < r1; ++r) {
+            const float g1 = h[(size_t)r * ldh + c] > 0.f ? post * gr[(size_t)r * ldg + c] : 0.f;
+            const float xh = (z[(size_t)r * ldz + c] - mean) * rstd;
+            dz[(size_t)r * lddz + c] = scale * (g1 - ga - xh * gb);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void vfn_act_bwd_rows_kernel(int act, const float* dy, int lddy, const float* y, int ldy, long long m,
+                                                                int n, int onehot, float* dz, int lddz) {
+    const long long r0 = (long long)blockIdx.x * EW_ROWS, r1 = min(m, r0 + EW_ROWS);
+    for (int c = threadIdx.x; c < n; c += 256) {
+        for (long long r = r0; r < r1; ++r) {
+            const float g = dy ? dy[(size_t)r * lddy + c] : (c == onehot ? 1.f : 0.f);
+            const float v = y[(size_t)r * ldy + c];
+            dz[(size_t)r * lddz + c] = act == ACT_TANH ? g * (1.f - v * v) : (act == ACT_SIGMOID ? g * v * (1.f - v) : g);
+        }
+    }
+}
+
+// dst[row][col0 + j] = scale * PE(src3[row])[j]: [x, sin(2^k x), cos(2^k x)]_{k<L} (models/helpers/embedder.py:11-37)
+__global__ __launch_bounds__(256) void vfn_embed_rows_kernel(const float* src3, int ld_src, int rows_per_src, long long m, int multires,
+                                                              float scale, float* dst, int ld_dst, int col0) {
+    const long long row = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int part = threadIdx.x & 3;
+    if (row >= m) return;
+    const float* sp = src3 + (size_t)(row / rows_per_src) * ld_src;
+    const float x[3] = {sp[0], sp[1], sp[2]};
+    float* out = dst + (size_t)row * ld_dst + col0;
+    if (part == 0) { out[0] = scale * x[0]; out[1] = scale * x[1]; out[2] = scale * x[2]; }
+    for (int q = part; q < 3 * multires; q += 4) {
+        const int k = q / 3, cc = q - 3 * k;
+        float s, cs;
+        sincosf(x[cc] * (float)(1 << k), &s, &cs);
+        out[3 + 6 * k + cc] = scale * s;
+        out[3 + 6 * k + 3 + cc] = scale * cs;
+    }
+}
+
+struct EmbedBwdPiece { const float* d; int ld, col0; float scale; };
+
+// d_src[row][c] (+)= sum over pieces of scale * (d[c] + sum_k 2^k (cos(2^k x) d[3+6k+c] - sin(2^k x) d[3+6k+3+c]))
+__global__ __launch_bounds__(256) void vfn_embed_rows_bwd_kernel(const float* src3, long long m, int multires, EmbedBwdPiece p0,
+                                                                  EmbedBwdPiece p1, float* d_src3, int accumulate) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 3 * m) return;
+    const long long row = i / 3;
+    const int c = (int)(i - 3 * row);
+    const float x = src3[i];
+    float total = accumulate ? d_src3[i] : 0.f;
+    const EmbedBwdPiece ps[2] = {p0, p1};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (!ps[q].d) continue;
+        const float* d = ps[q].d + (size_t)row * ps[q].ld + ps[q].col0;
+        float acc = d[c];
+        for (int k = 0; k < multires; ++k) {
+            const float f = (float)(1 << k);
+            float s, cs;
+            sincosf(x * f, &s, &cs);
+            acc += f * (cs * d[3 + 6 * k + c] - s * d[3 + 6 * k + 3 + c]);
+        }
+        total += ps[q].scale * acc;
+    }
+    d_src3[i] = total;
+}
+
+inline unsigned ew_blocks(long long m) { return (unsigned)((m + EW_ROWS - 1) / EW_ROWS); }
+
+}  // namespace
+
+extern "C" int vfn_linear_rows(int32_t transpose_w, const float* a, int32_t lda, const float* w, int32_t ldw, const float* bias,
+                               int64_t m, int32_t n_out, int32_t k_in, int32_t act, float* c, int32_t ldc, float* stats_part,
+                               void* stream) {
+    VFN_REQUIRE(a && w && c, "vfn_linear_rows: NULL argument");
+    VFN_REQUIRE(n_out >= 1 && k_in >= 1 && act >= 0 && act <= 2, "vfn_linear_rows: n_out=%d k_in=%d act=%d", n_out, k_in, act);
+    const int k_pad = (k_in + 7) & ~7;
+    VFN_REQUIRE((lda & 3) == 0 && lda >= k_pad && ((uintptr_t)a & 15) == 0,
+                "vfn_linear_rows: A needs 16-byte aligned rows with lda (%d) >= %d (k rounded up to 8; pad columns zero)", lda, k_pad);
+    VFN_REQUIRE(ldc >= n_out && ldw >= (transpose_w ? n_out : k_in), "vfn_linear_rows: ldc=%d ldw=%d too small", ldc, ldw);
+    if (m <= 0) return VFN_OK;
+    GemmArgs g = {};
+    g.a = a; g.w = w; g.bias = bias; g.c = c; g.stats_part = stats_part; g.m = m; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
+    g.n_out = n_out; g.k_in = k_in; g.k_pad = k_pad; g.act = act; g.stats_ld = n_out;
+    if (transpose_w) launch_gemm<true>(g, (hipStream_t)stream);
+    else launch_gemm<false>(g, (hipStream_t)stream);
+    return vfn_check_launch("vfn_linear_rows");
+}
+
+extern "C" int64_t vfn_linear_rows_stat_parts(int64_t m) { return m <= 0 ? 0 : (m + GM_ROWS - 1) / GM_ROWS; }
+extern "C" int64_t vfn_bstat_row_parts(int64_t m) { return m <= 0 ? 0 : (m + EW_ROWS - 1) / EW_ROWS; }
+
+extern "C" int vfn_colsum_finish(const float* part, int64_t n_parts, int32_t width, double* sums, void* stream) {
+    VFN_REQUIRE(part && sums && width >= 1 && n_parts >= 0, "vfn_colsum_finish: bad argument");
+    hipLaunchKernelGGL(vfn_colsum_finish_kernel, dim3(width), dim3(256), 0, (hipStream_t)stream, part, (int)n_parts, width, sums);
+    return vfn_check_launch("vfn_colsum_finish");
+}
+
+extern "C" int vfn_bstat_finalize(const double* sums, int64_t m, int32_t n, const float* gamma, const float* beta, float eps,
+                                  float momentum, float* running_mean, float* running_var, float* coef, void* stream) {
+    VFN_REQUIRE(sums && gamma && beta && coef && n >= 1 && m >= 1, "vfn_bstat_finalize: bad argument");
+    hipLaunchKernelGGL(vfn_bstat_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, (long long)m, n,
+                       gamma, beta, eps, momentum, running_mean, running_var, coef);
+    return vfn_check_launch("vfn_bstat_finalize");
+}
+
+extern "C" int vfn_bstat_relu_rows(const float* z, int32_t ldz, const float* coef, int64_t m, int32_t n, float post_scale, float* h,
+                                   int32_t ldh, void* stream) {
+    VFN_REQUIRE(z && coef && h && n >= 1 && ldz >= n && ldh >= n, "vfn_bstat_relu_rows: bad argument");
+    if (m <= 0) return VFN_OK;
+    hipLaunchKernelGGL(vfn_bstat_relu_rows_kernel, dim3(ew_blocks(m)), dim3(256), 0, (hipStream_t)stream, z, ldz, coef, (long long)m, n,
+                       post_scale, h, ldh);
+    return vfn_check_launch("vfn_bstat_relu_rows");
+}
+
+extern "C" int vfn_bstat_relu_bwd_sums(const float* g, int32_t ldg, const float* h, int32_t ldh, const float* z, int32_t ldz,
+                                       const float* coef, int64_t m, int32_t n, float post_scale, float* part, void* stream) {
+    VFN_REQUIRE(g && h && z && coef && part && n >= 1, "vfn_bstat_relu_bwd_sums: bad argument");
+    if (m <= 0) return VFN_OK;
+    hipLaunchKernelGGL(vfn_bstat_relu_bwd_sums_kernel, dim3(ew_blocks(m)), dim3(256), 0, (hipStream_t)stream, g, ldg, h, ldh, z, ldz,
+                       coef, (long long)m, n, post_scale, part);
+    return vfn_check_launch("vfn_bstat_relu_bwd_sums");
+}
+
+extern "C" int vfn_bstat_relu_bwd_rows(const float* g, int32_t ldg, const float* h, int32_t ldh, const float* z, int32_t ldz,
+                                       const float* coef, const double* sums, int64_t m, int32_t n, float post_scale, float* dz,
+                                       int32_t lddz, void* stream) {
+    VFN_REQUIRE(g && h && z && coef && sums && dz && n >= 1, "vfn_bstat_relu_bwd_rows: bad argument");
+    if (m <= 0) return VFN_OK;
+    hipLaunchKernelGGL(vfn_bstat_relu_bwd_rows_kernel, dim3(ew_blocks(m)), dim3(256), 0, (hipStream_t)stream, g, ldg, h, ldh, z, ldz,
+                       coef, sums, (long long)m, n, post_scale, dz, lddz);
+    return vfn_check_launch("vfn_bstat_relu_bwd_rows");
+}
+
+extern "C" int vfn_act_bwd_rows(int32_t act, const float* dy, int32_t lddy, const float* y, int32_t ldy, int64_t m, int32_t n,
+                                int32_t onehot_col, float* dz, int32_t lddz, void* stream) {
+    VFN_REQUIRE(y && dz && n >= 1 && act >= 0 && act <= 2, "vfn_act_bwd_rows: bad argument");
+    VFN_REQUIRE(dy || (onehot_col >= 0 && onehot_col < n), "vfn_act_bwd_rows: dy is NULL and onehot_col=%d is not a column", onehot_col);
+    if (m <= 0) return VFN_OK;
+    hipLaunchKernelGGL(vfn_act_bwd_rows_kernel, dim3(ew_blocks(m)), dim3(256), 0, (hipStream_t)stream, act, dy, lddy, y, ldy,
+                       (long long)m, n, onehot_col, dz, lddz);
+    return vfn_check_launch("vfn_act_bwd_rows");
+}
+
+extern "C" int vfn_embed_rows(const float* src3, int32_t ld_src, int32_t rows_per_src, int64_t m, int32_t multires, float scale,
+                              float* dst, int32_t ld_dst, int32_t col0, void* stream) {
+    VFN_REQUIRE(src3 && dst && multires >= 0 && multires <= 16 && ld_src >= 3 && rows_per_src >= 1, "vfn_embed_rows: bad argument");
+    VFN_REQUIRE(col0 >= 0 && col0 + 3 + 6 * multires <= ld_dst, "vfn_embed_rows: columns %d..%d exceed ld_dst=%d", col0,
+                col0 + 3 + 6 * multires, ld_dst);
+    if (m <= 0) return VFN_OK;
+    hipLaunchKernelGGL(vfn_embed_rows_kernel, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, (hipStream_t)stream, src3, ld_src,
+                       rows_per_src, (long long)m, multires, scale, dst, ld_dst, col0);
+    return vfn_check_launch("vfn_embed_rows");
+}
+
+extern "C" int vfn_embed_rows_bwd(const float* src3, int64_t m, int32_t multires, const float* d_a, int32_t ld_a, int32_t col_a,
+                                  float scale_a, const float* d_b, int32_t ld_b, int32_t col_b, float scale_b, float* d_src3,
+                                  int32_t accumulate, void* stream) {
+    VFN_REQUIRE(src3 && d_a && d_src3 && multires >= 0 && multires <= 16, "vfn_embed_rows_bwd: bad argument");
+    if (m <= 0) return VFN_OK;
+    const EmbedBwdPiece p0 = {d_a, ld_a, col_a, scale_a}, p1 = {d_b, ld_b, col_b, scale_b};
+    hipLaunchKernelGGL(vfn_embed_rows_bwd_kernel, dim3((unsigned)((3 * m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src3,
+                       (long long)m, multires, p0, p1, d_src3, accumulate);
+    return vfn_check_launch("vfn_embed_rows_bwd");
+}

@@ -28,6 +28,9 @@ EXPORTS = (
     "vfn_vf_render_fused16_fwd", "vfn_vf_mlp16_fwd_train", "vfn_vf_render_fused16_fwd_train",
     "vfn_vf_feat16_fwd", "vfn_render16_from_blocks", "vfn_grid_divergence", "vfn_grid_smooth_axis",
     "vfn_grid_unify_direction", "vfn_grid_comb_format", "vfn_weight_grad_partials_bf16", "vfn_unfold_weight_grads", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
+    "vfn_linear_rows", "vfn_linear_rows_stat_parts", "vfn_bstat_row_parts", "vfn_colsum_finish", "vfn_bstat_finalize",
+    "vfn_bstat_relu_rows", "vfn_bstat_relu_bwd_sums", "vfn_bstat_relu_bwd_rows", "vfn_act_bwd_rows", "vfn_embed_rows",
+    "vfn_embed_rows_bwd",
 )
 
 
@@ -85,6 +88,10 @@ def load() -> C.CDLL:
     lib.vfn_pack16_size.argtypes = [C.c_int32, C.POINTER(NetGeom)]
     lib.vfn_packed_bwd16_size.restype = C.c_int64
     lib.vfn_packed_bwd16_size.argtypes = [C.c_int32, C.POINTER(NetGeom)]
+    lib.vfn_linear_rows_stat_parts.restype = C.c_int64
+    lib.vfn_linear_rows_stat_parts.argtypes = [C.c_int64]
+    lib.vfn_bstat_row_parts.restype = C.c_int64
+    lib.vfn_bstat_row_parts.argtypes = [C.c_int64]
     for name in EXPORTS:
         getattr(lib, name)  # raises AttributeError if the ABI lost a symbol
     if lib.vfn_abi_version() != 1:
@@ -520,3 +527,108 @@ def grid_comb_format(choice: torch.Tensor, norms: torch.Tensor, n: int):
                                        _ptr(different, "different_side"), _ptr(pair_norms, "pair_norms"), _stream()),
            "vfn_grid_comb_format")
     return different, pair_norms
+
+
+# ------------------------------------------------------------------------------------------------
+# networks in training mode: batch-statistics BatchNorm, one launch per layer (csrc/vfn_bstat.hip)
+# ------------------------------------------------------------------------------------------------
+class Cols:
+    """Columns [col0, col0 + ...) of a contiguous row-major fp32 matrix: what the row-wise entry points take as
+    (pointer, leading dimension)."""
+
+    def __init__(self, base: torch.Tensor, col0: int = 0) -> None:
+        if not (base.is_cuda and base.dtype == torch.float32 and base.is_contiguous() and base.dim() == 2):
+            raise VfnError("Cols: expected a contiguous 2-D fp32 CUDA/HIP tensor (the HIP path has no CPU fallback)")
+        self.base, self.col0, self.ld = base, col0, base.shape[1]
+
+    @property
+    def ptr(self) -> C.c_void_p:
+        return C.c_void_p(self.base.data_ptr() + 4 * self.col0)
+
+    # what _ptr() asks of a tensor, so that the (pointer, ld) entry points written for whole tensors take column views too
+    is_cuda, dtype = True, torch.float32
+
+    def is_contiguous(self) -> bool:
+        return True
+
+    def data_ptr(self) -> int:
+        return self.base.data_ptr() + 4 * self.col0
+
+
+def _cols(x) -> "Cols":
+    return x if isinstance(x, Cols) else Cols(x)
+
+
+ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
+
+
+def linear_rows_stat_parts(m: int) -> int:
+    return int(load().vfn_linear_rows_stat_parts(m))
+
+
+def bstat_row_parts(m: int) -> int:
+    return int(load().vfn_bstat_row_parts(m))
+
+
+def linear_rows(a, w: torch.Tensor, bias, m: int, n_out: int, k_in: int, c, act: int = ACT_NONE, transpose_w: bool = False,
+                stats_part=None) -> None:
+    a, c = _cols(a), _cols(c)
+    _check(load().vfn_linear_rows(C.c_int32(int(transpose_w)), a.ptr, C.c_int32(a.ld), _ptr(w, "w"), C.c_int32(w.shape[1]),
+                                  _ptr(bias, "bias"), C.c_int64(m), C.c_int32(n_out), C.c_int32(k_in), C.c_int32(act), c.ptr,
+                                  C.c_int32(c.ld), _ptr(stats_part, "stats_part"), _stream()), "vfn_linear_rows")
+
+
+def colsum_finish(part: torch.Tensor, n_parts: int, width: int, sums: torch.Tensor) -> None:
+    _check(load().vfn_colsum_finish(_ptr(part, "part"), C.c_int64(n_parts), C.c_int32(width), _ptr(sums, "sums", torch.float64),
+                                    _stream()), "vfn_colsum_finish")
+
+
+def bstat_finalize(sums, m: int, n: int, gamma, beta, eps: float, momentum: float, running_mean, running_var, coef) -> None:
+    _check(load().vfn_bstat_finalize(_ptr(sums, "sums", torch.float64), C.c_int64(m), C.c_int32(n), _ptr(gamma, "gamma"),
+                                     _ptr(beta, "beta"), C.c_float(eps), C.c_float(momentum), _ptr(running_mean, "running_mean"),
+                                     _ptr(running_var, "running_var"), _ptr(coef, "coef"), _stream()), "vfn_bstat_finalize")
+
+
+def bstat_relu_rows(z, coef, m: int, n: int, post_scale: float, h) -> None:
+    z, h = _cols(z), _cols(h)
+    _check(load().vfn_bstat_relu_rows(z.ptr, C.c_int32(z.ld), _ptr(coef, "coef"), C.c_int64(m), C.c_int32(n),
+                                      C.c_float(post_scale), h.ptr, C.c_int32(h.ld), _stream()), "vfn_bstat_relu_rows")
+
+
+def bstat_relu_bwd_sums(g, h, z, coef, m: int, n: int, post_scale: float, part) -> None:
+    g, h, z = _cols(g), _cols(h), _cols(z)
+    _check(load().vfn_bstat_relu_bwd_sums(g.ptr, C.c_int32(g.ld), h.ptr, C.c_int32(h.ld), z.ptr, C.c_int32(z.ld),
+                                          _ptr(coef, "coef"), C.c_int64(m), C.c_int32(n), C.c_float(post_scale),
+                                          _ptr(part, "part"), _stream()), "vfn_bstat_relu_bwd_sums")
+
+
+def bstat_relu_bwd_rows(g, h, z, coef, sums, m: int, n: int, post_scale: float, dz) -> None:
+    g, h, z, dz = _cols(g), _cols(h), _cols(z), _cols(dz)
+    _check(load().vfn_bstat_relu_bwd_rows(g.ptr, C.c_int32(g.ld), h.ptr, C.c_int32(h.ld), z.ptr, C.c_int32(z.ld),
+                                          _ptr(coef, "coef"), _ptr(sums, "sums", torch.float64), C.c_int64(m), C.c_int32(n),
+                                          C.c_float(post_scale), dz.ptr, C.c_int32(dz.ld), _stream()), "vfn_bstat_relu_bwd_rows")
+
+
+def act_bwd_rows(act: int, dy, y, m: int, n: int, dz, onehot_col: int = -1) -> None:
+    y, dz = _cols(y), _cols(dz)
+    dy = None if dy is None else _cols(dy)
+    _check(load().vfn_act_bwd_rows(C.c_int32(act), dy.ptr if dy is not None else C.c_void_p(0),
+                                   C.c_int32(dy.ld if dy is not None else 0), y.ptr, C.c_int32(y.ld), C.c_int64(m), C.c_int32(n),
+                                   C.c_int32(onehot_col), dz.ptr, C.c_int32(dz.ld), _stream()), "vfn_act_bwd_rows")
+
+
+def embed_rows(src, m: int, multires: int, dst, scale: float = 1.0, rows_per_src: int = 1) -> None:
+    src, dst = _cols(src), _cols(dst)
+    _check(load().vfn_embed_rows(src.ptr, C.c_int32(src.ld), C.c_int32(rows_per_src), C.c_int64(m), C.c_int32(multires),
+                                 C.c_float(scale), C.c_void_p(dst.base.data_ptr()), C.c_int32(dst.ld), C.c_int32(dst.col0),
+                                 _stream()), "vfn_embed_rows")
+
+
+def embed_rows_bwd(src3: torch.Tensor, m: int, multires: int, d_a, scale_a: float, d_b, scale_b: float, d_src3: torch.Tensor,
+                   accumulate: bool = False) -> None:
+    d_a = _cols(d_a)
+    d_b = None if d_b is None else _cols(d_b)
+    _check(load().vfn_embed_rows_bwd(_ptr(src3, "src3"), C.c_int64(m), C.c_int32(multires), d_a.ptr, C.c_int32(d_a.ld),
+                                     C.c_int32(0), C.c_float(scale_a), d_b.ptr if d_b is not None else C.c_void_p(0),
+                                     C.c_int32(d_b.ld if d_b is not None else 0), C.c_int32(0), C.c_float(scale_b),
+                                     _ptr(d_src3, "d_src3"), C.c_int32(int(accumulate)), _stream()), "vfn_embed_rows_bwd")

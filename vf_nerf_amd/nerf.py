@@ -148,6 +148,8 @@ class VectorFieldNerf:
             self.vector_field_network.train()
         self.rendering_network.train()
         self.density.train()
+        if self.config.ray_sampler_config.fine_sampling():      # the alias: the VF net ends up in training mode either way
+            self.fine_vector_field_network.train()
 
     def eval(self) -> None:
         for m in self._modules():
@@ -289,10 +291,8 @@ class VectorFieldNerf:
                                       "reference (Q11); only 'volsdf' is implemented")
         if not cfg.ray_sampler_config.fine_sampling():
             raise ValueError("render() needs n_importance > 0 (the reference raises NameError without it, Q1)")
-        if self.vector_field_network.training:
-            raise NotImplementedError("the train-mode VF forward (batch-statistics BatchNorm + autograd Jacobian, "
-                                      "vector_field_network.py:146-173) is not on the HIP path; use model.eval() as the shipped "
-                                      "trainer does (Q8) — directional derivatives are available with numerical_jacobian=True")
+        if self.vector_field_network.training or self.rendering_network._batch_statistics():
+            return self._render_training_mode(pose, pixels, intrinsics, epoch, white, uniforms)
         from .autograd import fine_pass  # differentiable or plain, depending on torch.is_grad_enabled()
 
         dev = pose.device
@@ -370,6 +370,69 @@ class VectorFieldNerf:
             rgb = rgb + (1. - weights.sum(-1)[..., None])
         rep_dirs = ray_dirs.unsqueeze(1).expand(n, s_t, 3).reshape(-1, 3)
         return NerfOutput(points_coarse=pts, points_fine=None, coarse_normals=normals.view(n, s_t, 3),
+                          coarse_rgb_values=rgb, coarse_depth_map=depth, fine_normals=None, fine_rgb_values=None,
+                          fine_depth_map=None, z_vals=z, directional_derivtives=dd, ray_dirs=rep_dirs,
+                          coarse_colors=colors)
+
+    def _render_training_mode(self, pose, pixels, intrinsics, epoch: int, white: bool, uniforms) -> NerfOutput:
+        """render() with a network in training mode (after ``train()``, vector_field_nerf.py:139-150): BatchNorm normalises
+        with batch statistics, which the fused kernels cannot fold, so the networks are called one after the other
+        (``batchstat.py``: one launch per layer) with the per-ray stages in between — the reference's own call sequence
+        (vector_field_nerf.py:236-338).  The VF net sees two batches per call (its running statistics advance twice), the
+        rendering net one.  Directional derivatives: analytic, from the Jacobian columns of the proposal pass, listed twice
+        (the fine-pass values are computed and dropped by the reference, :303-305, Q10) — here they are not computed."""
+        from .batchstat import ray_composite
+        cfg = self.config
+        dev = pose.device
+        self._anneal(epoch, dev)
+        n = pixels.shape[0]
+        s_c = self.ray_sampler.N_samples
+        n_f = min(self.fine_sampler.N_samples, self.fine_sampler.max_samples)
+        uniforms = uniforms or {}
+
+        def draw(name, shape, needed):
+            if not needed:
+                return None
+            if name in uniforms:
+                return uniforms[name].to(dev).float().contiguous()
+            return self._uniform(shape, dev)
+
+        vf = self.vector_field_network
+        f = cfg.vf_net_config.feature_vector_dims
+        with torch.no_grad():
+            u_coarse = draw("u_coarse", (n, s_c), not self.ray_sampler.deterministic)
+            directions, ray_dirs, cam_loc, z_c, pts_c = self._rays(pose, pixels, intrinsics, u_coarse)
+            out_c = vf(pts_c.view(-1, 3))                       # training mode: [M, 3 + F + 9]
+            normals_c = out_c[:, :3].contiguous()
+            dd_c = None
+            if cfg.numerical_jacobian:
+                dd_c = self.compute_numerical_directional_derivatives(pts_c.view(-1, 3), normals_c).reshape(-1, 3)
+            elif vf.training:
+                dd_c = self.compute_directional_derivatives(pts_c.view(-1, 3), normals_c, out_c[:, 3 + f:3 + f + 9]).reshape(-1, 3)
+            scal = self.density.raw_scalars()
+            _, _, imax, _, _ = lib.ray_density_weights(self._density_params(), normals_c, ray_dirs, z_c, scal,
+                                                       want_sigma=False, want_weights=False, want_argmax=True)
+            u_fine = draw("u_fine", (n, n_f), not self.fine_sampler.deterministic)
+            u_add = draw("u_add", (n, n_f), True)
+            far, far_t = self._far_args(self.fine_sampler.far)
+            z, pts = lib.range_fine_sample(z_c, imax, directions, cam_loc, n_f, self.fine_sampler.near, far,
+                                           self.fine_sampler.range, u_add, u_fine, far_t)
+        s_t = s_c + n_f
+        flat = pts.view(-1, 3)
+        out_f = self.fine_vector_field_network(flat, jacobian=False)      # the Jacobian columns of this call are never used
+        normals = out_f[:, :3]
+        rep_dirs = ray_dirs.unsqueeze(1).expand(n, s_t, 3).reshape(-1, 3)
+        colors = self.rendering_network(flat, normals, rep_dirs, out_f[:, 3:3 + f])
+        rgb, depth, weights = ray_composite(self, normals, colors, z, ray_dirs)
+        dd = None
+        if cfg.numerical_jacobian:
+            dd_f = self.compute_numerical_directional_derivatives(flat, normals.reshape(-1, 3), fine=True)
+            dd = torch.cat([dd_c, dd_f.reshape(-1, 3)], dim=0).norm(dim=-1)
+        elif dd_c is not None:
+            dd = torch.cat([dd_c, dd_c], dim=0).norm(dim=-1)
+        if white:
+            rgb = rgb + (1. - weights.sum(-1)[..., None])
+        return NerfOutput(points_coarse=pts, points_fine=None, coarse_normals=normals.reshape(n, s_t, 3),
                           coarse_rgb_values=rgb, coarse_depth_map=depth, fine_normals=None, fine_rgb_values=None,
                           fine_depth_map=None, z_vals=z, directional_derivtives=dd, ray_dirs=rep_dirs,
                           coarse_colors=colors)

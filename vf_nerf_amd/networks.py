@@ -130,12 +130,10 @@ class _PackedMLP(nn.Module):
             self._f16x3_ok = ok
         return ok
 
-    def _require_eval_bn(self) -> None:
-        if self.training and any(self._bn(i) is not None for i in range(self.num_layers)):
-            raise NotImplementedError(
-                "train-mode BatchNorm / the autograd-Jacobian forward (vector_field_network.py:146-173) is not "
-                "on the HIP path yet; the shipped training regime calls model.eval() before training "
-                "(train/vector_field_nerf_train.py:140-141), which this implementation supports")
+    def _batch_statistics(self) -> bool:
+        """True in training mode with BatchNorm layers: they normalise with the statistics of the batch, which the fused
+        kernels (BatchNorm folded into the weights) cannot express — ``batchstat.py`` runs the layers one at a time."""
+        return self.training and any(self._bn(i) is not None for i in range(self.num_layers))
 
 
 class VectorFieldNetwork(_PackedMLP):
@@ -195,10 +193,16 @@ class VectorFieldNetwork(_PackedMLP):
         self.load_state_dict(torch.load(path, map_location=torch.device('cpu')))
         self.to(device)
 
-    def forward(self, points: torch.Tensor, vector_only: bool = False) -> torch.Tensor:
+    def forward(self, points: torch.Tensor, vector_only: bool = False, jacobian: bool = True) -> torch.Tensor:
         """points[M,3] -> [M, 3+F] (tanh'ed).  ``vector_only`` returns just the 3 vector columns and
-        skips the feature block of the last Linear (grid queries / proposal pass)."""
-        self._require_eval_bn()
+        skips the feature block of the last Linear (grid queries / proposal pass).
+        In training mode (vector_field_network.py:146-173): batch-statistics BatchNorm and nine more columns, the three
+        ``autograd.grad`` rows -> [M, 3+F+9]; the reference marks ``points`` as requiring grad in place, which is not done
+        here.  ``jacobian=False`` skips those columns (callers that drop them)."""
+        if self.training:           # like the reference: the Jacobian columns belong to training mode, BatchNorm or not
+            from .batchstat import vf_forward_train_mode
+            out = vf_forward_train_mode(self, points, want_jacobian=jacobian and not vector_only)
+            return out[:, :3].contiguous() if vector_only else out
         from .autograd import vf_forward  # local import: autograd wrappers depend on this module
         return vf_forward(self, points, vector_only)
 
@@ -232,8 +236,10 @@ class RenderingNetwork(_PackedMLP):
 
     def forward(self, points: torch.Tensor, normals: torch.Tensor, view_dirs: torch.Tensor,
                 feature_vectors: torch.Tensor) -> torch.Tensor:
-        self._require_eval_bn()
-        from .autograd import render_forward
         if self.config.detach_normals:
             normals = normals.detach()
+        if self._batch_statistics():
+            from .batchstat import render_forward_train_mode
+            return render_forward_train_mode(self, points, normals, view_dirs, feature_vectors)
+        from .autograd import render_forward
         return render_forward(self, points, normals, view_dirs, feature_vectors)
