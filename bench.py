@@ -292,6 +292,8 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync):
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                           "data": "synthetic", "final_loss": round(float(loss), 5),
+                          "networks": "training mode (batch-statistics BatchNorm, layer-at-a-time fp32 kernels)"
+                          if model.vector_field_network.training else "eval mode (the shipped regime, fused kernels)",
                           "config": {"workload": f"train step: render({args.rays} rays x {s_t}) + 2x{n_sup} supervision "
                                                  f"points through the VF net + L1/depth/unit-norm/supervision loss + "
                                                  f"backward + clip_grad_norm_ + Adam (sequential semantics over the duplicated parameter list)"}}), flush=True)
@@ -309,6 +311,9 @@ def main() -> None:
     ap.add_argument("--coarse", type=int, default=64)
     ap.add_argument("--fine", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-statistics", action="store_true",
+                    help="train workload with the networks in training mode (model.train(): batch-statistics BatchNorm, "
+                         "Jacobian columns, directional derivatives) instead of the shipped eval-mode regime (SURVEY Q8)")
     ap.add_argument("--precision", choices=("f16x3", "fp32"), default="f16x3",
                     help="MLP kernels: f16x3 = split-half products on the f16 matrix cores, fp32 accumulate (default, "
                          "fp32-equivalent accuracy); fp32 = exact fp32 MFMA")
@@ -367,6 +372,8 @@ def main() -> None:
         torch.cuda.synchronize()
 
     if args.workload == "train":
+        if args.batch_statistics:
+            model.train()
         train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync)
         return
 

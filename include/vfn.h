@@ -375,14 +375,13 @@ int vfn_bstat_finalize(const double* sums, int64_t m, int32_t n, const float* ga
 /* h[m][c] = post_scale * relu(z[m][c] * scale[c] + shift[c]), c < n. */
 int vfn_bstat_relu_rows(const float* z, int32_t ldz, const float* coef, int64_t m, int32_t n, float post_scale, float* h,
                         int32_t ldh, void* stream);
-/* Backward of the above through the batch statistics.  g = gradient wrt h.  With g' = post_scale g [h > 0] and
+/* Backward of the above through the batch statistics.  g = gradient wrt h.  With g' = post_scale g [z scale + shift > 0] and
  * x_hat = (z - mean) rstd:  part[vfn_bstat_row_parts(m)][2][n] = per-workgroup sums of g' and g' x_hat (= d beta, d gamma
  * after vfn_colsum_finish);  dz = gamma rstd (g' - sum g' / m - x_hat sum(g' x_hat) / m). */
-int vfn_bstat_relu_bwd_sums(const float* g, int32_t ldg, const float* h, int32_t ldh, const float* z, int32_t ldz,
-                            const float* coef, int64_t m, int32_t n, float post_scale, float* part, void* stream);
-int vfn_bstat_relu_bwd_rows(const float* g, int32_t ldg, const float* h, int32_t ldh, const float* z, int32_t ldz,
-                            const float* coef, const double* sums, int64_t m, int32_t n, float post_scale, float* dz,
-                            int32_t lddz, void* stream);
+int vfn_bstat_relu_bwd_sums(const float* g, int32_t ldg, const float* z, int32_t ldz, const float* coef, int64_t m, int32_t n,
+                            float post_scale, float* part, void* stream);
+int vfn_bstat_relu_bwd_rows(const float* g, int32_t ldg, const float* z, int32_t ldz, const float* coef, const double* sums,
+                            int64_t m, int32_t n, float post_scale, float* dz, int32_t lddz, void* stream);
 /* dz = dy (1 - y^2) (act 1, tanh) or dy y (1 - y) (act 2, sigmoid) or dy (act 0).  dy == NULL: dy is 1 in column
  * onehot_col and 0 elsewhere — the grad_outputs of the three autograd.grad calls of vector_field_network.py:150-171. */
 int vfn_act_bwd_rows(int32_t act, const float* dy, int32_t lddy, const float* y, int32_t ldy, int64_t m, int32_t n,

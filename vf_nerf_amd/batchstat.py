@@ -203,13 +203,13 @@ def _backward(net, st: _State, dz_last: torch.Tensor, pg: Optional[_ParamGrads],
         parts = lib.bstat_row_parts(m)
         part = torch.empty(parts, 2, n_prev, device=dev)
         z, coef = st.z[i - 1], st.coef[i - 1]
-        lib.bstat_relu_bwd_sums(g, st.x[i], z, coef, m, n_prev, post, part)
+        lib.bstat_relu_bwd_sums(g, z, coef, m, n_prev, post, part)
         sums = torch.empty(2, n_prev, dtype=torch.float64, device=dev)
         lib.colsum_finish(part, parts, 2 * n_prev, sums)
         if pg is not None:
             pg.batchnorm(i - 1, sums)
         dz = torch.zeros(m, _up8(n_prev), device=dev) if n_prev % 8 else torch.empty(m, _up8(n_prev), device=dev)
-        lib.bstat_relu_bwd_rows(g, st.x[i], z, coef, sums, m, n_prev, post, dz)
+        lib.bstat_relu_bwd_rows(g, z, coef, sums, m, n_prev, post, dz)
     raise AssertionError("unreachable")
 
 

@@ -11,7 +11,7 @@
 //   * vfn_colsum_finish        per-block partial sums -> double column sums,
 //   * vfn_bstat_finalize       sums -> mean / biased variance -> scale, shift, mean, rstd; running statistics update,
 //   * vfn_bstat_relu_rows      h = post * relu(z * scale + shift),
-//   * vfn_bstat_relu_bwd_sums  per-block partials of sum g', sum g' x_hat  (g' = post * g * [h > 0]),
+//   * vfn_bstat_relu_bwd_sums  per-block partials of sum g', sum g' x_hat  (g' = post * g * [z * scale + shift > 0]),
 //   * vfn_bstat_relu_bwd_rows  dz = gamma rstd (g' - mean g' - x_hat mean(g' x_hat)),
 //   * vfn_act_bwd_rows         tanh / sigmoid backward (or a one-hot seed for the autograd.grad rows),
 //   * vfn_embed_rows(_bwd)     positional encoding and its derivative wrt the point,
@@ -52,11 +52,18 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows_kernel(const GemmArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, g = lane >> 5;
-    const long long row_a = (long long)blockIdx.x * GM_ROWS + 32 * wave + c;     // A-operand row of this lane
-    const bool row_ok = row_a < a.m;
-    const float* arow = a.a + (size_t)(row_ok ? row_a : 0) * a.lda;
     constexpr int NCOL = NT * 32;
     constexpr int PER = NCOL * GM_KC / 256;      // W elements each thread stages per chunk
+    constexpr unsigned OOB = 0x7fffffffu;        // an offset past every buffer: the load returns 0, no branch
+
+    // bounds-checked buffer descriptors: A restricted to this workgroup's rows (rows past m read as zero), W whole
+    const long long blk_row0 = (long long)blockIdx.x * GM_ROWS;
+    const long long blk_rows = min((long long)GM_ROWS, a.m - blk_row0);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.a + (size_t)blk_row0 * a.lda), 0, (int)(blk_rows * a.lda * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w), 0, (int)((long long)(TRANS ? a.k_in : a.n_out) * a.ldw * 4), 0x00020000);
+    const unsigned a_row_off = (unsigned)(32 * wave + c) * (unsigned)a.lda * 4u;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -71,17 +78,24 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows_kernel(const GemmArgs 
         if (!TRANS) { kk = e & 31; n = e >> 5; }
         else { const int rest = e >> 6; kk = (e & 3) + 4 * (rest & 7); n = ((e >> 2) & 15) + 16 * (rest >> 3); }
     };
+    // per-thread W offsets of chunk 0 (bytes); a chunk further on adds kc * (TRANS ? ldw : 1) * 4
+    unsigned w_off[PER];
+    int w_kk[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        int n, kk;
+        stage_index(tid + 256 * r, n, kk);
+        const int col = a.n0 + n;
+        w_kk[r] = kk;
+        w_off[r] = col < a.n_out ? (TRANS ? ((unsigned)kk * (unsigned)a.ldw + (unsigned)col) * 4u : ((unsigned)col * (unsigned)a.ldw + (unsigned)kk) * 4u) : OOB;
+    }
+    const unsigned w_step = (TRANS ? (unsigned)a.ldw : 1u) * 4u;
     float wreg[PER];
     auto fetch_w = [&](int kc) {
 #pragma unroll
         for (int r = 0; r < PER; ++r) {
-            int n, kk;
-            stage_index(tid + 256 * r, n, kk);
-            const int col = a.n0 + n, k = kc + kk;
-            float v = 0.f;
-            if (n < NCOL && col < a.n_out && k < a.k_in)
-                v = TRANS ? a.w[(size_t)k * a.ldw + col] : a.w[(size_t)col * a.ldw + k];
-            wreg[r] = v;
+            const unsigned off = (w_off[r] == OOB || kc + w_kk[r] >= a.k_in) ? OOB : w_off[r] + (unsigned)kc * w_step;
+            wreg[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, off, 0, 0));
         }
     };
     auto stage_w = [&]() {
@@ -89,7 +103,17 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows_kernel(const GemmArgs 
         for (int r = 0; r < PER; ++r) {
             int n, kk;
             stage_index(tid + 256 * r, n, kk);
-            if (n < NCOL) s_b[n * GM_LD + kk] = wreg[r];
+            s_b[n * GM_LD + kk] = wreg[r];
+        }
+    };
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    f32x4 av[4];
+    auto fetch_a = [&](int kc) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const int k = kc + 8 * kb + 4 * g;
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs_a, k < a.k_pad ? a_row_off + (unsigned)k * 4u : OOB, 0, 0);
+            av[kb] = __builtin_bit_cast(f32x4, raw);
         }
     };
 
@@ -98,13 +122,10 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows_kernel(const GemmArgs 
         __syncthreads();               // every wave is done with the previous chunk
         stage_w();
         __syncthreads();
+        // this chunk's A fragments first, then the next chunk's W: loads return in order, so the MFMAs below wait only for
+        // the four A loads while the W prefetch stays in flight underneath them
+        fetch_a(kc);
         if (kc + GM_KC < a.k_pad) fetch_w(kc + GM_KC);
-        f32x4 av[4];
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            const int k = kc + 8 * kb + 4 * g;
-            av[kb] = (row_ok && k < a.k_pad) ? *reinterpret_cast<const f32x4*>(arow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             if (kc + 8 * kb >= a.k_pad) break;
@@ -219,38 +240,40 @@ __global__ __launch_bounds__(256) void vfn_bstat_relu_rows_kernel(const float* z
     const long long r0 = (long long)blockIdx.x * EW_ROWS, r1 = min(m, r0 + EW_ROWS);
     for (int c = threadIdx.x; c < n; c += 256) {
         const float sc = coef[c], sh = coef[n + c];
-        for (long long r = r0; r < r1; ++r) h[(size_t)r * ldh + c] = post * fmaxf(z[(size_t)r * ldz + c] * sc + sh, 0.f);
+        for (long long r = r0; r < r1; ++r) h[(size_t)r * ldh + c] = post * fmaxf(fmaf(z[(size_t)r * ldz + c], sc, sh), 0.f);
     }
 }
 
-__global__ __launch_bounds__(256) void vfn_bstat_relu_bwd_sums_kernel(const float* gr, int ldg, const float* h, int ldh, const float* z,
-                                                                       int ldz, const float* coef, long long m, int n, float post,
-                                                                       float* part) {
+// The ReLU mask is re-derived from z with the forward's own expression (fmaf(z, scale, shift) > 0): one read less per pass
+// than looking at the stored activation.
+__global__ __launch_bounds__(256) void vfn_bstat_relu_bwd_sums_kernel(const float* gr, int ldg, const float* z, int ldz, const float* coef,
+                                                                       long long m, int n, float post, float* part) {
     const long long r0 = (long long)blockIdx.x * EW_ROWS, r1 = min(m, r0 + EW_ROWS);
     for (int c = threadIdx.x; c < n; c += 256) {
-        const float mean = coef[2 * n + c], rstd = coef[3 * n + c];
+        const float sc = coef[c], sh = coef[n + c], mean = coef[2 * n + c], rstd = coef[3 * n + c];
         float s1 = 0.f, s2 = 0.f;
         for (long long r = r0; r < r1; ++r) {
-            const float g1 = h[(size_t)r * ldh + c] > 0.f ? post * gr[(size_t)r * ldg + c] : 0.f;
+            const float zv = z[(size_t)r * ldz + c];
+            const float g1 = fmaf(zv, sc, sh) > 0.f ? post * gr[(size_t)r * ldg + c] : 0.f;
             s1 += g1;
-            s2 += g1 * ((z[(size_t)r * ldz + c] - mean) * rstd);
+            s2 += g1 * ((zv - mean) * rstd);
         }
         part[((size_t)blockIdx.x * 2) * n + c] = s1;
         part[((size_t)blockIdx.x * 2 + 1) * n + c] = s2;
     }
 }
 
-__global__ __launch_bounds__(256) void vfn_bstat_relu_bwd_rows_kernel(const float* gr, int ldg, const float* h, int ldh, const float* z,
-                                                                       int ldz, const float* coef, const double* sums, long long m,
-                                                                       int n, float post, float* dz, int lddz) {
+__global__ __launch_bounds__(256) void vfn_bstat_relu_bwd_rows_kernel(const float* gr, int ldg, const float* z, int ldz, const float* coef,
+                                                                       const double* sums, long long m, int n, float post, float* dz,
+                                                                       int lddz) {
     const long long r0 = (long long)blockIdx.x * EW_ROWS, r1 = min(m, r0 + EW_ROWS);
     for (int c = threadIdx.x; c < n; c += 256) {
-        const float mean = coef[2 * n + c], rstd = coef[3 * n + c], scale = coef[c];     // scale = gamma * rstd
+        const float scale = coef[c], sh = coef[n + c], mean = coef[2 * n + c], rstd = coef[3 * n + c];     // scale = gamma * rstd
         const float ga = (float)(sums[c] / (double)m), gb = (float)(sums[n + c] / (double)m);
         for (long long r = r0; r < r1; ++r) {
-            const float g1 = h[(size_t)r * ldh + c] > 0.f ? post * gr[(size_t)r * ldg + c] : 0.f;
-            const float xh = (z[(size_t)r * ldz + c] - mean) * rstd;
-            dz[(size_t)r * lddz + c] = scale * (g1 - ga - xh * gb);
+            const float zv = z[(size_t)r * ldz + c];
+            const float g1 = fmaf(zv, scale, sh) > 0.f ? post * gr[(size_t)r * ldg + c] : 0.f;
+            dz[(size_t)r * lddz + c] = scale * (g1 - ga - (zv - mean) * rstd * gb);
         }
     }
 }
@@ -327,6 +350,7 @@ extern "C" int vfn_linear_rows(int32_t transpose_w, const float* a, int32_t lda,
     VFN_REQUIRE((lda & 3) == 0 && lda >= k_pad && ((uintptr_t)a & 15) == 0,
                 "vfn_linear_rows: A needs 16-byte aligned rows with lda (%d) >= %d (k rounded up to 8; pad columns zero)", lda, k_pad);
     VFN_REQUIRE(ldc >= n_out && ldw >= (transpose_w ? n_out : k_in), "vfn_linear_rows: ldc=%d ldw=%d too small", ldc, ldw);
+    VFN_REQUIRE((long long)(transpose_w ? k_in : n_out) * ldw * 4 < (1ll << 31), "vfn_linear_rows: W larger than 2 GiB");
     if (m <= 0) return VFN_OK;
     GemmArgs g = {};
     g.a = a; g.w = w; g.bias = bias; g.c = c; g.stats_part = stats_part; g.m = m; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
@@ -362,21 +386,20 @@ extern "C" int vfn_bstat_relu_rows(const float* z, int32_t ldz, const float* coe
     return vfn_check_launch("vfn_bstat_relu_rows");
 }
 
-extern "C" int vfn_bstat_relu_bwd_sums(const float* g, int32_t ldg, const float* h, int32_t ldh, const float* z, int32_t ldz,
-                                       const float* coef, int64_t m, int32_t n, float post_scale, float* part, void* stream) {
-    VFN_REQUIRE(g && h && z && coef && part && n >= 1, "vfn_bstat_relu_bwd_sums: bad argument");
+extern "C" int vfn_bstat_relu_bwd_sums(const float* g, int32_t ldg, const float* z, int32_t ldz, const float* coef, int64_t m, int32_t n,
+                                       float post_scale, float* part, void* stream) {
+    VFN_REQUIRE(g && z && coef && part && n >= 1, "vfn_bstat_relu_bwd_sums: bad argument");
     if (m <= 0) return VFN_OK;
-    hipLaunchKernelGGL(vfn_bstat_relu_bwd_sums_kernel, dim3(ew_blocks(m)), dim3(256), 0, (hipStream_t)stream, g, ldg, h, ldh, z, ldz,
+    hipLaunchKernelGGL(vfn_bstat_relu_bwd_sums_kernel, dim3(ew_blocks(m)), dim3(256), 0, (hipStream_t)stream, g, ldg, z, ldz,
                        coef, (long long)m, n, post_scale, part);
     return vfn_check_launch("vfn_bstat_relu_bwd_sums");
 }
 
-extern "C" int vfn_bstat_relu_bwd_rows(const float* g, int32_t ldg, const float* h, int32_t ldh, const float* z, int32_t ldz,
-                                       const float* coef, const double* sums, int64_t m, int32_t n, float post_scale, float* dz,
-                                       int32_t lddz, void* stream) {
-    VFN_REQUIRE(g && h && z && coef && sums && dz && n >= 1, "vfn_bstat_relu_bwd_rows: bad argument");
+extern "C" int vfn_bstat_relu_bwd_rows(const float* g, int32_t ldg, const float* z, int32_t ldz, const float* coef, const double* sums,
+                                       int64_t m, int32_t n, float post_scale, float* dz, int32_t lddz, void* stream) {
+    VFN_REQUIRE(g && z && coef && sums && dz && n >= 1, "vfn_bstat_relu_bwd_rows: bad argument");
     if (m <= 0) return VFN_OK;
-    hipLaunchKernelGGL(vfn_bstat_relu_bwd_rows_kernel, dim3(ew_blocks(m)), dim3(256), 0, (hipStream_t)stream, g, ldg, h, ldh, z, ldz,
+    hipLaunchKernelGGL(vfn_bstat_relu_bwd_rows_kernel, dim3(ew_blocks(m)), dim3(256), 0, (hipStream_t)stream, g, ldg, z, ldz,
                        coef, sums, (long long)m, n, post_scale, dz, lddz);
     return vfn_check_launch("vfn_bstat_relu_bwd_rows");
 }

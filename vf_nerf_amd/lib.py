@@ -595,16 +595,16 @@ def bstat_relu_rows(z, coef, m: int, n: int, post_scale: float, h) -> None:
                                       C.c_float(post_scale), h.ptr, C.c_int32(h.ld), _stream()), "vfn_bstat_relu_rows")
 
 
-def bstat_relu_bwd_sums(g, h, z, coef, m: int, n: int, post_scale: float, part) -> None:
-    g, h, z = _cols(g), _cols(h), _cols(z)
-    _check(load().vfn_bstat_relu_bwd_sums(g.ptr, C.c_int32(g.ld), h.ptr, C.c_int32(h.ld), z.ptr, C.c_int32(z.ld),
+def bstat_relu_bwd_sums(g, z, coef, m: int, n: int, post_scale: float, part) -> None:
+    g, z = _cols(g), _cols(z)
+    _check(load().vfn_bstat_relu_bwd_sums(g.ptr, C.c_int32(g.ld), z.ptr, C.c_int32(z.ld),
                                           _ptr(coef, "coef"), C.c_int64(m), C.c_int32(n), C.c_float(post_scale),
                                           _ptr(part, "part"), _stream()), "vfn_bstat_relu_bwd_sums")
 
 
-def bstat_relu_bwd_rows(g, h, z, coef, sums, m: int, n: int, post_scale: float, dz) -> None:
-    g, h, z, dz = _cols(g), _cols(h), _cols(z), _cols(dz)
-    _check(load().vfn_bstat_relu_bwd_rows(g.ptr, C.c_int32(g.ld), h.ptr, C.c_int32(h.ld), z.ptr, C.c_int32(z.ld),
+def bstat_relu_bwd_rows(g, z, coef, sums, m: int, n: int, post_scale: float, dz) -> None:
+    g, z, dz = _cols(g), _cols(z), _cols(dz)
+    _check(load().vfn_bstat_relu_bwd_rows(g.ptr, C.c_int32(g.ld), z.ptr, C.c_int32(z.ld),
                                           _ptr(coef, "coef"), _ptr(sums, "sums", torch.float64), C.c_int64(m), C.c_int32(n),
                                           C.c_float(post_scale), dz.ptr, C.c_int32(dz.ld), _stream()), "vfn_bstat_relu_bwd_rows")
 
