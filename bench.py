@@ -248,7 +248,7 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync):
     rgb_gt = torch.rand(args.rays, 3, generator=g).to(dev)
     depth_gt = (0.2 + 0.6 * torch.rand(args.rays, 1, generator=g)).to(dev)
     n_sup = (args.rays * s_t) // 10
-    bucket = vdist.GradientBucket(model) if world > 1 else None
+    bucket = vdist.GradientBucket(model) if (world > 1 or dist is not None) else None
     clip = model.config.scheduler_config.clip_norm
 
     def step():
@@ -336,8 +336,15 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     dist = None
-    if world > 1:
+    # VFN_BENCH_FORCE_DIST=1: create the RCCL process group (barriers, the max-over-ranks all-reduce, the gradient
+    # bucket) even with one rank — a single-GPU smoke test of the multi-GPU code path
+    force_dist = os.environ.get("VFN_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
