@@ -177,12 +177,14 @@ int vfn_range_fine_sample(const vfn_fine_params* p, const float* z_coarse, const
 /* The same sampler, additionally reporting the provenance of every sorted sample, so that a caller that already holds
  * per-sample results for the proposal samples (the reference evaluates the vector-field net on them twice:
  * vector_field_nerf.py:252-277 and :294-297) can evaluate only the N_f new ones and gather:
- * src[N,S_t] = ray*S_c + j for proposal sample j of the ray, N*S_c + ray*N_f + k for new sample k; new_points[N,N_f,3]
- * are the new samples in generation order.  Either may be NULL. */
+ * src[N,S_t] = ray*S_c + j for proposal sample j of the ray, new_row0 + ray*N_f + k for new sample k (new_row0 >= N*S_c:
+ * the row at which the caller stores the new samples' results); new_points[N,N_f,3] are the new samples in generation
+ * order; dst[new_row0 + N*N_f] is the inverse map, dst[src[i]] = i (rows no sample comes from are left untouched).
+ * Each of the three may be NULL. */
 int vfn_range_fine_sample_indexed(const vfn_fine_params* p, const float* z_coarse, const int64_t* argmax,
                                   const float* directions, const float* cam_loc, const float* far_per_ray,
                                   const float* u_fine, const float* u_add, float* z_vals, float* points, int32_t* src,
-                                  float* new_points, void* stream);
+                                  float* new_points, int32_t* dst, int64_t new_row0, void* stream);
 
 /* Counter-based uniforms in [0,1) for production sampling (Philox4x32-10, one 4-tuple per 4 outputs). */
 int vfn_fill_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
@@ -281,15 +283,20 @@ int vfn_mlp_bwd_chain_bf16(const vfn_net_geom* vf_geom, const void* vf_packed_bw
  * vector_field_nerf.py:252-277, then again among the S_c+N_f samples at :294-297); the two entry points below let a caller
  * evaluate it once per distinct sample and run the rendering net on gathered results — same arithmetic per sample as
  * vfn_vf_render_fused16_fwd, so the outputs are identical.
- * vfn_vf_feat16_fwd: points[M,3] -> out_vec[M,3] (tanh'ed vector columns) and out_blocks[M][1 KiB], the 256 tanh'ed features
- *   in the rendering kernel's operand format ([tile][lane half][hi|lo blocks], split f16).  M < 2^22.
- * vfn_render16_from_blocks: for sample m of the sorted batch, row src[m] of blocks / vecs (any concatenation of the buffers
- *   written above; vfn_range_fine_sample_indexed produces src) feeds the rendering net with points[m], ray_dirs[m / S];
- *   outputs normals[M,3] (= the gathered vector columns) and colors[M,3]. */
+ * vfn_vf_feat16_fwd: points[M,3] -> out_vec[M,3] (tanh'ed vector columns) and out_blocks, the 256 tanh'ed features in the
+ *   rendering kernel's operand format (split f16): 32 KiB per group of 32 consecutive rows,
+ *   [operand block 0..15][hi | lo][lane 0..63][16 B], i.e. the register image of the wave that owns those rows — every store
+ *   and every later load moves 1 KiB of consecutive bytes.  The buffer holds ceil(M / 32) groups (rows past M in the last
+ *   group are written with don't-care values); a launch must start on a group boundary of the buffer.  M < 2^22.
+ * vfn_render16_from_blocks: the rendering net over the n_rows stored rows, in storage order: row r has its features in
+ *   blocks, its vector columns in vecs[r], and dst[r] = its position among the sorted samples of the batch
+ *   (vfn_range_fine_sample_indexed produces dst; dst[r] < 0 marks a padding row): position points[dst[r]], view direction
+ *   ray_dirs[dst[r] / S]; writes normals[dst[r]] (= vecs[r]) and colors[dst[r]].  The rendering net is pointwise, so the
+ *   result equals vfn_vf_render_fused16_fwd on the sorted samples. */
 int vfn_vf_feat16_fwd(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
                       float* out_vec, void* out_blocks, void* stream);
 int vfn_render16_from_blocks(const vfn_net_geom* rn_geom, const void* rn_packed16, const void* blocks, const float* vecs,
-                             const int32_t* src, const float* points, const float* ray_dirs, int64_t n_points,
+                             const int32_t* dst, const float* points, const float* ray_dirs, int64_t n_rows,
                              int32_t samples_per_ray, float* normals, float* colors, void* stream);
 
 /* From partial slabs to parameter gradients, all layer entries of a net in one launch: sums the `groups` slabs written

@@ -74,7 +74,7 @@ def test_partial_tile_and_large_batch():
 
 def test_proposal_reuse_equals_fused_pass():
     """render() with the VF net evaluated once per distinct sample (vfn_vf_feat16_fwd on the proposal samples, again on the
-    N_f new ones, vfn_render16_from_blocks on the gathered features) against the single fused launch over all S_c+N_f
+    N_f new ones, vfn_render16_from_blocks over the stored rows, scattering to the sorted positions) against the single fused launch over all S_c+N_f
     samples: same per-sample arithmetic, so every output must agree to the last bit — including ragged ray counts, the
     all-zero-weights branch (argmax 0 -> uniform extra samples) and per-ray far."""
     import torch
@@ -119,3 +119,13 @@ def test_fine_sampler_provenance_index():
     expect = torch.cat([torch.arange(n)[:, None] * s_c + torch.arange(s_c)[None, :],
                         n * s_c + torch.arange(n)[:, None] * n_f + torch.arange(n_f)[None, :]], dim=1).int()
     assert torch.equal(rows, expect)
+    # the inverse map, with the new samples' rows moved to a 32-row group boundary (as render() stores them): padding
+    # rows stay -1, every other row names the sorted position it went to
+    row0 = lib.block_rows(n * s_c)
+    assert row0 > n * s_c                      # 37 * 16 = 592 -> 608: the layout has padding rows in this case
+    z2, p2, src2, newp2, dst = lib.range_fine_sample_indexed(z_c, imax, dirs, cam, n_f, 0.0, 1.0, 0.3, u_add, u_fine,
+                                                             new_row0=row0, want_dst=True)
+    assert torch.equal(z2, z1) and torch.equal(newp2, newp)
+    assert dst.shape[0] == row0 + n * n_f and bool((dst[n * s_c:row0] == -1).all())
+    assert torch.equal(torch.where(src >= n * s_c, src + (row0 - n * s_c), src), src2)
+    assert torch.equal(dst[src2.reshape(-1).long()].cpu(), torch.arange(n * (s_c + n_f), dtype=torch.int32))

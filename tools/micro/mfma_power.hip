@@ -9,7 +9,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ unsigned hashu(unsigned x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
 
-template <int VARIANT>   // bit 0: random operands; bit 2: A fragments from LDS (2 ds_read_b128 per 3 MFMAs)
+template <int VARIANT>   // bit 0: random operands; bit 2: A fragments from LDS (2 ds_read_b128 per 3 MFMAs); bit 3: two independent
+                         // accumulator chains (the cross terms a_hi*b_lo + a_lo*b_hi in their own accumulator)
 __global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* stamps, int iters) {
     __shared__ __attribute__((aligned(16))) uint4 lds[8192];
     const int lane = threadIdx.x & 63;
@@ -30,8 +31,8 @@ __global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* stam
     half8 b[4];
     for (int q = 0; q < 4; ++q) b[q] = __builtin_bit_cast(half8, lds[(q * 64 + lane + 4096) & 8191]);
     half8 areg[2] = {__builtin_bit_cast(half8, lds[lane]), __builtin_bit_cast(half8, lds[64 + lane])};
-    f32x16 acc;
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    f32x16 acc, acc2;
+    for (int q = 0; q < 16; ++q) { acc[q] = 0.f; acc2[q] = 0.f; }
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -42,14 +43,20 @@ __global__ __launch_bounds__(256, 1) void k(float* out, unsigned long long* stam
                 a1 = __builtin_bit_cast(half8, lds[(u * 128 + 64 + lane) & 4095]);
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[u & 3], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[(u + 1) & 3], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[u & 3], acc, 0, 0, 0);
+            if (VARIANT & 8) {
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[(u + 1) & 3], acc2, 0, 0, 0);
+                if (u & 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[u & 3], acc, 0, 0, 0);
+                else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[u & 3], acc2, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[(u + 1) & 3], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[u & 3], acc, 0, 0, 0);
+            }
         }
-        if ((it & 7) == 7) for (int q = 0; q < 16; ++q) acc[q] *= 1e-3f;   // keep the sums finite
+        if ((it & 7) == 7) for (int q = 0; q < 16; ++q) { acc[q] *= 1e-3f; acc2[q] *= 1e-3f; }   // keep the sums finite
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
-    for (int q = 0; q < 16; ++q) s += acc[q];
+    for (int q = 0; q < 16; ++q) s += acc[q] + acc2[q];
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
@@ -74,5 +81,8 @@ int main() {
     run<1>("random operands, registers");
     run<4>("constant operands, A from LDS");
     run<5>("random operands, A from LDS");
+    run<9>("random operands, registers, 2 chains");
+    run<13>("random operands, A from LDS, 2 chains");
+    run<8>("constant operands, registers, 2 chains");
     return 0;
 }

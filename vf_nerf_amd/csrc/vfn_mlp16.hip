@@ -328,9 +328,9 @@ struct Mlp16Args {
     float* save_aux_rn;
     // split launches: feature operand blocks, 1 KiB per point: [tile t][lane half g][hi 2t | lo 2t | hi 2t+1 | lo 2t+1] x 16 B
     uint4* blk_out;           // M16_BLKOUT: written for rows 0 .. n_points-1
-    const uint4* blk_in;      // M16_BLKIN: row src[m] feeds point m
-    const float* vec_in;      // M16_BLKIN: [rows,3] vector outputs of the feature launches (gathered like blk_in)
-    const int* src;           // M16_BLKIN: [M]
+    const uint4* blk_in;      // M16_BLKIN: block buffer, groups of 32 rows (store_blocks)
+    const float* vec_in;      // M16_BLKIN: [rows,3] vector outputs of the feature launches
+    const int* src;           // M16_BLKIN: [rows] position of every row among the sorted samples (< 0: padding row)
 };
 
 struct X16 { half8 hi[16]; half8 lo[16]; };     // 256 activation columns x this lane's point, split (16 K-blocks of 16)
@@ -453,15 +453,17 @@ __device__ __forceinline__ void save_group(const Pipe16& p, const f32x16& v, int
 //   last step    the bias and first fragments of chunk c+1 (cy).
 // The last tile of a layer is handed to the next layer call in cy.pend (PEPI = its epilogue, PKB = the K-block pair of
 // `xpend` it becomes); it is needed only by K steps PKB, PKB+1 of that layer's first tile.
-// Operand blocks 2 TILE, 2 TILE + 1 of `x` (one finished feature tile) -> this point's row of the block buffer.
+// Operand blocks 2 TILE, 2 TILE + 1 of `x` (one finished feature tile) -> the block buffer, in the registers' own order:
+// the 32 points of a wave form a 32 KiB group [operand block 0..15][hi | lo][lane 0..63][16 B], so every store (and every
+// load of the rendering launch, whose waves own the same 32 rows) moves 1 KiB of consecutive bytes.
 template <int TILE>
 __device__ __forceinline__ void store_blocks(const Pipe16& p, const X16& x) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.blk_out, 0, (int)p.blk_bytes, 0x00020000);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x.hi[2 * TILE + s]), rs, (int)p.blk_voff, TILE * 128 + s * 32, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x.lo[2 * TILE + s]), rs, (int)p.blk_voff, TILE * 128 + s * 32 + 16, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x.hi[2 * TILE + s]), rs, (int)p.blk_voff, (2 * TILE + s) * 2048, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x.lo[2 * TILE + s]), rs, (int)p.blk_voff, (2 * TILE + s) * 2048 + 1024, 0);
     }
 }
 
@@ -674,8 +676,8 @@ __device__ __forceinline__ void render_tail(const Mlp16Args& a, const Pipe16& p,
     layer16<MODE, C0 + 24, 16, 0, 8, R, R, 14, 12, 11>(xa, aux, xb, xa, cy, rgb, p, wave, lane);      // R3 -> xb
     layer16<MODE, C0 + 32, 16, 0, 1, EPI_HEAD_SIGMOID, R, 14, -1, 12>(xb, aux, xa, xb, cy, rgb, p, wave, lane);
     // outputs last: the only vector-memory stores of the kernel come after the last DMA wait
-    const long long mo = (long long)blockIdx.x * VFN16_PTS + (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
-    if (mo < a.n_points && (threadIdx.x & 32) == 0) {
+    const long long mo = m;        // fused launches: the point's own row; from blocks: its position among the sorted samples
+    if (in && (threadIdx.x & 32) == 0) {
         a.out_vec[mo * 3 + 0] = nrm[0]; a.out_vec[mo * 3 + 1] = nrm[1]; a.out_vec[mo * 3 + 2] = nrm[2];
         a.out_colors[mo * 3 + 0] = rgb[0]; a.out_colors[mo * 3 + 1] = rgb[1]; a.out_colors[mo * 3 + 2] = rgb[2];
     }
@@ -701,20 +703,23 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
 
     if constexpr ((MODE & M16_BLKIN) != 0) {
         // ---- rendering net only: this point's feature operand, normal, position and view direction come from memory ----
-        const int srow = in ? a.src[m] : 0;
+        // row m of the block / vector buffers is this lane's sample; dst[m] is its position among the sorted samples
+        // (points, view direction and outputs live there), negative for padding rows
+        const int dpos = in ? a.src[m] : -1;
+        const bool live = dpos >= 0;
         float xr[3] = {0.f, 0.f, 0.f}, dr[3] = {0.f, 0.f, 0.f}, nrm[3] = {0.f, 0.f, 0.f};
-        if (in) {
-            const long long di = m / a.dirs_div;
+        if (live) {
+            const long long di = dpos / a.dirs_div;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { xr[c] = a.points[m * 3 + c]; dr[c] = a.ray_dirs[di * 3 + c]; nrm[c] = a.vec_in[(long long)srow * 3 + c]; }
+            for (int c = 0; c < 3; ++c) { xr[c] = a.points[(long long)dpos * 3 + c]; dr[c] = a.ray_dirs[di * 3 + c]; nrm[c] = a.vec_in[m * 3 + c]; }
         }
         X16 xa, xb;
         {
-            const uint4* row = a.blk_in + (size_t)srow * 64 + g * 4;      // 64 uint4 per point, 4 per (tile, lane half)
+            const uint4* grp = a.blk_in + (size_t)(m >> 5) * 2048 + lane;      // 32 KiB per 32 rows, see store_blocks
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                uint4 q0 = row[t * 8 + 0], q1 = row[t * 8 + 1], q2 = row[t * 8 + 2], q3 = row[t * 8 + 3];
-                if (!in) { q0 = uint4{0, 0, 0, 0}; q1 = q0; q2 = q0; q3 = q0; }
+                uint4 q0 = uint4{0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
+                if (in) { q0 = grp[(4 * t + 0) * 64]; q1 = grp[(4 * t + 1) * 64]; q2 = grp[(4 * t + 2) * 64]; q3 = grp[(4 * t + 3) * 64]; }
                 half8 h0 = __builtin_bit_cast(half8, q0), l0 = __builtin_bit_cast(half8, q1);
                 half8 h1 = __builtin_bit_cast(half8, q2), l1 = __builtin_bit_cast(half8, q3);
                 asm volatile("" : "+a"(h0)); asm volatile("" : "+a"(l0)); asm volatile("" : "+a"(h1)); asm volatile("" : "+a"(l1));
@@ -735,7 +740,7 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) cy.pend[q] = 0.f;
         prefetch_chunk<MODE, 0>(cy, p, lane);
-        render_tail<MODE>(a, p, cy, xa, xb, xr, dr, nrm, m, in, g, wave, lane);
+        render_tail<MODE>(a, p, cy, xa, xb, xr, dr, nrm, live ? (long long)dpos : -1, live, g, wave, lane);
     } else {
     // this lane's point (the two lane halves of a wave share the 32 points); loaded BEFORE any DMA
     float x[3] = {0.f, 0.f, 0.f};
@@ -758,7 +763,8 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
                                                (int)((MODE & M16_RENDER) ? a.rn_bytes : a.vf_bytes), 0x00020000);
     p.saved = a.saved; p.slot_floats = a.n_points * 256; p.slot_bytes = (uint32_t)(a.n_points * 1024);
     p.save_voff = in ? (uint32_t)(m * 1024 + g * 16) : 0xfffffff0u;
-    p.blk_out = a.blk_out; p.blk_bytes = (uint32_t)(a.n_points * 1024); p.blk_voff = in ? (uint32_t)(m * 1024 + g * 64) : 0xfffffff0u;
+    p.blk_out = a.blk_out; p.blk_bytes = (uint32_t)(((a.n_points + 31) & ~31ll) * 1024);
+    p.blk_voff = (uint32_t)((m >> 5) * 32768 + lane * 16);      // past the last group -> out of the descriptor's range, dropped
     dma_chunk<MODE, 0>(p, wave, lane);
     dma_chunk<MODE, 1>(p, wave, lane);
 
@@ -920,7 +926,7 @@ extern "C" int vfn_vf_feat16_fwd(const vfn_net_geom* geom, const void* packed16,
 }
 
 extern "C" int vfn_render16_from_blocks(const vfn_net_geom* rn_geom, const void* rn_packed16, const void* blocks, const float* vecs,
-                                        const int32_t* src, const float* points, const float* ray_dirs, int64_t n_points,
+                                        const int32_t* dst, const float* points, const float* ray_dirs, int64_t n_points,
                                         int32_t samples_per_ray, float* normals, float* colors, void* stream) {
     Mlp16Args a = {};
     VfnNetPlan p32; Plan16 rn;
@@ -930,11 +936,11 @@ extern "C" int vfn_render16_from_blocks(const vfn_net_geom* rn_geom, const void*
     if (rc != VFN_OK) return rc;
     VFN_REQUIRE(rn_geom->feature_dims == VFN_HIDDEN, "vfn_render16_from_blocks: feature_dims must be %d", VFN_HIDDEN);
     if (n_points <= 0) return VFN_OK;
-    VFN_REQUIRE(rn_packed16 && blocks && vecs && src && points && ray_dirs && normals && colors, "vfn_render16_from_blocks: NULL argument");
+    VFN_REQUIRE(rn_packed16 && blocks && vecs && dst && points && ray_dirs && normals && colors, "vfn_render16_from_blocks: NULL argument");
     VFN_REQUIRE(samples_per_ray > 0, "vfn_render16_from_blocks: samples_per_ray must be > 0");
     a.rn_w = (const uint4*)rn_packed16; a.vf_w = a.rn_w; a.points = points; a.ray_dirs = ray_dirs; a.out_vec = normals; a.out_colors = colors;
     a.n_points = n_points; a.dirs_div = samples_per_ray; a.rn_multires = rn.multires; a.rn_bytes = rn.total_kb * 1024u; a.vf_bytes = a.rn_bytes;
-    a.blk_in = (const uint4*)blocks; a.vec_in = vecs; a.src = src;
+    a.blk_in = (const uint4*)blocks; a.vec_in = vecs; a.src = dst;
     const long long nblocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     hipLaunchKernelGGL(vfn_mlp16_kernel<M16_RN_BLK>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_render16_from_blocks");

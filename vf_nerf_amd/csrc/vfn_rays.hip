@@ -529,8 +529,10 @@ struct FineArgs {
     float* z_vals;
     float* points;
     // optional (vfn_range_fine_sample_indexed): where each sorted sample comes from, and the new samples on their own
-    int* src;            // [N,S_t]: coarse sample j of the ray -> ray*S_c + j; new sample k -> N*S_c + ray*N_f + k
+    int* src;            // [N,S_t]: coarse sample j of the ray -> ray*S_c + j; new sample k -> new_row0 + ray*N_f + k
     float* new_points;   // [N,N_f,3] in generation order
+    int* dst;            // the inverse: dst[src[i]] = i (sorted position of every stored sample), or NULL
+    int new_row0;        // first row of the new samples in the caller's row numbering (N*S_c, or rounded up)
 };
 
 __global__ __launch_bounds__(256) void vfn_fine_kernel(const FineArgs a) {
@@ -577,7 +579,9 @@ __global__ __launch_bounds__(256) void vfn_fine_kernel(const FineArgs a) {
             rank += (o < v || (o == v && j < i)) ? 1 : 0;
         }
         so[rank] = v;
-        if (a.src) a.src[(size_t)ray * St + rank] = i < Sc ? ray * Sc + i : a.p.n_rays * Sc + ray * Nf + (i - Sc);
+        const int row = i < Sc ? ray * Sc + i : a.new_row0 + ray * Nf + (i - Sc);
+        if (a.src) a.src[(size_t)ray * St + rank] = row;
+        if (a.dst) a.dst[row] = ray * St + rank;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -716,20 +720,23 @@ extern "C" int vfn_range_fine_sample(const vfn_fine_params* p, const float* z_co
                                      const float* directions, const float* cam_loc, const float* far_per_ray,
                                      const float* u_fine, const float* u_add, float* z_vals, float* points, void* stream) {
     return vfn_range_fine_sample_indexed(p, z_coarse, argmax, directions, cam_loc, far_per_ray, u_fine, u_add, z_vals, points,
-                                         nullptr, nullptr, stream);
+                                         nullptr, nullptr, nullptr, p ? (int64_t)p->n_rays * p->n_coarse : 0, stream);
 }
 
 extern "C" int vfn_range_fine_sample_indexed(const vfn_fine_params* p, const float* z_coarse, const int64_t* argmax,
                                              const float* directions, const float* cam_loc, const float* far_per_ray,
                                              const float* u_fine, const float* u_add, float* z_vals, float* points,
-                                             int32_t* src, float* new_points, void* stream) {
+                                             int32_t* src, float* new_points, int32_t* dst, int64_t new_row0, void* stream) {
     if (p && p->n_rays <= 0) return VFN_OK;
     VFN_REQUIRE(p && z_coarse && argmax && directions && cam_loc && u_add && z_vals && points,
                 "vfn_range_fine_sample: NULL argument (u_add is always required, ray_sampler.py:292)");
     VFN_REQUIRE(p->n_coarse >= 1 && p->n_fine >= 2 && p->n_coarse + p->n_fine <= MAX_SAMPLES,
                 "vfn_range_fine_sample: bad sizes (n_coarse=%d, n_fine=%d)", p->n_coarse, p->n_fine);
     VFN_REQUIRE((long long)p->n_rays * (p->n_coarse + p->n_fine) < (1ll << 31), "vfn_range_fine_sample: more than 2^31 samples");
-    FineArgs a{*p, z_coarse, (const long long*)argmax, directions, cam_loc, far_per_ray, u_fine, u_add, z_vals, points, src, new_points};
+    VFN_REQUIRE(new_row0 >= (long long)p->n_rays * p->n_coarse && new_row0 + (long long)p->n_rays * p->n_fine < (1ll << 31),
+                "vfn_range_fine_sample_indexed: new_row0=%lld must not overlap the proposal rows", (long long)new_row0);
+    FineArgs a{*p, z_coarse, (const long long*)argmax, directions, cam_loc, far_per_ray, u_fine, u_add, z_vals, points, src, new_points,
+               dst, (int)new_row0};
     const unsigned blocks = (unsigned)((p->n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
     const size_t shmem = (size_t)RAYS_PER_BLOCK * (p->n_coarse + p->n_fine) * 2 * sizeof(float);
     hipLaunchKernelGGL(vfn_fine_kernel, dim3(blocks), dim3(256), shmem, (hipStream_t)stream, a);

@@ -257,9 +257,16 @@ def range_fine_sample(z_coarse, argmax, directions, cam_loc, n_fine, near, far, 
     return z, pts
 
 
+def block_rows(m: int) -> int:
+    """Rows a block buffer needs for m stored rows: whole groups of 32 (vfn_vf_feat16_fwd)."""
+    return (m + 31) & ~31
+
+
 def range_fine_sample_indexed(z_coarse, argmax, directions, cam_loc, n_fine, near, far, fine_range, u_add, u_fine=None,
-                              far_per_ray=None):
-    """range_fine_sample plus src[N,S_t] (int32 provenance of every sorted sample) and new_points[N,N_f,3]."""
+                              far_per_ray=None, new_row0: Optional[int] = None, want_dst: bool = False):
+    """range_fine_sample plus src[N,S_t] (int32: the stored row every sorted sample comes from; the new samples' rows start
+    at ``new_row0``, default N*S_c) and new_points[N,N_f,3]; with ``want_dst`` also the inverse map dst[new_row0 + N*N_f]
+    (int32, -1 for rows no sample comes from)."""
     n, sc = z_coarse.shape
     dev = z_coarse.device
     step = 2 * fine_range / (n_fine - 1)
@@ -270,13 +277,20 @@ def range_fine_sample_indexed(z_coarse, argmax, directions, cam_loc, n_fine, nea
     pts = torch.empty(n, sc + n_fine, 3, device=dev)
     src = torch.empty(n, sc + n_fine, dtype=torch.int32, device=dev)
     new_pts = torch.empty(n, n_fine, 3, device=dev)
+    row0 = n * sc if new_row0 is None else int(new_row0)
+    dst = None
+    if want_dst:
+        rows = row0 + n * n_fine
+        dst = torch.empty(rows, dtype=torch.int32, device=dev) if row0 == n * sc else \
+            torch.full((rows,), -1, dtype=torch.int32, device=dev)
     _check(load().vfn_range_fine_sample_indexed(C.byref(p), _ptr(z_coarse, "z_coarse"), _ptr(argmax, "argmax", torch.int64),
                                                 _ptr(directions, "directions"), _ptr(cam_loc, "cam_loc"),
                                                 _ptr(far_per_ray, "far_per_ray"), _ptr(u_fine, "u_fine"),
                                                 _ptr(u_add, "u_add"), _ptr(z, "z_vals"), _ptr(pts, "points"),
-                                                _ptr(src, "src", torch.int32), _ptr(new_pts, "new_points"), _stream()),
+                                                _ptr(src, "src", torch.int32), _ptr(new_pts, "new_points"),
+                                                _ptr(dst, "dst", torch.int32), C.c_int64(row0), _stream()),
            "vfn_range_fine_sample_indexed")
-    return z, pts, src, new_pts
+    return (z, pts, src, new_pts, dst) if want_dst else (z, pts, src, new_pts)
 
 
 def fill_uniform(out: torch.Tensor, seed: int, offset: int) -> torch.Tensor:
@@ -436,22 +450,31 @@ BLOCK_BYTES = 1024   # one point's 256 features as split-f16 operand blocks
 
 
 def vf_feat16_fwd(geom: NetGeom, packed16, points, out_vec, out_blocks) -> None:
-    """VF net on points[M,3]; writes out_vec[M,3] and out_blocks[M, 1024] (uint8) — slices of larger buffers are fine."""
+    """VF net on points[M,3]; writes out_vec[M,3] and the feature operand blocks: out_blocks[block_rows(M), 1024] (uint8),
+    32-row groups in the rendering kernel's register order — slices of larger buffers are fine when they start on a
+    multiple of 32 rows."""
     m = points.shape[0]
+    if out_blocks.shape[0] < block_rows(m):
+        raise VfnError(f"out_blocks holds {out_blocks.shape[0]} rows, {block_rows(m)} (whole groups of 32) are needed")
     _check(load().vfn_vf_feat16_fwd(C.byref(geom), _ptr(packed16, "packed16", torch.uint8), _ptr(points, "points"),
                                     C.c_int64(m), _ptr(out_vec, "out_vec"), _ptr(out_blocks, "out_blocks", torch.uint8),
                                     _stream()), "vfn_vf_feat16_fwd")
 
 
-def render16_from_blocks(rn_geom: NetGeom, rn_packed16, blocks, vecs, src, points, ray_dirs, samples_per_ray: int):
+def render16_from_blocks(rn_geom: NetGeom, rn_packed16, blocks, vecs, dst, points, ray_dirs, samples_per_ray: int):
+    """Rendering net over the stored rows: row r -> sorted position dst[r] (points[dst[r]], ray_dirs[dst[r] / S]); returns
+    normals[M,3], colors[M,3] in sorted order (M = points.shape[0]; every sorted sample must be some row's dst)."""
     m = points.shape[0]
+    n_rows = dst.shape[0]
     dev = points.device
+    if blocks.shape[0] < block_rows(n_rows) or vecs.shape[0] < n_rows:
+        raise VfnError(f"{n_rows} rows need blocks[{block_rows(n_rows)}] and vecs[{n_rows}]")
     normals = torch.empty(m, 3, device=dev)
     colors = torch.empty(m, 3, device=dev)
     _check(load().vfn_render16_from_blocks(C.byref(rn_geom), _ptr(rn_packed16, "rn_packed16", torch.uint8),
                                            _ptr(blocks, "blocks", torch.uint8), _ptr(vecs, "vecs"),
-                                           _ptr(src, "src", torch.int32), _ptr(points, "points"), _ptr(ray_dirs, "ray_dirs"),
-                                           C.c_int64(m), C.c_int32(samples_per_ray), _ptr(normals, "normals"),
+                                           _ptr(dst, "dst", torch.int32), _ptr(points, "points"), _ptr(ray_dirs, "ray_dirs"),
+                                           C.c_int64(n_rows), C.c_int32(samples_per_ray), _ptr(normals, "normals"),
                                            _ptr(colors, "colors"), _stream()), "vfn_render16_from_blocks")
     return normals, colors
 

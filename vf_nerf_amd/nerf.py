@@ -320,11 +320,13 @@ class VectorFieldNerf:
             # (3) VF net on the proposal samples: vector columns (and, when they will be reused, the feature blocks)
             vf = self.vector_field_network
             if reuse:
+                # stored rows: the proposal samples, then (on a 32-row group boundary of the block buffer) the new ones
                 m_c, m_n = n * s_c, n * n_f
-                blocks = torch.empty(m_c + m_n, lib.BLOCK_BYTES, dtype=torch.uint8, device=dev)
-                vecs = torch.empty(m_c + m_n, 3, device=dev)
+                row0 = lib.block_rows(m_c)
+                blocks = torch.empty(row0 + lib.block_rows(m_n), lib.BLOCK_BYTES, dtype=torch.uint8, device=dev)
+                vecs = torch.empty(row0 + m_n, 3, device=dev)
                 with self._timed("vf_feat16"):
-                    lib.vf_feat16_fwd(vf.geometry(), vf.packed16_weights(), pts_c.view(-1, 3), vecs[:m_c], blocks[:m_c])
+                    lib.vf_feat16_fwd(vf.geometry(), vf.packed16_weights(), pts_c.view(-1, 3), vecs[:m_c], blocks[:row0])
                 normals_c = vecs[:m_c]
             elif self.uses_f16x3():
                 normals_c = lib.vf_mlp16_fwd(vf.geometry(), vf.packed16_weights(), pts_c.view(-1, 3))
@@ -342,8 +344,9 @@ class VectorFieldNerf:
             u_add = draw("u_add", (n, n_f), True)
             far, far_t = self._far_args(self.fine_sampler.far)
             if reuse:
-                z, pts, src, new_pts = lib.range_fine_sample_indexed(z_c, imax, directions, cam_loc, n_f, self.fine_sampler.near,
-                                                                     far, self.fine_sampler.range, u_add, u_fine, far_t)
+                z, pts, _, new_pts, dst = lib.range_fine_sample_indexed(z_c, imax, directions, cam_loc, n_f, self.fine_sampler.near,
+                                                                        far, self.fine_sampler.range, u_add, u_fine, far_t,
+                                                                        new_row0=row0, want_dst=True)
             else:
                 z, pts = lib.range_fine_sample(z_c, imax, directions, cam_loc, n_f, self.fine_sampler.near, far,
                                                self.fine_sampler.range, u_add, u_fine, far_t)
@@ -353,9 +356,9 @@ class VectorFieldNerf:
             with torch.no_grad():
                 rn = self.rendering_network
                 with self._timed("vf_feat16"):
-                    lib.vf_feat16_fwd(vf.geometry(), vf.packed16_weights(), new_pts.view(-1, 3), vecs[m_c:], blocks[m_c:])
-                with self._timed("render16"):
-                    normals, colors = lib.render16_from_blocks(rn.geometry(), rn.packed16_weights(), blocks, vecs, src.view(-1),
+                    lib.vf_feat16_fwd(vf.geometry(), vf.packed16_weights(), new_pts.view(-1, 3), vecs[row0:], blocks[row0:])
+                with self._timed("render16"):      # over the stored rows; results land at their sorted positions
+                    normals, colors = lib.render16_from_blocks(rn.geometry(), rn.packed16_weights(), blocks, vecs, dst,
                                                                pts.view(-1, 3), ray_dirs, s_t)
                 _, weights, _, rgb, depth = lib.ray_density_weights(self._density_params(), normals, ray_dirs, z, scal,
                                                                     colors=colors, want_sigma=False)
