@@ -212,3 +212,35 @@ def test_supervision_forward_in_training_mode_is_differentiable():
     for k in ("layers.2.0.weight", "layers.8.weight", "layers.5.1.weight"):
         got = dict(model.vector_field_network.named_parameters())[k].grad
         assert grad_rel_err(got, sd[k].grad) <= 2e-3, (k, grad_rel_err(got, sd[k].grad))
+
+
+def test_batch_statistics_layer_at_full_size():
+    """One BatchNorm'ed layer at the size of the headline chunk (524 288 rows): GEMM, column statistics, finalize and the
+    ReLU against torch on the same device in float64 — the partial-sum tree (4 096 workgroup partials per column, finished
+    in double) must hold the 1e-6 level of the small cases."""
+    from vf_nerf_amd import batchstat
+    torch.manual_seed(11)
+    m, k, n = 524288, 256, 256
+    x = torch.randn(m, k, device=DEV)
+    w = torch.randn(n, k, device=DEV) * 0.1
+    b, gamma, beta = torch.randn(n, device=DEV), torch.rand(n, device=DEV) + 0.5, torch.randn(n, device=DEV)
+    z = torch.empty(m, n, device=DEV)
+    parts = lib.linear_rows_stat_parts(m)
+    part = torch.empty(parts, 2, n, device=DEV)
+    lib.linear_rows(x, w, b, m, n, k, z, stats_part=part)
+    sums = torch.empty(2, n, dtype=torch.float64, device=DEV)
+    lib.colsum_finish(part, parts, 2 * n, sums)
+    rm, rv = torch.zeros(n, device=DEV), torch.ones(n, device=DEV)
+    coef = torch.empty(4, n, device=DEV)
+    lib.bstat_finalize(sums, m, n, gamma, beta, batchstat.BN_EPS, batchstat.BN_MOMENTUM, rm, rv, coef)
+    h = torch.empty(m, n, device=DEV)
+    lib.bstat_relu_rows(z, coef, m, n, 1.0, h)
+    z64 = x.double() @ w.double().t() + b.double()
+    assert float((z.double() - z64).abs().max()) <= 2e-6 * float(z64.abs().max())
+    mean, var = z64.mean(0), z64.var(0, unbiased=False)
+    assert float((coef[2].double() - mean).abs().max()) <= 1e-6 * max(1.0, float(mean.abs().max()))
+    assert float((coef[3].double() - 1 / torch.sqrt(var + 1e-5)).abs().max()) <= 1e-5 * float((1 / torch.sqrt(var + 1e-5)).max())
+    want_h = torch.relu((z64 - mean) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double())
+    assert float((h.double() - want_h).abs().max()) <= 2e-5
+    assert float((rm.double() - 0.1 * mean).abs().max()) <= 1e-6 * max(1.0, float(mean.abs().max()))
+    assert float((rv.double() - (0.9 + 0.1 * var * m / (m - 1))).abs().max()) <= 1e-5 * max(1.0, float(var.max()))
