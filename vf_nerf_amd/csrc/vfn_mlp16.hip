@@ -706,13 +706,8 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
         // row m of the block / vector buffers is this lane's sample; dst[m] is its position among the sorted samples
         // (points, view direction and outputs live there), negative for padding rows
         const int dpos = in ? a.src[m] : -1;
-        const bool live = dpos >= 0;
-        float xr[3] = {0.f, 0.f, 0.f}, dr[3] = {0.f, 0.f, 0.f}, nrm[3] = {0.f, 0.f, 0.f};
-        if (live) {
-            const long long di = dpos / a.dirs_div;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { xr[c] = a.points[(long long)dpos * 3 + c]; dr[c] = a.ray_dirs[di * 3 + c]; nrm[c] = a.vec_in[m * 3 + c]; }
-        }
+        // the 128 KiB of operands first (they do not depend on dpos); the loads that do are queued behind them, so the
+        // round trip of dst[m] hides under the operand transfer instead of preceding it
         X16 xa, xb;
         {
             const uint4* grp = a.blk_in + (size_t)(m >> 5) * 2048 + lane;      // 32 KiB per 32 rows, see store_blocks
@@ -725,6 +720,13 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
                 asm volatile("" : "+a"(h0)); asm volatile("" : "+a"(l0)); asm volatile("" : "+a"(h1)); asm volatile("" : "+a"(l1));
                 xb.hi[2 * t] = h0; xb.lo[2 * t] = l0; xb.hi[2 * t + 1] = h1; xb.lo[2 * t + 1] = l1;
             }
+        }
+        const bool live = dpos >= 0;
+        float xr[3] = {0.f, 0.f, 0.f}, dr[3] = {0.f, 0.f, 0.f}, nrm[3] = {0.f, 0.f, 0.f};
+        if (live) {
+            const long long di = dpos / a.dirs_div;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { xr[c] = a.points[(long long)dpos * 3 + c]; dr[c] = a.ray_dirs[di * 3 + c]; nrm[c] = a.vec_in[m * 3 + c]; }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         Pipe16 p;

@@ -331,6 +331,131 @@ __global__ __launch_bounds__(256, 1) void vfn_dw_kernel(const DwArgs a) {
     }
 }
 
+// The two thin shapes with 16-byte loads on their wide operand.  One buffer_load_b128 hands a lane four consecutive
+// columns c0 + 4 i + j of its row: they feed FOUR tiles (tile j takes column 4 i + j as its row/column i — a permutation of
+// which output index sits in which tile, undone when the slab is written), so the wide operand costs one load per row
+// pair instead of four, in 512-byte pieces.  Waves (ws, wx) = (half of the workgroup's rows, 128-column
+// span of the wide operand); the two row halves are added through LDS, one slab per workgroup.
+//   WIDE_A: A = dY[M][256] wide (n = 128 wx + 4 i + j), B = X[M][<=64] by scalar loads (2 tiles)      -> [256][64] slab
+//   else  : A = dY[M][<=32] by scalar loads (1 tile), B = X[M][256] wide (k = 128 wx + 4 i + j)       -> [32][256] slab
+template <bool WIDE_A>
+__global__ __launch_bounds__(256, 1) void vfn_dw_thin_kernel(const DwArgs a) {
+    constexpr int U = 8;
+    constexpr int NA = WIDE_A ? 4 : 1, NB = WIDE_A ? 2 : 4;
+    __shared__ float s_red[2][NA * NB * 16 + NA][64];      // the ws = 1 waves' accumulators (and column sums)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ws = wave >> 1, wx = wave & 1;
+    const int c = lane & 31, h = lane >> 5;
+    const int G = gridDim.x, g = blockIdx.x;
+    // the workgroup's slab of row pairs (the same partition as vfn_dw_kernel), split in two halves of whole load groups
+    const long long pairs = (a.n_points + 1) / 2;
+    const long long per = (pairs + G - 1) / G;
+    const long long s0 = g * per, s1 = min(pairs, s0 + per);
+    const long long half = (((s1 - s0 + 1) / 2 + 2 * U - 1) / (2 * U)) * (2 * U);
+    const long long p0 = ws == 0 ? s0 : min(s1, s0 + half), p1 = ws == 0 ? min(s1, s0 + half) : s1;
+
+    f32x16 acc[NA][NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int t = 0; t < NB; ++t) acc[i][t] = splat16(0.f);
+    float bsum[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) bsum[i] = 0.f;
+
+    const long long r_base = 2 * p0;
+    const long long rows_slab = max(0LL, min(2 * (p1 - p0), a.n_points - r_base));
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.dy + (size_t)r_base * a.ld_dy), 0, (int)(rows_slab * a.ld_dy * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x + (size_t)r_base * a.ld_x), 0, (int)(rows_slab * a.ld_x * 4), 0x00020000);
+    constexpr unsigned OOB = 0x7fffffffu;
+    // wide operand: columns 128 wx + 4 c .. + 3 (all valid: the wide side is a full 256-column matrix); narrow: 32 t + c
+    const unsigned wide_off = (unsigned)(128 * wx + 4 * c) * 4u;
+    unsigned nar_off[WIDE_A ? NB : NA];
+#pragma unroll
+    for (int t = 0; t < (WIDE_A ? NB : NA); ++t) {
+        const int col = 32 * t + c;
+        nar_off[t] = col < (WIDE_A ? a.k_valid : a.n_valid) ? (unsigned)col * 4u : OOB;
+    }
+
+    float av[2][U][NA], bv[2][U][NB];
+    auto load_group = [&](long long p, float (&aa)[U][NA], float (&bb)[U][NB]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned r = (unsigned)(2 * (p - p0 + u) + h);
+            const unsigned ra = r * (unsigned)a.ld_dy * 4u, rb = r * (unsigned)a.ld_x * 4u;
+            if (WIDE_A) {
+                // (cast the whole vector: __builtin_bit_cast on one element of an ext_vector reads element 0)
+                const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, ra + wide_off, 0, 0));
+#pragma unroll
+                for (int i = 0; i < NA; ++i) aa[u][i] = q[i];
+#pragma unroll
+                for (int t = 0; t < NB; ++t)
+                    bb[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, nar_off[t] == OOB ? OOB : rb + nar_off[t], 0, 0));
+            } else {
+                aa[u][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dy, nar_off[0] == OOB ? OOB : ra + nar_off[0], 0, 0));
+                const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, rb + wide_off, 0, 0));
+#pragma unroll
+                for (int t = 0; t < NB; ++t) bb[u][t] = q[t];
+            }
+        }
+    };
+    auto compute = [&](const float (&aa)[U][NA], const float (&bb)[U][NB]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                bsum[i] += aa[u][i];
+#pragma unroll
+                for (int t = 0; t < NB; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u][i], bb[u][t], acc[i][t], 0, 0, 0);
+            }
+    };
+    load_group(p0, av[0], bv[0]);
+    for (long long p = p0; p < p1; p += 2 * U) {      // rows past the slab read as zero: over-running it is harmless
+        load_group(p + U, av[1], bv[1]);
+        compute(av[0], bv[0]);
+        load_group(p + 2 * U, av[0], bv[0]);
+        compute(av[1], bv[1]);
+    }
+    // the second half's partial sums go through LDS to the first half's waves
+    if (ws == 1) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_red[wx][(i * NB + t) * 16 + r][lane] = acc[i][t][r];
+            s_red[wx][NA * NB * 16 + i][lane] = bsum[i];
+        }
+    }
+    __syncthreads();
+    if (ws == 1) return;
+    // D row = A index (r & 3) + 8 (r >> 2) + 4 h, col = B index c; wide tiles: index i of tile j is column 128 wx + 4 i + j
+    float* out = a.dw_part + (size_t)g * a.n_out * a.ld_out;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ai = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int n = WIDE_A ? 128 * wx + 4 * ai + i : ai;
+                const int k = WIDE_A ? 32 * t + c : 128 * wx + 4 * c + t;
+                out[(size_t)n * a.ld_out + k] = acc[i][t][r] + s_red[wx][(i * NB + t) * 16 + r][lane];
+            }
+    if (a.db_part && (WIDE_A || wx == 0)) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            float sum = bsum[i] + s_red[wx][NA * NB * 16 + i][lane];
+            sum += __shfl_xor(sum, 32, 64);
+            const int n = WIDE_A ? 128 * wx + 4 * c + i : c;
+            if (h == 0) a.db_part[(size_t)g * a.n_out + n] = sum;
+        }
+    }
+}
+
 int plan_or_error(int kind, const vfn_net_geom* g, VfnNetPlan* p, const char* what) {
     char err[256] = {0};
     int rc = vfn_make_plan(kind, g, p, err, sizeof(err));
@@ -382,10 +507,15 @@ extern "C" int vfn_weight_grad_partials(int32_t shape, const float* dy, int32_t 
         hipLaunchKernelGGL((vfn_dw_kernel<4, 4, 2, 2>), dim3(groups), dim3(256), 0, s, a);
     } else if (shape == 1) {
         a.ld_out = 64; a.n_out = 256;
-        hipLaunchKernelGGL((vfn_dw_kernel<2, 2, 4, 1>), dim3(groups), dim3(256), 0, s, a);
+        // 16-byte loads on dY when it is a full, aligned 256-column matrix (the shipped layers)
+        const bool wide = n_valid == 256 && (ld_dy & 3) == 0 && ((uintptr_t)dy & 15) == 0;
+        if (wide) hipLaunchKernelGGL((vfn_dw_thin_kernel<true>), dim3(groups), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((vfn_dw_kernel<2, 2, 4, 1>), dim3(groups), dim3(256), 0, s, a);
     } else if (shape == 2) {
         a.ld_out = 256; a.n_out = 32;
-        hipLaunchKernelGGL((vfn_dw_kernel<1, 2, 1, 4>), dim3(groups), dim3(256), 0, s, a);
+        const bool wide = k_valid == 256 && (ld_x & 3) == 0 && ((uintptr_t)x & 15) == 0;
+        if (wide) hipLaunchKernelGGL((vfn_dw_thin_kernel<false>), dim3(groups), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((vfn_dw_kernel<1, 2, 1, 4>), dim3(groups), dim3(256), 0, s, a);
     } else {
         vfn_set_error("vfn_weight_grad_partials: unknown shape %d", shape);
         return VFN_ERR_INVALID;
