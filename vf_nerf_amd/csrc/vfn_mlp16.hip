@@ -433,7 +433,11 @@ __device__ __forceinline__ void save_group(const Pipe16& p, const f32x16& v, int
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.saved + (long long)SLOT * p.slot_floats, 0,
                                                                         (int)p.slot_bytes, 0x00020000);
     const f32x4v g = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-#ifndef ABL_NOSAVE
+#if defined(ABL_SAVE_COALESCED)
+    // timing only (WRONG layout): the same bytes as one 1-KiB run per instruction, to price the row-major store pattern
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)(((p.save_voff >> 15) << 15) + (threadIdx.x & 63) * 16),
+                                           (4 * TILE + q) * 1024, VFN16_SAVE_AUX);
+#elif !defined(ABL_NOSAVE)
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)p.save_voff, (32 * TILE + 8 * q) * 4, VFN16_SAVE_AUX);
 #else
     asm volatile("" :: "v"(g));
