@@ -648,31 +648,34 @@ __device__ __forceinline__ void load_aux(A16& ax, const float* park) {
 
 // The rendering net on a feature operand that is already in `xb` (fused launches: straight from the VF net's epilogue;
 // M16_RN_BLK: gathered from the block buffer): aux = [p(3), d(3), sin/cos(2^k d)(6L), n(3)], four hidden layers, rgb head.
+// aux operand of the rendering net for one sample: [p(3), d(3), sin/cos(2^k d)(6L), n(3)]
 template <int MODE>
-__device__ __forceinline__ void render_tail(const Mlp16Args& a, const Pipe16& p, Carry16& cy, X16& xa, X16& xb, const float (&xr)[3],
-                                            const float (&dr)[3], const float (&nrm)[3], long long m, bool in, int g, int wave, int lane) {
+__device__ __forceinline__ void render_aux(const Mlp16Args& a, A16& aux, const float (&xr)[3], const float (&dr)[3], const float (&nrm)[3],
+                                           long long m, bool in, int g) {
+    const int rn_multires = a.rn_multires;
+    float sn[18], cs[18];
+#pragma unroll
+    for (int o = 0; o < 6; ++o)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (o < rn_multires) sincosf(dr[c] * (float)(1 << o), &sn[3 * o + c], &cs[3 * o + c]);
+            else { sn[3 * o + c] = 0.f; cs[3 * o + c] = 0.f; }
+        }
+    const int ncol = 6 + 6 * rn_multires;   // first normal column
+    auto rn_col = [&](int k) -> float {
+        if (k < 3) return xr[k];
+        if (k >= ncol) return k < ncol + 3 ? nrm[k - ncol] : 0.f;
+        return enc_value(dr, sn, cs, rn_multires, k - 3);
+    };
+    build_aux(aux, g, rn_col);
+    if ((MODE & M16_TRAIN) && in) save_aux(a.save_aux_rn, m, g, rn_col);
+}
+
+template <int MODE>
+__device__ __forceinline__ void render_tail(const Mlp16Args& a, const Pipe16& p, Carry16& cy, X16& xa, X16& xb, const A16& aux,
+                                            const float (&nrm)[3], long long m, bool in, int wave, int lane) {
     constexpr int R = EPI_RELU, NONE = -1;
     constexpr int C0 = rn_first_chunk(MODE);
-    const int rn_multires = a.rn_multires;
-    A16 aux;
-    {
-        float sn[18], cs[18];
-#pragma unroll
-        for (int o = 0; o < 6; ++o)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                if (o < rn_multires) sincosf(dr[c] * (float)(1 << o), &sn[3 * o + c], &cs[3 * o + c]);
-                else { sn[3 * o + c] = 0.f; cs[3 * o + c] = 0.f; }
-            }
-        const int ncol = 6 + 6 * rn_multires;   // first normal column
-        auto rn_col = [&](int k) -> float {
-            if (k < 3) return xr[k];
-            if (k >= ncol) return k < ncol + 3 ? nrm[k - ncol] : 0.f;
-            return enc_value(dr, sn, cs, rn_multires, k - 3);
-        };
-        build_aux(aux, g, rn_col);
-        if ((MODE & M16_TRAIN) && in) save_aux(a.save_aux_rn, m, g, rn_col);
-    }
     float rgb[3] = {0.f, 0.f, 0.f};
     layer16<MODE, C0 + 0, 16, 3, 8, R, NONE, 0, 9, -1>(xb, aux, xa, xb, cy, rgb, p, wave, lane);      // R0: [features ; p, PE(d), n]
     layer16<MODE, C0 + 8, 16, 0, 8, R, R, 14, 10, 9>(xa, aux, xb, xa, cy, rgb, p, wave, lane);        // R1
@@ -709,22 +712,10 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
         // ---- rendering net only: this point's feature operand, normal, position and view direction come from memory ----
         // row m of the block / vector buffers is this lane's sample; dst[m] is its position among the sorted samples
         // (points, view direction and outputs live there), negative for padding rows
+        // Memory order of the prologue (loads return in order, so every wait is a wait for everything issued before it):
+        // dst[m] alone and its round trip; then, in ONE batch, the three small loads that depend on it, the first two weight
+        // chunks (LDS-DMA) and the 128 KiB of feature operands; one wait.
         const int dpos = in ? a.src[m] : -1;
-        // the 128 KiB of operands first (they do not depend on dpos); the loads that do are queued behind them, so the
-        // round trip of dst[m] hides under the operand transfer instead of preceding it
-        X16 xa, xb;
-        {
-            const uint4* grp = a.blk_in + (size_t)(m >> 5) * 2048 + lane;      // 32 KiB per 32 rows, see store_blocks
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                uint4 q0 = uint4{0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
-                if (in) { q0 = grp[(4 * t + 0) * 64]; q1 = grp[(4 * t + 1) * 64]; q2 = grp[(4 * t + 2) * 64]; q3 = grp[(4 * t + 3) * 64]; }
-                half8 h0 = __builtin_bit_cast(half8, q0), l0 = __builtin_bit_cast(half8, q1);
-                half8 h1 = __builtin_bit_cast(half8, q2), l1 = __builtin_bit_cast(half8, q3);
-                asm volatile("" : "+a"(h0)); asm volatile("" : "+a"(l0)); asm volatile("" : "+a"(h1)); asm volatile("" : "+a"(l1));
-                xb.hi[2 * t] = h0; xb.lo[2 * t] = l0; xb.hi[2 * t + 1] = h1; xb.lo[2 * t + 1] = l1;
-            }
-        }
         const bool live = dpos >= 0;
         float xr[3] = {0.f, 0.f, 0.f}, dr[3] = {0.f, 0.f, 0.f}, nrm[3] = {0.f, 0.f, 0.f};
         if (live) {
@@ -732,7 +723,6 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) { xr[c] = a.points[(long long)dpos * 3 + c]; dr[c] = a.ray_dirs[di * 3 + c]; nrm[c] = a.vec_in[m * 3 + c]; }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         Pipe16 p;
         p.lds = s_ring;
         p.vf_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.rn_w), 0, (int)a.rn_bytes, 0x00020000);
@@ -740,13 +730,47 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
         p.saved = nullptr; p.slot_floats = 0; p.slot_bytes = 0; p.save_voff = 0; p.blk_out = nullptr; p.blk_bytes = 0; p.blk_voff = 0;
         dma_chunk<MODE, 0>(p, wave, lane);
         dma_chunk<MODE, 1>(p, wave, lane);
+        X16 xa, xb;
+        A16 aux;
+        {
+            // 32 KiB per 32 rows, see store_blocks; rows past the end get an out-of-range offset and read as zeros (no branch)
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rs_blk = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint4*>(a.blk_in), 0, (int)(((a.n_points + 31) & ~31ll) * 1024), 0x00020000);
+            const unsigned goff = in ? (unsigned)((m >> 5) * 32768 + lane * 16) : 0xfffffff0u;
+            // all 32 loads first, the register pinning afterwards: with the pins (volatile asm) inside the load loop hipcc
+            // waits for every group of four loads before it issues the next — eight exposed round trips per tile
+            u32x4 q[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) q[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_blk, goff, i * 1024, 0);
+            // the encoding of the view direction (12 sincosf) while the operands are on their way: the three small loads were
+            // issued before them, so their wait is a counted one
+            render_aux<MODE>(a, aux, xr, dr, nrm, -1, false, g);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                half8 h0 = __builtin_bit_cast(half8, q[4 * t + 0]), l0 = __builtin_bit_cast(half8, q[4 * t + 1]);
+                half8 h1 = __builtin_bit_cast(half8, q[4 * t + 2]), l1 = __builtin_bit_cast(half8, q[4 * t + 3]);
+                asm volatile("" : "+a"(h0)); asm volatile("" : "+a"(l0)); asm volatile("" : "+a"(h1)); asm volatile("" : "+a"(l1));
+                xb.hi[2 * t] = h0; xb.lo[2 * t] = l0; xb.hi[2 * t + 1] = h1; xb.lo[2 * t + 1] = l1;
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunks 0 and 1 landed
         __builtin_amdgcn_s_barrier();
         Carry16 cy;
 #pragma unroll
         for (int q = 0; q < 16; ++q) cy.pend[q] = 0.f;
         prefetch_chunk<MODE, 0>(cy, p, lane);
-        render_tail<MODE>(a, p, cy, xa, xb, xr, dr, nrm, live ? (long long)dpos : -1, live, g, wave, lane);
+#ifdef VFN16_STAMPS
+        const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();
+#endif
+        render_tail<MODE>(a, p, cy, xa, xb, aux, nrm, live ? (long long)dpos : -1, live, wave, lane);
+#ifdef VFN16_STAMPS
+        if (threadIdx.x == 0 && live) {
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
+            a.out_colors[(long long)dpos * 3 + 0] = (float)(st_t1 - st_t0); a.out_colors[(long long)dpos * 3 + 1] = (float)(t2 - st_t0);
+            a.out_colors[(long long)dpos * 3 + 2] = (float)(r2 - st_r0);
+        }
+#endif
     } else {
     // this lane's point (the two lane halves of a wave share the 32 points); loaded BEFORE any DMA
     float x[3] = {0.f, 0.f, 0.f};
@@ -803,6 +827,9 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     // are ever live
     X16 xa, xb;
     float vec[3] = {0.f, 0.f, 0.f};
+#ifdef VFN16_STAMPS
+    const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();      // prologue done
+#endif
     constexpr int R = EPI_RELU, T = EPI_TANH, NONE = -1;
     layer16<MODE, 0, 0, 3, 8, R, NONE, 0, 0, -1>(xa, aux, xb, xb, cy, vec, p, wave, lane);        // L0: encoding only
     layer16<MODE, 8, 16, 0, 8, R, R, 14, 1, 0>(xb, aux, xa, xb, cy, vec, p, wave, lane);         // L1
@@ -823,6 +850,12 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     layer16<MODE, 71, 16, 0, 1, EPI_HEAD_TANH, T, 14, -1, 8, false, BO>(xa, aux, xb, xb, cy, vec, p, wave, lane);
     if constexpr (!(MODE & M16_RENDER)) {
         if (in && g == 0) { a.out_vec[m * 3 + 0] = vec[0]; a.out_vec[m * 3 + 1] = vec[1]; a.out_vec[m * 3 + 2] = vec[2]; }
+#ifdef VFN16_STAMPS
+        if (threadIdx.x == 0) {   // timing-only build: prologue cycles, total cycles, total 100 MHz ticks of this workgroup
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
+            a.out_vec[m * 3 + 0] = (float)(st_t1 - st_t0); a.out_vec[m * 3 + 1] = (float)(t2 - st_t0); a.out_vec[m * 3 + 2] = (float)(r2 - st_r0);
+        }
+#endif
     } else {
     // the head's outputs sit in the lanes < 32; the other lane half of the same point needs them for the aux operand
     float nrm[3];
@@ -830,7 +863,9 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     for (int c = 0; c < 3; ++c) nrm[c] = __shfl(vec[c], lane & 31, 64);
     const float xr[3] = {s_park[0], s_park[1], s_park[2]};
     const float dr[3] = {s_park[4], s_park[5], s_park[6]};
-    render_tail<MODE>(a, p, cy, xa, xb, xr, dr, nrm, m, in, g, wave, lane);
+    A16 raux;
+    render_aux<MODE>(a, raux, xr, dr, nrm, m, in, g);
+    render_tail<MODE>(a, p, cy, xa, xb, raux, nrm, m, in, wave, lane);
     const long long mo = (long long)blockIdx.x * VFN16_PTS + (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
     (void)mo;
 #ifdef VFN16_STAMPS
