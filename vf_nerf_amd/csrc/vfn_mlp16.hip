@@ -648,19 +648,33 @@ __device__ __forceinline__ void load_aux(A16& ax, const float* park) {
 
 // The rendering net on a feature operand that is already in `xb` (fused launches: straight from the VF net's epilogue;
 // M16_RN_BLK: gathered from the block buffer): aux = [p(3), d(3), sin/cos(2^k d)(6L), n(3)], four hidden layers, rgb head.
+// sin / cos of 2^o x for the octaves o < multires of one 3-vector.  The two lanes that share a point (lane halves g = 0, 1)
+// each evaluate ONE octave of every pair (2j + g: same instruction stream, different argument) and swap results, so a lane
+// runs 3 * ceil(multires / 2) sincosf instead of 3 * multires — same inputs to the same function, so the values are
+// bit-identical to evaluating all of them.
+__device__ __forceinline__ void encode_sincos(const float (&x)[3], int multires, int g, float (&sn)[18], float (&cs)[18]) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float s = 0.f, k = 0.f;
+            if (2 * j < multires) {
+                sincosf(x[c] * (g ? (float)(2 << (2 * j)) : (float)(1 << (2 * j))), &s, &k);
+                if (2 * j + g >= multires) { s = 0.f; k = 0.f; }      // odd multires: the pair's upper octave does not exist
+            }
+            const float so = __shfl_xor(s, 32, 64), ko = __shfl_xor(k, 32, 64);
+            sn[6 * j + c] = g ? so : s;          cs[6 * j + c] = g ? ko : k;              // octave 2j
+            sn[6 * j + 3 + c] = g ? s : so;      cs[6 * j + 3 + c] = g ? k : ko;          // octave 2j + 1
+        }
+}
+
 // aux operand of the rendering net for one sample: [p(3), d(3), sin/cos(2^k d)(6L), n(3)]
 template <int MODE>
 __device__ __forceinline__ void render_aux(const Mlp16Args& a, A16& aux, const float (&xr)[3], const float (&dr)[3], const float (&nrm)[3],
                                            long long m, bool in, int g) {
     const int rn_multires = a.rn_multires;
     float sn[18], cs[18];
-#pragma unroll
-    for (int o = 0; o < 6; ++o)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            if (o < rn_multires) sincosf(dr[c] * (float)(1 << o), &sn[3 * o + c], &cs[3 * o + c]);
-            else { sn[3 * o + c] = 0.f; cs[3 * o + c] = 0.f; }
-        }
+    encode_sincos(dr, rn_multires, g, sn, cs);
     const int ncol = 6 + 6 * rn_multires;   // first normal column
     auto rn_col = [&](int k) -> float {
         if (k < 3) return xr[k];
@@ -797,19 +811,20 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     p.blk_voff = (uint32_t)((m >> 5) * 32768 + lane * 16);      // past the last group -> out of the descriptor's range, dropped
     dma_chunk<MODE, 0>(p, wave, lane);
     dma_chunk<MODE, 1>(p, wave, lane);
+#ifdef ABL_NODMA
+    // timing only (WRONG results): no DMA inside the layers; the three slots keep three full-size chunks of real weights,
+    // so the matrix cores still see random operands (an empty ring would feed zeros, which raises the clock)
+    dma_chunk<MODE, 9>(p, wave, lane);      // chunk 9 -> slot 0, 10 -> slot 1, 11 -> slot 2 (tiles of VF layer 1, 33 KiB each)
+    dma_chunk<MODE, 10>(p, wave, lane);
+    dma_chunk<MODE, 11>(p, wave, lane);
+#endif
 
     // ---- positional encoding of the point -> aux operand (and its parked copy for the skip layer) -----------
     const int vf_multires = a.vf_multires;
     A16 aux;
     {
         float sn[18], cs[18];
-#pragma unroll
-        for (int o = 0; o < 6; ++o)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                if (o < vf_multires) sincosf(x[c] * (float)(1 << o), &sn[3 * o + c], &cs[3 * o + c]);
-                else { sn[3 * o + c] = 0.f; cs[3 * o + c] = 0.f; }
-            }
+        encode_sincos(x, vf_multires, g, sn, cs);
         build_aux(aux, g, [&](int k) { return enc_value(x, sn, cs, vf_multires, k); });
         if ((MODE & M16_TRAIN) && in) save_aux(a.save_aux_vf, m, g, [&](int k) { return enc_value(x, sn, cs, vf_multires, k); });
         half8* pk = reinterpret_cast<half8*>(s_park + 8);
