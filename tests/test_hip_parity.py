@@ -396,3 +396,23 @@ def test_shared_pose_and_intrinsics():
         a = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms={"u_add": g["u_add"]})
         b = model.render(g["pose"][0], g["uv"], g["intrinsics"][:1], epoch=0, uniforms={"u_add": g["u_add"]})
     assert torch.equal(a.coarse_rgb_values, b.coarse_rgb_values) and torch.equal(a.z_vals, b.z_vals)
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """The boundary is a C ABI: tests/c_abi/abi_smoke.c (C11, gcc, no Python, no torch) builds a geometry, packs random
+    weights given in the reference's layout, launches rays / both VF kernels / one batch-statistics layer on its own stream
+    and checks them against closed forms, against each other and against a host loop; also the error statuses."""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(repo, "vf_nerf_amd", "csrc")
+    exe = str(tmp_path / "abi_smoke")
+    build = subprocess.run(["gcc", "-std=c11", "-D__HIP_PLATFORM_AMD__", os.path.join(repo, "tests", "c_abi", "abi_smoke.c"),
+                            "-I" + os.path.join(repo, "include"), "-I/opt/rocm/include", "-L" + csrc, "-lvfn", "-L/opt/rocm/lib",
+                            "-lamdhip64", "-lm", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib", "-o", exe],
+                           capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(run.stdout.strip())
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    assert "abi_smoke: ok" in run.stdout
