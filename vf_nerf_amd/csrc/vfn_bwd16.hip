@@ -243,10 +243,7 @@ __device__ __forceinline__ void epi_pair(f32x16& pend, const f32x4v (&mask)[4], 
 
 // A whole tile outside the pipelined loop (the tiles a chain starts from, and the very last one).
 template <int SLOT, int TILE, int MASK, int HEAD, bool SPLIT>
-__device__ __forceinline__ void finish_tile(f32x16& v, const Pipe& p, const float (&dz)[3], int g, X16& xout) {
-    f32x4v mask[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) mask[q] = load_group<SLOT, TILE>(p, q);
+__device__ __forceinline__ void finish_tile_with(f32x16& v, const f32x4v (&mask)[4], const Pipe& p, const float (&dz)[3], int g, X16& xout) {
     bf8 hi[2], lo[2];
 #pragma unroll
     for (int pr = 0; pr < 8; ++pr) epi_pair<MASK, HEAD, TILE>(v, mask, pr, p, dz, g, hi[pr >> 2], lo[pr >> 2], (pr & 3) * 2);
@@ -259,6 +256,24 @@ __device__ __forceinline__ void finish_tile(f32x16& v, const Pipe& p, const floa
             xout.hi[2 * TILE + s] = hi[s]; xout.lo[2 * TILE + s] = lo[s];
         }
     }
+}
+template <int SLOT, int TILE, int MASK, int HEAD, bool SPLIT>
+__device__ __forceinline__ void finish_tile(f32x16& v, const Pipe& p, const float (&dz)[3], int g, X16& xout) {
+    f32x4v mask[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mask[q] = load_group<SLOT, TILE>(p, q);
+    finish_tile_with<SLOT, TILE, MASK, HEAD, SPLIT>(v, mask, p, dz, g, xout);
+}
+// The eight tiles a chain starts from: ALL their saved activations are requested first (32 loads in one batch); with the
+// loads inside the per-tile code the register pins of finish_tile (volatile asm) keep hipcc from hoisting them and every
+// tile pays its own round trip to HBM before any matrix work exists to hide it.
+template <int SLOT>
+__device__ __forceinline__ void load_start_masks(const Pipe& p, f32x4v (&mk)[8][4]) {
+    static_for<8>([&](auto it) {
+        constexpr int t = decltype(it)::value;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mk[t][q] = load_group<SLOT, t>(p, q);
+    });
 }
 
 // One matrix step: xout <- f'(saved) * (W'^T xin [+ head]) — NCH chunks (C0 .. of the launch), one 32-row tile each.
@@ -389,15 +404,19 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
     X16 xa, xb;
     if constexpr (MODE == BM_FUSED) {
         // gradient wrt the last hidden output of the rendering net = rank-3 update from the rgb head, ReLU-masked (slot 12)
+        f32x4v mk[8][4];
+        load_start_masks<12>(p, mk);
         static_for<8>([&](auto it) {
             constexpr int t = decltype(it)::value;
             f32x16 v;
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = 0.f;
-            finish_tile<12, t, MASK_RELU, 1, true>(v, p, dzc, g, xa);
+            finish_tile_with<12, t, MASK_RELU, 1, true>(v, mk[t], p, dzc, g, xa);
         });
     } else if constexpr (MODE == BM_FULL) {
         // dZ_f = dF * (1 - F^2) straight from the caller's gradient (slot 8)
+        f32x4v mk[8][4];
+        load_start_masks<8>(p, mk);
         static_for<8>([&](auto it) {
             constexpr int t = decltype(it)::value;
             f32x16 v;
@@ -406,16 +425,18 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
                 const int k = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * g;
                 v[r] = in ? a.d_feats[m * a.vec_stride + k] : 0.f;
             }
-            finish_tile<8, t, MASK_TANH, -1, true>(v, p, dzv, g, xa);
+            finish_tile_with<8, t, MASK_TANH, -1, true>(v, mk[t], p, dzv, g, xa);
         });
     } else {
         // vector-only: gradient wrt the last plain hidden output = rank-3 update from the vector head (slot 7)
+        f32x4v mk[8][4];
+        load_start_masks<7>(p, mk);
         static_for<8>([&](auto it) {
             constexpr int t = decltype(it)::value;
             f32x16 v;
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = 0.f;
-            finish_tile<7, t, MASK_RELU, 0, true>(v, p, dzv, g, xa);
+            finish_tile_with<7, t, MASK_RELU, 0, true>(v, mk[t], p, dzv, g, xa);
         });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunks 0 and 1 landed, start tiles stored
