@@ -136,13 +136,7 @@ def view_bench(args, dev):
     n = uv.shape[0]
 
     def full_view():
-        rgb = torch.empty(n, 3, device=dev)
-        depth = torch.empty(n, 1, device=dev)
-        for lo in range(0, n, chunk):
-            hi = min(lo + chunk, n)
-            o = model.render(pose[lo:hi], uv[lo:hi], K[lo:hi], epoch=0)
-            rgb[lo:hi], depth[lo:hi] = o.coarse_rgb_values, o.coarse_depth_map
-        return rgb, depth
+        return model.render_chunked(pose, uv, K, epoch=0, chunk=chunk, n_streams=args.streams)
 
     with torch.no_grad():
         for _ in range(max(1, args.warmup // 3)):
@@ -175,7 +169,7 @@ def view_bench(args, dev):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16x3+f32acc" if args.precision == "f16x3" else "f32", "data": "synthetic",
         "config": {"workload": f"full view {w}x{h} = {n} rays in {chunk}-ray chunks x {s_c + n_f} samples, perturb off, "
-                               f"forward only (BASELINE.json configs[1])"},
+                               f"forward only, consecutive chunks on {args.streams} stream(s) (BASELINE.json configs[1])"},
         "parity_vs_oracle": {"image": f"{ws}x{hs} (same camera, intrinsics / 8), {ws * hs} rays",
                              "psnr_rgb_db": round(min(O.psnr(rgb, ref["rgb"]), 200.0), 2),
                              "mean_abs_depth_err": float((depth - ref["depth"].reshape(depth.shape)).abs().mean()),
@@ -324,6 +318,8 @@ def main() -> None:
                     help="render = the headline line (default); view = BASELINE configs[1] full view in 1024-ray chunks + "
                          "PSNR/depth vs the oracle image; grid = configs[4] dense grid queries; train = configs[2] step")
     ap.add_argument("--grid-res", type=int, default=256)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="view workload: HIP streams the consecutive ray chunks alternate over (1 = strictly one after the other)")
     ap.add_argument("--train", action="store_true",
                     help="time a training step instead (render with autograd + 2 supervision VF forwards + loss + "
                          "backward + clip + Adam, train/vector_field_nerf_train.py:177-260); not the headline metric")

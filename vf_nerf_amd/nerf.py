@@ -377,6 +377,35 @@ class VectorFieldNerf:
                           fine_depth_map=None, z_vals=z, directional_derivtives=dd, ray_dirs=rep_dirs,
                           coarse_colors=colors)
 
+    @torch.no_grad()
+    def render_chunked(self, pose: torch.Tensor, pixels: torch.Tensor, intrinsics: torch.Tensor, epoch: int, chunk: int = 1024,
+                       n_streams: int = 2, white: bool = False):
+        """A whole view, ``chunk`` rays at a time — the evaluator's loop (evaluation/methods.py:520-545 renders an image in
+        ``rays_per_batch`` pieces and keeps rgb and depth) — with consecutive chunks on alternating HIP streams: chunks are
+        independent, and a chunk of 1024 rays is only 2-4 rounds of workgroups per launch, so the next chunk's launches fill
+        the CUs that the current one's last round leaves idle and hide its small per-ray kernels.  Same arithmetic per
+        chunk as ``render()``; returns (rgb[N,3], depth[N,1])."""
+        n = pixels.shape[0]
+        dev = pixels.device
+        rgb = torch.empty(n, 3, device=dev)
+        depth = torch.empty(n, 1, device=dev)
+        shared_pose = pose.dim() == 1 or (pose.dim() == 2 and pose.shape == (4, 4)) or pose.shape[0] == 1
+        shared_k = intrinsics.dim() == 2 or intrinsics.shape[0] == 1
+        cur = torch.cuda.current_stream(dev)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, n_streams))]
+        for st in streams:
+            st.wait_stream(cur)
+        for i, lo in enumerate(range(0, n, chunk)):
+            hi = min(lo + chunk, n)
+            with torch.cuda.stream(streams[i % len(streams)]):
+                out = self.render(pose if shared_pose else pose[lo:hi], pixels[lo:hi], intrinsics if shared_k else intrinsics[lo:hi],
+                                  epoch, white)
+                rgb[lo:hi] = out.coarse_rgb_values
+                depth[lo:hi] = out.coarse_depth_map
+        for st in streams:
+            cur.wait_stream(st)
+        return rgb, depth
+
     def _render_training_mode(self, pose, pixels, intrinsics, epoch: int, white: bool, uniforms) -> NerfOutput:
         """render() with a network in training mode (after ``train()``, vector_field_nerf.py:139-150): BatchNorm normalises
         with batch statistics, which the fused kernels cannot fold, so the networks are called one after the other
