@@ -304,12 +304,23 @@ class VectorFieldNerf:
         perturb_f = not self.fine_sampler.deterministic
         uniforms = uniforms or {}
 
+        # the draws that are not supplied come from ONE Philox launch (three contiguous segments of one buffer)
+        wanted = [(name, shape) for name, shape, needed in (("u_coarse", (n, s_c), perturb_c), ("u_fine", (n, n_f), perturb_f),
+                                                            ("u_add", (n, n_f), True)) if needed and name not in uniforms]
+        drawn = {}
+        if wanted:
+            flat = self._uniform((sum(a * b for _, (a, b) in wanted),), dev)
+            o = 0
+            for name, (a, b) in wanted:
+                drawn[name] = flat[o:o + a * b].view(a, b)
+                o += a * b
+
         def draw(name, shape, needed):
             if not needed:
                 return None
             if name in uniforms:
                 return uniforms[name].to(dev).float().contiguous()
-            return self._uniform(shape, dev)
+            return drawn[name]
 
         # inference with the f16x3 kernels: evaluate the VF net once per distinct sample (see ``reuse_proposal``)
         reuse = self.reuse_proposal and self.uses_f16x3() and not self._needs_grad() and n * (s_c + n_f) < (1 << 22)
