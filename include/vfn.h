@@ -269,13 +269,17 @@ int vfn_weight_grad_partials_bf16(const float* dy, const float* x, int64_t n_poi
 /* vfn_mlp_bwd_chain on the bf16 matrix cores (split operands, three products per K-block, fp32 accumulation; shipped layer
  * shapes only, others return VFN_ERR_UNSUPPORTED).  Takes its own TRANSPOSED bf16 packs (vfn_pack_weights_bwd16; re-run
  * after every optimizer step) and the raw rows 0..2 of each net's last Linear ([3][256] fp32) for the 3-channel heads.
- * Same outputs as vfn_mlp_bwd_chain.  n_points < 2^22 per launch. */
+ * Same outputs as vfn_mlp_bwd_chain.  n_points < 2^22 per launch.
+ * `masks` = the sign bits the f16x3 training forwards write next to `saved` (save_masks[13][M][2][4] u32: per slot, point and
+ * lane half g one 16-byte word; tile t of the layer -> half t & 1 of dword t >> 1, bit r <-> output column
+ * 32 t + (r & 3) + 8 (r >> 2) + 4 g): a ReLU's backward needs only whether its output was positive, so the chain reads
+ * 32 bytes per point and layer instead of 1 KiB; `saved` itself is read only for the tanh'ed feature block (slot 8). */
 int64_t vfn_packed_bwd16_size(int32_t net_kind, const vfn_net_geom* geom);                      /* bytes */
 int vfn_pack_weights_bwd16(int32_t net_kind, const vfn_net_geom* geom, const vfn_layer_params* layers, void* packed,
                            void* stream);
 int vfn_mlp_bwd_chain_bf16(const vfn_net_geom* vf_geom, const void* vf_packed_bwd16, const float* vf_head_w,
                            const vfn_net_geom* rn_geom, const void* rn_packed_bwd16, const float* rn_head_w,
-                           const float* saved, float* dy, const float* d_colors, const float* colors,
+                           const float* saved, const uint32_t* masks, float* dy, const float* d_colors, const float* colors,
                            const float* d_vec, const float* vec, const float* d_feats, int32_t vec_stride,
                            int64_t n_points, float* dz_rgb, float* dz_vec, void* stream);
 
@@ -327,11 +331,12 @@ int vfn_sample_sphere_shell(int64_t n, float r_min, float r_max, const float* ce
  * (the feature slot is not written); with_features = 1 also writes the 256 tanh'ed features into their slot, from which
  * the caller assembles [M, 3+F].  n_points < 2^22 per launch. */
 int vfn_vf_mlp16_fwd_train(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
-                           int32_t with_features, float* out_vec, float* saved, float* save_aux_vf, void* stream);
+                           int32_t with_features, float* out_vec, float* saved, float* save_aux_vf, uint32_t* save_masks,
+                           void* stream);
 int vfn_vf_render_fused16_fwd_train(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
                                     const void* rn_packed16, const float* points, const float* ray_dirs,
                                     int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
-                                    float* saved, float* save_aux_vf, float* save_aux_rn, void* stream);
+                                    float* saved, float* save_aux_vf, float* save_aux_rn, uint32_t* save_masks, void* stream);
 
 /* =============================================================================================
  * Dense-grid stages between the vector-field queries and the mesh triangulation (evaluation/utils/mc_utils.py,

@@ -94,11 +94,14 @@ def test_training_forward_workspace_f16x3_matches_fp32():
     dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=1).to(dev)
     m, slots = n * s_t, len(_entries(vf)) + len(_entries(rn))
     ws32, ws16 = _Workspace(m, slots, dev), _Workspace(m, slots, dev)
+    ws16.saved.zero_()          # columns 224..255 of the 217-wide layer's slot are never written: define them for the sign-word check
     n32, c32 = lib.vf_render_fused_fwd_train(vf.geometry(), vf.packed_weights(), rn.geometry(), rn.packed_weights(), pts,
                                              dirs, s_t, ws32.saved, ws32.aux_vf, ws32.aux_rn)
     n16, c16 = lib.vf_render_fused16_fwd_train(vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(),
-                                               pts, dirs, s_t, ws16.saved, ws16.aux_vf, ws16.aux_rn)
+                                               pts, dirs, s_t, ws16.saved, ws16.aux_vf, ws16.aux_rn, ws16.masks)
     assert float((n16 - n32).abs().max()) < 2e-5 and float((c16 - c32).abs().max()) < 2e-5
+    # the sign-bit words next to the saved activations (what the bf16 chain reads instead of them) are exactly their signs
+    assert torch.equal(ws16.masks, lib.relu_sign_words(ws16.saved))
     assert float((ws16.aux_vf[:, :39] - ws32.aux_vf[:, :39]).abs().max()) < 1e-6
     assert float((ws16.aux_rn[:, :33] - ws32.aux_rn[:, :33]).abs().max()) < 2e-5      # holds the normals
     widths = [256, 256, 256, 217, 256, 256, 256, 256, 256, 256, 256, 256, 256]
@@ -109,9 +112,12 @@ def test_training_forward_workspace_f16x3_matches_fp32():
     # VF-only variants (supervision points), with and without the feature block
     for with_feat in (False, True):
         w32, w16 = _Workspace(m, len(_entries(vf)), dev), _Workspace(m, len(_entries(vf)), dev)
+        w16.saved.zero_()
         o32 = lib.vf_mlp_fwd_train(vf.geometry(), vf.packed_weights(), pts, 259 if with_feat else 3, w32.saved, w32.aux_vf)
-        o16 = lib.vf_mlp16_fwd_train(vf.geometry(), vf.packed16_weights(), pts, with_feat, w16.saved, w16.aux_vf)
+        o16 = lib.vf_mlp16_fwd_train(vf.geometry(), vf.packed16_weights(), pts, with_feat, w16.saved, w16.aux_vf, w16.masks)
         assert float((o16 - o32[:, :3]).abs().max()) < 2e-5
+        n_sl = 9 if with_feat else 8
+        assert torch.equal(w16.masks[:n_sl], lib.relu_sign_words(w16.saved[:n_sl]))
         for slot in range(9 if with_feat else 8):
             w = widths[slot]
             scale = max(1.0, float(w32.saved[slot][:, :w].abs().max()))
@@ -330,8 +336,9 @@ def test_dx_chain_bf16_split_matches_fp32():
     zr32, zv32, zr16, zv16 = (torch.empty(m, 4, device=dev) for _ in range(4))
     lib.mlp_bwd_chain(vf.geometry(), vf.packed_weights(), _packed_bwd(vf), rn.geometry(), rn.packed_weights(), _packed_bwd(rn),
                       ws.saved, dy32, dc, colors, dn, normals, None, 3, m, zr32, zv32)
+    masks = lib.relu_sign_words(ws.saved)      # the workspace of this test comes from the fp32 forward: derive the words
     lib.mlp_bwd_chain_bf16(vf.geometry(), _packed_bwd16(vf), _head_rows(vf), rn.geometry(), _packed_bwd16(rn), _head_rows(rn),
-                           ws.saved, dy16, dc, colors, dn, normals, None, 3, m, zr16, zv16)
+                           ws.saved, masks, dy16, dc, colors, dn, normals, None, 3, m, zr16, zv16)
     assert torch.equal(zr16, zr32) and torch.equal(zv16, zv32)
     widths = [256, 256, 256, 217, 256, 256, 256, 256, 256, 256, 256, 256, 256]
     compare("fused", [dy16[s][:, :w] for s, w in enumerate(widths)], [dy32[s][:, :w] for s, w in enumerate(widths)], range(13))
@@ -346,7 +353,7 @@ def test_dx_chain_bf16_split_matches_fp32():
         dfe = _offset_view(g, 3) if cols == 259 else None
         lib.mlp_bwd_chain(vf.geometry(), vf.packed_weights(), _packed_bwd(vf), None, None, None, ws.saved, dy32, None, None, g, o,
                           dfe, cols, m, None, zv32)
-        lib.mlp_bwd_chain_bf16(vf.geometry(), _packed_bwd16(vf), _head_rows(vf), None, None, None, ws.saved, dy16, None, None, g, o,
+        lib.mlp_bwd_chain_bf16(vf.geometry(), _packed_bwd16(vf), _head_rows(vf), None, None, None, ws.saved, masks, dy16, None, None, g, o,
                                dfe, cols, m, None, zv16)
         assert torch.equal(zv16, zv32)
         slots = range(9) if cols == 259 else range(8)

@@ -23,7 +23,7 @@ def call(l):
     rc = l.vfn_vf_render_fused16_fwd_train(C.byref(vf.geometry()), C.c_void_p(vf.packed16_weights().data_ptr()), C.byref(rn.geometry()),
         C.c_void_p(rn.packed16_weights().data_ptr()), C.c_void_p(pts.data_ptr()), C.c_void_p(dirs.data_ptr()), C.c_int64(m), C.c_int32(128),
         C.c_void_p(normals.data_ptr()), C.c_void_p(colors.data_ptr()), C.c_void_p(ws.saved.data_ptr()), C.c_void_p(ws.aux_vf.data_ptr()),
-        C.c_void_p(ws.aux_rn.data_ptr()), stream)
+        C.c_void_p(ws.aux_rn.data_ptr()), C.c_void_p(ws.masks.data_ptr()), stream)
     assert rc == 0, l.vfn_last_error()
 times = {n: [] for n in names}
 for n in names:

@@ -175,6 +175,8 @@ _F16_TRAIN_MAX_POINTS = 1 << 22   # the f16x3 training kernels address a workspa
 class _Workspace:
     def __init__(self, m: int, n_slots: int, dev) -> None:
         self.saved = torch.empty(n_slots, m, HID, device=dev)
+        # sign bits of the saved ReLU outputs (f16x3 training forwards write them, the bf16 chain reads them): 32 B per point and slot
+        self.masks = torch.empty(n_slots, m, 2, 4, dtype=torch.int32, device=dev)
         self.aux_vf = torch.empty(m, lib.AUX_K, device=dev)
         self.aux_rn = torch.empty(m, lib.AUX_K, device=dev)
 
@@ -195,7 +197,7 @@ class _FinePass(torch.autograd.Function):
         if model.uses_f16x3() and m < _F16_TRAIN_MAX_POINTS:   # split-half products, fp32-equivalent (csrc/vfn_mlp16.hip)
             normals, colors = lib.vf_render_fused16_fwd_train(vf.geometry(), vf.packed16_weights(), rn.geometry(),
                                                               rn.packed16_weights(), pts.reshape(-1, 3), ray_dirs, s_t,
-                                                              ws.saved, ws.aux_vf, ws.aux_rn)
+                                                              ws.saved, ws.aux_vf, ws.aux_rn, ws.masks)
         else:
             normals, colors = lib.vf_render_fused_fwd_train(vf.geometry(), vf.packed_weights(), rn.geometry(),
                                                             rn.packed_weights(), pts.reshape(-1, 3), ray_dirs, s_t,
@@ -235,7 +237,7 @@ class _FinePass(torch.autograd.Function):
         fast = model.uses_f16x3() and m < _F16_TRAIN_MAX_POINTS
         if fast:
             lib.mlp_bwd_chain_bf16(vf.geometry(), _packed_bwd16(vf), _head_rows(vf), rn.geometry(), _packed_bwd16(rn),
-                                   _head_rows(rn), ws.saved, dy, dc, colors, dn, normals, None, 3, m, dz_rgb, dz_vec)
+                                   _head_rows(rn), ws.saved, ws.masks, dy, dc, colors, dn, normals, None, 3, m, dz_rgb, dz_vec)
         else:
             lib.mlp_bwd_chain(vf.geometry(), vf.packed_weights(), _packed_bwd(vf), rn.geometry(), rn.packed_weights(),
                               _packed_bwd(rn), ws.saved, dy, dc, colors, dn, normals, None, 3, m, dz_rgb, dz_vec)
@@ -274,7 +276,7 @@ class _VFForward(torch.autograd.Function):
         ws = _Workspace(m, vf_h, dev)
         cols = 3 if (vector_only or not has_feat) else 3 + net._feature_dims()
         if getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3() and m < _F16_TRAIN_MAX_POINTS:
-            out = lib.vf_mlp16_fwd_train(net.geometry(), net.packed16_weights(), pts, cols > 3, ws.saved, ws.aux_vf)
+            out = lib.vf_mlp16_fwd_train(net.geometry(), net.packed16_weights(), pts, cols > 3, ws.saved, ws.aux_vf, ws.masks)
             if cols > 3:   # [vector | features]: the kernel left the features in their workspace slot
                 out = torch.cat([out, ws.saved[vf_h - 1]], dim=1)
         else:
@@ -297,7 +299,7 @@ class _VFForward(torch.autograd.Function):
             d_feats = _offset_view(d_out, 3)
         fast = getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3() and m < _F16_TRAIN_MAX_POINTS
         if fast:
-            lib.mlp_bwd_chain_bf16(net.geometry(), _packed_bwd16(net), _head_rows(net), None, None, None, ws.saved, dy,
+            lib.mlp_bwd_chain_bf16(net.geometry(), _packed_bwd16(net), _head_rows(net), None, None, None, ws.saved, ws.masks, dy,
                                    None, None, d_out, out, d_feats, cols, m, None, dz_vec)
         else:
             lib.mlp_bwd_chain(net.geometry(), net.packed_weights(), _packed_bwd(net), None, None, None, ws.saved, dy,

@@ -147,7 +147,8 @@ struct Bwd16Args {
     const uint4* rn_wt;
     const float* vf_head;     // [3][256] rows 0..2 of the VF net's last Linear
     const float* rn_head;     // [3][256] the rendering net's last Linear
-    const float* saved;       // [13][M][256]
+    const float* saved;       // [13][M][256]  (read only for the tanh'ed feature block, slot 8)
+    const uint32_t* masks;    // [13][M][2][4] u32: sign bits of the saved ReLU outputs (written by the training forwards)
     float* dy;                // [13][M][256]
     const float* d_colors; const float* colors;      // [M,3]
     const float* d_vec; const float* vec;            // row stride vec_stride
@@ -166,6 +167,7 @@ struct Pipe {
     const float* saved; float* dy;
     long long slot_floats; uint32_t slot_bytes;
     uint32_t voff;                   // m * 1024 + 16 * (lane >> 5); out of range for m >= M
+    u32x4 mw[13];                    // this lane's sign-bit words, one per slot: tile t -> half t & 1 of dword t >> 1, bit r <-> register r
 };
 
 struct Carry {
@@ -204,6 +206,17 @@ __device__ __forceinline__ f32x4v load_group(const Pipe& p, int q) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.saved) + (long long)SLOT * p.slot_floats, 0,
                                                                         (int)p.slot_bytes, 0x00020000);
     return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)p.voff, (32 * TILE + 8 * q) * 4, 0));
+}
+// what the epilogue multiplies by: for ReLU layers 1 / 0 from the sign bits (no memory access), for the tanh'ed feature
+// block the saved values themselves
+template <int SLOT, int TILE, int MASK>
+__device__ __forceinline__ f32x4v mask_group(const Pipe& p, int q) {
+    if constexpr (MASK == MASK_RELU) {
+        const unsigned bits = p.mw[SLOT][TILE >> 1] >> (16 * (TILE & 1) + 4 * q);
+        return f32x4v{(bits & 1u) ? 1.f : 0.f, (bits & 2u) ? 1.f : 0.f, (bits & 4u) ? 1.f : 0.f, (bits & 8u) ? 1.f : 0.f};
+    } else {
+        return load_group<SLOT, TILE>(p, q);
+    }
 }
 template <int SLOT, int TILE>
 __device__ __forceinline__ void store_group(const Pipe& p, const f32x16& v, int q) {
@@ -261,18 +274,18 @@ template <int SLOT, int TILE, int MASK, int HEAD, bool SPLIT>
 __device__ __forceinline__ void finish_tile(f32x16& v, const Pipe& p, const float (&dz)[3], int g, X16& xout) {
     f32x4v mask[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) mask[q] = load_group<SLOT, TILE>(p, q);
+    for (int q = 0; q < 4; ++q) mask[q] = mask_group<SLOT, TILE, MASK>(p, q);
     finish_tile_with<SLOT, TILE, MASK, HEAD, SPLIT>(v, mask, p, dz, g, xout);
 }
 // The eight tiles a chain starts from: ALL their saved activations are requested first (32 loads in one batch); with the
 // loads inside the per-tile code the register pins of finish_tile (volatile asm) keep hipcc from hoisting them and every
 // tile pays its own round trip to HBM before any matrix work exists to hide it.
-template <int SLOT>
+template <int SLOT, int MASK>
 __device__ __forceinline__ void load_start_masks(const Pipe& p, f32x4v (&mk)[8][4]) {
     static_for<8>([&](auto it) {
         constexpr int t = decltype(it)::value;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) mk[t][q] = load_group<SLOT, t>(p, q);
+        for (int q = 0; q < 4; ++q) mk[t][q] = mask_group<SLOT, t, MASK>(p, q);
     });
 }
 
@@ -338,7 +351,7 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
                     else store_group<(PSLOT >= 0 ? PSLOT : 0), (PT >= 0 ? PT : 0)>(p, cy.pend, q);
                 }
             }
-            if (st >= H && st < H + 4) mnext[st - H] = load_group<OSLOT, ch>(p, st - H);
+            if (st >= H && st < H + 4) mnext[st - H] = mask_group<OSLOT, ch, MASK>(p, st - H);
             if (st >= H && ddma.kb > 0) {
 #pragma unroll
                 for (int i = (st - H) * BW_PMAX / DSTEPS; i < (st - H + 1) * BW_PMAX / DSTEPS; ++i) {
@@ -396,6 +409,21 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
                                                ((MODE & 2) ? rn_pack_kb() : vf_pack_kb()) * 1024, 0x00020000);
     p.saved = a.saved; p.dy = a.dy; p.slot_floats = a.n_points * 256; p.slot_bytes = (uint32_t)(a.n_points * 1024);
     p.voff = in ? (uint32_t)(m * 1024 + g * 16) : 0xfffffff0u;
+    {   // sign bits of every ReLU layer this launch walks through: 16 bytes per slot, all requested now, in registers for good
+        const unsigned mbytes = (unsigned)(a.n_points * 32);
+        const unsigned mvoff = in ? (unsigned)((2 * m + g) * 16) : 0xfffffff0u;
+        static_for<13>([&](auto is) {
+            constexpr int sl = decltype(is)::value;
+            constexpr bool used = sl != 8 && (sl < 8 || MODE == BM_FUSED);
+            if constexpr (used) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    reinterpret_cast<unsigned char*>(const_cast<uint32_t*>(a.masks)) + (size_t)sl * mbytes, 0, (int)mbytes, 0x00020000);
+                p.mw[sl] = __builtin_amdgcn_raw_buffer_load_b128(rs, mvoff, 0, 0);
+            } else {
+                p.mw[sl] = u32x4{0, 0, 0, 0};
+            }
+        });
+    }
     dma_chunk<MODE, 0>(p, wave, lane);
     dma_chunk<MODE, 1>(p, wave, lane);
     __syncthreads();                       // head tables visible (this also waits for the two chunks: once, harmless)
@@ -405,7 +433,7 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
     if constexpr (MODE == BM_FUSED) {
         // gradient wrt the last hidden output of the rendering net = rank-3 update from the rgb head, ReLU-masked (slot 12)
         f32x4v mk[8][4];
-        load_start_masks<12>(p, mk);
+        load_start_masks<12, MASK_RELU>(p, mk);
         static_for<8>([&](auto it) {
             constexpr int t = decltype(it)::value;
             f32x16 v;
@@ -416,7 +444,7 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
     } else if constexpr (MODE == BM_FULL) {
         // dZ_f = dF * (1 - F^2) straight from the caller's gradient (slot 8)
         f32x4v mk[8][4];
-        load_start_masks<8>(p, mk);
+        load_start_masks<8, MASK_TANH>(p, mk);
         static_for<8>([&](auto it) {
             constexpr int t = decltype(it)::value;
             f32x16 v;
@@ -430,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
     } else {
         // vector-only: gradient wrt the last plain hidden output = rank-3 update from the vector head (slot 7)
         f32x4v mk[8][4];
-        load_start_masks<7>(p, mk);
+        load_start_masks<7, MASK_RELU>(p, mk);
         static_for<8>([&](auto it) {
             constexpr int t = decltype(it)::value;
             f32x16 v;
@@ -528,7 +556,7 @@ extern "C" int vfn_pack_weights_bwd16(int32_t net_kind, const vfn_net_geom* geom
 
 extern "C" int vfn_mlp_bwd_chain_bf16(const vfn_net_geom* vf_geom, const void* vf_packed_bwd16, const float* vf_head_w,
                                       const vfn_net_geom* rn_geom, const void* rn_packed_bwd16, const float* rn_head_w,
-                                      const float* saved, float* dy, const float* d_colors, const float* colors,
+                                      const float* saved, const uint32_t* masks, float* dy, const float* d_colors, const float* colors,
                                       const float* d_vec, const float* vec, const float* d_feats, int32_t vec_stride,
                                       int64_t n_points, float* dz_rgb, float* dz_vec, void* stream) {
     VFN_REQUIRE(vf_geom, "vfn_mlp_bwd_chain_bf16: NULL argument");
@@ -541,12 +569,12 @@ extern "C" int vfn_mlp_bwd_chain_bf16(const vfn_net_geom* vf_geom, const void* v
         VFN_REQUIRE(rn_packed_bwd16 && rn_head_w && d_colors && colors && dz_rgb, "vfn_mlp_bwd_chain_bf16: NULL rendering-net argument");
     }
     if (n_points <= 0) return VFN_OK;
-    VFN_REQUIRE(vf_packed_bwd16 && vf_head_w && saved && dy && d_vec && vec && dz_vec, "vfn_mlp_bwd_chain_bf16: NULL argument");
+    VFN_REQUIRE(vf_packed_bwd16 && vf_head_w && saved && masks && dy && d_vec && vec && dz_vec, "vfn_mlp_bwd_chain_bf16: NULL argument");
     VFN_REQUIRE(vec_stride >= 3, "vfn_mlp_bwd_chain_bf16: vec_stride must be >= 3");
     VFN_REQUIRE(n_points < (1ll << 22), "vfn_mlp_bwd_chain_bf16: at most 4194303 points per launch (32-bit slot offsets)");
     Bwd16Args a = {};
     a.vf_wt = (const uint4*)vf_packed_bwd16; a.rn_wt = (const uint4*)rn_packed_bwd16; a.vf_head = vf_head_w; a.rn_head = rn_head_w;
-    a.saved = saved; a.dy = dy; a.d_colors = d_colors; a.colors = colors; a.d_vec = d_vec; a.vec = vec; a.d_feats = d_feats;
+    a.saved = saved; a.masks = masks; a.dy = dy; a.d_colors = d_colors; a.colors = colors; a.d_vec = d_vec; a.vec = vec; a.d_feats = d_feats;
     a.dz_rgb = dz_rgb; a.dz_vec = dz_vec; a.n_points = n_points; a.vec_stride = vec_stride;
     const unsigned blocks = (unsigned)((n_points + BW_PTS - 1) / BW_PTS);
     hipStream_t s = (hipStream_t)stream;

@@ -326,6 +326,8 @@ struct Mlp16Args {
     float* saved;
     float* save_aux_vf;
     float* save_aux_rn;
+    // training modes: ReLU sign bits of every saved activation, [13][M][2][4] u32 (see save_mask)
+    uint32_t* save_masks;
     // split launches: feature operand blocks, 1 KiB per point: [tile t][lane half g][hi 2t | lo 2t | hi 2t+1 | lo 2t+1] x 16 B
     uint4* blk_out;           // M16_BLKOUT: written for rows 0 .. n_points-1
     const uint4* blk_in;      // M16_BLKIN: block buffer, groups of 32 rows (store_blocks)
@@ -345,6 +347,9 @@ struct Pipe16 {
     long long slot_floats;         // M * 256
     uint32_t slot_bytes;           // M * 1024 (the host checks that it fits)
     uint32_t save_voff;            // byte offset of this lane's 16-byte column group in a slot row; out of range for m >= M
+    uint32_t* masks;               // ReLU sign bits, 32 bytes per point and slot: [slot][m][lane half][4 dwords]
+    uint32_t mask_bytes;           // M * 32
+    uint32_t mask_voff;            // (2 m + (lane >> 5)) * 16, out of range for m >= M
     // feature operand blocks
     uint4* blk_out;
     uint32_t blk_bytes, blk_voff;  // rows * 1024; m * 1024 + 64 * (lane >> 5), out of range for m >= M
@@ -357,6 +362,7 @@ struct Carry16 {
     f32x16 pend;
     f32x16 bias;
     half8 fh0, fl0;
+    uint32_t lm[4];      // training: sign bits of the layer being produced, 16 per finished tile (tile t -> half t & 1 of dword t >> 1)
 };
 
 template <int N, typename F, int... I>
@@ -442,6 +448,27 @@ __device__ __forceinline__ void save_group(const Pipe16& p, const f32x16& v, int
 #else
     asm volatile("" :: "v"(g));
 #endif
+}
+
+// Training: the sign bits of a finished (activated) tile.  The dX chain needs of every ReLU output only whether it is
+// positive: 16 bits per lane and tile (bit r <-> accumulator register r, the same layout the chain's tiles have) instead of
+// 64 bytes of fp32 — the chain then reads 32 bytes per point and layer where it read 1 KiB.  The bits of a layer's tiles are
+// collected in cy.lm and leave as ONE 16-byte store when its last tile is done.
+template <int TILE>
+__device__ __forceinline__ void collect_mask(Carry16& cy) {
+    unsigned b = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b |= (cy.pend[r] > 0.f ? 1u : 0u) << r;
+    cy.lm[TILE >> 1] |= b << (16 * (TILE & 1));
+}
+template <int SLOT>
+__device__ __forceinline__ void store_mask(const Pipe16& p, Carry16& cy) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<unsigned char*>(p.masks) + (size_t)SLOT * p.mask_bytes, 0, (int)p.mask_bytes, 0x00020000);
+    const u32x4 w = {cy.lm[0], cy.lm[1], cy.lm[2], cy.lm[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)p.mask_voff, 0, 0);
+    cy.lm[0] = 0; cy.lm[1] = 0; cy.lm[2] = 0; cy.lm[3] = 0;
 }
 
 // One layer: xout <- f(W' [xin ; aux] + b') — NCH chunks (C0 .. C0+NCH-1 of the launch) of one 32-row output tile each.
@@ -570,6 +597,10 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
                 for (int q = (st - H) * 4 / SSTEPS; q < (st - H + 1) * 4 / SSTEPS; ++q) {
                     if (ch > 0) save_group<(SLOT >= 0 ? SLOT : 0), (ch > 0 ? ch - 1 : 0)>(p, cy.pend, q);
                     else save_group<(PSLOT >= 0 ? PSLOT : 0), PKB / 2>(p, cy.pend, q);
+                }
+                if (st == H) {       // its sign bits; the pending tile (ch == 0) is the last one of the previous layer
+                    if (ch > 0) collect_mask<(ch > 0 ? ch - 1 : 0)>(cy);
+                    else { collect_mask<PKB / 2>(cy); store_mask<(PSLOT >= 0 ? PSLOT : 0)>(p, cy); }
                 }
             }
             // -- split launches: a finished feature tile leaves as operand blocks, after the hand-over like the stores above
@@ -742,6 +773,7 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
         p.vf_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.rn_w), 0, (int)a.rn_bytes, 0x00020000);
         p.rn_w = p.vf_w;
         p.saved = nullptr; p.slot_floats = 0; p.slot_bytes = 0; p.save_voff = 0; p.blk_out = nullptr; p.blk_bytes = 0; p.blk_voff = 0;
+        p.masks = nullptr; p.mask_bytes = 0; p.mask_voff = 0;
         dma_chunk<MODE, 0>(p, wave, lane);
         dma_chunk<MODE, 1>(p, wave, lane);
         X16 xa, xb;
@@ -773,6 +805,7 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
         Carry16 cy;
 #pragma unroll
         for (int q = 0; q < 16; ++q) cy.pend[q] = 0.f;
+        cy.lm[0] = 0; cy.lm[1] = 0; cy.lm[2] = 0; cy.lm[3] = 0;
         prefetch_chunk<MODE, 0>(cy, p, lane);
 #ifdef VFN16_STAMPS
         const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();
@@ -807,6 +840,7 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
                                                (int)((MODE & M16_RENDER) ? a.rn_bytes : a.vf_bytes), 0x00020000);
     p.saved = a.saved; p.slot_floats = a.n_points * 256; p.slot_bytes = (uint32_t)(a.n_points * 1024);
     p.save_voff = in ? (uint32_t)(m * 1024 + g * 16) : 0xfffffff0u;
+    p.masks = a.save_masks; p.mask_bytes = (uint32_t)(a.n_points * 32); p.mask_voff = in ? (uint32_t)((2 * m + g) * 16) : 0xfffffff0u;
     p.blk_out = a.blk_out; p.blk_bytes = (uint32_t)(((a.n_points + 31) & ~31ll) * 1024);
     p.blk_voff = (uint32_t)((m >> 5) * 32768 + lane * 16);      // past the last group -> out of the descriptor's range, dropped
     dma_chunk<MODE, 0>(p, wave, lane);
@@ -836,6 +870,7 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     Carry16 cy;
 #pragma unroll
     for (int q = 0; q < 16; ++q) cy.pend[q] = 0.f;
+    cy.lm[0] = 0; cy.lm[1] = 0; cy.lm[2] = 0; cy.lm[3] = 0;
     prefetch_chunk<MODE, 0>(cy, p, lane);
 
     // ---- VF net: straight-line code with static operand-set roles, so that only one set plus the tiles produced so far
@@ -1006,7 +1041,8 @@ extern "C" int vfn_render16_from_blocks(const vfn_net_geom* rn_geom, const void*
 // training forwards: same arithmetic, plus the workspace the backward kernels read (include/vfn.h, "slots")
 // ------------------------------------------------------------------------------------------------
 extern "C" int vfn_vf_mlp16_fwd_train(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
-                                      int32_t with_features, float* out_vec, float* saved, float* save_aux_vf, void* stream) {
+                                      int32_t with_features, float* out_vec, float* saved, float* save_aux_vf, uint32_t* save_masks,
+                                      void* stream) {
     Mlp16Args a = {};
     VfnNetPlan p32; Plan16 vf;
     int rc = make_plan16(VFN_NET_VF, geom, &p32, &vf, "vfn_vf_mlp16_fwd_train");
@@ -1014,10 +1050,11 @@ extern "C" int vfn_vf_mlp16_fwd_train(const vfn_net_geom* geom, const void* pack
     rc = check_vf16(vf, "vfn_vf_mlp16_fwd_train");
     if (rc != VFN_OK) return rc;
     if (n_points <= 0) return VFN_OK;
-    VFN_REQUIRE(packed16 && points && out_vec && saved && save_aux_vf, "vfn_vf_mlp16_fwd_train: NULL argument");
+    VFN_REQUIRE(packed16 && points && out_vec && saved && save_aux_vf && save_masks, "vfn_vf_mlp16_fwd_train: NULL argument");
     VFN_REQUIRE(n_points < (1ll << 22), "vfn_vf_mlp16_fwd_train: at most 4194303 points per launch (32-bit slot offsets)");
     a.vf_w = (const uint4*)packed16; a.points = points; a.out_vec = out_vec; a.n_points = n_points; a.dirs_div = 1;
     a.vf_multires = vf.multires; a.vf_bytes = vf.total_kb * 1024u; a.saved = saved; a.save_aux_vf = save_aux_vf;
+    a.save_masks = save_masks;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     if (with_features) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_FULL_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_VEC_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
@@ -1027,7 +1064,7 @@ extern "C" int vfn_vf_mlp16_fwd_train(const vfn_net_geom* geom, const void* pack
 extern "C" int vfn_vf_render_fused16_fwd_train(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
                                                const void* rn_packed16, const float* points, const float* ray_dirs,
                                                int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
-                                               float* saved, float* save_aux_vf, float* save_aux_rn, void* stream) {
+                                               float* saved, float* save_aux_vf, float* save_aux_rn, uint32_t* save_masks, void* stream) {
     Mlp16Args a = {};
     VfnNetPlan p32; Plan16 vf, rn;
     int rc = make_plan16(VFN_NET_VF, vf_geom, &p32, &vf, "vfn_vf_render_fused16_fwd_train");
@@ -1039,14 +1076,14 @@ extern "C" int vfn_vf_render_fused16_fwd_train(const vfn_net_geom* vf_geom, cons
     rc = check_rn16(rn, "vfn_vf_render_fused16_fwd_train");
     if (rc != VFN_OK) return rc;
     if (n_points <= 0) return VFN_OK;
-    VFN_REQUIRE(vf_packed16 && rn_packed16 && points && ray_dirs && normals && colors && saved && save_aux_vf && save_aux_rn,
+    VFN_REQUIRE(vf_packed16 && rn_packed16 && points && ray_dirs && normals && colors && saved && save_aux_vf && save_aux_rn && save_masks,
                 "vfn_vf_render_fused16_fwd_train: NULL argument");
     VFN_REQUIRE(samples_per_ray > 0, "vfn_vf_render_fused16_fwd_train: samples_per_ray must be > 0");
     VFN_REQUIRE(n_points < (1ll << 22), "vfn_vf_render_fused16_fwd_train: at most 4194303 points per launch (32-bit slot offsets)");
     a.vf_w = (const uint4*)vf_packed16; a.rn_w = (const uint4*)rn_packed16; a.points = points; a.ray_dirs = ray_dirs;
     a.out_vec = normals; a.out_colors = colors; a.n_points = n_points; a.dirs_div = samples_per_ray;
     a.vf_multires = vf.multires; a.rn_multires = rn.multires; a.vf_bytes = vf.total_kb * 1024u; a.rn_bytes = rn.total_kb * 1024u;
-    a.saved = saved; a.save_aux_vf = save_aux_vf; a.save_aux_rn = save_aux_rn;
+    a.saved = saved; a.save_aux_vf = save_aux_vf; a.save_aux_rn = save_aux_rn; a.save_masks = save_masks;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_render_fused16_fwd_train");

@@ -372,14 +372,28 @@ def pack_weights_bwd16(kind: int, geom: NetGeom, layers: Sequence[dict], packed:
                                          _stream()), "vfn_pack_weights_bwd16")
 
 
-def mlp_bwd_chain_bf16(vf_geom, vf_packed_bwd16, vf_head_w, rn_geom, rn_packed_bwd16, rn_head_w, saved, dy, d_colors, colors,
+def relu_sign_words(saved: torch.Tensor) -> torch.Tensor:
+    """saved[slots, M, 256] -> the sign-bit words the f16x3 training forwards write next to it: int32 [slots, M, 2, 4] (per slot,
+    point and lane half g: tile t -> half t & 1 of dword t >> 1, bit r <-> column 32 t + (r & 3) + 8 (r >> 2) + 4 g).  A torch
+    restatement for callers that build a workspace by hand (tests)."""
+    dev = saved.device
+    r = torch.arange(16, device=dev)
+    col = (32 * torch.arange(8, device=dev)[None, :, None] + (r & 3)[None, None, :] + 8 * (r >> 2)[None, None, :]
+           + 4 * torch.arange(2, device=dev)[:, None, None])                     # [g, t, r]
+    bits = (saved[:, :, col.reshape(-1)] > 0).view(saved.shape[0], saved.shape[1], 2, 8, 16).to(torch.int64)
+    half = (bits << r).sum(-1)                                                   # [slots, M, g, t] 16-bit fields
+    words = half[..., 0::2] | (half[..., 1::2] << 16)                           # [slots, M, g, 4]
+    return torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()
+
+
+def mlp_bwd_chain_bf16(vf_geom, vf_packed_bwd16, vf_head_w, rn_geom, rn_packed_bwd16, rn_head_w, saved, masks, dy, d_colors, colors,
                        d_vec, vec, d_feats, vec_stride: int, n_points: int, dz_rgb, dz_vec):
     rn = C.byref(rn_geom) if rn_geom is not None else None
     _check(load().vfn_mlp_bwd_chain_bf16(C.byref(vf_geom), _ptr(vf_packed_bwd16, "vf_packed_bwd16", torch.uint8),
                                          _ptr(vf_head_w, "vf_head_w"), rn,
                                          _ptr(rn_packed_bwd16, "rn_packed_bwd16", torch.uint8), _ptr(rn_head_w, "rn_head_w"),
-                                         _ptr(saved, "saved"), _ptr(dy, "dy"), _ptr(d_colors, "d_colors"),
-                                         _ptr(colors, "colors"), _ptr(d_vec, "d_vec"), _ptr(vec, "vec"),
+                                         _ptr(saved, "saved"), _ptr(masks, "masks", torch.int32), _ptr(dy, "dy"),
+                                         _ptr(d_colors, "d_colors"), _ptr(colors, "colors"), _ptr(d_vec, "d_vec"), _ptr(vec, "vec"),
                                          _ptr(d_feats, "d_feats"), C.c_int32(vec_stride), C.c_int64(n_points),
                                          _ptr(dz_rgb, "dz_rgb"), _ptr(dz_vec, "dz_vec"), _stream()), "vfn_mlp_bwd_chain_bf16")
 
@@ -479,20 +493,20 @@ def render16_from_blocks(rn_geom: NetGeom, rn_packed16, blocks, vecs, dst, point
     return normals, colors
 
 
-def vf_mlp16_fwd_train(geom: NetGeom, packed16, points, with_features: bool, saved, aux_vf):
+def vf_mlp16_fwd_train(geom: NetGeom, packed16, points, with_features: bool, saved, aux_vf, masks):
     """f16x3 VF forward that fills the backward workspace; returns the vector columns [M,3] (the features, when
     evaluated, are in their ``saved`` slot)."""
     m = points.shape[0]
     out = torch.empty(m, 3, device=points.device)
     _check(load().vfn_vf_mlp16_fwd_train(C.byref(geom), _ptr(packed16, "packed16", torch.uint8), _ptr(points, "points"),
                                          C.c_int64(m), C.c_int32(1 if with_features else 0), _ptr(out, "out"),
-                                         _ptr(saved, "saved"), _ptr(aux_vf, "aux_vf"), _stream()),
+                                         _ptr(saved, "saved"), _ptr(aux_vf, "aux_vf"), _ptr(masks, "masks", torch.int32), _stream()),
            "vfn_vf_mlp16_fwd_train")
     return out
 
 
 def vf_render_fused16_fwd_train(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, samples_per_ray, saved,
-                                aux_vf, aux_rn):
+                                aux_vf, aux_rn, masks):
     m = points.shape[0]
     dev = points.device
     normals = torch.empty(m, 3, device=dev)
@@ -502,7 +516,8 @@ def vf_render_fused16_fwd_train(vf_geom, vf_packed16, rn_geom, rn_packed16, poin
                                                   _ptr(points, "points"), _ptr(ray_dirs, "ray_dirs"), C.c_int64(m),
                                                   C.c_int32(samples_per_ray), _ptr(normals, "normals"),
                                                   _ptr(colors, "colors"), _ptr(saved, "saved"), _ptr(aux_vf, "aux_vf"),
-                                                  _ptr(aux_rn, "aux_rn"), _stream()), "vfn_vf_render_fused16_fwd_train")
+                                                  _ptr(aux_rn, "aux_rn"), _ptr(masks, "masks", torch.int32), _stream()),
+           "vfn_vf_render_fused16_fwd_train")
     return normals, colors
 
 
