@@ -69,6 +69,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #ifndef VFN16_EPI_PER_MFMA
 #define VFN16_EPI_PER_MFMA 6     // VALU instructions of the pending epilogue scheduled behind each MFMA
 #endif
+#ifndef VFN16_MASK_STEP
+#define VFN16_MASK_STEP(H, NKB) (H)     // K step of a tile that carries the sign-bit collection of the pending tile (training)
+#endif
 #define VFN16_MAX_CHUNK_KB 39     // (16 act + 3 aux) K-blocks x 2 planes + 1 bias block
 
 struct Plan16 {
@@ -454,12 +457,16 @@ __device__ __forceinline__ void save_group(const Pipe16& p, const f32x16& v, int
 // positive: 16 bits per lane and tile (bit r <-> accumulator register r, the same layout the chain's tiles have) instead of
 // 64 bytes of fp32 — the chain then reads 32 bytes per point and layer where it read 1 KiB.  The bits of a layer's tiles are
 // collected in cy.lm and leave as ONE 16-byte store when its last tile is done.
-template <int TILE>
+template <int TILE, int EPI>
 __device__ __forceinline__ void collect_mask(Carry16& cy) {
-    unsigned b = 0;
+    if constexpr (EPI == EPI_RELU) {      // values are >= +0 here: positive <=> a non-zero bit pattern (two VALU ops per value)
+        typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
+        const u32x16 u = __builtin_bit_cast(u32x16, cy.pend);
+        unsigned b = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) b |= (cy.pend[r] > 0.f ? 1u : 0u) << r;
-    cy.lm[TILE >> 1] |= b << (16 * (TILE & 1));
+        for (int r = 0; r < 16; ++r) b |= min(u[r], 1u) << r;
+        cy.lm[TILE >> 1] |= b << (16 * (TILE & 1));
+    }                                     // the tanh'ed feature block has no mask: the chain reads its values
 }
 template <int SLOT>
 __device__ __forceinline__ void store_mask(const Pipe16& p, Carry16& cy) {
@@ -598,10 +605,12 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
                     if (ch > 0) save_group<(SLOT >= 0 ? SLOT : 0), (ch > 0 ? ch - 1 : 0)>(p, cy.pend, q);
                     else save_group<(PSLOT >= 0 ? PSLOT : 0), PKB / 2>(p, cy.pend, q);
                 }
-                if (st == H) {       // its sign bits; the pending tile (ch == 0) is the last one of the previous layer
-                    if (ch > 0) collect_mask<(ch > 0 ? ch - 1 : 0)>(cy);
-                    else { collect_mask<PKB / 2>(cy); store_mask<(PSLOT >= 0 ? PSLOT : 0)>(p, cy); }
+#ifndef ABL_NOMASK
+                if (st == VFN16_MASK_STEP(H, NKB)) {       // its sign bits; the pending tile (ch == 0) is the last one of the previous layer
+                    if (ch > 0) collect_mask<(ch > 0 ? ch - 1 : 0), EPI>(cy);
+                    else { collect_mask<PKB / 2, (PEPI >= 0 ? PEPI : 0)>(cy); store_mask<(PSLOT >= 0 ? PSLOT : 0)>(p, cy); }
                 }
+#endif
             }
             // -- split launches: a finished feature tile leaves as operand blocks, after the hand-over like the stores above
             if (st == H && ((BLK && ch > 0) || (PBLK && ch == 0))) {
