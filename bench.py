@@ -286,6 +286,7 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync):
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                           "data": "synthetic", "final_loss": round(float(loss), 5),
+                          "activation_storage": model.activation_storage,
                           "networks": "training mode (batch-statistics BatchNorm, layer-at-a-time fp32 kernels)"
                           if model.vector_field_network.training else "eval mode (the shipped regime, fused kernels)",
                           "config": {"workload": f"train step: render({args.rays} rays x {s_t}) + 2x{n_sup} supervision "
@@ -305,6 +306,9 @@ def main() -> None:
     ap.add_argument("--coarse", type=int, default=64)
     ap.add_argument("--fine", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--activations", choices=("fp32", "f16"), default="fp32",
+                    help="train workload: storage of the hidden activations for the weight-gradient kernels (f16 = opt-in, "
+                         "11-bit operands, half the workspace traffic; default fp32 = fp32-equivalent gradients)")
     ap.add_argument("--batch-statistics", action="store_true",
                     help="train workload with the networks in training mode (model.train(): batch-statistics BatchNorm, "
                          "Jacobian columns, directional derivatives) instead of the shipped eval-mode regime (SURVEY Q8)")
@@ -375,6 +379,7 @@ def main() -> None:
         torch.cuda.synchronize()
 
     if args.workload == "train":
+        model.activation_storage = args.activations
         if args.batch_statistics:
             model.train()
         train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync)

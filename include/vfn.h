@@ -231,7 +231,9 @@ int vfn_mlp_bwd_chain(const vfn_net_geom* vf_geom, const float* vf_packed, const
  * Columns >= n_valid of dY / >= k_valid of X read as zero. */
 int vfn_weight_grad_partials(int32_t shape, const float* dy, int32_t ld_dy, int32_t n_valid, const float* x,
                              int32_t ld_x, int32_t k_valid, int64_t n_points, int32_t groups, float* dw_part,
-                             float* db_part, void* stream);
+                             float* db_part, int32_t x_f16, void* stream);
+/* x_f16 != 0 (shape 2 only): the rows of X hold 256 f16 values in their first 512 bytes (the opt-in storage of the f16x3
+ * training forwards, see vfn_vf_mlp16_fwd_train); likewise for vfn_weight_grad_partials_bf16. */
 
 /* Backward of vfn_ray_density_weights: upstream d_rgb[N,3], d_depth[N], d_weights[N,S] (each may be NULL) ->
  * d_colors[N,S,3] (written, may be NULL), d_normals[N,S,3] (ACCUMULATED into), d_scalars[3] (atomically
@@ -264,7 +266,7 @@ int vfn_vf_render_fused16_fwd(const vfn_net_geom* vf_geom, const void* vf_packed
  * bf16 halves (16 significant bits, fp32 exponent range), three products per K-block, fp32 accumulation; same outputs
  * (`groups` slabs [groups][256][256] and [groups][256]).  ~2^-16 relative error per product under the sum over points. */
 int vfn_weight_grad_partials_bf16(const float* dy, const float* x, int64_t n_points, int32_t groups, float* dw_part,
-                                  float* db_part, void* stream);
+                                  float* db_part, int32_t x_f16, void* stream);
 
 /* vfn_mlp_bwd_chain on the bf16 matrix cores (split operands, three products per K-block, fp32 accumulation; shipped layer
  * shapes only, others return VFN_ERR_UNSUPPORTED).  Takes its own TRANSPOSED bf16 packs (vfn_pack_weights_bwd16; re-run
@@ -329,14 +331,19 @@ int vfn_sample_sphere_shell(int64_t n, float r_min, float r_max, const float* ce
  * workspace the backward entry points read (`saved` slots, save_aux_vf[M,40], save_aux_rn[M,40]; see "slots" above),
  * exactly like vfn_vf_mlp_fwd_train / vfn_vf_render_fused_fwd_train.  with_features = 0 evaluates only the vector head
  * (the feature slot is not written); with_features = 1 also writes the 256 tanh'ed features into their slot, from which
- * the caller assembles [M, 3+F].  n_points < 2^22 per launch. */
+ * the caller assembles [M, 3+F].  n_points < 2^22 per launch.
+ * save_masks: the sign bits of every saved ReLU output (see vfn_mlp_bwd_chain_bf16).  save_f16 != 0 (opt-in): the ReLU slots
+ * are stored as f16 — 256 values in the first 512 bytes of every 1 KiB row, the row stride does not change — which halves
+ * what the forward writes and the weight-gradient kernels read, at 11 instead of 24 significant bits in the activations that
+ * multiply dY (BASELINE.json configs[2] trains on bf16 matrix cores); the tanh'ed feature slot (8) stays fp32. */
 int vfn_vf_mlp16_fwd_train(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
                            int32_t with_features, float* out_vec, float* saved, float* save_aux_vf, uint32_t* save_masks,
-                           void* stream);
+                           int32_t save_f16, void* stream);
 int vfn_vf_render_fused16_fwd_train(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
                                     const void* rn_packed16, const float* points, const float* ray_dirs,
                                     int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
-                                    float* saved, float* save_aux_vf, float* save_aux_rn, uint32_t* save_masks, void* stream);
+                                    float* saved, float* save_aux_vf, float* save_aux_rn, uint32_t* save_masks, int32_t save_f16,
+                                    void* stream);
 
 /* =============================================================================================
  * Dense-grid stages between the vector-field queries and the mesh triangulation (evaluation/utils/mc_utils.py,

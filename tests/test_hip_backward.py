@@ -25,14 +25,17 @@ def _hip_gradients(fx, d, model):
     return float(loss), out
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x3", "fp32", "f16x3+f16act"])
 @pytest.mark.parametrize("name", FIXTURE_NAMES)
 def test_render_gradients(name, precision):
     """``precision`` selects the arithmetic of the activation-saving forward (split-half f16 products or exact fp32
-    MFMA); the backward kernels are fp32 either way."""
+    MFMA); "+f16act" additionally stores the hidden activations as f16 for the weight-gradient kernels (opt-in,
+    ``model.activation_storage``): the same 1e-3 bound must hold, the observed error is printed."""
     fx, d = load_fixture(name)
     model = build_model(fx, d, device="cuda:0")
-    model.precision = precision
+    f16act = precision.endswith("+f16act")
+    model.precision = precision.split("+")[0]
+    model.activation_storage = "f16" if f16act else "fp32"
     loss, out = _hip_gradients(fx, d, model)
     assert (out.z_vals.cpu() == d["z_vals"]).all(), "sampling must replay exactly for the comparison to be meaningful"
     ref_loss, ref = oracle_gradients(fx, d, build_model(fx, d))
@@ -42,6 +45,8 @@ def test_render_gradients(name, precision):
     # gradient by percents).  Count such flips from the saved activations; when there are any, the tight comparison is
     # made against the oracle re-run with THIS implementation's masks pinned.
     saved = model._debug_saved.cpu()
+    if f16act:            # the ReLU slots hold 256 f16 values in the first half of every row
+        saved = saved.view(torch.float16)[:, :, :256].float()
     slots = list(range(8)) + list(range(9, 13))          # VF hidden 0..7, rendering hidden 0..3 (slot 8 = features)
     masks, flips = [], 0
     for slot, act in zip(slots, ref["_hidden"]):

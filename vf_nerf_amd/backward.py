@@ -111,13 +111,15 @@ def _rn_inputs(feats: torch.Tensor, saved_slots: List[torch.Tensor]) -> List[tor
     return [feats] + list(saved_slots)
 
 
-def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=(), fast: bool = False
-                  ) -> Dict[torch.nn.Parameter, torch.Tensor]:
+def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=(), fast: bool = False, x_f16: bool = False,
+                  x_fp32_entries=()) -> Dict[torch.nn.Parameter, torch.Tensor]:
     """inputs[h]: [M,256] act input of hidden entry h (None if it has none); inputs[-1]: input of the 3-channel head.
     dy_slots[h]: [M,256] pre-activation gradient of entry h.  aux: [M,40].  dz_head: [M,4].  Runs the persistent
     weight-gradient kernels (``fast``: the 256 x 256 products on the bf16 matrix cores, csrc/vfn_dw16.hip), then ONE
     launch (csrc/vfn_unfold.hip) sums their partial slabs and un-folds BatchNorm / the skip scale onto the parameters:
-        W' = s * scale * W,  b' = s (b - mu) + beta_bn,  s = gamma / sqrt(var + eps)."""
+        W' = s * scale * W,  b' = s (b - mu) + beta_bn,  s = gamma / sqrt(var + eps).
+    ``x_f16``: the act inputs are workspace slots in the opt-in f16 storage (first 512 bytes of each row), except the
+    entries listed in ``x_fp32_entries`` (the rendering net's first layer reads the fp32 feature slot)."""
     dev = aux.device
     entries = _entries(net)
     G = _groups(m)
@@ -140,7 +142,7 @@ def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=(), fast: bo
         if e["act"] is not None:
             part = torch.empty(G, HID, HID, device=dev)
             if fast:
-                lib.weight_grad_partials_bf16(dy, inputs[h], m, G, part, db_part)
+                lib.weight_grad_partials_bf16(dy, inputs[h], m, G, part, db_part, x_f16=x_f16 and h not in x_fp32_entries)
             else:
                 lib.weight_grad_partials(0, dy, HID, HID, inputs[h], HID, HID, m, G, part, db_part)
             u.update(dw_act=part, act_c0=e["act"][0], act_nc=e["act"][1])
@@ -157,7 +159,7 @@ def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=(), fast: bo
     last = net._linear(net.num_layers - 1)
     part = torch.empty(G, 32, HID, device=dev)
     dbp = torch.empty(G, 32, device=dev)
-    lib.weight_grad_partials(2, dz_head, 4, 3, inputs[-1], HID, HID, m, G, part, dbp)
+    lib.weight_grad_partials(2, dz_head, 4, 3, inputs[-1], HID, HID, m, G, part, dbp, x_f16=x_f16)
     fresh = last.weight not in grads          # the feature rows of the last Linear were skipped (vector-only forward)
     unfold.append(dict(dw_act=part, db=dbp, w=last.weight.detach(), b_lin=last.bias.detach(), g_w=out_for(last.weight),
                        g_b=out_for(last.bias), rows=3, row_off=0, in_dim=last.in_features, slab_rows=32, act_c0=0,
@@ -173,7 +175,10 @@ _F16_TRAIN_MAX_POINTS = 1 << 22   # the f16x3 training kernels address a workspa
 
 
 class _Workspace:
-    def __init__(self, m: int, n_slots: int, dev) -> None:
+    def __init__(self, m: int, n_slots: int, dev, f16: bool = False) -> None:
+        # f16: the f16x3 training forward stores the ReLU slots as f16 (first 512 bytes of every row; opt-in, see
+        # VectorFieldNerf.activation_storage); the buffer keeps its shape, the tanh'ed feature slot stays fp32
+        self.f16 = f16
         self.saved = torch.empty(n_slots, m, HID, device=dev)
         # sign bits of the saved ReLU outputs (f16x3 training forwards write them, the bf16 chain reads them): 32 B per point and slot
         self.masks = torch.empty(n_slots, m, 2, 4, dtype=torch.int32, device=dev)
@@ -192,12 +197,13 @@ class _FinePass(torch.autograd.Function):
         m = n * s_t
         dev = pts.device
         vf_h, rn_h = len(_entries(vf)), len(_entries(rn))
-        ws = _Workspace(m, vf_h + rn_h, dev)
+        fast = model.uses_f16x3() and m < _F16_TRAIN_MAX_POINTS
+        ws = _Workspace(m, vf_h + rn_h, dev, f16=fast and getattr(model, "activation_storage", "fp32") == "f16")
         scal = model.density.raw_scalars()
-        if model.uses_f16x3() and m < _F16_TRAIN_MAX_POINTS:   # split-half products, fp32-equivalent (csrc/vfn_mlp16.hip)
+        if fast:                                               # split-half products, fp32-equivalent (csrc/vfn_mlp16.hip)
             normals, colors = lib.vf_render_fused16_fwd_train(vf.geometry(), vf.packed16_weights(), rn.geometry(),
                                                               rn.packed16_weights(), pts.reshape(-1, 3), ray_dirs, s_t,
-                                                              ws.saved, ws.aux_vf, ws.aux_rn, ws.masks)
+                                                              ws.saved, ws.aux_vf, ws.aux_rn, ws.masks, save_f16=ws.f16)
         else:
             normals, colors = lib.vf_render_fused_fwd_train(vf.geometry(), vf.packed_weights(), rn.geometry(),
                                                             rn.packed_weights(), pts.reshape(-1, 3), ray_dirs, s_t,
@@ -243,9 +249,10 @@ class _FinePass(torch.autograd.Function):
                               _packed_bwd(rn), ws.saved, dy, dc, colors, dn, normals, None, 3, m, dz_rgb, dz_vec)
         # (3) weight gradients
         g_vf = _weight_grads(vf, _vf_inputs(vf, [ws.saved[h] for h in range(vf_h)]), [dy[h] for h in range(vf_h)],
-                             ws.aux_vf, dz_vec, m, fast=model.uses_f16x3())
+                             ws.aux_vf, dz_vec, m, fast=model.uses_f16x3(), x_f16=ws.f16)
         g_rn = _weight_grads(rn, _rn_inputs(ws.saved[vf_h - 1], [ws.saved[vf_h + h] for h in range(rn_h)]),
-                             [dy[vf_h + h] for h in range(rn_h)], ws.aux_rn, dz_rgb, m, fast=model.uses_f16x3())
+                             [dy[vf_h + h] for h in range(rn_h)], ws.aux_rn, dz_rgb, m, fast=model.uses_f16x3(), x_f16=ws.f16,
+                             x_fp32_entries=(0,))
         # density scalars in density.parameters() order
         by_name = {"beta": dscal[0], "mean": dscal[1], "scale": dscal[2]}
         g_den = {p: by_name[name].reshape(p.shape) for name, p in model.density.named_parameters()}
@@ -273,10 +280,12 @@ class _VFForward(torch.autograd.Function):
         dev = pts.device
         has_feat = net._feature_dims() > 0
         vf_h = len(_entries(net))
-        ws = _Workspace(m, vf_h, dev)
         cols = 3 if (vector_only or not has_feat) else 3 + net._feature_dims()
-        if getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3() and m < _F16_TRAIN_MAX_POINTS:
-            out = lib.vf_mlp16_fwd_train(net.geometry(), net.packed16_weights(), pts, cols > 3, ws.saved, ws.aux_vf, ws.masks)
+        fast = getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3() and m < _F16_TRAIN_MAX_POINTS
+        ws = _Workspace(m, vf_h, dev, f16=fast and getattr(net, "activation_storage", "fp32") == "f16")
+        if fast:
+            out = lib.vf_mlp16_fwd_train(net.geometry(), net.packed16_weights(), pts, cols > 3, ws.saved, ws.aux_vf, ws.masks,
+                                         save_f16=ws.f16)
             if cols > 3:   # [vector | features]: the kernel left the features in their workspace slot
                 out = torch.cat([out, ws.saved[vf_h - 1]], dim=1)
         else:
@@ -307,7 +316,7 @@ class _VFForward(torch.autograd.Function):
         # vector-only forward: the feature block of the last Linear was never evaluated -> no gradient for it
         skip = (vf_h - 1,) if (net._feature_dims() > 0 and cols == 3) else ()
         grads = _weight_grads(net, _vf_inputs(net, [ws.saved[h] for h in range(vf_h)]), [dy[h] for h in range(vf_h)],
-                              ws.aux_vf, dz_vec, m, skip=skip, fast=fast)
+                              ws.aux_vf, dz_vec, m, skip=skip, fast=fast, x_f16=ws.f16)
         ctx.ws = None
         return (None, None, None, *[grads.get(p) for p in ctx.param_order])
 

@@ -42,7 +42,7 @@ constexpr int DW_BUF = 4 * DW_IMG;              // (dY | X) x (hi | lo)
 
 struct Dw16Args {
     const float* dy;      // [M][256]
-    const float* x;       // [M][256]
+    const float* x;       // [M][256] fp32, or (XH) 256 f16 values in the first 512 bytes of every 1 KiB row
     float* dw_part;       // [G][256][256]
     float* db_part;       // [G][256] or NULL
     long long n_points;
@@ -71,6 +71,7 @@ __device__ __forceinline__ void split4(const f32x4v v, uint2& hi, uint2& lo) {
     lo.y = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf2));
 }
 
+template <bool XH>
 __global__ __launch_bounds__(256, 1) void vfn_dw16_kernel(const Dw16Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * DW_BUF];
     const int tid = threadIdx.x;
@@ -104,14 +105,29 @@ __global__ __launch_bounds__(256, 1) void vfn_dw16_kernel(const Dw16Args a) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             ld_dy[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, lane * 16, (row0 + r) * 1024, 0);
-            ld_x[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, lane * 16, (row0 + r) * 1024, 0);
+            if (XH) {
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rs_x, lane * 8, (row0 + r) * 1024, 0);
+                ld_x[r] = u32x4{h[0], h[1], 0u, 0u};
+            } else {
+                ld_x[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, lane * 16, (row0 + r) * 1024, 0);
+            }
         }
     };
     auto stage = [&](int buf) {                              // split + write this wave's rows into the images of `buf`
         unsigned char* base = lds + buf * DW_BUF + (8 * wave) * DW_ROW + lane * 8;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const f32x4v vd = __builtin_bit_cast(f32x4v, ld_dy[r]), vx = __builtin_bit_cast(f32x4v, ld_x[r]);
+            const f32x4v vd = __builtin_bit_cast(f32x4v, ld_dy[r]);
+            f32x4v vx;
+            if (XH) {
+                typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 h = {ld_x[r][0], ld_x[r][1]};
+                vx = __builtin_convertvector(__builtin_bit_cast(half4, h), f32x4v);
+            } else {
+                vx = __builtin_bit_cast(f32x4v, ld_x[r]);
+            }
             uint2 hi, lo;
             split4(vd, hi, lo);
             *reinterpret_cast<uint2*>(base + 0 * DW_IMG + r * DW_ROW) = hi;
@@ -187,12 +203,13 @@ __global__ __launch_bounds__(256, 1) void vfn_dw16_kernel(const Dw16Args a) {
 }  // namespace
 
 extern "C" int vfn_weight_grad_partials_bf16(const float* dy, const float* x, int64_t n_points, int32_t groups,
-                                             float* dw_part, float* db_part, void* stream) {
+                                             float* dw_part, float* db_part, int32_t x_f16, void* stream) {
     VFN_REQUIRE(dy && x && dw_part, "vfn_weight_grad_partials_bf16: NULL argument");
     VFN_REQUIRE(groups >= 1 && groups <= 4096, "vfn_weight_grad_partials_bf16: groups=%d", groups);
     VFN_REQUIRE(n_points >= 0 && n_points < (1ll << 21) * groups, "vfn_weight_grad_partials_bf16: slab larger than 2 GiB");
     Dw16Args a = {};
     a.dy = dy; a.x = x; a.dw_part = dw_part; a.db_part = db_part; a.n_points = n_points;
-    hipLaunchKernelGGL(vfn_dw16_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, a);
+    if (x_f16) hipLaunchKernelGGL(vfn_dw16_kernel<true>, dim3(groups), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(vfn_dw16_kernel<false>, dim3(groups), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_weight_grad_partials_bf16");
 }

@@ -331,6 +331,7 @@ struct Mlp16Args {
     float* save_aux_rn;
     // training modes: ReLU sign bits of every saved activation, [13][M][2][4] u32 (see save_mask)
     uint32_t* save_masks;
+    int save_f16;             // training modes: store the ReLU slots as f16 (first 512 bytes of every 1 KiB row)
     // split launches: feature operand blocks, 1 KiB per point: [tile t][lane half g][hi 2t | lo 2t | hi 2t+1 | lo 2t+1] x 16 B
     uint4* blk_out;           // M16_BLKOUT: written for rows 0 .. n_points-1
     const uint4* blk_in;      // M16_BLKIN: block buffer, groups of 32 rows (store_blocks)
@@ -350,6 +351,8 @@ struct Pipe16 {
     long long slot_floats;         // M * 256
     uint32_t slot_bytes;           // M * 1024 (the host checks that it fits)
     uint32_t save_voff;            // byte offset of this lane's 16-byte column group in a slot row; out of range for m >= M
+    uint32_t save_voff16;          // f16 storage: m * 1024 + 8 * (lane >> 5) (row stride stays 1 KiB, 512 bytes of it are used)
+    int save16;                    // training: ReLU slots hold f16 values (the tanh'ed feature slot stays fp32)
     uint32_t* masks;               // ReLU sign bits, 32 bytes per point and slot: [slot][m][lane half][4 dwords]
     uint32_t mask_bytes;           // M * 32
     uint32_t mask_voff;            // (2 m + (lane >> 5)) * 16, out of range for m >= M
@@ -447,7 +450,14 @@ __device__ __forceinline__ void save_group(const Pipe16& p, const f32x16& v, int
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)(((p.save_voff >> 15) << 15) + (threadIdx.x & 63) * 16),
                                            (4 * TILE + q) * 1024, VFN16_SAVE_AUX);
 #elif !defined(ABL_NOSAVE)
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)p.save_voff, (32 * TILE + 8 * q) * 4, VFN16_SAVE_AUX);
+    if (SLOT != 8 && p.save16) {        // opt-in: 11-bit operands for the weight gradients, half the workspace traffic
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const half4 h = __builtin_convertvector(g, half4);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rs, (int)p.save_voff16, (32 * TILE + 8 * q) * 2, VFN16_SAVE_AUX);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)p.save_voff, (32 * TILE + 8 * q) * 4, VFN16_SAVE_AUX);
+    }
 #else
     asm volatile("" :: "v"(g));
 #endif
@@ -782,7 +792,7 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
         p.vf_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.rn_w), 0, (int)a.rn_bytes, 0x00020000);
         p.rn_w = p.vf_w;
         p.saved = nullptr; p.slot_floats = 0; p.slot_bytes = 0; p.save_voff = 0; p.blk_out = nullptr; p.blk_bytes = 0; p.blk_voff = 0;
-        p.masks = nullptr; p.mask_bytes = 0; p.mask_voff = 0;
+        p.masks = nullptr; p.mask_bytes = 0; p.mask_voff = 0; p.save16 = 0; p.save_voff16 = 0;
         dma_chunk<MODE, 0>(p, wave, lane);
         dma_chunk<MODE, 1>(p, wave, lane);
         X16 xa, xb;
@@ -850,6 +860,7 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     p.saved = a.saved; p.slot_floats = a.n_points * 256; p.slot_bytes = (uint32_t)(a.n_points * 1024);
     p.save_voff = in ? (uint32_t)(m * 1024 + g * 16) : 0xfffffff0u;
     p.masks = a.save_masks; p.mask_bytes = (uint32_t)(a.n_points * 32); p.mask_voff = in ? (uint32_t)((2 * m + g) * 16) : 0xfffffff0u;
+    p.save16 = a.save_f16; p.save_voff16 = in ? (uint32_t)(m * 1024 + g * 8) : 0xfffffff0u;
     p.blk_out = a.blk_out; p.blk_bytes = (uint32_t)(((a.n_points + 31) & ~31ll) * 1024);
     p.blk_voff = (uint32_t)((m >> 5) * 32768 + lane * 16);      // past the last group -> out of the descriptor's range, dropped
     dma_chunk<MODE, 0>(p, wave, lane);
@@ -1051,7 +1062,7 @@ extern "C" int vfn_render16_from_blocks(const vfn_net_geom* rn_geom, const void*
 // ------------------------------------------------------------------------------------------------
 extern "C" int vfn_vf_mlp16_fwd_train(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
                                       int32_t with_features, float* out_vec, float* saved, float* save_aux_vf, uint32_t* save_masks,
-                                      void* stream) {
+                                      int32_t save_f16, void* stream) {
     Mlp16Args a = {};
     VfnNetPlan p32; Plan16 vf;
     int rc = make_plan16(VFN_NET_VF, geom, &p32, &vf, "vfn_vf_mlp16_fwd_train");
@@ -1063,7 +1074,7 @@ extern "C" int vfn_vf_mlp16_fwd_train(const vfn_net_geom* geom, const void* pack
     VFN_REQUIRE(n_points < (1ll << 22), "vfn_vf_mlp16_fwd_train: at most 4194303 points per launch (32-bit slot offsets)");
     a.vf_w = (const uint4*)packed16; a.points = points; a.out_vec = out_vec; a.n_points = n_points; a.dirs_div = 1;
     a.vf_multires = vf.multires; a.vf_bytes = vf.total_kb * 1024u; a.saved = saved; a.save_aux_vf = save_aux_vf;
-    a.save_masks = save_masks;
+    a.save_masks = save_masks; a.save_f16 = save_f16 != 0;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     if (with_features) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_FULL_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_VEC_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
@@ -1073,7 +1084,8 @@ extern "C" int vfn_vf_mlp16_fwd_train(const vfn_net_geom* geom, const void* pack
 extern "C" int vfn_vf_render_fused16_fwd_train(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
                                                const void* rn_packed16, const float* points, const float* ray_dirs,
                                                int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
-                                               float* saved, float* save_aux_vf, float* save_aux_rn, uint32_t* save_masks, void* stream) {
+                                               float* saved, float* save_aux_vf, float* save_aux_rn, uint32_t* save_masks,
+                                               int32_t save_f16, void* stream) {
     Mlp16Args a = {};
     VfnNetPlan p32; Plan16 vf, rn;
     int rc = make_plan16(VFN_NET_VF, vf_geom, &p32, &vf, "vfn_vf_render_fused16_fwd_train");
@@ -1092,7 +1104,7 @@ extern "C" int vfn_vf_render_fused16_fwd_train(const vfn_net_geom* vf_geom, cons
     a.vf_w = (const uint4*)vf_packed16; a.rn_w = (const uint4*)rn_packed16; a.points = points; a.ray_dirs = ray_dirs;
     a.out_vec = normals; a.out_colors = colors; a.n_points = n_points; a.dirs_div = samples_per_ray;
     a.vf_multires = vf.multires; a.rn_multires = rn.multires; a.vf_bytes = vf.total_kb * 1024u; a.rn_bytes = rn.total_kb * 1024u;
-    a.saved = saved; a.save_aux_vf = save_aux_vf; a.save_aux_rn = save_aux_rn; a.save_masks = save_masks;
+    a.saved = saved; a.save_aux_vf = save_aux_vf; a.save_aux_rn = save_aux_rn; a.save_masks = save_masks; a.save_f16 = save_f16 != 0;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_render_fused16_fwd_train");

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void vfn_dw_kernel(const DwArgs a) {
 // span of the wide operand); the two row halves are added through LDS, one slab per workgroup.
 //   WIDE_A: A = dY[M][256] wide (n = 128 wx + 4 i + j), B = X[M][<=64] by scalar loads (2 tiles)      -> [256][64] slab
 //   else  : A = dY[M][<=32] by scalar loads (1 tile), B = X[M][256] wide (k = 128 wx + 4 i + j)       -> [32][256] slab
-template <bool WIDE_A>
+template <bool WIDE_A, bool XH = false>     // XH (narrow-A shape only): X rows hold 256 f16 values in their first 512 bytes
 __global__ __launch_bounds__(256, 1) void vfn_dw_thin_kernel(const DwArgs a) {
     constexpr int U = 8;
     constexpr int NA = WIDE_A ? 4 : 1, NB = WIDE_A ? 2 : 4;
@@ -396,7 +396,13 @@ __global__ __launch_bounds__(256, 1) void vfn_dw_thin_kernel(const DwArgs a) {
                     bb[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, nar_off[t] == OOB ? OOB : rb + nar_off[t], 0, 0));
             } else {
                 aa[u][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dy, nar_off[0] == OOB ? OOB : ra + nar_off[0], 0, 0));
-                const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, rb + wide_off, 0, 0));
+                f32x4 q;
+                if (XH) {
+                    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                    q = __builtin_convertvector(__builtin_bit_cast(half4, __builtin_amdgcn_raw_buffer_load_b64(rs_x, rb + wide_off / 2, 0, 0)), f32x4);
+                } else {
+                    q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, rb + wide_off, 0, 0));
+                }
 #pragma unroll
                 for (int t = 0; t < NB; ++t) bb[u][t] = q[t];
             }
@@ -495,9 +501,10 @@ extern "C" int vfn_mlp_bwd_chain(const vfn_net_geom* vf_geom, const float* vf_pa
 // shape: 0 = 256 x 256 (hidden layer, act inputs), 1 = 256 x 64 (aux inputs, 40 valid), 2 = 32 x 256 (3-channel head)
 extern "C" int vfn_weight_grad_partials(int32_t shape, const float* dy, int32_t ld_dy, int32_t n_valid, const float* x,
                                         int32_t ld_x, int32_t k_valid, int64_t n_points, int32_t groups, float* dw_part,
-                                        float* db_part, void* stream) {
+                                        float* db_part, int32_t x_f16, void* stream) {
     VFN_REQUIRE(dy && x && dw_part, "vfn_weight_grad_partials: NULL argument");
     VFN_REQUIRE(groups >= 1 && groups <= 4096, "vfn_weight_grad_partials: groups=%d", groups);
+    VFN_REQUIRE(!x_f16 || shape == 2, "vfn_weight_grad_partials: x_f16 is implemented for shape 2 (the 3-channel heads) only");
     DwArgs a = {};
     a.dy = dy; a.x = x; a.dw_part = dw_part; a.db_part = db_part; a.n_points = n_points;
     a.ld_dy = ld_dy; a.n_valid = n_valid; a.ld_x = ld_x; a.k_valid = k_valid;
@@ -514,7 +521,9 @@ extern "C" int vfn_weight_grad_partials(int32_t shape, const float* dy, int32_t 
     } else if (shape == 2) {
         a.ld_out = 256; a.n_out = 32;
         const bool wide = k_valid == 256 && (ld_x & 3) == 0 && ((uintptr_t)x & 15) == 0;
-        if (wide) hipLaunchKernelGGL((vfn_dw_thin_kernel<false>), dim3(groups), dim3(256), 0, s, a);
+        VFN_REQUIRE(!x_f16 || wide, "vfn_weight_grad_partials: f16 rows need the full, aligned 256-column X of shape 2");
+        if (wide && x_f16) hipLaunchKernelGGL((vfn_dw_thin_kernel<false, true>), dim3(groups), dim3(256), 0, s, a);
+        else if (wide) hipLaunchKernelGGL((vfn_dw_thin_kernel<false>), dim3(groups), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((vfn_dw_kernel<1, 2, 1, 4>), dim3(groups), dim3(256), 0, s, a);
     } else {
         vfn_set_error("vfn_weight_grad_partials: unknown shape %d", shape);

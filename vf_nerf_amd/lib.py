@@ -353,11 +353,11 @@ def mlp_bwd_chain(vf_geom, vf_packed, vf_packed_bwd, rn_geom, rn_packed, rn_pack
 
 
 def weight_grad_partials(shape: int, dy, ld_dy: int, n_valid: int, x, ld_x: int, k_valid: int, n_points: int,
-                         groups: int, dw_part, db_part=None):
+                         groups: int, dw_part, db_part=None, x_f16: bool = False):
     _check(load().vfn_weight_grad_partials(C.c_int32(shape), _ptr(dy, "dy"), C.c_int32(ld_dy), C.c_int32(n_valid),
                                            _ptr(x, "x"), C.c_int32(ld_x), C.c_int32(k_valid), C.c_int64(n_points),
                                            C.c_int32(groups), _ptr(dw_part, "dw_part"), _ptr(db_part, "db_part"),
-                                           _stream()), "vfn_weight_grad_partials")
+                                           C.c_int32(int(x_f16)), _stream()), "vfn_weight_grad_partials")
 
 
 def packed_bwd16_size(kind: int, geom: NetGeom) -> int:
@@ -418,10 +418,10 @@ def unfold_weight_grads(entries: Sequence[dict], groups: int) -> None:
     _check(load().vfn_unfold_weight_grads(arr, C.c_int32(len(entries)), C.c_int32(groups), _stream()), "vfn_unfold_weight_grads")
 
 
-def weight_grad_partials_bf16(dy, x, n_points: int, groups: int, dw_part, db_part=None):
+def weight_grad_partials_bf16(dy, x, n_points: int, groups: int, dw_part, db_part=None, x_f16: bool = False):
     """shape-0 weight_grad_partials (256 x 256, every column valid) on the bf16 matrix cores (split operands)."""
     _check(load().vfn_weight_grad_partials_bf16(_ptr(dy, "dy"), _ptr(x, "x"), C.c_int64(n_points), C.c_int32(groups),
-                                                _ptr(dw_part, "dw_part"), _ptr(db_part, "db_part"), _stream()),
+                                                _ptr(dw_part, "dw_part"), _ptr(db_part, "db_part"), C.c_int32(int(x_f16)), _stream()),
            "vfn_weight_grad_partials_bf16")
 
 
@@ -493,20 +493,20 @@ def render16_from_blocks(rn_geom: NetGeom, rn_packed16, blocks, vecs, dst, point
     return normals, colors
 
 
-def vf_mlp16_fwd_train(geom: NetGeom, packed16, points, with_features: bool, saved, aux_vf, masks):
+def vf_mlp16_fwd_train(geom: NetGeom, packed16, points, with_features: bool, saved, aux_vf, masks, save_f16: bool = False):
     """f16x3 VF forward that fills the backward workspace; returns the vector columns [M,3] (the features, when
     evaluated, are in their ``saved`` slot)."""
     m = points.shape[0]
     out = torch.empty(m, 3, device=points.device)
     _check(load().vfn_vf_mlp16_fwd_train(C.byref(geom), _ptr(packed16, "packed16", torch.uint8), _ptr(points, "points"),
                                          C.c_int64(m), C.c_int32(1 if with_features else 0), _ptr(out, "out"),
-                                         _ptr(saved, "saved"), _ptr(aux_vf, "aux_vf"), _ptr(masks, "masks", torch.int32), _stream()),
-           "vfn_vf_mlp16_fwd_train")
+                                         _ptr(saved, "saved"), _ptr(aux_vf, "aux_vf"), _ptr(masks, "masks", torch.int32),
+                                         C.c_int32(int(save_f16)), _stream()), "vfn_vf_mlp16_fwd_train")
     return out
 
 
 def vf_render_fused16_fwd_train(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, samples_per_ray, saved,
-                                aux_vf, aux_rn, masks):
+                                aux_vf, aux_rn, masks, save_f16: bool = False):
     m = points.shape[0]
     dev = points.device
     normals = torch.empty(m, 3, device=dev)
@@ -516,8 +516,8 @@ def vf_render_fused16_fwd_train(vf_geom, vf_packed16, rn_geom, rn_packed16, poin
                                                   _ptr(points, "points"), _ptr(ray_dirs, "ray_dirs"), C.c_int64(m),
                                                   C.c_int32(samples_per_ray), _ptr(normals, "normals"),
                                                   _ptr(colors, "colors"), _ptr(saved, "saved"), _ptr(aux_vf, "aux_vf"),
-                                                  _ptr(aux_rn, "aux_rn"), _ptr(masks, "masks", torch.int32), _stream()),
-           "vfn_vf_render_fused16_fwd_train")
+                                                  _ptr(aux_rn, "aux_rn"), _ptr(masks, "masks", torch.int32),
+                                                  C.c_int32(int(save_f16)), _stream()), "vfn_vf_render_fused16_fwd_train")
     return normals, colors
 
 

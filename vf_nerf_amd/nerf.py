@@ -96,6 +96,7 @@ class VectorFieldNerf:
         # Gradient-carrying calls always use the fp32 kernels.  The setting is shared with the networks so that
         # gradient-free vector queries made on them directly (grid extraction) follow it.
         self.precision = "f16x3"
+        self.activation_storage = "fp32"
         # Inference with the f16x3 kernels evaluates the VF net once per distinct sample: the proposal samples keep their
         # vector columns and feature operand blocks, only the N_f new samples are evaluated after the fine sampler, and the
         # rendering net gathers (the reference evaluates the proposal samples twice; same per-sample arithmetic, identical
@@ -211,6 +212,21 @@ class VectorFieldNerf:
             raise ValueError(f"precision must be 'f16x3' or 'fp32', got {value!r}")
         self._precision = value
         self.vector_field_network.precision = value
+
+    @property
+    def activation_storage(self) -> str:
+        """How the f16x3 training forward keeps the hidden activations for the weight-gradient kernels: ``"fp32"`` (default:
+        the gradients are fp32-equivalent, see DESIGN.md §3 Backward) or ``"f16"`` (opt-in: 11 significant bits in the
+        activation operand of dW = dY^T X, half the workspace traffic — what BASELINE.json's configs[2], "bf16 MFMA MLPs",
+        allows).  The dX chain is not affected: it reads sign bits either way."""
+        return self._activation_storage
+
+    @activation_storage.setter
+    def activation_storage(self, value: str) -> None:
+        if value not in ("fp32", "f16"):
+            raise ValueError(f"activation_storage must be 'fp32' or 'f16', got {value!r}")
+        self._activation_storage = value
+        self.vector_field_network.activation_storage = value
 
     def uses_f16x3(self) -> bool:
         """f16x3 inference kernels are used when requested AND specialised for both networks' geometry."""
