@@ -18,9 +18,10 @@ dev = torch.device("cuda:0")
 n_rays, s_c, n_f = 1024, 64, 64
 
 
-def run(precision):
+def run(precision, activations="fp32"):
     model, uv, pose, K = bench.build_scene(dev, n_rays, s_c, n_f, seed=0)
     model.precision = precision
+    model.activation_storage = activations
     g = torch.Generator().manual_seed(7)
     rgb_gt = torch.rand(n_rays, 3, generator=g).to(dev)
     depth_gt = (0.2 + 0.6 * torch.rand(n_rays, 1, generator=g)).to(dev)
@@ -49,6 +50,7 @@ def run(precision):
 
 fast, ms_fast = run("f16x3")
 exact, ms_exact = run("fp32")
+f16act, ms_f16act = run("f16x3", "f16")
 rel = [abs(a - b) / max(abs(b), 1e-9) for a, b in zip(fast, exact)]
 first_big = next((i for i, r in enumerate(rel) if r > 1e-3), None)
 print(json.dumps({
@@ -57,4 +59,8 @@ print(json.dumps({
     "loss_first_last": {"f16x3": [fast[0], fast[-1]], "fp32": [exact[0], exact[-1]]},
     "rel_diff_step0": rel[0], "rel_diff_max_first_10": max(rel[:10]), "rel_diff_median": sorted(rel)[len(rel) // 2], "rel_diff_max": max(rel),
     "first_step_with_rel_diff_above_1e-3": first_big,
+    "f16_activation_storage": {"ms_per_step": round(ms_f16act, 3), "loss_first_last": [f16act[0], f16act[-1]],
+                               "rel_diff_vs_fp32_step0": abs(f16act[0] - exact[0]) / max(abs(exact[0]), 1e-9),
+                               "rel_diff_vs_fp32_median": sorted(abs(a - b) / max(abs(b), 1e-9) for a, b in zip(f16act, exact))[len(exact) // 2],
+                               "loss_every_10_steps": f16act[::10]},
     "loss_every_10_steps": {"f16x3": fast[::10], "fp32": exact[::10]}}))
