@@ -434,6 +434,9 @@ def main() -> None:
                 "event_sampling": "HIP events around the MLP launches of every 4th timed step",
                 "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": hbm_traffic(f16, dom),
+                # what one launch has to move: points in, vector columns out, plus the 1 KiB feature block per point that the
+                # split launches hand over (written by vf_feat16, read by render16); weights stream from L2
+                "algorithmic_bytes": int(points * {"vf_feat16": 12 + 12 + 1024, "render16": 1024 + 12 + 12 + 4 + 24}.get(dom, 12 + 24)),
                 "flops_per_launch": flops_launch, "avg_launch_ms": round(kernel_ms, 4),
                 "peak_definition": ("dense f16 MFMA 2500 TFLOP/s / 3 products per fp32-equivalent product" if f16 else
                                     "fp32 MFMA 157.3 TFLOP/s"),
