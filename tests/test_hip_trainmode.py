@@ -244,3 +244,32 @@ def test_batch_statistics_layer_at_full_size():
     assert float((h.double() - want_h).abs().max()) <= 2e-5
     assert float((rm.double() - 0.1 * mean).abs().max()) <= 1e-6 * max(1.0, float(mean.abs().max()))
     assert float((rv.double() - (0.9 + 0.1 * var * m / (m - 1))).abs().max()) <= 1e-5 * max(1.0, float(var.max()))
+
+
+def test_standalone_rendering_net_is_differentiable_in_eval_mode():
+    """``RenderingNetwork.forward`` with gradients and eval-mode BatchNorm (the facade's get_colors / get_weights_and_color
+    under autograd): colours and the gradients wrt two parameters and the features against the oracle's autograd."""
+    fx, d = load_fixture("c1_det")
+    model = build_model(fx, d, device=DEV)          # eval mode
+    rn = model.rendering_network
+    torch.manual_seed(2)
+    m = 700
+    pts, nrm = torch.rand(m, 3) * 2 - 1, torch.nn.functional.normalize(torch.randn(m, 3), dim=1)
+    dirs, feats = torch.nn.functional.normalize(torch.randn(m, 3), dim=1), torch.tanh(torch.randn(m, 256))
+    coef = torch.randn(m, 3)
+    f_gpu = feats.to(DEV).requires_grad_(True)
+    out = rn(pts.to(DEV), nrm.to(DEV), dirs.to(DEV), f_gpu)
+    (out * coef.to(DEV)).sum().backward()
+    cpu = build_model(fx, d)
+    sd = {k: v.clone() for k, v in cpu.rendering_network.state_dict().items()}
+    keys = ("layers.0.0.weight", "layers.2.0.bias", "layers.3.1.weight", "layers.4.weight")
+    for k in keys:
+        sd[k].requires_grad_(True)
+    f_cpu = feats.clone().requires_grad_(True)
+    want = O.render_mlp(pts, nrm, dirs, f_cpu, sd)
+    (want * coef).sum().backward()
+    assert float((out.detach().cpu() - want.detach()).abs().max()) <= 1e-5
+    assert grad_rel_err(f_gpu.grad, f_cpu.grad) <= 1e-3
+    for k in keys:
+        got = dict(rn.named_parameters())[k].grad
+        assert grad_rel_err(got, sd[k].grad) <= 1e-3, (k, grad_rel_err(got, sd[k].grad))

@@ -344,5 +344,8 @@ def vf_forward_autograd(net, points, vector_only):
 
 
 def render_forward_autograd(net, points, normals, view_dirs, feats):
-    raise NotImplementedError("gradients through a stand-alone RenderingNetwork.forward are not wired yet; the "
-                              "training path differentiates the fused fine pass of render() instead")
+    """Stand-alone rendering-net forward with gradients (eval-mode BatchNorm): the training path differentiates the fused
+    fine pass of render() instead; this serves the secondary entry points, layer by layer (batchstat.py)."""
+    from .batchstat import render_forward_eval_autograd
+    return render_forward_eval_autograd(net, points.reshape(-1, 3), normals.reshape(-1, 3), view_dirs.reshape(-1, 3),
+                                        feats.reshape(-1, feats.shape[-1]))

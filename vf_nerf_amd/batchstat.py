@@ -42,6 +42,7 @@ class _State:
         self.coef: List[torch.Tensor] = []     # [4][n]: scale, shift, mean, rstd
         self.y: Optional[torch.Tensor] = None  # activated output of the last Linear
         self.m = 0
+        self.batch_stats = True                # False: eval-mode BatchNorm (running statistics), rows are independent
 
 
 def _bn_layers(net) -> int:
@@ -54,13 +55,24 @@ def _require_shape(net) -> None:
         raise NotImplementedError("the training-mode path expects BatchNorm after every Linear but the last (confs/vf_nerf.conf)")
 
 
-def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, update_running: bool = True) -> _State:
+def _running_coef(bn) -> torch.Tensor:
+    """[4][n] scale, shift, mean, rstd of an eval-mode BatchNorm1d (a handful of n-element torch ops on parameters)."""
+    rstd = torch.rsqrt(bn.running_var.detach() + BN_EPS)
+    scale = bn.weight.detach() * rstd
+    return torch.stack([scale, bn.bias.detach() - bn.running_mean.detach() * scale, bn.running_mean.detach(), rstd]).contiguous()
+
+
+def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, update_running: bool = True,
+             batch_stats: bool = True) -> _State:
     """x0[M, ld] = input matrix of layer 0 (pad columns zero).  ``fill_skip(dst: Cols, scale)`` writes the skip layer's
-    re-injected input (the positional encoding) next to the previous layer's output."""
+    re-injected input (the positional encoding) next to the previous layer's output.  ``batch_stats=False``: BatchNorm in
+    eval mode (running statistics, nothing updated) — the same layer-at-a-time kernels give a differentiable stand-alone
+    forward where the fused kernels have no backward of their own."""
     _require_shape(net)
     dev = x0.device
     st = _State()
     st.m = m
+    st.batch_stats = batch_stats
     L = net.num_layers
     skip = net._skip_layer()
     x = x0
@@ -69,16 +81,20 @@ def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, upda
         n, k = lin.out_features, lin.in_features
         st.x.append(x)
         z = torch.empty(m, _up8(n), device=dev) if n % 8 == 0 else torch.zeros(m, _up8(n), device=dev)
-        parts = lib.linear_rows_stat_parts(m)
-        part = torch.empty(parts, 2, n, device=dev)
-        lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, stats_part=part)
-        sums = torch.empty(2, n, dtype=torch.float64, device=dev)
-        lib.colsum_finish(part, parts, 2 * n, sums)
-        coef = torch.empty(4, n, device=dev)
-        lib.bstat_finalize(sums, m, n, bn.weight.detach(), bn.bias.detach(), BN_EPS, BN_MOMENTUM,
-                           bn.running_mean if update_running else None, bn.running_var if update_running else None, coef)
-        if update_running:
-            bn.num_batches_tracked += 1
+        if batch_stats:
+            parts = lib.linear_rows_stat_parts(m)
+            part = torch.empty(parts, 2, n, device=dev)
+            lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, stats_part=part)
+            sums = torch.empty(2, n, dtype=torch.float64, device=dev)
+            lib.colsum_finish(part, parts, 2 * n, sums)
+            coef = torch.empty(4, n, device=dev)
+            lib.bstat_finalize(sums, m, n, bn.weight.detach(), bn.bias.detach(), BN_EPS, BN_MOMENTUM,
+                               bn.running_mean if update_running else None, bn.running_var if update_running else None, coef)
+            if update_running:
+                bn.num_batches_tracked += 1
+        else:
+            lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z)
+            coef = _running_coef(bn)
         st.z.append(z)
         st.coef.append(coef)
         nxt_k = net._linear(i + 1).in_features
@@ -209,7 +225,8 @@ def _backward(net, st: _State, dz_last: torch.Tensor, pg: Optional[_ParamGrads],
         if pg is not None:
             pg.batchnorm(i - 1, sums)
         dz = torch.zeros(m, _up8(n_prev), device=dev) if n_prev % 8 else torch.empty(m, _up8(n_prev), device=dev)
-        lib.bstat_relu_bwd_rows(g, z, coef, sums, m, n_prev, post, dz)
+        # batch statistics: dz = gamma rstd (g' - mean g' - x_hat mean(g' x_hat)); running statistics: dz = gamma rstd g'
+        lib.bstat_relu_bwd_rows(g, z, coef, sums if st.batch_stats else torch.zeros_like(sums), m, n_prev, post, dz)
     raise AssertionError("unreachable")
 
 
@@ -301,7 +318,7 @@ class _RenderTrainMode(torch.autograd.Function):
     gradients to the parameters and the features."""
 
     @staticmethod
-    def forward(ctx, net, points, normals, view_dirs, feats, *params):
+    def forward(ctx, net, batch_stats, points, normals, view_dirs, feats, *params):
         m = points.shape[0]
         dev = points.device
         pe = 3 + 6 * net._multires() if net._multires() > 0 else 3
@@ -314,7 +331,7 @@ class _RenderTrainMode(torch.autograd.Function):
         lib.embed_rows(view_dirs.detach().reshape(-1, 3).float().contiguous(), m, net._multires(), Cols(x0, 3))
         lib.embed_rows(normals.detach().reshape(-1, 3).float().contiguous(), m, 0, Cols(x0, 3 + pe))
         x0[:, 6 + pe:6 + pe + f].copy_(feats.detach())
-        st = _forward(net, x0, m, lib.ACT_SIGMOID)
+        st = _forward(net, x0, m, lib.ACT_SIGMOID, batch_stats=batch_stats)
         ctx.net, ctx.st, ctx.cols, ctx.param_order = net, st, (6 + pe, f), list(params)
         return st.y[:, :3].contiguous()
 
@@ -329,13 +346,22 @@ class _RenderTrainMode(torch.autograd.Function):
         dx0, _ = _backward(net, st, dz, pg, want_dx0=True)
         grads = pg.finish()
         ctx.st = None
-        return (None, None, None, None, dx0[:, c0:c0 + f], *[grads.get(p) for p in ctx.param_order])
+        return (None, None, None, None, None, dx0[:, c0:c0 + f], *[grads.get(p) for p in ctx.param_order])
 
 
 def render_forward_train_mode(net, points, normals, view_dirs, feats) -> torch.Tensor:
     if not points.is_cuda:
         raise lib.VfnError("the training-mode forward runs on the device (no CPU fallback)")
-    return _RenderTrainMode.apply(net, points, normals, view_dirs, feats.float(), *list(net.parameters()))
+    return _RenderTrainMode.apply(net, True, points, normals, view_dirs, feats.float(), *list(net.parameters()))
+
+
+def render_forward_eval_autograd(net, points, normals, view_dirs, feats) -> torch.Tensor:
+    """Stand-alone ``RenderingNetwork.forward`` under autograd with eval-mode BatchNorm (the secondary entry points
+    get_colors / get_weights_and_color of the facade with gradients enabled): the layer-at-a-time kernels with the running
+    statistics, gradients to the parameters and the features."""
+    if not points.is_cuda:
+        raise lib.VfnError("the differentiable rendering-net forward runs on the device (no CPU fallback)")
+    return _RenderTrainMode.apply(net, False, points, normals, view_dirs, feats.float(), *list(net.parameters()))
 
 
 # ------------------------------------------------------------------------------------------------
