@@ -415,7 +415,12 @@ def main() -> None:
     if rank == 0:
         rays_per_s = args.rays * args.steps * world / elapsed
         # ALGORITHMIC fp32-equivalent FLOPs of one launch of that kernel (SURVEY.md §8d per-point figures x its points)
-        points = {"vf_feat16": args.rays * s_c, "render16": args.rays * s_t}.get(dom, args.rays * s_t)
+        # default pipeline: VF + blocks out on the S_c proposal samples, the fused VF + rendering launch on the N_f new samples
+        # (scattered to their sorted positions), the rendering net from blocks on the S_c stored ones; --no-reuse / fp32: one
+        # fused launch over all S_t samples
+        split = args.precision == "f16x3" and not args.no_reuse
+        points = {"vf_feat16": args.rays * s_c, "render16": args.rays * s_c,
+                  "fused16": args.rays * (n_f if split else s_t)}.get(dom, args.rays * s_t)
         macs = {"vf_feat16": VF_MACS, "render16": RN_MACS}.get(dom, VF_MACS + RN_MACS)
         flops_launch = 2.0 * macs * points
         achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
@@ -425,9 +430,9 @@ def main() -> None:
         # f16 MFMA products per fp32-equivalent product, so its matrix-pipe ceiling is the dense f16 peak / 3.
         peak = PEAK_F16_MFMA / 3.0 if f16 else PEAK_F32_MFMA
         roof = {"bound": "mfma",
-                "kernel": {"vf_feat16": "vfn_mlp16_kernel<M16_VF_BLK> (VF MLP, once per distinct sample: proposal samples, then the new fine samples)",
-                           "render16": "vfn_mlp16_kernel<M16_RN_BLK> (rendering MLP on gathered feature blocks)",
-                           "fused16": "vfn_mlp16_kernel<M16_FUSED> (VF MLP + rendering MLP, fine pass)",
+                "kernel": {"vf_feat16": "vfn_mlp16_kernel<M16_VF_BLK> (VF MLP on the proposal samples, feature blocks out)",
+                           "render16": "vfn_mlp16_kernel<M16_RN_BLK> (rendering MLP on the proposal samples' stored feature blocks)",
+                           "fused16": "vfn_mlp16_kernel<M16_FUSED> (VF MLP + rendering MLP: the new fine samples, or all samples with --no-reuse)",
                            "fused32": "vfn_mlp_kernel<MODE_FUSED> (VF MLP + rendering MLP, fine pass)"}[dom],
                 "launches_per_step": launches_per_step,
                 "kernel_ms_per_step_by_class": {k: round(sum(v) / max(1, (args.steps + 3) // 4), 4) for k, v in per_class.items()},
@@ -436,7 +441,7 @@ def main() -> None:
                 "frac": round(achieved / peak, 4), "traffic": hbm_traffic(f16, dom),
                 # what one launch has to move: points in, vector columns out, plus the 1 KiB feature block per point that the
                 # split launches hand over (written by vf_feat16, read by render16); weights stream from L2
-                "algorithmic_bytes": int(points * {"vf_feat16": 12 + 12 + 1024, "render16": 1024 + 12 + 12 + 4 + 24}.get(dom, 12 + 24)),
+                "algorithmic_bytes": int(points * {"vf_feat16": 12 + 12 + 1024, "render16": 1024 + 12 + 12 + 4 + 24}.get(dom, 12 + 4 + 24)),
                 "flops_per_launch": flops_launch, "avg_launch_ms": round(kernel_ms, 4),
                 "peak_definition": ("dense f16 MFMA 2500 TFLOP/s / 3 products per fp32-equivalent product" if f16 else
                                     "fp32 MFMA 157.3 TFLOP/s"),

@@ -301,6 +301,13 @@ int vfn_mlp_bwd_chain_bf16(const vfn_net_geom* vf_geom, const void* vf_packed_bw
  *   result equals vfn_vf_render_fused16_fwd on the sorted samples. */
 int vfn_vf_feat16_fwd(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
                       float* out_vec, void* out_blocks, void* stream);
+/* vfn_vf_render_fused16_fwd whose outputs of point m go to row out_index[m] of normals / colors (negative: dropped): the
+ * N_f new samples of the split pipeline need no block round trip at all — they run the fused launch in generation order
+ * (view direction of point m = ray_dirs[m / samples_per_ray]) and land at their sorted positions. */
+int vfn_vf_render_fused16_scatter(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
+                                  const void* rn_packed16, const float* points, const float* ray_dirs, int64_t n_points,
+                                  int32_t samples_per_ray, const int32_t* out_index, float* normals, float* colors,
+                                  void* stream);
 int vfn_render16_from_blocks(const vfn_net_geom* rn_geom, const void* rn_packed16, const void* blocks, const float* vecs,
                              const int32_t* dst, const float* points, const float* ray_dirs, int64_t n_rows,
                              int32_t samples_per_ray, float* normals, float* colors, void* stream);

@@ -337,6 +337,7 @@ struct Mlp16Args {
     const uint4* blk_in;      // M16_BLKIN: block buffer, groups of 32 rows (store_blocks)
     const float* vec_in;      // M16_BLKIN: [rows,3] vector outputs of the feature launches
     const int* src;           // M16_BLKIN: [rows] position of every row among the sorted samples (< 0: padding row)
+    const int* out_index;     // fused launches, optional: outputs of point m go to row out_index[m] (< 0: dropped) instead of m
 };
 
 struct X16 { half8 hi[16]; half8 lo[16]; };     // 256 activation columns x this lane's point, split (16 K-blocks of 16)
@@ -842,9 +843,11 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     float x[3] = {0.f, 0.f, 0.f};
     if (in) { x[0] = a.points[m * 3 + 0]; x[1] = a.points[m * 3 + 1]; x[2] = a.points[m * 3 + 2]; }
     float d[3] = {0.f, 0.f, 0.f};
+    int out_row = -1;              // scatter launches: where this point's outputs go
     if ((MODE & M16_RENDER) && in) {
         const long long di = m / a.dirs_div;
         d[0] = a.ray_dirs[di * 3 + 0]; d[1] = a.ray_dirs[di * 3 + 1]; d[2] = a.ray_dirs[di * 3 + 2];
+        if (a.out_index) out_row = a.out_index[m];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (MODE & M16_RENDER) {
@@ -935,7 +938,7 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     const float dr[3] = {s_park[4], s_park[5], s_park[6]};
     A16 raux;
     render_aux<MODE>(a, raux, xr, dr, nrm, m, in, g);
-    render_tail<MODE>(a, p, cy, xa, xb, raux, nrm, m, in, wave, lane);
+    render_tail<MODE>(a, p, cy, xa, xb, raux, nrm, a.out_index ? (long long)out_row : m, a.out_index ? out_row >= 0 : in, wave, lane);
     const long long mo = (long long)blockIdx.x * VFN16_PTS + (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
     (void)mo;
 #ifdef VFN16_STAMPS
@@ -1013,6 +1016,33 @@ extern "C" int vfn_vf_render_fused16_fwd(const vfn_net_geom* vf_geom, const void
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_render_fused16_fwd");
+}
+
+extern "C" int vfn_vf_render_fused16_scatter(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
+                                          const void* rn_packed16, const float* points, const float* ray_dirs,
+                                          int64_t n_points, int32_t samples_per_ray, const int32_t* out_index, float* normals,
+                                          float* colors, void* stream) {
+    Mlp16Args a = {};
+    VfnNetPlan p32; Plan16 vf, rn;
+    int rc = make_plan16(VFN_NET_VF, vf_geom, &p32, &vf, "vfn_vf_render_fused16_scatter");
+    if (rc != VFN_OK) return rc;
+    rc = make_plan16(VFN_NET_RENDER, rn_geom, &p32, &rn, "vfn_vf_render_fused16_scatter");
+    if (rc != VFN_OK) return rc;
+    rc = check_vf16(vf, "vfn_vf_render_fused16_scatter");
+    if (rc != VFN_OK) return rc;
+    rc = check_rn16(rn, "vfn_vf_render_fused16_scatter");
+    if (rc != VFN_OK) return rc;
+    VFN_REQUIRE(vf_geom->feature_dims == VFN_HIDDEN && rn_geom->feature_dims == VFN_HIDDEN,
+                "vfn_vf_render_fused16_scatter: both nets need feature_dims == %d", VFN_HIDDEN);
+    if (n_points <= 0) return VFN_OK;
+    VFN_REQUIRE(vf_packed16 && rn_packed16 && points && ray_dirs && normals && colors && out_index, "vfn_vf_render_fused16_scatter: NULL argument");
+    VFN_REQUIRE(samples_per_ray > 0, "vfn_vf_render_fused16_scatter: samples_per_ray must be > 0");
+    a.vf_w = (const uint4*)vf_packed16; a.rn_w = (const uint4*)rn_packed16; a.points = points; a.ray_dirs = ray_dirs;
+    a.out_vec = normals; a.out_colors = colors; a.out_index = out_index; a.n_points = n_points; a.dirs_div = samples_per_ray;
+    a.vf_multires = vf.multires; a.rn_multires = rn.multires; a.vf_bytes = vf.total_kb * 1024u; a.rn_bytes = rn.total_kb * 1024u;
+    const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
+    hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return vfn_check_launch("vfn_vf_render_fused16_scatter");
 }
 
 // ------------------------------------------------------------------------------------------------

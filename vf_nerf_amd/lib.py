@@ -30,7 +30,7 @@ EXPORTS = (
     "vfn_grid_unify_direction", "vfn_grid_comb_format", "vfn_weight_grad_partials_bf16", "vfn_unfold_weight_grads", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
     "vfn_linear_rows", "vfn_linear_rows_stat_parts", "vfn_bstat_row_parts", "vfn_colsum_finish", "vfn_bstat_finalize",
     "vfn_bstat_relu_rows", "vfn_bstat_relu_bwd_sums", "vfn_bstat_relu_bwd_rows", "vfn_act_bwd_rows", "vfn_embed_rows",
-    "vfn_embed_rows_bwd",
+    "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter",
 )
 
 
@@ -475,7 +475,23 @@ def vf_feat16_fwd(geom: NetGeom, packed16, points, out_vec, out_blocks) -> None:
                                     _stream()), "vfn_vf_feat16_fwd")
 
 
-def render16_from_blocks(rn_geom: NetGeom, rn_packed16, blocks, vecs, dst, points, ray_dirs, samples_per_ray: int):
+def vf_render_fused16_scatter(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, samples_per_ray: int, out_index,
+                              normals, colors) -> None:
+    """Fused VF + rendering launch over points[M,3] (view direction of point m: ray_dirs[m // samples_per_ray]); the outputs of
+    point m are written to row out_index[m] of the caller's normals / colors (int32; negative: dropped)."""
+    m = points.shape[0]
+    if out_index.shape[0] < m:
+        raise VfnError(f"out_index holds {out_index.shape[0]} entries for {m} points")
+    _check(load().vfn_vf_render_fused16_scatter(C.byref(vf_geom), _ptr(vf_packed16, "vf_packed16", torch.uint8),
+                                                C.byref(rn_geom), _ptr(rn_packed16, "rn_packed16", torch.uint8),
+                                                _ptr(points, "points"), _ptr(ray_dirs, "ray_dirs"), C.c_int64(m),
+                                                C.c_int32(samples_per_ray), _ptr(out_index, "out_index", torch.int32),
+                                                _ptr(normals, "normals"), _ptr(colors, "colors"), _stream()),
+           "vfn_vf_render_fused16_scatter")
+
+
+def render16_from_blocks(rn_geom: NetGeom, rn_packed16, blocks, vecs, dst, points, ray_dirs, samples_per_ray: int,
+                         normals=None, colors=None):
     """Rendering net over the stored rows: row r -> sorted position dst[r] (points[dst[r]], ray_dirs[dst[r] / S]); returns
     normals[M,3], colors[M,3] in sorted order (M = points.shape[0]; every sorted sample must be some row's dst)."""
     m = points.shape[0]
@@ -483,8 +499,9 @@ def render16_from_blocks(rn_geom: NetGeom, rn_packed16, blocks, vecs, dst, point
     dev = points.device
     if blocks.shape[0] < block_rows(n_rows) or vecs.shape[0] < n_rows:
         raise VfnError(f"{n_rows} rows need blocks[{block_rows(n_rows)}] and vecs[{n_rows}]")
-    normals = torch.empty(m, 3, device=dev)
-    colors = torch.empty(m, 3, device=dev)
+    if normals is None:
+        normals = torch.empty(m, 3, device=dev)
+        colors = torch.empty(m, 3, device=dev)
     _check(load().vfn_render16_from_blocks(C.byref(rn_geom), _ptr(rn_packed16, "rn_packed16", torch.uint8),
                                            _ptr(blocks, "blocks", torch.uint8), _ptr(vecs, "vecs"),
                                            _ptr(dst, "dst", torch.int32), _ptr(points, "points"), _ptr(ray_dirs, "ray_dirs"),

@@ -347,14 +347,13 @@ class VectorFieldNerf:
             # (3) VF net on the proposal samples: vector columns (and, when they will be reused, the feature blocks)
             vf = self.vector_field_network
             if reuse:
-                # stored rows: the proposal samples, then (on a 32-row group boundary of the block buffer) the new ones
+                # the proposal samples keep their vector columns and feature blocks (whole 32-row groups of the block buffer)
                 m_c, m_n = n * s_c, n * n_f
-                row0 = lib.block_rows(m_c)
-                blocks = torch.empty(row0 + lib.block_rows(m_n), lib.BLOCK_BYTES, dtype=torch.uint8, device=dev)
-                vecs = torch.empty(row0 + m_n, 3, device=dev)
+                blocks = torch.empty(lib.block_rows(m_c), lib.BLOCK_BYTES, dtype=torch.uint8, device=dev)
+                vecs = torch.empty(m_c, 3, device=dev)
                 with self._timed("vf_feat16"):
-                    lib.vf_feat16_fwd(vf.geometry(), vf.packed16_weights(), pts_c.view(-1, 3), vecs[:m_c], blocks[:row0])
-                normals_c = vecs[:m_c]
+                    lib.vf_feat16_fwd(vf.geometry(), vf.packed16_weights(), pts_c.view(-1, 3), vecs, blocks)
+                normals_c = vecs
             elif self.uses_f16x3():
                 normals_c = lib.vf_mlp16_fwd(vf.geometry(), vf.packed16_weights(), pts_c.view(-1, 3))
             else:
@@ -373,20 +372,24 @@ class VectorFieldNerf:
             if reuse:
                 z, pts, _, new_pts, dst = lib.range_fine_sample_indexed(z_c, imax, directions, cam_loc, n_f, self.fine_sampler.near,
                                                                         far, self.fine_sampler.range, u_add, u_fine, far_t,
-                                                                        new_row0=row0, want_dst=True)
+                                                                        want_dst=True)
             else:
                 z, pts = lib.range_fine_sample(z_c, imax, directions, cam_loc, n_f, self.fine_sampler.near, far,
                                                self.fine_sampler.range, u_add, u_fine, far_t)
         s_t = s_c + n_f
         if reuse:
-            # (7)-(11) VF net on the new samples only, rendering net on gathered features, density + composite
+            # (7)-(11) the new samples run the fused VF + rendering launch in generation order, the proposal samples the
+            # rendering net on their stored feature blocks; both write to the samples' sorted positions; density + composite
             with torch.no_grad():
                 rn = self.rendering_network
-                with self._timed("vf_feat16"):
-                    lib.vf_feat16_fwd(vf.geometry(), vf.packed16_weights(), new_pts.view(-1, 3), vecs[row0:], blocks[row0:])
-                with self._timed("render16"):      # over the stored rows; results land at their sorted positions
-                    normals, colors = lib.render16_from_blocks(rn.geometry(), rn.packed16_weights(), blocks, vecs, dst,
-                                                               pts.view(-1, 3), ray_dirs, s_t)
+                normals = torch.empty(n * s_t, 3, device=dev)
+                colors = torch.empty(n * s_t, 3, device=dev)
+                with self._timed("fused16"):
+                    lib.vf_render_fused16_scatter(vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(),
+                                                  new_pts.view(-1, 3), ray_dirs, n_f, dst[m_c:], normals, colors)
+                with self._timed("render16"):
+                    lib.render16_from_blocks(rn.geometry(), rn.packed16_weights(), blocks, vecs, dst[:m_c], pts.view(-1, 3),
+                                             ray_dirs, s_t, normals, colors)
                 _, weights, _, rgb, depth = lib.ray_density_weights(self._density_params(), normals, ray_dirs, z, scal,
                                                                     colors=colors, want_sigma=False)
         else:
