@@ -415,12 +415,12 @@ def main() -> None:
     if rank == 0:
         rays_per_s = args.rays * args.steps * world / elapsed
         # ALGORITHMIC fp32-equivalent FLOPs of one launch of that kernel (SURVEY.md §8d per-point figures x its points)
-        # default pipeline: VF + blocks out on the S_c proposal samples, the fused VF + rendering launch on the N_f new samples
-        # (scattered to their sorted positions), the rendering net from blocks on the S_c stored ones; --no-reuse / fp32: one
-        # fused launch over all S_t samples
+        # default pipeline: the fused VF + rendering launch twice, on the S_c proposal samples and on the N_f new samples (one VF
+        # evaluation per distinct sample; results scattered to their sorted positions); --no-reuse / fp32: the proposal pass
+        # (vector columns only) and one fused launch over all S_t samples
         split = args.precision == "f16x3" and not args.no_reuse
         points = {"vf_feat16": args.rays * s_c, "render16": args.rays * s_c,
-                  "fused16": args.rays * (n_f if split else s_t)}.get(dom, args.rays * s_t)
+                  "fused16": args.rays * s_t / (launches_per_step if split else 1.0)}.get(dom, args.rays * s_t)
         macs = {"vf_feat16": VF_MACS, "render16": RN_MACS}.get(dom, VF_MACS + RN_MACS)
         flops_launch = 2.0 * macs * points
         achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
@@ -432,7 +432,7 @@ def main() -> None:
         roof = {"bound": "mfma",
                 "kernel": {"vf_feat16": "vfn_mlp16_kernel<M16_VF_BLK> (VF MLP on the proposal samples, feature blocks out)",
                            "render16": "vfn_mlp16_kernel<M16_RN_BLK> (rendering MLP on the proposal samples' stored feature blocks)",
-                           "fused16": "vfn_mlp16_kernel<M16_FUSED> (VF MLP + rendering MLP: the new fine samples, or all samples with --no-reuse)",
+                           "fused16": "vfn_mlp16_kernel<M16_FUSED> (VF MLP + rendering MLP; default: one launch on the proposal samples, one on the new fine samples)",
                            "fused32": "vfn_mlp_kernel<MODE_FUSED> (VF MLP + rendering MLP, fine pass)"}[dom],
                 "launches_per_step": launches_per_step,
                 "kernel_ms_per_step_by_class": {k: round(sum(v) / max(1, (args.steps + 3) // 4), 4) for k, v in per_class.items()},

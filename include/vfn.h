@@ -301,6 +301,10 @@ int vfn_mlp_bwd_chain_bf16(const vfn_net_geom* vf_geom, const void* vf_packed_bw
  *   result equals vfn_vf_render_fused16_fwd on the sorted samples. */
 int vfn_vf_feat16_fwd(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
                       float* out_vec, void* out_blocks, void* stream);
+/* out_a[index[r]] = a[r] (and out_b[index[r]] = b[r] when b != NULL) for [n_rows,3] fp32 rows; negative indices are skipped.
+ * Moves per-sample results computed in generation order to their positions among the sorted samples. */
+int vfn_scatter_rows3(const float* a, const float* b, const int32_t* index, int64_t n_rows, float* out_a, float* out_b,
+                      void* stream);
 /* vfn_vf_render_fused16_fwd whose outputs of point m go to row out_index[m] of normals / colors (negative: dropped): the
  * N_f new samples of the split pipeline need no block round trip at all — they run the fused launch in generation order
  * (view direction of point m = ray_dirs[m / samples_per_ray]) and land at their sorted positions. */

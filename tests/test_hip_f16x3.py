@@ -129,3 +129,43 @@ def test_fine_sampler_provenance_index():
     assert dst.shape[0] == row0 + n * n_f and bool((dst[n * s_c:row0] == -1).all())
     assert torch.equal(torch.where(src >= n * s_c, src + (row0 - n * s_c), src), src2)
     assert torch.equal(dst[src2.reshape(-1).long()].cpu(), torch.arange(n * (s_c + n_f), dtype=torch.int32))
+
+
+def test_block_launches_equal_fused_launch():
+    """vfn_vf_feat16_fwd (VF net, feature operand blocks out) + vfn_render16_from_blocks (rendering net over the stored rows,
+    outputs scattered through an index) against the fused launch on the same samples: bit-identical normals and colours, for
+    a row count with padding rows in the last 32-row group and a non-trivial permutation; and vfn_scatter_rows3."""
+    import torch
+    from helpers import build_model, load_fixture
+    from vf_nerf_amd import lib
+    fx, d = load_fixture("c1_perturb")
+    model = build_model(fx, d, device="cuda:0")
+    vf, rn = model.vector_field_network, model.rendering_network
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(9)
+    n_rays, s = 13, 23                                    # 299 samples: 9 whole groups + 11 rows
+    m = n_rays * s
+    pts = (torch.rand(m, 3, generator=gen) * 2 - 1).to(dev)
+    dirs = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=gen), dim=1).to(dev)
+    want_n, want_c = lib.vf_render_fused16_fwd(vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(), pts, dirs, s)
+    # store the samples in a permuted order (rays stay together so that ray_dirs[dst // s] is the sample's direction)
+    perm = torch.cat([r * s + torch.randperm(s, generator=gen) for r in range(n_rays)]).to(dev)     # stored row -> sample
+    stored = pts[perm].contiguous()
+    vecs = torch.empty(m, 3, device=dev)
+    blocks = torch.empty(lib.block_rows(m), lib.BLOCK_BYTES, dtype=torch.uint8, device=dev)
+    lib.vf_feat16_fwd(vf.geometry(), vf.packed16_weights(), stored, vecs, blocks)
+    got_n, got_c = lib.render16_from_blocks(rn.geometry(), rn.packed16_weights(), blocks, vecs, perm.to(torch.int32), pts, dirs, s)
+    assert torch.equal(got_n, want_n) and torch.equal(got_c, want_c)
+    # the scatter launch and the row scatter against plain indexing
+    out_n, out_c = torch.zeros(m, 3, device=dev), torch.zeros(m, 3, device=dev)
+    idx = perm.to(torch.int32).clone()
+    idx[::7] = -1
+    lib.vf_render_fused16_scatter(vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(), stored,
+                                  dirs[perm // s].contiguous(), 1, idx, out_n, out_c)
+    keep = idx >= 0
+    assert torch.equal(out_n[perm[keep]], want_n[perm[keep]]) and torch.equal(out_c[perm[keep]], want_c[perm[keep]])
+    assert float(out_n[perm[~keep]].abs().max()) == 0.0
+    a, b = torch.randn(m, 3, device=dev), torch.randn(m, 3, device=dev)
+    oa, ob = torch.zeros(m, 3, device=dev), torch.zeros(m, 3, device=dev)
+    lib.scatter_rows3(a, b, idx, oa, ob)
+    assert torch.equal(oa[perm[keep]], a[keep]) and torch.equal(ob[perm[keep]], b[keep]) and float(oa[perm[~keep]].abs().max()) == 0.0

@@ -682,6 +682,22 @@ __global__ void vfn_sphere_shell_kernel(const ShellArgs a) {
     a.gt[i * 3 + 0] = dx * inv; a.gt[i * 3 + 1] = dy * inv; a.gt[i * 3 + 2] = dz * inv;
 }
 
+
+// out_a[index[r]] = a[r], out_b[index[r]] = b[r] for 3-float rows (negative index: skipped): per-sample results computed in
+// storage order move to their positions among the sorted samples
+__global__ __launch_bounds__(256) void vfn_scatter_rows3_kernel(const float* a, const float* b, const int* index, long long n,
+                                                                 float* out_a, float* out_b) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const int d = index[r];
+    if (d < 0) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        out_a[(long long)d * 3 + c] = a[r * 3 + c];
+        if (b) out_b[(long long)d * 3 + c] = b[r * 3 + c];
+    }
+}
+
 }  // namespace
 
 extern "C" int vfn_raygen_uniform(const vfn_raygen_params* p, const float* uv, const float* pose, const float* intrinsics,
@@ -741,6 +757,15 @@ extern "C" int vfn_range_fine_sample_indexed(const vfn_fine_params* p, const flo
     const size_t shmem = (size_t)RAYS_PER_BLOCK * (p->n_coarse + p->n_fine) * 2 * sizeof(float);
     hipLaunchKernelGGL(vfn_fine_kernel, dim3(blocks), dim3(256), shmem, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_range_fine_sample");
+}
+
+extern "C" int vfn_scatter_rows3(const float* a, const float* b, const int32_t* index, int64_t n_rows, float* out_a, float* out_b,
+                                 void* stream) {
+    VFN_REQUIRE(n_rows >= 0 && (n_rows == 0 || (a && index && out_a && (!b || out_b))), "vfn_scatter_rows3: NULL argument");
+    if (n_rows == 0) return VFN_OK;
+    hipLaunchKernelGGL(vfn_scatter_rows3_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, index,
+                       (long long)n_rows, out_a, out_b);
+    return vfn_check_launch("vfn_scatter_rows3");
 }
 
 extern "C" int vfn_fill_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {

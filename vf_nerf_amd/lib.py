@@ -30,7 +30,7 @@ EXPORTS = (
     "vfn_grid_unify_direction", "vfn_grid_comb_format", "vfn_weight_grad_partials_bf16", "vfn_unfold_weight_grads", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
     "vfn_linear_rows", "vfn_linear_rows_stat_parts", "vfn_bstat_row_parts", "vfn_colsum_finish", "vfn_bstat_finalize",
     "vfn_bstat_relu_rows", "vfn_bstat_relu_bwd_sums", "vfn_bstat_relu_bwd_rows", "vfn_act_bwd_rows", "vfn_embed_rows",
-    "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter",
+    "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_scatter_rows3",
 )
 
 
@@ -488,6 +488,15 @@ def vf_render_fused16_scatter(vf_geom, vf_packed16, rn_geom, rn_packed16, points
                                                 C.c_int32(samples_per_ray), _ptr(out_index, "out_index", torch.int32),
                                                 _ptr(normals, "normals"), _ptr(colors, "colors"), _stream()),
            "vfn_vf_render_fused16_scatter")
+
+
+def scatter_rows3(a, b, index, out_a, out_b) -> None:
+    """out_a[index[r]] = a[r], out_b[index[r]] = b[r] for [n,3] fp32 rows (int32 index, negative entries skipped)."""
+    n = a.shape[0]
+    if index.shape[0] < n:
+        raise VfnError(f"index holds {index.shape[0]} entries for {n} rows")
+    _check(load().vfn_scatter_rows3(_ptr(a, "a"), _ptr(b, "b"), _ptr(index, "index", torch.int32), C.c_int64(n), _ptr(out_a, "out_a"),
+                                    _ptr(out_b, "out_b"), _stream()), "vfn_scatter_rows3")
 
 
 def render16_from_blocks(rn_geom: NetGeom, rn_packed16, blocks, vecs, dst, points, ray_dirs, samples_per_ray: int,

@@ -347,13 +347,15 @@ class VectorFieldNerf:
             # (3) VF net on the proposal samples: vector columns (and, when they will be reused, the feature blocks)
             vf = self.vector_field_network
             if reuse:
-                # the proposal samples keep their vector columns and feature blocks (whole 32-row groups of the block buffer)
+                # The rendering net is pointwise and a proposal sample's inputs (point, view direction, its own VF outputs)
+                # are complete before the fine sampler runs, so the proposal samples go through the FUSED VF + rendering
+                # launch right away, in generation order; only where their results sit among the sorted samples is decided
+                # later (``dst``).
                 m_c, m_n = n * s_c, n * n_f
-                blocks = torch.empty(lib.block_rows(m_c), lib.BLOCK_BYTES, dtype=torch.uint8, device=dev)
-                vecs = torch.empty(m_c, 3, device=dev)
-                with self._timed("vf_feat16"):
-                    lib.vf_feat16_fwd(vf.geometry(), vf.packed16_weights(), pts_c.view(-1, 3), vecs, blocks)
-                normals_c = vecs
+                rn = self.rendering_network
+                with self._timed("fused16"):
+                    normals_c, colors_c = lib.vf_render_fused16_fwd(vf.geometry(), vf.packed16_weights(), rn.geometry(),
+                                                                    rn.packed16_weights(), pts_c.view(-1, 3), ray_dirs, s_c)
             elif self.uses_f16x3():
                 normals_c = lib.vf_mlp16_fwd(vf.geometry(), vf.packed16_weights(), pts_c.view(-1, 3))
             else:
@@ -378,18 +380,15 @@ class VectorFieldNerf:
                                                self.fine_sampler.range, u_add, u_fine, far_t)
         s_t = s_c + n_f
         if reuse:
-            # (7)-(11) the new samples run the fused VF + rendering launch in generation order, the proposal samples the
-            # rendering net on their stored feature blocks; both write to the samples' sorted positions; density + composite
+            # (7)-(11) the new samples run the same fused launch, their outputs scattered to the sorted positions; the proposal
+            # samples' results move there too (24 B per sample); density + composite
             with torch.no_grad():
-                rn = self.rendering_network
                 normals = torch.empty(n * s_t, 3, device=dev)
                 colors = torch.empty(n * s_t, 3, device=dev)
                 with self._timed("fused16"):
                     lib.vf_render_fused16_scatter(vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(),
                                                   new_pts.view(-1, 3), ray_dirs, n_f, dst[m_c:], normals, colors)
-                with self._timed("render16"):
-                    lib.render16_from_blocks(rn.geometry(), rn.packed16_weights(), blocks, vecs, dst[:m_c], pts.view(-1, 3),
-                                             ray_dirs, s_t, normals, colors)
+                lib.scatter_rows3(normals_c, colors_c, dst[:m_c], normals, colors)
                 _, weights, _, rgb, depth = lib.ray_density_weights(self._density_params(), normals, ray_dirs, z, scal,
                                                                     colors=colors, want_sigma=False)
         else:
