@@ -55,6 +55,10 @@ FIXTURES = {
     "train_mode": dict(seed=6, gain=2.0, n_rays=12, n_samples=16, n_importance=10, perturb=True, th=-0.2, n_window=5,
                        near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=11, pose="identity",
                        skew=0.0, far_per_ray=False, train=True),
+    # the shipped sampler sizes (confs/vf_nerf.conf:56-66: 100 proposal samples, n_importance 30 grown by 5 at epoch 0 -> 35, Q16)
+    "shipped_sizes": dict(seed=8, gain=2.0, n_rays=10, n_samples=100, n_importance=35, perturb=True, th=-2.0, n_window=11,
+                          near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=13, pose="orbit",
+                          skew=0.0, far_per_ray=False),
     "w1_det": dict(seed=4, gain=2.0, n_rays=16, n_samples=20, n_importance=12, perturb=False, th=-2.0, n_window=1,
                    near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=7, pose="identity",
                    skew=0.0, far_per_ray=False),

@@ -213,6 +213,7 @@ class _FinePass(torch.autograd.Function):
                                                             want_sigma=False)
         if getattr(model, "_keep_saved", False):   # test hook: expose the saved activations
             model._debug_saved = ws.saved
+            model._debug_masks = ws.masks if fast else None
         ctx.model, ctx.ws, ctx.dims, ctx.param_order = model, ws, (n, s_t, m, vf_h, rn_h), list(params)
         ctx.save_for_backward(normals, colors, z, ray_dirs, scal)
         return normals, colors, rgb, depth, weights

@@ -386,6 +386,21 @@ def relu_sign_words(saved: torch.Tensor) -> torch.Tensor:
     return torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()
 
 
+def unpack_sign_words(words: torch.Tensor) -> torch.Tensor:
+    """The inverse view of relu_sign_words: int32 [slots, M, 2, 4] -> bool [slots, M, 256] (True where the saved ReLU output
+    was positive) — exactly the masks the bf16 chain applies."""
+    dev = words.device
+    w = words.to(torch.int64) & 0xffffffff
+    r = torch.arange(16, device=dev)
+    half = torch.stack([w & 0xffff, w >> 16], dim=-1).reshape(*words.shape[:3], 8)       # [slots, M, g, t]
+    bits = ((half[..., None] >> r) & 1).bool()                                            # [slots, M, g, t, r]
+    col = (32 * torch.arange(8, device=dev)[None, :, None] + (r & 3)[None, None, :] + 8 * (r >> 2)[None, None, :]
+           + 4 * torch.arange(2, device=dev)[:, None, None]).reshape(-1)                  # [g, t, r] -> column
+    out = torch.zeros(words.shape[0], words.shape[1], 256, dtype=torch.bool, device=dev)
+    out[:, :, col] = bits.reshape(words.shape[0], words.shape[1], -1)
+    return out
+
+
 def mlp_bwd_chain_bf16(vf_geom, vf_packed_bwd16, vf_head_w, rn_geom, rn_packed_bwd16, rn_head_w, saved, masks, dy, d_colors, colors,
                        d_vec, vec, d_feats, vec_stride: int, n_points: int, dz_rgb, dz_vec):
     rn = C.byref(rn_geom) if rn_geom is not None else None
