@@ -1,20 +1,53 @@
 #!/bin/bash
 # Builds libvfn.so (HIP kernels + C ABI) for gfx950, in-tree.  hipcc cross-compiles without a GPU.
-set -euo pipefail
+# Every object is rebuilt from its source on every run (stale objects are deleted first) and every compile job's exit
+# status is checked one by one: a failing translation unit fails the build, it can never be linked from an older .o.
+set -uo pipefail
 cd "$(dirname "$0")"
 ARCH=${VFN_ARCH:-gfx950}
+OUT=${VFN_OUT:-libvfn.so}
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=${ARCH} -Wall -Wno-unused-function"
-hipcc $FLAGS -c vfn_pack.hip -o vfn_pack.o &
-hipcc $FLAGS -c vfn_mlp.hip -o vfn_mlp.o ${VFN_MLP_EXTRA:-} &
-hipcc $FLAGS -c vfn_mlp_bwd.hip -o vfn_mlp_bwd.o &
-hipcc $FLAGS -c vfn_dw16.hip -o vfn_dw16.o &
-hipcc $FLAGS -c vfn_unfold.hip -o vfn_unfold.o &
-hipcc $FLAGS -mllvm -amdgpu-mfma-vgpr-form -mllvm -pragma-unroll-threshold=10000000 -c vfn_bwd16.hip -o vfn_bwd16.o &
-# vfn_mlp16: accumulators in arch VGPRs (all AGPRs hold activations), full unrolling of the K loops (see its header)
-hipcc $FLAGS -mllvm -amdgpu-mfma-vgpr-form -mllvm -pragma-unroll-threshold=10000000 -c vfn_mlp16.hip -o vfn_mlp16.o ${VFN_MLP16_EXTRA:-} &
-hipcc $FLAGS -ffp-contract=off -c vfn_rays.hip -o vfn_rays.o &
-hipcc $FLAGS -ffp-contract=off -c vfn_grid.hip -o vfn_grid.o &
-hipcc $FLAGS -c vfn_bstat.hip -o vfn_bstat.o &
-wait
-hipcc -shared -fPIC --offload-arch=${ARCH} -o libvfn.so vfn_pack.o vfn_mlp.o vfn_mlp_bwd.o vfn_dw16.o vfn_unfold.o vfn_bwd16.o vfn_mlp16.o vfn_rays.o vfn_grid.o vfn_bstat.o
-echo "built $(pwd)/libvfn.so"
+# vfn_mlp16 / vfn_bwd16: accumulators in arch VGPRs (all AGPRs hold activations), full unrolling of the K loops
+MFMA16="-mllvm -amdgpu-mfma-vgpr-form -mllvm -pragma-unroll-threshold=10000000"
+UNITS="vfn_pack vfn_mlp vfn_mlp_bwd vfn_dw16 vfn_unfold vfn_bwd16 vfn_mlp16 vfn_rays vfn_grid vfn_bstat"
+
+extra_flags() {
+  case "$1" in
+    vfn_mlp)    echo "${VFN_MLP_EXTRA:-}" ;;
+    vfn_mlp16)  echo "$MFMA16 ${VFN_MLP16_EXTRA:-}" ;;
+    vfn_bwd16)  echo "$MFMA16 ${VFN_BWD16_EXTRA:-}" ;;
+    vfn_dw16)   echo "${VFN_DW16_EXTRA:-}" ;;
+    vfn_rays|vfn_grid) echo "-ffp-contract=off" ;;
+    *) echo "" ;;
+  esac
+}
+
+OBJDIR=${VFN_OBJDIR:-.}
+mkdir -p "$OBJDIR"
+rm -f "$OUT.tmp"
+declare -A PIDS
+OBJS=""
+for u in $UNITS; do
+  [ -f "$u.hip" ] || { echo "build.sh: missing source $u.hip" >&2; exit 1; }
+  rm -f "$OBJDIR/$u.o"
+  # shellcheck disable=SC2046
+  hipcc $FLAGS $(extra_flags "$u") -c "$u.hip" -o "$OBJDIR/$u.o" &
+  PIDS[$u]=$!
+  OBJS="$OBJS $OBJDIR/$u.o"
+done
+failed=""
+for u in $UNITS; do
+  if ! wait "${PIDS[$u]}"; then failed="$failed $u.hip"; fi
+done
+if [ -n "$failed" ]; then
+  echo "build.sh: compile FAILED for:$failed" >&2
+  rm -f "$OUT"
+  exit 1
+fi
+for u in $UNITS; do
+  [ -s "$OBJDIR/$u.o" ] || { echo "build.sh: $u.o missing after compile" >&2; rm -f "$OUT"; exit 1; }
+done
+# shellcheck disable=SC2086
+hipcc -shared -fPIC --offload-arch=${ARCH} -o "$OUT.tmp" $OBJS || { rm -f "$OUT" "$OUT.tmp"; exit 1; }
+mv -f "$OUT.tmp" "$OUT"
+echo "built $(pwd)/$OUT"
