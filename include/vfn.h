@@ -186,6 +186,19 @@ int vfn_range_fine_sample_indexed(const vfn_fine_params* p, const float* z_coars
                                   const float* u_fine, const float* u_add, float* z_vals, float* points, int32_t* src,
                                   float* new_points, int32_t* dst, int64_t new_row0, void* stream);
 
+/* The samplers as stand-alone calls, for callers that sample through the sampler OBJECTS rather than through render():
+ * UniformSampler.get_z_vals / RaySampler.sample (models/samplers/ray_sampler.py:113-142, :49-80) on given
+ * directions[N,3] (un-normalised, Q7) / cam_loc[N,3]: z = near (1 - t) + far t, stratified with u[N,S] when given
+ * (NULL = deterministic), points = cam_loc + z * directions (points may be NULL: depths only).  Same arithmetic, in the
+ * same order, as vfn_raygen_uniform: bit-identical depths. */
+int vfn_uniform_sample(int32_t n_rays, int32_t n_samples, float near, float far, const float* directions,
+                       const float* cam_loc, const float* t_vals, const float* far_per_ray, const float* u,
+                       float* z_vals, float* points, void* stream);
+
+/* out[r] = index of the FIRST maximum of row r of w[n_rows, n_cols] (torch.argmax(coarse_weights, dim=-1),
+ * ray_sampler.py:277; an all-zero row gives 0, Q9), int64. */
+int vfn_rows_argmax(const float* w, int32_t n_rows, int32_t n_cols, int64_t* out, void* stream);
+
 /* Counter-based uniforms in [0,1) for production sampling (Philox4x32-10, one 4-tuple per 4 outputs). */
 int vfn_fill_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 
@@ -242,6 +255,13 @@ int vfn_ray_density_weights_bwd(const vfn_density_params* p, const float* normal
                                 const float* z_vals, const float* density_scalars, const float* colors,
                                 const float* d_rgb, const float* d_depth, const float* d_weights,
                                 float* d_normals, float* d_colors, float* d_scalars, void* stream);
+
+/* Backward of the density alone — VectorFieldNerf.get_density under autograd (models/nerf/vector_field_nerf.py:442-474 is
+ * part of the reference's graph): upstream d_sigma[N,S] -> d_normals[N,S,3] (ACCUMULATED into), d_scalars[3]
+ * (atomically accumulated, may be NULL).  z_vals[N,S] only feeds the composite terms, which carry no gradient here. */
+int vfn_ray_density_sigma_bwd(const vfn_density_params* p, const float* normals, const float* ray_dirs,
+                              const float* z_vals, const float* density_scalars, const float* d_sigma,
+                              float* d_normals, float* d_scalars, void* stream);
 
 /* =============================================================================================
  * "f16x3" inference kernels: the same MLPs on the f16 matrix cores with fp32-equivalent accuracy.

@@ -342,6 +342,7 @@ class RenderSettings:
     vf_skip_in: tuple = (4,)
     render_multires: int = 4
     feature_dims: int = 256
+    detach_normals: bool = True        # RenderingNetConfig.detach_normals (rendering_network.py:76-77); the shipped conf sets True
     density: DensityParams = field(default_factory=DensityParams)
 
 
@@ -400,7 +401,7 @@ def render(uv: Tensor, pose: Tensor, intrinsics: Tensor, vf_sd: Dict[str, Tensor
                                            beta, mean, scale, return_parts=True)
     w_f = volsdf_weights(z_f, sigma_f, cfg.normalize)
     rep_dirs = ray_dirs.unsqueeze(1).repeat(1, s_t, 1).reshape(-1, 3)
-    colors = render_mlp(pts_f.reshape(-1, 3), nrm_flat.detach(), rep_dirs, feats, rn_sd, cfg.render_multires, hidden=hidden,
+    colors = render_mlp(pts_f.reshape(-1, 3), nrm_flat.detach() if cfg.detach_normals else nrm_flat, rep_dirs, feats, rn_sd, cfg.render_multires, hidden=hidden,
                         masks=masks, train=cfg.train_mode)
     rgb = torch.sum(w_f.unsqueeze(-1) * colors.reshape(n, s_t, 3), dim=1)
     depth = torch.sum(w_f.unsqueeze(-1) * z_f.unsqueeze(-1), dim=1)
@@ -415,7 +416,8 @@ def render(uv: Tensor, pose: Tensor, intrinsics: Tensor, vf_sd: Dict[str, Tensor
 
 
 # --------------------------------------------------------------------------------------
-# training-side restatement used by the loop-parity test: VFLoss  (models/losses/vf_loss.py:34-87)
+# trainer-side restatements, PINNED by tests/golden/trainer_steps.npz — outputs of the reference's own
+# VFLoss, SphereSampler, supervision helpers and VectorFieldNerfRunner.train_epoch (tests/golden/make_train_golden.py)
 # --------------------------------------------------------------------------------------
 @dataclass
 class LossWeights:      # confs/vf_nerf.conf:82-96
@@ -427,22 +429,110 @@ class LossWeights:      # confs/vf_nerf.conf:82-96
     directional_derivatives: float = 0.0
     norm_smaller_than_one_start: int = 11000
     depth_loss_clamp: float = 0.5
+    directional_derivatives_start: int = 100
+
+
+LOSS_TERM_NAMES = ("rgb_loss", "depth_loss", "unit_norm_loss", "supervision_loss", "norm_smaller_than_one_loss",
+                   "directional_derivatives_loss")
+
+
+def vf_loss_terms(rgb: Tensor, depth: Tensor, normals: Tensor, supervised: Tensor, rgb_gt: Tensor, depth_gt: Tensor,
+                  supervised_gt: Tensor, w: LossWeights, epoch: int = 0, directional: Optional[Tensor] = None):
+    """VFLoss.forward (models/losses/vf_loss.py:34-87) -> (total, the six terms in the order of its log dictionary).
+    L1 rgb; L1 depth clamped per element at depth_loss_clamp (skipped when the batch has no depth); mean (|n| - 1)^2; MSE on
+    the supervised normals (skipped when there are none); mean relu(|n| - 1)^2 from norm_smaller_than_one_start on; mean of
+    the directional-derivative norms from directional_derivatives_start on when render() returned any."""
+    zero = torch.tensor(0.0)
+    rgb_l = F.l1_loss(rgb, rgb_gt)                                                                      # :45
+    depth_l = F.l1_loss(depth, depth_gt, reduction="none").clamp(max=w.depth_loss_clamp).mean() \
+        if depth_gt.nelement() > 0 else zero                                                            # :48-51
+    flat = normals.reshape(-1, 3)
+    unit_l = torch.mean((torch.norm(flat, dim=1) - 1) ** 2)                                             # :54
+    sup_l = F.mse_loss(supervised, supervised_gt) if supervised.nelement() > 0 else zero                # :57-60
+    small_l = torch.mean(torch.pow(F.relu(torch.norm(flat, dim=1) - 1), 2)) \
+        if epoch >= w.norm_smaller_than_one_start else zero                                             # :63-66
+    dd_l = zero
+    if directional is not None and epoch >= w.directional_derivatives_start:                            # :69-71
+        dd_l = torch.mean(directional)
+    total = w.rgb * rgb_l + w.depth * depth_l + w.unit_norm * unit_l + w.supervision * sup_l + \
+        w.norm_smaller_than_one * small_l + w.directional_derivatives * dd_l                            # :74-79
+    return total, (rgb_l, depth_l, unit_l, sup_l, small_l, dd_l)
 
 
 def vf_loss(rgb: Tensor, depth: Tensor, normals: Tensor, supervised: Tensor, rgb_gt: Tensor, depth_gt: Tensor,
-            supervised_gt: Tensor, w: LossWeights, epoch: int = 0) -> Tensor:
-    """L1 rgb + clamped-L1 depth + unit-norm + supervision MSE (+ norm<1 after its start epoch); the
-    directional-derivative term is absent in the shipped regime (weight 0, derivatives None; Q8)."""
-    loss = w.rgb * F.l1_loss(rgb, rgb_gt)
-    if depth_gt.nelement() > 0:
-        loss = loss + w.depth * F.l1_loss(depth, depth_gt, reduction="none").clamp(max=w.depth_loss_clamp).mean()
-    flat = normals.reshape(-1, 3)
-    loss = loss + w.unit_norm * torch.mean((torch.norm(flat, dim=1) - 1) ** 2)
-    if supervised.nelement() > 0:
-        loss = loss + w.supervision * F.mse_loss(supervised, supervised_gt)
-    if epoch >= w.norm_smaller_than_one_start:
-        loss = loss + w.norm_smaller_than_one * torch.mean(torch.pow(F.relu(torch.norm(flat, dim=1) - 1), 2))
-    return loss
+            supervised_gt: Tensor, w: LossWeights, epoch: int = 0, directional: Optional[Tensor] = None) -> Tensor:
+    return vf_loss_terms(rgb, depth, normals, supervised, rgb_gt, depth_gt, supervised_gt, w, epoch, directional)[0]
+
+
+def border_indices_and_gt(points: Tensor, normals: Tensor, far: float, radius: float, centroid: Tensor):
+    """get_border_indices_and_gt (models/helpers/functions.py:75-98): normals of the ray samples farther than far/2 - radius
+    from the centroid, unit vectors from them to the centroid.  points / normals [N,S,3]."""
+    keep = torch.norm(points - centroid, dim=2) > (far / 2 - radius)
+    return normals.reshape(points.shape)[keep], F.normalize(centroid - points[keep], dim=1)
+
+
+def center_indices_and_gt(points: Tensor, normals: Tensor, centroid: Tensor, radius: float):
+    """get_center_indices_and_gt (models/helpers/functions.py:137-157): normals of the ray samples closer than radius to the
+    centroid, unit vectors from the centroid to them."""
+    keep = torch.norm(points - centroid, dim=2) < radius
+    return normals.reshape(points.shape)[keep], F.normalize(points[keep] - centroid, dim=1)
+
+
+def trainer_parameter_list(vf_params: Dict[str, Tensor], rn_params: Dict[str, Tensor], density_params: Dict[str, Tensor]):
+    """VectorFieldNerf.parameters() (models/nerf/vector_field_nerf.py:127-137): VF, rendering, density, then the VF parameters
+    AGAIN (fine_vector_field_network is the same object, Q4)."""
+    vf = list(vf_params.values())
+    return vf + list(rn_params.values()) + list(density_params.values()) + vf
+
+
+def trainer_epoch(vf_sd: Dict[str, Tensor], rn_sd: Dict[str, Tensor], density: Dict[str, Tensor], param_names, batches, cfg: RenderSettings,
+                  w: LossWeights, epoch: int, centroid: Tensor, border_radius: float, far: float, lr: float, lr_gamma: float,
+                  clip_norm: float, on_step=None):
+    """VectorFieldNerfRunner.train_epoch (train/vector_field_nerf_train.py:161-260) for the shipped branch (VF init not
+    "center": border shell + centre ball supervision, :193-216) and regime (networks in eval mode, :140-141).
+
+    vf_sd / rn_sd: state dicts whose entries named in ``param_names['vf'|'rn']`` are leaf tensors with requires_grad (updated
+    in place), density: {'beta','mean','scale'} leaves.  batches[t]: uv, pose, intrinsics, rgb_gt, depth_gt, the three render
+    draws (u_coarse, u_fine, u_add) and the two sphere samplers' numpy draws (border_draws, center_draws: columns phi,
+    cos(theta), u).  Optimizer = torch.optim.Adam over the duplicated list with the per-entry loop (foreach=False — what the
+    reference's torch 1.x did and what torch 2.x does on CPU tensors), ExponentialLR(gamma), clip_grad_norm_ with the per-entry
+    loop.  Returns one record per step: total, terms, clip norm, lr."""
+    vf_p = {k: vf_sd[k] for k in param_names["vf"]}
+    rn_p = {k: rn_sd[k] for k in param_names["rn"]}
+    plist = trainer_parameter_list(vf_p, rn_p, density)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")        # "duplicate parameters" — the point of the exercise
+        opt = torch.optim.Adam(plist, lr=lr, weight_decay=0.0, foreach=False)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, lr_gamma)
+    records = []
+    for b in batches:
+        out = render(b["uv"], b["pose"], b["intrinsics"], vf_sd, rn_sd, cfg, u_coarse=b.get("u_coarse"), u_fine=b.get("u_fine"),
+                     u_add=b["u_add"], beta=density["beta"], mean=density["mean"], scale=density["scale"])        # :177
+        n_sup = (out["points"].shape[0] * out["points"].shape[1]) // 10
+        bp, b_gt = sphere_shell_points_from_draws(b["border_draws"], far - 5 * border_radius, far, centroid, inward=True)   # :196-200
+        assert bp.shape[0] == n_sup
+        sup = [vf_mlp(bp, vf_sd, cfg.vf_multires, cfg.vf_skip_in)[:, :3]]                                         # :201
+        sup_gt = [b_gt]
+        rc_n, rc_gt = center_indices_and_gt(out["points"], out["normals"], centroid, border_radius)               # :204-207
+        cp, c_gt = sphere_shell_points_from_draws(b["center_draws"], 0.0, border_radius, centroid, inward=False)   # :208-211
+        sup += [rc_n, vf_mlp(cp, vf_sd, cfg.vf_multires, cfg.vf_skip_in)[:, :3]]                                  # :213
+        sup_gt += [rc_gt, c_gt]
+        total, terms = vf_loss_terms(out["rgb"], out["depth"], out["normals"], torch.cat(sup, 0), b["rgb_gt"], b["depth_gt"],
+                                     torch.cat(sup_gt, 0), w, epoch, out.get("directional_derivatives"))          # :233
+        opt.zero_grad()                                                                                           # :251
+        total.backward()
+        norm = torch.nn.utils.clip_grad_norm_(plist, clip_norm, foreach=False)                                    # :255
+        lr_now = opt.param_groups[0]["lr"]
+        opt.step()                                                                                                # :259
+        sched.step()                                                                                              # :260
+        rec = {"loss": total.detach(), "terms": [t.detach() for t in terms], "clip_total_norm": norm.detach(), "lr": lr_now,
+               "out": {k: v.detach() for k, v in out.items()}, "ray_center_normals": rc_n.detach(), "ray_center_gt": rc_gt,
+               "border_points": bp, "border_gt": b_gt, "center_points": cp, "center_gt": c_gt}
+        records.append(rec)
+        if on_step is not None:
+            on_step(len(records) - 1, rec)
+    return records, opt
 
 
 def psnr(a: Tensor, b: Tensor) -> float:
@@ -490,18 +580,27 @@ def numerical_directional_derivatives(points: Tensor, normals: Tensor, vf, fine:
 # --------------------------------------------------------------------------------------
 # supervision points  (models/samplers/sampler.py:160-193, models/helpers/functions.py:100-135)
 # --------------------------------------------------------------------------------------
-def sphere_shell_points(u: Tensor, r_min: float, r_max: float, centroid: Tensor, inward: bool) -> Tuple[Tensor, Tensor]:
-    """u[n,3] = the three uniform draws per sample in the reference's order (phi, cos(theta), radius).  The sampler
-    works in float64 numpy and casts to float32 before adding the centroid; gt = normalize(+-(p - c), eps 1e-12)."""
-    u64 = u.double()
-    phi = 2.0 * math.pi * u64[:, 0]
-    cos_t = 2.0 * u64[:, 1] - 1.0
+def sphere_shell_points_from_draws(draws: Tensor, r_min: float, r_max: float, centroid: Tensor, inward: bool) -> Tuple[Tensor, Tensor]:
+    """SphereSampler.sample (models/samplers/sampler.py:170-193) + sample_border_points / sample_center_points
+    (models/helpers/functions.py:100-135) on the sampler's own numpy draws: draws[n,3] float64 = phi ~ U(0, 2 pi),
+    cos(theta) ~ U(-1, 1), u ~ U(0, 1), in the order the sampler draws them.  float64 arithmetic, cast to float32 BEFORE the
+    centroid is added (functions.py:111,128); gt = normalize(+-(p - c), eps 1e-12)."""
+    d = draws.double()
+    phi, cos_t, u = d[:, 0], d[:, 1], d[:, 2]
     theta = torch.arccos(cos_t)
-    r = torch.pow(u64[:, 2], 1.0 / 3.0) * (r_max - r_min) + r_min
+    r = torch.pow(u, 1.0 / 3.0) * (r_max - r_min) + r_min           # np.cbrt
     local = torch.stack([r * torch.sin(theta) * torch.cos(phi), r * torch.sin(theta) * torch.sin(phi), r * torch.cos(theta)], dim=1)
     points = local.float() + centroid.float()
-    d = (centroid - points) if inward else (points - centroid)
-    return points, F.normalize(d, dim=1)
+    vec = (centroid - points) if inward else (points - centroid)
+    return points, F.normalize(vec, dim=1)
+
+
+def sphere_shell_points(u: Tensor, r_min: float, r_max: float, centroid: Tensor, inward: bool) -> Tuple[Tensor, Tensor]:
+    """The same on UNIT uniforms u[n,3] (phi = 2 pi u0, cos(theta) = 2 u1 - 1, radius draw u2): the form the device sampler
+    (vfn_sample_sphere_shell) is replayed against."""
+    u64 = u.double()
+    draws = torch.stack([2.0 * math.pi * u64[:, 0], 2.0 * u64[:, 1] - 1.0, u64[:, 2]], dim=1)
+    return sphere_shell_points_from_draws(draws, r_min, r_max, centroid, inward)
 
 
 # --------------------------------------------------------------------------------------

@@ -59,6 +59,10 @@ FIXTURES = {
     "shipped_sizes": dict(seed=8, gain=2.0, n_rays=10, n_samples=100, n_importance=35, perturb=True, th=-2.0, n_window=11,
                           near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=13, pose="orbit",
                           skew=0.0, far_per_ray=False),
+    # detach_normals=False (rendering_network.py:76-77; not the shipped value): the colours' gradient also reaches the normals
+    "attached_normals": dict(seed=9, gain=2.0, n_rays=12, n_samples=16, n_importance=10, perturb=True, th=-0.2, n_window=5,
+                             near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=15, pose="identity",
+                             skew=0.0, far_per_ray=False, detach_normals=False),
     "w1_det": dict(seed=4, gain=2.0, n_rays=16, n_samples=20, n_importance=12, perturb=False, th=-2.0, n_window=1,
                    near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=7, pose="identity",
                    skew=0.0, far_per_ray=False),
@@ -74,7 +78,7 @@ def ref_config(fx) -> "rcfg.VFNerfConfig":
                                        xavier_init=False, init=""),
         rendering_net_config=rcfg.RenderingNetConfig(output_dims=3, dimensions=[256] * 4, feature_vector_dims=256,
                                                      weight_norm=False, batch_norm=True, mode="idr",
-                                                     embedder_multires=4, detach_normals=True),
+                                                     embedder_multires=4, detach_normals=bool(fx.get("detach_normals", True))),
         ray_sampler_config=rcfg.RaySamplerConfig(n_samples=fx["n_samples"], n_importance=fx["n_importance"],
                                                  rays_per_batch=1024, perturb=fx["perturb"], near=fx["near"],
                                                  far=fx["far"], fine_range=fx["fine_range"], increase_every=50,

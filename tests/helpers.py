@@ -19,7 +19,7 @@ def load_fixture(name: str):
     """-> (fx: dict of scalars, data: dict of torch tensors)."""
     raw = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
     fx = ast.literal_eval(str(raw["fixture"]))
-    data = {k: torch.from_numpy(raw[k]) for k in raw.files if k != "fixture"}
+    data = {k: torch.from_numpy(raw[k]) for k in raw.files if raw[k].dtype.kind not in "US"}
     return fx, data
 
 
@@ -31,6 +31,7 @@ def build_model(fx: dict, data: Dict[str, torch.Tensor], device="cpu") -> "vf_ne
                                      perturb=fx["perturb"], near=fx["near"], far=fx["far"],
                                      fine_range=fx["fine_range"], dir_to_normal_th=fx["th"], n_window=fx["n_window"])
     cfg.numerical_jacobian = bool(fx.get("numjac", False))
+    cfg.rendering_net_config.detach_normals = bool(fx.get("detach_normals", True))
     model = vf_nerf_amd.VectorFieldNerf(cfg)
     synthetic.scale_hidden_weights(model.vector_field_network, model.rendering_network, fx["gain"])
     with torch.no_grad():
@@ -58,7 +59,7 @@ def build_model(fx: dict, data: Dict[str, torch.Tensor], device="cpu") -> "vf_ne
 
 def oracle_settings(fx: dict):
     from oracle import vfnerf_oracle as O
-    return O.RenderSettings(numerical_jacobian=bool(fx.get("numjac", False)), train_mode=bool(fx.get("train", False)), n_samples=fx["n_samples"], n_fine=fx["n_importance"], near=fx["near"], far=fx["far"],
+    return O.RenderSettings(detach_normals=bool(fx.get("detach_normals", True)), numerical_jacobian=bool(fx.get("numjac", False)), train_mode=bool(fx.get("train", False)), n_samples=fx["n_samples"], n_fine=fx["n_importance"], near=fx["near"], far=fx["far"],
                             fine_range=fx["fine_range"], perturb=fx["perturb"], n_window=fx["n_window"],
                             dir_to_normal_th=fx["th"], normalize=True,
                             density=O.DensityParams(beta=0.5, mean=0.7, scale=100.0, beta_bounds=(1e-4, 1e9),
@@ -117,3 +118,64 @@ def oracle_gradients(fx, d, model, masks=None):
     grads["_out"] = out           # every stage of the oracle's forward
     grads["_state"] = {"vf": vf_sd, "rn": rn_sd}      # train mode: running statistics advanced in place
     return float(loss), grads
+
+
+# ------------------------------------------------------------------------------------------------
+# trainer fixture (tests/golden/make_train_golden.py: outputs of the reference's own train_epoch / VFLoss / samplers)
+# ------------------------------------------------------------------------------------------------
+TRAINER_WATCH = (("vf", "layers.0.0.weight", None), ("vf", "layers.0.1.weight", None), ("vf", "layers.2.0.weight", 8),
+                 ("vf", "layers.4.1.bias", None), ("vf", "layers.8.weight", "head"), ("vf", "layers.8.bias", None),
+                 ("rn", "layers.0.0.weight", 8), ("rn", "layers.1.1.weight", None), ("rn", "layers.4.weight", None),
+                 ("rn", "layers.4.bias", None))
+
+
+def load_trainer_fixture():
+    return load_fixture("trainer_steps")
+
+
+def trainer_batches(fx, d, device="cpu"):
+    out = []
+    for t in range(fx["steps"]):
+        b = {k: d[f"s{t}.{k}"] for k in ("uv", "pose", "intrinsics", "rgb_gt", "depth_gt", "u_coarse", "u_fine", "u_add",
+                                        "border_draws", "center_draws", "border_u", "center_u")}
+        out.append({k: v.to(device) for k, v in b.items()})
+    return out
+
+
+def watched_slice(p: torch.Tensor, how):
+    if how == "head":
+        return p[:3]
+    if isinstance(how, int):
+        return p[::how, ::how]
+    return p
+
+
+def trainer_loss_weights(fx):
+    from oracle import vfnerf_oracle as O
+    return O.LossWeights()       # the shipped weights / thresholds (confs/vf_nerf.conf:74-90), which the fixture ran with
+
+
+def lr_gamma(fx) -> float:
+    return 0.1 ** (1.0 / fx["lr_decay_steps"])     # vector_field_nerf.py:65-67
+
+
+def narrow_checkpoint_model(d, device="cpu"):
+    """The facade with the geometry of the reference-written checkpoint fixture (tests/golden/ref_checkpoint_latest.pth;
+    recipe stored beside it by make_train_golden.py)."""
+    import numpy as np
+    raw = np.load(os.path.join(GOLDEN_DIR, "trainer_steps.npz"))
+    c = ast.literal_eval(str(raw["ckpt.recipe"]))
+    cfg = vf_nerf_amd.shipped_config(torch.device(device), n_samples=c["n_samples"], n_importance=c["n_importance"], perturb=True,
+                                     near=c["near"], far=c["far"], fine_range=c["fine_range"], dir_to_normal_th=c["th"],
+                                     n_window=c["n_window"])
+    cfg.vf_net_config.dimensions = list(c["vf_dims"])
+    cfg.vf_net_config.skip_connection_in = list(c["vf_skip"])
+    cfg.vf_net_config.feature_vector_dims = c["feat"]
+    cfg.rendering_net_config.dimensions = list(c["rn_dims"])
+    cfg.rendering_net_config.feature_vector_dims = c["feat"]
+    model = vf_nerf_amd.VectorFieldNerf(cfg)
+    model.eval()
+    return model, c
+
+
+REF_CHECKPOINT = os.path.join(GOLDEN_DIR, "ref_checkpoint_latest.pth")

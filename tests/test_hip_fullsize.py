@@ -123,3 +123,134 @@ def test_render_chunked_equals_chunk_by_chunk():
     torch.cuda.synchronize()
     assert torch.equal(rgb1, rgb2) and torch.equal(depth1, depth2)
     assert float(rgb1.abs().sum()) > 0
+
+
+def test_dense_grid_queries_at_full_size_against_the_oracle():
+    """BASELINE.json configs[4] (evaluation/utils/mc_utils.py:88-104 at resolution 512 -> 100 000-point blocks): 2^24
+    device-resident grid points (a 256^3 quadrant; a 512^3 one is 8 of these) through ``grid.get_set_predictions`` in both
+    precisions, a strided sample of 4096 points checked against the ORACLE's decoder(x)[:, :3], plus the rank dealing at this
+    size (two ranks cover every block exactly once) and the 4-column sample layout mc_utils builds."""
+    from oracle import vfnerf_oracle as O
+    from vf_nerf_amd import grid
+    m = _model()
+    dec = m.fine_vector_field_network
+    res = 256
+    ax = torch.linspace(-1.0, 1.0, res, device=DEV)
+    samples = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1).reshape(-1, 3).contiguous()
+    n = samples.shape[0]
+    assert n == 1 << 24
+    idx = torch.arange(0, n, n // 4096, device=DEV)[:4096]
+    cpu_sd = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
+    want = O.vf_mlp(samples[idx].cpu(), cpu_sd, 6, (4,))[:, :3]
+    for precision in ("f16x3", "fp32"):
+        m.precision = precision
+        got = grid.get_set_predictions(dec, samples, 100000, torch.device(DEV))
+        assert got.shape == (n, 3) and got.is_cuda
+        err = float((got[idx].cpu() - want).abs().max())
+        print(f"2^24 grid points, {precision}: max |err| vs oracle on 4096 strided points {err:.2e}")
+        assert err < 1e-4
+        assert float(got.abs().max()) <= 1.0
+    m.precision = "f16x3"
+    ref = grid.get_set_predictions(dec, samples, 100000, torch.device(DEV))
+    four = torch.cat([samples, torch.zeros(n, 1, device=DEV)], dim=1)
+    parts = [grid.get_set_predictions(dec, four, 100000, torch.device(DEV), rank=r, world_size=2) for r in range(2)]
+    assert torch.equal(parts[0] + parts[1], ref), "two ranks together reproduce the single-rank result bit for bit"
+    blk = 100000
+    assert float(parts[0][blk:2 * blk].abs().max()) == 0.0 and float(parts[1][:blk].abs().max()) == 0.0
+
+
+def _train_step(m, uv, pose, K, rgb_gt, depth_gt, centroid, n_sup, bucket=None):
+    """bench.train_bench's step (configs[2]): render + 2 x n_sup supervision points + loss + backward + clip + Adam."""
+    from vf_nerf_amd import optim, supervision
+    out = m.render(pose, uv, K, epoch=0)
+    bp, b_gt = supervision.sample_border_points(0.75, 1.0, n_sup, centroid, uv.device)
+    cp, c_gt = supervision.sample_center_points(centroid, 0.05, n_sup, uv.device)
+    sup_n = m.vector_field_network(torch.cat([bp, cp]))[:, :3]
+    sup_gt = torch.cat([b_gt, c_gt])
+    normals = out.coarse_normals.reshape(-1, 3)
+    loss = 2.0 * (out.coarse_rgb_values - rgb_gt).abs().mean() + \
+        0.5 * torch.clamp((out.coarse_depth_map - depth_gt).abs(), max=0.5).mean() + \
+        0.1 * ((normals.norm(dim=-1) - 1.0) ** 2).mean() + 1.0 * ((sup_n - sup_gt) ** 2).mean()
+    if bucket is not None:
+        bucket.zero()
+    else:
+        m.optimizer.zero_grad()
+    loss.backward()
+    if bucket is not None:
+        bucket.all_reduce_mean()
+    norm = optim.clip_grad_norm_(m.parameters(), m.config.scheduler_config.clip_norm)
+    return loss, norm
+
+
+@pytest.mark.parametrize("storage", ["f16", "fp32"])
+def test_training_step_at_full_size(storage):
+    """BASELINE.json configs[2] at its full size — one optimizer step on a 4096-ray batch x 128 samples with 2 x 52 428
+    supervision points — on the 16-bit matrix-core path (f16x3 forward, bf16-split backward; ``storage``: how the saved
+    activations are kept for the weight-gradient kernels) against the exact-fp32 HIP kernels from the same weights, rays, draws
+    and targets: (a) every parameter gradient within 1e-3 of the tensor's largest entry, (b) the loss within 1e-5, (c) after
+    optimizer.step the VF parameters' Adam step counter reads 2 (the alias, Q4), the rendering net's 1."""
+    from vf_nerf_amd import supervision
+    n, s_t = 4096, 128
+    uv, pose, K = synthetic.pinhole_batch(n, 1200, 680, 600.0, seed=9, device=DEV)
+    g = torch.Generator().manual_seed(7)
+    rgb_gt = torch.rand(n, 3, generator=g).to(DEV)
+    depth_gt = (0.2 + 0.6 * torch.rand(n, 1, generator=g)).to(DEV)
+    centroid = torch.tensor([0.0, 0.0, 0.6], device=DEV)
+    n_sup = (n * s_t) // 10
+    results = {}
+    for precision in ("f16x3", "fp32"):
+        m = _model()
+        m.precision = precision
+        m.activation_storage = storage if precision == "f16x3" else "fp32"
+        m.rng_seed, m._rng_offset = 5, 0
+        supervision.manual_seed(11)
+        loss, norm = _train_step(m, uv, pose, K, rgb_gt, depth_gt, centroid, n_sup)
+        grads = {id_: p.grad.detach().clone() for id_, p in enumerate(m.unique_parameters())}
+        m.optimizer.step()
+        results[precision] = (float(loss), float(norm), grads, m)
+    (l16, n16, g16, m16), (l32, n32, g32, m32) = results["f16x3"], results["fp32"]
+    assert abs(l16 - l32) <= 1e-5 * max(1.0, abs(l32)), (l16, l32)
+    worst = 0.0
+    for k in g32:
+        ref = g32[k]
+        err = float((g16[k] - ref).abs().max() / max(float(ref.abs().max()), 1e-30))
+        worst = max(worst, err)
+    print(f"4096 x 128 training step, activations {storage}: loss {l16:.6f} vs {l32:.6f}; clip norm {n16:.4f} vs {n32:.4f}; worst "
+          f"parameter-gradient difference {worst:.2e} of the tensor max")
+    assert worst < 1e-3
+    assert abs(n16 - n32) <= 1e-3 * n32
+    st = m16.optimizer.state
+    assert float(st[m16.vector_field_network.layers[3][0].weight]["step"]) == 2.0
+    assert float(st[m16.rendering_network.layers[2][0].weight]["step"]) == 1.0
+    assert all(torch.isfinite(p).all() for p in m16.unique_parameters())
+
+
+def test_gradient_bucket_path_equals_plain_path():
+    """Multi-GPU readiness on one GPU: the data-parallel step (``distributed.GradientBucket``: every ``param.grad`` a view into
+    ONE flat fp32 buffer, zeroed in place, all-reduced as one message) must leave bit-identical weights to the plain
+    single-process step, and the views must stay bound to the flat buffer across the backward of the HIP autograd functions."""
+    from vf_nerf_amd import distributed as vdist, supervision
+    n, s_t = 1024, 128
+    uv, pose, K = synthetic.pinhole_batch(n, 1200, 680, 600.0, seed=4, device=DEV)
+    g = torch.Generator().manual_seed(8)
+    rgb_gt, depth_gt = torch.rand(n, 3, generator=g).to(DEV), (0.2 + 0.6 * torch.rand(n, 1, generator=g)).to(DEV)
+    centroid = torch.tensor([0.0, 0.0, 0.6], device=DEV)
+    finals = []
+    for use_bucket in (False, True):
+        m = _model()
+        m.rng_seed, m._rng_offset = 2, 0
+        supervision.manual_seed(3)
+        bucket = vdist.GradientBucket(m) if use_bucket else None
+        if bucket is not None:
+            assert bucket.numel() == 805780, "the alias (Q4) must not double the bucket"
+        for _ in range(2):
+            _train_step(m, uv, pose, K, rgb_gt, depth_gt, centroid, (n * s_t) // 10, bucket=bucket)
+            if bucket is not None:
+                off = 0
+                for p in bucket.params:          # still views of the flat buffer after backward + clip
+                    assert p.grad.data_ptr() == bucket.flat.data_ptr() + 4 * off, "param.grad left the bucket"
+                    off += p.numel()
+            m.optimizer.step()
+            m.scheduler.step()
+        finals.append([p.detach().clone() for p in m.unique_parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*finals)), "bucketed and plain steps must give bit-identical weights"

@@ -152,3 +152,117 @@ def test_train_mode_matches_reference():
             got, want = sd[f"layers.{i}.1.{stat}"], d[f"bn.{net}.{i}.{stat}"]
             assert float((got - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max())), (net, i, stat)
         assert int(sd[f"layers.{i}.1.num_batches_tracked"]) == int(d[f"bn.{net}.{i}.num_batches_tracked"])
+
+
+# ------------------------------------------------------------------------------------------------
+# trainer-side pieces against the reference's own VFLoss / SphereSampler / helpers / train_epoch
+# ------------------------------------------------------------------------------------------------
+def test_vf_loss_matches_reference_vfloss():
+    """models/losses/vf_loss.py:34-87 on every branch: early epoch, past norm_smaller_than_one_start with directional
+    derivatives, derivatives before their start epoch, a batch without depth and without supervised normals."""
+    from helpers import load_trainer_fixture
+    _, d = load_trainer_fixture()
+    w = O.LossWeights(directional_derivatives=0.3)
+    base = {k[len("loss.in."):]: v for k, v in d.items() if k.startswith("loss.in.")}
+    for name in ("early", "late", "dd_before_start", "no_depth_no_sup"):
+        epoch, dd, depth, sup = [int(v) for v in d[f"loss.{name}.case"]]
+        total, terms = O.vf_loss_terms(base["rgb"], base["depth"], base["normals"], base["sup"] if sup else torch.empty(0, 3),
+                                       base["rgb_gt"], base["depth_gt"] if depth else torch.empty(0),
+                                       base["sup_gt"] if sup else torch.empty(0), w, epoch, base["dd"] if dd else None)
+        assert abs(float(total) - float(d[f"loss.{name}.total"])) <= 1e-6 * max(1.0, abs(float(total))), name
+        got = torch.stack([t.double() for t in terms])
+        assert float((got - d[f"loss.{name}.terms"]).abs().max()) <= 1e-6, (name, got, d[f"loss.{name}.terms"])
+    assert float(d["loss.late.terms"][4]) > 0 and float(d["loss.late.terms"][5]) > 0 and float(d["loss.dd_before_start.terms"][5]) == 0
+
+
+def test_supervision_samplers_match_reference():
+    """SphereSampler.sample + sample_border_points / sample_center_points (sampler.py:160-193, functions.py:100-135) replayed
+    on the sampler's own numpy draws: points and ground truth bit-identical; get_border_indices_and_gt / get_center_indices_and_gt
+    (functions.py:75-98,137-157) on fixed inputs."""
+    from helpers import load_trainer_fixture
+    fx, d = load_trainer_fixture()
+    c = torch.tensor(fx["centroid"])
+    for t in range(fx["steps"]):
+        r_min, r_max, num = d[f"s{t}.border_args"].tolist()
+        assert int(num) == (fx["n_rays"] * (fx["n_samples"] + fx["n_importance"])) // 10
+        assert abs(r_min - (fx["far"] - 5 * fx["border_radius"])) < 1e-12 and r_max == fx["far"]
+        p, g = O.sphere_shell_points_from_draws(d[f"s{t}.border_draws"], r_min, r_max, c, inward=True)
+        assert torch.equal(p, d[f"s{t}.border_points"]) and torch.equal(g, d[f"s{t}.border_gt"])
+        radius, num_c = d[f"s{t}.center_args"].tolist()
+        p, g = O.sphere_shell_points_from_draws(d[f"s{t}.center_draws"], 0.0, radius, c, inward=False)
+        assert torch.equal(p, d[f"s{t}.center_points"]) and torch.equal(g, d[f"s{t}.center_gt"])
+        # the unit-uniform form (what the device sampler is replayed against) agrees to float32 rounding
+        p2, g2 = O.sphere_shell_points(d[f"s{t}.center_u"], 0.0, radius, c, inward=False)
+        assert float((p2 - p).abs().max()) <= 1e-7 and float((g2 - g).abs().max()) <= 1e-5
+        # ray samples inside the centre ball: selection on the reference's own render outputs
+        n_, g_ = O.center_indices_and_gt(d[f"s{t}.out.points"], d[f"s{t}.out.normals"], c, radius)
+        assert torch.equal(n_, d[f"s{t}.ray_center_normals"]) and torch.equal(g_, d[f"s{t}.ray_center_gt"])
+    far, radius = d["border_idx.args"].tolist()
+    a, b = O.border_indices_and_gt(d["border_idx.points"], d["border_idx.normals"], far, radius, d["border_idx.centroid"])
+    assert torch.equal(a, d["border_idx.out_normals"]) and torch.equal(b, d["border_idx.out_gt"]) and 0 < a.shape[0] < 60
+
+
+def test_trainer_epoch_matches_reference_train_epoch():
+    """Three optimizer steps of the reference's own VectorFieldNerfRunner.train_epoch (train/vector_field_nerf_train.py:161-260;
+    captured by tests/golden/make_train_golden.py) against the oracle's restatement from the same weights, batches and draws:
+    sampled depths bit-identical at every step, the six loss terms, the total, the value clip_grad_norm_ returned, the learning
+    rate, and the watched parameters after every optimizer.step (VF parameters: two Adam updates per step, Q4)."""
+    from helpers import TRAINER_WATCH, load_trainer_fixture, lr_gamma, trainer_batches, trainer_loss_weights, watched_slice
+    fx, d = load_trainer_fixture()
+    model = build_model(fx, d)
+    vf_sd = {k: v.detach().clone() for k, v in model.vector_field_network.state_dict().items()}
+    rn_sd = {k: v.detach().clone() for k, v in model.rendering_network.state_dict().items()}
+    names = {"vf": [k for k, _ in model.vector_field_network.named_parameters()],
+             "rn": [k for k, _ in model.rendering_network.named_parameters()]}
+    for sd, keys in ((vf_sd, names["vf"]), (rn_sd, names["rn"])):
+        for k in keys:
+            sd[k].requires_grad_(True)
+    density = {k: torch.tensor(v, requires_grad=True) for k, v in (("beta", 0.5), ("scale", 100.0), ("mean", 0.7))}
+    w0 = {f"{net}.{key}": watched_slice(dict(vf=vf_sd, rn=rn_sd)[net][key].detach(), how).clone() for net, key, how in TRAINER_WATCH}
+    seen = []
+
+    def on_step(t, rec):
+        sds = {"vf": vf_sd, "rn": rn_sd}
+        seen.append({f"{net}.{key}": watched_slice(sds[net][key].detach(), how).clone() for net, key, how in TRAINER_WATCH} |
+                    {f"density.{k}": v.detach().clone().reshape(1) for k, v in density.items()})
+
+    recs, opt = O.trainer_epoch(vf_sd, rn_sd, density, names, trainer_batches(fx, d), oracle_settings(fx), trainer_loss_weights(fx),
+                                fx["epoch"], torch.tensor(fx["centroid"]), fx["border_radius"], fx["far"], fx["lr"], lr_gamma(fx),
+                                fx["clip_norm"], on_step=on_step)
+    lr = fx["lr"]
+    for t, rec in enumerate(recs):
+        assert torch.equal(rec["out"]["z_vals"], d[f"s{t}.out.z_vals"]), f"step {t}: sampled depths differ"
+        for k in ("rgb", "depth", "normals"):
+            want = d[f"s{t}.out.{k}"]
+            assert float((rec["out"][k].reshape(want.shape) - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), (t, k)
+        got = torch.stack([x.double() for x in rec["terms"]])
+        assert float((got - d[f"s{t}.loss_terms"]).abs().max()) <= 2e-6, (t, got, d[f"s{t}.loss_terms"])
+        assert abs(float(rec["loss"]) - float(d[f"s{t}.loss"])) <= 2e-6 * max(1.0, float(d[f"s{t}.loss"]))
+        assert abs(float(rec["clip_total_norm"]) - float(d[f"s{t}.clip_total_norm"])) <= 1e-4 * float(d[f"s{t}.clip_total_norm"]), t
+        assert abs(rec["lr"] - float(d[f"s{t}.lr"])) <= 1e-12
+        # parameters after the step: a step moves a weight by <= lr per Adam update; agreement is asked to 2 % of one update
+        for k, v in seen[t].items():
+            want = d[f"s{t}.after.{k}"]
+            assert float((v - want).abs().max()) <= 0.02 * lr + 1e-6 * float(want.abs().max()), (t, k, float((v - want).abs().max()))
+    # Q4: the aliased VF parameters took two updates per step, the rendering net's one
+    moved_vf = float((seen[0]["vf.layers.8.weight"] - w0["vf.layers.8.weight"]).abs().max())
+    moved_rn = float((seen[0]["rn.layers.4.weight"] - w0["rn.layers.4.weight"]).abs().max())
+    assert abs(moved_vf - 2 * lr) < 0.05 * lr and abs(moved_rn - lr) < 0.05 * lr, (moved_vf, moved_rn)
+    assert abs(opt.param_groups[0]["lr"] - float(d["final_lr"])) <= 1e-15
+
+
+def test_attached_normals_gradients_match_reference():
+    """detach_normals=False (rendering_network.py:76-77, not the shipped value): the colours' gradient also reaches the normals
+    and through them the VF net — forward unchanged, VF gradients different from the detached case."""
+    fx, d = load_fixture("attached_normals")
+    assert fx["detach_normals"] is False
+    model = build_model(fx, d)
+    loss, grads = oracle_gradients(fx, d, model)
+    assert torch.equal(grads["_out"]["z_vals"], d["z_vals"])
+    assert abs(loss - float(d["loss"])) <= 1e-5 * max(1.0, abs(float(d["loss"])))
+    for net, key in GRAD_KEYS:
+        err = grad_rel_err(grads[f"{net}.{key}"], d[f"grad.{net}.{key}"])
+        assert err < 1e-4, (net, key, err)
+    _, detached = oracle_gradients(dict(fx, detach_normals=True), d, model)
+    k = "vf.layers.7.1.weight"
+    assert grad_rel_err(detached[k], d[f"grad.{k}"]) > 1e-3, "the fixture must tell the two settings apart"

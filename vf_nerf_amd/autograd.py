@@ -18,6 +18,10 @@ def _flat3(t: torch.Tensor) -> torch.Tensor:
 
 
 def vf_forward(net, points: torch.Tensor, vector_only: bool = False) -> torch.Tensor:
+    if not net.supports_fused():       # a geometry the fused kernels are not specialised for: layer-at-a-time row kernels
+        from .batchstat import vf_forward_eval_rows
+        out = vf_forward_eval_rows(net, points)
+        return out[:, :3].contiguous() if vector_only else out
     if _wants_grad(net, points):
         from .backward import vf_forward_autograd
         return vf_forward_autograd(net, points, vector_only)
@@ -29,7 +33,7 @@ def vf_forward(net, points: torch.Tensor, vector_only: bool = False) -> torch.Te
 
 
 def render_forward(net, points, normals, view_dirs, feats) -> torch.Tensor:
-    if _wants_grad(net, points, normals, view_dirs, feats):
+    if _wants_grad(net, points, normals, view_dirs, feats) or not net.supports_fused():
         from .backward import render_forward_autograd
         return render_forward_autograd(net, points, normals, view_dirs, feats)
     return lib.render_mlp_fwd(net.geometry(), net.packed_weights(), _flat3(points), _flat3(normals),

@@ -215,6 +215,7 @@ class _FinePass(torch.autograd.Function):
             model._debug_saved = ws.saved
             model._debug_masks = ws.masks if fast else None
         ctx.model, ctx.ws, ctx.dims, ctx.param_order = model, ws, (n, s_t, m, vf_h, rn_h), list(params)
+        ctx.fast = fast            # the backward must run the kernels that match what THIS forward wrote (masks, f16 slots)
         ctx.save_for_backward(normals, colors, z, ray_dirs, scal)
         return normals, colors, rgb, depth, weights
 
@@ -241,7 +242,7 @@ class _FinePass(torch.autograd.Function):
         dy = torch.empty(vf_h + rn_h, m, HID, device=dev)
         dz_rgb = torch.empty(m, 4, device=dev)
         dz_vec = torch.empty(m, 4, device=dev)
-        fast = model.uses_f16x3() and m < _F16_TRAIN_MAX_POINTS
+        fast = ctx.fast
         if fast:
             lib.mlp_bwd_chain_bf16(vf.geometry(), _packed_bwd16(vf), _head_rows(vf), rn.geometry(), _packed_bwd16(rn),
                                    _head_rows(rn), ws.saved, ws.masks, dy, dc, colors, dn, normals, None, 3, m, dz_rgb, dz_vec)
@@ -250,9 +251,9 @@ class _FinePass(torch.autograd.Function):
                               _packed_bwd(rn), ws.saved, dy, dc, colors, dn, normals, None, 3, m, dz_rgb, dz_vec)
         # (3) weight gradients
         g_vf = _weight_grads(vf, _vf_inputs(vf, [ws.saved[h] for h in range(vf_h)]), [dy[h] for h in range(vf_h)],
-                             ws.aux_vf, dz_vec, m, fast=model.uses_f16x3(), x_f16=ws.f16)
+                             ws.aux_vf, dz_vec, m, fast=fast, x_f16=ws.f16)
         g_rn = _weight_grads(rn, _rn_inputs(ws.saved[vf_h - 1], [ws.saved[vf_h + h] for h in range(rn_h)]),
-                             [dy[vf_h + h] for h in range(rn_h)], ws.aux_rn, dz_rgb, m, fast=model.uses_f16x3(), x_f16=ws.f16,
+                             [dy[vf_h + h] for h in range(rn_h)], ws.aux_rn, dz_rgb, m, fast=fast, x_f16=ws.f16,
                              x_fp32_entries=(0,))
         # density scalars in density.parameters() order
         by_name = {"beta": dscal[0], "mean": dscal[1], "scale": dscal[2]}
@@ -292,6 +293,7 @@ class _VFForward(torch.autograd.Function):
         else:
             out = lib.vf_mlp_fwd_train(net.geometry(), net.packed_weights(), pts, cols, ws.saved, ws.aux_vf)
         ctx.net, ctx.ws, ctx.dims, ctx.param_order = net, ws, (m, vf_h, cols), list(params)
+        ctx.fast = fast            # not re-derived in backward: net.precision may have changed in between (numerical Jacobian)
         ctx.save_for_backward(out)
         return out
 
@@ -307,7 +309,7 @@ class _VFForward(torch.autograd.Function):
         d_feats = None
         if cols > 3:
             d_feats = _offset_view(d_out, 3)
-        fast = getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3() and m < _F16_TRAIN_MAX_POINTS
+        fast = ctx.fast
         if fast:
             lib.mlp_bwd_chain_bf16(net.geometry(), _packed_bwd16(net), _head_rows(net), None, None, None, ws.saved, ws.masks, dy,
                                    None, None, d_out, out, d_feats, cols, m, None, dz_vec)

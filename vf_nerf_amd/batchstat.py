@@ -110,6 +110,10 @@ def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, upda
     y = torch.zeros(m, _up8(last.out_features), device=dev)
     lib.linear_rows(x, last.weight.detach(), last.bias.detach(), m, last.out_features, last.in_features, y, act=final_act)
     st.y = y
+    if batch_stats and update_running:
+        # vfn_bstat_finalize advanced running_mean / running_var through raw pointers: their _version did not move, so the
+        # folded-BatchNorm packs keyed on (data_ptr, _version) would survive into a later eval()/render() with stale statistics
+        net._invalidate_packs()
     if getattr(net, "_keep_state", False):     # test hook: expose the activations of the latest forward
         net._debug_state = st
     return st
@@ -233,13 +237,14 @@ def _backward(net, st: _State, dz_last: torch.Tensor, pg: Optional[_ParamGrads],
 # ------------------------------------------------------------------------------------------------
 # vector-field network
 # ------------------------------------------------------------------------------------------------
-def _vf_forward_state(net, pts: torch.Tensor) -> _State:
+def _vf_forward_state(net, pts: torch.Tensor, batch_stats: bool = True) -> _State:
     m = pts.shape[0]
     L_pe = net._multires()
     k0 = net._linear(0).in_features
     x0 = torch.zeros(m, _up8(k0), device=pts.device)
     lib.embed_rows(pts, m, L_pe, x0)
-    return _forward(net, x0, m, lib.ACT_TANH, fill_skip=lambda dst, scale: lib.embed_rows(pts, m, L_pe, dst, scale))
+    return _forward(net, x0, m, lib.ACT_TANH, fill_skip=lambda dst, scale: lib.embed_rows(pts, m, L_pe, dst, scale),
+                    batch_stats=batch_stats)
 
 
 def _vf_point_grads(net, st: _State, pts: torch.Tensor, dz_last: torch.Tensor, pg: Optional[_ParamGrads]) -> torch.Tensor:
@@ -270,7 +275,7 @@ class _VFTrainMode(torch.autograd.Function):
     def forward(ctx, net, points, want_jacobian, *params):
         pts = points.detach().reshape(-1, 3).float().contiguous()
         m = pts.shape[0]
-        st = _vf_forward_state(net, pts)
+        st = _vf_forward_state(net, pts, batch_stats=net.training)
         n_out = net._linear(net.num_layers - 1).out_features
         cols = [st.y[:, :n_out]]
         if want_jacobian:
@@ -310,6 +315,21 @@ def vf_forward_train_mode(net, points: torch.Tensor, want_jacobian: bool = True)
     return _VFTrainMode.apply(net, points, want_jacobian, *list(net.parameters()))
 
 
+def vf_forward_eval_rows(net, points: torch.Tensor) -> torch.Tensor:
+    """``VectorFieldNetwork.forward`` in eval mode for a geometry the fused kernels are not specialised for (hidden widths
+    other than 256, e.g. a narrow checkpoint): the same layer-at-a-time row kernels with the running statistics -> [M, 3 + F].
+    Differentiable where the weight-gradient kernels have the layer's shape (``_ParamGrads.linear``)."""
+    if not points.is_cuda:
+        raise lib.VfnError("the layer-at-a-time forward runs on the device (no CPU fallback)")
+    if net.training:
+        raise ValueError("vf_forward_eval_rows is the eval-mode path")
+    if torch.is_grad_enabled() and (points.requires_grad or any(p.requires_grad for p in net.parameters())):
+        return _VFTrainMode.apply(net, points, False, *list(net.parameters()))
+    pts = points.detach().reshape(-1, 3).float().contiguous()
+    st = _vf_forward_state(net, pts, batch_stats=False)
+    return st.y[:, :net._linear(net.num_layers - 1).out_features].contiguous()
+
+
 # ------------------------------------------------------------------------------------------------
 # rendering network
 # ------------------------------------------------------------------------------------------------
@@ -333,6 +353,8 @@ class _RenderTrainMode(torch.autograd.Function):
         x0[:, 6 + pe:6 + pe + f].copy_(feats.detach())
         st = _forward(net, x0, m, lib.ACT_SIGMOID, batch_stats=batch_stats)
         ctx.net, ctx.st, ctx.cols, ctx.param_order = net, st, (6 + pe, f), list(params)
+        # rendering_network.py:76-77: with detach_normals=False the colours' gradient also reaches the normals
+        ctx.normal_cols = (3 + pe) if (ctx.needs_input_grad[3] and not net.config.detach_normals) else None
         return st.y[:, :3].contiguous()
 
     @staticmethod
@@ -346,7 +368,8 @@ class _RenderTrainMode(torch.autograd.Function):
         dx0, _ = _backward(net, st, dz, pg, want_dx0=True)
         grads = pg.finish()
         ctx.st = None
-        return (None, None, None, None, None, dx0[:, c0:c0 + f], *[grads.get(p) for p in ctx.param_order])
+        d_normals = None if ctx.normal_cols is None else dx0[:, ctx.normal_cols:ctx.normal_cols + 3]
+        return (None, None, None, d_normals, None, dx0[:, c0:c0 + f], *[grads.get(p) for p in ctx.param_order])
 
 
 def render_forward_train_mode(net, points, normals, view_dirs, feats) -> torch.Tensor:

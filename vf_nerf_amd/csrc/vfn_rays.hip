@@ -292,6 +292,7 @@ struct DensityBwdArgs {
     const float* d_rgb;     // [N,3] may be NULL
     const float* d_depth;   // [N]   may be NULL
     const float* d_weights; // [N,S] may be NULL
+    const float* d_sigma;   // [N,S] may be NULL: an upstream gradient on sigma itself (get_density under autograd)
     float* d_normals;       // [N,S,3] accumulated into (+=)
     float* d_colors;        // [N,S,3] written (may be NULL)
     float* d_scalars;       // [3] atomically accumulated: raw beta, mean, scale
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(256) void vfn_density_bwd_kernel(const DensityBwdAr
             if (j < L && sact[j] != 0.f) {
                 const float e = se[j];
                 const float de = gh * sT[j] * expf(-e) - suffix;
-                const float dsig = sdl[j] * de;
+                const float dsig = sdl[j] * de + (a.d_sigma ? a.d_sigma[(size_t)ray * S + j] : 0.f);
                 const float x = -sc[j];
                 const float ax = x - mean;
                 const float E = expf(-fabsf(ax) / beta);
@@ -698,7 +699,86 @@ __global__ __launch_bounds__(256) void vfn_scatter_rows3_kernel(const float* a, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The samplers as stand-alone calls (RaySampler.sample / get_z_vals through the sampler objects,
+// models/samplers/ray_sampler.py:49-80,113-142): proposal depths + points for GIVEN directions / origins, and the
+// first-maximum index of every row of a weight matrix (torch.argmax's tie rule, :277).
+// ------------------------------------------------------------------------------------------------
+struct UniformSampleArgs {
+    const float* directions;   // [N,3] un-normalised (Q7)
+    const float* cam_loc;      // [N,3]
+    const float* t_vals;       // [S]
+    const float* far_per_ray;  // [N] or NULL
+    const float* u;            // [N,S] or NULL
+    float* z_vals;             // [N,S]
+    float* points;             // [N,S,3] or NULL
+    int n_rays, n_samples;
+    float near, far;
+};
+
+__global__ __launch_bounds__(256) void vfn_uniform_sample_kernel(const UniformSampleArgs a) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = a.n_samples;
+    if (idx >= (long long)a.n_rays * S) return;
+    const int r = (int)(idx / S), s = (int)(idx - (long long)r * S);
+    const float near = a.near, far = a.far_per_ray ? a.far_per_ray[r] : a.far;
+    float z = coarse_z(near, far, a.t_vals[s]);
+    if (a.u) {
+        const float zl = (s > 0) ? coarse_z(near, far, a.t_vals[s - 1]) : z;
+        const float zu = (s < S - 1) ? coarse_z(near, far, a.t_vals[s + 1]) : z;
+        const float upper = (s < S - 1) ? 0.5f * (zu + z) : z;
+        const float lower = (s > 0) ? 0.5f * (z + zl) : z;
+        z = lower + (upper - lower) * a.u[idx];
+    }
+    a.z_vals[idx] = z;
+    if (a.points) {
+        a.points[idx * 3 + 0] = a.cam_loc[(size_t)r * 3 + 0] + z * a.directions[(size_t)r * 3 + 0];
+        a.points[idx * 3 + 1] = a.cam_loc[(size_t)r * 3 + 1] + z * a.directions[(size_t)r * 3 + 1];
+        a.points[idx * 3 + 2] = a.cam_loc[(size_t)r * 3 + 2] + z * a.directions[(size_t)r * 3 + 2];
+    }
+}
+
+__global__ __launch_bounds__(256) void vfn_rows_argmax_kernel(const float* w, int n_rows, int n_cols, long long* out) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (row >= n_rows) return;
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int j = lane; j < n_cols; j += WAVE) {
+        const float v = w[(size_t)row * n_cols + j];
+        if (v > best || (v != v && best == best)) { best = v; besti = j; }   // first maximum; a NaN wins, like torch.argmax
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, WAVE);
+        const int oi = __shfl_xor(besti, o, WAVE);
+        const bool take = (ob != ob) ? (best == best || oi < besti) : (best == best && (ob > best || (ob == best && oi < besti)));
+        if (take) { best = ob; besti = oi; }
+    }
+    if (lane == 0) out[row] = (besti == 0x7fffffff) ? 0 : besti;
+}
+
 }  // namespace
+
+extern "C" int vfn_uniform_sample(int32_t n_rays, int32_t n_samples, float near, float far, const float* directions,
+                                  const float* cam_loc, const float* t_vals, const float* far_per_ray, const float* u,
+                                  float* z_vals, float* points, void* stream) {
+    if (n_rays == 0) return VFN_OK;
+    VFN_REQUIRE(n_rays > 0 && n_samples >= 1, "vfn_uniform_sample: bad sizes (n_rays=%d, n_samples=%d)", n_rays, n_samples);
+    VFN_REQUIRE(t_vals && z_vals && (!points || (directions && cam_loc)), "vfn_uniform_sample: NULL argument");
+    UniformSampleArgs a{directions, cam_loc, t_vals, far_per_ray, u, z_vals, points, n_rays, n_samples, near, far};
+    const long long total = (long long)n_rays * n_samples;
+    hipLaunchKernelGGL(vfn_uniform_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return vfn_check_launch("vfn_uniform_sample");
+}
+
+extern "C" int vfn_rows_argmax(const float* w, int32_t n_rows, int32_t n_cols, int64_t* out, void* stream) {
+    if (n_rows == 0) return VFN_OK;
+    VFN_REQUIRE(w && out && n_rows > 0 && n_cols >= 1, "vfn_rows_argmax: bad argument");
+    hipLaunchKernelGGL(vfn_rows_argmax_kernel, dim3((unsigned)((n_rows + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK)), dim3(256), 0,
+                       (hipStream_t)stream, w, (int)n_rows, (int)n_cols, (long long*)out);
+    return vfn_check_launch("vfn_rows_argmax");
+}
 
 extern "C" int vfn_raygen_uniform(const vfn_raygen_params* p, const float* uv, const float* pose, const float* intrinsics,
                                   const float* t_vals, const float* far_per_ray, const float* u_coarse, float* directions,
@@ -788,11 +868,25 @@ extern "C" int vfn_ray_density_weights_bwd(const vfn_density_params* p, const fl
                 "vfn_ray_density_weights_bwd: n_samples=%d outside [2,%d]", p->n_samples, MAX_SAMPLES_BWD);
     VFN_REQUIRE(!(d_rgb && !colors), "vfn_ray_density_weights_bwd: d_rgb given without colors");
     if (p->n_rays <= 0) return VFN_OK;
-    DensityBwdArgs a{*p, normals, ray_dirs, z_vals, density_scalars, colors, d_rgb, d_depth, d_weights, d_normals, d_colors, d_scalars};
+    DensityBwdArgs a{*p, normals, ray_dirs, z_vals, density_scalars, colors, d_rgb, d_depth, d_weights, nullptr, d_normals, d_colors, d_scalars};
     const unsigned blocks = (unsigned)((p->n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
     const size_t shmem = (size_t)RAYS_PER_BLOCK * p->n_samples * 12 * sizeof(float);
     hipLaunchKernelGGL(vfn_density_bwd_kernel, dim3(blocks), dim3(256), shmem, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_ray_density_weights_bwd");
+}
+
+extern "C" int vfn_ray_density_sigma_bwd(const vfn_density_params* p, const float* normals, const float* ray_dirs,
+                                         const float* z_vals, const float* density_scalars, const float* d_sigma,
+                                         float* d_normals, float* d_scalars, void* stream) {
+    if (p && p->n_rays <= 0) return VFN_OK;
+    VFN_REQUIRE(p && normals && ray_dirs && z_vals && density_scalars && d_sigma && d_normals, "vfn_ray_density_sigma_bwd: NULL argument");
+    VFN_REQUIRE(p->n_samples >= 2 && p->n_samples <= MAX_SAMPLES_BWD,
+                "vfn_ray_density_sigma_bwd: n_samples=%d outside [2,%d]", p->n_samples, MAX_SAMPLES_BWD);
+    DensityBwdArgs a{*p, normals, ray_dirs, z_vals, density_scalars, nullptr, nullptr, nullptr, nullptr, d_sigma, d_normals, nullptr, d_scalars};
+    const unsigned blocks = (unsigned)((p->n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
+    const size_t shmem = (size_t)RAYS_PER_BLOCK * p->n_samples * 12 * sizeof(float);
+    hipLaunchKernelGGL(vfn_density_bwd_kernel, dim3(blocks), dim3(256), shmem, (hipStream_t)stream, a);
+    return vfn_check_launch("vfn_ray_density_sigma_bwd");
 }
 
 extern "C" int vfn_sample_sphere_shell(int64_t n, float r_min, float r_max, const float* centroid, int32_t inward, const float* u,

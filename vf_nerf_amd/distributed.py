@@ -39,6 +39,16 @@ def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def seed_rank_streams(model, rank: int, base_seed: int = 0) -> None:
+    """Give this rank its own device random streams: the sampler's Philox stream (``model.rng_seed``) and the supervision
+    sampler's (``supervision.manual_seed``).  With the defaults every rank would draw the same jitter and the same supervision
+    points for its shard of the batch — correct, but the shards' draws would be copies of one another."""
+    from . import supervision
+    model.rng_seed = (int(base_seed) << 16) + int(rank)
+    model._rng_offset = 0
+    supervision.manual_seed(0x5eed + 7919 * (int(rank) + 1) + int(base_seed))
+
+
 def shard_rays(pose: torch.Tensor, pixels: torch.Tensor, intrinsics: torch.Tensor, rank: int, world: int):
     lo, hi = shard_bounds(pixels.shape[0], rank, world)
     return pose[lo:hi], pixels[lo:hi], intrinsics[lo:hi]

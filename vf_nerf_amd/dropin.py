@@ -70,4 +70,45 @@ def install() -> None:
         pass
 
 
+    _patch_clip_grad_norm()
+
+
+_torch_clip = None
+
+
+def _patch_clip_grad_norm() -> None:
+    """The trainer calls ``torch.nn.utils.clip_grad_norm_(self.model.parameters(), clip_norm)``
+    (train/vector_field_nerf_train.py:254-255) on a list that names every VF parameter twice (Q4).  The sequential loop the
+    reference was written against clips such a gradient twice; PyTorch's multi-tensor implementation, which newer versions
+    pick on GPUs, scales duplicated tensors concurrently.  So that the trainer stays UNCHANGED, the function is wrapped: a
+    list of device parameters with duplicates goes to ``optim.clip_grad_norm_`` (same semantics as the sequential loop,
+    multi-tensor kernels over distinct tensors per pass); every other call reaches PyTorch's own function untouched."""
+    global _torch_clip
+    import torch
+    from . import optim
+    if _torch_clip is not None:
+        return
+    _torch_clip = torch.nn.utils.clip_grad_norm_
+
+    def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=False, foreach=None):
+        plist = [parameters] if isinstance(parameters, torch.Tensor) else list(parameters)
+        ids = [id(p) for p in plist]
+        if len(set(ids)) != len(ids) and float(norm_type) == 2.0 and not error_if_nonfinite and \
+                all(p.is_cuda for p in plist if p.grad is not None):
+            return optim.clip_grad_norm_(plist, max_norm, 2.0)
+        return _torch_clip(plist, max_norm, norm_type, error_if_nonfinite, foreach)
+
+    clip_grad_norm_.__wrapped__ = _torch_clip
+    torch.nn.utils.clip_grad_norm_ = clip_grad_norm_
+
+
+def uninstall_clip_grad_norm() -> None:
+    """Put PyTorch's own clip_grad_norm_ back (tests)."""
+    global _torch_clip
+    import torch
+    if _torch_clip is not None:
+        torch.nn.utils.clip_grad_norm_ = _torch_clip
+        _torch_clip = None
+
+
 install()

@@ -30,7 +30,8 @@ EXPORTS = (
     "vfn_grid_unify_direction", "vfn_grid_comb_format", "vfn_weight_grad_partials_bf16", "vfn_unfold_weight_grads", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
     "vfn_linear_rows", "vfn_linear_rows_stat_parts", "vfn_bstat_row_parts", "vfn_colsum_finish", "vfn_bstat_finalize",
     "vfn_bstat_relu_rows", "vfn_bstat_relu_bwd_sums", "vfn_bstat_relu_bwd_rows", "vfn_act_bwd_rows", "vfn_embed_rows",
-    "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_scatter_rows3",
+    "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax",
+    "vfn_ray_density_sigma_bwd",
 )
 
 
@@ -188,6 +189,38 @@ def raygen_uniform(uv, pose, intrinsics, t_vals, n_samples, near, far, far_per_r
                                      _ptr(ray_dirs, "ray_dirs"), _ptr(cam_loc, "cam_loc"), _ptr(z, "z"),
                                      _ptr(pts, "points"), _stream()), "vfn_raygen_uniform")
     return directions, ray_dirs, cam_loc, z, pts
+
+
+def uniform_sample(directions, cam_loc, t_vals, n_samples: int, near: float, far: float, far_per_ray=None, u=None,
+                   want_points: bool = True):
+    """UniformSampler.get_z_vals / RaySampler.sample on given directions[N,3] / cam_loc[N,3] -> (z[N,S], points[N,S,3] | None)."""
+    n = directions.shape[0]
+    dev = directions.device
+    z = torch.empty(n, n_samples, device=dev)
+    pts = torch.empty(n, n_samples, 3, device=dev) if want_points else None
+    _check(load().vfn_uniform_sample(C.c_int32(n), C.c_int32(n_samples), C.c_float(near), C.c_float(far),
+                                     _ptr(directions, "directions"), _ptr(cam_loc, "cam_loc"), _ptr(t_vals, "t_vals"),
+                                     _ptr(far_per_ray, "far_per_ray"), _ptr(u, "u"), _ptr(z, "z_vals"), _ptr(pts, "points"),
+                                     _stream()), "vfn_uniform_sample")
+    return z, pts
+
+
+def rows_argmax(w: torch.Tensor) -> torch.Tensor:
+    """First-maximum index of every row (torch.argmax(w, dim=-1) semantics) -> int64 [rows]."""
+    rows, cols = w.shape
+    out = torch.empty(rows, dtype=torch.int64, device=w.device)
+    _check(load().vfn_rows_argmax(_ptr(w, "w"), C.c_int32(rows), C.c_int32(cols), _ptr(out, "out", torch.int64), _stream()),
+           "vfn_rows_argmax")
+    return out
+
+
+def ray_density_sigma_bwd(dp: DensityParams, normals, ray_dirs, z_vals, scalars, d_sigma, d_normals, d_scalars) -> None:
+    n, s = z_vals.shape
+    dp.n_rays, dp.n_samples = n, s
+    _check(load().vfn_ray_density_sigma_bwd(C.byref(dp), _ptr(normals, "normals"), _ptr(ray_dirs, "ray_dirs"),
+                                            _ptr(z_vals, "z_vals"), _ptr(scalars, "scalars"), _ptr(d_sigma, "d_sigma"),
+                                            _ptr(d_normals, "d_normals"), _ptr(d_scalars, "d_scalars"), _stream()),
+           "vfn_ray_density_sigma_bwd")
 
 
 def vf_mlp_fwd(geom: NetGeom, packed, points, out_cols: int):

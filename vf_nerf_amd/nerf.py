@@ -67,6 +67,31 @@ class _EventScope:
         return False
 
 
+class _DensityOnly(torch.autograd.Function):
+    """sigma = get_density(normals, ray_dirs) with gradients to the normals and to beta / mean / scale."""
+
+    @staticmethod
+    def forward(ctx, model, normals, rd, *density_params):
+        n, s, _ = normals.shape
+        nrm = normals.detach().float().contiguous()
+        z = torch.zeros(n, s, device=nrm.device)
+        scal = model.density.raw_scalars()
+        sigma, _, _, _, _ = lib.ray_density_weights(model._density_params(), nrm, rd, z, scal, want_weights=False)
+        ctx.model = model
+        ctx.save_for_backward(nrm, rd, z, scal)
+        return sigma
+
+    @staticmethod
+    def backward(ctx, d_sigma):
+        nrm, rd, z, scal = ctx.saved_tensors
+        dn = torch.zeros_like(nrm)
+        dscal = torch.zeros(3, device=nrm.device)
+        lib.ray_density_sigma_bwd(ctx.model._density_params(), nrm, rd, z, scal, d_sigma.float().contiguous(), dn, dscal)
+        by_name = {"beta": dscal[0], "mean": dscal[1], "scale": dscal[2]}
+        dens = [by_name[name].reshape(p.shape) for name, p in ctx.model.density.named_parameters()]
+        return (None, dn, None, *dens)
+
+
 class VectorFieldNerf:
     def __init__(self, config) -> None:
         self.config = config
@@ -307,7 +332,13 @@ class VectorFieldNerf:
                                       "reference (Q11); only 'volsdf' is implemented")
         if not cfg.ray_sampler_config.fine_sampling():
             raise ValueError("render() needs n_importance > 0 (the reference raises NameError without it, Q1)")
-        if self.vector_field_network.training or self.rendering_network._batch_statistics():
+        if self.vector_field_network.training or self.rendering_network._batch_statistics() or not \
+                (self.vector_field_network.supports_fused() and self.rendering_network.supports_fused()) or \
+                (self._needs_grad() and not self.rendering_network.config.detach_normals):
+            # networks in training mode, a geometry the fused kernels are not specialised for, or gradients wanted with
+            # detach_normals=False (rendering_network.py:76-77: the colours' gradient then reaches the normals, which the fused
+            # dX chain — written for the shipped detach_normals=True — does not propagate): the networks are called one after
+            # the other, as the reference does
             return self._render_training_mode(pose, pixels, intrinsics, epoch, white, uniforms)
         from .autograd import fine_pass  # differentiable or plain, depending on torch.is_grad_enabled()
 
@@ -422,6 +453,10 @@ class VectorFieldNerf:
         shared_k = intrinsics.dim() == 2 or intrinsics.shape[0] == 1
         cur = torch.cuda.current_stream(dev)
         streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, n_streams))]
+        # Everything render() builds lazily and caches (weight packs, the density scalars' stack, the linspace table) is built
+        # HERE, on the current stream, before the side streams fork from it: a cache filled by chunk 0 on stream 0 would be
+        # read by chunk 1 on stream 1 with no dependency between the two.
+        self._warm_caches(dev)
         for st in streams:
             st.wait_stream(cur)
         for i, lo in enumerate(range(0, n, chunk)):
@@ -434,6 +469,20 @@ class VectorFieldNerf:
         for st in streams:
             cur.wait_stream(st)
         return rgb, depth
+
+    def _warm_caches(self, dev) -> None:
+        """Build, on the current stream, every lazily cached device object a gradient-free render() reads."""
+        vf, rn = self.vector_field_network, self.rendering_network
+        if vf.supports_fused() and rn.supports_fused():
+            if self.uses_f16x3():
+                vf.packed16_weights()
+                rn.packed16_weights()
+            else:
+                vf.packed_weights()
+                rn.packed_weights()
+            if self.config.numerical_jacobian:
+                vf.packed_weights()
+        self._linspace(self.ray_sampler.N_samples, dev)
 
     def _render_training_mode(self, pose, pixels, intrinsics, epoch: int, white: bool, uniforms) -> NerfOutput:
         """render() with a network in training mode (after ``train()``, vector_field_nerf.py:139-150): BatchNorm normalises
@@ -536,9 +585,13 @@ class VectorFieldNerf:
     # secondary entry points (vector_field_nerf.py:341-474)
     # ---------------------------------------------------------------------------------------------
     def get_density(self, normals: torch.Tensor, ray_dirs: torch.Tensor, fine: bool = False) -> torch.Tensor:
-        """normals[N,S,3], ray_dirs[N*S,3] (repeated per sample, as the reference passes them) -> sigma[N,S]."""
+        """normals[N,S,3], ray_dirs[N*S,3] (repeated per sample, as the reference passes them) -> sigma[N,S]
+        (vector_field_nerf.py:442-474).  Part of the graph like the reference's: under autograd the gradient reaches the
+        normals and the three density scalars (``vfn_ray_density_sigma_bwd``)."""
         n, s, _ = normals.shape
         rd = ray_dirs.reshape(n, s, 3)[:, 0, :].contiguous()
+        if torch.is_grad_enabled() and (normals.requires_grad or any(p.requires_grad for p in self.density.parameters())):
+            return _DensityOnly.apply(self, normals, rd, *list(self.density.parameters()))
         z = torch.zeros(n, s, device=normals.device)
         sigma, _, _, _, _ = lib.ray_density_weights(self._density_params(), normals.detach().float().contiguous(), rd,
                                                     z, self.density.raw_scalars(), want_weights=False)

@@ -71,13 +71,21 @@ class _PackedMLP(nn.Module):
                 [self._bn(i) is not None for i in range(self.num_layers)])
         return self._geom
 
+    def _invalidate_packs(self) -> None:
+        """Drop every pack built from the parameters / running statistics (they are re-built on next use).  Needed where a
+        kernel wrote one of those tensors through its raw pointer, which does not advance ``tensor._version``."""
+        for name in ("_packed16_cache", "_packed_bwd_cache", "_packed_bwd16_cache"):
+            if hasattr(self, name):
+                delattr(self, name)
+        self._packed_key = None
+
     def _apply(self, fn, *args, **kwargs):
         """.to() / .cuda() / .float() replace buffer tensors: drop the cached tensor list and the packs built from it."""
         out = super()._apply(fn, *args, **kwargs)
-        for name in ("_pack_tensors", "_packed16_cache", "_packed_bwd_cache", "_packed_bwd16_cache"):
-            if hasattr(self, name):
-                delattr(self, name)
-        self._packed, self._packed_key = None, None
+        if hasattr(self, "_pack_tensors"):
+            delattr(self, "_pack_tensors")
+        self._invalidate_packs()
+        self._packed = None
         return out
 
     def _pack_key(self):
@@ -128,6 +136,20 @@ class _PackedMLP(nn.Module):
             except lib.VfnError:
                 ok = False
             self._f16x3_ok = ok
+        return ok
+
+    def supports_fused(self) -> bool:
+        """True when the fused kernels (fp32 or f16x3) are specialised for this geometry: hidden width 256 everywhere
+        (include/vfn.h).  Other geometries — e.g. a narrow checkpoint — run layer by layer on the generic row kernels of
+        ``csrc/vfn_bstat.hip`` with eval-mode BatchNorm (``batchstat.py``); still HIP, never a CPU path."""
+        ok = getattr(self, "_fused_ok", None)
+        if ok is None:
+            try:
+                lib.packed_size(self._kind, self.geometry())
+                ok = True
+            except lib.VfnError:
+                ok = False
+            self._fused_ok = ok
         return ok
 
     def _batch_statistics(self) -> bool:

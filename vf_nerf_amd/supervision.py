@@ -18,6 +18,7 @@ from . import lib
 
 _seed = 0x5eed
 _offset = 0
+_replay = []          # explicit unit uniforms [n,3] consumed by the next sampler calls instead of the Philox stream
 
 
 def manual_seed(seed: int) -> None:
@@ -26,9 +27,21 @@ def manual_seed(seed: int) -> None:
     _seed, _offset = int(seed), 0
 
 
+def replay_uniforms(*draws: torch.Tensor) -> None:
+    """Queue explicit uniforms (each [n,3]: azimuth, cos(polar angle), radius draw, all in [0,1)) for the next sampler calls,
+    in call order — replaying a host run of the reference's numpy sampler (models/samplers/sampler.py:176-183) through the
+    device kernel.  An empty queue means the Philox stream."""
+    _replay.extend(draws)
+
+
 def _shell(r_min: float, r_max: float, num_samples: int, centroid: torch.Tensor, device, inward: bool):
     global _offset
     c = torch.as_tensor(centroid, dtype=torch.float32, device=device).reshape(3).contiguous()
+    if _replay:
+        u = _replay.pop(0)
+        if tuple(u.shape) != (int(num_samples), 3):
+            raise ValueError(f"replayed uniforms have shape {tuple(u.shape)}, the sampler needs {(int(num_samples), 3)}")
+        return lib.sample_sphere_shell(int(num_samples), float(r_min), float(r_max), c, inward, u=u.to(c.device).float().contiguous())
     pts, gt = lib.sample_sphere_shell(int(num_samples), float(r_min), float(r_max), c, inward, _seed, _offset)
     _offset += int(num_samples)
     return pts, gt
