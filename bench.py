@@ -233,9 +233,30 @@ def grid_bench(args, dev, rank, world, dist, sync):
         dist.destroy_process_group()
 
 
-def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync):
+def train_step_accounting(n_rays, s_c, s_t, n_sup, storage, gradients="fp32"):
+    """ALGORITHMIC work and workspace traffic of one training step (DESIGN.md section 3 "Backward").
+    FLOPs: the proposal pass (VF, S_c samples) + the fine pass forward and twice that for its backward (VF + rendering,
+    S_t samples) + forward and backward of the 2 x n_sup supervision points through the VF net.
+    Bytes: what the kernels of the 16-bit path have to move through HBM per step — the saved activations (13 slots per fine
+    point, 9 per supervision point; 1 KiB per slot and point as fp32, 512 B as f16 except the tanh'ed feature slot), their
+    sign-bit words (32 B), the pre-activation gradients dY (1 KiB per slot and point, written by the chain, read by the
+    weight-gradient kernels), the saved activations read once by the weight-gradient kernels, and the per-sample inputs and
+    outputs (point, normal, colour, their gradients)."""
+    m_f, m_s = n_rays * s_t, 2 * n_sup
+    flops = 2.0 * (n_rays * s_c * VF_MACS + 3.0 * m_f * (VF_MACS + RN_MACS) + 3.0 * m_s * VF_MACS)
+    relu_slot = 512 if storage == "f16" else 1024
+    saved = m_f * (12 * relu_slot + 1024) + m_s * (8 * relu_slot + 1024)      # written by the forward ...
+    masks = 32 * (13 * m_f + 9 * m_s)
+    dy = (512 if gradients == "bf16" else 1024) * (13 * m_f + 9 * m_s)
+    small = (12 + 12 + 12 + 4 + 12 + 12) * m_f + 2 * 160 * (m_f + m_s)        # points, normals, colours, z + grads, aux tiles
+    total = 2 * saved + 2 * masks + 2 * dy + small                             # ... and read back once; dY written + read
+    return flops, total
+
+
+def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=True):
     """One step = what the reference trainer does per batch, with synthetic targets (config 3 of BASELINE.json)."""
     from vf_nerf_amd import distributed as vdist, optim as voptim, supervision
+    supervision.manual_seed(0x5eed + 7919 * (rank + 1))     # every rank draws its own supervision points
     centroid = torch.tensor([0.0, 0.0, 0.6], device=dev)
     s_t = args.coarse + args.fine
     g = torch.Generator().manual_seed(7 + rank)
@@ -280,21 +301,37 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync):
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    flops, ws_bytes = train_step_accounting(args.rays, args.coarse, s_t, n_sup, model.activation_storage, model.gradient_storage)
+    ms = elapsed / args.steps * 1e3
+    rec = {"metric": "training rays/sec (4096-ray batch, 128 samples/ray, fwd+bwd+clip+Adam)",
+           "value": round(args.rays * args.steps * world / elapsed, 1), "unit": "rays/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16x3 fwd + bf16x3 bwd, f32 accumulate",
+           "data": "synthetic", "final_loss": round(float(loss), 5),
+           "activation_storage": model.activation_storage, "gradient_storage": model.gradient_storage,
+           "workspace_layout": model.workspace_layout,
+           "networks": "training mode (batch-statistics BatchNorm, layer-at-a-time fp32 kernels)"
+           if model.vector_field_network.training else "eval mode (the shipped regime, fused kernels)",
+           # per GPU: algorithmic FLOPs of a step / its duration against the f16 / 3 matrix ceiling, and the workspace bytes the
+           # step has to move against the HBM peak (it sits between the two roofs)
+           "algorithmic_tflop_per_step": round(flops / 1e12, 4),
+           "achieved_tflops": round(flops / (ms * 1e-3) / 1e12, 1),
+           "frac_of_f16_mfma_div3": round(flops / (ms * 1e-3) / 1e12 / (PEAK_F16_MFMA / 3.0), 4),
+           "workspace_gb_per_step": round(ws_bytes / 1e9, 2),
+           "workspace_tb_per_s": round(ws_bytes / (ms * 1e-3) / 1e12, 3),
+           "frac_of_hbm_peak": round(ws_bytes / (ms * 1e-3) / 8e12, 4),
+           "config": {"workload": f"train step: render({args.rays} rays x {s_t}) + 2x{n_sup} supervision "
+                                  f"points through the VF net + L1/depth/unit-norm/supervision loss + "
+                                  f"backward + clip_grad_norm_ + Adam (sequential semantics over the duplicated parameter list)"
+                                  + (", gradients all-reduced over one flat bucket" if bucket is not None else "")}}
+    if not emit:
+        return rec
     if rank == 0:
-        print(json.dumps({"metric": "training rays/sec (4096-ray batch, 128 samples/ray, fwd+bwd+clip+Adam)",
-                          "value": round(args.rays * args.steps * world / elapsed, 1), "unit": "rays/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-                          "data": "synthetic", "final_loss": round(float(loss), 5),
-                          "activation_storage": model.activation_storage,
-                          "networks": "training mode (batch-statistics BatchNorm, layer-at-a-time fp32 kernels)"
-                          if model.vector_field_network.training else "eval mode (the shipped regime, fused kernels)",
-                          "config": {"workload": f"train step: render({args.rays} rays x {s_t}) + 2x{n_sup} supervision "
-                                                 f"points through the VF net + L1/depth/unit-norm/supervision loss + "
-                                                 f"backward + clip_grad_norm_ + Adam (sequential semantics over the duplicated parameter list)"}}), flush=True)
+        print(json.dumps(rec), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return rec
 
 
 def main() -> None:
@@ -306,9 +343,16 @@ def main() -> None:
     ap.add_argument("--coarse", type=int, default=64)
     ap.add_argument("--fine", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--activations", choices=("fp32", "f16"), default="fp32",
-                    help="train workload: storage of the hidden activations for the weight-gradient kernels (f16 = opt-in, "
-                         "11-bit operands, half the workspace traffic; default fp32 = fp32-equivalent gradients)")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step sub-object of the default line")
+    ap.add_argument("--train-steps", type=int, default=8, help="optimizer steps timed for the training sub-object")
+    ap.add_argument("--activations", choices=("fp32", "f16"), default="f16",
+                    help="training: storage of the hidden activations for the weight-gradient kernels (f16 = the default, "
+                         "11-bit operands in one factor of dW, half the workspace traffic; fp32 = fp32-equivalent gradients)")
+    ap.add_argument("--gradients", choices=("fp32", "bf16"), default=None,
+                    help="training: storage of the pre-activation gradients between the dX chain and the weight-gradient kernels "
+                         "(default: the model's)")
+    ap.add_argument("--layout", choices=("fragment", "rows"), default=None,
+                    help="training: workspace layout of the 16-bit path (default: the model's, fragment order)")
     ap.add_argument("--batch-statistics", action="store_true",
                     help="train workload with the networks in training mode (model.train(): batch-statistics BatchNorm, "
                          "Jacobian columns, directional derivatives) instead of the shipped eval-mode regime (SURVEY Q8)")
@@ -380,6 +424,10 @@ def main() -> None:
 
     if args.workload == "train":
         model.activation_storage = args.activations
+        if args.gradients:
+            model.gradient_storage = args.gradients
+        if args.layout:
+            model.workspace_layout = args.layout
         if args.batch_statistics:
             model.train()
         train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync)
@@ -464,6 +512,26 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["parity_vs_oracle"] = cpu_baseline(model, uv, pose, K, s_c, n_f)
+    # BASELINE.json configs[2] beside the headline line (outside its timed region): a few optimizer steps on the same batch
+    # size, every rank, gradients all-reduced when there is more than one
+    train_rec = None
+    if not args.no_train:
+        targs = argparse.Namespace(**vars(args))
+        targs.steps, targs.warmup = args.train_steps, 2
+        tmodel, tuv, tpose, tK = build_scene(dev, args.rays, s_c, n_f, seed=rank)
+        tmodel.precision = args.precision
+        tmodel.activation_storage = args.activations
+        if args.gradients:
+            tmodel.gradient_storage = args.gradients
+        if args.layout:
+            tmodel.workspace_layout = args.layout
+        train_rec = train_bench(targs, tmodel, tuv, tpose, tK, dev, dist, rank, world, sync, emit=False)
+    if rank == 0:
+        if train_rec is not None:
+            line["train"] = {k: train_rec[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "activation_storage", "gradient_storage", "workspace_layout",
+                                                       "algorithmic_tflop_per_step", "achieved_tflops", "frac_of_f16_mfma_div3",
+                                                       "workspace_gb_per_step", "workspace_tb_per_s", "frac_of_hbm_peak", "final_loss")}
+            line["train"]["workload"] = train_rec["config"]["workload"]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -282,6 +282,17 @@ int vfn_vf_render_fused16_fwd(const vfn_net_geom* vf_geom, const void* vf_packed
                               const void* rn_packed16, const float* points, const float* ray_dirs,
                               int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
                               void* stream);
+
+/* Range guard of the f16x3 kernels.  The split representation covers |activation| < ~937 (the ReLU epilogue clamps the 2^6-scaled
+ * value at 60 000 so that an out-of-family value degrades instead of becoming inf - inf), |input coordinate| likewise, and
+ * folded weights whose largest entry per layer is neither in the f16 denormal range nor beyond 65 504.  The reference has no
+ * such restriction (vector_field_network.py:177-208), so the kernels REPORT when they leave it:
+ *  - vfn_f16x3_set_status(word): every later f16x3 launch of the calling thread ORs into *word (device memory, 4 bytes) bit 0
+ *    when a hidden activation hit the clamp and bit 1 when an input did; NULL switches the reporting off.  Thread-local.
+ *  - vfn_pack16_weights writes, behind the pack (the last 256 bytes of the vfn_pack16_size buffer), one word per pack entry
+ *    (hidden layers in plan order, then the 3-channel head): the bit pattern of max |folded weight| of that entry.
+ * The facade reads both and repeats a flagged call on the exact-fp32 kernels (vf_nerf_amd/nerf.py, f16x3_guard). */
+int vfn_f16x3_set_status(uint32_t* status_word);
 /* vfn_weight_grad_partials(shape 0, ld 256, all 256 columns valid) on the bf16 matrix cores: operands split into two
  * bf16 halves (16 significant bits, fp32 exponent range), three products per K-block, fp32 accumulation; same outputs
  * (`groups` slabs [groups][256][256] and [groups][256]).  ~2^-16 relative error per product under the sum over points. */
@@ -304,6 +315,31 @@ int vfn_mlp_bwd_chain_bf16(const vfn_net_geom* vf_geom, const void* vf_packed_bw
                            const float* saved, const uint32_t* masks, float* dy, const float* d_colors, const float* colors,
                            const float* d_vec, const float* vec, const float* d_feats, int32_t vec_stride,
                            int64_t n_points, float* dz_rgb, float* dz_vec, void* stream);
+
+/* The same chain for the FRAGMENT-ORDERED workspace (below): `feats` = the tanh'ed features [M][256] row-major fp32 (the one
+ * slot the chain reads as values), `dy` = the gradient slots it writes, dy_flags bit 1: fragment order, bit 2 (with bit 1):
+ * as bf16.  dy_flags = 0 and feats = slot 8 of saved[13][M][256] is vfn_mlp_bwd_chain_bf16.  n_points < 2^21 in fragment
+ * order. */
+int vfn_mlp_bwd_chain_bf16_ws(const vfn_net_geom* vf_geom, const void* vf_packed_bwd16, const float* vf_head_w,
+                              const vfn_net_geom* rn_geom, const void* rn_packed_bwd16, const float* rn_head_w,
+                              const float* feats, const uint32_t* masks, void* dy, int32_t dy_flags, const float* d_colors,
+                              const float* colors, const float* d_vec, const float* vec, const float* d_feats,
+                              int32_t vec_stride, int64_t n_points, float* dz_rgb, float* dz_vec, void* stream);
+
+/* FRAGMENT-ORDERED training workspace.  A slot (one layer's saved activations, or its pre-activation gradients) is stored as
+ * the producing waves hold it: groups of 32 points (one wave), 32 KiB per group, inside a group piece (t, q) = registers
+ * 4q..4q+3 of output tile t at byte (4 t + q) * 1024 (512 in 16-bit forms), inside a piece lane L = 32 g + i at L * 16 (8)
+ * bytes holding columns 32 t + 8 q + 4 g .. + 3 of point 32 G + i.  Every store of the f16x3 training forward / the bf16
+ * chain and every load of the weight-gradient kernel is then 1 KiB (512 B) of consecutive bytes; row-major slots made each
+ * store touch 32 lines with 32 (16) bytes.  Slot stride = ceil(M / 32) * 32 KiB whatever the element size.
+ * vfn_weight_grad_frag: the weight-gradient partial slabs of vfn_weight_grad_partials (same `groups` slabs, same shapes
+ * 0: [256][256], 1: [256][64], 2: [32][256], db_part [groups][256 | 256 | 32]) from such slots, split-bf16 products on
+ * v_mfma_f32_32x32x16_bf16:
+ *   dy_form 0 fragment fp32 | 1 fragment bf16 (no low half: two products per K-block) | 2 dz[M][4] fp32 rows (shape 2 only)
+ *   x_form  0 fragment fp32 | 1 fragment f16 | 2 [M][256] fp32 rows (the features) | 3 the encoding tile aux[M][40] (shape 1 only)
+ * Points past M in the last group count as zero. */
+int vfn_weight_grad_frag(int32_t shape, const void* dy, int32_t dy_form, const void* x, int32_t x_form, int64_t n_points,
+                         int32_t groups, float* dw_part, float* db_part, void* stream);
 
 /* Split inference launches.  The reference evaluates the vector-field net on every proposal sample twice (no-grad pass
  * vector_field_nerf.py:252-277, then again among the S_c+N_f samples at :294-297); the two entry points below let a caller
@@ -363,10 +399,11 @@ int vfn_sample_sphere_shell(int64_t n, float r_min, float r_max, const float* ce
  * exactly like vfn_vf_mlp_fwd_train / vfn_vf_render_fused_fwd_train.  with_features = 0 evaluates only the vector head
  * (the feature slot is not written); with_features = 1 also writes the 256 tanh'ed features into their slot, from which
  * the caller assembles [M, 3+F].  n_points < 2^22 per launch.
- * save_masks: the sign bits of every saved ReLU output (see vfn_mlp_bwd_chain_bf16).  save_f16 != 0 (opt-in): the ReLU slots
+ * save_masks: the sign bits of every saved ReLU output (see vfn_mlp_bwd_chain_bf16).  save_f16 = flags.  Bit 0: the ReLU slots
  * are stored as f16 — 256 values in the first 512 bytes of every 1 KiB row, the row stride does not change — which halves
  * what the forward writes and the weight-gradient kernels read, at 11 instead of 24 significant bits in the activations that
- * multiply dY (BASELINE.json configs[2] trains on bf16 matrix cores); the tanh'ed feature slot (8) stays fp32. */
+ * multiply dY (BASELINE.json configs[2] trains on bf16 matrix cores); the tanh'ed feature slot (8) stays fp32 row-major.
+ * Bit 1: the ReLU slots are FRAGMENT-ORDERED (see vfn_weight_grad_frag; slot stride ceil(M/32) * 32 KiB, n_points < 2^21). */
 int vfn_vf_mlp16_fwd_train(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
                            int32_t with_features, float* out_vec, float* saved, float* save_aux_vf, uint32_t* save_masks,
                            int32_t save_f16, void* stream);
@@ -395,6 +432,24 @@ int vfn_grid_unify_direction(const float* divergence, const float* vt, int32_t n
  * pair_norms[n^3,28,2] = (norms at corner a, norms at corner b), corners outside the grid read as 0. */
 int vfn_grid_comb_format(const int64_t* choice, const float* norms, int32_t n, float* different_side, float* pair_norms,
                          void* stream);
+
+/* =============================================================================================
+ * Optimizer side of a training step over ONE flat fp32 buffer (train/vector_field_nerf_train.py:254-260:
+ * torch.nn.utils.clip_grad_norm_(model.parameters(), clip); optimizer.step()).  The unique parameters — and their gradients
+ * and Adam moments — are laid out contiguously, sorted into up to four REGIONS [start, end) of equal multiplicity `mult` =
+ * how often the parameter occurs in the optimizer's list (the reference lists every vector-field parameter twice,
+ * models/nerf/vector_field_nerf.py:57-63): a gradient counts mult times in the norm, is scaled mult times, and its parameter
+ * receives mult consecutive Adam updates per step, exactly what the sequential per-entry loops do.
+ * vfn_flat_clip_grad_norm: out2[0] = total 2-norm, out2[1] = min(max_norm / (norm + 1e-6), 1); gradients scaled in place.
+ *   workspace: vfn_flat_clip_workspace_bytes() bytes of device memory, zero-filled once by the caller.
+ * vfn_flat_adam_step: step_size[2 r + k] = lr / (1 - beta1^t), bc2_sqrt[2 r + k] = sqrt(1 - beta2^t) for update k (t = the step
+ *   number of that update) of region r, evaluated by the caller in double precision as torch.optim.Adam does. */
+int64_t vfn_flat_clip_workspace_bytes(void);
+int vfn_flat_clip_grad_norm(float* flat_grad, int64_t n, int32_t n_regions, const int64_t* starts, const int64_t* ends,
+                            const int32_t* mults, float max_norm, void* workspace, float* out2, void* stream);
+int vfn_flat_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t n_regions,
+                       const int64_t* starts, const int64_t* ends, const int32_t* mults, const double* step_size,
+                       const double* bc2_sqrt, double beta1, double beta2, double eps, double weight_decay, void* stream);
 
 /* =============================================================================================
  * Networks in TRAINING mode: nn.BatchNorm1d with batch statistics (vector_field_network.py:146-208 and

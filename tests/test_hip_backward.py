@@ -27,17 +27,22 @@ def _hip_gradients(fx, d, model):
     return float(loss), out
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "fp32", "f16x3+f16act"])
+@pytest.mark.parametrize("precision", ["f16x3", "fp32", "f16x3+f16act", "f16x3+f16act+bf16dy", "f16x3+rows", "f16x3+f16act+rows"])
 @pytest.mark.parametrize("name", FIXTURE_NAMES)
 def test_render_gradients(name, precision):
     """``precision`` selects the arithmetic of the activation-saving forward (split-half f16 products or exact fp32
-    MFMA); "+f16act" additionally stores the hidden activations as f16 for the weight-gradient kernels (opt-in,
-    ``model.activation_storage``): the same 1e-3 bound must hold, the observed error is printed."""
+    MFMA); "+f16act" stores the hidden activations as f16 for the weight-gradient kernels (``model.activation_storage``, the
+    default), "+bf16dy" the pre-activation gradients as bf16 (``model.gradient_storage``), "+rows" keeps the row-major
+    workspace and its kernels instead of the fragment-ordered one (``model.workspace_layout``): the same 1e-3 bound must hold
+    for all of them, the observed error is printed."""
     fx, d = load_fixture(name)
     model = build_model(fx, d, device="cuda:0")
-    f16act = precision.endswith("+f16act")
-    model.precision = precision.split("+")[0]
+    opts = precision.split("+")
+    f16act = "f16act" in opts
+    model.precision = opts[0]
     model.activation_storage = "f16" if f16act else "fp32"
+    model.gradient_storage = "bf16" if "bf16dy" in opts else "fp32"
+    model.workspace_layout = "rows" if "rows" in opts else "fragment"
     loss, out = _hip_gradients(fx, d, model)
     assert (out.z_vals.cpu() == d["z_vals"]).all(), "sampling must replay exactly for the comparison to be meaningful"
     ref_loss, ref = oracle_gradients(fx, d, build_model(fx, d))
@@ -46,12 +51,9 @@ def test_render_gradients(name, precision):
     # zero, which legitimately changes the gradient of everything below (one unit of a 64-ray fixture moves a layer's
     # gradient by percents).  Count such flips from the saved activations; when there are any, the tight comparison is
     # made against the oracle re-run with THIS implementation's masks pinned.
-    saved = model._debug_saved.cpu()
-    if f16act:            # the ReLU slots hold 256 f16 values in the first half of every row
-        saved = saved.view(torch.float16)[:, :, :256].float()
     # the masks the backward applied: the sign-bit words of the 16-bit path (exact: a positive activation below the f16 range
-    # is stored as 0 with f16 storage but its unit is open), the saved values of the fp32 path
-    open_units = lib.unpack_sign_words(model._debug_masks).cpu() if model._debug_masks is not None else saved > 0
+    # is stored as 0 with f16 storage but its unit is open), the saved values of the fp32 path (row-major [slots][M][256])
+    open_units = lib.unpack_sign_words(model._debug_masks).cpu() if model._debug_masks is not None else model._debug_saved.cpu() > 0
     slots = list(range(8)) + list(range(9, 13))          # VF hidden 0..7, rendering hidden 0..3 (slot 8 = features)
     masks, flips = [], 0
     for slot, act in zip(slots, ref["_hidden"]):
@@ -76,12 +78,16 @@ def test_render_gradients(name, precision):
     for pname, p in model.density.named_parameters():
         err = grad_rel_err(p.grad.reshape(1), ref[f"density.{pname}"].reshape(1))
         print(f"density.{pname}: hip {float(p.grad):.6e} ref {float(ref['density.' + pname]):.6e}")
-        assert err < TOL, (pname, err)
+        assert err < (1e-2 if "bf16dy" in opts else TOL), (pname, err)
     print(f"{name}/{precision}: worst parameter-gradient error {worst[1]:.3e} at {worst[0]}")
-    assert all(e < TOL for _, _, e in errs), [x for x in errs if x[2] >= TOL]
+    # bf16 gradient storage (opt-in): 8 significant bits in one factor of every dW term; the rounding is unbiased and averages
+    # out over the points of a batch, so on these fixtures of a few hundred to a few thousand points it is still visible
+    # (Backward): bounded at 1e-2 here, ~1e-4 at the 524 288 points of a full batch
+    tol = 1e-2 if "bf16dy" in opts else TOL
+    assert all(e < tol for _, _, e in errs), [x for x in errs if x[2] >= tol]
     # and against the reference's own backward pass (captured in the fixture): tight when no unit flipped, a sanity
     # bound otherwise
-    tol_ref = TOL if flips == 0 else 1e-1
+    tol_ref = tol if flips == 0 else 1e-1
     for tag, key in GRAD_KEYS:
         err = grad_rel_err(dict(nets[tag].named_parameters())[key].grad, d[f"grad.{tag}.{key}"])
         assert err < tol_ref, ("vs reference", tag, key, err)
@@ -368,3 +374,109 @@ def test_dx_chain_bf16_split_matches_fp32():
         assert torch.equal(zv16, zv32)
         slots = range(9) if cols == 259 else range(8)
         compare(f"vf-only/{cols}", [dy16[s][:, :w] for s, w in enumerate(widths[:9])], [dy32[s][:, :w] for s, w in enumerate(widths[:9])], slots)
+
+
+def test_fragment_ordered_workspace_holds_the_row_major_values():
+    """The f16x3 training forward and the bf16 chain with a FRAGMENT-ORDERED workspace (include/vfn.h) against the same
+    launches with the row-major one: bit-identical activations (fp32 and f16 storage), sign words, outputs and dY slots;
+    bf16 dY = the fp32 gradients rounded to nearest even.  Ragged point counts (partial last group)."""
+    from vf_nerf_amd import lib
+    from vf_nerf_amd.backward import _Workspace, _entries, _packed_bwd16, _head_rows
+    fx, d = load_fixture("c1_perturb")
+    model = build_model(fx, d, device="cuda:0")
+    vf, rn = model.vector_field_network, model.rendering_network
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(5)
+    widths = [256, 256, 256, 217, 256, 256, 256, 256, 256, 256, 256, 256, 256]
+    for n, s_t in ((37, 12), (1, 3), (64, 16)):        # 444 (ragged), 3 (one partial group), 1024 (whole groups) points
+        m = n * s_t
+        pts = (torch.rand(m, 3, generator=gen) * 2 - 1).to(dev)
+        dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=1).to(dev)
+        slots = len(_entries(vf)) + len(_entries(rn))
+        dc = (torch.randn(m, 3, generator=gen) * 1e-4).to(dev)
+        dn = (torch.randn(m, 3, generator=gen) * 1e-5).to(dev)
+        for f16 in (False, True):
+            rows_ws, frag_ws = _Workspace(m, slots, dev, f16=f16), _Workspace(m, slots, dev, f16=f16, frag=True)
+            outs = []
+            for ws in (rows_ws, frag_ws):
+                ws.saved.fill_(float("nan"))
+                outs.append(lib.vf_render_fused16_fwd_train(vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(),
+                                                            pts, dirs, s_t, ws.saved, ws.aux_vf, ws.aux_rn, ws.masks, save_f16=ws.fwd_flags()))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+            assert torch.equal(rows_ws.masks, frag_ws.masks)
+            for slot, w in enumerate(widths):
+                a, b = frag_ws.rows(slot)[:, :w], rows_ws.rows(slot)[:, :w]
+                assert torch.equal(a, b), (m, f16, slot)
+            if f16:
+                continue
+            zr, zv = torch.empty(m, 4, device=dev), torch.empty(m, 4, device=dev)
+            dys = []
+            for ws, flags in ((rows_ws, 0), (frag_ws, lib.DY_FRAG), (frag_ws, lib.DY_FRAG | lib.DY_BF16)):
+                ws.dy16 = bool(flags & lib.DY_BF16)
+                dy = ws.new_dy()
+                dy.fill_(float("nan"))
+                lib.mlp_bwd_chain_bf16_ws(vf.geometry(), _packed_bwd16(vf), _head_rows(vf), rn.geometry(), _packed_bwd16(rn), _head_rows(rn),
+                                          ws.feats(8), ws.masks, dy, flags, dc, outs[0][1], dn, outs[0][0], None, 3, m, zr, zv)
+                dys.append(dy)
+            for slot, w in enumerate(widths):
+                want = dys[0][slot][:, :w]
+                assert torch.equal(lib.frag_to_rows(dys[1][slot], m)[:, :w], want), (m, slot)
+                got16 = lib.frag_to_rows(dys[2][slot], m, torch.bfloat16)[:, :w]
+                assert torch.equal(got16, want.to(torch.bfloat16).float()), (m, slot, "bf16")
+
+
+@pytest.mark.parametrize("m,groups", [(32 * 40, 5), (1000, 7), (33, 1), (5000, 64)])
+def test_weight_grad_frag_matches_float64(m, groups):
+    """vfn_weight_grad_frag (csrc/vfn_dwf.hip) in every operand form against a float64 product of the same operands: the three
+    shapes (256 x 256, 256 x 64 with the encoding tile, 32 x 256 with the head gradient), fragment fp32 / f16 / bf16 / row-major
+    operands, ragged point counts, more groups than steps.  Small integers make the 16-bit splits exact (this pins the operand
+    maps, the swizzled LDS images and the transposed reads); random data bounds the split error."""
+    from vf_nerf_amd import lib
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(m)
+
+    def operands(exact):
+        if exact:
+            dy = torch.randint(-3, 4, (m, 256), generator=gen).float()
+            x = torch.randint(-4, 5, (m, 256), generator=gen).float()
+            aux = torch.randint(-2, 3, (m, 40), generator=gen).float()
+            dz = torch.randint(-3, 4, (m, 4), generator=gen).float()
+        else:
+            dy = torch.randn(m, 256, generator=gen) * torch.logspace(-6, -2, 256)[None, :]
+            x = torch.relu(torch.randn(m, 256, generator=gen)) * 3
+            aux = torch.randn(m, 40, generator=gen)
+            dz = torch.randn(m, 4, generator=gen) * 1e-3
+        return dy.to(dev), x.to(dev), aux.to(dev), dz.to(dev)
+
+    for exact in (True, False):
+        dy, x, aux, dz = operands(exact)
+        dz[:, 3] = 0
+        forms_dy = {lib.DYF_FRAG32: (lib.rows_to_frag(dy), dy), lib.DYF_FRAGBF16: (lib.rows_to_frag(dy, torch.bfloat16), dy.to(torch.bfloat16).float())}
+        forms_x = {lib.XF_FRAG32: (lib.rows_to_frag(x), x), lib.XF_FRAG16: (lib.rows_to_frag(x, torch.float16), x.half().float()),
+                   lib.XF_ROWS32: (x.contiguous(), x)}
+        tol = 0.0 if exact else 3e-4
+
+        def check(tag, got, want, got_b, want_b):
+            scale = float(want.abs().max())
+            err = float((got.double() - want).abs().max())
+            assert err <= tol * scale + (0 if not exact else 0), (tag, m, groups, exact, err, scale)
+            if got_b is not None:
+                assert float((got_b.double() - want_b).abs().max()) <= (1e-5 if not exact else 0) * max(1e-30, float(want_b.abs().max())), (tag, "db")
+
+        for fdy, (bdy, vdy) in forms_dy.items():
+            for fx_, (bx, vx) in forms_x.items():
+                part = torch.full((groups, 256, 256), float("nan"), device=dev)
+                dbp = torch.full((groups, 256), float("nan"), device=dev)
+                lib.weight_grad_frag(0, bdy, fdy, bx, fx_, m, groups, part, dbp)
+                check(f"shape0/{fdy}/{fx_}", part.sum(0), vdy.double().T @ vx.double(), dbp.sum(0), vdy.double().sum(0))
+            part = torch.full((groups, 256, 64), float("nan"), device=dev)
+            dbp = torch.full((groups, 256), float("nan"), device=dev)
+            lib.weight_grad_frag(1, bdy, fdy, aux, lib.XF_AUX40, m, groups, part, dbp)
+            check(f"shape1/{fdy}", part.sum(0)[:, :40], vdy.double().T @ aux.double(), dbp.sum(0), vdy.double().sum(0))
+            assert float(part.sum(0)[:, 40:].abs().max()) == 0.0
+        for fx_, (bx, vx) in forms_x.items():
+            part = torch.full((groups, 32, 256), float("nan"), device=dev)
+            dbp = torch.full((groups, 32), float("nan"), device=dev)
+            lib.weight_grad_frag(2, dz, lib.DYF_DZ4, bx, fx_, m, groups, part, dbp)
+            check(f"shape2/{fx_}", part.sum(0)[:4], dz.double().T @ vx.double(), dbp.sum(0)[:4], dz.double().sum(0))
+            assert float(part.sum(0)[4:].abs().max()) == 0.0 and float(dbp.sum(0)[4:].abs().max()) == 0.0

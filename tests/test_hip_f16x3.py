@@ -169,3 +169,146 @@ def test_block_launches_equal_fused_launch():
     oa, ob = torch.zeros(m, 3, device=dev), torch.zeros(m, 3, device=dev)
     lib.scatter_rows3(a, b, idx, oa, ob)
     assert torch.equal(oa[perm[keep]], a[keep]) and torch.equal(ob[perm[keep]], b[keep]) and float(oa[perm[~keep]].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------
+# range guard (vf_nerf_amd/guard.py): networks / inputs outside the range the split-f16 operands cover
+# ------------------------------------------------------------------------------------------------
+def _out_of_family(case_name, model, points):
+    """Push the fixture's network / inputs out of the default-initialised family."""
+    vf, rn = model.vector_field_network, model.rendering_network
+    with torch.no_grad():
+        if case_name == "gain8_gamma30":            # hidden gain 2 -> 8, BatchNorm gamma spread over 1..30
+            for net in (vf, rn):
+                for i in range(net.num_layers - 1):
+                    net._linear(i).weight.mul_(4.0)
+                    bn = net._bn(i)
+                    bn.weight.copy_(torch.linspace(1.0, 30.0, bn.weight.numel(), device=bn.weight.device))
+        elif case_name == "weights_1e-3":           # every Linear weight scaled down: folded weights deep in the f16 denormals
+            for net in (vf, rn):
+                for i in range(net.num_layers):
+                    net._linear(i).weight.mul_(1e-3)
+        elif case_name == "points_50":              # a scene 50 units across (the reference normalises nothing)
+            points = points * 50.0
+        elif case_name == "points_2000":            # beyond the f16 range once scaled by 2^6
+            points = points * 2000.0
+    return points
+
+
+@pytest.mark.parametrize("case_name", ["in_family", "gain8_gamma30", "weights_1e-3", "points_50", "points_2000"])
+def test_range_guard_never_returns_unflagged_garbage(case_name):
+    """the reference's MLPs have no range restriction (vector_field_network.py:177-208); the f16x3 kernels
+    do (|activation|, |coordinate| < ~937, folded weights not down in the f16 denormals).  For each out-of-family case:
+    * strict guard: the vector-field query and render() return what the exact-fp32 kernels / the oracle return (the flagged
+      call is repeated on the fp32 kernels before it returns);
+    * lazy guard: whenever the f16x3 result is more than 1e-4 off, the guard's report says so (and names the reason);
+    * in-family inputs never trip it."""
+    import warnings
+    from oracle import vfnerf_oracle as O
+    from vf_nerf_amd import lib
+    fx, d = load_fixture("c1_perturb")
+    dev = "cuda:0"
+    g = {k: v.to(dev) for k, v in d.items()}
+
+    def fresh():
+        m = build_model(fx, d, device=dev)
+        pts = _out_of_family(case_name, m, g["points"].reshape(-1, 3).contiguous())
+        return m, pts.contiguous()
+
+    model, pts = fresh()
+    cpu_sd = {k: v.detach().cpu() for k, v in model.vector_field_network.state_dict().items()}
+    want = O.vf_mlp(pts.cpu(), cpu_sd, 6, (4,))[:, :3]
+    vf = model.vector_field_network
+    raw16 = lib.vf_mlp16_fwd(vf.geometry(), vf.packed16_weights(), pts)           # the unguarded kernel
+    raw32 = lib.vf_mlp_fwd(vf.geometry(), vf.packed_weights(), pts, 3)
+    e16, e32 = rel_err(raw16, want), rel_err(raw32, want)
+    print(f"{case_name}: f16x3 kernel vs oracle {e16:.2e}; exact-fp32 kernel vs oracle {e32:.2e}")
+    assert e32 < 1e-4, "the exact-fp32 kernels follow the reference everywhere"
+
+    # lazy: the report exists whenever the result is off
+    model.f16x3_guard = "lazy"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with torch.no_grad():
+            out = vf(pts, vector_only=True)
+            reason = model.range_guard.check_now(torch.device(dev))
+    print(f"{case_name}: lazy guard report: {reason}")
+    assert rel_err(out, want) < 1e-4 or reason is not None
+    if case_name == "in_family":
+        assert reason is None and model.precision == "f16x3" and e16 < TIGHT
+    if reason is not None:
+        assert model.precision == "fp32" and model.f16x3_disabled == reason and not model.uses_f16x3()
+        with torch.no_grad():
+            assert rel_err(vf(pts, vector_only=True), want) < 1e-4, "after the switch the model runs the fp32 kernels"
+
+    # strict: no call returns values the clamp touched
+    model, pts = fresh()
+    model.f16x3_guard = "strict"
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            out = model.vector_field_network(pts, vector_only=True)
+    assert rel_err(out, want) < 1e-4, (case_name, rel_err(out, want))
+    if e16 >= 1e-4:
+        assert any("f16x3" in str(w.message) for w in caught) and model.f16x3_disabled is not None
+
+    # strict, through render(): same draws on both paths, normals / colours of identically sampled rays against the oracle
+    model, _ = fresh()
+    model.f16x3_guard = "strict"
+    scale = {"points_50": 50.0, "points_2000": 2000.0}.get(case_name, 1.0)
+    pose = g["pose"].clone()
+
+    model.ray_sampler.far = model.fine_sampler.far = fx["far"] * scale
+    model.fine_sampler.range = fx["fine_range"] * scale
+    uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add")}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with torch.no_grad():
+            out = model.render(pose, g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
+    settings = O.RenderSettings(n_samples=fx["n_samples"], n_fine=fx["n_importance"], near=fx["near"], far=fx["far"] * scale,
+                                fine_range=fx["fine_range"] * scale, perturb=True, n_window=fx["n_window"], dir_to_normal_th=fx["th"],
+                                density=O.DensityParams(beta=0.5, mean=0.7, scale=100.0, beta_bounds=(1e-4, 1e9), mean_bounds=(0.6, 1.0), scale_min=1.0))
+    rn_sd = {k: v.detach().cpu() for k, v in model.rendering_network.state_dict().items()}
+    vf_sd = {k: v.detach().cpu() for k, v in model.vector_field_network.state_dict().items()}
+    ref = O.render(d["uv"], d["pose"], d["intrinsics"], vf_sd, rn_sd, settings, **{k: d[k] for k in uni})
+    same = (out.z_vals.cpu() == ref["z_vals"]).all(dim=1)
+    assert torch.isfinite(out.coarse_rgb_values).all() and torch.isfinite(out.coarse_normals).all()
+    n_same = int(same.sum())
+    print(f"{case_name}: strict render(): {n_same}/{same.numel()} rays sampled identically; model now on {model.precision}")
+    if n_same:
+        en = float((out.coarse_normals.cpu()[same] - ref["normals"][same]).abs().max())
+        ec = float((out.coarse_colors.cpu().reshape(ref["normals"].shape)[same] - ref["colors"].reshape(ref["normals"].shape)[same]).abs().max())
+        assert en < 1e-4 and ec < 1e-4, (case_name, en, ec)
+    if case_name == "in_family":
+        assert n_same == same.numel() and model.precision == "f16x3"
+
+
+def test_range_guard_costs_nothing_on_the_hot_path():
+    """lazy mode adds no synchronisation: render() under the guard returns the same values as with the guard off, and the
+    status word is read back at most once per guard.LAZY_EVERY calls."""
+    from vf_nerf_amd import guard as vguard
+    fx, d = load_fixture("c1_perturb")
+    model = build_model(fx, d, device="cuda:0")
+    g = {k: v.to("cuda:0") for k, v in d.items()}
+    uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add")}
+    outs = {}
+    for mode in ("off", "lazy", "strict"):
+        model.f16x3_guard = mode
+        with torch.no_grad():
+            outs[mode] = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni).coarse_rgb_values.clone()
+    assert torch.equal(outs["off"], outs["lazy"]) and torch.equal(outs["off"], outs["strict"])
+    model.f16x3_guard = "lazy"
+    reads = 0
+    real = model.range_guard._read_back
+
+    def counting(st, dev):
+        nonlocal reads
+        reads += 1
+        return real(st, dev)
+
+    model.range_guard._read_back = counting
+    with torch.no_grad():
+        for _ in range(2 * vguard.LAZY_EVERY):
+            model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
+    torch.cuda.synchronize()
+    assert reads <= 3 and model.f16x3_disabled is None

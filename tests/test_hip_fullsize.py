@@ -182,14 +182,27 @@ def _train_step(m, uv, pose, K, rgb_gt, depth_gt, centroid, n_sup, bucket=None):
     return loss, norm
 
 
-@pytest.mark.parametrize("storage", ["f16", "fp32"])
+@pytest.mark.parametrize("storage", ["f16", "fp32", "f16+bf16dy", "f16+rows"])
 def test_training_step_at_full_size(storage):
     """BASELINE.json configs[2] at its full size — one optimizer step on a 4096-ray batch x 128 samples with 2 x 52 428
-    supervision points — on the 16-bit matrix-core path (f16x3 forward, bf16-split backward; ``storage``: how the saved
-    activations are kept for the weight-gradient kernels) against the exact-fp32 HIP kernels from the same weights, rays, draws
-    and targets: (a) every parameter gradient within 1e-3 of the tensor's largest entry, (b) the loss within 1e-5, (c) after
-    optimizer.step the VF parameters' Adam step counter reads 2 (the alias, Q4), the rendering net's 1."""
-    from vf_nerf_amd import supervision
+    supervision points.  ``storage``: how the 16-bit path keeps its workspace (activations f16 | fp32, gradients bf16, row-major
+    instead of fragment order).
+
+    (a) The BACKWARD arithmetic: the same f16x3 forward differentiated by the 16-bit kernels (bf16-split dX chain and weight
+        gradients from the stored workspace) and by the exact-fp32 kernels (``backward_kernels = "fp32"``): every parameter
+        gradient within 1e-3 of the tensor's largest entry (measured 7e-5 with fp32 activations, 3.4e-4 with f16 ones, fragment
+        or row-major alike; the opt-in bf16 gradient storage: 3e-3, bounded at 1e-2).
+    (b) The whole 16-bit path against the whole exact-fp32 path from the same weights, samples and targets: the loss within
+        1e-5.  Their gradients are NOT asked to agree to 1e-3 at this size: the two forwards differ by ~1e-5 in the normals, the
+        density (scale 100 on a Laplace CDF of the cosine between neighbouring normals) turns that into ~1e-3 in the weights
+        of the rays that sit on a surface, and the gradient of the batch moves by 1-2 % of a tensor's largest entry (measured;
+        the round-1 row-major kernels show the same).  What is asserted is that the two gradients point the same way
+        (cosine > 0.999 per tensor family) — the tight per-gradient bounds live in tests/test_hip_backward.py, where the
+        forward can be pinned.
+    (c) After optimizer.step the VF parameters' Adam step counter reads 2 (the alias, Q4), the rendering net's 1.
+    The samples are drawn once (a gradient-free render) and every run differentiates the fine pass on them."""
+    from vf_nerf_amd import autograd as vauto, optim, supervision
+    opts = storage.split("+")
     n, s_t = 4096, 128
     uv, pose, K = synthetic.pinhole_batch(n, 1200, 680, 600.0, seed=9, device=DEV)
     g = torch.Generator().manual_seed(7)
@@ -197,28 +210,49 @@ def test_training_step_at_full_size(storage):
     depth_gt = (0.2 + 0.6 * torch.rand(n, 1, generator=g)).to(DEV)
     centroid = torch.tensor([0.0, 0.0, 0.6], device=DEV)
     n_sup = (n * s_t) // 10
+    sampler = _model()
+    sampler.precision = "fp32"
+    sampler.rng_seed, sampler._rng_offset = 5, 0
+    with torch.no_grad():
+        first = sampler.render(pose, uv, K, epoch=0)
+    pts, z = first.points_coarse, first.z_vals
+    ray_dirs = first.ray_dirs.view(n, s_t, 3)[:, 0, :].contiguous()
+    supervision.manual_seed(11)
+    bp, b_gt = supervision.sample_border_points(0.75, 1.0, n_sup, centroid, DEV)
+    cp, c_gt = supervision.sample_center_points(centroid, 0.05, n_sup, DEV)
     results = {}
-    for precision in ("f16x3", "fp32"):
+    for tag in ("16bit", "f16x3-forward+fp32-backward", "fp32"):
         m = _model()
-        m.precision = precision
-        m.activation_storage = storage if precision == "f16x3" else "fp32"
-        m.rng_seed, m._rng_offset = 5, 0
-        supervision.manual_seed(11)
-        loss, norm = _train_step(m, uv, pose, K, rgb_gt, depth_gt, centroid, n_sup)
-        grads = {id_: p.grad.detach().clone() for id_, p in enumerate(m.unique_parameters())}
+        m.precision = "fp32" if tag == "fp32" else "f16x3"
+        m.activation_storage = "f16" if opts[0] == "f16" else "fp32"
+        m.gradient_storage = "bf16" if "bf16dy" in opts else "fp32"
+        m.workspace_layout = "rows" if "rows" in opts else "fragment"
+        m.backward_kernels = m.vector_field_network.backward_kernels = "fp32" if tag == "f16x3-forward+fp32-backward" else "auto"
+        normals, colors, rgb, depth, weights = vauto.fine_pass(m, pts, z, ray_dirs)       # the differentiable part of render()
+        assert rgb.requires_grad
+        sup_n = m.vector_field_network(torch.cat([bp, cp]))[:, :3]
+        loss = 2.0 * (rgb - rgb_gt).abs().mean() + 0.5 * torch.clamp((depth - depth_gt).abs(), max=0.5).mean() + \
+            0.1 * ((normals.norm(dim=-1) - 1.0) ** 2).mean() + 1.0 * ((sup_n - torch.cat([b_gt, c_gt])) ** 2).mean()
+        m.optimizer.zero_grad()
+        loss.backward()
+        grads = [p.grad.detach().clone() for p in m.unique_parameters()]
+        norm = optim.clip_grad_norm_(m.parameters(), m.config.scheduler_config.clip_norm)
         m.optimizer.step()
-        results[precision] = (float(loss), float(norm), grads, m)
-    (l16, n16, g16, m16), (l32, n32, g32, m32) = results["f16x3"], results["fp32"]
-    assert abs(l16 - l32) <= 1e-5 * max(1.0, abs(l32)), (l16, l32)
-    worst = 0.0
-    for k in g32:
-        ref = g32[k]
-        err = float((g16[k] - ref).abs().max() / max(float(ref.abs().max()), 1e-30))
-        worst = max(worst, err)
-    print(f"4096 x 128 training step, activations {storage}: loss {l16:.6f} vs {l32:.6f}; clip norm {n16:.4f} vs {n32:.4f}; worst "
-          f"parameter-gradient difference {worst:.2e} of the tensor max")
-    assert worst < 1e-3
-    assert abs(n16 - n32) <= 1e-3 * n32
+        results[tag] = (float(loss), float(norm), grads, m)
+    (l16, n16, g16, m16), (lh, nh, gh, _), (l32, n32, g32, _) = (results[k] for k in ("16bit", "f16x3-forward+fp32-backward", "fp32"))
+    rel = lambda a, b: float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+    worst_bwd = max(rel(a, b) for a, b in zip(g16, gh))
+    worst_all = max(rel(a, b) for a, b in zip(g16, g32))
+    flat = lambda gs: torch.cat([t.reshape(-1).double() for t in gs])
+    cos = float(torch.nn.functional.cosine_similarity(flat(g16), flat(g32), dim=0))
+    print(f"4096 x 128 training step [{storage}]: loss {l16:.7f} (16-bit) / {l32:.7f} (fp32); clip norm {n16:.4f} / {nh:.4f} / {n32:.4f}; "
+          f"same forward, 16-bit vs fp32 backward: worst gradient difference {worst_bwd:.2e} of the tensor max; whole 16-bit path vs "
+          f"whole fp32 path: {worst_all:.2e}, cosine {cos:.6f}")
+    assert lh == l16 and abs(l16 - l32) <= 1e-5 * max(1.0, abs(l32)), (l16, lh, l32)
+    assert worst_bwd < (1e-2 if "bf16dy" in opts else 1e-3)      # (bf16 gradient storage, opt-in: 3e-3 measured — small sums such as the
+                                                                  # BatchNorm biases' keep the 8-bit rounding visible even at 524 288 points)
+    assert abs(n16 - nh) <= 1e-3 * nh
+    assert cos > 0.999 and worst_all < 0.1
     st = m16.optimizer.state
     assert float(st[m16.vector_field_network.layers[3][0].weight]["step"]) == 2.0
     assert float(st[m16.rendering_network.layers[2][0].weight]["step"]) == 1.0
@@ -227,7 +261,7 @@ def test_training_step_at_full_size(storage):
 
 def test_gradient_bucket_path_equals_plain_path():
     """Multi-GPU readiness on one GPU: the data-parallel step (``distributed.GradientBucket``: every ``param.grad`` a view into
-    ONE flat fp32 buffer, zeroed in place, all-reduced as one message) must leave bit-identical weights to the plain
+    ONE flat fp32 buffer, zeroed in place, all-reduced as one message) must leave the same weights as the plain
     single-process step, and the views must stay bound to the flat buffer across the backward of the HIP autograd functions."""
     from vf_nerf_amd import distributed as vdist, supervision
     n, s_t = 1024, 128
@@ -235,7 +269,7 @@ def test_gradient_bucket_path_equals_plain_path():
     g = torch.Generator().manual_seed(8)
     rgb_gt, depth_gt = torch.rand(n, 3, generator=g).to(DEV), (0.2 + 0.6 * torch.rand(n, 1, generator=g)).to(DEV)
     centroid = torch.tensor([0.0, 0.0, 0.6], device=DEV)
-    finals = []
+    finals, after_one = [], []
     for use_bucket in (False, True):
         m = _model()
         m.rng_seed, m._rng_offset = 2, 0
@@ -253,4 +287,10 @@ def test_gradient_bucket_path_equals_plain_path():
             m.optimizer.step()
             m.scheduler.step()
         finals.append([p.detach().clone() for p in m.unique_parameters()])
-    assert all(torch.equal(a, b) for a, b in zip(*finals)), "bucketed and plain steps must give bit-identical weights"
+    # Not bitwise: the three density scalars' gradients leave the per-ray kernel by atomicAdd (one per ray, order free), so
+    # the clip coefficient — and through it every update — differs in the last bits between ANY two runs.  What must hold is
+    # that the bucket changes nothing beyond that: two steps later every weight agrees to a thousandth of one Adam update.
+    lr = 5e-4
+    worst = max(float((a - b).abs().max()) for a, b in zip(*finals))
+    print(f"bucketed vs plain data path after two steps: max parameter difference {worst:.2e} ({worst / lr:.1e} lr)")
+    assert worst < 1e-2 * lr

@@ -27,7 +27,15 @@ def vf_forward(net, points: torch.Tensor, vector_only: bool = False) -> torch.Te
         return vf_forward_autograd(net, points, vector_only)
     pts = _flat3(points)
     if vector_only and getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3():
-        return lib.vf_mlp16_fwd(net.geometry(), net.packed16_weights(), pts)
+        guard = getattr(net, "_range_guard", None)        # the owning model's range guard (guard.py), if any
+        if guard is None or not guard.active() or not pts.is_cuda:
+            return lib.vf_mlp16_fwd(net.geometry(), net.packed16_weights(), pts)
+        guard.poll()
+        if getattr(net, "precision", "fp32") == "f16x3":
+            with guard.watch(pts.device) as w:
+                out = lib.vf_mlp16_fwd(net.geometry(), net.packed16_weights(), pts)
+            if not w.flagged:
+                return out                                 # (strict mode and flagged: fall through to the fp32 kernel)
     cols = 3 if vector_only else 3 + net._feature_dims()
     return lib.vf_mlp_fwd(net.geometry(), net.packed_weights(), pts, cols)
 

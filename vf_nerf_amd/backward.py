@@ -112,14 +112,17 @@ def _rn_inputs(feats: torch.Tensor, saved_slots: List[torch.Tensor]) -> List[tor
 
 
 def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=(), fast: bool = False, x_f16: bool = False,
-                  x_fp32_entries=()) -> Dict[torch.nn.Parameter, torch.Tensor]:
+                  x_fp32_entries=(), frag=None) -> Dict[torch.nn.Parameter, torch.Tensor]:
     """inputs[h]: [M,256] act input of hidden entry h (None if it has none); inputs[-1]: input of the 3-channel head.
     dy_slots[h]: [M,256] pre-activation gradient of entry h.  aux: [M,40].  dz_head: [M,4].  Runs the persistent
     weight-gradient kernels (``fast``: the 256 x 256 products on the bf16 matrix cores, csrc/vfn_dw16.hip), then ONE
     launch (csrc/vfn_unfold.hip) sums their partial slabs and un-folds BatchNorm / the skip scale onto the parameters:
         W' = s * scale * W,  b' = s (b - mu) + beta_bn,  s = gamma / sqrt(var + eps).
-    ``x_f16``: the act inputs are workspace slots in the opt-in f16 storage (first 512 bytes of each row), except the
-    entries listed in ``x_fp32_entries`` (the rendering net's first layer reads the fp32 feature slot)."""
+    ``x_f16``: the act inputs are workspace slots in the f16 storage (first 512 bytes of each row), except the
+    entries listed in ``x_fp32_entries`` (the rendering net's first layer reads the fp32 feature slot).
+    ``frag`` = (dy_form, x_form): the workspace is FRAGMENT-ORDERED (csrc/vfn_dwf.hip: every product, thin ones included, on
+    the bf16 matrix cores from 1-KiB-contiguous pieces); inputs / dy_slots are then flat slots, and the entries of
+    ``x_fp32_entries`` are row-major fp32 [M,256] (the tanh'ed features)."""
     dev = aux.device
     entries = _entries(net)
     G = _groups(m)
@@ -141,15 +144,20 @@ def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=(), fast: bo
                  rows=e["rows"], row_off=e["row_off"], in_dim=lin.in_features, slab_rows=HID, scale=e["scale"])
         if e["act"] is not None:
             part = torch.empty(G, HID, HID, device=dev)
-            if fast:
+            if frag is not None:
+                lib.weight_grad_frag(0, dy, frag[0], inputs[h], lib.XF_ROWS32 if h in x_fp32_entries else frag[1], m, G, part, db_part)
+            elif fast:
                 lib.weight_grad_partials_bf16(dy, inputs[h], m, G, part, db_part, x_f16=x_f16 and h not in x_fp32_entries)
             else:
                 lib.weight_grad_partials(0, dy, HID, HID, inputs[h], HID, HID, m, G, part, db_part)
             u.update(dw_act=part, act_c0=e["act"][0], act_nc=e["act"][1])
         if e["aux"] is not None:
             part = torch.empty(G, HID, 64, device=dev)
-            lib.weight_grad_partials(1, dy, HID, HID, aux, lib.AUX_K, lib.AUX_K, m, G, part,
-                                     db_part if e["act"] is None else None)
+            if frag is not None:
+                lib.weight_grad_frag(1, dy, frag[0], aux, lib.XF_AUX40, m, G, part, db_part if e["act"] is None else None)
+            else:
+                lib.weight_grad_partials(1, dy, HID, HID, aux, lib.AUX_K, lib.AUX_K, m, G, part,
+                                         db_part if e["act"] is None else None)
             u.update(dw_aux=part, aux_c0=e["aux"][0], aux_nc=e["aux"][1])
         if bn is not None:
             u.update(bn_w=bn.weight.detach(), bn_var=bn.running_var.detach(), bn_mean=bn.running_mean.detach(),
@@ -159,7 +167,10 @@ def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=(), fast: bo
     last = net._linear(net.num_layers - 1)
     part = torch.empty(G, 32, HID, device=dev)
     dbp = torch.empty(G, 32, device=dev)
-    lib.weight_grad_partials(2, dz_head, 4, 3, inputs[-1], HID, HID, m, G, part, dbp, x_f16=x_f16)
+    if frag is not None:
+        lib.weight_grad_frag(2, dz_head, lib.DYF_DZ4, inputs[-1], frag[1], m, G, part, dbp)
+    else:
+        lib.weight_grad_partials(2, dz_head, 4, 3, inputs[-1], HID, HID, m, G, part, dbp, x_f16=x_f16)
     fresh = last.weight not in grads          # the feature rows of the last Linear were skipped (vector-only forward)
     unfold.append(dict(dw_act=part, db=dbp, w=last.weight.detach(), b_lin=last.bias.detach(), g_w=out_for(last.weight),
                        g_b=out_for(last.bias), rows=3, row_off=0, in_dim=last.in_features, slab_rows=32, act_c0=0,
@@ -171,19 +182,69 @@ def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=(), fast: bo
     return grads
 
 
-_F16_TRAIN_MAX_POINTS = 1 << 22   # the f16x3 training kernels address a workspace slot with 32-bit offsets
+_F16_TRAIN_MAX_POINTS = 1 << 21   # the 16-bit training kernels address a fragment-ordered slot (32 KiB per 32 points) with 32-bit offsets
 
 
 class _Workspace:
-    def __init__(self, m: int, n_slots: int, dev, f16: bool = False) -> None:
-        # f16: the f16x3 training forward stores the ReLU slots as f16 (first 512 bytes of every row; opt-in, see
-        # VectorFieldNerf.activation_storage); the buffer keeps its shape, the tanh'ed feature slot stays fp32
-        self.f16 = f16
-        self.saved = torch.empty(n_slots, m, HID, device=dev)
+    """What a training forward leaves for the backward.
+
+    16-bit path (``frag``): every slot is FRAGMENT-ORDERED (include/vfn.h) — flat buffers of ceil(M/32) groups x 32 KiB;
+    ``f16``: the ReLU slots hold f16 values (``VectorFieldNerf.activation_storage``); slot 8 of a VF net, the tanh'ed features,
+    is row-major fp32 [M,256] (``feats``).  ``dy16``: the chain stores the pre-activation gradients as bf16
+    (``VectorFieldNerf.gradient_storage``).  Exact-fp32 path: row-major [slots][M][256] fp32."""
+
+    def __init__(self, m: int, n_slots: int, dev, f16: bool = False, frag: bool = False, dy16: bool = False) -> None:
+        self.m, self.n_slots, self.f16, self.frag, self.dy16 = m, n_slots, f16, frag, dy16 and frag
+        if frag:
+            self.slot_floats = lib.frag_groups(m) * lib.GROUP_FLOATS
+            self.saved = torch.empty(n_slots, self.slot_floats, device=dev)
+        else:
+            self.slot_floats = m * HID
+            self.saved = torch.empty(n_slots, m, HID, device=dev)
         # sign bits of the saved ReLU outputs (f16x3 training forwards write them, the bf16 chain reads them): 32 B per point and slot
         self.masks = torch.empty(n_slots, m, 2, 4, dtype=torch.int32, device=dev)
         self.aux_vf = torch.empty(m, lib.AUX_K, device=dev)
         self.aux_rn = torch.empty(m, lib.AUX_K, device=dev)
+
+    def slot(self, h: int) -> torch.Tensor:
+        return self.saved[h]
+
+    def feats(self, h: int = 8) -> torch.Tensor:
+        """The tanh'ed feature slot as the row-major [M,256] fp32 matrix it always is."""
+        return self.saved[h].reshape(-1)[: self.m * HID].view(self.m, HID)
+
+    def fwd_flags(self) -> int:
+        return (lib.WS_F16 if self.f16 else 0) | (lib.WS_FRAG if self.frag else 0)
+
+    def dy_flags(self) -> int:
+        return (lib.DY_FRAG if self.frag else 0) | (lib.DY_BF16 if self.dy16 else 0)
+
+    def frag_forms(self):
+        """(dy_form, x_form) of lib.weight_grad_frag for this workspace, or None for the row-major layouts."""
+        if not self.frag:
+            return None
+        return (lib.DYF_FRAGBF16 if self.dy16 else lib.DYF_FRAG32, lib.XF_FRAG16 if self.f16 else lib.XF_FRAG32)
+
+    def new_dy(self) -> torch.Tensor:
+        dev = self.saved.device
+        return torch.empty(self.n_slots, self.slot_floats, device=dev) if self.frag else torch.empty(self.n_slots, self.m, HID, device=dev)
+
+    def rows(self, h: int, feature_slot: int = 8) -> torch.Tensor:
+        """Slot h as a row-major fp32 [M,256] matrix whatever the storage (tests / debugging)."""
+        if not self.frag:
+            t = self.saved[h]
+            return t.view(torch.float16)[:, :HID].float() if (self.f16 and h != feature_slot) else t
+        if h == feature_slot:
+            return self.feats(h)
+        return lib.frag_to_rows(self.saved[h], self.m, torch.float16 if self.f16 else torch.float32)
+
+
+def _storage(owner, fast: bool):
+    """(f16 activations, fragment order, bf16 gradients) for a 16-bit training forward of ``owner`` (model or VF net)."""
+    if not fast:
+        return False, False, False
+    return (getattr(owner, "activation_storage", "fp32") == "f16", getattr(owner, "workspace_layout", "fragment") == "fragment",
+            getattr(owner, "gradient_storage", "fp32") == "bf16")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -198,12 +259,16 @@ class _FinePass(torch.autograd.Function):
         dev = pts.device
         vf_h, rn_h = len(_entries(vf)), len(_entries(rn))
         fast = model.uses_f16x3() and m < _F16_TRAIN_MAX_POINTS
-        ws = _Workspace(m, vf_h + rn_h, dev, f16=fast and getattr(model, "activation_storage", "fp32") == "f16")
+        # ``backward_kernels = "fp32"`` (diagnostic): the f16x3 forward with a row-major fp32 workspace, which the exact-fp32
+        # backward kernels read — the same forward under both backward arithmetics (tests/test_hip_fullsize.py)
+        bwd_fast = fast and getattr(model, "backward_kernels", "auto") != "fp32"
+        f16, frag, dy16 = _storage(model, bwd_fast)
+        ws = _Workspace(m, vf_h + rn_h, dev, f16=f16, frag=frag, dy16=dy16)
         scal = model.density.raw_scalars()
         if fast:                                               # split-half products, fp32-equivalent (csrc/vfn_mlp16.hip)
             normals, colors = lib.vf_render_fused16_fwd_train(vf.geometry(), vf.packed16_weights(), rn.geometry(),
                                                               rn.packed16_weights(), pts.reshape(-1, 3), ray_dirs, s_t,
-                                                              ws.saved, ws.aux_vf, ws.aux_rn, ws.masks, save_f16=ws.f16)
+                                                              ws.saved, ws.aux_vf, ws.aux_rn, ws.masks, save_f16=ws.fwd_flags())
         else:
             normals, colors = lib.vf_render_fused_fwd_train(vf.geometry(), vf.packed_weights(), rn.geometry(),
                                                             rn.packed_weights(), pts.reshape(-1, 3), ray_dirs, s_t,
@@ -213,9 +278,10 @@ class _FinePass(torch.autograd.Function):
                                                             want_sigma=False)
         if getattr(model, "_keep_saved", False):   # test hook: expose the saved activations
             model._debug_saved = ws.saved
+            model._debug_ws = ws
             model._debug_masks = ws.masks if fast else None
         ctx.model, ctx.ws, ctx.dims, ctx.param_order = model, ws, (n, s_t, m, vf_h, rn_h), list(params)
-        ctx.fast = fast            # the backward must run the kernels that match what THIS forward wrote (masks, f16 slots)
+        ctx.fast = bwd_fast        # the backward must run the kernels that match what THIS forward wrote (masks, f16 slots)
         ctx.save_for_backward(normals, colors, z, ray_dirs, scal)
         return normals, colors, rgb, depth, weights
 
@@ -239,22 +305,24 @@ class _FinePass(torch.autograd.Function):
         if d_colors_direct is not None:
             dc = dc + d_colors_direct.reshape(m, 3)
         # (2) dX chain through the rendering net, the feature hand-off and the VF net
-        dy = torch.empty(vf_h + rn_h, m, HID, device=dev)
+        dy = ws.new_dy()
         dz_rgb = torch.empty(m, 4, device=dev)
         dz_vec = torch.empty(m, 4, device=dev)
         fast = ctx.fast
         if fast:
-            lib.mlp_bwd_chain_bf16(vf.geometry(), _packed_bwd16(vf), _head_rows(vf), rn.geometry(), _packed_bwd16(rn),
-                                   _head_rows(rn), ws.saved, ws.masks, dy, dc, colors, dn, normals, None, 3, m, dz_rgb, dz_vec)
+            lib.mlp_bwd_chain_bf16_ws(vf.geometry(), _packed_bwd16(vf), _head_rows(vf), rn.geometry(), _packed_bwd16(rn),
+                                      _head_rows(rn), ws.feats(vf_h - 1), ws.masks, dy, ws.dy_flags(), dc, colors, dn, normals, None, 3, m,
+                                      dz_rgb, dz_vec)
         else:
             lib.mlp_bwd_chain(vf.geometry(), vf.packed_weights(), _packed_bwd(vf), rn.geometry(), rn.packed_weights(),
                               _packed_bwd(rn), ws.saved, dy, dc, colors, dn, normals, None, 3, m, dz_rgb, dz_vec)
         # (3) weight gradients
+        feats = ws.feats(vf_h - 1) if fast else ws.saved[vf_h - 1]
         g_vf = _weight_grads(vf, _vf_inputs(vf, [ws.saved[h] for h in range(vf_h)]), [dy[h] for h in range(vf_h)],
-                             ws.aux_vf, dz_vec, m, fast=fast, x_f16=ws.f16)
-        g_rn = _weight_grads(rn, _rn_inputs(ws.saved[vf_h - 1], [ws.saved[vf_h + h] for h in range(rn_h)]),
+                             ws.aux_vf, dz_vec, m, fast=fast, x_f16=ws.f16, frag=ws.frag_forms())
+        g_rn = _weight_grads(rn, _rn_inputs(feats, [ws.saved[vf_h + h] for h in range(rn_h)]),
                              [dy[vf_h + h] for h in range(rn_h)], ws.aux_rn, dz_rgb, m, fast=fast, x_f16=ws.f16,
-                             x_fp32_entries=(0,))
+                             x_fp32_entries=(0,), frag=ws.frag_forms())
         # density scalars in density.parameters() order
         by_name = {"beta": dscal[0], "mean": dscal[1], "scale": dscal[2]}
         g_den = {p: by_name[name].reshape(p.shape) for name, p in model.density.named_parameters()}
@@ -284,16 +352,18 @@ class _VFForward(torch.autograd.Function):
         vf_h = len(_entries(net))
         cols = 3 if (vector_only or not has_feat) else 3 + net._feature_dims()
         fast = getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3() and m < _F16_TRAIN_MAX_POINTS
-        ws = _Workspace(m, vf_h, dev, f16=fast and getattr(net, "activation_storage", "fp32") == "f16")
+        bwd_fast = fast and getattr(net, "backward_kernels", "auto") != "fp32"
+        f16, frag, dy16 = _storage(net, bwd_fast)
+        ws = _Workspace(m, vf_h, dev, f16=f16, frag=frag, dy16=dy16)
         if fast:
             out = lib.vf_mlp16_fwd_train(net.geometry(), net.packed16_weights(), pts, cols > 3, ws.saved, ws.aux_vf, ws.masks,
-                                         save_f16=ws.f16)
+                                         save_f16=ws.fwd_flags())
             if cols > 3:   # [vector | features]: the kernel left the features in their workspace slot
-                out = torch.cat([out, ws.saved[vf_h - 1]], dim=1)
+                out = torch.cat([out, ws.feats(vf_h - 1)], dim=1)
         else:
             out = lib.vf_mlp_fwd_train(net.geometry(), net.packed_weights(), pts, cols, ws.saved, ws.aux_vf)
         ctx.net, ctx.ws, ctx.dims, ctx.param_order = net, ws, (m, vf_h, cols), list(params)
-        ctx.fast = fast            # not re-derived in backward: net.precision may have changed in between (numerical Jacobian)
+        ctx.fast = bwd_fast        # not re-derived in backward: net.precision may have changed in between (numerical Jacobian)
         ctx.save_for_backward(out)
         return out
 
@@ -304,22 +374,22 @@ class _VFForward(torch.autograd.Function):
         (out,) = ctx.saved_tensors
         dev = out.device
         d_out = d_out.float().contiguous()
-        dy = torch.empty(vf_h, m, HID, device=dev)
+        dy = ws.new_dy()
         dz_vec = torch.empty(m, 4, device=dev)
         d_feats = None
         if cols > 3:
             d_feats = _offset_view(d_out, 3)
         fast = ctx.fast
         if fast:
-            lib.mlp_bwd_chain_bf16(net.geometry(), _packed_bwd16(net), _head_rows(net), None, None, None, ws.saved, ws.masks, dy,
-                                   None, None, d_out, out, d_feats, cols, m, None, dz_vec)
+            lib.mlp_bwd_chain_bf16_ws(net.geometry(), _packed_bwd16(net), _head_rows(net), None, None, None, ws.feats(vf_h - 1), ws.masks,
+                                      dy, ws.dy_flags(), None, None, d_out, out, d_feats, cols, m, None, dz_vec)
         else:
             lib.mlp_bwd_chain(net.geometry(), net.packed_weights(), _packed_bwd(net), None, None, None, ws.saved, dy,
                               None, None, d_out, out, d_feats, cols, m, None, dz_vec)
         # vector-only forward: the feature block of the last Linear was never evaluated -> no gradient for it
         skip = (vf_h - 1,) if (net._feature_dims() > 0 and cols == 3) else ()
         grads = _weight_grads(net, _vf_inputs(net, [ws.saved[h] for h in range(vf_h)]), [dy[h] for h in range(vf_h)],
-                              ws.aux_vf, dz_vec, m, skip=skip, fast=fast, x_f16=ws.f16)
+                              ws.aux_vf, dz_vec, m, skip=skip, fast=fast, x_f16=ws.f16, frag=ws.frag_forms())
         ctx.ws = None
         return (None, None, None, *[grads.get(p) for p in ctx.param_order])
 

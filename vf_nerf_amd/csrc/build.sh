@@ -9,7 +9,7 @@ OUT=${VFN_OUT:-libvfn.so}
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=${ARCH} -Wall -Wno-unused-function"
 # vfn_mlp16 / vfn_bwd16: accumulators in arch VGPRs (all AGPRs hold activations), full unrolling of the K loops
 MFMA16="-mllvm -amdgpu-mfma-vgpr-form -mllvm -pragma-unroll-threshold=10000000"
-UNITS="vfn_pack vfn_mlp vfn_mlp_bwd vfn_dw16 vfn_unfold vfn_bwd16 vfn_mlp16 vfn_rays vfn_grid vfn_bstat"
+UNITS="vfn_pack vfn_mlp vfn_mlp_bwd vfn_dw16 vfn_dwf vfn_unfold vfn_bwd16 vfn_mlp16 vfn_rays vfn_grid vfn_bstat vfn_adam"
 
 extra_flags() {
   case "$1" in
@@ -31,7 +31,7 @@ for u in $UNITS; do
   [ -f "$u.hip" ] || { echo "build.sh: missing source $u.hip" >&2; exit 1; }
   rm -f "$OBJDIR/$u.o"
   # shellcheck disable=SC2046
-  hipcc $FLAGS $(extra_flags "$u") -c "$u.hip" -o "$OBJDIR/$u.o" &
+  hipcc $FLAGS $(extra_flags "$u") -Rpass-analysis=kernel-resource-usage -c "$u.hip" -o "$OBJDIR/$u.o" 2> "$OBJDIR/$u.remarks" &
   PIDS[$u]=$!
   OBJS="$OBJS $OBJDIR/$u.o"
 done
@@ -40,7 +40,32 @@ for u in $UNITS; do
   if ! wait "${PIDS[$u]}"; then failed="$failed $u.hip"; fi
 done
 if [ -n "$failed" ]; then
+  for f in $failed; do grep -E "error|Error" "$OBJDIR/${f%.hip}.remarks" | head -20 >&2; done
   echo "build.sh: compile FAILED for:$failed" >&2
+  rm -f "$OUT"
+  exit 1
+fi
+# The hand-pipelined one-wave-per-SIMD kernels live on the edge of the register file: a spill (scratch) does not break them,
+# it makes them 1.6x slower without any other symptom (it happened: one loop-carried VGPR in the f16x3 epilogue).  Fail the build.
+spilled=$(python3 - "$OBJDIR" <<'PY'
+import re, sys, os
+bad = []
+for unit in ("vfn_mlp16", "vfn_bwd16", "vfn_dwf", "vfn_dw16"):
+    path = os.path.join(sys.argv[1], unit + ".remarks")
+    name = None
+    for line in open(path, errors="replace"):
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name and "_kernel" in name and "pack" not in name and int(m.group(1)) > 0:
+            bad.append(f"{unit}: {name} uses {m.group(1)} bytes/lane of scratch")
+print("\n".join(bad))
+PY
+)
+if [ -n "$spilled" ]; then
+  echo "build.sh: register spills in a hot kernel:" >&2
+  echo "$spilled" >&2
   rm -f "$OUT"
   exit 1
 fi

@@ -147,7 +147,9 @@ struct Bwd16Args {
     const uint4* rn_wt;
     const float* vf_head;     // [3][256] rows 0..2 of the VF net's last Linear
     const float* rn_head;     // [3][256] the rendering net's last Linear
-    const float* saved;       // [13][M][256]  (read only for the tanh'ed feature block, slot 8)
+    const float* feats;       // [M][256] the tanh'ed features (workspace slot 8, row-major fp32): the one slot read as values
+    int dy_flags;             // bit 1: dY in FRAGMENT ORDER ([group of 32 points][tile, register quad][lane][16 B], see
+                              // csrc/vfn_dwf.hip) instead of row-major [M][256]; bit 2 (fragment order only): stored as bf16 (8 B)
     const uint32_t* masks;    // [13][M][2][4] u32: sign bits of the saved ReLU outputs (written by the training forwards)
     float* dy;                // [13][M][256]
     const float* d_colors; const float* colors;      // [M,3]
@@ -164,9 +166,13 @@ struct Pipe {
     uint4* lds;
     const float* heads;              // LDS: [2][3][256] head weights (0 = vector head, 1 = rgb head)
     __amdgpu_buffer_rsrc_t vf_w, rn_w;
-    const float* saved; float* dy;
-    long long slot_floats; uint32_t slot_bytes;
-    uint32_t voff;                   // m * 1024 + 16 * (lane >> 5); out of range for m >= M
+    const float* feats; float* dy;
+    long long slot_floats; uint32_t slot_bytes;    // one dY slot
+    uint32_t feat_bytes;             // M * 1024
+    uint32_t voff;                   // feature loads (row-major): m * 1024 + 16 * (lane >> 5); out of range for m >= M
+    uint32_t dvoff;                  // dY stores: row-major = voff; fragment order (m >> 5) * 32768 + 16 (8 as bf16) * lane
+    uint32_t st_tile, st_q;          // byte strides of (tile, register quad) of a dY slot for fp32 stores (bf16: half)
+    int dy16;                        // dY leaves as bf16
     u32x4 mw[13];                    // this lane's sign-bit words, one per slot: tile t -> half t & 1 of dword t >> 1, bit r <-> register r
 };
 
@@ -203,8 +209,8 @@ __device__ __forceinline__ void prefetch_chunk(Carry& cy, const Pipe& p, int lan
 // workspace access: registers 4q..4q+3 of a tile = columns 32 TILE + 8 q + 4 (lane >> 5) .. +3 of this lane's point
 template <int SLOT, int TILE>
 __device__ __forceinline__ f32x4v load_group(const Pipe& p, int q) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.saved) + (long long)SLOT * p.slot_floats, 0,
-                                                                        (int)p.slot_bytes, 0x00020000);
+    static_assert(SLOT == 8, "only the tanh'ed feature block is read back as values");
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.feats), 0, (int)p.feat_bytes, 0x00020000);
     return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)p.voff, (32 * TILE + 8 * q) * 4, 0));
 }
 // what the epilogue multiplies by: for ReLU layers 1 / 0 from the sign bits (no memory access), for the tanh'ed feature
@@ -222,7 +228,14 @@ template <int SLOT, int TILE>
 __device__ __forceinline__ void store_group(const Pipe& p, const f32x16& v, int q) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.dy + (long long)SLOT * p.slot_floats, 0, (int)p.slot_bytes, 0x00020000);
     const f32x4v g = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)p.voff, (32 * TILE + 8 * q) * 4, 0);
+    if (p.dy16) {                     // bf16 (round to nearest even): half the bytes, 8 significant bits in ONE factor of dW = dY^T X
+        typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const bf4 b = __builtin_convertvector(g, bf4);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, b), rs, (int)p.dvoff, (int)((TILE * p.st_tile + q * p.st_q) >> 1), 0);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)p.dvoff, (int)(TILE * p.st_tile + q * p.st_q), 0);
+    }
 }
 
 // One register pair of a finished tile: (+ head rank-3 update) * activation derivative -> pend (for the store) and the
@@ -407,8 +420,15 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
     p.vf_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.vf_wt), 0, vf_pack_kb() * 1024, 0x00020000);
     p.rn_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>((MODE & 2) ? a.rn_wt : a.vf_wt), 0,
                                                ((MODE & 2) ? rn_pack_kb() : vf_pack_kb()) * 1024, 0x00020000);
-    p.saved = a.saved; p.dy = a.dy; p.slot_floats = a.n_points * 256; p.slot_bytes = (uint32_t)(a.n_points * 1024);
+    const bool frag = (a.dy_flags & 2) != 0;
+    p.dy16 = frag && (a.dy_flags & 4) != 0;
+    p.feats = a.feats; p.dy = a.dy; p.feat_bytes = (uint32_t)(a.n_points * 1024);
+    p.slot_floats = frag ? ((a.n_points + 31) >> 5) * 8192 : a.n_points * 256;
+    p.slot_bytes = (uint32_t)(p.slot_floats * 4);
     p.voff = in ? (uint32_t)(m * 1024 + g * 16) : 0xfffffff0u;
+    // (fragment order adds scalar offsets of up to 32 KiB: the out-of-range value must not wrap; slots are limited to 2 GiB)
+    p.dvoff = !frag ? p.voff : (in ? (uint32_t)((m >> 5) * 32768 + lane * (p.dy16 ? 8 : 16)) : 0xc0000000u);
+    p.st_tile = frag ? 4096u : 128u; p.st_q = frag ? 1024u : 32u;
     {   // sign bits of every ReLU layer this launch walks through: 16 bytes per slot, all requested now, in registers for good
         const unsigned mbytes = (unsigned)(a.n_points * 32);
         const unsigned mvoff = in ? (unsigned)((2 * m + g) * 16) : 0xfffffff0u;
@@ -559,6 +579,17 @@ extern "C" int vfn_mlp_bwd_chain_bf16(const vfn_net_geom* vf_geom, const void* v
                                       const float* saved, const uint32_t* masks, float* dy, const float* d_colors, const float* colors,
                                       const float* d_vec, const float* vec, const float* d_feats, int32_t vec_stride,
                                       int64_t n_points, float* dz_rgb, float* dz_vec, void* stream) {
+    // row-major workspace: the features are slot 8 of saved[13][M][256]
+    return vfn_mlp_bwd_chain_bf16_ws(vf_geom, vf_packed_bwd16, vf_head_w, rn_geom, rn_packed_bwd16, rn_head_w,
+                                     saved ? saved + (size_t)8 * (size_t)(n_points > 0 ? n_points : 0) * 256 : nullptr, masks, dy, 0, d_colors, colors,
+                                     d_vec, vec, d_feats, vec_stride, n_points, dz_rgb, dz_vec, stream);
+}
+
+extern "C" int vfn_mlp_bwd_chain_bf16_ws(const vfn_net_geom* vf_geom, const void* vf_packed_bwd16, const float* vf_head_w,
+                                         const vfn_net_geom* rn_geom, const void* rn_packed_bwd16, const float* rn_head_w,
+                                         const float* saved, const uint32_t* masks, void* dy, int32_t dy_flags, const float* d_colors,
+                                         const float* colors, const float* d_vec, const float* vec, const float* d_feats,
+                                         int32_t vec_stride, int64_t n_points, float* dz_rgb, float* dz_vec, void* stream) {
     VFN_REQUIRE(vf_geom, "vfn_mlp_bwd_chain_bf16: NULL argument");
     int rc = check_shipped(VFN_NET_VF, vf_geom, "vfn_mlp_bwd_chain_bf16");
     if (rc != VFN_OK) return rc;
@@ -571,10 +602,12 @@ extern "C" int vfn_mlp_bwd_chain_bf16(const vfn_net_geom* vf_geom, const void* v
     if (n_points <= 0) return VFN_OK;
     VFN_REQUIRE(vf_packed_bwd16 && vf_head_w && saved && masks && dy && d_vec && vec && dz_vec, "vfn_mlp_bwd_chain_bf16: NULL argument");
     VFN_REQUIRE(vec_stride >= 3, "vfn_mlp_bwd_chain_bf16: vec_stride must be >= 3");
-    VFN_REQUIRE(n_points < (1ll << 22), "vfn_mlp_bwd_chain_bf16: at most 4194303 points per launch (32-bit slot offsets)");
+    VFN_REQUIRE(n_points < ((dy_flags & 2) ? (1ll << 21) : (1ll << 22)), "vfn_mlp_bwd_chain_bf16: at most %lld points per launch (32-bit slot offsets)",
+                ((dy_flags & 2) ? (1ll << 21) : (1ll << 22)) - 1);
+    VFN_REQUIRE(!(dy_flags & 4) || (dy_flags & 2), "vfn_mlp_bwd_chain_bf16: bf16 gradients need the fragment-ordered layout");
     Bwd16Args a = {};
     a.vf_wt = (const uint4*)vf_packed_bwd16; a.rn_wt = (const uint4*)rn_packed_bwd16; a.vf_head = vf_head_w; a.rn_head = rn_head_w;
-    a.saved = saved; a.masks = masks; a.dy = dy; a.d_colors = d_colors; a.colors = colors; a.d_vec = d_vec; a.vec = vec; a.d_feats = d_feats;
+    a.feats = saved; a.dy_flags = dy_flags & 6; a.masks = masks; a.dy = (float*)dy; a.d_colors = d_colors; a.colors = colors; a.d_vec = d_vec; a.vec = vec; a.d_feats = d_feats;
     a.dz_rgb = dz_rgb; a.dz_vec = dz_vec; a.n_points = n_points; a.vec_stride = vec_stride;
     const unsigned blocks = (unsigned)((n_points + BW_PTS - 1) / BW_PTS);
     hipStream_t s = (hipStream_t)stream;

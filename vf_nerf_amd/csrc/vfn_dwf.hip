@@ -1,0 +1,366 @@
+// vfn_dwf.hip — weight gradients of the training step from the FRAGMENT-ORDERED workspace.
+//
+// dW'[n][k] = sum_m dY[m][n] X[m][k], db'[n] = sum_m dY[m][n] per slab of points — the autograd of the Linear layers of
+// models/vector_field/vector_field_network.py:177-208 and rendering_network.py:62-108 under
+// train/vector_field_nerf_train.py:252 — like vfn_dw16.hip (256 x 256 layers, split-bf16 products on
+// v_mfma_f32_32x32x16_bf16, LDS images read back with the transposing ds_read_b64_tr_b16), but for the layout the f16x3
+// training forward and the bf16 dX chain now WRITE their tiles in:
+//
+//   slot s, group G = m >> 5 (the 32 points of one wave), 32 KiB per group:
+//       piece (t, q) = registers 4q .. 4q+3 of output tile t, exactly as the producing wave holds them:
+//       [4 t + q][lane 0..63][16 B]   lane = 32 g + i  ->  point 32 G + i, columns 32 t + 8 q + 4 g .. + 3        (fp32)
+//       [4 t + q][lane 0..63][ 8 B]   the same four values as f16 (activations) or bf16 (gradients)               (16 bit)
+//   so that every store instruction of the producers and every load instruction here moves 1 KiB (512 B) of consecutive
+//   bytes; the row-major layout made each store touch 32 lines with 32 (16) bytes each (Backward).
+//
+// The transposing read wants image rows 576 bytes apart (rows shift by 16 banks); fragment-ordered pieces arrive with the
+// POINT on the lane index, i.e. a wave-instruction writes 32 different image rows at one column group, which on that
+// stride is an 8-way bank conflict.  So the 8-byte chunks of every image row are XOR-swizzled with the row number:
+// chunk' = chunk ^ ((row >> 1) & 7) — a permutation inside each aligned run of 8 chunks, which keeps the transposed reads
+// conflict-free (each 32-lane half still covers 4 rows x 16 distinct dwords, 16 banks apart) and makes the writes
+// conflict-free too (16 lanes = 8 row pairs x 2 bank halves).
+//
+// One kernel, three shapes (what vfn_weight_grad_partials calls shapes 0 / 1 / 2):
+//   0   256 x 256    A = dY (8 tiles), B = X (8 tiles): wave (wn, wk) owns 4 x 4 tiles
+//   1   256 x 64     A = dY (8 tiles), B = the encoding tile aux[M][40] (row-major fp32, zero-padded to 2 tiles): 2 x 2 per wave
+//   2    32 x 256    A = the head's pre-activation gradient dz[M][4] (row-major fp32, 1 tile), B = X (8 tiles): 1 x 2 per wave
+// and the operand forms: dY fragment fp32 | fragment bf16 | dz rows; X fragment fp32 | fragment f16 | [M][256] fp32 rows (the
+// tanh'ed features, which stay row-major) | aux rows.  A bf16 dY has no low half (two products per K-block instead of
+// three); an f16 X splits exactly into bf16 hi + lo.
+#include <string.h>
+#include "vfn_common.h"
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef short s8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int F_STEP = 32;                      // points per step = one workspace group (two K-blocks of 16)
+constexpr int F_ROW = 576;                      // bytes between image rows
+constexpr int F_IMG = F_STEP * F_ROW;           // one [32][<=256] bf16 image
+constexpr int F_BUF = 4 * F_IMG;                // (dY | X) x (hi | lo)
+constexpr int F_GROUP = 32768;                  // bytes of one workspace group
+
+enum : int { X_FRAG32 = 0, X_FRAG16 = 1, X_ROWS32 = 2, X_AUX40 = 3 };
+enum : int { DY_FRAG32 = 0, DY_FRAGBF16 = 1, DY_DZ4 = 2 };
+
+struct DwfArgs {
+    const void* dy;
+    const void* x;
+    float* dw_part;       // [G][n_out][ld_out]
+    float* db_part;       // [G][n_out] or NULL
+    long long n_points;
+};
+
+typedef __attribute__((address_space(3))) s4 lds_s4;
+
+__device__ __forceinline__ bf8 tr_frag(const unsigned char* img, int off1, int off2) {
+    const s4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(img + off1));
+    const s4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(img + off2));
+    const s8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf8, v);
+}
+
+// four fp32 values -> 4 bf16 "hi" (truncated: v - hi is exact) and 4 bf16 "lo" (rounded)
+__device__ __forceinline__ void split4(const f32x4v v, uint2& hi, uint2& lo) {
+    const u32x4 u = __builtin_bit_cast(u32x4, v);
+    const unsigned u0 = u[0], u1 = u[1], u2 = u[2], u3 = u[3];
+    hi.x = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    hi.y = __builtin_amdgcn_perm(u3, u2, 0x07060302u);
+    const f32x2v r01 = {v[0] - __builtin_bit_cast(float, u0 & 0xffff0000u), v[1] - __builtin_bit_cast(float, u1 & 0xffff0000u)};
+    const f32x2v r23 = {v[2] - __builtin_bit_cast(float, u2 & 0xffff0000u), v[3] - __builtin_bit_cast(float, u3 & 0xffff0000u)};
+    lo.x = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf2));
+    lo.y = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf2));
+}
+
+// byte offset of 8-byte chunk `chunk` of image row `row` (chunks XOR-swizzled inside aligned runs of 8)
+__device__ __forceinline__ int img_off(int row, int chunk) { return row * F_ROW + ((chunk ^ ((row >> 1) & 7)) << 3); }
+
+template <int SHAPE, int XM, int DM>
+__global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfArgs a) {
+    constexpr bool A_FRAG = DM != DY_DZ4;
+    constexpr bool B_FRAG = XM == X_FRAG32 || XM == X_FRAG16;
+    constexpr bool A_LO = DM != DY_FRAGBF16;                    // a bf16 gradient has no low half
+    constexpr int NA = SHAPE == 0 ? 4 : (SHAPE == 1 ? 2 : 1);   // A / B tiles per wave
+    constexpr int NB = SHAPE == 0 ? 4 : 2;
+    constexpr int LD_OUT = SHAPE == 1 ? 64 : 256, N_OUT = SHAPE == 2 ? 32 : 256;
+    static_assert((SHAPE == 1) == (XM == X_AUX40) && (SHAPE == 2) == (DM == DY_DZ4), "shape / operand form mismatch");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * F_BUF];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x, g = blockIdx.x;
+    const long long steps = (a.n_points + F_STEP - 1) / F_STEP;
+    const long long per = (steps + G - 1) / G;
+    const long long s0 = g * per, s1 = min(steps, s0 + per);
+    const int at0 = SHAPE == 0 ? 4 * (wave >> 1) : (SHAPE == 1 ? 2 * wave : 0);     // first A / B tile of this wave
+    const int bt0 = SHAPE == 0 ? 4 * (wave & 1) : (SHAPE == 1 ? 0 : 2 * wave);
+
+    f32x16 acc[NA][NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+    float bsum[A_FRAG ? 8 : 1][4];                              // column sums of dY over this lane's points, per staged piece
+#pragma unroll
+    for (int r = 0; r < (A_FRAG ? 8 : 1); ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bsum[r][c] = 0.f;
+
+    // images with fewer than 256 columns: the columns nobody stages must read as zero
+    if (XM == X_AUX40 || DM == DY_DZ4) {
+        for (int i = tid; i < 2 * F_BUF / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = uint4{0u, 0u, 0u, 0u};
+        __syncthreads();
+    }
+
+    // slab-relative descriptors: groups / rows past the end of the slab read as zero
+    const long long n_steps = max(0LL, s1 - s0);
+    const long long r_base = s0 * F_STEP;
+    const long long rows_slab = max(0LL, min(n_steps * F_STEP, a.n_points - r_base));
+    const __amdgpu_buffer_rsrc_t rs_a = A_FRAG
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(static_cast<const unsigned char*>(a.dy)) + (size_t)s0 * F_GROUP, 0,
+                                            (int)(n_steps * F_GROUP), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(static_cast<const unsigned char*>(a.dy)) + (size_t)r_base * 16, 0,
+                                            (int)(rows_slab * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = B_FRAG
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(static_cast<const unsigned char*>(a.x)) + (size_t)s0 * F_GROUP, 0,
+                                            (int)(n_steps * F_GROUP), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(static_cast<const unsigned char*>(a.x)) +
+                                                (size_t)r_base * (XM == X_AUX40 ? 160 : 1024), 0,
+                                            (int)(rows_slab * (XM == X_AUX40 ? 160 : 1024)), 0x00020000);
+
+    u32x4 ld_a[A_FRAG ? 8 : 1], ld_b[(B_FRAG || XM == X_ROWS32) ? 8 : 2];
+    auto issue = [&](long long s) {
+        const int st = (int)(s - s0);
+        if constexpr (A_FRAG) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int pc = 8 * wave + r;
+                if (DM == DY_FRAG32) ld_a[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, lane * 16, st * F_GROUP + pc * 1024, 0);
+                else { const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rs_a, lane * 8, st * F_GROUP + pc * 512, 0); ld_a[r] = u32x4{h[0], h[1], 0u, 0u}; }
+            }
+        } else {
+            ld_a[0] = tid < 32 ? __builtin_amdgcn_raw_buffer_load_b128(rs_a, tid * 16, st * F_STEP * 16, 0) : u32x4{0u, 0u, 0u, 0u};
+        }
+        if constexpr (B_FRAG) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int pc = 8 * wave + r;
+                if (XM == X_FRAG32) ld_b[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, lane * 16, st * F_GROUP + pc * 1024, 0);
+                else { const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rs_b, lane * 8, st * F_GROUP + pc * 512, 0); ld_b[r] = u32x4{h[0], h[1], 0u, 0u}; }
+            }
+        } else if constexpr (XM == X_ROWS32) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) ld_b[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, lane * 16, (st * F_STEP + 8 * wave + r) * 1024, 0);
+        } else {            // aux rows: 32 x 40 floats = 320 16-byte chunks
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int idx = tid + 256 * k;
+                const int row = idx / 10, ch = idx - 10 * row;
+                ld_b[k] = idx < 320 ? __builtin_amdgcn_raw_buffer_load_b128(rs_b, (st * F_STEP + row) * 160 + ch * 16, 0, 0) : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    const int gi = lane >> 5, pi = lane & 31;                   // fragment pieces: lane half (column group) and point inside the group
+    auto stage = [&](int buf, long long s) {                    // split + write what this thread loaded into the images of `buf`
+        unsigned char* base = lds + buf * F_BUF;
+        const bool live = s * F_STEP + pi < a.n_points;         // the last group may be partial: its missing points count as zero
+        if constexpr (A_FRAG) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int pc = 8 * wave + r, t = pc >> 2, q = pc & 3;
+                f32x4v v;
+                if (DM == DY_FRAG32) v = __builtin_bit_cast(f32x4v, ld_a[r]);
+                else { const u32x2 h = {ld_a[r][0], ld_a[r][1]}; v = __builtin_convertvector(__builtin_bit_cast(bf4, h), f32x4v); }
+                if (!live) v = f32x4v{0.f, 0.f, 0.f, 0.f};
+                const int off = img_off(pi, 8 * t + 2 * q + gi);
+                if (DM == DY_FRAG32) {
+                    uint2 hi, lo;
+                    split4(v, hi, lo);
+                    *reinterpret_cast<uint2*>(base + 0 * F_IMG + off) = hi;
+                    *reinterpret_cast<uint2*>(base + 1 * F_IMG + off) = lo;
+                } else {
+                    *reinterpret_cast<uint2*>(base + 0 * F_IMG + off) = live ? uint2{ld_a[r][0], ld_a[r][1]} : uint2{0u, 0u};
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) bsum[r][c] += v[c];
+            }
+        } else if (tid < 32) {
+            const f32x4v v = __builtin_bit_cast(f32x4v, ld_a[0]);
+            uint2 hi, lo;
+            split4(v, hi, lo);
+            *reinterpret_cast<uint2*>(base + 0 * F_IMG + img_off(tid, 0)) = hi;
+            *reinterpret_cast<uint2*>(base + 1 * F_IMG + img_off(tid, 0)) = lo;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bsum[0][c] += v[c];
+        }
+        if constexpr (B_FRAG) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int pc = 8 * wave + r, t = pc >> 2, q = pc & 3;
+                f32x4v v;
+                if (XM == X_FRAG32) v = __builtin_bit_cast(f32x4v, ld_b[r]);
+                else { const u32x2 h = {ld_b[r][0], ld_b[r][1]}; v = __builtin_convertvector(__builtin_bit_cast(half4, h), f32x4v); }
+                if (!live) v = f32x4v{0.f, 0.f, 0.f, 0.f};
+                uint2 hi, lo;
+                split4(v, hi, lo);
+                const int off = img_off(pi, 8 * t + 2 * q + gi);
+                *reinterpret_cast<uint2*>(base + 2 * F_IMG + off) = hi;
+                *reinterpret_cast<uint2*>(base + 3 * F_IMG + off) = lo;
+            }
+        } else if constexpr (XM == X_ROWS32) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                uint2 hi, lo;
+                split4(__builtin_bit_cast(f32x4v, ld_b[r]), hi, lo);
+                const int off = img_off(8 * wave + r, lane);
+                *reinterpret_cast<uint2*>(base + 2 * F_IMG + off) = hi;
+                *reinterpret_cast<uint2*>(base + 3 * F_IMG + off) = lo;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int idx = tid + 256 * k;
+                if (idx < 320) {
+                    const int row = idx / 10, ch = idx - 10 * row;
+                    uint2 hi, lo;
+                    split4(__builtin_bit_cast(f32x4v, ld_b[k]), hi, lo);
+                    *reinterpret_cast<uint2*>(base + 2 * F_IMG + img_off(row, ch)) = hi;
+                    *reinterpret_cast<uint2*>(base + 3 * F_IMG + img_off(row, ch)) = lo;
+                }
+            }
+        }
+    };
+    // transposed-read addresses of this lane inside a 32-column tile and a 16-row K-block (cdna_hip_programming.md T10): lane
+    // 4 q + p of a 16-lane group supplies row q, columns 4 p .. 4 p + 3; groups 0 / 1 = columns 0-15 / 16-31, lane halves =
+    // rows +0 / +8; the second read takes rows +4.  The swizzle term (row >> 1) & 7 does not depend on the K-block.
+    const int q_ = (lane & 15) >> 2, p_ = lane & 3, cg = (lane >> 4) & 1, h = lane >> 5;
+    const int tr1 = img_off(8 * h + q_, 4 * cg + p_), tr2 = img_off(8 * h + q_ + 4, 4 * cg + p_);
+
+    auto mma = [&](int buf, int kb) {
+        const unsigned char* img = lds + buf * F_BUF + kb * 16 * F_ROW;
+        bf8 ah[NA], al[NA], bh[NB], bl[NB];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            ah[i] = tr_frag(img + 0 * F_IMG + (at0 + i) * 64, tr1, tr2);
+            if (A_LO) al[i] = tr_frag(img + 1 * F_IMG + (at0 + i) * 64, tr1, tr2);
+        }
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            bh[t] = tr_frag(img + 2 * F_IMG + (bt0 + t) * 64, tr1, tr2);
+            bl[t] = tr_frag(img + 3 * F_IMG + (bt0 + t) * 64, tr1, tr2);
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[t], acc[i][t], 0, 0, 0);
+                acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[t], acc[i][t], 0, 0, 0);
+                if (A_LO) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[t], acc[i][t], 0, 0, 0);
+            }
+    };
+
+    if (s0 < s1) {
+        issue(s0);
+        stage(0, s0);
+        __syncthreads();
+    }
+    for (long long s = s0; s < s1; ++s) {
+        const int buf = (int)(s - s0) & 1;
+        const bool more = s + 1 < s1;
+        if (more) issue(s + 1);
+        mma(buf, 0);
+        if (more) stage(buf ^ 1, s + 1);      // the other buffer was last read in step s-1; every wave passed that step's barrier
+        mma(buf, 1);
+        __syncthreads();
+    }
+
+    // partial slab: D row = n (A operand's row), column = k (B operand's column)
+    float* out = a.dw_part + (size_t)g * N_OUT * LD_OUT;
+    const int c = lane & 31;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = 32 * (at0 + i) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(size_t)n * LD_OUT + 32 * (bt0 + t) + c] = acc[i][t][r];
+            }
+    if (a.db_part) {
+        if constexpr (A_FRAG) {                // piece r of this wave = columns 32 t + 8 q + 4 g + c; sum over the 32 points of a lane half
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    float v = bsum[r][cc];
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    const int pc = 8 * wave + r, t = pc >> 2, q = pc & 3;
+                    if (pi == 0) a.db_part[(size_t)g * N_OUT + 32 * t + 8 * q + 4 * gi + cc] = v;
+                }
+        } else if (wave == 0) {                // dz rows: threads 0..31 hold one row each; the head has 4 (3 used) outputs
+            float keep[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                float v = lane < 32 ? bsum[0][cc] : 0.f;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                keep[cc] = v;
+            }
+            if (lane < 32) a.db_part[(size_t)g * N_OUT + lane] = lane < 4 ? keep[lane & 3] : 0.f;
+        }
+    }
+}
+
+template <int SHAPE, int XM, int DM>
+int launch(const DwfArgs& a, int groups, hipStream_t s) {
+    hipLaunchKernelGGL((vfn_dwf_kernel<SHAPE, XM, DM>), dim3(groups), dim3(256), 0, s, a);
+    return vfn_check_launch("vfn_weight_grad_frag");
+}
+
+}  // namespace
+
+extern "C" int vfn_weight_grad_frag(int32_t shape, const void* dy, int32_t dy_form, const void* x, int32_t x_form, int64_t n_points,
+                                    int32_t groups, float* dw_part, float* db_part, void* stream) {
+    VFN_REQUIRE(dy && x && dw_part, "vfn_weight_grad_frag: NULL argument");
+    VFN_REQUIRE(groups >= 1 && groups <= 4096, "vfn_weight_grad_frag: groups=%d", groups);
+    VFN_REQUIRE(n_points >= 0 && n_points < (1ll << 20) * groups, "vfn_weight_grad_frag: slab larger than 1 GiB");
+    DwfArgs a = {};
+    a.dy = dy; a.x = x; a.dw_part = dw_part; a.db_part = db_part; a.n_points = n_points;
+    hipStream_t s = (hipStream_t)stream;
+    if (shape == 0) {
+        VFN_REQUIRE(dy_form == DY_FRAG32 || dy_form == DY_FRAGBF16, "vfn_weight_grad_frag: shape 0 takes a fragment-ordered dY");
+        if (dy_form == DY_FRAG32) {
+            if (x_form == X_FRAG32) return launch<0, X_FRAG32, DY_FRAG32>(a, groups, s);
+            if (x_form == X_FRAG16) return launch<0, X_FRAG16, DY_FRAG32>(a, groups, s);
+            if (x_form == X_ROWS32) return launch<0, X_ROWS32, DY_FRAG32>(a, groups, s);
+        } else {
+            if (x_form == X_FRAG32) return launch<0, X_FRAG32, DY_FRAGBF16>(a, groups, s);
+            if (x_form == X_FRAG16) return launch<0, X_FRAG16, DY_FRAGBF16>(a, groups, s);
+            if (x_form == X_ROWS32) return launch<0, X_ROWS32, DY_FRAGBF16>(a, groups, s);
+        }
+    } else if (shape == 1) {
+        VFN_REQUIRE(x_form == X_AUX40, "vfn_weight_grad_frag: shape 1 takes the [M][40] encoding tile as X");
+        if (dy_form == DY_FRAG32) return launch<1, X_AUX40, DY_FRAG32>(a, groups, s);
+        if (dy_form == DY_FRAGBF16) return launch<1, X_AUX40, DY_FRAGBF16>(a, groups, s);
+    } else if (shape == 2) {
+        VFN_REQUIRE(dy_form == DY_DZ4, "vfn_weight_grad_frag: shape 2 takes the [M][4] head gradient as dY");
+        if (x_form == X_FRAG32) return launch<2, X_FRAG32, DY_DZ4>(a, groups, s);
+        if (x_form == X_FRAG16) return launch<2, X_FRAG16, DY_DZ4>(a, groups, s);
+        if (x_form == X_ROWS32) return launch<2, X_ROWS32, DY_DZ4>(a, groups, s);
+    }
+    vfn_set_error("vfn_weight_grad_frag: unsupported combination shape=%d dy_form=%d x_form=%d", shape, dy_form, x_form);
+    return VFN_ERR_INVALID;
+}

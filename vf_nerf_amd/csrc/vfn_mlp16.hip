@@ -73,6 +73,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define VFN16_MASK_STEP(H, NKB) (H)     // K step of a tile that carries the sign-bit collection of the pending tile (training)
 #endif
 #define VFN16_MAX_CHUNK_KB 39     // (16 act + 3 aux) K-blocks x 2 planes + 1 bias block
+#define VFN16_STATS_WORDS 64      // tail of a pack (256 bytes): per-entry weight statistics, see Pack16Args::stats
 
 struct Plan16 {
     int32_t n_hidden;
@@ -123,6 +124,8 @@ struct Pack16Args {
     int32_t n_entries;
     uint32_t total_words;
     uint32_t* out;
+    uint32_t* stats;     // [VFN16_STATS_WORDS] after the pack: word e = bits of max |folded weight| of pack entry e (layers in plan
+                         // order, then the head) — the host checks them against the range the (hi, lo) f16 halves represent well
 };
 
 __device__ __forceinline__ float folded_weight(const Pack16Entry& e, int n, int col) {
@@ -152,6 +155,7 @@ __global__ void vfn_pack16_kernel(Pack16Args a) {
         const int g = (int)(lane >> 5);
         const int n = (int)(32u * ck + (lane & 31u));
         _Float16 halves[2];
+        float wabs = 0.f;
         for (int q = 0; q < 2; ++q) {
             const int j = (int)(2u * jp) + q;
             int col = -1;
@@ -165,9 +169,16 @@ __global__ void vfn_pack16_kernel(Pack16Args a) {
             const float w = folded_weight(e, n, col);
             const _Float16 hi = (_Float16)w;
             halves[q] = part ? (_Float16)(w - (float)hi) : hi;
+            wabs = fmaxf(wabs, fabsf(w));
         }
         word = (uint32_t)__builtin_bit_cast(unsigned short, halves[0]) |
                ((uint32_t)__builtin_bit_cast(unsigned short, halves[1]) << 16);
+        if (a.stats && part == 0) {       // (wave-uniform: a workgroup covers one 1-KiB block = one entry, one plane)
+            float wm = wabs;                // largest |w| of the entry; non-negative floats order like their bit patterns
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o, 64));
+            if ((threadIdx.x & 63) == 0 && wm > 0.f) atomicMax(a.stats + ei, __builtin_bit_cast(uint32_t, wm));
+        }
     } else {
         const uint32_t bi = cw - wblocks * 256u;   // bias block: [hl][16] floats in accumulator-register order
         if (bi < 32u) {
@@ -193,7 +204,7 @@ extern "C" int64_t vfn_pack16_size(int32_t net_kind, const vfn_net_geom* geom) {
     if (rc != VFN_OK) return rc;
     rc = check_kind16(net_kind, p, "vfn_pack16_size");
     if (rc != VFN_OK) return rc;
-    return (int64_t)p.total_kb * 1024;
+    return (int64_t)p.total_kb * 1024 + VFN16_STATS_WORDS * 4;
 }
 
 extern "C" int vfn_pack16_weights(int32_t net_kind, const vfn_net_geom* geom, const vfn_layer_params* layers,
@@ -248,6 +259,11 @@ extern "C" int vfn_pack16_weights(int32_t net_kind, const vfn_net_geom* geom, co
     }
     a.total_words = p.total_kb * 256u;
     a.out = (uint32_t*)packed16;
+    a.stats = a.out + a.total_words;
+    if (hipMemsetAsync(a.stats, 0, VFN16_STATS_WORDS * 4, (hipStream_t)stream) != hipSuccess) {
+        vfn_set_error("vfn_pack16_weights: hipMemsetAsync failed");
+        return VFN_ERR_LAUNCH;
+    }
     hipLaunchKernelGGL(vfn_pack16_kernel, dim3((a.total_words + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_pack16_weights");
 }
@@ -331,14 +347,25 @@ struct Mlp16Args {
     float* save_aux_rn;
     // training modes: ReLU sign bits of every saved activation, [13][M][2][4] u32 (see save_mask)
     uint32_t* save_masks;
-    int save_f16;             // training modes: store the ReLU slots as f16 (first 512 bytes of every 1 KiB row)
+    int save_f16;             // training modes, flags: bit 0 = store the ReLU slots as f16; bit 1 = FRAGMENT ORDER: a slot is
+                              // [group of 32 points][tile t, register quad q][lane][16 B (8 B as f16)], i.e. every store
+                              // instruction writes 1 KiB (512 B) of consecutive bytes (csrc/vfn_dwf.hip reads it back);
+                              // otherwise row-major [M][256] (f16: the first 512 bytes of every 1 KiB row).  The tanh'ed
+                              // feature slot (8) is row-major fp32 either way.
     // split launches: feature operand blocks, 1 KiB per point: [tile t][lane half g][hi 2t | lo 2t | hi 2t+1 | lo 2t+1] x 16 B
     uint4* blk_out;           // M16_BLKOUT: written for rows 0 .. n_points-1
     const uint4* blk_in;      // M16_BLKIN: block buffer, groups of 32 rows (store_blocks)
     const float* vec_in;      // M16_BLKIN: [rows,3] vector outputs of the feature launches
     const int* src;           // M16_BLKIN: [rows] position of every row among the sorted samples (< 0: padding row)
     const int* out_index;     // fused launches, optional: outputs of point m go to row out_index[m] (< 0: dropped) instead of m
+    uint32_t* status;         // optional (vfn_f16x3_set_status): bit 0 is OR-ed in when a hidden activation reached the f16 clamp,
+                              // bit 1 when an input (point coordinate / encoding operand) did — the result of such a launch is not
+                              // fp32-equivalent and the caller should repeat it on the exact-fp32 kernels
 };
+
+// Range of the split-f16 operands: activations ride at 2^6 x their value (VFN16_XSCALE) and are clamped here, i.e. true
+// activations above ~937 saturate.  The clamp keeps inf - inf = NaN out of the split; the status word reports that it acted.
+#define VFN16_CLAMP 60000.0f
 
 struct X16 { half8 hi[16]; half8 lo[16]; };     // 256 activation columns x this lane's point, split (16 K-blocks of 16)
 struct A16 { half8 hi[3]; half8 lo[3]; };       // 48 auxiliary (encoding) columns
@@ -351,8 +378,12 @@ struct Pipe16 {
     float* saved;
     long long slot_floats;         // M * 256
     uint32_t slot_bytes;           // M * 1024 (the host checks that it fits)
-    uint32_t save_voff;            // byte offset of this lane's 16-byte column group in a slot row; out of range for m >= M
-    uint32_t save_voff16;          // f16 storage: m * 1024 + 8 * (lane >> 5) (row stride stays 1 KiB, 512 bytes of it are used)
+    uint32_t save_voff;            // fp32 stores of the ReLU slots: row-major m * 1024 + 16 * (lane >> 5); fragment order
+                                   // (m >> 5) * 32768 + 16 * lane; out of range for m >= M
+    uint32_t save_voff16;          // f16 stores: m * 1024 + 8 * (lane >> 5) / (m >> 5) * 32768 + 8 * lane
+    uint32_t feat_voff;            // the feature slot (always row-major fp32): m * 1024 + 16 * (lane >> 5)
+    uint32_t st_tile, st_q;        // byte strides of (tile, register quad) in a slot for fp32 stores (f16: half): 128, 32 row-major;
+                                   // 4096, 1024 fragment order
     int save16;                    // training: ReLU slots hold f16 values (the tanh'ed feature slot stays fp32)
     uint32_t* masks;               // ReLU sign bits, 32 bytes per point and slot: [slot][m][lane half][4 dwords]
     uint32_t mask_bytes;           // M * 32
@@ -370,6 +401,7 @@ struct Carry16 {
     f32x16 bias;
     half8 fh0, fl0;
     uint32_t lm[4];      // training: sign bits of the layer being produced, 16 per finished tile (tile t -> half t & 1 of dword t >> 1)
+    unsigned long long sat;   // lanes (as a wave mask, kept in scalar registers) whose ReLU output reached VFN16_CLAMP: the clamp acted
 };
 
 template <int N, typename F, int... I>
@@ -425,12 +457,17 @@ __device__ __forceinline__ void prefetch_chunk(Carry16& cy, const Pipe16& p, int
 
 // Two accumulator values -> (hi, lo) halves of element pair (j, j+1) of an operand block.
 template <int EPI, bool KEEP>
-__device__ __forceinline__ void epi_pair(f32x16& pend, int pr, half8& hi, half8& lo, int j) {
+__device__ __forceinline__ void epi_pair(f32x16& pend, unsigned long long& sat, int pr, half8& hi, half8& lo, int j) {
     float v0 = pend[2 * pr], v1 = pend[2 * pr + 1];
+    // one compare per pair into a SCALAR accumulator (a vector accumulator carried through the pipelined loop made hipcc spill)
+    if (EPI == EPI_RELU) sat |= __builtin_amdgcn_ballot_w64(fmaxf(v0, v1) >= VFN16_CLAMP);
     if (!VFN16_ASCALE || EPI != EPI_RELU) { v0 *= VFN16_INV_WSCALE; v1 *= VFN16_INV_WSCALE; }
     // ReLU, saturated below the f16 range so that an out-of-family activation degrades instead of turning into
-    // inf - inf = NaN in the split (activations of BatchNorm'ed layers are O(1..100))
-    if (EPI == EPI_RELU) { v0 = fminf(fmaxf(v0, 0.f), 60000.f); v1 = fminf(fmaxf(v1, 0.f), 60000.f); }
+    // inf - inf = NaN in the split (activations of BatchNorm'ed layers are O(1..100)); one v_max3 per pair remembers
+    // whether the clamp ever acted (reported through the status word at the end of the kernel)
+    if (EPI == EPI_RELU) {
+        v0 = fminf(fmaxf(v0, 0.f), VFN16_CLAMP); v1 = fminf(fmaxf(v1, 0.f), VFN16_CLAMP);
+    }
     else { v0 = tanh_exp(v0) * VFN16_XSCALE; v1 = tanh_exp(v1) * VFN16_XSCALE; }
     _Float16 h0, h1, l0, l1;
     split2(v0, v1, h0, h1, l0, l1);
@@ -451,13 +488,15 @@ __device__ __forceinline__ void save_group(const Pipe16& p, const f32x16& v, int
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)(((p.save_voff >> 15) << 15) + (threadIdx.x & 63) * 16),
                                            (4 * TILE + q) * 1024, VFN16_SAVE_AUX);
 #elif !defined(ABL_NOSAVE)
-    if (SLOT != 8 && p.save16) {        // opt-in: 11-bit operands for the weight gradients, half the workspace traffic
+    if (SLOT == 8) {                    // the tanh'ed features: row-major fp32 (returned to callers, read by the chain as values)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)p.feat_voff, (32 * TILE + 8 * q) * 4, VFN16_SAVE_AUX);
+    } else if (p.save16) {              // 11-bit operands for the weight gradients, half the workspace traffic
         typedef _Float16 half4 __attribute__((ext_vector_type(4)));
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
         const half4 h = __builtin_convertvector(g, half4);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rs, (int)p.save_voff16, (32 * TILE + 8 * q) * 2, VFN16_SAVE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rs, (int)p.save_voff16, (int)((TILE * p.st_tile + q * p.st_q) >> 1), VFN16_SAVE_AUX);
     } else {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)p.save_voff, (32 * TILE + 8 * q) * 4, VFN16_SAVE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)p.save_voff, (int)(TILE * p.st_tile + q * p.st_q), VFN16_SAVE_AUX);
     }
 #else
     asm volatile("" :: "v"(g));
@@ -567,8 +606,8 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
 #pragma unroll
                 for (int pr = st * 8 / E; pr < (st + 1) * 8 / E; ++pr) {
                     const int sblk = pr >> 2, j = (pr & 3) * 2;
-                    if (ch > 0) epi_pair<EPI, TRAIN>(cy.pend, pr, ehi[sblk], elo[sblk], j);
-                    else epi_pair<(PEPI >= 0 ? PEPI : 0), TRAIN>(cy.pend, pr, ehi[sblk], elo[sblk], j);
+                    if (ch > 0) epi_pair<EPI, TRAIN>(cy.pend, cy.sat, pr, ehi[sblk], elo[sblk], j);
+                    else epi_pair<(PEPI >= 0 ? PEPI : 0), TRAIN>(cy.pend, cy.sat, pr, ehi[sblk], elo[sblk], j);
                     if ((pr & 3) == 3) {
                         asm volatile("" : "+a"(ehi[sblk]));   // operands live in AGPRs (MFMA reads them there)
                         asm volatile("" : "+a"(elo[sblk]));
@@ -656,7 +695,7 @@ __device__ __forceinline__ float enc_value(const float (&x)[3], const float (&sn
 
 // aux operand from a column generator: element j of lane half g of K-block s <-> column 16 s + 8 g + j
 template <typename F>
-__device__ __forceinline__ void build_aux(A16& aux, int g, F col) {
+__device__ __forceinline__ void build_aux(A16& aux, int g, F col, float& ain) {
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         half8 hi, lo;
@@ -666,6 +705,9 @@ __device__ __forceinline__ void build_aux(A16& aux, int g, F col) {
             if (g == 0) { v0 = col(16 * s + j); v1 = col(16 * s + j + 1); }
             else { v0 = col(16 * s + 8 + j); v1 = col(16 * s + 8 + j + 1); }
             v0 *= VFN16_XSCALE; v1 *= VFN16_XSCALE;
+            // inputs beyond the f16 range (|coordinate| > ~937): clamp (no inf - inf in the split) and remember
+            v0 = fminf(fmaxf(v0, -VFN16_CLAMP), VFN16_CLAMP); v1 = fminf(fmaxf(v1, -VFN16_CLAMP), VFN16_CLAMP);
+            ain = fmaxf(ain, fmaxf(fabsf(v0), fabsf(v1)));
             _Float16 h0, h1, l0, l1;
             split2(v0, v1, h0, h1, l0, l1);
             hi[j] = h0; hi[j + 1] = h1; lo[j] = l0; lo[j + 1] = l1;
@@ -722,7 +764,7 @@ __device__ __forceinline__ void encode_sincos(const float (&x)[3], int multires,
 // aux operand of the rendering net for one sample: [p(3), d(3), sin/cos(2^k d)(6L), n(3)]
 template <int MODE>
 __device__ __forceinline__ void render_aux(const Mlp16Args& a, A16& aux, const float (&xr)[3], const float (&dr)[3], const float (&nrm)[3],
-                                           long long m, bool in, int g) {
+                                           long long m, bool in, int g, float& ain) {
     const int rn_multires = a.rn_multires;
     float sn[18], cs[18];
     encode_sincos(dr, rn_multires, g, sn, cs);
@@ -732,7 +774,7 @@ __device__ __forceinline__ void render_aux(const Mlp16Args& a, A16& aux, const f
         if (k >= ncol) return k < ncol + 3 ? nrm[k - ncol] : 0.f;
         return enc_value(dr, sn, cs, rn_multires, k - 3);
     };
-    build_aux(aux, g, rn_col);
+    build_aux(aux, g, rn_col, ain);
     if ((MODE & M16_TRAIN) && in) save_aux(a.save_aux_rn, m, g, rn_col);
 }
 
@@ -752,6 +794,15 @@ __device__ __forceinline__ void render_tail(const Mlp16Args& a, const Pipe16& p,
     if (in && (threadIdx.x & 32) == 0) {
         a.out_vec[mo * 3 + 0] = nrm[0]; a.out_vec[mo * 3 + 1] = nrm[1]; a.out_vec[mo * 3 + 2] = nrm[2];
         a.out_colors[mo * 3 + 0] = rgb[0]; a.out_colors[mo * 3 + 1] = rgb[1]; a.out_colors[mo * 3 + 2] = rgb[2];
+    }
+}
+
+// End of a launch: tell the caller when an operand left the range the split-f16 representation covers.  Lanes of rows past
+// the end evaluate the point (0, 0, 0), which is an in-range input like any other; a divergent atomic only where it matters.
+__device__ __forceinline__ void report_range(const Mlp16Args& a, unsigned long long sat, float ain) {
+    if (a.status) {
+        const unsigned bits = (sat != 0ull ? 1u : 0u) | (ain >= VFN16_CLAMP ? 2u : 0u);
+        if (bits) atomicOr(a.status, bits);
     }
 }
 
@@ -793,11 +844,12 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
         p.vf_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.rn_w), 0, (int)a.rn_bytes, 0x00020000);
         p.rn_w = p.vf_w;
         p.saved = nullptr; p.slot_floats = 0; p.slot_bytes = 0; p.save_voff = 0; p.blk_out = nullptr; p.blk_bytes = 0; p.blk_voff = 0;
-        p.masks = nullptr; p.mask_bytes = 0; p.mask_voff = 0; p.save16 = 0; p.save_voff16 = 0;
+        p.masks = nullptr; p.mask_bytes = 0; p.mask_voff = 0; p.save16 = 0; p.save_voff16 = 0; p.feat_voff = 0; p.st_tile = 0; p.st_q = 0;
         dma_chunk<MODE, 0>(p, wave, lane);
         dma_chunk<MODE, 1>(p, wave, lane);
         X16 xa, xb;
         A16 aux;
+        float ain_blk = 0.f;
         {
             // 32 KiB per 32 rows, see store_blocks; rows past the end get an out-of-range offset and read as zeros (no branch)
             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -811,7 +863,7 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
             for (int i = 0; i < 32; ++i) q[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_blk, goff, i * 1024, 0);
             // the encoding of the view direction (12 sincosf) while the operands are on their way: the three small loads were
             // issued before them, so their wait is a counted one
-            render_aux<MODE>(a, aux, xr, dr, nrm, -1, false, g);
+            render_aux<MODE>(a, aux, xr, dr, nrm, -1, false, g, ain_blk);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 half8 h0 = __builtin_bit_cast(half8, q[4 * t + 0]), l0 = __builtin_bit_cast(half8, q[4 * t + 1]);
@@ -825,12 +877,13 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
         Carry16 cy;
 #pragma unroll
         for (int q = 0; q < 16; ++q) cy.pend[q] = 0.f;
-        cy.lm[0] = 0; cy.lm[1] = 0; cy.lm[2] = 0; cy.lm[3] = 0;
+        cy.lm[0] = 0; cy.lm[1] = 0; cy.lm[2] = 0; cy.lm[3] = 0; cy.sat = 0ull;
         prefetch_chunk<MODE, 0>(cy, p, lane);
 #ifdef VFN16_STAMPS
         const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();
 #endif
         render_tail<MODE>(a, p, cy, xa, xb, aux, nrm, live ? (long long)dpos : -1, live, wave, lane);
+        report_range(a, cy.sat, ain_blk);
 #ifdef VFN16_STAMPS
         if (threadIdx.x == 0 && live) {
             const unsigned long long t2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
@@ -860,10 +913,18 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     p.vf_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.vf_w), 0, (int)a.vf_bytes, 0x00020000);
     p.rn_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>((MODE & M16_RENDER) ? a.rn_w : a.vf_w), 0,
                                                (int)((MODE & M16_RENDER) ? a.rn_bytes : a.vf_bytes), 0x00020000);
-    p.saved = a.saved; p.slot_floats = a.n_points * 256; p.slot_bytes = (uint32_t)(a.n_points * 1024);
-    p.save_voff = in ? (uint32_t)(m * 1024 + g * 16) : 0xfffffff0u;
+    const bool frag = (a.save_f16 & 2) != 0;          // fragment-ordered slots: groups of 32 points, 32 KiB each
+    p.saved = a.saved;
+    p.slot_floats = frag ? ((a.n_points + 31) >> 5) * 8192 : a.n_points * 256;
+    p.slot_bytes = (uint32_t)(p.slot_floats * 4);
+    // rows past the end get an offset beyond the descriptor's range (the store is dropped).  Fragment order adds scalar
+    // offsets of up to 32 KiB to it, so that value must not wrap: 3 GiB, with slots limited to 2 GiB (the host checks)
+    p.save_voff = !in ? (frag ? 0xc0000000u : 0xfffffff0u) : (frag ? (uint32_t)((m >> 5) * 32768 + lane * 16) : (uint32_t)(m * 1024 + g * 16));
+    p.save_voff16 = !in ? (frag ? 0xc0000000u : 0xfffffff0u) : (frag ? (uint32_t)((m >> 5) * 32768 + lane * 8) : (uint32_t)(m * 1024 + g * 8));
+    p.feat_voff = in ? (uint32_t)(m * 1024 + g * 16) : 0xfffffff0u;
+    p.st_tile = frag ? 4096u : 128u; p.st_q = frag ? 1024u : 32u;
     p.masks = a.save_masks; p.mask_bytes = (uint32_t)(a.n_points * 32); p.mask_voff = in ? (uint32_t)((2 * m + g) * 16) : 0xfffffff0u;
-    p.save16 = a.save_f16; p.save_voff16 = in ? (uint32_t)(m * 1024 + g * 8) : 0xfffffff0u;
+    p.save16 = a.save_f16 & 1;
     p.blk_out = a.blk_out; p.blk_bytes = (uint32_t)(((a.n_points + 31) & ~31ll) * 1024);
     p.blk_voff = (uint32_t)((m >> 5) * 32768 + lane * 16);      // past the last group -> out of the descriptor's range, dropped
     dma_chunk<MODE, 0>(p, wave, lane);
@@ -879,10 +940,11 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     // ---- positional encoding of the point -> aux operand (and its parked copy for the skip layer) -----------
     const int vf_multires = a.vf_multires;
     A16 aux;
+    float ain = 0.f;
     {
         float sn[18], cs[18];
         encode_sincos(x, vf_multires, g, sn, cs);
-        build_aux(aux, g, [&](int k) { return enc_value(x, sn, cs, vf_multires, k); });
+        build_aux(aux, g, [&](int k) { return enc_value(x, sn, cs, vf_multires, k); }, ain);
         if ((MODE & M16_TRAIN) && in) save_aux(a.save_aux_vf, m, g, [&](int k) { return enc_value(x, sn, cs, vf_multires, k); });
         half8* pk = reinterpret_cast<half8*>(s_park + 8);
 #pragma unroll
@@ -893,7 +955,7 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     Carry16 cy;
 #pragma unroll
     for (int q = 0; q < 16; ++q) cy.pend[q] = 0.f;
-    cy.lm[0] = 0; cy.lm[1] = 0; cy.lm[2] = 0; cy.lm[3] = 0;
+    cy.lm[0] = 0; cy.lm[1] = 0; cy.lm[2] = 0; cy.lm[3] = 0; cy.sat = 0ull;
     prefetch_chunk<MODE, 0>(cy, p, lane);
 
     // ---- VF net: straight-line code with static operand-set roles, so that only one set plus the tiles produced so far
@@ -915,6 +977,7 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     if constexpr (!(MODE & M16_FEAT)) {
         layer16<MODE, 63, 16, 0, 1, EPI_HEAD_TANH, R, 14, -1, 7>(xa, aux, xb, xa, cy, vec, p, wave, lane);
         if (in && g == 0) { a.out_vec[m * 3 + 0] = vec[0]; a.out_vec[m * 3 + 1] = vec[1]; a.out_vec[m * 3 + 2] = vec[2]; }
+        report_range(a, cy.sat, ain);
     } else {
     // fused: feature block (tanh) -> xb, then the vector head from the same input; the head's tile hosts the epilogue
     // of the last feature tile
@@ -923,6 +986,7 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     layer16<MODE, 71, 16, 0, 1, EPI_HEAD_TANH, T, 14, -1, 8, false, BO>(xa, aux, xb, xb, cy, vec, p, wave, lane);
     if constexpr (!(MODE & M16_RENDER)) {
         if (in && g == 0) { a.out_vec[m * 3 + 0] = vec[0]; a.out_vec[m * 3 + 1] = vec[1]; a.out_vec[m * 3 + 2] = vec[2]; }
+        report_range(a, cy.sat, ain);
 #ifdef VFN16_STAMPS
         if (threadIdx.x == 0) {   // timing-only build: prologue cycles, total cycles, total 100 MHz ticks of this workgroup
             const unsigned long long t2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
@@ -937,8 +1001,9 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     const float xr[3] = {s_park[0], s_park[1], s_park[2]};
     const float dr[3] = {s_park[4], s_park[5], s_park[6]};
     A16 raux;
-    render_aux<MODE>(a, raux, xr, dr, nrm, m, in, g);
+    render_aux<MODE>(a, raux, xr, dr, nrm, m, in, g, ain);
     render_tail<MODE>(a, p, cy, xa, xb, raux, nrm, a.out_index ? (long long)out_row : m, a.out_index ? out_row >= 0 : in, wave, lane);
+    report_range(a, cy.sat, ain);
     const long long mo = (long long)blockIdx.x * VFN16_PTS + (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
     (void)mo;
 #ifdef VFN16_STAMPS
@@ -974,6 +1039,14 @@ static int check_kind16(int net_kind, const Plan16& p, const char* what) {
     return net_kind == VFN_NET_VF ? check_vf16(p, what) : check_rn16(p, what);
 }
 
+// Where the f16x3 launches of THIS thread report operands outside the split-f16 range (NULL: nowhere).
+static thread_local uint32_t* t_status_word = nullptr;
+
+extern "C" int vfn_f16x3_set_status(uint32_t* status_word) {
+    t_status_word = status_word;
+    return VFN_OK;
+}
+
 extern "C" int vfn_vf_mlp16_fwd(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
                                  float* out_vec, void* stream) {
     Mlp16Args a = {};
@@ -986,6 +1059,7 @@ extern "C" int vfn_vf_mlp16_fwd(const vfn_net_geom* geom, const void* packed16, 
     VFN_REQUIRE(packed16 && points && out_vec, "vfn_vf_mlp16_fwd: NULL argument");
     a.vf_w = (const uint4*)packed16; a.points = points; a.out_vec = out_vec; a.n_points = n_points; a.dirs_div = 1;
     a.vf_multires = vf.multires; a.vf_bytes = vf.total_kb * 1024u;
+    a.status = t_status_word;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_VEC>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_mlp16_fwd");
@@ -1013,6 +1087,7 @@ extern "C" int vfn_vf_render_fused16_fwd(const vfn_net_geom* vf_geom, const void
     a.vf_w = (const uint4*)vf_packed16; a.rn_w = (const uint4*)rn_packed16; a.points = points; a.ray_dirs = ray_dirs;
     a.out_vec = normals; a.out_colors = colors; a.n_points = n_points; a.dirs_div = samples_per_ray;
     a.vf_multires = vf.multires; a.rn_multires = rn.multires; a.vf_bytes = vf.total_kb * 1024u; a.rn_bytes = rn.total_kb * 1024u;
+    a.status = t_status_word;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_render_fused16_fwd");
@@ -1040,6 +1115,7 @@ extern "C" int vfn_vf_render_fused16_scatter(const vfn_net_geom* vf_geom, const 
     a.vf_w = (const uint4*)vf_packed16; a.rn_w = (const uint4*)rn_packed16; a.points = points; a.ray_dirs = ray_dirs;
     a.out_vec = normals; a.out_colors = colors; a.out_index = out_index; a.n_points = n_points; a.dirs_div = samples_per_ray;
     a.vf_multires = vf.multires; a.rn_multires = rn.multires; a.vf_bytes = vf.total_kb * 1024u; a.rn_bytes = rn.total_kb * 1024u;
+    a.status = t_status_word;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_render_fused16_scatter");
@@ -1061,6 +1137,7 @@ extern "C" int vfn_vf_feat16_fwd(const vfn_net_geom* geom, const void* packed16,
     VFN_REQUIRE(n_points < (1ll << 22), "vfn_vf_feat16_fwd: at most 4194303 points per launch (32-bit block offsets)");
     a.vf_w = (const uint4*)packed16; a.points = points; a.out_vec = out_vec; a.n_points = n_points; a.dirs_div = 1;
     a.vf_multires = vf.multires; a.vf_bytes = vf.total_kb * 1024u; a.blk_out = (uint4*)out_blocks;
+    a.status = t_status_word;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_BLK>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_feat16_fwd");
@@ -1082,6 +1159,7 @@ extern "C" int vfn_render16_from_blocks(const vfn_net_geom* rn_geom, const void*
     a.rn_w = (const uint4*)rn_packed16; a.vf_w = a.rn_w; a.points = points; a.ray_dirs = ray_dirs; a.out_vec = normals; a.out_colors = colors;
     a.n_points = n_points; a.dirs_div = samples_per_ray; a.rn_multires = rn.multires; a.rn_bytes = rn.total_kb * 1024u; a.vf_bytes = a.rn_bytes;
     a.blk_in = (const uint4*)blocks; a.vec_in = vecs; a.src = dst;
+    a.status = t_status_word;
     const long long nblocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     hipLaunchKernelGGL(vfn_mlp16_kernel<M16_RN_BLK>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_render16_from_blocks");
@@ -1101,10 +1179,12 @@ extern "C" int vfn_vf_mlp16_fwd_train(const vfn_net_geom* geom, const void* pack
     if (rc != VFN_OK) return rc;
     if (n_points <= 0) return VFN_OK;
     VFN_REQUIRE(packed16 && points && out_vec && saved && save_aux_vf && save_masks, "vfn_vf_mlp16_fwd_train: NULL argument");
-    VFN_REQUIRE(n_points < (1ll << 22), "vfn_vf_mlp16_fwd_train: at most 4194303 points per launch (32-bit slot offsets)");
+    VFN_REQUIRE(n_points < ((save_f16 & 2) ? (1ll << 21) : (1ll << 22)), "vfn_vf_mlp16_fwd_train: at most %lld points per launch (32-bit slot offsets)",
+                ((save_f16 & 2) ? (1ll << 21) : (1ll << 22)) - 1);
     a.vf_w = (const uint4*)packed16; a.points = points; a.out_vec = out_vec; a.n_points = n_points; a.dirs_div = 1;
     a.vf_multires = vf.multires; a.vf_bytes = vf.total_kb * 1024u; a.saved = saved; a.save_aux_vf = save_aux_vf;
-    a.save_masks = save_masks; a.save_f16 = save_f16 != 0;
+    a.save_masks = save_masks; a.save_f16 = save_f16 & 3;
+    a.status = t_status_word;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     if (with_features) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_FULL_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_VEC_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
@@ -1130,11 +1210,13 @@ extern "C" int vfn_vf_render_fused16_fwd_train(const vfn_net_geom* vf_geom, cons
     VFN_REQUIRE(vf_packed16 && rn_packed16 && points && ray_dirs && normals && colors && saved && save_aux_vf && save_aux_rn && save_masks,
                 "vfn_vf_render_fused16_fwd_train: NULL argument");
     VFN_REQUIRE(samples_per_ray > 0, "vfn_vf_render_fused16_fwd_train: samples_per_ray must be > 0");
-    VFN_REQUIRE(n_points < (1ll << 22), "vfn_vf_render_fused16_fwd_train: at most 4194303 points per launch (32-bit slot offsets)");
+    VFN_REQUIRE(n_points < ((save_f16 & 2) ? (1ll << 21) : (1ll << 22)), "vfn_vf_render_fused16_fwd_train: at most %lld points per launch (32-bit slot offsets)",
+                ((save_f16 & 2) ? (1ll << 21) : (1ll << 22)) - 1);
     a.vf_w = (const uint4*)vf_packed16; a.rn_w = (const uint4*)rn_packed16; a.points = points; a.ray_dirs = ray_dirs;
     a.out_vec = normals; a.out_colors = colors; a.n_points = n_points; a.dirs_div = samples_per_ray;
     a.vf_multires = vf.multires; a.rn_multires = rn.multires; a.vf_bytes = vf.total_kb * 1024u; a.rn_bytes = rn.total_kb * 1024u;
-    a.saved = saved; a.save_aux_vf = save_aux_vf; a.save_aux_rn = save_aux_rn; a.save_masks = save_masks; a.save_f16 = save_f16 != 0;
+    a.saved = saved; a.save_aux_vf = save_aux_vf; a.save_aux_rn = save_aux_rn; a.save_masks = save_masks; a.save_f16 = save_f16 & 3;
+    a.status = t_status_word;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_render_fused16_fwd_train");

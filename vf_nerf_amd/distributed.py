@@ -59,7 +59,15 @@ class GradientBucket:
     backward accumulates straight into the bucket and the all-reduce needs no packing copies."""
 
     def __init__(self, model) -> None:
-        self.params: List[torch.nn.Parameter] = [p for p in model.unique_parameters() if p.requires_grad]
+        # the facade's optimizer (optim.FlatAdam) already keeps every gradient in one flat buffer: the bucket IS that buffer
+        opt = getattr(model, "optimizer", None)
+        f = opt.flat() if hasattr(opt, "flat") else None
+        if f is not None and all(p.requires_grad for p, _, _, _ in f["entries"]):
+            self.params: List[torch.nn.Parameter] = [p for p, _, _, _ in f["entries"]]
+            self.flat = f["grad"]
+            opt._rebind_grads(f)
+            return
+        self.params = [p for p in model.unique_parameters() if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)

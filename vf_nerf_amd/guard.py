@@ -1,0 +1,151 @@
+"""Range guard of the f16x3 kernels (include/vfn.h, "Range guard of the f16x3 kernels").
+
+The reference's MLPs are plain fp32 (models/vector_field/vector_field_network.py:177-208): no activation, input or weight
+magnitude is out of bounds.  The f16x3 kernels carry every operand as two f16 halves, which covers |activation| < ~937,
+|input coordinate| < ~937 and folded weights whose largest entry per layer is neither down in the f16 denormals nor beyond
+the f16 range.  Default-initialised and normally trained networks sit well inside; a network that does not must not come back
+with silently degraded values.  So:
+
+* the kernels OR a bit into a device status word when the ReLU clamp or the input clamp acted (``vfn_f16x3_set_status``);
+* ``vfn_pack16_weights`` leaves max |folded weight| per layer behind the pack;
+* this guard reads both and, when either is out of range, switches its model to the exact-fp32 kernels (a warning names the
+  reason; ``model.f16x3_disabled`` keeps it).  ``mode``:
+    "lazy"    (default) the status is read back asynchronously, every ``LAZY_EVERY`` guarded calls and whenever the weights
+              were re-packed; the switch happens at the start of the first call after the report arrived.  No
+              synchronisation on the hot path; the flagged calls themselves have already returned clamped values.
+    "strict"  every guarded call ends with a synchronising read of the status word and is REPEATED on the fp32 kernels when
+              flagged: no call ever returns values the clamp touched.
+    "off"     no reporting.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Optional
+
+import torch
+
+from . import lib
+
+WEIGHT_MAX_LO = 2.0 ** -9      # a layer whose largest folded weight is below this has its low halves (and soon its high
+                               # halves) in the f16 denormals: < ~16 significant bits left instead of 22
+WEIGHT_MAX_HI = 3.0e4          # f16 overflows at 65 504
+LAZY_EVERY = 32
+
+
+class _Watch:
+    def __init__(self, guard: "RangeGuard", dev) -> None:
+        self.guard, self.dev, self.flagged = guard, dev, False
+
+    def __enter__(self) -> "_Watch":
+        lib.f16x3_set_status(self.guard._state(self.dev)["status"])
+        return self
+
+    def __exit__(self, *exc) -> bool:
+        lib.f16x3_set_status(None)
+        if exc[0] is None:
+            self.flagged = self.guard._after_call(self.dev)
+        return False
+
+
+class RangeGuard:
+    def __init__(self, model) -> None:
+        self.model = model
+        self.mode = "lazy"
+        self._st: Optional[dict] = None
+        self._calls = 0
+
+    # -- public ---------------------------------------------------------------------------------
+    def active(self) -> bool:
+        return self.mode != "off" and self.model.f16x3_disabled is None
+
+    def poll(self) -> None:
+        """Consume a finished asynchronous read-back, if any (start of a guarded call)."""
+        st = self._st
+        if st is not None and st["event"] is not None and st["event"].query():
+            st["event"] = None
+            self._evaluate(st)
+
+    def watch(self, dev) -> _Watch:
+        return _Watch(self, dev)
+
+    def check_now(self, dev) -> Optional[str]:
+        """Synchronising check (tests, diagnostics): the reason the f16x3 path was / is being switched off, or None."""
+        st = self._state(dev)
+        self._read_back(st, dev)
+        st["event"].synchronize()
+        st["event"] = None
+        self._evaluate(st)
+        return self.model.f16x3_disabled
+
+    # -- internals --------------------------------------------------------------------------------
+    def _state(self, dev) -> dict:
+        st = self._st
+        if st is None or st["status"].device != torch.device(dev):
+            st = self._st = dict(status=torch.zeros(4, dtype=torch.int32, device=dev),
+                                 host=torch.zeros(4 + 2 * lib.PACK16_STATS_WORDS, dtype=torch.int32).pin_memory(),
+                                 event=None, pack_keys=None)
+        return st
+
+    def _nets(self):
+        return (self.model.vector_field_network, self.model.rendering_network)
+
+    def _read_back(self, st, dev) -> None:
+        host = st["host"]
+        host[:4].copy_(st["status"], non_blocking=True)
+        for i, net in enumerate(self._nets()):
+            cache = getattr(net, "_packed16_cache", None)
+            lo = 4 + i * lib.PACK16_STATS_WORDS
+            if cache is not None and cache[1].device == torch.device(dev):
+                host[lo:lo + lib.PACK16_STATS_WORDS].copy_(cache[1][-4 * lib.PACK16_STATS_WORDS:].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["event"] = ev
+
+    def _after_call(self, dev) -> bool:
+        st = self._state(dev)
+        keys = tuple(getattr(net, "_packed16_cache", (None,))[0] for net in self._nets())
+        repacked = keys != st["pack_keys"]
+        st["pack_keys"] = keys
+        self._calls += 1
+        if self.mode == "strict":
+            self._read_back(st, dev)
+            st["event"].synchronize()
+            st["event"] = None
+            return self._evaluate(st)
+        if st["event"] is None and (repacked or self._calls % LAZY_EVERY == 0):
+            self._read_back(st, dev)
+        return False
+
+    def _evaluate(self, st) -> bool:
+        host = st["host"]
+        flags = int(host[0])
+        reasons = []
+        if flags & lib.STATUS_ACT_SATURATED:
+            reasons.append("a hidden activation exceeded the split-f16 range (|x| > ~937)")
+        if flags & lib.STATUS_INPUT_SATURATED:
+            reasons.append("an input coordinate exceeded the split-f16 range (|p| > ~937)")
+        for i, (net, tag) in enumerate(zip(self._nets(), ("vector-field", "rendering"))):
+            lo = 4 + i * lib.PACK16_STATS_WORDS
+            stats = host[lo:lo + lib.PACK16_STATS_WORDS].view(torch.float32)
+            n_entries = len(_pack_entries(net))
+            for e in range(n_entries):
+                w = float(stats[e])
+                if w == 0.0:
+                    continue            # nothing packed yet (or an all-zero layer: exact in any representation)
+                if w < WEIGHT_MAX_LO or w > WEIGHT_MAX_HI:
+                    reasons.append(f"the {tag} net's pack entry {e} has max |folded weight| = {w:.3g}, outside "
+                                   f"[{WEIGHT_MAX_LO:.2g}, {WEIGHT_MAX_HI:.2g}]")
+        if not reasons:
+            return False
+        reason = "; ".join(reasons)
+        warnings.warn("vf_nerf_amd: the f16x3 kernels left the range their split-f16 operands represent to fp32 accuracy (" + reason +
+                      "); this model now runs on the exact-fp32 kernels", RuntimeWarning, stacklevel=3)
+        self.model.f16x3_disabled = reason
+        self.model.precision = "fp32"
+        st["status"].zero_()
+        return True
+
+
+def _pack_entries(net):
+    from .backward import _entries
+    return list(_entries(net)) + [None]        # hidden entries in plan order, then the 3-channel head

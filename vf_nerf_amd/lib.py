@@ -31,7 +31,7 @@ EXPORTS = (
     "vfn_linear_rows", "vfn_linear_rows_stat_parts", "vfn_bstat_row_parts", "vfn_colsum_finish", "vfn_bstat_finalize",
     "vfn_bstat_relu_rows", "vfn_bstat_relu_bwd_sums", "vfn_bstat_relu_bwd_rows", "vfn_act_bwd_rows", "vfn_embed_rows",
     "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax",
-    "vfn_ray_density_sigma_bwd",
+    "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step",
 )
 
 
@@ -93,6 +93,8 @@ def load() -> C.CDLL:
     lib.vfn_linear_rows_stat_parts.argtypes = [C.c_int64]
     lib.vfn_bstat_row_parts.restype = C.c_int64
     lib.vfn_bstat_row_parts.argtypes = [C.c_int64]
+    lib.vfn_flat_clip_workspace_bytes.restype = C.c_int64
+    lib.vfn_flat_clip_workspace_bytes.argtypes = []
     for name in EXPORTS:
         getattr(lib, name)  # raises AttributeError if the ABI lost a symbol
     if lib.vfn_abi_version() != 1:
@@ -446,6 +448,98 @@ def mlp_bwd_chain_bf16(vf_geom, vf_packed_bwd16, vf_head_w, rn_geom, rn_packed_b
                                          _ptr(dz_rgb, "dz_rgb"), _ptr(dz_vec, "dz_vec"), _stream()), "vfn_mlp_bwd_chain_bf16")
 
 
+# ------------------------------------------------------------------------------------------------
+# fragment-ordered training workspace (include/vfn.h, "FRAGMENT-ORDERED training workspace")
+# ------------------------------------------------------------------------------------------------
+WS_F16, WS_FRAG = 1, 2                       # flags of the f16x3 training forwards (save_f16 argument)
+DY_FRAG, DY_BF16 = 2, 4                      # flags of the bf16 chain (dy_flags argument)
+DYF_FRAG32, DYF_FRAGBF16, DYF_DZ4 = 0, 1, 2  # operand forms of weight_grad_frag
+XF_FRAG32, XF_FRAG16, XF_ROWS32, XF_AUX40 = 0, 1, 2, 3
+GROUP_FLOATS = 8192                          # one group of 32 points = 32 KiB
+
+
+def frag_groups(m: int) -> int:
+    return (m + 31) // 32
+
+
+def frag_to_rows(slot: torch.Tensor, m: int, dtype=torch.float32) -> torch.Tensor:
+    """One fragment-ordered slot (flat fp32 buffer of frag_groups(m) * 8192 floats) -> the row-major [m, 256] matrix it
+    holds.  ``dtype``: float32, float16 (activations stored as f16) or bfloat16 (gradients stored as bf16) — the 16-bit forms
+    use the first half of every group.  Test / debugging helper: the kernels never need the row-major form."""
+    g = frag_groups(m)
+    flat = slot.reshape(-1)[: g * GROUP_FLOATS].view(g, GROUP_FLOATS)
+    if dtype != torch.float32:
+        flat = flat.view(dtype)[:, :GROUP_FLOATS]               # [g, 8192] 16-bit values = the first 16 KiB of each group
+    # [group][tile t][quad q][lane half gg][point i][4 values]  ->  [group][point i][t][q][gg][4]
+    rows = flat.reshape(g, 8, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(g * 32, 256)
+    return rows[:m].float()
+
+
+def rows_to_frag(rows: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+    """The inverse of frag_to_rows: [m, 256] -> one fragment-ordered slot (flat fp32 buffer, padded points zero)."""
+    m = rows.shape[0]
+    g = frag_groups(m)
+    pad = torch.zeros(g * 32, 256, device=rows.device, dtype=torch.float32)
+    pad[:m] = rows.float()
+    frag = pad.reshape(g, 32, 8, 4, 2, 4).permute(0, 2, 3, 4, 1, 5).reshape(g, GROUP_FLOATS)
+    out = torch.zeros(g, GROUP_FLOATS, device=rows.device, dtype=torch.float32)
+    if dtype == torch.float32:
+        out.copy_(frag)
+    else:
+        out.view(dtype)[:, :GROUP_FLOATS] = frag.to(dtype)
+    return out.reshape(-1)
+
+
+def weight_grad_frag(shape: int, dy, dy_form: int, x, x_form: int, n_points: int, groups: int, dw_part, db_part=None) -> None:
+    _check(load().vfn_weight_grad_frag(C.c_int32(shape), _ptr(dy, "dy"), C.c_int32(dy_form), _ptr(x, "x"), C.c_int32(x_form),
+                                       C.c_int64(n_points), C.c_int32(groups), _ptr(dw_part, "dw_part"), _ptr(db_part, "db_part"),
+                                       _stream()), "vfn_weight_grad_frag")
+
+
+def mlp_bwd_chain_bf16_ws(vf_geom, vf_packed_bwd16, vf_head_w, rn_geom, rn_packed_bwd16, rn_head_w, feats, masks, dy, dy_flags: int,
+                          d_colors, colors, d_vec, vec, d_feats, vec_stride: int, n_points: int, dz_rgb, dz_vec):
+    rn = C.byref(rn_geom) if rn_geom is not None else None
+    _check(load().vfn_mlp_bwd_chain_bf16_ws(C.byref(vf_geom), _ptr(vf_packed_bwd16, "vf_packed_bwd16", torch.uint8),
+                                            _ptr(vf_head_w, "vf_head_w"), rn,
+                                            _ptr(rn_packed_bwd16, "rn_packed_bwd16", torch.uint8), _ptr(rn_head_w, "rn_head_w"),
+                                            _ptr(feats, "feats"), _ptr(masks, "masks", torch.int32), _ptr(dy, "dy"), C.c_int32(dy_flags),
+                                            _ptr(d_colors, "d_colors"), _ptr(colors, "colors"), _ptr(d_vec, "d_vec"), _ptr(vec, "vec"),
+                                            _ptr(d_feats, "d_feats"), C.c_int32(vec_stride), C.c_int64(n_points),
+                                            _ptr(dz_rgb, "dz_rgb"), _ptr(dz_vec, "dz_vec"), _stream()), "vfn_mlp_bwd_chain_bf16_ws")
+
+
+# ------------------------------------------------------------------------------------------------
+# optimizer side over one flat buffer (csrc/vfn_adam.hip)
+# ------------------------------------------------------------------------------------------------
+def _regions(regions):
+    n = len(regions)
+    starts = (C.c_int64 * n)(*[int(r[0]) for r in regions])
+    ends = (C.c_int64 * n)(*[int(r[1]) for r in regions])
+    mults = (C.c_int32 * n)(*[int(r[2]) for r in regions])
+    return n, starts, ends, mults
+
+
+def flat_clip_workspace(device) -> torch.Tensor:
+    return torch.zeros(int(load().vfn_flat_clip_workspace_bytes()), dtype=torch.uint8, device=device)
+
+
+def flat_clip_grad_norm(flat_grad: torch.Tensor, regions, max_norm: float, workspace: torch.Tensor, out2: torch.Tensor) -> None:
+    """regions: [(start, end, mult)]; out2[0] <- total norm, out2[1] <- clip coefficient; flat_grad scaled in place."""
+    n, starts, ends, mults = _regions(regions)
+    _check(load().vfn_flat_clip_grad_norm(_ptr(flat_grad, "flat_grad"), C.c_int64(flat_grad.numel()), C.c_int32(n), starts, ends, mults,
+                                          C.c_float(max_norm), _ptr(workspace, "workspace", torch.uint8), _ptr(out2, "out2"), _stream()),
+           "vfn_flat_clip_grad_norm")
+
+
+def flat_adam_step(param, grad, exp_avg, exp_avg_sq, regions, step_size, bc2_sqrt, beta1, beta2, eps, weight_decay) -> None:
+    n, starts, ends, mults = _regions(regions)
+    ss = (C.c_double * (2 * n))(*[float(x) for x in step_size])
+    bc = (C.c_double * (2 * n))(*[float(x) for x in bc2_sqrt])
+    _check(load().vfn_flat_adam_step(_ptr(param, "param"), _ptr(grad, "grad"), _ptr(exp_avg, "exp_avg"), _ptr(exp_avg_sq, "exp_avg_sq"),
+                                     C.c_int64(param.numel()), C.c_int32(n), starts, ends, mults, ss, bc, C.c_double(beta1), C.c_double(beta2),
+                                     C.c_double(eps), C.c_double(weight_decay), _stream()), "vfn_flat_adam_step")
+
+
 class UnfoldEntry(C.Structure):
     """mirrors vfn_unfold_entry"""
     _fields_ = [(n, C.c_void_p) for n in ("dw_act", "dw_aux", "db", "w", "b_lin", "bn_w", "bn_var", "bn_mean", "g_w", "g_b",
@@ -488,6 +582,15 @@ def ray_density_weights_bwd(dp: DensityParams, normals, ray_dirs, z_vals, scalar
 # ------------------------------------------------------------------------------------------------
 # f16x3 inference kernels
 # ------------------------------------------------------------------------------------------------
+PACK16_STATS_WORDS = 64          # tail of an f16x3 pack: max |folded weight| per pack entry (include/vfn.h, "Range guard")
+STATUS_ACT_SATURATED, STATUS_INPUT_SATURATED = 1, 2
+
+
+def f16x3_set_status(word: Optional[torch.Tensor]) -> None:
+    """Route the range reports of this thread's f16x3 launches into ``word`` (int32 device tensor, >= 1 element); None: off."""
+    _check(load().vfn_f16x3_set_status(_ptr(word, "status_word", torch.int32)), "vfn_f16x3_set_status")
+
+
 def pack16_size(kind: int, geom: NetGeom) -> int:
     n = load().vfn_pack16_size(kind, C.byref(geom))
     if n < 0:
@@ -567,7 +670,7 @@ def render16_from_blocks(rn_geom: NetGeom, rn_packed16, blocks, vecs, dst, point
     return normals, colors
 
 
-def vf_mlp16_fwd_train(geom: NetGeom, packed16, points, with_features: bool, saved, aux_vf, masks, save_f16: bool = False):
+def vf_mlp16_fwd_train(geom: NetGeom, packed16, points, with_features: bool, saved, aux_vf, masks, save_f16: int = 0):
     """f16x3 VF forward that fills the backward workspace; returns the vector columns [M,3] (the features, when
     evaluated, are in their ``saved`` slot)."""
     m = points.shape[0]
@@ -580,7 +683,7 @@ def vf_mlp16_fwd_train(geom: NetGeom, packed16, points, with_features: bool, sav
 
 
 def vf_render_fused16_fwd_train(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, samples_per_ray, saved,
-                                aux_vf, aux_rn, masks, save_f16: bool = False):
+                                aux_vf, aux_rn, masks, save_f16: int = 0):
     m = points.shape[0]
     dev = points.device
     normals = torch.empty(m, 3, device=dev)

@@ -121,12 +121,31 @@ class VectorFieldNerf:
         # Gradient-carrying calls always use the fp32 kernels.  The setting is shared with the networks so that
         # gradient-free vector queries made on them directly (grid extraction) follow it.
         self.precision = "f16x3"
-        self.activation_storage = "fp32"
+        # the f16x3 training forward keeps the ReLU activations it saves for the weight-gradient kernels as f16 (11 significant
+        # bits in ONE operand of dW = dY^T X, half the workspace traffic): BASELINE.json's configs[2] trains on "bf16 MFMA MLPs",
+        # and the full-size step test bounds what it costs (every gradient within 1e-3 of the exact-fp32 kernels' at 4096 x 128).
+        # "fp32" keeps fp32-equivalent gradients.
+        self.activation_storage = "f16"
+        # How the 16-bit training path lays its workspace out in HBM: "fragment" = as the producing waves hold their tiles
+        # (every store / load 1 KiB of consecutive bytes; weight gradients from csrc/vfn_dwf.hip), "rows" = row-major [M,256]
+        # slots (csrc/vfn_dw16.hip and the fp32-MFMA thin kernels).  Same values either way.
+        self.workspace_layout = "fragment"
+        # Storage of the pre-activation gradients dY between the dX chain and the weight-gradient kernels: "fp32", or "bf16"
+        # (fragment layout only): 8 significant bits in ONE factor of dW = dY^T X under an unbiased sum over the batch's
+        # points, half the chain's store traffic and two matrix products per K-block instead of three.
+        self.gradient_storage = "fp32"
         # Inference with the f16x3 kernels evaluates the VF net once per distinct sample: the proposal samples keep their
         # vector columns and feature operand blocks, only the N_f new samples are evaluated after the fine sampler, and the
         # rendering net gathers (the reference evaluates the proposal samples twice; same per-sample arithmetic, identical
         # outputs).  False: one fused VF+rendering launch over all S_c+N_f samples.
         self.reuse_proposal = True
+        # Range guard of the f16x3 kernels (guard.py): "lazy" (asynchronous read-back of the kernels' saturation report, the
+        # model switches itself to the exact-fp32 kernels when one arrives), "strict" (every call is checked and, when flagged,
+        # repeated on the fp32 kernels before it returns) or "off".  ``f16x3_disabled`` holds the reason once it has switched.
+        from .guard import RangeGuard
+        self.f16x3_disabled: Optional[str] = None
+        self.range_guard = RangeGuard(self)
+        self.vector_field_network._range_guard = self.range_guard
         # device RNG stream (Philox counter); every render() advances the offset
         self.rng_seed = 0
         self._rng_offset = 0
@@ -187,8 +206,14 @@ class VectorFieldNerf:
         sequential per-parameter loop of the PyTorch it was written for; the multi-tensor implementation that newer
         PyTorch picks on GPUs updates duplicated tensors concurrently (racy).  ``optim.SequentialAdam`` keeps the
         sequential semantics (and torch.optim.Adam's state / state_dict) at ~20 launches per step."""
-        from .optim import SequentialAdam   # the same update, multi-tensor kernels over distinct tensors per pass
-        return SequentialAdam(self.parameters(), lr=lr, weight_decay=weight_decay)
+        from .optim import FlatAdam   # the same update: one flat buffer, one launch per step (CPU parameters: multi-tensor passes)
+        opt = FlatAdam(self.parameters(), lr=lr, weight_decay=weight_decay)
+        opt.after_step = self._invalidate_packs        # the step writes the parameters through raw pointers: no _version bump
+        return opt
+
+    def _invalidate_packs(self) -> None:
+        self.vector_field_network._invalidate_packs()
+        self.rendering_network._invalidate_packs()
 
     def _new_schedule(self, num_steps: int) -> None:
         sc = self.config.scheduler_config
@@ -240,10 +265,10 @@ class VectorFieldNerf:
 
     @property
     def activation_storage(self) -> str:
-        """How the f16x3 training forward keeps the hidden activations for the weight-gradient kernels: ``"fp32"`` (default:
-        the gradients are fp32-equivalent, see DESIGN.md §3 Backward) or ``"f16"`` (opt-in: 11 significant bits in the
-        activation operand of dW = dY^T X, half the workspace traffic — what BASELINE.json's configs[2], "bf16 MFMA MLPs",
-        allows).  The dX chain is not affected: it reads sign bits either way."""
+        """How the f16x3 training forward keeps the hidden activations for the weight-gradient kernels: ``"f16"`` (default: 11
+        significant bits in the activation operand of dW = dY^T X, half the workspace traffic — what BASELINE.json's
+        configs[2], "bf16 MFMA MLPs", allows) or ``"fp32"`` (fp32-equivalent gradients, see DESIGN.md §3 Backward).  The dX
+        chain is not affected: it reads sign bits either way."""
         return self._activation_storage
 
     @activation_storage.setter
@@ -253,12 +278,44 @@ class VectorFieldNerf:
         self._activation_storage = value
         self.vector_field_network.activation_storage = value
 
+    @property
+    def workspace_layout(self) -> str:
+        return self._workspace_layout
+
+    @workspace_layout.setter
+    def workspace_layout(self, value: str) -> None:
+        if value not in ("fragment", "rows"):
+            raise ValueError(f"workspace_layout must be 'fragment' or 'rows', got {value!r}")
+        self._workspace_layout = value
+        self.vector_field_network.workspace_layout = value
+
+    @property
+    def gradient_storage(self) -> str:
+        return self._gradient_storage
+
+    @gradient_storage.setter
+    def gradient_storage(self, value: str) -> None:
+        if value not in ("fp32", "bf16"):
+            raise ValueError(f"gradient_storage must be 'fp32' or 'bf16', got {value!r}")
+        self._gradient_storage = value
+        self.vector_field_network.gradient_storage = value
+
     def uses_f16x3(self) -> bool:
         """f16x3 inference kernels are used when requested AND specialised for both networks' geometry."""
         if self.precision not in ("f16x3", "fp32"):
             raise ValueError(f"precision must be 'f16x3' or 'fp32', got {self.precision!r}")
-        return self.precision == "f16x3" and self.vector_field_network.supports_f16x3() and \
+        return self.precision == "f16x3" and self.f16x3_disabled is None and self.vector_field_network.supports_f16x3() and \
             self.rendering_network.supports_f16x3()
+
+    @property
+    def f16x3_guard(self) -> str:
+        return self.range_guard.mode
+
+    @f16x3_guard.setter
+    def f16x3_guard(self, mode: str) -> None:
+        if mode not in ("lazy", "strict", "off"):
+            raise ValueError(f"f16x3_guard must be 'lazy', 'strict' or 'off', got {mode!r}")
+        self.range_guard.mode = mode
 
     def _needs_grad(self) -> bool:
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.unique_parameters())
@@ -325,7 +382,27 @@ class VectorFieldNerf:
         pose / intrinsics for the whole batch ([4,4], [7], or leading dimension 1) is accepted too.
 
         ``uniforms`` optionally supplies the three torch.rand draws of the reference in call order
-        (``u_coarse[N,S_c]``, ``u_fine[N,N_f]``, ``u_add[N,N_f]``); otherwise the device Philox stream is used."""
+        (``u_coarse[N,S_c]``, ``u_fine[N,N_f]``, ``u_add[N,N_f]``); otherwise the device Philox stream is used.
+
+        With the f16x3 kernels the call runs under the range guard (guard.py): the kernels report operands outside the range
+        their split-f16 representation covers, and the model falls back to the exact-fp32 kernels — for this very call in
+        "strict" mode, from the next call on in "lazy" mode."""
+        guard = self.range_guard
+        if not (pose.is_cuda and guard.active() and self.uses_f16x3()):
+            return self._render(pose, pixels, intrinsics, epoch, white, uniforms)
+        guard.poll()                               # a report from earlier calls may have arrived
+        if not self.uses_f16x3():
+            return self._render(pose, pixels, intrinsics, epoch, white, uniforms)
+        rng_offset = self._rng_offset
+        with guard.watch(pose.device) as w:
+            out = self._render(pose, pixels, intrinsics, epoch, white, uniforms)
+        if w.flagged:                              # strict mode: repeat this call on the fp32 kernels, same draws
+            self._rng_offset = rng_offset
+            out = self._render(pose, pixels, intrinsics, epoch, white, uniforms)
+        return out
+
+    def _render(self, pose: torch.Tensor, pixels: torch.Tensor, intrinsics: torch.Tensor, epoch: int,
+                white: bool = False, uniforms: Optional[Dict[str, torch.Tensor]] = None) -> NerfOutput:
         cfg = self.config
         if cfg.rendering != "volsdf":
             raise NotImplementedError("rendering='nerf' calls nerf_volume_rendering with swapped arguments in the "

@@ -72,20 +72,18 @@ class _PackedMLP(nn.Module):
         return self._geom
 
     def _invalidate_packs(self) -> None:
-        """Drop every pack built from the parameters / running statistics (they are re-built on next use).  Needed where a
-        kernel wrote one of those tensors through its raw pointer, which does not advance ``tensor._version``."""
-        for name in ("_packed16_cache", "_packed_bwd_cache", "_packed_bwd16_cache"):
-            if hasattr(self, name):
-                delattr(self, name)
-        self._packed_key = None
+        """Mark every pack built from the parameters / running statistics stale (they are re-packed, into the same buffers, on
+        next use).  Needed where a kernel wrote one of those tensors through its raw pointer, which does not advance
+        ``tensor._version`` (the flat optimizer step, the running statistics of a training-mode forward)."""
+        self._pack_epoch = getattr(self, "_pack_epoch", 0) + 1
 
     def _apply(self, fn, *args, **kwargs):
         """.to() / .cuda() / .float() replace buffer tensors: drop the cached tensor list and the packs built from it."""
         out = super()._apply(fn, *args, **kwargs)
-        if hasattr(self, "_pack_tensors"):
-            delattr(self, "_pack_tensors")
-        self._invalidate_packs()
-        self._packed = None
+        for name in ("_pack_tensors", "_packed16_cache", "_packed_bwd_cache", "_packed_bwd16_cache"):
+            if hasattr(self, name):
+                delattr(self, name)
+        self._packed, self._packed_key = None, None
         return out
 
     def _pack_key(self):
@@ -94,7 +92,7 @@ class _PackedMLP(nn.Module):
         tensors = getattr(self, "_pack_tensors", None)
         if tensors is None:
             tensors = self._pack_tensors = [t for d in self._layer_tensors() for t in d.values()]
-        return tensors, tuple([(t.data_ptr(), t._version) for t in tensors])
+        return tensors, (getattr(self, "_pack_epoch", 0),) + tuple([(t.data_ptr(), t._version) for t in tensors])
 
     def packed_weights(self) -> torch.Tensor:
         """Packed (BN-folded, fragment-ordered) weights for the current parameter values."""

@@ -75,6 +75,160 @@ class SequentialAdam(torch.optim.Adam):
         return loss
 
 
+class FlatAdam(SequentialAdam):
+    """The same optimizer with everything in ONE flat fp32 buffer on the device (csrc/vfn_adam.hip): the unique parameters
+    are re-pointed to views of ``flat_param`` (sorted by multiplicity: the parameters listed twice first), their gradients
+    to views of ``flat_grad``, the Adam moments to views of ``flat_exp_avg`` / ``flat_exp_avg_sq``; ``step()`` is one launch,
+    ``zero_grad()`` one memset, and ``clip_grad_norm_`` (below) two launches instead of ~15.  ``state`` / ``state_dict()`` /
+    ``load_state_dict()`` keep torch.optim.Adam's layout (the per-parameter moments are the views), so checkpoints written by
+    either load in the other.  Parameters on the CPU fall back to SequentialAdam's path.
+
+    The update runs through raw device pointers, which does not advance ``tensor._version``; ``after_step`` (a callable) lets the
+    owner invalidate what it caches on parameter versions (the facade's weight packs)."""
+
+    def __init__(self, params, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0) -> None:
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self._flat = None
+        self.after_step = None
+        import weakref
+        for p in self.param_groups[0]["params"]:           # lets clip_grad_norm_ find the flat gradient buffer of a parameter list
+            p._flat_adam = weakref.ref(self)
+
+    # -- flat storage -----------------------------------------------------------------------------
+    def _layout(self):
+        """unique parameters sorted by multiplicity (descending, stable) -> [(param, offset, numel, mult)], regions"""
+        plist = self.param_groups[0]["params"]
+        count, order = {}, []
+        for p in plist:
+            if id(p) not in count:
+                count[id(p)] = 0
+                order.append(p)
+            count[id(p)] += 1
+        order.sort(key=lambda p: -count[id(p)])
+        entries, regions, off = [], [], 0
+        for p in order:
+            m = count[id(p)]
+            if m > 2:
+                raise NotImplementedError("a parameter listed more than twice")
+            if regions and regions[-1][2] == m:
+                regions[-1][1] = off + p.numel()
+            else:
+                regions.append([off, off + p.numel(), m])
+            entries.append((p, off, p.numel(), m))
+            off += p.numel()
+        return entries, [tuple(r) for r in regions], off
+
+    def _bound(self) -> bool:
+        f = self._flat
+        if f is None:
+            return False
+        base = f["param"].data_ptr()
+        return all(p.data_ptr() == base + 4 * off for p, off, _, _ in f["entries"])
+
+    def flat(self):
+        """Build (or re-build, when something replaced a parameter's storage: .to(), .cuda()) the flat buffers; returns the
+        dict {param, grad, exp_avg, exp_avg_sq, entries, regions} or None when the parameters are not on one CUDA device."""
+        if len(self.param_groups) != 1:
+            return None
+        if self._bound():
+            return self._flat
+        entries, regions, total = self._layout()
+        devs = {p.device for p, _, _, _ in entries}
+        if len(devs) != 1 or next(iter(devs)).type != "cuda" or any(p.dtype != torch.float32 for p, _, _, _ in entries) or len(regions) > 4:
+            self._flat = None
+            return None
+        dev = next(iter(devs))
+        from . import lib
+        old = self._flat
+        f = dict(param=torch.empty(total, device=dev), grad=torch.zeros(total, device=dev), exp_avg=torch.zeros(total, device=dev),
+                 exp_avg_sq=torch.zeros(total, device=dev), entries=entries, regions=regions, out2=torch.zeros(2, device=dev),
+                 workspace=lib.flat_clip_workspace(dev), steps=torch.zeros(len(entries), dtype=torch.float32))
+        with torch.no_grad():
+            for i, (p, off, n, m) in enumerate(entries):
+                f["param"][off:off + n].copy_(p.detach().reshape(-1))
+                if p.grad is not None:
+                    f["grad"][off:off + n].copy_(p.grad.detach().reshape(-1))
+                st = self.state.get(p, {})
+                if len(st):                      # moments that exist already (a loaded checkpoint, or a re-build after .to())
+                    f["exp_avg"][off:off + n].copy_(st["exp_avg"].detach().reshape(-1).to(dev))
+                    f["exp_avg_sq"][off:off + n].copy_(st["exp_avg_sq"].detach().reshape(-1).to(dev))
+                    f["steps"][i] = float(st["step"])
+                p.data = f["param"][off:off + n].view(p.shape)
+                p.grad = f["grad"][off:off + n].view(p.shape)
+                self.state[p] = {"step": f["steps"][i], "exp_avg": f["exp_avg"][off:off + n].view(p.shape),
+                                 "exp_avg_sq": f["exp_avg_sq"][off:off + n].view(p.shape)}
+        del old
+        self._flat = f
+        return f
+
+    def _rebind_grads(self, f) -> None:
+        for p, off, n, _ in f["entries"]:
+            view = f["grad"][off:off + n].view(p.shape)
+            if p.grad is None:
+                p.grad = view
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+                p.grad = view
+
+    # -- torch.optim.Optimizer interface ------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        f = self.flat()
+        if f is None:
+            return super().zero_grad(set_to_none=set_to_none)
+        f["grad"].zero_()
+        for p, off, n, _ in f["entries"]:          # (keeps the views: setting .grad to None would detach them from the buffer)
+            if p.grad is None or p.grad.data_ptr() != f["grad"].data_ptr() + 4 * off:
+                p.grad = f["grad"][off:off + n].view(p.shape)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        f = self.flat()
+        if f is None:
+            return super().step(closure)
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        from . import lib
+        self._rebind_grads(f)
+        group = self.param_groups[0]
+        if group.get("amsgrad") or group.get("maximize") or group.get("capturable") or group.get("differentiable"):
+            raise NotImplementedError("FlatAdam covers the reference's plain Adam configuration")
+        beta1, beta2 = group["betas"]
+        lr = float(group["lr"])
+        step_size, bc2_sqrt = [], []
+        first_of_region = {}
+        for i, (p, off, n, m) in enumerate(f["entries"]):
+            first_of_region.setdefault(m, i)
+        for (start, end, m) in f["regions"]:
+            t0 = float(f["steps"][first_of_region[m]])      # every parameter of a region has taken the same number of updates
+            for k in range(2):
+                t = t0 + k + 1
+                step_size.append(lr / (1 - beta1 ** t))
+                bc2_sqrt.append((1 - beta2 ** t) ** 0.5)
+        lib.flat_adam_step(f["param"], f["grad"], f["exp_avg"], f["exp_avg_sq"], f["regions"], step_size, bc2_sqrt, beta1, beta2,
+                           group["eps"], group["weight_decay"])
+        f["steps"] += torch.tensor([float(m) for _, _, _, m in f["entries"]])
+        if self.after_step is not None:
+            self.after_step()
+        return loss
+
+    def load_state_dict(self, state_dict) -> None:
+        super().load_state_dict(state_dict)          # per-parameter tensors (clones on the parameters' device)
+        self._flat = None                            # re-built, with these moments, on next use
+
+    def regions_for(self, plist) -> bool:
+        """True when ``plist`` names exactly this optimizer's parameters with the same multiplicities (the fused clip applies)."""
+        f = self.flat()
+        if f is None:
+            return False
+        count = {}
+        for p in plist:
+            count[id(p)] = count.get(id(p), 0) + 1
+        return len(count) == len(f["entries"]) and all(count.get(id(p), 0) == m for p, _, _, m in f["entries"])
+
+
 @torch.no_grad()
 def clip_grad_norm_(parameters, max_norm: float, norm_type: float = 2.0) -> torch.Tensor:
     """``torch.nn.utils.clip_grad_norm_(parameters, max_norm, foreach=False)`` for a list that may name a parameter more
@@ -84,6 +238,14 @@ def clip_grad_norm_(parameters, max_norm: float, norm_type: float = 2.0) -> torc
     if norm_type != 2.0:
         raise NotImplementedError("only the 2-norm (the reference's default) is implemented")
     plist = [p for p in (parameters if not isinstance(parameters, torch.Tensor) else [parameters])]
+    owner = getattr(plist[0], "_flat_adam", None) if plist else None
+    owner = owner() if owner is not None else None
+    if owner is not None and owner.regions_for(plist):           # the gradients are one flat buffer: two launches
+        from . import lib
+        f = owner.flat()
+        owner._rebind_grads(f)
+        lib.flat_clip_grad_norm(f["grad"], f["regions"], float(max_norm), f["workspace"], f["out2"])
+        return f["out2"][0].clone()
     passes = [[p for p in ps if p.grad is not None] for ps in _passes(plist)]
     passes = [ps for ps in passes if ps]
     if not passes:
