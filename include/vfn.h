@@ -386,6 +386,11 @@ typedef struct {
     float scale;
 } vfn_unfold_entry;
 int vfn_unfold_weight_grads(const vfn_unfold_entry* entries, int32_t n_entries, int32_t groups, void* stream);
+/* The same with bit i of accumulate_mask saying that entry i ADDS its result to what g_w / g_b / g_bn_w / g_bn_b already hold:
+ * the targets are then the parameters' own .grad tensors, and autograd's ~90 per-parameter accumulation kernels per training
+ * step are not launched at all. */
+int vfn_unfold_weight_grads_acc(const vfn_unfold_entry* entries, int32_t n_entries, int32_t groups, uint32_t accumulate_mask,
+                                void* stream);
 
 /* Supervision points of the trainer (train/vector_field_nerf_train.py:186-214): n uniform samples in the spherical
  * shell r_min <= |p - centroid| <= r_max (models/samplers/sampler.py:160-193) and their radial unit ground truth

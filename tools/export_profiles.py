@@ -39,3 +39,31 @@ traffic["modes"] = {"vfn_mlp16_kernel<0>": "VF, vector columns only", "vfn_mlp16
 with open(os.path.join(out, f"traffic_{tag}.json"), "w") as fh:
     json.dump(traffic, fh, indent=1)
 print(open(os.path.join(out, f"traffic_{tag}.json")).read())
+
+# optional: matrix-pipe utilisation counters (a separate pass: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES
+# GRBM_GUI_ACTIVE -d <src>/pmc_mfma -o pm -- python3 bench.py ...).  Per kernel: the counters averaged over launches, the launch
+# duration from the kernel trace, and the derived figures of MI355X_MICROARCH.md: effective clock = GRBM_GUI_ACTIVE / 8 / duration,
+# matrix-pipe busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x clock cycles of the launch).
+pm = os.path.join(src, "pmc_mfma", "pm_results.db")
+if os.path.exists(pm):
+    c = sqlite3.connect(pm)
+    per = {}
+    q = "select kernel_name, counter_name, avg(value), count(*) from counters_collection group by kernel_name, counter_name"
+    for name, counter, val, n in c.execute(q):
+        if "vfn_" in name:
+            per.setdefault(short(name), {})[counter] = round(val, 1)
+            per[short(name)]["launches"] = n
+    dur = {short(name): avg for name, calls, total, avg, pct in rows}
+    for k, v in per.items():
+        us = dur.get(k)
+        if us and "GRBM_GUI_ACTIVE" in v:
+            clock_ghz = v["GRBM_GUI_ACTIVE"] / 8.0 / (us * 1e3)
+            v["avg_launch_us_kernel_trace"] = round(us, 2)
+            v["effective_clock_ghz"] = round(clock_ghz, 3)
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+                v["mfma_busy_fraction_of_1024_simds"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * clock_ghz * us * 1e3), 4)
+    with open(os.path.join(out, f"pmc_mfma_{tag}.json"), "w") as fh:
+        json.dump({"collected": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (own pass), averaged over "
+                                "launches; profiled passes run at a lower clock than un-profiled ones (MI355X_MICROARCH.md, DVFS (2))",
+                   "kernels": per}, fh, indent=1)
+    print(open(os.path.join(out, f"pmc_mfma_{tag}.json")).read())

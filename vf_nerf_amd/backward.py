@@ -128,8 +128,16 @@ def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=(), fast: bo
     G = _groups(m)
     grads: Dict[torch.nn.Parameter, torch.Tensor] = {}
     unfold = []
+    # When every parameter of the net already HAS a gradient tensor (the flat optimizer keeps them as views of one buffer, zeroed
+    # by zero_grad), the un-fold kernel adds straight into it and nothing is handed to autograd for these parameters: the ~90
+    # AccumulateGrad additions of a training step (one launch each) disappear.  (Tensor hooks on the parameters do not fire then.)
+    direct = getattr(net, "accumulate_into_grad", True) and all(
+        p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.device == dev and not p.grad.requires_grad
+        for p in net.parameters())
 
     def out_for(p):
+        if direct:
+            return p.grad
         if p not in grads:
             grads[p] = torch.empty_like(p)
         return grads[p]
@@ -171,14 +179,14 @@ def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=(), fast: bo
         lib.weight_grad_frag(2, dz_head, lib.DYF_DZ4, inputs[-1], frag[1], m, G, part, dbp)
     else:
         lib.weight_grad_partials(2, dz_head, 4, 3, inputs[-1], HID, HID, m, G, part, dbp, x_f16=x_f16)
-    fresh = last.weight not in grads          # the feature rows of the last Linear were skipped (vector-only forward)
+    fresh = not direct and last.weight not in grads          # the feature rows of the last Linear were skipped (vector-only forward)
     unfold.append(dict(dw_act=part, db=dbp, w=last.weight.detach(), b_lin=last.bias.detach(), g_w=out_for(last.weight),
                        g_b=out_for(last.bias), rows=3, row_off=0, in_dim=last.in_features, slab_rows=32, act_c0=0,
                        act_nc=HID, scale=1.0))
     if fresh and last.out_features > 3:
         grads[last.weight][3:].zero_()
         grads[last.bias][3:].zero_()
-    lib.unfold_weight_grads(unfold, G)
+    lib.unfold_weight_grads(unfold, G, accumulate_mask=(1 << len(unfold)) - 1 if direct else 0)
     return grads
 
 

@@ -134,6 +134,12 @@ int check_shipped(int net_kind, const vfn_net_geom* g, const char* what) {
 // ------------------------------------------------------------------------------------------------
 // kernel
 // ------------------------------------------------------------------------------------------------
+#ifndef BW16_EARLY_EPI
+#define BW16_EARLY_EPI 1
+#endif
+#ifndef BW16_LATE_STORES
+#define BW16_LATE_STORES 1
+#endif
 #define BW_SLOT_KB 32
 #define BW_SLOT (BW_SLOT_KB * 64)       // uint4 elements per ring slot
 #define BW_WAVES 4
@@ -309,9 +315,18 @@ template <int MODE, int C0, int NB, int NCH, int OSLOT, int MASK, int HEAD, int 
 __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Carry& cy, const Pipe& p, const float (&dzv)[3],
                                        const float (&dzc)[3], int wave, int lane) {
     constexpr int H = NB / 2;                         // hand-over after step H-1
+#if BW16_EARLY_EPI
+    // The pending tile's epilogue runs in the FIRST half of the chunk (its masks are register-resident sign bits; only the
+    // tanh'ed feature tiles load values, and wait for them) and its dY stores go out right after the hand-over: they then have
+    // a whole chunk to retire before the next vmcnt(0) instead of half of one.
+    constexpr int E = H;                              // steps 0 .. E-1 carry the pending tile's epilogue
+    constexpr int EPI0 = 0, ST0 = H;                  // first epilogue step, first store step
+#else
     constexpr int E = NB - 2 - H;                     // steps H .. H+E-1 carry the pending tile's epilogue
+    constexpr int EPI0 = H, ST0 = H + E;
+#endif
     constexpr int DSTEPS = NB - H;
-    static_assert(2 * PT >= H + E || PT < 0, "the pending tile must be complete before it is read");
+    static_assert(2 * PT >= EPI0 + E || PT < 0, "the pending tile must be complete before it is read");
     const int g = lane >> 5;
     static_for<NCH>([&](auto ich) {
         constexpr int ch = decltype(ich)::value;
@@ -336,15 +351,26 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, xin.hi[st], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, xin.lo[st], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, xin.hi[st], acc, 0, 0, 0);
-            // -- middle: ring hand-over (also retires the mask loads and dY stores issued in the previous chunk)
+            // -- middle: ring hand-over.  The wave must see ITS pieces of chunk c+1 landed (issued in the previous chunk's second
+            // half); the barrier then extends that to everybody's pieces and frees the slot of chunk c-1.  Vector-memory
+            // operations retire in issue order (MI355X_MICROARCH.md, s_waitcnt), and the only operations issued AFTER those DMA
+            // pieces are the previous chunk's dY stores (the very last instructions of its last step, below): the wait leaves
+            // exactly those in flight, so a tile's stores have a chunk and a half to retire instead of stalling every hand-over —
+            // the chain was bound by that store round trip, not by store bandwidth (3.8 ms -> see DESIGN.md).
             if (st == H - 1 && dnext.kb > 0) {
+#if BW16_LATE_STORES
+                constexpr bool prev_stored = ch > 0 ? (ch - 1 > 0 || PSLOT >= 0) : (C0 > first_chunk(MODE, first_step(MODE)));
+                if (!prev_stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // four store instructions per tile (16 or 8 bytes per lane)
+#else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                 __builtin_amdgcn_s_barrier();
             }
             // -- second half: the pending tile's epilogue ...
-            if (st >= H && st < H + E && (ch > 0 || PSLOT >= 0)) {
+            if (st >= EPI0 && st < EPI0 + E && (ch > 0 || PSLOT >= 0)) {
 #pragma unroll
-                for (int pr = (st - H) * 8 / E; pr < (st - H + 1) * 8 / E; ++pr) {
+                for (int pr = (st - EPI0) * 8 / E; pr < (st - EPI0 + 1) * 8 / E; ++pr) {
                     const int sblk = pr >> 2, j = (pr & 3) * 2;
                     if (ch > 0) epi_pair<MASK, HEAD, (ch > 0 ? ch - 1 : 0)>(cy.pend, cy.mask, pr, p, HEAD == 1 ? dzc : dzv, g, ehi[sblk], elo[sblk], j);
                     else epi_pair<PMASK, PHEAD, (PT >= 0 ? PT : 0)>(cy.pend, cy.mask, pr, p, PHEAD == 1 ? dzc : dzv, g, ehi[sblk], elo[sblk], j);
@@ -357,13 +383,15 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
                 }
             }
             // ... its dY stores, the mask loads of the tile being computed, and the DMA pieces of chunk c+2
-            if (st >= H + E && (ch > 0 || PSLOT >= 0)) {
+#if !BW16_LATE_STORES
+            if (st >= ST0 && st < ST0 + 2 && (ch > 0 || PSLOT >= 0)) {
 #pragma unroll
-                for (int q = (st - H - E) * 2; q < (st - H - E + 1) * 2; ++q) {
+                for (int q = (st - ST0) * 2; q < (st - ST0 + 1) * 2; ++q) {
                     if (ch > 0) store_group<OSLOT, (ch > 0 ? ch - 1 : 0)>(p, cy.pend, q);
                     else store_group<(PSLOT >= 0 ? PSLOT : 0), (PT >= 0 ? PT : 0)>(p, cy.pend, q);
                 }
             }
+#endif
             if (st >= H && st < H + 4) mnext[st - H] = mask_group<OSLOT, ch, MASK>(p, st - H);
             if (st >= H && ddma.kb > 0) {
 #pragma unroll
@@ -373,6 +401,17 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
                 }
             }
             if (st == NB - 1 && dnext.kb > 0) prefetch_chunk<MODE, (dnext.kb > 0 ? C + 1 : C)>(cy, p, lane);
+#if BW16_LATE_STORES
+            // the pending tile's dY: the LAST vector-memory instructions of the chunk (see the hand-over)
+            if (st == NB - 1 && (ch > 0 || PSLOT >= 0)) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (ch > 0) store_group<OSLOT, (ch > 0 ? ch - 1 : 0)>(p, cy.pend, q);
+                    else store_group<(PSLOT >= 0 ? PSLOT : 0), (PT >= 0 ? PT : 0)>(p, cy.pend, q);
+                }
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         cy.pend = acc;

@@ -366,6 +366,10 @@ struct Mlp16Args {
 // Range of the split-f16 operands: activations ride at 2^6 x their value (VFN16_XSCALE) and are clamped here, i.e. true
 // activations above ~937 saturate.  The clamp keeps inf - inf = NaN out of the split; the status word reports that it acted.
 #define VFN16_CLAMP 60000.0f
+#ifndef VFN16_RANGE_TRACK
+#define VFN16_RANGE_TRACK 2       // where the kernels look for values at the clamp: 0 nowhere, 1 per epilogue pair (+3.2 % on the fused
+                                  // launch), 2 per finished tile (+1.3 %; placing it in the shadow of the next tile's first MFMAs measured the same)
+#endif
 
 struct X16 { half8 hi[16]; half8 lo[16]; };     // 256 activation columns x this lane's point, split (16 K-blocks of 16)
 struct A16 { half8 hi[3]; half8 lo[3]; };       // 48 auxiliary (encoding) columns
@@ -460,7 +464,9 @@ template <int EPI, bool KEEP>
 __device__ __forceinline__ void epi_pair(f32x16& pend, unsigned long long& sat, int pr, half8& hi, half8& lo, int j) {
     float v0 = pend[2 * pr], v1 = pend[2 * pr + 1];
     // one compare per pair into a SCALAR accumulator (a vector accumulator carried through the pipelined loop made hipcc spill)
+#if VFN16_RANGE_TRACK == 1
     if (EPI == EPI_RELU) sat |= __builtin_amdgcn_ballot_w64(fmaxf(v0, v1) >= VFN16_CLAMP);
+#endif
     if (!VFN16_ASCALE || EPI != EPI_RELU) { v0 *= VFN16_INV_WSCALE; v1 *= VFN16_INV_WSCALE; }
     // ReLU, saturated below the f16 range so that an out-of-family activation degrades instead of turning into
     // inf - inf = NaN in the split (activations of BatchNorm'ed layers are O(1..100)); one v_max3 per pair remembers
@@ -675,6 +681,14 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
         }
         if (EPI == EPI_RELU || EPI == EPI_TANH) {
             cy.pend = acc;
+#if VFN16_RANGE_TRACK == 2
+            if (EPI == EPI_RELU) {        // the finished tile's largest (2^6-scaled) pre-activation: 8 v_max3 + one compare per tile
+                float mx = fmaxf(acc[0], acc[1]);
+#pragma unroll
+                for (int r = 2; r < 16; r += 2) mx = fmaxf(mx, fmaxf(acc[r], acc[r + 1]));
+                cy.sat |= __builtin_amdgcn_ballot_w64(mx >= VFN16_CLAMP);
+            }
+#endif
         } else {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {

@@ -30,11 +30,13 @@ struct UnfoldArgs {
     UnfoldEntry e[UF_MAX];
     int n_entries;
     int groups;
+    unsigned accumulate;   // bit i: entry i ADDS to what its gradient tensors hold (they are the parameters' .grad) instead of overwriting
 };
 
 __global__ __launch_bounds__(320) void vfn_unfold_kernel(const UnfoldArgs a) {
     __shared__ float red[320 / 64 + 1][2];
     const UnfoldEntry& e = a.e[blockIdx.y];
+    const bool acc = (a.accumulate >> blockIdx.y) & 1u;
     const int n = blockIdx.x;
     if (n >= e.rows) return;
     const int tid = threadIdx.x, G = a.groups;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(320) void vfn_unfold_kernel(const UnfoldArgs a) {
     float dg = 0.f;
     if (valid) {
         const size_t o = (size_t)row * e.in_dim + c0 + k;
-        e.g_w[o] = s_fold * sub;
+        e.g_w[o] = (acc ? e.g_w[o] : 0.f) + s_fold * sub;
         if (e.bn_w) dg = sub * e.w[o];
     }
     // block reduction of (dg, dbp)
@@ -72,10 +74,10 @@ __global__ __launch_bounds__(320) void vfn_unfold_kernel(const UnfoldArgs a) {
     if (tid == 0) {
         float dgam = 0.f, db = 0.f;
         for (int w = 0; w < (int)(blockDim.x + 63) / 64; ++w) { dgam += red[w][0]; db += red[w][1]; }
-        e.g_b[row] = s_fold * db;
+        e.g_b[row] = (acc ? e.g_b[row] : 0.f) + s_fold * db;
         if (e.bn_w) {
-            e.g_bn_w[row] = (dgam + db * (e.b_lin[row] - e.bn_mean[row])) * inv;
-            e.g_bn_b[row] = db;
+            e.g_bn_w[row] = (acc ? e.g_bn_w[row] : 0.f) + (dgam + db * (e.b_lin[row] - e.bn_mean[row])) * inv;
+            e.g_bn_b[row] = (acc ? e.g_bn_b[row] : 0.f) + db;
         }
     }
 }
@@ -84,6 +86,11 @@ __global__ __launch_bounds__(320) void vfn_unfold_kernel(const UnfoldArgs a) {
 
 // Flat C view of UnfoldEntry (include/vfn.h: vfn_unfold_entry has the same fields in the same order)
 extern "C" int vfn_unfold_weight_grads(const vfn_unfold_entry* entries, int32_t n_entries, int32_t groups, void* stream) {
+    return vfn_unfold_weight_grads_acc(entries, n_entries, groups, 0u, stream);
+}
+
+extern "C" int vfn_unfold_weight_grads_acc(const vfn_unfold_entry* entries, int32_t n_entries, int32_t groups, uint32_t accumulate_mask,
+                                           void* stream) {
     VFN_REQUIRE(entries && n_entries >= 1 && n_entries <= UF_MAX, "vfn_unfold_weight_grads: n_entries=%d outside [1,%d]", n_entries, UF_MAX);
     VFN_REQUIRE(groups >= 1 && groups <= 4096, "vfn_unfold_weight_grads: groups=%d", groups);
     static_assert(sizeof(vfn_unfold_entry) == sizeof(UnfoldEntry), "ABI struct and kernel struct must match");
@@ -99,7 +106,7 @@ extern "C" int vfn_unfold_weight_grads(const vfn_unfold_entry* entries, int32_t 
                     "vfn_unfold_weight_grads: entry %d has bad sizes", i);
         max_rows = e.rows > max_rows ? e.rows : max_rows;
     }
-    a.n_entries = n_entries; a.groups = groups;
+    a.n_entries = n_entries; a.groups = groups; a.accumulate = accumulate_mask;
     hipLaunchKernelGGL(vfn_unfold_kernel, dim3(max_rows, n_entries), dim3(320), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_unfold_weight_grads");
 }

@@ -31,7 +31,7 @@ EXPORTS = (
     "vfn_linear_rows", "vfn_linear_rows_stat_parts", "vfn_bstat_row_parts", "vfn_colsum_finish", "vfn_bstat_finalize",
     "vfn_bstat_relu_rows", "vfn_bstat_relu_bwd_sums", "vfn_bstat_relu_bwd_rows", "vfn_act_bwd_rows", "vfn_embed_rows",
     "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax",
-    "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step",
+    "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step", "vfn_unfold_weight_grads_acc",
 )
 
 
@@ -548,8 +548,9 @@ class UnfoldEntry(C.Structure):
                [("scale", C.c_float)]
 
 
-def unfold_weight_grads(entries: Sequence[dict], groups: int) -> None:
-    """entries: dicts with the tensors / ints of vfn_unfold_entry (missing tensors = NULL)."""
+def unfold_weight_grads(entries: Sequence[dict], groups: int, accumulate_mask: int = 0) -> None:
+    """entries: dicts with the tensors / ints of vfn_unfold_entry (missing tensors = NULL); bit i of ``accumulate_mask``: entry i
+    adds to its g_* tensors instead of overwriting them."""
     arr = (UnfoldEntry * len(entries))()
     for i, e in enumerate(entries):
         for name, _ in UnfoldEntry._fields_[:12]:
@@ -557,7 +558,8 @@ def unfold_weight_grads(entries: Sequence[dict], groups: int) -> None:
         for name, _ in UnfoldEntry._fields_[12:20]:
             setattr(arr[i], name, int(e.get(name, 0)))
         arr[i].scale = float(e.get("scale", 1.0))
-    _check(load().vfn_unfold_weight_grads(arr, C.c_int32(len(entries)), C.c_int32(groups), _stream()), "vfn_unfold_weight_grads")
+    _check(load().vfn_unfold_weight_grads_acc(arr, C.c_int32(len(entries)), C.c_int32(groups), C.c_uint32(accumulate_mask), _stream()),
+           "vfn_unfold_weight_grads")
 
 
 def weight_grad_partials_bf16(dy, x, n_points: int, groups: int, dw_part, db_part=None, x_f16: bool = False):
