@@ -346,7 +346,7 @@ def main() -> None:
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="untimed run of the same work right before the timed steps (the chip's clock settles under load)")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step sub-object of the default line")
-    ap.add_argument("--train-steps", type=int, default=8, help="optimizer steps timed for the training sub-object")
+    ap.add_argument("--train-steps", type=int, default=12, help="optimizer steps timed for the training sub-object")
     ap.add_argument("--activations", choices=("fp32", "f16"), default="f16",
                     help="training: storage of the hidden activations for the weight-gradient kernels (f16 = the default, "
                          "11-bit operands in one factor of dW, half the workspace traffic; fp32 = fp32-equivalent gradients)")
@@ -529,7 +529,9 @@ def main() -> None:
     train_rec = None
     if not args.no_train:
         targs = argparse.Namespace(**vars(args))
-        targs.steps, targs.warmup = args.train_steps, 2
+        targs.steps, targs.warmup = args.train_steps, 5      # (the first steps size the caching allocator's 15 GB of workspace)
+        del out
+        torch.cuda.empty_cache()
         tmodel, tuv, tpose, tK = build_scene(dev, args.rays, s_c, n_f, seed=rank)
         tmodel.precision = args.precision
         tmodel.activation_storage = args.activations

@@ -140,6 +140,14 @@ int check_shipped(int net_kind, const vfn_net_geom* g, const char* what) {
 #ifndef BW16_LATE_STORES
 #define BW16_LATE_STORES 1
 #endif
+#ifndef BW16_STORE_AUX
+#define BW16_STORE_AUX 2          // cache policy bits of the dY stores: 2 = nt (streaming).  With fragment-ordered slots every store is
+                                  // eight whole 128-byte lines; nt keeps 7 GB of write-once data from washing through the L2s:
+                                  // training step 12.5 -> 11.5 ms (0 = default write-back)
+#endif
+#ifndef BW_RING
+#define BW_RING 4                 // LDS ring slots of 32 KiB: a chunk's pieces are issued BW_RING - 1 chunks ahead
+#endif
 #define BW_SLOT_KB 32
 #define BW_SLOT (BW_SLOT_KB * 64)       // uint4 elements per ring slot
 #define BW_WAVES 4
@@ -203,11 +211,11 @@ __device__ __forceinline__ void dma_chunk(const Pipe& p, int wave, int lane) {
     constexpr ChunkD d = chunk_of(MODE, C);
 #pragma unroll
     for (int i = 0; i * BW_WAVES < d.kb; ++i)
-        if (wave + BW_WAVES * i < d.kb) dma_piece<d.net, d.off_kb, C % 3>(p, wave + BW_WAVES * i, lane);
+        if (wave + BW_WAVES * i < d.kb) dma_piece<d.net, d.off_kb, C % BW_RING>(p, wave + BW_WAVES * i, lane);
 }
 template <int MODE, int C>
 __device__ __forceinline__ void prefetch_chunk(Carry& cy, const Pipe& p, int lane) {
-    const uint4* cb = p.lds + (C % 3) * BW_SLOT;
+    const uint4* cb = p.lds + (C % BW_RING) * BW_SLOT;
     cy.fh0 = __builtin_bit_cast(bf8, cb[0 * 64 + lane]);
     cy.fl0 = __builtin_bit_cast(bf8, cb[1 * 64 + lane]);
 }
@@ -238,8 +246,10 @@ __device__ __forceinline__ void store_group(const Pipe& p, const f32x16& v, int 
         typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
         const bf4 b = __builtin_convertvector(g, bf4);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, b), rs, (int)p.dvoff, (int)((TILE * p.st_tile + q * p.st_q) >> 1), 0);
-    } else {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, b), rs, (int)p.dvoff, (int)((TILE * p.st_tile + q * p.st_q) >> 1), BW16_STORE_AUX);
+    } else if (p.st_q == 1024u) {     // fragment order: whole lines per instruction, streaming stores
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)p.dvoff, (int)(TILE * p.st_tile + q * p.st_q), BW16_STORE_AUX);
+    } else {                          // row-major: 32 lines x 32 bytes per instruction — the default write-back policy (nt costs +33 % there)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)p.dvoff, (int)(TILE * p.st_tile + q * p.st_q), 0);
     }
 }
@@ -331,9 +341,9 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
     static_for<NCH>([&](auto ich) {
         constexpr int ch = decltype(ich)::value;
         constexpr int C = C0 + ch;
-        constexpr ChunkD dcur = chunk_of(MODE, C), dnext = chunk_of(MODE, C + 1), ddma = chunk_of(MODE, C + 2);
+        constexpr ChunkD dcur = chunk_of(MODE, C), dnext = chunk_of(MODE, C + 1), ddma = chunk_of(MODE, C + BW_RING - 1);
         static_assert(dcur.kb == 2 * NB, "step shape and chunk table disagree");
-        const uint4* cb = p.lds + (C % 3) * BW_SLOT;
+        const uint4* cb = p.lds + (C % BW_RING) * BW_SLOT;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -359,9 +369,15 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
             // the chain was bound by that store round trip, not by store bandwidth (3.8 ms -> see DESIGN.md).
             if (st == H - 1 && dnext.kb > 0) {
 #if BW16_LATE_STORES
-                constexpr bool prev_stored = ch > 0 ? (ch - 1 > 0 || PSLOT >= 0) : (C0 > first_chunk(MODE, first_step(MODE)));
-                if (!prev_stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // four store instructions per tile (16 or 8 bytes per lane)
+                // operations younger than this wave's pieces of chunk c+1, which may stay in flight: the four dY stores at the end
+                // of a chunk (every chunk but the launch's first has a pending tile), and with a four-slot ring the pieces of
+                // chunk c+2 between them.  (The tanh tiles' value loads sit among them too: uncounted, so the wait is merely
+                // stricter there.)
+                constexpr int young = (C >= 1 ? 4 * (C - 1 > 0) : 0) +
+                                      (BW_RING > 3 ? (C >= 1 ? chunk_of(MODE, C - 1 + BW_RING - 1).kb / BW_WAVES : 0) + (C >= 2 ? 4 * (C - 2 > 0) : 0) : 0);
+                static_assert(young < 64, "vmcnt is a 6-bit field");
+                if constexpr (young == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(young) : "memory");
 #else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -396,8 +412,8 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
             if (st >= H && ddma.kb > 0) {
 #pragma unroll
                 for (int i = (st - H) * BW_PMAX / DSTEPS; i < (st - H + 1) * BW_PMAX / DSTEPS; ++i) {
-                    if (BW_WAVES * i + BW_WAVES <= ddma.kb) dma_piece<ddma.net, ddma.off_kb, (C + 2) % 3>(p, wave + BW_WAVES * i, lane);
-                    else if (BW_WAVES * i < ddma.kb) { if (wave + BW_WAVES * i < ddma.kb) dma_piece<ddma.net, ddma.off_kb, (C + 2) % 3>(p, wave + BW_WAVES * i, lane); }
+                    if (BW_WAVES * i + BW_WAVES <= ddma.kb) dma_piece<ddma.net, ddma.off_kb, (C + BW_RING - 1) % BW_RING>(p, wave + BW_WAVES * i, lane);
+                    else if (BW_WAVES * i < ddma.kb) { if (wave + BW_WAVES * i < ddma.kb) dma_piece<ddma.net, ddma.off_kb, (C + BW_RING - 1) % BW_RING>(p, wave + BW_WAVES * i, lane); }
                 }
             }
             if (st == NB - 1 && dnext.kb > 0) prefetch_chunk<MODE, (dnext.kb > 0 ? C + 1 : C)>(cy, p, lane);
@@ -422,8 +438,8 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
 
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
-    __shared__ __attribute__((aligned(16))) uint4 s_ring[3 * BW_SLOT + 2 * 3 * 256 / 4];
-    float* s_heads = reinterpret_cast<float*>(s_ring + 3 * BW_SLOT);
+    __shared__ __attribute__((aligned(16))) uint4 s_ring[BW_RING * BW_SLOT + 2 * 3 * 256 / 4];
+    float* s_heads = reinterpret_cast<float*>(s_ring + BW_RING * BW_SLOT);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -485,6 +501,7 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
     }
     dma_chunk<MODE, 0>(p, wave, lane);
     dma_chunk<MODE, 1>(p, wave, lane);
+    if (BW_RING > 3) dma_chunk<MODE, 2>(p, wave, lane);
     __syncthreads();                       // head tables visible (this also waits for the two chunks: once, harmless)
 
     // ---- the tiles the chain starts from: no matrix product, just the head update / the caller's gradient ----

@@ -52,7 +52,15 @@ __global__ __launch_bounds__(320) void vfn_unfold_kernel(const UnfoldArgs a) {
     const bool valid = slab != nullptr && k < nc;
     if (valid) {
         const float* p = slab + (size_t)n * ld + k;
-        for (int g = 0; g < G; ++g) s += p[(size_t)g * gstride];
+        int g = 0;
+        for (; g + 8 <= G; g += 8) {          // eight slabs in flight per thread (the sum keeps the slab order)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(g + u) * gstride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; g < G; ++g) s += p[(size_t)g * gstride];
     }
     float dbp = 0.f;
     for (int g = tid; g < G; g += blockDim.x) dbp += e.db[(size_t)g * e.slab_rows + n];

@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvfn.so")
+LIB_PATH = os.environ.get("VFN_LIB") or os.path.join(_HERE, "csrc", "libvfn.so")     # VFN_LIB: an experimental build (tools/)
 
 MAX_LAYERS = 16
 HIDDEN = 256
