@@ -9,7 +9,12 @@ the product package ``vf_nerf_amd`` never does.
 Parity pin: the reference has no tests / golden vectors of its own, so
 this oracle is pinned against outputs of the reference itself, captured in the build
 container by ``tests/golden/make_golden.py`` (imports ``/root/reference`` read-only) and
-committed as ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` replays them.
+committed as ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` replays them.  The
+trainer-side restatements (``vf_loss_terms``, ``sphere_shell_points_from_draws``, the
+supervision selections, ``trainer_epoch``) are pinned the same way by
+``tests/golden/make_train_golden.py``, which runs the reference's own ``train_epoch``,
+``VFLoss`` and ``SphereSampler`` (``trainer_steps.npz``): three optimizer steps reproduced
+bit for bit.
 
 Every function cites the reference lines it restates (paths relative to the reference
 root).  Weights are passed as state dicts using the reference's key names
