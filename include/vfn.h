@@ -199,6 +199,36 @@ int vfn_uniform_sample(int32_t n_rays, int32_t n_samples, float near, float far,
  * ray_sampler.py:277; an all-zero row gives 0, Q9), int64. */
 int vfn_rows_argmax(const float* w, int32_t n_rows, int32_t n_cols, int64_t* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The whole gradient-free render() in ONE call: VectorFieldNerf.render (models/nerf/vector_field_nerf.py:216-338) on the f16x3
+ * kernels with one vector-field evaluation per distinct sample — the launches of vfn_fill_uniform, vfn_raygen_uniform,
+ * vfn_vf_render_fused16_fwd (proposal samples), vfn_ray_density_weights (argmax), vfn_range_fine_sample_indexed,
+ * vfn_vf_render_fused16_scatter (new samples), vfn_scatter_rows3 and vfn_ray_density_weights (composite), issued from C on one
+ * stream out of one caller-supplied workspace (vfn_render_fwd_workspace_bytes; no allocation, no synchronisation).
+ * Random draws: u_coarse[N,S_c] / u_fine[N,N_f] (read only when the matching perturb flag is set) and u_add[N,N_f] (always
+ * consumed, Q9) may each be NULL, in which case they come from the Philox stream (seed, offset) in that order; the call
+ * consumes ceil(generated / 4) counter values.  far_*_per_ray: optional [N] (ray_sampler.py:126-127).
+ * Outputs: ray_dirs[N,3] (unit), z_vals[N,S_t], points[N,S_t,3], normals[N*S_t,3], colors[N*S_t,3], weights[N,S_t], rgb[N,3],
+ * depth[N]; N*S_t < 2^22.  Values are those of the individual entry points (bit-identical to calling them one by one). */
+typedef struct vfn_render_params {
+    int32_t n_rays, n_coarse, n_fine;   /* N, S_c, N_f = min(fine_sampler.N_samples, max_samples) */
+    int32_t pose_is_quat;
+    int32_t perturb_coarse, perturb_fine;
+    float near_coarse, near_fine;       /* ray_sampler.near, fine_sampler.near (the trainer sets both from the dataset bounds) */
+    float far_coarse, far_fine;         /* used when the per-ray pointer is NULL */
+    float fine_range, window_step, span; /* as in vfn_fine_params: window_step, span evaluated in double by the host */
+    vfn_density_params density;         /* n_rays / n_samples are filled in per pass */
+    uint64_t seed, offset;              /* Philox stream for the draws not supplied */
+} vfn_render_params;
+int64_t vfn_render_fwd_workspace_bytes(const vfn_render_params* p);
+int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf_geom, const void* vf_packed16,
+                   const vfn_net_geom* rn_geom, const void* rn_packed16, const float* uv, const float* pose,
+                   const float* intrinsics, const float* t_vals, const float* far_coarse_per_ray,
+                   const float* far_fine_per_ray, const float* density_scalars, const float* u_coarse,
+                   const float* u_fine, const float* u_add, void* workspace, float* ray_dirs, float* z_vals,
+                   float* points, float* normals, float* colors, float* weights, float* rgb, float* depth,
+                   void* stream);
+
 /* Counter-based uniforms in [0,1) for production sampling (Philox4x32-10, one 4-tuple per 4 outputs). */
 int vfn_fill_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 

@@ -312,3 +312,39 @@ def test_range_guard_costs_nothing_on_the_hot_path():
             model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
     torch.cuda.synchronize()
     assert reads <= 3 and model.f16x3_disabled is None
+
+
+@pytest.mark.parametrize("name", ["c1_perturb", "odd_orbit", "c1_det", "shipped_sizes"])
+def test_one_call_render_equals_the_launch_by_launch_path(name):
+    """vfn_render_fwd (csrc/vfn_render.hip: the whole gradient-free render() issued from C out of one workspace) against the
+    facade's launch-by-launch path: every output bit-identical — with the reference's draws replayed, with the device Philox
+    stream (same seed and offset: the draws and the advance of the stream must match), with per-ray far values, a shared
+    [4,4] pose, the white background — and against the reference's golden outputs."""
+    fx, d = load_fixture(name)
+    model = build_model(fx, d, device="cuda:0")
+    g = {k: v.to("cuda:0") for k, v in d.items()}
+    uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add") if k in g}
+    fields = ("points_coarse", "coarse_normals", "coarse_rgb_values", "coarse_depth_map", "z_vals", "ray_dirs", "coarse_colors")
+
+    def both(**kw):
+        outs = []
+        for one_call in (True, False):
+            model.one_call_render = one_call
+            model.rng_seed, model._rng_offset = 17, 5
+            with torch.no_grad():
+                outs.append((model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, **kw), model._rng_offset))
+        (a, off_a), (b, off_b) = outs
+        assert off_a == off_b
+        for f in fields:
+            assert torch.equal(getattr(a, f), getattr(b, f)), (name, f, kw.keys())
+        return a
+
+    out = both(uniforms=uni)
+    assert torch.equal(out.z_vals.cpu(), d["z_vals"]) and rel_err(out.coarse_rgb_values, d["rgb"]) < TIGHT
+    both()                                           # device Philox draws
+    both(uniforms=uni, white=True)
+    if name == "c1_det":                             # one pose / intrinsics for the whole batch
+        model.one_call_render = True
+        with torch.no_grad():
+            shared = model.render(g["pose"][0], g["uv"], g["intrinsics"][0], epoch=0, uniforms=uni)
+        assert torch.equal(shared.coarse_rgb_values, out.coarse_rgb_values)

@@ -1,0 +1,117 @@
+// vfn_render.hip — VectorFieldNerf.render (models/nerf/vector_field_nerf.py:216-338), gradient-free, as ONE entry point.
+//
+// The facade used to issue the launches of an inference render() one ctypes call at a time, with a torch allocation per
+// intermediate: ~0.5 ms of host time per call, which is what a 1 024-ray chunk takes on the device — the evaluator's chunk loop
+// (evaluation/methods.py:520-545) was host-bound.  vfn_render_fwd is the same launch sequence issued from C on one stream out of
+// one caller-supplied workspace (SURVEY.md section 8b lists this entry point):
+//   draws not supplied by the caller (one Philox launch)                        ray_sampler.py:138,287,292
+//   rays + proposal samples                                                      utils/rendering.py:12-60, ray_sampler.py:49-80,113-142
+//   fused VF + rendering net on the S_c proposal samples, in generation order    vector_field_nerf.py:252-256 (+ :315 for these samples)
+//   density -> weights -> argmax on the proposal pass                            :263-272, ray_sampler.py:277
+//   range fine sampler with provenance (where every stored sample lands)         ray_sampler.py:264-302
+//   fused VF + rendering net on the N_f NEW samples, outputs scattered           vector_field_nerf.py:294-297,315-318
+//   the proposal samples' normals / colours moved to their sorted positions
+//   density -> weights -> composite                                              :308-323
+// i.e. the f16x3 pipeline with one VF evaluation per distinct sample; nothing here computes: it only
+// sequences entry points of this library, so every value is what those entry points produce.
+#include <string.h>
+#include "vfn_common.h"
+
+namespace {
+
+struct Carve {
+    unsigned char* base;
+    size_t off;
+    template <typename T> T* take(size_t count) {
+        T* p = reinterpret_cast<T*>(base ? base + off : nullptr);
+        off += ((count * sizeof(T) + 255) / 256) * 256;
+        return p;
+    }
+};
+
+struct Ws {
+    float *u, *directions, *cam_loc, *z_c, *pts_c, *normals_c, *colors_c, *new_pts;
+    int64_t* imax;
+    int32_t* dst;
+    size_t bytes;
+};
+
+Ws carve(void* workspace, const vfn_render_params* p) {
+    const size_t n = (size_t)p->n_rays, sc = (size_t)p->n_coarse, nf = (size_t)p->n_fine;
+    Carve c{static_cast<unsigned char*>(workspace), 0};
+    Ws w;
+    w.u = c.take<float>(n * (sc + 2 * nf) + 4);
+    w.directions = c.take<float>(n * 3);
+    w.cam_loc = c.take<float>(n * 3);
+    w.z_c = c.take<float>(n * sc);
+    w.pts_c = c.take<float>(n * sc * 3);
+    w.normals_c = c.take<float>(n * sc * 3);
+    w.colors_c = c.take<float>(n * sc * 3);
+    w.new_pts = c.take<float>(n * nf * 3);
+    w.imax = c.take<int64_t>(n);
+    w.dst = c.take<int32_t>(n * (sc + nf));
+    w.bytes = c.off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" int64_t vfn_render_fwd_workspace_bytes(const vfn_render_params* p) {
+    if (!p || p->n_rays < 0 || p->n_coarse < 1 || p->n_fine < 2) return VFN_ERR_INVALID;
+    return (int64_t)carve(nullptr, p).bytes;
+}
+
+extern "C" int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf_geom, const void* vf_packed16,
+                              const vfn_net_geom* rn_geom, const void* rn_packed16, const float* uv, const float* pose,
+                              const float* intrinsics, const float* t_vals, const float* far_coarse_per_ray,
+                              const float* far_fine_per_ray, const float* density_scalars, const float* u_coarse,
+                              const float* u_fine, const float* u_add, void* workspace, float* ray_dirs, float* z_vals,
+                              float* points, float* normals, float* colors, float* weights, float* rgb, float* depth,
+                              void* stream) {
+    VFN_REQUIRE(p && vf_geom && rn_geom, "vfn_render_fwd: NULL argument");
+    if (p->n_rays == 0) return VFN_OK;
+    VFN_REQUIRE(p->n_rays > 0 && p->n_coarse >= 1 && p->n_fine >= 2, "vfn_render_fwd: bad sizes (n_rays=%d, n_coarse=%d, n_fine=%d)",
+                p->n_rays, p->n_coarse, p->n_fine);
+    VFN_REQUIRE(vf_packed16 && rn_packed16 && uv && pose && intrinsics && t_vals && density_scalars && workspace && ray_dirs && z_vals &&
+                points && normals && colors && weights && rgb && depth, "vfn_render_fwd: NULL argument");
+    const int n = p->n_rays, sc = p->n_coarse, nf = p->n_fine, st = sc + nf;
+    VFN_REQUIRE((long long)n * st < (1ll << 22), "vfn_render_fwd: at most 4194303 samples per call");
+    const Ws w = carve(workspace, p);
+    int rc;
+
+    // the draws the caller did not supply: one Philox launch over contiguous segments (the facade's order: coarse, fine, add)
+    const float* uc = p->perturb_coarse ? u_coarse : nullptr;
+    const float* uf = p->perturb_fine ? u_fine : nullptr;
+    const float* ua = u_add;
+    {
+        size_t need = 0;
+        float* cur = w.u;
+        if (p->perturb_coarse && !uc) { uc = cur; cur += (size_t)n * sc; need += (size_t)n * sc; }
+        if (p->perturb_fine && !uf) { uf = cur; cur += (size_t)n * nf; need += (size_t)n * nf; }
+        if (!ua) { ua = cur; need += (size_t)n * nf; }
+        if (need) {
+            rc = vfn_fill_uniform(w.u, (int64_t)need, p->seed, p->offset, stream);
+            if (rc != VFN_OK) return rc;
+        }
+    }
+    vfn_raygen_params rp = {n, sc, p->pose_is_quat, p->near_coarse, p->far_coarse};
+    rc = vfn_raygen_uniform(&rp, uv, pose, intrinsics, t_vals, far_coarse_per_ray, uc, w.directions, ray_dirs, w.cam_loc, w.z_c, w.pts_c, stream);
+    if (rc != VFN_OK) return rc;
+    rc = vfn_vf_render_fused16_fwd(vf_geom, vf_packed16, rn_geom, rn_packed16, w.pts_c, ray_dirs, (int64_t)n * sc, sc, w.normals_c, w.colors_c, stream);
+    if (rc != VFN_OK) return rc;
+    vfn_density_params dp = p->density;
+    dp.n_rays = n; dp.n_samples = sc;
+    rc = vfn_ray_density_weights(&dp, w.normals_c, ray_dirs, w.z_c, density_scalars, nullptr, nullptr, nullptr, w.imax, nullptr, nullptr, stream);
+    if (rc != VFN_OK) return rc;
+    vfn_fine_params fp = {n, sc, nf, p->near_fine, p->far_fine, p->fine_range, p->window_step, p->span};
+    rc = vfn_range_fine_sample_indexed(&fp, w.z_c, w.imax, w.directions, w.cam_loc, far_fine_per_ray, uf, ua, z_vals, points, nullptr, w.new_pts,
+                                       w.dst, (int64_t)n * sc, stream);
+    if (rc != VFN_OK) return rc;
+    rc = vfn_vf_render_fused16_scatter(vf_geom, vf_packed16, rn_geom, rn_packed16, w.new_pts, ray_dirs, (int64_t)n * nf, nf, w.dst + (size_t)n * sc,
+                                       normals, colors, stream);
+    if (rc != VFN_OK) return rc;
+    rc = vfn_scatter_rows3(w.normals_c, w.colors_c, w.dst, (int64_t)n * sc, normals, colors, stream);
+    if (rc != VFN_OK) return rc;
+    dp.n_samples = st;
+    return vfn_ray_density_weights(&dp, normals, ray_dirs, z_vals, density_scalars, colors, nullptr, weights, nullptr, rgb, depth, stream);
+}

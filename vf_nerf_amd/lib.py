@@ -31,7 +31,7 @@ EXPORTS = (
     "vfn_linear_rows", "vfn_linear_rows_stat_parts", "vfn_bstat_row_parts", "vfn_colsum_finish", "vfn_bstat_finalize",
     "vfn_bstat_relu_rows", "vfn_bstat_relu_bwd_sums", "vfn_bstat_relu_bwd_rows", "vfn_act_bwd_rows", "vfn_embed_rows",
     "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax",
-    "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step", "vfn_unfold_weight_grads_acc",
+    "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step", "vfn_unfold_weight_grads_acc", "vfn_render_fwd", "vfn_render_fwd_workspace_bytes",
 )
 
 
@@ -68,6 +68,14 @@ class FineParams(C.Structure):
                 ("window_step", C.c_float), ("span", C.c_float)]
 
 
+class RenderParams(C.Structure):
+    """mirrors vfn_render_params"""
+    _fields_ = [("n_rays", C.c_int32), ("n_coarse", C.c_int32), ("n_fine", C.c_int32), ("pose_is_quat", C.c_int32),
+                ("perturb_coarse", C.c_int32), ("perturb_fine", C.c_int32), ("near_coarse", C.c_float), ("near_fine", C.c_float),
+                ("far_coarse", C.c_float), ("far_fine", C.c_float), ("fine_range", C.c_float), ("window_step", C.c_float), ("span", C.c_float),
+                ("density", DensityParams), ("seed", C.c_uint64), ("offset", C.c_uint64)]
+
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -95,6 +103,8 @@ def load() -> C.CDLL:
     lib.vfn_bstat_row_parts.argtypes = [C.c_int64]
     lib.vfn_flat_clip_workspace_bytes.restype = C.c_int64
     lib.vfn_flat_clip_workspace_bytes.argtypes = []
+    lib.vfn_render_fwd_workspace_bytes.restype = C.c_int64
+    lib.vfn_render_fwd_workspace_bytes.argtypes = [C.POINTER(RenderParams)]
     for name in EXPORTS:
         getattr(lib, name)  # raises AttributeError if the ABI lost a symbol
     if lib.vfn_abi_version() != 1:
@@ -223,6 +233,32 @@ def ray_density_sigma_bwd(dp: DensityParams, normals, ray_dirs, z_vals, scalars,
                                             _ptr(z_vals, "z_vals"), _ptr(scalars, "scalars"), _ptr(d_sigma, "d_sigma"),
                                             _ptr(d_normals, "d_normals"), _ptr(d_scalars, "d_scalars"), _stream()),
            "vfn_ray_density_sigma_bwd")
+
+
+def render_workspace_bytes(rp: RenderParams) -> int:
+    n = load().vfn_render_fwd_workspace_bytes(C.byref(rp))
+    if n < 0:
+        raise VfnError("vfn_render_fwd_workspace_bytes: bad sizes")
+    return int(n)
+
+
+def render_fwd(rp: RenderParams, vf_geom, vf_packed16, rn_geom, rn_packed16, uv, pose, intrinsics, t_vals, far_c, far_f, scalars,
+               u_coarse, u_fine, u_add, workspace):
+    """The whole gradient-free render() in one call (csrc/vfn_render.hip) -> dict of output tensors."""
+    n, s_t = rp.n_rays, rp.n_coarse + rp.n_fine
+    dev = uv.device
+    out = dict(ray_dirs=torch.empty(n, 3, device=dev), z_vals=torch.empty(n, s_t, device=dev), points=torch.empty(n, s_t, 3, device=dev),
+               normals=torch.empty(n * s_t, 3, device=dev), colors=torch.empty(n * s_t, 3, device=dev),
+               weights=torch.empty(n, s_t, device=dev), rgb=torch.empty(n, 3, device=dev), depth=torch.empty(n, 1, device=dev))
+    _check(load().vfn_render_fwd(C.byref(rp), C.byref(vf_geom), _ptr(vf_packed16, "vf_packed16", torch.uint8), C.byref(rn_geom),
+                                 _ptr(rn_packed16, "rn_packed16", torch.uint8), _ptr(uv, "uv"), _ptr(pose, "pose"),
+                                 _ptr(intrinsics, "intrinsics"), _ptr(t_vals, "t_vals"), _ptr(far_c, "far_coarse_per_ray"),
+                                 _ptr(far_f, "far_fine_per_ray"), _ptr(scalars, "density_scalars"), _ptr(u_coarse, "u_coarse"),
+                                 _ptr(u_fine, "u_fine"), _ptr(u_add, "u_add"), _ptr(workspace, "workspace", torch.uint8),
+                                 _ptr(out["ray_dirs"], "ray_dirs"), _ptr(out["z_vals"], "z_vals"), _ptr(out["points"], "points"),
+                                 _ptr(out["normals"], "normals"), _ptr(out["colors"], "colors"), _ptr(out["weights"], "weights"),
+                                 _ptr(out["rgb"], "rgb"), _ptr(out["depth"], "depth"), _stream()), "vfn_render_fwd")
+    return out
 
 
 def vf_mlp_fwd(geom: NetGeom, packed, points, out_cols: int):
