@@ -39,25 +39,30 @@ if REPO not in sys.path:
 import torch  # noqa: E402
 
 VF_MACS, RN_MACS = 525056, 271360          # per point
+# of which the COLOUR BRANCH (csrc/vfn_mlp16.hip, M16_C2): the 256 x 256 feature block of the VF net's last Linear and the
+# rendering net except the 33 encoding columns (point, PE(view direction), normal) of its first layer
+COLOUR_MACS = 256 * 256 + RN_MACS - 33 * 256
 PEAK_F32_MFMA = 157.3                      # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA = 2500.0                     # TFLOP/s dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 SUSTAINED_F16_MFMA = 1570.0                # TFLOP/s a pure 32x32x16 f16 MFMA loop sustains on random operands with every CU
                                            # busy (power-limited clock ~1.8 GHz): tools/micro/mfma_power.hip, DESIGN.md §3
 
 
-def hbm_traffic(f16: bool, kernel_class: str = "fused16"):
+def hbm_traffic(f16: bool, kernel_class: str = "fused16", colour_products: int = 3):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside the
     benchmark): FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md §HBM) + WRITE_SIZE, in bytes."""
-    path = os.path.join(REPO, "profiles", "r02", "traffic_f16x3.json")
+    path = os.path.join(REPO, "profiles", "r02", "traffic_f16x3.json" if colour_products == 2 else "traffic_f16x3_3products.json")
     if not f16 or not os.path.exists(path):
         return None
     with open(path) as fh:
         t = json.load(fh)
-    sym = {"vf_feat16": "vfn_mlp16_kernel<9>", "render16": "vfn_mlp16_kernel<18>", "fused16": "vfn_mlp16_kernel<3>"}.get(kernel_class)
-    fetch, write = t["all_kernels"].get(f"FETCH_SIZE|{sym}"), t["all_kernels"].get(f"WRITE_SIZE|{sym}")
-    if fetch is None or write is None:
-        return None
-    return int((2.0 * fetch + write) * 1024)
+    syms = {"vf_feat16": ("vfn_mlp16_kernel<9>",), "render16": ("vfn_mlp16_kernel<18>",),
+            "fused16": ("vfn_mlp16_kernel<35>",) if colour_products == 2 else ("vfn_mlp16_kernel<3>",)}.get(kernel_class, ())
+    for sym in syms:
+        fetch, write = t["all_kernels"].get(f"FETCH_SIZE|{sym}"), t["all_kernels"].get(f"WRITE_SIZE|{sym}")
+        if fetch is not None and write is not None:
+            return int((2.0 * fetch + write) * 1024)
+    return None
 
 
 def build_scene(dev, n_rays, s_c, n_f, seed, perturb=True):
@@ -361,6 +366,9 @@ def main() -> None:
     ap.add_argument("--precision", choices=("f16x3", "fp32"), default="f16x3",
                     help="MLP kernels: f16x3 = split-half products on the f16 matrix cores, fp32 accumulate (default, "
                          "fp32-equivalent accuracy); fp32 = exact fp32 MFMA")
+    ap.add_argument("--colour-products", type=int, choices=(2, 3), default=None,
+                    help="f16 products per fp32-equivalent product in the colour branch of the f16x3 render (default: the model's, 2: "
+                         "weights of the feature block + rendering net as their f16 roundings, colours within 2e-5; 3: fp32-equivalent)")
     ap.add_argument("--no-reuse", action="store_true",
                     help="evaluate the VF net on the proposal samples twice, as the reference does (one fused VF+rendering "
                          "launch over all S_c+N_f samples), instead of once")
@@ -418,6 +426,8 @@ def main() -> None:
     model, uv, pose, K = build_scene(dev, args.rays, s_c, n_f, seed=rank)
     model.precision = args.precision
     model.reuse_proposal = not args.no_reuse
+    if args.colour_products:
+        model.colour_products = args.colour_products
 
     def sync():
         if dist is not None:
@@ -486,39 +496,49 @@ def main() -> None:
         hits = float((out.coarse_depth_map > 0).float().mean())
         f16 = args.precision == "f16x3"
         # achieved = ALGORITHMIC fp32-equivalent FLOPs per launch / measured duration.  The f16x3 kernel spends three
-        # f16 MFMA products per fp32-equivalent product, so its matrix-pipe ceiling is the dense f16 peak / 3.
-        peak = PEAK_F16_MFMA / 3.0 if f16 else PEAK_F32_MFMA
+        # f16 MFMA products per fp32-equivalent product — two in the colour branch when colour_products == 2 — so its matrix-pipe
+        # ceiling is the dense f16 peak / (f16 products per fp32-equivalent product, averaged over the launch's MACs).
+        cp = int(model.colour_products) if f16 and dom == "fused16" else 3
+        products = 3.0 - (COLOUR_MACS / (VF_MACS + RN_MACS) if cp == 2 else 0.0)
+        peak = PEAK_F16_MFMA / products if f16 else PEAK_F32_MFMA
         roof = {"bound": "mfma",
                 "kernel": {"vf_feat16": "vfn_mlp16_kernel<M16_VF_BLK> (VF MLP on the proposal samples, feature blocks out)",
                            "render16": "vfn_mlp16_kernel<M16_RN_BLK> (rendering MLP on the proposal samples' stored feature blocks)",
-                           "fused16": "vfn_mlp16_kernel<M16_FUSED> (VF MLP + rendering MLP; default: one launch on the proposal samples, one on the new fine samples)",
+                           "fused16": ("vfn_mlp16_kernel<M16_FUSED | M16_C2>" if cp == 2 else "vfn_mlp16_kernel<M16_FUSED>") +
+                                      " (VF MLP + rendering MLP; default: one launch on the proposal samples, one on the new fine samples)",
                            "fused32": "vfn_mlp_kernel<MODE_FUSED> (VF MLP + rendering MLP, fine pass)"}[dom],
                 "launches_per_step": launches_per_step,
                 "kernel_ms_per_step_by_class": {k: round(sum(v) / max(1, (args.steps + 3) // 4), 4) for k, v in per_class.items()},
                 "event_sampling": "HIP events around the MLP launches of every 4th timed step",
                 "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": hbm_traffic(f16, dom),
+                "frac": round(achieved / peak, 4), "traffic": hbm_traffic(f16, dom, cp),
                 # what one launch has to move: points in, vector columns out, plus the 1 KiB feature block per point that the
                 # split launches hand over (written by vf_feat16, read by render16); weights stream from L2
                 "algorithmic_bytes": int(points * {"vf_feat16": 12 + 12 + 1024, "render16": 1024 + 12 + 12 + 4 + 24}.get(dom, 12 + 4 + 24)),
                 "flops_per_launch": flops_launch, "avg_launch_ms": round(kernel_ms, 4),
-                "peak_definition": ("dense f16 MFMA 2500 TFLOP/s / 3 products per fp32-equivalent product" if f16 else
+                "peak_definition": ((f"dense f16 MFMA 2500 TFLOP/s / {products:.4g} f16 products per fp32-equivalent product (3 in the vector-field "
+                                     f"trunk, vector head and encoding columns, 2 in the colour branch = {COLOUR_MACS} of {VF_MACS + RN_MACS} MACs per sample)"
+                                     if cp == 2 else "dense f16 MFMA 2500 TFLOP/s / 3 products per fp32-equivalent product") if f16 else
                                     "fp32 MFMA 157.3 TFLOP/s"),
+                "executed_f16_tflops": round(achieved * products, 1) if f16 else None,
                 # BASELINE.md §3 states the path's roofline against the fp32 matrix peak:
                 "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA, 4)}
         if f16:   # context, not the graded fraction: the power-limited MFMA rate measured on this chip
-            roof["frac_of_measured_sustained_f16_mfma"] = round(achieved / (SUSTAINED_F16_MFMA / 3.0), 4)
+            roof["frac_of_measured_sustained_f16_mfma"] = round(achieved / (SUSTAINED_F16_MFMA / products), 4)
         line = {
             "metric": "rays/sec (4096-ray chunk, 128 samples/ray) + PSNR vs ref",
             "value": round(rays_per_s, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16x3+f32acc" if f16 else "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f16x3+f32acc (colour branch: f16 weights x split activations, 2 products)" if cp == 2 else "f16x3+f32acc") if f16 else "f32",
+            "data": "synthetic",
             "sustained": f"timed steps follow {args.sustain_seconds:g} s of the same work without a gap",
             "config": {"workload": f"VectorFieldNerf.render forward, {args.rays}-ray chunk x {s_t} samples/ray "
                                    f"(S_c={s_c} + N_f={n_f}), shipped 9x256 VF + 5x256 rendering MLPs, eval-mode BN, "
                                    f"stratified sampling on device Philox, Replica-like 1200x680 pinhole",
                        "rays_per_chunk_per_gpu": args.rays, "samples_per_ray": s_t, "parallelism": f"rays x{world}",
                        "vf_evaluations_per_ray": s_t if getattr(model, "reuse_proposal", False) and f16 else s_c + s_t,
+                       "colour_products": cp if f16 else None,
                        "rays_with_nonzero_depth": round(hits, 3)},
             "roofline": roof,
         }

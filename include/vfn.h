@@ -219,6 +219,8 @@ typedef struct vfn_render_params {
     float fine_range, window_step, span; /* as in vfn_fine_params: window_step, span evaluated in double by the host */
     vfn_density_params density;         /* n_rays / n_samples are filled in per pass */
     uint64_t seed, offset;              /* Philox stream for the draws not supplied */
+    int32_t colour_products;            /* 0 or 3: three products everywhere; 2: the colour branch on two (vfn_vf_render_fused16_products) */
+    int32_t reserved;
 } vfn_render_params;
 int64_t vfn_render_fwd_workspace_bytes(const vfn_render_params* p);
 int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf_geom, const void* vf_packed16,
@@ -398,6 +400,17 @@ int vfn_vf_render_fused16_scatter(const vfn_net_geom* vf_geom, const void* vf_pa
                                   const void* rn_packed16, const float* points, const float* ray_dirs, int64_t n_points,
                                   int32_t samples_per_ray, const int32_t* out_index, float* normals, float* colors,
                                   void* stream);
+/* The fused launch with the number of f16 products per fp32-equivalent product of its COLOUR BRANCH (the feature block of the
+ * vector-field net and the whole rendering net) chosen by the caller: colour_products = 3 is vfn_vf_render_fused16_fwd /
+ * _scatter; 2 evaluates that branch as w_hi x_hi + w_hi x_lo — weights as their f16 roundings, activations still split — which
+ * removes 14 % of the launch's matrix instructions and a third of its weight traffic.  The vector head and every layer before
+ * it keep three products, so normals (hence density, weights, depth, sample positions) are bit-identical to the 3-product
+ * launch; colours differ from the reference by <= 2e-5 on its golden outputs (contract: 1e-4).  out_index: NULL (outputs in
+ * place) or the scatter index.  Same packs as every other f16x3 entry point. */
+int vfn_vf_render_fused16_products(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
+                                   const void* rn_packed16, const float* points, const float* ray_dirs, int64_t n_points,
+                                   int32_t samples_per_ray, const int32_t* out_index, int32_t colour_products, float* normals,
+                                   float* colors, void* stream);
 int vfn_render16_from_blocks(const vfn_net_geom* rn_geom, const void* rn_packed16, const void* blocks, const float* vecs,
                              const int32_t* dst, const float* points, const float* ray_dirs, int64_t n_rows,
                              int32_t samples_per_ray, float* normals, float* colors, void* stream);

@@ -348,3 +348,135 @@ def test_one_call_render_equals_the_launch_by_launch_path(name):
         with torch.no_grad():
             shared = model.render(g["pose"][0], g["uv"], g["intrinsics"][0], epoch=0, uniforms=uni)
         assert torch.equal(shared.coarse_rgb_values, out.coarse_rgb_values)
+
+
+# ------------------------------------------------------------------------------------------------
+# colour branch on two products (csrc/vfn_mlp16.hip, M16_C2; the facade's default for gradient-free renders)
+# ------------------------------------------------------------------------------------------------
+COLOUR2_TOL = 4e-5          # colours of the two-product branch against the reference's outputs (measured 1.6e-5 .. 2.2e-5); contract 1e-4
+
+
+@pytest.mark.parametrize("name", FIXTURE_NAMES + ("attached_normals",))
+def test_two_product_colour_branch(name):
+    """vfn_vf_render_fused16_products with colour_products = 2: the vector head and everything before it keep three products, so
+    the normals are the 3-product launch's to the last bit; the colours stay within COLOUR2_TOL of the reference's golden
+    outputs (3 products: 2e-7) and of the exact-fp32 kernels; the scattering variant writes the same values to the rows it is
+    told to; render() with the two settings agrees bit for bit on everything but the colours / rgb."""
+    from vf_nerf_amd import lib
+    fx, d = load_fixture(name)
+    model = build_model(fx, d, device="cuda:0")
+    g = {k: v.to("cuda:0") for k, v in d.items()}
+    vf, rn = model.vector_field_network, model.rendering_network
+    s_t = fx["n_samples"] + fx["n_importance"]
+    pts, dirs = g["points"].reshape(-1, 3).contiguous(), g["ray_dirs"].contiguous()
+    args = (vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(), pts, dirs, s_t)
+    n3, c3 = lib.vf_render_fused16_fwd(*args, colour_products=3)
+    n2, c2 = lib.vf_render_fused16_fwd(*args, colour_products=2)
+    _, c32, _ = lib.vf_render_fused_fwd(vf.geometry(), vf.packed_weights(), rn.geometry(), rn.packed_weights(), pts, dirs, s_t)
+    assert torch.equal(n2, n3)
+    e3, e2, e2_32 = rel_err(c3, d["colors"]), rel_err(c2, d["colors"]), rel_err(c2, c32)
+    print(f"{name}: colours vs the reference: 3 products {e3:.2e}, 2 products {e2:.2e}; 2 products vs exact-fp32 kernels {e2_32:.2e}")
+    assert e3 < 2e-6 and e2 < COLOUR2_TOL and e2_32 < COLOUR2_TOL
+    # scatter: a permutation with dropped rows
+    m = pts.shape[0]
+    perm = torch.randperm(m, generator=torch.Generator().manual_seed(3)).to(torch.int32)
+    perm[::7] = -1
+    out_n = torch.full((m, 3), 7.0, device="cuda:0")
+    out_c = torch.full((m, 3), 7.0, device="cuda:0")
+    lib.vf_render_fused16_scatter(*args[:6], s_t, perm.to("cuda:0"), out_n, out_c, colour_products=2)
+    keep = (perm >= 0).to("cuda:0")
+    idx = perm.to("cuda:0").long()[keep]
+    assert torch.equal(out_n[idx], n2[keep]) and torch.equal(out_c[idx], c2[keep])
+    untouched = torch.ones(m, dtype=torch.bool, device="cuda:0")
+    untouched[idx] = False
+    assert bool((out_c[untouched] == 7.0).all())
+    # render(): products only move the colours
+    uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add") if k in g}
+    outs = {}
+    for k in (3, 2):
+        model.colour_products = k
+        for one_call in (True, False):
+            model.one_call_render = one_call
+            with torch.no_grad():
+                outs[k, one_call] = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
+    for k in (3, 2):
+        for f in ("z_vals", "coarse_normals", "coarse_colors", "coarse_rgb_values", "coarse_depth_map", "coarse_weights"):
+            if hasattr(outs[k, True], f):
+                assert torch.equal(getattr(outs[k, True], f), getattr(outs[k, False], f)), (k, f)
+    a, b = outs[3, True], outs[2, True]
+    for f in ("z_vals", "points_coarse", "coarse_normals", "coarse_depth_map"):
+        assert torch.equal(getattr(a, f), getattr(b, f)), f
+    e_rgb = rel_err(b.coarse_rgb_values, d["rgb"])
+    print(f"{name}: composited rgb of the two-product render vs the reference {e_rgb:.2e}")
+    assert torch.equal(b.z_vals.cpu(), d["z_vals"]) and e_rgb < COLOUR2_TOL and rel_err(a.coarse_rgb_values, d["rgb"]) < 2e-6
+
+
+def test_two_product_colours_are_measured_by_the_guard(monkeypatch):
+    """guard.py, colour self-check: on the calls whose status is read back, a few rays are evaluated again with three products;
+    a difference above guard.COLOUR_CHECK_TOL moves the model back to colour_products = 3 — in strict mode before the call
+    returns.  In-family networks stay on two products; with the tolerance lowered under the measured 2e-5 the switch happens and
+    the strict call returns exactly the three-product render; a rendering net pushed out of the family (hidden weights x 16,
+    BatchNorm gamma up to 30) is caught at the shipped tolerance or is within it."""
+    import warnings
+    from vf_nerf_amd import guard as vguard
+    fx, d = load_fixture("c1_perturb")
+    g = {k: v.to("cuda:0") for k, v in d.items()}
+    uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add")}
+
+    def render(model):
+        with torch.no_grad():
+            return model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
+
+    model = build_model(fx, d, device="cuda:0")
+    assert model.colour_products == 2
+    model.f16x3_guard = "strict"
+    two = render(model)
+    assert model.colour_products == 2 and model.range_guard.colour_products_reason is None
+    model.colour_products = 3
+    three = render(model)
+    diff = float((two.coarse_colors - three.coarse_colors).abs().max())
+    print(f"in family: two- vs three-product colours {diff:.2e} (tolerance {vguard.COLOUR_CHECK_TOL:.0e})")
+    assert 0 < diff < vguard.COLOUR_CHECK_TOL
+
+    monkeypatch.setattr(vguard, "COLOUR_CHECK_TOL", 1e-6)
+    for mode in ("strict", "lazy"):
+        model = build_model(fx, d, device="cuda:0")
+        model.f16x3_guard = mode
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            out = render(model)
+            if mode == "lazy":                     # the report arrives asynchronously; the switch happens when it is consumed
+                assert model.range_guard.check_now(torch.device("cuda:0")) is None
+                out = render(model)
+        assert model.colour_products == 3 and model.precision == "f16x3" and model.f16x3_disabled is None
+        assert any("colour_products" in str(w.message) for w in caught)
+        assert torch.equal(out.coarse_colors, three.coarse_colors) and torch.equal(out.coarse_rgb_values, three.coarse_rgb_values)
+    monkeypatch.undo()
+
+    # a rendering net out of the family: hidden weights x 2 and x 4 (fresh BatchNorm statistics normalise nothing, so the
+    # activations grow 16- and 256-fold by the head and the rounding errors of the weights with them).  Measured unguarded:
+    # 2.4e-4 and 3.2e-3 — outside the contract — and the self-check sends both back to three products.
+    for wmul in (2.0, 4.0):
+        model = build_model(fx, d, device="cuda:0")
+        rn = model.rendering_network
+        with torch.no_grad():
+            for i in range(rn.num_layers - 1):
+                rn._linear(i).weight.mul_(wmul)
+        rn._invalidate_packs()
+        model.f16x3_guard = "off"
+        model.precision = "fp32"
+        want = render(model)
+        model.precision = "f16x3"
+        raw = render(model)
+        assert torch.equal(raw.z_vals, want.z_vals)
+        raw_diff = float((raw.coarse_colors - want.coarse_colors).abs().max())
+        model.f16x3_guard = "strict"
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = render(model)
+        got_diff = float((got.coarse_colors - want.coarse_colors).abs().max())
+        print(f"rendering-net weights x{wmul:g}: unguarded two-product colours {raw_diff:.2e} off the exact-fp32 kernels; the strict guard "
+              f"returns {got_diff:.2e} (colour_products now {model.colour_products}, precision {model.precision})")
+        assert raw_diff > 1e-4, "the case is meant to be outside the contract without the guard"
+        assert got_diff < 1e-4 and model.colour_products == 3 and model.precision == "f16x3"
+        assert model.range_guard.colour_products_reason is not None

@@ -34,7 +34,8 @@ for counter, sub, stem in (("FETCH_SIZE", "prof_fetch", "pf"), ("WRITE_SIZE", "p
             traffic["all_kernels"][f"{counter}|{short(name)}"] = round(val, 2)
 # template arguments are the launch modes of csrc/vfn_mlp16.hip: <0> vector-only VF (grid queries), <3> fused VF + rendering,
 # <9> VF with feature blocks out (once per distinct sample), <18> rendering net on gathered blocks
-traffic["modes"] = {"vfn_mlp16_kernel<0>": "VF, vector columns only", "vfn_mlp16_kernel<3>": "fused VF + rendering (fine pass)",
+traffic["modes"] = {"vfn_mlp16_kernel<0>": "VF, vector columns only", "vfn_mlp16_kernel<3>": "fused VF + rendering, three products everywhere",
+                    "vfn_mlp16_kernel<35>": "fused VF + rendering, colour branch on two products (the default render; <3> then only appears as the guard's 128-ray self-check)",
                     "vfn_mlp16_kernel<9>": "VF + feature blocks out", "vfn_mlp16_kernel<18>": "rendering net on gathered blocks"}
 with open(os.path.join(out, f"traffic_{tag}.json"), "w") as fh:
     json.dump(traffic, fh, indent=1)

@@ -60,7 +60,8 @@ def fine_pass(model, pts: torch.Tensor, z: torch.Tensor, ray_dirs: torch.Tensor)
     vf_w, rn_w = (vf.packed16_weights(), rn.packed16_weights()) if f16 else (vf.packed_weights(), rn.packed_weights())
     with model._timed("fused16" if f16 else "fused32"):   # bench.py: HIP events around the dominant kernel
         if f16:
-            normals, colors = lib.vf_render_fused16_fwd(vf.geometry(), vf_w, rn.geometry(), rn_w, pts.view(-1, 3), ray_dirs, s_t)
+            normals, colors = lib.vf_render_fused16_fwd(vf.geometry(), vf_w, rn.geometry(), rn_w, pts.view(-1, 3), ray_dirs, s_t,
+                                                            colour_products=model.colour_products)
         else:
             normals, colors, _ = lib.vf_render_fused_fwd(vf.geometry(), vf_w, rn.geometry(), rn_w, pts.view(-1, 3), ray_dirs, s_t)
     _, weights, _, rgb, depth = lib.ray_density_weights(model._density_params(), normals, ray_dirs, z,

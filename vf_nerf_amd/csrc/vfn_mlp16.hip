@@ -71,6 +71,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #ifndef VFN16_EPI_PER_MFMA
 #define VFN16_EPI_PER_MFMA 6     // VALU instructions of the pending epilogue scheduled behind each MFMA
 #endif
+#ifndef VFN16_EPI_PER_MFMA2
+#define VFN16_EPI_PER_MFMA2 9    // the same for the two-product tiles of the colour branch (two MFMAs per K step)
+#endif
 #ifndef VFN16_MASK_STEP
 #define VFN16_MASK_STEP(H, NKB) (H)     // K step of a tile that carries the sign-bit collection of the pending tile (training)
 #endif
@@ -277,7 +280,12 @@ enum : int { EPI_RELU = 0, EPI_TANH = 1, EPI_HEAD_TANH = 2, EPI_HEAD_SIGMOID = 3
 // hidden layer's post-activation output and the encoding tiles are written out for the backward kernels)
 //   bit 3 = the feature block leaves the kernel as operand blocks (for a later rendering-net launch), bit 4 = rendering net
 //   only, its feature operand gathered from such blocks
-enum : int { M16_FEAT = 1, M16_RENDER = 2, M16_TRAIN = 4, M16_BLKOUT = 8, M16_BLKIN = 16,
+//   bit 5 = the COLOUR BRANCH (feature block of the VF net + the whole rendering net) runs on TWO products per fp32-equivalent
+//   product, w_hi x_hi + w_hi x_lo: its weights are used as their f16 roundings (11 significant bits), its activations stay
+//   split.  The vector head and everything before it keep three products, so normals, density, weights and depth are
+//   unchanged to the bit; colours move by <= 2e-5 on the reference's golden outputs (profiles/r02/ab_colour_products.txt),
+//   inside the 1e-4 contract.  The same pack serves both: a two-product chunk DMAs and reads only its hi planes.
+enum : int { M16_FEAT = 1, M16_RENDER = 2, M16_TRAIN = 4, M16_BLKOUT = 8, M16_BLKIN = 16, M16_C2 = 32,
              M16_VF_VEC = 0, M16_FUSED = M16_FEAT | M16_RENDER, M16_VF_BLK = M16_FEAT | M16_BLKOUT, M16_RN_BLK = M16_RENDER | M16_BLKIN,
              M16_VF_VEC_TRAIN = M16_TRAIN, M16_VF_FULL_TRAIN = M16_FEAT | M16_TRAIN, M16_FUSED_TRAIN = M16_FUSED | M16_TRAIN };
 
@@ -306,30 +314,34 @@ constexpr int chunk_kb(int act, int aux) { return 2 * (act + aux) + 1; }
 constexpr int vf_off_kb(int h) { int o = 0; for (int i = 0; i < h; ++i) o += VF_TILES[i] * chunk_kb(VF_ACT[i], VF_AUX[i]); return o; }
 constexpr int rn_off_kb(int h) { int o = 0; for (int i = 0; i < h; ++i) o += RN_TILES[i] * chunk_kb(RN_ACT[i], RN_AUX[i]); return o; }
 
-struct ChunkD { int net, off_kb, kb; };      // net 0 = VF pack, 1 = rendering pack; kb = 0: past the end
+struct ChunkD { int net, off_kb, kb, aux; };      // net 0 = VF pack, 1 = rendering pack; kb = 0: past the end; aux = encoding K-blocks
 // chunk c of the launch in consumption order (fused: VF hidden + features, VF head, rendering hidden, rendering head;
 // vector-only: the 8 plain VF layers, VF head)
 constexpr ChunkD chunk_of(int mode, int c) {
     if (!(mode & M16_BLKIN)) {
         const int vf_layers = (mode & M16_FEAT) ? 9 : 8;
         for (int h = 0; h < vf_layers; ++h) {
-            if (c < VF_TILES[h]) return {0, vf_off_kb(h) + c * chunk_kb(VF_ACT[h], VF_AUX[h]), chunk_kb(VF_ACT[h], VF_AUX[h])};
+            if (c < VF_TILES[h]) return {0, vf_off_kb(h) + c * chunk_kb(VF_ACT[h], VF_AUX[h]), chunk_kb(VF_ACT[h], VF_AUX[h]), VF_AUX[h]};
             c -= VF_TILES[h];
         }
-        if (c == 0) return {0, vf_off_kb(9), HEAD_KB};
+        if (c == 0) return {0, vf_off_kb(9), HEAD_KB, 0};
         c -= 1;
     }
     if (mode & M16_RENDER) {
         for (int h = 0; h < 4; ++h) {
-            if (c < RN_TILES[h]) return {1, rn_off_kb(h) + c * chunk_kb(RN_ACT[h], RN_AUX[h]), chunk_kb(RN_ACT[h], RN_AUX[h])};
+            if (c < RN_TILES[h]) return {1, rn_off_kb(h) + c * chunk_kb(RN_ACT[h], RN_AUX[h]), chunk_kb(RN_ACT[h], RN_AUX[h]), RN_AUX[h]};
             c -= RN_TILES[h];
         }
-        if (c == 0) return {1, rn_off_kb(4), HEAD_KB};
+        if (c == 0) return {1, rn_off_kb(4), HEAD_KB, 0};
     }
-    return {0, 0, 0};
+    return {0, 0, 0, 0};
 }
 
 constexpr int rn_first_chunk(int mode) { return (mode & M16_BLKIN) ? 0 : 72; }
+// chunks of the colour branch in a fused launch: the feature block (63..70) and the rendering net (72..104); 71 is the vector head
+// (the ENCODING K-blocks of such a chunk — the rendering net's first layer reads the point, PE(view direction) and the normal
+// there — keep three products: a weight's rounding error is multiplied by its input, and a point coordinate is not bounded)
+constexpr bool chunk_two(int mode, int c) { return (mode & M16_C2) && !(mode & M16_BLKIN) && c >= 63 && c != 71; }
 
 struct Mlp16Args {
     const uint4* vf_w;
@@ -458,7 +470,7 @@ __device__ __forceinline__ void prefetch_chunk(Carry16& cy, const Pipe16& p, int
 #pragma unroll
     for (int q = 0; q < 4; ++q) { cy.bias[q] = b0[q]; cy.bias[4 + q] = b1[q]; cy.bias[8 + q] = b2[q]; cy.bias[12 + q] = b3[q]; }
     cy.fh0 = __builtin_bit_cast(half8, cb[0 * 64 + lane]);
-    cy.fl0 = __builtin_bit_cast(half8, cb[1 * 64 + lane]);
+    if (!chunk_two(MODE, C)) cy.fl0 = __builtin_bit_cast(half8, cb[1 * 64 + lane]);     // (no two-product chunk starts with an encoding block)
 }
 
 // Two accumulator values -> (hi, lo) halves of element pair (j, j+1) of an operand block.
@@ -585,13 +597,24 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
         constexpr int C = C0 + ch;
         constexpr ChunkD dcur = chunk_of(MODE, C), dnext = chunk_of(MODE, C + 1), ddma = chunk_of(MODE, C + 2);
         static_assert(dcur.kb == 2 * NKB + 1, "layer shape and chunk table disagree");
+        constexpr bool W2 = chunk_two(MODE, C);            // this tile: two products, hi planes of the weights only
+        constexpr bool D2 = chunk_two(MODE, C + 2);        // the chunk being fetched: hi planes (even blocks) + the bias block
+        constexpr int DNKB = (ddma.kb - 1) / 2;             // pieces of a two-product chunk: hi planes, lo planes of the encoding blocks, bias
+        constexpr int DPIECES = D2 ? DNKB + ddma.aux + 1 : ddma.kb;
+        auto piece_blk = [&](int idx) -> int {
+            if (!D2) return idx;
+            if (ddma.aux == 0) return 2 * idx;
+            return idx < DNKB ? 2 * idx : (idx < DNKB + ddma.aux ? 2 * (idx - ddma.aux) + 1 : 2 * DNKB);
+        };
+        constexpr int PM = D2 ? (DPIECES + VFN16_WAVES - 1) / VFN16_WAVES : PMAX;
         const uint4* cb = p.lds + (C % 3) * VFN16_SLOT;
         f32x16 acc = cy.bias;
         half8 fh[VFN16_FDEPTH], fl[VFN16_FDEPTH];
-        fh[0] = cy.fh0; fl[0] = cy.fl0;
+        fh[0] = cy.fh0;
+        if (!W2 || ACT == 0) fl[0] = cy.fl0;
         if (VFN16_FDEPTH == 3 && NKB > 1) {
             fh[1] = __builtin_bit_cast(half8, cb[2 * 64 + lane]);
-            fl[1] = __builtin_bit_cast(half8, cb[3 * 64 + lane]);
+            if (!W2) fl[1] = __builtin_bit_cast(half8, cb[3 * 64 + lane]);
         }
         half8 ehi[2], elo[2];
 #pragma unroll
@@ -599,14 +622,14 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
             constexpr int AHEAD = VFN16_FDEPTH - 1;
             if (st + AHEAD < NKB) {
                 fh[(st + AHEAD) % VFN16_FDEPTH] = __builtin_bit_cast(half8, cb[(2 * (st + AHEAD)) * 64 + lane]);
-                fl[(st + AHEAD) % VFN16_FDEPTH] = __builtin_bit_cast(half8, cb[(2 * (st + AHEAD) + 1) * 64 + lane]);
+                if (!W2 || st + AHEAD >= ACT) fl[(st + AHEAD) % VFN16_FDEPTH] = __builtin_bit_cast(half8, cb[(2 * (st + AHEAD) + 1) * 64 + lane]);
             }
-            const half8 a_hi = fh[st % VFN16_FDEPTH], a_lo = fl[st % VFN16_FDEPTH];
+            const half8 a_hi = fh[st % VFN16_FDEPTH];
             const half8 x_hi = st < ACT ? xin.hi[st < ACT ? st : 0] : aux.hi[st >= ACT ? st - ACT : 0];
             const half8 x_lo = st < ACT ? xin.lo[st < ACT ? st : 0] : aux.lo[st >= ACT ? st - ACT : 0];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, x_hi, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, x_lo, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, x_hi, acc, 0, 0, 0);
+            if (!W2 || st >= ACT) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[st % VFN16_FDEPTH], x_hi, acc, 0, 0, 0);
             // -- first half: epilogue pairs of the pending tile
 #ifdef ABL_NOEPI
             if (st == 0 && (ch > 0 || PEPI >= 0)) asm volatile("" :: "v"(cy.pend));
@@ -628,13 +651,15 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
                 }
 #ifndef VFN16_NOGROUPS
                 // one MFMA, then its share of the epilogue in that MFMA's shadow
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, W2 ? 1 : 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, VFN16_EPI_PER_MFMA, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, W2 ? VFN16_EPI_PER_MFMA2 : VFN16_EPI_PER_MFMA, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, VFN16_EPI_PER_MFMA, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, VFN16_EPI_PER_MFMA, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, W2 ? VFN16_EPI_PER_MFMA2 : VFN16_EPI_PER_MFMA, 0);
+                if (!W2) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VFN16_EPI_PER_MFMA, 0);
+                }
 #endif
             }
             // -- middle: ring hand-over
@@ -652,9 +677,9 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
 #ifndef ABL_NODMA
             if (st >= H && st < H + DSTEPS && ddma.kb > 0) {
 #pragma unroll
-                for (int i = (st - H) * PMAX / DSTEPS; i < (st - H + 1) * PMAX / DSTEPS; ++i) {
-                    if (VFN16_WAVES * i + VFN16_WAVES <= ddma.kb) dma_piece<ddma.net, ddma.off_kb, (C + 2) % 3>(p, wave + VFN16_WAVES * i, lane);
-                    else if (VFN16_WAVES * i < ddma.kb) { if (wave + VFN16_WAVES * i < ddma.kb) dma_piece<ddma.net, ddma.off_kb, (C + 2) % 3>(p, wave + VFN16_WAVES * i, lane); }
+                for (int i = (st - H) * PM / DSTEPS; i < (st - H + 1) * PM / DSTEPS; ++i) {
+                    if (VFN16_WAVES * i + VFN16_WAVES <= DPIECES) dma_piece<ddma.net, ddma.off_kb, (C + 2) % 3>(p, piece_blk(wave + VFN16_WAVES * i), lane);
+                    else if (VFN16_WAVES * i < DPIECES) { if (wave + VFN16_WAVES * i < DPIECES) dma_piece<ddma.net, ddma.off_kb, (C + 2) % 3>(p, piece_blk(wave + VFN16_WAVES * i), lane); }
                 }
             }
 #endif
@@ -1084,60 +1109,59 @@ extern "C" int vfn_vf_mlp16_fwd(const vfn_net_geom* geom, const void* packed16, 
     return vfn_check_launch("vfn_vf_mlp16_fwd");
 }
 
+// fused launch: proposal samples in place (out_index NULL) or scattered; colour_products 3 (fp32-equivalent everywhere) or 2
+static int launch_fused16(const char* what, const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
+                          const void* rn_packed16, const float* points, const float* ray_dirs, int64_t n_points,
+                          int32_t samples_per_ray, const int32_t* out_index, bool scatter, int32_t colour_products, float* normals,
+                          float* colors, void* stream) {
+    Mlp16Args a = {};
+    VfnNetPlan p32; Plan16 vf, rn;
+    VFN_REQUIRE(vf_geom && rn_geom, "%s: NULL argument", what);
+    int rc = make_plan16(VFN_NET_VF, vf_geom, &p32, &vf, what);
+    if (rc != VFN_OK) return rc;
+    rc = make_plan16(VFN_NET_RENDER, rn_geom, &p32, &rn, what);
+    if (rc != VFN_OK) return rc;
+    rc = check_vf16(vf, what);
+    if (rc != VFN_OK) return rc;
+    rc = check_rn16(rn, what);
+    if (rc != VFN_OK) return rc;
+    VFN_REQUIRE(vf_geom->feature_dims == VFN_HIDDEN && rn_geom->feature_dims == VFN_HIDDEN, "%s: both nets need feature_dims == %d", what, VFN_HIDDEN);
+    VFN_REQUIRE(colour_products == 2 || colour_products == 3, "%s: colour_products must be 2 or 3 (got %d)", what, colour_products);
+    if (n_points <= 0) return VFN_OK;
+    VFN_REQUIRE(vf_packed16 && rn_packed16 && points && ray_dirs && normals && colors && (out_index || !scatter), "%s: NULL argument", what);
+    VFN_REQUIRE(samples_per_ray > 0, "%s: samples_per_ray must be > 0", what);
+    a.vf_w = (const uint4*)vf_packed16; a.rn_w = (const uint4*)rn_packed16; a.points = points; a.ray_dirs = ray_dirs;
+    a.out_vec = normals; a.out_colors = colors; a.out_index = out_index; a.n_points = n_points; a.dirs_div = samples_per_ray;
+    a.vf_multires = vf.multires; a.rn_multires = rn.multires; a.vf_bytes = vf.total_kb * 1024u; a.rn_bytes = rn.total_kb * 1024u;
+    a.status = t_status_word;
+    const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
+    if (colour_products == 2) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED | M16_C2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return vfn_check_launch(what);
+}
+
 extern "C" int vfn_vf_render_fused16_fwd(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
                                           const void* rn_packed16, const float* points, const float* ray_dirs,
                                           int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
                                           void* stream) {
-    Mlp16Args a = {};
-    VfnNetPlan p32; Plan16 vf, rn;
-    int rc = make_plan16(VFN_NET_VF, vf_geom, &p32, &vf, "vfn_vf_render_fused16_fwd");
-    if (rc != VFN_OK) return rc;
-    rc = make_plan16(VFN_NET_RENDER, rn_geom, &p32, &rn, "vfn_vf_render_fused16_fwd");
-    if (rc != VFN_OK) return rc;
-    rc = check_vf16(vf, "vfn_vf_render_fused16_fwd");
-    if (rc != VFN_OK) return rc;
-    rc = check_rn16(rn, "vfn_vf_render_fused16_fwd");
-    if (rc != VFN_OK) return rc;
-    VFN_REQUIRE(vf_geom->feature_dims == VFN_HIDDEN && rn_geom->feature_dims == VFN_HIDDEN,
-                "vfn_vf_render_fused16_fwd: both nets need feature_dims == %d", VFN_HIDDEN);
-    if (n_points <= 0) return VFN_OK;
-    VFN_REQUIRE(vf_packed16 && rn_packed16 && points && ray_dirs && normals && colors, "vfn_vf_render_fused16_fwd: NULL argument");
-    VFN_REQUIRE(samples_per_ray > 0, "vfn_vf_render_fused16_fwd: samples_per_ray must be > 0");
-    a.vf_w = (const uint4*)vf_packed16; a.rn_w = (const uint4*)rn_packed16; a.points = points; a.ray_dirs = ray_dirs;
-    a.out_vec = normals; a.out_colors = colors; a.n_points = n_points; a.dirs_div = samples_per_ray;
-    a.vf_multires = vf.multires; a.rn_multires = rn.multires; a.vf_bytes = vf.total_kb * 1024u; a.rn_bytes = rn.total_kb * 1024u;
-    a.status = t_status_word;
-    const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
-    hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-    return vfn_check_launch("vfn_vf_render_fused16_fwd");
+    return launch_fused16("vfn_vf_render_fused16_fwd", vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, n_points, samples_per_ray,
+                          nullptr, false, 3, normals, colors, stream);
 }
 
 extern "C" int vfn_vf_render_fused16_scatter(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
                                           const void* rn_packed16, const float* points, const float* ray_dirs,
                                           int64_t n_points, int32_t samples_per_ray, const int32_t* out_index, float* normals,
                                           float* colors, void* stream) {
-    Mlp16Args a = {};
-    VfnNetPlan p32; Plan16 vf, rn;
-    int rc = make_plan16(VFN_NET_VF, vf_geom, &p32, &vf, "vfn_vf_render_fused16_scatter");
-    if (rc != VFN_OK) return rc;
-    rc = make_plan16(VFN_NET_RENDER, rn_geom, &p32, &rn, "vfn_vf_render_fused16_scatter");
-    if (rc != VFN_OK) return rc;
-    rc = check_vf16(vf, "vfn_vf_render_fused16_scatter");
-    if (rc != VFN_OK) return rc;
-    rc = check_rn16(rn, "vfn_vf_render_fused16_scatter");
-    if (rc != VFN_OK) return rc;
-    VFN_REQUIRE(vf_geom->feature_dims == VFN_HIDDEN && rn_geom->feature_dims == VFN_HIDDEN,
-                "vfn_vf_render_fused16_scatter: both nets need feature_dims == %d", VFN_HIDDEN);
-    if (n_points <= 0) return VFN_OK;
-    VFN_REQUIRE(vf_packed16 && rn_packed16 && points && ray_dirs && normals && colors && out_index, "vfn_vf_render_fused16_scatter: NULL argument");
-    VFN_REQUIRE(samples_per_ray > 0, "vfn_vf_render_fused16_scatter: samples_per_ray must be > 0");
-    a.vf_w = (const uint4*)vf_packed16; a.rn_w = (const uint4*)rn_packed16; a.points = points; a.ray_dirs = ray_dirs;
-    a.out_vec = normals; a.out_colors = colors; a.out_index = out_index; a.n_points = n_points; a.dirs_div = samples_per_ray;
-    a.vf_multires = vf.multires; a.rn_multires = rn.multires; a.vf_bytes = vf.total_kb * 1024u; a.rn_bytes = rn.total_kb * 1024u;
-    a.status = t_status_word;
-    const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
-    hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-    return vfn_check_launch("vfn_vf_render_fused16_scatter");
+    return launch_fused16("vfn_vf_render_fused16_scatter", vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, n_points,
+                          samples_per_ray, out_index, true, 3, normals, colors, stream);
+}
+
+extern "C" int vfn_vf_render_fused16_products(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
+                                              const void* rn_packed16, const float* points, const float* ray_dirs, int64_t n_points,
+                                              int32_t samples_per_ray, const int32_t* out_index, int32_t colour_products,
+                                              float* normals, float* colors, void* stream) {
+    return launch_fused16("vfn_vf_render_fused16_products", vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, n_points,
+                          samples_per_ray, out_index, false, colour_products, normals, colors, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

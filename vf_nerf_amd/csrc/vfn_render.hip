@@ -76,6 +76,7 @@ extern "C" int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf
                 points && normals && colors && weights && rgb && depth, "vfn_render_fwd: NULL argument");
     const int n = p->n_rays, sc = p->n_coarse, nf = p->n_fine, st = sc + nf;
     VFN_REQUIRE((long long)n * st < (1ll << 22), "vfn_render_fwd: at most 4194303 samples per call");
+    VFN_REQUIRE(p->colour_products == 0 || p->colour_products == 2 || p->colour_products == 3, "vfn_render_fwd: colour_products must be 0, 2 or 3");
     const Ws w = carve(workspace, p);
     int rc;
 
@@ -97,7 +98,9 @@ extern "C" int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf
     vfn_raygen_params rp = {n, sc, p->pose_is_quat, p->near_coarse, p->far_coarse};
     rc = vfn_raygen_uniform(&rp, uv, pose, intrinsics, t_vals, far_coarse_per_ray, uc, w.directions, ray_dirs, w.cam_loc, w.z_c, w.pts_c, stream);
     if (rc != VFN_OK) return rc;
-    rc = vfn_vf_render_fused16_fwd(vf_geom, vf_packed16, rn_geom, rn_packed16, w.pts_c, ray_dirs, (int64_t)n * sc, sc, w.normals_c, w.colors_c, stream);
+    const int products = p->colour_products == 2 ? 2 : 3;
+    rc = vfn_vf_render_fused16_products(vf_geom, vf_packed16, rn_geom, rn_packed16, w.pts_c, ray_dirs, (int64_t)n * sc, sc, nullptr, products,
+                                        w.normals_c, w.colors_c, stream);
     if (rc != VFN_OK) return rc;
     vfn_density_params dp = p->density;
     dp.n_rays = n; dp.n_samples = sc;
@@ -107,8 +110,8 @@ extern "C" int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf
     rc = vfn_range_fine_sample_indexed(&fp, w.z_c, w.imax, w.directions, w.cam_loc, far_fine_per_ray, uf, ua, z_vals, points, nullptr, w.new_pts,
                                        w.dst, (int64_t)n * sc, stream);
     if (rc != VFN_OK) return rc;
-    rc = vfn_vf_render_fused16_scatter(vf_geom, vf_packed16, rn_geom, rn_packed16, w.new_pts, ray_dirs, (int64_t)n * nf, nf, w.dst + (size_t)n * sc,
-                                       normals, colors, stream);
+    rc = vfn_vf_render_fused16_products(vf_geom, vf_packed16, rn_geom, rn_packed16, w.new_pts, ray_dirs, (int64_t)n * nf, nf, w.dst + (size_t)n * sc,
+                                        products, normals, colors, stream);
     if (rc != VFN_OK) return rc;
     rc = vfn_scatter_rows3(w.normals_c, w.colors_c, w.dst, (int64_t)n * sc, normals, colors, stream);
     if (rc != VFN_OK) return rc;

@@ -16,6 +16,15 @@ with silently degraded values.  So:
     "strict"  every guarded call ends with a synchronising read of the status word and is REPEATED on the fp32 kernels when
               flagged: no call ever returns values the clamp touched.
     "off"     no reporting.
+
+Colour self-check.  With ``model.colour_products == 2`` the colour branch of gradient-free renders uses its weights as their f16
+roundings (csrc/vfn_mlp16.hip, M16_C2): a relative error of 2^-12 per weight that averages down to ~2e-5 on the colours of
+networks with O(1) activations, but grows with the activations' magnitude — nothing a range check could bound a priori.  So it is
+MEASURED: on the calls whose status is read back anyway (every call in "strict" mode, every ``LAZY_EVERY``-th and after every
+re-pack in "lazy" mode) ``COLOUR_CHECK_RAYS`` rays of the call, spread over the batch, are evaluated a second time with three
+products and the largest colour difference travels with the status word.  Above ``COLOUR_CHECK_TOL`` the model goes back to
+``colour_products = 3`` (a warning says so; in "strict" mode the call is repeated).  One launch of <= 128 workgroups: 0.12 ms
+where it runs, i.e. 0.2 % of a 4096-ray chunk in "lazy" mode.
 """
 from __future__ import annotations
 
@@ -30,6 +39,8 @@ WEIGHT_MAX_LO = 2.0 ** -9      # a layer whose largest folded weight is below th
                                # halves) in the f16 denormals: < ~16 significant bits left instead of 22
 WEIGHT_MAX_HI = 3.0e4          # f16 overflows at 65 504
 LAZY_EVERY = 32
+COLOUR_CHECK_TOL = 5.0e-5      # two-product colours may differ from three-product colours by this much (contract: 1e-4 of the reference)
+COLOUR_CHECK_RAYS = 128
 
 
 class _Watch:
@@ -39,6 +50,10 @@ class _Watch:
     def __enter__(self) -> "_Watch":
         lib.f16x3_set_status(self.guard._state(self.dev)["status"])
         return self
+
+    def sample(self, out) -> None:
+        """Colour self-check of a finished gradient-free render (see the module docstring); call inside the ``with`` block."""
+        self.guard._colour_sample(self.dev, out)
 
     def __exit__(self, *exc) -> bool:
         lib.f16x3_set_status(None)
@@ -51,6 +66,7 @@ class RangeGuard:
     def __init__(self, model) -> None:
         self.model = model
         self.mode = "lazy"
+        self.colour_products_reason: Optional[str] = None     # why the guard moved the model back to three-product colours
         self._st: Optional[dict] = None
         self._calls = 0
 
@@ -101,9 +117,39 @@ class RangeGuard:
         ev.record()
         st["event"] = ev
 
+    def _pack_keys(self):
+        return tuple(getattr(net, "_packed16_cache", (None,))[0] for net in self._nets())
+
+    def _reads_back(self, st) -> bool:
+        """Will the call in flight end with a read-back of the status?  (same decision as _after_call, before it)"""
+        if self.mode == "strict":
+            return True
+        return st["event"] is None and (self._pack_keys() != st["pack_keys"] or (self._calls + 1) % LAZY_EVERY == 0)
+
+    def _colour_sample(self, dev, out) -> None:
+        model = self.model
+        vf, rn = self._nets()
+        if model.colour_products != 2 or not model.uses_f16x3() or model._needs_grad() or vf.training or rn.training or \
+                out is None or getattr(out, "coarse_colors", None) is None or out.coarse_colors.numel() == 0:
+            return
+        st = self._state(dev)
+        if not self._reads_back(st):
+            return
+        with torch.no_grad():
+            n = out.z_vals.shape[0]
+            s_t = out.z_vals.shape[1]
+            idx = torch.arange(0, n, max(1, n // COLOUR_CHECK_RAYS), device=dev)[:COLOUR_CHECK_RAYS]
+            pts = out.points_coarse.reshape(n, s_t, 3)[idx].reshape(-1, 3).contiguous()
+            dirs = out.ray_dirs.reshape(n, s_t, 3)[idx, 0].contiguous()
+            two = out.coarse_colors.reshape(n, s_t, 3)[idx].reshape(-1, 3)
+            _, three = lib.vf_render_fused16_fwd(vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(), pts, dirs, s_t,
+                                                 colour_products=3)
+            slot = st["status"][1:2].view(torch.float32)
+            torch.maximum(slot, (three - two).abs().max().reshape(1), out=slot)
+
     def _after_call(self, dev) -> bool:
         st = self._state(dev)
-        keys = tuple(getattr(net, "_packed16_cache", (None,))[0] for net in self._nets())
+        keys = self._pack_keys()
         repacked = keys != st["pack_keys"]
         st["pack_keys"] = keys
         self._calls += 1
@@ -119,6 +165,15 @@ class RangeGuard:
     def _evaluate(self, st) -> bool:
         host = st["host"]
         flags = int(host[0])
+        colour_diff = float(host[1:2].view(torch.float32)[0])
+        colour_flag = False
+        if colour_diff > COLOUR_CHECK_TOL and self.model.colour_products == 2:
+            warnings.warn(f"vf_nerf_amd: two-product colours differ from three-product colours by {colour_diff:.2e} (> {COLOUR_CHECK_TOL:.0e}) on "
+                          "this model's data; colour_products is now 3", RuntimeWarning, stacklevel=3)
+            self.model.colour_products = 3
+            self.colour_products_reason = f"two-product colours were {colour_diff:.2e} off"
+            st["status"][1:2].zero_()
+            colour_flag = True
         reasons = []
         if flags & lib.STATUS_ACT_SATURATED:
             reasons.append("a hidden activation exceeded the split-f16 range (|x| > ~937)")
@@ -136,7 +191,7 @@ class RangeGuard:
                     reasons.append(f"the {tag} net's pack entry {e} has max |folded weight| = {w:.3g}, outside "
                                    f"[{WEIGHT_MAX_LO:.2g}, {WEIGHT_MAX_HI:.2g}]")
         if not reasons:
-            return False
+            return colour_flag
         reason = "; ".join(reasons)
         warnings.warn("vf_nerf_amd: the f16x3 kernels left the range their split-f16 operands represent to fp32 accuracy (" + reason +
                       "); this model now runs on the exact-fp32 kernels", RuntimeWarning, stacklevel=3)

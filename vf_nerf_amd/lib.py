@@ -30,7 +30,7 @@ EXPORTS = (
     "vfn_grid_unify_direction", "vfn_grid_comb_format", "vfn_weight_grad_partials_bf16", "vfn_unfold_weight_grads", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
     "vfn_linear_rows", "vfn_linear_rows_stat_parts", "vfn_bstat_row_parts", "vfn_colsum_finish", "vfn_bstat_finalize",
     "vfn_bstat_relu_rows", "vfn_bstat_relu_bwd_sums", "vfn_bstat_relu_bwd_rows", "vfn_act_bwd_rows", "vfn_embed_rows",
-    "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax",
+    "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_vf_render_fused16_products", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax",
     "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step", "vfn_unfold_weight_grads_acc", "vfn_render_fwd", "vfn_render_fwd_workspace_bytes",
 )
 
@@ -73,7 +73,7 @@ class RenderParams(C.Structure):
     _fields_ = [("n_rays", C.c_int32), ("n_coarse", C.c_int32), ("n_fine", C.c_int32), ("pose_is_quat", C.c_int32),
                 ("perturb_coarse", C.c_int32), ("perturb_fine", C.c_int32), ("near_coarse", C.c_float), ("near_fine", C.c_float),
                 ("far_coarse", C.c_float), ("far_fine", C.c_float), ("fine_range", C.c_float), ("window_step", C.c_float), ("span", C.c_float),
-                ("density", DensityParams), ("seed", C.c_uint64), ("offset", C.c_uint64)]
+                ("density", DensityParams), ("seed", C.c_uint64), ("offset", C.c_uint64), ("colour_products", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -664,13 +664,28 @@ def vf_feat16_fwd(geom: NetGeom, packed16, points, out_vec, out_blocks) -> None:
                                     _stream()), "vfn_vf_feat16_fwd")
 
 
+def _fused16_products(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, samples_per_ray, out_index, colour_products,
+                      normals, colors) -> None:
+    _check(load().vfn_vf_render_fused16_products(C.byref(vf_geom), _ptr(vf_packed16, "vf_packed16", torch.uint8),
+                                                 C.byref(rn_geom), _ptr(rn_packed16, "rn_packed16", torch.uint8),
+                                                 _ptr(points, "points"), _ptr(ray_dirs, "ray_dirs"), C.c_int64(points.shape[0]),
+                                                 C.c_int32(samples_per_ray),
+                                                 _ptr(out_index, "out_index", torch.int32) if out_index is not None else None,
+                                                 C.c_int32(colour_products), _ptr(normals, "normals"), _ptr(colors, "colors"),
+                                                 _stream()), "vfn_vf_render_fused16_products")
+
+
 def vf_render_fused16_scatter(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, samples_per_ray: int, out_index,
-                              normals, colors) -> None:
+                              normals, colors, colour_products: int = 3) -> None:
     """Fused VF + rendering launch over points[M,3] (view direction of point m: ray_dirs[m // samples_per_ray]); the outputs of
-    point m are written to row out_index[m] of the caller's normals / colors (int32; negative: dropped)."""
+    point m are written to row out_index[m] of the caller's normals / colors (int32; negative: dropped).  colour_products: see
+    vfn_vf_render_fused16_products."""
     m = points.shape[0]
     if out_index.shape[0] < m:
         raise VfnError(f"out_index holds {out_index.shape[0]} entries for {m} points")
+    if colour_products != 3:
+        return _fused16_products(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, samples_per_ray, out_index,
+                                 colour_products, normals, colors)
     _check(load().vfn_vf_render_fused16_scatter(C.byref(vf_geom), _ptr(vf_packed16, "vf_packed16", torch.uint8),
                                                 C.byref(rn_geom), _ptr(rn_packed16, "rn_packed16", torch.uint8),
                                                 _ptr(points, "points"), _ptr(ray_dirs, "ray_dirs"), C.c_int64(m),
@@ -736,11 +751,15 @@ def vf_render_fused16_fwd_train(vf_geom, vf_packed16, rn_geom, rn_packed16, poin
     return normals, colors
 
 
-def vf_render_fused16_fwd(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, samples_per_ray: int):
+def vf_render_fused16_fwd(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, samples_per_ray: int, colour_products: int = 3):
     m = points.shape[0]
     dev = points.device
     normals = torch.empty(m, 3, device=dev)
     colors = torch.empty(m, 3, device=dev)
+    if colour_products != 3:
+        _fused16_products(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, samples_per_ray, None, colour_products,
+                          normals, colors)
+        return normals, colors
     _check(load().vfn_vf_render_fused16_fwd(C.byref(vf_geom), _ptr(vf_packed16, "vf_packed16", torch.uint8),
                                             C.byref(rn_geom), _ptr(rn_packed16, "rn_packed16", torch.uint8),
                                             _ptr(points, "points"), _ptr(ray_dirs, "ray_dirs"), C.c_int64(m),

@@ -139,6 +139,12 @@ class VectorFieldNerf:
         # rendering net gathers (the reference evaluates the proposal samples twice; same per-sample arithmetic, identical
         # outputs).  False: one fused VF+rendering launch over all S_c+N_f samples.
         self.reuse_proposal = True
+        # f16 products per fp32-equivalent product in the COLOUR BRANCH of gradient-free f16x3 renders (the feature block of the VF
+        # net + the rendering net; csrc/vfn_mlp16.hip, M16_C2).  2: that branch's weights enter as their f16 roundings (activations
+        # stay split): -14 % matrix instructions, 1.13x on the fused launch; colours within 2e-5 of the exact-fp32 kernels / the
+        # reference's golden outputs (contract 1e-4, profiles/r02/ab_colour_products.txt), while normals, density, weights, depth and
+        # the sample positions are bit-identical to 3.  3: fp32-equivalent colours (1e-7).  Training forwards always use 3.
+        self.colour_products = 2
         # Range guard of the f16x3 kernels (guard.py): "lazy" (asynchronous read-back of the kernels' saturation report, the
         # model switches itself to the exact-fp32 kernels when one arrives), "strict" (every call is checked and, when flagged,
         # repeated on the fp32 kernels before it returns) or "off".  ``f16x3_disabled`` holds the reason once it has switched.
@@ -397,6 +403,7 @@ class VectorFieldNerf:
         rp.fine_range, rp.window_step = rng, 2 * rng / (n_f - 1)            # Python double arithmetic, as ray_sampler.py:279
         rp.span = (far_f - float(self.fine_sampler.near)) if far_ft is None else 0.0
         rp.density = self._density_params()
+        rp.colour_products = int(self.colour_products)
 
         def given(name, needed):
             return uniforms[name].to(dev).float().contiguous() if (needed and name in uniforms) else None
@@ -448,7 +455,8 @@ class VectorFieldNerf:
         rng_offset = self._rng_offset
         with guard.watch(pose.device) as w:
             out = self._render(pose, pixels, intrinsics, epoch, white, uniforms)
-        if w.flagged:                              # strict mode: repeat this call on the fp32 kernels, same draws
+            w.sample(out)                          # two-product colours: measured against three products on a few rays
+        if w.flagged:                              # strict mode: repeat this call on the kernels the guard switched to, same draws
             self._rng_offset = rng_offset
             out = self._render(pose, pixels, intrinsics, epoch, white, uniforms)
         return out
@@ -521,7 +529,8 @@ class VectorFieldNerf:
                 rn = self.rendering_network
                 with self._timed("fused16"):
                     normals_c, colors_c = lib.vf_render_fused16_fwd(vf.geometry(), vf.packed16_weights(), rn.geometry(),
-                                                                    rn.packed16_weights(), pts_c.view(-1, 3), ray_dirs, s_c)
+                                                                    rn.packed16_weights(), pts_c.view(-1, 3), ray_dirs, s_c,
+                                                                    colour_products=self.colour_products)
             elif self.uses_f16x3():
                 normals_c = lib.vf_mlp16_fwd(vf.geometry(), vf.packed16_weights(), pts_c.view(-1, 3))
             else:
@@ -553,7 +562,8 @@ class VectorFieldNerf:
                 colors = torch.empty(n * s_t, 3, device=dev)
                 with self._timed("fused16"):
                     lib.vf_render_fused16_scatter(vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(),
-                                                  new_pts.view(-1, 3), ray_dirs, n_f, dst[m_c:], normals, colors)
+                                                  new_pts.view(-1, 3), ray_dirs, n_f, dst[m_c:], normals, colors,
+                                                  colour_products=self.colour_products)
                 lib.scatter_rows3(normals_c, colors_c, dst[:m_c], normals, colors)
                 _, weights, _, rgb, depth = lib.ray_density_weights(self._density_params(), normals, ray_dirs, z, scal,
                                                                     colors=colors, want_sigma=False)
