@@ -435,6 +435,29 @@ int vfn_unfold_weight_grads(const vfn_unfold_entry* entries, int32_t n_entries, 
 int vfn_unfold_weight_grads_acc(const vfn_unfold_entry* entries, int32_t n_entries, int32_t groups, uint32_t accumulate_mask,
                                 void* stream);
 
+/* The parameter gradients of ONE network from a fragment-ordered workspace in ONE call (csrc/vfn_wgrad.hip): the
+ * vfn_weight_grad_frag launches of every layer entry (activation columns, encoding columns), of the 3-channel head, and the
+ * vfn_unfold_weight_grads_acc launch, issued on `stream` out of `scratch` (vfn_net_weight_grads_scratch_bytes; no allocation, no
+ * synchronisation) — loss.backward() through vector_field_network.py:177-208 / rendering_network.py:62-108
+ * (train/vector_field_nerf_train.py:252) after the dX chain has written the gradient slots.
+ *   layers[geom->n_layers]: the reference's parameters per nn.Linear (+ BatchNorm1d) and where their gradients go;
+ *   saved / dy: THIS net's first activation / gradient slot (slot stride slot_bytes = ceil(M/32) * 32 KiB);
+ *   dy_form / x_form as in vfn_weight_grad_frag; feats: the tanh'ed features [M][256] fp32 rows (rendering net: input of its
+ *   first layer; vector-field net: unused, may be NULL); aux: this net's encoding tile [M][40]; dz_head: [M][4];
+ *   with_features = 0 (vector-field net only): the forward was vector-only, the feature block's rows get no gradient;
+ *   accumulate != 0: results are ADDED to the gradient tensors (they are the parameters' .grad), else written.
+ * vfn_weight_grad_groups(M) = the number of partial slabs per product the entry points use for M points. */
+typedef struct vfn_wgrad_layer {
+    const float* weight; const float* bias; const float* bn_weight; const float* bn_var; const float* bn_mean;
+    float* g_weight; float* g_bias; float* g_bn_weight; float* g_bn_bias;
+} vfn_wgrad_layer;
+int32_t vfn_weight_grad_groups(int64_t n_points);
+int64_t vfn_net_weight_grads_scratch_bytes(int32_t net_kind, const vfn_net_geom* geom, int64_t n_points);
+int vfn_net_weight_grads_frag(int32_t net_kind, const vfn_net_geom* geom, const vfn_wgrad_layer* layers, const void* saved,
+                              const void* dy, int64_t slot_bytes, int32_t dy_form, int32_t x_form, const float* feats,
+                              const float* aux, const float* dz_head, int64_t n_points, int32_t with_features,
+                              int32_t accumulate, void* scratch, void* stream);
+
 /* Supervision points of the trainer (train/vector_field_nerf_train.py:186-214): n uniform samples in the spherical
  * shell r_min <= |p - centroid| <= r_max (models/samplers/sampler.py:160-193) and their radial unit ground truth
  * (models/helpers/functions.py:100-135): inward = 1 -> normalize(centroid - p) (sample_border_points), 0 -> normalize(p -

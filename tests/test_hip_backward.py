@@ -480,3 +480,48 @@ def test_weight_grad_frag_matches_float64(m, groups):
             lib.weight_grad_frag(2, dz, lib.DYF_DZ4, bx, fx_, m, groups, part, dbp)
             check(f"shape2/{fx_}", part.sum(0)[:4], dz.double().T @ vx.double(), dbp.sum(0)[:4], dz.double().sum(0))
             assert float(part.sum(0)[4:].abs().max()) == 0.0 and float(dbp.sum(0)[4:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("storage", ["f16", "fp32", "f16+bf16dy"])
+def test_one_call_weight_gradients_equal_the_launch_by_launch_path(storage):
+    """vfn_net_weight_grads_frag (csrc/vfn_wgrad.hip: every weight-gradient launch of a net and the un-fold issued from C out of
+    one scratch buffer, results added into the parameters' .grad) against the facade's launch-by-launch sequence: the same
+    launches on the same data, so every gradient must agree to the last bit — through the fused fine pass (both nets), a
+    vector-only supervision forward (feature block skipped) and a full VF forward, accumulated into the same .grad tensors."""
+    fx, d = load_fixture("shipped_sizes")
+    g = {k: v.to("cuda:0") for k, v in d.items() if isinstance(v, torch.Tensor)}
+    uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add") if k in g}
+    a, b, c = (t.to("cuda:0") for t in loss_coefficients(*d["z_vals"].shape))
+    sup = torch.rand(777, 3, generator=torch.Generator().manual_seed(5)).to("cuda:0") - 0.5
+    opts = storage.split("+")
+    grads = {}
+    for one_call in (True, False):
+        model = build_model(fx, d, device="cuda:0")
+        model.activation_storage = opts[0]
+        model.gradient_storage = "bf16" if "bf16dy" in opts else "fp32"
+        for net in (model.vector_field_network, model.rendering_network):
+            net.one_call_weight_grads = one_call
+        calls = []
+        real = lib.net_weight_grads_frag
+        lib.net_weight_grads_frag = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        try:
+            model.optimizer.zero_grad()                      # FlatAdam: .grad tensors exist (views of one buffer), zeroed
+            assert all(p.grad is not None for p in model.unique_parameters())
+            out = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
+            vf = model.vector_field_network
+            loss = (out.coarse_rgb_values * a).sum() + (out.coarse_depth_map * b).sum() + (out.coarse_normals * c).sum() + \
+                vf(sup, vector_only=True).pow(2).sum() + vf(sup[:300]).sum()
+            loss.backward()
+        finally:
+            lib.net_weight_grads_frag = real
+        assert len(calls) == (4 if one_call else 0), calls   # fine pass: two nets; two stand-alone VF forwards
+        grads[one_call] = {f"{tag}.{n}": p.grad.detach().clone()
+                           for tag, mod in (("vf", model.vector_field_network), ("rn", model.rendering_network), ("density", model.density))
+                           for n, p in mod.named_parameters() if p.grad is not None}
+    assert grads[True].keys() == grads[False].keys() and len(grads[True]) > 40
+    for name in grads[True]:
+        x, y = grads[True][name], grads[False][name]
+        if name.startswith("density."):                     # float atomics across workgroups (vfn_density_bwd_kernel): not bit-stable
+            assert torch.allclose(x, y, rtol=1e-4, atol=1e-6), name
+        else:
+            assert torch.equal(x, y), (name, float((x - y).abs().max()))

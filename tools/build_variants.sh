@@ -9,6 +9,6 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -mllvm -a
 for v in "$@"; do
   name=${v%%:*}; defs=${v#*:}
   ( hipcc $FLAGS $defs -c vfn_mlp16.hip -o /tmp/vfn_mlp16_$name.o && \
-    hipcc -shared -fPIC --offload-arch=gfx950 -o libvfn_$name.so vfn_pack.o vfn_mlp.o vfn_mlp_bwd.o vfn_dw16.o vfn_dwf.o vfn_unfold.o vfn_bwd16.o /tmp/vfn_mlp16_$name.o vfn_rays.o vfn_grid.o vfn_bstat.o vfn_adam.o && echo built $name ) &
+    hipcc -shared -fPIC --offload-arch=gfx950 -o libvfn_$name.so vfn_pack.o vfn_mlp.o vfn_mlp_bwd.o vfn_dw16.o vfn_dwf.o vfn_unfold.o vfn_bwd16.o /tmp/vfn_mlp16_$name.o vfn_rays.o vfn_grid.o vfn_bstat.o vfn_adam.o vfn_render.o vfn_wgrad.o && echo built $name ) &
 done
 wait

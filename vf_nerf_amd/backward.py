@@ -111,8 +111,44 @@ def _rn_inputs(feats: torch.Tensor, saved_slots: List[torch.Tensor]) -> List[tor
     return [feats] + list(saved_slots)
 
 
+def _layer_table(net):
+    """vfn_wgrad_layer array of the net (parameters and their .grad tensors per reference layer), rebuilt when an address moves."""
+    rows = []
+    for i in range(net.num_layers):
+        lin, bn = net._linear(i), net._bn(i)
+        row = [lin.weight, lin.bias, None, None, None, lin.weight.grad, lin.bias.grad, None, None]
+        if bn is not None:
+            row[2:5] = [bn.weight, bn.running_var, bn.running_mean]
+            row[7:9] = [bn.weight.grad, bn.bias.grad]
+        rows.append(row)
+    key = tuple(0 if t is None else t.data_ptr() for row in rows for t in row)
+    cache = getattr(net, "_wgrad_table", None)
+    if cache is None or cache[0] != key:
+        arr = (lib.WgradLayer * len(rows))()
+        k = 0
+        for i in range(len(rows)):
+            for name, _ in lib.WgradLayer._fields_:
+                setattr(arr[i], name, key[k] or None)
+                k += 1
+        cache = net._wgrad_table = (key, arr)
+    return cache[1]
+
+
+def _wgrad_scratch(net, m: int, dev) -> torch.Tensor:
+    cache = getattr(net, "_wgrad_scratch_cache", None)
+    if cache is None:
+        cache = net._wgrad_scratch_cache = {}
+    key = (m, str(dev))
+    buf = cache.get(key)
+    if buf is None:
+        if len(cache) >= 4:
+            cache.clear()
+        buf = cache[key] = torch.empty(lib.net_weight_grads_scratch_bytes(net._kind, net.geometry(), m), dtype=torch.uint8, device=dev)
+    return buf
+
+
 def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=(), fast: bool = False, x_f16: bool = False,
-                  x_fp32_entries=(), frag=None) -> Dict[torch.nn.Parameter, torch.Tensor]:
+                  x_fp32_entries=(), frag=None, ws_ref=None) -> Dict[torch.nn.Parameter, torch.Tensor]:
     """inputs[h]: [M,256] act input of hidden entry h (None if it has none); inputs[-1]: input of the 3-channel head.
     dy_slots[h]: [M,256] pre-activation gradient of entry h.  aux: [M,40].  dz_head: [M,4].  Runs the persistent
     weight-gradient kernels (``fast``: the 256 x 256 products on the bf16 matrix cores, csrc/vfn_dw16.hip), then ONE
@@ -134,6 +170,16 @@ def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=(), fast: bo
     direct = getattr(net, "accumulate_into_grad", True) and all(
         p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.device == dev and not p.grad.requires_grad
         for p in net.parameters())
+
+    if frag is not None and direct and ws_ref is not None and getattr(net, "one_call_weight_grads", True):
+        # fragment-ordered workspace, gradients accumulated in place: the whole launch sequence below from C out of one cached
+        # scratch buffer (csrc/vfn_wgrad.hip: same launches, same values; ~45 Python-side operations per backward fewer).
+        # ws_ref = (saved [slots, slot_floats], dy [slots, slot_floats], this net's first slot)
+        saved, dy_all, first = ws_ref
+        lib.net_weight_grads_frag(net._kind, net.geometry(), _layer_table(net), saved, first, dy_all, saved.shape[1], frag[0], frag[1],
+                                  inputs[0] if 0 in x_fp32_entries else None, aux, dz_head, m, with_features=not skip,
+                                  accumulate=True, scratch=_wgrad_scratch(net, m, dev))
+        return {}
 
     def out_for(p):
         if direct:
@@ -327,10 +373,10 @@ class _FinePass(torch.autograd.Function):
         # (3) weight gradients
         feats = ws.feats(vf_h - 1) if fast else ws.saved[vf_h - 1]
         g_vf = _weight_grads(vf, _vf_inputs(vf, [ws.saved[h] for h in range(vf_h)]), [dy[h] for h in range(vf_h)],
-                             ws.aux_vf, dz_vec, m, fast=fast, x_f16=ws.f16, frag=ws.frag_forms())
+                             ws.aux_vf, dz_vec, m, fast=fast, x_f16=ws.f16, frag=ws.frag_forms(), ws_ref=(ws.saved, dy, 0))
         g_rn = _weight_grads(rn, _rn_inputs(feats, [ws.saved[vf_h + h] for h in range(rn_h)]),
                              [dy[vf_h + h] for h in range(rn_h)], ws.aux_rn, dz_rgb, m, fast=fast, x_f16=ws.f16,
-                             x_fp32_entries=(0,), frag=ws.frag_forms())
+                             x_fp32_entries=(0,), frag=ws.frag_forms(), ws_ref=(ws.saved, dy, vf_h))
         # density scalars in density.parameters() order
         by_name = {"beta": dscal[0], "mean": dscal[1], "scale": dscal[2]}
         g_den = {p: by_name[name].reshape(p.shape) for name, p in model.density.named_parameters()}
@@ -397,7 +443,7 @@ class _VFForward(torch.autograd.Function):
         # vector-only forward: the feature block of the last Linear was never evaluated -> no gradient for it
         skip = (vf_h - 1,) if (net._feature_dims() > 0 and cols == 3) else ()
         grads = _weight_grads(net, _vf_inputs(net, [ws.saved[h] for h in range(vf_h)]), [dy[h] for h in range(vf_h)],
-                              ws.aux_vf, dz_vec, m, skip=skip, fast=fast, x_f16=ws.f16, frag=ws.frag_forms())
+                              ws.aux_vf, dz_vec, m, skip=skip, fast=fast, x_f16=ws.f16, frag=ws.frag_forms(), ws_ref=(ws.saved, dy, 0))
         ctx.ws = None
         return (None, None, None, *[grads.get(p) for p in ctx.param_order])
 

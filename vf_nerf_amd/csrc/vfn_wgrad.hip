@@ -1,0 +1,169 @@
+// vfn_wgrad.hip — the parameter gradients of ONE network from a fragment-ordered training workspace, as one entry point.
+//
+// loss.backward() through models/vector_field/vector_field_network.py:177-208 / rendering_network.py:62-108
+// (train/vector_field_nerf_train.py:252) needs, per nn.Linear (+ eval-mode BatchNorm1d), dW = dY^T X, db and the BatchNorm
+// gradients.  The facade used to issue these launch by launch — per layer entry a partial-slab launch for the activation
+// columns, one for the encoding columns, then one un-fold launch per net — with a torch allocation per slab: ~45 Python-side
+// operations per backward, 1.9 ms of host time at the reference's 1 024-ray batches where the device needs 1.2 ms.
+// vfn_net_weight_grads_frag is that sequence issued from C out of one caller-supplied scratch buffer:
+//     for every layer entry h of the net (csrc/vfn_plan.h; vf_nerf_amd/backward.py::_entries is the same table):
+//         vfn_weight_grad_frag(shape 0)  dY_h^T X_h      [256][256] slabs, X_h = the slot of entry h-1 (rendering net, h = 0: the
+//                                                         fp32 feature rows)
+//         vfn_weight_grad_frag(shape 1)  dY_h^T aux      [256][64] slabs (entries that read the encoding tile)
+//     vfn_weight_grad_frag(shape 2)      dz_head^T X_last for the 3-channel head
+//     vfn_unfold_weight_grads_acc        slabs summed, BatchNorm / skip scale un-folded, added into (or written over) the
+//                                        parameters' gradient tensors
+// Nothing here computes: it sequences entry points of this library, so every value is what those entry points produce.
+#include <math.h>
+#include <string.h>
+#include "vfn_common.h"
+#include "vfn_plan.h"
+
+namespace {
+
+struct Entry {
+    int layer, rows, row_off;
+    int act_c0, act_nc;      // act_nc = 0: no activation input
+    int aux_c0, aux_nc;      // aux_nc = 0: no encoding input
+    float scale;
+    int x_slot;              // slot holding the activation input; -1: the caller's fp32 feature rows (rendering net, entry 0)
+};
+
+// the entries of a net in slot order, then the slot that feeds the 3-channel head
+int make_entries(int net_kind, const vfn_net_geom* g, Entry* e, int* head_x_slot, const char* what) {
+    VfnNetPlan plan;
+    char err[256] = {0};
+    int rc = vfn_make_plan(net_kind, g, &plan, err, sizeof(err));
+    if (rc != VFN_OK) { vfn_set_error("%s: %s", what, err); return rc; }
+    const int L = g->n_layers, pe = plan.pe_dim, F = g->feature_dims;
+    int n = 0;
+    if (net_kind == VFN_NET_VF) {
+        for (int i = 0; i < L - 1; ++i) {
+            Entry& x = e[n];
+            x = Entry{i, g->out_dims[i], 0, 0, 0, 0, 0, 1.0f, n - 1};
+            if (i == 0) { x.aux_c0 = 0; x.aux_nc = pe; }
+            else if (i == g->skip_layer) {
+                x.act_c0 = 0; x.act_nc = g->out_dims[i - 1]; x.aux_c0 = g->out_dims[i - 1]; x.aux_nc = pe;
+                x.scale = 0.70710678118654752440f;
+            } else { x.act_c0 = 0; x.act_nc = VFN_HIDDEN; }
+            ++n;
+        }
+        const int last_plain = n - 1;
+        if (F > 0) { e[n] = Entry{L - 1, F, 3, 0, VFN_HIDDEN, 0, 0, 1.0f, last_plain}; ++n; }
+        *head_x_slot = last_plain;
+    } else {
+        for (int i = 0; i < L - 1; ++i) {
+            Entry& x = e[n];
+            x = Entry{i, g->out_dims[i], 0, 0, VFN_HIDDEN, 0, 0, 1.0f, n - 1};
+            if (i == 0) { x.act_c0 = 6 + pe; x.act_nc = F; x.aux_c0 = 0; x.aux_nc = 6 + pe; x.x_slot = -1; }
+            ++n;
+        }
+        *head_x_slot = n - 1;
+    }
+    if (n != plan.n_hidden) { vfn_set_error("%s: %d entries against %d planned layers", what, n, plan.n_hidden); return VFN_ERR_INVALID; }
+    return n;
+}
+
+int groups_for(int64_t m) {
+    const int64_t g = m / 256;
+    return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
+}
+
+struct Carve {
+    unsigned char* base;
+    size_t off;
+    float* take(size_t floats) {
+        float* p = reinterpret_cast<float*>(base ? base + off : nullptr);
+        off += ((floats * 4 + 255) / 256) * 256;
+        return p;
+    }
+};
+
+}  // namespace
+
+extern "C" int32_t vfn_weight_grad_groups(int64_t n_points) { return groups_for(n_points); }
+
+extern "C" int64_t vfn_net_weight_grads_scratch_bytes(int32_t net_kind, const vfn_net_geom* geom, int64_t n_points) {
+    if (!geom || n_points < 0) return VFN_ERR_INVALID;
+    Entry e[VFN_MAX_LAYERS + 1];
+    int head_slot;
+    const int n = make_entries(net_kind, geom, e, &head_slot, "vfn_net_weight_grads_scratch_bytes");
+    if (n < 0) return n;
+    const size_t G = (size_t)groups_for(n_points);
+    Carve c{nullptr, 0};
+    for (int h = 0; h < n; ++h) {
+        c.take(G * VFN_HIDDEN);
+        if (e[h].act_nc) c.take(G * VFN_HIDDEN * VFN_HIDDEN);
+        if (e[h].aux_nc) c.take(G * VFN_HIDDEN * 64);
+    }
+    c.take(G * 32 * VFN_HIDDEN);
+    c.take(G * 32);
+    return (int64_t)c.off;
+}
+
+extern "C" int vfn_net_weight_grads_frag(int32_t net_kind, const vfn_net_geom* geom, const vfn_wgrad_layer* layers, const void* saved,
+                                         const void* dy, int64_t slot_bytes, int32_t dy_form, int32_t x_form, const float* feats,
+                                         const float* aux, const float* dz_head, int64_t n_points, int32_t with_features,
+                                         int32_t accumulate, void* scratch, void* stream) {
+    const char* what = "vfn_net_weight_grads_frag";
+    VFN_REQUIRE(geom && layers && saved && dy && aux && dz_head && scratch, "%s: NULL argument", what);
+    if (n_points <= 0) return VFN_OK;
+    Entry e[VFN_MAX_LAYERS + 1];
+    int head_slot;
+    const int n = make_entries(net_kind, geom, e, &head_slot, what);
+    if (n < 0) return n;
+    VFN_REQUIRE(n + 1 <= 12, "%s: %d entries (the un-fold launch takes 12)", what, n + 1);
+    VFN_REQUIRE(net_kind == VFN_NET_VF || feats, "%s: the rendering net's first layer reads the fp32 feature rows", what);
+    VFN_REQUIRE(slot_bytes > 0 && slot_bytes % 1024 == 0, "%s: slot_bytes = %lld", what, (long long)slot_bytes);
+    const int G = groups_for(n_points);
+    const unsigned char* sv = static_cast<const unsigned char*>(saved);
+    const unsigned char* dyb = static_cast<const unsigned char*>(dy);
+    Carve c{static_cast<unsigned char*>(scratch), 0};
+    vfn_unfold_entry u[12];
+    memset(u, 0, sizeof(u));
+    int nu = 0;
+    const bool skip_feat = net_kind == VFN_NET_VF && geom->feature_dims > 0 && !with_features;
+    for (int h = 0; h < n; ++h) {
+        const Entry& x = e[h];
+        float* db = c.take((size_t)G * VFN_HIDDEN);
+        float* dw_act = x.act_nc ? c.take((size_t)G * VFN_HIDDEN * VFN_HIDDEN) : nullptr;
+        float* dw_aux = x.aux_nc ? c.take((size_t)G * VFN_HIDDEN * 64) : nullptr;
+        if (skip_feat && h == n - 1) continue;       // vector-only forward: the feature block was never evaluated
+        const vfn_wgrad_layer& q = layers[x.layer];
+        VFN_REQUIRE(q.weight && q.bias && q.g_weight && q.g_bias, "%s: layer %d has a NULL weight / bias / gradient pointer", what, x.layer);
+        const void* dy_h = dyb + (size_t)h * slot_bytes;
+        int rc;
+        if (dw_act) {
+            const bool rows = x.x_slot < 0;
+            rc = vfn_weight_grad_frag(0, dy_h, dy_form, rows ? (const void*)feats : (const void*)(sv + (size_t)x.x_slot * slot_bytes),
+                                      rows ? 2 : x_form, n_points, G, dw_act, db, stream);
+            if (rc != VFN_OK) return rc;
+        }
+        if (dw_aux) {
+            rc = vfn_weight_grad_frag(1, dy_h, dy_form, aux, 3, n_points, G, dw_aux, dw_act ? nullptr : db, stream);
+            if (rc != VFN_OK) return rc;
+        }
+        vfn_unfold_entry& o = u[nu++];
+        o.dw_act = dw_act; o.dw_aux = dw_aux; o.db = db;
+        o.w = q.weight; o.b_lin = q.bias; o.g_w = q.g_weight; o.g_b = q.g_bias;
+        if (geom->has_bn[x.layer]) {
+            VFN_REQUIRE(q.bn_weight && q.bn_var && q.bn_mean && q.g_bn_weight && q.g_bn_bias, "%s: layer %d BatchNorm pointer NULL", what, x.layer);
+            o.bn_w = q.bn_weight; o.bn_var = q.bn_var; o.bn_mean = q.bn_mean; o.g_bn_w = q.g_bn_weight; o.g_bn_b = q.g_bn_bias;
+        }
+        o.rows = x.rows; o.row_off = x.row_off; o.in_dim = geom->in_dims[x.layer]; o.slab_rows = VFN_HIDDEN;
+        o.act_c0 = x.act_c0; o.act_nc = x.act_nc; o.aux_c0 = x.aux_c0; o.aux_nc = x.aux_nc; o.scale = x.scale;
+    }
+    {   // 3-channel head = rows 0..2 of the last Linear (no BatchNorm)
+        float* part = c.take((size_t)G * 32 * VFN_HIDDEN);
+        float* dbp = c.take((size_t)G * 32);
+        const int L = geom->n_layers;
+        const vfn_wgrad_layer& q = layers[L - 1];
+        VFN_REQUIRE(q.weight && q.bias && q.g_weight && q.g_bias, "%s: the last layer has a NULL weight / bias / gradient pointer", what);
+        int rc = vfn_weight_grad_frag(2, dz_head, 2, sv + (size_t)head_slot * slot_bytes, x_form, n_points, G, part, dbp, stream);
+        if (rc != VFN_OK) return rc;
+        vfn_unfold_entry& o = u[nu++];
+        o.dw_act = part; o.db = dbp; o.w = q.weight; o.b_lin = q.bias; o.g_w = q.g_weight; o.g_b = q.g_bias;
+        o.rows = 3; o.row_off = 0; o.in_dim = geom->in_dims[L - 1]; o.slab_rows = 32; o.act_c0 = 0; o.act_nc = VFN_HIDDEN; o.scale = 1.0f;
+    }
+    return vfn_unfold_weight_grads_acc(u, nu, G, accumulate ? (1u << nu) - 1u : 0u, stream);
+}

@@ -30,7 +30,8 @@ EXPORTS = (
     "vfn_grid_unify_direction", "vfn_grid_comb_format", "vfn_weight_grad_partials_bf16", "vfn_unfold_weight_grads", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
     "vfn_linear_rows", "vfn_linear_rows_stat_parts", "vfn_bstat_row_parts", "vfn_colsum_finish", "vfn_bstat_finalize",
     "vfn_bstat_relu_rows", "vfn_bstat_relu_bwd_sums", "vfn_bstat_relu_bwd_rows", "vfn_act_bwd_rows", "vfn_embed_rows",
-    "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_vf_render_fused16_products", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax",
+    "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_vf_render_fused16_products", "vfn_net_weight_grads_frag", "vfn_net_weight_grads_scratch_bytes",
+    "vfn_weight_grad_groups", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax",
     "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step", "vfn_unfold_weight_grads_acc", "vfn_render_fwd", "vfn_render_fwd_workspace_bytes",
 )
 
@@ -90,6 +91,7 @@ def load() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     lib.vfn_last_error.restype = C.c_char_p
     lib.vfn_packed_size.restype = C.c_int64
+    lib.vfn_net_weight_grads_scratch_bytes.restype = C.c_int64
     lib.vfn_packed_size.argtypes = [C.c_int32, C.POINTER(NetGeom)]
     lib.vfn_packed_bwd_size.restype = C.c_int64
     lib.vfn_packed_bwd_size.argtypes = [C.c_int32, C.POINTER(NetGeom)]
@@ -530,6 +532,38 @@ def weight_grad_frag(shape: int, dy, dy_form: int, x, x_form: int, n_points: int
     _check(load().vfn_weight_grad_frag(C.c_int32(shape), _ptr(dy, "dy"), C.c_int32(dy_form), _ptr(x, "x"), C.c_int32(x_form),
                                        C.c_int64(n_points), C.c_int32(groups), _ptr(dw_part, "dw_part"), _ptr(db_part, "db_part"),
                                        _stream()), "vfn_weight_grad_frag")
+
+
+class WgradLayer(C.Structure):
+    """mirrors vfn_wgrad_layer"""
+    _fields_ = [(n, C.c_void_p) for n in ("weight", "bias", "bn_weight", "bn_var", "bn_mean", "g_weight", "g_bias", "g_bn_weight", "g_bn_bias")]
+
+
+def weight_grad_groups(n_points: int) -> int:
+    return int(load().vfn_weight_grad_groups(C.c_int64(n_points)))
+
+
+def net_weight_grads_scratch_bytes(kind: int, geom, n_points: int) -> int:
+    n = int(load().vfn_net_weight_grads_scratch_bytes(C.c_int32(kind), C.byref(geom), C.c_int64(n_points)))
+    if n < 0:
+        _check(n, "vfn_net_weight_grads_scratch_bytes")
+    return n
+
+
+def net_weight_grads_frag(kind: int, geom, layer_table, saved, slot_index: int, dy, slot_floats: int, dy_form: int, x_form: int, feats,
+                          aux, dz_head, n_points: int, with_features: bool, accumulate: bool, scratch) -> None:
+    """All weight-gradient launches of one net + the un-fold, from C (csrc/vfn_wgrad.hip).  ``layer_table``: a WgradLayer array
+    (parameter and gradient pointers per reference layer); ``saved`` / ``dy``: [slots, slot_floats] workspaces, ``slot_index`` the
+    net's first slot in both."""
+    for t, name in ((saved, "saved"), (dy, "dy")):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == slot_floats):
+            raise VfnError(f"{name}: expected a contiguous CUDA float32 [slots, {slot_floats}] workspace")
+    off = slot_index * slot_floats * 4
+    _check(load().vfn_net_weight_grads_frag(C.c_int32(kind), C.byref(geom), layer_table, C.c_void_p(saved.data_ptr() + off),
+                                            C.c_void_p(dy.data_ptr() + off), C.c_int64(slot_floats * 4), C.c_int32(dy_form), C.c_int32(x_form),
+                                            _ptr(feats, "feats"), _ptr(aux, "aux"), _ptr(dz_head, "dz_head"), C.c_int64(n_points),
+                                            C.c_int32(int(with_features)), C.c_int32(int(accumulate)), _ptr(scratch, "scratch", torch.uint8),
+                                            _stream()), "vfn_net_weight_grads_frag")
 
 
 def mlp_bwd_chain_bf16_ws(vf_geom, vf_packed_bwd16, vf_head_w, rn_geom, rn_packed_bwd16, rn_head_w, feats, masks, dy, dy_flags: int,
