@@ -201,15 +201,18 @@ int vfn_rows_argmax(const float* w, int32_t n_rows, int32_t n_cols, int64_t* out
 
 /* ---------------------------------------------------------------------------------------------
  * The whole gradient-free render() in ONE call: VectorFieldNerf.render (models/nerf/vector_field_nerf.py:216-338) on the f16x3
- * kernels with one vector-field evaluation per distinct sample — the launches of vfn_fill_uniform, vfn_raygen_uniform,
- * vfn_vf_render_fused16_fwd (proposal samples), vfn_ray_density_weights (argmax), vfn_range_fine_sample_indexed,
- * vfn_vf_render_fused16_scatter (new samples), vfn_scatter_rows3 and vfn_ray_density_weights (composite), issued from C on one
- * stream out of one caller-supplied workspace (vfn_render_fwd_workspace_bytes; no allocation, no synchronisation).
+ * kernels with one vector-field evaluation per distinct sample, issued from C on one stream out of one caller-supplied workspace
+ * (vfn_render_fwd_workspace_bytes; no allocation, no synchronisation) as FIVE launches: rays + proposal samples (missing draws
+ * generated in place) | fused VF + rendering net on the proposal samples | proposal weights -> argmax -> range fine sampler |
+ * the fused launch on the new samples, outputs scattered | weights + composite (which also moves the proposal samples' normals
+ * and colours to their sorted positions).  The per-ray launches run the kernels of vfn_raygen_uniform, vfn_fill_uniform,
+ * vfn_ray_density_weights, vfn_range_fine_sample_indexed and vfn_scatter_rows3, so every value equals what those entry points
+ * produce called one by one.
  * Random draws: u_coarse[N,S_c] / u_fine[N,N_f] (read only when the matching perturb flag is set) and u_add[N,N_f] (always
  * consumed, Q9) may each be NULL, in which case they come from the Philox stream (seed, offset) in that order; the call
  * consumes ceil(generated / 4) counter values.  far_*_per_ray: optional [N] (ray_sampler.py:126-127).
  * Outputs: ray_dirs[N,3] (unit), z_vals[N,S_t], points[N,S_t,3], normals[N*S_t,3], colors[N*S_t,3], weights[N,S_t], rgb[N,3],
- * depth[N]; N*S_t < 2^22.  Values are those of the individual entry points (bit-identical to calling them one by one). */
+ * depth[N]; N*S_t < 2^22. */
 typedef struct vfn_render_params {
     int32_t n_rays, n_coarse, n_fine;   /* N, S_c, N_f = min(fine_sampler.N_samples, max_samples) */
     int32_t pose_is_quat;
@@ -220,7 +223,7 @@ typedef struct vfn_render_params {
     vfn_density_params density;         /* n_rays / n_samples are filled in per pass */
     uint64_t seed, offset;              /* Philox stream for the draws not supplied */
     int32_t colour_products;            /* 0 or 3: three products everywhere; 2: the colour branch on two (vfn_vf_render_fused16_products) */
-    int32_t reserved;
+    int32_t separate_launches;          /* 0: the five merged launches; 1: the same pipeline through the stand-alone entry points (eight) */
 } vfn_render_params;
 int64_t vfn_render_fwd_workspace_bytes(const vfn_render_params* p);
 int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf_geom, const void* vf_packed16,

@@ -328,15 +328,16 @@ def test_one_call_render_equals_the_launch_by_launch_path(name):
 
     def both(**kw):
         outs = []
-        for one_call in (True, False):
-            model.one_call_render = one_call
+        for one_call, separate in ((True, False), (False, False), (True, True)):      # five merged launches | Python | eight from C
+            model.one_call_render, model.render_separate_launches = one_call, separate
             model.rng_seed, model._rng_offset = 17, 5
             with torch.no_grad():
                 outs.append((model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, **kw), model._rng_offset))
-        (a, off_a), (b, off_b) = outs
-        assert off_a == off_b
+        (a, off_a), (b, off_b), (c, off_c) = outs
+        model.render_separate_launches = False
+        assert off_a == off_b == off_c
         for f in fields:
-            assert torch.equal(getattr(a, f), getattr(b, f)), (name, f, kw.keys())
+            assert torch.equal(getattr(a, f), getattr(b, f)) and torch.equal(getattr(a, f), getattr(c, f)), (name, f, kw.keys())
         return a
 
     out = both(uniforms=uni)

@@ -23,3 +23,16 @@ static inline int vfn_check_launch(const char* what) {
     }
     return VFN_OK;
 }
+
+// launches shared between translation units, not part of the ABI (csrc/vfn_rays.hip, used by csrc/vfn_render.hip)
+int vfn_internal_raygen(const vfn_raygen_params* p, const float* uv, const float* pose, const float* intrinsics, const float* t_vals,
+                        const float* far_per_ray, const float* u_coarse, int gen_u, long long u_base, uint64_t seed, uint64_t offset,
+                        float* directions, float* ray_dirs, float* cam_loc, float* z_vals, float* points, void* stream);
+int vfn_internal_density_fine(const vfn_density_params* dp, const float* normals_c, const float* ray_dirs, const float* z_c,
+                              const float* density_scalars, const vfn_fine_params* fp, const float* directions, const float* cam_loc,
+                              const float* far_per_ray, const float* u_fine, const float* u_add, int gen_fine, int gen_add,
+                              long long fine_base, long long add_base, uint64_t seed, uint64_t offset, float* z_vals, float* points,
+                              int32_t* src, float* new_points, int32_t* dst, int64_t new_row0, void* stream);
+int vfn_internal_composite_gather(const vfn_density_params* dp, float* normals, const float* ray_dirs, const float* z_vals,
+                                  const float* density_scalars, float* colors, const int32_t* src, const float* normals_c,
+                                  const float* colors_c, int64_t n_stored_c, float* weights, float* rgb, float* depth, void* stream);

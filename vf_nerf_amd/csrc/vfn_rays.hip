@@ -24,6 +24,30 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+
+// Element e of the uniform stream (seed, offset) as vfn_fill_uniform lays it out: one Philox block per 4 consecutive outputs.
+struct PhiloxStream { unsigned long long seed, offset; };
+__device__ __forceinline__ float philox_uniform(const PhiloxStream& ps, long long e) {
+    const unsigned long long ctr = ps.offset + (unsigned long long)(e >> 2);
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    uint32_t k[2] = {(uint32_t)ps.seed, (uint32_t)(ps.seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+    const int i = (int)(e & 3);
+    const uint32_t v = i == 0 ? c[0] : (i == 1 ? c[1] : (i == 2 ? c[2] : c[3]));
+    return (float)(v >> 8) * (1.0f / 16777216.0f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: rays + coarse z + points
 //   utils/rendering.py:12-60, utils/pinhole_model.py:9-63, models/samplers/ray_sampler.py:49-80,113-142
@@ -43,6 +67,11 @@ struct RaygenArgs {
     float* cam_loc;
     float* z_vals;
     float* points;
+    // vfn_render_fwd: the draws come from the Philox stream instead of `u` (element u_base + ray * S + s of it), the values
+    // vfn_fill_uniform would have written there
+    int gen_u;
+    long long u_base;
+    PhiloxStream ps;
 };
 
 __device__ __forceinline__ float coarse_z(float near, float far, float t) { return near * (1.0f - t) + far * t; }
@@ -104,12 +133,12 @@ __global__ __launch_bounds__(256) void vfn_raygen_kernel(const RaygenArgs a) {
         if (r >= n) break;
         const float near = a.p.near, far = s_ray[lr][6];
         float z = coarse_z(near, far, a.t_vals[s]);
-        if (a.u) {
+        if (a.u || a.gen_u) {
             const float zl = (s > 0) ? coarse_z(near, far, a.t_vals[s - 1]) : z;
             const float zu = (s < S - 1) ? coarse_z(near, far, a.t_vals[s + 1]) : z;
             const float upper = (s < S - 1) ? 0.5f * (zu + z) : z;
             const float lower = (s > 0) ? 0.5f * (z + zl) : z;
-            z = lower + (upper - lower) * a.u[(size_t)r * S + s];
+            z = lower + (upper - lower) * (a.gen_u ? philox_uniform(a.ps, a.u_base + (long long)r * S + s) : a.u[(size_t)r * S + s]);
         }
         const size_t o = (size_t)r * S + s;
         a.z_vals[o] = z;
@@ -137,6 +166,13 @@ struct DensityArgs {
     long long* argmax;
     float* rgb;
     float* depth;
+    // vfn_render_fwd, composite pass: sorted sample j of the ray is stored row src[ray * S + j]; rows below n_stored_c are
+    // proposal samples whose normal / colour still sit in generation order in normals_c / colors_c — they are moved to their
+    // sorted position in `normals` / `colors` (both written here) on the way in (what vfn_scatter_rows3 did in its own launch)
+    const int* src;
+    const float* normals_c;
+    const float* colors_c;
+    int n_stored_c;
 };
 
 __device__ __forceinline__ float laplace_cdf(float x, float beta, float scale, float mean) {
@@ -148,18 +184,23 @@ __device__ __forceinline__ float laplace_cdf(float x, float beta, float scale, f
 
 __device__ __forceinline__ float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 
-__global__ __launch_bounds__(256) void vfn_density_kernel(const DensityArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float dsm[];
+// one ray, one wave; `su` = S * 5 floats of LDS owned by the wave.  Returns the index of the first maximum of the weights.
+__device__ __forceinline__ int density_ray(const DensityArgs& a, float* su, int ray, int lane) {
     const int S = a.p.n_samples;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * RAYS_PER_BLOCK + wv;
-    if (ray >= a.p.n_rays) return;  // whole wave exits together; no block-level barriers below
-    float* su = dsm + (size_t)wv * S * 5;  // unit normals [S][3]
     float* sz = su + (size_t)S * 3;        // z [S]
     float* se = sz + S;                    // free energy / weights [S]
 
     const float* nrm = a.normals + (size_t)ray * S * 3;
     for (int j = lane; j < S; j += WAVE) {
+        if (a.src) {
+            const int row = a.src[(size_t)ray * S + j];
+            if (row < a.n_stored_c) {
+                float* no = const_cast<float*>(nrm) + j * 3;
+                float* co = const_cast<float*>(a.colors) + ((size_t)ray * S + j) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { no[c] = a.normals_c[(size_t)row * 3 + c]; co[c] = a.colors_c[(size_t)row * 3 + c]; }
+            }
+        }
         const float x = nrm[j * 3 + 0], y = nrm[j * 3 + 1], z = nrm[j * 3 + 2];
         const float nn = fmaxf(sqrtf((x * x + y * y) + z * z), 1e-8f);
         su[j * 3 + 0] = x / nn; su[j * 3 + 1] = y / nn; su[j * 3 + 2] = z / nn;
@@ -254,15 +295,14 @@ __global__ __launch_bounds__(256) void vfn_density_kernel(const DensityArgs a) {
             acc[3] += w * sz[j];
         }
     }
-    if (a.argmax) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ob = __shfl_xor(best, o, WAVE);
-            const int oi = __shfl_xor(besti, o, WAVE);
-            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
-        }
-        if (lane == 0) a.argmax[ray] = (besti == 0x7fffffff) ? 0 : besti;
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, WAVE);
+        const int oi = __shfl_xor(besti, o, WAVE);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
     }
+    besti = (besti == 0x7fffffff) ? 0 : besti;
+    if (a.argmax && lane == 0) a.argmax[ray] = besti;
     if (col) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = wave_sum(acc[c]);
@@ -271,6 +311,15 @@ __global__ __launch_bounds__(256) void vfn_density_kernel(const DensityArgs a) {
             a.depth[ray] = acc[3];
         }
     }
+    return besti;
+}
+
+__global__ __launch_bounds__(256) void vfn_density_kernel(const DensityArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (ray >= a.p.n_rays) return;  // whole wave exits together; no block-level barriers below
+    (void)density_ray(a, dsm + (size_t)wv * a.p.n_samples * 5, ray, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -534,18 +583,16 @@ struct FineArgs {
     float* new_points;   // [N,N_f,3] in generation order
     int* dst;            // the inverse: dst[src[i]] = i (sorted position of every stored sample), or NULL
     int new_row0;        // first row of the new samples in the caller's row numbering (N*S_c, or rounded up)
+    // vfn_render_fwd: draws from the Philox stream instead of u_fine / u_add (elements fine_base / add_base + ray * N_f + k)
+    int gen_fine, gen_add;
+    long long fine_base, add_base;
+    PhiloxStream ps;
 };
 
-__global__ __launch_bounds__(256) void vfn_fine_kernel(const FineArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float fsm[];
+// one ray, one wave; `sv` = St * 2 floats of LDS owned by the wave; imax = first maximum of the proposal weights
+__device__ __forceinline__ void fine_ray(const FineArgs& a, float* sv, int ray, int lane, long long imax) {
     const int Sc = a.p.n_coarse, Nf = a.p.n_fine, St = Sc + Nf;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * RAYS_PER_BLOCK + wv;
-    if (ray >= a.p.n_rays) return;
-    float* sv = fsm + (size_t)wv * St * 2;  // unsorted values [St]
     float* so = sv + St;                    // sorted values [St]
-
-    const long long imax = a.argmax[ray];
     const float* zc = a.z_coarse + (size_t)ray * Sc;
     for (int j = lane; j < Sc; j += WAVE) sv[j] = zc[j];
     const float near = a.p.near;
@@ -556,18 +603,19 @@ __global__ __launch_bounds__(256) void vfn_fine_kernel(const FineArgs a) {
         const float step = a.p.window_step;
         for (int k = lane; k < Nf; k += WAVE) {
             float z = base + step * (float)k;
-            if (a.u_fine) {
+            if (a.u_fine || a.gen_fine) {
                 const float zl = base + step * (float)(k - 1);
                 const float zu = base + step * (float)(k + 1);
                 const float upper = (k < Nf - 1) ? 0.5f * (zu + z) : z;
                 const float lower = (k > 0) ? 0.5f * (z + zl) : z;
-                z = lower + (upper - lower) * a.u_fine[(size_t)ray * Nf + k];
+                z = lower + (upper - lower) * (a.gen_fine ? philox_uniform(a.ps, a.fine_base + (long long)ray * Nf + k) : a.u_fine[(size_t)ray * Nf + k]);
             }
             sv[Sc + k] = z;
         }
     } else {
         const float span = a.far_per_ray ? (far - near) : a.p.span;
-        for (int k = lane; k < Nf; k += WAVE) sv[Sc + k] = a.u_add[(size_t)ray * Nf + k] * span + near;
+        for (int k = lane; k < Nf; k += WAVE)
+            sv[Sc + k] = (a.gen_add ? philox_uniform(a.ps, a.add_base + (long long)ray * Nf + k) : a.u_add[(size_t)ray * Nf + k]) * span + near;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -607,20 +655,32 @@ __global__ __launch_bounds__(256) void vfn_fine_kernel(const FineArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void vfn_fine_kernel(const FineArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (ray >= a.p.n_rays) return;
+    fine_ray(a, fsm + (size_t)wv * (a.p.n_coarse + a.p.n_fine) * 2, ray, lane, a.argmax[ray]);
+}
+
+// proposal weights -> argmax -> fine samples of the same ray in ONE launch (vfn_render_fwd): the wave that finds the first
+// maximum of its ray's weights goes on to place the ray's fine samples; same device functions as the two stand-alone kernels
+__global__ __launch_bounds__(256) void vfn_density_fine_kernel(const DensityArgs d, const FineArgs f) {
+    extern __shared__ __attribute__((aligned(16))) float dfm[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (ray >= d.p.n_rays) return;
+    const int per_wave = max(d.p.n_samples * 5, (f.p.n_coarse + f.p.n_fine) * 2);
+    float* lds = dfm + (size_t)wv * per_wave;
+    const int imax = density_ray(d, lds, ray, lane);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    fine_ray(f, lds, ray, lane, (long long)imax);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 uniforms in [0,1)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
-    const uint32_t n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
-}
-
 __global__ void vfn_uniform_kernel(float* out, long long n, unsigned long long seed, unsigned long long offset) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one Philox block per 4 outputs
     const long long base = g * 4;
@@ -837,6 +897,52 @@ extern "C" int vfn_range_fine_sample_indexed(const vfn_fine_params* p, const flo
     const size_t shmem = (size_t)RAYS_PER_BLOCK * (p->n_coarse + p->n_fine) * 2 * sizeof(float);
     hipLaunchKernelGGL(vfn_fine_kernel, dim3(blocks), dim3(256), shmem, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_range_fine_sample");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Launches used by vfn_render_fwd only (csrc/vfn_render.hip; declared in vfn_common.h): the same kernels with the Philox draws
+// generated in place, the proposal argmax and the fine sampler in one launch, and the proposal results moved to their sorted
+// positions by the composite launch.  Values are those of the stand-alone entry points, bit for bit.
+// ------------------------------------------------------------------------------------------------
+int vfn_internal_raygen(const vfn_raygen_params* p, const float* uv, const float* pose, const float* intrinsics, const float* t_vals,
+                        const float* far_per_ray, const float* u_coarse, int gen_u, long long u_base, uint64_t seed, uint64_t offset,
+                        float* directions, float* ray_dirs, float* cam_loc, float* z_vals, float* points, void* stream) {
+    RaygenArgs a{*p, uv, pose, intrinsics, t_vals, far_per_ray, u_coarse, directions, ray_dirs, cam_loc, z_vals, points};
+    a.gen_u = gen_u; a.u_base = u_base; a.ps = PhiloxStream{seed, offset};
+    const unsigned blocks = (unsigned)((p->n_rays + K1_RAYS - 1) / K1_RAYS);
+    hipLaunchKernelGGL(vfn_raygen_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return vfn_check_launch("vfn_render_fwd (rays)");
+}
+
+int vfn_internal_density_fine(const vfn_density_params* dp, const float* normals_c, const float* ray_dirs, const float* z_c,
+                              const float* density_scalars, const vfn_fine_params* fp, const float* directions, const float* cam_loc,
+                              const float* far_per_ray, const float* u_fine, const float* u_add, int gen_fine, int gen_add,
+                              long long fine_base, long long add_base, uint64_t seed, uint64_t offset, float* z_vals, float* points,
+                              int32_t* src, float* new_points, int32_t* dst, int64_t new_row0, void* stream) {
+    VFN_REQUIRE(dp->n_samples >= 2 && dp->n_samples <= MAX_SAMPLES && fp->n_coarse + fp->n_fine <= MAX_SAMPLES && fp->n_fine >= 2 &&
+                dp->n_window >= 1, "vfn_render_fwd: sample counts outside what the per-ray kernels support (n_coarse=%d, n_fine=%d)",
+                fp->n_coarse, fp->n_fine);
+    VFN_REQUIRE((long long)fp->n_rays * (fp->n_coarse + fp->n_fine) < (1ll << 31), "vfn_render_fwd: more than 2^31 samples");
+    DensityArgs d{*dp, normals_c, ray_dirs, z_c, density_scalars, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    FineArgs f{*fp, z_c, nullptr, directions, cam_loc, far_per_ray, u_fine, u_add, z_vals, points, src, new_points, dst, (int)new_row0};
+    f.gen_fine = gen_fine; f.gen_add = gen_add; f.fine_base = fine_base; f.add_base = add_base; f.ps = PhiloxStream{seed, offset};
+    const unsigned blocks = (unsigned)((dp->n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
+    const int per_wave = dp->n_samples * 5 > (fp->n_coarse + fp->n_fine) * 2 ? dp->n_samples * 5 : (fp->n_coarse + fp->n_fine) * 2;
+    hipLaunchKernelGGL(vfn_density_fine_kernel, dim3(blocks), dim3(256), (size_t)RAYS_PER_BLOCK * per_wave * sizeof(float),
+                       (hipStream_t)stream, d, f);
+    return vfn_check_launch("vfn_render_fwd (proposal weights + fine sampler)");
+}
+
+int vfn_internal_composite_gather(const vfn_density_params* dp, float* normals, const float* ray_dirs, const float* z_vals,
+                                  const float* density_scalars, float* colors, const int32_t* src, const float* normals_c,
+                                  const float* colors_c, int64_t n_stored_c, float* weights, float* rgb, float* depth, void* stream) {
+    VFN_REQUIRE(dp->n_samples >= 2 && dp->n_samples <= MAX_SAMPLES, "vfn_render_fwd: n_samples=%d outside [2,%d]", dp->n_samples, MAX_SAMPLES);
+    DensityArgs a{*dp, normals, ray_dirs, z_vals, density_scalars, colors, nullptr, weights, nullptr, rgb, depth};
+    a.src = src; a.normals_c = normals_c; a.colors_c = colors_c; a.n_stored_c = (int)n_stored_c;
+    const unsigned blocks = (unsigned)((dp->n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
+    hipLaunchKernelGGL(vfn_density_kernel, dim3(blocks), dim3(256), (size_t)RAYS_PER_BLOCK * dp->n_samples * 5 * sizeof(float),
+                       (hipStream_t)stream, a);
+    return vfn_check_launch("vfn_render_fwd (composite)");
 }
 
 extern "C" int vfn_scatter_rows3(const float* a, const float* b, const int32_t* index, int64_t n_rows, float* out_a, float* out_b,

@@ -4,16 +4,17 @@
 // intermediate: ~0.5 ms of host time per call, which is what a 1 024-ray chunk takes on the device — the evaluator's chunk loop
 // (evaluation/methods.py:520-545) was host-bound.  vfn_render_fwd is the same launch sequence issued from C on one stream out of
 // one caller-supplied workspace (SURVEY.md section 8b lists this entry point):
-//   draws not supplied by the caller (one Philox launch)                        ray_sampler.py:138,287,292
-//   rays + proposal samples                                                      utils/rendering.py:12-60, ray_sampler.py:49-80,113-142
+//   rays + proposal samples (draws not supplied by the caller: Philox, in place)  utils/rendering.py:12-60, ray_sampler.py:49-80,113-142
 //   fused VF + rendering net on the S_c proposal samples, in generation order    vector_field_nerf.py:252-256 (+ :315 for these samples)
-//   density -> weights -> argmax on the proposal pass                            :263-272, ray_sampler.py:277
-//   range fine sampler with provenance (where every stored sample lands)         ray_sampler.py:264-302
+//   density -> weights -> argmax on the proposal pass, then, in the same launch,  :263-272, ray_sampler.py:277
+//   the range fine sampler with provenance (where every stored sample lands)     ray_sampler.py:264-302
 //   fused VF + rendering net on the N_f NEW samples, outputs scattered           vector_field_nerf.py:294-297,315-318
-//   the proposal samples' normals / colours moved to their sorted positions
-//   density -> weights -> composite                                              :308-323
-// i.e. the f16x3 pipeline with one VF evaluation per distinct sample; nothing here computes: it only
-// sequences entry points of this library, so every value is what those entry points produce.
+//   density -> weights -> composite; on its way in the launch moves the proposal  :308-323
+//   samples' normals / colours to their sorted positions
+// i.e. the f16x3 pipeline with one VF evaluation per distinct sample in FIVE launches; the per-ray ones are
+// the kernels of the stand-alone entry points (vfn_raygen_uniform, vfn_ray_density_weights, vfn_range_fine_sample_indexed,
+// vfn_scatter_rows3, vfn_fill_uniform) compiled into three launches, so every value is what those entry points produce, bit for
+// bit (tests/test_hip_f16x3.py::test_one_call_render_equals_the_launch_by_launch_path).
 #include <string.h>
 #include "vfn_common.h"
 
@@ -30,9 +31,9 @@ struct Carve {
 };
 
 struct Ws {
-    float *u, *directions, *cam_loc, *z_c, *pts_c, *normals_c, *colors_c, *new_pts;
+    float *directions, *cam_loc, *z_c, *pts_c, *normals_c, *colors_c, *new_pts, *u;
+    int32_t *dst, *src;
     int64_t* imax;
-    int32_t* dst;
     size_t bytes;
 };
 
@@ -40,7 +41,6 @@ Ws carve(void* workspace, const vfn_render_params* p) {
     const size_t n = (size_t)p->n_rays, sc = (size_t)p->n_coarse, nf = (size_t)p->n_fine;
     Carve c{static_cast<unsigned char*>(workspace), 0};
     Ws w;
-    w.u = c.take<float>(n * (sc + 2 * nf) + 4);
     w.directions = c.take<float>(n * 3);
     w.cam_loc = c.take<float>(n * 3);
     w.z_c = c.take<float>(n * sc);
@@ -48,8 +48,10 @@ Ws carve(void* workspace, const vfn_render_params* p) {
     w.normals_c = c.take<float>(n * sc * 3);
     w.colors_c = c.take<float>(n * sc * 3);
     w.new_pts = c.take<float>(n * nf * 3);
-    w.imax = c.take<int64_t>(n);
     w.dst = c.take<int32_t>(n * (sc + nf));
+    w.src = c.take<int32_t>(n * (sc + nf));
+    w.u = c.take<float>(p->separate_launches ? n * (sc + 2 * nf) + 4 : 0);      // eight-launch plan only
+    w.imax = c.take<int64_t>(p->separate_launches ? n : 0);
     w.bytes = c.off;
     return w;
 }
@@ -79,42 +81,60 @@ extern "C" int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf
     VFN_REQUIRE(p->colour_products == 0 || p->colour_products == 2 || p->colour_products == 3, "vfn_render_fwd: colour_products must be 0, 2 or 3");
     const Ws w = carve(workspace, p);
     int rc;
-
-    // the draws the caller did not supply: one Philox launch over contiguous segments (the facade's order: coarse, fine, add)
-    const float* uc = p->perturb_coarse ? u_coarse : nullptr;
-    const float* uf = p->perturb_fine ? u_fine : nullptr;
-    const float* ua = u_add;
-    {
-        size_t need = 0;
-        float* cur = w.u;
-        if (p->perturb_coarse && !uc) { uc = cur; cur += (size_t)n * sc; need += (size_t)n * sc; }
-        if (p->perturb_fine && !uf) { uf = cur; cur += (size_t)n * nf; need += (size_t)n * nf; }
-        if (!ua) { ua = cur; need += (size_t)n * nf; }
-        if (need) {
-            rc = vfn_fill_uniform(w.u, (int64_t)need, p->seed, p->offset, stream);
-            if (rc != VFN_OK) return rc;
-        }
-    }
+    // the draws the caller did not supply are elements of ONE Philox stream (seed, offset), laid out as vfn_fill_uniform would
+    // fill one buffer with the segments coarse, fine, add (the facade's order); the kernels generate the elements they consume
+    const int gen_c = p->perturb_coarse && !u_coarse, gen_f = p->perturb_fine && !u_fine, gen_a = !u_add;
+    const long long base_f = gen_c ? (long long)n * sc : 0, base_a = base_f + (gen_f ? (long long)n * nf : 0);
     vfn_raygen_params rp = {n, sc, p->pose_is_quat, p->near_coarse, p->far_coarse};
-    rc = vfn_raygen_uniform(&rp, uv, pose, intrinsics, t_vals, far_coarse_per_ray, uc, w.directions, ray_dirs, w.cam_loc, w.z_c, w.pts_c, stream);
-    if (rc != VFN_OK) return rc;
     const int products = p->colour_products == 2 ? 2 : 3;
+    if (p->separate_launches) {
+        // the same pipeline through the stand-alone entry points, eight launches (A/B timing of the merged plan; same values)
+        const float* uc = p->perturb_coarse ? u_coarse : nullptr;
+        const float* uf = p->perturb_fine ? u_fine : nullptr;
+        const float* ua = u_add;
+        if (gen_c) uc = w.u;
+        if (gen_f) uf = w.u + base_f;
+        if (gen_a) ua = w.u + base_a;
+        const long long need = base_a + (gen_a ? (long long)n * nf : 0);
+        if (need) { rc = vfn_fill_uniform(w.u, need, p->seed, p->offset, stream); if (rc != VFN_OK) return rc; }
+        rc = vfn_raygen_uniform(&rp, uv, pose, intrinsics, t_vals, far_coarse_per_ray, uc, w.directions, ray_dirs, w.cam_loc, w.z_c, w.pts_c, stream);
+        if (rc != VFN_OK) return rc;
+        rc = vfn_vf_render_fused16_products(vf_geom, vf_packed16, rn_geom, rn_packed16, w.pts_c, ray_dirs, (int64_t)n * sc, sc, nullptr, products,
+                                            w.normals_c, w.colors_c, stream);
+        if (rc != VFN_OK) return rc;
+        vfn_density_params dq = p->density;
+        dq.n_rays = n; dq.n_samples = sc;
+        rc = vfn_ray_density_weights(&dq, w.normals_c, ray_dirs, w.z_c, density_scalars, nullptr, nullptr, nullptr, w.imax, nullptr, nullptr, stream);
+        if (rc != VFN_OK) return rc;
+        vfn_fine_params fq = {n, sc, nf, p->near_fine, p->far_fine, p->fine_range, p->window_step, p->span};
+        rc = vfn_range_fine_sample_indexed(&fq, w.z_c, w.imax, w.directions, w.cam_loc, far_fine_per_ray, uf, ua, z_vals, points, nullptr, w.new_pts,
+                                           w.dst, (int64_t)n * sc, stream);
+        if (rc != VFN_OK) return rc;
+        rc = vfn_vf_render_fused16_products(vf_geom, vf_packed16, rn_geom, rn_packed16, w.new_pts, ray_dirs, (int64_t)n * nf, nf,
+                                            w.dst + (size_t)n * sc, products, normals, colors, stream);
+        if (rc != VFN_OK) return rc;
+        rc = vfn_scatter_rows3(w.normals_c, w.colors_c, w.dst, (int64_t)n * sc, normals, colors, stream);
+        if (rc != VFN_OK) return rc;
+        dq.n_samples = st;
+        return vfn_ray_density_weights(&dq, normals, ray_dirs, z_vals, density_scalars, colors, nullptr, weights, nullptr, rgb, depth, stream);
+    }
+    rc = vfn_internal_raygen(&rp, uv, pose, intrinsics, t_vals, far_coarse_per_ray, p->perturb_coarse ? u_coarse : nullptr, gen_c, 0, p->seed,
+                             p->offset, w.directions, ray_dirs, w.cam_loc, w.z_c, w.pts_c, stream);
+    if (rc != VFN_OK) return rc;
     rc = vfn_vf_render_fused16_products(vf_geom, vf_packed16, rn_geom, rn_packed16, w.pts_c, ray_dirs, (int64_t)n * sc, sc, nullptr, products,
                                         w.normals_c, w.colors_c, stream);
     if (rc != VFN_OK) return rc;
     vfn_density_params dp = p->density;
     dp.n_rays = n; dp.n_samples = sc;
-    rc = vfn_ray_density_weights(&dp, w.normals_c, ray_dirs, w.z_c, density_scalars, nullptr, nullptr, nullptr, w.imax, nullptr, nullptr, stream);
-    if (rc != VFN_OK) return rc;
     vfn_fine_params fp = {n, sc, nf, p->near_fine, p->far_fine, p->fine_range, p->window_step, p->span};
-    rc = vfn_range_fine_sample_indexed(&fp, w.z_c, w.imax, w.directions, w.cam_loc, far_fine_per_ray, uf, ua, z_vals, points, nullptr, w.new_pts,
-                                       w.dst, (int64_t)n * sc, stream);
+    rc = vfn_internal_density_fine(&dp, w.normals_c, ray_dirs, w.z_c, density_scalars, &fp, w.directions, w.cam_loc, far_fine_per_ray,
+                                   p->perturb_fine ? u_fine : nullptr, u_add, gen_f, gen_a, base_f, base_a, p->seed, p->offset, z_vals, points,
+                                   w.src, w.new_pts, w.dst, (int64_t)n * sc, stream);
     if (rc != VFN_OK) return rc;
     rc = vfn_vf_render_fused16_products(vf_geom, vf_packed16, rn_geom, rn_packed16, w.new_pts, ray_dirs, (int64_t)n * nf, nf, w.dst + (size_t)n * sc,
                                         products, normals, colors, stream);
     if (rc != VFN_OK) return rc;
-    rc = vfn_scatter_rows3(w.normals_c, w.colors_c, w.dst, (int64_t)n * sc, normals, colors, stream);
-    if (rc != VFN_OK) return rc;
     dp.n_samples = st;
-    return vfn_ray_density_weights(&dp, normals, ray_dirs, z_vals, density_scalars, colors, nullptr, weights, nullptr, rgb, depth, stream);
+    return vfn_internal_composite_gather(&dp, normals, ray_dirs, z_vals, density_scalars, colors, w.src, w.normals_c, w.colors_c, (int64_t)n * sc,
+                                         weights, rgb, depth, stream);
 }

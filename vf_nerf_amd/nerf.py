@@ -404,6 +404,7 @@ class VectorFieldNerf:
         rp.span = (far_f - float(self.fine_sampler.near)) if far_ft is None else 0.0
         rp.density = self._density_params()
         rp.colour_products = int(self.colour_products)
+        rp.separate_launches = int(getattr(self, "render_separate_launches", False))      # A/B switch (tools/ab_render_plan.py)
 
         def given(name, needed):
             return uniforms[name].to(dev).float().contiguous() if (needed and name in uniforms) else None
@@ -413,7 +414,7 @@ class VectorFieldNerf:
             (n * n_f if u_a is None else 0)
         rp.seed, rp.offset = self.rng_seed & (2 ** 64 - 1), self._rng_offset & (2 ** 64 - 1)
         self._rng_offset += (generated + 3) // 4
-        key = (n, s_c, n_f, str(dev), torch.cuda.current_stream(dev).cuda_stream)
+        key = (n, s_c, n_f, str(dev), torch.cuda.current_stream(dev).cuda_stream, rp.separate_launches)
         ws = self._render_ws.get(key)
         if ws is None:
             if len(self._render_ws) > 8:
