@@ -74,6 +74,11 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #ifndef VFN16_EPI_PER_MFMA2
 #define VFN16_EPI_PER_MFMA2 9    // the same for the two-product tiles of the colour branch (two MFMAs per K step)
 #endif
+#ifndef VFN16_LATE_STORES
+#define VFN16_LATE_STORES 1      // training modes: the stores of a finished tile are the LAST vector-memory instructions of a chunk (after
+                                 // its DMA pieces), so the next ring hand-over waits with vmcnt(4) — operations retire in issue order,
+                                 // the four youngest are those stores — instead of draining them
+#endif
 #ifndef VFN16_MASK_STEP
 #define VFN16_MASK_STEP(H, NKB) (H)     // K step of a tile that carries the sign-bit collection of the pending tile (training)
 #endif
@@ -591,7 +596,12 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
     constexpr int DSTEPS = DSPAN < VFN16_DMA_STEPS ? DSPAN : VFN16_DMA_STEPS;          // steps that carry DMA pieces
     static_assert(PEPI < 0 || PKB >= E, "the pending tile must be complete before it is read");
     constexpr bool TRAIN = (MODE & M16_TRAIN) != 0;
-    constexpr int SSTEPS = DSPAN < 4 ? DSPAN : 4;      // training: steps after the hand-over that carry the 4 stores of a tile
+    constexpr bool LATE = TRAIN && VFN16_LATE_STORES;
+    // late stores: DMA pieces in steps [H, DEND), the (mask store and the) four stores of the pending tile in steps [DEND, NKB)
+    constexpr int DEND = LATE ? (NKB - 4 > H + 1 ? NKB - 4 : (H + 1 < NKB ? H + 1 : NKB - 1)) : 0;
+    constexpr int SBEG = LATE ? DEND : H;
+    constexpr int SSTEPS = LATE ? (NKB - DEND > 0 ? NKB - DEND : 1) : (DSPAN < 4 ? DSPAN : 4);      // steps that carry the 4 stores of a tile
+    constexpr int DST = LATE ? (DEND - H > 0 ? DEND - H : 1) : DSTEPS;                             // steps that carry DMA pieces
     static_for<NCH>([&](auto ich) {
         constexpr int ch = decltype(ich)::value;
         constexpr int C = C0 + ch;
@@ -669,15 +679,19 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
                 if ((MODE & M16_TRAIN) != 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else
 #endif
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // late stores: the previous chunk ended with the four stores of its pending tile (every chunk but the launch's
+                // first and the one after a layer that starts without a pending tile); everything older — the DMA pieces of
+                // chunk c+1 among it — has landed once at most those four are outstanding
+                if (LATE && C > 0 && (ch == 0 || ch > 1 || PEPI >= 0)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
 #endif
             }
             // -- second half: this step's share of the DMA pieces of chunk c+2
 #ifndef ABL_NODMA
-            if (st >= H && st < H + DSTEPS && ddma.kb > 0) {
+            if (st >= H && st < H + DST && ddma.kb > 0) {
 #pragma unroll
-                for (int i = (st - H) * PM / DSTEPS; i < (st - H + 1) * PM / DSTEPS; ++i) {
+                for (int i = (st - H) * PM / DST; i < (st - H + 1) * PM / DST; ++i) {
                     if (VFN16_WAVES * i + VFN16_WAVES <= DPIECES) dma_piece<ddma.net, ddma.off_kb, (C + 2) % 3>(p, piece_blk(wave + VFN16_WAVES * i), lane);
                     else if (VFN16_WAVES * i < DPIECES) { if (wave + VFN16_WAVES * i < DPIECES) dma_piece<ddma.net, ddma.off_kb, (C + 2) % 3>(p, piece_blk(wave + VFN16_WAVES * i), lane); }
                 }
@@ -685,18 +699,18 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
 #endif
             // -- training: the finished (activated) pending tile goes out after the hand-over, so that the stores have
             // half a chunk to retire before the next vmcnt(0)
-            if (TRAIN && st >= H && st < H + SSTEPS && (ch > 0 || PEPI >= 0)) {
-#pragma unroll
-                for (int q = (st - H) * 4 / SSTEPS; q < (st - H + 1) * 4 / SSTEPS; ++q) {
-                    if (ch > 0) save_group<(SLOT >= 0 ? SLOT : 0), (ch > 0 ? ch - 1 : 0)>(p, cy.pend, q);
-                    else save_group<(PSLOT >= 0 ? PSLOT : 0), PKB / 2>(p, cy.pend, q);
-                }
+            if (TRAIN && st >= SBEG && st < SBEG + SSTEPS && (ch > 0 || PEPI >= 0)) {
 #ifndef ABL_NOMASK
-                if (st == VFN16_MASK_STEP(H, NKB)) {       // its sign bits; the pending tile (ch == 0) is the last one of the previous layer
+                if (st == (LATE ? SBEG : VFN16_MASK_STEP(H, NKB))) {       // its sign bits; the pending tile (ch == 0) is the last one of the previous layer
                     if (ch > 0) collect_mask<(ch > 0 ? ch - 1 : 0), EPI>(cy);
                     else { collect_mask<PKB / 2, (PEPI >= 0 ? PEPI : 0)>(cy); store_mask<(PSLOT >= 0 ? PSLOT : 0)>(p, cy); }
                 }
 #endif
+#pragma unroll
+                for (int q = (st - SBEG) * 4 / SSTEPS; q < (st - SBEG + 1) * 4 / SSTEPS; ++q) {
+                    if (ch > 0) save_group<(SLOT >= 0 ? SLOT : 0), (ch > 0 ? ch - 1 : 0)>(p, cy.pend, q);
+                    else save_group<(PSLOT >= 0 ? PSLOT : 0), PKB / 2>(p, cy.pend, q);
+                }
             }
             // -- split launches: a finished feature tile leaves as operand blocks, after the hand-over like the stores above
             if (st == H && ((BLK && ch > 0) || (PBLK && ch == 0))) {
