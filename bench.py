@@ -252,7 +252,7 @@ def train_step_accounting(n_rays, s_c, s_t, n_sup, storage, gradients="fp32"):
     relu_slot = 512 if storage == "f16" else 1024
     saved = m_f * (12 * relu_slot + 1024) + m_s * (8 * relu_slot + 1024)      # written by the forward ...
     masks = 32 * (13 * m_f + 9 * m_s)
-    dy = (512 if gradients == "bf16" else 1024) * (13 * m_f + 9 * m_s)
+    dy = (512 if gradients in ("bf16", "f16") else 1024) * (13 * m_f + 9 * m_s)
     small = (12 + 12 + 12 + 4 + 12 + 12) * m_f + 2 * 160 * (m_f + m_s)        # points, normals, colours, z + grads, aux tiles
     total = 2 * saved + 2 * masks + 2 * dy + small                             # ... and read back once; dY written + read
     return flops, total
@@ -355,7 +355,7 @@ def main() -> None:
     ap.add_argument("--activations", choices=("fp32", "f16"), default="f16",
                     help="training: storage of the hidden activations for the weight-gradient kernels (f16 = the default, "
                          "11-bit operands in one factor of dW, half the workspace traffic; fp32 = fp32-equivalent gradients)")
-    ap.add_argument("--gradients", choices=("fp32", "bf16"), default=None,
+    ap.add_argument("--gradients", choices=("fp32", "f16", "bf16"), default=None,
                     help="training: storage of the pre-activation gradients between the dX chain and the weight-gradient kernels "
                          "(default: the model's)")
     ap.add_argument("--layout", choices=("fragment", "rows"), default=None,

@@ -27,7 +27,7 @@ def _hip_gradients(fx, d, model):
     return float(loss), out
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "fp32", "f16x3+f16act", "f16x3+f16act+bf16dy", "f16x3+rows", "f16x3+f16act+rows"])
+@pytest.mark.parametrize("precision", ["f16x3", "fp32", "f16x3+f16act", "f16x3+f16act+bf16dy", "f16x3+f16act+f16dy", "f16x3+f16dy", "f16x3+rows", "f16x3+f16act+rows"])
 @pytest.mark.parametrize("name", FIXTURE_NAMES)
 def test_render_gradients(name, precision):
     """``precision`` selects the arithmetic of the activation-saving forward (split-half f16 products or exact fp32
@@ -41,7 +41,7 @@ def test_render_gradients(name, precision):
     f16act = "f16act" in opts
     model.precision = opts[0]
     model.activation_storage = "f16" if f16act else "fp32"
-    model.gradient_storage = "bf16" if "bf16dy" in opts else "fp32"
+    model.gradient_storage = "bf16" if "bf16dy" in opts else ("f16" if "f16dy" in opts else "fp32")
     model.workspace_layout = "rows" if "rows" in opts else "fragment"
     loss, out = _hip_gradients(fx, d, model)
     assert (out.z_vals.cpu() == d["z_vals"]).all(), "sampling must replay exactly for the comparison to be meaningful"
@@ -411,8 +411,7 @@ def test_fragment_ordered_workspace_holds_the_row_major_values():
                 continue
             zr, zv = torch.empty(m, 4, device=dev), torch.empty(m, 4, device=dev)
             dys = []
-            for ws, flags in ((rows_ws, 0), (frag_ws, lib.DY_FRAG), (frag_ws, lib.DY_FRAG | lib.DY_BF16)):
-                ws.dy16 = bool(flags & lib.DY_BF16)
+            for ws, flags in ((rows_ws, 0), (frag_ws, lib.DY_FRAG), (frag_ws, lib.DY_FRAG | lib.DY_BF16), (frag_ws, lib.DY_FRAG | lib.DY_F16S)):
                 dy = ws.new_dy()
                 dy.fill_(float("nan"))
                 lib.mlp_bwd_chain_bf16_ws(vf.geometry(), _packed_bwd16(vf), _head_rows(vf), rn.geometry(), _packed_bwd16(rn), _head_rows(rn),
@@ -423,6 +422,19 @@ def test_fragment_ordered_workspace_holds_the_row_major_values():
                 assert torch.equal(lib.frag_to_rows(dys[1][slot], m)[:, :w], want), (m, slot)
                 got16 = lib.frag_to_rows(dys[2][slot], m, torch.bfloat16)[:, :w]
                 assert torch.equal(got16, want.to(torch.bfloat16).float()), (m, slot, "bf16")
+                # scaled f16 (dY form 3): exactly what the host-side encoder makes of the fp32 gradients, exponent bytes included
+                # (padding lanes of the last group carry 255; the values of those lanes are never read)
+                full = lib.frag_to_rows(dys[1][slot], m)            # all columns as the fragment-ordered fp32 run holds them
+                tiles = (w + 31) // 32                              # (slot 3 has seven tiles: the eighth is never written; its exponent
+                full[:, 32 * tiles:] = 0                            # bytes must say "all zero")
+                enc = lib.rows_to_frag_f16s(full).view(-1, lib.GROUP_FLOATS)
+                got = dys[3][slot].view(-1, lib.GROUP_FLOATS)
+                assert torch.equal(lib.frag_f16s_to_rows(got, m)[:, :32 * tiles], lib.frag_f16s_to_rows(enc, m)[:, :32 * tiles]), (m, slot, "f16s values")
+                eb_got = got.view(torch.uint8)[:, lib.F16S_EXP_OFF:lib.F16S_EXP_OFF + 512].reshape(-1, 8, 2, 32)
+                eb_enc = enc.view(torch.uint8)[:, lib.F16S_EXP_OFF:lib.F16S_EXP_OFF + 512].reshape(-1, 8, 2, 32)
+                assert torch.equal(eb_got, eb_enc), (m, slot, "f16s exponents")
+                rel = float((lib.frag_f16s_to_rows(got, m)[:, :w] - want).abs().max() / want.abs().max().clamp_min(1e-30))
+                assert rel < 2 ** -11, (m, slot, rel)
 
 
 @pytest.mark.parametrize("m,groups", [(32 * 40, 5), (1000, 7), (33, 1), (5000, 64)])
@@ -451,7 +463,13 @@ def test_weight_grad_frag_matches_float64(m, groups):
     for exact in (True, False):
         dy, x, aux, dz = operands(exact)
         dz[:, 3] = 0
-        forms_dy = {lib.DYF_FRAG32: (lib.rows_to_frag(dy), dy), lib.DYF_FRAGBF16: (lib.rows_to_frag(dy, torch.bfloat16), dy.to(torch.bfloat16).float())}
+        f16s = lib.rows_to_frag_f16s(dy)                # tile-scaled f16 (what the chain writes with gradient_storage = "f16")
+        forms_dy = {lib.DYF_FRAG32: (lib.rows_to_frag(dy), dy), lib.DYF_FRAGBF16: (lib.rows_to_frag(dy, torch.bfloat16), dy.to(torch.bfloat16).float()),
+                    lib.DYF_FRAGF16S: (f16s, lib.frag_f16s_to_rows(f16s, m))}
+        if exact:
+            assert torch.equal(forms_dy[lib.DYF_FRAGF16S][1], dy)
+        else:
+            assert float((forms_dy[lib.DYF_FRAGF16S][1] - dy).abs().max() / dy.abs().max()) < 2 ** -11
         forms_x = {lib.XF_FRAG32: (lib.rows_to_frag(x), x), lib.XF_FRAG16: (lib.rows_to_frag(x, torch.float16), x.half().float()),
                    lib.XF_ROWS32: (x.contiguous(), x)}
         tol = 0.0 if exact else 3e-4
@@ -482,7 +500,7 @@ def test_weight_grad_frag_matches_float64(m, groups):
             assert float(part.sum(0)[4:].abs().max()) == 0.0 and float(dbp.sum(0)[4:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("storage", ["f16", "fp32", "f16+bf16dy"])
+@pytest.mark.parametrize("storage", ["f16", "fp32", "f16+bf16dy", "f16+f16dy", "fp32+f16dy"])
 def test_one_call_weight_gradients_equal_the_launch_by_launch_path(storage):
     """vfn_net_weight_grads_frag (csrc/vfn_wgrad.hip: every weight-gradient launch of a net and the un-fold issued from C out of
     one scratch buffer, results added into the parameters' .grad) against the facade's launch-by-launch sequence: the same
@@ -498,7 +516,7 @@ def test_one_call_weight_gradients_equal_the_launch_by_launch_path(storage):
     for one_call in (True, False):
         model = build_model(fx, d, device="cuda:0")
         model.activation_storage = opts[0]
-        model.gradient_storage = "bf16" if "bf16dy" in opts else "fp32"
+        model.gradient_storage = "bf16" if "bf16dy" in opts else ("f16" if "f16dy" in opts else "fp32")
         for net in (model.vector_field_network, model.rendering_network):
             net.one_call_weight_grads = one_call
         calls = []

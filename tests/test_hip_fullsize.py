@@ -182,7 +182,7 @@ def _train_step(m, uv, pose, K, rgb_gt, depth_gt, centroid, n_sup, bucket=None):
     return loss, norm
 
 
-@pytest.mark.parametrize("storage", ["f16", "fp32", "f16+bf16dy", "f16+rows"])
+@pytest.mark.parametrize("storage", ["f16", "fp32", "f16+bf16dy", "f16+f16dy", "f16+rows"])
 def test_training_step_at_full_size(storage):
     """BASELINE.json configs[2] at its full size — one optimizer step on a 4096-ray batch x 128 samples with 2 x 52 428
     supervision points.  ``storage``: how the 16-bit path keeps its workspace (activations f16 | fp32, gradients bf16, row-major
@@ -225,7 +225,7 @@ def test_training_step_at_full_size(storage):
         m = _model()
         m.precision = "fp32" if tag == "fp32" else "f16x3"
         m.activation_storage = "f16" if opts[0] == "f16" else "fp32"
-        m.gradient_storage = "bf16" if "bf16dy" in opts else "fp32"
+        m.gradient_storage = "bf16" if "bf16dy" in opts else ("f16" if "f16dy" in opts else "fp32")
         m.workspace_layout = "rows" if "rows" in opts else "fragment"
         m.backward_kernels = m.vector_field_network.backward_kernels = "fp32" if tag == "f16x3-forward+fp32-backward" else "auto"
         normals, colors, rgb, depth, weights = vauto.fine_pass(m, pts, z, ray_dirs)       # the differentiable part of render()

@@ -42,20 +42,27 @@ def _oracle_run(fx, d):
     return recs, grads
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3+fp32grads", "f16x3"])
 def test_trainer_steps_replay_on_hip(precision):
     """Three steps of the reference's train_epoch (train/vector_field_nerf_train.py:169-260) replayed on the HIP path through
     the interface the trainer uses — render(pose, pixels, intrinsics, epoch, white), functions.sample_border_points /
     get_center_indices_and_gt / sample_center_points, vector_field_network(points)[:, :3], VFLoss, optimizer.zero_grad,
     backward, clip_grad_norm_(model.parameters(), clip), optimizer.step, scheduler.step — with the reference's own draws.
     Steps 0 and 1: the six loss terms and the total within 1e-4, the clip norm within 1e-3, sampled depths bit-identical, the
-    parameters after the step within 2 % of one Adam update where the gradient is significant.  Step 2 onward is reported
+    parameters after the step within 2 % of one Adam update where the gradient is significant — with the exact-fp32 kernels and
+    with the f16x3 kernels keeping fp32 gradients between the chain and the weight-gradient kernels.  The DEFAULT storage (scaled
+    f16 gradients, every parameter gradient within 1e-3 of the fp32 kernels') is held to the same bounds at step 0 and to 1e-3 on
+    the loss terms at step 1 (3.4e-4 measured): Adam's first update is +-lr by the SIGN of each gradient, so the 5e-4 of rounding
+    in the gradients decides more signs than the 7e-5 of the fp32 storage do.  Step 2 onward is reported
     and bounded loosely: Adam's early updates are +-lr per weight, i.e. sign decisions on gradients that are partly
     rounding noise, so two fp32-accurate implementations drift apart by design."""
     fx, d = load_trainer_fixture()
     dev = torch.device(DEV)
     model = build_model(fx, d, device=DEV)
-    model.precision = precision
+    model.precision = precision.split("+")[0]
+    if "fp32grads" in precision:
+        model.gradient_storage = "fp32"
+    default_storage = precision == "f16x3"
     model.scheduler = torch.optim.lr_scheduler.ExponentialLR(model.optimizer, lr_gamma(fx))     # lr_decay_steps of the fixture
     crit = vloss.VFLoss(SimpleNamespace(depth_loss_clamp=0.5, norm_smaller_than_one_start=11000, directional_derivatives_start=100),
                         SimpleNamespace(rgb=2.0, depth=0.5, unit_norm=0.1, supervision=1.0, norm_smaller_than_one=0.1,
@@ -114,7 +121,7 @@ def test_trainer_steps_replay_on_hip(precision):
         assert int(rc_normals.shape[0]) == int(d[f"s{t}.ray_center_normals"].shape[0]) or not same_z
         if t <= 1:
             assert same_z and e_pts < 5e-6
-            assert e_terms < 1e-4 and e_loss < 1e-4, report[-1]
+            assert e_terms < (1e-3 if (default_storage and t == 1) else 1e-4) and e_loss < 1e-4, report[-1]
         if t == 0:      # identical weights: the gradient norm and the update itself agree
             assert e_clip < 1e-3 and worst_w < 0.02 * lr + 1e-7, report[-1]
         else:
@@ -123,7 +130,12 @@ def test_trainer_steps_replay_on_hip(precision):
             # side of zero moves a layer's gradient by a percent.  Observed: clip norm 0.15 % (fp32 kernels) / 2 % (f16x3) off at
             # step 1 with the watched weights within one update, 2 % / 26 % at step 2.  Bounded, not pinned (DESIGN.md section 5,
             # loss-curve agreement).
-            assert e_clip < (0.05 if t == 1 else 0.5) and worst_w < (2.0 if t == 1 else 6.0) * lr and e_loss < 5e-2, report[-1]
+            # (default 16-bit gradient storage: more of the first update's signs are decided by rounding, see the docstring — by
+            # step 2 that run has its own weights, so only its loss is bounded there)
+            if default_storage:
+                assert (e_clip < 0.3 and worst_w < 4.0 * lr) if t == 1 else e_loss < 0.1, report[-1]
+            else:
+                assert e_clip < (0.05 if t == 1 else 0.5) and worst_w < (2.0 if t == 1 else 6.0) * lr and e_loss < 5e-2, report[-1]
     st = model.optimizer.state[model.vector_field_network.layers[8].weight]
     assert float(st["step"]) == 2 * fx["steps"], "the aliased VF parameters take two Adam updates per step (Q4)"
     assert float(model.optimizer.state[model.rendering_network.layers[4].weight]["step"]) == fx["steps"]

@@ -2,7 +2,7 @@
 (precision "f16x3": f16-split forward, bf16-split dX chain and weight gradients) against the exact-fp32 MFMA kernels, from
 the same initial weights, the same rays, targets and random draws, over >= 100 optimizer steps.
 
-    python tools/train_curve.py [steps] > profiles/r01/train_curve.json
+    python tools/train_curve.py [steps] > profiles/r02/train_curve.json
 
 Both runs are chaotic in the usual sense (a ReLU unit or a proposal argmax landing on the other side flips a discrete
 event and the trajectories part), so what is reported is the relative loss difference per step and its running
@@ -18,10 +18,11 @@ dev = torch.device("cuda:0")
 n_rays, s_c, n_f = 1024, 64, 64
 
 
-def run(precision, activations="fp32"):
+def run(precision, activations="fp32", gradients="fp32"):
     model, uv, pose, K = bench.build_scene(dev, n_rays, s_c, n_f, seed=0)
     model.precision = precision
     model.activation_storage = activations
+    model.gradient_storage = gradients
     g = torch.Generator().manual_seed(7)
     rgb_gt = torch.rand(n_rays, 3, generator=g).to(dev)
     depth_gt = (0.2 + 0.6 * torch.rand(n_rays, 1, generator=g)).to(dev)
@@ -48,19 +49,24 @@ def run(precision, activations="fp32"):
     return [float(x) for x in losses], (time.perf_counter() - t0) / steps * 1e3
 
 
-fast, ms_fast = run("f16x3")
 exact, ms_exact = run("fp32")
-f16act, ms_f16act = run("f16x3", "f16")
-rel = [abs(a - b) / max(abs(b), 1e-9) for a, b in zip(fast, exact)]
-first_big = next((i for i, r in enumerate(rel) if r > 1e-3), None)
+runs = {"fp32 activations, fp32 gradients": run("f16x3", "fp32", "fp32"),
+        "f16 activations, fp32 gradients": run("f16x3", "f16", "fp32"),
+        "f16 activations, scaled f16 gradients (default)": run("f16x3", "f16", "f16"),
+        "f16 activations, bf16 gradients": run("f16x3", "f16", "bf16")}
+
+
+def stats(losses):
+    rel = [abs(a - b) / max(abs(b), 1e-9) for a, b in zip(losses, exact)]
+    return {"loss_first_last": [losses[0], losses[-1]], "rel_diff_step0": rel[0], "rel_diff_max_first_10": max(rel[:10]),
+            "rel_diff_median": sorted(rel)[len(rel) // 2], "rel_diff_max": max(rel),
+            "first_step_with_rel_diff_above_1e-3": next((i for i, r in enumerate(rel) if r > 1e-3), None),
+            "mean_loss_last_20": sum(losses[-20:]) / 20, "loss_every_10_steps": losses[::10]}
+
+
 print(json.dumps({
-    "workload": f"{steps} optimizer steps, {n_rays} rays x {s_c + n_f} samples + 4096 supervision points, same weights / rays / targets / draws",
-    "ms_per_step": {"f16x3": round(ms_fast, 3), "fp32": round(ms_exact, 3)},
-    "loss_first_last": {"f16x3": [fast[0], fast[-1]], "fp32": [exact[0], exact[-1]]},
-    "rel_diff_step0": rel[0], "rel_diff_max_first_10": max(rel[:10]), "rel_diff_median": sorted(rel)[len(rel) // 2], "rel_diff_max": max(rel),
-    "first_step_with_rel_diff_above_1e-3": first_big,
-    "f16_activation_storage": {"ms_per_step": round(ms_f16act, 3), "loss_first_last": [f16act[0], f16act[-1]],
-                               "rel_diff_vs_fp32_step0": abs(f16act[0] - exact[0]) / max(abs(exact[0]), 1e-9),
-                               "rel_diff_vs_fp32_median": sorted(abs(a - b) / max(abs(b), 1e-9) for a, b in zip(f16act, exact))[len(exact) // 2],
-                               "loss_every_10_steps": f16act[::10]},
-    "loss_every_10_steps": {"f16x3": fast[::10], "fp32": exact[::10]}}))
+    "workload": f"{steps} optimizer steps, {n_rays} rays x {s_c + n_f} samples + 4096 supervision points, same weights / rays / targets / draws; "
+                "relative loss differences against the exact-fp32 kernels' run",
+    "fp32_kernels": {"ms_per_step": round(ms_exact, 3), "loss_first_last": [exact[0], exact[-1]], "mean_loss_last_20": sum(exact[-20:]) / 20,
+                     "loss_every_10_steps": exact[::10]},
+    "f16x3": {k: dict(stats(v[0]), ms_per_step=round(v[1], 3)) for k, v in runs.items()}}, indent=1))

@@ -244,11 +244,14 @@ class _Workspace:
 
     16-bit path (``frag``): every slot is FRAGMENT-ORDERED (include/vfn.h) — flat buffers of ceil(M/32) groups x 32 KiB;
     ``f16``: the ReLU slots hold f16 values (``VectorFieldNerf.activation_storage``); slot 8 of a VF net, the tanh'ed features,
-    is row-major fp32 [M,256] (``feats``).  ``dy16``: the chain stores the pre-activation gradients as bf16
-    (``VectorFieldNerf.gradient_storage``).  Exact-fp32 path: row-major [slots][M][256] fp32."""
+    is row-major fp32 [M,256] (``feats``).  ``dy16``: the chain stores the pre-activation gradients in 16 bits —
+    "bf16", or "f16" = f16 of the values scaled per lane and tile with the exponents behind each group's pieces (csrc/vfn_dwf.hip,
+    "dY form 3") (``VectorFieldNerf.gradient_storage``).  Exact-fp32 path: row-major [slots][M][256] fp32."""
 
-    def __init__(self, m: int, n_slots: int, dev, f16: bool = False, frag: bool = False, dy16: bool = False) -> None:
-        self.m, self.n_slots, self.f16, self.frag, self.dy16 = m, n_slots, f16, frag, dy16 and frag
+    def __init__(self, m: int, n_slots: int, dev, f16: bool = False, frag: bool = False, dy16=False) -> None:
+        dy16 = {True: "bf16", False: None, None: None, "fp32": None}.get(dy16, dy16) if frag else None
+        assert dy16 in (None, "bf16", "f16"), dy16
+        self.m, self.n_slots, self.f16, self.frag, self.dy16 = m, n_slots, f16, frag, dy16
         if frag:
             self.slot_floats = lib.frag_groups(m) * lib.GROUP_FLOATS
             self.saved = torch.empty(n_slots, self.slot_floats, device=dev)
@@ -271,13 +274,13 @@ class _Workspace:
         return (lib.WS_F16 if self.f16 else 0) | (lib.WS_FRAG if self.frag else 0)
 
     def dy_flags(self) -> int:
-        return (lib.DY_FRAG if self.frag else 0) | (lib.DY_BF16 if self.dy16 else 0)
+        return (lib.DY_FRAG if self.frag else 0) | {None: 0, "bf16": lib.DY_BF16, "f16": lib.DY_F16S}[self.dy16]
 
     def frag_forms(self):
         """(dy_form, x_form) of lib.weight_grad_frag for this workspace, or None for the row-major layouts."""
         if not self.frag:
             return None
-        return (lib.DYF_FRAGBF16 if self.dy16 else lib.DYF_FRAG32, lib.XF_FRAG16 if self.f16 else lib.XF_FRAG32)
+        return ({None: lib.DYF_FRAG32, "bf16": lib.DYF_FRAGBF16, "f16": lib.DYF_FRAGF16S}[self.dy16], lib.XF_FRAG16 if self.f16 else lib.XF_FRAG32)
 
     def new_dy(self) -> torch.Tensor:
         dev = self.saved.device
@@ -294,11 +297,12 @@ class _Workspace:
 
 
 def _storage(owner, fast: bool):
-    """(f16 activations, fragment order, bf16 gradients) for a 16-bit training forward of ``owner`` (model or VF net)."""
+    """(f16 activations, fragment order, 16-bit gradient form or None) for a 16-bit training forward of ``owner`` (model or VF net)."""
     if not fast:
-        return False, False, False
+        return False, False, None
+    grads = getattr(owner, "gradient_storage", "fp32")
     return (getattr(owner, "activation_storage", "fp32") == "f16", getattr(owner, "workspace_layout", "fragment") == "fragment",
-            getattr(owner, "gradient_storage", "fp32") == "bf16")
+            None if grads == "fp32" else grads)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -34,7 +34,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-enum : int { BM_VEC = 0, BM_FULL = 1, BM_FUSED = 3 };     // bit 0: the feature block's step is present; bit 1: rendering net
+enum : int { BM_VEC = 0, BM_FULL = 1, BM_FUSED = 3, BM_F16S = 16 };     // bit 0: the feature block's step is present; bit 1: rendering net; bit 4: scaled f16 gradients
 enum : int { MASK_RELU = 0, MASK_TANH = 1 };
 
 // ------------------------------------------------------------------------------------------------
@@ -186,7 +186,10 @@ struct Pipe {
     uint32_t voff;                   // feature loads (row-major): m * 1024 + 16 * (lane >> 5); out of range for m >= M
     uint32_t dvoff;                  // dY stores: row-major = voff; fragment order (m >> 5) * 32768 + 16 (8 as bf16) * lane
     uint32_t st_tile, st_q;          // byte strides of (tile, register quad) of a dY slot for fp32 stores (bf16: half)
-    int dy16;                        // dY leaves as bf16
+    int dy16;                        // dY leaves as 1: bf16, 2: scaled f16 (csrc/vfn_dwf.hip, "dY form 3")
+    uint32_t evoff;                  // scaled f16: this lane's exponent byte of tile 0, (m >> 5) * 32768 + 16384 + lane; out of range
+                                     // past the last group (lanes of padding points in a live group write 255 = "all zero")
+    int live;                        // this lane's point exists
     u32x4 mw[13];                    // this lane's sign-bit words, one per slot: tile t -> half t & 1 of dword t >> 1, bit r <-> register r
 };
 
@@ -238,11 +241,26 @@ __device__ __forceinline__ f32x4v mask_group(const Pipe& p, int q) {
         return load_group<SLOT, TILE>(p, q);
     }
 }
+typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+// scaled f16: the exponent byte (k + 64) and the scale 2^k of this lane's 16 values of a tile, max |v| 2^k in [2^14, 2^15)
+__device__ __forceinline__ float tile_scale(const f32x16& v, int& b) {
+    float m = fmaxf(fabsf(v[0]), fabsf(v[1]));
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) m = fmaxf(m, fmaxf(fabsf(v[r]), fabsf(v[r + 1])));
+    const int biased = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu);
+    b = biased == 0 ? 255 : min(max(205 - biased, 1), 190);
+    return biased == 0 ? 0.f : __builtin_bit_cast(float, (unsigned)(b + 63) << 23);
+}
 template <int SLOT, int TILE>
-__device__ __forceinline__ void store_group(const Pipe& p, const f32x16& v, int q) {
+__device__ __forceinline__ void store_group(const Pipe& p, const f32x16& v, int q, float scale = 1.0f) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.dy + (long long)SLOT * p.slot_floats, 0, (int)p.slot_bytes, 0x00020000);
     const f32x4v g = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-    if (p.dy16) {                     // bf16 (round to nearest even): half the bytes, 8 significant bits in ONE factor of dW = dY^T X
+    if (p.dy16 == 2) {                // f16 of the scaled values: 11 significant bits in ONE factor of dW = dY^T X
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const half4 h = __builtin_convertvector(g * scale, half4);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rs, (int)p.dvoff, (int)((TILE * p.st_tile + q * p.st_q) >> 1), BW16_STORE_AUX);
+    } else if (p.dy16) {              // bf16 (round to nearest even): half the bytes, 8 significant bits in ONE factor of dW = dY^T X
         typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
         const bf4 b = __builtin_convertvector(g, bf4);
@@ -252,6 +270,39 @@ __device__ __forceinline__ void store_group(const Pipe& p, const f32x16& v, int 
     } else {                          // row-major: 32 lines x 32 bytes per instruction — the default write-back policy (nt costs +33 % there)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)p.dvoff, (int)(TILE * p.st_tile + q * p.st_q), 0);
     }
+}
+// scaled f16, spread over the K steps of the next tile: one register quad -> four f16 of the scaled values
+__device__ __forceinline__ u32x2s pack_quad_f16s(const f32x16& v, int q, float scale) {
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    const f32x4v g = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    return __builtin_bit_cast(u32x2s, __builtin_convertvector(g * scale, half4));
+}
+// ... and the stores of a tile encoded that way: exponent byte(s) first, the four pieces last
+template <int SLOT, int TILE>
+__device__ __forceinline__ void store_tile_f16s(const Pipe& p, int b, const u32x2s (&eq)[4]) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.dy + (long long)SLOT * p.slot_floats, 0, (int)p.slot_bytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(p.live ? b : 255), rs, (int)p.evoff, TILE * 64, 0);
+    if constexpr (SLOT == 3 && TILE == 6) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)255, rs, (int)p.evoff, 7 * 64, 0);   // see store_tile
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        __builtin_amdgcn_raw_buffer_store_b64(eq[q], rs, (int)p.dvoff, (int)((TILE * p.st_tile + q * p.st_q) >> 1), BW16_STORE_AUX);
+}
+// a whole finished tile: (scaled f16: the lane's exponent byte first, so that the four piece stores stay the youngest
+// vector-memory operations of the chunk), then its four register quads
+template <int SLOT, int TILE>
+__device__ __forceinline__ void store_tile(const Pipe& p, const f32x16& v) {
+    float scale = 1.0f;
+    if (p.dy16 == 2) {
+        int b;
+        scale = tile_scale(v, b);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.dy + (long long)SLOT * p.slot_floats, 0, (int)p.slot_bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(p.live ? b : 255), rs, (int)p.evoff, TILE * 64, 0);
+        // slot 3 (the 217-wide layer in front of the skip) has seven tiles: its eighth is never produced, and the weight-gradient
+        // kernel takes the smallest exponent byte of a whole slab as its common scale — that tile must read as "all zero"
+        if constexpr (SLOT == 3 && TILE == 6) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)255, rs, (int)p.evoff, 7 * 64, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) store_group<SLOT, TILE>(p, v, q, scale);
 }
 
 // One register pair of a finished tile: (+ head rank-3 update) * activation derivative -> pend (for the store) and the
@@ -289,8 +340,7 @@ __device__ __forceinline__ void finish_tile_with(f32x16& v, const f32x4v (&mask)
     bf8 hi[2], lo[2];
 #pragma unroll
     for (int pr = 0; pr < 8; ++pr) epi_pair<MASK, HEAD, TILE>(v, mask, pr, p, dz, g, hi[pr >> 2], lo[pr >> 2], (pr & 3) * 2);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) store_group<SLOT, TILE>(p, v, q);
+    store_tile<SLOT, TILE>(p, v);
     if (SPLIT) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -321,9 +371,13 @@ __device__ __forceinline__ void load_start_masks(const Pipe& p, f32x4v (&mk)[8][
 // One matrix step: xout <- f'(saved) * (W'^T xin [+ head]) — NCH chunks (C0 .. of the launch), one 32-row tile each.
 //   OSLOT / MASK / HEAD describe the tiles this step produces; P* the pending tile handed over by the previous step
 //   (PT = its tile index: it becomes K-blocks 2 PT, 2 PT + 1 of `xpend` = this step's own input).
-template <int MODE, int C0, int NB, int NCH, int OSLOT, int MASK, int HEAD, int PSLOT, int PT, int PMASK, int PHEAD>
+// MX = launch mode (bits 0-1: BM_*) | BM_F16S (the gradients leave as scaled f16: compile-time, so that the encode sits in the
+// hand-scheduled steps without branches)
+template <int MX, int C0, int NB, int NCH, int OSLOT, int MASK, int HEAD, int PSLOT, int PT, int PMASK, int PHEAD>
 __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Carry& cy, const Pipe& p, const float (&dzv)[3],
                                        const float (&dzc)[3], int wave, int lane) {
+    constexpr int MODE = MX & 3;
+    constexpr bool F16S = (MX & BM_F16S) != 0;
     constexpr int H = NB / 2;                         // hand-over after step H-1
 #if BW16_EARLY_EPI
     // The pending tile's epilogue runs in the FIRST half of the chunk (its masks are register-resident sign bits; only the
@@ -350,6 +404,12 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
         bf8 fh[2], fl[2];
         fh[0] = cy.fh0; fl[0] = cy.fl0;
         bf8 ehi[2], elo[2];
+        // scaled f16 gradients: the pending tile is encoded in the shadow of this tile's second half (scale at step H, one
+        // register quad per step after it), so that the last step only issues the stores
+        float esc = 1.0f;
+        int eb = 255;
+        u32x2s eq[4] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+        constexpr bool ENC_SPREAD = BW16_EARLY_EPI && BW16_LATE_STORES && H + 5 < NB;
         f32x4v mnext[4];
 #pragma unroll
         for (int st = 0; st < NB; ++st) {
@@ -408,6 +468,10 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
                 }
             }
 #endif
+            if (ENC_SPREAD && F16S && (ch > 0 || PSLOT >= 0)) {
+                if (st == H) esc = tile_scale(cy.pend, eb);
+                if (st > H && st <= H + 4) eq[st - H - 1] = pack_quad_f16s(cy.pend, st - H - 1, esc);
+            }
             if (st >= H && st < H + 4) mnext[st - H] = mask_group<OSLOT, ch, MASK>(p, st - H);
             if (st >= H && ddma.kb > 0) {
 #pragma unroll
@@ -421,10 +485,12 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
             // the pending tile's dY: the LAST vector-memory instructions of the chunk (see the hand-over)
             if (st == NB - 1 && (ch > 0 || PSLOT >= 0)) {
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (ch > 0) store_group<OSLOT, (ch > 0 ? ch - 1 : 0)>(p, cy.pend, q);
-                    else store_group<(PSLOT >= 0 ? PSLOT : 0), (PT >= 0 ? PT : 0)>(p, cy.pend, q);
+                if (ENC_SPREAD && F16S) {
+                    if (ch > 0) store_tile_f16s<OSLOT, (ch > 0 ? ch - 1 : 0)>(p, eb, eq);
+                    else store_tile_f16s<(PSLOT >= 0 ? PSLOT : 0), (PT >= 0 ? PT : 0)>(p, eb, eq);
+                } else {
+                    if (ch > 0) store_tile<OSLOT, (ch > 0 ? ch - 1 : 0)>(p, cy.pend);
+                    else store_tile<(PSLOT >= 0 ? PSLOT : 0), (PT >= 0 ? PT : 0)>(p, cy.pend);
                 }
             }
 #endif
@@ -436,8 +502,9 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
     });
 }
 
-template <int MODE>
+template <int MX>
 __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
+    constexpr int MODE = MX & 3;
     __shared__ __attribute__((aligned(16))) uint4 s_ring[BW_RING * BW_SLOT + 2 * 3 * 256 / 4];
     float* s_heads = reinterpret_cast<float*>(s_ring + BW_RING * BW_SLOT);
     const int tid = threadIdx.x;
@@ -476,7 +543,9 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
     p.rn_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>((MODE & 2) ? a.rn_wt : a.vf_wt), 0,
                                                ((MODE & 2) ? rn_pack_kb() : vf_pack_kb()) * 1024, 0x00020000);
     const bool frag = (a.dy_flags & 2) != 0;
-    p.dy16 = frag && (a.dy_flags & 4) != 0;
+    p.dy16 = (MX & BM_F16S) ? 2 : ((frag && (a.dy_flags & 4)) ? 1 : 0);
+    p.live = in ? 1 : 0;
+    p.evoff = (m & ~31ll) < a.n_points ? (uint32_t)((m >> 5) * 32768 + 16384 + lane) : 0xc0000000u;
     p.feats = a.feats; p.dy = a.dy; p.feat_bytes = (uint32_t)(a.n_points * 1024);
     p.slot_floats = frag ? ((a.n_points + 31) >> 5) * 8192 : a.n_points * 256;
     p.slot_bytes = (uint32_t)(p.slot_floats * 4);
@@ -553,33 +622,33 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
     constexpr int R = MASK_RELU, T = MASK_TANH;
     // step16<MODE, C0, NB, NCH, OSLOT, MASK, HEAD, PSLOT, PT, PMASK, PHEAD>(xin, xout, xpend, ...)
     if constexpr (MODE == BM_FUSED) {
-        step16<MODE, first_chunk(MODE, 0), 16, 8, 11, R, -1, -1, -1, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);   // through R3
-        step16<MODE, first_chunk(MODE, 1), 16, 8, 10, R, -1, 11, 7, R, -1>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);    // R2
-        step16<MODE, first_chunk(MODE, 2), 16, 8, 9, R, -1, 10, 7, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);     // R1
-        step16<MODE, first_chunk(MODE, 3), 16, 8, 8, T, -1, 9, 7, R, -1>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);      // R0 -> features
-        step16<MODE, first_chunk(MODE, 4), 16, 8, 7, R, 0, 8, 7, T, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);       // feature block + vector head
+        step16<MX, first_chunk(MODE, 0), 16, 8, 11, R, -1, -1, -1, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);   // through R3
+        step16<MX, first_chunk(MODE, 1), 16, 8, 10, R, -1, 11, 7, R, -1>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);    // R2
+        step16<MX, first_chunk(MODE, 2), 16, 8, 9, R, -1, 10, 7, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);     // R1
+        step16<MX, first_chunk(MODE, 3), 16, 8, 8, T, -1, 9, 7, R, -1>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);      // R0 -> features
+        step16<MX, first_chunk(MODE, 4), 16, 8, 7, R, 0, 8, 7, T, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);       // feature block + vector head
     } else if constexpr (MODE == BM_FULL) {
-        step16<MODE, first_chunk(MODE, 4), 16, 8, 7, R, 0, -1, -1, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);
+        step16<MX, first_chunk(MODE, 4), 16, 8, 7, R, 0, -1, -1, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);
     }
     if constexpr (MODE != BM_VEC) {
         // gradient of VF hidden 7 is in xb
-        step16<MODE, first_chunk(MODE, 5), 16, 8, 6, R, -1, 7, 7, R, 0>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);       // L7
-        step16<MODE, first_chunk(MODE, 6), 16, 8, 5, R, -1, 6, 7, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);      // L6
-        step16<MODE, first_chunk(MODE, 7), 16, 8, 4, R, -1, 5, 7, R, -1>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);      // L5
-        step16<MODE, first_chunk(MODE, 8), 16, 7, 3, R, -1, 4, 7, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);      // L4 (skip): 217 inputs
-        step16<MODE, first_chunk(MODE, 9), 14, 8, 2, R, -1, 3, 6, R, -1>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);      // L3
-        step16<MODE, first_chunk(MODE, 10), 16, 8, 1, R, -1, 2, 7, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);     // L2
-        step16<MODE, first_chunk(MODE, 11), 16, 8, 0, R, -1, 1, 7, R, -1>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);     // L1
+        step16<MX, first_chunk(MODE, 5), 16, 8, 6, R, -1, 7, 7, R, 0>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);       // L7
+        step16<MX, first_chunk(MODE, 6), 16, 8, 5, R, -1, 6, 7, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);      // L6
+        step16<MX, first_chunk(MODE, 7), 16, 8, 4, R, -1, 5, 7, R, -1>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);      // L5
+        step16<MX, first_chunk(MODE, 8), 16, 7, 3, R, -1, 4, 7, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);      // L4 (skip): 217 inputs
+        step16<MX, first_chunk(MODE, 9), 14, 8, 2, R, -1, 3, 6, R, -1>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);      // L3
+        step16<MX, first_chunk(MODE, 10), 16, 8, 1, R, -1, 2, 7, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);     // L2
+        step16<MX, first_chunk(MODE, 11), 16, 8, 0, R, -1, 1, 7, R, -1>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);     // L1
         finish_tile<0, 7, R, -1, false>(cy.pend, p, dzv, g, xa);
     } else {
         // vector-only: the start tiles (gradient of VF hidden 7) are in xa
-        step16<MODE, first_chunk(MODE, 5), 16, 8, 6, R, -1, -1, -1, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);
-        step16<MODE, first_chunk(MODE, 6), 16, 8, 5, R, -1, 6, 7, R, -1>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);
-        step16<MODE, first_chunk(MODE, 7), 16, 8, 4, R, -1, 5, 7, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);
-        step16<MODE, first_chunk(MODE, 8), 16, 7, 3, R, -1, 4, 7, R, -1>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);
-        step16<MODE, first_chunk(MODE, 9), 14, 8, 2, R, -1, 3, 6, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);
-        step16<MODE, first_chunk(MODE, 10), 16, 8, 1, R, -1, 2, 7, R, -1>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);
-        step16<MODE, first_chunk(MODE, 11), 16, 8, 0, R, -1, 1, 7, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);
+        step16<MX, first_chunk(MODE, 5), 16, 8, 6, R, -1, -1, -1, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);
+        step16<MX, first_chunk(MODE, 6), 16, 8, 5, R, -1, 6, 7, R, -1>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);
+        step16<MX, first_chunk(MODE, 7), 16, 8, 4, R, -1, 5, 7, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);
+        step16<MX, first_chunk(MODE, 8), 16, 7, 3, R, -1, 4, 7, R, -1>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);
+        step16<MX, first_chunk(MODE, 9), 14, 8, 2, R, -1, 3, 6, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);
+        step16<MX, first_chunk(MODE, 10), 16, 8, 1, R, -1, 2, 7, R, -1>(xb, xa, xb, cy, p, dzv, dzc, wave, lane);
+        step16<MX, first_chunk(MODE, 11), 16, 8, 0, R, -1, 1, 7, R, -1>(xa, xb, xa, cy, p, dzv, dzc, wave, lane);
         finish_tile<0, 7, R, -1, false>(cy.pend, p, dzv, g, xa);
     }
 }
@@ -660,14 +729,22 @@ extern "C" int vfn_mlp_bwd_chain_bf16_ws(const vfn_net_geom* vf_geom, const void
     VFN_REQUIRE(vec_stride >= 3, "vfn_mlp_bwd_chain_bf16: vec_stride must be >= 3");
     VFN_REQUIRE(n_points < ((dy_flags & 2) ? (1ll << 21) : (1ll << 22)), "vfn_mlp_bwd_chain_bf16: at most %lld points per launch (32-bit slot offsets)",
                 ((dy_flags & 2) ? (1ll << 21) : (1ll << 22)) - 1);
-    VFN_REQUIRE(!(dy_flags & 4) || (dy_flags & 2), "vfn_mlp_bwd_chain_bf16: bf16 gradients need the fragment-ordered layout");
+    VFN_REQUIRE(!(dy_flags & 12) || (dy_flags & 2), "vfn_mlp_bwd_chain_bf16: 16-bit gradients need the fragment-ordered layout");
+    VFN_REQUIRE((dy_flags & 12) != 12, "vfn_mlp_bwd_chain_bf16: dy_flags asks for bf16 AND scaled f16 gradients");
+#if !BW16_LATE_STORES
+    VFN_REQUIRE(!(dy_flags & 8), "vfn_mlp_bwd_chain_bf16: this build stores a tile's quads in separate steps; scaled f16 gradients need BW16_LATE_STORES");
+#endif
     Bwd16Args a = {};
     a.vf_wt = (const uint4*)vf_packed_bwd16; a.rn_wt = (const uint4*)rn_packed_bwd16; a.vf_head = vf_head_w; a.rn_head = rn_head_w;
-    a.feats = saved; a.dy_flags = dy_flags & 6; a.masks = masks; a.dy = (float*)dy; a.d_colors = d_colors; a.colors = colors; a.d_vec = d_vec; a.vec = vec; a.d_feats = d_feats;
+    a.feats = saved; a.dy_flags = dy_flags & 14; a.masks = masks; a.dy = (float*)dy; a.d_colors = d_colors; a.colors = colors; a.d_vec = d_vec; a.vec = vec; a.d_feats = d_feats;
     a.dz_rgb = dz_rgb; a.dz_vec = dz_vec; a.n_points = n_points; a.vec_stride = vec_stride;
     const unsigned blocks = (unsigned)((n_points + BW_PTS - 1) / BW_PTS);
     hipStream_t s = (hipStream_t)stream;
-    if (fused) hipLaunchKernelGGL(vfn_bwd16_kernel<BM_FUSED>, dim3(blocks), dim3(256), 0, s, a);
+    if (dy_flags & 8) {
+        if (fused) hipLaunchKernelGGL(vfn_bwd16_kernel<BM_FUSED | BM_F16S>, dim3(blocks), dim3(256), 0, s, a);
+        else if (d_feats) hipLaunchKernelGGL(vfn_bwd16_kernel<BM_FULL | BM_F16S>, dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(vfn_bwd16_kernel<BM_VEC | BM_F16S>, dim3(blocks), dim3(256), 0, s, a);
+    } else if (fused) hipLaunchKernelGGL(vfn_bwd16_kernel<BM_FUSED>, dim3(blocks), dim3(256), 0, s, a);
     else if (d_feats) hipLaunchKernelGGL(vfn_bwd16_kernel<BM_FULL>, dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(vfn_bwd16_kernel<BM_VEC>, dim3(blocks), dim3(256), 0, s, a);
     return vfn_check_launch("vfn_mlp_bwd_chain_bf16");

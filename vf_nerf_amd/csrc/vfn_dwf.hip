@@ -27,6 +27,16 @@
 // and the operand forms: dY fragment fp32 | fragment bf16 | dz rows; X fragment fp32 | fragment f16 | [M][256] fp32 rows (the
 // tanh'ed features, which stay row-major) | aux rows.  A bf16 dY has no low half (two products per K-block instead of
 // three); an f16 X splits exactly into bf16 hi + lo.
+//
+// dY form 3, "scaled f16" (what the chain writes with dy_flags bit 3): the 16 values a lane holds of a gradient tile (one point,
+// 16 of the tile's 32 columns: the lane's accumulator registers) are stored as f16(dY * 2^k) with k chosen per lane and tile so
+// that the largest magnitude lands in [2^14, 2^15): 11 significant bits whatever the gradient's scale, no overflow, no state
+// carried between steps.  The four 512-byte pieces of tile t sit where the bf16 form has them; byte 16384 + 64 t + lane of the
+// group holds k + 64 (255: all 16 values are zero).  A slab's workgroup reads the exponent bytes of its groups first, takes K =
+// the smallest k among them, multiplies every value by 2^(K - k) <= 1 on its way into LDS (values 2^-24 below the slab's largest
+// vanish — they could not move a sum that is compared to the tensor's largest entry) and multiplies its result by 2^-K:
+// operands with ONE common scale, so the products run on v_mfma_f32_32x32x16_f16 with f16 activations as they are — one product
+// per K-block, exact 11 x 11-bit operands — and an fp32 X (feature rows, encoding tile) as f16 hi + lo (two products).
 #include <string.h>
 #include "vfn_common.h"
 
@@ -51,7 +61,8 @@ constexpr int F_BUF = 4 * F_IMG;                // (dY | X) x (hi | lo)
 constexpr int F_GROUP = 32768;                  // bytes of one workspace group
 
 enum : int { X_FRAG32 = 0, X_FRAG16 = 1, X_ROWS32 = 2, X_AUX40 = 3 };
-enum : int { DY_FRAG32 = 0, DY_FRAGBF16 = 1, DY_DZ4 = 2 };
+enum : int { DY_FRAG32 = 0, DY_FRAGBF16 = 1, DY_DZ4 = 2, DY_FRAGF16S = 3 };
+constexpr int F_EXP_OFF = 16384;                // exponent bytes of a group (form 3): [tile 0..7][lane 0..63], behind its 16 KiB of 16-bit pieces
 
 struct DwfArgs {
     const void* dy;
@@ -82,6 +93,15 @@ __device__ __forceinline__ void split4(const f32x4v v, uint2& hi, uint2& lo) {
     lo.y = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf2));
 }
 
+// four fp32 values -> 4 f16 "hi" (rounded) and 4 f16 "lo" (the residual, rounded)
+__device__ __forceinline__ void split4h(const f32x4v v, uint2& hi, uint2& lo) {
+    const half4 h = __builtin_convertvector(v, half4);
+    const f32x4v r = v - __builtin_convertvector(h, f32x4v);
+    const half4 l = __builtin_convertvector(r, half4);
+    const u32x2 hu = __builtin_bit_cast(u32x2, h), lu = __builtin_bit_cast(u32x2, l);
+    hi.x = hu[0]; hi.y = hu[1]; lo.x = lu[0]; lo.y = lu[1];
+}
+
 // byte offset of 8-byte chunk `chunk` of image row `row` (chunks XOR-swizzled inside aligned runs of 8)
 __device__ __forceinline__ int img_off(int row, int chunk) { return row * F_ROW + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
@@ -89,7 +109,9 @@ template <int SHAPE, int XM, int DM>
 __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfArgs a) {
     constexpr bool A_FRAG = DM != DY_DZ4;
     constexpr bool B_FRAG = XM == X_FRAG32 || XM == X_FRAG16;
-    constexpr bool A_LO = DM != DY_FRAGBF16;                    // a bf16 gradient has no low half
+    constexpr bool F16 = DM == DY_FRAGF16S;                     // tile-scaled f16 gradient: f16 matrix instruction, one common scale per slab
+    constexpr bool A_LO = DM != DY_FRAGBF16 && !F16;            // a 16-bit gradient has no low half
+    constexpr bool B_LO = !(F16 && XM == X_FRAG16);             // f16 activations enter an f16 product as they are
     constexpr int NA = SHAPE == 0 ? 4 : (SHAPE == 1 ? 2 : 1);   // A / B tiles per wave
     constexpr int NB = SHAPE == 0 ? 4 : 2;
     constexpr int LD_OUT = SHAPE == 1 ? 64 : 256, N_OUT = SHAPE == 2 ? 32 : 256;
@@ -124,8 +146,33 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfArgs a) {
         __syncthreads();
     }
 
-    // slab-relative descriptors: groups / rows past the end of the slab read as zero
     const long long n_steps = max(0LL, s1 - s0);
+    // form 3: the smallest tile exponent of this slab = the common scale of its operands
+    int bmin = 255;
+    if constexpr (F16) {
+        const unsigned char* gp = static_cast<const unsigned char*>(a.dy) + (size_t)s0 * F_GROUP + F_EXP_OFF;
+        for (long long idx = tid; idx < n_steps * 32; idx += 256) {             // 512 exponent bytes per group = 32 x 16 bytes
+            const uint4 e = *reinterpret_cast<const uint4*>(gp + (size_t)(idx >> 5) * F_GROUP + (idx & 31) * 16);
+            const unsigned w[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bmin = min(bmin, (int)((w[j] >> (8 * k)) & 0xffu));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bmin = min(bmin, __shfl_xor(bmin, o, 64));
+        int* red = reinterpret_cast<int*>(lds);
+        __syncthreads();
+        if (lane == 0) red[wave] = bmin;
+        __syncthreads();
+        bmin = __builtin_amdgcn_readfirstlane(min(min(red[0], red[1]), min(red[2], red[3])));
+        __syncthreads();
+        if (XM == X_AUX40) {            // (the reduction used the first bytes of the zero-filled images)
+            if (tid < 4) red[tid] = 0;
+            __syncthreads();
+        }
+    }
+    // slab-relative descriptors: groups / rows past the end of the slab read as zero
     const long long r_base = s0 * F_STEP;
     const long long rows_slab = max(0LL, min(n_steps * F_STEP, a.n_points - r_base));
     const __amdgpu_buffer_rsrc_t rs_a = A_FRAG
@@ -141,8 +188,13 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfArgs a) {
                                             (int)(rows_slab * (XM == X_AUX40 ? 160 : 1024)), 0x00020000);
 
     u32x4 ld_a[A_FRAG ? 8 : 1], ld_b[(B_FRAG || XM == X_ROWS32) ? 8 : 2];
+    unsigned ld_e[2] = {0u, 0u};                                // form 3: this lane's exponent bytes of the wave's two tiles (2 wave, 2 wave + 1)
     auto issue = [&](long long s) {
         const int st = (int)(s - s0);
+        if constexpr (F16) {
+            ld_e[0] = __builtin_amdgcn_raw_buffer_load_b8(rs_a, lane, st * F_GROUP + F_EXP_OFF + (2 * wave) * 64, 0);
+            ld_e[1] = __builtin_amdgcn_raw_buffer_load_b8(rs_a, lane, st * F_GROUP + F_EXP_OFF + (2 * wave + 1) * 64, 0);
+        }
         if constexpr (A_FRAG) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -182,6 +234,16 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfArgs a) {
                 const int pc = 8 * wave + r, t = pc >> 2, q = pc & 3;
                 f32x4v v;
                 if (DM == DY_FRAG32) v = __builtin_bit_cast(f32x4v, ld_a[r]);
+                else if (F16) {
+                    // rescale from the lane's own exponent to the slab's: 2^(bmin - b) <= 1, exact in f16 down to 2^-24
+                    const int b = (int)(ld_e[r >> 2] & 0xffu);
+                    const int d = b - bmin;
+                    const _Float16 f = (b == 255 || d > 24) ? (_Float16)0.f : (_Float16)__builtin_bit_cast(float, (unsigned)(127 - d) << 23);
+                    const half4 hv = __builtin_bit_cast(half4, u32x2{ld_a[r][0], ld_a[r][1]}) * half4{f, f, f, f};
+                    const u32x2 hu = __builtin_bit_cast(u32x2, hv);
+                    ld_a[r][0] = hu[0]; ld_a[r][1] = hu[1];
+                    v = __builtin_convertvector(hv, f32x4v);
+                }
                 else { const u32x2 h = {ld_a[r][0], ld_a[r][1]}; v = __builtin_convertvector(__builtin_bit_cast(bf4, h), f32x4v); }
                 if (!live) v = f32x4v{0.f, 0.f, 0.f, 0.f};
                 const int off = img_off(pi, 8 * t + 2 * q + gi);
@@ -213,17 +275,21 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfArgs a) {
                 if (XM == X_FRAG32) v = __builtin_bit_cast(f32x4v, ld_b[r]);
                 else { const u32x2 h = {ld_b[r][0], ld_b[r][1]}; v = __builtin_convertvector(__builtin_bit_cast(half4, h), f32x4v); }
                 if (!live) v = f32x4v{0.f, 0.f, 0.f, 0.f};
-                uint2 hi, lo;
-                split4(v, hi, lo);
                 const int off = img_off(pi, 8 * t + 2 * q + gi);
-                *reinterpret_cast<uint2*>(base + 2 * F_IMG + off) = hi;
-                *reinterpret_cast<uint2*>(base + 3 * F_IMG + off) = lo;
+                if constexpr (!B_LO) {        // f16 activations under an f16 product: the stored bits
+                    *reinterpret_cast<uint2*>(base + 2 * F_IMG + off) = live ? uint2{ld_b[r][0], ld_b[r][1]} : uint2{0u, 0u};
+                } else {
+                    uint2 hi, lo;
+                    if (F16) split4h(v, hi, lo); else split4(v, hi, lo);
+                    *reinterpret_cast<uint2*>(base + 2 * F_IMG + off) = hi;
+                    *reinterpret_cast<uint2*>(base + 3 * F_IMG + off) = lo;
+                }
             }
         } else if constexpr (XM == X_ROWS32) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 uint2 hi, lo;
-                split4(__builtin_bit_cast(f32x4v, ld_b[r]), hi, lo);
+                if (F16) split4h(__builtin_bit_cast(f32x4v, ld_b[r]), hi, lo); else split4(__builtin_bit_cast(f32x4v, ld_b[r]), hi, lo);
                 const int off = img_off(8 * wave + r, lane);
                 *reinterpret_cast<uint2*>(base + 2 * F_IMG + off) = hi;
                 *reinterpret_cast<uint2*>(base + 3 * F_IMG + off) = lo;
@@ -235,7 +301,7 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfArgs a) {
                 if (idx < 320) {
                     const int row = idx / 10, ch = idx - 10 * row;
                     uint2 hi, lo;
-                    split4(__builtin_bit_cast(f32x4v, ld_b[k]), hi, lo);
+                    if (F16) split4h(__builtin_bit_cast(f32x4v, ld_b[k]), hi, lo); else split4(__builtin_bit_cast(f32x4v, ld_b[k]), hi, lo);
                     *reinterpret_cast<uint2*>(base + 2 * F_IMG + img_off(row, ch)) = hi;
                     *reinterpret_cast<uint2*>(base + 3 * F_IMG + img_off(row, ch)) = lo;
                 }
@@ -259,15 +325,21 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfArgs a) {
 #pragma unroll
         for (int t = 0; t < NB; ++t) {
             bh[t] = tr_frag(img + 2 * F_IMG + (bt0 + t) * 64, tr1, tr2);
-            bl[t] = tr_frag(img + 3 * F_IMG + (bt0 + t) * 64, tr1, tr2);
+            if (B_LO) bl[t] = tr_frag(img + 3 * F_IMG + (bt0 + t) * 64, tr1, tr2);
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i)
 #pragma unroll
             for (int t = 0; t < NB; ++t) {
-                acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[t], acc[i][t], 0, 0, 0);
-                acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[t], acc[i][t], 0, 0, 0);
-                if (A_LO) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[t], acc[i][t], 0, 0, 0);
+                if constexpr (F16) {
+                    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bh[t]), acc[i][t], 0, 0, 0);
+                    if (B_LO) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bl[t]), acc[i][t], 0, 0, 0);
+                } else {
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[t], acc[i][t], 0, 0, 0);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[t], acc[i][t], 0, 0, 0);
+                    if (A_LO) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[t], acc[i][t], 0, 0, 0);
+                }
             }
     };
 
@@ -289,15 +361,19 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfArgs a) {
     // partial slab: D row = n (A operand's row), column = k (B operand's column)
     float* out = a.dw_part + (size_t)g * N_OUT * LD_OUT;
     const int c = lane & 31;
+    // form 3: back from the slab's common scale 2^(bmin - 64) (an all-zero slab has nothing to scale)
+    const float unscale = (F16 && bmin != 255) ? __builtin_bit_cast(float, (unsigned)(127 + 64 - bmin) << 23) : 1.0f;
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int t = 0; t < NB; ++t)
+        for (int t = 0; t < NB; ++t) {
+            if (F16) asm volatile("" : "+a"(acc[i][t]));       // the accumulators stay in the AGPRs (the scaling below would pull all 256 into VGPRs)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = 32 * (at0 + i) + (r & 3) + 8 * (r >> 2) + 4 * h;
-                out[(size_t)n * LD_OUT + 32 * (bt0 + t) + c] = acc[i][t][r];
+                out[(size_t)n * LD_OUT + 32 * (bt0 + t) + c] = F16 ? acc[i][t][r] * unscale : acc[i][t][r];
             }
+        }
     if (a.db_part) {
         if constexpr (A_FRAG) {                // piece r of this wave = columns 32 t + 8 q + 4 g + c; sum over the 32 points of a lane half
 #pragma unroll
@@ -308,7 +384,7 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfArgs a) {
 #pragma unroll
                     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
                     const int pc = 8 * wave + r, t = pc >> 2, q = pc & 3;
-                    if (pi == 0) a.db_part[(size_t)g * N_OUT + 32 * t + 8 * q + 4 * gi + cc] = v;
+                    if (pi == 0) a.db_part[(size_t)g * N_OUT + 32 * t + 8 * q + 4 * gi + cc] = F16 ? v * unscale : v;
                 }
         } else if (wave == 0) {                // dz rows: threads 0..31 hold one row each; the head has 4 (3 used) outputs
             float keep[4];
@@ -341,8 +417,12 @@ extern "C" int vfn_weight_grad_frag(int32_t shape, const void* dy, int32_t dy_fo
     a.dy = dy; a.x = x; a.dw_part = dw_part; a.db_part = db_part; a.n_points = n_points;
     hipStream_t s = (hipStream_t)stream;
     if (shape == 0) {
-        VFN_REQUIRE(dy_form == DY_FRAG32 || dy_form == DY_FRAGBF16, "vfn_weight_grad_frag: shape 0 takes a fragment-ordered dY");
-        if (dy_form == DY_FRAG32) {
+        VFN_REQUIRE(dy_form == DY_FRAG32 || dy_form == DY_FRAGBF16 || dy_form == DY_FRAGF16S, "vfn_weight_grad_frag: shape 0 takes a fragment-ordered dY");
+        if (dy_form == DY_FRAGF16S) {
+            if (x_form == X_FRAG32) return launch<0, X_FRAG32, DY_FRAGF16S>(a, groups, s);
+            if (x_form == X_FRAG16) return launch<0, X_FRAG16, DY_FRAGF16S>(a, groups, s);
+            if (x_form == X_ROWS32) return launch<0, X_ROWS32, DY_FRAGF16S>(a, groups, s);
+        } else if (dy_form == DY_FRAG32) {
             if (x_form == X_FRAG32) return launch<0, X_FRAG32, DY_FRAG32>(a, groups, s);
             if (x_form == X_FRAG16) return launch<0, X_FRAG16, DY_FRAG32>(a, groups, s);
             if (x_form == X_ROWS32) return launch<0, X_ROWS32, DY_FRAG32>(a, groups, s);
@@ -355,6 +435,7 @@ extern "C" int vfn_weight_grad_frag(int32_t shape, const void* dy, int32_t dy_fo
         VFN_REQUIRE(x_form == X_AUX40, "vfn_weight_grad_frag: shape 1 takes the [M][40] encoding tile as X");
         if (dy_form == DY_FRAG32) return launch<1, X_AUX40, DY_FRAG32>(a, groups, s);
         if (dy_form == DY_FRAGBF16) return launch<1, X_AUX40, DY_FRAGBF16>(a, groups, s);
+        if (dy_form == DY_FRAGF16S) return launch<1, X_AUX40, DY_FRAGF16S>(a, groups, s);
     } else if (shape == 2) {
         VFN_REQUIRE(dy_form == DY_DZ4, "vfn_weight_grad_frag: shape 2 takes the [M][4] head gradient as dY");
         if (x_form == X_FRAG32) return launch<2, X_FRAG32, DY_DZ4>(a, groups, s);

@@ -490,8 +490,8 @@ def mlp_bwd_chain_bf16(vf_geom, vf_packed_bwd16, vf_head_w, rn_geom, rn_packed_b
 # fragment-ordered training workspace (include/vfn.h, "FRAGMENT-ORDERED training workspace")
 # ------------------------------------------------------------------------------------------------
 WS_F16, WS_FRAG = 1, 2                       # flags of the f16x3 training forwards (save_f16 argument)
-DY_FRAG, DY_BF16 = 2, 4                      # flags of the bf16 chain (dy_flags argument)
-DYF_FRAG32, DYF_FRAGBF16, DYF_DZ4 = 0, 1, 2  # operand forms of weight_grad_frag
+DY_FRAG, DY_BF16, DY_F16S = 2, 4, 8          # flags of the bf16 chain (dy_flags argument): fragment order, bf16, scaled f16
+DYF_FRAG32, DYF_FRAGBF16, DYF_DZ4, DYF_FRAGF16S = 0, 1, 2, 3  # operand forms of weight_grad_frag (3: tile-scaled f16)
 XF_FRAG32, XF_FRAG16, XF_ROWS32, XF_AUX40 = 0, 1, 2, 3
 GROUP_FLOATS = 8192                          # one group of 32 points = 32 KiB
 
@@ -526,6 +526,44 @@ def rows_to_frag(rows: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
     else:
         out.view(dtype)[:, :GROUP_FLOATS] = frag.to(dtype)
     return out.reshape(-1)
+
+
+F16S_EXP_OFF = 16384     # byte offset of the 8 x 64 exponent bytes inside a group of a scaled f16 gradient slot (dy form 3)
+
+
+def rows_to_frag_f16s(rows: torch.Tensor) -> torch.Tensor:
+    """[m, 256] fp32 -> one fragment-ordered slot in the scaled f16 form the bf16 chain writes with DY_F16S (csrc/vfn_dwf.hip,
+    "dY form 3"): per group, 32-column tile t and lane (point i, column half gg: the 16 columns 8 q + 4 gg + c of the tile),
+    f16(v * 2^k) with max |v| * 2^k in [2^14, 2^15) and the byte k + 64 (255: all 16 values zero) at F16S_EXP_OFF + 64 t + lane.
+    Test helper (the chain is the producer)."""
+    m = rows.shape[0]
+    g = frag_groups(m)
+    pad = torch.zeros(g * 32, 256, device=rows.device, dtype=torch.float32)
+    pad[:m] = rows.float()
+    v = pad.reshape(g, 32, 8, 4, 2, 4)                                       # [group][point i][tile t][quad q][half gg][c]
+    mx = v.abs().amax(dim=(3, 5))                                            # [g, i, t, gg]
+    biased = (mx.view(torch.int32) >> 23) & 0xff
+    b = torch.where(biased == 0, torch.full_like(biased, 255), (205 - biased).clamp(1, 190))
+    scale = ((b.clamp(max=190) + 63) << 23).view(torch.float32)
+    scale = torch.where(b == 255, torch.zeros_like(scale), scale)
+    scaled = v * scale[:, :, :, None, :, None]
+    frag = scaled.permute(0, 2, 3, 4, 1, 5).reshape(g, GROUP_FLOATS)          # [group][t][q][gg][i][c]
+    out = torch.zeros(g, GROUP_FLOATS, device=rows.device, dtype=torch.float32)
+    out.view(torch.float16)[:, :GROUP_FLOATS] = frag.to(torch.float16)
+    out.view(torch.uint8)[:, F16S_EXP_OFF:F16S_EXP_OFF + 512] = b.permute(0, 2, 3, 1).reshape(g, 512).to(torch.uint8)   # [t][lane = 32 gg + i]
+    return out.reshape(-1)
+
+
+def frag_f16s_to_rows(slot: torch.Tensor, m: int) -> torch.Tensor:
+    """The row-major [m, 256] fp32 values a scaled f16 gradient slot holds (test / debugging helper)."""
+    g = frag_groups(m)
+    flat = slot.reshape(-1)[: g * GROUP_FLOATS].view(g, GROUP_FLOATS)
+    b = flat.view(torch.uint8)[:, F16S_EXP_OFF:F16S_EXP_OFF + 512].to(torch.int32).reshape(g, 8, 2, 32)     # [t][gg][i]
+    inv = ((127 + 64 - b.clamp(max=190)) << 23).view(torch.float32)
+    inv = torch.where(b == 255, torch.zeros_like(inv), inv)
+    vals = flat.view(torch.float16)[:, :GROUP_FLOATS].float().reshape(g, 8, 4, 2, 32, 4) * inv[:, :, None, :, :, None]
+    rows = vals.permute(0, 4, 1, 2, 3, 5).reshape(g * 32, 256)
+    return rows[:m]
 
 
 def weight_grad_frag(shape: int, dy, dy_form: int, x, x_form: int, n_points: int, groups: int, dw_part, db_part=None) -> None:

@@ -130,10 +130,14 @@ class VectorFieldNerf:
         # (every store / load 1 KiB of consecutive bytes; weight gradients from csrc/vfn_dwf.hip), "rows" = row-major [M,256]
         # slots (csrc/vfn_dw16.hip and the fp32-MFMA thin kernels).  Same values either way.
         self.workspace_layout = "fragment"
-        # Storage of the pre-activation gradients dY between the dX chain and the weight-gradient kernels: "fp32", or "bf16"
-        # (fragment layout only): 8 significant bits in ONE factor of dW = dY^T X under an unbiased sum over the batch's
-        # points, half the chain's store traffic and two matrix products per K-block instead of three.
-        self.gradient_storage = "fp32"
+        # Storage of the pre-activation gradients dY between the dX chain and the weight-gradient kernels (16-bit forms: fragment
+        # layout only).  "fp32"; "f16": f16 of the values scaled per lane and tile (the 16 values a lane holds share a power of
+        # two that puts their largest in [2^14, 2^15); csrc/vfn_dwf.hip "dY form 3") — 11 significant bits whatever the gradient's
+        # scale, half the chain's store traffic, and with f16 activations ONE f16 matrix product per K-block in dW = dY^T X instead
+        # of three bf16 ones; "bf16": 8 significant bits, two products.  Default "f16": with f16 activations every parameter
+        # gradient stays within 1e-3 of the exact-fp32 kernels' (5.3e-4 measured at 4096 x 128, tests/test_hip_fullsize.py; fp32
+        # storage: 3.4e-4) and the training step takes 10.0 instead of 11.4 ms.
+        self.gradient_storage = "f16"
         # Inference with the f16x3 kernels evaluates the VF net once per distinct sample: the proposal samples keep their
         # vector columns and feature operand blocks, only the N_f new samples are evaluated after the fine sampler, and the
         # rendering net gathers (the reference evaluates the proposal samples twice; same per-sample arithmetic, identical
@@ -304,8 +308,8 @@ class VectorFieldNerf:
 
     @gradient_storage.setter
     def gradient_storage(self, value: str) -> None:
-        if value not in ("fp32", "bf16"):
-            raise ValueError(f"gradient_storage must be 'fp32' or 'bf16', got {value!r}")
+        if value not in ("fp32", "f16", "bf16"):
+            raise ValueError(f"gradient_storage must be 'fp32', 'f16' or 'bf16', got {value!r}")
         self._gradient_storage = value
         self.vector_field_network.gradient_storage = value
 
