@@ -353,8 +353,8 @@ int vfn_mlp_bwd_chain_bf16(const vfn_net_geom* vf_geom, const void* vf_packed_bw
 
 /* The same chain for the FRAGMENT-ORDERED workspace (below): `feats` = the tanh'ed features [M][256] row-major fp32 (the one
  * slot the chain reads as values), `dy` = the gradient slots it writes, dy_flags bit 1: fragment order, bit 2 (with bit 1):
- * as bf16.  dy_flags = 0 and feats = slot 8 of saved[13][M][256] is vfn_mlp_bwd_chain_bf16.  n_points < 2^21 in fragment
- * order. */
+ * as bf16, bit 3 (with bit 1, not with bit 2): as SCALED f16 (vfn_weight_grad_frag, dy_form 3).  dy_flags = 0 and feats =
+ * slot 8 of saved[13][M][256] is vfn_mlp_bwd_chain_bf16.  n_points < 2^21 in fragment order. */
 int vfn_mlp_bwd_chain_bf16_ws(const vfn_net_geom* vf_geom, const void* vf_packed_bwd16, const float* vf_head_w,
                               const vfn_net_geom* rn_geom, const void* rn_packed_bwd16, const float* rn_head_w,
                               const float* feats, const uint32_t* masks, void* dy, int32_t dy_flags, const float* d_colors,
@@ -371,6 +371,11 @@ int vfn_mlp_bwd_chain_bf16_ws(const vfn_net_geom* vf_geom, const void* vf_packed
  * 0: [256][256], 1: [256][64], 2: [32][256], db_part [groups][256 | 256 | 32]) from such slots, split-bf16 products on
  * v_mfma_f32_32x32x16_bf16:
  *   dy_form 0 fragment fp32 | 1 fragment bf16 (no low half: two products per K-block) | 2 dz[M][4] fp32 rows (shape 2 only)
+ *           3 fragment SCALED f16: the 16 values lane L holds of tile t are f16(dY * 2^k), k chosen by the producer so that the
+ *             largest magnitude lies in [2^14, 2^15) (11 significant bits at any gradient scale); pieces where the bf16 form has
+ *             them, the byte k + 64 (255: all zero) at byte 16384 + 64 t + L of the group.  The kernel brings a slab's pieces to
+ *             one common scale and multiplies on v_mfma_f32_32x32x16_f16: one product per K-block with f16 activations (x_form 1),
+ *             two with fp32 ones (f16 hi + lo)
  *   x_form  0 fragment fp32 | 1 fragment f16 | 2 [M][256] fp32 rows (the features) | 3 the encoding tile aux[M][40] (shape 1 only)
  * Points past M in the last group count as zero. */
 int vfn_weight_grad_frag(int32_t shape, const void* dy, int32_t dy_form, const void* x, int32_t x_form, int64_t n_points,
