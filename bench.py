@@ -358,6 +358,9 @@ def main() -> None:
     ap.add_argument("--gradients", choices=("fp32", "f16", "bf16"), default=None,
                     help="training: storage of the pre-activation gradients between the dX chain and the weight-gradient kernels "
                          "(default: the model's)")
+    ap.add_argument("--sorted-fine-pass", action="store_true",
+                    help="training: the reference's call structure (gradient-free proposal pass, then the saving forward over all "
+                         "sorted samples) instead of one VF evaluation per distinct sample (backward.StoredFinePass)")
     ap.add_argument("--layout", choices=("fragment", "rows"), default=None,
                     help="training: workspace layout of the 16-bit path (default: the model's, fragment order)")
     ap.add_argument("--batch-statistics", action="store_true",
@@ -442,6 +445,7 @@ def main() -> None:
             model.workspace_layout = args.layout
         if args.batch_statistics:
             model.train()
+        model.reuse_proposal_training = not args.sorted_fine_pass
         train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync)
         return
 

@@ -20,6 +20,7 @@ def _hip_gradients(fx, d, model):
     for p in model.unique_parameters():
         p.grad = None
     model._keep_saved = True
+    model._debug_dst = None
     out = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
     a, b, c = (t.to("cuda:0") for t in loss_coefficients(*d["z_vals"].shape))
     loss = (out.coarse_rgb_values * a).sum() + (out.coarse_depth_map * b).sum() + (out.coarse_normals * c).sum()
@@ -54,6 +55,11 @@ def test_render_gradients(name, precision):
     # the masks the backward applied: the sign-bit words of the 16-bit path (exact: a positive activation below the f16 range
     # is stored as 0 with f16 storage but its unit is open), the saved values of the fp32 path (row-major [slots][M][256])
     open_units = lib.unpack_sign_words(model._debug_masks).cpu() if model._debug_masks is not None else model._debug_saved.cpu() > 0
+    if getattr(model, "_debug_dst", None) is not None:     # one VF evaluation per distinct sample: the workspace is in STORAGE order
+        dst = model._debug_dst.cpu().long()                 # (proposal samples, then the new ones); row r is sorted sample dst[r]
+        sorted_units = torch.empty_like(open_units)
+        sorted_units[:, dst] = open_units
+        open_units = sorted_units
     slots = list(range(8)) + list(range(9, 13))          # VF hidden 0..7, rendering hidden 0..3 (slot 8 = features)
     masks, flips = [], 0
     for slot, act in zip(slots, ref["_hidden"]):
@@ -543,3 +549,42 @@ def test_one_call_weight_gradients_equal_the_launch_by_launch_path(storage):
             assert torch.allclose(x, y, rtol=1e-4, atol=1e-6), name
         else:
             assert torch.equal(x, y), (name, float((x - y).abs().max()))
+
+
+@pytest.mark.parametrize("name", ["c1_perturb", "odd_orbit", "shipped_sizes"])
+def test_training_render_with_one_vf_evaluation_per_sample(name):
+    """backward.StoredFinePass (the activation-saving forward on the proposal samples first, on the new samples after the
+    sampler, one workspace in storage order) against the fused forward over the sorted samples with its separate gradient-free
+    proposal pass (``model.reuse_proposal_training = False``): every forward output bit-identical (same per-sample arithmetic,
+    same draws), parameter gradients equal up to the order of the sums over points (1e-5 of each tensor's largest entry; the
+    fixtures whose proposal block is not a multiple of 32 points fall back to the sorted path and must agree exactly)."""
+    fx, d = load_fixture(name)
+    g = {k: v.to("cuda:0") for k, v in d.items() if isinstance(v, torch.Tensor)}
+    uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add") if k in g}
+    a, b, c = (t.to("cuda:0") for t in loss_coefficients(*d["z_vals"].shape))
+    res = {}
+    for stored in (True, False):
+        model = build_model(fx, d, device="cuda:0")
+        model.gradient_storage = "fp32"                 # (the comparison is about the ORDER of the sums, not their storage)
+        model.reuse_proposal_training = stored
+        model._keep_saved, model._debug_dst = True, None
+        model.optimizer.zero_grad()
+        out = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
+        loss = (out.coarse_rgb_values * a).sum() + (out.coarse_depth_map * b).sum() + (out.coarse_normals * c).sum()
+        loss.backward()
+        grads = {f"{tag}.{n}": p.grad.detach().clone()
+                 for tag, mod in (("vf", model.vector_field_network), ("rn", model.rendering_network), ("density", model.density))
+                 for n, p in mod.named_parameters()}
+        res[stored] = (out, grads, model._debug_dst is not None)
+    (o1, g1, used), (o0, g0, _) = res[True], res[False]
+    n_rays, s_c = d["z_vals"].shape[0], fx["n_samples"]
+    assert used == ((n_rays * s_c) % 32 == 0), "the stored path runs when the proposal block is whole groups of 32 points"
+    for f in ("z_vals", "points_coarse", "coarse_normals", "coarse_colors", "coarse_rgb_values", "coarse_depth_map"):
+        assert torch.equal(getattr(o1, f), getattr(o0, f)), f
+    worst = 0.0
+    for k in g1:
+        scale = float(g0[k].abs().max())
+        err = float((g1[k] - g0[k]).abs().max()) / max(scale, 1e-30)
+        worst = max(worst, err)
+        assert err < (1e-5 if used else 1e-12) or k.startswith("density."), (k, err)
+    print(f"{name}: stored path used: {used}; worst gradient difference {worst:.2e}")

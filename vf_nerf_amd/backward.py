@@ -391,6 +391,118 @@ class _FinePass(torch.autograd.Function):
         return (None, None, None, None, *out)
 
 
+# ------------------------------------------------------------------------------------------------
+# fine pass of a training render() with ONE vector-field evaluation per distinct sample
+# ------------------------------------------------------------------------------------------------
+class StoredFinePass:
+    """The reference's training render evaluates the VF net on every proposal sample twice: without gradients for the proposal
+    weights (vector_field_nerf.py:252-277), then again among the S_c + N_f samples of the differentiated fine pass (:294-318).
+    The rendering net is pointwise and a proposal sample's inputs are complete before the fine sampler runs, so here the
+    activation-saving fused forward runs on the proposal samples FIRST (its normals feed the proposal weights), after the
+    sampler on the N_f new samples, both filling one workspace in storage order [proposal samples | new samples]; the results
+    are scattered to their sorted positions for the density / composite, and the backward gathers the per-sample gradients
+    back to storage order, where the chain and the weight-gradient kernels walk the workspace once — their sums over points
+    do not care about the order.  Same per-sample arithmetic as the fused launch over the sorted samples, so every forward
+    value is bit-identical; one 64-sample vector-only launch less per step."""
+
+    def __init__(self, model, n: int, s_c: int, n_f: int, dev) -> None:
+        vf, rn = model.vector_field_network, model.rendering_network
+        self.model, self.n, self.s_c, self.n_f = model, n, s_c, n_f
+        self.m_c, self.m = n * s_c, n * (s_c + n_f)
+        self.vf_h, self.rn_h = len(_entries(vf)), len(_entries(rn))
+        f16, frag, dy16 = _storage(model, True)
+        assert frag
+        self.ws = _Workspace(self.m, self.vf_h + self.rn_h, dev, f16=f16, frag=True, dy16=dy16)
+        self.normals_s = torch.empty(self.m, 3, device=dev)      # storage order
+        self.colors_s = torch.empty(self.m, 3, device=dev)
+
+    @staticmethod
+    def applicable(model, n: int, s_c: int, n_f: int) -> bool:
+        return bool(getattr(model, "reuse_proposal_training", True) and model.uses_f16x3() and model.workspace_layout == "fragment" and
+                    getattr(model, "backward_kernels", "auto") != "fp32" and (n * s_c) % 32 == 0 and
+                    0 < n * (s_c + n_f) < _F16_TRAIN_MAX_POINTS and not model.config.numerical_jacobian and
+                    model.rendering_network.config.detach_normals)
+
+    def _launch(self, pts, ray_dirs, per_ray: int, first: int, count: int) -> None:
+        model, ws = self.model, self.ws
+        vf, rn = model.vector_field_network, model.rendering_network
+        lib.vf_render_fused16_fwd_train(vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(), pts.reshape(-1, 3),
+                                        ray_dirs, per_ray, ws.saved, ws.aux_vf, ws.aux_rn, ws.masks, save_f16=ws.fwd_flags(),
+                                        ws_first=first, ws_points=self.m, normals=self.normals_s[first:first + count],
+                                        colors=self.colors_s[first:first + count])
+
+    def proposal(self, pts_c, ray_dirs) -> torch.Tensor:
+        """Saving forward on the proposal samples (generation order); returns their normals [N*S_c, 3]."""
+        self._launch(pts_c, ray_dirs, self.s_c, 0, self.m_c)
+        return self.normals_s[: self.m_c]
+
+    def finish(self, new_pts, dst, z, ray_dirs):
+        """Saving forward on the new samples, then the differentiable tail: (normals, colors, rgb, depth, weights), sorted."""
+        self._launch(new_pts, ray_dirs, self.n_f, self.m_c, self.m - self.m_c)
+        self.dst = dst
+        model = self.model
+        params = list(model.vector_field_network.parameters()) + list(model.rendering_network.parameters()) + list(model.density.parameters())
+        return _StoredFinePassFn.apply(self, z, ray_dirs, *params)
+
+
+class _StoredFinePassFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sp: "StoredFinePass", z, ray_dirs, *params):
+        model = sp.model
+        n, s_t, m = sp.n, sp.s_c + sp.n_f, sp.m
+        dev = z.device
+        normals = torch.empty(m, 3, device=dev)
+        colors = torch.empty(m, 3, device=dev)
+        lib.scatter_rows3(sp.normals_s, sp.colors_s, sp.dst, normals, colors)
+        scal = model.density.raw_scalars()
+        _, weights, _, rgb, depth = lib.ray_density_weights(model._density_params(), normals, ray_dirs, z, scal, colors=colors, want_sigma=False)
+        if getattr(model, "_keep_saved", False):   # test hook
+            model._debug_saved, model._debug_ws, model._debug_masks, model._debug_dst = sp.ws.saved, sp.ws, sp.ws.masks, sp.dst
+        ctx.sp, ctx.param_order = sp, list(params)
+        ctx.save_for_backward(normals, colors, z, ray_dirs, scal)
+        return normals, colors, rgb, depth, weights
+
+    @staticmethod
+    def backward(ctx, d_normals, d_colors_direct, d_rgb, d_depth, d_weights):
+        sp = ctx.sp
+        model, ws = sp.model, sp.ws
+        n, s_t, m, vf_h, rn_h = sp.n, sp.s_c + sp.n_f, sp.m, sp.vf_h, sp.rn_h
+        normals, colors, z, ray_dirs, scal = ctx.saved_tensors
+        vf, rn = model.vector_field_network, model.rendering_network
+        dev = normals.device
+
+        def cont(t, shape):
+            return None if t is None else t.reshape(shape).float().contiguous()
+
+        # (1) per-ray backward on the SORTED samples
+        dn = torch.zeros(m, 3, device=dev) if d_normals is None else d_normals.reshape(m, 3).float().clone()
+        dc = torch.empty(m, 3, device=dev)
+        dscal = torch.zeros(3, device=dev)
+        lib.ray_density_weights_bwd(model._density_params(), normals, ray_dirs, z, scal, colors, cont(d_rgb, (n, 3)),
+                                    cont(d_depth, (n,)), cont(d_weights, (n, s_t)), dn, dc, dscal)
+        if d_colors_direct is not None:
+            dc = dc + d_colors_direct.reshape(m, 3)
+        # ... gathered to storage order: row r of the workspace is sorted sample dst[r]
+        idx = sp.dst.long()
+        dn_s, dc_s = dn.index_select(0, idx), dc.index_select(0, idx)
+        # (2) dX chain over the workspace, (3) weight gradients
+        dy = ws.new_dy()
+        dz_rgb = torch.empty(m, 4, device=dev)
+        dz_vec = torch.empty(m, 4, device=dev)
+        lib.mlp_bwd_chain_bf16_ws(vf.geometry(), _packed_bwd16(vf), _head_rows(vf), rn.geometry(), _packed_bwd16(rn), _head_rows(rn),
+                                  ws.feats(vf_h - 1), ws.masks, dy, ws.dy_flags(), dc_s, sp.colors_s, dn_s, sp.normals_s, None, 3, m, dz_rgb, dz_vec)
+        feats = ws.feats(vf_h - 1)
+        g_vf = _weight_grads(vf, _vf_inputs(vf, [ws.saved[h] for h in range(vf_h)]), [dy[h] for h in range(vf_h)],
+                             ws.aux_vf, dz_vec, m, fast=True, x_f16=ws.f16, frag=ws.frag_forms(), ws_ref=(ws.saved, dy, 0))
+        g_rn = _weight_grads(rn, _rn_inputs(feats, [ws.saved[vf_h + h] for h in range(rn_h)]),
+                             [dy[vf_h + h] for h in range(rn_h)], ws.aux_rn, dz_rgb, m, fast=True, x_f16=ws.f16,
+                             x_fp32_entries=(0,), frag=ws.frag_forms(), ws_ref=(ws.saved, dy, vf_h))
+        by_name = {"beta": dscal[0], "mean": dscal[1], "scale": dscal[2]}
+        g_den = {p: by_name[name].reshape(p.shape) for name, p in model.density.named_parameters()}
+        sp.ws = None
+        return (None, None, None, *[g_vf.get(p, g_rn.get(p, g_den.get(p))) for p in ctx.param_order])
+
+
 def fine_pass_autograd(model, pts, z, ray_dirs):
     params = list(model.vector_field_network.parameters()) + list(model.rendering_network.parameters()) + \
         list(model.density.parameters())

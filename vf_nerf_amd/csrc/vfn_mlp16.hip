@@ -377,6 +377,8 @@ struct Mlp16Args {
     const float* vec_in;      // M16_BLKIN: [rows,3] vector outputs of the feature launches
     const int* src;           // M16_BLKIN: [rows] position of every row among the sorted samples (< 0: padding row)
     const int* out_index;     // fused launches, optional: outputs of point m go to row out_index[m] (< 0: dropped) instead of m
+    long long ws_first, ws_points;   // training modes: this launch's points are points ws_first .. of a workspace sized for ws_points
+                                     // (one workspace filled by several launches: the proposal samples, then the new fine samples)
     uint32_t* status;         // optional (vfn_f16x3_set_status): bit 0 is OR-ed in when a hidden activation reached the f16 clamp,
                               // bit 1 when an input (point coordinate / encoding operand) did — the result of such a launch is not
                               // fp32-equivalent and the caller should repeat it on the exact-fp32 kernels
@@ -973,15 +975,16 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
                                                (int)((MODE & M16_RENDER) ? a.rn_bytes : a.vf_bytes), 0x00020000);
     const bool frag = (a.save_f16 & 2) != 0;          // fragment-ordered slots: groups of 32 points, 32 KiB each
     p.saved = a.saved;
-    p.slot_floats = frag ? ((a.n_points + 31) >> 5) * 8192 : a.n_points * 256;
+    const long long mw = m + a.ws_first;              // this point's place in the workspace
+    p.slot_floats = frag ? ((a.ws_points + 31) >> 5) * 8192 : a.ws_points * 256;
     p.slot_bytes = (uint32_t)(p.slot_floats * 4);
     // rows past the end get an offset beyond the descriptor's range (the store is dropped).  Fragment order adds scalar
     // offsets of up to 32 KiB to it, so that value must not wrap: 3 GiB, with slots limited to 2 GiB (the host checks)
-    p.save_voff = !in ? (frag ? 0xc0000000u : 0xfffffff0u) : (frag ? (uint32_t)((m >> 5) * 32768 + lane * 16) : (uint32_t)(m * 1024 + g * 16));
-    p.save_voff16 = !in ? (frag ? 0xc0000000u : 0xfffffff0u) : (frag ? (uint32_t)((m >> 5) * 32768 + lane * 8) : (uint32_t)(m * 1024 + g * 8));
-    p.feat_voff = in ? (uint32_t)(m * 1024 + g * 16) : 0xfffffff0u;
+    p.save_voff = !in ? (frag ? 0xc0000000u : 0xfffffff0u) : (frag ? (uint32_t)((mw >> 5) * 32768 + lane * 16) : (uint32_t)(mw * 1024 + g * 16));
+    p.save_voff16 = !in ? (frag ? 0xc0000000u : 0xfffffff0u) : (frag ? (uint32_t)((mw >> 5) * 32768 + lane * 8) : (uint32_t)(mw * 1024 + g * 8));
+    p.feat_voff = in ? (uint32_t)(mw * 1024 + g * 16) : 0xfffffff0u;
     p.st_tile = frag ? 4096u : 128u; p.st_q = frag ? 1024u : 32u;
-    p.masks = a.save_masks; p.mask_bytes = (uint32_t)(a.n_points * 32); p.mask_voff = in ? (uint32_t)((2 * m + g) * 16) : 0xfffffff0u;
+    p.masks = a.save_masks; p.mask_bytes = (uint32_t)(a.ws_points * 32); p.mask_voff = in ? (uint32_t)((2 * mw + g) * 16) : 0xfffffff0u;
     p.save16 = a.save_f16 & 1;
     p.blk_out = a.blk_out; p.blk_bytes = (uint32_t)(((a.n_points + 31) & ~31ll) * 1024);
     p.blk_voff = (uint32_t)((m >> 5) * 32768 + lane * 16);      // past the last group -> out of the descriptor's range, dropped
@@ -1003,7 +1006,7 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
         float sn[18], cs[18];
         encode_sincos(x, vf_multires, g, sn, cs);
         build_aux(aux, g, [&](int k) { return enc_value(x, sn, cs, vf_multires, k); }, ain);
-        if ((MODE & M16_TRAIN) && in) save_aux(a.save_aux_vf, m, g, [&](int k) { return enc_value(x, sn, cs, vf_multires, k); });
+        if ((MODE & M16_TRAIN) && in) save_aux(a.save_aux_vf, mw, g, [&](int k) { return enc_value(x, sn, cs, vf_multires, k); });
         half8* pk = reinterpret_cast<half8*>(s_park + 8);
 #pragma unroll
         for (int q = 0; q < 3; ++q) { pk[2 * q] = aux.hi[q]; pk[2 * q + 1] = aux.lo[q]; }
@@ -1059,7 +1062,7 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     const float xr[3] = {s_park[0], s_park[1], s_park[2]};
     const float dr[3] = {s_park[4], s_park[5], s_park[6]};
     A16 raux;
-    render_aux<MODE>(a, raux, xr, dr, nrm, m, in, g, ain);
+    render_aux<MODE>(a, raux, xr, dr, nrm, (MODE & M16_TRAIN) ? mw : m, in, g, ain);
     render_tail<MODE>(a, p, cy, xa, xb, raux, nrm, a.out_index ? (long long)out_row : m, a.out_index ? out_row >= 0 : in, wave, lane);
     report_range(a, cy.sat, ain);
     const long long mo = (long long)blockIdx.x * VFN16_PTS + (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
@@ -1241,6 +1244,7 @@ extern "C" int vfn_vf_mlp16_fwd_train(const vfn_net_geom* geom, const void* pack
     a.vf_w = (const uint4*)packed16; a.points = points; a.out_vec = out_vec; a.n_points = n_points; a.dirs_div = 1;
     a.vf_multires = vf.multires; a.vf_bytes = vf.total_kb * 1024u; a.saved = saved; a.save_aux_vf = save_aux_vf;
     a.save_masks = save_masks; a.save_f16 = save_f16 & 3;
+    a.ws_first = 0; a.ws_points = n_points;
     a.status = t_status_word;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     if (with_features) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_FULL_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
@@ -1253,6 +1257,15 @@ extern "C" int vfn_vf_render_fused16_fwd_train(const vfn_net_geom* vf_geom, cons
                                                int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
                                                float* saved, float* save_aux_vf, float* save_aux_rn, uint32_t* save_masks,
                                                int32_t save_f16, void* stream) {
+    return vfn_vf_render_fused16_fwd_train_at(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, n_points, samples_per_ray, normals, colors,
+                                              saved, save_aux_vf, save_aux_rn, save_masks, save_f16, 0, n_points, stream);
+}
+
+extern "C" int vfn_vf_render_fused16_fwd_train_at(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
+                                                  const void* rn_packed16, const float* points, const float* ray_dirs,
+                                                  int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
+                                                  float* saved, float* save_aux_vf, float* save_aux_rn, uint32_t* save_masks,
+                                                  int32_t save_f16, int64_t ws_first, int64_t ws_points, void* stream) {
     Mlp16Args a = {};
     VfnNetPlan p32; Plan16 vf, rn;
     int rc = make_plan16(VFN_NET_VF, vf_geom, &p32, &vf, "vfn_vf_render_fused16_fwd_train");
@@ -1267,8 +1280,12 @@ extern "C" int vfn_vf_render_fused16_fwd_train(const vfn_net_geom* vf_geom, cons
     VFN_REQUIRE(vf_packed16 && rn_packed16 && points && ray_dirs && normals && colors && saved && save_aux_vf && save_aux_rn && save_masks,
                 "vfn_vf_render_fused16_fwd_train: NULL argument");
     VFN_REQUIRE(samples_per_ray > 0, "vfn_vf_render_fused16_fwd_train: samples_per_ray must be > 0");
-    VFN_REQUIRE(n_points < ((save_f16 & 2) ? (1ll << 21) : (1ll << 22)), "vfn_vf_render_fused16_fwd_train: at most %lld points per launch (32-bit slot offsets)",
+    VFN_REQUIRE(ws_first >= 0 && ws_first + n_points <= ws_points, "vfn_vf_render_fused16_fwd_train: points %lld .. %lld outside a workspace of %lld",
+                (long long)ws_first, (long long)(ws_first + n_points), (long long)ws_points);
+    VFN_REQUIRE(!(save_f16 & 2) || ws_first % 32 == 0, "vfn_vf_render_fused16_fwd_train: ws_first must be a multiple of 32 in fragment order");
+    VFN_REQUIRE(ws_points < ((save_f16 & 2) ? (1ll << 21) : (1ll << 22)), "vfn_vf_render_fused16_fwd_train: at most %lld points per workspace (32-bit slot offsets)",
                 ((save_f16 & 2) ? (1ll << 21) : (1ll << 22)) - 1);
+    a.ws_first = ws_first; a.ws_points = ws_points;
     a.vf_w = (const uint4*)vf_packed16; a.rn_w = (const uint4*)rn_packed16; a.points = points; a.ray_dirs = ray_dirs;
     a.out_vec = normals; a.out_colors = colors; a.n_points = n_points; a.dirs_div = samples_per_ray;
     a.vf_multires = vf.multires; a.rn_multires = rn.multires; a.vf_bytes = vf.total_kb * 1024u; a.rn_bytes = rn.total_kb * 1024u;

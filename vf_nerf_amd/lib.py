@@ -30,7 +30,7 @@ EXPORTS = (
     "vfn_grid_unify_direction", "vfn_grid_comb_format", "vfn_weight_grad_partials_bf16", "vfn_unfold_weight_grads", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
     "vfn_linear_rows", "vfn_linear_rows_stat_parts", "vfn_bstat_row_parts", "vfn_colsum_finish", "vfn_bstat_finalize",
     "vfn_bstat_relu_rows", "vfn_bstat_relu_bwd_sums", "vfn_bstat_relu_bwd_rows", "vfn_act_bwd_rows", "vfn_embed_rows",
-    "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_vf_render_fused16_products", "vfn_net_weight_grads_frag", "vfn_net_weight_grads_scratch_bytes",
+    "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_vf_render_fused16_products", "vfn_net_weight_grads_frag", "vfn_net_weight_grads_scratch_bytes", "vfn_vf_render_fused16_fwd_train_at",
     "vfn_weight_grad_groups", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax",
     "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step", "vfn_unfold_weight_grads_acc", "vfn_render_fwd", "vfn_render_fwd_workspace_bytes",
 )
@@ -808,18 +808,22 @@ def vf_mlp16_fwd_train(geom: NetGeom, packed16, points, with_features: bool, sav
 
 
 def vf_render_fused16_fwd_train(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, samples_per_ray, saved,
-                                aux_vf, aux_rn, masks, save_f16: int = 0):
+                                aux_vf, aux_rn, masks, save_f16: int = 0, ws_first: int = 0, ws_points: Optional[int] = None,
+                                normals=None, colors=None):
+    """``ws_first`` / ``ws_points``: the launch fills points ws_first .. of a workspace sized for ws_points points (default: the
+    whole workspace = this launch's points).  ``normals`` / ``colors``: optional [m,3] outputs to write into."""
     m = points.shape[0]
     dev = points.device
-    normals = torch.empty(m, 3, device=dev)
-    colors = torch.empty(m, 3, device=dev)
-    _check(load().vfn_vf_render_fused16_fwd_train(C.byref(vf_geom), _ptr(vf_packed16, "vf_packed16", torch.uint8),
-                                                  C.byref(rn_geom), _ptr(rn_packed16, "rn_packed16", torch.uint8),
-                                                  _ptr(points, "points"), _ptr(ray_dirs, "ray_dirs"), C.c_int64(m),
-                                                  C.c_int32(samples_per_ray), _ptr(normals, "normals"),
-                                                  _ptr(colors, "colors"), _ptr(saved, "saved"), _ptr(aux_vf, "aux_vf"),
-                                                  _ptr(aux_rn, "aux_rn"), _ptr(masks, "masks", torch.int32),
-                                                  C.c_int32(int(save_f16)), _stream()), "vfn_vf_render_fused16_fwd_train")
+    normals = torch.empty(m, 3, device=dev) if normals is None else normals
+    colors = torch.empty(m, 3, device=dev) if colors is None else colors
+    _check(load().vfn_vf_render_fused16_fwd_train_at(C.byref(vf_geom), _ptr(vf_packed16, "vf_packed16", torch.uint8),
+                                                     C.byref(rn_geom), _ptr(rn_packed16, "rn_packed16", torch.uint8),
+                                                     _ptr(points, "points"), _ptr(ray_dirs, "ray_dirs"), C.c_int64(m),
+                                                     C.c_int32(samples_per_ray), _ptr(normals, "normals"),
+                                                     _ptr(colors, "colors"), _ptr(saved, "saved"), _ptr(aux_vf, "aux_vf"),
+                                                     _ptr(aux_rn, "aux_rn"), _ptr(masks, "masks", torch.int32),
+                                                     C.c_int32(int(save_f16)), C.c_int64(ws_first), C.c_int64(m if ws_points is None else ws_points),
+                                                     _stream()), "vfn_vf_render_fused16_fwd_train")
     return normals, colors
 
 

@@ -518,6 +518,10 @@ class VectorFieldNerf:
 
         # inference with the f16x3 kernels: evaluate the VF net once per distinct sample (see ``reuse_proposal``)
         reuse = self.reuse_proposal and self.uses_f16x3() and not self._needs_grad() and n * (s_c + n_f) < (1 << 22)
+        # with gradients: the activation-saving forward on the proposal samples first, on the new samples after the sampler, one
+        # workspace in storage order (backward.StoredFinePass)
+        from .backward import StoredFinePass
+        train_reuse = self.reuse_proposal and self._needs_grad() and StoredFinePass.applicable(self, n, s_c, n_f)
 
         with torch.no_grad():
             # (1)-(2) rays + proposal samples
@@ -536,6 +540,9 @@ class VectorFieldNerf:
                     normals_c, colors_c = lib.vf_render_fused16_fwd(vf.geometry(), vf.packed16_weights(), rn.geometry(),
                                                                     rn.packed16_weights(), pts_c.view(-1, 3), ray_dirs, s_c,
                                                                     colour_products=self.colour_products)
+            elif train_reuse:
+                stored = StoredFinePass(self, n, s_c, n_f, dev)
+                normals_c = stored.proposal(pts_c, ray_dirs)
             elif self.uses_f16x3():
                 normals_c = lib.vf_mlp16_fwd(vf.geometry(), vf.packed16_weights(), pts_c.view(-1, 3))
             else:
@@ -551,7 +558,7 @@ class VectorFieldNerf:
             u_fine = draw("u_fine", (n, n_f), perturb_f)
             u_add = draw("u_add", (n, n_f), True)
             far, far_t = self._far_args(self.fine_sampler.far)
-            if reuse:
+            if reuse or train_reuse:
                 z, pts, _, new_pts, dst = lib.range_fine_sample_indexed(z_c, imax, directions, cam_loc, n_f, self.fine_sampler.near,
                                                                         far, self.fine_sampler.range, u_add, u_fine, far_t,
                                                                         want_dst=True)
@@ -572,6 +579,10 @@ class VectorFieldNerf:
                 lib.scatter_rows3(normals_c, colors_c, dst[:m_c], normals, colors)
                 _, weights, _, rgb, depth = lib.ray_density_weights(self._density_params(), normals, ray_dirs, z, scal,
                                                                     colors=colors, want_sigma=False)
+        elif train_reuse:
+            # (7)-(11) under autograd: the new samples join the proposal samples in the workspace; density + composite on the
+            # sorted results; the backward walks the workspace once
+            normals, colors, rgb, depth, weights = stored.finish(new_pts, dst, z, ray_dirs)
         else:
             # (7)-(11) fine pass: VF net + rendering net + density + composite
             normals, colors, rgb, depth, weights = fine_pass(self, pts, z, ray_dirs)
