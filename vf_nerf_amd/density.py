@@ -39,9 +39,18 @@ class LaplaceDensity(nn.Module):
         return torch.clamp(self.mean, self.mean_bounds[0].to(self.mean.device), self.mean_bounds[1].to(self.mean.device))
 
     def raw_scalars(self) -> torch.Tensor:
-        """[beta, mean, scale] as one device tensor (the kernel clamps them itself)."""
+        """[beta, mean, scale] as one device tensor (the kernel clamps them itself).  Cached on the parameters' (address,
+        version); an optimizer that writes through raw pointers calls ``_invalidate_scalars`` (VectorFieldNerf._invalidate_packs)."""
         scale = self.scale if hasattr(self, 'scale') else 1 / self.get_beta()
-        return torch.stack([self.beta.detach(), self.mean.detach(), scale.detach()]).float().contiguous()
+        key = tuple((t.data_ptr(), t._version) for t in (self.beta, self.mean, scale)) + (getattr(self, "_scalars_epoch", 0),)
+        cache = getattr(self, "_scalars_cache", None)
+        if cache is None or cache[0] != key or not hasattr(self, 'scale'):
+            cache = (key, torch.stack([self.beta.detach(), self.mean.detach(), scale.detach()]).float().contiguous())
+            self._scalars_cache = cache
+        return cache[1]
+
+    def _invalidate_scalars(self) -> None:
+        self._scalars_epoch = getattr(self, "_scalars_epoch", 0) + 1
 
     def forward(self, input: torch.Tensor, beta=None, scale=None, mean=None, cutoff: float = -0.5) -> torch.Tensor:
         """Element-wise density of a [M,1] tensor: a thin tensor-op path kept for API parity (the hot path

@@ -227,6 +227,7 @@ class VectorFieldNerf:
     def _invalidate_packs(self) -> None:
         self.vector_field_network._invalidate_packs()
         self.rendering_network._invalidate_packs()
+        self.density._invalidate_scalars()
 
     def _new_schedule(self, num_steps: int) -> None:
         sc = self.config.scheduler_config
@@ -644,6 +645,7 @@ class VectorFieldNerf:
             if self.config.numerical_jacobian:
                 vf.packed_weights()
         self._linspace(self.ray_sampler.N_samples, dev)
+        self.density.raw_scalars()
 
     def _render_training_mode(self, pose, pixels, intrinsics, epoch: int, white: bool, uniforms) -> NerfOutput:
         """render() with a network in training mode (after ``train()``, vector_field_nerf.py:139-150): BatchNorm normalises
