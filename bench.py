@@ -358,6 +358,8 @@ def main() -> None:
     ap.add_argument("--gradients", choices=("fp32", "f16", "bf16"), default=None,
                     help="training: storage of the pre-activation gradients between the dX chain and the weight-gradient kernels "
                          "(default: the model's)")
+    ap.add_argument("--train-colour-products", type=int, choices=(2, 3), default=None,
+                    help="training: products of the colour branch in the activation-saving forward (default: the model's, 3)")
     ap.add_argument("--sorted-fine-pass", action="store_true",
                     help="training: the reference's call structure (gradient-free proposal pass, then the saving forward over all "
                          "sorted samples) instead of one VF evaluation per distinct sample (backward.StoredFinePass)")
@@ -446,6 +448,8 @@ def main() -> None:
         if args.batch_statistics:
             model.train()
         model.reuse_proposal_training = not args.sorted_fine_pass
+        if args.train_colour_products:
+            model.training_colour_products = args.train_colour_products
         train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync)
         return
 

@@ -495,12 +495,14 @@ int vfn_vf_render_fused16_fwd_train(const vfn_net_geom* vf_geom, const void* vf_
  * ws_first + n_points - 1 of every slot, of the sign-bit words and of the encoding tiles (outputs normals / colors stay
  * launch-local, [n_points,3]).  A training render evaluates the vector-field net once per distinct sample this way: the proposal
  * samples (vector_field_nerf.py:252-256) and, after the fine sampler, the new samples (:294-297) fill ONE workspace in storage
- * order, which the chain and the weight-gradient kernels then walk once.  ws_first % 32 == 0 in fragment order. */
+ * order, which the chain and the weight-gradient kernels then walk once.  ws_first % 32 == 0 in fragment order.
+ * colour_products: 3, or 2 = the colour branch of THIS forward on two products (vfn_vf_render_fused16_products): the loss sees
+ * colours 2e-5 off, the saved activations move by less than their f16 storage rounds them, the backward is unchanged. */
 int vfn_vf_render_fused16_fwd_train_at(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
                                        const void* rn_packed16, const float* points, const float* ray_dirs,
                                        int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
                                        float* saved, float* save_aux_vf, float* save_aux_rn, uint32_t* save_masks,
-                                       int32_t save_f16, int64_t ws_first, int64_t ws_points, void* stream);
+                                       int32_t save_f16, int64_t ws_first, int64_t ws_points, int32_t colour_products, void* stream);
 
 /* =============================================================================================
  * Dense-grid stages between the vector-field queries and the mesh triangulation (evaluation/utils/mc_utils.py,

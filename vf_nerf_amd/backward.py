@@ -296,6 +296,12 @@ class _Workspace:
         return lib.frag_to_rows(self.saved[h], self.m, torch.float16 if self.f16 else torch.float32)
 
 
+def _train_products(model) -> int:
+    """f16 products per fp32-equivalent product in the colour branch of an activation-saving forward (``training_colour_products``,
+    default 3; 2 only while the inference setting is 2 as well — the guard's colour self-check speaks for both)."""
+    return 2 if (getattr(model, "training_colour_products", 3) == 2 and getattr(model, "colour_products", 3) == 2) else 3
+
+
 def _storage(owner, fast: bool):
     """(f16 activations, fragment order, 16-bit gradient form or None) for a 16-bit training forward of ``owner`` (model or VF net)."""
     if not fast:
@@ -326,7 +332,8 @@ class _FinePass(torch.autograd.Function):
         if fast:                                               # split-half products, fp32-equivalent (csrc/vfn_mlp16.hip)
             normals, colors = lib.vf_render_fused16_fwd_train(vf.geometry(), vf.packed16_weights(), rn.geometry(),
                                                               rn.packed16_weights(), pts.reshape(-1, 3), ray_dirs, s_t,
-                                                              ws.saved, ws.aux_vf, ws.aux_rn, ws.masks, save_f16=ws.fwd_flags())
+                                                              ws.saved, ws.aux_vf, ws.aux_rn, ws.masks, save_f16=ws.fwd_flags(),
+                                                              colour_products=_train_products(model))
         else:
             normals, colors = lib.vf_render_fused_fwd_train(vf.geometry(), vf.packed_weights(), rn.geometry(),
                                                             rn.packed_weights(), pts.reshape(-1, 3), ray_dirs, s_t,
@@ -429,7 +436,7 @@ class StoredFinePass:
         lib.vf_render_fused16_fwd_train(vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(), pts.reshape(-1, 3),
                                         ray_dirs, per_ray, ws.saved, ws.aux_vf, ws.aux_rn, ws.masks, save_f16=ws.fwd_flags(),
                                         ws_first=first, ws_points=self.m, normals=self.normals_s[first:first + count],
-                                        colors=self.colors_s[first:first + count])
+                                        colors=self.colors_s[first:first + count], colour_products=_train_products(model))
 
     def proposal(self, pts_c, ray_dirs) -> torch.Tensor:
         """Saving forward on the proposal samples (generation order); returns their normals [N*S_c, 3]."""

@@ -1258,14 +1258,15 @@ extern "C" int vfn_vf_render_fused16_fwd_train(const vfn_net_geom* vf_geom, cons
                                                float* saved, float* save_aux_vf, float* save_aux_rn, uint32_t* save_masks,
                                                int32_t save_f16, void* stream) {
     return vfn_vf_render_fused16_fwd_train_at(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, n_points, samples_per_ray, normals, colors,
-                                              saved, save_aux_vf, save_aux_rn, save_masks, save_f16, 0, n_points, stream);
+                                              saved, save_aux_vf, save_aux_rn, save_masks, save_f16, 0, n_points, 3, stream);
 }
 
 extern "C" int vfn_vf_render_fused16_fwd_train_at(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
                                                   const void* rn_packed16, const float* points, const float* ray_dirs,
                                                   int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,
                                                   float* saved, float* save_aux_vf, float* save_aux_rn, uint32_t* save_masks,
-                                                  int32_t save_f16, int64_t ws_first, int64_t ws_points, void* stream) {
+                                                  int32_t save_f16, int64_t ws_first, int64_t ws_points, int32_t colour_products,
+                                                  void* stream) {
     Mlp16Args a = {};
     VfnNetPlan p32; Plan16 vf, rn;
     int rc = make_plan16(VFN_NET_VF, vf_geom, &p32, &vf, "vfn_vf_render_fused16_fwd_train");
@@ -1292,6 +1293,8 @@ extern "C" int vfn_vf_render_fused16_fwd_train_at(const vfn_net_geom* vf_geom, c
     a.saved = saved; a.save_aux_vf = save_aux_vf; a.save_aux_rn = save_aux_rn; a.save_masks = save_masks; a.save_f16 = save_f16 & 3;
     a.status = t_status_word;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
-    hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    VFN_REQUIRE(colour_products == 2 || colour_products == 3, "vfn_vf_render_fused16_fwd_train: colour_products must be 2 or 3 (got %d)", colour_products);
+    if (colour_products == 2) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED_TRAIN | M16_C2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_render_fused16_fwd_train");
 }

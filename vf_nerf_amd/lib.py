@@ -809,7 +809,7 @@ def vf_mlp16_fwd_train(geom: NetGeom, packed16, points, with_features: bool, sav
 
 def vf_render_fused16_fwd_train(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, samples_per_ray, saved,
                                 aux_vf, aux_rn, masks, save_f16: int = 0, ws_first: int = 0, ws_points: Optional[int] = None,
-                                normals=None, colors=None):
+                                normals=None, colors=None, colour_products: int = 3):
     """``ws_first`` / ``ws_points``: the launch fills points ws_first .. of a workspace sized for ws_points points (default: the
     whole workspace = this launch's points).  ``normals`` / ``colors``: optional [m,3] outputs to write into."""
     m = points.shape[0]
@@ -823,7 +823,7 @@ def vf_render_fused16_fwd_train(vf_geom, vf_packed16, rn_geom, rn_packed16, poin
                                                      _ptr(colors, "colors"), _ptr(saved, "saved"), _ptr(aux_vf, "aux_vf"),
                                                      _ptr(aux_rn, "aux_rn"), _ptr(masks, "masks", torch.int32),
                                                      C.c_int32(int(save_f16)), C.c_int64(ws_first), C.c_int64(m if ws_points is None else ws_points),
-                                                     _stream()), "vfn_vf_render_fused16_fwd_train")
+                                                     C.c_int32(colour_products), _stream()), "vfn_vf_render_fused16_fwd_train")
     return normals, colors
 
 
