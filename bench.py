@@ -238,17 +238,18 @@ def grid_bench(args, dev, rank, world, dist, sync):
         dist.destroy_process_group()
 
 
-def train_step_accounting(n_rays, s_c, s_t, n_sup, storage, gradients="fp32"):
+def train_step_accounting(n_rays, s_c, s_t, n_sup, storage, gradients="fp32", separate_proposal=False):
     """ALGORITHMIC work and workspace traffic of one training step (DESIGN.md section 3 "Backward").
-    FLOPs: the proposal pass (VF, S_c samples) + the fine pass forward and twice that for its backward (VF + rendering,
-    S_t samples) + forward and backward of the 2 x n_sup supervision points through the VF net.
+    FLOPs: the fine pass forward and twice that for its backward (VF + rendering, S_t samples) + forward and backward of the
+    2 x n_sup supervision points through the VF net (+ the reference's separate vector-only proposal pass over the S_c samples
+    only when it is actually run: with one VF evaluation per distinct sample the proposal samples are part of the fine pass).
     Bytes: what the kernels of the 16-bit path have to move through HBM per step — the saved activations (13 slots per fine
     point, 9 per supervision point; 1 KiB per slot and point as fp32, 512 B as f16 except the tanh'ed feature slot), their
     sign-bit words (32 B), the pre-activation gradients dY (1 KiB per slot and point, written by the chain, read by the
     weight-gradient kernels), the saved activations read once by the weight-gradient kernels, and the per-sample inputs and
     outputs (point, normal, colour, their gradients)."""
     m_f, m_s = n_rays * s_t, 2 * n_sup
-    flops = 2.0 * (n_rays * s_c * VF_MACS + 3.0 * m_f * (VF_MACS + RN_MACS) + 3.0 * m_s * VF_MACS)
+    flops = 2.0 * ((n_rays * s_c * VF_MACS if separate_proposal else 0.0) + 3.0 * m_f * (VF_MACS + RN_MACS) + 3.0 * m_s * VF_MACS)
     relu_slot = 512 if storage == "f16" else 1024
     saved = m_f * (12 * relu_slot + 1024) + m_s * (8 * relu_slot + 1024)      # written by the forward ...
     masks = 32 * (13 * m_f + 9 * m_s)
@@ -306,7 +307,10 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    flops, ws_bytes = train_step_accounting(args.rays, args.coarse, s_t, n_sup, model.activation_storage, model.gradient_storage)
+    from vf_nerf_amd.backward import StoredFinePass
+    stored = model.reuse_proposal and StoredFinePass.applicable(model, args.rays, args.coarse, s_t - args.coarse)
+    flops, ws_bytes = train_step_accounting(args.rays, args.coarse, s_t, n_sup, model.activation_storage, model.gradient_storage,
+                                            separate_proposal=not stored)
     ms = elapsed / args.steps * 1e3
     rec = {"metric": "training rays/sec (4096-ray batch, 128 samples/ray, fwd+bwd+clip+Adam)",
            "value": round(args.rays * args.steps * world / elapsed, 1), "unit": "rays/s", "n_gpus": world,
