@@ -373,7 +373,7 @@ int vfn_mlp_bwd_chain_bf16_ws(const vfn_net_geom* vf_geom, const void* vf_packed
  *   dy_form 0 fragment fp32 | 1 fragment bf16 (no low half: two products per K-block) | 2 dz[M][4] fp32 rows (shape 2 only)
  *           3 fragment SCALED f16: the 16 values lane L holds of tile t are f16(dY * 2^k), k chosen by the producer so that the
  *             largest magnitude lies in [2^14, 2^15) (11 significant bits at any gradient scale); pieces where the bf16 form has
- *             them, the byte k + 64 (255: all zero) at byte 16384 + 64 t + L of the group.  The kernel brings a slab's pieces to
+ *             them, the byte k + 113 (255: all zero) at byte 16384 + 64 t + L of the group.  The kernel brings a slab's pieces to
  *             one common scale and multiplies on v_mfma_f32_32x32x16_f16: one product per K-block with f16 activations (x_form 1),
  *             two with fp32 ones (f16 hi + lo)
  *   x_form  0 fragment fp32 | 1 fragment f16 | 2 [M][256] fp32 rows (the features) | 3 the encoding tile aux[M][40] (shape 1 only)

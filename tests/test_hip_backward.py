@@ -591,3 +591,32 @@ def test_training_render_with_one_vf_evaluation_per_sample(name):
         worst = max(worst, err)
         assert err < (1e-5 if used else 1e-12) or k.startswith("density."), (k, err)
     print(f"{name}: stored path used: {used}; worst gradient difference {worst:.2e}")
+
+
+@pytest.mark.parametrize("scale", [1e-30, 1e-12, 1e-5, 1.0, 1e12, 1e25, 1e33])
+def test_scaled_f16_gradients_at_any_magnitude(scale):
+    """dY form 3 (csrc/vfn_dwf.hip) carries its own power-of-two scale per lane and tile, so the weight gradient it yields must
+    be as accurate for gradients of 1e-30 as for gradients of 1e+25 (a batch-mean loss puts dY far below the f16 range; nothing
+    bounds it from above either), with rows of wildly different magnitude in one slab, all-zero tiles and all-zero points."""
+    from vf_nerf_amd import lib
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(11)
+    m, groups = 3000, 9
+    dy = torch.randn(m, 256, generator=gen) * torch.logspace(-3, 0, 256)[None, :] * torch.logspace(0, -4, m)[:, None]
+    dy[:, 64:96] = 0                       # an all-zero tile everywhere
+    dy[100:164] = 0                        # two all-zero groups
+    dy = (dy * scale).to(dev)
+    x = (torch.relu(torch.randn(m, 256, generator=gen)) * 3).to(dev)
+    slot = lib.rows_to_frag_f16s(dy)
+    held = lib.frag_f16s_to_rows(slot, m)
+    assert float((held - dy).abs().max() / dy.abs().max()) < 2 ** -11
+    part = torch.full((groups, 256, 256), float("nan"), device=dev)
+    dbp = torch.full((groups, 256), float("nan"), device=dev)
+    lib.weight_grad_frag(0, slot, lib.DYF_FRAGF16S, lib.rows_to_frag(x, torch.float16), lib.XF_FRAG16, m, groups, part, dbp)
+    want = held.double().T @ x.half().double()
+    got = part.sum(0).double()
+    assert torch.isfinite(got).all()
+    err = float((got - want).abs().max() / want.abs().max())
+    print(f"scale {scale:g}: dW error {err:.2e} of the largest entry")
+    assert err < 1e-5
+    assert float((dbp.sum(0).double() - held.double().sum(0)).abs().max() / held.double().sum(0).abs().max()) < 1e-5

@@ -242,14 +242,14 @@ __device__ __forceinline__ f32x4v mask_group(const Pipe& p, int q) {
     }
 }
 typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
-// scaled f16: the exponent byte (k + 64) and the scale 2^k of this lane's 16 values of a tile, max |v| 2^k in [2^14, 2^15)
+// scaled f16: the exponent byte (k + 113) and the scale 2^k of this lane's 16 values of a tile, max |v| 2^k in [2^14, 2^15)
 __device__ __forceinline__ float tile_scale(const f32x16& v, int& b) {
     float m = fmaxf(fabsf(v[0]), fabsf(v[1]));
 #pragma unroll
     for (int r = 2; r < 16; r += 2) m = fmaxf(m, fmaxf(fabsf(v[r]), fabsf(v[r + 1])));
     const int biased = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu);
-    b = biased == 0 ? 255 : min(max(205 - biased, 1), 190);
-    return biased == 0 ? 0.f : __builtin_bit_cast(float, (unsigned)(b + 63) << 23);
+    b = biased == 0 ? 255 : min(254 - biased, 239);       // k + 113: every normal fp32 magnitude has its byte (below 2^-112 the scale saturates)
+    return biased == 0 ? 0.f : __builtin_bit_cast(float, (unsigned)(b + 14) << 23);
 }
 template <int SLOT, int TILE>
 __device__ __forceinline__ void store_group(const Pipe& p, const f32x16& v, int q, float scale = 1.0f) {

@@ -32,7 +32,7 @@
 // 16 of the tile's 32 columns: the lane's accumulator registers) are stored as f16(dY * 2^k) with k chosen per lane and tile so
 // that the largest magnitude lands in [2^14, 2^15): 11 significant bits whatever the gradient's scale, no overflow, no state
 // carried between steps.  The four 512-byte pieces of tile t sit where the bf16 form has them; byte 16384 + 64 t + lane of the
-// group holds k + 64 (255: all 16 values are zero).  A slab's workgroup reads the exponent bytes of its groups first, takes K =
+// group holds k + 113 (255: all 16 values are zero).  A slab's workgroup reads the exponent bytes of its groups first, takes K =
 // the smallest k among them, multiplies every value by 2^(K - k) <= 1 on its way into LDS (values 2^-24 below the slab's largest
 // vanish — they could not move a sum that is compared to the tensor's largest entry) and multiplies its result by 2^-K:
 // operands with ONE common scale, so the products run on v_mfma_f32_32x32x16_f16 with f16 activations as they are — one product
@@ -361,8 +361,8 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfArgs a) {
     // partial slab: D row = n (A operand's row), column = k (B operand's column)
     float* out = a.dw_part + (size_t)g * N_OUT * LD_OUT;
     const int c = lane & 31;
-    // form 3: back from the slab's common scale 2^(bmin - 64) (an all-zero slab has nothing to scale)
-    const float unscale = (F16 && bmin != 255) ? __builtin_bit_cast(float, (unsigned)(127 + 64 - bmin) << 23) : 1.0f;
+    // form 3: back from the slab's common scale 2^(bmin - 113) (an all-zero slab has nothing to scale)
+    const float unscale = (F16 && bmin != 255) ? __builtin_bit_cast(float, (unsigned)(240 - bmin) << 23) : 1.0f;
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll

@@ -534,7 +534,7 @@ F16S_EXP_OFF = 16384     # byte offset of the 8 x 64 exponent bytes inside a gro
 def rows_to_frag_f16s(rows: torch.Tensor) -> torch.Tensor:
     """[m, 256] fp32 -> one fragment-ordered slot in the scaled f16 form the bf16 chain writes with DY_F16S (csrc/vfn_dwf.hip,
     "dY form 3"): per group, 32-column tile t and lane (point i, column half gg: the 16 columns 8 q + 4 gg + c of the tile),
-    f16(v * 2^k) with max |v| * 2^k in [2^14, 2^15) and the byte k + 64 (255: all 16 values zero) at F16S_EXP_OFF + 64 t + lane.
+    f16(v * 2^k) with max |v| * 2^k in [2^14, 2^15) and the byte k + 113 (255: all 16 values zero) at F16S_EXP_OFF + 64 t + lane.
     Test helper (the chain is the producer)."""
     m = rows.shape[0]
     g = frag_groups(m)
@@ -543,8 +543,8 @@ def rows_to_frag_f16s(rows: torch.Tensor) -> torch.Tensor:
     v = pad.reshape(g, 32, 8, 4, 2, 4)                                       # [group][point i][tile t][quad q][half gg][c]
     mx = v.abs().amax(dim=(3, 5))                                            # [g, i, t, gg]
     biased = (mx.view(torch.int32) >> 23) & 0xff
-    b = torch.where(biased == 0, torch.full_like(biased, 255), (205 - biased).clamp(1, 190))
-    scale = ((b.clamp(max=190) + 63) << 23).view(torch.float32)
+    b = torch.where(biased == 0, torch.full_like(biased, 255), (254 - biased).clamp(0, 239))
+    scale = ((b.clamp(max=239) + 14) << 23).view(torch.float32)
     scale = torch.where(b == 255, torch.zeros_like(scale), scale)
     scaled = v * scale[:, :, :, None, :, None]
     frag = scaled.permute(0, 2, 3, 4, 1, 5).reshape(g, GROUP_FLOATS)          # [group][t][q][gg][i][c]
@@ -559,7 +559,7 @@ def frag_f16s_to_rows(slot: torch.Tensor, m: int) -> torch.Tensor:
     g = frag_groups(m)
     flat = slot.reshape(-1)[: g * GROUP_FLOATS].view(g, GROUP_FLOATS)
     b = flat.view(torch.uint8)[:, F16S_EXP_OFF:F16S_EXP_OFF + 512].to(torch.int32).reshape(g, 8, 2, 32)     # [t][gg][i]
-    inv = ((127 + 64 - b.clamp(max=190)) << 23).view(torch.float32)
+    inv = ((240 - b.clamp(max=239)) << 23).view(torch.float32)
     inv = torch.where(b == 255, torch.zeros_like(inv), inv)
     vals = flat.view(torch.float16)[:, :GROUP_FLOATS].float().reshape(g, 8, 4, 2, 32, 4) * inv[:, :, None, :, :, None]
     rows = vals.permute(0, 4, 1, 2, 3, 5).reshape(g * 32, 256)
