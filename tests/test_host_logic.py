@@ -304,3 +304,26 @@ def test_reference_written_checkpoint_loads():
     assert again["optimizer"]["param_groups"][0]["params"] == ck["optimizer"]["param_groups"][0]["params"]
     assert again["optimizer"]["state"].keys() == ck["optimizer"]["state"].keys()
     assert again["scheduler"]["last_epoch"] == ck["scheduler"]["last_epoch"]
+
+
+def test_scaled_f16_gradient_slot_round_trip():
+    """The host-side encoder / decoder of the scaled f16 gradient form (lib.rows_to_frag_f16s / frag_f16s_to_rows: what the GPU
+    tests compare the chain's output with, and feed the weight-gradient kernel): small integers survive exactly, random values to
+    11 significant bits per lane-tile at any magnitude, all-zero lanes carry the byte 255, padding points decode to nothing."""
+    import torch
+    from vf_nerf_amd import lib
+    g = torch.Generator().manual_seed(0)
+    ints = torch.randint(-3, 4, (77, 256), generator=g).float()
+    assert torch.equal(lib.frag_f16s_to_rows(lib.rows_to_frag_f16s(ints), 77), ints)
+    for scale in (1e-30, 1e-20, 1.0, 1e20, 1e37):          # (fp32 denormals count as zero: the smallest here is 1e-36)
+        dy = torch.randn(1000, 256, generator=g) * torch.logspace(-6, 0, 256)[None, :] * scale
+        dy[17] = 0
+        slot = lib.rows_to_frag_f16s(dy)
+        back = lib.frag_f16s_to_rows(slot, 1000)
+        lane_max = dy.reshape(1000, 8, 4, 2, 4).abs().amax(dim=(2, 4), keepdim=True).expand(1000, 8, 4, 2, 4).reshape(1000, 256)
+        assert float(((back - dy).abs() / lane_max.clamp_min(1e-45)).max()) < 2 ** -11, scale
+        groups = lib.frag_groups(1000)
+        exps = slot.view(groups, lib.GROUP_FLOATS).view(torch.uint8)[:, lib.F16S_EXP_OFF:lib.F16S_EXP_OFF + 512].reshape(groups, 8, 2, 32)
+        assert bool((exps[17 // 32, :, :, 17 % 32] == 255).all())            # the all-zero point
+        assert bool((exps[-1, :, :, 1000 % 32:] == 255).all())               # padding points of the last group
+        assert int(exps[exps != 255].max()) <= 239
