@@ -283,9 +283,13 @@ __device__ __forceinline__ void store_tile_f16s(const Pipe& p, int b, const u32x
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.dy + (long long)SLOT * p.slot_floats, 0, (int)p.slot_bytes, 0x00020000);
     __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(p.live ? b : 255), rs, (int)p.evoff, TILE * 64, 0);
     if constexpr (SLOT == 3 && TILE == 6) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)255, rs, (int)p.evoff, 7 * 64, 0);   // see store_tile
+#ifdef BW16_ABL_NOSTORE      // timing only: the encode stays, the pieces do not leave
+    asm volatile("" :: "v"(eq[0]), "v"(eq[1]), "v"(eq[2]), "v"(eq[3]));
+#else
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         __builtin_amdgcn_raw_buffer_store_b64(eq[q], rs, (int)p.dvoff, (int)((TILE * p.st_tile + q * p.st_q) >> 1), BW16_STORE_AUX);
+#endif
 }
 // a whole finished tile: (scaled f16: the lane's exponent byte first, so that the four piece stores stay the youngest
 // vector-memory operations of the chunk), then its four register quads
