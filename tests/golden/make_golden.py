@@ -63,6 +63,11 @@ FIXTURES = {
     "attached_normals": dict(seed=9, gain=2.0, n_rays=12, n_samples=16, n_importance=10, perturb=True, th=-0.2, n_window=5,
                              near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=15, pose="identity",
                              skew=0.0, far_per_ray=False, detach_normals=False),
+    # the sampler sizes of BASELINE.json's headline (64 proposal + 64 fine samples, stratified), a proposal block of whole groups of
+    # 32 points (the training render then evaluates the VF net once per distinct sample, backward.StoredFinePass)
+    "bench_sizes": dict(seed=11, gain=2.0, n_rays=96, n_samples=64, n_importance=64, perturb=True, th=-0.2, n_window=11,
+                        near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=17, pose="orbit",
+                        skew=0.0, far_per_ray=False),
     "w1_det": dict(seed=4, gain=2.0, n_rays=16, n_samples=20, n_importance=12, perturb=False, th=-2.0, n_window=1,
                    near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=7, pose="identity",
                    skew=0.0, far_per_ray=False),

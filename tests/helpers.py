@@ -12,7 +12,7 @@ import vf_nerf_amd
 from vf_nerf_amd import synthetic
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-FIXTURE_NAMES = ("c1_det", "c1_perturb", "odd_orbit", "w1_det", "shipped_sizes")
+FIXTURE_NAMES = ("c1_det", "c1_perturb", "odd_orbit", "w1_det", "shipped_sizes", "bench_sizes")
 
 
 def load_fixture(name: str):
