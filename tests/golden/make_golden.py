@@ -68,6 +68,12 @@ FIXTURES = {
     "bench_sizes": dict(seed=11, gain=2.0, n_rays=96, n_samples=64, n_importance=64, perturb=True, th=-0.2, n_window=11,
                         near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=17, pose="orbit",
                         skew=0.0, far_per_ray=False),
+    # an epoch past anneal_start with the shipped "hard" annealing: the reference then rewrites config.cos_sim_weights every call
+    # (vector_field_nerf.py:232-234), which get_density ignores.  (white=True cannot be captured: the reference
+    # raises UnboundLocalError in its coarse block, Q12.)
+    "anneal_epoch": dict(seed=12, gain=2.0, n_rays=20, n_samples=24, n_importance=16, perturb=True, th=-0.2, n_window=11,
+                         near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=19, pose="orbit",
+                         skew=0.0, far_per_ray=False, epoch=1000),
     "w1_det": dict(seed=4, gain=2.0, n_rays=16, n_samples=20, n_importance=12, perturb=False, th=-2.0, n_window=1,
                    near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=7, pose="identity",
                    skew=0.0, far_per_ray=False),
@@ -173,7 +179,7 @@ def capture(fx, model):
     try:
         torch.manual_seed(1000 + fx["seed"])
         with torch.no_grad():
-            out = model.render(pose, uv, K, epoch=0)
+            out = model.render(pose, uv, K, fx.get("epoch", 0), fx.get("white", False))
         directions, ray_dirs, cam_loc = ref_rendering.get_ray_directions_and_cam_location(uv, pose, K, device=CPU)
     finally:
         torch.rand = real_rand
@@ -240,7 +246,7 @@ def capture_grads(fx, model, data):
     try:
         for p in model.parameters():
             p.grad = None
-        out = model.render(data["pose"], data["uv"], data["intrinsics"], epoch=0)
+        out = model.render(data["pose"], data["uv"], data["intrinsics"], fx.get("epoch", 0), fx.get("white", False))
     finally:
         torch.rand = real_rand
     assert torch.equal(out.z_vals, data["z_vals"])

@@ -189,6 +189,29 @@ def test_render_end_to_end(case):
     assert psnr > 60.0
 
 
+def test_render_at_an_annealing_epoch_matches_the_reference():
+    """Past ``anneal_start`` the reference rewrites ``config.cos_sim_weights`` on every render (vector_field_nerf.py:232-234) and
+    then does not use them (get_density takes uniform weights).  Fixture captured from the reference at epoch 1000
+    with the shipped "hard" annealing: the HIP render at that epoch — both precisions, one-call and launch-by-launch — samples
+    the same depths and agrees within the contract; the facade's config holds the annealed window afterwards, like the
+    reference's."""
+    fx, d = load_fixture("anneal_epoch")
+    g = {k: v.to(dev()) for k, v in d.items() if isinstance(v, torch.Tensor)}
+    uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add") if k in g}
+    for precision in ("fp32", "f16x3"):
+        for one_call in (True, False):
+            model = build_model(fx, d, device=dev())
+            model.precision, model.one_call_render = precision, one_call
+            before = model.config.cos_sim_weights.clone()
+            with torch.no_grad():
+                out = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=fx["epoch"], uniforms=uni)
+            assert torch.equal(out.z_vals.cpu(), d["z_vals"]), (precision, one_call)
+            assert rel_err(out.coarse_normals.reshape(-1, 3), d["normals"].reshape(-1, 3)) < 2e-5
+            assert rel_err(out.coarse_rgb_values, d["rgb"]) < TOL and rel_err(out.coarse_depth_map.reshape(-1), d["depth"].reshape(-1)) < TOL
+            after = model.config.cos_sim_weights
+            assert not torch.equal(after.cpu(), before.cpu()) and abs(float(after.sum()) - 1.0) < 1e-5, "the annealed window replaces the uniform one"
+
+
 def test_white_background_adds_missing_opacity():
     fx, d = load_fixture("w1_det")
     model = build_model(fx, d, device="cuda:0")

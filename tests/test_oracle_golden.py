@@ -17,7 +17,7 @@ def _run(name):
     return fx, d, out
 
 
-@pytest.mark.parametrize("name", FIXTURE_NAMES)
+@pytest.mark.parametrize("name", FIXTURE_NAMES + ("anneal_epoch",))      # (anneal_epoch: captured at epoch 1000, past anneal_start — Q6)
 def test_render_matches_reference_bitwise_stages(name):
     """Sampling stages and indices are bit-exact; everything downstream of the MLPs within 1e-6."""
     fx, d, out = _run(name)
