@@ -20,14 +20,17 @@ with torch.no_grad():
 pts = out.points_coarse.reshape(-1, 3).contiguous(); dirs = out.ray_dirs[::128].contiguous()
 m = pts.shape[0]
 normals = torch.empty(m, 3, device=dev); colors = torch.empty(m, 3, device=dev)
-ref_n, ref_c = lib.vf_render_fused16_fwd(vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(), pts, dirs, 128)
+ref_n, ref_c = lib.vf_render_fused16_fwd(vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(), pts, dirs, 128,
+                                         colour_products=int(__import__('os').environ.get('COLOUR_PRODUCTS', '2')))
 libs = {}
 for n in names:
     l = C.CDLL(n); l.vfn_last_error.restype = C.c_char_p; libs[n] = l
+import os
+PRODUCTS = int(os.environ.get("COLOUR_PRODUCTS", "2"))       # the shipped default of gradient-free renders; 3: three products everywhere
 def call(l):
-    rc = l.vfn_vf_render_fused16_fwd(C.byref(vf.geometry()), C.c_void_p(vf.packed16_weights().data_ptr()), C.byref(rn.geometry()),
+    rc = l.vfn_vf_render_fused16_products(C.byref(vf.geometry()), C.c_void_p(vf.packed16_weights().data_ptr()), C.byref(rn.geometry()),
         C.c_void_p(rn.packed16_weights().data_ptr()), C.c_void_p(pts.data_ptr()), C.c_void_p(dirs.data_ptr()), C.c_int64(m), C.c_int32(128),
-        C.c_void_p(normals.data_ptr()), C.c_void_p(colors.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        None, C.c_int32(PRODUCTS), C.c_void_p(normals.data_ptr()), C.c_void_p(colors.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, l.vfn_last_error()
 times = {n: [] for n in names}
 for n in names:
