@@ -30,7 +30,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int GM_ROWS = 128;    // rows per workgroup (4 waves x 32)
 constexpr int GM_KC = 32;       // contraction chunk staged in LDS
 constexpr int GM_LD = 36;       // LDS row stride (floats): 16-byte aligned, conflict-free b128 reads
-constexpr int ACT_NONE = 0, ACT_TANH = 1, ACT_SIGMOID = 2;
+[[maybe_unused]] constexpr int ACT_NONE = 0;
+constexpr int ACT_TANH = 1, ACT_SIGMOID = 2;
 
 struct GemmArgs {
     const float* a; const float* w; const float* bias; float* c; float* stats_part;

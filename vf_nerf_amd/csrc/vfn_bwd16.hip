@@ -388,10 +388,12 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
     // tanh'ed feature tiles load values, and wait for them) and its dY stores go out right after the hand-over: they then have
     // a whole chunk to retire before the next vmcnt(0) instead of half of one.
     constexpr int E = H;                              // steps 0 .. E-1 carry the pending tile's epilogue
-    constexpr int EPI0 = 0, ST0 = H;                  // first epilogue step, first store step
+    constexpr int EPI0 = 0;                           // first epilogue step
+    [[maybe_unused]] constexpr int ST0 = H;           // first store step (builds without BW16_LATE_STORES)
 #else
     constexpr int E = NB - 2 - H;                     // steps H .. H+E-1 carry the pending tile's epilogue
-    constexpr int EPI0 = H, ST0 = H + E;
+    constexpr int EPI0 = H;
+    [[maybe_unused]] constexpr int ST0 = H + E;
 #endif
     constexpr int DSTEPS = NB - H;
     static_assert(2 * PT >= EPI0 + E || PT < 0, "the pending tile must be complete before it is read");
