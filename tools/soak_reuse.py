@@ -1,5 +1,7 @@
-"""Soak check of the split inference path (stored rows + scatter) against the fused launch over odd sizes: bit-equality of
-every output for many (rays, S_c, N_f), including row counts that are not multiples of the 32-row block groups."""
+"""Soak check of the inference paths over odd sizes: the one-call render (vfn_render_fwd, five merged launches), the same pipeline
+launch by launch from Python, the eight-launch plan from C, and the single fused launch over all sorted samples (no reuse of the
+proposal evaluation) — bit-equality of every output for many (rays, S_c, N_f), with the colour branch on two and on three
+products, including row counts that are not multiples of the 32-row groups."""
 import sys, itertools, torch
 sys.path.insert(0, '.')
 import bench
@@ -8,15 +10,19 @@ bad = 0
 cases = list(itertools.product((1, 3, 31, 33, 100, 257, 1000, 4097), ((64, 64), (100, 35), (100, 100), (17, 9), (33, 2))))
 for n, (s_c, n_f) in cases:
     model, uv, pose, K = bench.build_scene(dev, n, s_c, n_f, seed=n)
-    outs = []
-    for reuse in (True, False):
-        model.reuse_proposal = reuse
-        model._rng_offset = 0
-        with torch.no_grad():
-            outs.append(model.render(pose, uv, K, epoch=0))
-    a, b = outs
-    ok = all(torch.equal(getattr(a, f), getattr(b, f)) for f in ("z_vals", "points_coarse", "coarse_normals", "coarse_colors", "coarse_rgb_values", "coarse_depth_map"))
-    finite = bool(torch.isfinite(a.coarse_rgb_values).all())
+    ok, finite = True, True
+    for products in (2, 3):
+        model.colour_products = products
+        outs = []
+        for reuse, one_call, separate in ((True, True, False), (True, False, False), (True, True, True), (False, False, False)):
+            model.reuse_proposal, model.one_call_render, model.render_separate_launches = reuse, one_call, separate
+            model._rng_offset = 0
+            with torch.no_grad():
+                outs.append(model.render(pose, uv, K, epoch=0))
+        a = outs[0]
+        ok = ok and all(torch.equal(getattr(a, f), getattr(b, f)) for b in outs[1:]
+                        for f in ("z_vals", "points_coarse", "coarse_normals", "coarse_colors", "coarse_rgb_values", "coarse_depth_map"))
+        finite = finite and bool(torch.isfinite(a.coarse_rgb_values).all())
     if not (ok and finite):
         bad += 1
         print("MISMATCH", n, s_c, n_f, ok, finite)
