@@ -360,6 +360,16 @@ int vfn_mlp_bwd_chain_bf16_ws(const vfn_net_geom* vf_geom, const void* vf_packed
                               const float* feats, const uint32_t* masks, void* dy, int32_t dy_flags, const float* d_colors,
                               const float* colors, const float* d_vec, const float* vec, const float* d_feats,
                               int32_t vec_stride, int64_t n_points, float* dz_rgb, float* dz_vec, void* stream);
+/* The same over PART of a workspace sized for ws_points points: the launch's n_points points are points ws_first .. of feats,
+ * masks, dy, dz_rgb and dz_vec (workspace-indexed); d_colors / colors / d_vec / vec / d_feats stay launch-local.  Several
+ * forwards can then share one workspace (vfn_vf_render_fused16_fwd_train_at, vfn_vf_mlp16_fwd_train_at) and the weight-gradient
+ * kernels walk it once. */
+int vfn_mlp_bwd_chain_bf16_ws_at(const vfn_net_geom* vf_geom, const void* vf_packed_bwd16, const float* vf_head_w,
+                                 const vfn_net_geom* rn_geom, const void* rn_packed_bwd16, const float* rn_head_w,
+                                 const float* feats, const uint32_t* masks, void* dy, int32_t dy_flags, const float* d_colors,
+                                 const float* colors, const float* d_vec, const float* vec, const float* d_feats,
+                                 int32_t vec_stride, int64_t n_points, float* dz_rgb, float* dz_vec, int64_t ws_first,
+                                 int64_t ws_points, void* stream);
 
 /* FRAGMENT-ORDERED training workspace.  A slot (one layer's saved activations, or its pre-activation gradients) is stored as
  * the producing waves hold it: groups of 32 points (one wave), 32 KiB per group, inside a group piece (t, q) = registers
@@ -459,6 +469,18 @@ typedef struct vfn_wgrad_layer {
     const float* weight; const float* bias; const float* bn_weight; const float* bn_var; const float* bn_mean;
     float* g_weight; float* g_bias; float* g_bn_weight; float* g_bn_bias;
 } vfn_wgrad_layer;
+/* ... and the same for a SUBSET of the net's products: parts = VFN_WGRAD_LAYERS (the hidden layers) | VFN_WGRAD_FEATURES (the
+ * feature block of the vector-field net's last Linear) | VFN_WGRAD_HEAD (its 3 output channels).  One workspace can hold points
+ * whose forward included the feature block (the fine pass of render()) followed by points whose forward did not (the trainer's
+ * supervision points, vector_field_nerf_train.py:191,203,215): LAYERS | HEAD then run once over all of them, FEATURES over the
+ * first block only (pointers of a sub-range of points: slot base + (first / 32) * 32 KiB, aux + first * 40, dz_head + first * 4). */
+#define VFN_WGRAD_LAYERS 1u
+#define VFN_WGRAD_FEATURES 2u
+#define VFN_WGRAD_HEAD 4u
+int vfn_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_geom* geom, const vfn_wgrad_layer* layers, const void* saved,
+                                   const void* dy, int64_t slot_bytes, int32_t dy_form, int32_t x_form, const float* feats,
+                                   const float* aux, const float* dz_head, int64_t n_points, uint32_t parts, int32_t accumulate,
+                                   void* scratch, void* stream);
 int32_t vfn_weight_grad_groups(int64_t n_points);
 int64_t vfn_net_weight_grads_scratch_bytes(int32_t net_kind, const vfn_net_geom* geom, int64_t n_points);
 int vfn_net_weight_grads_frag(int32_t net_kind, const vfn_net_geom* geom, const vfn_wgrad_layer* layers, const void* saved,
@@ -486,6 +508,9 @@ int vfn_sample_sphere_shell(int64_t n, float r_min, float r_max, const float* ce
 int vfn_vf_mlp16_fwd_train(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
                            int32_t with_features, float* out_vec, float* saved, float* save_aux_vf, uint32_t* save_masks,
                            int32_t save_f16, void* stream);
+int vfn_vf_mlp16_fwd_train_at(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
+                              int32_t with_features, float* out_vec, float* saved, float* save_aux_vf, uint32_t* save_masks,
+                              int32_t save_f16, int64_t ws_first, int64_t ws_points, void* stream);    /* see ..._fused16_fwd_train_at */
 int vfn_vf_render_fused16_fwd_train(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
                                     const void* rn_packed16, const float* points, const float* ray_dirs,
                                     int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,

@@ -625,3 +625,65 @@ def test_scaled_f16_gradients_at_any_magnitude(scale):
     print(f"scale {scale:g}: dW error {err:.2e} of the largest entry")
     assert err < 1e-5
     assert float((dbp.sum(0).double() - held.double().sum(0)).abs().max() / held.double().sum(0).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["c1_perturb", "bench_sizes"])
+def test_shared_step_workspace_gives_the_same_gradients(name):
+    """backward.StepWorkspace: vector-field forwards that follow a render() under autograd append their points to the render's
+    workspace (ragged batches padded with points of zero upstream gradient), every backward runs its own dX chain, and ONE
+    sequence of weight-gradient launches at the end of the backward pass covers all of them.  Against private workspaces
+    (``model.shared_step_workspace = False``): forward values bit-identical, every parameter gradient equal up to the order of
+    the sums (1e-5 of the tensor's largest entry) — with a full forward (features evaluated, their gradient zero: what the
+    trainer's ``vector_field_network(points)[:, :3]`` is), a vector-only forward, a batch too large for the room that is left
+    (falls back to its own workspace) and a forward that takes no part in the loss."""
+    fx, d = load_fixture(name)
+    g = {k: v.to("cuda:0") for k, v in d.items() if isinstance(v, torch.Tensor)}
+    uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add") if k in g}
+    a, b, c = (t.to("cuda:0") for t in loss_coefficients(*d["z_vals"].shape))
+    gen = torch.Generator().manual_seed(3)
+    m_fine = d["z_vals"].numel()
+    sup_a = (torch.rand(max(33, m_fine // 10) + 5, 3, generator=gen) - 0.5).to("cuda:0")          # ragged
+    sup_b = (torch.rand(64, 3, generator=gen) - 0.5).to("cuda:0")
+    sup_big = (torch.rand(m_fine, 3, generator=gen) - 0.5).to("cuda:0")                            # does not fit behind the fine pass
+    sup_unused = (torch.rand(40, 3, generator=gen) - 0.5).to("cuda:0")
+    res = {}
+    for shared in (True, False):
+        model = build_model(fx, d, device="cuda:0")
+        model.shared_step_workspace = shared
+        vf = model.vector_field_network
+        model.optimizer.zero_grad()                                   # gradient views exist: results are added in place
+        out = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
+        pool = getattr(vf, "_step_ws", None)
+        assert (pool is not None) == (shared and m_fine % 32 == 0 or shared)       # (a ragged fine pass still owns a pool, without room)
+        full = vf(sup_a)                                              # [M, 259]
+        vec = vf(sup_b, vector_only=True)
+        big = vf(sup_big)[:, :3]
+        _ = vf(sup_unused)                                            # appended, never differentiated
+        if shared and m_fine % 32 == 0:
+            assert pool.next > _round32_(m_fine), "the supervision forwards joined the render's workspace"
+        loss = (out.coarse_rgb_values * a).sum() + (out.coarse_depth_map * b).sum() + (out.coarse_normals * c).sum() + \
+            full[:, :3].pow(2).sum() + vec.pow(2).sum() + 0.1 * big.sum()
+        loss.backward()
+        res[shared] = (out, full.detach(), vec.detach(), {n: p.grad.detach().clone() for n, p in _named(model)})
+    (o1, f1, v1, g1), (o0, f0, v0, g0) = res[True], res[False]
+    assert torch.equal(o1.coarse_rgb_values, o0.coarse_rgb_values) and torch.equal(o1.coarse_normals, o0.coarse_normals)
+    assert torch.equal(f1, f0) and torch.equal(v1, v0)
+    worst = 0.0
+    for k in g1:
+        if k.startswith("density."):
+            continue
+        scale = max(float(g0[k].abs().max()), 1e-30)
+        e1 = float((g1[k] - g0[k]).abs().max()) / scale
+        worst = max(worst, e1)
+        assert e1 < 1e-5, (k, e1)
+    print(f"{name}: shared vs private workspaces: worst gradient difference {worst:.2e}")
+
+
+def _round32_(n):
+    return (n + 31) // 32 * 32
+
+
+def _named(model):
+    for tag, mod in (("vf", model.vector_field_network), ("rn", model.rendering_network), ("density", model.density)):
+        for n, p in mod.named_parameters():
+            yield f"{tag}.{n}", p

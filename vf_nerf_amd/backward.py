@@ -147,6 +147,14 @@ def _wgrad_scratch(net, m: int, dev) -> torch.Tensor:
     return buf
 
 
+def _direct_ok(net, dev) -> bool:
+    """Every parameter of the net has a gradient tensor the un-fold kernel can add into (the flat optimizer's views)."""
+    dev = torch.device(dev)
+    return bool(getattr(net, "accumulate_into_grad", True)) and all(
+        p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.device == dev and not p.grad.requires_grad
+        for p in net.parameters())
+
+
 def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=(), fast: bool = False, x_f16: bool = False,
                   x_fp32_entries=(), frag=None, ws_ref=None) -> Dict[torch.nn.Parameter, torch.Tensor]:
     """inputs[h]: [M,256] act input of hidden entry h (None if it has none); inputs[-1]: input of the 3-channel head.
@@ -167,9 +175,7 @@ def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=(), fast: bo
     # When every parameter of the net already HAS a gradient tensor (the flat optimizer keeps them as views of one buffer, zeroed
     # by zero_grad), the un-fold kernel adds straight into it and nothing is handed to autograd for these parameters: the ~90
     # AccumulateGrad additions of a training step (one launch each) disappear.  (Tensor hooks on the parameters do not fire then.)
-    direct = getattr(net, "accumulate_into_grad", True) and all(
-        p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.device == dev and not p.grad.requires_grad
-        for p in net.parameters())
+    direct = _direct_ok(net, dev)
 
     if frag is not None and direct and ws_ref is not None and getattr(net, "one_call_weight_grads", True):
         # fragment-ordered workspace, gradients accumulated in place: the whole launch sequence below from C out of one cached
@@ -399,6 +405,103 @@ class _FinePass(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------
+# one workspace per training step, shared by the fine pass of render() and the vector-field forwards that follow it
+# ------------------------------------------------------------------------------------------------
+def _round32(n: int) -> int:
+    return (n + 31) // 32 * 32
+
+
+class StepWorkspace:
+    """The trainer differentiates three vector-field evaluations per step: the fine pass of render() and the two supervision
+    batches (train/vector_field_nerf_train.py:177,191,203,215).  Their weight gradients are sums over points of the same
+    products, so the later forwards APPEND their points to the workspace the fine pass laid out (whole groups of 32 points;
+    a ragged batch is padded with points whose upstream gradient is zero, which contribute exactly nothing), every backward
+    runs its own dX chain over its region, and ONE sequence of weight-gradient launches walks everything that was
+    differentiated — issued by a callback at the end of the backward pass — instead of one sequence (and one set of partial
+    slabs, and one un-fold) per forward.  Needs the flat optimizer's gradient views (results are added in place)."""
+
+    EXTRA = 0.3             # room for the supervision points, as a fraction of the fine pass's points (the trainer uses 0.2)
+
+    def __init__(self, model, m_fine: int, n_slots: int, dev) -> None:
+        self.model, self.m_fine = model, m_fine
+        fine = _round32(m_fine)
+        extra = _round32(int(fine * self.EXTRA)) if m_fine % 32 == 0 else 0
+        if fine + extra >= _F16_TRAIN_MAX_POINTS:
+            extra = max(0, (_F16_TRAIN_MAX_POINTS - 32 - fine) // 32 * 32)
+        self.total = fine + extra
+        f16, frag, dy16 = _storage(model, True)
+        self.ws = _Workspace(self.total, n_slots, dev, f16=f16, frag=True, dy16=dy16)
+        self.storage = (f16, dy16)
+        self.next = fine
+        self.dy: Optional[torch.Tensor] = None
+        self.dz_vec: Optional[torch.Tensor] = None
+        self.done: List[tuple] = []           # (first, padded count, has features) of the regions whose chain has run
+        self.queued = False
+
+    def take(self, count: int) -> Optional[int]:
+        """First point of a fresh region of ``count`` (padded) points, or None when the workspace is full."""
+        if count % 32 or self.next + count > self.total:
+            return None
+        first = self.next
+        self.next += count
+        return first
+
+    def gradients(self):
+        if self.dy is None:
+            self.dy = self.ws.new_dy()
+            self.dz_vec = torch.empty(self.total, 4, device=self.dy.device)
+        return self.dy, self.dz_vec
+
+    def mark_done(self, first: int, count: int, features: bool) -> None:
+        self.done.append((first, count, features))
+        if not self.queued:
+            self.queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
+    def flush(self) -> None:
+        """End of the backward pass: the vector-field net's weight gradients over every region whose chain has run."""
+        self.queued = False
+        regions, self.done = sorted(self.done), []
+        if not regions:
+            return
+        vf = self.model.vector_field_network
+        ws, (dy, dz_vec) = self.ws, self.gradients()
+        dev = dy.device
+        forms = ws.frag_forms()
+        for p in vf.parameters():             # (gradients dropped between forward and backward, e.g. zero_grad(set_to_none=True):
+            if p.grad is None:                #  nothing was handed to autograd for these parameters, so the sums start here)
+                p.grad = torch.zeros_like(p)
+        table = _layer_table(vf)
+
+        def launch(first, count, parts):
+            lib.net_weight_grads_frag(vf._kind, vf.geometry(), table, ws.saved, 0, dy, ws.slot_floats, forms[0], forms[1], None, ws.aux_vf,
+                                      dz_vec, count, True, True, _wgrad_scratch(vf, count, dev), first_point=first, parts=parts)
+
+        # maximal runs of adjacent regions; inside a run, maximal sub-runs of regions whose forward included the feature block
+        i = 0
+        while i < len(regions):
+            j = i
+            while j + 1 < len(regions) and regions[j][0] + regions[j][1] == regions[j + 1][0]:
+                j += 1
+            first, count = regions[i][0], regions[j][0] + regions[j][1] - regions[i][0]
+            if all(r[2] for r in regions[i:j + 1]):
+                launch(first, count, lib.WGRAD_LAYERS | lib.WGRAD_FEATURES | lib.WGRAD_HEAD)
+            else:
+                launch(first, count, lib.WGRAD_LAYERS | lib.WGRAD_HEAD)
+                k = i
+                while k <= j:
+                    if regions[k][2]:
+                        e = k
+                        while e + 1 <= j and regions[e + 1][2]:
+                            e += 1
+                        launch(regions[k][0], regions[e][0] + regions[e][1] - regions[k][0], lib.WGRAD_FEATURES)
+                        k = e + 1
+                    else:
+                        k += 1
+            i = j + 1
+
+
+# ------------------------------------------------------------------------------------------------
 # fine pass of a training render() with ONE vector-field evaluation per distinct sample
 # ------------------------------------------------------------------------------------------------
 class StoredFinePass:
@@ -419,7 +522,15 @@ class StoredFinePass:
         self.vf_h, self.rn_h = len(_entries(vf)), len(_entries(rn))
         f16, frag, dy16 = _storage(model, True)
         assert frag
-        self.ws = _Workspace(self.m, self.vf_h + self.rn_h, dev, f16=f16, frag=True, dy16=dy16)
+        # the step's shared workspace (StepWorkspace) when the gradients can be added in place, else a private one
+        self.pool = None
+        if getattr(model, "shared_step_workspace", True) and _direct_ok(vf, dev) and _direct_ok(rn, dev):
+            self.pool = StepWorkspace(model, self.m, self.vf_h + self.rn_h, dev)
+            self.ws = self.pool.ws
+        else:
+            self.ws = _Workspace(self.m, self.vf_h + self.rn_h, dev, f16=f16, frag=True, dy16=dy16)
+        vf._step_ws = self.pool                                   # (replaces the previous step's; None: later VF forwards stand alone)
+        self.ws_points = self.ws.m
         self.normals_s = torch.empty(self.m, 3, device=dev)      # storage order
         self.colors_s = torch.empty(self.m, 3, device=dev)
 
@@ -435,7 +546,7 @@ class StoredFinePass:
         vf, rn = model.vector_field_network, model.rendering_network
         lib.vf_render_fused16_fwd_train(vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(), pts.reshape(-1, 3),
                                         ray_dirs, per_ray, ws.saved, ws.aux_vf, ws.aux_rn, ws.masks, save_f16=ws.fwd_flags(),
-                                        ws_first=first, ws_points=self.m, normals=self.normals_s[first:first + count],
+                                        ws_first=first, ws_points=self.ws_points, normals=self.normals_s[first:first + count],
                                         colors=self.colors_s[first:first + count], colour_products=_train_products(model))
 
     def proposal(self, pts_c, ray_dirs) -> torch.Tensor:
@@ -492,18 +603,27 @@ class _StoredFinePassFn(torch.autograd.Function):
         # ... gathered to storage order: row r of the workspace is sorted sample dst[r]
         idx = sp.dst.long()
         dn_s, dc_s = dn.index_select(0, idx), dc.index_select(0, idx)
-        # (2) dX chain over the workspace, (3) weight gradients
-        dy = ws.new_dy()
+        # (2) dX chain over the fine pass's region of the workspace, (3) weight gradients
+        pool = sp.pool
         dz_rgb = torch.empty(m, 4, device=dev)
-        dz_vec = torch.empty(m, 4, device=dev)
+        if pool is not None:
+            dy, dz_vec = pool.gradients()
+        else:
+            dy, dz_vec = ws.new_dy(), torch.empty(m, 4, device=dev)
         lib.mlp_bwd_chain_bf16_ws(vf.geometry(), _packed_bwd16(vf), _head_rows(vf), rn.geometry(), _packed_bwd16(rn), _head_rows(rn),
-                                  ws.feats(vf_h - 1), ws.masks, dy, ws.dy_flags(), dc_s, sp.colors_s, dn_s, sp.normals_s, None, 3, m, dz_rgb, dz_vec)
+                                  ws.feats(vf_h - 1), ws.masks, dy, ws.dy_flags(), dc_s, sp.colors_s, dn_s, sp.normals_s, None, 3, m, dz_rgb, dz_vec,
+                                  ws_first=0, ws_points=sp.ws_points)
         feats = ws.feats(vf_h - 1)
-        g_vf = _weight_grads(vf, _vf_inputs(vf, [ws.saved[h] for h in range(vf_h)]), [dy[h] for h in range(vf_h)],
-                             ws.aux_vf, dz_vec, m, fast=True, x_f16=ws.f16, frag=ws.frag_forms(), ws_ref=(ws.saved, dy, 0))
         g_rn = _weight_grads(rn, _rn_inputs(feats, [ws.saved[vf_h + h] for h in range(rn_h)]),
                              [dy[vf_h + h] for h in range(rn_h)], ws.aux_rn, dz_rgb, m, fast=True, x_f16=ws.f16,
                              x_fp32_entries=(0,), frag=ws.frag_forms(), ws_ref=(ws.saved, dy, vf_h))
+        if pool is not None:
+            pool.mark_done(0, m, True)          # the vector-field net's products wait for the other regions of this backward pass
+                                                # (a ragged m stays its own run: the weight-gradient kernel masks its last group's tail)
+            g_vf = {}
+        else:
+            g_vf = _weight_grads(vf, _vf_inputs(vf, [ws.saved[h] for h in range(vf_h)]), [dy[h] for h in range(vf_h)],
+                                 ws.aux_vf, dz_vec, m, fast=True, x_f16=ws.f16, frag=ws.frag_forms(), ws_ref=(ws.saved, dy, 0))
         by_name = {"beta": dscal[0], "mean": dscal[1], "scale": dscal[2]}
         g_den = {p: by_name[name].reshape(p.shape) for name, p in model.density.named_parameters()}
         sp.ws = None
@@ -531,6 +651,22 @@ class _VFForward(torch.autograd.Function):
         fast = getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3() and m < _F16_TRAIN_MAX_POINTS
         bwd_fast = fast and getattr(net, "backward_kernels", "auto") != "fp32"
         f16, frag, dy16 = _storage(net, bwd_fast)
+        # a render() under autograd earlier in this step left room in its workspace: append (StepWorkspace)
+        pool = getattr(net, "_step_ws", None)
+        if pool is not None and bwd_fast and frag and m > 0 and pool.storage == (f16, dy16) and pool.ws.saved.device == dev and _direct_ok(net, dev):
+            mp = _round32(m)
+            first = pool.take(mp)
+            if first is not None:
+                pts_p = pts if mp == m else torch.cat([pts, pts.new_zeros(mp - m, 3)])      # padding points: their upstream gradient is zero
+                out_p = lib.vf_mlp16_fwd_train(net.geometry(), net.packed16_weights(), pts_p, cols > 3, pool.ws.saved, pool.ws.aux_vf,
+                                               pool.ws.masks, save_f16=pool.ws.fwd_flags(), ws_first=first, ws_points=pool.total)
+                if cols > 3:
+                    out_p = torch.cat([out_p, pool.ws.feats(vf_h - 1)[first:first + mp]], dim=1)
+                ctx.net, ctx.ws, ctx.dims, ctx.param_order = net, None, (m, vf_h, cols), list(params)
+                ctx.region, ctx.fast = (pool, first, mp), True
+                ctx.save_for_backward(out_p)
+                return out_p[:m]
+        ctx.region = None
         ws = _Workspace(m, vf_h, dev, f16=f16, frag=frag, dy16=dy16)
         if fast:
             out = lib.vf_mlp16_fwd_train(net.geometry(), net.packed16_weights(), pts, cols > 3, ws.saved, ws.aux_vf, ws.masks,
@@ -551,6 +687,18 @@ class _VFForward(torch.autograd.Function):
         (out,) = ctx.saved_tensors
         dev = out.device
         d_out = d_out.float().contiguous()
+        if ctx.region is not None:
+            # this forward's points live in the step's shared workspace: the chain runs over their region, the weight gradients
+            # wait for the end of the backward pass (StepWorkspace.flush)
+            pool, first, mp = ctx.region
+            if mp != m:
+                d_out = torch.cat([d_out, d_out.new_zeros(mp - m, cols)])
+            dy, dz_all = pool.gradients()
+            lib.mlp_bwd_chain_bf16_ws(net.geometry(), _packed_bwd16(net), _head_rows(net), None, None, None, pool.ws.feats(vf_h - 1), pool.ws.masks,
+                                      dy, pool.ws.dy_flags(), None, None, d_out, out, _offset_view(d_out, 3) if cols > 3 else None, cols, mp, None,
+                                      dz_all, ws_first=first, ws_points=pool.total)
+            pool.mark_done(first, mp, cols > 3)
+            return (None, None, None, *[None for _ in ctx.param_order])
         dy = ws.new_dy()
         dz_vec = torch.empty(m, 4, device=dev)
         d_feats = None

@@ -172,6 +172,7 @@ struct Bwd16Args {
     float* dz_rgb; float* dz_vec;                    // [M,4]
     long long n_points;
     int vec_stride;
+    long long ws_first, ws_points;   // this launch's points are points ws_first .. of a workspace (feats, masks, dy, dz_*) sized for ws_points
 };
 
 struct X16 { bf8 hi[16]; bf8 lo[16]; };
@@ -537,8 +538,8 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
             }
         }
         if (g == 0) {
-            *reinterpret_cast<f32x4v*>(a.dz_vec + m * 4) = f32x4v{dzv[0], dzv[1], dzv[2], 0.f};
-            if (MODE & 2) *reinterpret_cast<f32x4v*>(a.dz_rgb + m * 4) = f32x4v{dzc[0], dzc[1], dzc[2], 0.f};
+            *reinterpret_cast<f32x4v*>(a.dz_vec + (m + a.ws_first) * 4) = f32x4v{dzv[0], dzv[1], dzv[2], 0.f};
+            if (MODE & 2) *reinterpret_cast<f32x4v*>(a.dz_rgb + (m + a.ws_first) * 4) = f32x4v{dzc[0], dzc[1], dzc[2], 0.f};
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -551,17 +552,18 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
     const bool frag = (a.dy_flags & 2) != 0;
     p.dy16 = (MX & BM_F16S) ? 2 : ((frag && (a.dy_flags & 4)) ? 1 : 0);
     p.live = in ? 1 : 0;
-    p.evoff = (m & ~31ll) < a.n_points ? (uint32_t)((m >> 5) * 32768 + 16384 + lane) : 0xc0000000u;
-    p.feats = a.feats; p.dy = a.dy; p.feat_bytes = (uint32_t)(a.n_points * 1024);
-    p.slot_floats = frag ? ((a.n_points + 31) >> 5) * 8192 : a.n_points * 256;
+    const long long mw = m + a.ws_first;          // this point's place in the workspace
+    p.evoff = (m & ~31ll) < a.n_points ? (uint32_t)((mw >> 5) * 32768 + 16384 + lane) : 0xc0000000u;
+    p.feats = a.feats; p.dy = a.dy; p.feat_bytes = (uint32_t)(a.ws_points * 1024);
+    p.slot_floats = frag ? ((a.ws_points + 31) >> 5) * 8192 : a.ws_points * 256;
     p.slot_bytes = (uint32_t)(p.slot_floats * 4);
-    p.voff = in ? (uint32_t)(m * 1024 + g * 16) : 0xfffffff0u;
+    p.voff = in ? (uint32_t)(mw * 1024 + g * 16) : 0xfffffff0u;
     // (fragment order adds scalar offsets of up to 32 KiB: the out-of-range value must not wrap; slots are limited to 2 GiB)
-    p.dvoff = !frag ? p.voff : (in ? (uint32_t)((m >> 5) * 32768 + lane * (p.dy16 ? 8 : 16)) : 0xc0000000u);
+    p.dvoff = !frag ? p.voff : (in ? (uint32_t)((mw >> 5) * 32768 + lane * (p.dy16 ? 8 : 16)) : 0xc0000000u);
     p.st_tile = frag ? 4096u : 128u; p.st_q = frag ? 1024u : 32u;
     {   // sign bits of every ReLU layer this launch walks through: 16 bytes per slot, all requested now, in registers for good
-        const unsigned mbytes = (unsigned)(a.n_points * 32);
-        const unsigned mvoff = in ? (unsigned)((2 * m + g) * 16) : 0xfffffff0u;
+        const unsigned mbytes = (unsigned)(a.ws_points * 32);
+        const unsigned mvoff = in ? (unsigned)((2 * mw + g) * 16) : 0xfffffff0u;
         static_for<13>([&](auto is) {
             constexpr int sl = decltype(is)::value;
             constexpr bool used = sl != 8 && (sl < 8 || MODE == BM_FUSED);
@@ -721,6 +723,16 @@ extern "C" int vfn_mlp_bwd_chain_bf16_ws(const vfn_net_geom* vf_geom, const void
                                          const float* saved, const uint32_t* masks, void* dy, int32_t dy_flags, const float* d_colors,
                                          const float* colors, const float* d_vec, const float* vec, const float* d_feats,
                                          int32_t vec_stride, int64_t n_points, float* dz_rgb, float* dz_vec, void* stream) {
+    return vfn_mlp_bwd_chain_bf16_ws_at(vf_geom, vf_packed_bwd16, vf_head_w, rn_geom, rn_packed_bwd16, rn_head_w, saved, masks, dy, dy_flags, d_colors,
+                                        colors, d_vec, vec, d_feats, vec_stride, n_points, dz_rgb, dz_vec, 0, n_points, stream);
+}
+
+extern "C" int vfn_mlp_bwd_chain_bf16_ws_at(const vfn_net_geom* vf_geom, const void* vf_packed_bwd16, const float* vf_head_w,
+                                            const vfn_net_geom* rn_geom, const void* rn_packed_bwd16, const float* rn_head_w,
+                                            const float* saved, const uint32_t* masks, void* dy, int32_t dy_flags, const float* d_colors,
+                                            const float* colors, const float* d_vec, const float* vec, const float* d_feats,
+                                            int32_t vec_stride, int64_t n_points, float* dz_rgb, float* dz_vec, int64_t ws_first,
+                                            int64_t ws_points, void* stream) {
     VFN_REQUIRE(vf_geom, "vfn_mlp_bwd_chain_bf16: NULL argument");
     int rc = check_shipped(VFN_NET_VF, vf_geom, "vfn_mlp_bwd_chain_bf16");
     if (rc != VFN_OK) return rc;
@@ -733,7 +745,10 @@ extern "C" int vfn_mlp_bwd_chain_bf16_ws(const vfn_net_geom* vf_geom, const void
     if (n_points <= 0) return VFN_OK;
     VFN_REQUIRE(vf_packed_bwd16 && vf_head_w && saved && masks && dy && d_vec && vec && dz_vec, "vfn_mlp_bwd_chain_bf16: NULL argument");
     VFN_REQUIRE(vec_stride >= 3, "vfn_mlp_bwd_chain_bf16: vec_stride must be >= 3");
-    VFN_REQUIRE(n_points < ((dy_flags & 2) ? (1ll << 21) : (1ll << 22)), "vfn_mlp_bwd_chain_bf16: at most %lld points per launch (32-bit slot offsets)",
+    VFN_REQUIRE(ws_first >= 0 && ws_first + n_points <= ws_points, "vfn_mlp_bwd_chain_bf16: points %lld .. %lld outside a workspace of %lld",
+                (long long)ws_first, (long long)(ws_first + n_points), (long long)ws_points);
+    VFN_REQUIRE(!(dy_flags & 2) || ws_first % 32 == 0, "vfn_mlp_bwd_chain_bf16: ws_first must be a multiple of 32 in fragment order");
+    VFN_REQUIRE(ws_points < ((dy_flags & 2) ? (1ll << 21) : (1ll << 22)), "vfn_mlp_bwd_chain_bf16: at most %lld points per workspace (32-bit slot offsets)",
                 ((dy_flags & 2) ? (1ll << 21) : (1ll << 22)) - 1);
     VFN_REQUIRE(!(dy_flags & 12) || (dy_flags & 2), "vfn_mlp_bwd_chain_bf16: 16-bit gradients need the fragment-ordered layout");
     VFN_REQUIRE((dy_flags & 12) != 12, "vfn_mlp_bwd_chain_bf16: dy_flags asks for bf16 AND scaled f16 gradients");
@@ -744,6 +759,7 @@ extern "C" int vfn_mlp_bwd_chain_bf16_ws(const vfn_net_geom* vf_geom, const void
     a.vf_wt = (const uint4*)vf_packed_bwd16; a.rn_wt = (const uint4*)rn_packed_bwd16; a.vf_head = vf_head_w; a.rn_head = rn_head_w;
     a.feats = saved; a.dy_flags = dy_flags & 14; a.masks = masks; a.dy = (float*)dy; a.d_colors = d_colors; a.colors = colors; a.d_vec = d_vec; a.vec = vec; a.d_feats = d_feats;
     a.dz_rgb = dz_rgb; a.dz_vec = dz_vec; a.n_points = n_points; a.vec_stride = vec_stride;
+    a.ws_first = ws_first; a.ws_points = ws_points;
     const unsigned blocks = (unsigned)((n_points + BW_PTS - 1) / BW_PTS);
     hipStream_t s = (hipStream_t)stream;
     if (dy_flags & 8) {

@@ -1231,6 +1231,13 @@ extern "C" int vfn_render16_from_blocks(const vfn_net_geom* rn_geom, const void*
 extern "C" int vfn_vf_mlp16_fwd_train(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
                                       int32_t with_features, float* out_vec, float* saved, float* save_aux_vf, uint32_t* save_masks,
                                       int32_t save_f16, void* stream) {
+    return vfn_vf_mlp16_fwd_train_at(geom, packed16, points, n_points, with_features, out_vec, saved, save_aux_vf, save_masks, save_f16, 0, n_points,
+                                     stream);
+}
+
+extern "C" int vfn_vf_mlp16_fwd_train_at(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
+                                         int32_t with_features, float* out_vec, float* saved, float* save_aux_vf, uint32_t* save_masks,
+                                         int32_t save_f16, int64_t ws_first, int64_t ws_points, void* stream) {
     Mlp16Args a = {};
     VfnNetPlan p32; Plan16 vf;
     int rc = make_plan16(VFN_NET_VF, geom, &p32, &vf, "vfn_vf_mlp16_fwd_train");
@@ -1239,12 +1246,15 @@ extern "C" int vfn_vf_mlp16_fwd_train(const vfn_net_geom* geom, const void* pack
     if (rc != VFN_OK) return rc;
     if (n_points <= 0) return VFN_OK;
     VFN_REQUIRE(packed16 && points && out_vec && saved && save_aux_vf && save_masks, "vfn_vf_mlp16_fwd_train: NULL argument");
-    VFN_REQUIRE(n_points < ((save_f16 & 2) ? (1ll << 21) : (1ll << 22)), "vfn_vf_mlp16_fwd_train: at most %lld points per launch (32-bit slot offsets)",
+    VFN_REQUIRE(ws_first >= 0 && ws_first + n_points <= ws_points, "vfn_vf_mlp16_fwd_train: points %lld .. %lld outside a workspace of %lld",
+                (long long)ws_first, (long long)(ws_first + n_points), (long long)ws_points);
+    VFN_REQUIRE(!(save_f16 & 2) || ws_first % 32 == 0, "vfn_vf_mlp16_fwd_train: ws_first must be a multiple of 32 in fragment order");
+    VFN_REQUIRE(ws_points < ((save_f16 & 2) ? (1ll << 21) : (1ll << 22)), "vfn_vf_mlp16_fwd_train: at most %lld points per workspace (32-bit slot offsets)",
                 ((save_f16 & 2) ? (1ll << 21) : (1ll << 22)) - 1);
     a.vf_w = (const uint4*)packed16; a.points = points; a.out_vec = out_vec; a.n_points = n_points; a.dirs_div = 1;
     a.vf_multires = vf.multires; a.vf_bytes = vf.total_kb * 1024u; a.saved = saved; a.save_aux_vf = save_aux_vf;
     a.save_masks = save_masks; a.save_f16 = save_f16 & 3;
-    a.ws_first = 0; a.ws_points = n_points;
+    a.ws_first = ws_first; a.ws_points = ws_points;
     a.status = t_status_word;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     if (with_features) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_FULL_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);

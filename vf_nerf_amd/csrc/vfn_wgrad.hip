@@ -105,6 +105,14 @@ extern "C" int vfn_net_weight_grads_frag(int32_t net_kind, const vfn_net_geom* g
                                          const void* dy, int64_t slot_bytes, int32_t dy_form, int32_t x_form, const float* feats,
                                          const float* aux, const float* dz_head, int64_t n_points, int32_t with_features,
                                          int32_t accumulate, void* scratch, void* stream) {
+    return vfn_net_weight_grads_frag_part(net_kind, geom, layers, saved, dy, slot_bytes, dy_form, x_form, feats, aux, dz_head, n_points,
+                                          with_features ? 0xffffffffu : ~VFN_WGRAD_FEATURES, accumulate, scratch, stream);
+}
+
+extern "C" int vfn_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_geom* geom, const vfn_wgrad_layer* layers, const void* saved,
+                                              const void* dy, int64_t slot_bytes, int32_t dy_form, int32_t x_form, const float* feats,
+                                              const float* aux, const float* dz_head, int64_t n_points, uint32_t parts,
+                                              int32_t accumulate, void* scratch, void* stream) {
     const char* what = "vfn_net_weight_grads_frag";
     VFN_REQUIRE(geom && layers && saved && dy && aux && dz_head && scratch, "%s: NULL argument", what);
     if (n_points <= 0) return VFN_OK;
@@ -122,13 +130,15 @@ extern "C" int vfn_net_weight_grads_frag(int32_t net_kind, const vfn_net_geom* g
     vfn_unfold_entry u[12];
     memset(u, 0, sizeof(u));
     int nu = 0;
-    const bool skip_feat = net_kind == VFN_NET_VF && geom->feature_dims > 0 && !with_features;
+    const bool has_feat = net_kind == VFN_NET_VF && geom->feature_dims > 0;
+    VFN_REQUIRE(parts & (VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD), "%s: parts = 0", what);
     for (int h = 0; h < n; ++h) {
         const Entry& x = e[h];
         float* db = c.take((size_t)G * VFN_HIDDEN);
         float* dw_act = x.act_nc ? c.take((size_t)G * VFN_HIDDEN * VFN_HIDDEN) : nullptr;
         float* dw_aux = x.aux_nc ? c.take((size_t)G * VFN_HIDDEN * 64) : nullptr;
-        if (skip_feat && h == n - 1) continue;       // vector-only forward: the feature block was never evaluated
+        const bool is_feat = has_feat && h == n - 1;
+        if (!(parts & (is_feat ? VFN_WGRAD_FEATURES : VFN_WGRAD_LAYERS))) continue;       // (vector-only forward: the feature block was never evaluated)
         const vfn_wgrad_layer& q = layers[x.layer];
         VFN_REQUIRE(q.weight && q.bias && q.g_weight && q.g_bias, "%s: layer %d has a NULL weight / bias / gradient pointer", what, x.layer);
         const void* dy_h = dyb + (size_t)h * slot_bytes;
@@ -153,7 +163,7 @@ extern "C" int vfn_net_weight_grads_frag(int32_t net_kind, const vfn_net_geom* g
         o.rows = x.rows; o.row_off = x.row_off; o.in_dim = geom->in_dims[x.layer]; o.slab_rows = VFN_HIDDEN;
         o.act_c0 = x.act_c0; o.act_nc = x.act_nc; o.aux_c0 = x.aux_c0; o.aux_nc = x.aux_nc; o.scale = x.scale;
     }
-    {   // 3-channel head = rows 0..2 of the last Linear (no BatchNorm)
+    if (parts & VFN_WGRAD_HEAD) {   // 3-channel head = rows 0..2 of the last Linear (no BatchNorm)
         float* part = c.take((size_t)G * 32 * VFN_HIDDEN);
         float* dbp = c.take((size_t)G * 32);
         const int L = geom->n_layers;
@@ -165,5 +175,6 @@ extern "C" int vfn_net_weight_grads_frag(int32_t net_kind, const vfn_net_geom* g
         o.dw_act = part; o.db = dbp; o.w = q.weight; o.b_lin = q.bias; o.g_w = q.g_weight; o.g_b = q.g_bias;
         o.rows = 3; o.row_off = 0; o.in_dim = geom->in_dims[L - 1]; o.slab_rows = 32; o.act_c0 = 0; o.act_nc = VFN_HIDDEN; o.scale = 1.0f;
     }
+    if (nu == 0) return VFN_OK;
     return vfn_unfold_weight_grads_acc(u, nu, G, accumulate ? (1u << nu) - 1u : 0u, stream);
 }

@@ -30,7 +30,8 @@ EXPORTS = (
     "vfn_grid_unify_direction", "vfn_grid_comb_format", "vfn_weight_grad_partials_bf16", "vfn_unfold_weight_grads", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
     "vfn_linear_rows", "vfn_linear_rows_stat_parts", "vfn_bstat_row_parts", "vfn_colsum_finish", "vfn_bstat_finalize",
     "vfn_bstat_relu_rows", "vfn_bstat_relu_bwd_sums", "vfn_bstat_relu_bwd_rows", "vfn_act_bwd_rows", "vfn_embed_rows",
-    "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_vf_render_fused16_products", "vfn_net_weight_grads_frag", "vfn_net_weight_grads_scratch_bytes", "vfn_vf_render_fused16_fwd_train_at",
+    "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_vf_render_fused16_products", "vfn_net_weight_grads_frag", "vfn_net_weight_grads_frag_part", "vfn_net_weight_grads_scratch_bytes", "vfn_vf_render_fused16_fwd_train_at",
+    "vfn_vf_mlp16_fwd_train_at", "vfn_mlp_bwd_chain_bf16_ws_at",
     "vfn_weight_grad_groups", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax",
     "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step", "vfn_unfold_weight_grads_acc", "vfn_render_fwd", "vfn_render_fwd_workspace_bytes",
 )
@@ -588,32 +589,53 @@ def net_weight_grads_scratch_bytes(kind: int, geom, n_points: int) -> int:
     return n
 
 
+WGRAD_LAYERS, WGRAD_FEATURES, WGRAD_HEAD = 1, 2, 4
+
+
 def net_weight_grads_frag(kind: int, geom, layer_table, saved, slot_index: int, dy, slot_floats: int, dy_form: int, x_form: int, feats,
-                          aux, dz_head, n_points: int, with_features: bool, accumulate: bool, scratch) -> None:
+                          aux, dz_head, n_points: int, with_features: bool, accumulate: bool, scratch, first_point: int = 0,
+                          parts: Optional[int] = None) -> None:
     """All weight-gradient launches of one net + the un-fold, from C (csrc/vfn_wgrad.hip).  ``layer_table``: a WgradLayer array
     (parameter and gradient pointers per reference layer); ``saved`` / ``dy``: [slots, slot_floats] workspaces, ``slot_index`` the
     net's first slot in both."""
     for t, name in ((saved, "saved"), (dy, "dy")):
         if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == slot_floats):
             raise VfnError(f"{name}: expected a contiguous CUDA float32 [slots, {slot_floats}] workspace")
-    off = slot_index * slot_floats * 4
-    _check(load().vfn_net_weight_grads_frag(C.c_int32(kind), C.byref(geom), layer_table, C.c_void_p(saved.data_ptr() + off),
-                                            C.c_void_p(dy.data_ptr() + off), C.c_int64(slot_floats * 4), C.c_int32(dy_form), C.c_int32(x_form),
-                                            _ptr(feats, "feats"), _ptr(aux, "aux"), _ptr(dz_head, "dz_head"), C.c_int64(n_points),
-                                            C.c_int32(int(with_features)), C.c_int32(int(accumulate)), _ptr(scratch, "scratch", torch.uint8),
-                                            _stream()), "vfn_net_weight_grads_frag")
+    # ``first_point`` (a multiple of 32): the products run over points first_point .. first_point + n_points - 1 of the workspace;
+    # ``parts``: WGRAD_* mask (default: everything, or everything but the feature block when ``with_features`` is False)
+    if first_point % 32:
+        raise VfnError(f"first_point = {first_point} is not a multiple of 32")
+    off = slot_index * slot_floats * 4 + (first_point // 32) * GROUP_FLOATS * 4
+    if parts is None:
+        parts = (WGRAD_LAYERS | WGRAD_FEATURES | WGRAD_HEAD) if with_features else (WGRAD_LAYERS | WGRAD_HEAD)
+
+    def at(t, row_floats):
+        return None if t is None else C.c_void_p(t.data_ptr() + first_point * row_floats * 4)
+
+    for t, name in ((feats, "feats"), (aux, "aux"), (dz_head, "dz_head")):
+        if t is not None and not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+            raise VfnError(f"{name}: expected a contiguous CUDA float32 tensor")
+    _check(load().vfn_net_weight_grads_frag_part(C.c_int32(kind), C.byref(geom), layer_table, C.c_void_p(saved.data_ptr() + off),
+                                                 C.c_void_p(dy.data_ptr() + off), C.c_int64(slot_floats * 4), C.c_int32(dy_form), C.c_int32(x_form),
+                                                 at(feats, HIDDEN), at(aux, AUX_K), at(dz_head, 4), C.c_int64(n_points),
+                                                 C.c_uint32(parts), C.c_int32(int(accumulate)), _ptr(scratch, "scratch", torch.uint8),
+                                                 _stream()), "vfn_net_weight_grads_frag")
 
 
 def mlp_bwd_chain_bf16_ws(vf_geom, vf_packed_bwd16, vf_head_w, rn_geom, rn_packed_bwd16, rn_head_w, feats, masks, dy, dy_flags: int,
-                          d_colors, colors, d_vec, vec, d_feats, vec_stride: int, n_points: int, dz_rgb, dz_vec):
+                          d_colors, colors, d_vec, vec, d_feats, vec_stride: int, n_points: int, dz_rgb, dz_vec,
+                          ws_first: int = 0, ws_points: Optional[int] = None):
+    """``ws_first`` / ``ws_points``: the launch's points are points ws_first .. of a workspace (feats, masks, dy, dz_rgb, dz_vec)
+    sized for ws_points; the per-sample inputs (d_colors, colors, d_vec, vec, d_feats) stay launch-local."""
     rn = C.byref(rn_geom) if rn_geom is not None else None
-    _check(load().vfn_mlp_bwd_chain_bf16_ws(C.byref(vf_geom), _ptr(vf_packed_bwd16, "vf_packed_bwd16", torch.uint8),
-                                            _ptr(vf_head_w, "vf_head_w"), rn,
-                                            _ptr(rn_packed_bwd16, "rn_packed_bwd16", torch.uint8), _ptr(rn_head_w, "rn_head_w"),
-                                            _ptr(feats, "feats"), _ptr(masks, "masks", torch.int32), _ptr(dy, "dy"), C.c_int32(dy_flags),
-                                            _ptr(d_colors, "d_colors"), _ptr(colors, "colors"), _ptr(d_vec, "d_vec"), _ptr(vec, "vec"),
-                                            _ptr(d_feats, "d_feats"), C.c_int32(vec_stride), C.c_int64(n_points),
-                                            _ptr(dz_rgb, "dz_rgb"), _ptr(dz_vec, "dz_vec"), _stream()), "vfn_mlp_bwd_chain_bf16_ws")
+    _check(load().vfn_mlp_bwd_chain_bf16_ws_at(C.byref(vf_geom), _ptr(vf_packed_bwd16, "vf_packed_bwd16", torch.uint8),
+                                               _ptr(vf_head_w, "vf_head_w"), rn,
+                                               _ptr(rn_packed_bwd16, "rn_packed_bwd16", torch.uint8), _ptr(rn_head_w, "rn_head_w"),
+                                               _ptr(feats, "feats"), _ptr(masks, "masks", torch.int32), _ptr(dy, "dy"), C.c_int32(dy_flags),
+                                               _ptr(d_colors, "d_colors"), _ptr(colors, "colors"), _ptr(d_vec, "d_vec"), _ptr(vec, "vec"),
+                                               _ptr(d_feats, "d_feats"), C.c_int32(vec_stride), C.c_int64(n_points),
+                                               _ptr(dz_rgb, "dz_rgb"), _ptr(dz_vec, "dz_vec"), C.c_int64(ws_first),
+                                               C.c_int64(n_points if ws_points is None else ws_points), _stream()), "vfn_mlp_bwd_chain_bf16_ws")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -795,15 +817,17 @@ def render16_from_blocks(rn_geom: NetGeom, rn_packed16, blocks, vecs, dst, point
     return normals, colors
 
 
-def vf_mlp16_fwd_train(geom: NetGeom, packed16, points, with_features: bool, saved, aux_vf, masks, save_f16: int = 0):
+def vf_mlp16_fwd_train(geom: NetGeom, packed16, points, with_features: bool, saved, aux_vf, masks, save_f16: int = 0,
+                       ws_first: int = 0, ws_points: Optional[int] = None):
     """f16x3 VF forward that fills the backward workspace; returns the vector columns [M,3] (the features, when
-    evaluated, are in their ``saved`` slot)."""
+    evaluated, are in their ``saved`` slot).  ``ws_first`` / ``ws_points``: as in vf_render_fused16_fwd_train."""
     m = points.shape[0]
     out = torch.empty(m, 3, device=points.device)
-    _check(load().vfn_vf_mlp16_fwd_train(C.byref(geom), _ptr(packed16, "packed16", torch.uint8), _ptr(points, "points"),
-                                         C.c_int64(m), C.c_int32(1 if with_features else 0), _ptr(out, "out"),
-                                         _ptr(saved, "saved"), _ptr(aux_vf, "aux_vf"), _ptr(masks, "masks", torch.int32),
-                                         C.c_int32(int(save_f16)), _stream()), "vfn_vf_mlp16_fwd_train")
+    _check(load().vfn_vf_mlp16_fwd_train_at(C.byref(geom), _ptr(packed16, "packed16", torch.uint8), _ptr(points, "points"),
+                                            C.c_int64(m), C.c_int32(1 if with_features else 0), _ptr(out, "out"),
+                                            _ptr(saved, "saved"), _ptr(aux_vf, "aux_vf"), _ptr(masks, "masks", torch.int32),
+                                            C.c_int32(int(save_f16)), C.c_int64(ws_first), C.c_int64(m if ws_points is None else ws_points),
+                                            _stream()), "vfn_vf_mlp16_fwd_train")
     return out
 
 
