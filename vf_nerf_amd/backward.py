@@ -149,10 +149,34 @@ def _wgrad_scratch(net, m: int, dev) -> torch.Tensor:
 
 def _direct_ok(net, dev) -> bool:
     """Every parameter of the net has a gradient tensor the un-fold kernel can add into (the flat optimizer's views)."""
+    if not getattr(net, "accumulate_into_grad", True):
+        return False
     dev = torch.device(dev)
-    return bool(getattr(net, "accumulate_into_grad", True)) and all(
-        p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.device == dev and not p.grad.requires_grad
-        for p in net.parameters())
+    plist = getattr(net, "_param_list_cache", None)
+    if plist is None:
+        plist = net._param_list_cache = list(net.parameters())
+    # the flat optimizer's views (optim.FlatAdam) are contiguous fp32 slices of one device buffer by construction: when every
+    # gradient IS the view it made, nothing else needs checking
+    owner = getattr(plist[0], "_flat_adam", None) if plist else None
+    owner = owner() if owner is not None else None
+    if owner is not None and owner._flat is not None and owner._flat["grad"].device == dev:
+        views = owner._flat.get("grad_views")
+        if views is not None:
+            by_id = owner._flat.get("view_of")
+            if by_id is None:
+                by_id = owner._flat["view_of"] = {id(p): v for (p, _, _, _), v in zip(owner._flat["entries"], views)}
+            if all(p.grad is by_id.get(id(p)) and p.grad is not None for p in plist):
+                return True
+    return all(p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.device == dev and not p.grad.requires_grad
+               for p in plist)
+
+
+def _ensure_grads(net) -> None:
+    """A forward that chose in-place accumulation handed autograd ONE anchor parameter per net; should the gradients have been
+    dropped since (zero_grad(set_to_none=True)), the sums start from fresh zeros here."""
+    for p in net.parameters():
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
 
 
 def _weight_grads(net, inputs, dy_slots, aux, dz_head, m: int, skip=(), fast: bool = False, x_f16: bool = False,
@@ -437,13 +461,15 @@ class StepWorkspace:
         self.dz_vec: Optional[torch.Tensor] = None
         self.done: List[tuple] = []           # (first, padded count, has features) of the regions whose chain has run
         self.queued = False
+        self.regions, self.finished = 1, 0    # regions handed out (the fine pass is the first) / regions whose weight gradients are done
 
     def take(self, count: int) -> Optional[int]:
         """First point of a fresh region of ``count`` (padded) points, or None when the workspace is full."""
-        if count % 32 or self.next + count > self.total:
+        if self.ws is None or count % 32 or self.next + count > self.total:
             return None
         first = self.next
         self.next += count
+        self.regions += 1
         return first
 
     def gradients(self):
@@ -499,6 +525,11 @@ class StepWorkspace:
                     else:
                         k += 1
             i = j + 1
+        # every region differentiated: the step's 20 GB go back to the allocator now, not when the next render replaces this object
+        # (a second backward over the same graph is not supported by these functions anyway)
+        self.finished += len(regions)
+        if self.finished >= self.regions:
+            self.ws = self.dy = self.dz_vec = None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -559,7 +590,12 @@ class StoredFinePass:
         self._launch(new_pts, ray_dirs, self.n_f, self.m_c, self.m - self.m_c)
         self.dst = dst
         model = self.model
-        params = list(model.vector_field_network.parameters()) + list(model.rendering_network.parameters()) + list(model.density.parameters())
+        vf, rn = model.vector_field_network, model.rendering_network
+        if self.pool is not None:
+            # gradients are added in place: autograd only needs an anchor per net to call the backward (90 fewer inputs to track)
+            params = [next(iter(vf.parameters())), next(iter(rn.parameters()))] + list(model.density.parameters())
+        else:
+            params = list(vf.parameters()) + list(rn.parameters()) + list(model.density.parameters())
         return _StoredFinePassFn.apply(self, z, ray_dirs, *params)
 
 
@@ -614,6 +650,8 @@ class _StoredFinePassFn(torch.autograd.Function):
                                   ws.feats(vf_h - 1), ws.masks, dy, ws.dy_flags(), dc_s, sp.colors_s, dn_s, sp.normals_s, None, 3, m, dz_rgb, dz_vec,
                                   ws_first=0, ws_points=sp.ws_points)
         feats = ws.feats(vf_h - 1)
+        if pool is not None:
+            _ensure_grads(rn)
         g_rn = _weight_grads(rn, _rn_inputs(feats, [ws.saved[vf_h + h] for h in range(rn_h)]),
                              [dy[vf_h + h] for h in range(rn_h)], ws.aux_rn, dz_rgb, m, fast=True, x_f16=ws.f16,
                              x_fp32_entries=(0,), frag=ws.frag_forms(), ws_ref=(ws.saved, dy, vf_h))
@@ -653,7 +691,8 @@ class _VFForward(torch.autograd.Function):
         f16, frag, dy16 = _storage(net, bwd_fast)
         # a render() under autograd earlier in this step left room in its workspace: append (StepWorkspace)
         pool = getattr(net, "_step_ws", None)
-        if pool is not None and bwd_fast and frag and m > 0 and pool.storage == (f16, dy16) and pool.ws.saved.device == dev and _direct_ok(net, dev):
+        if pool is not None and pool.ws is not None and bwd_fast and frag and m > 0 and pool.storage == (f16, dy16) and \
+                pool.ws.saved.device == dev and _direct_ok(net, dev):
             mp = _round32(m)
             first = pool.take(mp)
             if first is not None:
@@ -713,6 +752,8 @@ class _VFForward(torch.autograd.Function):
                               None, None, d_out, out, d_feats, cols, m, None, dz_vec)
         # vector-only forward: the feature block of the last Linear was never evaluated -> no gradient for it
         skip = (vf_h - 1,) if (net._feature_dims() > 0 and cols == 3) else ()
+        if len(ctx.param_order) == 1:         # anchor input only (vf_forward_autograd): the gradients are added in place
+            _ensure_grads(net)
         grads = _weight_grads(net, _vf_inputs(net, [ws.saved[h] for h in range(vf_h)]), [dy[h] for h in range(vf_h)],
                               ws.aux_vf, dz_vec, m, skip=skip, fast=fast, x_f16=ws.f16, frag=ws.frag_forms(), ws_ref=(ws.saved, dy, 0))
         ctx.ws = None
@@ -738,7 +779,14 @@ def _offset_view(t: torch.Tensor, col0: int) -> _RawPointer:
 
 
 def vf_forward_autograd(net, points, vector_only):
-    return _VFForward.apply(net, points, vector_only, *list(net.parameters()))
+    plist = getattr(net, "_param_list_cache", None)
+    if plist is None:
+        plist = net._param_list_cache = list(net.parameters())
+    pool = getattr(net, "_step_ws", None)
+    if pool is not None and points.is_cuda and _direct_ok(net, points.device):
+        # (the forward will either join the step's workspace or accumulate in place from its own: one anchor input is enough)
+        return _VFForward.apply(net, points, vector_only, plist[0])
+    return _VFForward.apply(net, points, vector_only, *plist)
 
 
 def render_forward_autograd(net, points, normals, view_dirs, feats):

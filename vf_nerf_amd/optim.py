@@ -162,13 +162,25 @@ class FlatAdam(SequentialAdam):
         self._flat = f
         return f
 
+    def _grad_views(self, f):
+        views = f.get("grad_views")
+        if views is None:
+            views = f["grad_views"] = [f["grad"][off:off + n].view(p.shape) for p, off, n, _ in f["entries"]]
+        return views
+
     def _rebind_grads(self, f) -> None:
-        for p, off, n, _ in f["entries"]:
-            view = f["grad"][off:off + n].view(p.shape)
-            if p.grad is None:
+        """Every ``param.grad`` is (again) its view of the flat gradient buffer; a gradient that autograd or the caller put
+        somewhere else is copied in.  The views are made once: the common case is fifty identity checks."""
+        for (p, off, n, _), view in zip(f["entries"], self._grad_views(f)):
+            g = p.grad
+            if g is view:
+                continue
+            if g is None:
                 p.grad = view
-            elif p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad)
+            elif g.data_ptr() != view.data_ptr():
+                view.copy_(g)
+                p.grad = view
+            else:
                 p.grad = view
 
     # -- torch.optim.Optimizer interface ------------------------------------------------------------
@@ -177,9 +189,9 @@ class FlatAdam(SequentialAdam):
         if f is None:
             return super().zero_grad(set_to_none=set_to_none)
         f["grad"].zero_()
-        for p, off, n, _ in f["entries"]:          # (keeps the views: setting .grad to None would detach them from the buffer)
-            if p.grad is None or p.grad.data_ptr() != f["grad"].data_ptr() + 4 * off:
-                p.grad = f["grad"][off:off + n].view(p.shape)
+        for (p, off, n, _), view in zip(f["entries"], self._grad_views(f)):     # (keeps the views: setting .grad to None would detach them from the buffer)
+            if p.grad is not view:
+                p.grad = view
 
     @torch.no_grad()
     def step(self, closure=None):
