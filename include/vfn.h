@@ -224,6 +224,10 @@ typedef struct vfn_render_params {
     uint64_t seed, offset;              /* Philox stream for the draws not supplied */
     int32_t colour_products;            /* 0 or 3: three products everywhere; 2: the colour branch on two (vfn_vf_render_fused16_products) */
     int32_t separate_launches;          /* 0: the five merged launches; 1: the same pipeline through the stand-alone entry points (eight) */
+    int32_t streams;                    /* 2: the batch in two halves, the second on an internal side stream forked from and joined
+                                         * into `stream` (same values; the halves fill each other's partial rounds); 1: one stream;
+                                         * 0: two halves when the fused launches would leave >= 5 % of their workgroup slots empty */
+    int32_t reserved;
 } vfn_render_params;
 int64_t vfn_render_fwd_workspace_bytes(const vfn_render_params* p);
 int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf_geom, const void* vf_packed16,

@@ -314,7 +314,7 @@ def test_range_guard_costs_nothing_on_the_hot_path():
     assert reads <= 3 and model.f16x3_disabled is None
 
 
-@pytest.mark.parametrize("name", ["c1_perturb", "odd_orbit", "c1_det", "shipped_sizes"])
+@pytest.mark.parametrize("name", ["c1_perturb", "odd_orbit", "c1_det", "shipped_sizes", "bench_sizes"])
 def test_one_call_render_equals_the_launch_by_launch_path(name):
     """vfn_render_fwd (csrc/vfn_render.hip: the whole gradient-free render() issued from C out of one workspace) against the
     facade's launch-by-launch path: every output bit-identical — with the reference's draws replayed, with the device Philox
@@ -328,20 +328,23 @@ def test_one_call_render_equals_the_launch_by_launch_path(name):
 
     def both(**kw):
         outs = []
-        for one_call, separate in ((True, False), (False, False), (True, True)):      # five merged launches | Python | eight from C
-            model.one_call_render, model.render_separate_launches = one_call, separate
+        # two halves on two streams inside the call (default) | five merged launches on one stream | Python | eight launches from C
+        for one_call, separate, streams in ((True, False, 2), (True, False, 1), (False, False, 1), (True, True, 1)):
+            model.one_call_render, model.render_separate_launches, model.render_streams = one_call, separate, streams
             model.rng_seed, model._rng_offset = 17, 5
             with torch.no_grad():
                 outs.append((model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, **kw), model._rng_offset))
-        (a, off_a), (b, off_b), (c, off_c) = outs
-        model.render_separate_launches = False
-        assert off_a == off_b == off_c
-        for f in fields:
-            assert torch.equal(getattr(a, f), getattr(b, f)) and torch.equal(getattr(a, f), getattr(c, f)), (name, f, kw.keys())
+        (a, off_a) = outs[0]
+        model.render_separate_launches, model.render_streams = False, 0
+        for (b, off_b) in outs[1:]:
+            assert off_a == off_b
+            for f in fields:
+                assert torch.equal(getattr(a, f), getattr(b, f)), (name, f, kw.keys())
         return a
 
     out = both(uniforms=uni)
-    assert torch.equal(out.z_vals.cpu(), d["z_vals"]) and rel_err(out.coarse_rgb_values, d["rgb"]) < TIGHT
+    # (bench_sizes: 4e-5 in rgb with any kernel — the weights' conditioning, DESIGN.md section 4 — inside the 1e-4 contract)
+    assert torch.equal(out.z_vals.cpu(), d["z_vals"]) and rel_err(out.coarse_rgb_values, d["rgb"]) < (1e-4 if name == "bench_sizes" else TIGHT)
     both()                                           # device Philox draws
     both(uniforms=uni, white=True)
     if name == "c1_det":                             # one pose / intrinsics for the whole batch

@@ -14,8 +14,9 @@ for n, (s_c, n_f) in cases:
     for products in (2, 3):
         model.colour_products = products
         outs = []
-        for reuse, one_call, separate in ((True, True, False), (True, False, False), (True, True, True), (False, False, False)):
-            model.reuse_proposal, model.one_call_render, model.render_separate_launches = reuse, one_call, separate
+        for reuse, one_call, separate, streams in ((True, True, False, 2), (True, True, False, 1), (True, False, False, 1), (True, True, True, 1),
+                                                   (False, False, False, 1)):
+            model.reuse_proposal, model.one_call_render, model.render_separate_launches, model.render_streams = reuse, one_call, separate, streams
             model._rng_offset = 0
             with torch.no_grad():
                 outs.append(model.render(pose, uv, K, epoch=0))

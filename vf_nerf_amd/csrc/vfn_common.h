@@ -25,9 +25,9 @@ static inline int vfn_check_launch(const char* what) {
 }
 
 // launches shared between translation units, not part of the ABI (csrc/vfn_rays.hip, used by csrc/vfn_render.hip)
-int vfn_internal_raygen(const vfn_raygen_params* p, const float* uv, const float* pose, const float* intrinsics, const float* t_vals,
-                        const float* far_per_ray, const float* u_coarse, int gen_u, long long u_base, uint64_t seed, uint64_t offset,
-                        float* directions, float* ray_dirs, float* cam_loc, float* z_vals, float* points, void* stream);
+int vfn_internal_raygen(const vfn_raygen_params* p, const float* uv, const float* pose, const float* intrinsics, const float* k_sign,
+                        const float* t_vals, const float* far_per_ray, const float* u_coarse, int gen_u, long long u_base, uint64_t seed,
+                        uint64_t offset, float* directions, float* ray_dirs, float* cam_loc, float* z_vals, float* points, void* stream);
 int vfn_internal_density_fine(const vfn_density_params* dp, const float* normals_c, const float* ray_dirs, const float* z_c,
                               const float* density_scalars, const vfn_fine_params* fp, const float* directions, const float* cam_loc,
                               const float* far_per_ray, const float* u_fine, const float* u_add, int gen_fine, int gen_add,

@@ -72,6 +72,8 @@ struct RaygenArgs {
     int gen_u;
     long long u_base;
     PhiloxStream ps;
+    const float* k_sign;     // intrinsics whose [1][1] entry gives the sign of the camera's z axis (utils/rendering.py:42 reads ray 0 of
+                             // the BATCH): NULL = K; a launch over part of a batch passes the batch's first matrix
 };
 
 __device__ __forceinline__ float coarse_z(float near, float far, float t) { return near * (1.0f - t) + far * t; }
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void vfn_raygen_kernel(const RaygenArgs a) {
         }
         const float* Kr = a.K + (size_t)r * 16;
         const float fx = Kr[0], sk = Kr[1], cx = Kr[2], fy = Kr[5], cy = Kr[6];
-        const float fy0 = a.K[5];  // sign is read from ray 0 only (utils/rendering.py:42)
+        const float fy0 = (a.k_sign ? a.k_sign : a.K)[5];  // sign is read from ray 0 only (utils/rendering.py:42)
         const float zs = (fy0 > 0.f) ? 1.f : ((fy0 < 0.f) ? -1.f : 0.f);
         const float u = a.uv[(size_t)r * 2 + 0], v = a.uv[(size_t)r * 2 + 1];
         const float za = fabsf(zs);
@@ -904,11 +906,11 @@ extern "C" int vfn_range_fine_sample_indexed(const vfn_fine_params* p, const flo
 // generated in place, the proposal argmax and the fine sampler in one launch, and the proposal results moved to their sorted
 // positions by the composite launch.  Values are those of the stand-alone entry points, bit for bit.
 // ------------------------------------------------------------------------------------------------
-int vfn_internal_raygen(const vfn_raygen_params* p, const float* uv, const float* pose, const float* intrinsics, const float* t_vals,
-                        const float* far_per_ray, const float* u_coarse, int gen_u, long long u_base, uint64_t seed, uint64_t offset,
-                        float* directions, float* ray_dirs, float* cam_loc, float* z_vals, float* points, void* stream) {
+int vfn_internal_raygen(const vfn_raygen_params* p, const float* uv, const float* pose, const float* intrinsics, const float* k_sign,
+                        const float* t_vals, const float* far_per_ray, const float* u_coarse, int gen_u, long long u_base, uint64_t seed,
+                        uint64_t offset, float* directions, float* ray_dirs, float* cam_loc, float* z_vals, float* points, void* stream) {
     RaygenArgs a{*p, uv, pose, intrinsics, t_vals, far_per_ray, u_coarse, directions, ray_dirs, cam_loc, z_vals, points};
-    a.gen_u = gen_u; a.u_base = u_base; a.ps = PhiloxStream{seed, offset};
+    a.gen_u = gen_u; a.u_base = u_base; a.ps = PhiloxStream{seed, offset}; a.k_sign = k_sign;
     const unsigned blocks = (unsigned)((p->n_rays + K1_RAYS - 1) / K1_RAYS);
     hipLaunchKernelGGL(vfn_raygen_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_render_fwd (rays)");

@@ -56,6 +56,22 @@ Ws carve(void* workspace, const vfn_render_params* p) {
     return w;
 }
 
+// one side stream (+ fork / join events) per host thread and device, made on first use
+struct Side { hipStream_t s; hipEvent_t fork, join; int dev; };
+Side* side_stream() {
+    static thread_local Side side = {nullptr, nullptr, nullptr, -1};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (side.dev != dev) {
+        if (side.dev >= 0) { (void)hipStreamDestroy(side.s); (void)hipEventDestroy(side.fork); (void)hipEventDestroy(side.join); side.dev = -1; }
+        if (hipStreamCreateWithFlags(&side.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&side.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&side.join, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(side.s); return nullptr; }
+        side.dev = dev;
+    }
+    return &side;
+}
+
 }  // namespace
 
 extern "C" int64_t vfn_render_fwd_workspace_bytes(const vfn_render_params* p) {
@@ -118,23 +134,76 @@ extern "C" int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf
         dq.n_samples = st;
         return vfn_ray_density_weights(&dq, normals, ray_dirs, z_vals, density_scalars, colors, nullptr, weights, nullptr, rgb, depth, stream);
     }
-    rc = vfn_internal_raygen(&rp, uv, pose, intrinsics, t_vals, far_coarse_per_ray, p->perturb_coarse ? u_coarse : nullptr, gen_c, 0, p->seed,
-                             p->offset, w.directions, ray_dirs, w.cam_loc, w.z_c, w.pts_c, stream);
-    if (rc != VFN_OK) return rc;
-    rc = vfn_vf_render_fused16_products(vf_geom, vf_packed16, rn_geom, rn_packed16, w.pts_c, ray_dirs, (int64_t)n * sc, sc, nullptr, products,
-                                        w.normals_c, w.colors_c, stream);
-    if (rc != VFN_OK) return rc;
-    vfn_density_params dp = p->density;
-    dp.n_rays = n; dp.n_samples = sc;
-    vfn_fine_params fp = {n, sc, nf, p->near_fine, p->far_fine, p->fine_range, p->window_step, p->span};
-    rc = vfn_internal_density_fine(&dp, w.normals_c, ray_dirs, w.z_c, density_scalars, &fp, w.directions, w.cam_loc, far_fine_per_ray,
-                                   p->perturb_fine ? u_fine : nullptr, u_add, gen_f, gen_a, base_f, base_a, p->seed, p->offset, z_vals, points,
-                                   w.src, w.new_pts, w.dst, (int64_t)n * sc, stream);
-    if (rc != VFN_OK) return rc;
-    rc = vfn_vf_render_fused16_products(vf_geom, vf_packed16, rn_geom, rn_packed16, w.new_pts, ray_dirs, (int64_t)n * nf, nf, w.dst + (size_t)n * sc,
-                                        products, normals, colors, stream);
-    if (rc != VFN_OK) return rc;
-    dp.n_samples = st;
-    return vfn_internal_composite_gather(&dp, normals, ray_dirs, z_vals, density_scalars, colors, w.src, w.normals_c, w.colors_c, (int64_t)n * sc,
-                                         weights, rgb, depth, stream);
+    // The five launches of a range of rays [ray0, ray0 + nh) of the batch on one stream.  Every array is per ray (or per sample of a
+    // ray), so a range works on slices; the Philox elements keep their batch-wide indices, the camera's z sign stays the batch's.
+    auto stage = [&](int which, int ray0, int nh, hipStream_t s) -> int {
+        const size_t r = (size_t)ray0;
+        float* dirs_h = ray_dirs + r * 3;
+        float* n_c = w.normals_c + r * sc * 3; float* c_c = w.colors_c + r * sc * 3;
+        int32_t* dst_h = w.dst + r * st; int32_t* src_h = w.src + r * st;
+        vfn_density_params dp = p->density;
+        dp.n_rays = nh;
+        switch (which) {
+        case 0: {
+            vfn_raygen_params rq = {nh, sc, p->pose_is_quat, p->near_coarse, p->far_coarse};
+            return vfn_internal_raygen(&rq, uv + r * 2, pose + r * (p->pose_is_quat ? 7 : 16), intrinsics + r * 16, intrinsics, t_vals,
+                                       far_coarse_per_ray ? far_coarse_per_ray + r : nullptr,
+                                       (p->perturb_coarse && u_coarse) ? u_coarse + r * sc : nullptr, gen_c, (long long)r * sc, p->seed, p->offset,
+                                       w.directions + r * 3, dirs_h, w.cam_loc + r * 3, w.z_c + r * sc, w.pts_c + r * sc * 3, s);
+        }
+        case 1:
+            return vfn_vf_render_fused16_products(vf_geom, vf_packed16, rn_geom, rn_packed16, w.pts_c + r * sc * 3, dirs_h, (int64_t)nh * sc, sc, nullptr,
+                                                  products, n_c, c_c, s);
+        case 2: {
+            dp.n_samples = sc;
+            vfn_fine_params fp = {nh, sc, nf, p->near_fine, p->far_fine, p->fine_range, p->window_step, p->span};
+            return vfn_internal_density_fine(&dp, n_c, dirs_h, w.z_c + r * sc, density_scalars, &fp, w.directions + r * 3, w.cam_loc + r * 3,
+                                             far_fine_per_ray ? far_fine_per_ray + r : nullptr, (p->perturb_fine && u_fine) ? u_fine + r * nf : nullptr,
+                                             u_add ? u_add + r * nf : nullptr, gen_f, gen_a, base_f + (long long)r * nf, base_a + (long long)r * nf,
+                                             p->seed, p->offset, z_vals + r * st, points + r * st * 3, src_h, w.new_pts + r * nf * 3, dst_h,
+                                             (int64_t)nh * sc, s);
+        }
+        case 3:
+            return vfn_vf_render_fused16_products(vf_geom, vf_packed16, rn_geom, rn_packed16, w.new_pts + r * nf * 3, dirs_h, (int64_t)nh * nf, nf,
+                                                  dst_h + (size_t)nh * sc, products, normals + r * st * 3, colors + r * st * 3, s);
+        default:
+            dp.n_samples = st;
+            return vfn_internal_composite_gather(&dp, normals + r * st * 3, dirs_h, z_vals + r * st, density_scalars, colors + r * st * 3, src_h, n_c, c_c,
+                                                 (int64_t)nh * sc, weights + r * st, rgb + r * 3, depth + r, s);
+        }
+    };
+    hipStream_t main_s = (hipStream_t)stream;
+    // streams: 1 = one stream, 2 = two halves, 0 = two halves when that pays: at least 512 rays and the two fused launches leave >= 5 %
+    // of their workgroup slots empty (one workgroup of 128 points per CU and round of 256; e.g. 1 024 rays x (100 + 35) samples =
+    // 800 + 280 workgroups = 4 + 2 rounds for 4.2 rounds of work: +13 %; whole rounds, or halves too small to fill the chip: nothing
+    // to gain, and 256-ray calls lose 10 %)
+    bool split = p->streams == 2 && n >= 64;
+    if (p->streams == 0 && n >= 512) {
+        const long long wp = ((long long)n * sc + 127) / 128, wq = ((long long)n * nf + 127) / 128;
+        const long long waste = (wp + 255) / 256 * 256 - wp + (wq + 255) / 256 * 256 - wq;
+        split = 20 * waste >= wp + wq;
+    }
+    Side* side = split ? side_stream() : nullptr;
+    if (!side) {
+        for (int k = 0; k < 5; ++k) { rc = stage(k, 0, n, main_s); if (rc != VFN_OK) return rc; }
+        return VFN_OK;
+    }
+    // two halves of the batch, the second on a side stream forked from (and joined back into) the caller's: each half's per-ray
+    // launches and the last, partial round of its fused launches run while the other half's workgroups fill the rest of the chip
+    const int n0 = ((n / 2 + 3) / 4) * 4, n1 = n - n0;
+    if (hipEventRecord(side->fork, main_s) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess) {
+        vfn_set_error("vfn_render_fwd: could not fork the side stream");
+        return VFN_ERR_LAUNCH;
+    }
+    for (int k = 0; k < 5; ++k) {
+        rc = stage(k, 0, n0, main_s);
+        if (rc == VFN_OK) rc = stage(k, n0, n1, side->s);
+        if (rc != VFN_OK) break;
+    }
+    // (joined even after an error, so that the caller's stream never runs ahead of work already issued on the side stream)
+    if (hipEventRecord(side->join, side->s) != hipSuccess || hipStreamWaitEvent(main_s, side->join, 0) != hipSuccess) {
+        vfn_set_error("vfn_render_fwd: could not join the side stream");
+        return VFN_ERR_LAUNCH;
+    }
+    return rc;
 }

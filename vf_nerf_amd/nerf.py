@@ -162,6 +162,11 @@ class VectorFieldNerf:
         self._t_vals: Dict[Tuple[int, str], torch.Tensor] = {}
         # gradient-free f16x3 render() as one C call (vfn_render_fwd) out of a cached workspace; False: launch by launch from Python
         self.one_call_render = True
+        # ... in two halves of the batch, the second on a side stream inside that call (forked from / joined into the current stream):
+        # a half's per-ray launches and the partial last round of its fused launches overlap with the other half's workgroups
+        # (+13 % at 1 024 rays x (100 + 35) samples, whose launches are 4 + 2 rounds of workgroups for 4.2 rounds of work).  Same
+        # values.  0: when that pays (>= 512 rays and >= 5 % of the workgroup slots empty), 1: never, 2: always.
+        self.render_streams = 0
         self._render_ws: Dict[tuple, torch.Tensor] = {}
 
     # ---------------------------------------------------------------------------------------------
@@ -410,6 +415,7 @@ class VectorFieldNerf:
         rp.density = self._density_params()
         rp.colour_products = int(self.colour_products)
         rp.separate_launches = int(getattr(self, "render_separate_launches", False))      # A/B switch (tools/ab_render_plan.py)
+        rp.streams = int(self.render_streams)
 
         def given(name, needed):
             return uniforms[name].to(dev).float().contiguous() if (needed and name in uniforms) else None
