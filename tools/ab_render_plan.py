@@ -8,7 +8,7 @@ import sys, statistics, time, torch
 sys.path.insert(0, '.')
 import bench
 dev = torch.device('cuda:0')
-PLANS = {"two halves on two streams": (False, 2), "five launches, one stream": (False, 1), "eight launches, one stream": (True, 1)}
+PLANS = {"2 ranges": (False, 2), "3 ranges": (False, 3), "4 ranges": (False, 4), "one stream": (False, 1), "eight launches, one stream": (True, 1)}
 for rays, s_c, n_f in ((4096, 64, 64), (1024, 64, 64), (256, 64, 64), (4096, 100, 35), (1024, 100, 35)):
     model, uv, pose, K = bench.build_scene(dev, rays, s_c, n_f, 0)
     times = {k: [] for k in PLANS}

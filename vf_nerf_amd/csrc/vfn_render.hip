@@ -56,17 +56,23 @@ Ws carve(void* workspace, const vfn_render_params* p) {
     return w;
 }
 
-// one side stream (+ fork / join events) per host thread and device, made on first use
-struct Side { hipStream_t s; hipEvent_t fork, join; int dev; };
-Side* side_stream() {
-    static thread_local Side side = {nullptr, nullptr, nullptr, -1};
+// side streams (+ one fork event and a join event each) per host thread and device, made on first use
+constexpr int MAX_SIDE = 3;
+struct Side { hipStream_t s[MAX_SIDE]; hipEvent_t fork, join[MAX_SIDE]; int dev; };
+Side* side_streams() {
+    static thread_local Side side = {{nullptr, nullptr, nullptr}, nullptr, {nullptr, nullptr, nullptr}, -1};
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     if (side.dev != dev) {
-        if (side.dev >= 0) { (void)hipStreamDestroy(side.s); (void)hipEventDestroy(side.fork); (void)hipEventDestroy(side.join); side.dev = -1; }
-        if (hipStreamCreateWithFlags(&side.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&side.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&side.join, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(side.s); return nullptr; }
+        if (side.dev >= 0) {
+            for (int i = 0; i < MAX_SIDE; ++i) { (void)hipStreamDestroy(side.s[i]); (void)hipEventDestroy(side.join[i]); }
+            (void)hipEventDestroy(side.fork);
+            side.dev = -1;
+        }
+        if (hipEventCreateWithFlags(&side.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        for (int i = 0; i < MAX_SIDE; ++i)
+            if (hipStreamCreateWithFlags(&side.s[i], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&side.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
         side.dev = dev;
     }
     return &side;
@@ -177,33 +183,33 @@ extern "C" int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf
     // of their workgroup slots empty (one workgroup of 128 points per CU and round of 256; e.g. 1 024 rays x (100 + 35) samples =
     // 800 + 280 workgroups = 4 + 2 rounds for 4.2 rounds of work: +13 %; whole rounds, or halves too small to fill the chip: nothing
     // to gain, and 256-ray calls lose 10 %)
-    bool split = p->streams == 2 && n >= 64;
+    int parts = (p->streams >= 2 && p->streams <= MAX_SIDE + 1 && n >= 32 * p->streams) ? p->streams : 1;
     if (p->streams == 0 && n >= 512) {
         const long long wp = ((long long)n * sc + 127) / 128, wq = ((long long)n * nf + 127) / 128;
         const long long waste = (wp + 255) / 256 * 256 - wp + (wq + 255) / 256 * 256 - wq;
-        split = 20 * waste >= wp + wq;
+        if (20 * waste >= wp + wq) parts = 2;
     }
-    Side* side = split ? side_stream() : nullptr;
+    Side* side = parts > 1 ? side_streams() : nullptr;
     if (!side) {
         for (int k = 0; k < 5; ++k) { rc = stage(k, 0, n, main_s); if (rc != VFN_OK) return rc; }
         return VFN_OK;
     }
-    // two halves of the batch, the second on a side stream forked from (and joined back into) the caller's: each half's per-ray
-    // launches and the last, partial round of its fused launches run while the other half's workgroups fill the rest of the chip
-    const int n0 = ((n / 2 + 3) / 4) * 4, n1 = n - n0;
-    if (hipEventRecord(side->fork, main_s) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess) {
-        vfn_set_error("vfn_render_fwd: could not fork the side stream");
-        return VFN_ERR_LAUNCH;
-    }
-    for (int k = 0; k < 5; ++k) {
-        rc = stage(k, 0, n0, main_s);
-        if (rc == VFN_OK) rc = stage(k, n0, n1, side->s);
-        if (rc != VFN_OK) break;
-    }
-    // (joined even after an error, so that the caller's stream never runs ahead of work already issued on the side stream)
-    if (hipEventRecord(side->join, side->s) != hipSuccess || hipStreamWaitEvent(main_s, side->join, 0) != hipSuccess) {
-        vfn_set_error("vfn_render_fwd: could not join the side stream");
-        return VFN_ERR_LAUNCH;
-    }
+    // the batch in `parts` ranges of rays, all but the first on side streams forked from (and joined back into) the caller's: a
+    // range's per-ray launches and the last, partial round of its fused launches run while the others' workgroups fill the chip
+    int r0[MAX_SIDE + 2];
+    for (int i = 0; i <= parts; ++i) r0[i] = i == parts ? n : (int)((long long)n * i / parts + 3) / 4 * 4;
+    if (hipEventRecord(side->fork, main_s) != hipSuccess) { vfn_set_error("vfn_render_fwd: could not fork the side streams"); return VFN_ERR_LAUNCH; }
+    for (int i = 1; i < parts; ++i)
+        if (hipStreamWaitEvent(side->s[i - 1], side->fork, 0) != hipSuccess) { vfn_set_error("vfn_render_fwd: could not fork the side streams"); return VFN_ERR_LAUNCH; }
+    rc = VFN_OK;
+    for (int k = 0; k < 5 && rc == VFN_OK; ++k)
+        for (int i = 0; i < parts && rc == VFN_OK; ++i)
+            if (r0[i + 1] > r0[i]) rc = stage(k, r0[i], r0[i + 1] - r0[i], i == 0 ? main_s : side->s[i - 1]);
+    // (joined even after an error, so that the caller's stream never runs ahead of work already issued on a side stream)
+    for (int i = 1; i < parts; ++i)
+        if (hipEventRecord(side->join[i - 1], side->s[i - 1]) != hipSuccess || hipStreamWaitEvent(main_s, side->join[i - 1], 0) != hipSuccess) {
+            vfn_set_error("vfn_render_fwd: could not join the side streams");
+            return VFN_ERR_LAUNCH;
+        }
     return rc;
 }
