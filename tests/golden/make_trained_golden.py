@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Golden vectors on TRAINED weights of the shipped geometry (8 x 256 vector-field net, 4 x 256 rendering net).
+
+Every other fixture holds weights of one family: seed + default init x gain 2 + a recentred vector head.  This one leaves
+the family the way the reference does: the reference's OWN trainer step (``train/vector_field_nerf_train.py:161-292``,
+``VectorFieldNerfRunner.train_epoch``, driven exactly as in ``make_train_golden.py``) runs for a few hundred optimizer
+steps on a LEARNABLE synthetic target — rgb and depth rendered by the reference's ``render()`` from a teacher model with a
+different weight seed — and the reference's ``render()`` is then captured stage by stage on the state
+it arrived at (``make_golden.capture`` / ``capture_grads``), with the trained weights stored in the fixture.
+
+Runs only in the build container (needs /root/reference, read-only); nothing of the reference's source travels.
+
+    python tests/golden/make_trained_golden.py          # ~4 minutes on 8 cores
+
+Writes
+* ``trained_256.npz``          weights after training (``w.vf.*``, ``w.rn.*``, ``w.density.*``), the loss curve of the
+                               reference trainer (``curve.*``), and a stage-by-stage capture + gradients at the headline
+                               sampler sizes (64 + 64, stratified, dir_to_normal_th -0.2);
+* ``trained_256_shipped.npz``  a second capture on the same weights at the shipped sampler sizes (100 + 35, th -2), no weights.
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(HERE, f"{name}.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+mtg = _load("make_train_golden")        # stubs the host-only modules, imports the reference trainer, chdir()s to it
+mg = _load("make_golden")               # capture() / capture_grads() on a reference model
+from vf_nerf_amd import synthetic  # noqa: E402
+
+rcfg, ref_train, RefVFLoss = mtg.rcfg, mtg.ref_train, mtg.RefVFLoss
+CPU = torch.device("cpu")
+
+# the training run (student seed, teacher seed, batches) -----------------------------------------------------------------------
+TRAIN = dict(seed=21, teacher_seed=22, gain=2.0, n_rays=64, n_samples=32, n_importance=32, perturb=True, th=-0.2, n_window=11,
+             near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, skew=0.0, views=8, steps_per_epoch=100, epochs=12,
+             centroid=(0.0, 0.0, 0.55), border_radius=0.15, clip_norm=0.5, lr=5e-4, lr_decay_steps=50000, numpy_seed=2025,
+             torch_seed=3100, cam_seed=300)
+
+# the captures on the trained state (make_golden.FIXTURES-style records; `seed` only offsets the capture's torch seed) --------
+CAPTURES = {
+    "trained_256": dict(seed=21, gain=2.0, n_rays=48, n_samples=64, n_importance=64, perturb=True, th=-0.2, n_window=11,
+                        near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=31, pose="orbit",
+                        skew=0.0, far_per_ray=False, trained=True),
+    "trained_256_shipped": dict(seed=21, gain=2.0, n_rays=12, n_samples=100, n_importance=35, perturb=True, th=-2.0, n_window=11,
+                                near=0.0, far=1.0, fine_range=0.3, width=64, height=64, focal=60.0, cam_seed=33, pose="orbit",
+                                skew=0.0, far_per_ray=False, trained=True, weights_in="trained_256"),
+}
+
+
+def view_pose(i: int) -> torch.Tensor:
+    return synthetic.orbit_pose(-35.0 + 10.0 * i, 5.0 + 2.0 * (i % 3), 0.9)
+
+
+def make_batches(fx, teacher):
+    """Fixed training batches: random pixels of `views` orbit views, targets rendered by the TEACHER (reference render(),
+    deterministic sampling so that the target of a pixel does not depend on the draw)."""
+    keep = (teacher.ray_sampler.deterministic, teacher.fine_sampler.deterministic)
+    teacher.ray_sampler.deterministic = teacher.fine_sampler.deterministic = True
+    batches = []
+    torch.manual_seed(fx["torch_seed"] - 1)
+    for t in range(fx["steps_per_epoch"]):
+        uv, pose, K = synthetic.pinhole_batch(fx["n_rays"], fx["width"], fx["height"], fx["focal"], fx["cam_seed"] + t,
+                                              pose=view_pose(t % fx["views"]), skew=fx["skew"])
+        with torch.no_grad():
+            out = teacher.render(pose, uv, K, 0, False)
+        batches.append({"uv": uv.unsqueeze(0), "pose": pose.unsqueeze(0), "intrinsics": K.unsqueeze(0),
+                        "rgb": out.coarse_rgb_values.detach().clone().unsqueeze(0),
+                        "depth": out.coarse_depth_map.detach().clone().unsqueeze(0)})
+    teacher.ray_sampler.deterministic, teacher.fine_sampler.deterministic = keep
+    return batches
+
+
+def train(fx):
+    student = mtg.build_reference_model(fx)
+    mtg.own_model_matches(fx, student)
+    teacher = mtg.build_reference_model(dict(fx, seed=fx["teacher_seed"]))
+    batches = make_batches(fx, teacher)
+    hit = float(np.mean([float((b["depth"] > 0.02).float().mean()) for b in batches]))
+
+    runner = object.__new__(ref_train.VectorFieldNerfRunner)       # __init__ needs dataset files, an init .pth, wandb: bypassed
+    runner.config = types.SimpleNamespace(
+        vf_nerf_config=student.config, offline=True,
+        dataset_config=types.SimpleNamespace(dataset_name="replica", border_radius=fx["border_radius"]),
+        vf_loss_weights=rcfg.VFLossWeights(rgb=2.0, depth=0.5, unit_norm=0.1, supervision=1.0, norm_smaller_than_one=0.1,
+                                           directional_derivatives=0.0),
+        vf_loss_config=rcfg.VFLossConfig(norm_smaller_than_one_start=11000, depth_loss_clamp=0.5, directional_derivatives_start=100))
+    runner.dataset = mtg._Dataset(fx)
+    runner.dataloader = batches
+    runner.model = student
+    runner.loss = RefVFLoss(runner.config.vf_loss_config, runner.config.vf_loss_weights)
+    student.eval()                                                  # trainer :140-141 (directional-derivative weight 0)
+
+    curve = {"loss": [], "terms": [], "clip": []}
+    real_clip = torch.nn.utils.clip_grad_norm_
+
+    def clip_spy(params, max_norm, *a, **k):
+        out = real_clip(list(params), max_norm, *a, **k)
+        curve["clip"].append(float(out))
+        return out
+
+    names = ("rgb_loss", "depth_loss", "unit_norm_loss", "supervision_loss", "norm_smaller_than_one_loss", "directional_derivatives_loss")
+
+    def loss_spy(module, inputs, output):          # (a forward hook's return value would replace the output)
+        curve["loss"].append(float(output[0].detach()))
+        curve["terms"].append([float(output[1][k]) for k in names])
+
+    hook = runner.loss.register_forward_hook(loss_spy)
+    torch.nn.utils.clip_grad_norm_ = clip_spy
+    t0 = time.time()
+    try:
+        torch.manual_seed(fx["torch_seed"])
+        np.random.seed(fx["numpy_seed"])
+        for epoch in range(fx["epochs"]):
+            runner.train_epoch(epoch)                               # <- the reference's own loop body
+            print(f"  epoch {epoch}: mean loss {np.mean(curve['loss'][-fx['steps_per_epoch']:]):.4f}  ({time.time() - t0:.0f} s)", flush=True)
+    finally:
+        torch.nn.utils.clip_grad_norm_ = real_clip
+        hook.remove()
+    steps = fx["epochs"] * fx["steps_per_epoch"]
+    assert len(curve["loss"]) == steps and len(curve["clip"]) == steps
+    assert float(student.optimizer.state[student.vector_field_network.layers[8].weight]["step"]) == 2 * steps     # Q4
+    # PSNR of the student against the teacher's targets, before (fresh student) / after, on the training batches
+    fresh = mtg.build_reference_model(fx)
+
+    def psnr(model):
+        model.ray_sampler.deterministic = model.fine_sampler.deterministic = True
+        se, n = 0.0, 0
+        with torch.no_grad():
+            for b in batches[:16]:
+                out = model.render(b["pose"][0], b["uv"][0], b["intrinsics"][0], 0, False)
+                se += float(((out.coarse_rgb_values - b["rgb"][0]) ** 2).sum())
+                n += b["rgb"][0].numel()
+        model.ray_sampler.deterministic = model.fine_sampler.deterministic = False
+        return -10.0 * np.log10(se / n)
+
+    stats = {"curve.loss": np.array(curve["loss"]), "curve.terms": np.array(curve["terms"]), "curve.clip": np.array(curve["clip"]),
+             "curve.psnr_before_after": np.array([psnr(fresh), psnr(student)]), "curve.target_hit_fraction": np.array([hit])}
+    return student, stats
+
+
+def weight_arrays(model):
+    out = {}
+    for tag, mod in (("vf", model.vector_field_network), ("rn", model.rendering_network), ("density", model.density)):
+        for k, v in mod.state_dict().items():
+            out[f"w.{tag}.{k}"] = v.detach().cpu().numpy()
+    return out
+
+
+def main() -> None:
+    torch.set_num_threads(8)
+    student, stats = train(TRAIN)
+    student.eval()
+    first, last = stats["curve.loss"][:20].mean(), stats["curve.loss"][-20:].mean()
+    print(f"trained: loss {first:.4f} -> {last:.4f}; PSNR vs teacher {stats['curve.psnr_before_after']}; "
+          f"density beta/mean/scale {float(student.density.get_beta()):.4f} {float(student.density.get_mean()):.4f} "
+          f"{float(student.density.get_scale()):.3f}")
+    chk = synthetic.weights_checksum({"vf": student.vector_field_network.state_dict(), "rn": student.rendering_network.state_dict(),
+                                      "density": student.density.state_dict()})
+    for name, fx in CAPTURES.items():
+        # the capture reads the sampler sizes from the model: same networks, this capture's samplers
+        student.ray_sampler.N_samples, student.fine_sampler.N_samples = fx["n_samples"], fx["n_importance"]
+        student.config.dir_to_normal_th = fx["th"]
+        data, _ = mg.capture(fx, student)
+        data.update(mg.capture_grads(fx, student, data))
+        arrays = {k: v.detach().cpu().numpy() for k, v in data.items()}
+        arrays["weights_checksum"] = np.array([chk["sum"], chk["abs_sum"], chk["count"]], dtype=np.float64)
+        arrays["fixture"] = np.array(repr(fx))
+        if "weights_in" not in fx:
+            arrays.update(weight_arrays(student))
+            arrays.update(stats)
+            arrays["train_recipe"] = np.array(repr(TRAIN))
+        path = os.path.join(HERE, f"{name}.npz")
+        np.savez_compressed(path, **arrays)
+        nz = float((data["weights"].sum(-1) > 0.5).float().mean())
+        print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); rays with surface hits: {nz:.2f}; "
+              f"argmax>0: {float((data['max_indices'] > 0).float().mean()):.2f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -12,7 +12,9 @@ import vf_nerf_amd
 from vf_nerf_amd import synthetic
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-FIXTURE_NAMES = ("c1_det", "c1_perturb", "odd_orbit", "w1_det", "shipped_sizes", "bench_sizes")
+# trained_256*: weights the reference's own trainer arrived at after 1200 optimizer steps (tests/golden/make_trained_golden.py);
+# every other fixture holds weights of the synthetic init family (seed + default init x gain + recentred vector head)
+FIXTURE_NAMES = ("c1_det", "c1_perturb", "odd_orbit", "w1_det", "shipped_sizes", "bench_sizes", "trained_256", "trained_256_shipped")
 
 
 def load_fixture(name: str):
@@ -33,11 +35,18 @@ def build_model(fx: dict, data: Dict[str, torch.Tensor], device="cpu") -> "vf_ne
     cfg.numerical_jacobian = bool(fx.get("numjac", False))
     cfg.rendering_net_config.detach_normals = bool(fx.get("detach_normals", True))
     model = vf_nerf_amd.VectorFieldNerf(cfg)
-    synthetic.scale_hidden_weights(model.vector_field_network, model.rendering_network, fx["gain"])
-    with torch.no_grad():
-        last = model.vector_field_network.layers[8]
-        last.weight[:3] = data["head_weight"]
-        last.bias[:3] = data["head_bias"]
+    if fx.get("trained"):
+        # trained state: the weights are stored (in this fixture or in the one it names)
+        src = data if "weights_in" not in fx else load_fixture(fx["weights_in"])[1]
+        for tag, mod in (("vf", model.vector_field_network), ("rn", model.rendering_network), ("density", model.density)):
+            sd = {k[len(f"w.{tag}."):]: v for k, v in src.items() if k.startswith(f"w.{tag}.")}
+            mod.load_state_dict(sd)
+    else:
+        synthetic.scale_hidden_weights(model.vector_field_network, model.rendering_network, fx["gain"])
+        with torch.no_grad():
+            last = model.vector_field_network.layers[8]
+            last.weight[:3] = data["head_weight"]
+            last.bias[:3] = data["head_bias"]
     chk = synthetic.weights_checksum({"vf": model.vector_field_network.state_dict(),
                                       "rn": model.rendering_network.state_dict(),
                                       "density": model.density.state_dict()})
@@ -57,12 +66,27 @@ def build_model(fx: dict, data: Dict[str, torch.Tensor], device="cpu") -> "vf_ne
     return model
 
 
+_SCALARS = {}
+
+
+def density_scalars(fx: dict):
+    """(beta, mean, scale) as stored parameters: the shipped initial values, or the trained fixture's."""
+    if not fx.get("trained"):
+        return 0.5, 0.7, 100.0
+    src = fx.get("weights_in", "trained_256")
+    if src not in _SCALARS:
+        raw = np.load(os.path.join(GOLDEN_DIR, f"{src}.npz"))
+        _SCALARS[src] = tuple(float(raw[f"w.density.{k}"].reshape(-1)[0]) for k in ("beta", "mean", "scale"))
+    return _SCALARS[src]
+
+
 def oracle_settings(fx: dict):
     from oracle import vfnerf_oracle as O
+    beta0, mean0, scale0 = density_scalars(fx)
     return O.RenderSettings(detach_normals=bool(fx.get("detach_normals", True)), numerical_jacobian=bool(fx.get("numjac", False)), train_mode=bool(fx.get("train", False)), n_samples=fx["n_samples"], n_fine=fx["n_importance"], near=fx["near"], far=fx["far"],
                             fine_range=fx["fine_range"], perturb=fx["perturb"], n_window=fx["n_window"],
                             dir_to_normal_th=fx["th"], normalize=True,
-                            density=O.DensityParams(beta=0.5, mean=0.7, scale=100.0, beta_bounds=(1e-4, 1e9),
+                            density=O.DensityParams(beta=beta0, mean=mean0, scale=scale0, beta_bounds=(1e-4, 1e9),
                                                     mean_bounds=(0.6, 1.0), scale_min=1.0))
 
 
@@ -102,9 +126,10 @@ def oracle_gradients(fx, d, model, masks=None):
         for name, _ in net.named_parameters():
             sd[name].requires_grad_(True)
             leaves[f"{tag}.{name}"] = sd[name]
-    beta = torch.tensor(0.5, requires_grad=True)
-    mean = torch.tensor(0.7, requires_grad=True)
-    scale = torch.tensor(100.0, requires_grad=True)
+    beta0, mean0, scale0 = density_scalars(fx)
+    beta = torch.tensor(beta0, requires_grad=True)
+    mean = torch.tensor(mean0, requires_grad=True)
+    scale = torch.tensor(scale0, requires_grad=True)
     hidden = []
     out = O.render(d["uv"], d["pose"], d["intrinsics"], vf_sd, rn_sd, oracle_settings(fx), u_coarse=d.get("u_coarse"),
                    u_fine=d.get("u_fine"), u_add=d["u_add"], far=d.get("far_per_ray"), beta=beta, mean=mean, scale=scale,

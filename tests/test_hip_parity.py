@@ -160,9 +160,36 @@ def test_composite_with_reference_inputs(case):
     assert depth.shape == (d["depth"].shape[0], 1)
 
 
+def _account(out, d, label):
+    """Per-ray accounting of a render against a reference fixture -> dict of measured figures (printed by the callers):
+    fraction of rays whose sorted sample depths are bit-identical, fraction of those inside 1e-4 (rgb, depth), the worst
+    absolute errors, and the worst RELATIVE error over entries with |ref| > 1e-2 (an absolute bound alone says little about
+    values in [0, 1])."""
+    same_z = (out.z_vals.cpu() == d["z_vals"]).all(dim=1)
+    rgb, depth = out.coarse_rgb_values.cpu(), out.coarse_depth_map.cpu()
+    rgb_err = (rgb - d["rgb"]).abs().max(dim=1)[0]
+    dep_err = (depth - d["depth"]).abs().reshape(-1)
+    ok = (rgb_err < TOL) & (dep_err < TOL * max(1.0, float(d["depth"].abs().max())))
+    g = same_z
+    nrm_err = (out.coarse_normals.cpu() - d["normals"]).abs().amax(dim=(1, 2))
+    col_err = (out.coarse_colors.cpu().reshape(d["z_vals"].shape[0], -1, 3) - d["colors"].reshape(d["z_vals"].shape[0], -1, 3)).abs().amax(dim=(1, 2))
+
+    def worst_rel(a, b):
+        big = b.abs() > 1e-2
+        return float(((a - b).abs()[big] / b.abs()[big]).max()) if bool(big.any()) else 0.0
+
+    res = dict(frac_same_z=float(same_z.float().mean()), n_rays=int(same_z.numel()), n_diff_z=int((~same_z).sum()),
+               frac_within_tol=float(ok[g].float().mean()) if bool(g.any()) else 0.0,
+               max_rgb=float(rgb_err[g].max()), max_depth=float(dep_err[g].max()), max_normals=float(nrm_err[g].max()),
+               max_colors=float(col_err[g].max()), rel_rgb=worst_rel(rgb[g], d["rgb"][g]), rel_depth=worst_rel(depth[g], d["depth"][g]))
+    print(label, {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in res.items()})
+    return res
+
+
 def test_render_end_to_end(case):
-    """Whole render() with the reference's random draws replayed.  A ray only counts as an outlier when a
-    discontinuity (argmax / mask threshold) flipped; such rays must be rare and everything else within 1e-4."""
+    """Whole render() (the DEFAULT path: f16x3, two-product colours, one C call) with the reference's random draws replayed.
+    A ray only counts as an outlier when a discontinuity (argmax / mask threshold) flipped.  Bounds are what is observed on
+    these fixtures (every ray samples identically, every ray inside 1e-4), with one ray of slack on the larger fixtures."""
     from oracle import vfnerf_oracle as O
     fx, d, g, model = case
     uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add") if k in g}
@@ -174,19 +201,52 @@ def test_render_end_to_end(case):
     assert out.coarse_rgb_values.shape == (n, 3) and out.coarse_depth_map.shape == (n, 1)
     assert out.z_vals.shape == (n, s_t) and out.ray_dirs.shape == (n * s_t, 3) and out.coarse_colors.shape == (n * s_t, 3)
     assert out.fine_normals is None and out.directional_derivtives is None
-    same_z = (out.z_vals.cpu() == d["z_vals"]).all(dim=1)
-    frac = float(same_z.float().mean())
-    print(f"rays with bit-identical fine z: {frac:.3f}")
-    assert frac >= 0.9
-    good = same_z
-    rgb_err = (out.coarse_rgb_values.cpu() - d["rgb"]).abs().max(dim=1)[0]
-    dep_err = (out.coarse_depth_map.cpu() - d["depth"]).abs().reshape(-1)
-    print(f"max rgb err (matching rays) {float(rgb_err[good].max()):.3e}, depth {float(dep_err[good].max()):.3e}")
-    ok = (rgb_err < TOL) & (dep_err < TOL * max(1.0, float(d['depth'].abs().max())))
-    assert float(ok[good].float().mean()) >= 0.97, "fp32 noise may flip a density mask on a few rays, not more"
+    r = _account(out, d, f"end-to-end {fx.get('n_rays')}x{s_t}")
+    assert r["frac_same_z"] >= 0.99 or r["n_diff_z"] <= 1, "fp32 noise may move the argmax of one ray, not more"
+    assert r["frac_within_tol"] >= 0.995 or (r["n_rays"] - r["n_diff_z"]) * (1 - r["frac_within_tol"]) <= 1.01
+    assert r["rel_rgb"] < 5e-4 and r["rel_depth"] < 5e-4, "element-wise relative error of entries with |ref| > 1e-2 (observed: <= 1e-4)"
+    good = (out.z_vals.cpu() == d["z_vals"]).all(dim=1)
     psnr = O.psnr(out.coarse_rgb_values.cpu()[good], d["rgb"][good])
     print(f"PSNR vs reference (matching rays): {psnr:.1f} dB")
-    assert psnr > 60.0
+    assert psnr > 80.0
+
+
+@pytest.mark.parametrize("mode", ["default", "launch_by_launch", "colour3", "fp32"])
+@pytest.mark.parametrize("name", ["trained_256", "trained_256_shipped"])
+def test_render_on_trained_weights(name, mode):
+    """Weights the REFERENCE'S OWN TRAINER arrived at (1200 optimizer steps of train_epoch on a teacher-rendered target at the
+    shipped 8 x 256 / 4 x 256 geometry, tests/golden/make_trained_golden.py), i.e. outside the synthetic init family of every
+    other fixture, through the fused f16x3 kernels: the default path (two-product colours, one C call), the same launch by
+    launch, three products, and the exact-fp32 kernels.  Sample depths bit-exact; rgb / depth / normals / colours inside the
+    1e-4 contract on EVERY ray; the range guard, in strict mode, has nothing to report (no switch to fp32, colours stay on two
+    products)."""
+    import warnings
+    fx, d = load_fixture(name)
+    g = to_dev(d)
+    model = build_model(fx, d, device="cuda:0")
+    if mode == "launch_by_launch":
+        model.one_call_render = False
+    elif mode == "colour3":
+        model.colour_products = 3
+    elif mode == "fp32":
+        model.precision = "fp32"
+    model.f16x3_guard = "strict"
+    uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add") if k in g}
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)          # a guard switch warns: it must not happen here
+        with torch.no_grad():
+            out = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
+    r = _account(out, d, f"trained {name} {mode}")
+    assert torch.equal(out.z_vals.cpu(), d["z_vals"]), "sample depths must be bit-exact on trained weights"
+    assert r["frac_within_tol"] == 1.0
+    assert r["max_rgb"] < TOL and r["max_depth"] < TOL and r["max_normals"] < TOL and r["max_colors"] < TOL
+    if mode != "fp32":
+        assert model.uses_f16x3() and model.f16x3_disabled is None, model.f16x3_disabled
+        assert model.range_guard.check_now(dev()) is None
+    if mode in ("default", "launch_by_launch"):
+        assert model.colour_products == 2 and model.range_guard.colour_products_reason is None
+    if mode in ("colour3", "fp32"):
+        assert r["max_colors"] < TIGHT and r["max_rgb"] < TIGHT
 
 
 def test_render_at_an_annealing_epoch_matches_the_reference():
