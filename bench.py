@@ -3,8 +3,9 @@
 128 samples per ray (S_c = N_f = 64), synthetic random-weight scene, one process per GPU.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 --steps 20 --warmup 3          # starts its own 8 ranks (torch.distributed.run as a CHILD process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus 8 --steps 20 --warmup 3
+        bench.py --gpus 8 --steps 20 --warmup 3             # ... or is started as a rank by the caller's launcher
 
 A step = one render() of one 4096-ray chunk per rank (rays shard embarrassingly: no data-path collective,
 weak scaling).  The timed region is bracketed by barrier + torch.cuda.synchronize() on both sides; the time is
@@ -65,10 +66,10 @@ def hbm_traffic(f16: bool, kernel_class: str = "fused16", colour_products: int =
     return None
 
 
-def build_scene(dev, n_rays, s_c, n_f, seed, perturb=True):
+def build_scene(dev, n_rays, s_c, n_f, seed, perturb=True, weight_seed=0):
     import vf_nerf_amd
     from vf_nerf_amd import synthetic
-    torch.manual_seed(0)
+    torch.manual_seed(weight_seed)
     cfg = vf_nerf_amd.shipped_config(dev, n_samples=s_c, n_importance=n_f, perturb=perturb, dir_to_normal_th=-0.2)
     model = vf_nerf_amd.VectorFieldNerf(cfg)
     model.eval()
@@ -111,14 +112,70 @@ def cpu_baseline(model, uv, pose, K, s_c, n_f, sample_rays=1024, budget_s=12.0):
         # against the oracle's output (the oracle is the checker here, never the thing measured as `value`)
         out = model.render(pose[:sample_rays], uv[:sample_rays], K[:sample_rays], epoch=0, uniforms=uni)
     rgb, depth = out.coarse_rgb_values.cpu(), out.coarse_depth_map.cpu()
-    same = (out.z_vals.cpu() == ref["z_vals"]).all(dim=1)
-    parity = {"rays": sample_rays, "psnr_rgb_db": round(min(O.psnr(rgb, ref["rgb"]), 200.0), 2),
-              "mean_abs_depth_err": float((depth - ref["depth"].reshape(depth.shape)).abs().mean()),
-              "max_abs_rgb_err_identically_sampled_rays": float((rgb - ref["rgb"]).abs().max(dim=1)[0][same].max()),
-              "rays_sampled_bit_identically": round(float(same.float().mean()), 4)}
+    parity = {"rays": sample_rays, "colour_products_ran": int(model.colour_products) if model.uses_f16x3() else None,
+              "psnr_rgb_db": round(min(O.psnr(rgb, ref["rgb"]), 200.0), 2)}
+    parity.update(ray_accounting(out.z_vals.cpu(), rgb, depth, ref["z_vals"], ref["rgb"], ref["depth"].reshape(depth.shape)))
     return {"value": round(sample_rays * reps / el, 1), "unit": "rays/s", "cores": threads, "kind": "port",
             "sample": f"{reps} x oracle render() of {sample_rays} rays x {s_c + n_f} samples, torch fp32 CPU, "
                       f"{threads} threads, {el:.1f} s"}, parity
+
+
+def ray_accounting(z, rgb, depth, ref_z, ref_rgb, ref_depth, tol=1e-4, z_tol=0.0):
+    """Per-ray accounting of a render against a reference: how many rays sampled bit-identical depths (z_tol > 0: every depth
+    within z_tol — a float64 reference has no bit-identical depths), and of THOSE how many are inside the contract (|rgb| and
+    |depth| errors below `tol`); worst errors over them and over all rays."""
+    same = (z == ref_z).all(dim=1) if z_tol == 0.0 else ((z.double() - ref_z.double()).abs() <= z_tol).all(dim=1)
+    e_rgb = (rgb - ref_rgb).abs().max(dim=1)[0]
+    e_dep = (depth - ref_depth).abs().reshape(-1)
+    inside = (e_rgb < tol) & (e_dep < tol)
+    n_same = int(same.sum())
+    return {"rays_sampled_bit_identically": round(float(same.float().mean()), 5), "rays_with_different_z": int((~same).sum()),
+            "frac_rays_within_1e-4": round(float(inside[same].float().mean()), 5) if n_same else None,
+            "frac_all_rays_within_1e-4": round(float(inside.float().mean()), 5),
+            "max_abs_rgb_err_identically_sampled_rays": float(e_rgb[same].max()) if n_same else None,
+            "max_abs_depth_err_identically_sampled_rays": float(e_dep[same].max()) if n_same else None,
+            "max_abs_rgb_err": float(e_rgb.max()), "mean_abs_depth_err": float(e_dep.mean())}
+
+
+def trained_weights_parity(dev, precision="f16x3"):
+    """The DEFAULT render path on weights the reference's own trainer produced (tests/golden/trained_256.npz: 1200 steps of
+    train_epoch on a teacher-rendered target, stage outputs captured from the reference's render(); make_trained_golden.py)
+    against the reference's outputs stored there — no oracle involved.  The range guard runs in strict mode: what it reports,
+    and which product count actually produced the colours, is part of the record."""
+    import ast
+    import warnings
+    import numpy as np
+    import vf_nerf_amd
+    path = os.path.join(REPO, "tests", "golden", "trained_256.npz")
+    if not os.path.exists(path):
+        return None
+    raw = np.load(path)
+    fx = ast.literal_eval(str(raw["fixture"]))
+    cfg = vf_nerf_amd.shipped_config(dev, n_samples=fx["n_samples"], n_importance=fx["n_importance"], perturb=fx["perturb"],
+                                     near=fx["near"], far=fx["far"], fine_range=fx["fine_range"], dir_to_normal_th=fx["th"],
+                                     n_window=fx["n_window"])
+    model = vf_nerf_amd.VectorFieldNerf(cfg)
+    for tag, mod in (("vf", model.vector_field_network), ("rn", model.rendering_network), ("density", model.density)):
+        mod.load_state_dict({k[len(f"w.{tag}."):]: torch.from_numpy(raw[k]) for k in raw.files if k.startswith(f"w.{tag}.")})
+    model.eval()
+    model.precision = precision
+    model.f16x3_guard = "strict"
+    g = lambda k: torch.from_numpy(raw[k]).to(dev)           # noqa: E731
+    uni = {k: g(k) for k in ("u_coarse", "u_fine", "u_add")}
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            out = model.render(g("pose"), g("uv"), g("intrinsics"), epoch=0, uniforms=uni)
+    rec = {"fixture": "tests/golden/trained_256.npz (reference train_epoch x 1200 steps; reference render() outputs)",
+           "rays": fx["n_rays"], "samples": fx["n_samples"] + fx["n_importance"],
+           "colour_products_ran": int(model.colour_products) if model.uses_f16x3() else None,
+           "kernels": "f16x3" if model.uses_f16x3() else "fp32",
+           "guard": {"mode": "strict", "switched_to_fp32": model.f16x3_disabled, "colour_products_reason": model.range_guard.colour_products_reason,
+                     "warnings": [str(w.message)[:160] for w in caught if issubclass(w.category, RuntimeWarning)]},
+           "max_abs_normals_err": float((out.coarse_normals.cpu() - torch.from_numpy(raw["normals"])).abs().max())}
+    rec.update(ray_accounting(out.z_vals.cpu(), out.coarse_rgb_values.cpu(), out.coarse_depth_map.cpu(), torch.from_numpy(raw["z_vals"]),
+                              torch.from_numpy(raw["rgb"]), torch.from_numpy(raw["depth"]).reshape(-1, 1)))
+    return rec
 
 
 def _oracle_inputs(model):
@@ -140,8 +197,18 @@ def view_bench(args, dev):
     uv, pose, K = synthetic.pinhole_image(w, h, f, device=dev)
     n = uv.shape[0]
 
-    def full_view():
-        return model.render_chunked(pose, uv, K, epoch=0, chunk=chunk, n_streams=args.streams)
+    if args.as_evaluator:
+        # the evaluator's own situation (evaluation/methods.py:504-545): the dataset hands the view over as HOST tensors with the pose
+        # and intrinsics replicated per ray, and wants rgb / depth back on the host -> evaluator.render_view (what dropin.install()
+        # puts behind evaluation.methods.render_images); uploads and the download are inside the timed region
+        from vf_nerf_amd import evaluator
+        uv_h, pose_h, K_h = uv.cpu(), pose.cpu(), K.cpu()
+
+        def full_view():
+            return evaluator.render_view(model, pose_h, uv_h, K_h, 0, split_size=chunk, n_streams=args.streams)
+    else:
+        def full_view():
+            return model.render_chunked(pose, uv, K, epoch=0, chunk=chunk, n_streams=args.streams)
 
     with torch.no_grad():
         for _ in range(max(1, args.warmup // 3)):
@@ -159,6 +226,9 @@ def view_bench(args, dev):
         g = torch.Generator().manual_seed(21)
         uni = {"u_add": torch.rand(ws * hs, n_f, generator=g)}
         o = model.render(pose_s, uv_s, K_s, epoch=0, uniforms=uni)
+        model.precision = "fp32"                       # the exact-fp32 HIP kernels on the same rays: the second column of the accounting
+        o32 = model.render(pose_s, uv_s, K_s, epoch=0, uniforms=uni)
+        model.precision = args.precision
         torch.set_num_threads(min(32, os.cpu_count() or 1))
         settings = O.RenderSettings(n_samples=s_c, n_fine=n_f, perturb=False, dir_to_normal_th=-0.2, fine_range=0.3,
                                     density=O.DensityParams(scale_min=1.0))
@@ -166,7 +236,23 @@ def view_bench(args, dev):
         t1 = time.perf_counter()
         ref = O.render(uv_s.cpu(), pose_s.cpu(), K_s.cpu(), vf_sd, rn_sd, settings, **uni)
         cpu_s = time.perf_counter() - t1
+        # the yardstick: the SAME oracle in float64 (every tensor promoted; nothing else changed).  The distance of the fp32 oracle
+        # from it is what "the reference's own fp32 arithmetic" can claim on these rays — a density threshold (Laplace scale 100
+        # on a windowed cosine) turns a 1e-7 difference in a normal into a different sigma wherever a sample sits on the edge
+        dbl = lambda sd: {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}     # noqa: E731
+        t2 = time.perf_counter()
+        ref64 = O.render(uv_s.cpu().double(), pose_s.cpu().double(), K_s.cpu().double(), dbl(vf_sd), dbl(rn_sd), settings,
+                         u_add=uni["u_add"].double())
+        cpu64_s = time.perf_counter() - t2
+
+    def account(z, rgb_a, dep_a, zb, rgb_b, dep_b, exact_z=True):
+        # (float64 depths are not comparable bit for bit: "same sampling" = every depth within 1e-6)
+        return ray_accounting(z, rgb_a.float(), dep_a.float().reshape(-1, 1), zb, rgb_b.float(), dep_b.float().reshape(-1, 1),
+                              z_tol=0.0 if exact_z else 1e-6)
+
     rgb, depth = o.coarse_rgb_values.cpu(), o.coarse_depth_map.cpu()
+    rgb32, depth32 = o32.coarse_rgb_values.cpu(), o32.coarse_depth_map.cpu()
+    r64_rgb, r64_dep, r64_z = ref64["rgb"], ref64["depth"], ref64["z_vals"]
     print(json.dumps({
         "metric": "rays/sec (full 1200x680 view, 1024-ray chunks, 128 samples/ray) + PSNR/depth vs ref",
         "value": round(n * args.steps / elapsed, 1), "unit": "rays/s", "n_gpus": 1, "steps": args.steps,
@@ -174,13 +260,20 @@ def view_bench(args, dev):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16x3+f32acc" if args.precision == "f16x3" else "f32", "data": "synthetic",
         "config": {"workload": f"full view {w}x{h} = {n} rays in {chunk}-ray chunks x {s_c + n_f} samples, perturb off, "
-                               f"forward only, consecutive chunks on {args.streams} stream(s) (BASELINE.json configs[1])"},
+                               f"forward only, consecutive chunks on {args.streams} stream(s) (BASELINE.json configs[1])" +
+                               (", as the evaluator runs it: host tensors in (pose / intrinsics per ray), host rgb / depth out, uploads and "
+                                "download inside the timed region (evaluator.render_view)" if args.as_evaluator else ", inputs resident in HBM"),
+                   "colour_products": int(model.colour_products) if args.precision == "f16x3" else None},
         "parity_vs_oracle": {"image": f"{ws}x{hs} (same camera, intrinsics / 8), {ws * hs} rays",
                              "psnr_rgb_db": round(min(O.psnr(rgb, ref["rgb"]), 200.0), 2),
-                             "mean_abs_depth_err": float((depth - ref["depth"].reshape(depth.shape)).abs().mean()),
-                             "max_abs_rgb_err": float((rgb - ref["rgb"]).abs().max()),
                              "argmax_indices_equal": bool((o.z_vals.cpu() == ref["z_vals"]).all()),
-                             "oracle_seconds": round(cpu_s, 1)}}), flush=True)
+                             "oracle_seconds": round(cpu_s, 1), "oracle_float64_seconds": round(cpu64_s, 1),
+                             # who is how far from whom, per ray (contract: 1e-4)
+                             "hip_default_vs_oracle_f32": account(o.z_vals.cpu(), rgb, depth, ref["z_vals"], ref["rgb"], ref["depth"]),
+                             "hip_exact_fp32_vs_oracle_f32": account(o32.z_vals.cpu(), rgb32, depth32, ref["z_vals"], ref["rgb"], ref["depth"]),
+                             "oracle_f32_vs_oracle_f64": account(ref["z_vals"], ref["rgb"], ref["depth"], r64_z, r64_rgb, r64_dep, exact_z=False),
+                             "hip_default_vs_oracle_f64": account(o.z_vals.cpu(), rgb, depth, r64_z, r64_rgb, r64_dep, exact_z=False),
+                             "hip_exact_fp32_vs_oracle_f64": account(o32.z_vals.cpu(), rgb32, depth32, r64_z, r64_rgb, r64_dep, exact_z=False)}}), flush=True)
 
 
 def grid_bench(args, dev, rank, world, dist, sync):
@@ -238,6 +331,94 @@ def grid_bench(args, dev, rank, world, dist, sync):
         dist.destroy_process_group()
 
 
+def grid_stages_bench(args, dev):
+    """the dense-grid stages between the vector-field queries and the triangulation (evaluation/methods.py:
+    210-253 -> mc_utils.extract_divergence / unify_direction / make_comb_format, guassian_smoothing.smooth_vf) on a res^3 grid whose
+    field is the scene's own vector field (queried on the device first).  Every stage is HBM-bound: reported as ALGORITHMIC bytes per
+    cell (each grid value in and out once) / average launch time (HIP events) against the 8 TB/s HBM peak."""
+    from vf_nerf_amd import grid, lib as vlib
+    model, _, _, _ = build_scene(dev, 16, 64, 64, seed=0)
+    model.precision = args.precision
+    dec = model.fine_vector_field_network
+    reps = max(3, args.steps // 2)
+
+    def timed(fn, reps=reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def field(res):
+        ax = torch.linspace(-1.0, 1.0, res, device=dev)
+        pts = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1).reshape(-1, 3).contiguous()
+        pred = grid.get_set_predictions(dec, pts, 100000, dev)
+        del pts
+        return pred
+
+    out = {}
+    stages = []
+    for res in sorted({args.grid_res, args.unify_res}):
+        pred = field(res)
+        cells = res ** 3
+        rec = {}
+        if res == args.grid_res:
+            div = None
+
+            def f_div():
+                nonlocal div
+                div = vlib.grid_divergence(pred, res, -0.5)
+            ms = timed(f_div)
+            rec["divergence"] = {"ms": round(ms, 4), "bytes_per_cell": 16, "tb_per_s": round(cells * 16 / ms / 1e9, 3)}
+            w9 = grid.gaussian_weights(9, 2.0)
+            tmp = torch.empty_like(pred)
+            for axis in (0, 1, 2):
+                ms = timed(lambda: vlib.grid_smooth_axis(pred, tmp, res, axis, w9))
+                rec[f"smooth_k9_axis{axis}"] = {"ms": round(ms, 4), "bytes_per_cell": 24, "tb_per_s": round(cells * 24 / ms / 1e9, 3)}
+            w3 = grid.gaussian_weights(3, 1.0)
+            ms3 = sum(timed(lambda: vlib.grid_smooth_axis(pred, tmp, res, axis, w3)) for axis in (0, 1, 2))
+            rec["smooth_k3_three_axes"] = {"ms": round(ms3, 4), "bytes_per_cell": 72, "tb_per_s": round(cells * 72 / ms3 / 1e9, 3)}
+            ms9 = sum(rec[f"smooth_k9_axis{a}"]["ms"] for a in (0, 1, 2))
+            rec["smooth_k9_three_axes"] = {"ms": round(ms9, 4), "bytes_per_cell": 72, "tb_per_s": round(cells * 72 / ms9 / 1e9, 3)}
+            rec["surface_cell_fraction"] = round(float(div.mean()), 5)
+            del tmp
+        if res == args.unify_res:
+            div = vlib.grid_divergence(pred, res, -0.5)
+            vt = torch.nn.functional.normalize(pred, dim=1)
+            norms = torch.norm(pred, dim=1)
+            sides = choice = None
+
+            def f_uni():
+                nonlocal sides, choice
+                sides, choice = vlib.grid_unify_direction_sides(div.reshape(-1), vt, res)
+            ms = timed(f_uni)
+            rec["unify_direction"] = {"ms": round(ms, 4), "bytes_per_cell": 69, "tb_per_s": round(cells * 69 / ms / 1e9, 3),
+                                      "note": "4 B mask in, 64 B int64 table + 1 B side byte out; corner vectors only for surface cells"}
+            ms = timed(lambda: vlib.grid_comb_format_sides(sides, norms, res), reps=3)
+            rec["make_comb_format_from_side_bytes"] = {"ms": round(ms, 4), "bytes_per_cell": 341, "tb_per_s": round(cells * 341 / ms / 1e9, 3)}
+            ms = timed(lambda: vlib.grid_comb_format(choice, norms, res), reps=3)
+            rec["make_comb_format_from_int64_table"] = {"ms": round(ms, 4), "bytes_per_cell": 404, "tb_per_s": round(cells * 404 / ms / 1e9, 3)}
+            rec["surface_cell_fraction"] = round(float(div.mean()), 5)
+            del vt, norms, sides, choice
+        out[f"res_{res}"] = rec
+        stages += [v["tb_per_s"] for v in rec.values() if isinstance(v, dict)]
+        del pred, div
+        torch.cuda.empty_cache()
+    best_div = out[f"res_{args.grid_res}"]["divergence"]
+    print(json.dumps({"metric": "dense-grid stage throughput (algorithmic HBM bytes / launch time)", "value": best_div["tb_per_s"], "unit": "TB/s",
+                      "n_gpus": 1, "steps": reps, "warmup": 1, "ms_per_step": best_div["ms"], "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": f"extract_divergence / smooth_vf at {args.grid_res}^3, unify_direction / make_comb_format at "
+                                             f"{args.unify_res}^3, field = the scene's vector field on the grid (SURVEY.md section 8f N3)"},
+                      "roofline": {"bound": "hbm", "achieved": best_div["tb_per_s"] * 1e3, "peak": 8000.0, "unit": "GB/s",
+                                   "frac": round(best_div["tb_per_s"] / 8.0, 4), "traffic": None, "kernel": "vfn_grid_divergence_kernel"},
+                      "stages": out}), flush=True)
+
+
 def train_step_accounting(n_rays, s_c, s_t, n_sup, storage, gradients="fp32", separate_proposal=False):
     """ALGORITHMIC work and workspace traffic of one training step (DESIGN.md section 3 "Backward").
     FLOPs: the fine pass forward and twice that for its backward (VF + rendering, S_t samples) + forward and backward of the
@@ -259,41 +440,39 @@ def train_step_accounting(n_rays, s_c, s_t, n_sup, storage, gradients="fp32", se
     return flops, total
 
 
+def train_dtype_label(model) -> str:
+    """What the training step computes in, said as it is: forward f16x3 (three f16 products, fp32 accumulate), dX chain bf16x3; the
+    weight gradients dW = dY^T X from the STORED operands — activations f16 or fp32, gradients per-lane-scaled f16 / bf16 / fp32 —
+    on one to three products per K block."""
+    if model.precision != "f16x3":
+        return "f32 (exact fp32 MFMA kernels)"
+    act, grad = model.activation_storage, model.gradient_storage
+    dw = {("f16", "f16"): "one f16 product (f16 activations x per-lane-scaled f16 gradients, 11 x 11 bits)",
+          ("f16", "bf16"): "two bf16 products (f16 activations as bf16 hi+lo x bf16 gradients)",
+          ("f16", "fp32"): "three bf16 products (f16 activations x fp32 gradients)",
+          ("fp32", "f16"): "two f16 products (fp32 activations as f16 hi+lo x scaled-f16 gradients)"}.get((act, grad), "three bf16 products (fp32-equivalent)")
+    return f"f16x3 fwd + bf16x3 dX chain + dW on {dw}; f32 accumulate; activations stored {act}, gradients stored {grad}"
+
+
 def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=True):
     """One step = what the reference trainer does per batch, with synthetic targets (config 3 of BASELINE.json)."""
-    from vf_nerf_amd import distributed as vdist, optim as voptim, supervision
+    from vf_nerf_amd import distributed as vdist, supervision, trainer
     supervision.manual_seed(0x5eed + 7919 * (rank + 1))     # every rank draws its own supervision points
-    centroid = torch.tensor([0.0, 0.0, 0.6], device=dev)
     s_t = args.coarse + args.fine
-    g = torch.Generator().manual_seed(7 + rank)
-    rgb_gt = torch.rand(args.rays, 3, generator=g).to(dev)
-    depth_gt = (0.2 + 0.6 * torch.rand(args.rays, 1, generator=g)).to(dev)
+    # a LEARNABLE target (SURVEY.md section 8d C3): rgb / depth of these rays as a teacher model of another weight seed renders them
+    teacher, _, _, _ = build_scene(dev, 16, args.coarse, args.fine, seed=rank, perturb=False, weight_seed=1)
+    teacher.precision = "fp32"
+    with torch.no_grad():
+        t_out = teacher.render(pose, uv, K, epoch=0)
+    rgb_gt, depth_gt = t_out.coarse_rgb_values.clone(), t_out.coarse_depth_map.clone()
+    del teacher, t_out
     n_sup = (args.rays * s_t) // 10
     bucket = vdist.GradientBucket(model) if (world > 1 or dist is not None) else None
-    clip = model.config.scheduler_config.clip_norm
+    # the reference trainer's loop body (train/vector_field_nerf_train.py:172-260) on the shipped loss / supervision settings
+    run_step = trainer.TrainStep(model, (0.0, 0.0, 0.6), border_radius=0.05, far=1.0, bucket=bucket)
 
     def step():
-        out = model.render(pose, uv, K, epoch=0)
-        # border + centre supervision points, as the trainer draws them (train/vector_field_nerf_train.py:198-214)
-        bp, b_gt = supervision.sample_border_points(0.75, 1.0, n_sup, centroid, dev)
-        cp, c_gt = supervision.sample_center_points(centroid, 0.05, n_sup, dev)
-        sup_n = model.vector_field_network(torch.cat([bp, cp]))[:, :3]
-        sup_gt = torch.cat([b_gt, c_gt])
-        normals = out.coarse_normals.reshape(-1, 3)
-        loss = 2.0 * (out.coarse_rgb_values - rgb_gt).abs().mean() + \
-            0.5 * torch.clamp((out.coarse_depth_map - depth_gt).abs(), max=0.5).mean() + \
-            0.1 * ((normals.norm(dim=-1) - 1.0) ** 2).mean() + 1.0 * ((sup_n - sup_gt) ** 2).mean()
-        if bucket is not None:
-            bucket.zero()
-        else:
-            model.optimizer.zero_grad()
-        loss.backward()
-        if bucket is not None:
-            bucket.all_reduce_mean()
-        voptim.clip_grad_norm_(model.parameters(), clip)       # = torch's clip_grad_norm_(..., foreach=False), Q4-exact
-        model.optimizer.step()
-        model.scheduler.step()
-        return loss
+        return run_step(pose, uv, K, rgb_gt, depth_gt, epoch=0)[0]
 
     for _ in range(args.warmup):
         step()
@@ -301,12 +480,28 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0
     sync()
     elapsed = time.perf_counter() - t0
+    _, rates = rank_rates(dist, local_elapsed, args.rays * args.steps, dev)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the step's one collective on its own (outside the timed region): the flat 805 780-element fp32 bucket, sum + divide
+    bucket_ms = None
+    if bucket is not None and dist is not None and dist.get_world_size() > 1:
+        for _ in range(3):
+            bucket.all_reduce_mean()
+        sync()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            bucket.all_reduce_mean()
+        e1.record()
+        torch.cuda.synchronize()
+        bucket_ms = e0.elapsed_time(e1) / 20.0
     from vf_nerf_amd.backward import StoredFinePass
     stored = model.reuse_proposal and StoredFinePass.applicable(model, args.rays, args.coarse, s_t - args.coarse)
     flops, ws_bytes = train_step_accounting(args.rays, args.coarse, s_t, n_sup, model.activation_storage, model.gradient_storage,
@@ -315,8 +510,10 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
     rec = {"metric": "training rays/sec (4096-ray batch, 128 samples/ray, fwd+bwd+clip+Adam)",
            "value": round(args.rays * args.steps * world / elapsed, 1), "unit": "rays/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16x3 fwd + bf16x3 bwd, f32 accumulate",
-           "data": "synthetic", "final_loss": round(float(loss), 5),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": train_dtype_label(model),
+           "data": "synthetic", "final_loss": round(float(loss), 5), "per_rank_rays_per_s": rates,
+           "bucket_allreduce_ms": round(bucket_ms, 4) if bucket_ms is not None else None,
+           "bucket_elements": bucket.numel() if bucket is not None else None,
            "activation_storage": model.activation_storage, "gradient_storage": model.gradient_storage,
            "workspace_layout": model.workspace_layout,
            "networks": "training mode (batch-statistics BatchNorm, layer-at-a-time fp32 kernels)"
@@ -343,6 +540,103 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
     return rec
 
 
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start N ranks as CHILD processes (torch.distributed.run; never an
+    exec, and before this process has made any GPU call), wait, relay rank 0's JSON line.  The reference's multi-GPU entry is
+    automatic too (models/nerf/vector_field_nerf.py:70-75 wraps the modules in nn.DataParallel when num_gpus > 1,
+    config_parser/vf_nerf_config_parser.py:88); here it is one process per GPU over RCCL."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes on this driver)
+    env["VFN_BENCH_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout.splitlines():
+        try:
+            rec = json.loads(out)
+            if isinstance(rec, dict) and "metric" in rec:
+                line = out
+                continue
+        except ValueError:
+            pass
+        print(out, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"bench.py: the {n}-rank run failed (exit code {proc.returncode}, JSON line {'present' if line else 'missing'})", file=sys.stderr)
+        return proc.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+def rank_rates(dist, elapsed_local: float, units_per_rank: float, dev):
+    """(max elapsed over ranks, {per-rank units/s min / max / world size as the process group reports it})."""
+    if dist is None:
+        return elapsed_local, {"min": round(units_per_rank / elapsed_local, 1), "max": round(units_per_rank / elapsed_local, 1), "dist_world_size": 1}
+    world = dist.get_world_size()
+    mine = torch.tensor([elapsed_local], device=dev, dtype=torch.float64)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    times = [float(t.item()) for t in every]
+    return max(times), {"min": round(units_per_rank / max(times), 1), "max": round(units_per_rank / min(times), 1), "dist_world_size": world}
+
+
+def dry_run(args, rank: int, world: int, dist) -> None:
+    """--dry-run (with --backend gloo: no GPU anywhere): the multi-rank plumbing of this file on the CPU — process group, parameter
+    broadcast, the flat gradient bucket's all-reduce, barriers, max-over-ranks timing, per-rank rates, rank 0's single JSON line — with
+    a sleep where the render would be.  `value` of such a line is not a measurement ("dry_run": true)."""
+    import vf_nerf_amd
+    from vf_nerf_amd import distributed as vdist
+    dev = torch.device("cpu")
+    torch.set_num_threads(1)
+    torch.manual_seed(rank)
+    model = vf_nerf_amd.VectorFieldNerf(vf_nerf_amd.shipped_config(dev, n_samples=8, n_importance=8))
+    vdist.broadcast_parameters(model, src=0)
+    vdist.seed_rank_streams(model, rank)
+    bucket = vdist.GradientBucket(model)
+    for i, p in enumerate(model.unique_parameters()):
+        p.grad.fill_(float(rank + 1) * (i + 1))
+    t_b = time.perf_counter()
+    bucket.all_reduce_mean()
+    bucket_ms = (time.perf_counter() - t_b) * 1e3
+    expect = sum(range(1, world + 1)) / world
+    ok = all(torch.allclose(p.grad, torch.full_like(p, expect * (i + 1))) for i, p in enumerate(model.unique_parameters()))
+    same = model.vector_field_network.layers[0][0].weight.detach().double().sum().reshape(1)
+    sums = [torch.zeros_like(same) for _ in range(world)]
+    if dist is not None:
+        dist.all_gather(sums, same)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))          # the slowest rank sets the step time
+    local = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    _, rates = rank_rates(dist, local, args.rays * args.steps, dev)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "rays/sec (4096-ray chunk, 128 samples/ray) + PSNR vs ref", "value": round(args.rays * args.steps * world / elapsed, 1),
+                          "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "none", "data": "synthetic", "dry_run": True, "backend": args.backend, "per_rank_rays_per_s": rates,
+                          "bucket_elements": bucket.numel(), "bucket_allreduce_ok": bool(ok), "bucket_allreduce_ms": round(bucket_ms, 3),
+                          "replicas_identical_after_broadcast": bool(all(float(x) == float(sums[0]) for x in sums)) if dist is not None else True,
+                          "config": {"workload": f"dry run of the {args.workload} workload's multi-rank plumbing (no device work)",
+                                     "parallelism": f"rays x{world}"}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,6 +649,7 @@ def main() -> None:
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="untimed run of the same work right before the timed steps (the chip's clock settles under load)")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step sub-object of the default line")
+    ap.add_argument("--no-fp32-equivalent", action="store_true", help="skip the second timed region with three products everywhere")
     ap.add_argument("--train-steps", type=int, default=12, help="optimizer steps timed for the training sub-object")
     ap.add_argument("--activations", choices=("fp32", "f16"), default="f16",
                     help="training: storage of the hidden activations for the weight-gradient kernels (f16 = the default, "
@@ -381,10 +676,18 @@ def main() -> None:
     ap.add_argument("--no-reuse", action="store_true",
                     help="evaluate the VF net on the proposal samples twice, as the reference does (one fused VF+rendering "
                          "launch over all S_c+N_f samples), instead of once")
-    ap.add_argument("--workload", choices=("render", "view", "grid", "train"), default="render",
+    ap.add_argument("--unify-res", type=int, default=256, help="grid-stages workload: resolution of the unify / comb stages")
+    ap.add_argument("--workload", choices=("render", "view", "grid", "grid-stages", "train"), default="render",
                     help="render = the headline line (default); view = BASELINE configs[1] full view in 1024-ray chunks + "
                          "PSNR/depth vs the oracle image; grid = configs[4] dense grid queries; train = configs[2] step")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="process-group backend for --gpus N > 1 (nccl = RCCL; gloo: --dry-run)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="run only the multi-rank plumbing (process group, broadcast, gradient-bucket all-reduce, timing protocol, JSON line); "
+                         "with --backend gloo no GPU is touched")
     ap.add_argument("--grid-res", type=int, default=256)
+    ap.add_argument("--as-evaluator", action="store_true",
+                    help="view workload: time evaluator.render_view on HOST inputs (per-ray pose / intrinsics) with the download inside the "
+                         "timed region — what the reference's evaluation/methods.py:render_images gets through vf_nerf_amd.dropin")
     ap.add_argument("--streams", type=int, default=2,
                     help="view workload: HIP streams the consecutive ray chunks alternate over (1 = strictly one after the other)")
     ap.add_argument("--train", action="store_true",
@@ -392,16 +695,19 @@ def main() -> None:
                          "backward + clip + Adam, train/vector_field_nerf_train.py:177-260); not the headline metric")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not started by a launcher: start the ranks ourselves (children; this process never touches the GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     dist = None
     # VFN_BENCH_FORCE_DIST=1: create the RCCL process group (barriers, the max-over-ranks all-reduce, the gradient
     # bucket) even with one rank — a single-GPU smoke test of the multi-GPU code path
     force_dist = os.environ.get("VFN_BENCH_FORCE_DIST") == "1"
+    use_gpu = not (args.dry_run and args.backend == "gloo")
     if world > 1 or force_dist:
         import torch.distributed as dist
         if world == 1:
@@ -409,8 +715,14 @@ def main() -> None:
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if use_gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(args.backend, device_id=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
+        else:
+            dist.init_process_group(args.backend)
+    if args.dry_run:
+        dry_run(args, rank, world, dist)
+        return
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -418,6 +730,13 @@ def main() -> None:
     lib.load()  # fail loudly when the HIP extension is missing
     if args.train:
         args.workload = "train"
+    if args.workload == "grid-stages":
+        if world > 1:
+            raise SystemExit("--workload grid-stages is a single-GPU configuration")
+        if args.grid_res == 256:
+            args.grid_res = 512
+        grid_stages_bench(args, dev)
+        return
     if args.workload in ("view", "grid"):
         def sync0():
             if dist is not None:
@@ -473,12 +792,36 @@ def main() -> None:
         sync()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            # HIP events around the MLP launches on every fourth step of the timed region: a pair of timing events costs a
-            # few microseconds of stream time, 1.4 % of the step when every launch of every step is bracketed
+            # HIP events around the two fused launches on every fourth step of the timed region, recorded by the one-call C path
+            # itself on its launch stream (vfn_render_params.timing_events): the path that is timed is the path that ships.  (Every
+            # step would be 8 more stream markers per step.)
             model._kernel_events = events if i % 4 == 0 else None
             out = model.render(pose, uv, K, epoch=0)
+        torch.cuda.synchronize()
+        local_elapsed = time.perf_counter() - t0
         sync()
         elapsed = time.perf_counter() - t0
+        model._kernel_events = None
+
+        # the same region with three products everywhere (fp32-equivalent colours, 1e-7): reported beside `value`, never instead
+        elapsed3 = None
+        if args.precision == "f16x3" and int(model.colour_products) == 2 and not args.no_fp32_equivalent:
+            model.colour_products = 3
+            for _ in range(max(3, args.warmup)):
+                model.render(pose, uv, K, epoch=0)
+            torch.cuda.synchronize()
+            t_burn = time.perf_counter()
+            while time.perf_counter() - t_burn < min(1.0, args.sustain_seconds):
+                for _ in range(16):
+                    model.render(pose, uv, K, epoch=0)
+                torch.cuda.synchronize()
+            sync()
+            t3 = time.perf_counter()
+            for i in range(args.steps):
+                model.render(pose, uv, K, epoch=0)
+            sync()
+            elapsed3 = time.perf_counter() - t3
+            model.colour_products = 2
     model._kernel_events = None
     # dominant kernel class = the one with the largest share of the timed region (HIP events on the launch stream)
     per_class = {}
@@ -488,10 +831,11 @@ def main() -> None:
     kernel_ms = sum(per_class[dom]) / len(per_class[dom])
     launches_per_step = len(per_class[dom]) / max(1, (args.steps + 3) // 4)
 
+    _, rates = rank_rates(dist, local_elapsed, args.rays * args.steps, dev)
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, elapsed3 or 0.0], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, elapsed3 = float(t[0].item()), (float(t[1].item()) if elapsed3 is not None else None)
 
     if rank == 0:
         rays_per_s = args.rays * args.steps * world / elapsed
@@ -521,7 +865,7 @@ def main() -> None:
                            "fused32": "vfn_mlp_kernel<MODE_FUSED> (VF MLP + rendering MLP, fine pass)"}[dom],
                 "launches_per_step": launches_per_step,
                 "kernel_ms_per_step_by_class": {k: round(sum(v) / max(1, (args.steps + 3) // 4), 4) for k, v in per_class.items()},
-                "event_sampling": "HIP events around the MLP launches of every 4th timed step",
+                "event_sampling": "HIP events recorded by vfn_render_fwd around its two fused launches on every 4th timed step (one-call path)",
                 "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": hbm_traffic(f16, dom, cp),
                 # what one launch has to move: points in, vector columns out, plus the 1 KiB feature block per point that the
@@ -545,6 +889,10 @@ def main() -> None:
             "dtype": ("f16x3+f32acc (colour branch: f16 weights x split activations, 2 products)" if cp == 2 else "f16x3+f32acc") if f16 else "f32",
             "data": "synthetic",
             "sustained": f"timed steps follow {args.sustain_seconds:g} s of the same work without a gap",
+            "value_fp32_equivalent": round(args.rays * args.steps * world / elapsed3, 1) if elapsed3 else None,
+            "value_definition": ("value: colour_products=2 (the default: colour-branch weights as f16 roundings, colours within 2e-5 of fp32); "
+                                 "value_fp32_equivalent: three f16 products everywhere (1e-7), same steps, same protocol") if elapsed3 else None,
+            "per_rank_rays_per_s": rates,
             "config": {"workload": f"VectorFieldNerf.render forward, {args.rays}-ray chunk x {s_t} samples/ray "
                                    f"(S_c={s_c} + N_f={n_f}), shipped 9x256 VF + 5x256 rendering MLPs, eval-mode BN, "
                                    f"stratified sampling on device Philox, Replica-like 1200x680 pinhole",
@@ -556,6 +904,7 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["parity_vs_oracle"] = cpu_baseline(model, uv, pose, K, s_c, n_f)
+            line["parity_trained_weights"] = trained_weights_parity(dev, args.precision)
     # BASELINE.json configs[2] beside the headline line (outside its timed region): a few optimizer steps on the same batch
     # size, every rank, gradients all-reduced when there is more than one
     train_rec = None

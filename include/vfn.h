@@ -19,7 +19,9 @@
 extern "C" {
 #endif
 
-#define VFN_ABI_VERSION 1
+/* Bumped whenever a POD struct's layout or an entry point's signature changes (2: vfn_render_params.timing_events,
+ * vfn_abi_struct_bytes).  The Python binding reads this constant from this file and refuses a library that reports another. */
+#define VFN_ABI_VERSION 2
 
 typedef enum vfn_status {
     VFN_OK = 0,
@@ -31,6 +33,10 @@ typedef enum vfn_status {
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* vfn_last_error(void);
 int vfn_abi_version(void);
+/* sizeof() of the POD structs of this header as the library was compiled, by index: 0 vfn_net_geom, 1 vfn_layer_params,
+ * 2 vfn_raygen_params, 3 vfn_density_params, 4 vfn_fine_params, 5 vfn_render_params, 6 vfn_unfold_entry, 7 vfn_wgrad_layer;
+ * -1 for any other index.  A binding checks its own mirrors of the structs against these (tests/test_host_logic.py). */
+int32_t vfn_abi_struct_bytes(int32_t which);
 
 /* ---------------------------------------------------------------------------------------------
  * Network geometry + packed weights.
@@ -228,6 +234,10 @@ typedef struct vfn_render_params {
                                          * into `stream` (same values; the halves fill each other's partial rounds); 1: one stream;
                                          * 0: two halves when the fused launches would leave >= 5 % of their workgroup slots empty */
     int32_t reserved;
+    void* timing_events[4];             /* optional hipEvent_t handles (NULL: none), recorded on the launch stream around the two fused
+                                         * VF + rendering launches: [0] before / [1] after the one on the proposal samples, [2] / [3] the one
+                                         * on the new samples (with `streams` > 1: around the FIRST range's launches).  bench.py times the
+                                         * dominant kernel with these without leaving the one-call path. */
 } vfn_render_params;
 int64_t vfn_render_fwd_workspace_bytes(const vfn_render_params* p);
 int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf_geom, const void* vf_packed16,
@@ -552,6 +562,12 @@ int vfn_grid_unify_direction(const float* divergence, const float* vt, int32_t n
  * pair_norms[n^3,28,2] = (norms at corner a, norms at corner b), corners outside the grid read as 0. */
 int vfn_grid_comb_format(const int64_t* choice, const float* norms, int32_t n, float* different_side, float* pair_norms,
                          void* stream);
+/* The same two stages with the side bits of a cell as ONE byte (bit q = corner q's side): `sides`[n^3] is written beside (choice
+ * != NULL) or instead of (choice == NULL) the int64 table, and vfn_grid_comb_format_sides reads it instead of 64 B per cell.  What
+ * evaluation/methods.py:248-253 does with the table — hand it to make_comb_format and delete it — needs nothing else. */
+int vfn_grid_unify_direction_sides(const float* divergence, const float* vt, int32_t n, uint8_t* sides, int64_t* choice, void* stream);
+int vfn_grid_comb_format_sides(const uint8_t* sides, const float* norms, int32_t n, float* different_side, float* pair_norms,
+                               void* stream);
 
 /* =============================================================================================
  * Optimizer side of a training step over ONE flat fp32 buffer (train/vector_field_nerf_train.py:254-260:

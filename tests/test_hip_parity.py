@@ -37,7 +37,7 @@ def case(request):
 def test_library_is_the_hip_build():
     from vf_nerf_amd import lib
     l = lib.load()
-    assert l.vfn_abi_version() == 1
+    assert l.vfn_abi_version() == lib.ABI_VERSION
     with open("/proc/self/maps") as f:
         assert "libvfn.so" in f.read()
 
@@ -475,6 +475,63 @@ def test_grid_stages_on_hip():
     assert float((div != want).float().mean()) < 1e-3
     with pytest.raises(Exception):
         grid.extract_divergence(pred, n)      # host tensors are refused: no CPU fallback
+
+
+@pytest.mark.parametrize("n", [64, 70, 131])
+def test_grid_stages_tiled_kernels_at_larger_sizes(n):
+    """The LDS-tiled / register-window kernels of round 3 on grids that span several footprints, march segments and partial
+    tiles (64: whole tiles and vector accesses; 70: partial tiles, two march segments; 131: odd row lengths -> the scalar
+    paths, a last wave that is not full), against the oracle's restatement of the reference's functions.  Thresholded /
+    argmin'ed outputs may differ where the deciding fp32 quantity sits within rounding of the boundary (conv3d sums in another
+    order): bounded as a fraction; everything that is a pure gather or comparison of integers is exact."""
+    from oracle import vfnerf_oracle as O
+    from vf_nerf_amd import grid, lib
+    gen = torch.Generator().manual_seed(n)
+    ax = torch.linspace(-1, 1, n)
+    p = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1).reshape(-1, 3)
+    # a field with surfaces: points towards the nearest of two spheres' shells, plus noise; a few exactly-zero vectors
+    d1, d2 = p - torch.tensor([0.3, 0.0, 0.0]), p + torch.tensor([0.4, 0.2, 0.1])
+    r1, r2 = d1.norm(dim=1, keepdim=True), d2.norm(dim=1, keepdim=True)
+    f1, f2 = -d1 / r1.clamp_min(1e-6) * torch.sign(r1 - 0.45), -d2 / r2.clamp_min(1e-6) * torch.sign(r2 - 0.3)
+    pred = torch.where((r1 - 0.45).abs() < (r2 - 0.3).abs(), f1, f2) * (0.2 + torch.rand(n ** 3, 1, generator=gen)) + \
+        0.05 * torch.randn(n ** 3, 3, generator=gen)
+    pred[::997] = 0.0
+    pred = pred.contiguous()
+    dp = pred.to(dev())
+    div = grid.extract_divergence(dp, n)
+    want_div = O.grid_divergence(pred, n)
+    frac = float((div.cpu() != want_div).float().mean())
+    print(f"n={n}: surface cells {float(want_div.mean()):.4f}, divergence mask mismatches {frac:.2e}")
+    assert float(want_div.mean()) > 0.005 and frac < 2e-4
+    assert float(div[-1].abs().max()) == 0 and float(div[:, -1].abs().max()) == 0 and float(div[:, :, -1].abs().max()) == 0
+    for k, sigma in ((3, 1.0), (9, 2.0), (5, 1.5)):                      # 5: the generic per-voxel kernel
+        sm = grid.smooth_vf(dp.reshape(n, n, n, 3), k=k, sigma=sigma)
+        err = float((sm.cpu() - O.smooth_field(pred.reshape(n, n, n, 3), k, sigma)).abs().max())
+        assert err < 2e-6, (k, err)
+    assert torch.equal(dp.cpu(), pred), "smooth_vf must not write into its input"
+    vt = torch.nn.functional.normalize(pred, dim=1)
+    dvt = vt.to(dev()).reshape(n, n, n, 3)
+    choice = grid.unify_direction(div, dvt.permute(3, 0, 1, 2), N=n)
+    want_choice = O.grid_unify_direction(div.cpu(), vt.reshape(n, n, n, 3).permute(3, 0, 1, 2), n)
+    cell_diff = float((choice.cpu() != want_choice).any(dim=1).float().sum() / max(1.0, float(div.sum())))
+    print(f"n={n}: surface cells whose corner sides differ from the oracle's: {cell_diff:.2e}")
+    assert choice.shape == (n ** 3, 8) and choice.dtype == torch.int64 and cell_diff < 2e-3
+    assert int(choice.min()) == 0 and int(choice.max()) == 1 and int(choice[div.reshape(-1) != 1].abs().sum()) == 0
+    sides, table = lib.grid_unify_direction_sides(div.reshape(-1).contiguous(), dvt.reshape(-1, 3).contiguous(), n)
+    assert torch.equal(table, choice)
+    bits = torch.stack([(sides.long() >> q) & 1 for q in range(8)], dim=1)
+    assert torch.equal(bits, choice), "the side byte holds the same eight decisions"
+    norms = torch.norm(pred, dim=1)
+    dn = norms.to(dev())
+    want_comb, want_pairs = O.grid_comb_format(choice.cpu(), norms, n)
+    comb, pairs = grid.make_comb_format(choice, dn, n)                     # the tensor unify_direction returned: side bytes
+    assert torch.equal(comb.cpu(), want_comb) and torch.equal(pairs.cpu(), want_pairs)
+    comb2, pairs2 = grid.make_comb_format(choice.clone(), dn, n)           # any other int64 table: read as it is
+    assert torch.equal(comb2, comb) and torch.equal(pairs2, pairs)
+    odd = choice.clone()
+    odd[::3] = odd[::3] * 5 + torch.arange(8, device=odd.device) % 3       # entries outside {0, 1}: "!=" on the integers themselves
+    comb3, _ = grid.make_comb_format(odd, dn, n)
+    assert torch.equal(comb3.cpu(), O.grid_comb_format(odd.cpu(), norms, n)[0])
 
 
 def test_shared_pose_and_intrinsics():

@@ -429,3 +429,144 @@ def test_model_optimizer_is_flat_and_survives_load_and_repacking():
     out.coarse_rgb_values.sum().backward()
     other.optimizer.step()
     assert float(other.optimizer.state[other.vector_field_network.layers[0][0].weight]["step"]) == 4.0
+
+
+def test_argmax_nan_rule_is_the_same_in_every_kernel():
+    """torch.argmax's order (ray_sampler.py:277 takes torch.argmax of the proposal weights): the first maximum, and a NaN beats
+    every number (the first NaN wins).  The stand-alone row argmax and the argmax inside the density / composite launch share
+    one comparison (csrc/vfn_rays.hip: argmax_takes), so they agree with torch and with each other on rows holding NaNs."""
+    w = torch.rand(6, 130, device=DEV)
+    w[1, 70] = float("nan")
+    w[2, 3] = w[2, 99] = float("nan")
+    w[3, 129] = float("nan")
+    w[4] = float("nan")
+    want = torch.argmax(w.cpu(), dim=-1)
+    assert want.tolist()[1:5] == [70, 3, 129, 0]
+    assert torch.equal(lib.rows_argmax(w).cpu(), want)
+    # the same rule inside vfn_ray_density_weights (a NaN depth makes the weights NaN from that sample on; a NaN normal does not:
+    # the cosine's clamped norms drop it): the launch's argmax is torch's argmax of the launch's own weights, and the stand-alone
+    # kernel agrees
+    fx, d = load_fixture("c1_perturb")
+    model = build_model(fx, d, device=DEV)
+    g = {k: v.to(DEV) for k, v in d.items() if isinstance(v, torch.Tensor)}
+    z = g["z_coarse"].clone().contiguous()
+    z[5, 9] = float("nan")
+    z[7, 0] = float("nan")
+    _, wts, imax, _, _ = lib.ray_density_weights(model._density_params(), g["normals_coarse"].contiguous(), g["ray_dirs"].contiguous(), z,
+                                                 model.density.raw_scalars(), want_argmax=True)
+    print("rays with NaN weights:", int(torch.isnan(wts).any(dim=1).sum()))
+    assert torch.equal(imax.cpu(), torch.argmax(wts.cpu(), dim=-1)), "argmax of the launch's own weights, torch order"
+    assert torch.equal(lib.rows_argmax(wts).cpu(), imax.cpu())
+
+
+@pytest.mark.parametrize("storage", ["f16+f16", "fp32+fp32", "f16+bf16"])
+def test_non_finite_upstream_gradient_reaches_the_weight_gradients(storage):
+    """A diverging step must not be masked: the reference's fp32 autograd turns an Inf in d(loss)/d(rgb) into non-finite
+    parameter gradients (and clip_grad_norm_ into a NaN norm).  The scaled-f16 gradient storage used to encode a tile whose
+    largest magnitude is Inf as "all zero" and to drop NaNs from the maximum (csrc/vfn_bwd16.hip: tile_scale); now the lane's
+    values leave as NaN.  Every storage: each watched weight gradient is non-finite somewhere and the clip norm is not finite."""
+    fx, d = load_fixture("bench_sizes")
+    g = {k: v.to(DEV) for k, v in d.items() if isinstance(v, torch.Tensor)}
+    model = build_model(fx, d, device=DEV)
+    model.activation_storage, model.gradient_storage = storage.split("+")
+    out = model.render(g["pose"], g["uv"], g["intrinsics"], 0, uniforms={k: g[k] for k in ("u_coarse", "u_fine", "u_add")})
+    coeff = torch.ones_like(out.coarse_rgb_values)
+    hit = int(torch.argmax(out.coarse_depth_map.detach().reshape(-1)))          # a ray that composites something
+    coeff[hit, 1] = float("inf")
+    model.optimizer.zero_grad()
+    (out.coarse_rgb_values * coeff).sum().backward()
+    nets = {"vf": model.vector_field_network, "rn": model.rendering_network}
+    for net, key in (("rn", "layers.4.weight"), ("rn", "layers.1.0.weight"), ("vf", "layers.8.weight"), ("vf", "layers.5.0.weight"), ("vf", "layers.0.0.weight")):
+        grad = dict(nets[net].named_parameters())[key].grad
+        assert not bool(torch.isfinite(grad).all()), f"{storage}: {net}.{key} came out finite from an infinite upstream gradient"
+    norm = optim.clip_grad_norm_(model.parameters(), 0.5)
+    assert not bool(torch.isfinite(norm)), float(norm)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "f16x3"])
+def test_training_converges_on_teacher_targets(mode):
+    """SURVEY.md section 8d C3 in small: the reference trainer's step (trainer.TrainStep = train/vector_field_nerf_train.py:172-260)
+    on a LEARNABLE target — rgb / depth of four orbit views rendered by a teacher of another weight seed — from the same
+    initial weights, batches and random streams with the exact-fp32 kernels and with the default 16-bit path (f16x3 forward,
+    f16 activations, scaled-f16 gradients).  120 steps of 256 rays x (32 + 32): the loss must come down by a fixed factor in both,
+    and the 16-bit run must end inside a band around the fp32 run (tools/train_curve.py holds the long version)."""
+    import vf_nerf_amd
+    from vf_nerf_amd import synthetic, trainer
+    dev = torch.device(DEV)
+
+    def scene(seed):
+        torch.manual_seed(seed)
+        cfg = vf_nerf_amd.shipped_config(dev, n_samples=32, n_importance=32, perturb=True, dir_to_normal_th=-0.2)
+        m = vf_nerf_amd.VectorFieldNerf(cfg)
+        m.eval()
+        synthetic.scale_hidden_weights(m.vector_field_network, m.rendering_network, 2.0)
+        with torch.no_grad():
+            pts = synthetic.frustum_points(20000, seed=1234).to(dev)
+            keep = m.precision
+            m.precision = "fp32"
+            mean, std = synthetic.vector_head_stats_from_tanh(m.vector_field_network(pts, vector_only=True))
+            m.precision = keep
+            synthetic.recentre_vector_head(m.vector_field_network, mean, std)
+        return m
+
+    pool = trainer.TeacherTargets(scene(1), views=4, width=48, height=48, focal=45.0, seed=3)
+    curves = {}
+    for tag in ("fp32", mode) if mode != "fp32" else ("fp32",):
+        model = scene(0)
+        model.precision = "fp32" if tag == "fp32" else "f16x3"
+        model.rng_seed, model._rng_offset = 11, 0
+        supervision.manual_seed(3)
+        step = trainer.TrainStep(model, (0.0, 0.0, 0.55), border_radius=0.15, far=1.0)
+        losses = []
+        for t in range(120):
+            pose, uv, K, rgb_gt, depth_gt = pool.batch(t, 256)
+            losses.append(step(pose, uv, K, rgb_gt, depth_gt, epoch=0)[0])
+        curves[tag] = [float(x) for x in losses]
+        first, last = sum(curves[tag][:5]) / 5, sum(curves[tag][-10:]) / 10
+        print(f"[{tag}] loss first 5 steps {first:.4f} -> last 10 steps {last:.4f} (x{last / first:.3f})")
+        assert last < 0.8 * first, (tag, first, last)
+    if mode != "fp32":
+        a, b = sum(curves["fp32"][-10:]) / 10, sum(curves[mode][-10:]) / 10
+        print(f"final loss {mode} / fp32 = {b / a:.4f}")
+        assert abs(b / a - 1.0) < 0.25
+
+
+def test_evaluator_loop_through_the_dropin_gets_the_chunked_values():
+    """The evaluator renders a view chunk by chunk (evaluation/methods.py:513-545): per chunk it uploads pixels / pose / intrinsics,
+    calls model.render(pose, pixels, intrinsics, epoch, white) and pulls coarse_rgb_values / coarse_depth_map back with .cpu().
+    That loop, restated here shape for shape on host tensors as the dataset hands them over (per-ray pose / intrinsics, a last
+    chunk that is not full), against evaluator.render_view — what vf_nerf_amd.dropin puts behind evaluation.methods.render_images:
+    chunks on two streams, one download.  Same random stream position -> the same values, bit for bit."""
+    import numpy as np
+    from vf_nerf_amd import evaluator, synthetic
+    fx, d = load_fixture("c1_perturb")
+    model = build_model(fx, d, device=DEV)
+    w, h, split = 40, 27, 256                                  # 1080 rays: four full chunks and one of 56
+    uv, pose, K = synthetic.pinhole_image(w, h, 38.0, pose=synthetic.orbit_pose(20.0, 8.0, 0.9))
+    assert not uv.is_cuda and pose.shape == (w * h, 4, 4)
+    device = torch.device(DEV)
+
+    model.rng_seed, model._rng_offset = 5, 0
+    rgb = np.zeros((h, w, 3))
+    depth_map = np.zeros((h, w, 1))
+    n = uv.shape[0]
+    pixels_split, pose_split, k_split = torch.split(uv, split, dim=0), torch.split(pose, split, dim=0), torch.split(K, split, dim=0)
+    with torch.no_grad():
+        for j in range(int(np.ceil(n / split))):
+            pixels = pixels_split[j].to(device)
+            output = model.render(pose_split[j].to(device), pixels, k_split[j].to(device), 0, False)
+            rows, cols = pixels[:, 1].long().cpu().numpy(), pixels[:, 0].long().cpu().numpy()
+            rgb[rows, cols, :] = output.coarse_rgb_values.cpu().numpy()
+            depth_map[rows, cols, :] = output.coarse_depth_map.cpu().numpy()
+
+    model.rng_seed, model._rng_offset = 5, 0
+    rgb_values, depth_values = evaluator.render_view(model, pose, uv, K, 0, split_size=split)
+    assert rgb_values.shape == (n, 3) and depth_values.shape == (n, 1)
+    rows, cols = uv[:, 1].long().numpy(), uv[:, 0].long().numpy()
+    assert np.array_equal(rgb[rows, cols, :].astype(np.float32), rgb_values)
+    assert np.array_equal(depth_map[rows, cols, :].astype(np.float32), depth_values)
+    assert float(depth_values.max()) > 0.05, "the view composites something"
+    # a pose / intrinsics shared by the whole view (one copy) gives the same image
+    model.rng_seed, model._rng_offset = 5, 0
+    rgb_shared, _ = evaluator.render_view(model, pose[0], uv, K[0], 0, split_size=split)
+    assert np.array_equal(rgb_shared, rgb_values)

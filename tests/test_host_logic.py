@@ -30,7 +30,43 @@ def test_library_exports_every_declared_symbol():
     handle = lib.load()
     for name in declared:
         assert hasattr(handle, name), name
-    assert handle.vfn_abi_version() == 1
+    assert handle.vfn_abi_version() == lib.ABI_VERSION == 2
+
+
+def test_binding_signatures_come_from_the_header():
+    """Every export carries restype + argtypes generated from include/vfn.h; a few known prototypes are spelled out here, and the
+    binding's struct mirrors have the sizes the library was compiled with."""
+    import ctypes as C
+    handle = lib.load()
+    protos = lib.header_prototypes()
+    assert set(protos) == set(lib.EXPORTS)
+    for name in lib.EXPORTS:
+        fn = getattr(handle, name)
+        assert fn.argtypes is not None and len(fn.argtypes) == len(protos[name][1]), name
+    assert protos["vfn_fill_uniform"] == ("int", ["float*", "int64_t", "uint64_t", "uint64_t", "void*"])
+    assert protos["vfn_uniform_sample"][1][:4] == ["int32_t", "int32_t", "float", "float"]
+    assert protos["vfn_render_fwd"][1][0] == "const vfn_render_params*" and len(protos["vfn_render_fwd"][1]) == 25
+    assert handle.vfn_last_error.restype is C.c_char_p and handle.vfn_packed_size.restype is C.c_int64
+    for i, mirror in enumerate(lib.struct_mirrors()):
+        assert handle.vfn_abi_struct_bytes(i) == C.sizeof(mirror), mirror.__name__
+    assert handle.vfn_abi_struct_bytes(99) == -1
+    assert C.sizeof(lib.RenderParams) % 8 == 0 and lib.RenderParams.timing_events.size == 4 * C.sizeof(C.c_void_p)
+
+
+def test_reordered_arguments_are_refused_before_the_call():
+    """A pointer where a size belongs, a float where an integer belongs, an integer where a pointer belongs: the generated
+    argtypes raise at conversion time, nothing is launched."""
+    import ctypes as C
+    handle = lib.load()
+    with pytest.raises(C.ArgumentError):
+        handle.vfn_fill_uniform(C.c_void_p(0), C.c_void_p(0), 1, 2, None)            # pointer as the element count
+    with pytest.raises(C.ArgumentError):
+        handle.vfn_fill_uniform(None, 1.5, 1, 2, None)                               # float as the element count
+    with pytest.raises(C.ArgumentError):
+        handle.vfn_fill_uniform(C.c_int32(4), 4, 1, 2, None)                         # integer as the output pointer
+    with pytest.raises(C.ArgumentError):
+        handle.vfn_uniform_sample(1, 1, None, 1.0, None, None, None, None, None, None, None, None)   # pointer as `near`
+    assert handle.vfn_fill_uniform(None, C.c_int32(0), 1, 2, None) == 0              # n = 0: accepted, nothing to do (width converted)
 
 
 def test_packed_size_and_plan_errors():
@@ -327,3 +363,82 @@ def test_scaled_f16_gradient_slot_round_trip():
         assert bool((exps[17 // 32, :, :, 17 % 32] == 255).all())            # the all-zero point
         assert bool((exps[-1, :, :, 1000 % 32:] == 255).all())               # padding points of the last group
         assert int(exps[exps != 255].max()) <= 239
+
+
+def test_bench_launches_its_own_ranks_dry_run_gloo_world2():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks as child processes (torch.distributed.run), and rank
+    0's single JSON line comes back through the parent.  --backend gloo --dry-run: the plumbing only (process group, parameter
+    broadcast, flat gradient bucket all-reduce, barrier / max-over-ranks timing, per-rank rates), no GPU anywhere."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "4",
+                           "--warmup", "1"], cwd=tempfile.gettempdir(), env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, proc.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["per_rank_rays_per_s"]["dist_world_size"] == 2 and rec["dry_run"] is True
+    assert rec["bucket_elements"] == 805780 and rec["bucket_allreduce_ok"] and rec["replicas_identical_after_broadcast"]
+    assert rec["steps"] == 4 and rec["scaling"] == "weak" and rec["per_rank_rays_per_s"]["min"] <= rec["per_rank_rays_per_s"]["max"]
+    # rank 1 sleeps twice as long per step as rank 0: the whole-job figure follows the slowest rank
+    assert rec["value"] <= 2 * rec["per_rank_rays_per_s"]["min"] * 1.05
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run"], env=env,
+                          capture_output=True, text=True, timeout=300)
+    assert proc.returncode != 0 and "started 1 rank" in (proc.stderr + proc.stdout)
+
+
+def test_dropin_puts_the_chunked_view_renderer_behind_the_evaluator():
+    """evaluation.methods imports open3d / pyrender / trimesh at the top, so it only exists where the reference's environment
+    does; with a module of that name present, install() replaces its render_images and nothing else in it."""
+    import importlib
+    import sys
+    import types
+    saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in ("models", "evaluation")}
+    fake_pkg, fake = types.ModuleType("evaluation"), types.ModuleType("evaluation.methods")
+    fake_pkg.__path__ = []
+    fake.render_images, fake.metrics = (lambda *a, **k: "reference"), (lambda *a, **k: "reference metrics")
+    try:
+        sys.modules["evaluation"], sys.modules["evaluation.methods"] = fake_pkg, fake
+        dropin = importlib.import_module("vf_nerf_amd.dropin")
+        dropin.install()
+        from vf_nerf_amd import evaluator
+        assert fake.render_images is evaluator.render_images and fake.metrics() == "reference metrics"
+    finally:
+        import vf_nerf_amd.dropin as dropin
+        dropin.uninstall_clip_grad_norm()
+        for k in [k for k in sys.modules if k.split(".")[0] in ("models", "evaluation")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def test_lazy_loss_terms_behave_like_the_dict_the_trainer_expects():
+    """VFLoss returns {name: float}; the trainer aliases it as its running sums, adds a key, adds step values with += and divides
+    in place (train/vector_field_nerf_train.py:262-279)."""
+    from types import SimpleNamespace as NS
+    from vf_nerf_amd.loss import VFLoss
+    crit = VFLoss(NS(depth_loss_clamp=0.5, norm_smaller_than_one_start=11000, directional_derivatives_start=100),
+                  NS(rgb=2.0, depth=0.5, unit_norm=0.1, supervision=1.0, norm_smaller_than_one=0.1, directional_derivatives=0.0))
+    g = torch.Generator().manual_seed(0)
+    pred = {"rgb": torch.rand(4, 3, generator=g), "depth": torch.rand(4, 1, generator=g), "normals": torch.randn(9, 3, generator=g),
+            "supervised_normals": torch.randn(3, 3, generator=g), "directional_derivatives": None}
+    gt = {"rgb": torch.rand(4, 3, generator=g), "depth": torch.rand(4, 1, generator=g), "supervised_normals": torch.randn(3, 3, generator=g)}
+    loss, terms = crit(pred, gt, 0)
+    assert isinstance(terms, dict) and list(terms.keys())[0] == "rgb_loss" and len(terms) == 6
+    average = terms
+    average["loss"] = loss.item()
+    _, more = crit(pred, gt, 0)
+    for key in more.keys():
+        average[key] += more[key]
+    for key in average.keys():
+        average[key] /= 2
+    assert abs(average["rgb_loss"] - float((pred["rgb"] - gt["rgb"]).abs().mean())) < 1e-7
+    assert abs(2.0 * average["rgb_loss"] + 0.5 * average["depth_loss"] + 0.1 * average["unit_norm_loss"] + average["supervision_loss"]
+               - 2 * average["loss"]) < 1e-5

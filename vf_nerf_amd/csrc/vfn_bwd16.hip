@@ -244,13 +244,26 @@ __device__ __forceinline__ f32x4v mask_group(const Pipe& p, int q) {
 }
 typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
 // scaled f16: the exponent byte (k + 113) and the scale 2^k of this lane's 16 values of a tile, max |v| 2^k in [2^14, 2^15)
-__device__ __forceinline__ float tile_scale(const f32x16& v, int& b) {
+__device__ __forceinline__ float tile_scale(const f32x16& v, int& b, bool live = true) {
     float m = fmaxf(fabsf(v[0]), fabsf(v[1]));
 #pragma unroll
     for (int r = 2; r < 16; r += 2) m = fmaxf(m, fmaxf(fabsf(v[r]), fabsf(v[r + 1])));
+    // fmaxf drops NaNs and an Inf maximum has no exponent byte: a non-finite gradient of a LIVE point (a diverging step) must not leave
+    // as "all zero".  max |v| on the bit patterns (sign cleared) orders NaN / Inf above every finite value; the lane's 16 values then
+    // leave as NaN (whatever factor the consumer rescales them by, 0 included, they stay NaN), so the weight gradients they enter come
+    // out non-finite as the reference's fp32 products would; byte 239 does not move the slab's common scale.  (Lanes past the last
+    // point may hold anything; their byte is 255 and the consumer zeroes them.)
+    unsigned mb = max(__builtin_bit_cast(unsigned, v[0]) & 0x7fffffffu, __builtin_bit_cast(unsigned, v[1]) & 0x7fffffffu);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2)
+        mb = max(mb, max(__builtin_bit_cast(unsigned, v[r]) & 0x7fffffffu, __builtin_bit_cast(unsigned, v[r + 1]) & 0x7fffffffu));
+    if (live && (mb >> 23) == 255u) {
+        b = 239;
+        return __builtin_bit_cast(float, 0x7fc00000u);
+    }
     const int biased = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu);
-    b = biased == 0 ? 255 : min(254 - biased, 239);       // k + 113: every normal fp32 magnitude has its byte (below 2^-112 the scale saturates)
-    return biased == 0 ? 0.f : __builtin_bit_cast(float, (unsigned)(b + 14) << 23);
+    b = (biased == 0 || biased == 255) ? 255 : min(254 - biased, 239);       // k + 113: every normal fp32 magnitude has its byte (below 2^-112 the scale saturates)
+    return (biased == 0 || biased == 255) ? 0.f : __builtin_bit_cast(float, (unsigned)(b + 14) << 23);
 }
 template <int SLOT, int TILE>
 __device__ __forceinline__ void store_group(const Pipe& p, const f32x16& v, int q, float scale = 1.0f) {
@@ -299,7 +312,7 @@ __device__ __forceinline__ void store_tile(const Pipe& p, const f32x16& v) {
     float scale = 1.0f;
     if (p.dy16 == 2) {
         int b;
-        scale = tile_scale(v, b);
+        scale = tile_scale(v, b, p.live);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.dy + (long long)SLOT * p.slot_floats, 0, (int)p.slot_bytes, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(p.live ? b : 255), rs, (int)p.evoff, TILE * 64, 0);
         // slot 3 (the 217-wide layer in front of the skip) has seven tiles: its eighth is never produced, and the weight-gradient
@@ -476,7 +489,7 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
             }
 #endif
             if (ENC_SPREAD && F16S && (ch > 0 || PSLOT >= 0)) {
-                if (st == H) esc = tile_scale(cy.pend, eb);
+                if (st == H) esc = tile_scale(cy.pend, eb, p.live);
                 if (st > H && st <= H + 4) eq[st - H - 1] = pack_quad_f16s(cy.pend, st - H - 1, esc);
             }
             if (st >= H && st < H + 4) mnext[st - H] = mask_group<OSLOT, ch, MASK>(p, st - H);

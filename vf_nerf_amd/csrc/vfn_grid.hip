@@ -1,8 +1,20 @@
 // vfn_grid.hip — the dense-grid stages between the vector-field queries and the mesh triangulation:
 // evaluation/utils/mc_utils.py:34-86 (extract_divergence), :107-167 (unify_direction), :170-223 (make_comb_format) and
 // evaluation/utils/guassian_smoothing.py:81-97 (smooth_vf).  The reference runs them as conv3d / gather chains on CPU
-// tensors of res^3 x 3 floats; here each is one HBM-bound kernel over the grid, one thread per cell, the innermost grid
-// index on consecutive lanes (the 2x2x2 corner gathers of neighbouring cells overlap in L2).
+// tensors of res^3 x 3 floats; here each is an HBM-bound kernel whose every grid value crosses HBM ONCE and whose every
+// store instruction writes whole consecutive lines:
+//   divergence   a workgroup owns an 8 x 64 footprint of cells in (j, k) and marches along i; the normalised field of the
+//                next plane is staged in LDS (each vector read and normalised once per workgroup, not eight times), the
+//                mask leaves as 256 contiguous bytes per wave.  Algorithmic 16 B / cell (12 in, 4 out).
+//   smoothing    axes 0 and 1: the filter runs along a strided axis, so every FLOAT of the interleaved [.., 3] layout is
+//                independent — a lane owns four consecutive floats and marches along the axis with the k taps in registers
+//                (each input read once, 16-byte accesses); axis 2: whole rows staged in LDS.  24 B / cell / pass.
+//   unify        one lane per cell; the 8-corner analysis only where the divergence mask is set; the eight int64 per cell
+//                leave through wave-wide 1 KiB stores (a lane's own eight stores would touch 64 lines each).  68 B / cell.
+//   comb         per-cell inputs (side bits, 8 corner norms) staged in LDS, the 28 + 56 floats per cell written as
+//                float4 rows of the wave's contiguous output range.  336 B / cell out.
+// Arithmetic per value is unchanged from the round-2 kernels (same expressions, same order, -ffp-contract=off): masks,
+// choices and pair tables stay bit-identical to the reference's functions (tests/test_hip_parity.py).
 //
 // Grid layout: cell (i, j, k) -> flat index (i N + j) N + k; vector field [N^3, 3] row-major.  The 8 cell corners in the
 // order of the reference's selection filters: (0,0,0) (0,1,0) (1,1,0) (1,0,0) (0,0,1) (0,1,1) (1,1,1) (1,0,1) as (di,dj,dk);
@@ -21,33 +33,86 @@ __device__ __forceinline__ void load_vec(const float* vt, long long N, int i, in
     } else { v[0] = v[1] = v[2] = 0.f; }
 }
 
-// ---- divergence mask: 1 where the normalised field converges onto the cell (mc_utils.py:34-86) ----
-__global__ void vfn_grid_divergence_kernel(const float* vt, float* out, int N, float threshold) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)N * N * N;
-    if (idx >= total) return;
-    const int k = (int)(idx % N), j = (int)((idx / N) % N), i = (int)(idx / ((long long)N * N));
-    float res = 0.f;
-    if (i < N - 1 && j < N - 1 && k < N - 1) {
-        const float inv3 = 1.0f / sqrtf(3.0f);
-        const float face_area = (float)(1.7320508075688772 / 4.0), shape_volume = (float)(1.4142135623730951 / 3.0);
-        float s = 0.f;
-        // corner c of the 2x2x2 box = (a, b, cc) = (c >> 2, (c >> 1) & 1, c & 1), outward direction (2a-1, 2b-1, 2cc-1) / sqrt(3)
-        for (int c = 0; c < 8; ++c) {
-            const int a = c >> 2, b = (c >> 1) & 1, cc = c & 1;
-            float v[3];
-            load_vec(vt, N, i + a, j + b, k + cc, v);
-            const float nrm = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
-            const float x = (v[0] / nrm) * (a ? inv3 : -inv3) + (v[1] / nrm) * (b ? inv3 : -inv3) + (v[2] / nrm) * (cc ? inv3 : -inv3);
-            s += x * fabsf(x) * face_area;
+// ------------------------------------------------------------------------------------------------------------------------
+// divergence mask: 1 where the normalised field converges onto the cell (mc_utils.py:34-86)
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int DV_TJ = 8, DV_TK = 64;                         // cells of the footprint; (TJ+1) x (TK+1) vectors per plane
+constexpr int DV_PLANE = (DV_TJ + 1) * (DV_TK + 1);          // 585 vectors
+constexpr int DV_PER_THREAD = (DV_PLANE + 255) / 256;        // 3
+
+__global__ __launch_bounds__(256) void vfn_grid_divergence_kernel(const float* __restrict__ vt, float* __restrict__ out, int N, float threshold,
+                                                                  int seg_len) {
+    __shared__ float u[3][DV_PLANE * 3];                     // normalised vectors of three consecutive planes (21 KB)
+    const int tid = threadIdx.x;
+    const int k0 = blockIdx.x * DV_TK, j0 = blockIdx.y * DV_TJ;
+    const int i0 = blockIdx.z * seg_len, i1 = min(N, i0 + seg_len);
+    if (i0 >= i1) return;
+    const long long NN = (long long)N * N;
+
+    float r[DV_PER_THREAD][3];
+    auto fetch = [&](int i) {                                // this thread's vectors of plane i -> registers (zeros outside the grid)
+#pragma unroll
+        for (int s = 0; s < DV_PER_THREAD; ++s) {
+            const int v = tid + 256 * s;
+            const int j = j0 + v / (DV_TK + 1), k = k0 + v % (DV_TK + 1);
+            if (v < DV_PLANE && i < N && j < N && k < N) {
+                const long long o = ((long long)i * NN + (long long)j * N + k) * 3;
+                r[s][0] = vt[o]; r[s][1] = vt[o + 1]; r[s][2] = vt[o + 2];
+            } else { r[s][0] = r[s][1] = r[s][2] = 0.f; }
         }
-        res = s / shape_volume;
+    };
+    auto stash = [&](int b) {                                // normalise (F.normalize: v / max(|v|, 1e-12)) and store
+#pragma unroll
+        for (int s = 0; s < DV_PER_THREAD; ++s) {
+            const int v = tid + 256 * s;
+            if (v < DV_PLANE) {
+                const float nrm = fmaxf(sqrtf(r[s][0] * r[s][0] + r[s][1] * r[s][1] + r[s][2] * r[s][2]), 1e-12f);
+                u[b][v * 3] = r[s][0] / nrm; u[b][v * 3 + 1] = r[s][1] / nrm; u[b][v * 3 + 2] = r[s][2] / nrm;
+            }
+        }
+    };
+    const float inv3 = 1.0f / sqrtf(3.0f);
+    const float face_area = (float)(1.7320508075688772 / 4.0), shape_volume = (float)(1.4142135623730951 / 3.0);
+    const int kk = tid & 63, jj = tid >> 6;                  // this thread's two cells of a plane: (jj, kk) and (jj + 4, kk)
+
+    fetch(i0);
+    stash(0);
+    fetch(i0 + 1);
+    int n = 0;
+    for (int i = i0; i < i1; ++i, ++n) {
+        const int b0 = n % 3, b1 = (n + 1) % 3;
+        stash(b1);                                           // plane i + 1 (nobody reads buffer (n + 1) % 3 any more: one barrier per plane)
+        if (i + 2 <= i1) fetch(i + 2);                       // in flight during the barrier and the arithmetic
+        __syncthreads();
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int cj = jj + 4 * half;
+            const int j = j0 + cj, k = k0 + kk;
+            if (j >= N || k >= N) continue;
+            float res = 0.f;
+            if (i < N - 1 && j < N - 1 && k < N - 1) {
+                float s = 0.f;
+                // corner c of the 2x2x2 box = (a, b, cc) = (c >> 2, (c >> 1) & 1, c & 1), outward direction (2a-1, 2b-1, 2cc-1) / sqrt(3)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int a = c >> 2, b = (c >> 1) & 1, cc = c & 1;
+                    const float* p = &u[a ? b1 : b0][((cj + b) * (DV_TK + 1) + kk + cc) * 3];
+                    const float x = p[0] * (a ? inv3 : -inv3) + p[1] * (b ? inv3 : -inv3) + p[2] * (cc ? inv3 : -inv3);
+                    s += x * fabsf(x) * face_area;
+                }
+                res = s / shape_volume;
+            }
+            out[(long long)i * NN + (long long)j * N + k] = res > threshold ? 0.f : 1.f;
+        }
     }
-    out[idx] = res > threshold ? 0.f : 1.f;
 }
 
-// ---- one pass of the separable Gaussian along one axis, replicate padding (guassian_smoothing.py:81-97) ----
+// ------------------------------------------------------------------------------------------------------------------------
+// one pass of the separable Gaussian along one axis, replicate padding (guassian_smoothing.py:81-97)
+// ------------------------------------------------------------------------------------------------------------------------
 struct SmoothArgs { const float* in; float* out; int N; int axis; int k; float w[16]; };
+
+// any odd k <= 15 (the reference only uses 3 and 9): one thread per voxel, taps re-read through the caches
 __global__ void vfn_grid_smooth_kernel(const SmoothArgs a) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // voxel index
     const long long N = a.N, total = N * N * N;
@@ -65,64 +130,255 @@ __global__ void vfn_grid_smooth_kernel(const SmoothArgs a) {
     a.out[idx * 3] = acc[0]; a.out[idx * 3 + 1] = acc[1]; a.out[idx * 3 + 2] = acc[2];
 }
 
-// ---- per surface cell: the two most opposed corner vectors, and for every corner which of the two it sides with
-//      (mc_utils.py:107-167) ----
-__global__ void vfn_grid_unify_kernel(const float* div, const float* vt, long long* choice, int N) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)N * N * N;
-    if (idx >= total) return;
-    long long* out = choice + idx * 8;
-    if (div[idx] != 1.0f) {
+template <int V> struct Pack;
+template <> struct Pack<4> { typedef float4 T; };
+template <> struct Pack<1> { typedef float T; };
+template <int V> __device__ __forceinline__ void fma_pack(typename Pack<V>::T& acc, float w, const typename Pack<V>::T& x);
+template <> __device__ __forceinline__ void fma_pack<4>(float4& acc, float w, const float4& x) {
+    acc.x += w * x.x; acc.y += w * x.y; acc.z += w * x.z; acc.w += w * x.w;
+}
+template <> __device__ __forceinline__ void fma_pack<1>(float& acc, float w, const float& x) { acc += w * x; }
+template <int V> __device__ __forceinline__ typename Pack<V>::T zero_pack();
+template <> __device__ __forceinline__ float4 zero_pack<4>() { return float4{0.f, 0.f, 0.f, 0.f}; }
+template <> __device__ __forceinline__ float zero_pack<1>() { return 0.f; }
+
+// Axes 0 and 1.  The grid as a flat float array: element (outer, p, inner) at (outer * N + p) * inner_len + inner, the filter
+// runs over p; inner_len = 3 N^2 (axis 0, outer_len 1) or 3 N (axis 1, outer_len N).  A lane owns V consecutive `inner` floats of
+// one `outer` and marches p over [p_lo, p_hi) of its segment with the K taps in a register ring whose slots rotate at compile
+// time (the march is unrolled K positions at a time): every input is read once, every access is V floats wide and consecutive
+// across lanes.  Sums run over the taps in ascending order, like the per-voxel kernel.
+template <int K, int V>
+__global__ __launch_bounds__(256) void vfn_grid_smooth_march_kernel(const SmoothArgs a, long long inner_len, int outer_len, int seg_len) {
+    typedef typename Pack<V>::T T;
+    const long long cols = inner_len / V;
+    const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= cols * outer_len) return;
+    const long long outer = col / cols, inner = (col % cols) * V;
+    const int N = a.N, H = K / 2;
+    const int p_lo = blockIdx.y * seg_len, p_hi = min(N, p_lo + seg_len);
+    if (p_lo >= p_hi) return;
+    const float* src = a.in + outer * (long long)N * inner_len + inner;
+    float* dst = a.out + outer * (long long)N * inner_len + inner;
+    auto at = [&](int q) -> T {                              // replicate padding
+        q = q < 0 ? 0 : (q >= N ? N - 1 : q);
+        return *reinterpret_cast<const T*>(src + (long long)q * inner_len);
+    };
+    T win[K];                                                // position p_lo + m K + s: tap t sits in slot (s + t) % K
 #pragma unroll
-        for (int q = 0; q < 8; ++q) out[q] = 0;
-        return;
+    for (int t = 0; t < K - 1; ++t) win[t] = at(p_lo + t - H);
+    for (int p = p_lo; p < p_hi; p += K) {
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            if (p + s < p_hi) {
+                win[(s + K - 1) % K] = at(p + s + H);
+                T acc = zero_pack<V>();
+#pragma unroll
+                for (int t = 0; t < K; ++t) fma_pack<V>(acc, a.w[t], win[(s + t) % K]);
+                *reinterpret_cast<T*>(dst + (long long)(p + s) * inner_len) = acc;
+            }
+        }
     }
+}
+
+// Axis 2 (the innermost grid index): a row of N vectors = 3 N consecutive floats, the taps are 3 floats apart.  A workgroup
+// stages SM_ROWS whole rows in LDS (each input read once, consecutive) and every lane produces consecutive output floats.
+constexpr int SM_ROWS = 4;
+template <int K>
+__global__ __launch_bounds__(256) void vfn_grid_smooth_rows_kernel(const SmoothArgs a) {
+    extern __shared__ float rows[];                          // SM_ROWS x 3N floats
+    const int N = a.N, H = K / 2, row_len = 3 * N;
+    const long long n_rows = (long long)N * N;
+    const long long r0 = (long long)blockIdx.x * SM_ROWS;
+    const int nr = (int)min((long long)SM_ROWS, n_rows - r0);
+    const int floats = nr * row_len;
+    const float* src = a.in + r0 * row_len;
+    float* dst = a.out + r0 * row_len;
+    if ((row_len & 3) == 0) {
+        for (int f = threadIdx.x * 4; f < floats; f += 1024) *reinterpret_cast<float4*>(rows + f) = *reinterpret_cast<const float4*>(src + f);
+    } else {
+        for (int f = threadIdx.x; f < floats; f += 256) rows[f] = src[f];
+    }
+    __syncthreads();
+    auto one = [&](const float* row_base, int e) -> float {  // e = 3 kpos + c within the row
+        const int kpos = e / 3, c = e - kpos * 3;
+        const float* row = row_base + c;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            int q = kpos + t - H;
+            q = q < 0 ? 0 : (q >= N ? N - 1 : q);
+            acc += a.w[t] * row[q * 3];
+        }
+        return acc;
+    };
+    for (int r = 0; r < nr; ++r) {
+        const float* row = rows + r * row_len;
+        float* drow = dst + (long long)r * row_len;
+        if ((row_len & 3) == 0) {
+            for (int e = threadIdx.x * 4; e < row_len; e += 1024)
+                *reinterpret_cast<float4*>(drow + e) = float4{one(row, e), one(row, e + 1), one(row, e + 2), one(row, e + 3)};
+        } else {
+            for (int e = threadIdx.x; e < row_len; e += 256) drow[e] = one(row, e);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// per surface cell: the two most opposed corner vectors, and for every corner which of the two it sides with
+// (mc_utils.py:107-167).  Side bits of a cell = one byte; the int64 [N^3, 8] table of the reference's interface is written
+// from the bytes by the whole wave: 64 cells x 64 B = 4 KiB consecutive, four stores of 1 KiB.
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned cell_sides(const float* vt, int N, long long idx) {
     const int k = (int)(idx % N), j = (int)((idx / N) % N), i = (int)(idx / ((long long)N * N));
     float v[8][3];
 #pragma unroll
     for (int q = 0; q < 8; ++q) load_vec(vt, N, i + CORNER[q][0], j + CORNER[q][1], k + CORNER[q][2], v[q]);
     float best = -3.4e38f;
-    int bi = 0;
+    float fx = 0.f, fy = 0.f, fz = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
     for (int a = 0; a < 8; ++a)
+#pragma unroll
         for (int b = 0; b < 8; ++b) {
             const float d = 1.0f - ((v[a][0] * v[b][0] + v[a][1] * v[b][1]) + v[a][2] * v[b][2]);
-            if (d > best) { best = d; bi = a * 8 + b; }       // first maximum, as torch.argmax
+            if (d > best) {                                   // first maximum, as torch.argmax over the 64 pairs (a-major)
+                best = d;
+                fx = v[a][0]; fy = v[a][1]; fz = v[a][2]; sx = v[b][0]; sy = v[b][1]; sz = v[b][2];
+            }
         }
-    const int f = bi >> 3, s = bi & 7;
+    unsigned bits = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const float d1x = v[f][0] - v[q][0], d1y = v[f][1] - v[q][1], d1z = v[f][2] - v[q][2];
-        const float d2x = v[s][0] - v[q][0], d2y = v[s][1] - v[q][1], d2z = v[s][2] - v[q][2];
+        const float d1x = fx - v[q][0], d1y = fy - v[q][1], d1z = fz - v[q][2];
+        const float d2x = sx - v[q][0], d2y = sy - v[q][1], d2z = sz - v[q][2];
         const float n1 = sqrtf(d1x * d1x + d1y * d1y + d1z * d1z), n2 = sqrtf(d2x * d2x + d2y * d2y + d2z * d2z);
-        out[q] = n2 < n1 ? 1 : 0;                            // argmin over (first, second): first on ties
+        bits |= (n2 < n1 ? 1u : 0u) << q;                    // argmin over (first, second): first on ties
+    }
+    return bits;
+}
+
+__global__ __launch_bounds__(256) void vfn_grid_unify_kernel(const float* __restrict__ div, const float* __restrict__ vt, long long* __restrict__ choice,
+                                                             unsigned char* __restrict__ sides, int N) {
+    const long long total = (long long)N * N * N;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    unsigned bits = 0;
+    if (idx < total && div[idx] == 1.0f) bits = cell_sides(vt, N, idx);
+    if (sides && idx < total) sides[idx] = (unsigned char)bits;
+    if (!choice) return;
+    const long long first = idx - lane;                      // the wave's first cell
+    typedef long long ll2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = it * 64 + lane;                        // 16-byte chunk of the wave's 4 KiB: cell c / 4, corners 2 (c % 4), + 1
+        const unsigned m = (unsigned)__shfl((int)bits, c >> 2, 64);
+        const int q0 = (c & 3) * 2;
+        if (first + (c >> 2) < total)
+            *reinterpret_cast<ll2*>(choice + (first + (c >> 2)) * 8 + q0) = ll2{(long long)((m >> q0) & 1u), (long long)((m >> (q0 + 1)) & 1u)};
     }
 }
 
-// ---- the 28 corner pairs of every cell: do the two corners side differently, and their field magnitudes
-//      (mc_utils.py:170-223) ----
-__global__ void vfn_grid_comb_kernel(const long long* choice, const float* norms, float* different, float* pair_norms, int N) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// ------------------------------------------------------------------------------------------------------------------------
+// the 28 corner pairs of every cell: do the two corners side differently, and their field magnitudes (mc_utils.py:170-223)
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ __constant__ unsigned char PAIR_A[28] = {0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6};
+__device__ __constant__ unsigned char PAIR_B[28] = {1, 2, 3, 4, 5, 6, 7, 2, 3, 4, 5, 6, 7, 3, 4, 5, 6, 7, 4, 5, 6, 7, 5, 6, 7, 6, 7, 7};
+
+template <bool FROM_BYTES>
+__global__ __launch_bounds__(256) void vfn_grid_comb_kernel(const long long* __restrict__ choice, const unsigned char* __restrict__ sides,
+                                                            const float* __restrict__ norms, float* __restrict__ different,
+                                                            float* __restrict__ pair_norms, int N) {
+    __shared__ float nr[4][64][9];                           // 8 corner norms per cell (+1: lanes 9 floats apart, no bank conflict)
+    __shared__ unsigned mk[4][64];                           // side bits per cell
+    __shared__ unsigned char pa[28], pb[28];
     const long long total = (long long)N * N * N;
-    if (idx >= total) return;
-    const int k = (int)(idx % N), j = (int)((idx / N) % N), i = (int)(idx / ((long long)N * N));
-    float nr[8];
-    long long ch[8];
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 28) { pa[threadIdx.x] = PAIR_A[threadIdx.x]; pb[threadIdx.x] = PAIR_B[threadIdx.x]; }
+    unsigned bits = 0;
+    if (idx < total) {
+        const int k = (int)(idx % N), j = (int)((idx / N) % N), i = (int)(idx / ((long long)N * N));
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int ii = i + CORNER[q][0], jj = j + CORNER[q][1], kk = k + CORNER[q][2];
-        nr[q] = (ii < N && jj < N && kk < N) ? norms[((long long)ii * N + jj) * N + kk] : 0.f;
-        ch[q] = choice[idx * 8 + q];
-    }
-    int c = 0;
-    for (int a = 0; a < 7; ++a)
-        for (int b = a + 1; b < 8; ++b, ++c) {
-            different[idx * 28 + c] = ch[a] != ch[b] ? 1.f : 0.f;
-            pair_norms[(idx * 28 + c) * 2] = nr[a];
-            pair_norms[(idx * 28 + c) * 2 + 1] = nr[b];
+        for (int q = 0; q < 8; ++q) {
+            const int ii = i + CORNER[q][0], jj = j + CORNER[q][1], kk = k + CORNER[q][2];
+            nr[wave][lane][q] = (ii < N && jj < N && kk < N) ? norms[((long long)ii * N + jj) * N + kk] : 0.f;
         }
+        if (FROM_BYTES) bits = sides[idx];
+        else {
+            // "!=" between two int64 entries of the table: with entries 0 / 1 (what unify_direction writes) one bit per entry holds
+            // it; any other table is compared entry by entry below
+            typedef long long ll2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const ll2 v = *reinterpret_cast<const ll2*>(choice + idx * 8 + 2 * h);
+                bits |= (v[0] != 0 ? 1u : 0u) << (2 * h) | (v[1] != 0 ? 1u : 0u) << (2 * h + 1);
+                if ((v[0] & ~1ll) | (v[1] & ~1ll)) bits |= 0x100u;      // an entry outside {0, 1}
+            }
+        }
+    }
+    mk[wave][lane] = bits;
+    __syncthreads();
+    const long long first = idx - lane;
+    const int valid = (int)min(64ll, total - first);         // cells of this wave inside the grid
+    if (valid <= 0) return;
+    const bool general = !FROM_BYTES && __any((int)(bits & 0x100u));
+    // different_side: 28 floats per cell, the wave's 64 cells = 1792 consecutive floats = 7 x (64 lanes x float4)
+    float* d0 = different + first * 28;
+    for (int it = 0; it < 7; ++it) {
+        const int e0 = 4 * (it * 64 + lane);
+        float val[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = e0 + r, cell = e / 28, c = e - cell * 28;
+            const unsigned m = mk[wave][cell];
+            float x = (float)(((m >> pa[c]) ^ (m >> pb[c])) & 1u);
+            if (general && cell < valid) x = choice[(first + cell) * 8 + pa[c]] != choice[(first + cell) * 8 + pb[c]] ? 1.f : 0.f;
+            val[r] = x;
+        }
+        if (e0 + 3 < valid * 28) *reinterpret_cast<float4*>(d0 + e0) = float4{val[0], val[1], val[2], val[3]};
+        else
+            for (int r = 0; r < 4; ++r) if (e0 + r < valid * 28) d0[e0 + r] = val[r];
+    }
+    // pair_norms: 56 floats per cell = 14 x (64 lanes x float4)
+    float* p0 = pair_norms + first * 56;
+    for (int it = 0; it < 14; ++it) {
+        const int e0 = 4 * (it * 64 + lane);
+        float val[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = e0 + r, cell = e / 56, rem = e - cell * 56, c = rem >> 1;
+            val[r] = nr[wave][cell][(rem & 1) ? pb[c] : pa[c]];
+        }
+        if (e0 + 3 < valid * 56) *reinterpret_cast<float4*>(p0 + e0) = float4{val[0], val[1], val[2], val[3]};
+        else
+            for (int r = 0; r < 4; ++r) if (e0 + r < valid * 56) p0[e0 + r] = val[r];
+    }
 }
 
 inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
+
+template <int K>
+int launch_smooth(const SmoothArgs& a, hipStream_t s) {
+    const long long N = a.N;
+    if (a.axis == 2) {
+        const size_t lds = (size_t)SM_ROWS * 3 * N * sizeof(float);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(vfn_grid_smooth_rows_kernel<K>), dim3((unsigned)((N * N + SM_ROWS - 1) / SM_ROWS)), dim3(256), lds, s, a);
+        return VFN_OK;
+    }
+    const long long inner_len = a.axis == 0 ? 3 * N * N : 3 * N;
+    const int outer_len = a.axis == 0 ? 1 : (int)N;
+    const int v = (inner_len % 4 == 0) ? 4 : 1;
+    const long long lanes = inner_len / v * outer_len;
+    // enough waves to fill the chip: split the march into segments (each re-reads K - 1 planes) while there are fewer than ~2048
+    int segs = (int)((2048ll * 64 + lanes - 1) / lanes);
+    segs = segs < 1 ? 1 : (segs > (int)((N + 4 * K - 1) / (4 * K)) ? (int)((N + 4 * K - 1) / (4 * K)) : segs);
+    int seg_len = (int)((N + segs - 1) / segs);
+    seg_len = (seg_len + K - 1) / K * K;
+    segs = (int)((N + seg_len - 1) / seg_len);
+    const dim3 grid(blocks_for(lanes), (unsigned)segs);
+    if (v == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(vfn_grid_smooth_march_kernel<K, 4>), grid, dim3(256), 0, s, a, inner_len, outer_len, seg_len);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(vfn_grid_smooth_march_kernel<K, 1>), grid, dim3(256), 0, s, a, inner_len, outer_len, seg_len);
+    return VFN_OK;
+}
 
 }  // namespace
 
@@ -130,7 +386,13 @@ extern "C" int vfn_grid_divergence(const float* vt, int32_t n, float threshold, 
     if (n <= 0) return VFN_OK;
     VFN_REQUIRE(vt && out, "vfn_grid_divergence: NULL argument");
     VFN_REQUIRE(n <= 1024, "vfn_grid_divergence: resolution %d > 1024", n);
-    hipLaunchKernelGGL(vfn_grid_divergence_kernel, dim3(blocks_for((long long)n * n * n)), dim3(256), 0, (hipStream_t)stream, vt, out, n, threshold);
+    const int bx = (n + DV_TK - 1) / DV_TK, by = (n + DV_TJ - 1) / DV_TJ;
+    // planes per workgroup: whole columns when the footprints alone fill the chip, else segments of >= 16 planes (one extra plane each)
+    int segs = (2048 + bx * by - 1) / (bx * by);
+    segs = segs < 1 ? 1 : (segs > (n + 15) / 16 ? (n + 15) / 16 : segs);
+    const int seg_len = (n + segs - 1) / segs;
+    hipLaunchKernelGGL(vfn_grid_divergence_kernel, dim3(bx, by, (n + seg_len - 1) / seg_len), dim3(256), 0, (hipStream_t)stream, vt, out, n, threshold,
+                       seg_len);
     return vfn_check_launch("vfn_grid_divergence");
 }
 
@@ -141,7 +403,12 @@ extern "C" int vfn_grid_smooth_axis(const float* in, float* out, int32_t n, int3
     SmoothArgs a{};
     a.in = in; a.out = out; a.N = n; a.axis = axis; a.k = k;
     for (int t = 0; t < k; ++t) a.w[t] = weights_host[t];
-    hipLaunchKernelGGL(vfn_grid_smooth_kernel, dim3(blocks_for((long long)n * n * n)), dim3(256), 0, (hipStream_t)stream, a);
+    // the two filters the reference uses (k = 3 with sigma 1, k = 9 with sigma 2: evaluation/methods.py:214-221) have register-window /
+    // LDS-row kernels; rows must fit the LDS budget of the axis-2 kernel
+    const bool fits = (size_t)SM_ROWS * 3 * n * sizeof(float) <= 64 * 1024;
+    if (k == 3 && (axis != 2 || fits)) launch_smooth<3>(a, (hipStream_t)stream);
+    else if (k == 9 && (axis != 2 || fits)) launch_smooth<9>(a, (hipStream_t)stream);
+    else hipLaunchKernelGGL(vfn_grid_smooth_kernel, dim3(blocks_for((long long)n * n * n)), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_grid_smooth_axis");
 }
 
@@ -150,15 +417,33 @@ extern "C" int vfn_grid_unify_direction(const float* divergence, const float* vt
     VFN_REQUIRE(divergence && vt && choice, "vfn_grid_unify_direction: NULL argument");
     VFN_REQUIRE(n <= 1024, "vfn_grid_unify_direction: resolution %d > 1024", n);
     hipLaunchKernelGGL(vfn_grid_unify_kernel, dim3(blocks_for((long long)n * n * n)), dim3(256), 0, (hipStream_t)stream, divergence, vt,
-                       (long long*)choice, n);
+                       (long long*)choice, (unsigned char*)nullptr, n);
     return vfn_check_launch("vfn_grid_unify_direction");
+}
+
+extern "C" int vfn_grid_unify_direction_sides(const float* divergence, const float* vt, int32_t n, uint8_t* sides, int64_t* choice, void* stream) {
+    if (n <= 0) return VFN_OK;
+    VFN_REQUIRE(divergence && vt && sides, "vfn_grid_unify_direction_sides: NULL argument");
+    VFN_REQUIRE(n <= 1024, "vfn_grid_unify_direction_sides: resolution %d > 1024", n);
+    hipLaunchKernelGGL(vfn_grid_unify_kernel, dim3(blocks_for((long long)n * n * n)), dim3(256), 0, (hipStream_t)stream, divergence, vt,
+                       (long long*)choice, (unsigned char*)sides, n);
+    return vfn_check_launch("vfn_grid_unify_direction_sides");
 }
 
 extern "C" int vfn_grid_comb_format(const int64_t* choice, const float* norms, int32_t n, float* different_side, float* pair_norms, void* stream) {
     if (n <= 0) return VFN_OK;
     VFN_REQUIRE(choice && norms && different_side && pair_norms, "vfn_grid_comb_format: NULL argument");
     VFN_REQUIRE(n <= 1024, "vfn_grid_comb_format: resolution %d > 1024", n);
-    hipLaunchKernelGGL(vfn_grid_comb_kernel, dim3(blocks_for((long long)n * n * n)), dim3(256), 0, (hipStream_t)stream,
-                       (const long long*)choice, norms, different_side, pair_norms, n);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(vfn_grid_comb_kernel<false>), dim3(blocks_for((long long)n * n * n)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)choice, (const unsigned char*)nullptr, norms, different_side, pair_norms, n);
     return vfn_check_launch("vfn_grid_comb_format");
+}
+
+extern "C" int vfn_grid_comb_format_sides(const uint8_t* sides, const float* norms, int32_t n, float* different_side, float* pair_norms, void* stream) {
+    if (n <= 0) return VFN_OK;
+    VFN_REQUIRE(sides && norms && different_side && pair_norms, "vfn_grid_comb_format_sides: NULL argument");
+    VFN_REQUIRE(n <= 1024, "vfn_grid_comb_format_sides: resolution %d > 1024", n);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(vfn_grid_comb_kernel<true>), dim3(blocks_for((long long)n * n * n)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)nullptr, (const unsigned char*)sides, norms, different_side, pair_norms, n);
+    return vfn_check_launch("vfn_grid_comb_format_sides");
 }

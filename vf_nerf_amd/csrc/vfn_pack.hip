@@ -25,6 +25,19 @@ void vfn_set_error(const char* fmt, ...) {
 
 extern "C" const char* vfn_last_error(void) { return g_last_error.c_str(); }
 extern "C" int vfn_abi_version(void) { return VFN_ABI_VERSION; }
+extern "C" int32_t vfn_abi_struct_bytes(int32_t which) {
+    switch (which) {
+    case 0: return (int32_t)sizeof(vfn_net_geom);
+    case 1: return (int32_t)sizeof(vfn_layer_params);
+    case 2: return (int32_t)sizeof(vfn_raygen_params);
+    case 3: return (int32_t)sizeof(vfn_density_params);
+    case 4: return (int32_t)sizeof(vfn_fine_params);
+    case 5: return (int32_t)sizeof(vfn_render_params);
+    case 6: return (int32_t)sizeof(vfn_unfold_entry);
+    case 7: return (int32_t)sizeof(vfn_wgrad_layer);
+    default: return -1;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // planning

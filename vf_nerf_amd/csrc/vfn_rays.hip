@@ -14,6 +14,13 @@
 
 namespace {
 
+// torch.argmax order, shared by every argmax in this file (ray_sampler.py:277 takes torch.argmax of the proposal weights): the
+// first maximum; a NaN beats every number (the first NaN wins).  `oi` / `besti` break ties towards the smaller index.
+__device__ __forceinline__ bool argmax_takes(float ob, int oi, float best, int besti) {
+    if (ob != ob) return best == best || oi < besti;
+    return best == best && (ob > best || (ob == best && oi < besti));
+}
+
 constexpr int WAVE = 64;
 constexpr int RAYS_PER_BLOCK = 4;   // one wave per ray, 256 threads
 constexpr int MAX_SAMPLES = 512;    // per-ray samples supported by the LDS carve-up (<= 40 KiB dynamic LDS)
@@ -291,7 +298,7 @@ __device__ __forceinline__ int density_ray(const DensityArgs& a, float* su, int 
         float w = se[j];
         if (a.p.normalize) w = w / den;
         if (a.weights) a.weights[(size_t)ray * S + j] = w;
-        if (w > best) { best = w; besti = j; }
+        if (argmax_takes(w, j, best, besti)) { best = w; besti = j; }
         if (col) {
             acc[0] += w * col[j * 3 + 0]; acc[1] += w * col[j * 3 + 1]; acc[2] += w * col[j * 3 + 2];
             acc[3] += w * sz[j];
@@ -301,7 +308,7 @@ __device__ __forceinline__ int density_ray(const DensityArgs& a, float* su, int 
     for (int o = 32; o > 0; o >>= 1) {
         const float ob = __shfl_xor(best, o, WAVE);
         const int oi = __shfl_xor(besti, o, WAVE);
-        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        if (argmax_takes(ob, oi, best, besti)) { best = ob; besti = oi; }
     }
     besti = (besti == 0x7fffffff) ? 0 : besti;
     if (a.argmax && lane == 0) a.argmax[ray] = besti;
@@ -808,14 +815,13 @@ __global__ __launch_bounds__(256) void vfn_rows_argmax_kernel(const float* w, in
     int besti = 0x7fffffff;
     for (int j = lane; j < n_cols; j += WAVE) {
         const float v = w[(size_t)row * n_cols + j];
-        if (v > best || (v != v && best == best)) { best = v; besti = j; }   // first maximum; a NaN wins, like torch.argmax
+        if (argmax_takes(v, j, best, besti)) { best = v; besti = j; }   // first maximum; a NaN wins, like torch.argmax
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ob = __shfl_xor(best, o, WAVE);
         const int oi = __shfl_xor(besti, o, WAVE);
-        const bool take = (ob != ob) ? (best == best || oi < besti) : (best == best && (ob > best || (ob == best && oi < besti)));
-        if (take) { best = ob; besti = oi; }
+        if (argmax_takes(ob, oi, best, besti)) { best = ob; besti = oi; }
     }
     if (lane == 0) out[row] = (besti == 0x7fffffff) ? 0 : besti;
 }

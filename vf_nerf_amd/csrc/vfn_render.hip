@@ -179,6 +179,10 @@ extern "C" int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf
         }
     };
     hipStream_t main_s = (hipStream_t)stream;
+    // optional timing events around the two fused launches (stages 1 and 3) on the stream they are issued on
+    auto mark = [&](int slot) {
+        if (p->timing_events[slot]) (void)hipEventRecord((hipEvent_t)p->timing_events[slot], main_s);
+    };
     // streams: 1 = one stream, 2 = two halves, 0 = two halves when that pays: at least 512 rays and the two fused launches leave >= 5 %
     // of their workgroup slots empty (one workgroup of 128 points per CU and round of 256; e.g. 1 024 rays x (100 + 35) samples =
     // 800 + 280 workgroups = 4 + 2 rounds for 4.2 rounds of work: +13 %; whole rounds, or halves too small to fill the chip: nothing
@@ -191,7 +195,12 @@ extern "C" int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf
     }
     Side* side = parts > 1 ? side_streams() : nullptr;
     if (!side) {
-        for (int k = 0; k < 5; ++k) { rc = stage(k, 0, n, main_s); if (rc != VFN_OK) return rc; }
+        for (int k = 0; k < 5; ++k) {
+            if (k == 1 || k == 3) mark(k - 1);
+            rc = stage(k, 0, n, main_s);
+            if (rc != VFN_OK) return rc;
+            if (k == 1 || k == 3) mark(k);
+        }
         return VFN_OK;
     }
     // the batch in `parts` ranges of rays, all but the first on side streams forked from (and joined back into) the caller's: a
@@ -204,7 +213,11 @@ extern "C" int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf
     rc = VFN_OK;
     for (int k = 0; k < 5 && rc == VFN_OK; ++k)
         for (int i = 0; i < parts && rc == VFN_OK; ++i)
-            if (r0[i + 1] > r0[i]) rc = stage(k, r0[i], r0[i + 1] - r0[i], i == 0 ? main_s : side->s[i - 1]);
+            if (r0[i + 1] > r0[i]) {
+                if (i == 0 && (k == 1 || k == 3)) mark(k - 1);
+                rc = stage(k, r0[i], r0[i + 1] - r0[i], i == 0 ? main_s : side->s[i - 1]);
+                if (i == 0 && (k == 1 || k == 3)) mark(k);
+            }
     // (joined even after an error, so that the caller's stream never runs ahead of work already issued on a side stream)
     for (int i = 1; i < parts; ++i)
         if (hipEventRecord(side->join[i - 1], side->s[i - 1]) != hipSuccess || hipStreamWaitEvent(main_s, side->join[i - 1], 0) != hipSuccess) {

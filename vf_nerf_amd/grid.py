@@ -132,14 +132,28 @@ def smooth_vf(vf: torch.Tensor, k: int = 3, sigma: float = 1.0) -> torch.Tensor:
     return b.view(n, n, n, 3)
 
 
+_last_sides = None       # (weak reference to the table unify_direction returned last, its version, the same sides as bytes)
+
+
 def unify_direction(divergence_grid: torch.Tensor, vt_grid: torch.Tensor, N: int = 64) -> torch.Tensor:
-    """divergence_grid[N,N,N], vt_grid[3,N,N,N] (normalised field, channel first as the reference passes it) -> [N^3,8]."""
+    """divergence_grid[N,N,N], vt_grid[3,N,N,N] (normalised field, channel first as the reference passes it) -> [N^3,8] int64.
+    The side bits are also kept as one byte per cell; ``make_comb_format`` reads those when it is handed this very tensor,
+    unmodified (which is all evaluation/methods.py:248-253 does with it) instead of 64 B per cell."""
+    global _last_sides
+    import weakref
     vt = _dev_f32(vt_grid.permute(1, 2, 3, 0).reshape(-1, 3))
-    return lib.grid_unify_direction(_dev_f32(divergence_grid.reshape(-1)), vt, N)
+    sides, choice = lib.grid_unify_direction_sides(_dev_f32(divergence_grid.reshape(-1)), vt, N)
+    _last_sides = (weakref.ref(choice), choice._version, sides)
+    return choice
 
 
 def make_comb_format(choice_side: torch.Tensor, norms: torch.Tensor, N: int):
     """choice_side[N^3,8], norms[N^3] -> (different_side[N^3,28], different_side_norms[N^3,28,2])."""
+    global _last_sides
     if not choice_side.is_cuda:
         raise lib.VfnError("the dense-grid stages run on the device")
+    held = _last_sides
+    if held is not None and held[0]() is choice_side and held[1] == choice_side._version:
+        _last_sides = None
+        return lib.grid_comb_format_sides(held[2], _dev_f32(norms.reshape(-1)), N)
     return lib.grid_comb_format(choice_side.to(torch.int64).contiguous(), _dev_f32(norms.reshape(-1)), N)

@@ -20,14 +20,14 @@ HIDDEN = 256
 NET_VF, NET_RENDER = 0, 1
 
 EXPORTS = (
-    "vfn_last_error", "vfn_abi_version", "vfn_packed_size", "vfn_pack_weights", "vfn_raygen_uniform",
+    "vfn_last_error", "vfn_abi_version", "vfn_abi_struct_bytes", "vfn_packed_size", "vfn_pack_weights", "vfn_raygen_uniform",
     "vfn_vf_mlp_fwd", "vfn_render_mlp_fwd", "vfn_vf_render_fused_fwd", "vfn_ray_density_weights",
     "vfn_range_fine_sample", "vfn_range_fine_sample_indexed", "vfn_fill_uniform", "vfn_sample_sphere_shell", "vfn_packed_bwd_size", "vfn_pack_weights_bwd",
     "vfn_vf_mlp_fwd_train", "vfn_vf_render_fused_fwd_train", "vfn_mlp_bwd_chain", "vfn_weight_grad_partials",
     "vfn_ray_density_weights_bwd", "vfn_pack16_size", "vfn_pack16_weights", "vfn_vf_mlp16_fwd",
     "vfn_vf_render_fused16_fwd", "vfn_vf_mlp16_fwd_train", "vfn_vf_render_fused16_fwd_train",
     "vfn_vf_feat16_fwd", "vfn_render16_from_blocks", "vfn_grid_divergence", "vfn_grid_smooth_axis",
-    "vfn_grid_unify_direction", "vfn_grid_comb_format", "vfn_weight_grad_partials_bf16", "vfn_unfold_weight_grads", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
+    "vfn_grid_unify_direction", "vfn_grid_comb_format", "vfn_grid_unify_direction_sides", "vfn_grid_comb_format_sides", "vfn_weight_grad_partials_bf16", "vfn_unfold_weight_grads", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
     "vfn_linear_rows", "vfn_linear_rows_stat_parts", "vfn_bstat_row_parts", "vfn_colsum_finish", "vfn_bstat_finalize",
     "vfn_bstat_relu_rows", "vfn_bstat_relu_bwd_sums", "vfn_bstat_relu_bwd_rows", "vfn_act_bwd_rows", "vfn_embed_rows",
     "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_vf_render_fused16_products", "vfn_net_weight_grads_frag", "vfn_net_weight_grads_frag_part", "vfn_net_weight_grads_scratch_bytes", "vfn_vf_render_fused16_fwd_train_at",
@@ -75,10 +75,119 @@ class RenderParams(C.Structure):
     _fields_ = [("n_rays", C.c_int32), ("n_coarse", C.c_int32), ("n_fine", C.c_int32), ("pose_is_quat", C.c_int32),
                 ("perturb_coarse", C.c_int32), ("perturb_fine", C.c_int32), ("near_coarse", C.c_float), ("near_fine", C.c_float),
                 ("far_coarse", C.c_float), ("far_fine", C.c_float), ("fine_range", C.c_float), ("window_step", C.c_float), ("span", C.c_float),
-                ("density", DensityParams), ("seed", C.c_uint64), ("offset", C.c_uint64), ("colour_products", C.c_int32), ("separate_launches", C.c_int32), ("streams", C.c_int32), ("reserved", C.c_int32)]
+                ("density", DensityParams), ("seed", C.c_uint64), ("offset", C.c_uint64), ("colour_products", C.c_int32), ("separate_launches", C.c_int32), ("streams", C.c_int32), ("reserved", C.c_int32),
+                ("timing_events", C.c_void_p * 4)]
 
 
 _lib: Optional[C.CDLL] = None
+
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vfn.h")
+
+
+def _header_text() -> str:
+    import re
+    with open(HEADER_PATH) as fh:
+        text = fh.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return re.sub(r"//[^\n]*", "", text)
+
+
+def header_abi_version() -> int:
+    import re
+    with open(HEADER_PATH) as fh:
+        return int(re.search(r"#define\s+VFN_ABI_VERSION\s+(\d+)", fh.read()).group(1))
+
+
+ABI_VERSION = header_abi_version()       # include/vfn.h is the single source: the library must report the same number
+
+
+def header_prototypes() -> dict:
+    """{name: (return type, [parameter types])} of every ``vfn_*`` entry point declared in include/vfn.h, as C type strings
+    without the parameter names (``"const float*"``, ``"int64_t"``, ...)."""
+    import re
+    out = {}
+    for ret, name, params in re.findall(r"^\s*([A-Za-z_][\w\s\*]*?)\b(vfn_\w+)\s*\(([^;{}]*?)\)\s*;", _header_text(), flags=re.M | re.S):
+        plist = []
+        for prm in params.replace("\n", " ").split(","):
+            prm = re.sub(r"\s+", " ", prm).strip()
+            if prm in ("void", ""):
+                continue
+            plist.append(re.match(r"(.*?)\s*\w+$", prm).group(1).replace(" *", "*").strip())
+        out[name] = (re.sub(r"\s+", " ", ret).strip(), plist)
+    return out
+
+
+_INT_TYPES = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "uint32_t": C.c_uint32, "uint64_t": C.c_uint64}
+_FLOAT_TYPES = {"float": C.c_float, "double": C.c_double}
+_C_INTS = (C.c_int8, C.c_int16, C.c_int32, C.c_int64, C.c_uint8, C.c_uint16, C.c_uint32, C.c_uint64, C.c_bool)
+
+
+class _IntArg:
+    """argtypes entry of an integer parameter: Python ints and ctypes integers of any width pass (converted to the declared
+    width); floats, pointers and None do not — a call whose arguments were reordered fails here instead of reaching the kernel."""
+
+    def __init__(self, ctype, what):
+        self.ctype, self.what = ctype, what
+
+    def from_param(self, v):
+        if isinstance(v, _C_INTS):
+            v = v.value
+        if isinstance(v, bool):
+            v = int(v)
+        if not isinstance(v, int):
+            raise TypeError(f"{self.what}: expected an integer, got {type(v).__name__}")
+        return self.ctype(v)
+
+
+class _FloatArg:
+    def __init__(self, ctype, what):
+        self.ctype, self.what = ctype, what
+
+    def from_param(self, v):
+        if isinstance(v, (C.c_float, C.c_double)):
+            v = v.value
+        if isinstance(v, bool) or not isinstance(v, (int, float)):
+            raise TypeError(f"{self.what}: expected a real number, got {type(v).__name__}")
+        return self.ctype(float(v))
+
+
+class _PtrArg:
+    """argtypes entry of a pointer parameter: None, c_void_p, byref()/pointer() results and ctypes arrays / structures pass."""
+
+    def __init__(self, what):
+        self.what = what
+
+    def from_param(self, v):
+        if v is None:
+            return C.c_void_p(0)
+        if isinstance(v, (C.c_void_p, C.c_char_p, C.Array, C._Pointer)) or type(v).__name__ == "CArgObject":
+            return v
+        if isinstance(v, C.Structure):
+            return C.byref(v)
+        raise TypeError(f"{self.what}: expected a pointer (None, c_void_p, byref(struct), ctypes array), got {type(v).__name__}")
+
+
+def _declare(lib: C.CDLL) -> None:
+    """restype / argtypes of EVERY export, generated from the prototypes of include/vfn.h (the header is the single source; a
+    signature edited there reaches the binding without a second hand-written list)."""
+    protos = header_prototypes()
+    for name in EXPORTS:
+        fn = getattr(lib, name)               # raises AttributeError if the ABI lost a symbol
+        if name not in protos:
+            raise VfnError(f"{name} is exported by the binding but not declared in {HEADER_PATH}")
+        ret, params = protos[name]
+        fn.restype = C.c_char_p if ret == "const char*" else _INT_TYPES[ret]
+        args = []
+        for i, t in enumerate(params):
+            what = f"{name} argument {i} ({t})"
+            args.append(_PtrArg(what) if t.endswith("*") else
+                        _IntArg(_INT_TYPES[t], what) if t in _INT_TYPES else _FloatArg(_FLOAT_TYPES[t], what))
+        fn.argtypes = args
+
+
+def struct_mirrors():
+    """The ctypes mirrors of the header's POD structs in the order of ``vfn_abi_struct_bytes``."""
+    return (NetGeom, LayerParams, RaygenParams, DensityParams, FineParams, RenderParams, UnfoldEntry, WgradLayer)
 
 
 def load() -> C.CDLL:
@@ -90,28 +199,12 @@ def load() -> C.CDLL:
         raise VfnError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        f"or vf_nerf_amd/csrc/build.sh (there is no CPU fallback)")
     lib = C.CDLL(LIB_PATH)
-    lib.vfn_last_error.restype = C.c_char_p
-    lib.vfn_packed_size.restype = C.c_int64
-    lib.vfn_net_weight_grads_scratch_bytes.restype = C.c_int64
-    lib.vfn_packed_size.argtypes = [C.c_int32, C.POINTER(NetGeom)]
-    lib.vfn_packed_bwd_size.restype = C.c_int64
-    lib.vfn_packed_bwd_size.argtypes = [C.c_int32, C.POINTER(NetGeom)]
-    lib.vfn_pack16_size.restype = C.c_int64
-    lib.vfn_pack16_size.argtypes = [C.c_int32, C.POINTER(NetGeom)]
-    lib.vfn_packed_bwd16_size.restype = C.c_int64
-    lib.vfn_packed_bwd16_size.argtypes = [C.c_int32, C.POINTER(NetGeom)]
-    lib.vfn_linear_rows_stat_parts.restype = C.c_int64
-    lib.vfn_linear_rows_stat_parts.argtypes = [C.c_int64]
-    lib.vfn_bstat_row_parts.restype = C.c_int64
-    lib.vfn_bstat_row_parts.argtypes = [C.c_int64]
-    lib.vfn_flat_clip_workspace_bytes.restype = C.c_int64
-    lib.vfn_flat_clip_workspace_bytes.argtypes = []
-    lib.vfn_render_fwd_workspace_bytes.restype = C.c_int64
-    lib.vfn_render_fwd_workspace_bytes.argtypes = [C.POINTER(RenderParams)]
-    for name in EXPORTS:
-        getattr(lib, name)  # raises AttributeError if the ABI lost a symbol
-    if lib.vfn_abi_version() != 1:
-        raise VfnError(f"libvfn.so ABI {lib.vfn_abi_version()} != 1")
+    _declare(lib)
+    if lib.vfn_abi_version() != ABI_VERSION:
+        raise VfnError(f"libvfn.so reports ABI {lib.vfn_abi_version()}, include/vfn.h says {ABI_VERSION}: rebuild the library")
+    for i, mirror in enumerate(struct_mirrors()):
+        if lib.vfn_abi_struct_bytes(i) != C.sizeof(mirror):
+            raise VfnError(f"{mirror.__name__}: {C.sizeof(mirror)} bytes in the binding, {lib.vfn_abi_struct_bytes(i)} in libvfn.so")
     _lib = lib
     return lib
 
@@ -889,6 +982,25 @@ def grid_unify_direction(divergence: torch.Tensor, vt: torch.Tensor, n: int) -> 
     _check(load().vfn_grid_unify_direction(_ptr(divergence, "divergence"), _ptr(vt, "vt"), C.c_int32(n),
                                            _ptr(choice, "choice", torch.int64), _stream()), "vfn_grid_unify_direction")
     return choice
+
+
+def grid_unify_direction_sides(divergence: torch.Tensor, vt: torch.Tensor, n: int, want_table: bool = True):
+    """-> (sides[n^3] uint8: bit q = corner q's side, choice[n^3,8] int64 | None)."""
+    sides = torch.empty(n * n * n, dtype=torch.uint8, device=vt.device)
+    choice = torch.empty(n * n * n, 8, dtype=torch.int64, device=vt.device) if want_table else None
+    _check(load().vfn_grid_unify_direction_sides(_ptr(divergence, "divergence"), _ptr(vt, "vt"), C.c_int32(n), _ptr(sides, "sides", torch.uint8),
+                                                 _ptr(choice, "choice", torch.int64), _stream()), "vfn_grid_unify_direction_sides")
+    return sides, choice
+
+
+def grid_comb_format_sides(sides: torch.Tensor, norms: torch.Tensor, n: int):
+    dev = norms.device
+    different = torch.empty(n * n * n, 28, device=dev)
+    pair_norms = torch.empty(n * n * n, 28, 2, device=dev)
+    _check(load().vfn_grid_comb_format_sides(_ptr(sides, "sides", torch.uint8), _ptr(norms, "norms"), C.c_int32(n),
+                                             _ptr(different, "different_side"), _ptr(pair_norms, "pair_norms"), _stream()),
+           "vfn_grid_comb_format_sides")
+    return different, pair_norms
 
 
 def grid_comb_format(choice: torch.Tensor, norms: torch.Tensor, n: int):

@@ -1,8 +1,11 @@
 """``VFLoss`` with the interface of the reference's ``models/losses/vf_loss.py:13-87``: same constructor
 arguments (a config with ``depth_loss_clamp`` / ``norm_smaller_than_one_start`` / ``directional_derivatives_start`` and a
 weights record), same ``forward(pred, gt, epoch) -> (loss, {name: float})``, same terms.  The reference reads its six log
-scalars back with six ``.item()`` calls — six device synchronisations per training step; here they are stacked on the
-device and read back once.  ``vf_nerf_amd.dropin`` installs it as ``models.losses.vf_loss.VFLoss``.
+scalars back with six ``.item()`` calls — six device synchronisations in the MIDDLE of every training step (between the loss
+and ``backward()``, with the device idle while the host catches up); here they are stacked on the device, copied to pinned
+host memory asynchronously, and the returned dict fetches them the first time a value is READ (``_LazyTerms``) — in the
+reference trainer that is after ``optimizer.step()`` has been queued (train/vector_field_nerf_train.py:262-275), and a loop
+that never looks at the terms never synchronises.  ``vf_nerf_amd.dropin`` installs it as ``models.losses.vf_loss.VFLoss``.
 """
 from __future__ import annotations
 
@@ -13,6 +16,71 @@ from torch import nn
 
 _NAMES = ("rgb_loss", "depth_loss", "unit_norm_loss", "supervision_loss", "norm_smaller_than_one_loss",
           "directional_derivatives_loss")
+
+
+class _LazyTerms(dict):
+    """{name: float} whose values arrive from the device on first read.  Keys, length and iteration order are available at
+    once; every way of reading a value (indexing, get, values, items, pop, copy, repr, comparison) waits for the copy first."""
+
+    def __init__(self, names, stacked: torch.Tensor) -> None:
+        super().__init__((n, None) for n in names)
+        self._pending = None
+        if stacked.is_cuda:
+            host = torch.empty(stacked.shape, dtype=stacked.dtype, pin_memory=True)
+            host.copy_(stacked, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(stacked.device))
+            self._pending = (host, ev, tuple(names))
+        else:
+            dict.update(self, zip(names, stacked.tolist()))
+
+    def _fetch(self) -> None:
+        if self._pending is not None:
+            host, ev, names = self._pending
+            self._pending = None
+            ev.synchronize()
+            for n, v in zip(names, host.tolist()):
+                if dict.__getitem__(self, n) is None:          # (a value the caller has overwritten meanwhile stays)
+                    dict.__setitem__(self, n, v)
+
+    def __getitem__(self, k):
+        self._fetch()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        self._fetch()
+        return dict.get(self, k, default)
+
+    def values(self):
+        self._fetch()
+        return dict.values(self)
+
+    def items(self):
+        self._fetch()
+        return dict.items(self)
+
+    def pop(self, *a):
+        self._fetch()
+        return dict.pop(self, *a)
+
+    def copy(self):
+        self._fetch()
+        return dict(dict.items(self))
+
+    def __repr__(self) -> str:
+        self._fetch()
+        return dict.__repr__(self)
+
+    def __eq__(self, other) -> bool:
+        self._fetch()
+        return dict.__eq__(self, other)
+
+    def __ne__(self, other) -> bool:
+        return not self.__eq__(other)
+
+    def __reduce__(self):
+        self._fetch()
+        return (dict, (dict(dict.items(self)),))
 
 
 class VFLoss(nn.Module):
@@ -45,5 +113,5 @@ class VFLoss(nn.Module):
         terms = (rgb_loss, depth_loss, unit_norm_loss, supervision_loss, smaller_loss, dd_loss)
         loss = w.rgb * rgb_loss + w.depth * depth_loss + w.unit_norm * unit_norm_loss + w.supervision * supervision_loss + \
             w.norm_smaller_than_one * smaller_loss + w.directional_derivatives * dd_loss
-        values = torch.stack([t.detach() for t in terms]).tolist()          # one read-back instead of six
-        return loss, dict(zip(_NAMES, values))
+        # one asynchronous read-back instead of six synchronising ones; the values are waited for when first read
+        return loss, _LazyTerms(_NAMES, torch.stack([t.detach() for t in terms]))

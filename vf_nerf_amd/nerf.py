@@ -432,8 +432,19 @@ class VectorFieldNerf:
                 self._render_ws.clear()
             ws = self._render_ws[key] = torch.empty(lib.render_workspace_bytes(rp), dtype=torch.uint8, device=dev)
         vf, rn = self.vector_field_network, self.rendering_network
+        # bench.py hook: HIP events around the two fused launches, recorded by vfn_render_fwd itself on its launch stream (the
+        # handles exist once an event has been recorded; the call records them again, in place)
+        sink = getattr(self, "_kernel_events", None)
+        if sink is not None:
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            for i, e in enumerate(evs):
+                e.record()
+                rp.timing_events[i] = e.cuda_event
         o = lib.render_fwd(rp, vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(), pixels.float().contiguous(),
                            pose, intrinsics, self._linspace(s_c, dev), far_ct, far_ft, self.density.raw_scalars(), u_c, u_f, u_a, ws)
+        if sink is not None:
+            sink.append(("fused16", evs[0], evs[1]))
+            sink.append(("fused16", evs[2], evs[3]))
         s_t = s_c + n_f
         rgb = o["rgb"]
         if white:
@@ -502,7 +513,7 @@ class VectorFieldNerf:
 
         # gradient-free f16x3 render: the whole launch sequence from C (same launches, same values, ~10x less host time)
         if self.one_call_render and self.reuse_proposal and self.uses_f16x3() and not self._needs_grad() and \
-                0 < n * (s_c + n_f) < (1 << 22) and not cfg.numerical_jacobian and getattr(self, "_kernel_events", None) is None:
+                0 < n * (s_c + n_f) < (1 << 22) and not cfg.numerical_jacobian:
             return self._render_one_call(pose, pixels, intrinsics, uniforms, n, s_c, n_f, perturb_c, perturb_f, white)
 
         # the draws that are not supplied come from ONE Philox launch (three contiguous segments of one buffer)
@@ -612,13 +623,17 @@ class VectorFieldNerf:
         ``rays_per_batch`` pieces and keeps rgb and depth) — with consecutive chunks on alternating HIP streams: chunks are
         independent, and a chunk of 1024 rays is only 2-4 rounds of workgroups per launch, so the next chunk's launches fill
         the CUs that the current one's last round leaves idle and hide its small per-ray kernels.  Same arithmetic per
-        chunk as ``render()``; returns (rgb[N,3], depth[N,1])."""
+        chunk as ``render()``; returns (rgb[N,3], depth[N,1]) on the device.  ``pose`` / ``pixels`` / ``intrinsics`` may live on the host."""
         n = pixels.shape[0]
-        dev = pixels.device
+        dev = pixels.device if pixels.is_cuda else torch.device(self.config.cuda_config.device)
         rgb = torch.empty(n, 3, device=dev)
         depth = torch.empty(n, 1, device=dev)
         shared_pose = pose.dim() == 1 or (pose.dim() == 2 and pose.shape == (4, 4)) or pose.shape[0] == 1
         shared_k = intrinsics.dim() == 2 or intrinsics.shape[0] == 1
+        if shared_pose:
+            pose = pose.to(dev)
+        if shared_k:
+            intrinsics = intrinsics.to(dev)
         cur = torch.cuda.current_stream(dev)
         streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, n_streams))]
         # Everything render() builds lazily and caches (weight packs, the density scalars' stack, the linspace table) is built
@@ -630,8 +645,10 @@ class VectorFieldNerf:
         for i, lo in enumerate(range(0, n, chunk)):
             hi = min(lo + chunk, n)
             with torch.cuda.stream(streams[i % len(streams)]):
-                out = self.render(pose if shared_pose else pose[lo:hi], pixels[lo:hi], intrinsics if shared_k else intrinsics[lo:hi],
-                                  epoch, white)
+                # host inputs (the evaluator's dataset hands a whole view over as CPU tensors, evaluation/methods.py:504-526): a
+                # chunk's upload is issued on the chunk's stream, so it overlaps the other stream's kernels
+                out = self.render(pose if shared_pose else pose[lo:hi].to(dev, non_blocking=True), pixels[lo:hi].to(dev, non_blocking=True),
+                                  intrinsics if shared_k else intrinsics[lo:hi].to(dev, non_blocking=True), epoch, white)
                 rgb[lo:hi] = out.coarse_rgb_values
                 depth[lo:hi] = out.coarse_depth_map
         for st in streams:
