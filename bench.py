@@ -49,21 +49,33 @@ SUSTAINED_F16_MFMA = 1570.0                # TFLOP/s a pure 32x32x16 f16 MFMA lo
                                            # busy (power-limited clock ~1.8 GHz): tools/micro/mfma_power.hip, DESIGN.md §3
 
 
+def kernel_sources_sha16() -> str:
+    import hashlib
+    src = b"".join(open(os.path.join(REPO, "vf_nerf_amd", "csrc", f), "rb").read() for f in ("vfn_mlp16.hip", "vfn_bwd16.hip", "vfn_dwf.hip"))
+    return hashlib.sha256(src).hexdigest()[:16]
+
+
 def hbm_traffic(f16: bool, kernel_class: str = "fused16", colour_products: int = 3):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside the
-    benchmark): FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md §HBM) + WRITE_SIZE, in bytes."""
-    path = os.path.join(REPO, "profiles", "r02", "traffic_f16x3.json" if colour_products == 2 else "traffic_f16x3_3products.json")
-    if not f16 or not os.path.exists(path):
-        return None
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside the benchmark; its
+    counters need their own passes): FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md section HBM) + WRITE_SIZE, in
+    bytes -> (bytes | None, provenance).  The provenance names the file and says whether the kernel sources have changed since the
+    counters were collected (tools/export_profiles.py stores a fingerprint of them)."""
+    name = "traffic_f16x3.json" if colour_products == 2 else "traffic_f16x3_3products.json"
+    path = next((p for p in (os.path.join(REPO, "profiles", r, name) for r in ("r03", "r02")) if os.path.exists(p)), None)
+    if not f16 or path is None:
+        return None, None
     with open(path) as fh:
         t = json.load(fh)
+    sha = t.get("kernel_sources_sha16")
+    prov = {"file": os.path.relpath(path, REPO), "collected_with": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)",
+            "kernel_sources_unchanged_since": (sha == kernel_sources_sha16()) if sha else None}
     syms = {"vf_feat16": ("vfn_mlp16_kernel<9>",), "render16": ("vfn_mlp16_kernel<18>",),
             "fused16": ("vfn_mlp16_kernel<35>",) if colour_products == 2 else ("vfn_mlp16_kernel<3>",)}.get(kernel_class, ())
     for sym in syms:
         fetch, write = t["all_kernels"].get(f"FETCH_SIZE|{sym}"), t["all_kernels"].get(f"WRITE_SIZE|{sym}")
         if fetch is not None and write is not None:
-            return int((2.0 * fetch + write) * 1024)
-    return None
+            return int((2.0 * fetch + write) * 1024), prov
+    return None, prov
 
 
 def build_scene(dev, n_rays, s_c, n_f, seed, perturb=True, weight_seed=0):
@@ -867,7 +879,7 @@ def main() -> None:
                 "kernel_ms_per_step_by_class": {k: round(sum(v) / max(1, (args.steps + 3) // 4), 4) for k, v in per_class.items()},
                 "event_sampling": "HIP events recorded by vfn_render_fwd around its two fused launches on every 4th timed step (one-call path)",
                 "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": hbm_traffic(f16, dom, cp),
+                "frac": round(achieved / peak, 4), "traffic": hbm_traffic(f16, dom, cp)[0], "traffic_source": hbm_traffic(f16, dom, cp)[1],
                 # what one launch has to move: points in, vector columns out, plus the 1 KiB feature block per point that the
                 # split launches hand over (written by vf_feat16, read by render16); weights stream from L2
                 "algorithmic_bytes": int(points * {"vf_feat16": 12 + 12 + 1024, "render16": 1024 + 12 + 12 + 4 + 24}.get(dom, 12 + 4 + 24)),

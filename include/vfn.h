@@ -205,6 +205,11 @@ int vfn_uniform_sample(int32_t n_rays, int32_t n_samples, float near, float far,
  * ray_sampler.py:277; an all-zero row gives 0, Q9), int64. */
 int vfn_rows_argmax(const float* w, int32_t n_rows, int32_t n_cols, int64_t* out, void* stream);
 
+/* RaySampler.sample with additional_depths (ray_sampler.py:69-73): z_out[N, S + E] = sort(cat(z_vals[N,S], extra[N,E])) per ray
+ * (ascending, NaN last, like torch.sort), points[N, S + E, 3] = cam_loc + z_out * directions (NULL: depths only).  S + E <= 2048. */
+int vfn_merge_sort_depths(const float* z_vals, const float* extra, int32_t n_rays, int32_t n_samples, int32_t n_extra,
+                          const float* directions, const float* cam_loc, float* z_out, float* points, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * The whole gradient-free render() in ONE call: VectorFieldNerf.render (models/nerf/vector_field_nerf.py:216-338) on the f16x3
  * kernels with one vector-field evaluation per distinct sample, issued from C on one stream out of one caller-supplied workspace

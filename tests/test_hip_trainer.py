@@ -570,3 +570,63 @@ def test_evaluator_loop_through_the_dropin_gets_the_chunked_values():
     model.rng_seed, model._rng_offset = 5, 0
     rgb_shared, _ = evaluator.render_view(model, pose[0], uv, K[0], 0, split_size=split)
     assert np.array_equal(rgb_shared, rgb_values)
+
+
+def test_frozen_parameters_are_left_alone_by_the_training_step():
+    """requires_grad_(False) on parameters of both nets: the in-place gradient mode and the flat Adam kernel would
+    write every element of their flat buffers, so such a model takes autograd's own accumulation and the per-parameter Adam
+    path — frozen tensors keep their values bit for bit and get neither a gradient nor optimizer state, the others train; the
+    supervision forward's loss still reaches the vector-field net although its FIRST parameter is frozen."""
+    from vf_nerf_amd import trainer
+    fx, d = load_fixture("c1_perturb")
+    g = {k: v.to(DEV) for k, v in d.items() if isinstance(v, torch.Tensor)}
+    model = build_model(fx, d, device=DEV)
+    vf, rn = model.vector_field_network, model.rendering_network
+    frozen = [vf.layers[0][0].weight, vf.layers[3][0].bias, rn.layers[1][0].weight]
+    for p in frozen:
+        p.requires_grad_(False)
+    before = [p.detach().clone() for p in frozen]
+    moving = [vf.layers[5][0].weight, rn.layers[4].weight, vf.layers[8].weight]
+    moving_before = [p.detach().clone() for p in moving]
+    step = trainer.TrainStep(model, (0.0, 0.0, 0.55), border_radius=0.15, far=1.0)
+    gen = torch.Generator().manual_seed(1)
+    rgb_gt, depth_gt = torch.rand(fx["n_rays"], 3, generator=gen).to(DEV), torch.rand(fx["n_rays"], 1, generator=gen).to(DEV)
+    for _ in range(2):
+        loss, _ = step(g["pose"], g["uv"], g["intrinsics"], rgb_gt, depth_gt, epoch=0)
+        assert bool(torch.isfinite(loss))
+    for p, b in zip(frozen, before):
+        assert torch.equal(p.detach(), b) and p.grad is None and len(model.optimizer.state.get(p, {})) == 0
+    for p, b in zip(moving, moving_before):
+        assert not torch.equal(p.detach(), b)
+    assert float(model.optimizer.state[vf.layers[8].weight]["step"]) == 4 and float(model.optimizer.state[rn.layers[4].weight]["step"]) == 2
+    # supervision only: the loss reaches the vector-field net through autograd although its first parameter is frozen
+    model.optimizer.zero_grad()
+    pts = torch.rand(64, 3, device=DEV)
+    (model.vector_field_network(pts)[:, :3] ** 2).sum().backward()
+    assert vf.layers[5][0].weight.grad is not None and float(vf.layers[5][0].weight.grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("name", ["c1_perturb", "odd_orbit"])
+def test_sampler_additional_depths_sorted_on_the_device(name):
+    """RaySampler.sample(..., additional_depths) (ray_sampler.py:69-73: cat, torch.sort, points recomputed) through the device
+    merge-sort (vfn_merge_sort_depths), against torch's own sort of the same depths; duplicates, a NaN (sorts last) and a number of
+    depths that is not a power of two included."""
+    fx, d = load_fixture(name)
+    model = build_model(fx, d, device=DEV)
+    g = {k: v.to(DEV) for k, v in d.items() if isinstance(v, torch.Tensor)}
+    sampler = model.ray_sampler
+    sampler.deterministic = True
+    n = fx["n_rays"]
+    gen = torch.Generator().manual_seed(3)
+    extra = (fx["near"] + (fx["far"] - fx["near"]) * torch.rand(n, 7, generator=gen)).to(DEV)
+    extra[:, 3] = extra[:, 1]                       # duplicates
+    extra[2, 5] = float("nan")
+    pts, z = sampler.sample(g["directions"].reshape(n, 1, 3), g["cam_loc"], additional_depths=extra)
+    z_plain = sampler.get_z_vals(g["directions"].reshape(n, 1, 3), g["cam_loc"])
+    want, _ = torch.cat((z_plain, extra), dim=1).sort(dim=1)
+    assert z.shape == (n, fx["n_samples"] + 7) and pts.shape == (n, fx["n_samples"] + 7, 3)
+    same = (z == want) | (torch.isnan(z) & torch.isnan(want))
+    assert bool(same.all()) and bool(torch.isnan(z[2, -1])) and int(torch.isnan(z).sum()) == 1
+    ok = ~torch.isnan(z)
+    want_pts = g["cam_loc"].unsqueeze(1) + want.unsqueeze(2) * g["directions"].reshape(n, 1, 3)
+    assert float((pts - want_pts)[ok].abs().max()) < 1e-6

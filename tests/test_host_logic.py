@@ -442,3 +442,46 @@ def test_lazy_loss_terms_behave_like_the_dict_the_trainer_expects():
     assert abs(average["rgb_loss"] - float((pred["rgb"] - gt["rgb"]).abs().mean())) < 1e-7
     assert abs(2.0 * average["rgb_loss"] + 0.5 * average["depth_loss"] + 0.1 * average["unit_norm_loss"] + average["supervision_loss"]
                - 2 * average["loss"]) < 1e-5
+
+
+def test_modules_and_parameters_stay_picklable_next_to_the_flat_optimizer(tmp_path):
+    """The optimizer finds its parameters through a registry outside the tensors (optim.owner_of): nothing lands in a
+    Parameter's __dict__, so torch.save(module) / torch.save({'p': param}) / pickle keep working after model.optimizer exists."""
+    import pickle
+    from vf_nerf_amd import optim
+    m = _cpu_model(n_samples=8, n_importance=8)
+    p = m.vector_field_network.layers[0][0].weight
+    assert optim.owner_of(p) is m.optimizer and "_flat_adam" not in p.__dict__
+    torch.save(m.rendering_network, tmp_path / "module.pt")
+    torch.save({"p": p}, tmp_path / "param.pt")
+    again = pickle.loads(pickle.dumps(p))
+    assert torch.equal(again, p) and optim.owner_of(again) is None
+    back = torch.load(tmp_path / "module.pt", weights_only=False)
+    assert torch.equal(back.layers[0][0].weight, m.rendering_network.layers[0][0].weight)
+
+
+def test_adam_skips_frozen_parameters_like_torch():
+    """requires_grad_(False) on a parameter: torch.optim.Adam neither updates it nor counts a step for it (grad is None), with
+    weight decay as without.  SequentialAdam / FlatAdam (CPU path here; the device path is tests/test_hip_trainer.py) agree with
+    torch.optim.Adam(foreach=False) on a list with a duplicated and a frozen parameter."""
+    from vf_nerf_amd import optim
+    torch.manual_seed(0)
+    a = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2, 2))]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    for ps in (a, b):
+        ps[1].requires_grad_(False)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        oa = optim.FlatAdam(a + a[:1], lr=1e-2, weight_decay=0.1)
+        ob = torch.optim.Adam(b + b[:1], lr=1e-2, weight_decay=0.1, foreach=False)
+    for _ in range(3):
+        for ps, o in ((a, oa), (b, ob)):
+            o.zero_grad()
+            loss = (ps[0] ** 2).sum() + (ps[2] * 3).sum() + (ps[1] * 0).sum()
+            loss.backward()
+            o.step()
+    for p, q in zip(a, b):
+        assert torch.allclose(p, q, atol=1e-7)
+    assert a[1].grad is None and len(oa.state.get(a[1], {})) == 0
+    assert float(oa.state[a[0]]["step"]) == 6 and float(oa.state[a[2]]["step"]) == 3

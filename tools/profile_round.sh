@@ -1,0 +1,26 @@
+#!/bin/bash
+# The rocprofv3 passes behind profiles/rNN/ (run on the GPU box from the repository root):  bash tools/profile_round.sh [out_dir]
+# Kernel trace and every counter set in its OWN pass (MI355X_MICROARCH.md, HBM / rocprofv3 section); the program after `--` is python3
+# itself (no wrapper: the profiler's preloaded library has initialised the GPU before the program starts).
+set -u
+R=$(pwd)
+OUT=${1:-gpurun_out/export}
+mkdir -p "$R/$OUT" "$R/gpurun_out"
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --no-cpu-baseline --no-train"
+rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_kt" -o kt -- $B --steps 20 > "$R/gpurun_out/prof_kt.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE -d "$R/gpurun_out/prof_fetch" -o pf -- $B --steps 5 --no-fp32-equivalent > "$R/gpurun_out/prof_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE -d "$R/gpurun_out/prof_write" -o pw -- $B --steps 5 --no-fp32-equivalent > "$R/gpurun_out/prof_write.log" 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$R/gpurun_out/pmc_mfma" -o pm -- $B --steps 5 --no-fp32-equivalent > "$R/gpurun_out/pmc_mfma.log" 2>&1
+cd "$R" && python3 tools/export_profiles.py gpurun_out "$OUT" f16x3 > "$OUT/export_f16x3.log" 2>&1
+# the training step and the dense-grid stages: kernel tables
+cd /tmp
+rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_train" -o kt -- python3 $R/bench.py --workload train --steps 15 > "$R/gpurun_out/prof_train.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_train1024" -o kt -- python3 $R/bench.py --workload train --rays 1024 --steps 40 > "$R/gpurun_out/prof_train1024.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_grid" -o kt -- python3 $R/bench.py --workload grid-stages > "$R/gpurun_out/prof_grid.log" 2>&1
+cd "$R"
+python3 tools/topk.py gpurun_out/prof_train/kt_results.db 30 > "$OUT/train_kernel_stats.txt"
+python3 tools/topk.py gpurun_out/prof_train1024/kt_results.db 30 > "$OUT/train1024_kernel_stats.txt"
+python3 tools/topk.py gpurun_out/prof_grid/kt_results.db 30 > "$OUT/grid_stage_stats.txt"
+tail -1 gpurun_out/prof_train.log > "$OUT/bench_train_profiled.json"
+ls -la "$OUT"

@@ -24,6 +24,14 @@ def vf_forward(net, points: torch.Tensor, vector_only: bool = False) -> torch.Te
         return out[:, :3].contiguous() if vector_only else out
     if _wants_grad(net, points):
         from .backward import vf_forward_autograd
+        # the trainer's supervision batches (train/vector_field_nerf_train.py:191,203,215) run the f16x3 training forward too: their
+        # operands are under the range guard's watch like render()'s (a report switches the model to the exact-fp32 kernels)
+        guard = getattr(net, "_range_guard", None)
+        if guard is not None and guard.active() and points.is_cuda and getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3():
+            guard.poll()
+            if getattr(net, "precision", "fp32") == "f16x3":
+                with guard.watch(points.device):
+                    return vf_forward_autograd(net, points, vector_only)
         return vf_forward_autograd(net, points, vector_only)
     pts = _flat3(points)
     if vector_only and getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3():

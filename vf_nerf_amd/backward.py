@@ -155,10 +155,16 @@ def _direct_ok(net, dev) -> bool:
     plist = getattr(net, "_param_list_cache", None)
     if plist is None:
         plist = net._param_list_cache = list(net.parameters())
+    # In-place mode writes every parameter's gradient (and hands autograd ONE anchor per net): only sound when every parameter
+    # wants a gradient and nobody listens for it — a frozen parameter must not be touched, a tensor hook / post-accumulate hook
+    # would never fire.  Otherwise: the full parameter list through autograd's own accumulation.
+    for p in plist:
+        if not p.requires_grad or p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
+            return False
     # the flat optimizer's views (optim.FlatAdam) are contiguous fp32 slices of one device buffer by construction: when every
     # gradient IS the view it made, nothing else needs checking
-    owner = getattr(plist[0], "_flat_adam", None) if plist else None
-    owner = owner() if owner is not None else None
+    from .optim import owner_of
+    owner = owner_of(plist[0]) if plist else None
     if owner is not None and owner._flat is not None and owner._flat["grad"].device == dev:
         views = owner._flat.get("grad_views")
         if views is not None:
@@ -486,6 +492,8 @@ class StepWorkspace:
 
     def flush(self) -> None:
         """End of the backward pass: the vector-field net's weight gradients over every region whose chain has run."""
+        # (the flag and the list are reset FIRST: should a launch below raise, the pool's later backward passes queue a flush again
+        # instead of silently leaving the vector-field net's weight gradients out)
         self.queued = False
         regions, self.done = sorted(self.done), []
         if not regions:

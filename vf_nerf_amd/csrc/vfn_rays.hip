@@ -826,6 +826,46 @@ __global__ __launch_bounds__(256) void vfn_rows_argmax_kernel(const float* w, in
     if (lane == 0) out[row] = (besti == 0x7fffffff) ? 0 : besti;
 }
 
+// RaySampler.sample with additional_depths (ray_sampler.py:69-73): the sampler's depths and the extra ones concatenated, sorted
+// ascending per ray (torch.sort: a NaN sorts last), the points recomputed.  One wave per ray; a bitonic network over the ray's
+// depths in LDS, padded to a power of two with NaNs (they sort behind everything, a real +inf included).
+__global__ __launch_bounds__(256) void vfn_merge_sort_depths_kernel(const float* z, const float* extra, int n_rays, int s, int e, int p2,
+                                                                    const float* directions, const float* cam_loc, float* z_out, float* points) {
+    extern __shared__ float sbuf[];                          // RAYS_PER_BLOCK x p2
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + wv;
+    const bool live = ray < n_rays;
+    float* buf = sbuf + wv * p2;
+    const int tot = s + e;
+    for (int i = lane; i < p2; i += WAVE)
+        buf[i] = !live || i >= tot ? __builtin_nanf("") : (i < s ? z[(size_t)ray * s + i] : extra[(size_t)ray * e + (i - s)]);
+    __syncthreads();
+    for (int k = 2; k <= p2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < p2; i += WAVE) {
+                const int q = i ^ j;
+                if (q > i) {
+                    const float a = buf[i], b = buf[q];
+                    const bool a_gt_b = (a != a && b == b) || a > b;          // NaN above every number, like torch.sort
+                    const bool up = (i & k) == 0;
+                    if (a_gt_b == up && (a_gt_b || (b != b && a == a) || b > a)) { buf[i] = b; buf[q] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    if (!live) return;
+    for (int i = lane; i < tot; i += WAVE) {
+        const float zz = buf[i];
+        const size_t idx = (size_t)ray * tot + i;
+        z_out[idx] = zz;
+        if (points) {
+            points[idx * 3 + 0] = cam_loc[(size_t)ray * 3 + 0] + zz * directions[(size_t)ray * 3 + 0];
+            points[idx * 3 + 1] = cam_loc[(size_t)ray * 3 + 1] + zz * directions[(size_t)ray * 3 + 1];
+            points[idx * 3 + 2] = cam_loc[(size_t)ray * 3 + 2] + zz * directions[(size_t)ray * 3 + 2];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int vfn_uniform_sample(int32_t n_rays, int32_t n_samples, float near, float far, const float* directions,
@@ -838,6 +878,21 @@ extern "C" int vfn_uniform_sample(int32_t n_rays, int32_t n_samples, float near,
     const long long total = (long long)n_rays * n_samples;
     hipLaunchKernelGGL(vfn_uniform_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_uniform_sample");
+}
+
+extern "C" int vfn_merge_sort_depths(const float* z_vals, const float* extra, int32_t n_rays, int32_t n_samples, int32_t n_extra,
+                                     const float* directions, const float* cam_loc, float* z_out, float* points, void* stream) {
+    if (n_rays == 0) return VFN_OK;
+    VFN_REQUIRE(n_rays > 0 && n_samples >= 0 && n_extra >= 0 && n_samples + n_extra >= 1 && n_samples + n_extra <= 2048,
+                "vfn_merge_sort_depths: bad sizes (n_rays=%d, n_samples=%d, n_extra=%d; at most 2048 depths per ray)", n_rays, n_samples, n_extra);
+    VFN_REQUIRE((z_vals || n_samples == 0) && (extra || n_extra == 0) && z_out && (!points || (directions && cam_loc)),
+                "vfn_merge_sort_depths: NULL argument");
+    int p2 = 2;
+    while (p2 < n_samples + n_extra) p2 <<= 1;
+    hipLaunchKernelGGL(vfn_merge_sort_depths_kernel, dim3((unsigned)((n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK)), dim3(256),
+                       (size_t)RAYS_PER_BLOCK * p2 * sizeof(float), (hipStream_t)stream, z_vals, extra, (int)n_rays, (int)n_samples, (int)n_extra, p2,
+                       directions, cam_loc, z_out, points);
+    return vfn_check_launch("vfn_merge_sort_depths");
 }
 
 extern "C" int vfn_rows_argmax(const float* w, int32_t n_rows, int32_t n_cols, int64_t* out, void* stream) {

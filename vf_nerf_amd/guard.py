@@ -115,7 +115,7 @@ class RangeGuard:
             if cache is not None and cache[1].device == torch.device(dev):
                 host[lo:lo + lib.PACK16_STATS_WORDS].copy_(cache[1][-4 * lib.PACK16_STATS_WORDS:].view(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
-        ev.record()
+        ev.record(torch.cuda.current_stream(dev))      # the stream of `dev` the copies above were issued on (not the current device's)
         st["event"] = ev
 
     def _pack_keys(self):

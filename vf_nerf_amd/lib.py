@@ -32,7 +32,7 @@ EXPORTS = (
     "vfn_bstat_relu_rows", "vfn_bstat_relu_bwd_sums", "vfn_bstat_relu_bwd_rows", "vfn_act_bwd_rows", "vfn_embed_rows",
     "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_vf_render_fused16_products", "vfn_net_weight_grads_frag", "vfn_net_weight_grads_frag_part", "vfn_net_weight_grads_scratch_bytes", "vfn_vf_render_fused16_fwd_train_at",
     "vfn_vf_mlp16_fwd_train_at", "vfn_mlp_bwd_chain_bf16_ws_at",
-    "vfn_weight_grad_groups", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax",
+    "vfn_weight_grad_groups", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax", "vfn_merge_sort_depths",
     "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step", "vfn_unfold_weight_grads_acc", "vfn_render_fwd", "vfn_render_fwd_workspace_bytes",
 )
 
@@ -311,6 +311,19 @@ def uniform_sample(directions, cam_loc, t_vals, n_samples: int, near: float, far
                                      _ptr(far_per_ray, "far_per_ray"), _ptr(u, "u"), _ptr(z, "z_vals"), _ptr(pts, "points"),
                                      _stream()), "vfn_uniform_sample")
     return z, pts
+
+
+def merge_sort_depths(z: torch.Tensor, extra: torch.Tensor, directions=None, cam_loc=None):
+    """sort(cat(z[N,S], extra[N,E]), dim=1) per ray on the device (+ the points along the rays when directions / cam_loc are given)
+    -> (z_out[N,S+E], points[N,S+E,3] | None)."""
+    n, s = z.shape
+    e = extra.shape[1]
+    out = torch.empty(n, s + e, device=z.device)
+    pts = torch.empty(n, s + e, 3, device=z.device) if directions is not None else None
+    _check(load().vfn_merge_sort_depths(_ptr(z, "z_vals"), _ptr(extra, "extra"), C.c_int32(n), C.c_int32(s), C.c_int32(e),
+                                        _ptr(directions, "directions"), _ptr(cam_loc, "cam_loc"), _ptr(out, "z_out"), _ptr(pts, "points"),
+                                        _stream()), "vfn_merge_sort_depths")
+    return out, pts
 
 
 def rows_argmax(w: torch.Tensor) -> torch.Tensor:

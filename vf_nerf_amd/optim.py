@@ -18,6 +18,29 @@ import torch
 from torch.optim.adam import adam as _functional_adam
 
 
+# Which FlatAdam owns a parameter: kept OUTSIDE the tensor (an attribute on the Parameter would land in its __dict__ and make the
+# Parameter, and every module holding it, unpicklable: torch.save(module), spawn arguments).  id(p) -> (weakref to p, weakref to the
+# optimizer); an entry whose parameter has died (its id may be reused) is recognised by the identity check and dropped.
+_OWNERS = {}
+
+
+def _register_owner(p: torch.nn.Parameter, opt) -> None:
+    import weakref
+    _OWNERS[id(p)] = (weakref.ref(p), weakref.ref(opt))
+    if len(_OWNERS) > 4096:                       # forget entries of parameters that no longer exist
+        for k in [k for k, (rp, ro) in _OWNERS.items() if rp() is None or ro() is None]:
+            del _OWNERS[k]
+
+
+def owner_of(p: torch.nn.Parameter):
+    """The FlatAdam that holds ``p`` in its flat buffers, or None."""
+    hit = _OWNERS.get(id(p))
+    if hit is None:
+        return None
+    rp, ro = hit
+    return ro() if rp() is p else None
+
+
 def _passes(params: Iterable[torch.nn.Parameter]) -> List[List[torch.nn.Parameter]]:
     """[params seen >= 1 times, params seen >= 2 times, ...] in first-occurrence order."""
     count, order = {}, []
@@ -91,9 +114,8 @@ class FlatAdam(SequentialAdam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self._flat = None
         self.after_step = None
-        import weakref
         for p in self.param_groups[0]["params"]:           # lets clip_grad_norm_ find the flat gradient buffer of a parameter list
-            p._flat_adam = weakref.ref(self)
+            _register_owner(p, self)
 
     # -- flat storage -----------------------------------------------------------------------------
     def _layout(self):
@@ -124,7 +146,7 @@ class FlatAdam(SequentialAdam):
         if f is None:
             return False
         base = f["param"].data_ptr()
-        return all(p.data_ptr() == base + 4 * off for p, off, _, _ in f["entries"])
+        return all(p.data_ptr() == base + 4 * off and p.requires_grad for p, off, _, _ in f["entries"])
 
     def flat(self):
         """Build (or re-build, when something replaced a parameter's storage: .to(), .cuda()) the flat buffers; returns the
@@ -134,6 +156,19 @@ class FlatAdam(SequentialAdam):
         if self._bound():
             return self._flat
         entries, regions, total = self._layout()
+        if any(not p.requires_grad for p, _, _, _ in entries):
+            # A frozen parameter (requires_grad_(False)) has no gradient: torch.optim.Adam skips it — no update, no step count, no
+            # weight decay.  The flat kernels update every element of the buffer, so such a list takes SequentialAdam's per-parameter
+            # path (which skips ``grad is None``); a gradient view this optimizer attached earlier must not pose as a gradient.
+            old = self._flat
+            if old is not None:
+                views = {id(v) for v in old.get("grad_views", [])}
+                for p, _, _, _ in old["entries"]:
+                    if not p.requires_grad and (id(p.grad) in views or (p.grad is not None and p.grad.data_ptr() >= old["grad"].data_ptr() and
+                                                                          p.grad.data_ptr() < old["grad"].data_ptr() + 4 * old["grad"].numel())):
+                        p.grad = None
+            self._flat = None
+            return None
         devs = {p.device for p, _, _, _ in entries}
         if len(devs) != 1 or next(iter(devs)).type != "cuda" or any(p.dtype != torch.float32 for p, _, _, _ in entries) or len(regions) > 4:
             self._flat = None
@@ -250,8 +285,7 @@ def clip_grad_norm_(parameters, max_norm: float, norm_type: float = 2.0) -> torc
     if norm_type != 2.0:
         raise NotImplementedError("only the 2-norm (the reference's default) is implemented")
     plist = [p for p in (parameters if not isinstance(parameters, torch.Tensor) else [parameters])]
-    owner = getattr(plist[0], "_flat_adam", None) if plist else None
-    owner = owner() if owner is not None else None
+    owner = owner_of(plist[0]) if plist else None
     if owner is not None and owner.regions_for(plist):           # the gradients are one flat buffer: two launches
         from . import lib
         f = owner.flat()

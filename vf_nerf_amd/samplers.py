@@ -80,8 +80,8 @@ class RaySampler:
         dirs, cam = self._rays(ray_dirs, cam_loc)
         if additional_depths.shape[0] > 0:                      # :69-73: merge extra depths, sort, recompute the points
             z = self.get_z_vals(ray_dirs, cam_loc, device=device, coarse_z_vals=coarse_z_vals, coarse_weights=coarse_weights)
-            z, _ = torch.cat((z, additional_depths.to(z.device).float()), dim=1).sort(dim=1)
-            return cam.unsqueeze(1) + z.unsqueeze(2) * dirs.unsqueeze(1), z
+            z, pts = lib.merge_sort_depths(z.contiguous(), additional_depths.to(z.device).float().contiguous(), dirs, cam)
+            return pts, z
         return self._sample(dirs, cam, coarse_z_vals, coarse_weights, want_points=True)
 
     def get_z_vals(self, ray_dirs: torch.Tensor, cam_loc: torch.Tensor, device: Optional[torch.device] = None,
