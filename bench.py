@@ -265,7 +265,7 @@ def view_bench(args, dev):
     rgb, depth = o.coarse_rgb_values.cpu(), o.coarse_depth_map.cpu()
     rgb32, depth32 = o32.coarse_rgb_values.cpu(), o32.coarse_depth_map.cpu()
     r64_rgb, r64_dep, r64_z = ref64["rgb"], ref64["depth"], ref64["z_vals"]
-    print(json.dumps({
+    emit(({
         "metric": "rays/sec (full 1200x680 view, 1024-ray chunks, 128 samples/ray) + PSNR/depth vs ref",
         "value": round(n * args.steps / elapsed, 1), "unit": "rays/s", "n_gpus": 1, "steps": args.steps,
         "warmup": max(1, args.warmup // 3), "ms_per_step": round(elapsed / args.steps * 1e3, 2),
@@ -285,7 +285,7 @@ def view_bench(args, dev):
                              "hip_exact_fp32_vs_oracle_f32": account(o32.z_vals.cpu(), rgb32, depth32, ref["z_vals"], ref["rgb"], ref["depth"]),
                              "oracle_f32_vs_oracle_f64": account(ref["z_vals"], ref["rgb"], ref["depth"], r64_z, r64_rgb, r64_dep, exact_z=False),
                              "hip_default_vs_oracle_f64": account(o.z_vals.cpu(), rgb, depth, r64_z, r64_rgb, r64_dep, exact_z=False),
-                             "hip_exact_fp32_vs_oracle_f64": account(o32.z_vals.cpu(), rgb32, depth32, r64_z, r64_rgb, r64_dep, exact_z=False)}}), flush=True)
+                             "hip_exact_fp32_vs_oracle_f64": account(o32.z_vals.cpu(), rgb32, depth32, r64_z, r64_rgb, r64_dep, exact_z=False)}}))
 
 
 def grid_bench(args, dev, rank, world, dist, sync):
@@ -327,7 +327,7 @@ def grid_bench(args, dev, rank, world, dist, sync):
         idx = idx[(idx // 100000) % world == 0]                      # rows this rank evaluated
         ref = O.vf_mlp(samples[idx], vf_sd, 6, (4,))[:, :3]
         err = float((got[idx] - ref).abs().max())
-        print(json.dumps({
+        emit(({
             "metric": "grid points/sec (vector-field queries for quadrant marching cubes)",
             "value": round(n * args.steps / elapsed, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps,
             "warmup": max(1, args.warmup // 3), "ms_per_step": round(elapsed / args.steps * 1e3, 2),
@@ -337,7 +337,7 @@ def grid_bench(args, dev, rank, world, dist, sync):
                                    f"max_batch 100000 (BASELINE.json configs[4], one quadrant)",
                        "parallelism": f"blocks x{world}"},
             "device_resident_points_per_s": round(resident, 1),
-            "max_abs_err_vs_oracle_4096_points": err}), flush=True)
+            "max_abs_err_vs_oracle_4096_points": err}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -421,14 +421,14 @@ def grid_stages_bench(args, dev):
         del pred, div
         torch.cuda.empty_cache()
     best_div = out[f"res_{args.grid_res}"]["divergence"]
-    print(json.dumps({"metric": "dense-grid stage throughput (algorithmic HBM bytes / launch time)", "value": best_div["tb_per_s"], "unit": "TB/s",
+    emit(({"metric": "dense-grid stage throughput (algorithmic HBM bytes / launch time)", "value": best_div["tb_per_s"], "unit": "TB/s",
                       "n_gpus": 1, "steps": reps, "warmup": 1, "ms_per_step": best_div["ms"], "higher_is_better": True, "scaling": "weak",
                       "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                       "config": {"workload": f"extract_divergence / smooth_vf at {args.grid_res}^3, unify_direction / make_comb_format at "
                                              f"{args.unify_res}^3, field = the scene's vector field on the grid (SURVEY.md section 8f N3)"},
                       "roofline": {"bound": "hbm", "achieved": best_div["tb_per_s"] * 1e3, "peak": 8000.0, "unit": "GB/s",
                                    "frac": round(best_div["tb_per_s"] / 8.0, 4), "traffic": None, "kernel": "vfn_grid_divergence_kernel"},
-                      "stages": out}), flush=True)
+                      "stages": out}))
 
 
 def train_step_accounting(n_rays, s_c, s_t, n_sup, storage, gradients="fp32", separate_proposal=False):
@@ -545,11 +545,34 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
     if not emit:
         return rec
     if rank == 0:
-        print(json.dumps(rec), flush=True)
+        emit((rec))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     return rec
+
+
+_REAL_STDOUT = None
+
+
+def claim_stdout() -> None:
+    """The contract is ONE JSON line on stdout.  Libraries below Python write there too (RCCL prints its version banner through C
+    stdio when the process exits, i.e. AFTER the line): the process's stdout (fd 1) is pointed at stderr for everything else, and
+    the line goes out through a private duplicate of the original descriptor."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(rec) -> None:
+    data = (json.dumps(rec) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
 
 
 def launch_ranks(n: int, argv) -> int:
@@ -636,14 +659,14 @@ def dry_run(args, rank: int, world: int, dist) -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        print(json.dumps({"metric": "rays/sec (4096-ray chunk, 128 samples/ray) + PSNR vs ref", "value": round(args.rays * args.steps * world / elapsed, 1),
+        emit(({"metric": "rays/sec (4096-ray chunk, 128 samples/ray) + PSNR vs ref", "value": round(args.rays * args.steps * world / elapsed, 1),
                           "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "none", "data": "synthetic", "dry_run": True, "backend": args.backend, "per_rank_rays_per_s": rates,
                           "bucket_elements": bucket.numel(), "bucket_allreduce_ok": bool(ok), "bucket_allreduce_ms": round(bucket_ms, 3),
                           "replicas_identical_after_broadcast": bool(all(float(x) == float(sums[0]) for x in sums)) if dist is not None else True,
                           "config": {"workload": f"dry run of the {args.workload} workload's multi-rank plumbing (no device work)",
-                                     "parallelism": f"rays x{world}"}}), flush=True)
+                                     "parallelism": f"rays x{world}"}}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -710,6 +733,7 @@ def main() -> None:
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not started by a launcher: start the ranks ourselves (children; this process never touches the GPU)
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -939,7 +963,7 @@ def main() -> None:
                                                        "algorithmic_tflop_per_step", "achieved_tflops", "frac_of_f16_mfma_div3",
                                                        "workspace_gb_per_step", "workspace_tb_per_s", "frac_of_hbm_peak", "final_loss")}
             line["train"]["workload"] = train_rec["config"]["workload"]
-        print(json.dumps(line), flush=True)
+        emit((line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

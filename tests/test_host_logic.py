@@ -485,3 +485,35 @@ def test_adam_skips_frozen_parameters_like_torch():
         assert torch.allclose(p, q, atol=1e-7)
     assert a[1].grad is None and len(oa.state.get(a[1], {})) == 0
     assert float(oa.state[a[0]]["step"]) == 6 and float(oa.state[a[2]]["step"]) == 3
+
+
+def test_dense_centre_selection_gives_the_compacted_loss_and_gradient():
+    """trainer.TrainStep's default: the ray samples inside the centre ball without boolean-mask compaction (no host
+    synchronisation): rows outside enter as zeros and the mean's denominator is the selected-row count (VFLoss
+    ``supervised_rows``).  Same supervision loss and the same gradient wrt the normals as functions.py:137-157 + VFLoss's mean."""
+    from types import SimpleNamespace as NS
+    from vf_nerf_amd import supervision
+    from vf_nerf_amd.loss import VFLoss
+    crit = VFLoss(NS(depth_loss_clamp=0.5, norm_smaller_than_one_start=11000, directional_derivatives_start=100),
+                  NS(rgb=2.0, depth=0.5, unit_norm=0.1, supervision=1.0, norm_smaller_than_one=0.1, directional_derivatives=0.0))
+    g = torch.Generator().manual_seed(3)
+    pts = torch.rand(7, 20, 3, generator=g) * 0.6 + torch.tensor([-0.3, -0.3, 0.25])
+    centroid, radius = torch.tensor([0.0, 0.0, 0.55]), 0.15
+    extra, extra_gt = torch.randn(11, 3, generator=g), torch.randn(11, 3, generator=g)
+    common = {"rgb": torch.rand(7, 3, generator=g), "depth": torch.rand(7, 1, generator=g), "directional_derivatives": None}
+    gt_common = {"rgb": torch.rand(7, 3, generator=g), "depth": torch.rand(7, 1, generator=g)}
+    results = []
+    for dense in (False, True):
+        normals = torch.randn(7, 20, 3, generator=torch.Generator().manual_seed(9)).requires_grad_(True)
+        if dense:
+            rc_n, rc_gt, n_sel = supervision.center_rows_dense(pts, normals, centroid, radius)
+            pred = dict(common, normals=normals.reshape(-1, 3), supervised_normals=torch.cat([extra, rc_n]), supervised_rows=n_sel + 11.0)
+        else:
+            rc_n, rc_gt = supervision.get_center_indices_and_gt(pts, normals, centroid, radius)
+            assert 0 < rc_n.shape[0] < 140
+            pred = dict(common, normals=normals.reshape(-1, 3), supervised_normals=torch.cat([extra, rc_n]))
+        loss, terms = crit(pred, dict(gt_common, supervised_normals=torch.cat([extra_gt, rc_gt])), 0)
+        loss.backward()
+        results.append((float(loss), terms["supervision_loss"], normals.grad.clone()))
+    (la, sa, ga), (lb, sb, gb) = results
+    assert abs(la - lb) < 1e-6 and abs(sa - sb) < 1e-6 and float((ga - gb).abs().max()) < 1e-7

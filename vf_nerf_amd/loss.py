@@ -22,12 +22,23 @@ class _LazyTerms(dict):
     """{name: float} whose values arrive from the device on first read.  Keys, length and iteration order are available at
     once; every way of reading a value (indexing, get, values, items, pop, copy, repr, comparison) waits for the copy first."""
 
+    _ring = []            # pinned host buffers, reused round-robin (a fresh pinned allocation per step costs more than the step's loss)
+    _next = 0
+
+    @classmethod
+    def _host(cls, n: int, dtype) -> torch.Tensor:
+        if len(cls._ring) < 64:
+            cls._ring.append(torch.empty(16, dtype=torch.float32, pin_memory=True))
+        buf = cls._ring[cls._next % len(cls._ring)]
+        cls._next += 1
+        return buf[:n]
+
     def __init__(self, names, stacked: torch.Tensor) -> None:
         super().__init__((n, None) for n in names)
         self._pending = None
         if stacked.is_cuda:
-            host = torch.empty(stacked.shape, dtype=stacked.dtype, pin_memory=True)
-            host.copy_(stacked, non_blocking=True)
+            host = self._host(stacked.numel(), stacked.dtype)          # (64 steps may pass before a slot is reused)
+            host.copy_(stacked.float(), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(stacked.device))
             self._pending = (host, ev, tuple(names))
@@ -102,7 +113,13 @@ class VFLoss(nn.Module):
         unit_norm_loss = ((norms - 1) ** 2).mean()
         supervision_loss = zero
         if pred["supervised_normals"].nelement() > 0:
-            supervision_loss = ((pred["supervised_normals"] - gt["supervised_normals"]) ** 2).mean()
+            rows = pred.get("supervised_rows")
+            if rows is None:
+                supervision_loss = ((pred["supervised_normals"] - gt["supervised_normals"]) ** 2).mean()
+            else:
+                # extension (trainer.TrainStep): some rows are placeholders with prediction = ground truth = 0; the mean runs over
+                # the `rows` real ones (a device scalar), so no row count has to travel to the host
+                supervision_loss = ((pred["supervised_normals"] - gt["supervised_normals"]) ** 2).sum() / (3.0 * rows)
         smaller_loss = zero
         if epoch >= self.config.norm_smaller_than_one_start:
             smaller_loss = (torch.relu(norms - 1) ** 2).mean()

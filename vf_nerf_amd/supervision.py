@@ -75,3 +75,16 @@ def get_center_indices_and_gt(points: torch.Tensor, normals: torch.Tensor, centr
     (functions.py:137-157)."""
     keep = torch.linalg.vector_norm(points - centroid, dim=2) < radius
     return normals.reshape(points.shape)[keep], F.normalize(points[keep] - centroid, dim=1)
+
+
+def center_rows_dense(points: torch.Tensor, normals: torch.Tensor, centroid: torch.Tensor, radius: float):
+    """``get_center_indices_and_gt`` without the compaction: every ray sample keeps its row, rows outside the centre ball are
+    ZERO in both the prediction and the ground truth (they add nothing to a sum of squared differences and receive no gradient),
+    and the number of selected rows comes back as a device scalar -> (normals[N*S,3] masked, gt[N*S,3] masked, count).  No
+    boolean-mask indexing, hence no host synchronisation (trainer.TrainStep uses it with VFLoss's ``supervised_rows``)."""
+    diff = points - centroid
+    keep = (torch.linalg.vector_norm(diff, dim=2) < radius).unsqueeze(-1)
+    gt = F.normalize(diff, dim=2)
+    zero = torch.zeros((), device=points.device, dtype=normals.dtype)
+    return (torch.where(keep, normals.reshape(points.shape), zero).reshape(-1, 3), torch.where(keep, gt, zero).reshape(-1, 3),
+            keep.sum().to(normals.dtype))

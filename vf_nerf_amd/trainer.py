@@ -36,7 +36,8 @@ SHIPPED_LOSS_WEIGHTS = dict(rgb=2.0, depth=0.5, unit_norm=0.1, supervision=1.0, 
 
 
 class TrainStep:
-    def __init__(self, model, centroid, border_radius: float = 0.15, far: Optional[float] = None, criterion=None, bucket=None) -> None:
+    def __init__(self, model, centroid, border_radius: float = 0.15, far: Optional[float] = None, criterion=None, bucket=None,
+                 compact_selection: bool = False) -> None:
         self.model = model
         dev = model.config.cuda_config.device
         self.centroid = torch.as_tensor(centroid, dtype=torch.float32, device=dev)
@@ -44,6 +45,12 @@ class TrainStep:
         self.far = float(model.ray_sampler.far if far is None else far)
         self.criterion = criterion or vloss.VFLoss(SimpleNamespace(**SHIPPED_LOSS_CONFIG), SimpleNamespace(**SHIPPED_LOSS_WEIGHTS))
         self.bucket = bucket                       # distributed.GradientBucket or None
+        # The ray samples inside the centre ball are a data-dependent subset (functions.py:137-157: boolean-mask indexing, i.e. a
+        # device synchronisation in the middle of the step while the host learns the row count).  False (default): the same loss
+        # term without compaction — unselected rows enter with prediction = ground truth = 0 and the mean's denominator is the
+        # selected-row count kept on the device (``supervised_rows``, an extension of this package's VFLoss): no synchronisation,
+        # the same value and gradients up to the order of the sum.  True: the reference's compaction, sync included.
+        self.compact_selection = bool(compact_selection)
         self.last_total_norm = None
         self.last_outputs = None
 
@@ -54,12 +61,17 @@ class TrainStep:
         outputs = model.render(pose, pixels, intrinsics, epoch, white, uniforms=uniforms)
         n_sup = (outputs.points_coarse.shape[0] * outputs.points_coarse.shape[1]) // 10
         sup, sup_gt = [], []
+        rows = None                                # number of supervised rows as a device scalar (dense selection only)
         if cfg.border_supervision:
             bp, b_gt = supervision.sample_border_points(self.far - 5 * self.radius, self.far, n_sup, self.centroid, dev)
             sup.append(model.vector_field_network(bp)[:, :3])
             sup_gt.append(b_gt)
         if cfg.center_supervision:
-            rc_n, rc_gt = supervision.get_center_indices_and_gt(outputs.points_coarse, outputs.coarse_normals, self.centroid, self.radius)
+            if self.compact_selection:
+                rc_n, rc_gt = supervision.get_center_indices_and_gt(outputs.points_coarse, outputs.coarse_normals, self.centroid, self.radius)
+            else:
+                rc_n, rc_gt, n_sel = supervision.center_rows_dense(outputs.points_coarse, outputs.coarse_normals, self.centroid, self.radius)
+                rows = n_sel + float((n_sup if cfg.border_supervision else 0) + n_sup)
             cp, c_gt = supervision.sample_center_points(self.centroid, self.radius, n_sup, dev)
             sup += [rc_n, model.vector_field_network(cp)[:, :3]]
             sup_gt += [rc_gt, c_gt]
@@ -67,6 +79,8 @@ class TrainStep:
                        "normals": outputs.coarse_normals.reshape(-1, 3),
                        "supervised_normals": torch.cat(sup, dim=0) if sup else torch.empty(0, 3, device=dev),
                        "directional_derivatives": outputs.directional_derivtives}
+        if rows is not None:
+            predictions["supervised_rows"] = rows
         ground_truth = {"rgb": rgb_gt.reshape(-1, 3), "depth": depth_gt,
                         "supervised_normals": torch.cat(sup_gt, dim=0) if sup_gt else torch.empty(0, device=dev)}
         loss, terms = self.criterion(predictions, ground_truth, epoch)
