@@ -265,7 +265,7 @@ def view_bench(args, dev):
     rgb, depth = o.coarse_rgb_values.cpu(), o.coarse_depth_map.cpu()
     rgb32, depth32 = o32.coarse_rgb_values.cpu(), o32.coarse_depth_map.cpu()
     r64_rgb, r64_dep, r64_z = ref64["rgb"], ref64["depth"], ref64["z_vals"]
-    emit(({
+    emit_line(({
         "metric": "rays/sec (full 1200x680 view, 1024-ray chunks, 128 samples/ray) + PSNR/depth vs ref",
         "value": round(n * args.steps / elapsed, 1), "unit": "rays/s", "n_gpus": 1, "steps": args.steps,
         "warmup": max(1, args.warmup // 3), "ms_per_step": round(elapsed / args.steps * 1e3, 2),
@@ -327,7 +327,7 @@ def grid_bench(args, dev, rank, world, dist, sync):
         idx = idx[(idx // 100000) % world == 0]                      # rows this rank evaluated
         ref = O.vf_mlp(samples[idx], vf_sd, 6, (4,))[:, :3]
         err = float((got[idx] - ref).abs().max())
-        emit(({
+        emit_line(({
             "metric": "grid points/sec (vector-field queries for quadrant marching cubes)",
             "value": round(n * args.steps / elapsed, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps,
             "warmup": max(1, args.warmup // 3), "ms_per_step": round(elapsed / args.steps * 1e3, 2),
@@ -421,7 +421,7 @@ def grid_stages_bench(args, dev):
         del pred, div
         torch.cuda.empty_cache()
     best_div = out[f"res_{args.grid_res}"]["divergence"]
-    emit(({"metric": "dense-grid stage throughput (algorithmic HBM bytes / launch time)", "value": best_div["tb_per_s"], "unit": "TB/s",
+    emit_line(({"metric": "dense-grid stage throughput (algorithmic HBM bytes / launch time)", "value": best_div["tb_per_s"], "unit": "TB/s",
                       "n_gpus": 1, "steps": reps, "warmup": 1, "ms_per_step": best_div["ms"], "higher_is_better": True, "scaling": "weak",
                       "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                       "config": {"workload": f"extract_divergence / smooth_vf at {args.grid_res}^3, unify_direction / make_comb_format at "
@@ -545,7 +545,7 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
     if not emit:
         return rec
     if rank == 0:
-        emit((rec))
+        emit_line((rec))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -566,7 +566,7 @@ def claim_stdout() -> None:
         os.dup2(2, 1)
 
 
-def emit(rec) -> None:
+def emit_line(rec) -> None:
     data = (json.dumps(rec) + "\n").encode()
     if _REAL_STDOUT is None:
         sys.stdout.write(data.decode())
@@ -659,7 +659,7 @@ def dry_run(args, rank: int, world: int, dist) -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        emit(({"metric": "rays/sec (4096-ray chunk, 128 samples/ray) + PSNR vs ref", "value": round(args.rays * args.steps * world / elapsed, 1),
+        emit_line(({"metric": "rays/sec (4096-ray chunk, 128 samples/ray) + PSNR vs ref", "value": round(args.rays * args.steps * world / elapsed, 1),
                           "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "none", "data": "synthetic", "dry_run": True, "backend": args.backend, "per_rank_rays_per_s": rates,
@@ -963,7 +963,7 @@ def main() -> None:
                                                        "algorithmic_tflop_per_step", "achieved_tflops", "frac_of_f16_mfma_div3",
                                                        "workspace_gb_per_step", "workspace_tb_per_s", "frac_of_hbm_peak", "final_loss")}
             line["train"]["workload"] = train_rec["config"]["workload"]
-        emit((line))
+        emit_line((line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -34,7 +34,8 @@ typedef enum vfn_status {
 const char* vfn_last_error(void);
 int vfn_abi_version(void);
 /* sizeof() of the POD structs of this header as the library was compiled, by index: 0 vfn_net_geom, 1 vfn_layer_params,
- * 2 vfn_raygen_params, 3 vfn_density_params, 4 vfn_fine_params, 5 vfn_render_params, 6 vfn_unfold_entry, 7 vfn_wgrad_layer;
+ * 2 vfn_raygen_params, 3 vfn_density_params, 4 vfn_fine_params, 5 vfn_render_params, 6 vfn_unfold_entry, 7 vfn_wgrad_layer,
+ * 8 vfn_loss_params;
  * -1 for any other index.  A binding checks its own mirrors of the structs against these (tests/test_host_logic.py). */
 int32_t vfn_abi_struct_bytes(int32_t which);
 
@@ -506,6 +507,36 @@ int vfn_net_weight_grads_frag(int32_t net_kind, const vfn_net_geom* geom, const 
                               const void* dy, int64_t slot_bytes, int32_t dy_form, int32_t x_form, const float* feats,
                               const float* aux, const float* dz_head, int64_t n_points, int32_t with_features,
                               int32_t accumulate, void* scratch, void* stream);
+
+/* VFLoss (models/losses/vf_loss.py:34-87) and the trainer's centre-ball selection (models/helpers/functions.py:137-157,
+ * train/vector_field_nerf_train.py:203-214) fused (csrc/vfn_loss.hip): vfn_vf_loss_fwd = one reduction launch + a one-workgroup finish
+ * -> out_terms[8] = {rgb, depth, unit_norm, supervision, norm_smaller_than_one, 0 (the directional-derivative term stays with the
+ * caller), weighted total of the five, supervision rows}; vfn_vf_loss_bwd = one elementwise launch writing d total / d inputs times
+ * the device scalar grad_out (NULL: 1).  rgb[N,3], depth[N] (has_depth), normals[M,3]; up to three supervision segments
+ * sup_pred[k][n_sup[k],3] / sup_gt[k] (host arrays of three device pointers); ray_center != 0: the rows of `normals` whose point
+ * (`points`[M,3]) lies within `radius` of `centroid` form a fourth segment with ground truth normalize(point - centroid) — selected
+ * and counted on the device, no compaction, no host synchronisation.  `workspace`: vfn_vf_loss_workspace_bytes() bytes, written by
+ * the forward call and read by the backward call (the supervision mean's data-dependent denominator lives there). */
+typedef struct vfn_loss_params {
+    int64_t n_rays, n_normals;
+    int64_t n_sup[3];
+    int32_t has_depth;       /* 0: no depth term (the batch has no depth ground truth) */
+    int32_t smaller_on;      /* epoch >= norm_smaller_than_one_start */
+    int32_t ray_center;
+    int32_t reserved;
+    float w_rgb, w_depth, w_unit, w_sup, w_smaller;
+    float depth_clamp;
+    float radius;
+    float centroid[3];
+} vfn_loss_params;
+int64_t vfn_vf_loss_workspace_bytes(void);
+int vfn_vf_loss_fwd(const vfn_loss_params* p, const float* rgb, const float* rgb_gt, const float* depth, const float* depth_gt,
+                    const float* normals, const float* points, const float* const* sup_pred, const float* const* sup_gt,
+                    void* workspace, float* out_terms, void* stream);
+int vfn_vf_loss_bwd(const vfn_loss_params* p, const float* rgb, const float* rgb_gt, const float* depth, const float* depth_gt,
+                    const float* normals, const float* points, const float* const* sup_pred, const float* const* sup_gt,
+                    const void* workspace, const float* grad_out, float* d_rgb, float* d_depth, float* d_normals,
+                    float* const* d_sup, void* stream);
 
 /* Supervision points of the trainer (train/vector_field_nerf_train.py:186-214): n uniform samples in the spherical
  * shell r_min <= |p - centroid| <= r_max (models/samplers/sampler.py:160-193) and their radial unit ground truth

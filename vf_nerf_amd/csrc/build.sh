@@ -9,7 +9,7 @@ OUT=${VFN_OUT:-libvfn.so}
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=${ARCH} -Wall -Wno-unused-function"
 # vfn_mlp16 / vfn_bwd16: accumulators in arch VGPRs (all AGPRs hold activations), full unrolling of the K loops
 MFMA16="-mllvm -amdgpu-mfma-vgpr-form -mllvm -pragma-unroll-threshold=10000000"
-UNITS="vfn_pack vfn_mlp vfn_mlp_bwd vfn_dw16 vfn_dwf vfn_unfold vfn_bwd16 vfn_mlp16 vfn_rays vfn_grid vfn_bstat vfn_adam vfn_render vfn_wgrad"
+UNITS="vfn_pack vfn_mlp vfn_mlp_bwd vfn_dw16 vfn_dwf vfn_unfold vfn_bwd16 vfn_mlp16 vfn_rays vfn_grid vfn_bstat vfn_adam vfn_render vfn_wgrad vfn_loss"
 
 extra_flags() {
   case "$1" in

@@ -35,6 +35,7 @@ extern "C" int32_t vfn_abi_struct_bytes(int32_t which) {
     case 5: return (int32_t)sizeof(vfn_render_params);
     case 6: return (int32_t)sizeof(vfn_unfold_entry);
     case 7: return (int32_t)sizeof(vfn_wgrad_layer);
+    case 8: return (int32_t)sizeof(vfn_loss_params);
     default: return -1;
     }
 }

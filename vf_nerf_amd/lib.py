@@ -34,6 +34,7 @@ EXPORTS = (
     "vfn_vf_mlp16_fwd_train_at", "vfn_mlp_bwd_chain_bf16_ws_at",
     "vfn_weight_grad_groups", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax", "vfn_merge_sort_depths",
     "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step", "vfn_unfold_weight_grads_acc", "vfn_render_fwd", "vfn_render_fwd_workspace_bytes",
+    "vfn_vf_loss_workspace_bytes", "vfn_vf_loss_fwd", "vfn_vf_loss_bwd",
 )
 
 
@@ -77,6 +78,13 @@ class RenderParams(C.Structure):
                 ("far_coarse", C.c_float), ("far_fine", C.c_float), ("fine_range", C.c_float), ("window_step", C.c_float), ("span", C.c_float),
                 ("density", DensityParams), ("seed", C.c_uint64), ("offset", C.c_uint64), ("colour_products", C.c_int32), ("separate_launches", C.c_int32), ("streams", C.c_int32), ("reserved", C.c_int32),
                 ("timing_events", C.c_void_p * 4)]
+
+
+class LossParams(C.Structure):
+    """mirrors vfn_loss_params"""
+    _fields_ = [("n_rays", C.c_int64), ("n_normals", C.c_int64), ("n_sup", C.c_int64 * 3), ("has_depth", C.c_int32), ("smaller_on", C.c_int32),
+                ("ray_center", C.c_int32), ("reserved", C.c_int32), ("w_rgb", C.c_float), ("w_depth", C.c_float), ("w_unit", C.c_float),
+                ("w_sup", C.c_float), ("w_smaller", C.c_float), ("depth_clamp", C.c_float), ("radius", C.c_float), ("centroid", C.c_float * 3)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -187,7 +195,7 @@ def _declare(lib: C.CDLL) -> None:
 
 def struct_mirrors():
     """The ctypes mirrors of the header's POD structs in the order of ``vfn_abi_struct_bytes``."""
-    return (NetGeom, LayerParams, RaygenParams, DensityParams, FineParams, RenderParams, UnfoldEntry, WgradLayer)
+    return (NetGeom, LayerParams, RaygenParams, DensityParams, FineParams, RenderParams, UnfoldEntry, WgradLayer, LossParams)
 
 
 def load() -> C.CDLL:
@@ -311,6 +319,35 @@ def uniform_sample(directions, cam_loc, t_vals, n_samples: int, near: float, far
                                      _ptr(far_per_ray, "far_per_ray"), _ptr(u, "u"), _ptr(z, "z_vals"), _ptr(pts, "points"),
                                      _stream()), "vfn_uniform_sample")
     return z, pts
+
+
+def _ptr3(tensors, name: str):
+    arr = (C.c_void_p * 3)()
+    for k in range(3):
+        t = tensors[k] if k < len(tensors) else None
+        arr[k] = _ptr(t, f"{name}[{k}]").value if t is not None else None
+    return arr
+
+
+def vf_loss_workspace(dev) -> torch.Tensor:
+    return torch.empty(int(load().vfn_vf_loss_workspace_bytes()) // 4, device=dev)
+
+
+def vf_loss_fwd(lp: LossParams, rgb, rgb_gt, depth, depth_gt, normals, points, sup_pred, sup_gt, workspace) -> torch.Tensor:
+    """-> out[8] on the device: five terms, 0, weighted total, supervision rows (csrc/vfn_loss.hip)."""
+    out = torch.empty(8, device=workspace.device)
+    _check(load().vfn_vf_loss_fwd(C.byref(lp), _ptr(rgb, "rgb"), _ptr(rgb_gt, "rgb_gt"), _ptr(depth, "depth"), _ptr(depth_gt, "depth_gt"),
+                                  _ptr(normals, "normals"), _ptr(points, "points"), _ptr3(sup_pred, "sup_pred"), _ptr3(sup_gt, "sup_gt"),
+                                  _ptr(workspace, "workspace"), _ptr(out, "out_terms"), _stream()), "vfn_vf_loss_fwd")
+    return out
+
+
+def vf_loss_bwd(lp: LossParams, rgb, rgb_gt, depth, depth_gt, normals, points, sup_pred, sup_gt, workspace, grad_out, d_rgb, d_depth,
+                d_normals, d_sup) -> None:
+    _check(load().vfn_vf_loss_bwd(C.byref(lp), _ptr(rgb, "rgb"), _ptr(rgb_gt, "rgb_gt"), _ptr(depth, "depth"), _ptr(depth_gt, "depth_gt"),
+                                  _ptr(normals, "normals"), _ptr(points, "points"), _ptr3(sup_pred, "sup_pred"), _ptr3(sup_gt, "sup_gt"),
+                                  _ptr(workspace, "workspace"), _ptr(grad_out, "grad_out"), _ptr(d_rgb, "d_rgb"), _ptr(d_depth, "d_depth"),
+                                  _ptr(d_normals, "d_normals"), _ptr3(d_sup, "d_sup"), _stream()), "vfn_vf_loss_bwd")
 
 
 def merge_sort_depths(z: torch.Tensor, extra: torch.Tensor, directions=None, cam_loc=None):

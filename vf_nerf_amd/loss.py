@@ -58,6 +58,9 @@ class _LazyTerms(dict):
         self._fetch()
         return dict.__getitem__(self, k)
 
+    def __iter__(self):          # (an overridden __iter__ also keeps dict(terms) / {**terms} off CPython's raw-copy fast path)
+        return dict.__iter__(self)
+
     def get(self, k, default=None):
         self._fetch()
         return dict.get(self, k, default)
@@ -94,15 +97,98 @@ class _LazyTerms(dict):
         return (dict, (dict(dict.items(self)),))
 
 
+class _FusedLoss(torch.autograd.Function):
+    """The five tensor terms of VFLoss in csrc/vfn_loss.hip: forward = one reduction launch + a one-workgroup finish, backward = one
+    elementwise launch (instead of ~40 tensor-op launches over [N*S_t, 3] operands).  Inputs after the fixed ones: the supervision
+    segments as pred0, gt0, pred1, gt1, ... (at most three pairs)."""
+
+    @staticmethod
+    def forward(ctx, lp, rgb, rgb_gt, depth, depth_gt, normals, points, *segs):
+        from . import lib
+        ws = lib.vf_loss_workspace(rgb.device)
+        preds, gts = list(segs[0::2]), list(segs[1::2])
+        out = lib.vf_loss_fwd(lp, rgb, rgb_gt, depth, depth_gt, normals, points, preds, gts, ws)
+        ctx.lp, ctx.ws, ctx.n_seg = lp, ws, len(preds)
+        ctx.save_for_backward(rgb, rgb_gt, depth, depth_gt, normals, points, *segs)
+        ctx.mark_non_differentiable(out)
+        return out[6].clone(), out
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms):
+        from . import lib
+        rgb, rgb_gt, depth, depth_gt, normals, points, *segs = ctx.saved_tensors
+        preds, gts = list(segs[0::2]), list(segs[1::2])
+        need = ctx.needs_input_grad            # (lp, rgb, rgb_gt, depth, depth_gt, normals, points, pred0, gt0, ...)
+        d_rgb = torch.empty_like(rgb) if need[1] else None
+        d_depth = torch.empty_like(depth) if (need[3] and depth is not None) else None
+        d_normals = torch.empty_like(normals) if need[5] else None
+        d_sup = [torch.empty_like(p) if need[7 + 2 * k] else None for k, p in enumerate(preds)]
+        lib.vf_loss_bwd(ctx.lp, rgb, rgb_gt, depth, depth_gt, normals, points, preds, gts, ctx.ws, g_total.reshape(1).float().contiguous(),
+                        d_rgb, d_depth, d_normals, d_sup)
+        grads = [None, d_rgb, None, d_depth, None, d_normals, None]
+        for k in range(ctx.n_seg):
+            grads += [d_sup[k], None]
+        return tuple(grads)
+
+
 class VFLoss(nn.Module):
     def __init__(self, config, weights) -> None:
         super().__init__()
         self.config = config
         self.weights = weights
+        # device tensors: the terms come from the fused kernels of csrc/vfn_loss.hip (False: the tensor-op formulation below, which
+        # is also what CPU tensors get)
+        self.fused = True
+
+    def _fused_forward(self, pred, gt, epoch: int):
+        from . import lib
+        w, rgb = self.weights, pred["rgb"]
+
+        def f32(t):
+            return t.float().contiguous()
+
+        normals = f32(pred["normals"].reshape(-1, 3))
+        segments = pred.get("supervised_segments")
+        if segments is None:
+            segments = [(pred["supervised_normals"], gt["supervised_normals"])] if pred["supervised_normals"].nelement() > 0 else []
+        segments = [(f32(a.reshape(-1, 3)), f32(b.reshape(-1, 3))) for a, b in segments if a.nelement() > 0]
+        if len(segments) > 3:
+            segments = segments[:2] + [(torch.cat([a for a, _ in segments[2:]]), torch.cat([b for _, b in segments[2:]]))]
+        lp = lib.LossParams()
+        lp.n_rays, lp.n_normals = rgb.shape[0], normals.shape[0]
+        for k, (a, _) in enumerate(segments):
+            lp.n_sup[k] = a.shape[0]
+        has_depth = gt["depth"].nelement() > 0
+        lp.has_depth, lp.smaller_on = int(has_depth), int(epoch >= self.config.norm_smaller_than_one_start)
+        lp.w_rgb, lp.w_depth, lp.w_unit, lp.w_sup, lp.w_smaller = float(w.rgb), float(w.depth), float(w.unit_norm), float(w.supervision), \
+            float(w.norm_smaller_than_one)
+        lp.depth_clamp = float(self.config.depth_loss_clamp)
+        points = None
+        rc = pred.get("ray_center")                # (points[N,S,3] | [M,3], centroid as three Python floats, radius): trainer.TrainStep
+        if rc is not None:
+            points = f32(rc[0].reshape(-1, 3))
+            lp.ray_center, lp.radius = 1, float(rc[2])
+            for i in range(3):
+                lp.centroid[i] = float(rc[1][i])
+        flat = [t for pair in segments for t in pair]
+        total, out = _FusedLoss.apply(lp, f32(rgb.reshape(-1, 3)), f32(gt["rgb"].reshape(-1, 3)), f32(pred["depth"].reshape(-1)) if has_depth else None,
+                                      f32(gt["depth"].reshape(-1)) if has_depth else None, normals, points, *flat)
+        terms = out[:6]
+        dd = pred.get("directional_derivatives")
+        if dd is not None and epoch >= self.config.directional_derivatives_start:
+            dd_loss = dd.mean()
+            total = total + w.directional_derivatives * dd_loss
+            terms = terms.clone()
+            terms[5] = dd_loss.detach()
+        return total, _LazyTerms(_NAMES, terms)
 
     def forward(self, pred: Dict[str, torch.Tensor], gt: Dict[str, torch.Tensor], epoch: int
                 ) -> Tuple[torch.Tensor, Dict[str, float]]:
         rgb = pred["rgb"]
+        if self.fused and rgb.is_cuda and rgb.dtype == torch.float32 and pred["normals"].is_cuda:
+            return self._fused_forward(pred, gt, epoch)
+        if pred.get("supervised_segments") is not None or pred.get("ray_center") is not None:
+            raise ValueError("supervised_segments / ray_center are inputs of the fused device loss (CUDA tensors, VFLoss.fused = True)")
         zero = torch.zeros((), device=rgb.device, dtype=rgb.dtype)
         w = self.weights
         rgb_loss = (rgb - gt["rgb"]).abs().mean()

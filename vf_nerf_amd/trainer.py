@@ -41,6 +41,7 @@ class TrainStep:
         self.model = model
         dev = model.config.cuda_config.device
         self.centroid = torch.as_tensor(centroid, dtype=torch.float32, device=dev)
+        self.centroid_host = tuple(float(x) for x in (centroid.tolist() if isinstance(centroid, torch.Tensor) else centroid))
         self.radius = float(border_radius)
         self.far = float(model.ray_sampler.far if far is None else far)
         self.criterion = criterion or vloss.VFLoss(SimpleNamespace(**SHIPPED_LOSS_CONFIG), SimpleNamespace(**SHIPPED_LOSS_WEIGHTS))
@@ -60,29 +61,43 @@ class TrainStep:
         cfg = model.config
         outputs = model.render(pose, pixels, intrinsics, epoch, white, uniforms=uniforms)
         n_sup = (outputs.points_coarse.shape[0] * outputs.points_coarse.shape[1]) // 10
+        fused = bool(getattr(self.criterion, "fused", False)) and not self.compact_selection and outputs.coarse_normals.is_cuda
         sup, sup_gt = [], []
-        rows = None                                # number of supervised rows as a device scalar (dense selection only)
+        rows = None                                # number of supervised rows as a device scalar (dense selection without the fused loss)
+        ray_center = None
         if cfg.border_supervision:
             bp, b_gt = supervision.sample_border_points(self.far - 5 * self.radius, self.far, n_sup, self.centroid, dev)
             sup.append(model.vector_field_network(bp)[:, :3])
             sup_gt.append(b_gt)
         if cfg.center_supervision:
-            if self.compact_selection:
+            if fused:          # selected, counted and differentiated inside the loss kernels (csrc/vfn_loss.hip): nothing to build here
+                ray_center = (outputs.points_coarse, self.centroid_host, self.radius)
+            elif self.compact_selection:
                 rc_n, rc_gt = supervision.get_center_indices_and_gt(outputs.points_coarse, outputs.coarse_normals, self.centroid, self.radius)
+                sup.append(rc_n)
+                sup_gt.append(rc_gt)
             else:
                 rc_n, rc_gt, n_sel = supervision.center_rows_dense(outputs.points_coarse, outputs.coarse_normals, self.centroid, self.radius)
                 rows = n_sel + float((n_sup if cfg.border_supervision else 0) + n_sup)
+                sup.append(rc_n)
+                sup_gt.append(rc_gt)
             cp, c_gt = supervision.sample_center_points(self.centroid, self.radius, n_sup, dev)
-            sup += [rc_n, model.vector_field_network(cp)[:, :3]]
-            sup_gt += [rc_gt, c_gt]
+            sup.append(model.vector_field_network(cp)[:, :3])
+            sup_gt.append(c_gt)
         predictions = {"rgb": outputs.coarse_rgb_values, "depth": outputs.coarse_depth_map,
                        "normals": outputs.coarse_normals.reshape(-1, 3),
-                       "supervised_normals": torch.cat(sup, dim=0) if sup else torch.empty(0, 3, device=dev),
                        "directional_derivatives": outputs.directional_derivtives}
-        if rows is not None:
-            predictions["supervised_rows"] = rows
-        ground_truth = {"rgb": rgb_gt.reshape(-1, 3), "depth": depth_gt,
-                        "supervised_normals": torch.cat(sup_gt, dim=0) if sup_gt else torch.empty(0, device=dev)}
+        ground_truth = {"rgb": rgb_gt.reshape(-1, 3), "depth": depth_gt}
+        if fused:
+            predictions["supervised_segments"] = list(zip(sup, sup_gt))
+            predictions["supervised_normals"] = ground_truth["supervised_normals"] = torch.empty(0, 3, device=dev)
+            if ray_center is not None:
+                predictions["ray_center"] = ray_center
+        else:
+            predictions["supervised_normals"] = torch.cat(sup, dim=0) if sup else torch.empty(0, 3, device=dev)
+            ground_truth["supervised_normals"] = torch.cat(sup_gt, dim=0) if sup_gt else torch.empty(0, device=dev)
+            if rows is not None:
+                predictions["supervised_rows"] = rows
         loss, terms = self.criterion(predictions, ground_truth, epoch)
         if self.bucket is not None:
             self.bucket.zero()
