@@ -51,6 +51,16 @@ def test_render_gradients(name, precision):
     assert (out.z_vals.cpu() == d["z_vals"]).all(), "sampling must replay exactly for the comparison to be meaningful"
     ref_loss, ref = oracle_gradients(fx, d, build_model(fx, d))
     assert abs(loss - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss))
+    # An assertion that does NOT depend on this implementation's ReLU masks: the whole parameter gradient against the oracle's own
+    # (unpinned) autograd, per network, as a direction and a length.  Looser than the per-tensor bounds below — a unit on the other
+    # side of zero moves a layer's gradient by percents on these small fixtures — but independent of anything the kernels report.
+    for tag, net in (("vf", model.vector_field_network), ("rn", model.rendering_network)):
+        a = torch.cat([p.grad.detach().reshape(-1).double().cpu() for _, p in net.named_parameters()])
+        b = torch.cat([ref[f"{tag}.{k}"].reshape(-1).double() for k, _ in net.named_parameters()])
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        print(f"{name}/{precision}: {tag} gradient vs the oracle's unpinned autograd: cosine {cos:.6f}, length ratio {float(a.norm() / b.norm()):.5f}")
+        # observed over the eight fixtures: cosine >= 0.99997 (0.9998 with the opt-in two-product forward), length within 6e-4
+        assert cos > (0.9995 if "c2" in opts or "bf16dy" in opts else 0.9999) and abs(float(a.norm() / b.norm()) - 1.0) < 3e-3, (tag, cos)
     # ReLU kinks: two fp32-accurate implementations can disagree on the sign of a pre-activation that is ~1e-7 from
     # zero, which legitimately changes the gradient of everything below (one unit of a 64-ray fixture moves a layer's
     # gradient by percents).  Count such flips from the saved activations; when there are any, the tight comparison is
@@ -70,7 +80,9 @@ def test_render_gradients(name, precision):
         masks.append(open_units[slot][:, :w])
         flips += int((masks[-1] != (act > 0)).sum())
     print(f"{name}/{precision}: ReLU sign flips between HIP and CPU activations: {flips}")
-    assert flips <= (max(4, d["z_vals"].numel() // 1000) if "c2" not in opts else 4000)      # (an 11-bit forward in the colour branch moves more units across zero: the oracle re-runs with these masks)
+    # (an 11-bit forward in the colour branch moves more units across zero — measured 0.013 .. 0.078 flips per point over the eight
+    # fixtures, i.e. one in ~15 000 of the colour branch's units — the oracle re-runs with these masks)
+    assert flips <= (max(4, d["z_vals"].numel() // 1000) if "c2" not in opts else max(8, d["z_vals"].numel() // 10))
     if flips:
         ref_loss, ref = oracle_gradients(fx, d, build_model(fx, d), masks=masks)
         assert abs(loss - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss))
