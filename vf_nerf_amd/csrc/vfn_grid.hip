@@ -3,8 +3,8 @@
 // evaluation/utils/guassian_smoothing.py:81-97 (smooth_vf).  The reference runs them as conv3d / gather chains on CPU
 // tensors of res^3 x 3 floats; here each is an HBM-bound kernel whose every grid value crosses HBM ONCE and whose every
 // store instruction writes whole consecutive lines:
-//   divergence   a workgroup owns an 8 x 64 footprint of cells in (j, k) and marches along i; the normalised field of the
-//                next plane is staged in LDS (each vector read and normalised once per workgroup, not eight times), the
+//   divergence   a workgroup owns an 8 x 64 footprint of cells in (j, k) and marches along i; the corner terms of the
+//                next plane are staged in LDS (each vector read, normalised and evaluated once per workgroup, not eight times), the
 //                mask leaves as 256 contiguous bytes per wave.  Algorithmic 16 B / cell (12 in, 4 out).
 //   smoothing    axes 0 and 1: the filter runs along a strided axis, so every FLOAT of the interleaved [.., 3] layout is
 //                independent — a lane owns four consecutive floats and marches along the axis with the k taps in registers
@@ -40,14 +40,22 @@ constexpr int DV_TJ = 8, DV_TK = 64;                         // cells of the foo
 constexpr int DV_PLANE = (DV_TJ + 1) * (DV_TK + 1);          // 585 vectors
 constexpr int DV_PER_THREAD = (DV_PLANE + 255) / 256;        // 3
 
+// What a vector contributes to a cell depends on which corner of the cell it is: corner (a, b, cc) takes
+//   x = n0 (a ? +1 : -1) / sqrt(3) + n1 (b ? +1 : -1) / sqrt(3) + n2 (cc ? +1 : -1) / sqrt(3),   term = x |x| face_area,
+// and a vector is corner (a, b, cc) of exactly one cell.  Negating all three signs negates x exactly (IEEE products and sums are
+// symmetric), hence the term: the four patterns with a = 0, T[b][cc], are computed ONCE per vector when its plane is staged, and
+// corner (1, b, cc) reads -T[1 - b][1 - cc].  A cell is then eight LDS reads and eight additions — in the same order and with the
+// same values as the eight full evaluations it replaces, so the mask is bit for bit the one of the per-cell formulation.
 __global__ __launch_bounds__(256) void vfn_grid_divergence_kernel(const float* __restrict__ vt, float* __restrict__ out, int N, float threshold,
                                                                   int seg_len) {
-    __shared__ float u[3][DV_PLANE * 3];                     // normalised vectors of three consecutive planes (21 KB)
+    __shared__ float T[3][DV_PLANE * 4];                     // the four a = 0 terms of every vector of three consecutive planes (28 KB)
     const int tid = threadIdx.x;
     const int k0 = blockIdx.x * DV_TK, j0 = blockIdx.y * DV_TJ;
     const int i0 = blockIdx.z * seg_len, i1 = min(N, i0 + seg_len);
     if (i0 >= i1) return;
     const long long NN = (long long)N * N;
+    const float inv3 = 1.0f / sqrtf(3.0f);
+    const float face_area = (float)(1.7320508075688772 / 4.0), shape_volume = (float)(1.4142135623730951 / 3.0);
 
     float r[DV_PER_THREAD][3];
     auto fetch = [&](int i) {                                // this thread's vectors of plane i -> registers (zeros outside the grid)
@@ -61,18 +69,25 @@ __global__ __launch_bounds__(256) void vfn_grid_divergence_kernel(const float* _
             } else { r[s][0] = r[s][1] = r[s][2] = 0.f; }
         }
     };
-    auto stash = [&](int b) {                                // normalise (F.normalize: v / max(|v|, 1e-12)) and store
+    auto stash = [&](int buf) {                              // normalise (F.normalize: v / max(|v|, 1e-12)), evaluate the four terms, store
 #pragma unroll
         for (int s = 0; s < DV_PER_THREAD; ++s) {
             const int v = tid + 256 * s;
             if (v < DV_PLANE) {
                 const float nrm = fmaxf(sqrtf(r[s][0] * r[s][0] + r[s][1] * r[s][1] + r[s][2] * r[s][2]), 1e-12f);
-                u[b][v * 3] = r[s][0] / nrm; u[b][v * 3 + 1] = r[s][1] / nrm; u[b][v * 3 + 2] = r[s][2] / nrm;
+                const float n0 = r[s][0] / nrm, n1 = r[s][1] / nrm, n2 = r[s][2] / nrm;
+                float4 t;
+                float* tp = &t.x;
+#pragma unroll
+                for (int bc = 0; bc < 4; ++bc) {
+                    const int b = bc >> 1, cc = bc & 1;
+                    const float x = n0 * (-inv3) + n1 * (b ? inv3 : -inv3) + n2 * (cc ? inv3 : -inv3);
+                    tp[bc] = x * fabsf(x) * face_area;
+                }
+                *reinterpret_cast<float4*>(&T[buf][v * 4]) = t;
             }
         }
     };
-    const float inv3 = 1.0f / sqrtf(3.0f);
-    const float face_area = (float)(1.7320508075688772 / 4.0), shape_volume = (float)(1.4142135623730951 / 3.0);
     const int kk = tid & 63, jj = tid >> 6;                  // this thread's two cells of a plane: (jj, kk) and (jj + 4, kk)
 
     fetch(i0);
@@ -96,9 +111,8 @@ __global__ __launch_bounds__(256) void vfn_grid_divergence_kernel(const float* _
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const int a = c >> 2, b = (c >> 1) & 1, cc = c & 1;
-                    const float* p = &u[a ? b1 : b0][((cj + b) * (DV_TK + 1) + kk + cc) * 3];
-                    const float x = p[0] * (a ? inv3 : -inv3) + p[1] * (b ? inv3 : -inv3) + p[2] * (cc ? inv3 : -inv3);
-                    s += x * fabsf(x) * face_area;
+                    const int vec = (cj + b) * (DV_TK + 1) + kk + cc;
+                    s += a ? -T[b1][vec * 4 + 2 * (1 - b) + (1 - cc)] : T[b0][vec * 4 + 2 * b + cc];
                 }
                 res = s / shape_volume;
             }
@@ -387,8 +401,9 @@ extern "C" int vfn_grid_divergence(const float* vt, int32_t n, float threshold, 
     VFN_REQUIRE(vt && out, "vfn_grid_divergence: NULL argument");
     VFN_REQUIRE(n <= 1024, "vfn_grid_divergence: resolution %d > 1024", n);
     const int bx = (n + DV_TK - 1) / DV_TK, by = (n + DV_TJ - 1) / DV_TJ;
-    // planes per workgroup: whole columns when the footprints alone fill the chip, else segments of >= 16 planes (one extra plane each)
-    int segs = (2048 + bx * by - 1) / (bx * by);
+    // planes per workgroup: segments of >= 16 planes (one extra plane each) until there are ~8 192 workgroups — five fit on a CU
+    // (28 KB of LDS each), and 2 048 of them would be 1.6 rounds of the chip, i.e. a fifth of it idle in the second
+    int segs = (8192 + bx * by - 1) / (bx * by);
     segs = segs < 1 ? 1 : (segs > (n + 15) / 16 ? (n + 15) / 16 : segs);
     const int seg_len = (n + segs - 1) / segs;
     hipLaunchKernelGGL(vfn_grid_divergence_kernel, dim3(bx, by, (n + seg_len - 1) / seg_len), dim3(256), 0, (hipStream_t)stream, vt, out, n, threshold,
