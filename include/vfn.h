@@ -465,6 +465,8 @@ typedef struct {
     int32_t rows, row_off, in_dim, slab_rows;
     int32_t act_c0, act_nc, aux_c0, aux_nc;
     float scale;
+    int32_t groups_act, groups_aux, groups_db;   /* slabs of dw_act / dw_aux / db of THIS entry; 0: the call's `groups` (products batched
+                                                  * into one launch, csrc/vfn_wgrad.hip, have fewer slabs than single ones) */
 } vfn_unfold_entry;
 int vfn_unfold_weight_grads(const vfn_unfold_entry* entries, int32_t n_entries, int32_t groups, void* stream);
 /* The same with bit i of accumulate_mask saying that entry i ADDS its result to what g_w / g_b / g_bn_w / g_bn_b already hold:

@@ -530,8 +530,10 @@ def test_weight_grad_frag_matches_float64(m, groups):
 def test_one_call_weight_gradients_equal_the_launch_by_launch_path(storage):
     """vfn_net_weight_grads_frag (csrc/vfn_wgrad.hip: every weight-gradient launch of a net and the un-fold issued from C out of
     one scratch buffer, results added into the parameters' .grad) against the facade's launch-by-launch sequence: the same
-    launches on the same data, so every gradient must agree to the last bit — through the fused fine pass (both nets), a
-    vector-only supervision forward (feature block skipped) and a full VF forward, accumulated into the same .grad tensors."""
+    products on the same data — since round 3 the C path issues the products of one shape as ONE launch with fewer, larger partial
+    slabs each, so the sums over points run in another order: every gradient within 1e-5 of the tensor's largest entry (observed
+    ~1e-6) — through the fused fine pass (both nets), a vector-only supervision forward (feature block skipped) and a full VF
+    forward, accumulated into the same .grad tensors."""
     fx, d = load_fixture("shipped_sizes")
     g = {k: v.to("cuda:0") for k, v in d.items() if isinstance(v, torch.Tensor)}
     uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add") if k in g}
@@ -563,12 +565,16 @@ def test_one_call_weight_gradients_equal_the_launch_by_launch_path(storage):
                            for tag, mod in (("vf", model.vector_field_network), ("rn", model.rendering_network), ("density", model.density))
                            for n, p in mod.named_parameters() if p.grad is not None}
     assert grads[True].keys() == grads[False].keys() and len(grads[True]) > 40
+    worst = 0.0
     for name in grads[True]:
         x, y = grads[True][name], grads[False][name]
         if name.startswith("density."):                     # float atomics across workgroups (vfn_density_bwd_kernel): not bit-stable
             assert torch.allclose(x, y, rtol=1e-4, atol=1e-6), name
         else:
-            assert torch.equal(x, y), (name, float((x - y).abs().max()))
+            err = float((x - y).abs().max()) / max(float(y.abs().max()), 1e-30)
+            worst = max(worst, err)
+            assert err < 1e-5, (name, err)
+    print(f"{storage}: worst difference between the one-call and the launch-by-launch weight gradients {worst:.2e} of a tensor's largest entry")
 
 
 @pytest.mark.parametrize("name", ["c1_perturb", "odd_orbit", "shipped_sizes"])

@@ -36,3 +36,8 @@ int vfn_internal_density_fine(const vfn_density_params* dp, const float* normals
 int vfn_internal_composite_gather(const vfn_density_params* dp, float* normals, const float* ray_dirs, const float* z_vals,
                                   const float* density_scalars, float* colors, const int32_t* src, const float* normals_c,
                                   const float* colors_c, int64_t n_stored_c, float* weights, float* rgb, float* depth, void* stream);
+
+// csrc/vfn_dwf.hip, used by csrc/vfn_wgrad.hip: n (<= 8) weight-gradient products of one shape and operand form as ONE launch of
+// n x groups workgroups (vfn_weight_grad_frag is the n = 1 case)
+int vfn_internal_weight_grad_frag_batch(int32_t shape, int32_t dy_form, int32_t x_form, int32_t n, const void* const* dy, const void* const* x,
+                                        float* const* dw_part, float* const* db_part, int64_t n_points, int32_t groups, void* stream);

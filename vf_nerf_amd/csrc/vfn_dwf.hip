@@ -71,6 +71,11 @@ struct DwfArgs {
     float* db_part;       // [G][n_out] or NULL
     long long n_points;
 };
+// Several products of the SAME shape and operand forms in one launch (blockIdx.y picks the product, blockIdx.x its slab): a net's
+// 256 x 256 weight gradients need not be one launch of 256 slabs each — eight of them as ONE launch of 8 x 32 workgroups fill
+// the chip just the same and write an eighth of the partial slabs (64 MB per product and launch otherwise, read back by the un-fold).
+constexpr int DWF_BATCH = 8;
+struct DwfBatch { DwfArgs v[DWF_BATCH]; };
 
 typedef __attribute__((address_space(3))) s4 lds_s4;
 
@@ -106,7 +111,8 @@ __device__ __forceinline__ void split4h(const f32x4v v, uint2& hi, uint2& lo) {
 __device__ __forceinline__ int img_off(int row, int chunk) { return row * F_ROW + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
 template <int SHAPE, int XM, int DM>
-__global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfArgs a) {
+__global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
+    const DwfArgs a = batch.v[blockIdx.y];
     constexpr bool A_FRAG = DM != DY_DZ4;
     constexpr bool B_FRAG = XM == X_FRAG32 || XM == X_FRAG16;
     constexpr bool F16 = DM == DY_FRAGF16S;                     // tile-scaled f16 gradient: f16 matrix instruction, one common scale per slab
@@ -401,8 +407,8 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfArgs a) {
 }
 
 template <int SHAPE, int XM, int DM>
-int launch(const DwfArgs& a, int groups, hipStream_t s) {
-    hipLaunchKernelGGL((vfn_dwf_kernel<SHAPE, XM, DM>), dim3(groups), dim3(256), 0, s, a);
+int launch(const DwfBatch& a, int n, int groups, hipStream_t s) {
+    hipLaunchKernelGGL((vfn_dwf_kernel<SHAPE, XM, DM>), dim3(groups, n), dim3(256), 0, s, a);
     return vfn_check_launch("vfn_weight_grad_frag");
 }
 
@@ -410,37 +416,45 @@ int launch(const DwfArgs& a, int groups, hipStream_t s) {
 
 extern "C" int vfn_weight_grad_frag(int32_t shape, const void* dy, int32_t dy_form, const void* x, int32_t x_form, int64_t n_points,
                                     int32_t groups, float* dw_part, float* db_part, void* stream) {
-    VFN_REQUIRE(dy && x && dw_part, "vfn_weight_grad_frag: NULL argument");
+    return vfn_internal_weight_grad_frag_batch(shape, dy_form, x_form, 1, &dy, &x, &dw_part, &db_part, n_points, groups, stream);
+}
+
+int vfn_internal_weight_grad_frag_batch(int32_t shape, int32_t dy_form, int32_t x_form, int32_t n, const void* const* dy, const void* const* x,
+                                        float* const* dw_part, float* const* db_part, int64_t n_points, int32_t groups, void* stream) {
+    VFN_REQUIRE(n >= 1 && n <= DWF_BATCH && dy && x && dw_part && db_part, "vfn_weight_grad_frag: bad batch (n=%d)", n);
     VFN_REQUIRE(groups >= 1 && groups <= 4096, "vfn_weight_grad_frag: groups=%d", groups);
     VFN_REQUIRE(n_points >= 0 && n_points < (1ll << 20) * groups, "vfn_weight_grad_frag: slab larger than 1 GiB");
-    DwfArgs a = {};
-    a.dy = dy; a.x = x; a.dw_part = dw_part; a.db_part = db_part; a.n_points = n_points;
+    DwfBatch a = {};
+    for (int i = 0; i < n; ++i) {
+        VFN_REQUIRE(dy[i] && x[i] && dw_part[i], "vfn_weight_grad_frag: NULL argument");
+        a.v[i].dy = dy[i]; a.v[i].x = x[i]; a.v[i].dw_part = dw_part[i]; a.v[i].db_part = db_part[i]; a.v[i].n_points = n_points;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (shape == 0) {
         VFN_REQUIRE(dy_form == DY_FRAG32 || dy_form == DY_FRAGBF16 || dy_form == DY_FRAGF16S, "vfn_weight_grad_frag: shape 0 takes a fragment-ordered dY");
         if (dy_form == DY_FRAGF16S) {
-            if (x_form == X_FRAG32) return launch<0, X_FRAG32, DY_FRAGF16S>(a, groups, s);
-            if (x_form == X_FRAG16) return launch<0, X_FRAG16, DY_FRAGF16S>(a, groups, s);
-            if (x_form == X_ROWS32) return launch<0, X_ROWS32, DY_FRAGF16S>(a, groups, s);
+            if (x_form == X_FRAG32) return launch<0, X_FRAG32, DY_FRAGF16S>(a, n, groups, s);
+            if (x_form == X_FRAG16) return launch<0, X_FRAG16, DY_FRAGF16S>(a, n, groups, s);
+            if (x_form == X_ROWS32) return launch<0, X_ROWS32, DY_FRAGF16S>(a, n, groups, s);
         } else if (dy_form == DY_FRAG32) {
-            if (x_form == X_FRAG32) return launch<0, X_FRAG32, DY_FRAG32>(a, groups, s);
-            if (x_form == X_FRAG16) return launch<0, X_FRAG16, DY_FRAG32>(a, groups, s);
-            if (x_form == X_ROWS32) return launch<0, X_ROWS32, DY_FRAG32>(a, groups, s);
+            if (x_form == X_FRAG32) return launch<0, X_FRAG32, DY_FRAG32>(a, n, groups, s);
+            if (x_form == X_FRAG16) return launch<0, X_FRAG16, DY_FRAG32>(a, n, groups, s);
+            if (x_form == X_ROWS32) return launch<0, X_ROWS32, DY_FRAG32>(a, n, groups, s);
         } else {
-            if (x_form == X_FRAG32) return launch<0, X_FRAG32, DY_FRAGBF16>(a, groups, s);
-            if (x_form == X_FRAG16) return launch<0, X_FRAG16, DY_FRAGBF16>(a, groups, s);
-            if (x_form == X_ROWS32) return launch<0, X_ROWS32, DY_FRAGBF16>(a, groups, s);
+            if (x_form == X_FRAG32) return launch<0, X_FRAG32, DY_FRAGBF16>(a, n, groups, s);
+            if (x_form == X_FRAG16) return launch<0, X_FRAG16, DY_FRAGBF16>(a, n, groups, s);
+            if (x_form == X_ROWS32) return launch<0, X_ROWS32, DY_FRAGBF16>(a, n, groups, s);
         }
     } else if (shape == 1) {
         VFN_REQUIRE(x_form == X_AUX40, "vfn_weight_grad_frag: shape 1 takes the [M][40] encoding tile as X");
-        if (dy_form == DY_FRAG32) return launch<1, X_AUX40, DY_FRAG32>(a, groups, s);
-        if (dy_form == DY_FRAGBF16) return launch<1, X_AUX40, DY_FRAGBF16>(a, groups, s);
-        if (dy_form == DY_FRAGF16S) return launch<1, X_AUX40, DY_FRAGF16S>(a, groups, s);
+        if (dy_form == DY_FRAG32) return launch<1, X_AUX40, DY_FRAG32>(a, n, groups, s);
+        if (dy_form == DY_FRAGBF16) return launch<1, X_AUX40, DY_FRAGBF16>(a, n, groups, s);
+        if (dy_form == DY_FRAGF16S) return launch<1, X_AUX40, DY_FRAGF16S>(a, n, groups, s);
     } else if (shape == 2) {
         VFN_REQUIRE(dy_form == DY_DZ4, "vfn_weight_grad_frag: shape 2 takes the [M][4] head gradient as dY");
-        if (x_form == X_FRAG32) return launch<2, X_FRAG32, DY_DZ4>(a, groups, s);
-        if (x_form == X_FRAG16) return launch<2, X_FRAG16, DY_DZ4>(a, groups, s);
-        if (x_form == X_ROWS32) return launch<2, X_ROWS32, DY_DZ4>(a, groups, s);
+        if (x_form == X_FRAG32) return launch<2, X_FRAG32, DY_DZ4>(a, n, groups, s);
+        if (x_form == X_FRAG16) return launch<2, X_FRAG16, DY_DZ4>(a, n, groups, s);
+        if (x_form == X_ROWS32) return launch<2, X_ROWS32, DY_DZ4>(a, n, groups, s);
     }
     vfn_set_error("vfn_weight_grad_frag: unsupported combination shape=%d dy_form=%d x_form=%d", shape, dy_form, x_form);
     return VFN_ERR_INVALID;

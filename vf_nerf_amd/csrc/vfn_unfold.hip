@@ -25,6 +25,7 @@ struct UnfoldEntry {
     int rows, row_off, in_dim, slab_rows;
     int act_c0, act_nc, aux_c0, aux_nc;
     float scale;
+    int groups_act, groups_aux, groups_db;      // 0: the launch's `groups`
 };
 struct UnfoldArgs {
     UnfoldEntry e[UF_MAX];
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(320) void vfn_unfold_kernel(const UnfoldArgs a) {
     const bool acc = (a.accumulate >> blockIdx.y) & 1u;
     const int n = blockIdx.x;
     if (n >= e.rows) return;
-    const int tid = threadIdx.x, G = a.groups;
+    const int tid = threadIdx.x;
     const int row = e.row_off + n;
     // this thread's column
     const bool is_act = tid < 256;
@@ -48,6 +49,8 @@ __global__ __launch_bounds__(320) void vfn_unfold_kernel(const UnfoldArgs a) {
     const int nc = is_act ? e.act_nc : e.aux_nc, c0 = is_act ? e.act_c0 : e.aux_c0;
     const size_t gstride = is_act ? (size_t)e.slab_rows * 256 : (size_t)256 * 64;
     const int ld = is_act ? 256 : 64;
+    const int G = is_act ? (e.groups_act ? e.groups_act : a.groups) : (e.groups_aux ? e.groups_aux : a.groups);
+    const int GB = e.groups_db ? e.groups_db : a.groups;
     float s = 0.f;
     const bool valid = slab != nullptr && k < nc;
     if (valid) {
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(320) void vfn_unfold_kernel(const UnfoldArgs a) {
         for (; g < G; ++g) s += p[(size_t)g * gstride];
     }
     float dbp = 0.f;
-    for (int g = tid; g < G; g += blockDim.x) dbp += e.db[(size_t)g * e.slab_rows + n];
+    for (int g = tid; g < GB; g += blockDim.x) dbp += e.db[(size_t)g * e.slab_rows + n];
     const float inv = e.bn_w ? rsqrtf(e.bn_var[row] + 1e-5f) : 0.f;
     const float s_fold = e.bn_w ? e.bn_w[row] * inv : 1.0f;
     const float sub = s * e.scale;
@@ -112,6 +115,8 @@ extern "C" int vfn_unfold_weight_grads_acc(const vfn_unfold_entry* entries, int3
         VFN_REQUIRE(!e.bn_w || (e.bn_var && e.bn_mean && e.b_lin && e.g_bn_w && e.g_bn_b), "vfn_unfold_weight_grads: entry %d BatchNorm pointer NULL", i);
         VFN_REQUIRE(e.rows >= 1 && e.rows <= e.slab_rows && e.slab_rows <= 256 && e.act_nc <= 256 && e.aux_nc <= 64,
                     "vfn_unfold_weight_grads: entry %d has bad sizes", i);
+        VFN_REQUIRE(e.groups_act >= 0 && e.groups_act <= 4096 && e.groups_aux >= 0 && e.groups_aux <= 4096 && e.groups_db >= 0 && e.groups_db <= 4096,
+                    "vfn_unfold_weight_grads: entry %d has bad slab counts", i);
         max_rows = e.rows > max_rows ? e.rows : max_rows;
     }
     a.n_entries = n_entries; a.groups = groups; a.accumulate = accumulate_mask;

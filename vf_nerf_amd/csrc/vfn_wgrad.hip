@@ -6,6 +6,7 @@
 // columns, one for the encoding columns, then one un-fold launch per net — with a torch allocation per slab: ~45 Python-side
 // operations per backward, 1.9 ms of host time at the reference's 1 024-ray batches where the device needs 1.2 ms.
 // vfn_net_weight_grads_frag is that sequence issued from C out of one caller-supplied scratch buffer:
+//     (round 3: the products of one shape and operand form leave as ONE launch of slabs x products workgroups, see the loop below)
 //     for every layer entry h of the net (csrc/vfn_plan.h; vf_nerf_amd/backward.py::_entries is the same table):
 //         vfn_weight_grad_frag(shape 0)  dY_h^T X_h      [256][256] slabs, X_h = the slot of entry h-1 (rendering net, h = 0: the
 //                                                         fp32 feature rows)
@@ -132,6 +133,26 @@ extern "C" int vfn_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_ge
     int nu = 0;
     const bool has_feat = net_kind == VFN_NET_VF && geom->feature_dims > 0;
     VFN_REQUIRE(parts & (VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD), "%s: parts = 0", what);
+    // Products of one shape and operand form go out as ONE launch of (slabs x products) workgroups (csrc/vfn_dwf.hip, DwfBatch): the
+    // activation-column products whose X is a workspace slot (7 + the feature block for the vector-field net, 3 for the rendering
+    // net), and the encoding-column products.  A batch of k products runs G / k slabs each, so the chip is as full as with one launch
+    // of G slabs per product while the partial slabs written here and read back by the un-fold shrink k-fold (64 MB per product
+    // otherwise, whatever the batch size: a third of a weight-gradient launch's traffic at the reference's 1 024-ray batches).
+    struct Batch { int n; const void* dy[8]; const void* x[8]; float* dw[8]; float* db[8]; int unfold_idx[8]; };
+    Batch act = {}, enc = {};
+    auto flush = [&](Batch& b, int shape, int xf) -> int {
+        if (b.n == 0) return VFN_OK;
+        int gb = G / b.n;
+        gb = gb < 1 ? 1 : gb;
+        int rc = vfn_internal_weight_grad_frag_batch(shape, dy_form, xf, b.n, b.dy, b.x, b.dw, b.db, n_points, gb, stream);
+        for (int i = 0; i < b.n; ++i) {
+            vfn_unfold_entry& o = u[b.unfold_idx[i]];
+            if (shape == 0) { o.groups_act = gb; o.groups_db = gb; }
+            else { o.groups_aux = gb; if (b.db[i]) o.groups_db = gb; }
+        }
+        b.n = 0;
+        return rc;
+    };
     for (int h = 0; h < n; ++h) {
         const Entry& x = e[h];
         float* db = c.take((size_t)G * VFN_HIDDEN);
@@ -143,15 +164,21 @@ extern "C" int vfn_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_ge
         VFN_REQUIRE(q.weight && q.bias && q.g_weight && q.g_bias, "%s: layer %d has a NULL weight / bias / gradient pointer", what, x.layer);
         const void* dy_h = dyb + (size_t)h * slot_bytes;
         int rc;
+        const int ui = nu;
         if (dw_act) {
-            const bool rows = x.x_slot < 0;
-            rc = vfn_weight_grad_frag(0, dy_h, dy_form, rows ? (const void*)feats : (const void*)(sv + (size_t)x.x_slot * slot_bytes),
-                                      rows ? 2 : x_form, n_points, G, dw_act, db, stream);
-            if (rc != VFN_OK) return rc;
+            if (x.x_slot < 0) {       // the rendering net's first layer reads the fp32 feature ROWS: another operand form, its own launch
+                rc = vfn_weight_grad_frag(0, dy_h, dy_form, (const void*)feats, 2, n_points, G, dw_act, db, stream);
+                if (rc != VFN_OK) return rc;
+            } else {
+                if (act.n == 8) { rc = flush(act, 0, x_form); if (rc != VFN_OK) return rc; }
+                act.dy[act.n] = dy_h; act.x[act.n] = sv + (size_t)x.x_slot * slot_bytes; act.dw[act.n] = dw_act; act.db[act.n] = db;
+                act.unfold_idx[act.n++] = ui;
+            }
         }
         if (dw_aux) {
-            rc = vfn_weight_grad_frag(1, dy_h, dy_form, aux, 3, n_points, G, dw_aux, dw_act ? nullptr : db, stream);
-            if (rc != VFN_OK) return rc;
+            if (enc.n == 8) { rc = flush(enc, 1, 3); if (rc != VFN_OK) return rc; }
+            enc.dy[enc.n] = dy_h; enc.x[enc.n] = aux; enc.dw[enc.n] = dw_aux; enc.db[enc.n] = dw_act ? nullptr : db;
+            enc.unfold_idx[enc.n++] = ui;
         }
         vfn_unfold_entry& o = u[nu++];
         o.dw_act = dw_act; o.dw_aux = dw_aux; o.db = db;
@@ -162,6 +189,12 @@ extern "C" int vfn_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_ge
         }
         o.rows = x.rows; o.row_off = x.row_off; o.in_dim = geom->in_dims[x.layer]; o.slab_rows = VFN_HIDDEN;
         o.act_c0 = x.act_c0; o.act_nc = x.act_nc; o.aux_c0 = x.aux_c0; o.aux_nc = x.aux_nc; o.scale = x.scale;
+    }
+    {
+        int rc = flush(act, 0, x_form);
+        if (rc != VFN_OK) return rc;
+        rc = flush(enc, 1, 3);
+        if (rc != VFN_OK) return rc;
     }
     if (parts & VFN_WGRAD_HEAD) {   // 3-channel head = rows 0..2 of the last Linear (no BatchNorm)
         float* part = c.take((size_t)G * 32 * VFN_HIDDEN);

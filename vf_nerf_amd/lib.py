@@ -818,7 +818,7 @@ class UnfoldEntry(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dw_act", "dw_aux", "db", "w", "b_lin", "bn_w", "bn_var", "bn_mean", "g_w", "g_b",
                                           "g_bn_w", "g_bn_b")] + \
                [(n, C.c_int32) for n in ("rows", "row_off", "in_dim", "slab_rows", "act_c0", "act_nc", "aux_c0", "aux_nc")] + \
-               [("scale", C.c_float)]
+               [("scale", C.c_float)] + [(n, C.c_int32) for n in ("groups_act", "groups_aux", "groups_db")]
 
 
 def unfold_weight_grads(entries: Sequence[dict], groups: int, accumulate_mask: int = 0) -> None:
