@@ -442,7 +442,9 @@ def train_step_accounting(n_rays, s_c, s_t, n_sup, storage, gradients="fp32", se
     weight-gradient kernels), the saved activations read once by the weight-gradient kernels, and the per-sample inputs and
     outputs (point, normal, colour, their gradients)."""
     m_f, m_s = n_rays * s_t, 2 * n_sup
-    flops = 2.0 * ((n_rays * s_c * VF_MACS if separate_proposal else 0.0) + 3.0 * m_f * (VF_MACS + RN_MACS) + 3.0 * m_s * VF_MACS)
+    # (supervision points: the three vector columns only — trainer.TrainStep's vector-only call; the 256 x 256 feature block of the
+    # reference's full forward there is never read and is not counted)
+    flops = 2.0 * ((n_rays * s_c * VF_MACS if separate_proposal else 0.0) + 3.0 * m_f * (VF_MACS + RN_MACS) + 3.0 * m_s * (VF_MACS - 256 * 256))
     relu_slot = 512 if storage == "f16" else 1024
     saved = m_f * (12 * relu_slot + 1024) + m_s * (8 * relu_slot + 1024)      # written by the forward ...
     masks = 32 * (13 * m_f + 9 * m_s)

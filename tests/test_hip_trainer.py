@@ -483,21 +483,22 @@ def test_non_finite_upstream_gradient_reaches_the_weight_gradients(storage):
     assert not bool(torch.isfinite(norm)), float(norm)
 
 
-@pytest.mark.parametrize("mode", ["fp32", "f16x3"])
-def test_training_converges_on_teacher_targets(mode):
+def test_training_converges_on_teacher_targets():
     """SURVEY.md section 8d C3 in small: the reference trainer's step (trainer.TrainStep = train/vector_field_nerf_train.py:172-260)
-    on a LEARNABLE target — rgb / depth of four orbit views rendered by a teacher of another weight seed — from the same
-    initial weights, batches and random streams with the exact-fp32 kernels and with the default 16-bit path (f16x3 forward,
-    f16 activations, scaled-f16 gradients).  120 steps of 256 rays x (32 + 32): the loss must come down by a fixed factor in both,
-    start from the same loss, and the 16-bit run must not end worse than the fp32 run by more than run-to-run scatter
-    (tools/train_curve.py holds the long version with its band)."""
+    on a LEARNABLE target — rgb / depth of eight orbit views rendered by a teacher of another weight seed — from the same initial
+    weights, batches and random streams with the exact-fp32 kernels and with the default 16-bit path (f16x3 forward, f16
+    activations, scaled-f16 gradients).  300 steps of 1 024 rays x (64 + 64): both start from the same loss, both bring it below
+    0.6 of where it started (observed: 0.4 .. 0.5), and neither ends far from the other.  Single runs are chaotic (a ReLU unit or
+    an argmax on the other side flips a discrete event and the trajectories part): the band here is wide on purpose; the long
+    comparison with three random streams per arithmetic and its 0.3 dB band is tools/train_curve.py ->
+    profiles/r03/train_curve.json."""
     import vf_nerf_amd
     from vf_nerf_amd import synthetic, trainer
     dev = torch.device(DEV)
 
     def scene(seed):
         torch.manual_seed(seed)
-        cfg = vf_nerf_amd.shipped_config(dev, n_samples=32, n_importance=32, perturb=True, dir_to_normal_th=-0.2)
+        cfg = vf_nerf_amd.shipped_config(dev, n_samples=64, n_importance=64, perturb=True, dir_to_normal_th=-0.2)
         m = vf_nerf_amd.VectorFieldNerf(cfg)
         m.eval()
         synthetic.scale_hidden_weights(m.vector_field_network, m.rendering_network, 2.0)
@@ -510,28 +511,26 @@ def test_training_converges_on_teacher_targets(mode):
             synthetic.recentre_vector_head(m.vector_field_network, mean, std)
         return m
 
-    pool = trainer.TeacherTargets(scene(1), views=4, width=48, height=48, focal=45.0, seed=3)
+    pool = trainer.TeacherTargets(scene(1), views=8, width=64, height=64, focal=60.0, seed=5)
     curves = {}
-    for tag in ("fp32", mode) if mode != "fp32" else ("fp32",):
+    for tag in ("fp32", "f16x3"):
         model = scene(0)
-        model.precision = "fp32" if tag == "fp32" else "f16x3"
+        model.precision = tag
         model.rng_seed, model._rng_offset = 11, 0
         supervision.manual_seed(3)
         step = trainer.TrainStep(model, (0.0, 0.0, 0.55), border_radius=0.15, far=1.0)
         losses = []
-        for t in range(120):
-            pose, uv, K, rgb_gt, depth_gt = pool.batch(t, 256)
+        for t in range(300):
+            pose, uv, K, rgb_gt, depth_gt = pool.batch(t, 1024)
             losses.append(step(pose, uv, K, rgb_gt, depth_gt, epoch=0)[0])
         curves[tag] = [float(x) for x in losses]
-        first, last = sum(curves[tag][:5]) / 5, sum(curves[tag][-10:]) / 10
-        print(f"[{tag}] loss first 5 steps {first:.4f} -> last 10 steps {last:.4f} (x{last / first:.3f})")
-        assert last < 0.8 * first, (tag, first, last)
-    if mode != "fp32":
-        a, b = sum(curves["fp32"][-10:]) / 10, sum(curves[mode][-10:]) / 10
-        print(f"final loss {mode} / fp32 = {b / a:.4f}")
-        # (single short runs are chaotic: 120 steps of 256 rays end 25 % apart either way from run to run; the long, multi-stream
-        # comparison with its band is tools/train_curve.py -> profiles/r03/train_curve.json.  Here: the 16-bit run is not worse.)
-        assert b < 1.3 * a and abs(curves[mode][0] - curves["fp32"][0]) < 1e-3 * curves["fp32"][0]
+        first, last = sum(curves[tag][:10]) / 10, sum(curves[tag][-50:]) / 50
+        print(f"[{tag}] loss first 10 steps {first:.4f} -> last 50 steps {last:.4f} (x{last / first:.3f})")
+        assert last < 0.6 * first, (tag, first, last)
+    a, b = sum(curves["fp32"][-50:]) / 50, sum(curves["f16x3"][-50:]) / 50
+    print(f"final loss f16x3 / fp32 = {b / a:.4f}; first-step losses {curves['fp32'][0]:.6f} / {curves['f16x3'][0]:.6f}")
+    assert abs(curves["f16x3"][0] - curves["fp32"][0]) < 1e-4 * curves["fp32"][0], "same state, same batch: the same first loss"
+    assert 0.6 < b / a < 1.67
 
 
 def test_evaluator_loop_through_the_dropin_gets_the_chunked_values():
