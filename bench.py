@@ -51,7 +51,7 @@ SUSTAINED_F16_MFMA = 1570.0                # TFLOP/s a pure 32x32x16 f16 MFMA lo
 
 def kernel_sources_sha16() -> str:
     import hashlib
-    src = b"".join(open(os.path.join(REPO, "vf_nerf_amd", "csrc", f), "rb").read() for f in ("vfn_mlp16.hip", "vfn_bwd16.hip", "vfn_dwf.hip"))
+    src = b"".join(open(os.path.join(REPO, "vf_nerf_amd", "csrc", f), "rb").read() for f in ("vfn_mlp16.hip",))
     return hashlib.sha256(src).hexdigest()[:16]
 
 

@@ -27,8 +27,9 @@ with open(os.path.join(out, f"bench_kernel_stats_{tag}.csv"), "w", newline="") a
 
 import hashlib
 _repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# bench.py compares this fingerprint of the kernel sources with the tree it runs in and says so when the counters are older than the code
-_src = b"".join(open(os.path.join(_repo, "vf_nerf_amd", "csrc", f), "rb").read() for f in ("vfn_mlp16.hip", "vfn_bwd16.hip", "vfn_dwf.hip"))
+# bench.py compares this fingerprint of the dominant kernel's source (csrc/vfn_mlp16.hip) with the tree it runs in and says so when
+# the counters are older than the code
+_src = b"".join(open(os.path.join(_repo, "vf_nerf_amd", "csrc", f), "rb").read() for f in ("vfn_mlp16.hip",))
 traffic = {"collected": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, averaged over launches (KB)",
            "kernel_sources_sha16": hashlib.sha256(_src).hexdigest()[:16], "all_kernels": {}}
 for counter, sub, stem in (("FETCH_SIZE", "prof_fetch", "pf"), ("WRITE_SIZE", "prof_write", "pw")):
