@@ -9,8 +9,9 @@
 //   smoothing    axes 0 and 1: the filter runs along a strided axis, so every FLOAT of the interleaved [.., 3] layout is
 //                independent — a lane owns four consecutive floats and marches along the axis with the k taps in registers
 //                (each input read once, 16-byte accesses); axis 2: whole rows staged in LDS.  24 B / cell / pass.
-//   unify        one lane per cell; the 8-corner analysis only where the divergence mask is set; the eight int64 per cell
-//                leave through wave-wide 1 KiB stores (a lane's own eight stores would touch 64 lines each).  68 B / cell.
+//   unify        one lane per cell for the mask and the stores, a whole wave per SURFACE cell for the 8-corner analysis (the wave
+//                walks the set bits of its ballot); the eight int64 per cell leave through wave-wide 1 KiB stores (a lane's
+//                own eight stores would touch 64 lines each).  69 B / cell.
 //   comb         per-cell inputs (side bits, 8 corner norms) staged in LDS, the 28 + 56 floats per cell written as
 //                float4 rows of the wave's contiguous output range.  336 B / cell out.
 // Arithmetic per value is unchanged from the round-2 kernels (same expressions, same order, -ffp-contract=off): masks,
@@ -242,32 +243,39 @@ __global__ __launch_bounds__(256) void vfn_grid_smooth_rows_kernel(const SmoothA
 // (mc_utils.py:107-167).  Side bits of a cell = one byte; the int64 [N^3, 8] table of the reference's interface is written
 // from the bytes by the whole wave: 64 cells x 64 B = 4 KiB consecutive, four stores of 1 KiB.
 // ------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned cell_sides(const float* vt, int N, long long idx) {
+// The analysis of ONE surface cell by a whole wave: lanes 0..23 fetch the 24 floats of its eight corner vectors, lane L = 8 a + b
+// evaluates the pair (a, b) of the 64 — the reference's distance matrix 1 - <v_a, v_b> in its own order of operations — a wave
+// reduction picks the first maximum in a-major order (torch.argmax over the flattened 8 x 8 matrix), lanes 0..7 decide their
+// corner's side.  Surface cells are a few percent of the grid: a wave walks the set bits of its ballot instead of sending all 64
+// lanes through 64 pairs whenever one of them sits on the surface (which also took 176 VGPRs, i.e. two waves per SIMD for a
+// kernel whose real job is to write 64 bytes per cell).
+__device__ __forceinline__ unsigned cell_sides_wave(const float* __restrict__ vt, int N, long long idx, int lane) {
     const int k = (int)(idx % N), j = (int)((idx / N) % N), i = (int)(idx / ((long long)N * N));
-    float v[8][3];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) load_vec(vt, N, i + CORNER[q][0], j + CORNER[q][1], k + CORNER[q][2], v[q]);
-    float best = -3.4e38f;
-    float fx = 0.f, fy = 0.f, fz = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const float d = 1.0f - ((v[a][0] * v[b][0] + v[a][1] * v[b][1]) + v[a][2] * v[b][2]);
-            if (d > best) {                                   // first maximum, as torch.argmax over the 64 pairs (a-major)
-                best = d;
-                fx = v[a][0]; fy = v[a][1]; fz = v[a][2]; sx = v[b][0]; sy = v[b][1]; sz = v[b][2];
-            }
-        }
-    unsigned bits = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float d1x = fx - v[q][0], d1y = fy - v[q][1], d1z = fz - v[q][2];
-        const float d2x = sx - v[q][0], d2y = sy - v[q][1], d2z = sz - v[q][2];
-        const float n1 = sqrtf(d1x * d1x + d1y * d1y + d1z * d1z), n2 = sqrtf(d2x * d2x + d2y * d2y + d2z * d2z);
-        bits |= (n2 < n1 ? 1u : 0u) << q;                    // argmin over (first, second): first on ties
+    float val = 0.f;
+    if (lane < 24) {
+        const int q = lane / 3, c = lane - 3 * q;
+        const int ii = i + CORNER[q][0], jj = j + CORNER[q][1], kk = k + CORNER[q][2];
+        if (ii < N && jj < N && kk < N) val = vt[(((long long)ii * N + jj) * N + kk) * 3 + c];
     }
-    return bits;
+    const int a = lane >> 3, b = lane & 7;
+    const float a0 = __shfl(val, 3 * a, 64), a1 = __shfl(val, 3 * a + 1, 64), a2 = __shfl(val, 3 * a + 2, 64);
+    const float b0 = __shfl(val, 3 * b, 64), b1 = __shfl(val, 3 * b + 1, 64), b2 = __shfl(val, 3 * b + 2, 64);
+    float best = 1.0f - ((a0 * b0 + a1 * b1) + a2 * b2);
+    int bi = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }      // first maximum, as torch.argmax
+    }
+    const int f = bi >> 3, sc = bi & 7;
+    const float fx = __shfl(val, 3 * f, 64), fy = __shfl(val, 3 * f + 1, 64), fz = __shfl(val, 3 * f + 2, 64);
+    const float sx = __shfl(val, 3 * sc, 64), sy = __shfl(val, 3 * sc + 1, 64), sz = __shfl(val, 3 * sc + 2, 64);
+    // lanes 0..7 hold (b0, b1, b2) = corner `lane` (b = lane there)
+    const float d1x = fx - b0, d1y = fy - b1, d1z = fz - b2;
+    const float d2x = sx - b0, d2y = sy - b1, d2z = sz - b2;
+    const float n1 = sqrtf(d1x * d1x + d1y * d1y + d1z * d1z), n2 = sqrtf(d2x * d2x + d2y * d2y + d2z * d2z);
+    return (unsigned)(__ballot(n2 < n1) & 0xffull);                              // argmin over (first, second): first on ties
 }
 
 __global__ __launch_bounds__(256) void vfn_grid_unify_kernel(const float* __restrict__ div, const float* __restrict__ vt, long long* __restrict__ choice,
@@ -275,11 +283,17 @@ __global__ __launch_bounds__(256) void vfn_grid_unify_kernel(const float* __rest
     const long long total = (long long)N * N * N;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    const long long first = idx - lane;                      // the wave's first cell
     unsigned bits = 0;
-    if (idx < total && div[idx] == 1.0f) bits = cell_sides(vt, N, idx);
+    unsigned long long todo = __ballot(idx < total && div[idx < total ? idx : 0] == 1.0f);
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const unsigned m = cell_sides_wave(vt, N, first + src, lane);
+        if (lane == src) bits = m;
+    }
     if (sides && idx < total) sides[idx] = (unsigned char)bits;
     if (!choice) return;
-    const long long first = idx - lane;                      // the wave's first cell
     typedef long long ll2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
