@@ -209,11 +209,11 @@ def view_bench(args, dev):
     uv, pose, K = synthetic.pinhole_image(w, h, f, device=dev)
     n = uv.shape[0]
 
+    from vf_nerf_amd import evaluator
     if args.as_evaluator:
         # the evaluator's own situation (evaluation/methods.py:504-545): the dataset hands the view over as HOST tensors with the pose
         # and intrinsics replicated per ray, and wants rgb / depth back on the host -> evaluator.render_view (what dropin.install()
         # puts behind evaluation.methods.render_images); uploads and the download are inside the timed region
-        from vf_nerf_amd import evaluator
         uv_h, pose_h, K_h = uv.cpu(), pose.cpu(), K.cpu()
 
         def full_view():
@@ -231,6 +231,14 @@ def view_bench(args, dev):
             full_view()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        if args.no_parity:
+            emit_line(({"metric": "rays/sec (full 1200x680 view) — throughput only (--no-parity)", "value": round(n * args.steps / elapsed, 1), "unit": "rays/s",
+                        "n_gpus": 1, "steps": args.steps, "warmup": max(1, args.warmup // 3), "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+                        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16x3+f32acc" if args.precision == "f16x3" else "f32",
+                        "data": "synthetic",
+                        "config": {"workload": f"full view {w}x{h} in {chunk}-ray chunks x {s_c} + {n_f} samples, {args.streams} stream(s)" +
+                                               (f", as the evaluator runs it (host in / host out; grouped into >= {evaluator.MIN_CHUNK}-ray chunks)" if args.as_evaluator else "")}}))
+            return
 
         # parity image: same camera at 1/8 resolution on both sides, identical u_add draw (Q9)
         ws, hs = w // 8, h // 8
@@ -273,8 +281,9 @@ def view_bench(args, dev):
         "dtype": "f16x3+f32acc" if args.precision == "f16x3" else "f32", "data": "synthetic",
         "config": {"workload": f"full view {w}x{h} = {n} rays in {chunk}-ray chunks x {s_c + n_f} samples, perturb off, "
                                f"forward only, consecutive chunks on {args.streams} stream(s) (BASELINE.json configs[1])" +
-                               (", as the evaluator runs it: host tensors in (pose / intrinsics per ray), host rgb / depth out, uploads and "
-                                "download inside the timed region (evaluator.render_view)" if args.as_evaluator else ", inputs resident in HBM"),
+                               (f", as the evaluator runs it: host tensors in (pose / intrinsics per ray), host rgb / depth out, uploads and "
+                                f"download inside the timed region (evaluator.render_view: split_size {chunk}, grouped into chunks of >= {evaluator.MIN_CHUNK} rays)"
+                                if args.as_evaluator else ", inputs resident in HBM"),
                    "colour_products": int(model.colour_products) if args.precision == "f16x3" else None},
         "parity_vs_oracle": {"image": f"{ws}x{hs} (same camera, intrinsics / 8), {ws * hs} rays",
                              "psnr_rgb_db": round(min(O.psnr(rgb, ref["rgb"]), 200.0), 2),
@@ -722,6 +731,7 @@ def main() -> None:
                     help="run only the multi-rank plumbing (process group, broadcast, gradient-bucket all-reduce, timing protocol, JSON line); "
                          "with --backend gloo no GPU is touched")
     ap.add_argument("--grid-res", type=int, default=256)
+    ap.add_argument("--no-parity", action="store_true", help="view workload: skip the oracle parity image (fp32 + float64, ~50 s of CPU)")
     ap.add_argument("--as-evaluator", action="store_true",
                     help="view workload: time evaluator.render_view on HOST inputs (per-ray pose / intrinsics) with the download inside the "
                          "timed region — what the reference's evaluation/methods.py:render_images gets through vf_nerf_amd.dropin")

@@ -562,7 +562,7 @@ def test_evaluator_loop_through_the_dropin_gets_the_chunked_values():
             depth_map[rows, cols, :] = output.coarse_depth_map.cpu().numpy()
 
     model.rng_seed, model._rng_offset = 5, 0
-    rgb_values, depth_values = evaluator.render_view(model, pose, uv, K, 0, split_size=split)
+    rgb_values, depth_values = evaluator.render_view(model, pose, uv, K, 0, split_size=split, min_chunk=0)      # the reference's chunking
     assert rgb_values.shape == (n, 3) and depth_values.shape == (n, 1)
     rows, cols = uv[:, 1].long().numpy(), uv[:, 0].long().numpy()
     assert np.array_equal(rgb[rows, cols, :].astype(np.float32), rgb_values)
@@ -570,8 +570,20 @@ def test_evaluator_loop_through_the_dropin_gets_the_chunked_values():
     assert float(depth_values.max()) > 0.05, "the view composites something"
     # a pose / intrinsics shared by the whole view (one copy) gives the same image
     model.rng_seed, model._rng_offset = 5, 0
-    rgb_shared, _ = evaluator.render_view(model, pose[0], uv, K[0], 0, split_size=split)
+    rgb_shared, _ = evaluator.render_view(model, pose[0], uv, K[0], 0, split_size=split, min_chunk=0)
     assert np.array_equal(rgb_shared, rgb_values)
+    # The default groups the view into larger chunks than the reference's split (rays are independent; its split bounds ITS
+    # activation memory).  With deterministic samplers the only draw left is the uniform fine samples of rays WITHOUT a surface
+    # (Q9): rays whose value does not depend on the seed must not depend on the chunking either, bit for bit.
+    model.ray_sampler.deterministic = model.fine_sampler.deterministic = True
+    views = {}
+    for tag, seed, mc in (("split", 5, 0), ("split, other seed", 6, 0), ("grouped", 5, evaluator.MIN_CHUNK)):
+        model.rng_seed, model._rng_offset = seed, 0
+        views[tag] = evaluator.render_view(model, pose, uv, K, 0, split_size=split, min_chunk=mc)
+    draw_free = (views["split"][0] == views["split, other seed"][0]).all(axis=1) & (views["split"][1] == views["split, other seed"][1]).all(axis=1)
+    assert draw_free.mean() > 0.3, "the view has rays with a surface"
+    assert np.array_equal(views["grouped"][0][draw_free], views["split"][0][draw_free])
+    assert np.array_equal(views["grouped"][1][draw_free], views["split"][1][draw_free])
 
 
 def test_frozen_parameters_are_left_alone_by_the_training_step():

@@ -17,12 +17,25 @@ import numpy as np
 import torch
 
 
+MIN_CHUNK = 8192        # rays per launch group of a whole view (see render_view)
+
+
 @torch.no_grad()
 def render_view(model, all_pose: torch.Tensor, all_pixels: torch.Tensor, all_intrinsics: torch.Tensor, epoch: int,
-                split_size: int = 512, white: bool = False, n_streams: int = 2) -> Tuple[np.ndarray, np.ndarray]:
+                split_size: int = 512, white: bool = False, n_streams: int = 2, min_chunk: int = MIN_CHUNK) -> Tuple[np.ndarray, np.ndarray]:
     """One view, as the dataset hands it over (host or device tensors, pose / intrinsics replicated per ray or shared) ->
-    (rgb[N,3], depth[N,1]) numpy arrays; chunks of ``split_size`` rays like the reference's loop (methods.py:513-545)."""
-    rgb, depth = model.render_chunked(all_pose, all_pixels, all_intrinsics, epoch, chunk=split_size, n_streams=n_streams, white=white)
+    (rgb[N,3], depth[N,1]) numpy arrays.
+
+    ``split_size`` is the reference loop's chunk (methods.py:513-545), there to bound ITS activation memory: its un-fused
+    forward materialises [rays x samples, 256] per layer.  Here nothing of the kind exists (the fused kernels keep activations on
+    chip; a chunk's outputs are 52 B per sample), and rays are independent end to end, so the view is rendered in chunks of
+    max(split_size, ``min_chunk``) rays: at the shipped sampler sizes (100 + 35 samples) a 512-ray chunk is 1.6 + 0.5 rounds of
+    workgroups per fused launch — 1.32 M rays/s against 2.06 M in 8 192-ray chunks on one MI355X.  Every ray's value is the one
+    the 512-ray loop computes for the same random draws; which draws a ray gets (stratified jitter, the uniform fine samples of
+    rays without a surface, Q9) depends on its position in the stream as it does in the reference.  ``min_chunk = 0``: exactly the
+    reference's chunking."""
+    chunk = max(int(split_size), int(min_chunk))
+    rgb, depth = model.render_chunked(all_pose, all_pixels, all_intrinsics, epoch, chunk=chunk, n_streams=n_streams, white=white)
     host = torch.empty(rgb.shape[0], 4, pin_memory=True)
     host[:, :3].copy_(rgb, non_blocking=True)
     host[:, 3:].copy_(depth, non_blocking=True)
