@@ -749,3 +749,21 @@ def test_train_step_is_the_same_step_with_and_without_the_fused_loss():
         for a, b in zip(out[mode][3:], out["fused"][3:]):
             assert float((a - b).abs().max()) < 0.2 * 5e-4, mode                      # well inside one Adam update (lr 5e-4)
     assert out["fused"][1]["supervision_loss"] > 0
+
+
+def test_lazy_loss_terms_survive_the_pinned_ring_wrapping_around():
+    """The six log scalars travel through a ring of 64 pinned buffers and are fetched on first read: a dict that is still unread
+    when its buffer comes round again is read before the buffer is handed on, so late readers get their own step's values."""
+    crit = vloss.VFLoss(SimpleNamespace(depth_loss_clamp=0.5, norm_smaller_than_one_start=11000, directional_derivatives_start=100),
+                        SimpleNamespace(rgb=2.0, depth=0.5, unit_norm=0.1, supervision=1.0, norm_smaller_than_one=0.1, directional_derivatives=0.0))
+    gen = torch.Generator().manual_seed(0)
+    gt = {"rgb": torch.rand(8, 3, generator=gen).to(DEV), "depth": torch.rand(8, 1, generator=gen).to(DEV), "supervised_normals": torch.empty(0, device=DEV)}
+    kept, want = [], []
+    for i in range(150):
+        pred = {"rgb": torch.full((8, 3), 0.01 * i, device=DEV), "depth": torch.rand(8, 1, generator=gen).to(DEV),
+                "normals": torch.randn(16, 3, generator=gen).to(DEV), "supervised_normals": torch.empty(0, 3, device=DEV), "directional_derivatives": None}
+        _, terms = crit(pred, gt, 0)
+        kept.append(terms)
+        want.append(float((pred["rgb"] - gt["rgb"]).abs().mean()))
+    for i in (0, 1, 63, 64, 65, 100, 149):
+        assert abs(kept[i]["rgb_loss"] - want[i]) < 1e-6, i

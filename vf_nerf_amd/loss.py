@@ -22,22 +22,27 @@ class _LazyTerms(dict):
     """{name: float} whose values arrive from the device on first read.  Keys, length and iteration order are available at
     once; every way of reading a value (indexing, get, values, items, pop, copy, repr, comparison) waits for the copy first."""
 
-    _ring = []            # pinned host buffers, reused round-robin (a fresh pinned allocation per step costs more than the step's loss)
-    _next = 0
+    _ring = []            # [pinned host buffer, weak reference to the dict that last used it], reused round-robin (a fresh pinned
+    _next = 0             # allocation per step costs more than the step's loss)
 
-    @classmethod
-    def _host(cls, n: int, dtype) -> torch.Tensor:
+    def _host(self, n: int) -> torch.Tensor:
+        import weakref
+        cls = _LazyTerms
         if len(cls._ring) < 64:
-            cls._ring.append(torch.empty(16, dtype=torch.float32, pin_memory=True))
-        buf = cls._ring[cls._next % len(cls._ring)]
+            cls._ring.append([torch.empty(16, dtype=torch.float32, pin_memory=True), None])
+        slot = cls._ring[cls._next % len(cls._ring)]
         cls._next += 1
-        return buf[:n]
+        prev = slot[1]() if slot[1] is not None else None
+        if prev is not None and prev is not self:
+            prev._fetch()                      # 64 dicts later somebody still has not read this one: read it before its buffer goes
+        slot[1] = weakref.ref(self)
+        return slot[0][:n]
 
     def __init__(self, names, stacked: torch.Tensor) -> None:
         super().__init__((n, None) for n in names)
         self._pending = None
         if stacked.is_cuda:
-            host = self._host(stacked.numel(), stacked.dtype)          # (64 steps may pass before a slot is reused)
+            host = self._host(stacked.numel())
             host.copy_(stacked.float(), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(stacked.device))
