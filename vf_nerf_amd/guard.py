@@ -13,6 +13,9 @@ with silently degraded values.  So:
     "lazy"    (default) the status is read back asynchronously, every ``LAZY_EVERY`` guarded calls and whenever the weights
               were re-packed; the switch happens at the start of the first call after the report arrived.  No
               synchronisation on the hot path; the flagged calls themselves have already returned clamped values.
+              One exception (round 3): the FIRST gradient-free render on a (re)packed set of weights is checked like a strict
+              call — one synchronisation per weight change, none per chunk of a view — so that a model whose two-product
+              colours are out of tolerance never returns them, not even for the calls an asynchronous report would take to arrive.
     "strict"  every guarded call ends with a synchronising read of the status word and is REPEATED on the fp32 kernels when
               flagged: no call ever returns values the clamp touched.
     "off"     no reporting.
@@ -147,6 +150,7 @@ class RangeGuard:
                                                  colour_products=3)
             slot = st["status"][1:2].view(torch.float32)
             torch.maximum(slot, (three - two).abs().max().reshape(1), out=slot)
+            st["sampled"] = True
 
     def _after_call(self, dev) -> bool:
         st = self._state(dev)
@@ -154,7 +158,10 @@ class RangeGuard:
         repacked = keys != st["pack_keys"]
         st["pack_keys"] = keys
         self._calls += 1
-        if self.mode == "strict":
+        sampled = st.pop("sampled", False)
+        if self.mode == "strict" or (repacked and sampled):      # (lazy: the first colour-checked render on these weights, see above)
+            if st["event"] is not None:
+                st["event"].synchronize()
             self._read_back(st, dev)
             st["event"].synchronize()
             st["event"] = None
