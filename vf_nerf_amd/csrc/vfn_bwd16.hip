@@ -248,22 +248,19 @@ __device__ __forceinline__ float tile_scale(const f32x16& v, int& b, bool live =
     float m = fmaxf(fabsf(v[0]), fabsf(v[1]));
 #pragma unroll
     for (int r = 2; r < 16; r += 2) m = fmaxf(m, fmaxf(fabsf(v[r]), fabsf(v[r + 1])));
-    // fmaxf drops NaNs and an Inf maximum has no exponent byte: a non-finite gradient of a LIVE point (a diverging step) must not leave
-    // as "all zero".  max |v| on the bit patterns (sign cleared) orders NaN / Inf above every finite value; the lane's 16 values then
-    // leave as NaN (whatever factor the consumer rescales them by, 0 included, they stay NaN), so the weight gradients they enter come
-    // out non-finite as the reference's fp32 products would; byte 239 does not move the slab's common scale.  (Lanes past the last
-    // point may hold anything; their byte is 255 and the consumer zeroes them.)
-    unsigned mb = max(__builtin_bit_cast(unsigned, v[0]) & 0x7fffffffu, __builtin_bit_cast(unsigned, v[1]) & 0x7fffffffu);
-#pragma unroll
-    for (int r = 2; r < 16; r += 2)
-        mb = max(mb, max(__builtin_bit_cast(unsigned, v[r]) & 0x7fffffffu, __builtin_bit_cast(unsigned, v[r + 1]) & 0x7fffffffu));
-    if (live && (mb >> 23) == 255u) {
-        b = 239;
-        return __builtin_bit_cast(float, 0x7fc00000u);
-    }
+    // A non-finite gradient of a LIVE point (a diverging step) must not be masked.  NaNs beside finite values need nothing: fmaxf drops
+    // them from the maximum, they are stored as f16 NaNs and stay NaN under whatever factor the consumer rescales them by (0 included).
+    // What used to be lost is a lane whose maximum is Inf (or whose 16 values are all NaN): biased exponent 255 has no byte and the
+    // lane left as "all zero".  Its values now leave as NaN under byte 239 (which does not move the slab's common scale), so the weight
+    // gradients they enter come out non-finite as the reference's fp32 products would.  (Lanes past the last point may hold anything;
+    // their byte is 255 and the consumer zeroes them.)
     const int biased = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu);
-    b = (biased == 0 || biased == 255) ? 255 : min(254 - biased, 239);       // k + 113: every normal fp32 magnitude has its byte (below 2^-112 the scale saturates)
-    return (biased == 0 || biased == 255) ? 0.f : __builtin_bit_cast(float, (unsigned)(b + 14) << 23);
+    if (biased == 255) {
+        b = live ? 239 : 255;
+        return live ? __builtin_bit_cast(float, 0x7fc00000u) : 0.f;
+    }
+    b = biased == 0 ? 255 : min(254 - biased, 239);       // k + 113: every normal fp32 magnitude has its byte (below 2^-112 the scale saturates)
+    return biased == 0 ? 0.f : __builtin_bit_cast(float, (unsigned)(b + 14) << 23);
 }
 template <int SLOT, int TILE>
 __device__ __forceinline__ void store_group(const Pipe& p, const f32x16& v, int q, float scale = 1.0f) {
