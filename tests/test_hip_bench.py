@@ -1,0 +1,63 @@
+"""bench.py's contract, checked on the device: ONE JSON line on stdout, the required keys, and the arithmetic between them."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *args], capture_output=True, text=True, timeout=timeout, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, f"stdout must carry exactly one line, got {len(lines)}: {proc.stdout[:500]}"
+    return json.loads(lines[0])
+
+
+def test_default_line_has_the_contract_keys_and_consistent_arithmetic():
+    d = _run("--gpus", "1", "--steps", "8", "--warmup", "2", "--sustain-seconds", "0.3", "--train-steps", "3")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2 and d["unit"] == "rays/s" and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["data"] == "synthetic" and "workload" in d["config"]
+    assert "4096" in d["metric"] and d["config"]["rays_per_chunk_per_gpu"] == 4096 and d["config"]["samples_per_ray"] == 128
+    # value = rays of all timed steps / time
+    assert abs(d["value"] - 4096 * 1000.0 / d["ms_per_step"]) < 2e-3 * d["value"]
+    assert d["value_fp32_equivalent"] is not None and d["value_fp32_equivalent"] < d["value"] * 1.02
+    assert d["per_rank_rays_per_s"]["dist_world_size"] == 1
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
+    assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) < 1e-2 * r["achieved"]
+    assert 2 * r["avg_launch_ms"] <= d["ms_per_step"] * 1.02, "two launches of the dominant kernel fit in a step"
+    assert 0.3 < r["frac"] < 1.0 and r["traffic"] is None or r["traffic"] > r["algorithmic_bytes"]
+    assert r["traffic_source"] is None or "file" in r["traffic_source"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "rays/s" and c["cores"] >= 1 and 0 < c["value"] < d["value"] / 100
+    p = d["parity_vs_oracle"]
+    assert p["rays_with_different_z"] == 0 and p["frac_rays_within_1e-4"] == 1.0 and p["colour_products_ran"] == 2
+    t = d["parity_trained_weights"]
+    assert t["frac_rays_within_1e-4"] == 1.0 and t["rays_with_different_z"] == 0 and t["guard"]["switched_to_fp32"] is None
+    tr = d["train"]
+    assert tr["unit"] == "rays/s" and abs(tr["value"] - 4096 * 1000.0 / tr["ms_per_step"]) < 2e-3 * tr["value"] and 0.2 < tr["frac_of_f16_mfma_div3"] < 1.0
+
+
+def test_rccl_process_group_with_one_rank_keeps_stdout_to_the_json_line():
+    """VFN_BENCH_FORCE_DIST=1: the multi-GPU code path (RCCL process group, barriers, max-over-ranks all-reduce, the gradient
+    bucket) on one GPU.  RCCL prints a version banner through C stdio at exit: it must not reach stdout."""
+    env_keep = os.environ.get("VFN_BENCH_FORCE_DIST")
+    os.environ["VFN_BENCH_FORCE_DIST"] = "1"
+    try:
+        d = _run("--workload", "train", "--rays", "1024", "--steps", "5", "--warmup", "2")
+    finally:
+        if env_keep is None:
+            del os.environ["VFN_BENCH_FORCE_DIST"]
+        else:
+            os.environ["VFN_BENCH_FORCE_DIST"] = env_keep
+    assert d["n_gpus"] == 1 and d["bucket_elements"] == 805780 and d["per_rank_rays_per_s"]["dist_world_size"] == 1
+    assert "all-reduced over one flat bucket" in d["config"]["workload"]
