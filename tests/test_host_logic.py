@@ -517,3 +517,68 @@ def test_dense_centre_selection_gives_the_compacted_loss_and_gradient():
         results.append((float(loss), terms["supervision_loss"], normals.grad.clone()))
     (la, sa, ga), (lb, sb, gb) = results
     assert abs(la - lb) < 1e-6 and abs(sa - sb) < 1e-6 and float((ga - gb).abs().max()) < 1e-7
+
+
+def _dp_step_worker(rank, world, port, result_dir):
+    """One data-parallel optimizer step on the CPU: this rank's shard of the fixture's rays through the ORACLE's render + autograd
+    (there is no CPU backend of the product's kernels; the oracle is the checker's compute here), the gradients written into the
+    flat bucket, ONE all-reduce, the clip over the duplicated parameter list, the optimizer's step — everything after the gradients
+    is product code (distributed.shard_bounds / GradientBucket / optim.clip_grad_norm_ / FlatAdam's CPU path)."""
+    from helpers import build_model, load_fixture, oracle_settings
+    from oracle import vfnerf_oracle as O
+    from vf_nerf_amd import optim
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        vdist.init_from_env("gloo")
+    torch.set_num_threads(2)
+    fx, d = load_fixture("c1_perturb")
+    model = build_model(fx, d)
+    if world > 1:
+        vdist.broadcast_parameters(model, src=0)
+    bucket = vdist.GradientBucket(model)
+    lo, hi = vdist.shard_bounds(d["uv"].shape[0], rank, world)
+    pose, uv, K = vdist.shard_rays(d["pose"], d["uv"], d["intrinsics"], rank, world)
+    assert uv.shape[0] == hi - lo
+    vf_sd = {k: v.detach().clone() for k, v in model.vector_field_network.state_dict().items()}
+    rn_sd = {k: v.detach().clone() for k, v in model.rendering_network.state_dict().items()}
+    leaves = {}
+    for net, sd in ((model.vector_field_network, vf_sd), (model.rendering_network, rn_sd)):
+        for name, p in net.named_parameters():
+            sd[name].requires_grad_(True)
+            leaves[id(p)] = sd[name]
+    out = O.render(uv, pose, K, vf_sd, rn_sd, oracle_settings(fx), u_coarse=d["u_coarse"][lo:hi], u_fine=d["u_fine"][lo:hi], u_add=d["u_add"][lo:hi])
+    loss = 2.0 * out["rgb"].abs().mean() + 0.5 * out["depth"].mean() + 0.1 * ((out["normals"].reshape(-1, 3).norm(dim=1) - 1) ** 2).mean()
+    loss.backward()
+    bucket.zero()
+    for p in model.unique_parameters():
+        if id(p) in leaves and leaves[id(p)].grad is not None:
+            p.grad.copy_(leaves[id(p)].grad)
+    bucket.all_reduce_mean()
+    norm = optim.clip_grad_norm_(model.parameters(), model.config.scheduler_config.clip_norm)
+    model.optimizer.step()
+    watched = {k: dict(net.named_parameters())[k].detach().clone()
+               for net, k in ((model.vector_field_network, "layers.5.0.weight"), (model.vector_field_network, "layers.8.weight"),
+                              (model.rendering_network, "layers.2.0.weight"), (model.rendering_network, "layers.4.bias"))}
+    torch.save({"loss": float(loss), "norm": float(norm), "w": watched, "rays": hi - lo}, os.path.join(result_dir, f"dp_w{world}_r{rank}.pt"))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_equals_the_single_process_step():
+    """BASELINE.json configs[3] in small, on the CPU: the rays of a batch sharded over two ranks, one all-reduce (mean) of the flat
+    gradient bucket before the clip, then the optimizer's step — against ONE process taking the same step on the whole batch.  With
+    equal shards the mean of the shard losses is the batch loss, so the clip norm and the weights after the step must agree (both
+    ranks with each other exactly; with the single process up to the order of the sums)."""
+    port = 29700 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as tmp:
+        _dp_step_worker(0, 1, port, tmp)
+        mp.spawn(_dp_step_worker, args=(2, port, tmp), nprocs=2, join=True)
+        one = torch.load(os.path.join(tmp, "dp_w1_r0.pt"))
+        two = [torch.load(os.path.join(tmp, f"dp_w2_r{r}.pt")) for r in range(2)]
+    assert one["rays"] == 48 and [t["rays"] for t in two] == [24, 24]
+    assert abs(0.5 * (two[0]["loss"] + two[1]["loss"]) - one["loss"]) < 1e-6 * max(1.0, abs(one["loss"]))
+    assert abs(two[0]["norm"] - two[1]["norm"]) == 0.0 and abs(two[0]["norm"] - one["norm"]) < 1e-4 * one["norm"]
+    for k in one["w"]:
+        assert torch.equal(two[0]["w"][k], two[1]["w"][k]), k                      # replicas stay identical
+        moved = float((one["w"][k] - two[0]["w"][k]).abs().max())
+        assert moved < 0.05 * 5e-4, (k, moved)                                     # a twentieth of one Adam update (lr 5e-4)
