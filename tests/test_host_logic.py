@@ -571,7 +571,7 @@ def test_two_rank_data_parallel_step_equals_the_single_process_step():
     ranks with each other exactly; with the single process up to the order of the sums)."""
     port = 29700 + (os.getpid() % 2000)
     with tempfile.TemporaryDirectory() as tmp:
-        _dp_step_worker(0, 1, port, tmp)
+        mp.spawn(_dp_step_worker, args=(1, port, tmp), nprocs=1, join=True)      # (own process: the worker pins torch's thread count)
         mp.spawn(_dp_step_worker, args=(2, port, tmp), nprocs=2, join=True)
         one = torch.load(os.path.join(tmp, "dp_w1_r0.pt"))
         two = [torch.load(os.path.join(tmp, f"dp_w2_r{r}.pt")) for r in range(2)]
