@@ -349,17 +349,21 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
             }
     };
 
+    // The pieces of step s + 1 are requested as soon as the registers are free — right after step s's pieces were split into LDS —
+    // and not at the start of step s + 1's own trip: they then have the second K-block of this step, the barrier and the first K-block
+    // of the next step to land in (two K-blocks of 16 MFMAs instead of one; the stream is latency-bound per CU).
     if (s0 < s1) {
         issue(s0);
         stage(0, s0);
+        if (s0 + 1 < s1) issue(s0 + 1);
         __syncthreads();
     }
     for (long long s = s0; s < s1; ++s) {
         const int buf = (int)(s - s0) & 1;
         const bool more = s + 1 < s1;
-        if (more) issue(s + 1);
         mma(buf, 0);
         if (more) stage(buf ^ 1, s + 1);      // the other buffer was last read in step s-1; every wave passed that step's barrier
+        if (s + 2 < s1) issue(s + 2);
         mma(buf, 1);
         __syncthreads();
     }
