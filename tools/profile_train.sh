@@ -1,0 +1,11 @@
+set -u
+R=$(pwd); OUT=gpurun_out/export_train; mkdir -p $R/$OUT $R/gpurun_out/pt
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --workload train"
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/pt/prof_kt -o kt -- $B --steps 15 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pt/prof_fetch -o pf -- $B --steps 6 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pt/prof_write -o pw -- $B --steps 6 > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $R/gpurun_out/pt/pmc_mfma -o pm -- $B --steps 6 > /dev/null 2>&1
+cd $R && python3 tools/export_profiles.py gpurun_out/pt $OUT train > $OUT/export_train.log 2>&1
+rm -rf gpurun_out/pt
+ls $OUT
