@@ -1,3 +1,6 @@
+"""cProfile of 100 training steps (trainer.TrainStep, 1 024 rays x 128): where the HOST time of a step goes, function by function
+(tools/host_profile.py has the per-phase view).  `run_backward` carrying ~1 ms of its own means the host is waiting for the device
+there, i.e. the step is device-bound:    python tools/host_cprofile.py"""
 import sys, cProfile, pstats, torch
 sys.path.insert(0, '.')
 import bench

@@ -1,3 +1,6 @@
+#!/bin/bash
+# rocprofv3 passes over the training step (kernel trace, FETCH_SIZE, WRITE_SIZE, MFMA-busy counters; each in its OWN pass) ->
+# gpurun_out/export_train/{bench_kernel_stats_train.csv, traffic_train.json, pmc_mfma_train.json}:   bash tools/profile_train.sh
 set -u
 R=$(pwd); OUT=gpurun_out/export_train; mkdir -p $R/$OUT $R/gpurun_out/pt
 cd /tmp && export TMPDIR=/tmp
