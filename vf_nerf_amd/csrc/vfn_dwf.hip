@@ -118,6 +118,11 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
     constexpr bool F16 = DM == DY_FRAGF16S;                     // tile-scaled f16 gradient: f16 matrix instruction, one common scale per slab
     constexpr bool A_LO = DM != DY_FRAGBF16 && !F16;            // a 16-bit gradient has no low half
     constexpr bool B_LO = !(F16 && XM == X_FRAG16);             // f16 activations enter an f16 product as they are
+    // the default training form (tile-scaled f16 gradient x f16 activations: 32 KiB of pieces per group and operand pair... 16 KiB each)
+    // takes TWO workspace groups per step: its images are single (no low halves), so a buffer holds 64 rows of each, and a step
+    // requests 64 KiB per workgroup instead of 32 — the stream is latency-bound per CU
+    constexpr bool WIDE = SHAPE == 0 && F16 && XM == X_FRAG16;
+    constexpr int GPS = WIDE ? 2 : 1;                           // groups per step
     constexpr int NA = SHAPE == 0 ? 4 : (SHAPE == 1 ? 2 : 1);   // A / B tiles per wave
     constexpr int NB = SHAPE == 0 ? 4 : 2;
     constexpr int LD_OUT = SHAPE == 1 ? 64 : 256, N_OUT = SHAPE == 2 ? 32 : 256;
@@ -127,7 +132,8 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x, g = blockIdx.x;
-    const long long steps = (a.n_points + F_STEP - 1) / F_STEP;
+    const long long groups_total = (a.n_points + F_STEP - 1) / F_STEP;
+    const long long steps = (groups_total + GPS - 1) / GPS;
     const long long per = (steps + G - 1) / G;
     const long long s0 = g * per, s1 = min(steps, s0 + per);
     const int at0 = SHAPE == 0 ? 4 * (wave >> 1) : (SHAPE == 1 ? 2 * wave : 0);     // first A / B tile of this wave
@@ -153,11 +159,13 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
     }
 
     const long long n_steps = max(0LL, s1 - s0);
+    const long long g_base = s0 * GPS;                                              // first group of the slab
+    const long long n_groups = max(0LL, min(groups_total, s1 * GPS) - g_base);      // groups it holds (the last step may hold one)
     // form 3: the smallest tile exponent of this slab = the common scale of its operands
     int bmin = 255;
     if constexpr (F16) {
-        const unsigned char* gp = static_cast<const unsigned char*>(a.dy) + (size_t)s0 * F_GROUP + F_EXP_OFF;
-        for (long long idx = tid; idx < n_steps * 32; idx += 256) {             // 512 exponent bytes per group = 32 x 16 bytes
+        const unsigned char* gp = static_cast<const unsigned char*>(a.dy) + (size_t)g_base * F_GROUP + F_EXP_OFF;
+        for (long long idx = tid; idx < n_groups * 32; idx += 256) {             // 512 exponent bytes per group = 32 x 16 bytes
             const uint4 e = *reinterpret_cast<const uint4*>(gp + (size_t)(idx >> 5) * F_GROUP + (idx & 31) * 16);
             const unsigned w[4] = {e.x, e.y, e.z, e.w};
 #pragma unroll
@@ -179,44 +187,51 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
         }
     }
     // slab-relative descriptors: groups / rows past the end of the slab read as zero
-    const long long r_base = s0 * F_STEP;
+    const long long r_base = g_base * F_STEP;
     const long long rows_slab = max(0LL, min(n_steps * F_STEP, a.n_points - r_base));
     const __amdgpu_buffer_rsrc_t rs_a = A_FRAG
-        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(static_cast<const unsigned char*>(a.dy)) + (size_t)s0 * F_GROUP, 0,
-                                            (int)(n_steps * F_GROUP), 0x00020000)
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(static_cast<const unsigned char*>(a.dy)) + (size_t)g_base * F_GROUP, 0,
+                                            (int)(n_groups * F_GROUP), 0x00020000)
         : __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(static_cast<const unsigned char*>(a.dy)) + (size_t)r_base * 16, 0,
                                             (int)(rows_slab * 16), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = B_FRAG
-        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(static_cast<const unsigned char*>(a.x)) + (size_t)s0 * F_GROUP, 0,
-                                            (int)(n_steps * F_GROUP), 0x00020000)
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(static_cast<const unsigned char*>(a.x)) + (size_t)g_base * F_GROUP, 0,
+                                            (int)(n_groups * F_GROUP), 0x00020000)
         : __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(static_cast<const unsigned char*>(a.x)) +
                                                 (size_t)r_base * (XM == X_AUX40 ? 160 : 1024), 0,
                                             (int)(rows_slab * (XM == X_AUX40 ? 160 : 1024)), 0x00020000);
 
-    u32x4 ld_a[A_FRAG ? 8 : 1], ld_b[(B_FRAG || XM == X_ROWS32) ? 8 : 2];
-    unsigned ld_e[2] = {0u, 0u};                                // form 3: this lane's exponent bytes of the wave's two tiles (2 wave, 2 wave + 1)
+    u32x4 ld_a[A_FRAG ? 8 * GPS : 1], ld_b[(B_FRAG || XM == X_ROWS32) ? 8 * GPS : 2];
+    unsigned ld_e[2 * GPS] = {};                                // form 3: this lane's exponent bytes of the wave's two tiles (2 wave, 2 wave + 1)
     auto issue = [&](long long s) {
-        const int st = (int)(s - s0);
+        const int st = (int)(s - s0) * GPS;                     // slab-relative group (a group past the slab's end reads as zero)
         if constexpr (F16) {
-            ld_e[0] = __builtin_amdgcn_raw_buffer_load_b8(rs_a, lane, st * F_GROUP + F_EXP_OFF + (2 * wave) * 64, 0);
-            ld_e[1] = __builtin_amdgcn_raw_buffer_load_b8(rs_a, lane, st * F_GROUP + F_EXP_OFF + (2 * wave + 1) * 64, 0);
+#pragma unroll
+            for (int gq = 0; gq < GPS; ++gq) {
+                ld_e[2 * gq + 0] = __builtin_amdgcn_raw_buffer_load_b8(rs_a, lane, (st + gq) * F_GROUP + F_EXP_OFF + (2 * wave) * 64, 0);
+                ld_e[2 * gq + 1] = __builtin_amdgcn_raw_buffer_load_b8(rs_a, lane, (st + gq) * F_GROUP + F_EXP_OFF + (2 * wave + 1) * 64, 0);
+            }
         }
         if constexpr (A_FRAG) {
 #pragma unroll
+            for (int gq = 0; gq < GPS; ++gq)
+#pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int pc = 8 * wave + r;
-                if (DM == DY_FRAG32) ld_a[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, lane * 16, st * F_GROUP + pc * 1024, 0);
-                else { const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rs_a, lane * 8, st * F_GROUP + pc * 512, 0); ld_a[r] = u32x4{h[0], h[1], 0u, 0u}; }
+                if (DM == DY_FRAG32) ld_a[8 * gq + r] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, lane * 16, (st + gq) * F_GROUP + pc * 1024, 0);
+                else { const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rs_a, lane * 8, (st + gq) * F_GROUP + pc * 512, 0); ld_a[8 * gq + r] = u32x4{h[0], h[1], 0u, 0u}; }
             }
         } else {
             ld_a[0] = tid < 32 ? __builtin_amdgcn_raw_buffer_load_b128(rs_a, tid * 16, st * F_STEP * 16, 0) : u32x4{0u, 0u, 0u, 0u};
         }
         if constexpr (B_FRAG) {
 #pragma unroll
+            for (int gq = 0; gq < GPS; ++gq)
+#pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int pc = 8 * wave + r;
-                if (XM == X_FRAG32) ld_b[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, lane * 16, st * F_GROUP + pc * 1024, 0);
-                else { const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rs_b, lane * 8, st * F_GROUP + pc * 512, 0); ld_b[r] = u32x4{h[0], h[1], 0u, 0u}; }
+                if (XM == X_FRAG32) ld_b[8 * gq + r] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, lane * 16, (st + gq) * F_GROUP + pc * 1024, 0);
+                else { const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rs_b, lane * 8, (st + gq) * F_GROUP + pc * 512, 0); ld_b[8 * gq + r] = u32x4{h[0], h[1], 0u, 0u}; }
             }
         } else if constexpr (XM == X_ROWS32) {
 #pragma unroll
@@ -233,33 +248,36 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
     const int gi = lane >> 5, pi = lane & 31;                   // fragment pieces: lane half (column group) and point inside the group
     auto stage = [&](int buf, long long s) {                    // split + write what this thread loaded into the images of `buf`
         unsigned char* base = lds + buf * F_BUF;
-        const bool live = s * F_STEP + pi < a.n_points;         // the last group may be partial: its missing points count as zero
         if constexpr (A_FRAG) {
 #pragma unroll
+            for (int gq = 0; gq < GPS; ++gq)
+#pragma unroll
             for (int r = 0; r < 8; ++r) {
+                const bool live = (s * GPS + gq) * F_STEP + pi < a.n_points;    // the last group may be partial: its missing points count as zero
+                u32x4& la = ld_a[8 * gq + r];
                 const int pc = 8 * wave + r, t = pc >> 2, q = pc & 3;
                 f32x4v v;
-                if (DM == DY_FRAG32) v = __builtin_bit_cast(f32x4v, ld_a[r]);
+                if (DM == DY_FRAG32) v = __builtin_bit_cast(f32x4v, la);
                 else if (F16) {
                     // rescale from the lane's own exponent to the slab's: 2^(bmin - b) <= 1, exact in f16 down to 2^-24
-                    const int b = (int)(ld_e[r >> 2] & 0xffu);
+                    const int b = (int)(ld_e[2 * gq + (r >> 2)] & 0xffu);
                     const int d = b - bmin;
                     const _Float16 f = (b == 255 || d > 24) ? (_Float16)0.f : (_Float16)__builtin_bit_cast(float, (unsigned)(127 - d) << 23);
-                    const half4 hv = __builtin_bit_cast(half4, u32x2{ld_a[r][0], ld_a[r][1]}) * half4{f, f, f, f};
+                    const half4 hv = __builtin_bit_cast(half4, u32x2{la[0], la[1]}) * half4{f, f, f, f};
                     const u32x2 hu = __builtin_bit_cast(u32x2, hv);
-                    ld_a[r][0] = hu[0]; ld_a[r][1] = hu[1];
+                    la[0] = hu[0]; la[1] = hu[1];
                     v = __builtin_convertvector(hv, f32x4v);
                 }
-                else { const u32x2 h = {ld_a[r][0], ld_a[r][1]}; v = __builtin_convertvector(__builtin_bit_cast(bf4, h), f32x4v); }
+                else { const u32x2 h = {la[0], la[1]}; v = __builtin_convertvector(__builtin_bit_cast(bf4, h), f32x4v); }
                 if (!live) v = f32x4v{0.f, 0.f, 0.f, 0.f};
-                const int off = img_off(pi, 8 * t + 2 * q + gi);
+                const int off = img_off(32 * gq + pi, 8 * t + 2 * q + gi);
                 if (DM == DY_FRAG32) {
                     uint2 hi, lo;
                     split4(v, hi, lo);
                     *reinterpret_cast<uint2*>(base + 0 * F_IMG + off) = hi;
                     *reinterpret_cast<uint2*>(base + 1 * F_IMG + off) = lo;
                 } else {
-                    *reinterpret_cast<uint2*>(base + 0 * F_IMG + off) = live ? uint2{ld_a[r][0], ld_a[r][1]} : uint2{0u, 0u};
+                    *reinterpret_cast<uint2*>(base + 0 * F_IMG + off) = live ? uint2{la[0], la[1]} : uint2{0u, 0u};
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) bsum[r][c] += v[c];
@@ -275,15 +293,19 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
         }
         if constexpr (B_FRAG) {
 #pragma unroll
+            for (int gq = 0; gq < GPS; ++gq)
+#pragma unroll
             for (int r = 0; r < 8; ++r) {
+                const bool live = (s * GPS + gq) * F_STEP + pi < a.n_points;
+                const u32x4 lb = ld_b[8 * gq + r];
                 const int pc = 8 * wave + r, t = pc >> 2, q = pc & 3;
                 f32x4v v;
-                if (XM == X_FRAG32) v = __builtin_bit_cast(f32x4v, ld_b[r]);
-                else { const u32x2 h = {ld_b[r][0], ld_b[r][1]}; v = __builtin_convertvector(__builtin_bit_cast(half4, h), f32x4v); }
+                if (XM == X_FRAG32) v = __builtin_bit_cast(f32x4v, lb);
+                else { const u32x2 h = {lb[0], lb[1]}; v = __builtin_convertvector(__builtin_bit_cast(half4, h), f32x4v); }
                 if (!live) v = f32x4v{0.f, 0.f, 0.f, 0.f};
-                const int off = img_off(pi, 8 * t + 2 * q + gi);
+                const int off = img_off(32 * gq + pi, 8 * t + 2 * q + gi);
                 if constexpr (!B_LO) {        // f16 activations under an f16 product: the stored bits
-                    *reinterpret_cast<uint2*>(base + 2 * F_IMG + off) = live ? uint2{ld_b[r][0], ld_b[r][1]} : uint2{0u, 0u};
+                    *reinterpret_cast<uint2*>(base + 2 * F_IMG + off) = live ? uint2{lb[0], lb[1]} : uint2{0u, 0u};
                 } else {
                     uint2 hi, lo;
                     if (F16) split4h(v, hi, lo); else split4(v, hi, lo);
@@ -361,10 +383,12 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
     for (long long s = s0; s < s1; ++s) {
         const int buf = (int)(s - s0) & 1;
         const bool more = s + 1 < s1;
-        mma(buf, 0);
+#pragma unroll
+        for (int kb = 0; kb < GPS; ++kb) mma(buf, kb);
         if (more) stage(buf ^ 1, s + 1);      // the other buffer was last read in step s-1; every wave passed that step's barrier
         if (s + 2 < s1) issue(s + 2);
-        mma(buf, 1);
+#pragma unroll
+        for (int kb = GPS; kb < 2 * GPS; ++kb) mma(buf, kb);
         __syncthreads();
     }
 
