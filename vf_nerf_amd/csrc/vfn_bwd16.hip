@@ -436,8 +436,10 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
             }
             const bf8 a_hi = fh[st & 1], a_lo = fl[st & 1];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, xin.hi[st], acc, 0, 0, 0);
+#ifndef ABL_P1
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, xin.lo[st], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, xin.hi[st], acc, 0, 0, 0);
+#endif
             // -- middle: ring hand-over.  The wave must see ITS pieces of chunk c+1 landed (issued in the previous chunk's second
             // half); the barrier then extends that to everybody's pieces and frees the slot of chunk c-1.  Vector-memory
             // operations retire in issue order (MI355X_MICROARCH.md, s_waitcnt), and the only operations issued AFTER those DMA

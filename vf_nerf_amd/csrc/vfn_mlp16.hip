@@ -640,8 +640,10 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
             const half8 x_hi = st < ACT ? xin.hi[st < ACT ? st : 0] : aux.hi[st >= ACT ? st - ACT : 0];
             const half8 x_lo = st < ACT ? xin.lo[st < ACT ? st : 0] : aux.lo[st >= ACT ? st - ACT : 0];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, x_hi, acc, 0, 0, 0);
+#ifndef ABL_P1
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, x_lo, acc, 0, 0, 0);
             if (!W2 || st >= ACT) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[st % VFN16_FDEPTH], x_hi, acc, 0, 0, 0);
+#endif
             // -- first half: epilogue pairs of the pending tile
 #ifdef ABL_NOEPI
             if (st == 0 && (ch > 0 || PEPI >= 0)) asm volatile("" :: "v"(cy.pend));
