@@ -470,6 +470,9 @@ def train_dtype_label(model) -> str:
     if model.precision != "f16x3":
         return "f32 (exact fp32 MFMA kernels)"
     act, grad = model.activation_storage, model.gradient_storage
+    if getattr(model, "training_products", 3) == 1 and (act, grad, model.workspace_layout) == ("f16", "f16", "fragment"):
+        return ("16-bit-native (opt-in, outside the 1e-4 contract): f16 fwd (one product per K block, 11-bit operands) + bf16 dX chain (one "
+                "product, 8-bit operands) + dW on one f16 product; f32 accumulate; activations stored f16, gradients stored scaled f16")
     dw = {("f16", "f16"): "one f16 product (f16 activations x per-lane-scaled f16 gradients, 11 x 11 bits)",
           ("f16", "bf16"): "two bf16 products (f16 activations as bf16 hi+lo x bf16 gradients)",
           ("f16", "fp32"): "three bf16 products (f16 activations x fp32 gradients)",
@@ -538,7 +541,7 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
            "bucket_allreduce_ms": round(bucket_ms, 4) if bucket_ms is not None else None,
            "bucket_elements": bucket.numel() if bucket is not None else None,
            "activation_storage": model.activation_storage, "gradient_storage": model.gradient_storage,
-           "workspace_layout": model.workspace_layout,
+           "workspace_layout": model.workspace_layout, "training_products": int(getattr(model, "training_products", 3)),
            "networks": "training mode (batch-statistics BatchNorm, layer-at-a-time fp32 kernels)"
            if model.vector_field_network.training else "eval mode (the shipped regime, fused kernels)",
            # per GPU: algorithmic FLOPs of a step / its duration against the f16 / 3 matrix ceiling, and the workspace bytes the
@@ -705,6 +708,9 @@ def main() -> None:
                          "(default: the model's)")
     ap.add_argument("--train-colour-products", type=int, choices=(2, 3), default=None,
                     help="training: products of the colour branch in the activation-saving forward (default: the model's, 3)")
+    ap.add_argument("--train-products", type=int, choices=(1, 3), default=None,
+                    help="training: 1 = the opt-in 16-bit-native mode (one f16 / bf16 product per K block in the saving forward / the dX "
+                         "chain, BASELINE.json configs[2] as written; outside the 1e-4 contract); default 3 (split operands, fp32-equivalent)")
     ap.add_argument("--sorted-fine-pass", action="store_true",
                     help="training: the reference's call structure (gradient-free proposal pass, then the saving forward over all "
                          "sorted samples) instead of one VF evaluation per distinct sample (backward.StoredFinePass)")
@@ -821,6 +827,8 @@ def main() -> None:
         model.reuse_proposal_training = not args.sorted_fine_pass
         if args.train_colour_products:
             model.training_colour_products = args.train_colour_products
+        if args.train_products:
+            model.training_products = args.train_products
         train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync)
         return
 

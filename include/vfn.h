@@ -365,6 +365,10 @@ int vfn_weight_grad_partials_bf16(const float* dy, const float* x, int64_t n_poi
 int64_t vfn_packed_bwd16_size(int32_t net_kind, const vfn_net_geom* geom);                      /* bytes */
 int vfn_pack_weights_bwd16(int32_t net_kind, const vfn_net_geom* geom, const vfn_layer_params* layers, void* packed,
                            void* stream);
+/* The same pack with round_hi != 0: the hi planes hold the bf16 ROUNDING of the folded weights (to nearest even) instead of
+ * their truncation — the pack of the single-product chain (dy_flags bit 4 below), which reads nothing else. */
+int vfn_pack_weights_bwd16_mode(int32_t net_kind, const vfn_net_geom* geom, const vfn_layer_params* layers, int32_t round_hi,
+                                void* packed, void* stream);
 int vfn_mlp_bwd_chain_bf16(const vfn_net_geom* vf_geom, const void* vf_packed_bwd16, const float* vf_head_w,
                            const vfn_net_geom* rn_geom, const void* rn_packed_bwd16, const float* rn_head_w,
                            const float* saved, const uint32_t* masks, float* dy, const float* d_colors, const float* colors,
@@ -374,7 +378,11 @@ int vfn_mlp_bwd_chain_bf16(const vfn_net_geom* vf_geom, const void* vf_packed_bw
 /* The same chain for the FRAGMENT-ORDERED workspace (below): `feats` = the tanh'ed features [M][256] row-major fp32 (the one
  * slot the chain reads as values), `dy` = the gradient slots it writes, dy_flags bit 1: fragment order, bit 2 (with bit 1):
  * as bf16, bit 3 (with bit 1, not with bit 2): as SCALED f16 (vfn_weight_grad_frag, dy_form 3).  dy_flags = 0 and feats =
- * slot 8 of saved[13][M][256] is vfn_mlp_bwd_chain_bf16.  n_points < 2^21 in fragment order. */
+ * slot 8 of saved[13][M][256] is vfn_mlp_bwd_chain_bf16.  n_points < 2^21 in fragment order.
+ * dy_flags bit 4 (with bits 1 and 3; fused or vector-only chains): SINGLE-PRODUCT arithmetic — one bf16 product per K-block on
+ * round-to-nearest operands (8 significant bits each) instead of three on split ones (16): the chain of the opt-in 16-bit-native
+ * training mode (BASELINE.json configs[2], "bf16 MFMA MLPs" as written; vf_nerf_amd: model.training_products = 1).  Takes packs
+ * made by vfn_pack_weights_bwd16_mode(round_hi = 1).  Outside the 1e-3 gradient bound of the default chain by construction. */
 int vfn_mlp_bwd_chain_bf16_ws(const vfn_net_geom* vf_geom, const void* vf_packed_bwd16, const float* vf_head_w,
                               const vfn_net_geom* rn_geom, const void* rn_packed_bwd16, const float* rn_head_w,
                               const float* feats, const uint32_t* masks, void* dy, int32_t dy_flags, const float* d_colors,
@@ -556,7 +564,12 @@ int vfn_sample_sphere_shell(int64_t n, float r_min, float r_max, const float* ce
  * are stored as f16 — 256 values in the first 512 bytes of every 1 KiB row, the row stride does not change — which halves
  * what the forward writes and the weight-gradient kernels read, at 11 instead of 24 significant bits in the activations that
  * multiply dY (BASELINE.json configs[2] trains on bf16 matrix cores); the tanh'ed feature slot (8) stays fp32 row-major.
- * Bit 1: the ReLU slots are FRAGMENT-ORDERED (see vfn_weight_grad_frag; slot stride ceil(M/32) * 32 KiB, n_points < 2^21). */
+ * Bit 1: the ReLU slots are FRAGMENT-ORDERED (see vfn_weight_grad_frag; slot stride ceil(M/32) * 32 KiB, n_points < 2^21).
+ * Bit 2 (vfn_vf_mlp16_fwd_train[_at] with with_features = 0; the fused launch takes colour_products = 1 instead): SINGLE-PRODUCT
+ * arithmetic — every K-block is ONE f16 product of the operands' f16 roundings (11 significant bits each, fp32 accumulation)
+ * instead of three on split operands: the forward of the opt-in 16-bit-native training mode (BASELINE.json configs[2], "bf16
+ * MFMA MLPs" as written — f16 keeps three more bits at the same matrix rate).  Same pack (its hi planes), same workspace; the
+ * outputs are ~1e-3 from the fp32 ones, i.e. OUTSIDE the 1e-4 contract: never a default, never used by gradient-free renders. */
 int vfn_vf_mlp16_fwd_train(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
                            int32_t with_features, float* out_vec, float* saved, float* save_aux_vf, uint32_t* save_masks,
                            int32_t save_f16, void* stream);
@@ -574,7 +587,8 @@ int vfn_vf_render_fused16_fwd_train(const vfn_net_geom* vf_geom, const void* vf_
  * samples (vector_field_nerf.py:252-256) and, after the fine sampler, the new samples (:294-297) fill ONE workspace in storage
  * order, which the chain and the weight-gradient kernels then walk once.  ws_first % 32 == 0 in fragment order.
  * colour_products: 3, or 2 = the colour branch of THIS forward on two products (vfn_vf_render_fused16_products): the loss sees
- * colours 2e-5 off, the saved activations move by less than their f16 storage rounds them, the backward is unchanged. */
+ * colours 2e-5 off, the saved activations move by less than their f16 storage rounds them, the backward is unchanged;
+ * 1 = ONE product everywhere (see save_f16 bit 2 above). */
 int vfn_vf_render_fused16_fwd_train_at(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
                                        const void* rn_packed16, const float* points, const float* ray_dirs,
                                        int64_t n_points, int32_t samples_per_ray, float* normals, float* colors,

@@ -70,18 +70,21 @@ def _packed_bwd(net) -> torch.Tensor:
     return cache[1]
 
 
-def _packed_bwd16(net) -> torch.Tensor:
-    """Transposed bf16-split pack for the bf16 dX chain (csrc/vfn_bwd16.hip), cached on the parameter versions."""
+def _packed_bwd16(net, rounded: bool = False) -> torch.Tensor:
+    """Transposed bf16-split pack for the bf16 dX chain (csrc/vfn_bwd16.hip), cached on the parameter versions.  ``rounded``: the
+    pack of the single-product chain (hi planes rounded to nearest; its own cache)."""
     tensors, key = net._pack_key()
     dev = tensors[0].device
-    cache = getattr(net, "_packed_bwd16_cache", None)
+    name = "_packed_bwd16r_cache" if rounded else "_packed_bwd16_cache"
+    cache = getattr(net, name, None)
     if cache is None or cache[0] != key or cache[1].device != dev:
         geom = net.geometry()
         buf = torch.empty(lib.packed_bwd16_size(net._kind, geom), dtype=torch.uint8, device=dev)
         with torch.no_grad():
-            lib.pack_weights_bwd16(net._kind, geom, [{k: v.detach() for k, v in d.items()} for d in net._layer_tensors()], buf)
-        net._packed_bwd16_cache = (key, buf)
-        cache = net._packed_bwd16_cache
+            lib.pack_weights_bwd16(net._kind, geom, [{k: v.detach() for k, v in d.items()} for d in net._layer_tensors()], buf,
+                                   round_hi=rounded)
+        cache = (key, buf)
+        setattr(net, name, cache)
     return cache[1]
 
 
@@ -282,10 +285,16 @@ class _Workspace:
     ``f16``: the ReLU slots hold f16 values (``VectorFieldNerf.activation_storage``); slot 8 of a VF net, the tanh'ed features,
     is row-major fp32 [M,256] (``feats``).  ``dy16``: the chain stores the pre-activation gradients in 16 bits —
     "bf16", or "f16" = f16 of the values scaled per lane and tile with the exponents behind each group's pieces (csrc/vfn_dwf.hip,
-    "dY form 3") (``VectorFieldNerf.gradient_storage``).  Exact-fp32 path: row-major [slots][M][256] fp32."""
+    "dY form 3") (``VectorFieldNerf.gradient_storage``).  Exact-fp32 path: row-major [slots][M][256] fp32.
+    ``dy16 = "f16p1"`` (``VectorFieldNerf.training_products = 1`` on the default storages): the same workspace as "f16", filled and
+    walked by the SINGLE-PRODUCT forward and chain (``single``)."""
 
     def __init__(self, m: int, n_slots: int, dev, f16: bool = False, frag: bool = False, dy16=False) -> None:
         dy16 = {True: "bf16", False: None, None: None, "fp32": None}.get(dy16, dy16) if frag else None
+        self.single = dy16 == "f16p1"
+        if self.single:
+            assert f16 and frag
+            dy16 = "f16"
         assert dy16 in (None, "bf16", "f16"), dy16
         self.m, self.n_slots, self.f16, self.frag, self.dy16 = m, n_slots, f16, frag, dy16
         if frag:
@@ -307,10 +316,10 @@ class _Workspace:
         return self.saved[h].reshape(-1)[: self.m * HID].view(self.m, HID)
 
     def fwd_flags(self) -> int:
-        return (lib.WS_F16 if self.f16 else 0) | (lib.WS_FRAG if self.frag else 0)
+        return (lib.WS_F16 if self.f16 else 0) | (lib.WS_FRAG if self.frag else 0) | (lib.WS_P1 if self.single else 0)
 
     def dy_flags(self) -> int:
-        return (lib.DY_FRAG if self.frag else 0) | {None: 0, "bf16": lib.DY_BF16, "f16": lib.DY_F16S}[self.dy16]
+        return (lib.DY_FRAG if self.frag else 0) | {None: 0, "bf16": lib.DY_BF16, "f16": lib.DY_F16S}[self.dy16] | (lib.DY_P1 if self.single else 0)
 
     def frag_forms(self):
         """(dy_form, x_form) of lib.weight_grad_frag for this workspace, or None for the row-major layouts."""
@@ -343,8 +352,10 @@ def _storage(owner, fast: bool):
     if not fast:
         return False, False, None
     grads = getattr(owner, "gradient_storage", "fp32")
-    return (getattr(owner, "activation_storage", "fp32") == "f16", getattr(owner, "workspace_layout", "fragment") == "fragment",
-            None if grads == "fp32" else grads)
+    f16, frag = getattr(owner, "activation_storage", "fp32") == "f16", getattr(owner, "workspace_layout", "fragment") == "fragment"
+    if getattr(owner, "training_products", 3) == 1 and f16 and frag and grads == "f16":
+        grads = "f16p1"        # single-product forward and chain on the default storages (_Workspace.single)
+    return f16, frag, None if grads == "fp32" else grads
 
 
 # ------------------------------------------------------------------------------------------------
@@ -369,7 +380,7 @@ class _FinePass(torch.autograd.Function):
             normals, colors = lib.vf_render_fused16_fwd_train(vf.geometry(), vf.packed16_weights(), rn.geometry(),
                                                               rn.packed16_weights(), pts.reshape(-1, 3), ray_dirs, s_t,
                                                               ws.saved, ws.aux_vf, ws.aux_rn, ws.masks, save_f16=ws.fwd_flags(),
-                                                              colour_products=_train_products(model))
+                                                              colour_products=1 if ws.single else _train_products(model))
         else:
             normals, colors = lib.vf_render_fused_fwd_train(vf.geometry(), vf.packed_weights(), rn.geometry(),
                                                             rn.packed_weights(), pts.reshape(-1, 3), ray_dirs, s_t,
@@ -411,7 +422,7 @@ class _FinePass(torch.autograd.Function):
         dz_vec = torch.empty(m, 4, device=dev)
         fast = ctx.fast
         if fast:
-            lib.mlp_bwd_chain_bf16_ws(vf.geometry(), _packed_bwd16(vf), _head_rows(vf), rn.geometry(), _packed_bwd16(rn),
+            lib.mlp_bwd_chain_bf16_ws(vf.geometry(), _packed_bwd16(vf, ws.single), _head_rows(vf), rn.geometry(), _packed_bwd16(rn, ws.single),
                                       _head_rows(rn), ws.feats(vf_h - 1), ws.masks, dy, ws.dy_flags(), dc, colors, dn, normals, None, 3, m,
                                       dz_rgb, dz_vec)
         else:
@@ -586,7 +597,7 @@ class StoredFinePass:
         lib.vf_render_fused16_fwd_train(vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(), pts.reshape(-1, 3),
                                         ray_dirs, per_ray, ws.saved, ws.aux_vf, ws.aux_rn, ws.masks, save_f16=ws.fwd_flags(),
                                         ws_first=first, ws_points=self.ws_points, normals=self.normals_s[first:first + count],
-                                        colors=self.colors_s[first:first + count], colour_products=_train_products(model))
+                                        colors=self.colors_s[first:first + count], colour_products=1 if ws.single else _train_products(model))
 
     def proposal(self, pts_c, ray_dirs) -> torch.Tensor:
         """Saving forward on the proposal samples (generation order); returns their normals [N*S_c, 3]."""
@@ -654,7 +665,7 @@ class _StoredFinePassFn(torch.autograd.Function):
             dy, dz_vec = pool.gradients()
         else:
             dy, dz_vec = ws.new_dy(), torch.empty(m, 4, device=dev)
-        lib.mlp_bwd_chain_bf16_ws(vf.geometry(), _packed_bwd16(vf), _head_rows(vf), rn.geometry(), _packed_bwd16(rn), _head_rows(rn),
+        lib.mlp_bwd_chain_bf16_ws(vf.geometry(), _packed_bwd16(vf, ws.single), _head_rows(vf), rn.geometry(), _packed_bwd16(rn, ws.single), _head_rows(rn),
                                   ws.feats(vf_h - 1), ws.masks, dy, ws.dy_flags(), dc_s, sp.colors_s, dn_s, sp.normals_s, None, 3, m, dz_rgb, dz_vec,
                                   ws_first=0, ws_points=sp.ws_points)
         feats = ws.feats(vf_h - 1)
@@ -697,6 +708,8 @@ class _VFForward(torch.autograd.Function):
         fast = getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3() and m < _F16_TRAIN_MAX_POINTS
         bwd_fast = fast and getattr(net, "backward_kernels", "auto") != "fp32"
         f16, frag, dy16 = _storage(net, bwd_fast)
+        if dy16 == "f16p1" and cols > 3:
+            dy16 = "f16"           # the single-product kernels evaluate the vector columns only: a [vector | features] forward keeps three
         # a render() under autograd earlier in this step left room in its workspace: append (StepWorkspace)
         pool = getattr(net, "_step_ws", None)
         if pool is not None and pool.ws is not None and bwd_fast and frag and m > 0 and pool.storage == (f16, dy16) and \
@@ -741,7 +754,7 @@ class _VFForward(torch.autograd.Function):
             if mp != m:
                 d_out = torch.cat([d_out, d_out.new_zeros(mp - m, cols)])
             dy, dz_all = pool.gradients()
-            lib.mlp_bwd_chain_bf16_ws(net.geometry(), _packed_bwd16(net), _head_rows(net), None, None, None, pool.ws.feats(vf_h - 1), pool.ws.masks,
+            lib.mlp_bwd_chain_bf16_ws(net.geometry(), _packed_bwd16(net, pool.ws.single), _head_rows(net), None, None, None, pool.ws.feats(vf_h - 1), pool.ws.masks,
                                       dy, pool.ws.dy_flags(), None, None, d_out, out, _offset_view(d_out, 3) if cols > 3 else None, cols, mp, None,
                                       dz_all, ws_first=first, ws_points=pool.total)
             pool.mark_done(first, mp, cols > 3)
@@ -753,7 +766,7 @@ class _VFForward(torch.autograd.Function):
             d_feats = _offset_view(d_out, 3)
         fast = ctx.fast
         if fast:
-            lib.mlp_bwd_chain_bf16_ws(net.geometry(), _packed_bwd16(net), _head_rows(net), None, None, None, ws.feats(vf_h - 1), ws.masks,
+            lib.mlp_bwd_chain_bf16_ws(net.geometry(), _packed_bwd16(net, ws.single), _head_rows(net), None, None, None, ws.feats(vf_h - 1), ws.masks,
                                       dy, ws.dy_flags(), None, None, d_out, out, d_feats, cols, m, None, dz_vec)
         else:
             lib.mlp_bwd_chain(net.geometry(), net.packed_weights(), _packed_bwd(net), None, None, None, ws.saved, dy,

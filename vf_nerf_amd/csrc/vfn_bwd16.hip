@@ -34,7 +34,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-enum : int { BM_VEC = 0, BM_FULL = 1, BM_FUSED = 3, BM_F16S = 16 };     // bit 0: the feature block's step is present; bit 1: rendering net; bit 4: scaled f16 gradients
+enum : int { BM_VEC = 0, BM_FULL = 1, BM_FUSED = 3, BM_F16S = 16, BM_P1 = 32 };     // bit 0: the feature block's step is present; bit 1: rendering net; bit 4: scaled f16 gradients
+// bit 5 (BM_P1): ONE bf16 product per K-block, round-to-nearest hi halves only (8 significant bits per operand) — the chain of the
+// opt-in 16-bit-native training mode (BASELINE.json configs[2], "bf16 MFMA MLPs"); only the hi planes of the pack are fetched.
 enum : int { MASK_RELU = 0, MASK_TANH = 1 };
 
 // ------------------------------------------------------------------------------------------------
@@ -82,6 +84,7 @@ struct PackTArgs {
     int32_t n_entries;
     uint32_t total_words;
     uint32_t* out;
+    int32_t rne;          // hi plane rounded to nearest even (single-product chain) instead of truncated (three-product chain: w - hi exact)
 };
 
 __global__ void vfn_pack_bwd16_kernel(PackTArgs a) {
@@ -108,7 +111,8 @@ __global__ void vfn_pack_bwd16_kernel(PackTArgs a) {
             w = e.w[(size_t)row * e.in_dim + e.col_off + k] * e.scale;
             if (e.bn_w) w *= e.bn_w[row] / sqrtf(e.bn_var[row] + 1e-5f);
         }
-        const unsigned u = __builtin_bit_cast(unsigned, w);
+        unsigned u = __builtin_bit_cast(unsigned, w);
+        if (a.rne) u = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)w) << 16;
         const float hi = __builtin_bit_cast(float, u & 0xffff0000u);
         const __bf16 lo = (__bf16)(w - hi);
         halves[q] = part ? __builtin_bit_cast(unsigned short, lo) : (unsigned short)(u >> 16);
@@ -210,18 +214,27 @@ __device__ __forceinline__ void dma_piece(const Pipe& p, int blk, int lane) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(NET ? p.rn_w : p.vf_w, (lds_void*)(p.lds + SLOT * BW_SLOT + blk * 64), 16, lane * 16,
                                              (OFF_KB + blk) * 1024, 0, 0);
 }
-template <int MODE, int C>
+// single-product launches fetch the hi planes (even blocks) only.  Every wave issues the SAME number of pieces (the hand-over's
+// vmcnt immediate counts them): a chunk whose hi planes do not divide by the wave count repeats its first blocks (same bytes, same place).
+constexpr int p1_pieces(int kb) { return ((kb / 2 + BW_WAVES - 1) / BW_WAVES) * BW_WAVES; }
+__device__ __forceinline__ int p1_block(int idx, int kb) { return 2 * (idx < kb / 2 ? idx : idx - kb / 2); }
+template <int MODE, int C, bool P1 = false>
 __device__ __forceinline__ void dma_chunk(const Pipe& p, int wave, int lane) {
     constexpr ChunkD d = chunk_of(MODE, C);
+    if constexpr (P1) {
+#pragma unroll
+        for (int i = 0; i * BW_WAVES < p1_pieces(d.kb); ++i) dma_piece<d.net, d.off_kb, C % BW_RING>(p, p1_block(wave + BW_WAVES * i, d.kb), lane);
+    } else {
 #pragma unroll
     for (int i = 0; i * BW_WAVES < d.kb; ++i)
         if (wave + BW_WAVES * i < d.kb) dma_piece<d.net, d.off_kb, C % BW_RING>(p, wave + BW_WAVES * i, lane);
+    }
 }
-template <int MODE, int C>
+template <int MODE, int C, bool P1 = false>
 __device__ __forceinline__ void prefetch_chunk(Carry& cy, const Pipe& p, int lane) {
     const uint4* cb = p.lds + (C % BW_RING) * BW_SLOT;
     cy.fh0 = __builtin_bit_cast(bf8, cb[0 * 64 + lane]);
-    cy.fl0 = __builtin_bit_cast(bf8, cb[1 * 64 + lane]);
+    if constexpr (!P1) cy.fl0 = __builtin_bit_cast(bf8, cb[1 * 64 + lane]);
 }
 
 // workspace access: registers 4q..4q+3 of a tile = columns 32 TILE + 8 q + 4 (lane >> 5) .. +3 of this lane's point
@@ -323,7 +336,7 @@ __device__ __forceinline__ void store_tile(const Pipe& p, const f32x16& v) {
 // One register pair of a finished tile: (+ head rank-3 update) * activation derivative -> pend (for the store) and the
 // (hi, lo) bf16 halves of element pair (j, j+1) of an operand block.
 //   HEAD: -1 none, 0 vector head, 1 rgb head; dz: this point's 3 head pre-activation gradients
-template <int MASK, int HEAD, int TILE>
+template <int MASK, int HEAD, int TILE, bool P1 = false>
 __device__ __forceinline__ void epi_pair(f32x16& pend, const f32x4v (&mask)[4], int pr, const Pipe& p, const float (&dz)[3], int g,
                                          bf8& hi, bf8& lo, int j) {
     float v0 = pend[2 * pr], v1 = pend[2 * pr + 1];
@@ -339,6 +352,14 @@ __device__ __forceinline__ void epi_pair(f32x16& pend, const f32x4v (&mask)[4], 
     if (MASK == MASK_RELU) { v0 = s0 > 0.f ? v0 : 0.f; v1 = s1 > 0.f ? v1 : 0.f; }
     else { v0 *= 1.0f - s0 * s0; v1 *= 1.0f - s1 * s1; }
     pend[2 * pr] = v0; pend[2 * pr + 1] = v1;
+    if constexpr (P1) {          // single product: the bf16 rounding (to nearest even) is the operand
+        typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+        const f32x2v v = {v0, v1};
+        u32x4v hv = __builtin_bit_cast(u32x4v, hi);
+        hv[j >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+        hi = __builtin_bit_cast(bf8, hv);
+        return;
+    }
     const unsigned u0 = __builtin_bit_cast(unsigned, v0), u1 = __builtin_bit_cast(unsigned, v1);
     const unsigned hp = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
     const f32x2v r = {v0 - __builtin_bit_cast(float, u0 & 0xffff0000u), v1 - __builtin_bit_cast(float, u1 & 0xffff0000u)};
@@ -350,26 +371,27 @@ __device__ __forceinline__ void epi_pair(f32x16& pend, const f32x4v (&mask)[4], 
 }
 
 // A whole tile outside the pipelined loop (the tiles a chain starts from, and the very last one).
-template <int SLOT, int TILE, int MASK, int HEAD, bool SPLIT>
+template <int SLOT, int TILE, int MASK, int HEAD, bool SPLIT, bool P1 = false>
 __device__ __forceinline__ void finish_tile_with(f32x16& v, const f32x4v (&mask)[4], const Pipe& p, const float (&dz)[3], int g, X16& xout) {
     bf8 hi[2], lo[2];
 #pragma unroll
-    for (int pr = 0; pr < 8; ++pr) epi_pair<MASK, HEAD, TILE>(v, mask, pr, p, dz, g, hi[pr >> 2], lo[pr >> 2], (pr & 3) * 2);
+    for (int pr = 0; pr < 8; ++pr) epi_pair<MASK, HEAD, TILE, P1>(v, mask, pr, p, dz, g, hi[pr >> 2], lo[pr >> 2], (pr & 3) * 2);
     store_tile<SLOT, TILE>(p, v);
     if (SPLIT) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            asm volatile("" : "+a"(hi[s])); asm volatile("" : "+a"(lo[s]));
-            xout.hi[2 * TILE + s] = hi[s]; xout.lo[2 * TILE + s] = lo[s];
+            asm volatile("" : "+a"(hi[s]));
+            xout.hi[2 * TILE + s] = hi[s];
+            if constexpr (!P1) { asm volatile("" : "+a"(lo[s])); xout.lo[2 * TILE + s] = lo[s]; }
         }
     }
 }
-template <int SLOT, int TILE, int MASK, int HEAD, bool SPLIT>
+template <int SLOT, int TILE, int MASK, int HEAD, bool SPLIT, bool P1 = false>
 __device__ __forceinline__ void finish_tile(f32x16& v, const Pipe& p, const float (&dz)[3], int g, X16& xout) {
     f32x4v mask[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) mask[q] = mask_group<SLOT, TILE, MASK>(p, q);
-    finish_tile_with<SLOT, TILE, MASK, HEAD, SPLIT>(v, mask, p, dz, g, xout);
+    finish_tile_with<SLOT, TILE, MASK, HEAD, SPLIT, P1>(v, mask, p, dz, g, xout);
 }
 // The eight tiles a chain starts from: ALL their saved activations are requested first (32 loads in one batch); with the
 // loads inside the per-tile code the register pins of finish_tile (volatile asm) keep hipcc from hoisting them and every
@@ -393,6 +415,7 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
                                        const float (&dzc)[3], int wave, int lane) {
     constexpr int MODE = MX & 3;
     constexpr bool F16S = (MX & BM_F16S) != 0;
+    constexpr bool P1 = (MX & BM_P1) != 0;
     constexpr int H = NB / 2;                         // hand-over after step H-1
 #if BW16_EARLY_EPI
     // The pending tile's epilogue runs in the FIRST half of the chunk (its masks are register-resident sign bits; only the
@@ -419,7 +442,8 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         bf8 fh[2], fl[2];
-        fh[0] = cy.fh0; fl[0] = cy.fl0;
+        fh[0] = cy.fh0;
+        if constexpr (!P1) fl[0] = cy.fl0;
         bf8 ehi[2], elo[2];
         // scaled f16 gradients: the pending tile is encoded in the shadow of this tile's second half (scale at step H, one
         // register quad per step after it), so that the last step only issues the stores
@@ -432,13 +456,16 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
         for (int st = 0; st < NB; ++st) {
             if (st + 1 < NB) {
                 fh[(st + 1) & 1] = __builtin_bit_cast(bf8, cb[(2 * (st + 1)) * 64 + lane]);
-                fl[(st + 1) & 1] = __builtin_bit_cast(bf8, cb[(2 * (st + 1) + 1) * 64 + lane]);
+                if constexpr (!P1) fl[(st + 1) & 1] = __builtin_bit_cast(bf8, cb[(2 * (st + 1) + 1) * 64 + lane]);
             }
-            const bf8 a_hi = fh[st & 1], a_lo = fl[st & 1];
+            const bf8 a_hi = fh[st & 1];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, xin.hi[st], acc, 0, 0, 0);
 #ifndef ABL_P1
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, xin.lo[st], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, xin.hi[st], acc, 0, 0, 0);
+            if constexpr (!P1) {
+                const bf8 a_lo = fl[st & 1];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, xin.lo[st], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, xin.hi[st], acc, 0, 0, 0);
+            }
 #endif
             // -- middle: ring hand-over.  The wave must see ITS pieces of chunk c+1 landed (issued in the previous chunk's second
             // half); the barrier then extends that to everybody's pieces and frees the slot of chunk c-1.  Vector-memory
@@ -452,8 +479,9 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
                 // of a chunk (every chunk but the launch's first has a pending tile), and with a four-slot ring the pieces of
                 // chunk c+2 between them.  (The tanh tiles' value loads sit among them too: uncounted, so the wait is merely
                 // stricter there.)
+                constexpr int ahead_kb = chunk_of(MODE, C - 1 + BW_RING - 1 > 0 ? C - 1 + BW_RING - 1 : 0).kb;
                 constexpr int young = (C >= 1 ? 4 * (C - 1 > 0) : 0) +
-                                      (BW_RING > 3 ? (C >= 1 ? chunk_of(MODE, C - 1 + BW_RING - 1).kb / BW_WAVES : 0) + (C >= 2 ? 4 * (C - 2 > 0) : 0) : 0);
+                                      (BW_RING > 3 ? (C >= 1 ? (P1 ? p1_pieces(ahead_kb) : ahead_kb) / BW_WAVES : 0) + (C >= 2 ? 4 * (C - 2 > 0) : 0) : 0);
                 static_assert(young < 64, "vmcnt is a 6-bit field");
                 if constexpr (young == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(young) : "memory");
@@ -467,13 +495,13 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
 #pragma unroll
                 for (int pr = (st - EPI0) * 8 / E; pr < (st - EPI0 + 1) * 8 / E; ++pr) {
                     const int sblk = pr >> 2, j = (pr & 3) * 2;
-                    if (ch > 0) epi_pair<MASK, HEAD, (ch > 0 ? ch - 1 : 0)>(cy.pend, cy.mask, pr, p, HEAD == 1 ? dzc : dzv, g, ehi[sblk], elo[sblk], j);
-                    else epi_pair<PMASK, PHEAD, (PT >= 0 ? PT : 0)>(cy.pend, cy.mask, pr, p, PHEAD == 1 ? dzc : dzv, g, ehi[sblk], elo[sblk], j);
+                    if (ch > 0) epi_pair<MASK, HEAD, (ch > 0 ? ch - 1 : 0), P1>(cy.pend, cy.mask, pr, p, HEAD == 1 ? dzc : dzv, g, ehi[sblk], elo[sblk], j);
+                    else epi_pair<PMASK, PHEAD, (PT >= 0 ? PT : 0), P1>(cy.pend, cy.mask, pr, p, PHEAD == 1 ? dzc : dzv, g, ehi[sblk], elo[sblk], j);
                     if ((pr & 3) == 3) {
                         asm volatile("" : "+a"(ehi[sblk]));
-                        asm volatile("" : "+a"(elo[sblk]));
-                        if (ch > 0) { xout.hi[2 * (ch > 0 ? ch - 1 : 0) + sblk] = ehi[sblk]; xout.lo[2 * (ch > 0 ? ch - 1 : 0) + sblk] = elo[sblk]; }
-                        else { xpend.hi[2 * (PT >= 0 ? PT : 0) + sblk] = ehi[sblk]; xpend.lo[2 * (PT >= 0 ? PT : 0) + sblk] = elo[sblk]; }
+                        if constexpr (!P1) asm volatile("" : "+a"(elo[sblk]));
+                        if (ch > 0) { xout.hi[2 * (ch > 0 ? ch - 1 : 0) + sblk] = ehi[sblk]; if constexpr (!P1) xout.lo[2 * (ch > 0 ? ch - 1 : 0) + sblk] = elo[sblk]; }
+                        else { xpend.hi[2 * (PT >= 0 ? PT : 0) + sblk] = ehi[sblk]; if constexpr (!P1) xpend.lo[2 * (PT >= 0 ? PT : 0) + sblk] = elo[sblk]; }
                     }
                 }
             }
@@ -492,14 +520,20 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
                 if (st > H && st <= H + 4) eq[st - H - 1] = pack_quad_f16s(cy.pend, st - H - 1, esc);
             }
             if (st >= H && st < H + 4) mnext[st - H] = mask_group<OSLOT, ch, MASK>(p, st - H);
-            if (st >= H && ddma.kb > 0) {
+            if (P1 && st >= H && ddma.kb > 0) {
+                constexpr int NP = p1_pieces(ddma.kb) / BW_WAVES;        // pieces per wave
+#pragma unroll
+                for (int i = (st - H) * NP / DSTEPS; i < (st - H + 1) * NP / DSTEPS; ++i)
+                    dma_piece<ddma.net, ddma.off_kb, (C + BW_RING - 1) % BW_RING>(p, p1_block(wave + BW_WAVES * i, ddma.kb), lane);
+            }
+            if (!P1 && st >= H && ddma.kb > 0) {
 #pragma unroll
                 for (int i = (st - H) * BW_PMAX / DSTEPS; i < (st - H + 1) * BW_PMAX / DSTEPS; ++i) {
                     if (BW_WAVES * i + BW_WAVES <= ddma.kb) dma_piece<ddma.net, ddma.off_kb, (C + BW_RING - 1) % BW_RING>(p, wave + BW_WAVES * i, lane);
                     else if (BW_WAVES * i < ddma.kb) { if (wave + BW_WAVES * i < ddma.kb) dma_piece<ddma.net, ddma.off_kb, (C + BW_RING - 1) % BW_RING>(p, wave + BW_WAVES * i, lane); }
                 }
             }
-            if (st == NB - 1 && dnext.kb > 0) prefetch_chunk<MODE, (dnext.kb > 0 ? C + 1 : C)>(cy, p, lane);
+            if (st == NB - 1 && dnext.kb > 0) prefetch_chunk<MODE, (dnext.kb > 0 ? C + 1 : C), P1>(cy, p, lane);
 #if BW16_LATE_STORES
             // the pending tile's dY: the LAST vector-memory instructions of the chunk (see the hand-over)
             if (st == NB - 1 && (ch > 0 || PSLOT >= 0)) {
@@ -524,6 +558,7 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
 template <int MX>
 __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
     constexpr int MODE = MX & 3;
+    constexpr bool P1 = (MX & BM_P1) != 0;
     __shared__ __attribute__((aligned(16))) uint4 s_ring[BW_RING * BW_SLOT + 2 * 3 * 256 / 4];
     float* s_heads = reinterpret_cast<float*>(s_ring + BW_RING * BW_SLOT);
     const int tid = threadIdx.x;
@@ -588,9 +623,9 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
             }
         });
     }
-    dma_chunk<MODE, 0>(p, wave, lane);
-    dma_chunk<MODE, 1>(p, wave, lane);
-    if (BW_RING > 3) dma_chunk<MODE, 2>(p, wave, lane);
+    dma_chunk<MODE, 0, P1>(p, wave, lane);
+    dma_chunk<MODE, 1, P1>(p, wave, lane);
+    if (BW_RING > 3) dma_chunk<MODE, 2, P1>(p, wave, lane);
     __syncthreads();                       // head tables visible (this also waits for the two chunks: once, harmless)
 
     // ---- the tiles the chain starts from: no matrix product, just the head update / the caller's gradient ----
@@ -604,7 +639,7 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
             f32x16 v;
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = 0.f;
-            finish_tile_with<12, t, MASK_RELU, 1, true>(v, mk[t], p, dzc, g, xa);
+            finish_tile_with<12, t, MASK_RELU, 1, true, P1>(v, mk[t], p, dzc, g, xa);
         });
     } else if constexpr (MODE == BM_FULL) {
         // dZ_f = dF * (1 - F^2) straight from the caller's gradient (slot 8)
@@ -618,7 +653,7 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
                 const int k = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * g;
                 v[r] = in ? a.d_feats[m * a.vec_stride + k] : 0.f;
             }
-            finish_tile_with<8, t, MASK_TANH, -1, true>(v, mk[t], p, dzv, g, xa);
+            finish_tile_with<8, t, MASK_TANH, -1, true, P1>(v, mk[t], p, dzv, g, xa);
         });
     } else {
         // vector-only: gradient wrt the last plain hidden output = rank-3 update from the vector head (slot 7)
@@ -629,7 +664,7 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
             f32x16 v;
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = 0.f;
-            finish_tile_with<7, t, MASK_RELU, 0, true>(v, mk[t], p, dzv, g, xa);
+            finish_tile_with<7, t, MASK_RELU, 0, true, P1>(v, mk[t], p, dzv, g, xa);
         });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunks 0 and 1 landed, start tiles stored
@@ -637,7 +672,7 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
     Carry cy;
 #pragma unroll
     for (int r = 0; r < 16; ++r) cy.pend[r] = 0.f;
-    prefetch_chunk<MODE, 0>(cy, p, lane);
+    prefetch_chunk<MODE, 0, P1>(cy, p, lane);
 
     constexpr int R = MASK_RELU, T = MASK_TANH;
     // step16<MODE, C0, NB, NCH, OSLOT, MASK, HEAD, PSLOT, PT, PMASK, PHEAD>(xin, xout, xpend, ...)
@@ -687,6 +722,11 @@ extern "C" int64_t vfn_packed_bwd16_size(int32_t net_kind, const vfn_net_geom* g
 
 extern "C" int vfn_pack_weights_bwd16(int32_t net_kind, const vfn_net_geom* geom, const vfn_layer_params* layers,
                                       void* packed, void* stream) {
+    return vfn_pack_weights_bwd16_mode(net_kind, geom, layers, 0, packed, stream);
+}
+
+extern "C" int vfn_pack_weights_bwd16_mode(int32_t net_kind, const vfn_net_geom* geom, const vfn_layer_params* layers, int32_t round_hi,
+                                           void* packed, void* stream) {
     VFN_REQUIRE(geom && layers && packed, "vfn_pack_weights_bwd16: NULL argument");
     int rc = check_shipped(net_kind, geom, "vfn_pack_weights_bwd16");
     if (rc != VFN_OK) return rc;
@@ -715,6 +755,7 @@ extern "C" int vfn_pack_weights_bwd16(int32_t net_kind, const vfn_net_geom* geom
     }
     a.total_words = (uint32_t)(net_kind == VFN_NET_VF ? vf_pack_kb() : rn_pack_kb()) * 256u;
     a.out = (uint32_t*)packed;
+    a.rne = round_hi ? 1 : 0;
     hipLaunchKernelGGL(vfn_pack_bwd16_kernel, dim3((a.total_words + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_pack_weights_bwd16");
 }
@@ -774,7 +815,11 @@ extern "C" int vfn_mlp_bwd_chain_bf16_ws_at(const vfn_net_geom* vf_geom, const v
     a.ws_first = ws_first; a.ws_points = ws_points;
     const unsigned blocks = (unsigned)((n_points + BW_PTS - 1) / BW_PTS);
     hipStream_t s = (hipStream_t)stream;
-    if (dy_flags & 8) {
+    if (dy_flags & 16) {       // single-product chain (opt-in 16-bit-native training): scaled f16 gradients, fused or vector-only
+        VFN_REQUIRE((dy_flags & 8) && !(d_feats && !fused), "vfn_mlp_bwd_chain_bf16: the single-product chain takes scaled f16 gradients and no feature gradient");
+        if (fused) hipLaunchKernelGGL(vfn_bwd16_kernel<BM_FUSED | BM_F16S | BM_P1>, dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(vfn_bwd16_kernel<BM_VEC | BM_F16S | BM_P1>, dim3(blocks), dim3(256), 0, s, a);
+    } else if (dy_flags & 8) {
         if (fused) hipLaunchKernelGGL(vfn_bwd16_kernel<BM_FUSED | BM_F16S>, dim3(blocks), dim3(256), 0, s, a);
         else if (d_feats) hipLaunchKernelGGL(vfn_bwd16_kernel<BM_FULL | BM_F16S>, dim3(blocks), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(vfn_bwd16_kernel<BM_VEC | BM_F16S>, dim3(blocks), dim3(256), 0, s, a);

@@ -290,7 +290,11 @@ enum : int { EPI_RELU = 0, EPI_TANH = 1, EPI_HEAD_TANH = 2, EPI_HEAD_SIGMOID = 3
 //   split.  The vector head and everything before it keep three products, so normals, density, weights and depth are
 //   unchanged to the bit; colours move by <= 2e-5 on the reference's golden outputs (profiles/r02/ab_colour_products.txt),
 //   inside the 1e-4 contract.  The same pack serves both: a two-product chunk DMAs and reads only its hi planes.
-enum : int { M16_FEAT = 1, M16_RENDER = 2, M16_TRAIN = 4, M16_BLKOUT = 8, M16_BLKIN = 16, M16_C2 = 32,
+//   bit 6 = ONE product per K-block everywhere, w_hi x_hi: plain f16 arithmetic with fp32 accumulation (11 significant bits per
+//   operand) — the opt-in 16-bit-native TRAINING forward (BASELINE.json configs[2], "bf16 MFMA MLPs" as written; f16 has three
+//   more bits at the same matrix rate and the range guard covers its exponent range).  Same pack: only the hi planes and the
+//   bias block of a chunk are fetched.  Outside the 1e-4 contract by construction; never the default.
+enum : int { M16_FEAT = 1, M16_RENDER = 2, M16_TRAIN = 4, M16_BLKOUT = 8, M16_BLKIN = 16, M16_C2 = 32, M16_P1 = 64,
              M16_VF_VEC = 0, M16_FUSED = M16_FEAT | M16_RENDER, M16_VF_BLK = M16_FEAT | M16_BLKOUT, M16_RN_BLK = M16_RENDER | M16_BLKIN,
              M16_VF_VEC_TRAIN = M16_TRAIN, M16_VF_FULL_TRAIN = M16_FEAT | M16_TRAIN, M16_FUSED_TRAIN = M16_FUSED | M16_TRAIN };
 
@@ -347,6 +351,7 @@ constexpr int rn_first_chunk(int mode) { return (mode & M16_BLKIN) ? 0 : 72; }
 // (the ENCODING K-blocks of such a chunk — the rendering net's first layer reads the point, PE(view direction) and the normal
 // there — keep three products: a weight's rounding error is multiplied by its input, and a point coordinate is not bounded)
 constexpr bool chunk_two(int mode, int c) { return (mode & M16_C2) && !(mode & M16_BLKIN) && c >= 63 && c != 71; }
+constexpr bool mode_one(int mode) { return (mode & M16_P1) != 0; }
 
 struct Mlp16Args {
     const uint4* vf_w;
@@ -463,9 +468,16 @@ __device__ __forceinline__ void dma_piece(const Pipe16& p, int blk, int lane) {
 template <int MODE, int C>
 __device__ __forceinline__ void dma_chunk(const Pipe16& p, int wave, int lane) {     // whole chunk at once (prologue only)
     constexpr ChunkD d = chunk_of(MODE, C);
+    if constexpr (mode_one(MODE)) {      // hi planes (even blocks) and the bias block (the last one)
+        constexpr int NKB = (d.kb - 1) / 2;
+#pragma unroll
+        for (int i = 0; i * VFN16_WAVES < NKB + 1; ++i)
+            if (wave + VFN16_WAVES * i < NKB + 1) dma_piece<d.net, d.off_kb, C % 3>(p, 2 * (wave + VFN16_WAVES * i), lane);
+    } else {
 #pragma unroll
     for (int i = 0; i * VFN16_WAVES < d.kb; ++i)
         if (wave + VFN16_WAVES * i < d.kb) dma_piece<d.net, d.off_kb, C % 3>(p, wave + VFN16_WAVES * i, lane);
+    }
 }
 
 template <int MODE, int C>
@@ -477,11 +489,11 @@ __device__ __forceinline__ void prefetch_chunk(Carry16& cy, const Pipe16& p, int
 #pragma unroll
     for (int q = 0; q < 4; ++q) { cy.bias[q] = b0[q]; cy.bias[4 + q] = b1[q]; cy.bias[8 + q] = b2[q]; cy.bias[12 + q] = b3[q]; }
     cy.fh0 = __builtin_bit_cast(half8, cb[0 * 64 + lane]);
-    if (!chunk_two(MODE, C)) cy.fl0 = __builtin_bit_cast(half8, cb[1 * 64 + lane]);     // (no two-product chunk starts with an encoding block)
+    if (!chunk_two(MODE, C) && !mode_one(MODE)) cy.fl0 = __builtin_bit_cast(half8, cb[1 * 64 + lane]);     // (no two-product chunk starts with an encoding block)
 }
 
 // Two accumulator values -> (hi, lo) halves of element pair (j, j+1) of an operand block.
-template <int EPI, bool KEEP>
+template <int EPI, bool KEEP, bool LO = true>
 __device__ __forceinline__ void epi_pair(f32x16& pend, unsigned long long& sat, int pr, half8& hi, half8& lo, int j) {
     float v0 = pend[2 * pr], v1 = pend[2 * pr + 1];
     // one compare per pair into a SCALAR accumulator (a vector accumulator carried through the pipelined loop made hipcc spill)
@@ -496,9 +508,15 @@ __device__ __forceinline__ void epi_pair(f32x16& pend, unsigned long long& sat, 
         v0 = fminf(fmaxf(v0, 0.f), VFN16_CLAMP); v1 = fminf(fmaxf(v1, 0.f), VFN16_CLAMP);
     }
     else { v0 = tanh_exp(v0) * VFN16_XSCALE; v1 = tanh_exp(v1) * VFN16_XSCALE; }
-    _Float16 h0, h1, l0, l1;
-    split2(v0, v1, h0, h1, l0, l1);
-    hi[j] = h0; hi[j + 1] = h1; lo[j] = l0; lo[j + 1] = l1;
+    if constexpr (LO) {
+        _Float16 h0, h1, l0, l1;
+        split2(v0, v1, h0, h1, l0, l1);
+        hi[j] = h0; hi[j + 1] = h1; lo[j] = l0; lo[j + 1] = l1;
+    } else {                              // single-product mode: the f16 rounding is the operand
+        const float2v v = {v0, v1};
+        const half2v h = __builtin_convertvector(v, half2v);
+        hi[j] = h[0]; hi[j + 1] = h[1];
+    }
     if (KEEP) { pend[2 * pr] = v0 * (1.0f / VFN16_XSCALE); pend[2 * pr + 1] = v1 * (1.0f / VFN16_XSCALE); }   // training: the value the backward reads
 }
 
@@ -609,11 +627,13 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
         constexpr int C = C0 + ch;
         constexpr ChunkD dcur = chunk_of(MODE, C), dnext = chunk_of(MODE, C + 1), ddma = chunk_of(MODE, C + 2);
         static_assert(dcur.kb == 2 * NKB + 1, "layer shape and chunk table disagree");
+        constexpr bool P1 = mode_one(MODE);                // one product per K-block: hi planes only, no lo halves anywhere
         constexpr bool W2 = chunk_two(MODE, C);            // this tile: two products, hi planes of the weights only
-        constexpr bool D2 = chunk_two(MODE, C + 2);        // the chunk being fetched: hi planes (even blocks) + the bias block
+        constexpr bool D2 = chunk_two(MODE, C + 2) || P1;  // the chunk being fetched: hi planes (even blocks) + the bias block
         constexpr int DNKB = (ddma.kb - 1) / 2;             // pieces of a two-product chunk: hi planes, lo planes of the encoding blocks, bias
-        constexpr int DPIECES = D2 ? DNKB + ddma.aux + 1 : ddma.kb;
+        constexpr int DPIECES = P1 ? DNKB + 1 : (D2 ? DNKB + ddma.aux + 1 : ddma.kb);
         auto piece_blk = [&](int idx) -> int {
+            if (P1) return idx < DNKB ? 2 * idx : 2 * DNKB;
             if (!D2) return idx;
             if (ddma.aux == 0) return 2 * idx;
             return idx < DNKB ? 2 * idx : (idx < DNKB + ddma.aux ? 2 * (idx - ddma.aux) + 1 : 2 * DNKB);
@@ -623,10 +643,10 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
         f32x16 acc = cy.bias;
         half8 fh[VFN16_FDEPTH], fl[VFN16_FDEPTH];
         fh[0] = cy.fh0;
-        if (!W2 || ACT == 0) fl[0] = cy.fl0;
+        if (!P1 && (!W2 || ACT == 0)) fl[0] = cy.fl0;
         if (VFN16_FDEPTH == 3 && NKB > 1) {
             fh[1] = __builtin_bit_cast(half8, cb[2 * 64 + lane]);
-            if (!W2) fl[1] = __builtin_bit_cast(half8, cb[3 * 64 + lane]);
+            if (!W2 && !P1) fl[1] = __builtin_bit_cast(half8, cb[3 * 64 + lane]);
         }
         half8 ehi[2], elo[2];
 #pragma unroll
@@ -634,15 +654,17 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
             constexpr int AHEAD = VFN16_FDEPTH - 1;
             if (st + AHEAD < NKB) {
                 fh[(st + AHEAD) % VFN16_FDEPTH] = __builtin_bit_cast(half8, cb[(2 * (st + AHEAD)) * 64 + lane]);
-                if (!W2 || st + AHEAD >= ACT) fl[(st + AHEAD) % VFN16_FDEPTH] = __builtin_bit_cast(half8, cb[(2 * (st + AHEAD) + 1) * 64 + lane]);
+                if (!P1 && (!W2 || st + AHEAD >= ACT)) fl[(st + AHEAD) % VFN16_FDEPTH] = __builtin_bit_cast(half8, cb[(2 * (st + AHEAD) + 1) * 64 + lane]);
             }
             const half8 a_hi = fh[st % VFN16_FDEPTH];
             const half8 x_hi = st < ACT ? xin.hi[st < ACT ? st : 0] : aux.hi[st >= ACT ? st - ACT : 0];
             const half8 x_lo = st < ACT ? xin.lo[st < ACT ? st : 0] : aux.lo[st >= ACT ? st - ACT : 0];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, x_hi, acc, 0, 0, 0);
 #ifndef ABL_P1
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, x_lo, acc, 0, 0, 0);
-            if (!W2 || st >= ACT) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[st % VFN16_FDEPTH], x_hi, acc, 0, 0, 0);
+            if constexpr (!P1) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, x_lo, acc, 0, 0, 0);
+                if (!W2 || st >= ACT) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[st % VFN16_FDEPTH], x_hi, acc, 0, 0, 0);
+            }
 #endif
             // -- first half: epilogue pairs of the pending tile
 #ifdef ABL_NOEPI
@@ -654,16 +676,17 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
 #pragma unroll
                 for (int pr = st * 8 / E; pr < (st + 1) * 8 / E; ++pr) {
                     const int sblk = pr >> 2, j = (pr & 3) * 2;
-                    if (ch > 0) epi_pair<EPI, TRAIN>(cy.pend, cy.sat, pr, ehi[sblk], elo[sblk], j);
-                    else epi_pair<(PEPI >= 0 ? PEPI : 0), TRAIN>(cy.pend, cy.sat, pr, ehi[sblk], elo[sblk], j);
+                    if (ch > 0) epi_pair<EPI, TRAIN, !P1>(cy.pend, cy.sat, pr, ehi[sblk], elo[sblk], j);
+                    else epi_pair<(PEPI >= 0 ? PEPI : 0), TRAIN, !P1>(cy.pend, cy.sat, pr, ehi[sblk], elo[sblk], j);
                     if ((pr & 3) == 3) {
                         asm volatile("" : "+a"(ehi[sblk]));   // operands live in AGPRs (MFMA reads them there)
-                        asm volatile("" : "+a"(elo[sblk]));
-                        if (ch > 0) { xout.hi[2 * (ch > 0 ? ch - 1 : 0) + sblk] = ehi[sblk]; xout.lo[2 * (ch > 0 ? ch - 1 : 0) + sblk] = elo[sblk]; }
-                        else { xpend.hi[PKB + sblk] = ehi[sblk]; xpend.lo[PKB + sblk] = elo[sblk]; }
+                        if constexpr (!P1) asm volatile("" : "+a"(elo[sblk]));
+                        if (ch > 0) { xout.hi[2 * (ch > 0 ? ch - 1 : 0) + sblk] = ehi[sblk]; if constexpr (!P1) xout.lo[2 * (ch > 0 ? ch - 1 : 0) + sblk] = elo[sblk]; }
+                        else { xpend.hi[PKB + sblk] = ehi[sblk]; if constexpr (!P1) xpend.lo[PKB + sblk] = elo[sblk]; }
                     }
                 }
 #ifndef VFN16_NOGROUPS
+                if constexpr (!P1) {
                 // one MFMA, then its share of the epilogue in that MFMA's shadow
                 __builtin_amdgcn_sched_group_barrier(0x100, W2 ? 1 : 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -673,6 +696,7 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
                 if (!W2) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, VFN16_EPI_PER_MFMA, 0);
+                }
                 }
 #endif
             }
@@ -1259,7 +1283,11 @@ extern "C" int vfn_vf_mlp16_fwd_train_at(const vfn_net_geom* geom, const void* p
     a.ws_first = ws_first; a.ws_points = ws_points;
     a.status = t_status_word;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
-    if (with_features) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_FULL_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (save_f16 & 4) {        // single-product arithmetic (opt-in 16-bit-native training, vector columns only)
+        VFN_REQUIRE(!with_features, "vfn_vf_mlp16_fwd_train: the single-product forward computes the vector columns only");
+        hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_VEC_TRAIN | M16_P1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    else if (with_features) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_FULL_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_VEC_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_mlp16_fwd_train");
 }
@@ -1305,8 +1333,9 @@ extern "C" int vfn_vf_render_fused16_fwd_train_at(const vfn_net_geom* vf_geom, c
     a.saved = saved; a.save_aux_vf = save_aux_vf; a.save_aux_rn = save_aux_rn; a.save_masks = save_masks; a.save_f16 = save_f16 & 3;
     a.status = t_status_word;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
-    VFN_REQUIRE(colour_products == 2 || colour_products == 3, "vfn_vf_render_fused16_fwd_train: colour_products must be 2 or 3 (got %d)", colour_products);
-    if (colour_products == 2) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED_TRAIN | M16_C2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    VFN_REQUIRE(colour_products >= 1 && colour_products <= 3, "vfn_vf_render_fused16_fwd_train: colour_products must be 1, 2 or 3 (got %d)", colour_products);
+    if (colour_products == 1) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED_TRAIN | M16_P1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);   // one product EVERYWHERE
+    else if (colour_products == 2) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED_TRAIN | M16_C2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_render_fused16_fwd_train");
 }

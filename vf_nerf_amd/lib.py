@@ -27,7 +27,7 @@ EXPORTS = (
     "vfn_ray_density_weights_bwd", "vfn_pack16_size", "vfn_pack16_weights", "vfn_vf_mlp16_fwd",
     "vfn_vf_render_fused16_fwd", "vfn_vf_mlp16_fwd_train", "vfn_vf_render_fused16_fwd_train",
     "vfn_vf_feat16_fwd", "vfn_render16_from_blocks", "vfn_grid_divergence", "vfn_grid_smooth_axis",
-    "vfn_grid_unify_direction", "vfn_grid_comb_format", "vfn_grid_unify_direction_sides", "vfn_grid_comb_format_sides", "vfn_weight_grad_partials_bf16", "vfn_unfold_weight_grads", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_mlp_bwd_chain_bf16",
+    "vfn_grid_unify_direction", "vfn_grid_comb_format", "vfn_grid_unify_direction_sides", "vfn_grid_comb_format_sides", "vfn_weight_grad_partials_bf16", "vfn_unfold_weight_grads", "vfn_packed_bwd16_size", "vfn_pack_weights_bwd16", "vfn_pack_weights_bwd16_mode", "vfn_mlp_bwd_chain_bf16",
     "vfn_linear_rows", "vfn_linear_rows_stat_parts", "vfn_bstat_row_parts", "vfn_colsum_finish", "vfn_bstat_finalize",
     "vfn_bstat_relu_rows", "vfn_bstat_relu_bwd_sums", "vfn_bstat_relu_bwd_rows", "vfn_act_bwd_rows", "vfn_embed_rows",
     "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_vf_render_fused16_products", "vfn_net_weight_grads_frag", "vfn_net_weight_grads_frag_part", "vfn_net_weight_grads_scratch_bytes", "vfn_vf_render_fused16_fwd_train_at",
@@ -584,9 +584,10 @@ def packed_bwd16_size(kind: int, geom: NetGeom) -> int:
     return int(n)
 
 
-def pack_weights_bwd16(kind: int, geom: NetGeom, layers: Sequence[dict], packed: torch.Tensor) -> None:
-    _check(load().vfn_pack_weights_bwd16(kind, C.byref(geom), _layer_array(geom, layers), _ptr(packed, "packed", torch.uint8),
-                                         _stream()), "vfn_pack_weights_bwd16")
+def pack_weights_bwd16(kind: int, geom: NetGeom, layers: Sequence[dict], packed: torch.Tensor, round_hi: bool = False) -> None:
+    """``round_hi``: hi planes rounded to nearest instead of truncated — the pack of the single-product chain (DY_P1)."""
+    _check(load().vfn_pack_weights_bwd16_mode(kind, C.byref(geom), _layer_array(geom, layers), C.c_int32(int(bool(round_hi))),
+                                              _ptr(packed, "packed", torch.uint8), _stream()), "vfn_pack_weights_bwd16")
 
 
 def relu_sign_words(saved: torch.Tensor) -> torch.Tensor:
@@ -633,8 +634,8 @@ def mlp_bwd_chain_bf16(vf_geom, vf_packed_bwd16, vf_head_w, rn_geom, rn_packed_b
 # ------------------------------------------------------------------------------------------------
 # fragment-ordered training workspace (include/vfn.h, "FRAGMENT-ORDERED training workspace")
 # ------------------------------------------------------------------------------------------------
-WS_F16, WS_FRAG = 1, 2                       # flags of the f16x3 training forwards (save_f16 argument)
-DY_FRAG, DY_BF16, DY_F16S = 2, 4, 8          # flags of the bf16 chain (dy_flags argument): fragment order, bf16, scaled f16
+WS_F16, WS_FRAG, WS_P1 = 1, 2, 4             # flags of the f16x3 training forwards (save_f16 argument); WS_P1: single-product arithmetic
+DY_FRAG, DY_BF16, DY_F16S, DY_P1 = 2, 4, 8, 16   # flags of the bf16 chain (dy_flags argument): fragment order, bf16, scaled f16, single product
 DYF_FRAG32, DYF_FRAGBF16, DYF_DZ4, DYF_FRAGF16S = 0, 1, 2, 3  # operand forms of weight_grad_frag (3: tile-scaled f16)
 XF_FRAG32, XF_FRAG16, XF_ROWS32, XF_AUX40 = 0, 1, 2, 3
 GROUP_FLOATS = 8192                          # one group of 32 points = 32 KiB

@@ -138,6 +138,12 @@ class VectorFieldNerf:
         # gradient stays within 1e-3 of the exact-fp32 kernels' (5.3e-4 measured at 4096 x 128, tests/test_hip_fullsize.py; fp32
         # storage: 3.4e-4) and the training step takes 10.0 instead of 11.4 ms.
         self.gradient_storage = "f16"
+        # f16 / bf16 matrix products per fp32-equivalent product in the TRAINING kernels.  3 (default): split operands, fp32-equivalent
+        # forward (the reference's loss values to 1e-4) and a dX chain inside 1e-3.  1 (opt-in; needs the default storages above):
+        # BASELINE.json configs[2] "bf16 MFMA MLPs" as written — the saving forward multiplies f16 roundings (11 bits per operand),
+        # the chain bf16 roundings (8 bits), one product per K-block, fp32 accumulation; gradient-free renders are NOT affected.
+        # Outside the 1e-4 / 1e-3 contracts by construction; what it costs in convergence: profiles/r03/train_curve_p1.json.
+        self.training_products = 3
         # Inference with the f16x3 kernels evaluates the VF net once per distinct sample: the proposal samples keep their
         # vector columns and feature operand blocks, only the N_f new samples are evaluated after the fine sampler, and the
         # rendering net gathers (the reference evaluates the proposal samples twice; same per-sample arithmetic, identical
@@ -307,6 +313,17 @@ class VectorFieldNerf:
             raise ValueError(f"workspace_layout must be 'fragment' or 'rows', got {value!r}")
         self._workspace_layout = value
         self.vector_field_network.workspace_layout = value
+
+    @property
+    def training_products(self) -> int:
+        return self._training_products
+
+    @training_products.setter
+    def training_products(self, value: int) -> None:
+        if value not in (1, 3):
+            raise ValueError(f"training_products must be 3 (fp32-equivalent split products) or 1 (16-bit-native), got {value!r}")
+        self._training_products = int(value)
+        self.vector_field_network.training_products = int(value)
 
     @property
     def gradient_storage(self) -> str:

@@ -80,7 +80,7 @@ class _PackedMLP(nn.Module):
     def _apply(self, fn, *args, **kwargs):
         """.to() / .cuda() / .float() replace buffer tensors: drop the cached tensor list and the packs built from it."""
         out = super()._apply(fn, *args, **kwargs)
-        for name in ("_pack_tensors", "_packed16_cache", "_packed_bwd_cache", "_packed_bwd16_cache"):
+        for name in ("_pack_tensors", "_packed16_cache", "_packed_bwd_cache", "_packed_bwd16_cache", "_packed_bwd16r_cache"):
             if hasattr(self, name):
                 delattr(self, name)
         self._packed, self._packed_key = None, None
