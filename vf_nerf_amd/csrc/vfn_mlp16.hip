@@ -352,6 +352,32 @@ constexpr int rn_first_chunk(int mode) { return (mode & M16_BLKIN) ? 0 : 72; }
 // there — keep three products: a weight's rounding error is multiplied by its input, and a point coordinate is not bounded)
 constexpr bool chunk_two(int mode, int c) { return (mode & M16_C2) && !(mode & M16_BLKIN) && c >= 63 && c != 71; }
 constexpr bool mode_one(int mode) { return (mode & M16_P1) != 0; }
+// The weight ring.  Split modes: three slots of one whole chunk (<= 39 KiB) each, a chunk's pieces requested two chunks ahead.  The
+// single-product modes fetch the hi planes and the bias block only and store them COMPACTLY (K-block s at block s, bias behind them:
+// <= 20 KiB), so five slots fit where three did and a chunk is requested FOUR ahead: with a third of the matrix work per chunk the
+// stores of a finished tile need more than the chunk and a half a three-slot ring gives them to retire (the hand-over's vmcnt leaves
+// the stores of the last three chunks in flight instead of one's; 942 -> see DESIGN.md section 3, Backward 5).
+#ifndef VFN16_P1_RING
+#define VFN16_P1_RING 5
+#endif
+#define VFN16_P1_SLOT_KB 20
+constexpr int ring_of(int mode) { return mode_one(mode) ? VFN16_P1_RING : 3; }
+constexpr int slot_u4(int mode) { return mode_one(mode) ? VFN16_P1_SLOT_KB * 64 : VFN16_MAX_CHUNK_KB * 64; }      // uint4 elements per slot
+constexpr int slot_base(int mode, int c) { return (c % ring_of(mode)) * slot_u4(mode); }
+static_assert(VFN16_P1_RING * VFN16_P1_SLOT_KB <= 3 * VFN16_MAX_CHUNK_KB, "the single-product ring must fit into the split modes' ring");
+// single-product training launches: vector-memory operations a wave has issued AFTER its pieces of chunk c+1 when it reaches the
+// hand-over of chunk c.  Chunk k issues, in this order, the pieces of chunk k+RING-1 and then the four stores of its pending tile
+// (none in the launch's first chunk and in the rendering net's first: no pending tile there); the first RING-1 chunks are requested
+// in the prologue.  Pieces per wave: at least floor(pieces / waves).
+constexpr int stores_of(int mode, int c) { return (c == 0 || ((mode & M16_RENDER) && c == rn_first_chunk(mode))) ? 0 : 4; }
+constexpr int young_ops(int mode, int c) {
+    const int ring = ring_of(mode);
+    int n = 0;
+    for (int k = (c - ring + 2 > 0 ? c - ring + 2 : 0); k < c; ++k) n += stores_of(mode, k);
+    for (int j = 2; j <= ring - 2; ++j)
+        if (c + j >= ring - 1 && chunk_of(mode, c + j).kb > 0) n += (((chunk_of(mode, c + j).kb - 1) / 2 + 1) / VFN16_WAVES);
+    return n;
+}
 
 struct Mlp16Args {
     const uint4* vf_w;
@@ -460,9 +486,9 @@ __device__ __forceinline__ void split2(float a, float b, _Float16& h0, _Float16&
 __device__ __forceinline__ float tanh_exp(float v) { return 1.0f - 2.0f / (1.0f + expf(2.0f * v)); }
 
 // One 1-KiB LDS-DMA piece: block `blk` of chunk descriptor D into ring slot SLOT.
-template <int NET, int OFF_KB, int SLOT>
-__device__ __forceinline__ void dma_piece(const Pipe16& p, int blk, int lane) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(NET ? p.rn_w : p.vf_w, (lds_void*)(p.lds + SLOT * VFN16_SLOT + blk * 64), 16,
+template <int NET, int OFF_KB, int LDS_U4>
+__device__ __forceinline__ void dma_piece(const Pipe16& p, int blk, int lane, int dst_blk = -1) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(NET ? p.rn_w : p.vf_w, (lds_void*)(p.lds + LDS_U4 + (dst_blk < 0 ? blk : dst_blk) * 64), 16,
                                              lane * 16, (OFF_KB + blk) * 1024, 0, 0);
 }
 template <int MODE, int C>
@@ -472,19 +498,19 @@ __device__ __forceinline__ void dma_chunk(const Pipe16& p, int wave, int lane) {
         constexpr int NKB = (d.kb - 1) / 2;
 #pragma unroll
         for (int i = 0; i * VFN16_WAVES < NKB + 1; ++i)
-            if (wave + VFN16_WAVES * i < NKB + 1) dma_piece<d.net, d.off_kb, C % 3>(p, 2 * (wave + VFN16_WAVES * i), lane);
+            if (wave + VFN16_WAVES * i < NKB + 1) dma_piece<d.net, d.off_kb, slot_base(MODE, C)>(p, 2 * (wave + VFN16_WAVES * i), lane, wave + VFN16_WAVES * i);
     } else {
 #pragma unroll
     for (int i = 0; i * VFN16_WAVES < d.kb; ++i)
-        if (wave + VFN16_WAVES * i < d.kb) dma_piece<d.net, d.off_kb, C % 3>(p, wave + VFN16_WAVES * i, lane);
+        if (wave + VFN16_WAVES * i < d.kb) dma_piece<d.net, d.off_kb, slot_base(MODE, C)>(p, wave + VFN16_WAVES * i, lane);
     }
 }
 
 template <int MODE, int C>
 __device__ __forceinline__ void prefetch_chunk(Carry16& cy, const Pipe16& p, int lane) {
     constexpr ChunkD d = chunk_of(MODE, C);
-    const uint4* cb = p.lds + (C % 3) * VFN16_SLOT;
-    const f32x4v* bb = reinterpret_cast<const f32x4v*>(cb + (d.kb - 1) * 64) + (lane >> 5) * 4;
+    const uint4* cb = p.lds + slot_base(MODE, C);
+    const f32x4v* bb = reinterpret_cast<const f32x4v*>(cb + (mode_one(MODE) ? (d.kb - 1) / 2 : d.kb - 1) * 64) + (lane >> 5) * 4;
     const f32x4v b0 = bb[0], b1 = bb[1], b2 = bb[2], b3 = bb[3];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { cy.bias[q] = b0[q]; cy.bias[4 + q] = b1[q]; cy.bias[8 + q] = b2[q]; cy.bias[12 + q] = b3[q]; }
@@ -625,11 +651,12 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
     static_for<NCH>([&](auto ich) {
         constexpr int ch = decltype(ich)::value;
         constexpr int C = C0 + ch;
-        constexpr ChunkD dcur = chunk_of(MODE, C), dnext = chunk_of(MODE, C + 1), ddma = chunk_of(MODE, C + 2);
+        constexpr int RING = ring_of(MODE);
+        constexpr ChunkD dcur = chunk_of(MODE, C), dnext = chunk_of(MODE, C + 1), ddma = chunk_of(MODE, C + RING - 1);
         static_assert(dcur.kb == 2 * NKB + 1, "layer shape and chunk table disagree");
         constexpr bool P1 = mode_one(MODE);                // one product per K-block: hi planes only, no lo halves anywhere
         constexpr bool W2 = chunk_two(MODE, C);            // this tile: two products, hi planes of the weights only
-        constexpr bool D2 = chunk_two(MODE, C + 2) || P1;  // the chunk being fetched: hi planes (even blocks) + the bias block
+        constexpr bool D2 = chunk_two(MODE, C + RING - 1) || P1;  // the chunk being fetched: hi planes (even blocks) + the bias block
         constexpr int DNKB = (ddma.kb - 1) / 2;             // pieces of a two-product chunk: hi planes, lo planes of the encoding blocks, bias
         constexpr int DPIECES = P1 ? DNKB + 1 : (D2 ? DNKB + ddma.aux + 1 : ddma.kb);
         auto piece_blk = [&](int idx) -> int {
@@ -639,13 +666,14 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
             return idx < DNKB ? 2 * idx : (idx < DNKB + ddma.aux ? 2 * (idx - ddma.aux) + 1 : 2 * DNKB);
         };
         constexpr int PM = D2 ? (DPIECES + VFN16_WAVES - 1) / VFN16_WAVES : PMAX;
-        const uint4* cb = p.lds + (C % 3) * VFN16_SLOT;
+        const uint4* cb = p.lds + slot_base(MODE, C);
+        constexpr int FB = P1 ? 1 : 2;                      // blocks per K step in the slot (compact hi planes / hi + lo)
         f32x16 acc = cy.bias;
         half8 fh[VFN16_FDEPTH], fl[VFN16_FDEPTH];
         fh[0] = cy.fh0;
         if (!P1 && (!W2 || ACT == 0)) fl[0] = cy.fl0;
         if (VFN16_FDEPTH == 3 && NKB > 1) {
-            fh[1] = __builtin_bit_cast(half8, cb[2 * 64 + lane]);
+            fh[1] = __builtin_bit_cast(half8, cb[FB * 64 + lane]);
             if (!W2 && !P1) fl[1] = __builtin_bit_cast(half8, cb[3 * 64 + lane]);
         }
         half8 ehi[2], elo[2];
@@ -653,7 +681,7 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
         for (int st = 0; st < NKB; ++st) {
             constexpr int AHEAD = VFN16_FDEPTH - 1;
             if (st + AHEAD < NKB) {
-                fh[(st + AHEAD) % VFN16_FDEPTH] = __builtin_bit_cast(half8, cb[(2 * (st + AHEAD)) * 64 + lane]);
+                fh[(st + AHEAD) % VFN16_FDEPTH] = __builtin_bit_cast(half8, cb[(FB * (st + AHEAD)) * 64 + lane]);
                 if (!P1 && (!W2 || st + AHEAD >= ACT)) fl[(st + AHEAD) % VFN16_FDEPTH] = __builtin_bit_cast(half8, cb[(2 * (st + AHEAD) + 1) * 64 + lane]);
             }
             const half8 a_hi = fh[st % VFN16_FDEPTH];
@@ -710,6 +738,14 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
                 // late stores: the previous chunk ended with the four stores of its pending tile (every chunk but the launch's
                 // first and the one after a layer that starts without a pending tile); everything older — the DMA pieces of
                 // chunk c+1 among it — has landed once at most those four are outstanding
+                if constexpr (P1 && LATE) {
+                    // five-slot ring: younger than this wave's pieces of chunk c+1 are the stores of the last RING-2 chunks and the
+                    // pieces of chunks c+2 .. c+RING-2 between them (lower bounds: a smaller immediate only waits for more)
+                    constexpr int young = young_ops(MODE, C);
+                    static_assert(young < 64, "vmcnt is a 6-bit field");
+                    if constexpr (young == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(young) : "memory");
+                } else
                 if (LATE && C > 0 && (ch == 0 || ch > 1 || PEPI >= 0)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -720,8 +756,8 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
             if (st >= H && st < H + DST && ddma.kb > 0) {
 #pragma unroll
                 for (int i = (st - H) * PM / DST; i < (st - H + 1) * PM / DST; ++i) {
-                    if (VFN16_WAVES * i + VFN16_WAVES <= DPIECES) dma_piece<ddma.net, ddma.off_kb, (C + 2) % 3>(p, piece_blk(wave + VFN16_WAVES * i), lane);
-                    else if (VFN16_WAVES * i < DPIECES) { if (wave + VFN16_WAVES * i < DPIECES) dma_piece<ddma.net, ddma.off_kb, (C + 2) % 3>(p, piece_blk(wave + VFN16_WAVES * i), lane); }
+                    if (VFN16_WAVES * i + VFN16_WAVES <= DPIECES) dma_piece<ddma.net, ddma.off_kb, slot_base(MODE, C + RING - 1)>(p, piece_blk(wave + VFN16_WAVES * i), lane, P1 ? wave + VFN16_WAVES * i : -1);
+                    else if (VFN16_WAVES * i < DPIECES) { if (wave + VFN16_WAVES * i < DPIECES) dma_piece<ddma.net, ddma.off_kb, slot_base(MODE, C + RING - 1)>(p, piece_blk(wave + VFN16_WAVES * i), lane, P1 ? wave + VFN16_WAVES * i : -1); }
                 }
             }
 #endif
@@ -1016,6 +1052,7 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     p.blk_voff = (uint32_t)((m >> 5) * 32768 + lane * 16);      // past the last group -> out of the descriptor's range, dropped
     dma_chunk<MODE, 0>(p, wave, lane);
     dma_chunk<MODE, 1>(p, wave, lane);
+    if constexpr (mode_one(MODE)) static_for<VFN16_P1_RING - 3>([&](auto ic) { dma_chunk<MODE, 2 + decltype(ic)::value>(p, wave, lane); });
 #ifdef ABL_NODMA
     // timing only (WRONG results): no DMA inside the layers; the three slots keep three full-size chunks of real weights,
     // so the matrix cores still see random operands (an empty ring would feed zeros, which raises the clock)
