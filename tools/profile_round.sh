@@ -24,3 +24,5 @@ python3 tools/topk.py gpurun_out/prof_train1024/kt_results.db 30 > "$OUT/train10
 python3 tools/topk.py gpurun_out/prof_grid/kt_results.db 30 > "$OUT/grid_stage_stats.txt"
 tail -1 gpurun_out/prof_train.log > "$OUT/bench_train_profiled.json"
 ls -la "$OUT"
+# the raw rocprofv3 outputs are scratch (and would push gpurun_out/ past what is merged back)
+rm -rf gpurun_out/prof_kt gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/pmc_mfma gpurun_out/prof_train gpurun_out/prof_train1024 gpurun_out/prof_grid
