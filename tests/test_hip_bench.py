@@ -61,3 +61,13 @@ def test_rccl_process_group_with_one_rank_keeps_stdout_to_the_json_line():
             os.environ["VFN_BENCH_FORCE_DIST"] = env_keep
     assert d["n_gpus"] == 1 and d["bucket_elements"] == 805780 and d["per_rank_rays_per_s"]["dist_world_size"] == 1
     assert "all-reduced over one flat bucket" in d["config"]["workload"]
+
+
+def test_single_product_line_says_what_it_is():
+    """--train-products 1: the opt-in 16-bit-native mode is named in `dtype`, carries `training_products`, and is not priced against the
+    three-product ceiling; the default line is."""
+    d1 = _run("--workload", "train", "--rays", "1024", "--steps", "5", "--warmup", "2", "--train-products", "1", "--no-parity")
+    d3 = _run("--workload", "train", "--rays", "1024", "--steps", "5", "--warmup", "2", "--no-parity")
+    assert d1["training_products"] == 1 and d1["dtype"].startswith("16-bit-native") and d1["frac_of_f16_mfma_div3"] is None and 0 < d1["frac_of_f16_mfma"] < 1
+    assert d3["training_products"] == 3 and d3["dtype"].startswith("f16x3") and 0.1 < d3["frac_of_f16_mfma_div3"] < 1.0
+    assert d1["metric"] == d3["metric"] and d1["final_loss"] == d1["final_loss"]
