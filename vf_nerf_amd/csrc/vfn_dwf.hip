@@ -37,6 +37,12 @@
 // vanish — they could not move a sum that is compared to the tensor's largest entry) and multiplies its result by 2^-K:
 // operands with ONE common scale, so the products run on v_mfma_f32_32x32x16_f16 with f16 activations as they are — one product
 // per K-block, exact 11 x 11-bit operands — and an fp32 X (feature rows, encoding tile) as f16 hi + lo (two products).
+//
+// Steps.  A step stages one workspace group (32 points = two K-blocks of 16) of both operands into one of two LDS buffers while the
+// matrix cores work on the other; the next step's pieces are requested right after the split, so they have two K-blocks and a
+// barrier to land in (the stream is latency-bound per CU).  The default training form (dY form 3 x f16 activations) has single
+// images — no lo halves — so a buffer holds 64 rows of each and a step takes TWO groups: 64 KiB per workgroup in flight out of the
+// same registers and LDS (WIDE in the kernel; 560 -> 512 us per batched 256 x 256 launch at 524 288 points).
 #include <string.h>
 #include "vfn_common.h"
 
