@@ -127,9 +127,19 @@ def cpu_baseline(model, uv, pose, K, s_c, n_f, sample_rays=1024, budget_s=12.0):
     parity = {"rays": sample_rays, "colour_products_ran": int(model.colour_products) if model.uses_f16x3() else None,
               "psnr_rgb_db": round(min(O.psnr(rgb, ref["rgb"]), 200.0), 2)}
     parity.update(ray_accounting(out.z_vals.cpu(), rgb, depth, ref["z_vals"], ref["rgb"], ref["depth"].reshape(depth.shape)))
-    return {"value": round(sample_rays * reps / el, 1), "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x oracle render() of {sample_rays} rays x {s_c + n_f} samples, torch fp32 CPU, "
-                      f"{threads} threads, {el:.1f} s"}, parity
+    rec = {"value": round(sample_rays * reps / el, 1), "unit": "rays/s", "cores": threads, "kind": "port",
+           "sample": f"{reps} x oracle render() of {sample_rays} rays x {s_c + n_f} samples, torch fp32 CPU, "
+                     f"{threads} threads, {el:.1f} s"}
+    # how the port compares with the reference's own CPU render(): measured where the reference exists (the build container,
+    # tools/cpu_reference_vs_port.py) and carried as a committed file — nothing of the reference is read here
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03", "cpu_reference_vs_port.json")) as fh:
+            cmp = json.load(fh)
+        rec["port_over_reference_speed"] = {"ratio": cmp["oracle_over_reference"], "measured_on": cmp["workload"],
+                                            "file": "profiles/r03/cpu_reference_vs_port.json"}
+    except (OSError, KeyError, ValueError):
+        pass
+    return rec, parity
 
 
 def ray_accounting(z, rgb, depth, ref_z, ref_rgb, ref_depth, tol=1e-4, z_tol=0.0):
