@@ -582,3 +582,28 @@ def test_two_rank_data_parallel_step_equals_the_single_process_step():
         assert torch.equal(two[0]["w"][k], two[1]["w"][k]), k                      # replicas stay identical
         moved = float((one["w"][k] - two[0]["w"][k]).abs().max())
         assert moved < 0.05 * 5e-4, (k, moved)                                     # a twentieth of one Adam update (lr 5e-4)
+
+
+def test_training_products_knob_and_what_it_selects():
+    """``model.training_products``: 3 by default, 1 = the opt-in 16-bit-native mode — shared with the vector-field net (its standalone
+    forwards follow it), refused for anything else, and selected by ``backward._storage`` only on the default storages (f16
+    activations, fragment order, scaled-f16 gradients); a workspace of that kind asks the kernels for single products."""
+    import vf_nerf_amd
+    from vf_nerf_amd import backward, lib
+    model = vf_nerf_amd.VectorFieldNerf(vf_nerf_amd.shipped_config(torch.device("cpu"), n_samples=8, n_importance=8))
+    assert model.training_products == 3 and backward._storage(model, True) == (True, True, "f16")
+    model.training_products = 1
+    assert model.vector_field_network.training_products == 1
+    assert backward._storage(model, True) == (True, True, "f16p1") and backward._storage(model.vector_field_network, True) == (True, True, "f16p1")
+    assert backward._storage(model, False) == (False, False, None)
+    for attr, other in (("activation_storage", "fp32"), ("gradient_storage", "bf16"), ("workspace_layout", "rows")):
+        keep = getattr(model, attr)
+        setattr(model, attr, other)
+        assert backward._storage(model, True)[2] != "f16p1", attr      # any other storage: the mode does not apply, three products run
+        setattr(model, attr, keep)
+    with pytest.raises(ValueError):
+        model.training_products = 2
+    ws = backward._Workspace(64, 13, torch.device("cpu"), f16=True, frag=True, dy16="f16p1")
+    assert ws.single and ws.dy16 == "f16" and ws.fwd_flags() == (lib.WS_F16 | lib.WS_FRAG | lib.WS_P1) and ws.dy_flags() == (lib.DY_FRAG | lib.DY_F16S | lib.DY_P1)
+    ws3 = backward._Workspace(64, 13, torch.device("cpu"), f16=True, frag=True, dy16="f16")
+    assert not ws3.single and ws3.fwd_flags() == (lib.WS_F16 | lib.WS_FRAG) and ws3.dy_flags() == (lib.DY_FRAG | lib.DY_F16S)
