@@ -146,9 +146,37 @@ __device__ __forceinline__ float folded_weight(const Pack16Entry& e, int n, int 
     return w * e.scale * VFN16_PACK_WSCALE;
 }
 
-__global__ void vfn_pack16_kernel(Pack16Args a) {
+// Range statistics: max |folded weight| of every pack entry (non-negative floats order like their bit patterns).  VFN16_STAT_WGS extra
+// workgroups per entry at the end of the grid sweep its weights coalesced (workgroup s takes rows s, s + 32, ...) and each ends with
+// ONE atomicMax.  (The pack blocks used to do it — a wave-level maximum and an atomicMax per wave, 4 368 operations on ten words:
+// operations on one address serialise at the memory side, ~10 ns each, and were 43 of this kernel's 53 us for the vector-field net's
+// 2.2 MB; 13 us now.  It runs twice per optimizer step.)
+#define VFN16_STAT_WGS 32
+__device__ __forceinline__ void pack16_entry_stats(const Pack16Args& a, int ei, int share) {
+    __shared__ float s_max[4];
+    const Pack16Entry& e = a.e[ei];
+    const int ncol = e.act_valid + e.aux_valid;
+    float m = 0.f;
+    for (int n = share; n < e.n_rows; n += VFN16_STAT_WGS)
+        for (int c = (int)threadIdx.x; c < ncol; c += (int)blockDim.x)
+            m = fmaxf(m, fabsf(folded_weight(e, n, c < e.act_valid ? e.act_col_off + c : e.aux_col_off + (c - e.act_valid))));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float wm = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        if (wm > 0.f) atomicMax(a.stats + ei, __builtin_bit_cast(uint32_t, wm));
+    }
+}
+
+__global__ __launch_bounds__(256) void vfn_pack16_kernel(Pack16Args a) {
+    if (blockIdx.x * blockDim.x >= a.total_words) {      // the statistics workgroups behind the pack's blocks
+        const int sidx = (int)(blockIdx.x - a.total_words / blockDim.x);
+        if (a.stats) pack16_entry_stats(a, sidx / VFN16_STAT_WGS, sidx % VFN16_STAT_WGS);
+        return;
+    }
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.total_words) return;
     int ei = 0;
     for (int i = 1; i < a.n_entries; ++i)
         if (idx >= a.e[i].off_kb * 256u) ei = i;
@@ -165,7 +193,6 @@ __global__ void vfn_pack16_kernel(Pack16Args a) {
         const int g = (int)(lane >> 5);
         const int n = (int)(32u * ck + (lane & 31u));
         _Float16 halves[2];
-        float wabs = 0.f;
         for (int q = 0; q < 2; ++q) {
             const int j = (int)(2u * jp) + q;
             int col = -1;
@@ -179,16 +206,9 @@ __global__ void vfn_pack16_kernel(Pack16Args a) {
             const float w = folded_weight(e, n, col);
             const _Float16 hi = (_Float16)w;
             halves[q] = part ? (_Float16)(w - (float)hi) : hi;
-            wabs = fmaxf(wabs, fabsf(w));
         }
         word = (uint32_t)__builtin_bit_cast(unsigned short, halves[0]) |
                ((uint32_t)__builtin_bit_cast(unsigned short, halves[1]) << 16);
-        if (a.stats && part == 0) {       // (wave-uniform: a workgroup covers one 1-KiB block = one entry, one plane)
-            float wm = wabs;                // largest |w| of the entry; non-negative floats order like their bit patterns
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o, 64));
-            if ((threadIdx.x & 63) == 0 && wm > 0.f) atomicMax(a.stats + ei, __builtin_bit_cast(uint32_t, wm));
-        }
     } else {
         const uint32_t bi = cw - wblocks * 256u;   // bias block: [hl][16] floats in accumulator-register order
         if (bi < 32u) {
@@ -274,7 +294,7 @@ extern "C" int vfn_pack16_weights(int32_t net_kind, const vfn_net_geom* geom, co
         vfn_set_error("vfn_pack16_weights: hipMemsetAsync failed");
         return VFN_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(vfn_pack16_kernel, dim3((a.total_words + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(vfn_pack16_kernel, dim3(a.total_words / 256 + VFN16_STAT_WGS * a.n_entries), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_pack16_weights");
 }
 
