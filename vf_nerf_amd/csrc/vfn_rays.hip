@@ -366,12 +366,10 @@ __device__ __forceinline__ double wave_excl_scan_d(double v, int lane) {
     return incl - v;
 }
 
-__global__ __launch_bounds__(256) void vfn_density_bwd_kernel(const DensityBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float bsm[];
+// one ray by one wave; the ray's contribution to the gradients of the three density scalars comes back in (gb, gm, gs)
+__device__ __forceinline__ void density_bwd_ray(const DensityBwdArgs& a, float* bsm, int wv, int lane, int ray, float& gb_out, float& gm_out,
+                                                float& gs_out) {
     const int S = a.p.n_samples;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * RAYS_PER_BLOCK + wv;
-    if (ray >= a.p.n_rays) return;
     float* su = bsm + (size_t)wv * S * 12;  // unit normals [S][3]
     float* sinv = su + (size_t)S * 3;       // 1 / max(|n|, eps)
     float* sz = sinv + S;
@@ -525,12 +523,7 @@ __global__ __launch_bounds__(256) void vfn_density_bwd_kernel(const DensityBwdAr
         }
     }
     __builtin_amdgcn_wave_barrier();
-    gb = wave_sum(gb); gm = wave_sum(gm); gs = wave_sum(gs);
-    if (lane == 0 && a.d_scalars) {
-        if (braw >= a.p.beta_min && braw <= a.p.beta_max) atomicAdd(a.d_scalars + 0, gb);
-        if (mraw >= a.p.mean_min && mraw <= a.p.mean_max) atomicAdd(a.d_scalars + 1, gm);
-        if (fabsf(sraw) >= a.p.scale_min) atomicAdd(a.d_scalars + 2, (sraw >= 0.f) ? gs : -gs);
-    }
+    gb_out = wave_sum(gb); gm_out = wave_sum(gm); gs_out = wave_sum(gs);
     // gather dL/d u_j from every cosine it takes part in, then project through the normalisation
     for (int j = lane; j < S; j += WAVE) {
         float du[3] = {0.f, 0.f, 0.f};
@@ -570,6 +563,30 @@ __global__ __launch_bounds__(256) void vfn_density_bwd_kernel(const DensityBwdAr
         }
         float* o = a.d_normals + ((size_t)ray * S + j) * 3;
         o[0] += dn[0]; o[1] += dn[1]; o[2] += dn[2];
+    }
+}
+
+// blockDim.x / 64 rays per workgroup (one wave each).  The gradients of the raw density scalars (clamped parameters: no gradient
+// outside their bounds, density_functions.py:129-204) are summed over the workgroup's rays in LDS and leave as ONE atomicAdd per
+// scalar and workgroup: one per ray was 12 288 atomics on three words of one line at 4 096 rays, and operations on one address
+// serialise at the memory side (~10 ns each) — most of this kernel's 170 us.
+__global__ __launch_bounds__(1024) void vfn_density_bwd_kernel(const DensityBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float bsm[];
+    __shared__ float s_red[16][3];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+    const int ray = blockIdx.x * waves + wv;
+    float gb = 0.f, gm = 0.f, gs = 0.f;
+    if (ray < a.p.n_rays) density_bwd_ray(a, bsm, wv, lane, ray, gb, gm, gs);
+    if (!a.d_scalars) return;
+    if (lane == 0) { s_red[wv][0] = gb; s_red[wv][1] = gm; s_red[wv][2] = gs; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float v = 0.f;
+        for (int w = 0; w < waves; ++w) v += s_red[w][threadIdx.x];
+        const float braw = a.scalars[0], mraw = a.scalars[1], sraw = a.scalars[2];
+        if (threadIdx.x == 0 && braw >= a.p.beta_min && braw <= a.p.beta_max) atomicAdd(a.d_scalars + 0, v);
+        if (threadIdx.x == 1 && mraw >= a.p.mean_min && mraw <= a.p.mean_max) atomicAdd(a.d_scalars + 1, v);
+        if (threadIdx.x == 2 && fabsf(sraw) >= a.p.scale_min) atomicAdd(a.d_scalars + 2, (sraw >= 0.f) ? v : -v);
     }
 }
 
@@ -1027,6 +1044,14 @@ extern "C" int vfn_fill_uniform(float* out, int64_t n, uint64_t seed, uint64_t o
     return vfn_check_launch("vfn_fill_uniform");
 }
 
+// rays (waves) per workgroup of the backward kernel: up to sixteen while their LDS (48 bytes per sample and ray) stays inside the
+// 64 KiB a launch may ask for dynamically without further ado (eight rays at 128 samples)
+static int bwd_rays_per_block(int n_samples) {
+    int rpb = 16;
+    while (rpb > 1 && (size_t)rpb * n_samples * 12 * sizeof(float) > 60 * 1024) rpb >>= 1;
+    return rpb;
+}
+
 extern "C" int vfn_ray_density_weights_bwd(const vfn_density_params* p, const float* normals, const float* ray_dirs,
                                            const float* z_vals, const float* density_scalars, const float* colors,
                                            const float* d_rgb, const float* d_depth, const float* d_weights,
@@ -1038,9 +1063,10 @@ extern "C" int vfn_ray_density_weights_bwd(const vfn_density_params* p, const fl
     VFN_REQUIRE(!(d_rgb && !colors), "vfn_ray_density_weights_bwd: d_rgb given without colors");
     if (p->n_rays <= 0) return VFN_OK;
     DensityBwdArgs a{*p, normals, ray_dirs, z_vals, density_scalars, colors, d_rgb, d_depth, d_weights, nullptr, d_normals, d_colors, d_scalars};
-    const unsigned blocks = (unsigned)((p->n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
-    const size_t shmem = (size_t)RAYS_PER_BLOCK * p->n_samples * 12 * sizeof(float);
-    hipLaunchKernelGGL(vfn_density_bwd_kernel, dim3(blocks), dim3(256), shmem, (hipStream_t)stream, a);
+    const int rpb = bwd_rays_per_block(p->n_samples);
+    const unsigned blocks = (unsigned)((p->n_rays + rpb - 1) / rpb);
+    const size_t shmem = (size_t)rpb * p->n_samples * 12 * sizeof(float);
+    hipLaunchKernelGGL(vfn_density_bwd_kernel, dim3(blocks), dim3(64 * rpb), shmem, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_ray_density_weights_bwd");
 }
 
@@ -1052,9 +1078,10 @@ extern "C" int vfn_ray_density_sigma_bwd(const vfn_density_params* p, const floa
     VFN_REQUIRE(p->n_samples >= 2 && p->n_samples <= MAX_SAMPLES_BWD,
                 "vfn_ray_density_sigma_bwd: n_samples=%d outside [2,%d]", p->n_samples, MAX_SAMPLES_BWD);
     DensityBwdArgs a{*p, normals, ray_dirs, z_vals, density_scalars, nullptr, nullptr, nullptr, nullptr, d_sigma, d_normals, nullptr, d_scalars};
-    const unsigned blocks = (unsigned)((p->n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
-    const size_t shmem = (size_t)RAYS_PER_BLOCK * p->n_samples * 12 * sizeof(float);
-    hipLaunchKernelGGL(vfn_density_bwd_kernel, dim3(blocks), dim3(256), shmem, (hipStream_t)stream, a);
+    const int rpb = bwd_rays_per_block(p->n_samples);
+    const unsigned blocks = (unsigned)((p->n_rays + rpb - 1) / rpb);
+    const size_t shmem = (size_t)rpb * p->n_samples * 12 * sizeof(float);
+    hipLaunchKernelGGL(vfn_density_bwd_kernel, dim3(blocks), dim3(64 * rpb), shmem, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_ray_density_sigma_bwd");
 }
 
