@@ -1,9 +1,11 @@
 #!/bin/bash
-# per-kernel MEDIAN / min / max launch duration of the training bench (an average hides cold first launches) -> gpurun_out/km_<tag>.txt
+# per-kernel MEDIAN / min / max launch duration of a bench.py run (an average hides cold first launches) -> gpurun_out/km_<tag>.txt
+#   bash tools/kernel_median.sh <tag> [bench.py arguments; default: --workload train --steps 15 --no-parity]
 R=$(pwd); tag=${1:-x}; shift
 mkdir -p $R/gpurun_out/ktmp
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d $R/gpurun_out/ktmp -o kt -- python3 $R/bench.py --workload train --steps 15 --no-parity "$@" > /dev/null 2>&1 < /dev/null
+if [ $# -eq 0 ]; then set -- --workload train --steps 15 --no-parity; fi
+rocprofv3 --kernel-trace -d $R/gpurun_out/ktmp -o kt -- python3 $R/bench.py "$@" > /dev/null 2>&1 < /dev/null
 cd $R
 python3 - "$tag" <<'PY'
 import sqlite3, sys, glob, statistics
