@@ -172,8 +172,9 @@ class RangeGuard:
 
     def _evaluate(self, st) -> bool:
         host = st["host"]
+        as_float = host.view(torch.float32).tolist()      # one conversion: per-element reads of a tensor cost ~2 us each, ~30 of them per call
         flags = int(host[0])
-        colour_diff = float(host[1:2].view(torch.float32)[0])
+        colour_diff = as_float[1]
         colour_flag = False
         if colour_diff > COLOUR_CHECK_TOL and self.model.colour_products == 2:
             warnings.warn(f"vf_nerf_amd: two-product colours differ from three-product colours by {colour_diff:.2e} (> {COLOUR_CHECK_TOL:.0e}) on "
@@ -189,10 +190,10 @@ class RangeGuard:
             reasons.append("an input coordinate exceeded the split-f16 range (|p| > ~937)")
         for i, (net, tag) in enumerate(zip(self._nets(), ("vector-field", "rendering"))):
             lo = 4 + i * lib.PACK16_STATS_WORDS
-            stats = host[lo:lo + lib.PACK16_STATS_WORDS].view(torch.float32)
+            stats = as_float[lo:lo + lib.PACK16_STATS_WORDS]
             n_entries = len(_pack_entries(net))
             for e in range(n_entries):
-                w = float(stats[e])
+                w = stats[e]
                 if w == 0.0:
                     continue            # nothing packed yet (or an all-zero layer: exact in any representation)
                 if w < WEIGHT_MAX_LO or w > WEIGHT_MAX_HI:
