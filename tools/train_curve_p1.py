@@ -2,7 +2,7 @@
 streams of the default path (f16x3 forward, bf16x3 chain) beside three of the single-product kernels (f16 forward, bf16 chain) —
 same teacher, initial weights, batches and streams as train_curve.py, so its exact-fp32 family is the common yardstick.
 
-    python tools/train_curve_p1.py [steps] > profiles/r03/train_curve_p1.json"""
+    python tools/train_curve_p1.py [steps] [rays per batch] > profiles/r03/train_curve_p1.json"""
 import json, sys, time
 import torch
 sys.path.insert(0, '.')
@@ -11,7 +11,7 @@ from vf_nerf_amd import supervision, trainer
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 dev = torch.device("cuda:0")
-n_rays, s_c, n_f = 1024, 64, 64
+n_rays, s_c, n_f = (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 64, 64
 centroid = (0.0, 0.0, 0.55)
 teacher, _, _, _ = bench.build_scene(dev, 16, s_c, n_f, seed=0, weight_seed=1)
 pool = trainer.TeacherTargets(teacher, views=8, width=64, height=64, focal=60.0, seed=5)
