@@ -20,8 +20,8 @@ extern "C" {
 #endif
 
 /* Bumped whenever a POD struct's layout or an entry point's signature changes (2: vfn_render_params.timing_events,
- * vfn_abi_struct_bytes).  The Python binding reads this constant from this file and refuses a library that reports another. */
-#define VFN_ABI_VERSION 2
+ * vfn_abi_struct_bytes; 3: vfn_f16x3_set_clock_probe, vfn_train_step).  The Python binding reads this constant from this file and refuses a library that reports another. */
+#define VFN_ABI_VERSION 3
 
 typedef enum vfn_status {
     VFN_OK = 0,
@@ -348,6 +348,13 @@ int vfn_vf_render_fused16_fwd(const vfn_net_geom* vf_geom, const void* vf_packed
  *    (hidden layers in plan order, then the 3-channel head): the bit pattern of max |folded weight| of that entry.
  * The facade reads both and repeats a flagged call on the exact-fp32 kernels (vf_nerf_amd/nerf.py, f16x3_guard). */
 int vfn_f16x3_set_status(uint32_t* status_word);
+/* Clock probe of the dominant kernel.  The fused VF + rendering launch is power-limited: the shader clock it runs at is a result
+ * of the launch, not a constant of the chip (1.9-2.1 GHz measured against a nominal 2.4).  After vfn_f16x3_set_clock_probe(stamps,
+ * slots) every gradient-free fused launch of the calling thread (vfn_vf_render_fused16_fwd / _products / _scatter, and through them
+ * vfn_render_fwd) has workgroup b < slots store two uint64 at stamps[2b], stamps[2b+1] (device memory): the shader-clock cycles
+ * (s_memtime) and the 100 MHz constant-clock ticks (s_memrealtime) between its first and its last instruction.  cycles / ticks x
+ * 0.1 = GHz while that workgroup ran.  NULL / 0 switches it off (the default).  Thread-local.  No reference counterpart. */
+int vfn_f16x3_set_clock_probe(uint64_t* stamps, int64_t slots);
 /* vfn_weight_grad_partials(shape 0, ld 256, all 256 columns valid) on the bf16 matrix cores: operands split into two
  * bf16 halves (16 significant bits, fp32 exponent range), three products per K-block, fp32 accumulation; same outputs
  * (`groups` slabs [groups][256][256] and [groups][256]).  ~2^-16 relative error per product under the sum over points. */

@@ -1,7 +1,7 @@
 """Training path on the GPU: gradients of a fixed linear functional of (rgb, depth, normals) from the HIP backward
 kernels against the CPU oracle's autograd and against gradients captured from the reference's own backward pass.
-Tolerance: 1e-3 of each gradient tensor's max magnitude (sums over thousands of points in a different order);
-observed errors are printed."""
+Tolerances are PER MODE, at about three times what each arithmetic is observed to deliver (``MODE_TOL``; sums over
+thousands of points in a different order); observed errors are printed."""
 import pytest
 import torch
 
@@ -12,6 +12,24 @@ from vf_nerf_amd import lib
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
+# Worst parameter-gradient error (of the tensor's largest entry) against the oracle with this implementation's ReLU masks pinned, per
+# arithmetic; observed over the eight fixtures on MI355X (round 4, gpurun_out/r04/grad_errs.txt) in brackets.  A 5x regression of
+# any mode fails its line; the blanket 1e-3 of rounds 1-3 would have let the exact modes slip by an order of magnitude.
+MODE_TOL = {
+    "fp32": 1e-4,                      # exact fp32 MFMA forward + backward                              [1.5e-6 .. 2.8e-5]
+    "f16x3": 2e-4,                     # split-f16 forward, bf16x3 chain, fp32 storages                  [6.7e-5 .. 7.7e-5]
+    "f16x3+rows": 2e-4,                #   ... row-major workspace                                       [6.0e-5 .. 7.2e-5]
+    "f16x3+f16dy": 1e-3,               # scaled-f16 gradient storage                                     [2.3e-4 .. 7.9e-4]
+    "f16x3+f16act": 1e-3,              # f16 activation storage                                          [2.0e-4 .. 7.3e-4]
+    "f16x3+f16act+rows": 1e-3,         #                                                                 [2.0e-4 .. 7.1e-4]
+    "f16x3+f16act+f16dy": 1e-3,        # the DEFAULT 16-bit storages                                     [2.8e-4 .. 7.4e-4]
+    "f16x3+f16act+f16dy+c2": 1e-3,     #   ... with the saving forward's colour branch on two products   [3.7e-4 .. 7.3e-4]
+    "f16x3+f16act+bf16dy": 1e-2,       # bf16 gradient storage (opt-in, 8 significant bits)              [1.7e-3 .. 4.5e-3]
+}
+# the 64 + 64-sample fixture: two fp32 evaluations of this step already differ by 8e-4 (exact-fp32 kernels against the CPU oracle:
+# the density amplifies the normals' rounding into the weights, and the gradient follows) — the FLOOR of every mode there
+# [fp32 8.2e-4, f16x3 8.0e-4, 16-bit storages 9.3e-4 .. 1.1e-3, bf16 3.6e-3]
+BENCH_SIZES_TOL = {"exact": 1.5e-3, "stored16": 2e-3}
 
 
 def _hip_gradients(fx, d, model):
@@ -104,21 +122,24 @@ def test_render_gradients(name, precision):
     # bf16 gradient storage (opt-in): 8 significant bits in one factor of every dW term; the rounding is unbiased and averages
     # out over the points of a batch, so on these fixtures of a few hundred to a few thousand points it is still visible
     # (Backward): bounded at 1e-2 here, ~1e-4 at the 524 288 points of a full batch
-    tol = 1e-2 if "bf16dy" in opts else TOL
-    # the 64 + 64-sample fixture: two fp32 evaluations of this step already differ by 8e-4 (exact-fp32 kernels against the CPU
-    # oracle: the density amplifies the normals' rounding into the weights, and the gradient follows); the 16-bit storages add
-    # their 3-5e-4 on top of that floor
-    if name == "bench_sizes" and ("f16act" in opts or "f16dy" in opts) and "bf16dy" not in opts:
-        tol = 2e-3
+    tol = MODE_TOL[precision]
+    if name == "bench_sizes" and "bf16dy" not in opts:
+        tol = BENCH_SIZES_TOL["stored16" if ("f16act" in opts or "f16dy" in opts) else "exact"]
     assert all(e < tol for _, _, e in errs), [x for x in errs if x[2] >= tol]
-    # and against the reference's own backward pass (captured in the fixture): tight when no unit flipped, a sanity
-    # bound otherwise
-    tol_ref = tol if flips == 0 else 1e-1
+    # and against the reference's own backward pass (captured in the fixture): the mode's own bound when no unit flipped; 1e-2 when
+    # at most four did (one unit on the other side of zero moves a layer's gradient by ~0.2 % on fixtures of a few hundred points);
+    # a sanity bound beyond that (the opt-in 11-bit colour branch and bf16 storage move dozens of units)
+    tol_ref = max(tol, 1e-3 if name == "bench_sizes" else 0.0) if flips == 0 else (max(tol, 1e-2) if flips <= 4 else 1e-1)
+    worst_ref = 0.0
     for tag, key in GRAD_KEYS:
         err = grad_rel_err(dict(nets[tag].named_parameters())[key].grad, d[f"grad.{tag}.{key}"])
-        assert err < tol_ref, ("vs reference", tag, key, err)
+        worst_ref = max(worst_ref, err)
+        assert err < tol_ref, ("vs reference", tag, key, err, flips)
     for k in ("beta", "mean", "scale"):
-        assert grad_rel_err(getattr(model.density, k).grad.reshape(1), d[f"grad.density.{k}"]) < tol_ref
+        err = grad_rel_err(getattr(model.density, k).grad.reshape(1), d[f"grad.density.{k}"])
+        worst_ref = max(worst_ref, err)
+        assert err < tol_ref, ("vs reference", k, err, flips)
+    print(f"{name}/{precision}: worst error vs the REFERENCE's captured gradients {worst_ref:.3e} with {flips} flipped units (bound {tol_ref:.0e})")
 
 
 def test_training_forward_workspace_f16x3_matches_fp32():

@@ -29,7 +29,17 @@ def test_default_line_has_the_contract_keys_and_consistent_arithmetic():
     assert "4096" in d["metric"] and d["config"]["rays_per_chunk_per_gpu"] == 4096 and d["config"]["samples_per_ray"] == 128
     # value = rays of all timed steps / time
     assert abs(d["value"] - 4096 * 1000.0 / d["ms_per_step"]) < 2e-3 * d["value"]
-    assert d["value_fp32_equivalent"] is not None and d["value_fp32_equivalent"] < d["value"] * 1.02
+    # the default path IS the fp32-equivalent one (three products everywhere) and runs on TRAINED weights; the opt-in two-product
+    # colour branch and the random-weight scene are reported beside it
+    assert d["value_fp32_equivalent"] == d["value"] and d["config"]["colour_products"] == 3
+    assert d["weights"]["fixture"] in ("tests/golden/trained_far.npz", "tests/golden/trained_256.npz")
+    assert d["value_random_weight_scene"] is not None and 0.85 < d["value_random_weight_scene"] / d["value"] < 1.15
+    assert d["value_two_product_opt_in"] is not None and d["value_two_product_opt_in"] > d["value"] * 0.98
+    c2 = d["two_product_check"]
+    assert c2["geometry_bit_identical"] and c2["max_abs_colour_difference"] > 0
+    assert c2["strict_guard_keeps_two_products"] == (c2["colour_products_reason"] is None)
+    if d["weights"]["fixture"].endswith("trained_far.npz"):       # far from init: the self-check refuses the opt-in there
+        assert not c2["strict_guard_keeps_two_products"] and c2["max_abs_colour_difference"] > c2["guard_tolerance"]
     assert d["per_rank_rays_per_s"]["dist_world_size"] == 1
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
@@ -37,10 +47,11 @@ def test_default_line_has_the_contract_keys_and_consistent_arithmetic():
     assert 2 * r["avg_launch_ms"] <= d["ms_per_step"] * 1.02, "two launches of the dominant kernel fit in a step"
     assert 0.3 < r["frac"] < 1.0 and r["traffic"] is None or r["traffic"] > r["algorithmic_bytes"]
     assert r["traffic_source"] is None or "file" in r["traffic_source"]
+    assert 1.0 < r["effective_clock_ghz"] < 2.6 and r["effective_clock"]["workgroups"] >= 1024
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "rays/s" and c["cores"] >= 1 and 0 < c["value"] < d["value"] / 100
     p = d["parity_vs_oracle"]
-    assert p["rays_with_different_z"] == 0 and p["frac_rays_within_1e-4"] == 1.0 and p["colour_products_ran"] == 2
+    assert p["rays_with_different_z"] == 0 and p["frac_rays_within_1e-4"] == 1.0 and p["colour_products_ran"] == 3
     t = d["parity_trained_weights"]
     assert t["frac_rays_within_1e-4"] == 1.0 and t["rays_with_different_z"] == 0 and t["guard"]["switched_to_fp32"] is None
     tr = d["train"]

@@ -436,7 +436,8 @@ def test_two_product_colours_are_measured_by_the_guard(monkeypatch):
             return model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
 
     model = build_model(fx, d, device="cuda:0")
-    assert model.colour_products == 2
+    assert model.colour_products == 3          # the default since round 4: two products are an opt-in (they do not survive training)
+    model.colour_products = 2
     model.f16x3_guard = "strict"
     two = render(model)
     assert model.colour_products == 2 and model.range_guard.colour_products_reason is None
@@ -449,6 +450,7 @@ def test_two_product_colours_are_measured_by_the_guard(monkeypatch):
     monkeypatch.setattr(vguard, "COLOUR_CHECK_TOL", 1e-6)
     for mode in ("strict", "lazy"):
         model = build_model(fx, d, device="cuda:0")
+        model.colour_products = 2
         model.f16x3_guard = mode
         with warnings.catch_warnings(record=True) as caught:
             warnings.simplefilter("always")
@@ -471,6 +473,7 @@ def test_two_product_colours_are_measured_by_the_guard(monkeypatch):
             for i in range(rn.num_layers - 1):
                 rn._linear(i).weight.mul_(wmul)
         rn._invalidate_packs()
+        model.colour_products = 2
         model.f16x3_guard = "off"
         model.precision = "fp32"
         want = render(model)

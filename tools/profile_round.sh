@@ -7,11 +7,11 @@ R=$(pwd)
 OUT=${1:-gpurun_out/export}
 mkdir -p "$R/$OUT" "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-train"
+B="python3 $R/bench.py --no-cpu-baseline --no-train --no-two-product-leg --no-random-weight-leg"
 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_kt" -o kt -- $B --steps 20 > "$R/gpurun_out/prof_kt.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE -d "$R/gpurun_out/prof_fetch" -o pf -- $B --steps 5 --no-fp32-equivalent > "$R/gpurun_out/prof_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE -d "$R/gpurun_out/prof_write" -o pw -- $B --steps 5 --no-fp32-equivalent > "$R/gpurun_out/prof_write.log" 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$R/gpurun_out/pmc_mfma" -o pm -- $B --steps 5 --no-fp32-equivalent > "$R/gpurun_out/pmc_mfma.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE -d "$R/gpurun_out/prof_fetch" -o pf -- $B --steps 5 > "$R/gpurun_out/prof_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE -d "$R/gpurun_out/prof_write" -o pw -- $B --steps 5 > "$R/gpurun_out/prof_write.log" 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$R/gpurun_out/pmc_mfma" -o pm -- $B --steps 5 > "$R/gpurun_out/pmc_mfma.log" 2>&1
 cd "$R" && python3 tools/export_profiles.py gpurun_out "$OUT" f16x3 > "$OUT/export_f16x3.log" 2>&1
 # the training step and the dense-grid stages: kernel tables
 cd /tmp

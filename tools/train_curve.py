@@ -56,6 +56,8 @@ def run(precision, activations="fp32", gradients="fp32", stream=0):
             "depth_loss_last_25_mean": sum(t["depth_loss"] for t in terms[-25:]) / 25,
             "supervision_loss_last_25_mean": sum(t["supervision_loss"] for t in terms[-25:]) / 25,
             "psnr_vs_teacher_before_after_db": [round(psnr0, 3), round(pool.psnr(model), 3)],
+            "guard_switched_to_fp32": model.f16x3_disabled, "colour_products_reason": model.range_guard.colour_products_reason,
+            "two_product_check_after_training": bench.two_product_check(model, *[pool.batch(777_000, 1024)[i] for i in (1, 0, 2)]) if model.uses_f16x3() else None,
             "loss_mean_per_25_steps": [round(sum(losses[i:i + 25]) / len(losses[i:i + 25]), 5) for i in range(0, steps, 25)]}
 
 

@@ -33,8 +33,10 @@ def run(products, stream):
     ms = (time.perf_counter() - t0) / steps * 1e3
     losses = [float(x) for x in losses]
     return {"ms_per_step": round(ms, 3), "loss_first_10_mean": sum(losses[:10]) / 10, "loss_last_25_mean": sum(losses[-25:]) / 25,
-            "psnr_vs_teacher_before_after_db": [round(psnr0, 3), round(pool.psnr(model), 3)], "non_finite_losses": sum(1 for x in losses if x != x),
-            "guard_switched_to_fp32": model.f16x3_disabled,
+            "psnr_vs_teacher_before_after_db": [round(psnr0, 3), round(pool.psnr(model), 3)],
+            "guard_switched_to_fp32": model.f16x3_disabled, "colour_products_reason": model.range_guard.colour_products_reason,
+            "two_product_check_after_training": bench.two_product_check(model, *[pool.batch(777_000, 1024)[i] for i in (1, 0, 2)]) if model.uses_f16x3() else None,
+            "non_finite_losses": sum(1 for x in losses if x != x),
             "loss_mean_per_100_steps": [round(sum(losses[i:i + 100]) / len(losses[i:i + 100]), 5) for i in range(0, steps, 100)]}
 
 

@@ -30,8 +30,12 @@ def vf_forward(net, points: torch.Tensor, vector_only: bool = False) -> torch.Te
         if guard is not None and guard.active() and points.is_cuda and getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3():
             guard.poll()
             if getattr(net, "precision", "fp32") == "f16x3":
-                with guard.watch(points.device):
-                    return vf_forward_autograd(net, points, vector_only)
+                with guard.watch(points.device) as w:
+                    out = vf_forward_autograd(net, points, vector_only)
+                if not w.flagged:
+                    return out
+                # strict mode and flagged: the guard has switched the net to the exact-fp32 kernels; this forward is repeated on them,
+                # so that no call returns values the clamp touched (the abandoned graph of the first attempt is simply dropped)
         return vf_forward_autograd(net, points, vector_only)
     pts = _flat3(points)
     if vector_only and getattr(net, "precision", "fp32") == "f16x3" and net.supports_f16x3():

@@ -75,4 +75,6 @@ done
 # shellcheck disable=SC2086
 hipcc -shared -fPIC --offload-arch=${ARCH} -o "$OUT.tmp" $OBJS || { rm -f "$OUT" "$OUT.tmp"; exit 1; }
 mv -f "$OUT.tmp" "$OUT"
+# the binding generates its signatures from the header: leave a copy inside the package for installs without the repository around them
+cp -f ../../include/vfn.h ../vfn_abi.h
 echo "built $(pwd)/$OUT"

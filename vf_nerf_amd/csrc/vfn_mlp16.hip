@@ -433,6 +433,8 @@ struct Mlp16Args {
     uint32_t* status;         // optional (vfn_f16x3_set_status): bit 0 is OR-ed in when a hidden activation reached the f16 clamp,
                               // bit 1 when an input (point coordinate / encoding operand) did — the result of such a launch is not
                               // fp32-equivalent and the caller should repeat it on the exact-fp32 kernels
+    unsigned long long* clock;   // optional (vfn_f16x3_set_clock_probe): workgroup b < clock_slots of a fused VF + rendering launch leaves
+    long long clock_slots;       // its shader-clock cycles (s_memtime) in clock[2b] and its 100 MHz ticks (s_memrealtime) in clock[2b+1]
 };
 
 // Range of the split-f16 operands: activations ride at 2^6 x their value (VFN16_XSCALE) and are clamped here, i.e. true
@@ -963,6 +965,12 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
 #ifdef VFN16_STAMPS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    // clock probe (fused VF + rendering launches only; scalar registers, a uniform branch): what the shader clock was while THIS
+    // workgroup ran — the kernel is power-limited, so the clock is a result, not a constant (bench.py: roofline.effective_clock_ghz)
+    unsigned long long ck_t0 = 0ull, ck_r0 = 0ull;
+    if constexpr ((MODE & M16_RENDER) != 0 && (MODE & M16_BLKIN) == 0 && (MODE & M16_TRAIN) == 0) {
+        if (a.clock) { ck_t0 = __builtin_amdgcn_s_memtime(); ck_r0 = __builtin_amdgcn_s_memrealtime(); }
+    }
     const long long m = (long long)blockIdx.x * VFN16_PTS + wave * 32 + (lane & 31);
     const bool in = m < a.n_points;
 
@@ -1148,6 +1156,12 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     render_aux<MODE>(a, raux, xr, dr, nrm, (MODE & M16_TRAIN) ? mw : m, in, g, ain);
     render_tail<MODE>(a, p, cy, xa, xb, raux, nrm, a.out_index ? (long long)out_row : m, a.out_index ? out_row >= 0 : in, wave, lane);
     report_range(a, cy.sat, ain);
+    if constexpr ((MODE & M16_TRAIN) == 0) {
+        if (a.clock && threadIdx.x == 0 && (long long)blockIdx.x < a.clock_slots) {
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+            a.clock[2 * blockIdx.x] = t1 - ck_t0; a.clock[2 * blockIdx.x + 1] = r1 - ck_r0;
+        }
+    }
     const long long mo = (long long)blockIdx.x * VFN16_PTS + (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
     (void)mo;
 #ifdef VFN16_STAMPS
@@ -1191,6 +1205,17 @@ extern "C" int vfn_f16x3_set_status(uint32_t* status_word) {
     return VFN_OK;
 }
 
+// Where the fused VF + rendering launches of THIS thread leave their per-workgroup clock stamps (NULL: nowhere).
+static thread_local unsigned long long* t_clock_probe = nullptr;
+static thread_local long long t_clock_slots = 0;
+
+extern "C" int vfn_f16x3_set_clock_probe(uint64_t* stamps, int64_t slots) {
+    VFN_REQUIRE(slots >= 0 && (stamps || slots == 0), "vfn_f16x3_set_clock_probe: %lld slots without a buffer", (long long)slots);
+    t_clock_probe = reinterpret_cast<unsigned long long*>(stamps);
+    t_clock_slots = stamps ? slots : 0;
+    return VFN_OK;
+}
+
 extern "C" int vfn_vf_mlp16_fwd(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
                                  float* out_vec, void* stream) {
     Mlp16Args a = {};
@@ -1204,6 +1229,7 @@ extern "C" int vfn_vf_mlp16_fwd(const vfn_net_geom* geom, const void* packed16, 
     a.vf_w = (const uint4*)packed16; a.points = points; a.out_vec = out_vec; a.n_points = n_points; a.dirs_div = 1;
     a.vf_multires = vf.multires; a.vf_bytes = vf.total_kb * 1024u;
     a.status = t_status_word;
+    a.clock = t_clock_probe; a.clock_slots = t_clock_slots;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_VEC>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_mlp16_fwd");
@@ -1234,6 +1260,7 @@ static int launch_fused16(const char* what, const vfn_net_geom* vf_geom, const v
     a.out_vec = normals; a.out_colors = colors; a.out_index = out_index; a.n_points = n_points; a.dirs_div = samples_per_ray;
     a.vf_multires = vf.multires; a.rn_multires = rn.multires; a.vf_bytes = vf.total_kb * 1024u; a.rn_bytes = rn.total_kb * 1024u;
     a.status = t_status_word;
+    a.clock = t_clock_probe; a.clock_slots = t_clock_slots;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     if (colour_products == 2) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED | M16_C2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
@@ -1281,6 +1308,7 @@ extern "C" int vfn_vf_feat16_fwd(const vfn_net_geom* geom, const void* packed16,
     a.vf_w = (const uint4*)packed16; a.points = points; a.out_vec = out_vec; a.n_points = n_points; a.dirs_div = 1;
     a.vf_multires = vf.multires; a.vf_bytes = vf.total_kb * 1024u; a.blk_out = (uint4*)out_blocks;
     a.status = t_status_word;
+    a.clock = t_clock_probe; a.clock_slots = t_clock_slots;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_BLK>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_feat16_fwd");
@@ -1303,6 +1331,7 @@ extern "C" int vfn_render16_from_blocks(const vfn_net_geom* rn_geom, const void*
     a.n_points = n_points; a.dirs_div = samples_per_ray; a.rn_multires = rn.multires; a.rn_bytes = rn.total_kb * 1024u; a.vf_bytes = a.rn_bytes;
     a.blk_in = (const uint4*)blocks; a.vec_in = vecs; a.src = dst;
     a.status = t_status_word;
+    a.clock = t_clock_probe; a.clock_slots = t_clock_slots;
     const long long nblocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     hipLaunchKernelGGL(vfn_mlp16_kernel<M16_RN_BLK>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_render16_from_blocks");
@@ -1339,6 +1368,7 @@ extern "C" int vfn_vf_mlp16_fwd_train_at(const vfn_net_geom* geom, const void* p
     a.save_masks = save_masks; a.save_f16 = save_f16 & 3;
     a.ws_first = ws_first; a.ws_points = ws_points;
     a.status = t_status_word;
+    a.clock = t_clock_probe; a.clock_slots = t_clock_slots;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     if (save_f16 & 4) {        // single-product arithmetic (opt-in 16-bit-native training, vector columns only)
         VFN_REQUIRE(!with_features, "vfn_vf_mlp16_fwd_train: the single-product forward computes the vector columns only");
@@ -1389,6 +1419,7 @@ extern "C" int vfn_vf_render_fused16_fwd_train_at(const vfn_net_geom* vf_geom, c
     a.vf_multires = vf.multires; a.rn_multires = rn.multires; a.vf_bytes = vf.total_kb * 1024u; a.rn_bytes = rn.total_kb * 1024u;
     a.saved = saved; a.save_aux_vf = save_aux_vf; a.save_aux_rn = save_aux_rn; a.save_masks = save_masks; a.save_f16 = save_f16 & 3;
     a.status = t_status_word;
+    a.clock = t_clock_probe; a.clock_slots = t_clock_slots;
     const long long blocks = (n_points + VFN16_PTS - 1) / VFN16_PTS;
     VFN_REQUIRE(colour_products >= 1 && colour_products <= 3, "vfn_vf_render_fused16_fwd_train: colour_products must be 1, 2 or 3 (got %d)", colour_products);
     if (colour_products == 1) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED_TRAIN | M16_P1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);   // one product EVERYWHERE

@@ -48,11 +48,19 @@ COLOUR_CHECK_RAYS = 128
 
 
 class _Watch:
+    """Re-entrant: a guarded call made inside another guarded call (a vector-field forward issued by a render() that is itself
+    under watch) joins the outer watch — only the OUTERMOST exit clears the kernels' status pointer, counts the call and evaluates
+    the report; an inner watch reports ``flagged = False`` and leaves the verdict (and a strict-mode repeat) to the outer one."""
+
     def __init__(self, guard: "RangeGuard", dev) -> None:
-        self.guard, self.dev, self.flagged = guard, dev, False
+        self.guard, self.dev, self.flagged, self.outermost = guard, dev, False, False
 
     def __enter__(self) -> "_Watch":
-        lib.f16x3_set_status(self.guard._state(self.dev)["status"])
+        g = self.guard
+        self.outermost = g._depth == 0
+        g._depth += 1
+        if self.outermost:
+            lib.f16x3_set_status(g._state(self.dev)["status"])
         return self
 
     def sample(self, out) -> None:
@@ -60,9 +68,12 @@ class _Watch:
         self.guard._colour_sample(self.dev, out)
 
     def __exit__(self, *exc) -> bool:
-        lib.f16x3_set_status(None)
-        if exc[0] is None:
-            self.flagged = self.guard._after_call(self.dev)
+        g = self.guard
+        g._depth -= 1
+        if self.outermost:
+            lib.f16x3_set_status(None)
+            if exc[0] is None:
+                self.flagged = g._after_call(self.dev)
         return False
 
 
@@ -73,6 +84,7 @@ class RangeGuard:
         self.colour_products_reason: Optional[str] = None     # why the guard moved the model back to three-product colours
         self._st: Optional[dict] = None
         self._calls = 0
+        self._depth = 0            # nesting of watches (_Watch)
 
     # -- public ---------------------------------------------------------------------------------
     def active(self) -> bool:

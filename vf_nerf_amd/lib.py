@@ -33,7 +33,7 @@ EXPORTS = (
     "vfn_embed_rows_bwd", "vfn_vf_render_fused16_scatter", "vfn_vf_render_fused16_products", "vfn_net_weight_grads_frag", "vfn_net_weight_grads_frag_part", "vfn_net_weight_grads_scratch_bytes", "vfn_vf_render_fused16_fwd_train_at",
     "vfn_vf_mlp16_fwd_train_at", "vfn_mlp_bwd_chain_bf16_ws_at",
     "vfn_weight_grad_groups", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax", "vfn_merge_sort_depths",
-    "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step", "vfn_unfold_weight_grads_acc", "vfn_render_fwd", "vfn_render_fwd_workspace_bytes",
+    "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_f16x3_set_clock_probe", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step", "vfn_unfold_weight_grads_acc", "vfn_render_fwd", "vfn_render_fwd_workspace_bytes",
     "vfn_vf_loss_workspace_bytes", "vfn_vf_loss_fwd", "vfn_vf_loss_bwd",
 )
 
@@ -89,24 +89,46 @@ class LossParams(C.Structure):
 
 _lib: Optional[C.CDLL] = None
 
-HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vfn.h")
+def _find_header() -> str:
+    """include/vfn.h of the repository, or the copy the build leaves inside the package (``vf_nerf_amd/vfn_abi.h``, written by
+    csrc/build.sh) for a package that was copied / installed without the repository around it; ``VFN_HEADER`` overrides both."""
+    for cand in (os.environ.get("VFN_HEADER"), os.path.join(os.path.dirname(_HERE), "include", "vfn.h"), os.path.join(_HERE, "vfn_abi.h")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise VfnError(f"include/vfn.h not found next to the package ({os.path.dirname(_HERE)}/include) nor as {_HERE}/vfn_abi.h: the binding's "
+                   "signatures are generated from it; set VFN_HEADER or rebuild with vf_nerf_amd/csrc/build.sh")
+
+
+_header_cache: dict = {}
+
+
+def _header_raw() -> str:
+    if "raw" not in _header_cache:
+        path = _find_header()
+        with open(path) as fh:
+            _header_cache["raw"], _header_cache["path"] = fh.read(), path
+    return _header_cache["raw"]
 
 
 def _header_text() -> str:
     import re
-    with open(HEADER_PATH) as fh:
-        text = fh.read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"/\*.*?\*/", "", _header_raw(), flags=re.S)
     return re.sub(r"//[^\n]*", "", text)
 
 
 def header_abi_version() -> int:
     import re
-    with open(HEADER_PATH) as fh:
-        return int(re.search(r"#define\s+VFN_ABI_VERSION\s+(\d+)", fh.read()).group(1))
+    return int(re.search(r"#define\s+VFN_ABI_VERSION\s+(\d+)", _header_raw()).group(1))
 
 
-ABI_VERSION = header_abi_version()       # include/vfn.h is the single source: the library must report the same number
+def __getattr__(name: str):
+    # read on first use, not at import: the CPU-only parts of the package (loss, optimizer, host logic) import this module too
+    if name == "ABI_VERSION":            # include/vfn.h is the single source: the library must report the same number
+        return header_abi_version()
+    if name == "HEADER_PATH":
+        _header_raw()
+        return _header_cache["path"]
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
 def header_prototypes() -> dict:
@@ -120,6 +142,9 @@ def header_prototypes() -> dict:
             prm = re.sub(r"\s+", " ", prm).strip()
             if prm in ("void", ""):
                 continue
+            if "[" in prm or "(" in prm:        # array parameters / function pointers: not a form this generator understands
+                raise VfnError(f"{name}: parameter '{prm}' of include/vfn.h is an array or a function pointer; the binding generator "
+                               "handles scalars and plain pointers only")
             plist.append(re.match(r"(.*?)\s*\w+$", prm).group(1).replace(" *", "*").strip())
         out[name] = (re.sub(r"\s+", " ", ret).strip(), plist)
     return out
@@ -182,7 +207,7 @@ def _declare(lib: C.CDLL) -> None:
     for name in EXPORTS:
         fn = getattr(lib, name)               # raises AttributeError if the ABI lost a symbol
         if name not in protos:
-            raise VfnError(f"{name} is exported by the binding but not declared in {HEADER_PATH}")
+            raise VfnError(f"{name} is exported by the binding but not declared in {_header_cache['path']}")
         ret, params = protos[name]
         fn.restype = C.c_char_p if ret == "const char*" else _INT_TYPES[ret]
         args = []
@@ -208,8 +233,8 @@ def load() -> C.CDLL:
                        f"or vf_nerf_amd/csrc/build.sh (there is no CPU fallback)")
     lib = C.CDLL(LIB_PATH)
     _declare(lib)
-    if lib.vfn_abi_version() != ABI_VERSION:
-        raise VfnError(f"libvfn.so reports ABI {lib.vfn_abi_version()}, include/vfn.h says {ABI_VERSION}: rebuild the library")
+    if lib.vfn_abi_version() != header_abi_version():
+        raise VfnError(f"libvfn.so reports ABI {lib.vfn_abi_version()}, include/vfn.h says {header_abi_version()}: rebuild the library")
     for i, mirror in enumerate(struct_mirrors()):
         if lib.vfn_abi_struct_bytes(i) != C.sizeof(mirror):
             raise VfnError(f"{mirror.__name__}: {C.sizeof(mirror)} bytes in the binding, {lib.vfn_abi_struct_bytes(i)} in libvfn.so")
@@ -865,6 +890,24 @@ STATUS_ACT_SATURATED, STATUS_INPUT_SATURATED = 1, 2
 def f16x3_set_status(word: Optional[torch.Tensor]) -> None:
     """Route the range reports of this thread's f16x3 launches into ``word`` (int32 device tensor, >= 1 element); None: off."""
     _check(load().vfn_f16x3_set_status(_ptr(word, "status_word", torch.int32)), "vfn_f16x3_set_status")
+
+
+def f16x3_set_clock_probe(stamps: Optional[torch.Tensor]) -> None:
+    """Route the per-workgroup clock stamps of this thread's gradient-free fused launches into ``stamps`` (int64 device tensor
+    [slots, 2]: shader-clock cycles, 100 MHz ticks of workgroup b; csrc/vfn_mlp16.hip); None: off."""
+    slots = 0 if stamps is None else stamps.numel() // 2
+    _check(load().vfn_f16x3_set_clock_probe(_ptr(stamps, "stamps", torch.int64), slots), "vfn_f16x3_set_clock_probe")
+
+
+def clock_ghz_from_stamps(stamps: torch.Tensor) -> Optional[dict]:
+    """{median, min, max} shader clock in GHz over the workgroups that left a stamp (cycles / 100-MHz-ticks x 0.1)."""
+    st = stamps.reshape(-1, 2).cpu().double()
+    st = st[(st[:, 1] > 0) & (st[:, 0] > 0)]
+    if st.shape[0] == 0:
+        return None
+    ghz = st[:, 0] / st[:, 1] * 0.1
+    return {"median": round(float(ghz.median()), 4), "min": round(float(ghz.min()), 4), "max": round(float(ghz.max()), 4),
+            "workgroups": int(st.shape[0]), "median_workgroup_us": round(float(st[:, 1].median()) / 100.0, 2)}
 
 
 def pack16_size(kind: int, geom: NetGeom) -> int:

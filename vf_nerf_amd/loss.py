@@ -9,7 +9,7 @@ that never looks at the terms never synchronises.  ``vf_nerf_amd.dropin`` instal
 """
 from __future__ import annotations
 
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 from torch import nn
@@ -187,11 +187,39 @@ class VFLoss(nn.Module):
             terms[5] = dd_loss.detach()
         return total, _LazyTerms(_NAMES, terms)
 
+    @staticmethod
+    def _fused_shapes_ok(pred, gt) -> Optional[str]:
+        """The fused kernels read raw pointers with sizes taken from pred["rgb"] / pred["normals"] alone: every other operand must
+        have exactly the matching extent (the tensor-op formulation below would raise or broadcast on a mismatch; a kernel would
+        read out of bounds).  Returns what does not match, or None."""
+        n = pred["rgb"].reshape(-1, 3).shape[0] if pred["rgb"].numel() % 3 == 0 else -1
+        if n < 0 or gt["rgb"].numel() != 3 * n:
+            return f"rgb {tuple(pred['rgb'].shape)} against ground truth {tuple(gt['rgb'].shape)}"
+        if gt["depth"].nelement() > 0 and (pred["depth"] is None or pred["depth"].numel() != n or gt["depth"].numel() != n):
+            return f"depth {None if pred['depth'] is None else tuple(pred['depth'].shape)} / ground truth {tuple(gt['depth'].shape)} for {n} rays"
+        if pred["normals"].numel() % 3:
+            return f"normals {tuple(pred['normals'].shape)}"
+        rc = pred.get("ray_center")
+        if rc is not None and rc[0].numel() != pred["normals"].numel():
+            return f"ray_center points {tuple(rc[0].shape)} against normals {tuple(pred['normals'].shape)}"
+        segments = pred.get("supervised_segments")
+        if segments is None:
+            segments = [(pred["supervised_normals"], gt["supervised_normals"])] if pred["supervised_normals"].nelement() > 0 else []
+        for k, (a, b) in enumerate(segments):
+            if a.numel() % 3 or a.numel() != b.numel():
+                return f"supervised segment {k}: prediction {tuple(a.shape)} against ground truth {tuple(b.shape)}"
+        return None
+
     def forward(self, pred: Dict[str, torch.Tensor], gt: Dict[str, torch.Tensor], epoch: int
                 ) -> Tuple[torch.Tensor, Dict[str, float]]:
         rgb = pred["rgb"]
         if self.fused and rgb.is_cuda and rgb.dtype == torch.float32 and pred["normals"].is_cuda:
-            return self._fused_forward(pred, gt, epoch)
+            bad = self._fused_shapes_ok(pred, gt)
+            if bad is None:
+                return self._fused_forward(pred, gt, epoch)
+            if pred.get("supervised_segments") is not None or pred.get("ray_center") is not None:
+                raise ValueError("VFLoss: operand sizes do not match (" + bad + ")")
+            # plain reference-style operands of unequal extent: the tensor-op formulation decides (it raises or broadcasts as torch does)
         if pred.get("supervised_segments") is not None or pred.get("ray_center") is not None:
             raise ValueError("supervised_segments / ray_center are inputs of the fused device loss (CUDA tensors, VFLoss.fused = True)")
         zero = torch.zeros((), device=rgb.device, dtype=rgb.dtype)

@@ -150,11 +150,15 @@ class VectorFieldNerf:
         # outputs).  False: one fused VF+rendering launch over all S_c+N_f samples.
         self.reuse_proposal = True
         # f16 products per fp32-equivalent product in the COLOUR BRANCH of gradient-free f16x3 renders (the feature block of the VF
-        # net + the rendering net; csrc/vfn_mlp16.hip, M16_C2).  2: that branch's weights enter as their f16 roundings (activations
-        # stay split): -14 % matrix instructions, 1.13x on the fused launch; colours within 2e-5 of the exact-fp32 kernels / the
-        # reference's golden outputs (contract 1e-4, profiles/r02/ab_colour_products.txt), while normals, density, weights, depth and
-        # the sample positions are bit-identical to 3.  3: fp32-equivalent colours (1e-7).  Training forwards always use 3.
-        self.colour_products = 2
+        # net + the rendering net; csrc/vfn_mlp16.hip, M16_C2).  3 (default since round 4): fp32-equivalent colours (1e-7).  2 (opt-in):
+        # that branch's weights enter as their f16 roundings (activations stay split): -14 % matrix instructions, 1.10-1.13x on the
+        # fused launch, normals / density / weights / depth / sample positions bit-identical to 3, colours within 2e-5 ON NEAR-INIT
+        # WEIGHTS — and 1e-4 .. 1e-3 on trained ones: every model trained for >= 1 000 steps on the GPU in round 3 (18 of 18) and the
+        # reference-trained far-from-init fixture (tests/golden/trained_far.npz) measure outside the contract, the error growing with
+        # the step count (profiles/r04/two_product_after_training.json).  With 2 the range guard still measures the difference on the
+        # model's own data and goes back to 3 (guard.py); a trained model therefore ends up on 3 either way, which is why 3 is what
+        # ships and what bench.py's `value` is measured in.  Training forwards always use 3.
+        self.colour_products = 3
         # Range guard of the f16x3 kernels (guard.py): "lazy" (asynchronous read-back of the kernels' saturation report, the
         # model switches itself to the exact-fp32 kernels when one arrives), "strict" (every call is checked and, when flagged,
         # repeated on the fp32 kernels before it returns) or "off".  ``f16x3_disabled`` holds the reason once it has switched.

@@ -174,6 +174,14 @@ class FlatAdam(SequentialAdam):
             self._flat = None
             return None
         dev = next(iter(devs))
+        # One bias correction per region and update (step()): sound only while every parameter of a region has taken the same number
+        # of updates.  A parameter that sat out some steps frozen (SequentialAdam's path skipped it) has a smaller count than its
+        # neighbours: such a list stays on the per-parameter path, whose corrections are per parameter like torch.optim.Adam's.
+        for m in {m for _, _, _, m in entries}:
+            counts = {float(self.state[p]["step"]) if len(self.state.get(p, {})) else 0.0 for p, _, _, mm in entries if mm == m}
+            if len(counts) > 1:
+                self._flat = None
+                return None
         from . import lib
         old = self._flat
         f = dict(param=torch.empty(total, device=dev), grad=torch.zeros(total, device=dev), exp_avg=torch.zeros(total, device=dev),
@@ -249,7 +257,7 @@ class FlatAdam(SequentialAdam):
         for i, (p, off, n, m) in enumerate(f["entries"]):
             first_of_region.setdefault(m, i)
         for (start, end, m) in f["regions"]:
-            t0 = float(f["steps"][first_of_region[m]])      # every parameter of a region has taken the same number of updates
+            t0 = float(f["steps"][first_of_region[m]])      # every parameter of a region has taken the same number of updates (flat() checks)
             for k in range(2):
                 t = t0 + k + 1
                 step_size.append(lr / (1 - beta1 ** t))

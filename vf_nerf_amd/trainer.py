@@ -92,7 +92,12 @@ class TrainStep:
         if pts:
             net = model.vector_field_network
             both = torch.cat(pts) if len(pts) > 1 else pts[0]
-            sup.append(net(both, vector_only=True) if not net.training else net(both)[:, :3])
+            if not net.training:
+                sup.append(net(both, vector_only=True))
+            else:
+                # training mode: BatchNorm normalises every batch with ITS statistics and advances the running ones once per call, so
+                # the two batches go through two calls exactly as the reference makes them (:201,213)
+                sup.append(torch.cat([net(p)[:, :3] for p in pts]) if len(pts) > 1 else net(pts[0])[:, :3])
             sup_gt.append(torch.cat(gts) if len(gts) > 1 else gts[0])
         predictions = {"rgb": outputs.coarse_rgb_values, "depth": outputs.coarse_depth_map,
                        "normals": outputs.coarse_normals.reshape(-1, 3),
