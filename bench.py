@@ -104,6 +104,7 @@ def build_scene(dev, n_rays, s_c, n_f, seed, perturb=True, weight_seed=0):
     return model, uv, pose, K
 
 
+TRAINED_SCENE_FOCAL = 1143.0
 TRAINED_FIXTURES = ("trained_far.npz", "trained_256.npz")      # tests/golden: weights the reference's own trainer arrived at
 
 
@@ -139,7 +140,11 @@ def build_trained_scene(dev, n_rays, s_c, n_f, seed):
     what = load_trained_weights(model)
     if what is None:
         return None
-    uv, pose, K = synthetic.pinhole_batch(n_rays, 1200, 680, 600.0, seed=100 + seed, device=dev, pose=synthetic.orbit_pose(-35.0, 5.0, 0.9))
+    # 1200 x 680 pixels of the first training view; the focal length keeps the view INSIDE the frustum the model was trained on
+    # (64 x 64 pixels at f = 60: |x / z| <= 0.525 -> f = 1143 for 1200 pixels).  Outside it a trained field extrapolates to vectors
+    # of any length, the normalisation in front of the density is ill-conditioned there, and no two fp32 evaluations agree to 1e-4.
+    uv, pose, K = synthetic.pinhole_batch(n_rays, 1200, 680, TRAINED_SCENE_FOCAL, seed=100 + seed, device=dev, pose=synthetic.orbit_pose(-35.0, 5.0, 0.9))
+    what["camera"] = f"1200x680 pinhole, f = {TRAINED_SCENE_FOCAL:g} (the horizontal field of view of the 64x64 / f = 60 training views), first training pose"
     return model, uv, pose, K, what
 
 
@@ -1094,7 +1099,8 @@ def main() -> None:
             "per_rank_rays_per_s": rates,
             "config": {"workload": f"VectorFieldNerf.render forward, {args.rays}-ray chunk x {s_t} samples/ray "
                                    f"(S_c={s_c} + N_f={n_f}), shipped 9x256 VF + 5x256 rendering MLPs, eval-mode BN, "
-                                   f"stratified sampling on device Philox, Replica-like 1200x680 pinhole",
+                                   f"stratified sampling on device Philox, Replica-like 1200x680 pinhole" +
+                                   (f" (f = {TRAINED_SCENE_FOCAL:g}: the training views' field of view)" if scene_info is not None else ""),
                        "rays_per_chunk_per_gpu": args.rays, "samples_per_ray": s_t, "parallelism": f"rays x{world}",
                        "vf_evaluations_per_ray": s_t if getattr(model, "reuse_proposal", False) and f16 else s_c + s_t,
                        "colour_products": cp if f16 else None,

@@ -35,7 +35,7 @@ const char* vfn_last_error(void);
 int vfn_abi_version(void);
 /* sizeof() of the POD structs of this header as the library was compiled, by index: 0 vfn_net_geom, 1 vfn_layer_params,
  * 2 vfn_raygen_params, 3 vfn_density_params, 4 vfn_fine_params, 5 vfn_render_params, 6 vfn_unfold_entry, 7 vfn_wgrad_layer,
- * 8 vfn_loss_params;
+ * 8 vfn_loss_params, 9 vfn_train_step_params, 10 vfn_train_step_io;
  * -1 for any other index.  A binding checks its own mirrors of the structs against these (tests/test_host_logic.py). */
 int32_t vfn_abi_struct_bytes(int32_t which);
 
@@ -645,6 +645,76 @@ int vfn_flat_clip_grad_norm(float* flat_grad, int64_t n, int32_t n_regions, cons
 int vfn_flat_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t n_regions,
                        const int64_t* starts, const int64_t* ends, const int32_t* mults, const double* step_size,
                        const double* bc2_sqrt, double beta1, double beta2, double eps, double weight_decay, void* stream);
+
+/* =============================================================================================
+ * ONE training step in ONE call (csrc/vfn_train.hip): the reference trainer's loop body, train/vector_field_nerf_train.py:172-260 in the
+ * regime every shipped scene runs (eval-mode networks, :140-141; border + centre supervision, :186-216; VFLoss; zero_grad; backward;
+ * clip_grad_norm_ over the duplicated parameter list; Adam.step) issued from C on one stream out of one caller-supplied workspace —
+ * what vfn_render_fwd is to the gradient-free render().  It SEQUENCES entry points of this header (the f16x3 saving forwards with one
+ * vector-field evaluation per distinct sample, vfn_vf_loss_fwd / _bwd, the bf16 chains over one fragment-ordered workspace shared by
+ * the fine pass and the supervision batch, vfn_net_weight_grads_frag_part, vfn_flat_clip_grad_norm, vfn_flat_adam_step, the re-packs),
+ * so every value is what those entry points produce called one by one.
+ *   phases: VFN_TRAIN_FORWARD_BACKWARD ends with every parameter's gradient ADDED into flat_grad (zeroed first); a multi-rank caller
+ *           all-reduces flat_grad, then calls again with VFN_TRAIN_OPTIMIZER (clip, Adam, re-pack).  Both bits: the whole step.
+ *   render: sizes, samplers, density, Philox (seed, offset) of the three draws (laid out coarse | fine | add, as vfn_render_fwd);
+ *           colour_products / separate_launches / streams / timing_events are ignored.  N S_c and N S_t must be multiples of 32.
+ *   loss:   weights, clamp and flags of VFLoss; n_rays / n_normals / n_sup are filled in by the call (ONE supervision segment: the
+ *           border batch followed by the centre batch; ray_center selects the ray samples inside the centre ball on the device).
+ *   n_sup:  points per supervision batch (the trainer uses (N S_t) / 10); border / center: which batches exist; the shells are
+ *           [border_r_min, border_r_max] (inward ground truth) and [0, sup_radius] (outward) around sup_centroid; their draws come
+ *           from the Philox stream (sup_seed, sup_offset) — border first — unless sup_u_border / sup_u_center supply them ([n_sup,3]).
+ *   save_flags / dy_flags / dy_form / x_form: the storage forms of the training workspace (vfn_vf_render_fused16_fwd_train_at,
+ *           vfn_mlp_bwd_chain_bf16_ws_at, vfn_weight_grad_frag); fragment order (save_flags bit 1) is required.
+ *   forward_products: colour_products of the saving forwards (3; 2; 1 = the single-product mode, which also takes dy_flags bit 4).
+ *   regions / step_size / bc2_sqrt / betas / eps / weight_decay / max_norm: as vfn_flat_clip_grad_norm and vfn_flat_adam_step.
+ *   repack: re-pack vf_packed16, rn_packed16 and the two transposed bf16 packs from the updated parameters at the end of phase 2.
+ * Outputs of phase 1 (caller-allocated, the NerfOutput of the step's render): ray_dirs[N,3], z_vals[N,S_t], points[N,S_t,3],
+ * normals[N S_t,3], colors[N S_t,3], weights[N,S_t], rgb[N,3], depth[N]; out_terms[8] as vfn_vf_loss_fwd.  Phase 2: out_norm[2] as
+ * vfn_flat_clip_grad_norm.  No allocation, no synchronisation, no host read-back. */
+#define VFN_TRAIN_FORWARD_BACKWARD 1
+#define VFN_TRAIN_OPTIMIZER 2
+typedef struct vfn_train_step_params {
+    vfn_render_params render;
+    vfn_loss_params loss;
+    int64_t n_sup;
+    int32_t border, center;
+    float sup_centroid[3];
+    float sup_radius;                   /* centre ball [0, sup_radius] (outward ground truth); also the radius of the ray_center selection */
+    float border_r_min, border_r_max;   /* border shell (inward ground truth): far - 5 radius .. far, evaluated by the host in double as Python does */
+    int32_t phases;
+    uint64_t sup_seed, sup_offset;
+    int32_t save_flags, dy_flags, dy_form, x_form;
+    int32_t forward_products;
+    int32_t repack;
+    int32_t n_regions;
+    int32_t mults[4];
+    int64_t starts[4], ends[4];
+    double step_size[8], bc2_sqrt[8];
+    double beta1, beta2, eps, weight_decay;
+    float max_norm;
+    int32_t reserved;
+} vfn_train_step_params;
+typedef struct vfn_train_step_io {
+    const vfn_net_geom* vf_geom; const vfn_net_geom* rn_geom;
+    void* vf_packed16; void* rn_packed16; void* vf_packed_bwd16; void* rn_packed_bwd16;       /* read by phase 1, rewritten by the re-pack */
+    const vfn_layer_params* vf_layers; const vfn_layer_params* rn_layers;                     /* host arrays [n_layers]: the re-pack's inputs */
+    const vfn_wgrad_layer* vf_wgrad; const vfn_wgrad_layer* rn_wgrad;                         /* host arrays [n_layers]: parameters and where their gradients go */
+    const float* vf_head_w; const float* rn_head_w;                                           /* rows 0..2 of each net's last Linear */
+    const float* beta; const float* mean; const float* scale;                                 /* the density's three raw scalars ... */
+    float* g_beta; float* g_mean; float* g_scale;                                             /* ... and their gradient words (inside flat_grad) */
+    float* flat_param; float* flat_grad; float* exp_avg; float* exp_avg_sq; int64_t n_flat;   /* the optimizer's flat buffers (vfn_flat_adam_step) */
+    void* clip_workspace;
+    const float* uv; const float* pose; const float* intrinsics; const float* t_vals;
+    const float* far_coarse_per_ray; const float* far_fine_per_ray;
+    const float* u_coarse; const float* u_fine; const float* u_add;                           /* optional supplied draws (parity runs) */
+    const float* sup_u_border; const float* sup_u_center;
+    const float* rgb_gt; const float* depth_gt;
+    void* workspace;                                                                          /* vfn_train_step_workspace_bytes() bytes */
+    float* ray_dirs; float* z_vals; float* points; float* normals; float* colors; float* weights; float* rgb; float* depth;
+    float* out_terms; float* out_norm;
+} vfn_train_step_io;
+int64_t vfn_train_step_workspace_bytes(const vfn_train_step_params* p, const vfn_net_geom* vf_geom, const vfn_net_geom* rn_geom);
+int vfn_train_step(const vfn_train_step_params* p, const vfn_train_step_io* io, void* stream);
 
 /* =============================================================================================
  * Networks in TRAINING mode: nn.BatchNorm1d with batch statistics (vector_field_network.py:146-208 and

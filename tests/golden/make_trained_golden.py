@@ -60,7 +60,7 @@ TRAIN = dict(seed=21, teacher_seed=22, gain=2.0, n_rays=64, n_samples=32, n_impo
              torch_seed=3100, cam_seed=300)
 
 # the far-from-init run: more rays per batch, five times the steps; everything else as above
-TRAIN_FAR = dict(TRAIN, n_rays=256, epochs=int(os.environ.get("VFN_FAR_EPOCHS", "60")), torch_seed=3200, numpy_seed=2026)
+TRAIN_FAR = dict(TRAIN, n_rays=256, epochs=int(os.environ.get("VFN_FAR_EPOCHS", "80")), torch_seed=3200, numpy_seed=2026)
 
 # the captures on the trained state (make_golden.FIXTURES-style records; `seed` only offsets the capture's torch seed) --------
 CAPTURES = {

@@ -14,13 +14,15 @@ from vf_nerf_amd import synthetic
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # trained_256*: weights the reference's own trainer arrived at after 1200 optimizer steps (tests/golden/make_trained_golden.py);
 # every other fixture holds weights of the synthetic init family (seed + default init x gain + recentred vector head)
-FIXTURE_NAMES = ("c1_det", "c1_perturb", "odd_orbit", "w1_det", "shipped_sizes", "bench_sizes", "trained_256", "trained_256_shipped")
+FIXTURE_NAMES = ("c1_det", "c1_perturb", "odd_orbit", "w1_det", "shipped_sizes", "bench_sizes", "trained_256", "trained_256_shipped",
+                 "trained_far")
 
 
 def load_fixture(name: str):
     """-> (fx: dict of scalars, data: dict of torch tensors)."""
     raw = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
     fx = ast.literal_eval(str(raw["fixture"]))
+    fx["name"] = name
     data = {k: torch.from_numpy(raw[k]) for k in raw.files if raw[k].dtype.kind not in "US"}
     return fx, data
 
@@ -73,7 +75,7 @@ def density_scalars(fx: dict):
     """(beta, mean, scale) as stored parameters: the shipped initial values, or the trained fixture's."""
     if not fx.get("trained"):
         return 0.5, 0.7, 100.0
-    src = fx.get("weights_in", "trained_256")
+    src = fx.get("weights_in", fx.get("name", "trained_256"))       # a trained fixture holds its own weights unless it names another's
     if src not in _SCALARS:
         raw = np.load(os.path.join(GOLDEN_DIR, f"{src}.npz"))
         _SCALARS[src] = tuple(float(raw[f"w.density.{k}"].reshape(-1)[0]) for k in ("beta", "mean", "scale"))

@@ -9,7 +9,7 @@ OUT=${VFN_OUT:-libvfn.so}
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=${ARCH} -Wall -Wno-unused-function"
 # vfn_mlp16 / vfn_bwd16: accumulators in arch VGPRs (all AGPRs hold activations), full unrolling of the K loops
 MFMA16="-mllvm -amdgpu-mfma-vgpr-form -mllvm -pragma-unroll-threshold=10000000"
-UNITS="vfn_pack vfn_mlp vfn_mlp_bwd vfn_dw16 vfn_dwf vfn_unfold vfn_bwd16 vfn_mlp16 vfn_rays vfn_grid vfn_bstat vfn_adam vfn_render vfn_wgrad vfn_loss"
+UNITS="vfn_pack vfn_mlp vfn_mlp_bwd vfn_dw16 vfn_dwf vfn_unfold vfn_bwd16 vfn_mlp16 vfn_rays vfn_grid vfn_bstat vfn_adam vfn_render vfn_wgrad vfn_loss vfn_train"
 
 extra_flags() {
   case "$1" in
@@ -27,8 +27,17 @@ mkdir -p "$OBJDIR"
 rm -f "$OUT.tmp"
 declare -A PIDS
 OBJS=""
+# VFN_ONLY="unit unit": developer shortcut — recompile only these units and link them with the other units' EXISTING objects (which
+# must be newer than their sources; anything else is refused).  The default, and what __graft_entry__.build() runs, rebuilds everything.
+ONLY=${VFN_ONLY:-}
 for u in $UNITS; do
   [ -f "$u.hip" ] || { echo "build.sh: missing source $u.hip" >&2; exit 1; }
+  if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $u "; then
+    if [ -s "$OBJDIR/$u.o" ] && [ "$OBJDIR/$u.o" -nt "$u.hip" ] && [ "$OBJDIR/$u.o" -nt vfn_common.h ] && [ "$OBJDIR/$u.o" -nt ../../include/vfn.h ]; then
+      OBJS="$OBJS $OBJDIR/$u.o"; touch "$OBJDIR/$u.remarks"; continue
+    fi
+    echo "build.sh: VFN_ONLY given but $u.o is missing or older than its sources" >&2; exit 1
+  fi
   rm -f "$OBJDIR/$u.o"
   # shellcheck disable=SC2046
   hipcc $FLAGS $(extra_flags "$u") -Rpass-analysis=kernel-resource-usage -c "$u.hip" -o "$OBJDIR/$u.o" 2> "$OBJDIR/$u.remarks" &
@@ -37,6 +46,7 @@ for u in $UNITS; do
 done
 failed=""
 for u in $UNITS; do
+  [ -n "${PIDS[$u]:-}" ] || continue
   if ! wait "${PIDS[$u]}"; then failed="$failed $u.hip"; fi
 done
 if [ -n "$failed" ]; then

@@ -36,6 +36,8 @@ extern "C" int32_t vfn_abi_struct_bytes(int32_t which) {
     case 6: return (int32_t)sizeof(vfn_unfold_entry);
     case 7: return (int32_t)sizeof(vfn_wgrad_layer);
     case 8: return (int32_t)sizeof(vfn_loss_params);
+    case 9: return (int32_t)sizeof(vfn_train_step_params);
+    case 10: return (int32_t)sizeof(vfn_train_step_io);
     default: return -1;
     }
 }

@@ -1,0 +1,318 @@
+// vfn_train.hip — ONE training step of the reference trainer's loop body as one entry point.
+//
+// train/vector_field_nerf_train.py:172-260 (the branch every shipped scene takes: eval-mode networks, :140-141; border + centre
+// supervision; VFLoss; zero_grad; backward; clip_grad_norm_ over the duplicated parameter list; Adam.step) is ~60 Python-side
+// operations per step in the facade (vf_nerf_amd/trainer.py::TrainStep through backward.py's autograd functions): at the reference's
+// batch size (1 024 rays) that is 2.2 ms of host time for a step whose kernels take 2.4 ms — eight ranks on one host would be
+// host-bound.  vfn_train_step issues the same launches, in the same order, from C on one stream out of ONE caller-supplied
+// workspace (vfn_train_step_workspace_bytes), the way vfn_render_fwd does for the gradient-free render:
+//
+//   phase 1 (VFN_TRAIN_FORWARD_BACKWARD)
+//     prep                      density scalars gathered, centroid, padding rows and the three scalar gradients zeroed
+//     rays + proposal samples   utils/rendering.py:12-60, ray_sampler.py:49-80,113-142        (draws generated in place or supplied)
+//     saving fused forward      vector_field_nerf.py:252-256 on the S_c proposal samples -> workspace rows [0, N S_c)
+//     weights -> argmax -> fine ray_sampler.py:264-302 with provenance (src / dst)
+//     saving fused forward      :294-297,315-318 on the N_f new samples -> workspace rows [N S_c, N S_t)
+//     density + composite       :308-323, gathering every sample from storage order to its sorted position
+//     supervision points        train.py:186-214 (functions.py:100-135): border shell, centre ball -> one batch, padded to 32
+//     saving vector-only fwd    train.py:201,213 on both batches -> workspace rows [N S_t, N S_t + pad32(2 n_sup))
+//     VFLoss forward            vf_loss.py:34-87 (+ the centre-ball rows of functions.py:137-157, selected on the device)
+//     zero the flat gradient    train.py:251
+//     VFLoss backward           train.py:252 ...
+//     dX chain, supervision     ... through the vector-field net over the supervision rows
+//     per-ray backward          d rgb / d depth (+ the loss's d normals) -> d colours, d normals, the three density scalars
+//     gather to storage order   row r of the workspace is sorted sample dst[r]
+//     dX chain, fine pass       rendering net -> feature hand-off -> vector-field net over rows [0, N S_t)
+//     weight gradients          rendering net (rows of the fine pass), vector-field net (hidden layers + head over ALL rows,
+//                               feature block over the fine pass's), un-folded and ADDED into the flat gradient
+//     density scalar gradients  added into the flat gradient
+//   [the caller all-reduces the flat gradient here when there is more than one rank: distributed.GradientBucket]
+//   phase 2 (VFN_TRAIN_OPTIMIZER)
+//     clip_grad_norm_           train.py:254-255 over the duplicated list (Q4)       vfn_flat_clip_grad_norm
+//     Adam                      train.py:258, sequential semantics                    vfn_flat_adam_step
+//     re-pack                   the four weight packs the next step reads
+//
+// Nothing here computes: it sequences entry points and internal launches of this library on slices of one workspace, so every
+// value is what the launch-by-launch path produces (tests/test_hip_trainer.py::test_one_call_training_step_equals_the_launch_by_launch_step).
+#include <string.h>
+#include "vfn_common.h"
+#include "vfn_plan.h"
+
+namespace {
+
+struct Carve {
+    unsigned char* base;
+    size_t off;
+    template <typename T> T* take(size_t count) {
+        T* p = reinterpret_cast<T*>(base ? base + off : nullptr);
+        off += ((count * sizeof(T) + 255) / 256) * 256;
+        return p;
+    }
+};
+
+constexpr size_t GROUP_BYTES = 32768;      // one group of 32 points of a fragment-ordered slot
+
+struct Ws {
+    // render intermediates
+    float *directions, *cam_loc, *z_c, *pts_c, *new_pts;
+    int32_t *dst, *src;
+    // per-sample results in STORAGE order [proposal samples | new samples] and their gradients
+    float *normals_s, *colors_s, *dn_s, *dc_s;
+    // sorted per-sample gradients
+    float *dn, *dc;
+    // supervision batch (padded to whole groups of 32 points)
+    float *sup_pts, *sup_gt, *sup_pred, *d_sup;
+    // loss
+    float *d_rgb, *d_depth;
+    void* loss_ws;
+    // scalars: [beta, mean, scale] gathered, their gradients, the supervision centroid
+    float *scal, *dscal, *centroid;
+    // training workspace
+    unsigned char *saved, *dy;
+    uint32_t* masks;
+    float *aux_vf, *aux_rn, *dz_vec, *dz_rgb;
+    void *scratch_vf, *scratch_rn;
+    size_t slot_bytes;
+    long long m_c, m, m_sup, m_sup_pad, total;
+    int vf_h, rn_h;
+    size_t bytes;
+};
+
+long long pad32(long long n) { return (n + 31) / 32 * 32; }
+
+int hidden_entries(int net_kind, const vfn_net_geom* g, const char* what) {
+    VfnNetPlan plan;
+    char err[256] = {0};
+    int rc = vfn_make_plan(net_kind, g, &plan, err, sizeof(err));
+    if (rc != VFN_OK) { vfn_set_error("%s: %s", what, err); return rc; }
+    return plan.n_hidden;
+}
+
+// `out` (the caller's per-sample / per-ray outputs) are separate buffers: the workspace holds only what a step needs internally
+int carve(void* workspace, const vfn_train_step_params* p, const vfn_net_geom* vf_geom, const vfn_net_geom* rn_geom, Ws* w) {
+    const long long n = p->render.n_rays, sc = p->render.n_coarse, nf = p->render.n_fine, st = sc + nf;
+    w->vf_h = hidden_entries(VFN_NET_VF, vf_geom, "vfn_train_step");
+    if (w->vf_h < 0) return w->vf_h;
+    w->rn_h = hidden_entries(VFN_NET_RENDER, rn_geom, "vfn_train_step");
+    if (w->rn_h < 0) return w->rn_h;
+    w->m_c = n * sc; w->m = n * st;
+    w->m_sup = (long long)p->n_sup * ((p->border ? 1 : 0) + (p->center ? 1 : 0));
+    w->m_sup_pad = pad32(w->m_sup);
+    w->total = w->m + w->m_sup_pad;
+    const int slots = w->vf_h + w->rn_h;
+    w->slot_bytes = (size_t)((w->total + 31) / 32) * GROUP_BYTES;
+    Carve c{static_cast<unsigned char*>(workspace), 0};
+    w->directions = c.take<float>(n * 3);
+    w->cam_loc = c.take<float>(n * 3);
+    w->z_c = c.take<float>(n * sc);
+    w->pts_c = c.take<float>(n * sc * 3);
+    w->new_pts = c.take<float>(n * nf * 3);
+    w->dst = c.take<int32_t>(w->m);
+    w->src = c.take<int32_t>(w->m);
+    w->normals_s = c.take<float>(w->m * 3);
+    w->colors_s = c.take<float>(w->m * 3);
+    w->dn_s = c.take<float>(w->m * 3);
+    w->dc_s = c.take<float>(w->m * 3);
+    w->dn = c.take<float>(w->m * 3);
+    w->dc = c.take<float>(w->m * 3);
+    w->sup_pts = c.take<float>(w->m_sup_pad * 3);
+    w->sup_gt = c.take<float>(w->m_sup_pad * 3);
+    w->sup_pred = c.take<float>(w->m_sup_pad * 3);
+    w->d_sup = c.take<float>(w->m_sup_pad * 3);
+    w->d_rgb = c.take<float>(n * 3);
+    w->d_depth = c.take<float>(n);
+    w->loss_ws = c.take<unsigned char>((size_t)vfn_vf_loss_workspace_bytes());
+    w->scal = c.take<float>(4);
+    w->dscal = c.take<float>(4);
+    w->centroid = c.take<float>(4);
+    w->saved = c.take<unsigned char>((size_t)slots * w->slot_bytes);
+    w->dy = c.take<unsigned char>((size_t)slots * w->slot_bytes);
+    w->masks = c.take<uint32_t>((size_t)slots * w->total * 8);
+    w->aux_vf = c.take<float>(w->total * 40);
+    w->aux_rn = c.take<float>(w->total * 40);
+    w->dz_vec = c.take<float>(w->total * 4);
+    w->dz_rgb = c.take<float>(w->m * 4);
+    const int64_t s_vf = vfn_net_weight_grads_scratch_bytes(VFN_NET_VF, vf_geom, w->total);
+    const int64_t s_rn = vfn_net_weight_grads_scratch_bytes(VFN_NET_RENDER, rn_geom, w->m);
+    if (s_vf < 0 || s_rn < 0) return VFN_ERR_UNSUPPORTED;
+    w->scratch_vf = c.take<unsigned char>((size_t)s_vf);
+    w->scratch_rn = c.take<unsigned char>((size_t)s_rn);
+    w->bytes = c.off;
+    return VFN_OK;
+}
+
+struct PrepArgs {
+    const float *beta, *mean, *scale;
+    float *scal, *dscal, *centroid;
+    float cx, cy, cz;
+    float *pad_pts, *pad_gt, *pad_dsup;       // rows [m_sup, m_sup_pad) of the supervision batch and of its upstream gradient
+    int pad_floats;
+};
+
+__global__ void vfn_train_prep_kernel(const PrepArgs a) {
+    const int t = threadIdx.x;
+    if (t == 0) {
+        a.scal[0] = *a.beta; a.scal[1] = *a.mean; a.scal[2] = *a.scale;
+        a.dscal[0] = 0.f; a.dscal[1] = 0.f; a.dscal[2] = 0.f;
+        a.centroid[0] = a.cx; a.centroid[1] = a.cy; a.centroid[2] = a.cz;
+    }
+    if (t < a.pad_floats) { a.pad_pts[t] = 0.f; a.pad_gt[t] = 0.f; a.pad_dsup[t] = 0.f; }
+}
+
+__global__ void vfn_train_scalar_grads_kernel(const float* dscal, float* g_beta, float* g_mean, float* g_scale) {
+    if (threadIdx.x == 0) { *g_beta += dscal[0]; *g_mean += dscal[1]; *g_scale += dscal[2]; }
+}
+
+#define STEP(call)                       \
+    do {                                 \
+        rc = (call);                     \
+        if (rc != VFN_OK) return rc;     \
+    } while (0)
+
+}  // namespace
+
+extern "C" int64_t vfn_train_step_workspace_bytes(const vfn_train_step_params* p, const vfn_net_geom* vf_geom, const vfn_net_geom* rn_geom) {
+    if (!p || !vf_geom || !rn_geom || p->render.n_rays < 1 || p->render.n_coarse < 1 || p->render.n_fine < 2 || p->n_sup < 0) return VFN_ERR_INVALID;
+    Ws w;
+    const int rc = carve(nullptr, p, vf_geom, rn_geom, &w);
+    return rc != VFN_OK ? rc : (int64_t)w.bytes;
+}
+
+extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_step_io* io, void* stream) {
+    VFN_REQUIRE(p && io && io->vf_geom && io->rn_geom, "vfn_train_step: NULL argument");
+    const vfn_render_params& r = p->render;
+    VFN_REQUIRE(r.n_rays > 0 && r.n_coarse >= 1 && r.n_fine >= 2, "vfn_train_step: bad sizes (n_rays=%d, n_coarse=%d, n_fine=%d)", r.n_rays,
+                r.n_coarse, r.n_fine);
+    VFN_REQUIRE(p->phases & (VFN_TRAIN_FORWARD_BACKWARD | VFN_TRAIN_OPTIMIZER), "vfn_train_step: phases = %d selects nothing", p->phases);
+    const int n = r.n_rays, sc = r.n_coarse, nf = r.n_fine, st = sc + nf;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+
+    if (p->phases & VFN_TRAIN_FORWARD_BACKWARD) {
+        VFN_REQUIRE(io->workspace && io->vf_packed16 && io->rn_packed16 && io->vf_packed_bwd16 && io->rn_packed_bwd16 && io->vf_wgrad && io->rn_wgrad &&
+                    io->vf_head_w && io->rn_head_w && io->beta && io->mean && io->scale && io->g_beta && io->g_mean && io->g_scale && io->flat_grad &&
+                    io->uv && io->pose && io->intrinsics && io->t_vals && io->rgb_gt && io->out_terms && io->ray_dirs && io->z_vals && io->points &&
+                    io->normals && io->colors && io->weights && io->rgb && io->depth, "vfn_train_step: NULL argument");
+        VFN_REQUIRE(((long long)n * sc) % 32 == 0 && ((long long)n * st) % 32 == 0,
+                    "vfn_train_step: the proposal samples and all samples must be whole groups of 32 points (%d rays x %d + %d)", n, sc, nf);
+        VFN_REQUIRE(p->save_flags & 2, "vfn_train_step: the fragment-ordered workspace only (save_flags bit 1)");
+        VFN_REQUIRE(!p->loss.has_depth || io->depth_gt, "vfn_train_step: has_depth without depth_gt");
+        Ws w;
+        STEP(carve(io->workspace, p, io->vf_geom, io->rn_geom, &w));
+        VFN_REQUIRE(w.total < (1ll << 21), "vfn_train_step: at most 2097151 workspace points per step (%lld)", w.total);
+        const int pad_floats = (int)((w.m_sup_pad - w.m_sup) * 3);
+        PrepArgs pa{io->beta, io->mean, io->scale, w.scal, w.dscal, w.centroid, p->sup_centroid[0], p->sup_centroid[1], p->sup_centroid[2],
+                    w.sup_pts + w.m_sup * 3, w.sup_gt + w.m_sup * 3, w.d_sup + w.m_sup * 3, pad_floats};
+        hipLaunchKernelGGL(vfn_train_prep_kernel, dim3(1), dim3(128), 0, s, pa);
+        STEP(vfn_check_launch("vfn_train_step (prep)"));
+
+        // ---- render() under autograd: one vector-field evaluation per distinct sample (backward.StoredFinePass) -----------------------
+        const int gen_c = r.perturb_coarse && !io->u_coarse, gen_f = r.perturb_fine && !io->u_fine, gen_a = !io->u_add;
+        const long long base_f = gen_c ? (long long)n * sc : 0, base_a = base_f + (gen_f ? (long long)n * nf : 0);
+        vfn_raygen_params rq = {n, sc, r.pose_is_quat, r.near_coarse, r.far_coarse};
+        STEP(vfn_internal_raygen(&rq, io->uv, io->pose, io->intrinsics, io->intrinsics, io->t_vals, io->far_coarse_per_ray,
+                                 r.perturb_coarse ? io->u_coarse : nullptr, gen_c, 0, r.seed, r.offset, w.directions, io->ray_dirs, w.cam_loc, w.z_c,
+                                 w.pts_c, s));
+        float* saved_f = reinterpret_cast<float*>(w.saved);
+        STEP(vfn_vf_render_fused16_fwd_train_at(io->vf_geom, io->vf_packed16, io->rn_geom, io->rn_packed16, w.pts_c, io->ray_dirs, w.m_c, sc,
+                                                w.normals_s, w.colors_s, saved_f, w.aux_vf, w.aux_rn, w.masks, p->save_flags, 0, w.total,
+                                                p->forward_products, s));
+        vfn_density_params dp = r.density;
+        dp.n_rays = n; dp.n_samples = sc;
+        vfn_fine_params fp = {n, sc, nf, r.near_fine, r.far_fine, r.fine_range, r.window_step, r.span};
+        STEP(vfn_internal_density_fine(&dp, w.normals_s, io->ray_dirs, w.z_c, w.scal, &fp, w.directions, w.cam_loc, io->far_fine_per_ray,
+                                       r.perturb_fine ? io->u_fine : nullptr, io->u_add, gen_f, gen_a, base_f, base_a, r.seed, r.offset, io->z_vals,
+                                       io->points, w.src, w.new_pts, w.dst, w.m_c, s));
+        STEP(vfn_vf_render_fused16_fwd_train_at(io->vf_geom, io->vf_packed16, io->rn_geom, io->rn_packed16, w.new_pts, io->ray_dirs, w.m - w.m_c, nf,
+                                                w.normals_s + w.m_c * 3, w.colors_s + w.m_c * 3, saved_f, w.aux_vf, w.aux_rn, w.masks, p->save_flags,
+                                                w.m_c, w.total, p->forward_products, s));
+        dp.n_samples = st;
+        // every sample (proposal and new) moves from storage order to its sorted position on the way into the composite launch
+        STEP(vfn_internal_composite_gather(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, w.src, w.normals_s, w.colors_s, w.m,
+                                           io->weights, io->rgb, io->depth, s));
+
+        // ---- supervision points and their vector-only forward (train.py:186-216) -----------------------------------------------------
+        long long row = 0;
+        if (p->border && p->n_sup > 0) {
+            STEP(vfn_sample_sphere_shell(p->n_sup, p->border_r_min, p->border_r_max, w.centroid, 1, io->sup_u_border, p->sup_seed,
+                                         p->sup_offset, w.sup_pts, w.sup_gt, s));
+            row += p->n_sup;
+        }
+        if (p->center && p->n_sup > 0) {
+            STEP(vfn_sample_sphere_shell(p->n_sup, 0.0f, p->sup_radius, w.centroid, 0, io->sup_u_center, p->sup_seed,
+                                         p->sup_offset + (io->sup_u_border || !p->border ? 0 : (uint64_t)p->n_sup), w.sup_pts + row * 3,
+                                         w.sup_gt + row * 3, s));
+            row += p->n_sup;
+        }
+        if (w.m_sup_pad > 0)
+            STEP(vfn_vf_mlp16_fwd_train_at(io->vf_geom, io->vf_packed16, w.sup_pts, w.m_sup_pad, 0, w.sup_pred, saved_f, w.aux_vf, w.masks,
+                                           p->save_flags, w.m, w.total, s));
+
+        // ---- VFLoss forward / backward (vf_loss.py:34-87; the centre-ball rows of functions.py:137-157 inside the launches) -------------
+        vfn_loss_params lp = p->loss;
+        lp.n_rays = n; lp.n_normals = w.m;
+        lp.n_sup[0] = w.m_sup; lp.n_sup[1] = 0; lp.n_sup[2] = 0;
+        const float* sup_pred[3] = {w.m_sup ? w.sup_pred : nullptr, nullptr, nullptr};
+        const float* sup_gt[3] = {w.m_sup ? w.sup_gt : nullptr, nullptr, nullptr};
+        float* d_sup[3] = {w.m_sup ? w.d_sup : nullptr, nullptr, nullptr};
+        const float* loss_points = lp.ray_center ? io->points : nullptr;
+        STEP(vfn_vf_loss_fwd(&lp, io->rgb, io->rgb_gt, lp.has_depth ? io->depth : nullptr, lp.has_depth ? io->depth_gt : nullptr, io->normals,
+                             loss_points, sup_pred, sup_gt, w.loss_ws, io->out_terms, s));
+        if (hipMemsetAsync(io->flat_grad, 0, (size_t)io->n_flat * sizeof(float), s) != hipSuccess) {
+            vfn_set_error("vfn_train_step: could not zero the flat gradient");
+            return VFN_ERR_LAUNCH;
+        }
+        // d normals of the loss lands in `dn`, where the per-ray backward ADDS the density path's share
+        STEP(vfn_vf_loss_bwd(&lp, io->rgb, io->rgb_gt, lp.has_depth ? io->depth : nullptr, lp.has_depth ? io->depth_gt : nullptr, io->normals,
+                             loss_points, sup_pred, sup_gt, w.loss_ws, nullptr, w.d_rgb, lp.has_depth ? w.d_depth : nullptr, w.dn, d_sup, s));
+
+        // ---- backward: supervision chain, per-ray backward, fine chain, weight gradients -------------------------------------------------
+        const float* feats = saved_f + (size_t)(w.vf_h - 1) * (w.slot_bytes / 4);           // the tanh'ed feature slot, row-major fp32
+        if (w.m_sup_pad > 0)
+            STEP(vfn_mlp_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, nullptr, nullptr, nullptr, feats, w.masks, w.dy,
+                                              p->dy_flags, nullptr, nullptr, w.d_sup, w.sup_pred, nullptr, 3, w.m_sup_pad, nullptr, w.dz_vec, w.m,
+                                              w.total, s));
+        STEP(vfn_ray_density_weights_bwd(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, w.d_rgb, lp.has_depth ? w.d_depth : nullptr,
+                                         nullptr, w.dn, w.dc, w.dscal, s));
+        // row src[i] of the workspace is sorted sample i: gradients to storage order
+        STEP(vfn_scatter_rows3(w.dn, w.dc, w.src, w.m, w.dn_s, w.dc_s, s));
+        STEP(vfn_mlp_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, io->rn_geom, io->rn_packed_bwd16, io->rn_head_w, feats,
+                                          w.masks, w.dy, p->dy_flags, w.dc_s, w.colors_s, w.dn_s, w.normals_s, nullptr, 3, w.m, w.dz_rgb, w.dz_vec, 0,
+                                          w.total, s));
+        const size_t rn_off = (size_t)w.vf_h * w.slot_bytes;
+        STEP(vfn_net_weight_grads_frag_part(VFN_NET_RENDER, io->rn_geom, io->rn_wgrad, w.saved + rn_off, w.dy + rn_off, (int64_t)w.slot_bytes,
+                                            p->dy_form, p->x_form, feats, w.aux_rn, w.dz_rgb, w.m,
+                                            VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD, 1, w.scratch_rn, s));
+        // vector-field net: hidden layers + head over ALL rows (fine pass + supervision), the feature block over the fine pass's rows
+        if (w.m_sup_pad > 0) {
+            STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form,
+                                                nullptr, w.aux_vf, w.dz_vec, w.total, VFN_WGRAD_LAYERS | VFN_WGRAD_HEAD, 1, w.scratch_vf, s));
+            STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form,
+                                                nullptr, w.aux_vf, w.dz_vec, w.m, VFN_WGRAD_FEATURES, 1, w.scratch_vf, s));
+        } else {
+            STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form,
+                                                nullptr, w.aux_vf, w.dz_vec, w.m, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD, 1,
+                                                w.scratch_vf, s));
+        }
+        hipLaunchKernelGGL(vfn_train_scalar_grads_kernel, dim3(1), dim3(64), 0, s, w.dscal, io->g_beta, io->g_mean, io->g_scale);
+        STEP(vfn_check_launch("vfn_train_step (density scalar gradients)"));
+    }
+
+    if (p->phases & VFN_TRAIN_OPTIMIZER) {
+        VFN_REQUIRE(io->flat_param && io->flat_grad && io->exp_avg && io->exp_avg_sq && io->clip_workspace && io->out_norm && io->n_flat > 0 &&
+                    p->n_regions >= 1 && p->n_regions <= 4, "vfn_train_step: optimizer phase without its buffers");
+        STEP(vfn_flat_clip_grad_norm(io->flat_grad, io->n_flat, p->n_regions, p->starts, p->ends, p->mults, p->max_norm, io->clip_workspace,
+                                     io->out_norm, s));
+        STEP(vfn_flat_adam_step(io->flat_param, io->flat_grad, io->exp_avg, io->exp_avg_sq, io->n_flat, p->n_regions, p->starts, p->ends, p->mults,
+                                p->step_size, p->bc2_sqrt, p->beta1, p->beta2, p->eps, p->weight_decay, s));
+        if (p->repack) {
+            VFN_REQUIRE(io->vf_layers && io->rn_layers && io->vf_packed16 && io->rn_packed16 && io->vf_packed_bwd16 && io->rn_packed_bwd16,
+                        "vfn_train_step: repack without the layer tables / packs");
+            STEP(vfn_pack16_weights(VFN_NET_VF, io->vf_geom, io->vf_layers, io->vf_packed16, s));
+            STEP(vfn_pack16_weights(VFN_NET_RENDER, io->rn_geom, io->rn_layers, io->rn_packed16, s));
+            STEP(vfn_pack_weights_bwd16_mode(VFN_NET_VF, io->vf_geom, io->vf_layers, p->forward_products == 1 ? 1 : 0, io->vf_packed_bwd16, s));
+            STEP(vfn_pack_weights_bwd16_mode(VFN_NET_RENDER, io->rn_geom, io->rn_layers, p->forward_products == 1 ? 1 : 0, io->rn_packed_bwd16, s));
+        }
+    }
+    return VFN_OK;
+}

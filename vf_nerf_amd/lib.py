@@ -34,7 +34,7 @@ EXPORTS = (
     "vfn_vf_mlp16_fwd_train_at", "vfn_mlp_bwd_chain_bf16_ws_at",
     "vfn_weight_grad_groups", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax", "vfn_merge_sort_depths",
     "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_f16x3_set_clock_probe", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step", "vfn_unfold_weight_grads_acc", "vfn_render_fwd", "vfn_render_fwd_workspace_bytes",
-    "vfn_vf_loss_workspace_bytes", "vfn_vf_loss_fwd", "vfn_vf_loss_bwd",
+    "vfn_vf_loss_workspace_bytes", "vfn_vf_loss_fwd", "vfn_vf_loss_bwd", "vfn_train_step", "vfn_train_step_workspace_bytes",
 )
 
 
@@ -86,6 +86,29 @@ class LossParams(C.Structure):
                 ("ray_center", C.c_int32), ("reserved", C.c_int32), ("w_rgb", C.c_float), ("w_depth", C.c_float), ("w_unit", C.c_float),
                 ("w_sup", C.c_float), ("w_smaller", C.c_float), ("depth_clamp", C.c_float), ("radius", C.c_float), ("centroid", C.c_float * 3)]
 
+
+class TrainStepParams(C.Structure):
+    """mirrors vfn_train_step_params"""
+    _fields_ = [("render", RenderParams), ("loss", LossParams), ("n_sup", C.c_int64), ("border", C.c_int32), ("center", C.c_int32),
+                ("sup_centroid", C.c_float * 3), ("sup_radius", C.c_float), ("border_r_min", C.c_float), ("border_r_max", C.c_float), ("phases", C.c_int32),
+                ("sup_seed", C.c_uint64), ("sup_offset", C.c_uint64), ("save_flags", C.c_int32), ("dy_flags", C.c_int32), ("dy_form", C.c_int32),
+                ("x_form", C.c_int32), ("forward_products", C.c_int32), ("repack", C.c_int32), ("n_regions", C.c_int32), ("mults", C.c_int32 * 4),
+                ("starts", C.c_int64 * 4), ("ends", C.c_int64 * 4), ("step_size", C.c_double * 8), ("bc2_sqrt", C.c_double * 8),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double), ("max_norm", C.c_float),
+                ("reserved", C.c_int32)]
+
+
+class TrainStepIO(C.Structure):
+    """mirrors vfn_train_step_io (every member a pointer except n_flat)"""
+    _fields_ = [(n, C.c_void_p) for n in ("vf_geom", "rn_geom", "vf_packed16", "rn_packed16", "vf_packed_bwd16", "rn_packed_bwd16", "vf_layers", "rn_layers",
+                                          "vf_wgrad", "rn_wgrad", "vf_head_w", "rn_head_w", "beta", "mean", "scale", "g_beta", "g_mean", "g_scale",
+                                          "flat_param", "flat_grad", "exp_avg", "exp_avg_sq")] + [("n_flat", C.c_int64)] + \
+               [(n, C.c_void_p) for n in ("clip_workspace", "uv", "pose", "intrinsics", "t_vals", "far_coarse_per_ray", "far_fine_per_ray", "u_coarse", "u_fine",
+                                          "u_add", "sup_u_border", "sup_u_center", "rgb_gt", "depth_gt", "workspace", "ray_dirs", "z_vals", "points", "normals",
+                                          "colors", "weights", "rgb", "depth", "out_terms", "out_norm")]
+
+
+TRAIN_FORWARD_BACKWARD, TRAIN_OPTIMIZER = 1, 2
 
 _lib: Optional[C.CDLL] = None
 
@@ -220,7 +243,8 @@ def _declare(lib: C.CDLL) -> None:
 
 def struct_mirrors():
     """The ctypes mirrors of the header's POD structs in the order of ``vfn_abi_struct_bytes``."""
-    return (NetGeom, LayerParams, RaygenParams, DensityParams, FineParams, RenderParams, UnfoldEntry, WgradLayer, LossParams)
+    return (NetGeom, LayerParams, RaygenParams, DensityParams, FineParams, RenderParams, UnfoldEntry, WgradLayer, LossParams, TrainStepParams,
+            TrainStepIO)
 
 
 def load() -> C.CDLL:
@@ -890,6 +914,18 @@ STATUS_ACT_SATURATED, STATUS_INPUT_SATURATED = 1, 2
 def f16x3_set_status(word: Optional[torch.Tensor]) -> None:
     """Route the range reports of this thread's f16x3 launches into ``word`` (int32 device tensor, >= 1 element); None: off."""
     _check(load().vfn_f16x3_set_status(_ptr(word, "status_word", torch.int32)), "vfn_f16x3_set_status")
+
+
+def train_step_workspace_bytes(params: "TrainStepParams", vf_geom: NetGeom, rn_geom: NetGeom) -> int:
+    n = int(load().vfn_train_step_workspace_bytes(C.byref(params), C.byref(vf_geom), C.byref(rn_geom)))
+    if n < 0:
+        raise VfnError(f"vfn_train_step_workspace_bytes failed (status {n}): {load().vfn_last_error().decode()}")
+    return n
+
+
+def train_step(params: "TrainStepParams", io: "TrainStepIO") -> None:
+    """One training step (or one of its two phases) from C: vf_nerf_amd/onecall.py fills the structs."""
+    _check(load().vfn_train_step(C.byref(params), C.byref(io), _stream()), "vfn_train_step")
 
 
 def f16x3_set_clock_probe(stamps: Optional[torch.Tensor]) -> None:

@@ -236,17 +236,9 @@ class FlatAdam(SequentialAdam):
             if p.grad is not view:
                 p.grad = view
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        f = self.flat()
-        if f is None:
-            return super().step(closure)
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
-        from . import lib
-        self._rebind_grads(f)
+    def step_scalars(self, f):
+        """(beta1, beta2, step_size[2 per region], bc2_sqrt[2 per region]) of the NEXT update, evaluated on the host in double
+        precision as torch.optim.Adam does — what vfn_flat_adam_step (and vfn_train_step) take."""
         group = self.param_groups[0]
         if group.get("amsgrad") or group.get("maximize") or group.get("capturable") or group.get("differentiable"):
             raise NotImplementedError("FlatAdam covers the reference's plain Adam configuration")
@@ -262,11 +254,33 @@ class FlatAdam(SequentialAdam):
                 t = t0 + k + 1
                 step_size.append(lr / (1 - beta1 ** t))
                 bc2_sqrt.append((1 - beta2 ** t) ** 0.5)
-        lib.flat_adam_step(f["param"], f["grad"], f["exp_avg"], f["exp_avg_sq"], f["regions"], step_size, bc2_sqrt, beta1, beta2,
-                           group["eps"], group["weight_decay"])
-        f["steps"] += torch.tensor([float(m) for _, _, _, m in f["entries"]])
+        return beta1, beta2, step_size, bc2_sqrt
+
+    def finish_step(self, f) -> None:
+        """Bookkeeping after the update kernels ran (here or inside vfn_train_step): step counters, the owner's pack invalidation."""
+        inc = f.get("step_increments")
+        if inc is None:
+            inc = f["step_increments"] = torch.tensor([float(m) for _, _, _, m in f["entries"]])
+        f["steps"] += inc
         if self.after_step is not None:
             self.after_step()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        f = self.flat()
+        if f is None:
+            return super().step(closure)
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        from . import lib
+        self._rebind_grads(f)
+        group = self.param_groups[0]
+        beta1, beta2, step_size, bc2_sqrt = self.step_scalars(f)
+        lib.flat_adam_step(f["param"], f["grad"], f["exp_avg"], f["exp_avg_sq"], f["regions"], step_size, bc2_sqrt, beta1, beta2,
+                           group["eps"], group["weight_decay"])
+        self.finish_step(f)
         return loss
 
     def load_state_dict(self, state_dict) -> None:

@@ -54,11 +54,17 @@ class TrainStep:
         self.compact_selection = bool(compact_selection)
         self.last_total_norm = None
         self.last_outputs = None
+        # the whole step as ONE C call (vfn_train_step) when the regime allows it (onecall.OneCallStep.applicable: the shipped one);
+        # ``model.one_call_train_step = False`` keeps the launch-by-launch path below, which the tests hold equal to it
+        from .onecall import OneCallStep
+        self.one_call = OneCallStep(self)
 
     def __call__(self, pose, pixels, intrinsics, rgb_gt, depth_gt, epoch: int = 0, white: bool = False,
                  uniforms: Optional[Dict[str, torch.Tensor]] = None) -> Tuple[torch.Tensor, Dict[str, float]]:
         model, dev = self.model, self.centroid.device
         cfg = model.config
+        if self.one_call.applicable(pose, white, pixels.shape[0]):
+            return self.one_call.run(pose, pixels, intrinsics, rgb_gt, depth_gt, epoch, uniforms)
         outputs = model.render(pose, pixels, intrinsics, epoch, white, uniforms=uniforms)
         n_sup = (outputs.points_coarse.shape[0] * outputs.points_coarse.shape[1]) // 10
         fused = bool(getattr(self.criterion, "fused", False)) and not self.compact_selection and outputs.coarse_normals.is_cuda
