@@ -657,7 +657,8 @@ int vfn_flat_adam_step(float* param, const float* grad, float* exp_avg, float* e
  *   phases: VFN_TRAIN_FORWARD_BACKWARD ends with every parameter's gradient ADDED into flat_grad (zeroed first); a multi-rank caller
  *           all-reduces flat_grad, then calls again with VFN_TRAIN_OPTIMIZER (clip, Adam, re-pack).  Both bits: the whole step.
  *   render: sizes, samplers, density, Philox (seed, offset) of the three draws (laid out coarse | fine | add, as vfn_render_fwd);
- *           colour_products / separate_launches / streams / timing_events are ignored.  N S_c and N S_t must be multiples of 32.
+ *           colour_products / separate_launches / timing_events are ignored; streams >= 2: the supervision batch's forward and chain
+ *           run on an internal side stream forked from / joined into `stream` (same values).  N S_c and N S_t must be multiples of 32.
  *   loss:   weights, clamp and flags of VFLoss; n_rays / n_normals / n_sup are filled in by the call (ONE supervision segment: the
  *           border batch followed by the centre batch; ray_center selects the ray samples inside the centre ball on the device).
  *   n_sup:  points per supervision batch (the trainer uses (N S_t) / 10); border / center: which batches exist; the shells are

@@ -82,3 +82,19 @@ def test_single_product_line_says_what_it_is():
     assert d1["training_products"] == 1 and d1["dtype"].startswith("16-bit-native") and d1["frac_of_f16_mfma_div3"] is None and 0 < d1["frac_of_f16_mfma"] < 1
     assert d3["training_products"] == 3 and d3["dtype"].startswith("f16x3") and 0.1 < d3["frac_of_f16_mfma_div3"] < 1.0
     assert d1["metric"] == d3["metric"] and d1["final_loss"] == d1["final_loss"]
+
+
+def test_view_workload_per_ray_accounting_at_view_scale():
+    """BASELINE.json configs[1] (`bench.py --workload view`): the 12 750 rays of the 150 x 85 parity image of the full view, HIP default
+    path against the CPU oracle (fp32), accounted per ray.  Sample depths are bit-identical on EVERY ray; at least 99.8 % of the rays are
+    inside the 1e-4 contract in rgb and depth (observed 99.89 %: a handful of rays per ten thousand sit on a density threshold where the
+    reference's own fp32 arithmetic is 1e-3 from its float64 value — DESIGN.md section 4; the float64 yardstick itself is the tool's, not
+    this test's: --no-float64)."""
+    d = _run("--workload", "view", "--steps", "1", "--warmup", "3", "--no-float64", timeout=900)
+    p = d["parity_vs_oracle"]
+    a = p["hip_default_vs_oracle_f32"]
+    print(f"view parity image {p['image']}: rays sampled identically {a['rays_sampled_bit_identically']}, inside 1e-4 {a['frac_all_rays_within_1e-4']}, "
+          f"worst rgb {a['max_abs_rgb_err']:.2e}; exact-fp32 kernels: {p['hip_exact_fp32_vs_oracle_f32']['frac_all_rays_within_1e-4']}; PSNR {p['psnr_rgb_db']} dB")
+    assert p["argmax_indices_equal"] and a["rays_with_different_z"] == 0 and a["rays_sampled_bit_identically"] == 1.0
+    assert a["frac_all_rays_within_1e-4"] >= 0.998 and p["hip_exact_fp32_vs_oracle_f32"]["frac_all_rays_within_1e-4"] >= 0.998
+    assert p["psnr_rgb_db"] > 90.0 and d["value"] > 1.0e6 and d["config"]["colour_products"] == 3

@@ -28,10 +28,11 @@ from vf_nerf_amd import supervision, trainer  # noqa: E402
 if cores > 0:
     torch.set_num_threads(cores)
 dev = torch.device("cuda", 0)
-out = {"rays": rays, "samples": 128, "steps": steps, "host_cores": len(os.sched_getaffinity(0))}
+out = {"rays": rays, "samples": 128, "steps": steps, "host_cores": len(os.sched_getaffinity(0)), "train_step_streams": int(os.environ.get("VFN_TRAIN_STREAMS", "2"))}
 for path in ("one_call", "python"):
     model, uv, pose, K = bench.build_scene(dev, rays, 64, 64, seed=0)
     model.one_call_train_step = path == "one_call"
+    model.train_step_streams = int(os.environ.get("VFN_TRAIN_STREAMS", "2"))        # A/B of the side stream inside vfn_train_step
     teacher, _, _, _ = bench.build_scene(dev, 16, 64, 64, seed=0, perturb=False, weight_seed=1)
     teacher.precision = "fp32"
     with torch.no_grad():

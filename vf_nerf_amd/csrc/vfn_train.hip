@@ -163,6 +163,38 @@ __global__ void vfn_train_scalar_grads_kernel(const float* dscal, float* g_beta,
     if (threadIdx.x == 0) { *g_beta += dscal[0]; *g_mean += dscal[1]; *g_scale += dscal[2]; }
 }
 
+// one side stream (+ fork / join events) per host thread and device, made on first use: the supervision batch's forward and
+// chain are independent of the fine pass until the loss / the weight gradients, and at the reference's batch size they are
+// 0.8-round launches that leave the chip mostly idle when they run alone
+struct Side { hipStream_t s; hipEvent_t fork, join; int dev; };
+Side* side_stream() {
+    static thread_local Side side = {nullptr, nullptr, nullptr, -1};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (side.dev != dev) {
+        if (side.dev >= 0) { (void)hipStreamDestroy(side.s); (void)hipEventDestroy(side.fork); (void)hipEventDestroy(side.join); side.dev = -1; }
+        if (hipStreamCreateWithFlags(&side.s, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&side.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&side.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        side.dev = dev;
+    }
+    return &side;
+}
+int fork_to(Side* sd, hipStream_t from) {
+    if (hipEventRecord(sd->fork, from) != hipSuccess || hipStreamWaitEvent(sd->s, sd->fork, 0) != hipSuccess) {
+        vfn_set_error("vfn_train_step: could not fork the side stream");
+        return VFN_ERR_LAUNCH;
+    }
+    return VFN_OK;
+}
+int join_into(Side* sd, hipStream_t into) {
+    if (hipEventRecord(sd->join, sd->s) != hipSuccess || hipStreamWaitEvent(into, sd->join, 0) != hipSuccess) {
+        vfn_set_error("vfn_train_step: could not join the side stream");
+        return VFN_ERR_LAUNCH;
+    }
+    return VFN_OK;
+}
+
 #define STEP(call)                       \
     do {                                 \
         rc = (call);                     \
@@ -206,6 +238,32 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
         hipLaunchKernelGGL(vfn_train_prep_kernel, dim3(1), dim3(128), 0, s, pa);
         STEP(vfn_check_launch("vfn_train_step (prep)"));
 
+        // the supervision batch runs on a side stream beside the render (render.streams >= 2; joined in front of the loss): its points
+        // depend on nothing but the prep launch
+        Side* sd = (r.streams >= 2 && w.m_sup_pad > 0) ? side_stream() : nullptr;
+        hipStream_t ss = sd ? sd->s : s;
+        if (sd) STEP(fork_to(sd, s));
+        float* saved_f = reinterpret_cast<float*>(w.saved);
+        auto supervision_forward = [&]() -> int {
+            long long row = 0;
+            if (p->border && p->n_sup > 0) {
+                STEP(vfn_sample_sphere_shell(p->n_sup, p->border_r_min, p->border_r_max, w.centroid, 1, io->sup_u_border, p->sup_seed, p->sup_offset,
+                                             w.sup_pts, w.sup_gt, ss));
+                row += p->n_sup;
+            }
+            if (p->center && p->n_sup > 0) {
+                STEP(vfn_sample_sphere_shell(p->n_sup, 0.0f, p->sup_radius, w.centroid, 0, io->sup_u_center, p->sup_seed,
+                                             p->sup_offset + (io->sup_u_border || !p->border ? 0 : (uint64_t)p->n_sup), w.sup_pts + row * 3,
+                                             w.sup_gt + row * 3, ss));
+                row += p->n_sup;
+            }
+            if (w.m_sup_pad > 0)
+                STEP(vfn_vf_mlp16_fwd_train_at(io->vf_geom, io->vf_packed16, w.sup_pts, w.m_sup_pad, 0, w.sup_pred, saved_f, w.aux_vf, w.masks,
+                                               p->save_flags, w.m, w.total, ss));
+            return VFN_OK;
+        };
+        if (sd) STEP(supervision_forward());
+
         // ---- render() under autograd: one vector-field evaluation per distinct sample (backward.StoredFinePass) -----------------------
         const int gen_c = r.perturb_coarse && !io->u_coarse, gen_f = r.perturb_fine && !io->u_fine, gen_a = !io->u_add;
         const long long base_f = gen_c ? (long long)n * sc : 0, base_a = base_f + (gen_f ? (long long)n * nf : 0);
@@ -213,7 +271,6 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
         STEP(vfn_internal_raygen(&rq, io->uv, io->pose, io->intrinsics, io->intrinsics, io->t_vals, io->far_coarse_per_ray,
                                  r.perturb_coarse ? io->u_coarse : nullptr, gen_c, 0, r.seed, r.offset, w.directions, io->ray_dirs, w.cam_loc, w.z_c,
                                  w.pts_c, s));
-        float* saved_f = reinterpret_cast<float*>(w.saved);
         STEP(vfn_vf_render_fused16_fwd_train_at(io->vf_geom, io->vf_packed16, io->rn_geom, io->rn_packed16, w.pts_c, io->ray_dirs, w.m_c, sc,
                                                 w.normals_s, w.colors_s, saved_f, w.aux_vf, w.aux_rn, w.masks, p->save_flags, 0, w.total,
                                                 p->forward_products, s));
@@ -232,21 +289,8 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
                                            io->weights, io->rgb, io->depth, s));
 
         // ---- supervision points and their vector-only forward (train.py:186-216) -----------------------------------------------------
-        long long row = 0;
-        if (p->border && p->n_sup > 0) {
-            STEP(vfn_sample_sphere_shell(p->n_sup, p->border_r_min, p->border_r_max, w.centroid, 1, io->sup_u_border, p->sup_seed,
-                                         p->sup_offset, w.sup_pts, w.sup_gt, s));
-            row += p->n_sup;
-        }
-        if (p->center && p->n_sup > 0) {
-            STEP(vfn_sample_sphere_shell(p->n_sup, 0.0f, p->sup_radius, w.centroid, 0, io->sup_u_center, p->sup_seed,
-                                         p->sup_offset + (io->sup_u_border || !p->border ? 0 : (uint64_t)p->n_sup), w.sup_pts + row * 3,
-                                         w.sup_gt + row * 3, s));
-            row += p->n_sup;
-        }
-        if (w.m_sup_pad > 0)
-            STEP(vfn_vf_mlp16_fwd_train_at(io->vf_geom, io->vf_packed16, w.sup_pts, w.m_sup_pad, 0, w.sup_pred, saved_f, w.aux_vf, w.masks,
-                                           p->save_flags, w.m, w.total, s));
+        if (sd) STEP(join_into(sd, s));
+        else STEP(supervision_forward());
 
         // ---- VFLoss forward / backward (vf_loss.py:34-87; the centre-ball rows of functions.py:137-157 inside the launches) -------------
         vfn_loss_params lp = p->loss;
@@ -268,10 +312,13 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
 
         // ---- backward: supervision chain, per-ray backward, fine chain, weight gradients -------------------------------------------------
         const float* feats = saved_f + (size_t)(w.vf_h - 1) * (w.slot_bytes / 4);           // the tanh'ed feature slot, row-major fp32
-        if (w.m_sup_pad > 0)
+        if (w.m_sup_pad > 0) {
+            // (beside the per-ray backward and the fine pass's chain when there is a side stream; joined in front of the weight gradients)
+            if (sd) STEP(fork_to(sd, s));
             STEP(vfn_mlp_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, nullptr, nullptr, nullptr, feats, w.masks, w.dy,
                                               p->dy_flags, nullptr, nullptr, w.d_sup, w.sup_pred, nullptr, 3, w.m_sup_pad, nullptr, w.dz_vec, w.m,
-                                              w.total, s));
+                                              w.total, ss));
+        }
         STEP(vfn_ray_density_weights_bwd(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, w.d_rgb, lp.has_depth ? w.d_depth : nullptr,
                                          nullptr, w.dn, w.dc, w.dscal, s));
         // row src[i] of the workspace is sorted sample i: gradients to storage order
@@ -284,6 +331,7 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
                                             p->dy_form, p->x_form, feats, w.aux_rn, w.dz_rgb, w.m,
                                             VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD, 1, w.scratch_rn, s));
         // vector-field net: hidden layers + head over ALL rows (fine pass + supervision), the feature block over the fine pass's rows
+        if (sd) STEP(join_into(sd, s));
         if (w.m_sup_pad > 0) {
             STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form,
                                                 nullptr, w.aux_vf, w.dz_vec, w.total, VFN_WGRAD_LAYERS | VFN_WGRAD_HEAD, 1, w.scratch_vf, s));

@@ -23,7 +23,7 @@ from torch import nn
 from . import lib
 from .density import LaplaceDensity
 from .networks import RenderingNetwork, VectorFieldNetwork
-from .render_output import NerfOutput
+from .render_output import NerfOutput, RepeatedRows
 from .samplers import RangeFineSampler, UniformSampler
 
 
@@ -470,7 +470,7 @@ class VectorFieldNerf:
         rgb = o["rgb"]
         if white:
             rgb = rgb + (1. - o["weights"].sum(-1)[..., None])
-        rep_dirs = o["ray_dirs"].unsqueeze(1).expand(n, s_t, 3).reshape(-1, 3)
+        rep_dirs = RepeatedRows(o["ray_dirs"], s_t)            # [N * S_t, 3] on first access (nothing on the hot path reads it)
         return NerfOutput(points_coarse=o["points"], points_fine=None, coarse_normals=o["normals"].view(n, s_t, 3),
                           coarse_rgb_values=rgb, coarse_depth_map=o["depth"], fine_normals=None, fine_rgb_values=None,
                           fine_depth_map=None, z_vals=o["z_vals"], directional_derivtives=None, ray_dirs=rep_dirs,

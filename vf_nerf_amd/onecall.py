@@ -20,7 +20,7 @@ import torch
 from . import lib
 from . import loss as vloss
 from . import supervision
-from .render_output import NerfOutput
+from .render_output import NerfOutput, RepeatedRows
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -168,6 +168,8 @@ class OneCallStep:
         rp.fine_range, rp.window_step = rng, 2 * rng / (n_f - 1)
         rp.span = (far_f - float(model.fine_sampler.near)) if far_ft is None else 0.0
         rp.density = model._density_params()
+        # 2: the supervision batch's forward and chain on a side stream inside the call, beside the fine pass's (same values)
+        rp.streams = int(getattr(model, "train_step_streams", 2))
 
         def given(name, needed):
             return uniforms[name].to(dev).float().contiguous() if (needed and name in uniforms) else None
@@ -279,12 +281,13 @@ class OneCallStep:
             bucket.all_reduce_mean()
             call(lib.TRAIN_OPTIMIZER)
         del keep_alive
+        opt._opt_called = True                   # (what torch's LRScheduler looks at before it warns about the call order)
         opt.finish_step(f)                       # step counters; invalidates the packs' keys (the parameters changed under them) ...
         self._mark_packs_current(single)         # ... and the call has already re-packed them
         model.scheduler.step()
 
         step.last_total_norm = out_norm[0]
-        rep_dirs = ray_dirs.view(n, 3).unsqueeze(1).expand(n, s_t, 3).reshape(-1, 3)
+        rep_dirs = RepeatedRows(ray_dirs.view(n, 3), s_t)
         step.last_outputs = NerfOutput(points_coarse=pts.view(n, s_t, 3), points_fine=None, coarse_normals=normals.view(n, s_t, 3),
                                        coarse_rgb_values=rgb.view(n, 3), coarse_depth_map=depth.view(n, 1), fine_normals=None, fine_rgb_values=None,
                                        fine_depth_map=None, z_vals=z.view(n, s_t), directional_derivtives=None, ray_dirs=rep_dirs,

@@ -38,7 +38,28 @@ def _to_dict(self):
     return {k: getattr(self, k) for k in _DICT_KEYS}
 
 
+class RepeatedRows:
+    """``rows[N,3]`` standing for the reference's ``ray_dirs`` output, every ray's direction repeated for each of its ``times``
+    samples ([N * times, 3], models/nerf/vector_field_nerf.py:239-249,336).  Nothing in the reference's trainer, evaluator or loss
+    reads that field, and materialising it is a launch and 12 bytes per sample on every render: it is built on first access."""
+
+    def __init__(self, rows: torch.Tensor, times: int) -> None:
+        self.rows, self.times = rows, int(times)
+
+    def materialise(self) -> torch.Tensor:
+        n = self.rows.shape[0]
+        return self.rows.reshape(n, 1, 3).expand(n, self.times, 3).reshape(-1, 3)
+
+
+def _getattribute(self, name):
+    value = object.__getattribute__(self, name)
+    if name == "ray_dirs" and isinstance(value, RepeatedRows):
+        value = value.materialise()
+        object.__setattr__(self, "ray_dirs", value)
+    return value
+
+
 NerfOutput = make_dataclass(
     "NerfOutput",
     [(n, torch.Tensor) for n in _MANDATORY] + [(n, Optional[torch.Tensor], field(default=None)) for n in _OPTIONAL],
-    namespace=dict(fine_active=_fine_active, get_normals=_get_normals, to_dict=_to_dict, __module__=__name__))
+    namespace=dict(fine_active=_fine_active, get_normals=_get_normals, to_dict=_to_dict, __getattribute__=_getattribute, __module__=__name__))
