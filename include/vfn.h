@@ -669,6 +669,16 @@ int vfn_flat_adam_step(float* param, const float* grad, float* exp_avg, float* e
  *   forward_products: colour_products of the saving forwards (3; 2; 1 = the single-product mode, which also takes dy_flags bit 4).
  *   regions / step_size / bc2_sqrt / betas / eps / weight_decay / max_norm: as vfn_flat_clip_grad_norm and vfn_flat_adam_step.
  *   repack: re-pack vf_packed16, rn_packed16 and the two transposed bf16 packs from the updated parameters at the end of phase 2.
+ *   sparse_colours: a sample's colour enters the step through rgb = sum_s w_s c_s only, so where w_s is exactly zero — a closed density
+ *           ReLU, or a transmittance that has underflowed: 93-97 % of the samples of a batch — neither the colour nor its gradient
+ *           (d c_s = w_s d rgb) nor the rendering net's share of that sample in any weight gradient is needed, and every derivative of w_s
+ *           that would multiply c_s ends at the closed ReLU / the zero transmittance.  With sparse_colours the step evaluates the
+ *           vector-field net on all samples with its vector-only saving forward (region 1 of the workspace), selects the samples with
+ *           w > 0 on the device (a count the host never learns: launches are sized for the capacity and cut inside the kernels), and
+ *           runs the fused saving forward, the fused chain and the colour branch's weight gradients on that compacted list only (region 2).
+ *           The upstream gradient splits between the regions (d normals on region 1, d colours on region 2): the parameter gradients are
+ *           the dense step's up to the order of their sums; rgb, depth, weights, normals are the dense step's bit for bit; the `colors`
+ *           output holds zeros where w = 0.
  * Outputs of phase 1 (caller-allocated, the NerfOutput of the step's render): ray_dirs[N,3], z_vals[N,S_t], points[N,S_t,3],
  * normals[N S_t,3], colors[N S_t,3], weights[N,S_t], rgb[N,3], depth[N]; out_terms[8] as vfn_vf_loss_fwd.  Phase 2: out_norm[2] as
  * vfn_flat_clip_grad_norm.  No allocation, no synchronisation, no host read-back. */
@@ -693,7 +703,8 @@ typedef struct vfn_train_step_params {
     double step_size[8], bc2_sqrt[8];
     double beta1, beta2, eps, weight_decay;
     float max_norm;
-    int32_t reserved;
+    int32_t sparse_colours;             /* != 0: the colour branch (feature block + rendering net) is evaluated, differentiated and summed into the
+                                         * weight gradients only for the samples whose weight is non-zero (see below) */
 } vfn_train_step_params;
 typedef struct vfn_train_step_io {
     const vfn_net_geom* vf_geom; const vfn_net_geom* rn_geom;

@@ -833,13 +833,14 @@ def test_train_step_is_the_same_step_with_and_without_the_fused_loss():
     assert out["fused"][1]["supervision_loss"] > 0
 
 
-@pytest.mark.parametrize("mode", ["default", "fp32_storages", "single_product", "replayed_draws"])
+@pytest.mark.parametrize("mode", ["default", "dense_colours", "fp32_storages", "single_product", "replayed_draws"])
 def test_one_call_training_step_equals_the_launch_by_launch_step(mode):
     """vfn_train_step (csrc/vfn_train.hip, vf_nerf_amd/onecall.py) issues the launches of trainer.TrainStep's Python path from C out
     of one workspace.  Two models with the same weights, batches and random streams, one per path, three steps:
 
     * step 0 starts from identical state and its forward is deterministic: loss, the six terms, sampled depths, rgb / depth /
-      normals / colours are BIT-identical;
+      normals are BIT-identical, and so are the colours wherever the C call evaluates them (by default only where a sample's weight
+      is non-zero — the exact sparse colour branch of include/vfn.h; "dense_colours" switches it off);
     * gradients leave two kernels through atomicAdd (the density scalars, the loss reductions), so from there on the two runs agree
       to rounding, not bitwise: clip norm within 1e-5, parameters after each step within 2 % of one Adam update (lr) wherever the
       update is not a coin flip, losses of steps 1-2 within 1e-4;
@@ -861,6 +862,7 @@ def test_one_call_training_step_equals_the_launch_by_launch_step(mode):
         elif mode == "single_product":
             model.training_products = 1
         model.one_call_train_step = path == "one_call"
+        model.sparse_colour_training = mode != "dense_colours"      # (the C call's default: the colour branch only where w > 0; exact)
         model.rng_seed, model._rng_offset = 5, 0
         supervision.manual_seed(9)
         step = trainer.TrainStep(model, (0.0, 0.0, 0.55), border_radius=0.15, far=1.0)
@@ -887,8 +889,14 @@ def test_one_call_training_step_equals_the_launch_by_launch_step(mode):
                                  float(model.optimizer.state[model.rendering_network.layers[4].weight]["step"])))
     a, b = runs["one_call"], runs["python"]
     lr = 5e-4
-    for k in ("z", "rgb", "depth", "normals", "colors"):
+    for k in ("z", "rgb", "depth", "normals"):
         assert torch.equal(a["rec"][0][k], b["rec"][0][k]), f"step 0 {k}"
+    # colours: the sparse colour branch evaluates them only where the sample's weight is non-zero (zeros elsewhere: they multiply a zero
+    # weight); where it does, they are the dense path's bit for bit — and rgb = sum w c above IS bit-identical
+    ca, cb = a["rec"][0]["colors"], b["rec"][0]["colors"]
+    evaluated = (ca != 0).any(dim=1)
+    assert torch.equal(ca[evaluated], cb[evaluated]) and (mode == "dense_colours") == bool(evaluated.all())
+    print(f"[{mode}] colour branch evaluated on {float(evaluated.float().mean()):.3f} of the samples")
     assert a["rec"][0]["loss"] == b["rec"][0]["loss"] and a["rec"][0]["terms"] == b["rec"][0]["terms"]
     for t in range(3):
         ra, rb = a["rec"][t], b["rec"][t]
@@ -896,8 +904,13 @@ def test_one_call_training_step_equals_the_launch_by_launch_step(mode):
         frac = sum(int(((x - y).abs() > 0.02 * lr).sum()) for x, y in zip(ra["params"], rb["params"])) / sum(x.numel() for x in ra["params"])
         print(f"[{mode}] step {t}: loss {ra['loss']:.6f} / {rb['loss']:.6f}; clip norm {ra['norm']:.6f} / {rb['norm']:.6f}; parameters differ by at most "
               f"{worst / lr:.3f} lr, {frac:.2e} of them by more than 0.02 lr")
-        assert abs(ra["norm"] - rb["norm"]) < 1e-5 * rb["norm"] * (1 if t == 0 else 100)
-        assert abs(ra["loss"] - rb["loss"]) < 1e-4 * max(1.0, abs(rb["loss"]))
+        # "dense_colours" runs the Python path's launches one for one: agreement to the order of a few atomic additions.  The sparse colour
+        # branch (the default) splits every sample's upstream gradient between two chain passes (d normals on region 1, d colours on
+        # region 2), each rounded to the 16-bit gradient storage / the bf16x3 operands on its own instead of after their fp32 sum: the
+        # parameter gradients agree to the storages' own precision (2.6e-5 in the clip norm observed), not to the last bit
+        tight = mode == "dense_colours"
+        assert abs(ra["norm"] - rb["norm"]) < (1e-5 if tight else 2e-4) * rb["norm"] * (1 if t == 0 else 100)
+        assert abs(ra["loss"] - rb["loss"]) < (1e-4 if (tight or t == 0) else 1e-3) * max(1.0, abs(rb["loss"]))
         if mode == "single_product" and t > 0:
             # one product per K-block multiplies the weights' f16 ROUNDINGS: a weight that differs by 1e-6 between the two runs (the
             # atomics of step 0) can round to the neighbouring f16 value, 6e-5 away — the single-product arithmetic is discontinuous in
@@ -907,9 +920,59 @@ def test_one_call_training_step_equals_the_launch_by_launch_step(mode):
         else:
             # (a coin-flip sign is at most two updates of lr apart; the fraction of coin flips grows with every step as the two runs —
             # identical up to the order of a few atomic additions — drift apart: observed 0 / 5e-4 / 9e-3 on steps 0 / 1 / 2)
-            assert frac < (1e-5, 5e-3, 5e-2)[t] and worst <= 2.05 * lr * 2
+            assert frac < ((1e-5, 5e-3, 5e-2) if tight else (6e-3, 3e-2, 1.5e-1))[t] and worst <= 2.05 * lr * 2
     assert a["rng"] == b["rng"] and a["lr"] == b["lr"] and a["steps"] == b["steps"] == (6.0, 3.0)
     assert float((a["img"] - b["img"]).abs().max()) < 5e-3, "renders right after the steps: the re-packed weights are the updated ones"
+
+
+def test_sparse_colour_branch_gives_the_dense_gradients():
+    """vfn_train_step's sparse colour branch (include/vfn.h: the rendering net and the feature block evaluated, differentiated and summed
+    into the weight gradients only for the samples with w > 0) against the dense step, on the GRADIENTS themselves: phase 1 of the call
+    (forward + backward) with a stand-in for the gradient bucket that snapshots the flat gradient where a multi-rank run would all-reduce
+    it.  512 rays x (64 + 64) + supervision, default 16-bit storages and fp32 storages: every parameter's gradient within the storage's own
+    bound of the dense one-call step's and of the Python path's (1e-3 of the tensor's largest entry with the 16-bit storages, the bound
+    test_render_gradients holds the dense path to against the oracle; 2e-4 with fp32 storages), the density scalars included; the loss
+    and the outputs other than the un-evaluated colours bit-identical."""
+    from vf_nerf_amd import trainer
+    import bench
+    dev = torch.device(DEV)
+
+    class Snapshot:                                  # what trainer.TrainStep asks of a bucket
+        def __init__(self, model):
+            self.model, self.grads = model, None
+
+        def zero(self):
+            self.model.optimizer.zero_grad()
+
+        def all_reduce_mean(self):
+            self.grads = [p.grad.detach().clone() for p in self.model.unique_parameters()]
+
+    worst_all = {}
+    for storages in ("f16", "fp32"):
+        got = {}
+        for tag, one_call, sparse in (("sparse", True, True), ("dense", True, False), ("python", False, False)):
+            model, uv, pose, K = bench.build_scene(dev, 512, 64, 64, seed=0)
+            model.activation_storage = model.gradient_storage = storages
+            model.one_call_train_step, model.sparse_colour_training = one_call, sparse
+            model.rng_seed, model._rng_offset = 3, 0
+            supervision.manual_seed(21)
+            gen = torch.Generator().manual_seed(2)
+            rgb_gt, depth_gt = torch.rand(512, 3, generator=gen).to(dev), (0.2 + 0.6 * torch.rand(512, 1, generator=gen)).to(dev)
+            snap = Snapshot(model)
+            step = trainer.TrainStep(model, (0.0, 0.0, 0.6), border_radius=0.05, far=1.0, bucket=snap)
+            loss, _ = step(pose, uv, K, rgb_gt, depth_gt, epoch=0)
+            assert (step.one_call.why_not is None) == one_call, step.one_call.why_not
+            got[tag] = (float(loss), snap.grads, step.last_outputs.coarse_rgb_values.clone(), step.last_outputs.coarse_depth_map.clone())
+        names = [f"{net}.{k}" for net, mod in (("vf", model.vector_field_network), ("rn", model.rendering_network), ("density", model.density))
+                 for k, _ in mod.named_parameters()]
+        assert got["sparse"][0] == got["dense"][0] == got["python"][0]
+        assert torch.equal(got["sparse"][2], got["python"][2]) and torch.equal(got["sparse"][3], got["python"][3])
+        tol = 1e-3 if storages == "f16" else 2e-4
+        for a, b in (("sparse", "dense"), ("sparse", "python"), ("dense", "python")):
+            worst = max((float((x - y).abs().max() / y.abs().max().clamp_min(1e-30)), nm) for x, y, nm in zip(got[a][1], got[b][1], names))
+            worst_all[storages, a, b] = worst
+            print(f"[{storages} storages] {a} vs {b}: worst parameter-gradient difference {worst[0]:.2e} of the tensor's largest entry ({worst[1]})")
+            assert worst[0] < (tol if "sparse" in (a, b) else 1e-5), (storages, a, b, worst)
 
 
 def test_lazy_loss_terms_survive_the_pinned_ring_wrapping_around():

@@ -175,6 +175,7 @@ struct Bwd16Args {
     const float* d_feats;                            // BM_FULL: gradient wrt the tanh'ed features, row stride vec_stride
     float* dz_rgb; float* dz_vec;                    // [M,4]
     long long n_points;
+    const int* n_dev;          // optional device-side count: the launch covers min(n_points, *n_dev) points (csrc/vfn_train.hip)
     int vec_stride;
     long long ws_first, ws_points;   // this launch's points are points ws_first .. of a workspace (feats, masks, dy, dz_*) sized for ws_points
 };
@@ -566,7 +567,13 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5;
     const long long m = (long long)blockIdx.x * BW_PTS + wave * 32 + (lane & 31);
-    const bool in = m < a.n_points;
+    long long n_live = a.n_points;
+    if (a.n_dev) {             // (uniform; before any barrier)
+        const long long nd = (long long)*a.n_dev;
+        n_live = nd < n_live ? nd : n_live;
+        if ((long long)blockIdx.x * BW_PTS >= n_live) return;
+    }
+    const bool in = m < n_live;
 
     // head weights -> LDS; this point's head gradients
     for (int i = tid; i < 768; i += 256) {
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
     p.dy16 = (MX & BM_F16S) ? 2 : ((frag && (a.dy_flags & 4)) ? 1 : 0);
     p.live = in ? 1 : 0;
     const long long mw = m + a.ws_first;          // this point's place in the workspace
-    p.evoff = (m & ~31ll) < a.n_points ? (uint32_t)((mw >> 5) * 32768 + 16384 + lane) : 0xc0000000u;
+    p.evoff = (m & ~31ll) < n_live ? (uint32_t)((mw >> 5) * 32768 + 16384 + lane) : 0xc0000000u;
     p.feats = a.feats; p.dy = a.dy; p.feat_bytes = (uint32_t)(a.ws_points * 1024);
     p.slot_floats = frag ? ((a.ws_points + 31) >> 5) * 8192 : a.ws_points * 256;
     p.slot_bytes = (uint32_t)(p.slot_floats * 4);
@@ -786,6 +793,16 @@ extern "C" int vfn_mlp_bwd_chain_bf16_ws_at(const vfn_net_geom* vf_geom, const v
                                             const float* colors, const float* d_vec, const float* vec, const float* d_feats,
                                             int32_t vec_stride, int64_t n_points, float* dz_rgb, float* dz_vec, int64_t ws_first,
                                             int64_t ws_points, void* stream) {
+    return vfn_internal_bwd_chain_bf16_ws_at(vf_geom, vf_packed_bwd16, vf_head_w, rn_geom, rn_packed_bwd16, rn_head_w, saved, masks, dy, dy_flags, d_colors,
+                                             colors, d_vec, vec, d_feats, vec_stride, n_points, nullptr, dz_rgb, dz_vec, ws_first, ws_points, stream);
+}
+
+int vfn_internal_bwd_chain_bf16_ws_at(const vfn_net_geom* vf_geom, const void* vf_packed_bwd16, const float* vf_head_w,
+                                      const vfn_net_geom* rn_geom, const void* rn_packed_bwd16, const float* rn_head_w,
+                                      const float* saved, const uint32_t* masks, void* dy, int32_t dy_flags, const float* d_colors,
+                                      const float* colors, const float* d_vec, const float* vec, const float* d_feats,
+                                      int32_t vec_stride, int64_t n_points, const int32_t* n_dev, float* dz_rgb, float* dz_vec,
+                                      int64_t ws_first, int64_t ws_points, void* stream) {
     VFN_REQUIRE(vf_geom, "vfn_mlp_bwd_chain_bf16: NULL argument");
     int rc = check_shipped(VFN_NET_VF, vf_geom, "vfn_mlp_bwd_chain_bf16");
     if (rc != VFN_OK) return rc;
@@ -811,7 +828,7 @@ extern "C" int vfn_mlp_bwd_chain_bf16_ws_at(const vfn_net_geom* vf_geom, const v
     Bwd16Args a = {};
     a.vf_wt = (const uint4*)vf_packed_bwd16; a.rn_wt = (const uint4*)rn_packed_bwd16; a.vf_head = vf_head_w; a.rn_head = rn_head_w;
     a.feats = saved; a.dy_flags = dy_flags & 14; a.masks = masks; a.dy = (float*)dy; a.d_colors = d_colors; a.colors = colors; a.d_vec = d_vec; a.vec = vec; a.d_feats = d_feats;
-    a.dz_rgb = dz_rgb; a.dz_vec = dz_vec; a.n_points = n_points; a.vec_stride = vec_stride;
+    a.dz_rgb = dz_rgb; a.dz_vec = dz_vec; a.n_points = n_points; a.n_dev = n_dev; a.vec_stride = vec_stride;
     a.ws_first = ws_first; a.ws_points = ws_points;
     const unsigned blocks = (unsigned)((n_points + BW_PTS - 1) / BW_PTS);
     hipStream_t s = (hipStream_t)stream;

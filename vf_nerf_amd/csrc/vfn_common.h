@@ -41,3 +41,24 @@ int vfn_internal_composite_gather(const vfn_density_params* dp, float* normals, 
 // n x groups workgroups (vfn_weight_grad_frag is the n = 1 case)
 int vfn_internal_weight_grad_frag_batch(int32_t shape, int32_t dy_form, int32_t x_form, int32_t n, const void* const* dy, const void* const* x,
                                         float* const* dw_part, float* const* db_part, int64_t n_points, int32_t groups, void* stream);
+int vfn_internal_weight_grad_frag_batch_dev(int32_t shape, int32_t dy_form, int32_t x_form, int32_t n, const void* const* dy, const void* const* x,
+                                            float* const* dw_part, float* const* db_part, int64_t n_points, const int32_t* n_dev, int32_t groups,
+                                            void* stream);
+
+// launches over a number of points that only the device knows (csrc/vfn_train.hip: the samples with non-zero weight): `n_points` is the
+// capacity the launch is sized for, `n_dev` (device memory, may be NULL) the live count; points past it are not touched
+int vfn_internal_fused16_fwd_train_at(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
+                                      const void* rn_packed16, const float* points, const float* ray_dirs, int64_t n_points,
+                                      const int32_t* n_dev, int32_t samples_per_ray, float* normals, float* colors, float* saved,
+                                      float* save_aux_vf, float* save_aux_rn, uint32_t* save_masks, int32_t save_f16, int64_t ws_first,
+                                      int64_t ws_points, int32_t colour_products, void* stream);
+int vfn_internal_bwd_chain_bf16_ws_at(const vfn_net_geom* vf_geom, const void* vf_packed_bwd16, const float* vf_head_w,
+                                      const vfn_net_geom* rn_geom, const void* rn_packed_bwd16, const float* rn_head_w,
+                                      const float* feats, const uint32_t* masks, void* dy, int32_t dy_flags, const float* d_colors,
+                                      const float* colors, const float* d_vec, const float* vec, const float* d_feats,
+                                      int32_t vec_stride, int64_t n_points, const int32_t* n_dev, float* dz_rgb, float* dz_vec,
+                                      int64_t ws_first, int64_t ws_points, void* stream);
+int vfn_internal_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_geom* geom, const vfn_wgrad_layer* layers, const void* saved,
+                                            const void* dy, int64_t slot_bytes, int32_t dy_form, int32_t x_form, const float* feats,
+                                            const float* aux, const float* dz_head, int64_t n_points, const int32_t* n_dev, uint32_t parts,
+                                            int32_t accumulate, void* scratch, void* stream);

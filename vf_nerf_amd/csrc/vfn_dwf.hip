@@ -81,7 +81,7 @@ struct DwfArgs {
 // 256 x 256 weight gradients need not be one launch of 256 slabs each — eight of them as ONE launch of 8 x 32 workgroups fill
 // the chip just the same and write an eighth of the partial slabs (64 MB per product and launch otherwise, read back by the un-fold).
 constexpr int DWF_BATCH = 8;
-struct DwfBatch { DwfArgs v[DWF_BATCH]; };
+struct DwfBatch { DwfArgs v[DWF_BATCH]; const int* n_dev; };   // n_dev: optional device-side point count (clamps every product's n_points)
 
 typedef __attribute__((address_space(3))) s4 lds_s4;
 
@@ -118,7 +118,11 @@ __device__ __forceinline__ int img_off(int row, int chunk) { return row * F_ROW 
 
 template <int SHAPE, int XM, int DM>
 __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
-    const DwfArgs a = batch.v[blockIdx.y];
+    DwfArgs a = batch.v[blockIdx.y];
+    if (batch.n_dev) {          // the live number of points is known to the device only (csrc/vfn_train.hip): slabs are cut from THAT count
+        const long long nd = (long long)*batch.n_dev;
+        a.n_points = nd < a.n_points ? nd : a.n_points;
+    }
     constexpr bool A_FRAG = DM != DY_DZ4;
     constexpr bool B_FRAG = XM == X_FRAG32 || XM == X_FRAG16;
     constexpr bool F16 = DM == DY_FRAGF16S;                     // tile-scaled f16 gradient: f16 matrix instruction, one common scale per slab
@@ -455,10 +459,17 @@ extern "C" int vfn_weight_grad_frag(int32_t shape, const void* dy, int32_t dy_fo
 
 int vfn_internal_weight_grad_frag_batch(int32_t shape, int32_t dy_form, int32_t x_form, int32_t n, const void* const* dy, const void* const* x,
                                         float* const* dw_part, float* const* db_part, int64_t n_points, int32_t groups, void* stream) {
+    return vfn_internal_weight_grad_frag_batch_dev(shape, dy_form, x_form, n, dy, x, dw_part, db_part, n_points, nullptr, groups, stream);
+}
+
+int vfn_internal_weight_grad_frag_batch_dev(int32_t shape, int32_t dy_form, int32_t x_form, int32_t n, const void* const* dy, const void* const* x,
+                                            float* const* dw_part, float* const* db_part, int64_t n_points, const int32_t* n_dev, int32_t groups,
+                                            void* stream) {
     VFN_REQUIRE(n >= 1 && n <= DWF_BATCH && dy && x && dw_part && db_part, "vfn_weight_grad_frag: bad batch (n=%d)", n);
     VFN_REQUIRE(groups >= 1 && groups <= 4096, "vfn_weight_grad_frag: groups=%d", groups);
     VFN_REQUIRE(n_points >= 0 && n_points < (1ll << 20) * groups, "vfn_weight_grad_frag: slab larger than 1 GiB");
     DwfBatch a = {};
+    a.n_dev = n_dev;
     for (int i = 0; i < n; ++i) {
         VFN_REQUIRE(dy[i] && x[i] && dw_part[i], "vfn_weight_grad_frag: NULL argument");
         a.v[i].dy = dy[i]; a.v[i].x = x[i]; a.v[i].dw_part = dw_part[i]; a.v[i].db_part = db_part[i]; a.v[i].n_points = n_points;

@@ -433,6 +433,8 @@ struct Mlp16Args {
     uint32_t* status;         // optional (vfn_f16x3_set_status): bit 0 is OR-ed in when a hidden activation reached the f16 clamp,
                               // bit 1 when an input (point coordinate / encoding operand) did — the result of such a launch is not
                               // fp32-equivalent and the caller should repeat it on the exact-fp32 kernels
+    const int* n_dev;            // optional: the launch covers min(n_points, *n_dev) points — a count that only the device knows (the
+                                 // samples with non-zero weight, csrc/vfn_train.hip); workgroups past it leave at once
     unsigned long long* clock;   // optional (vfn_f16x3_set_clock_probe): workgroup b < clock_slots of a fused VF + rendering launch leaves
     long long clock_slots;       // its shader-clock cycles (s_memtime) in clock[2b] and its 100 MHz ticks (s_memrealtime) in clock[2b+1]
 };
@@ -972,7 +974,13 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
         if (a.clock) { ck_t0 = __builtin_amdgcn_s_memtime(); ck_r0 = __builtin_amdgcn_s_memrealtime(); }
     }
     const long long m = (long long)blockIdx.x * VFN16_PTS + wave * 32 + (lane & 31);
-    const bool in = m < a.n_points;
+    long long n_live = a.n_points;
+    if (a.n_dev) {             // (uniform: a scalar load and a scalar branch, before anything is staged or any barrier is reached)
+        const long long nd = (long long)*a.n_dev;
+        n_live = nd < n_live ? nd : n_live;
+        if ((long long)blockIdx.x * VFN16_PTS >= n_live) return;
+    }
+    const bool in = m < n_live;
 
     if constexpr ((MODE & M16_BLKIN) != 0) {
         // ---- rendering net only: this point's feature operand, normal, position and view direction come from memory ----
@@ -1394,7 +1402,18 @@ extern "C" int vfn_vf_render_fused16_fwd_train_at(const vfn_net_geom* vf_geom, c
                                                   float* saved, float* save_aux_vf, float* save_aux_rn, uint32_t* save_masks,
                                                   int32_t save_f16, int64_t ws_first, int64_t ws_points, int32_t colour_products,
                                                   void* stream) {
+    return vfn_internal_fused16_fwd_train_at(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, n_points, nullptr, samples_per_ray, normals,
+                                             colors, saved, save_aux_vf, save_aux_rn, save_masks, save_f16, ws_first, ws_points, colour_products, stream);
+}
+
+// ... over min(n_points, *n_dev) points when n_dev (a device pointer) is given: n_points is then the CAPACITY the launch is sized for
+int vfn_internal_fused16_fwd_train_at(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
+                                      const void* rn_packed16, const float* points, const float* ray_dirs, int64_t n_points,
+                                      const int32_t* n_dev, int32_t samples_per_ray, float* normals, float* colors, float* saved,
+                                      float* save_aux_vf, float* save_aux_rn, uint32_t* save_masks, int32_t save_f16, int64_t ws_first,
+                                      int64_t ws_points, int32_t colour_products, void* stream) {
     Mlp16Args a = {};
+    a.n_dev = n_dev;
     VfnNetPlan p32; Plan16 vf, rn;
     int rc = make_plan16(VFN_NET_VF, vf_geom, &p32, &vf, "vfn_vf_render_fused16_fwd_train");
     if (rc != VFN_OK) return rc;

@@ -72,6 +72,10 @@ struct Ws {
     uint32_t* masks;
     float *aux_vf, *aux_rn, *dz_vec, *dz_rgb;
     void *scratch_vf, *scratch_rn;
+    // sparse colour branch (region 2 = the samples with non-zero weight, compacted): selection and per-selected-sample buffers
+    int32_t *cnt, *off, *k_dev, *sel_sorted;
+    float *pts_sel, *dirs_sel, *normals_sel, *colors_sel, *dc_sel, *zero3;
+    long long cap, r2_first;
     size_t slot_bytes;
     long long m_c, m, m_sup, m_sup_pad, total;
     int vf_h, rn_h;
@@ -98,7 +102,10 @@ int carve(void* workspace, const vfn_train_step_params* p, const vfn_net_geom* v
     w->m_c = n * sc; w->m = n * st;
     w->m_sup = (long long)p->n_sup * ((p->border ? 1 : 0) + (p->center ? 1 : 0));
     w->m_sup_pad = pad32(w->m_sup);
-    w->total = w->m + w->m_sup_pad;
+    // sparse colour branch: region 2 can hold every sample (the count of samples with w > 0 is known to the device only)
+    w->cap = p->sparse_colours ? pad32(w->m) : 0;
+    w->r2_first = w->m + w->m_sup_pad;
+    w->total = w->m + w->m_sup_pad + w->cap;
     const int slots = w->vf_h + w->rn_h;
     w->slot_bytes = (size_t)((w->total + 31) / 32) * GROUP_BYTES;
     Carve c{static_cast<unsigned char*>(workspace), 0};
@@ -109,16 +116,28 @@ int carve(void* workspace, const vfn_train_step_params* p, const vfn_net_geom* v
     w->new_pts = c.take<float>(n * nf * 3);
     w->dst = c.take<int32_t>(w->m);
     w->src = c.take<int32_t>(w->m);
-    w->normals_s = c.take<float>(w->m * 3);
+    // the vector outputs of region 1 and of the supervision batch are ONE array (normals_s | sup_pred), their upstream gradients
+    // another (dn_s | d_sup): the sparse path runs one vector-only chain over both
+    w->normals_s = c.take<float>((w->m + w->m_sup_pad) * 3);
+    w->sup_pred = w->normals_s + w->m * 3;
     w->colors_s = c.take<float>(w->m * 3);
-    w->dn_s = c.take<float>(w->m * 3);
+    w->dn_s = c.take<float>((w->m + w->m_sup_pad) * 3);
+    w->d_sup = w->dn_s + w->m * 3;
     w->dc_s = c.take<float>(w->m * 3);
     w->dn = c.take<float>(w->m * 3);
     w->dc = c.take<float>(w->m * 3);
     w->sup_pts = c.take<float>(w->m_sup_pad * 3);
     w->sup_gt = c.take<float>(w->m_sup_pad * 3);
-    w->sup_pred = c.take<float>(w->m_sup_pad * 3);
-    w->d_sup = c.take<float>(w->m_sup_pad * 3);
+    w->cnt = c.take<int32_t>(p->sparse_colours ? n : 0);
+    w->off = c.take<int32_t>(p->sparse_colours ? n : 0);
+    w->k_dev = c.take<int32_t>(p->sparse_colours ? 4 : 0);
+    w->sel_sorted = c.take<int32_t>(w->cap);
+    w->pts_sel = c.take<float>(w->cap * 3);
+    w->dirs_sel = c.take<float>(w->cap * 3);
+    w->normals_sel = c.take<float>(w->cap * 3);
+    w->colors_sel = c.take<float>(w->cap * 3);
+    w->dc_sel = c.take<float>(w->cap * 3);
+    w->zero3 = c.take<float>(w->cap * 3);
     w->d_rgb = c.take<float>(n * 3);
     w->d_depth = c.take<float>(n);
     w->loss_ws = c.take<unsigned char>((size_t)vfn_vf_loss_workspace_bytes());
@@ -131,7 +150,7 @@ int carve(void* workspace, const vfn_train_step_params* p, const vfn_net_geom* v
     w->aux_vf = c.take<float>(w->total * 40);
     w->aux_rn = c.take<float>(w->total * 40);
     w->dz_vec = c.take<float>(w->total * 4);
-    w->dz_rgb = c.take<float>(w->m * 4);
+    w->dz_rgb = c.take<float>((p->sparse_colours ? w->total : w->m) * 4);      // (workspace-indexed: region 2 sits behind the other rows)
     const int64_t s_vf = vfn_net_weight_grads_scratch_bytes(VFN_NET_VF, vf_geom, w->total);
     const int64_t s_rn = vfn_net_weight_grads_scratch_bytes(VFN_NET_RENDER, rn_geom, w->m);
     if (s_vf < 0 || s_rn < 0) return VFN_ERR_UNSUPPORTED;
@@ -157,6 +176,68 @@ __global__ void vfn_train_prep_kernel(const PrepArgs a) {
         a.centroid[0] = a.cx; a.centroid[1] = a.cy; a.centroid[2] = a.cz;
     }
     if (t < a.pad_floats) { a.pad_pts[t] = 0.f; a.pad_gt[t] = 0.f; a.pad_dsup[t] = 0.f; }
+}
+
+// ---- sparse colour branch: which samples have a non-zero weight -----------------------------------------------------------------
+// One wave per ray (4 rays per workgroup).  Pass 1 counts, a one-workgroup scan turns the counts into offsets (ray order: the
+// compacted list is deterministic), pass 2 writes, per selected sample, its sorted index, its point and its ray's direction.
+__global__ void vfn_sel_count_kernel(const float* w, int n_rays, int S, int32_t* cnt) {
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (ray >= n_rays) return;
+    int c = 0;
+    for (int j = lane; j < S; j += 64) c += w[(size_t)ray * S + j] > 0.f ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) cnt[ray] = c;
+}
+
+__global__ __launch_bounds__(256) void vfn_sel_scan_kernel(const int32_t* cnt, int n, int32_t* off, int32_t* k_dev) {
+    __shared__ int s_sum[256];
+    const int t = threadIdx.x;
+    const int per = (n + 255) / 256, lo = t * per, hi = min(n, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += cnt[i];
+    s_sum[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {          // inclusive scan of the 256 chunk sums
+        const int v = t >= o ? s_sum[t - o] : 0;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    int run = s_sum[t] - sum;                    // exclusive
+    for (int i = lo; i < hi; ++i) { off[i] = run; run += cnt[i]; }
+    if (t == 255) k_dev[0] = s_sum[255];
+}
+
+__global__ void vfn_sel_compact_kernel(const float* w, int n_rays, int S, const int32_t* off, const float* points, const float* ray_dirs,
+                                       int32_t* sel_sorted, float* pts_sel, float* dirs_sel) {
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (ray >= n_rays) return;
+    int base = off[ray];
+    const float dx = ray_dirs[(size_t)ray * 3 + 0], dy = ray_dirs[(size_t)ray * 3 + 1], dz = ray_dirs[(size_t)ray * 3 + 2];
+    for (int j0 = 0; j0 < S; j0 += 64) {
+        const int j = j0 + lane;
+        const bool sel = j < S && w[(size_t)ray * S + j] > 0.f;
+        const unsigned long long mask = __ballot(sel);
+        if (sel) {
+            const int k = base + __popcll(mask & ((1ull << lane) - 1ull));
+            const size_t i = (size_t)ray * S + j;
+            sel_sorted[k] = (int32_t)i;
+            pts_sel[(size_t)k * 3 + 0] = points[i * 3 + 0]; pts_sel[(size_t)k * 3 + 1] = points[i * 3 + 1]; pts_sel[(size_t)k * 3 + 2] = points[i * 3 + 2];
+            dirs_sel[(size_t)k * 3 + 0] = dx; dirs_sel[(size_t)k * 3 + 1] = dy; dirs_sel[(size_t)k * 3 + 2] = dz;
+        }
+        base += __popcll(mask);
+    }
+}
+
+// out[index[k]] = a[k] (scatter) or out[k] = a[index[k]] (gather) for the k < *k_dev selected rows of [.,3] arrays
+__global__ void vfn_sel_rows3_kernel(const float* a, const int32_t* index, const int32_t* k_dev, float* out, int gather) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (long long)*k_dev) return;
+    const size_t i = (size_t)index[k];
+    const size_t from = gather ? i : (size_t)k, to = gather ? (size_t)k : i;
+    out[to * 3 + 0] = a[from * 3 + 0]; out[to * 3 + 1] = a[from * 3 + 1]; out[to * 3 + 2] = a[from * 3 + 2];
 }
 
 __global__ void vfn_train_scalar_grads_kernel(const float* dscal, float* g_beta, float* g_mean, float* g_scale) {
@@ -271,22 +352,54 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
         STEP(vfn_internal_raygen(&rq, io->uv, io->pose, io->intrinsics, io->intrinsics, io->t_vals, io->far_coarse_per_ray,
                                  r.perturb_coarse ? io->u_coarse : nullptr, gen_c, 0, r.seed, r.offset, w.directions, io->ray_dirs, w.cam_loc, w.z_c,
                                  w.pts_c, s));
-        STEP(vfn_vf_render_fused16_fwd_train_at(io->vf_geom, io->vf_packed16, io->rn_geom, io->rn_packed16, w.pts_c, io->ray_dirs, w.m_c, sc,
-                                                w.normals_s, w.colors_s, saved_f, w.aux_vf, w.aux_rn, w.masks, p->save_flags, 0, w.total,
-                                                p->forward_products, s));
+        const bool sparse = p->sparse_colours != 0;
+        const int sel_blocks = (n + 3) / 4;
+        if (sparse)      // region 1: the vector-field net alone (vector head, no feature block) on every sample
+            STEP(vfn_vf_mlp16_fwd_train_at(io->vf_geom, io->vf_packed16, w.pts_c, w.m_c, 0, w.normals_s, saved_f, w.aux_vf, w.masks, p->save_flags, 0,
+                                           w.total, s));
+        else
+            STEP(vfn_vf_render_fused16_fwd_train_at(io->vf_geom, io->vf_packed16, io->rn_geom, io->rn_packed16, w.pts_c, io->ray_dirs, w.m_c, sc,
+                                                    w.normals_s, w.colors_s, saved_f, w.aux_vf, w.aux_rn, w.masks, p->save_flags, 0, w.total,
+                                                    p->forward_products, s));
         vfn_density_params dp = r.density;
         dp.n_rays = n; dp.n_samples = sc;
         vfn_fine_params fp = {n, sc, nf, r.near_fine, r.far_fine, r.fine_range, r.window_step, r.span};
         STEP(vfn_internal_density_fine(&dp, w.normals_s, io->ray_dirs, w.z_c, w.scal, &fp, w.directions, w.cam_loc, io->far_fine_per_ray,
                                        r.perturb_fine ? io->u_fine : nullptr, io->u_add, gen_f, gen_a, base_f, base_a, r.seed, r.offset, io->z_vals,
                                        io->points, w.src, w.new_pts, w.dst, w.m_c, s));
-        STEP(vfn_vf_render_fused16_fwd_train_at(io->vf_geom, io->vf_packed16, io->rn_geom, io->rn_packed16, w.new_pts, io->ray_dirs, w.m - w.m_c, nf,
-                                                w.normals_s + w.m_c * 3, w.colors_s + w.m_c * 3, saved_f, w.aux_vf, w.aux_rn, w.masks, p->save_flags,
-                                                w.m_c, w.total, p->forward_products, s));
         dp.n_samples = st;
-        // every sample (proposal and new) moves from storage order to its sorted position on the way into the composite launch
-        STEP(vfn_internal_composite_gather(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, w.src, w.normals_s, w.colors_s, w.m,
-                                           io->weights, io->rgb, io->depth, s));
+        if (sparse) {
+            STEP(vfn_vf_mlp16_fwd_train_at(io->vf_geom, io->vf_packed16, w.new_pts, w.m - w.m_c, 0, w.normals_s + w.m_c * 3, saved_f, w.aux_vf, w.masks,
+                                           p->save_flags, w.m_c, w.total, s));
+            // normals to their sorted positions, weights (no colours yet)
+            STEP(vfn_scatter_rows3(w.normals_s, nullptr, w.dst, w.m, io->normals, nullptr, s));
+            STEP(vfn_ray_density_weights(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, nullptr, nullptr, io->weights, nullptr, nullptr, nullptr, s));
+            // the samples with w > 0, compacted in ray order; their count stays on the device
+            hipLaunchKernelGGL(vfn_sel_count_kernel, dim3(sel_blocks), dim3(256), 0, s, io->weights, n, st, w.cnt);
+            hipLaunchKernelGGL(vfn_sel_scan_kernel, dim3(1), dim3(256), 0, s, w.cnt, n, w.off, w.k_dev);
+            hipLaunchKernelGGL(vfn_sel_compact_kernel, dim3(sel_blocks), dim3(256), 0, s, io->weights, n, st, w.off, io->points, io->ray_dirs,
+                               w.sel_sorted, w.pts_sel, w.dirs_sel);
+            STEP(vfn_check_launch("vfn_train_step (selection)"));
+            // region 2: the fused saving forward (vector-field net + rendering net) on the selected samples only
+            STEP(vfn_internal_fused16_fwd_train_at(io->vf_geom, io->vf_packed16, io->rn_geom, io->rn_packed16, w.pts_sel, w.dirs_sel, w.cap, w.k_dev, 1,
+                                                   w.normals_sel, w.colors_sel, saved_f, w.aux_vf, w.aux_rn, w.masks, p->save_flags, w.r2_first, w.total,
+                                                   p->forward_products, s));
+            // colours: zero where w = 0 (they multiply a zero weight), the selected ones at their sorted positions; composite
+            if (hipMemsetAsync(io->colors, 0, (size_t)w.m * 3 * sizeof(float), s) != hipSuccess) {
+                vfn_set_error("vfn_train_step: could not clear the colours");
+                return VFN_ERR_LAUNCH;
+            }
+            hipLaunchKernelGGL(vfn_sel_rows3_kernel, dim3((unsigned)((w.cap + 255) / 256)), dim3(256), 0, s, w.colors_sel, w.sel_sorted, w.k_dev, io->colors, 0);
+            STEP(vfn_check_launch("vfn_train_step (colour scatter)"));
+            STEP(vfn_ray_density_weights(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, nullptr, io->weights, nullptr, io->rgb, io->depth, s));
+        } else {
+            STEP(vfn_vf_render_fused16_fwd_train_at(io->vf_geom, io->vf_packed16, io->rn_geom, io->rn_packed16, w.new_pts, io->ray_dirs, w.m - w.m_c, nf,
+                                                    w.normals_s + w.m_c * 3, w.colors_s + w.m_c * 3, saved_f, w.aux_vf, w.aux_rn, w.masks, p->save_flags,
+                                                    w.m_c, w.total, p->forward_products, s));
+            // every sample (proposal and new) moves from storage order to its sorted position on the way into the composite launch
+            STEP(vfn_internal_composite_gather(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, w.src, w.normals_s, w.colors_s, w.m,
+                                               io->weights, io->rgb, io->depth, s));
+        }
 
         // ---- supervision points and their vector-only forward (train.py:186-216) -----------------------------------------------------
         if (sd) STEP(join_into(sd, s));
@@ -312,6 +425,38 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
 
         // ---- backward: supervision chain, per-ray backward, fine chain, weight gradients -------------------------------------------------
         const float* feats = saved_f + (size_t)(w.vf_h - 1) * (w.slot_bytes / 4);           // the tanh'ed feature slot, row-major fp32
+        const size_t rn_off = (size_t)w.vf_h * w.slot_bytes;
+        if (sparse) {
+            // per-ray backward on the sorted samples: d colours = w d rgb (zero wherever w is), d normals += the density path's share
+            STEP(vfn_ray_density_weights_bwd(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, w.d_rgb, lp.has_depth ? w.d_depth : nullptr,
+                                             nullptr, w.dn, w.dc, w.dscal, s));
+            STEP(vfn_scatter_rows3(w.dn, nullptr, w.src, w.m, w.dn_s, nullptr, s));       // row src[i] of region 1 is sorted sample i
+            hipLaunchKernelGGL(vfn_sel_rows3_kernel, dim3((unsigned)((w.cap + 255) / 256)), dim3(256), 0, s, w.dc, w.sel_sorted, w.k_dev, w.dc_sel, 1);
+            STEP(vfn_check_launch("vfn_train_step (colour-gradient gather)"));
+            if (hipMemsetAsync(w.zero3, 0, (size_t)w.cap * 3 * sizeof(float), s) != hipSuccess) {
+                vfn_set_error("vfn_train_step: could not clear the zero rows");
+                return VFN_ERR_LAUNCH;
+            }
+            // ONE vector-only chain over region 1 and the supervision rows (d normals | d supervision predictions)
+            STEP(vfn_mlp_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, nullptr, nullptr, nullptr, feats, w.masks, w.dy, p->dy_flags,
+                                              nullptr, nullptr, w.dn_s, w.normals_s, nullptr, 3, w.m + w.m_sup_pad, nullptr, w.dz_vec, 0, w.total, s));
+            // the fused chain over region 2: d colours in, no gradient at the vector head (region 1 carries it)
+            STEP(vfn_internal_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, io->rn_geom, io->rn_packed_bwd16, io->rn_head_w, feats,
+                                                   w.masks, w.dy, p->dy_flags, w.dc_sel, w.colors_sel, w.zero3, w.normals_sel, nullptr, 3, w.cap, w.k_dev,
+                                                   w.dz_rgb, w.dz_vec, w.r2_first, w.total, s));
+            const size_t r2_off = (size_t)(w.r2_first / 32) * GROUP_BYTES;
+            // weight gradients: the rendering net over region 2; the vector-field net's hidden layers + head over region 1 and the
+            // supervision rows, its hidden layers + feature block over region 2 (the head's gradient there is zero)
+            STEP(vfn_internal_net_weight_grads_frag_part(VFN_NET_RENDER, io->rn_geom, io->rn_wgrad, w.saved + rn_off + r2_off, w.dy + rn_off + r2_off,
+                                                         (int64_t)w.slot_bytes, p->dy_form, p->x_form, feats + w.r2_first * 256, w.aux_rn + w.r2_first * 40,
+                                                         w.dz_rgb + w.r2_first * 4, w.cap, w.k_dev, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD, 1,
+                                                         w.scratch_rn, s));
+            STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form, nullptr,
+                                                w.aux_vf, w.dz_vec, w.m + w.m_sup_pad, VFN_WGRAD_LAYERS | VFN_WGRAD_HEAD, 1, w.scratch_vf, s));
+            STEP(vfn_internal_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved + r2_off, w.dy + r2_off, (int64_t)w.slot_bytes,
+                                                         p->dy_form, p->x_form, nullptr, w.aux_vf + w.r2_first * 40, w.dz_vec + w.r2_first * 4, w.cap,
+                                                         w.k_dev, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES, 1, w.scratch_vf, s));
+        } else {
         if (w.m_sup_pad > 0) {
             // (beside the per-ray backward and the fine pass's chain when there is a side stream; joined in front of the weight gradients)
             if (sd) STEP(fork_to(sd, s));
@@ -326,7 +471,6 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
         STEP(vfn_mlp_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, io->rn_geom, io->rn_packed_bwd16, io->rn_head_w, feats,
                                           w.masks, w.dy, p->dy_flags, w.dc_s, w.colors_s, w.dn_s, w.normals_s, nullptr, 3, w.m, w.dz_rgb, w.dz_vec, 0,
                                           w.total, s));
-        const size_t rn_off = (size_t)w.vf_h * w.slot_bytes;
         STEP(vfn_net_weight_grads_frag_part(VFN_NET_RENDER, io->rn_geom, io->rn_wgrad, w.saved + rn_off, w.dy + rn_off, (int64_t)w.slot_bytes,
                                             p->dy_form, p->x_form, feats, w.aux_rn, w.dz_rgb, w.m,
                                             VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD, 1, w.scratch_rn, s));
@@ -334,13 +478,14 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
         if (sd) STEP(join_into(sd, s));
         if (w.m_sup_pad > 0) {
             STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form,
-                                                nullptr, w.aux_vf, w.dz_vec, w.total, VFN_WGRAD_LAYERS | VFN_WGRAD_HEAD, 1, w.scratch_vf, s));
+                                                nullptr, w.aux_vf, w.dz_vec, w.m + w.m_sup_pad, VFN_WGRAD_LAYERS | VFN_WGRAD_HEAD, 1, w.scratch_vf, s));
             STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form,
                                                 nullptr, w.aux_vf, w.dz_vec, w.m, VFN_WGRAD_FEATURES, 1, w.scratch_vf, s));
         } else {
             STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form,
                                                 nullptr, w.aux_vf, w.dz_vec, w.m, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD, 1,
                                                 w.scratch_vf, s));
+        }
         }
         hipLaunchKernelGGL(vfn_train_scalar_grads_kernel, dim3(1), dim3(64), 0, s, w.dscal, io->g_beta, io->g_mean, io->g_scale);
         STEP(vfn_check_launch("vfn_train_step (density scalar gradients)"));

@@ -114,7 +114,20 @@ extern "C" int vfn_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_ge
                                               const void* dy, int64_t slot_bytes, int32_t dy_form, int32_t x_form, const float* feats,
                                               const float* aux, const float* dz_head, int64_t n_points, uint32_t parts,
                                               int32_t accumulate, void* scratch, void* stream) {
+    return vfn_internal_net_weight_grads_frag_part(net_kind, geom, layers, saved, dy, slot_bytes, dy_form, x_form, feats, aux, dz_head, n_points, nullptr,
+                                                   parts, accumulate, scratch, stream);
+}
+
+// ... over min(n_points, *n_dev) points when n_dev (device memory) is given: the slab count and the scratch are sized for n_points, every
+// slab's range is cut from the live count inside the kernels (slabs past it write zeros)
+int vfn_internal_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_geom* geom, const vfn_wgrad_layer* layers, const void* saved,
+                                            const void* dy, int64_t slot_bytes, int32_t dy_form, int32_t x_form, const float* feats,
+                                            const float* aux, const float* dz_head, int64_t n_points, const int32_t* n_dev, uint32_t parts,
+                                            int32_t accumulate, void* scratch, void* stream) {
     const char* what = "vfn_net_weight_grads_frag";
+    auto one = [&](int32_t shape, const void* dy1, int32_t dyf, const void* x1, int32_t xf, float* dw1, float* db1) -> int {
+        return vfn_internal_weight_grad_frag_batch_dev(shape, dyf, xf, 1, &dy1, &x1, &dw1, &db1, n_points, n_dev, groups_for(n_points), stream);
+    };
     VFN_REQUIRE(geom && layers && saved && dy && aux && dz_head && scratch, "%s: NULL argument", what);
     if (n_points <= 0) return VFN_OK;
     Entry e[VFN_MAX_LAYERS + 1];
@@ -144,7 +157,7 @@ extern "C" int vfn_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_ge
         if (b.n == 0) return VFN_OK;
         int gb = G / b.n;
         gb = gb < 1 ? 1 : gb;
-        int rc = vfn_internal_weight_grad_frag_batch(shape, dy_form, xf, b.n, b.dy, b.x, b.dw, b.db, n_points, gb, stream);
+        int rc = vfn_internal_weight_grad_frag_batch_dev(shape, dy_form, xf, b.n, b.dy, b.x, b.dw, b.db, n_points, n_dev, gb, stream);
         for (int i = 0; i < b.n; ++i) {
             vfn_unfold_entry& o = u[b.unfold_idx[i]];
             if (shape == 0) { o.groups_act = gb; o.groups_db = gb; }
@@ -167,7 +180,7 @@ extern "C" int vfn_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_ge
         const int ui = nu;
         if (dw_act) {
             if (x.x_slot < 0) {       // the rendering net's first layer reads the fp32 feature ROWS: another operand form, its own launch
-                rc = vfn_weight_grad_frag(0, dy_h, dy_form, (const void*)feats, 2, n_points, G, dw_act, db, stream);
+                rc = one(0, dy_h, dy_form, (const void*)feats, 2, dw_act, db);
                 if (rc != VFN_OK) return rc;
             } else {
                 if (act.n == 8) { rc = flush(act, 0, x_form); if (rc != VFN_OK) return rc; }
@@ -202,7 +215,7 @@ extern "C" int vfn_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_ge
         const int L = geom->n_layers;
         const vfn_wgrad_layer& q = layers[L - 1];
         VFN_REQUIRE(q.weight && q.bias && q.g_weight && q.g_bias, "%s: the last layer has a NULL weight / bias / gradient pointer", what);
-        int rc = vfn_weight_grad_frag(2, dz_head, 2, sv + (size_t)head_slot * slot_bytes, x_form, n_points, G, part, dbp, stream);
+        int rc = one(2, dz_head, 2, sv + (size_t)head_slot * slot_bytes, x_form, part, dbp);
         if (rc != VFN_OK) return rc;
         vfn_unfold_entry& o = u[nu++];
         o.dw_act = part; o.db = dbp; o.w = q.weight; o.b_lin = q.bias; o.g_w = q.g_weight; o.g_b = q.g_bias;

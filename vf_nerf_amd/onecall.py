@@ -71,7 +71,8 @@ class OneCallStep:
             return no("sample counts are not whole groups of 32 points")
         n_sup = (n * (s_c + n_f)) // 10
         pad = (2 * n_sup + 31) // 32 * 32
-        if n * (s_c + n_f) + pad >= (1 << 21):
+        sparse = bool(getattr(model, "sparse_colour_training", True))
+        if n * (s_c + n_f) * (2 if sparse else 1) + pad >= (1 << 21):
             return no("too many points for one fragment-ordered workspace")
         from .optim import FlatAdam
         opt = model.optimizer
@@ -233,9 +234,11 @@ class OneCallStep:
         pr.beta1, pr.beta2, pr.eps, pr.weight_decay = beta1, beta2, group["eps"], group["weight_decay"]
         pr.max_norm = float(cfg.scheduler_config.clip_norm)
         pr.repack = 1
+        # the colour branch only where a sample's weight is non-zero (exact: include/vfn.h, vfn_train_step); False: dense, as the Python path
+        pr.sparse_colours = int(bool(getattr(model, "sparse_colour_training", True)))
 
         # ---- buffers ------------------------------------------------------------------------------------------------------------------
-        key = (n, s_c, n_f, n_sup, pr.border, pr.center, str(dev))
+        key = (n, s_c, n_f, n_sup, pr.border, pr.center, pr.sparse_colours, str(dev))
         ws = self._ws.get(key)
         if ws is None:
             self._ws.clear()
