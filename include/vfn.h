@@ -239,7 +239,11 @@ typedef struct vfn_render_params {
     int32_t streams;                    /* 2: the batch in two halves, the second on an internal side stream forked from and joined
                                          * into `stream` (same values; the halves fill each other's partial rounds); 1: one stream;
                                          * 0: two halves when the fused launches would leave >= 5 % of their workgroup slots empty */
-    int32_t reserved;
+    int32_t sparse_colours;             /* != 0 (opt-in): colours are evaluated only for the samples whose weight is non-zero — the vector-field
+                                         * net on every sample with its vector-only launch, the fused VF + rendering launch on the compacted list
+                                         * of samples with w > 0 (a count the host never learns).  rgb, depth, weights, normals, z_vals, points are
+                                         * bit-identical to the dense plan; `colors` holds zeros where w = 0.  For callers that keep rgb / depth
+                                         * only (evaluation/methods.py:528-540) */
     void* timing_events[4];             /* optional hipEvent_t handles (NULL: none), recorded on the launch stream around the two fused
                                          * VF + rendering launches: [0] before / [1] after the one on the proposal samples, [2] / [3] the one
                                          * on the new samples (with `streams` > 1: around the FIRST range's launches).  bench.py times the

@@ -491,3 +491,42 @@ def test_two_product_colours_are_measured_by_the_guard(monkeypatch):
         assert raw_diff > 1e-4, "the case is meant to be outside the contract without the guard"
         assert got_diff < 1e-4 and model.colour_products == 3 and model.precision == "f16x3"
         assert model.range_guard.colour_products_reason is not None
+
+
+@pytest.mark.parametrize("name", ["c1_perturb", "odd_orbit", "bench_sizes", "trained_256", "trained_far"])
+def test_sparse_colours_render_equals_the_dense_render(name):
+    """model.sparse_colours (vfn_render_params.sparse_colours; what evaluator.render_view asks for): the vector-field net on every sample
+    with its vector-only launch, the fused VF + rendering launch only on the compacted list of samples whose weight is non-zero (the
+    count never leaves the device).  Against the dense plan on the same draws: sample depths, points, normals, rgb, depth BIT-identical;
+    colours bit-identical wherever they were evaluated, zero elsewhere — and every sample they were NOT evaluated for carries zero weight
+    (checked through the composite: rgb is unchanged to the bit)."""
+    import os
+    from helpers import GOLDEN_DIR
+    if not os.path.exists(os.path.join(GOLDEN_DIR, f"{name}.npz")):
+        pytest.skip(f"tests/golden/{name}.npz has not been generated")
+    fx, d = load_fixture(name)
+    g = {k: v.to("cuda:0") for k, v in d.items() if isinstance(v, torch.Tensor)}
+    uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add") if k in g}
+    model = build_model(fx, d, device="cuda:0")
+    outs = {}
+    for sparse in (False, True):
+        model.sparse_colours = sparse
+        with torch.no_grad():
+            outs[sparse] = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
+    a, b = outs[False], outs[True]
+    for f in ("z_vals", "points_coarse", "coarse_normals", "coarse_rgb_values", "coarse_depth_map"):
+        assert torch.equal(getattr(a, f), getattr(b, f)), f
+    evaluated = (b.coarse_colors != 0).any(dim=1)
+    assert torch.equal(b.coarse_colors[evaluated], a.coarse_colors[evaluated])
+    frac = float(evaluated.float().mean())
+    print(f"{name}: colours evaluated for {frac:.3f} of the {evaluated.numel()} samples; rgb / depth / normals / depths bit-identical to the dense render")
+    assert 0.0 < frac < 0.6
+    assert torch.equal(b.z_vals.cpu(), d["z_vals"]) and rel_err(b.coarse_rgb_values, d["rgb"]) < 1e-4
+    # without supplied draws (the device Philox stream generates them inside the kernels): the same stream position, the same image
+    model.rng_seed = 9
+    for sparse in (False, True):
+        model.sparse_colours, model._rng_offset = sparse, 0
+        with torch.no_grad():
+            outs[sparse] = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0)
+    assert torch.equal(outs[False].coarse_rgb_values, outs[True].coarse_rgb_values) and torch.equal(outs[False].z_vals, outs[True].z_vals)
+    assert model._rng_offset > 0

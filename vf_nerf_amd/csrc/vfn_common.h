@@ -62,3 +62,12 @@ int vfn_internal_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_geom
                                             const void* dy, int64_t slot_bytes, int32_t dy_form, int32_t x_form, const float* feats,
                                             const float* aux, const float* dz_head, int64_t n_points, const int32_t* n_dev, uint32_t parts,
                                             int32_t accumulate, void* scratch, void* stream);
+
+// csrc/vfn_rays.hip: the samples with non-zero weight, compacted on the device (the sparse colour branch of vfn_train_step / vfn_render_fwd)
+int vfn_internal_select_positive(const float* weights, int n_rays, int n_samples, const float* points, const float* ray_dirs, int32_t* cnt,
+                                 int32_t* off, int32_t* k_dev, int32_t* sel_sorted, float* pts_sel, float* dirs_sel, void* stream);
+int vfn_internal_rows3_by_index(const float* a, const int32_t* index, const int32_t* k_dev, int64_t capacity, float* out, int gather, void* stream);
+// csrc/vfn_mlp16.hip: the gradient-free fused launch over min(n_points, *n_dev) points (outputs scattered through out_index when given)
+int vfn_internal_fused16_products_dev(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom, const void* rn_packed16,
+                                      const float* points, const float* ray_dirs, int64_t n_points, const int32_t* n_dev, int32_t samples_per_ray,
+                                      const int32_t* out_index, int32_t colour_products, float* normals, float* colors, void* stream);

@@ -1247,8 +1247,9 @@ extern "C" int vfn_vf_mlp16_fwd(const vfn_net_geom* geom, const void* packed16, 
 static int launch_fused16(const char* what, const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom,
                           const void* rn_packed16, const float* points, const float* ray_dirs, int64_t n_points,
                           int32_t samples_per_ray, const int32_t* out_index, bool scatter, int32_t colour_products, float* normals,
-                          float* colors, void* stream) {
+                          float* colors, void* stream, const int32_t* n_dev = nullptr) {
     Mlp16Args a = {};
+    a.n_dev = n_dev;
     VfnNetPlan p32; Plan16 vf, rn;
     VFN_REQUIRE(vf_geom && rn_geom, "%s: NULL argument", what);
     int rc = make_plan16(VFN_NET_VF, vf_geom, &p32, &vf, what);
@@ -1297,6 +1298,13 @@ extern "C" int vfn_vf_render_fused16_products(const vfn_net_geom* vf_geom, const
                                               float* normals, float* colors, void* stream) {
     return launch_fused16("vfn_vf_render_fused16_products", vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs, n_points,
                           samples_per_ray, out_index, false, colour_products, normals, colors, stream);
+}
+
+int vfn_internal_fused16_products_dev(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom, const void* rn_packed16,
+                                      const float* points, const float* ray_dirs, int64_t n_points, const int32_t* n_dev, int32_t samples_per_ray,
+                                      const int32_t* out_index, int32_t colour_products, float* normals, float* colors, void* stream) {
+    return launch_fused16("vfn_render_fwd (colour branch on the selected samples)", vf_geom, vf_packed16, rn_geom, rn_packed16, points, ray_dirs,
+                          n_points, samples_per_ray, out_index, false, colour_products, normals, colors, stream, n_dev);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1025,6 +1025,98 @@ int vfn_internal_composite_gather(const vfn_density_params* dp, float* normals, 
     return vfn_check_launch("vfn_render_fwd (composite)");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sparse colour branch (csrc/vfn_train.hip, csrc/vfn_render.hip): the samples of a batch whose weight is non-zero, compacted.
+// rgb = sum_s w_s c_s needs a colour only where w_s != 0 — a few percent of the samples (a closed density ReLU, or a transmittance
+// that has underflowed, make the weight EXACTLY zero).
+// ------------------------------------------------------------------------------------------------
+namespace {
+// One wave per ray (4 rays per workgroup).  Pass 1 counts, a one-workgroup scan turns the counts into offsets (ray order: the
+// compacted list is deterministic), pass 2 writes, per selected sample, its sorted index, its point and its ray's direction.
+__global__ void vfn_sel_count_kernel(const float* w, int n_rays, int S, int32_t* cnt) {
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (ray >= n_rays) return;
+    int c = 0;
+    for (int j = lane; j < S; j += 64) c += w[(size_t)ray * S + j] > 0.f ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) cnt[ray] = c;
+}
+
+__global__ __launch_bounds__(256) void vfn_sel_scan_kernel(const int32_t* cnt, int n, int32_t* off, int32_t* k_dev) {
+    __shared__ int s_sum[256];
+    const int t = threadIdx.x;
+    const int per = (n + 255) / 256, lo = t * per, hi = min(n, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += cnt[i];
+    s_sum[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {          // inclusive scan of the 256 chunk sums
+        const int v = t >= o ? s_sum[t - o] : 0;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    int run = s_sum[t] - sum;                    // exclusive
+    for (int i = lo; i < hi; ++i) { off[i] = run; run += cnt[i]; }
+    if (t == 255) k_dev[0] = s_sum[255];
+}
+
+__global__ void vfn_sel_compact_kernel(const float* w, int n_rays, int S, const int32_t* off, const float* points, const float* ray_dirs,
+                                       int32_t* sel_sorted, float* pts_sel, float* dirs_sel) {
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (ray >= n_rays) return;
+    int base = off[ray];
+    const float dx = ray_dirs[(size_t)ray * 3 + 0], dy = ray_dirs[(size_t)ray * 3 + 1], dz = ray_dirs[(size_t)ray * 3 + 2];
+    for (int j0 = 0; j0 < S; j0 += 64) {
+        const int j = j0 + lane;
+        const bool sel = j < S && w[(size_t)ray * S + j] > 0.f;
+        const unsigned long long mask = __ballot(sel);
+        if (sel) {
+            const int k = base + __popcll(mask & ((1ull << lane) - 1ull));
+            const size_t i = (size_t)ray * S + j;
+            sel_sorted[k] = (int32_t)i;
+            pts_sel[(size_t)k * 3 + 0] = points[i * 3 + 0]; pts_sel[(size_t)k * 3 + 1] = points[i * 3 + 1]; pts_sel[(size_t)k * 3 + 2] = points[i * 3 + 2];
+            dirs_sel[(size_t)k * 3 + 0] = dx; dirs_sel[(size_t)k * 3 + 1] = dy; dirs_sel[(size_t)k * 3 + 2] = dz;
+        }
+        base += __popcll(mask);
+    }
+}
+
+// out[index[k]] = a[k] (scatter) or out[k] = a[index[k]] (gather) for the k < *k_dev selected rows of [.,3] arrays
+__global__ void vfn_sel_rows3_kernel(const float* a, const int32_t* index, const int32_t* k_dev, float* out, int gather) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (long long)*k_dev) return;
+    const size_t i = (size_t)index[k];
+    const size_t from = gather ? i : (size_t)k, to = gather ? (size_t)k : i;
+    out[to * 3 + 0] = a[from * 3 + 0]; out[to * 3 + 1] = a[from * 3 + 1]; out[to * 3 + 2] = a[from * 3 + 2];
+}
+
+}  // namespace
+
+// weights[N,S] (sorted order), points[N,S,3], ray_dirs[N,3] -> k_dev[0] = number K of samples with w > 0 (device memory; the host never
+// learns it), and for k < K, in ray order: sel_sorted[k] = the sample's index ray * S + j, pts_sel[k], dirs_sel[k].  cnt / off: [N] scratch.
+int vfn_internal_select_positive(const float* weights, int n_rays, int n_samples, const float* points, const float* ray_dirs, int32_t* cnt,
+                                 int32_t* off, int32_t* k_dev, int32_t* sel_sorted, float* pts_sel, float* dirs_sel, void* stream) {
+    VFN_REQUIRE(weights && points && ray_dirs && cnt && off && k_dev && sel_sorted && pts_sel && dirs_sel && n_rays > 0 && n_samples > 0,
+                "vfn_internal_select_positive: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((n_rays + 3) / 4);
+    hipLaunchKernelGGL(vfn_sel_count_kernel, dim3(blocks), dim3(256), 0, s, weights, n_rays, n_samples, cnt);
+    hipLaunchKernelGGL(vfn_sel_scan_kernel, dim3(1), dim3(256), 0, s, cnt, n_rays, off, k_dev);
+    hipLaunchKernelGGL(vfn_sel_compact_kernel, dim3(blocks), dim3(256), 0, s, weights, n_rays, n_samples, off, points, ray_dirs, sel_sorted, pts_sel,
+                       dirs_sel);
+    return vfn_check_launch("sample selection (w > 0)");
+}
+
+// gather != 0: out[k] = a[index[k]]; else out[index[k]] = a[k]; for the k < *k_dev (<= capacity) selected rows of [., 3] arrays
+int vfn_internal_rows3_by_index(const float* a, const int32_t* index, const int32_t* k_dev, int64_t capacity, float* out, int gather, void* stream) {
+    VFN_REQUIRE(a && index && k_dev && out && capacity >= 0, "vfn_internal_rows3_by_index: bad argument");
+    if (capacity == 0) return VFN_OK;
+    hipLaunchKernelGGL(vfn_sel_rows3_kernel, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, index, k_dev, out, gather);
+    return vfn_check_launch("selected rows scatter / gather");
+}
+
 extern "C" int vfn_scatter_rows3(const float* a, const float* b, const int32_t* index, int64_t n_rows, float* out_a, float* out_b,
                                  void* stream) {
     VFN_REQUIRE(n_rows >= 0 && (n_rows == 0 || (a && index && out_a && (!b || out_b))), "vfn_scatter_rows3: NULL argument");

@@ -34,6 +34,9 @@ struct Ws {
     float *directions, *cam_loc, *z_c, *pts_c, *normals_c, *colors_c, *new_pts, *u;
     int32_t *dst, *src;
     int64_t* imax;
+    // sparse colours: the samples with w > 0, compacted (csrc/vfn_rays.hip, vfn_internal_select_positive)
+    int32_t *cnt, *off, *k_dev, *sel_sorted;
+    float *pts_sel, *dirs_sel;
     size_t bytes;
 };
 
@@ -45,13 +48,20 @@ Ws carve(void* workspace, const vfn_render_params* p) {
     w.cam_loc = c.take<float>(n * 3);
     w.z_c = c.take<float>(n * sc);
     w.pts_c = c.take<float>(n * sc * 3);
-    w.normals_c = c.take<float>(n * sc * 3);
+    w.normals_c = c.take<float>(n * (p->sparse_colours ? sc + nf : sc) * 3);      // (sparse colours: [proposal | new] in storage order)
     w.colors_c = c.take<float>(n * sc * 3);
     w.new_pts = c.take<float>(n * nf * 3);
     w.dst = c.take<int32_t>(n * (sc + nf));
     w.src = c.take<int32_t>(n * (sc + nf));
     w.u = c.take<float>(p->separate_launches ? n * (sc + 2 * nf) + 4 : 0);      // eight-launch plan only
     w.imax = c.take<int64_t>(p->separate_launches ? n : 0);
+    const size_t cap = p->sparse_colours ? n * (sc + nf) : 0;
+    w.cnt = c.take<int32_t>(p->sparse_colours ? n : 0);
+    w.off = c.take<int32_t>(p->sparse_colours ? n : 0);
+    w.k_dev = c.take<int32_t>(p->sparse_colours ? 4 : 0);
+    w.sel_sorted = c.take<int32_t>(cap);
+    w.pts_sel = c.take<float>(cap * 3);
+    w.dirs_sel = c.take<float>(cap * 3);
     w.bytes = c.off;
     return w;
 }
@@ -109,6 +119,46 @@ extern "C" int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf
     const long long base_f = gen_c ? (long long)n * sc : 0, base_a = base_f + (gen_f ? (long long)n * nf : 0);
     vfn_raygen_params rp = {n, sc, p->pose_is_quat, p->near_coarse, p->far_coarse};
     const int products = p->colour_products == 2 ? 2 : 3;
+    if (p->sparse_colours) {
+        // Sparse colours (opt-in; what evaluator.render_view asks for: evaluation/methods.py:528-540 keeps rgb and depth only).  A colour
+        // enters rgb = sum_s w_s c_s only where w_s != 0 — a few percent of the samples — so the vector-field net runs on every
+        // sample with its vector-only launch, the weights follow, and the fused VF + rendering launch covers the compacted list of
+        // samples with w > 0 only (device-side count).  rgb, depth, weights, normals, z_vals, points: bit-identical to the dense
+        // plan; `colors` holds zeros where w = 0.
+        const float* uc = (p->perturb_coarse && u_coarse) ? u_coarse : nullptr;
+        rc = vfn_internal_raygen(&rp, uv, pose, intrinsics, intrinsics, t_vals, far_coarse_per_ray, uc, gen_c, 0, p->seed, p->offset, w.directions, ray_dirs,
+                                 w.cam_loc, w.z_c, w.pts_c, stream);
+        if (rc != VFN_OK) return rc;
+        rc = vfn_vf_mlp16_fwd(vf_geom, vf_packed16, w.pts_c, (int64_t)n * sc, w.normals_c, stream);
+        if (rc != VFN_OK) return rc;
+        vfn_density_params dq = p->density;
+        dq.n_rays = n; dq.n_samples = sc;
+        vfn_fine_params fq = {n, sc, nf, p->near_fine, p->far_fine, p->fine_range, p->window_step, p->span};
+        rc = vfn_internal_density_fine(&dq, w.normals_c, ray_dirs, w.z_c, density_scalars, &fq, w.directions, w.cam_loc, far_fine_per_ray,
+                                       (p->perturb_fine && u_fine) ? u_fine : nullptr, u_add, gen_f, gen_a, base_f, base_a, p->seed, p->offset, z_vals,
+                                       points, w.src, w.new_pts, w.dst, (int64_t)n * sc, stream);
+        if (rc != VFN_OK) return rc;
+        rc = vfn_vf_mlp16_fwd(vf_geom, vf_packed16, w.new_pts, (int64_t)n * nf, w.normals_c + (size_t)n * sc * 3, stream);
+        if (rc != VFN_OK) return rc;
+        rc = vfn_scatter_rows3(w.normals_c, nullptr, w.dst, (int64_t)n * st, normals, nullptr, stream);
+        if (rc != VFN_OK) return rc;
+        dq.n_samples = st;
+        rc = vfn_ray_density_weights(&dq, normals, ray_dirs, z_vals, density_scalars, nullptr, nullptr, weights, nullptr, nullptr, nullptr, stream);
+        if (rc != VFN_OK) return rc;
+        rc = vfn_internal_select_positive(weights, n, st, points, ray_dirs, w.cnt, w.off, w.k_dev, w.sel_sorted, w.pts_sel, w.dirs_sel, stream);
+        if (rc != VFN_OK) return rc;
+        if (hipMemsetAsync(colors, 0, (size_t)n * st * 3 * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+            vfn_set_error("vfn_render_fwd: could not clear the colours");
+            return VFN_ERR_LAUNCH;
+        }
+        // (the fused launch writes the selected samples' normals again — the same values — and their colours at their sorted rows)
+        if (p->timing_events[0]) (void)hipEventRecord((hipEvent_t)p->timing_events[0], (hipStream_t)stream);
+        rc = vfn_internal_fused16_products_dev(vf_geom, vf_packed16, rn_geom, rn_packed16, w.pts_sel, w.dirs_sel, (int64_t)n * st, w.k_dev, 1, w.sel_sorted,
+                                               products, normals, colors, stream);
+        if (rc != VFN_OK) return rc;
+        if (p->timing_events[1]) (void)hipEventRecord((hipEvent_t)p->timing_events[1], (hipStream_t)stream);
+        return vfn_ray_density_weights(&dq, normals, ray_dirs, z_vals, density_scalars, colors, nullptr, weights, nullptr, rgb, depth, stream);
+    }
     if (p->separate_launches) {
         // the same pipeline through the stand-alone entry points, eight launches (A/B timing of the merged plan; same values)
         const float* uc = p->perturb_coarse ? u_coarse : nullptr;

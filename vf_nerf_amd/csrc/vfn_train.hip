@@ -178,68 +178,6 @@ __global__ void vfn_train_prep_kernel(const PrepArgs a) {
     if (t < a.pad_floats) { a.pad_pts[t] = 0.f; a.pad_gt[t] = 0.f; a.pad_dsup[t] = 0.f; }
 }
 
-// ---- sparse colour branch: which samples have a non-zero weight -----------------------------------------------------------------
-// One wave per ray (4 rays per workgroup).  Pass 1 counts, a one-workgroup scan turns the counts into offsets (ray order: the
-// compacted list is deterministic), pass 2 writes, per selected sample, its sorted index, its point and its ray's direction.
-__global__ void vfn_sel_count_kernel(const float* w, int n_rays, int S, int32_t* cnt) {
-    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (ray >= n_rays) return;
-    int c = 0;
-    for (int j = lane; j < S; j += 64) c += w[(size_t)ray * S + j] > 0.f ? 1 : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if (lane == 0) cnt[ray] = c;
-}
-
-__global__ __launch_bounds__(256) void vfn_sel_scan_kernel(const int32_t* cnt, int n, int32_t* off, int32_t* k_dev) {
-    __shared__ int s_sum[256];
-    const int t = threadIdx.x;
-    const int per = (n + 255) / 256, lo = t * per, hi = min(n, lo + per);
-    int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += cnt[i];
-    s_sum[t] = sum;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {          // inclusive scan of the 256 chunk sums
-        const int v = t >= o ? s_sum[t - o] : 0;
-        __syncthreads();
-        s_sum[t] += v;
-        __syncthreads();
-    }
-    int run = s_sum[t] - sum;                    // exclusive
-    for (int i = lo; i < hi; ++i) { off[i] = run; run += cnt[i]; }
-    if (t == 255) k_dev[0] = s_sum[255];
-}
-
-__global__ void vfn_sel_compact_kernel(const float* w, int n_rays, int S, const int32_t* off, const float* points, const float* ray_dirs,
-                                       int32_t* sel_sorted, float* pts_sel, float* dirs_sel) {
-    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (ray >= n_rays) return;
-    int base = off[ray];
-    const float dx = ray_dirs[(size_t)ray * 3 + 0], dy = ray_dirs[(size_t)ray * 3 + 1], dz = ray_dirs[(size_t)ray * 3 + 2];
-    for (int j0 = 0; j0 < S; j0 += 64) {
-        const int j = j0 + lane;
-        const bool sel = j < S && w[(size_t)ray * S + j] > 0.f;
-        const unsigned long long mask = __ballot(sel);
-        if (sel) {
-            const int k = base + __popcll(mask & ((1ull << lane) - 1ull));
-            const size_t i = (size_t)ray * S + j;
-            sel_sorted[k] = (int32_t)i;
-            pts_sel[(size_t)k * 3 + 0] = points[i * 3 + 0]; pts_sel[(size_t)k * 3 + 1] = points[i * 3 + 1]; pts_sel[(size_t)k * 3 + 2] = points[i * 3 + 2];
-            dirs_sel[(size_t)k * 3 + 0] = dx; dirs_sel[(size_t)k * 3 + 1] = dy; dirs_sel[(size_t)k * 3 + 2] = dz;
-        }
-        base += __popcll(mask);
-    }
-}
-
-// out[index[k]] = a[k] (scatter) or out[k] = a[index[k]] (gather) for the k < *k_dev selected rows of [.,3] arrays
-__global__ void vfn_sel_rows3_kernel(const float* a, const int32_t* index, const int32_t* k_dev, float* out, int gather) {
-    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= (long long)*k_dev) return;
-    const size_t i = (size_t)index[k];
-    const size_t from = gather ? i : (size_t)k, to = gather ? (size_t)k : i;
-    out[to * 3 + 0] = a[from * 3 + 0]; out[to * 3 + 1] = a[from * 3 + 1]; out[to * 3 + 2] = a[from * 3 + 2];
-}
-
 __global__ void vfn_train_scalar_grads_kernel(const float* dscal, float* g_beta, float* g_mean, float* g_scale) {
     if (threadIdx.x == 0) { *g_beta += dscal[0]; *g_mean += dscal[1]; *g_scale += dscal[2]; }
 }
@@ -353,7 +291,6 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
                                  r.perturb_coarse ? io->u_coarse : nullptr, gen_c, 0, r.seed, r.offset, w.directions, io->ray_dirs, w.cam_loc, w.z_c,
                                  w.pts_c, s));
         const bool sparse = p->sparse_colours != 0;
-        const int sel_blocks = (n + 3) / 4;
         if (sparse)      // region 1: the vector-field net alone (vector head, no feature block) on every sample
             STEP(vfn_vf_mlp16_fwd_train_at(io->vf_geom, io->vf_packed16, w.pts_c, w.m_c, 0, w.normals_s, saved_f, w.aux_vf, w.masks, p->save_flags, 0,
                                            w.total, s));
@@ -375,11 +312,7 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
             STEP(vfn_scatter_rows3(w.normals_s, nullptr, w.dst, w.m, io->normals, nullptr, s));
             STEP(vfn_ray_density_weights(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, nullptr, nullptr, io->weights, nullptr, nullptr, nullptr, s));
             // the samples with w > 0, compacted in ray order; their count stays on the device
-            hipLaunchKernelGGL(vfn_sel_count_kernel, dim3(sel_blocks), dim3(256), 0, s, io->weights, n, st, w.cnt);
-            hipLaunchKernelGGL(vfn_sel_scan_kernel, dim3(1), dim3(256), 0, s, w.cnt, n, w.off, w.k_dev);
-            hipLaunchKernelGGL(vfn_sel_compact_kernel, dim3(sel_blocks), dim3(256), 0, s, io->weights, n, st, w.off, io->points, io->ray_dirs,
-                               w.sel_sorted, w.pts_sel, w.dirs_sel);
-            STEP(vfn_check_launch("vfn_train_step (selection)"));
+            STEP(vfn_internal_select_positive(io->weights, n, st, io->points, io->ray_dirs, w.cnt, w.off, w.k_dev, w.sel_sorted, w.pts_sel, w.dirs_sel, s));
             // region 2: the fused saving forward (vector-field net + rendering net) on the selected samples only
             STEP(vfn_internal_fused16_fwd_train_at(io->vf_geom, io->vf_packed16, io->rn_geom, io->rn_packed16, w.pts_sel, w.dirs_sel, w.cap, w.k_dev, 1,
                                                    w.normals_sel, w.colors_sel, saved_f, w.aux_vf, w.aux_rn, w.masks, p->save_flags, w.r2_first, w.total,
@@ -389,8 +322,7 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
                 vfn_set_error("vfn_train_step: could not clear the colours");
                 return VFN_ERR_LAUNCH;
             }
-            hipLaunchKernelGGL(vfn_sel_rows3_kernel, dim3((unsigned)((w.cap + 255) / 256)), dim3(256), 0, s, w.colors_sel, w.sel_sorted, w.k_dev, io->colors, 0);
-            STEP(vfn_check_launch("vfn_train_step (colour scatter)"));
+            STEP(vfn_internal_rows3_by_index(w.colors_sel, w.sel_sorted, w.k_dev, w.cap, io->colors, 0, s));
             STEP(vfn_ray_density_weights(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, nullptr, io->weights, nullptr, io->rgb, io->depth, s));
         } else {
             STEP(vfn_vf_render_fused16_fwd_train_at(io->vf_geom, io->vf_packed16, io->rn_geom, io->rn_packed16, w.new_pts, io->ray_dirs, w.m - w.m_c, nf,
@@ -431,8 +363,7 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
             STEP(vfn_ray_density_weights_bwd(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, w.d_rgb, lp.has_depth ? w.d_depth : nullptr,
                                              nullptr, w.dn, w.dc, w.dscal, s));
             STEP(vfn_scatter_rows3(w.dn, nullptr, w.src, w.m, w.dn_s, nullptr, s));       // row src[i] of region 1 is sorted sample i
-            hipLaunchKernelGGL(vfn_sel_rows3_kernel, dim3((unsigned)((w.cap + 255) / 256)), dim3(256), 0, s, w.dc, w.sel_sorted, w.k_dev, w.dc_sel, 1);
-            STEP(vfn_check_launch("vfn_train_step (colour-gradient gather)"));
+            STEP(vfn_internal_rows3_by_index(w.dc, w.sel_sorted, w.k_dev, w.cap, w.dc_sel, 1, s));
             if (hipMemsetAsync(w.zero3, 0, (size_t)w.cap * 3 * sizeof(float), s) != hipSuccess) {
                 vfn_set_error("vfn_train_step: could not clear the zero rows");
                 return VFN_ERR_LAUNCH;

@@ -18,6 +18,10 @@ import torch
 
 
 MIN_CHUNK = 8192        # rays per launch group of a whole view (see render_view)
+# render_view keeps rgb and depth only (as the reference's loop does, evaluation/methods.py:528-540), so it asks render() for SPARSE
+# colours: the rendering net is evaluated only for the samples whose weight is non-zero — a few percent — which leaves rgb and depth
+# bit-identical (model.sparse_colours, include/vfn.h vfn_render_params.sparse_colours).  False: the dense plan.
+SPARSE_COLOURS = True
 
 
 @torch.no_grad()
@@ -35,7 +39,12 @@ def render_view(model, all_pose: torch.Tensor, all_pixels: torch.Tensor, all_int
     rays without a surface, Q9) depends on its position in the stream as it does in the reference.  ``min_chunk = 0``: exactly the
     reference's chunking."""
     chunk = max(int(split_size), int(min_chunk))
-    rgb, depth = model.render_chunked(all_pose, all_pixels, all_intrinsics, epoch, chunk=chunk, n_streams=n_streams, white=white)
+    keep = getattr(model, "sparse_colours", False)
+    model.sparse_colours = bool(SPARSE_COLOURS) or keep
+    try:
+        rgb, depth = model.render_chunked(all_pose, all_pixels, all_intrinsics, epoch, chunk=chunk, n_streams=n_streams, white=white)
+    finally:
+        model.sparse_colours = keep
     host = torch.empty(rgb.shape[0], 4, pin_memory=True)
     host[:, :3].copy_(rgb, non_blocking=True)
     host[:, 3:].copy_(depth, non_blocking=True)

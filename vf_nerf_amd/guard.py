@@ -160,8 +160,11 @@ class RangeGuard:
             two = out.coarse_colors.reshape(n, s_t, 3)[idx].reshape(-1, 3)
             _, three = lib.vf_render_fused16_fwd(vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(), pts, dirs, s_t,
                                                  colour_products=3)
+            diff = (three - two).abs()
+            if getattr(model, "sparse_colours", False):        # colours exist only where the sample's weight is non-zero
+                diff = diff * (two != 0).any(dim=1, keepdim=True)
             slot = st["status"][1:2].view(torch.float32)
-            torch.maximum(slot, (three - two).abs().max().reshape(1), out=slot)
+            torch.maximum(slot, diff.max().reshape(1), out=slot)
             st["sampled"] = True
 
     def _after_call(self, dev) -> bool:

@@ -76,7 +76,7 @@ class RenderParams(C.Structure):
     _fields_ = [("n_rays", C.c_int32), ("n_coarse", C.c_int32), ("n_fine", C.c_int32), ("pose_is_quat", C.c_int32),
                 ("perturb_coarse", C.c_int32), ("perturb_fine", C.c_int32), ("near_coarse", C.c_float), ("near_fine", C.c_float),
                 ("far_coarse", C.c_float), ("far_fine", C.c_float), ("fine_range", C.c_float), ("window_step", C.c_float), ("span", C.c_float),
-                ("density", DensityParams), ("seed", C.c_uint64), ("offset", C.c_uint64), ("colour_products", C.c_int32), ("separate_launches", C.c_int32), ("streams", C.c_int32), ("reserved", C.c_int32),
+                ("density", DensityParams), ("seed", C.c_uint64), ("offset", C.c_uint64), ("colour_products", C.c_int32), ("separate_launches", C.c_int32), ("streams", C.c_int32), ("sparse_colours", C.c_int32),
                 ("timing_events", C.c_void_p * 4)]
 
 

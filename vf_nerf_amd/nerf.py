@@ -177,6 +177,12 @@ class VectorFieldNerf:
         # (+13 % at 1 024 rays x (100 + 35) samples, whose launches are 4 + 2 rounds of workgroups for 4.2 rounds of work).  Same
         # values.  0: when that pays (>= 512 rays and >= 5 % of the workgroup slots empty), 1: never, 2: always.
         self.render_streams = 0
+        # Sparse colours (opt-in; gradient-free one-call renders): rgb = sum_s w_s c_s needs a colour only where w_s != 0 — 3-7 % of the
+        # samples — so the vector-field net runs on every sample with its vector-only launch and the fused VF + rendering launch on the
+        # compacted list of samples with w > 0 only (csrc/vfn_render.hip).  rgb, depth, weights, normals, z_vals, points: bit-identical;
+        # ``coarse_colors`` holds zeros where w = 0 (the reference has no consumer of that field: only vector_field_nerf.py:338 writes
+        # it).  evaluator.render_view switches it on for its own calls; render() itself stays dense.
+        self.sparse_colours = False
         self._render_ws: Dict[tuple, torch.Tensor] = {}
 
     # ---------------------------------------------------------------------------------------------
@@ -437,6 +443,7 @@ class VectorFieldNerf:
         rp.colour_products = int(self.colour_products)
         rp.separate_launches = int(getattr(self, "render_separate_launches", False))      # A/B switch (tools/ab_render_plan.py)
         rp.streams = int(self.render_streams)
+        rp.sparse_colours = int(bool(self.sparse_colours))
 
         def given(name, needed):
             return uniforms[name].to(dev).float().contiguous() if (needed and name in uniforms) else None
@@ -446,7 +453,7 @@ class VectorFieldNerf:
             (n * n_f if u_a is None else 0)
         rp.seed, rp.offset = self.rng_seed & (2 ** 64 - 1), self._rng_offset & (2 ** 64 - 1)
         self._rng_offset += (generated + 3) // 4
-        key = (n, s_c, n_f, str(dev), torch.cuda.current_stream(dev).cuda_stream, rp.separate_launches)
+        key = (n, s_c, n_f, str(dev), torch.cuda.current_stream(dev).cuda_stream, rp.separate_launches, rp.sparse_colours)
         ws = self._render_ws.get(key)
         if ws is None:
             if len(self._render_ws) > 8:
