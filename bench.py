@@ -639,6 +639,17 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
     flops, ws_bytes = train_step_accounting(args.rays, args.coarse, s_t, n_sup, model.activation_storage, model.gradient_storage,
                                             separate_proposal=not stored)
     ms = elapsed / args.steps * 1e3
+    # what the step actually executed: with the one-call step's sparse colour branch (exact: DESIGN.md section 1) the colour branch's
+    # share of the algorithmic FLOPs runs on the selected fraction of the samples only
+    one_call = run_step.one_call.why_not is None
+    sparse = one_call and bool(getattr(model, "sparse_colour_training", True))
+    sel = None
+    if sparse and run_step.last_colour_counts is not None:
+        c = run_step.last_colour_counts.tolist()
+        sel = c[0] / max(1.0, c[1])
+    colour_share = 3.0 * args.rays * s_t * 2.0 * (256 * 256 + RN_MACS) / flops   # fraction of the step's dense FLOPs in the colour branch (feature block + rendering net)
+    executed = flops * (1.0 - colour_share * (1.0 - sel)) + (3.0 * 2.0 * args.rays * s_t * sel * (VF_MACS - 256 * 256) if sel is not None else 0.0) \
+        if sel is not None else flops
     rec = {"metric": "training rays/sec (4096-ray batch, 128 samples/ray, fwd+bwd+clip+Adam)",
            "value": round(args.rays * args.steps * world / elapsed, 1), "unit": "rays/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -652,7 +663,15 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
            if model.vector_field_network.training else "eval mode (the shipped regime, fused kernels)",
            # per GPU: algorithmic FLOPs of a step / its duration against the f16 / 3 matrix ceiling, and the workspace bytes the
            # step has to move against the HBM peak (it sits between the two roofs)
+           "step_issued_as": "one C call (vfn_train_step)" if one_call else f"launch by launch from Python ({run_step.one_call.why_not})",
+           "sparse_colour_branch": {"on": sparse, "samples_with_nonzero_weight": round(sel, 4) if sel is not None else None,
+                                    "note": "exact: a sample's colour, its gradient and the rendering net's share of it in the weight gradients are needed only "
+                                            "where its weight is non-zero; the selected samples re-run the vector-field trunk in the fused launch"},
+           # algorithmic = the DENSE step's FLOPs, whatever was skipped as exactly zero; executed = what the launches computed
            "algorithmic_tflop_per_step": round(flops / 1e12, 4),
+           "executed_tflop_per_step": round(executed / 1e12, 4),
+           "executed_tflops": round(executed / (ms * 1e-3) / 1e12, 1),
+           "frac_of_f16_mfma_div3_executed": round(executed / (ms * 1e-3) / 1e12 / (PEAK_F16_MFMA / 3.0), 4),
            "achieved_tflops": round(flops / (ms * 1e-3) / 1e12, 1),
            # (three matrix products per algorithmic one on the default path; the opt-in single-product mode is priced against the
            # whole peak and carries no div3 figure)
@@ -1139,7 +1158,8 @@ def main() -> None:
     if rank == 0:
         if train_rec is not None:
             line["train"] = {k: train_rec[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "activation_storage", "gradient_storage", "workspace_layout",
-                                                       "algorithmic_tflop_per_step", "achieved_tflops", "frac_of_f16_mfma_div3",
+                                                       "step_issued_as", "sparse_colour_branch", "algorithmic_tflop_per_step", "executed_tflop_per_step",
+                                                       "executed_tflops", "frac_of_f16_mfma_div3_executed", "achieved_tflops", "frac_of_f16_mfma_div3",
                                                        "workspace_gb_per_step", "workspace_tb_per_s", "frac_of_hbm_peak", "final_loss")}
             line["train"]["workload"] = train_rec["config"]["workload"]
         emit_line((line))

@@ -684,7 +684,8 @@ int vfn_flat_adam_step(float* param, const float* grad, float* exp_avg, float* e
  *           the dense step's up to the order of their sums; rgb, depth, weights, normals are the dense step's bit for bit; the `colors`
  *           output holds zeros where w = 0.
  * Outputs of phase 1 (caller-allocated, the NerfOutput of the step's render): ray_dirs[N,3], z_vals[N,S_t], points[N,S_t,3],
- * normals[N S_t,3], colors[N S_t,3], weights[N,S_t], rgb[N,3], depth[N]; out_terms[8] as vfn_vf_loss_fwd.  Phase 2: out_norm[2] as
+ * normals[N S_t,3], colors[N S_t,3], weights[N,S_t], rgb[N,3], depth[N]; out_terms[8] as vfn_vf_loss_fwd; out_counts[2] (optional) =
+ * the number of samples the colour branch was evaluated for (sparse_colours: those with w > 0) and N S_t.  Phase 2: out_norm[2] as
  * vfn_flat_clip_grad_norm.  No allocation, no synchronisation, no host read-back. */
 #define VFN_TRAIN_FORWARD_BACKWARD 1
 #define VFN_TRAIN_OPTIMIZER 2
@@ -728,6 +729,7 @@ typedef struct vfn_train_step_io {
     void* workspace;                                                                          /* vfn_train_step_workspace_bytes() bytes */
     float* ray_dirs; float* z_vals; float* points; float* normals; float* colors; float* weights; float* rgb; float* depth;
     float* out_terms; float* out_norm;
+    float* out_counts;                                                                        /* optional [2]: samples the colour branch ran on, all samples */
 } vfn_train_step_io;
 int64_t vfn_train_step_workspace_bytes(const vfn_train_step_params* p, const vfn_net_geom* vf_geom, const vfn_net_geom* rn_geom);
 int vfn_train_step(const vfn_train_step_params* p, const vfn_train_step_io* io, void* stream);

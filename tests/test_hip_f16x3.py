@@ -357,6 +357,11 @@ def test_one_call_render_equals_the_launch_by_launch_path(name):
 # ------------------------------------------------------------------------------------------------
 # colour branch on two products (csrc/vfn_mlp16.hip, M16_C2; the facade's default for gradient-free renders)
 # ------------------------------------------------------------------------------------------------
+def vguard_tol() -> float:
+    from vf_nerf_amd import guard
+    return guard.COLOUR_CHECK_TOL
+
+
 COLOUR2_TOL = 4e-5          # colours of the two-product branch against the reference's outputs (measured 1.6e-5 .. 2.2e-5); contract 1e-4
 
 
@@ -380,7 +385,15 @@ def test_two_product_colour_branch(name):
     assert torch.equal(n2, n3)
     e3, e2, e2_32 = rel_err(c3, d["colors"]), rel_err(c2, d["colors"]), rel_err(c2, c32)
     print(f"{name}: colours vs the reference: 3 products {e3:.2e}, 2 products {e2:.2e}; 2 products vs exact-fp32 kernels {e2_32:.2e}")
-    assert e3 < 2e-6 and e2 < COLOUR2_TOL and e2_32 < COLOUR2_TOL
+    # trained_far is the state the opt-in does NOT survive (8 000 optimizer steps of the reference trainer: a saturating rendering
+    # net, pre-activations of 10-90; tests/golden/make_trained_golden.py --far): there the two-product colours are asserted to be
+    # OUTSIDE the guard's tolerance — the finding that made three products the default — and still a rounding-level effect
+    far = name == "trained_far"
+    assert e3 < 2e-6
+    if far:
+        assert vguard_tol() < e2_32 < 5e-3 and e2 < 5e-3, (e2, e2_32)
+    else:
+        assert e2 < COLOUR2_TOL and e2_32 < COLOUR2_TOL
     # scatter: a permutation with dropped rows
     m = pts.shape[0]
     perm = torch.randperm(m, generator=torch.Generator().manual_seed(3)).to(torch.int32)
@@ -416,7 +429,11 @@ def test_two_product_colour_branch(name):
     e_23 = rel_err(b.coarse_rgb_values, a.coarse_rgb_values)
     e_rgb, e_rgb3 = rel_err(b.coarse_rgb_values, d["rgb"]), rel_err(a.coarse_rgb_values, d["rgb"])
     print(f"{name}: composited rgb, two vs three products {e_23:.2e}; vs the reference: two {e_rgb:.2e}, three {e_rgb3:.2e}")
-    assert torch.equal(b.z_vals.cpu(), d["z_vals"]) and e_23 < COLOUR2_TOL and e_rgb < 1e-4 and e_rgb3 < 1e-4 and e_rgb < e_rgb3 + COLOUR2_TOL
+    assert torch.equal(b.z_vals.cpu(), d["z_vals"]) and e_rgb3 < 1e-4
+    if far:
+        assert e_23 < 2e-3          # (composited: the weights average the colour error down; reported above, not within the 4e-5 of in-family nets)
+    else:
+        assert e_23 < COLOUR2_TOL and e_rgb < 1e-4 and e_rgb < e_rgb3 + COLOUR2_TOL
 
 
 def test_two_product_colours_are_measured_by_the_guard(monkeypatch):

@@ -142,6 +142,57 @@ def test_trainer_steps_replay_on_hip(precision):
     assert abs(model.optimizer.param_groups[0]["lr"] - float(d["final_lr"])) < 1e-15
 
 
+@pytest.mark.parametrize("colours", ["sparse", "dense"])
+def test_one_call_step_replays_the_reference_trainer_steps(colours):
+    """The steps of the reference's OWN train_epoch recorded in tests/golden/trainer_steps.npz (draws, six loss terms, clip norm,
+    post-step weights) replayed through trainer.TrainStep's ONE C call (vfn_train_step) — by default with the sparse colour branch —
+    instead of through the calls the trainer makes one by one (test_trainer_steps_replay_on_hip).  Step 0 starts from the
+    reference's own state: sampled depths bit-identical, loss terms within 1e-4, the clip norm within 1e-3 and the watched weights
+    after the update within 2 % of one Adam update where the gradient is significant — the bounds the launch-by-launch replay is held
+    to with the default 16-bit storages.  Step 1 within 1e-3 on the loss terms; later steps are other trajectories (Adam's sign
+    decisions), bounded loosely."""
+    from vf_nerf_amd import trainer
+    fx, d = load_trainer_fixture()
+    dev = torch.device(DEV)
+    model = build_model(fx, d, device=DEV)
+    model.sparse_colour_training = colours == "sparse"
+    model.scheduler = torch.optim.lr_scheduler.ExponentialLR(model.optimizer, lr_gamma(fx))
+    crit = vloss.VFLoss(SimpleNamespace(depth_loss_clamp=0.5, norm_smaller_than_one_start=11000, directional_derivatives_start=100),
+                        SimpleNamespace(rgb=2.0, depth=0.5, unit_norm=0.1, supervision=1.0, norm_smaller_than_one=0.1, directional_derivatives=0.0))
+    step = trainer.TrainStep(model, fx["centroid"], border_radius=fx["border_radius"], far=fx["far"], criterion=crit)
+    _, oracle_grads = _oracle_run(fx, d)
+    lr = fx["lr"]
+    for t, b in enumerate(trainer_batches(fx, d, device=DEV)):
+        supervision.replay_uniforms(b["border_u"], b["center_u"])
+        lr_now = model.optimizer.param_groups[0]["lr"]
+        loss, terms = step(b["pose"], b["uv"], b["intrinsics"], b["rgb_gt"], b["depth_gt"], epoch=fx["epoch"],
+                           uniforms={k: b[k] for k in ("u_coarse", "u_fine", "u_add")})
+        assert step.one_call.why_not is None, step.one_call.why_not
+        out = step.last_outputs
+        same_z = bool(torch.equal(out.z_vals.cpu(), d[f"s{t}.out.z_vals"]))
+        e_terms = float((torch.tensor(list(terms.values()), dtype=torch.float64) - d[f"s{t}.loss_terms"]).abs().max())
+        e_loss = abs(float(loss) - float(d[f"s{t}.loss"])) / max(1.0, float(d[f"s{t}.loss"]))
+        e_clip = abs(float(step.last_total_norm) - float(d[f"s{t}.clip_total_norm"])) / float(d[f"s{t}.clip_total_norm"])
+        nets = {"vf": model.vector_field_network, "rn": model.rendering_network}
+        worst_w = 0.0
+        for net, key, how in TRAINER_WATCH:
+            got = watched_slice(dict(nets[net].named_parameters())[key].detach().cpu(), how)
+            g = oracle_grads[t][f"{net}.{key}"]
+            sig = g.abs() > 1e-2 * g.abs().max()
+            worst_w = max(worst_w, float((got - d[f"s{t}.after.{net}.{key}"]).abs()[sig].max()))
+        print(f"[one call, {colours} colours] step {t}: depths identical {same_z}; loss terms |d| {e_terms:.2e}; total rel {e_loss:.2e}; clip norm rel "
+              f"{e_clip:.2e}; watched weights (significant gradients) off by {worst_w / lr:.3f} lr")
+        assert abs(lr_now - float(d[f"s{t}.lr"])) < 1e-12
+        if t == 0:
+            assert same_z and e_terms < 1e-4 and e_loss < 1e-4 and e_clip < 1e-3 and worst_w < 0.02 * lr + 1e-7
+        elif t == 1:
+            assert same_z and e_terms < 1e-3 and e_clip < 0.3 and worst_w < 4.0 * lr
+        else:
+            assert e_loss < 0.1
+    assert float(model.optimizer.state[model.vector_field_network.layers[8].weight]["step"]) == 2 * fx["steps"]
+    assert abs(model.optimizer.param_groups[0]["lr"] - float(d["final_lr"])) < 1e-15
+
+
 def test_dropin_wraps_clip_grad_norm_for_the_duplicated_list():
     """`import vf_nerf_amd.dropin` leaves the trainer's own `torch.nn.utils.clip_grad_norm_(model.parameters(), c)` line
     (train/vector_field_nerf_train.py:254-255) correct on the GPU: duplicated device parameters go through the sequential
@@ -817,7 +868,8 @@ def test_train_step_is_the_same_step_with_and_without_the_fused_loss():
     out = {}
     for mode in ("fused", "dense", "compact"):
         model = build_model(fx, d, device=DEV)
-        supervision.manual_seed(5)
+        model.one_call_train_step = False        # the three LOSS formulations through the same (launch-by-launch) step; the one-call step
+        supervision.manual_seed(5)               # has its own comparisons (test_one_call_*)
         step = trainer.TrainStep(model, (0.0, 0.0, 0.55), border_radius=0.15, far=1.0, compact_selection=(mode == "compact"))
         step.criterion.fused = mode == "fused"
         loss, terms = step(g["pose"], g["uv"], g["intrinsics"], rgb_gt, depth_gt, epoch=0, uniforms=uni)

@@ -178,8 +178,12 @@ __global__ void vfn_train_prep_kernel(const PrepArgs a) {
     if (t < a.pad_floats) { a.pad_pts[t] = 0.f; a.pad_gt[t] = 0.f; a.pad_dsup[t] = 0.f; }
 }
 
-__global__ void vfn_train_scalar_grads_kernel(const float* dscal, float* g_beta, float* g_mean, float* g_scale) {
-    if (threadIdx.x == 0) { *g_beta += dscal[0]; *g_mean += dscal[1]; *g_scale += dscal[2]; }
+__global__ void vfn_train_scalar_grads_kernel(const float* dscal, float* g_beta, float* g_mean, float* g_scale, const int32_t* k_dev, float m,
+                                              float* out_counts) {
+    if (threadIdx.x == 0) {
+        *g_beta += dscal[0]; *g_mean += dscal[1]; *g_scale += dscal[2];
+        if (out_counts) { out_counts[0] = k_dev ? (float)*k_dev : m; out_counts[1] = m; }
+    }
 }
 
 // one side stream (+ fork / join events) per host thread and device, made on first use: the supervision batch's forward and
@@ -418,7 +422,8 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
                                                 w.scratch_vf, s));
         }
         }
-        hipLaunchKernelGGL(vfn_train_scalar_grads_kernel, dim3(1), dim3(64), 0, s, w.dscal, io->g_beta, io->g_mean, io->g_scale);
+        hipLaunchKernelGGL(vfn_train_scalar_grads_kernel, dim3(1), dim3(64), 0, s, w.dscal, io->g_beta, io->g_mean, io->g_scale,
+                           sparse ? w.k_dev : nullptr, (float)w.m, io->out_counts);
         STEP(vfn_check_launch("vfn_train_step (density scalar gradients)"));
     }
 

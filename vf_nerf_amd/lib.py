@@ -105,7 +105,7 @@ class TrainStepIO(C.Structure):
                                           "flat_param", "flat_grad", "exp_avg", "exp_avg_sq")] + [("n_flat", C.c_int64)] + \
                [(n, C.c_void_p) for n in ("clip_workspace", "uv", "pose", "intrinsics", "t_vals", "far_coarse_per_ray", "far_fine_per_ray", "u_coarse", "u_fine",
                                           "u_add", "sup_u_border", "sup_u_center", "rgb_gt", "depth_gt", "workspace", "ray_dirs", "z_vals", "points", "normals",
-                                          "colors", "weights", "rgb", "depth", "out_terms", "out_norm")]
+                                          "colors", "weights", "rgb", "depth", "out_terms", "out_norm", "out_counts")]
 
 
 TRAIN_FORWARD_BACKWARD, TRAIN_OPTIMIZER = 1, 2

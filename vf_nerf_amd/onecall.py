@@ -245,7 +245,7 @@ class OneCallStep:
             need = lib.train_step_workspace_bytes(pr, model.vector_field_network.geometry(), model.rendering_network.geometry())
             ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=dev)
         # the step's outputs: one allocation, sliced (ray_dirs, z_vals, points, normals, colors, weights, rgb, depth, out_terms, out_norm)
-        sizes = (n * 3, n * s_t, m * 3, m * 3, m * 3, n * s_t, n * 3, n, 8, 2)
+        sizes = (n * 3, n * s_t, m * 3, m * 3, m * 3, n * s_t, n * 3, n, 8, 4)
         flat = torch.empty(sum(sizes), device=dev)
         views, o = [], 0
         for k in sizes:
@@ -261,6 +261,7 @@ class OneCallStep:
         io.workspace = _p(ws)
         io.ray_dirs, io.z_vals, io.points, io.normals, io.colors, io.weights, io.rgb, io.depth = (_p(t) for t in views[:8])
         io.out_terms, io.out_norm = _p(out_terms), _p(out_norm)
+        io.out_counts = out_norm.data_ptr() + 8           # [2:4] of the same little tensor: samples the colour branch ran on, all samples
         keep_alive = (pixels, pose, intrinsics, u_c, u_f, u_a, replay, rgb_gt, depth_gt, far_ct, far_ft)     # until the call has been issued
 
         # ---- the call(s) --------------------------------------------------------------------------------------------------------------
@@ -290,6 +291,7 @@ class OneCallStep:
         model.scheduler.step()
 
         step.last_total_norm = out_norm[0]
+        step.last_colour_counts = out_norm[2:4]       # device [selected, all]: read (synchronising) only by whoever reports it
         rep_dirs = RepeatedRows(ray_dirs.view(n, 3), s_t)
         step.last_outputs = NerfOutput(points_coarse=pts.view(n, s_t, 3), points_fine=None, coarse_normals=normals.view(n, s_t, 3),
                                        coarse_rgb_values=rgb.view(n, 3), coarse_depth_map=depth.view(n, 1), fine_normals=None, fine_rgb_values=None,

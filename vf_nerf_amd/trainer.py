@@ -54,6 +54,7 @@ class TrainStep:
         self.compact_selection = bool(compact_selection)
         self.last_total_norm = None
         self.last_outputs = None
+        self.last_colour_counts = None             # one-call step: device [samples the colour branch ran on, all samples]
         # the whole step as ONE C call (vfn_train_step) when the regime allows it (onecall.OneCallStep.applicable: the shipped one);
         # ``model.one_call_train_step = False`` keeps the launch-by-launch path below, which the tests hold equal to it
         from .onecall import OneCallStep
