@@ -586,22 +586,40 @@ def train_dtype_label(model) -> str:
     return f"f16x3 fwd + bf16x3 dX chain + dW on {dw}; f32 accumulate; activations stored {act}, gradients stored {grad}"
 
 
+def training_targets(model, uv, pose, K, dev, s_c, n_f, rank=0):
+    """(rgb_gt, depth_gt, centroid, border radius) of a training-step workload on these rays.
+    TRAINED weights (the model came from build_trained_scene): the targets are the model's OWN deterministic render of the rays
+    (exact-fp32 kernels), so the steps run at the state a long training run sits in — the scene stays, and with it the fraction of
+    samples that carry weight.  Random weights: a LEARNABLE target, rgb / depth as a teacher model of
+    another weight seed renders them — note that this scene loses its surfaces within two Adam steps (every weight becomes zero),
+    so a step timed there flatters the sparse colour branch."""
+    if getattr(model, "_bench_trained_weights", None) is not None:
+        keep = (model.precision, model.ray_sampler.deterministic, model.fine_sampler.deterministic)
+        model.precision, model.ray_sampler.deterministic, model.fine_sampler.deterministic = "fp32", True, True
+        with torch.no_grad():
+            t_out = model.render(pose, uv, K, epoch=0)
+        model.precision, model.ray_sampler.deterministic, model.fine_sampler.deterministic = keep
+        # (the recipe the fixture was trained with: tests/golden/make_trained_golden.py)
+        return t_out.coarse_rgb_values.clone(), t_out.coarse_depth_map.clone(), (0.0, 0.0, 0.55), 0.15
+    teacher, _, _, _ = build_scene(dev, 16, s_c, n_f, seed=rank, perturb=False, weight_seed=1)
+    teacher.precision = "fp32"
+    with torch.no_grad():
+        t_out = teacher.render(pose, uv, K, epoch=0)
+    return t_out.coarse_rgb_values.clone(), t_out.coarse_depth_map.clone(), (0.0, 0.0, 0.6), 0.05
+
+
 def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=True):
     """One step = what the reference trainer does per batch, with synthetic targets (config 3 of BASELINE.json)."""
     from vf_nerf_amd import distributed as vdist, supervision, trainer
     supervision.manual_seed(0x5eed + 7919 * (rank + 1))     # every rank draws its own supervision points
     s_t = args.coarse + args.fine
-    # a LEARNABLE target (SURVEY.md section 8d C3): rgb / depth of these rays as a teacher model of another weight seed renders them
-    teacher, _, _, _ = build_scene(dev, 16, args.coarse, args.fine, seed=rank, perturb=False, weight_seed=1)
-    teacher.precision = "fp32"
-    with torch.no_grad():
-        t_out = teacher.render(pose, uv, K, epoch=0)
-    rgb_gt, depth_gt = t_out.coarse_rgb_values.clone(), t_out.coarse_depth_map.clone()
-    del teacher, t_out
+    trained = getattr(model, "_bench_trained_weights", None)
+    rgb_gt, depth_gt, centroid, radius = training_targets(model, uv, pose, K, dev, args.coarse, args.fine, rank)
     n_sup = (args.rays * s_t) // 10
     bucket = vdist.GradientBucket(model) if (world > 1 or dist is not None) else None
     # the reference trainer's loop body (train/vector_field_nerf_train.py:172-260) on the shipped loss / supervision settings
-    run_step = trainer.TrainStep(model, (0.0, 0.0, 0.6), border_radius=0.05, far=1.0, bucket=bucket)
+    run_step = trainer.TrainStep(model, centroid, border_radius=radius, far=1.0, bucket=bucket)
+    counts = []
 
     def step():
         return run_step(pose, uv, K, rgb_gt, depth_gt, epoch=0)[0]
@@ -609,11 +627,15 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
     for _ in range(args.warmup):
         step()
     sync()
+    if run_step.last_colour_counts is not None:
+        counts.append(run_step.last_colour_counts.tolist())
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
     local_elapsed = time.perf_counter() - t0
+    if run_step.last_colour_counts is not None:
+        counts.append(run_step.last_colour_counts.tolist())
     sync()
     elapsed = time.perf_counter() - t0
     _, rates = rank_rates(dist, local_elapsed, args.rays * args.steps, dev)
@@ -644,9 +666,8 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
     one_call = run_step.one_call.why_not is None
     sparse = one_call and bool(getattr(model, "sparse_colour_training", True))
     sel = None
-    if sparse and run_step.last_colour_counts is not None:
-        c = run_step.last_colour_counts.tolist()
-        sel = c[0] / max(1.0, c[1])
+    if sparse and counts:
+        sel = sum(c[0] / max(1.0, c[1]) for c in counts) / len(counts)        # (before and after the timed steps)
     colour_share = 3.0 * args.rays * s_t * 2.0 * (256 * 256 + RN_MACS) / flops   # fraction of the step's dense FLOPs in the colour branch (feature block + rendering net)
     executed = flops * (1.0 - colour_share * (1.0 - sel)) + (3.0 * 2.0 * args.rays * s_t * sel * (VF_MACS - 256 * 256) if sel is not None else 0.0) \
         if sel is not None else flops
@@ -664,7 +685,9 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
            # per GPU: algorithmic FLOPs of a step / its duration against the f16 / 3 matrix ceiling, and the workspace bytes the
            # step has to move against the HBM peak (it sits between the two roofs)
            "step_issued_as": "one C call (vfn_train_step)" if one_call else f"launch by launch from Python ({run_step.one_call.why_not})",
+           "weights": trained if trained is not None else {"fixture": None, "trained_by": "nobody: synthetic random weights; targets rendered by a teacher of another seed"},
            "sparse_colour_branch": {"on": sparse, "samples_with_nonzero_weight": round(sel, 4) if sel is not None else None,
+                                    "before_and_after_the_timed_steps": [round(c[0] / max(1.0, c[1]), 4) for c in counts] if sparse else None,
                                     "note": "exact: a sample's colour, its gradient and the rendering net's share of it in the weight gradients are needed only "
                                             "where its weight is non-zero; the selected samples re-run the vector-field trunk in the fused launch"},
            # algorithmic = the DENSE step's FLOPs, whatever was skipped as exactly zero; executed = what the launches computed
@@ -943,11 +966,12 @@ def main() -> None:
     s_t = s_c + n_f
     # The headline scene carries TRAINED weights (what a user of the reference renders: evaluation/methods.py:474-547 runs on the
     # state train/vector_field_nerf_train.py:136-292 arrived at); --weights random = the synthetic random-weight scene of rounds 1-3.
-    # The training workload always starts from the random-weight scene (it trains).
+    # The training workload takes them too (its targets: the model's own render, train_bench).
     scene_info = None
-    built = build_trained_scene(dev, args.rays, s_c, n_f, seed=rank) if (args.weights == "trained" and args.workload == "render") else None
+    built = build_trained_scene(dev, args.rays, s_c, n_f, seed=rank) if (args.weights == "trained" and args.workload in ("render", "train")) else None
     if built is not None:
         model, uv, pose, K, scene_info = built
+        model._bench_trained_weights = scene_info
     else:
         model, uv, pose, K = build_scene(dev, args.rays, s_c, n_f, seed=rank)
     model.precision = args.precision
@@ -1147,7 +1171,12 @@ def main() -> None:
         targs.steps, targs.warmup = args.train_steps, 5      # (the first steps size the caching allocator's 15 GB of workspace)
         del out
         torch.cuda.empty_cache()
-        tmodel, tuv, tpose, tK = build_scene(dev, args.rays, s_c, n_f, seed=rank)
+        tbuilt = build_trained_scene(dev, args.rays, s_c, n_f, seed=rank) if args.weights == "trained" else None
+        if tbuilt is not None:
+            tmodel, tuv, tpose, tK, tinfo = tbuilt
+            tmodel._bench_trained_weights = tinfo
+        else:
+            tmodel, tuv, tpose, tK = build_scene(dev, args.rays, s_c, n_f, seed=rank)
         tmodel.precision = args.precision
         tmodel.activation_storage = args.activations
         if args.gradients:
@@ -1158,7 +1187,7 @@ def main() -> None:
     if rank == 0:
         if train_rec is not None:
             line["train"] = {k: train_rec[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "activation_storage", "gradient_storage", "workspace_layout",
-                                                       "step_issued_as", "sparse_colour_branch", "algorithmic_tflop_per_step", "executed_tflop_per_step",
+                                                       "step_issued_as", "weights", "sparse_colour_branch", "algorithmic_tflop_per_step", "executed_tflop_per_step",
                                                        "executed_tflops", "frac_of_f16_mfma_div3_executed", "achieved_tflops", "frac_of_f16_mfma_div3",
                                                        "workspace_gb_per_step", "workspace_tb_per_s", "frac_of_hbm_peak", "final_loss")}
             line["train"]["workload"] = train_rec["config"]["workload"]

@@ -30,17 +30,18 @@ if cores > 0:
 dev = torch.device("cuda", 0)
 out = {"rays": rays, "samples": 128, "steps": steps, "host_cores": len(os.sched_getaffinity(0)), "train_step_streams": int(os.environ.get("VFN_TRAIN_STREAMS", "2"))}
 for path in ("one_call", "python"):
-    model, uv, pose, K = bench.build_scene(dev, rays, 64, 64, seed=0)
+    built = bench.build_trained_scene(dev, rays, 64, 64, seed=0)             # trained weights, targets = the model's own render (bench.training_targets)
+    if built is not None:
+        model, uv, pose, K, info = built
+        model._bench_trained_weights = info
+    else:
+        model, uv, pose, K = bench.build_scene(dev, rays, 64, 64, seed=0)
     model.one_call_train_step = path == "one_call"
+    model.sparse_colour_training = os.environ.get("VFN_SPARSE_COLOURS", "1") != "0"
     model.train_step_streams = int(os.environ.get("VFN_TRAIN_STREAMS", "2"))        # A/B of the side stream inside vfn_train_step
-    teacher, _, _, _ = bench.build_scene(dev, 16, 64, 64, seed=0, perturb=False, weight_seed=1)
-    teacher.precision = "fp32"
-    with torch.no_grad():
-        t_out = teacher.render(pose, uv, K, epoch=0)
-    rgb_gt, depth_gt = t_out.coarse_rgb_values.clone(), t_out.coarse_depth_map.clone()
-    del teacher, t_out
+    rgb_gt, depth_gt, centroid, radius = bench.training_targets(model, uv, pose, K, dev, 64, 64)
     supervision.manual_seed(7)
-    step = trainer.TrainStep(model, (0.0, 0.0, 0.6), border_radius=0.05, far=1.0)
+    step = trainer.TrainStep(model, centroid, border_radius=radius, far=1.0)
     for _ in range(8):
         step(pose, uv, K, rgb_gt, depth_gt, epoch=0)
     torch.cuda.synchronize()
@@ -58,7 +59,10 @@ for path in ("one_call", "python"):
         step(pose, uv, K, rgb_gt, depth_gt, epoch=0)
         iso += time.perf_counter() - t1
     torch.cuda.synchronize()
+    sel = step.last_colour_counts.tolist() if step.last_colour_counts is not None else None
     out[path] = {"took_one_call_path": step.one_call.why_not is None, "why_not": step.one_call.why_not,
+                 "sparse_colour_branch": bool(model.sparse_colour_training) and step.one_call.why_not is None,
+                 "samples_with_nonzero_weight": round(sel[0] / sel[1], 4) if sel else None,
                  "wall_ms_per_step": round(wall / steps * 1e3, 4), "host_issue_ms_per_step_back_to_back": round(host / steps * 1e3, 4),
                  "host_issue_ms_per_step_empty_queue": round(iso / min(steps, 30) * 1e3, 4)}
 print(json.dumps(out))
