@@ -1029,6 +1029,71 @@ def test_sparse_colour_branch_gives_the_dense_gradients():
             assert worst[0] < (tol if "sparse" in (a, b) else 1e-5), (storages, a, b, worst)
 
 
+@pytest.mark.parametrize("case", ["no_sample_selected", "oscillating_field", "ragged_selection_count"])
+def test_sparse_colour_branch_edge_cases(case):
+    """The device-side selection of vfn_train_step at its edges, against the dense Python path on the same weights, rays and draws:
+    * no sample carries weight (a vector head that never flips: density identically zero, K = 0 — every launch of region 2 leaves at
+      once, the colour branch's gradients are exactly zero);
+    * a vector head twelve times as steep (an oscillating, saturated field: other rays and other samples carry the weight);
+    * a selection count that is not a multiple of 32 / 128 (partial last group and workgroup of region 2) — true of any real batch, made
+      explicit here by checking the count.
+    Forward outputs bit-identical, parameter gradients within 1e-3 of a tensor's largest entry (the bound of the default storages)."""
+    from vf_nerf_amd import trainer
+    fx, d = load_fixture("c1_perturb")
+    g = {k: v.to(DEV) for k, v in d.items() if isinstance(v, torch.Tensor)}
+    n = fx["n_rays"]
+    gen = torch.Generator().manual_seed(1)
+    rgb_gt, depth_gt = torch.rand(n, 3, generator=gen).to(DEV), torch.rand(n, 1, generator=gen).to(DEV)
+    uni = {k: g[k] for k in ("u_coarse", "u_fine", "u_add")}
+
+    class Snapshot:
+        def __init__(self, model):
+            self.model, self.grads = model, None
+
+        def zero(self):
+            self.model.optimizer.zero_grad()
+
+        def all_reduce_mean(self):
+            self.grads = [p.grad.detach().clone() for p in self.model.unique_parameters()]
+
+    got = {}
+    for path in ("one_call", "python"):
+        model = build_model(fx, d, device=DEV)
+        head = model.vector_field_network.layers[8]
+        with torch.no_grad():
+            if case == "no_sample_selected":
+                head.weight[:3].zero_()
+                head.bias[:3] = torch.tensor([0.3, -0.2, 0.9])
+            elif case == "oscillating_field":
+                head.weight[:3].mul_(12.0)
+        model.vector_field_network._invalidate_packs()
+        model.one_call_train_step = path == "one_call"
+        supervision.manual_seed(4)
+        snap = Snapshot(model)
+        step = trainer.TrainStep(model, (0.0, 0.0, 0.55), border_radius=0.15, far=1.0, bucket=snap)
+        loss, _ = step(g["pose"], g["uv"], g["intrinsics"], rgb_gt, depth_gt, epoch=0, uniforms=uni)
+        assert (step.one_call.why_not is None) == (path == "one_call"), step.one_call.why_not
+        o = step.last_outputs
+        counts = step.last_colour_counts.tolist() if path == "one_call" else None
+        got[path] = (float(loss), snap.grads, o.coarse_rgb_values.clone(), o.coarse_depth_map.clone(), o.coarse_normals.clone(), counts)
+    a, b = got["one_call"], got["python"]
+    k, m = int(a[5][0]), int(a[5][1])
+    print(f"[{case}] selected {k} of {m} samples ({k / m:.3f}); loss {a[0]:.6f} / {b[0]:.6f}")
+    assert a[0] == b[0] and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    assert all(bool(torch.isfinite(x).all()) for x in a[1])
+    worst = max(float((x - y).abs().max() / y.abs().max().clamp_min(1e-30)) for x, y in zip(a[1], b[1]) if float(y.abs().max()) > 0)
+    print(f"[{case}] worst parameter-gradient difference to the dense Python path: {worst:.2e} of the tensor's largest entry")
+    assert worst < 1e-3
+    if case == "no_sample_selected":
+        assert k == 0 and float(a[2].abs().max()) == 0.0
+        rn_grads = a[1][len(list(build_model(fx, d).vector_field_network.parameters())):-3]
+        assert all(float(x.abs().max()) == 0.0 for x in rn_grads), "no colour was used: the rendering net gets no gradient at all"
+    elif case == "oscillating_field":
+        assert 0 < k < m
+    else:
+        assert k % 32 != 0 and 0 < k < m
+
+
 def test_lazy_loss_terms_survive_the_pinned_ring_wrapping_around():
     """The six log scalars travel through a ring of 64 pinned buffers and are fetched on first read: a dict that is still unread
     when its buffer comes round again is read before the buffer is handed on, so late readers get their own step's values."""
