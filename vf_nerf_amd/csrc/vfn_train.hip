@@ -372,22 +372,28 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
                 vfn_set_error("vfn_train_step: could not clear the zero rows");
                 return VFN_ERR_LAUNCH;
             }
-            // ONE vector-only chain over region 1 and the supervision rows (d normals | d supervision predictions)
-            STEP(vfn_mlp_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, nullptr, nullptr, nullptr, feats, w.masks, w.dy, p->dy_flags,
-                                              nullptr, nullptr, w.dn_s, w.normals_s, nullptr, 3, w.m + w.m_sup_pad, nullptr, w.dz_vec, 0, w.total, s));
+            // Region 2's chain and the rendering net's weight gradients are small launches (a few percent of the samples: 0.6 rounds of
+            // workgroups at 4096 rays) that touch nothing region 1's chain and weight gradients touch (other rows of the workspace, other
+            // parameters' gradients, their own scratch): they run on the side stream beside them.
+            const size_t r2_off = (size_t)(w.r2_first / 32) * GROUP_BYTES;
+            if (sd) STEP(fork_to(sd, s));
             // the fused chain over region 2: d colours in, no gradient at the vector head (region 1 carries it)
             STEP(vfn_internal_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, io->rn_geom, io->rn_packed_bwd16, io->rn_head_w, feats,
                                                    w.masks, w.dy, p->dy_flags, w.dc_sel, w.colors_sel, w.zero3, w.normals_sel, nullptr, 3, w.cap, w.k_dev,
-                                                   w.dz_rgb, w.dz_vec, w.r2_first, w.total, s));
-            const size_t r2_off = (size_t)(w.r2_first / 32) * GROUP_BYTES;
+                                                   w.dz_rgb, w.dz_vec, w.r2_first, w.total, ss));
             // weight gradients: the rendering net over region 2; the vector-field net's hidden layers + head over region 1 and the
             // supervision rows, its hidden layers + feature block over region 2 (the head's gradient there is zero)
             STEP(vfn_internal_net_weight_grads_frag_part(VFN_NET_RENDER, io->rn_geom, io->rn_wgrad, w.saved + rn_off + r2_off, w.dy + rn_off + r2_off,
                                                          (int64_t)w.slot_bytes, p->dy_form, p->x_form, feats + w.r2_first * 256, w.aux_rn + w.r2_first * 40,
                                                          w.dz_rgb + w.r2_first * 4, w.cap, w.k_dev, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD, 1,
-                                                         w.scratch_rn, s));
+                                                         w.scratch_rn, ss));
+            // ONE vector-only chain over region 1 and the supervision rows (d normals | d supervision predictions)
+            STEP(vfn_mlp_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, nullptr, nullptr, nullptr, feats, w.masks, w.dy, p->dy_flags,
+                                              nullptr, nullptr, w.dn_s, w.normals_s, nullptr, 3, w.m + w.m_sup_pad, nullptr, w.dz_vec, 0, w.total, s));
             STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form, nullptr,
                                                 w.aux_vf, w.dz_vec, w.m + w.m_sup_pad, VFN_WGRAD_LAYERS | VFN_WGRAD_HEAD, 1, w.scratch_vf, s));
+            // (the vector-field net's gradients of region 2 are ADDED to the same tensors: after both of the above)
+            if (sd) STEP(join_into(sd, s));
             STEP(vfn_internal_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved + r2_off, w.dy + r2_off, (int64_t)w.slot_bytes,
                                                          p->dy_form, p->x_form, nullptr, w.aux_vf + w.r2_first * 40, w.dz_vec + w.r2_first * 4, w.cap,
                                                          w.k_dev, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES, 1, w.scratch_vf, s));
