@@ -14,9 +14,13 @@ DEV = "cuda:0"
 
 @pytest.mark.parametrize("m,k,n", [(1, 39, 256), (130, 256, 217), (257, 256, 259), (1000, 289, 256), (77, 256, 3), (4096, 256, 256)])
 @pytest.mark.parametrize("transpose", [False, True])
-def test_linear_rows_against_float64(m, k, n, transpose):
-    """C = tanh(A W^T + b) / C = A W on the fp32 matrix cores vs float64 on the CPU: 1e-6 of the largest |z| (products are
-    exact fp32, the sums of k terms round in fp32); column sums of z and z^2 within 1e-5."""
+@pytest.mark.parametrize("arith", ["exact", "split_f16", "split_bf16"])
+def test_linear_rows_against_float64(m, k, n, transpose, arith):
+    """C = tanh(A W^T + b) / C = A W on the matrix cores vs float64 on the CPU.  Exact fp32 instruction: 1e-6 of the largest |z|
+    (products are exact fp32, the sums of k terms round in fp32).  Split f16 (three f16 products per product, 22 significant bits,
+    what the forward GEMMs of the training-mode networks run on): the same 1e-6.  Split bf16 (16 significant bits with fp32's range,
+    the backward GEMMs): 3e-5 — and, scaled down by 1e-6 like a gradient, still 3e-5 of ITS largest entry (no underflow).
+    Column sums of z and z^2 within 1e-5 / the arithmetic's own bound."""
     torch.manual_seed(m + k + n)
     kp, ldc = (k + 7) & ~7, (n + 7) & ~7
     a = torch.zeros(m, kp)
@@ -26,18 +30,26 @@ def test_linear_rows_against_float64(m, k, n, transpose):
     c = torch.full((m, ldc), 7.0, device=DEV)
     parts = lib.linear_rows_stat_parts(m)
     part = torch.empty(parts, 2, n, device=DEV)
+    mode = {"exact": lib.GEMM_EXACT, "split_f16": lib.GEMM_SPLIT_F16, "split_bf16": lib.GEMM_SPLIT_BF16}[arith]
+    tol = 3e-5 if arith == "split_bf16" else 1e-6
     lib.linear_rows(a.to(DEV), w.to(DEV), None if b is None else b.to(DEV), m, n, k, c, act=lib.ACT_NONE if transpose else lib.ACT_TANH,
-                    transpose_w=transpose, stats_part=part)
+                    transpose_w=transpose, stats_part=part, arith=mode)
     z = a[:, :k].double() @ (w.double() if transpose else w.double().t()) + (0 if b is None else b.double())
     want = z if transpose else torch.tanh(z)
     got = c.cpu()
-    assert float((got[:, :n].double() - want).abs().max()) <= 1e-6 * max(1.0, float(z.abs().max()))
+    err = float((got[:, :n].double() - want).abs().max()) / max(1.0, float(z.abs().max()))
+    print(f"{arith} m={m} k={k} n={n} transpose={transpose}: {err:.2e} of the largest |z|")
+    assert err <= tol
     assert bool((got[:, n:] == 7.0).all()), "columns past n_out must not be written"
     sums = torch.empty(2 * n, dtype=torch.float64, device=DEV)
     lib.colsum_finish(part, parts, 2 * n, sums)
     s = sums.cpu().view(2, n)
-    assert float((s[0] - z.sum(0)).abs().max()) <= 1e-5 * float(z.abs().sum(0).max())
-    assert float((s[1] - (z * z).sum(0)).abs().max()) <= 1e-5 * float((z * z).sum(0).max())
+    assert float((s[0] - z.sum(0)).abs().max()) <= max(1e-5, 10 * tol) * float(z.abs().sum(0).max())
+    assert float((s[1] - (z * z).sum(0)).abs().max()) <= max(1e-5, 10 * tol) * float((z * z).sum(0).max())
+    if arith == "split_bf16" and transpose:          # gradient-sized operands: bf16 halves keep fp32's exponent range
+        c2 = torch.zeros((m, ldc), device=DEV)
+        lib.linear_rows((a * 1e-6).to(DEV), w.to(DEV), None, m, n, k, c2, transpose_w=True, arith=mode)
+        assert float((c2.cpu()[:, :n].double() - 1e-6 * z).abs().max()) <= tol * 1e-6 * max(1.0, float(z.abs().max()))
 
 
 def test_embed_rows_and_its_derivative():

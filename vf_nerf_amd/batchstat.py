@@ -62,6 +62,23 @@ def _running_coef(bn) -> torch.Tensor:
     return torch.stack([scale, bn.bias.detach() - bn.running_mean.detach() * scale, bn.running_mean.detach(), rstd]).contiguous()
 
 
+def _arith(net, backward: bool) -> int:
+    """Arithmetic of the layer GEMMs (csrc/vfn_bstat.hip): ``net.gemm_arithmetic`` = "fp32" (default: the exact fp32 matrix
+    instruction) or "split" (opt-in: three f16 products per product in the forward GEMMs — 22 significant bits, like the fused f16x3
+    kernels — and three bf16 products in the backward GEMMs dX = dZ W, whose operands have any magnitude: 16 bits, the fused dX
+    chain's split; the 256 x 256 weight gradients on the bf16 cores as well).  Measured (round 4, profiles/r04/linear_rows_microbench.txt):
+    the split GEMM runs 0.66 ms against 0.80-0.87 ms at M = 524 288 — 1.25x, not the 5x of its matrix cycles, because the kernel is
+    bound by how it fetches its A operand (32-byte pieces of rows 1 KiB apart), not by the matrix pipe — and the training-mode step
+    79 ms against 92 ms, while the bf16 backward moves the worst parameter gradient from 1.7e-3 to 2.5e-3 of the reference's.  Not
+    worth the default; the lever that is left is staging A through LDS with whole-line loads."""
+    mode = getattr(net, "gemm_arithmetic", "fp32")
+    if mode == "fp32":
+        return lib.GEMM_EXACT
+    if mode != "split":
+        raise ValueError(f"gemm_arithmetic must be 'split' or 'fp32', got {mode!r}")
+    return lib.GEMM_SPLIT_BF16 if backward else lib.GEMM_SPLIT_F16
+
+
 def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, update_running: bool = True,
              batch_stats: bool = True) -> _State:
     """x0[M, ld] = input matrix of layer 0 (pad columns zero).  ``fill_skip(dst: Cols, scale)`` writes the skip layer's
@@ -84,7 +101,7 @@ def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, upda
         if batch_stats:
             parts = lib.linear_rows_stat_parts(m)
             part = torch.empty(parts, 2, n, device=dev)
-            lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, stats_part=part)
+            lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, stats_part=part, arith=_arith(net, False))
             sums = torch.empty(2, n, dtype=torch.float64, device=dev)
             lib.colsum_finish(part, parts, 2 * n, sums)
             coef = torch.empty(4, n, device=dev)
@@ -93,7 +110,7 @@ def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, upda
             if update_running:
                 bn.num_batches_tracked += 1
         else:
-            lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z)
+            lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, arith=_arith(net, False))
             coef = _running_coef(bn)
         st.z.append(z)
         st.coef.append(coef)
@@ -108,7 +125,7 @@ def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, upda
     last = net._linear(L - 1)
     st.x.append(x)
     y = torch.zeros(m, _up8(last.out_features), device=dev)
-    lib.linear_rows(x, last.weight.detach(), last.bias.detach(), m, last.out_features, last.in_features, y, act=final_act)
+    lib.linear_rows(x, last.weight.detach(), last.bias.detach(), m, last.out_features, last.in_features, y, act=final_act, arith=_arith(net, False))
     st.y = y
     if batch_stats and update_running:
         # vfn_bstat_finalize advanced running_mean / running_var through raw pointers: their _version did not move, so the
@@ -142,6 +159,7 @@ class _ParamGrads:
         lin = self.net._linear(i)
         n, k = lin.out_features, lin.in_features
         dev, G, m = dz.device, self.G, self.m
+        split = getattr(self.net, "gemm_arithmetic", "fp32") == "split"
         row_blocks = []
         if n % 256 != 0 and n % 256 <= 32 and n > 32:     # 259 = 3 + 256: rows 0..2 as the narrow head, the rest as one block
             row_blocks.append((0, n % 256, 2))
@@ -176,7 +194,12 @@ class _ParamGrads:
                     u.update(dw_act=part, act_c0=c0, act_nc=nc)
                 elif kind == "act":
                     part = torch.empty(G, 256, 256, device=dev)
-                    lib.weight_grad_partials(0, dzv, dzv.ld, rows, xv, xv.ld, nc, m, G, part, db_part if first else None)
+                    if split and rows == 256 and nc == 256 and r0 == 0 and c0 == 0 and dzv.ld == 256 and xv.ld == 256:
+                        # a full 256 x 256 product of two dense [M,256] matrices: the bf16 matrix cores (three products on split operands,
+                        # csrc/vfn_dw16.hip — what the fused path's row-major backward uses), 4x the fp32 matrix instruction's rate
+                        lib.weight_grad_partials_bf16(dz, x, m, G, part, db_part if first else None)
+                    else:
+                        lib.weight_grad_partials(0, dzv, dzv.ld, rows, xv, xv.ld, nc, m, G, part, db_part if first else None)
                     u.update(dw_act=part, act_c0=c0, act_nc=nc)
                 else:
                     part = torch.empty(G, 256, 64, device=dev)
@@ -212,7 +235,7 @@ def _backward(net, st: _State, dz_last: torch.Tensor, pg: Optional[_ParamGrads],
         if i == 0 and not want_dx0:
             return None, skip_piece
         g = torch.zeros(m, _up8(k), device=dev) if k % 8 else torch.empty(m, _up8(k), device=dev)
-        lib.linear_rows(dz, lin.weight.detach(), None, m, k, n, g, transpose_w=True)      # dX = dZ W
+        lib.linear_rows(dz, lin.weight.detach(), None, m, k, n, g, transpose_w=True, arith=_arith(net, True))      # dX = dZ W
         if i == 0:
             return g, skip_piece
         # BatchNorm + ReLU of layer i-1, whose (scaled) output is columns [0, n_prev) of x[i]

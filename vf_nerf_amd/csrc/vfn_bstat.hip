@@ -180,6 +180,196 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows_kernel(const GemmArgs 
     }
 }
 
+// ---- the same GEMM on the 16-bit matrix cores with SPLIT operands (round 4) --------------------------------------------------
+// Every fp32 operand is carried as two 16-bit halves and a product is a_hi b_hi + a_hi b_lo + a_lo b_hi on v_mfma_f32_32x32x16_*
+// with fp32 accumulation: 3 MFMAs of 32 cycles per K = 16 instead of 8 fp32 MFMAs of 64 cycles (5.3x fewer matrix cycles).
+//   F16 (forward GEMMs: batch-normalised activations, weights of O(0.1)): hi = f16(v), lo = f16(v - hi): 22 significant bits; A rides
+//        at 2^6 x its value so that its low halves stay out of the f16 denormals (undone in the epilogue), the weights' low halves
+//        may be denormal (the MFMA honours them: an absolute resolution of 6e-8);
+//   BF16 (backward GEMMs dX = dZ W: gradients of any magnitude): hi = the top 16 bits (truncation), lo = bf16(v - hi): 16 significant
+//        bits with fp32's exponent range, no scaling needed — the dX chain of the fused kernels (csrc/vfn_bwd16.hip) is the same split.
+// Same tiling as the exact kernel (128 rows x NT x 32 columns per workgroup, W staged in LDS in chunks of 32 k, A fragments from
+// global memory by bounds-checked 16-byte loads), same epilogue (bias, activation, per-workgroup column sums of z and z^2).
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+constexpr int GM_LDH = 40;      // LDS row stride of a 16-bit W plane (elements): 80 bytes, 16-byte aligned
+
+template <bool BF>
+__device__ __forceinline__ void split2(float v, unsigned short& hi, unsigned short& lo) {
+    if constexpr (BF) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        hi = (unsigned short)(u >> 16);
+        const float r = v - __builtin_bit_cast(float, u & 0xffff0000u);
+        lo = __builtin_bit_cast(unsigned short, (__bf16)r);
+    } else {
+        const _Float16 h = (_Float16)v;
+        hi = __builtin_bit_cast(unsigned short, h);
+        lo = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)h));
+    }
+}
+
+template <int NT, bool TRANS, bool BF>
+__global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short s_hi[NT * 32 * GM_LDH];
+    __shared__ __attribute__((aligned(16))) unsigned short s_lo[NT * 32 * GM_LDH];
+    __shared__ float s_red[2][4][NT * 32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, g = lane >> 5;
+    constexpr int NCOL = NT * 32;
+    constexpr int PER = NCOL * 16 / 256;         // PAIRS of consecutive k each thread stages per chunk of 32 k
+    constexpr unsigned OOB = 0x7fffffffu;
+    constexpr float A_SCALE = BF ? 1.0f : 64.0f;
+
+    const long long blk_row0 = (long long)blockIdx.x * GM_ROWS;
+    const long long blk_rows = min((long long)GM_ROWS, a.m - blk_row0);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.a + (size_t)blk_row0 * a.lda), 0, (int)(blk_rows * a.lda * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w), 0, (int)((long long)(TRANS ? a.k_in : a.n_out) * a.ldw * 4), 0x00020000);
+    const unsigned a_row_off = (unsigned)(32 * wave + c) * (unsigned)a.lda * 4u;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // pair e of the chunk -> (column n, first contraction index kk of the pair).  Plain: consecutive lanes walk k (coalesced 8-byte
+    // reads of W[n][k]).  Transposed: consecutive lanes walk n (coalesced rows of W[k][n]), two rows per pair.
+    auto stage_index = [&](int e, int& n, int& kk) {
+        if (!TRANS) { kk = 2 * (e & 15); n = e >> 4; }
+        else { n = e % NCOL; kk = 2 * (e / NCOL); }
+    };
+    float wreg[PER][2];
+    auto fetch_w = [&](int kc) {
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            int n, kk;
+            stage_index(tid + 256 * r, n, kk);
+            const int col = a.n0 + n;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = kc + kk + q;
+                const unsigned off = (col < a.n_out && k < a.k_in)
+                    ? (TRANS ? ((unsigned)k * (unsigned)a.ldw + (unsigned)col) * 4u : ((unsigned)col * (unsigned)a.ldw + (unsigned)k) * 4u) : OOB;
+                wreg[r][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, off, 0, 0));
+            }
+        }
+    };
+    auto stage_w = [&]() {
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            int n, kk;
+            stage_index(tid + 256 * r, n, kk);
+            unsigned short h0, l0, h1, l1;
+            split2<BF>(wreg[r][0], h0, l0);
+            split2<BF>(wreg[r][1], h1, l1);
+            *reinterpret_cast<unsigned*>(s_hi + n * GM_LDH + kk) = (unsigned)h0 | ((unsigned)h1 << 16);
+            *reinterpret_cast<unsigned*>(s_lo + n * GM_LDH + kk) = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+    };
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    f32x4 av[2][2];          // [K step of 16][first / second group of four k of this lane's eight]
+    auto fetch_a = [&](int kc) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = kc + 16 * ks + 8 * g + 4 * q;
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs_a, k < a.k_pad ? a_row_off + (unsigned)k * 4u : OOB, 0, 0);
+                av[ks][q] = __builtin_bit_cast(f32x4, raw);
+            }
+    };
+
+    fetch_w(0);
+    for (int kc = 0; kc < a.k_pad; kc += GM_KC) {
+        __syncthreads();               // every wave is done with the previous chunk
+        stage_w();
+        __syncthreads();
+        fetch_a(kc);
+        if (kc + GM_KC < a.k_pad) fetch_w(kc + GM_KC);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (kc + 16 * ks >= a.k_pad) break;
+            u16x8 ah, al;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                unsigned short h, l;
+                split2<BF>(av[ks][t >> 2][t & 3] * A_SCALE, h, l);
+                ah[t] = h; al[t] = l;
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const u16x8 bh = *reinterpret_cast<const u16x8*>(s_hi + (32 * j + c) * GM_LDH + 16 * ks + 8 * g);
+                const u16x8 bl = *reinterpret_cast<const u16x8*>(s_lo + (32 * j + c) * GM_LDH + 16 * ks + 8 * g);
+                if constexpr (BF) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, ah), __builtin_bit_cast(b8, bh), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, ah), __builtin_bit_cast(b8, bl), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, al), __builtin_bit_cast(b8, bh), acc[j], 0, 0, 0);
+                } else {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ah), __builtin_bit_cast(h8, bh), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ah), __builtin_bit_cast(h8, bl), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, al), __builtin_bit_cast(h8, bh), acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // epilogue: D row = (r&3) + 8 (r>>2) + 4 g, col = c  (as the exact kernel; the f16 form undoes A's scale first)
+    const long long row0 = (long long)blockIdx.x * GM_ROWS + 32 * wave;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = a.n0 + 32 * j + c;
+        const bool col_ok = col < a.n_out;
+        const float b = (a.bias && col_ok) ? a.bias[col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            const float z = acc[j][r] * (1.0f / A_SCALE) + b;
+            if (row < a.m && col_ok) {
+                s1 += z;
+                s2 += z * z;
+                float y = z;
+                if (a.act == ACT_TANH) y = tanhf(z);
+                else if (a.act == ACT_SIGMOID) y = 1.0f / (1.0f + expf(-z));
+                a.c[(size_t)row * a.ldc + col] = y;
+            }
+        }
+        if (a.stats_part) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (g == 0) { s_red[0][wave][32 * j + c] = s1; s_red[1][wave][32 * j + c] = s2; }
+        }
+    }
+    if (a.stats_part) {
+        __syncthreads();
+        for (int i = tid; i < 2 * NCOL; i += 256) {
+            const int which = i / NCOL, n = i - which * NCOL;
+            const int col = a.n0 + n;
+            if (col < a.n_out) {
+                const float s = s_red[which][0][n] + s_red[which][1][n] + s_red[which][2][n] + s_red[which][3][n];
+                a.stats_part[((size_t)blockIdx.x * 2 + which) * a.stats_ld + col] = s;
+            }
+        }
+    }
+}
+
+template <bool TRANS, bool BF>
+void launch_gemm16(GemmArgs a, hipStream_t s) {
+    const unsigned blocks = (unsigned)((a.m + GM_ROWS - 1) / GM_ROWS);
+    for (int n0 = 0; n0 < a.n_out; n0 += 256) {
+        a.n0 = n0;
+        const int tiles = (min(a.n_out - n0, 256) + 31) / 32;
+        if (tiles > 4) hipLaunchKernelGGL((vfn_linear_rows16_kernel<8, TRANS, BF>), dim3(blocks), dim3(256), 0, s, a);
+        else if (tiles > 2) hipLaunchKernelGGL((vfn_linear_rows16_kernel<4, TRANS, BF>), dim3(blocks), dim3(256), 0, s, a);
+        else if (tiles > 1) hipLaunchKernelGGL((vfn_linear_rows16_kernel<2, TRANS, BF>), dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((vfn_linear_rows16_kernel<1, TRANS, BF>), dim3(blocks), dim3(256), 0, s, a);
+    }
+}
+
 template <bool TRANS>
 void launch_gemm(GemmArgs a, hipStream_t s) {
     const unsigned blocks = (unsigned)((a.m + GM_ROWS - 1) / GM_ROWS);
@@ -350,14 +540,19 @@ extern "C" int vfn_linear_rows(int32_t transpose_w, const float* a, int32_t lda,
     const int k_pad = (k_in + 7) & ~7;
     VFN_REQUIRE((lda & 3) == 0 && lda >= k_pad && ((uintptr_t)a & 15) == 0,
                 "vfn_linear_rows: A needs 16-byte aligned rows with lda (%d) >= %d (k rounded up to 8; pad columns zero)", lda, k_pad);
-    VFN_REQUIRE(ldc >= n_out && ldw >= (transpose_w ? n_out : k_in), "vfn_linear_rows: ldc=%d ldw=%d too small", ldc, ldw);
-    VFN_REQUIRE((long long)(transpose_w ? k_in : n_out) * ldw * 4 < (1ll << 31), "vfn_linear_rows: W larger than 2 GiB");
+    VFN_REQUIRE(ldc >= n_out && ldw >= ((transpose_w & 1) ? n_out : k_in), "vfn_linear_rows: ldc=%d ldw=%d too small", ldc, ldw);
+    VFN_REQUIRE((long long)((transpose_w & 1) ? k_in : n_out) * ldw * 4 < (1ll << 31), "vfn_linear_rows: W larger than 2 GiB");
     if (m <= 0) return VFN_OK;
     GemmArgs g = {};
     g.a = a; g.w = w; g.bias = bias; g.c = c; g.stats_part = stats_part; g.m = m; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
     g.n_out = n_out; g.k_in = k_in; g.k_pad = k_pad; g.act = act; g.stats_ld = n_out;
-    if (transpose_w) launch_gemm<true>(g, (hipStream_t)stream);
-    else launch_gemm<false>(g, (hipStream_t)stream);
+    const int arith = transpose_w & 6;           // bit 1: split f16 (forward magnitudes), bit 2: split bf16 (any magnitude); neither: exact fp32
+    VFN_REQUIRE(arith != 6, "vfn_linear_rows: both split arithmetics requested");
+    hipStream_t s = (hipStream_t)stream;
+    if (arith == 2) { if (transpose_w & 1) launch_gemm16<true, false>(g, s); else launch_gemm16<false, false>(g, s); }
+    else if (arith == 4) { if (transpose_w & 1) launch_gemm16<true, true>(g, s); else launch_gemm16<false, true>(g, s); }
+    else if (transpose_w & 1) launch_gemm<true>(g, s);
+    else launch_gemm<false>(g, s);
     return vfn_check_launch("vfn_linear_rows");
 }
 
