@@ -744,7 +744,9 @@ int vfn_train_step(const vfn_train_step_params* p, const vfn_train_step_io* io, 
 /* (transpose_w is a bit field: bit 0 = the transposition below; bits 1-2 = the arithmetic — 0: exact fp32 (v_mfma_f32_32x32x2f32); 2: SPLIT
  *  f16, every operand as two f16 halves and a product as a_hi b_hi + a_hi b_lo + a_lo b_hi on v_mfma_f32_32x32x16_f16 with fp32
  *  accumulation, 22 significant bits, for forward GEMMs on normalised activations; 4: SPLIT bf16, the same with bf16 halves, 16 significant
- *  bits and fp32's exponent range, for backward GEMMs on gradients of any magnitude.  5.3x fewer matrix cycles than the exact form.)
+ *  bits and fp32's exponent range; 6: bf16 in THREE parts (hi | mid | lo = 24 bits), six products: fp32-equivalent at fp32's exponent
+ *  range, for backward GEMMs on gradients of any magnitude.  5.3x / 5.3x / 2.7x fewer matrix cycles than the exact form; A goes through LDS
+ *  in whole cache lines in these forms.)
  * transpose_w = 0: C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]), W = nn.Linear weight [n_out][ldw], k_in columns
  *                  (torch.nn.functional.linear); act 0 none / 1 tanh / 2 sigmoid.
  * transpose_w = 1: C[m][j] = sum_k A[m][k] W[k][j], W [k_in][ldw], j < n_out  (the input gradient dX = dZ W).

@@ -14,12 +14,13 @@ DEV = "cuda:0"
 
 @pytest.mark.parametrize("m,k,n", [(1, 39, 256), (130, 256, 217), (257, 256, 259), (1000, 289, 256), (77, 256, 3), (4096, 256, 256)])
 @pytest.mark.parametrize("transpose", [False, True])
-@pytest.mark.parametrize("arith", ["exact", "split_f16", "split_bf16"])
+@pytest.mark.parametrize("arith", ["exact", "split_f16", "split_bf16", "bf16x6"])
 def test_linear_rows_against_float64(m, k, n, transpose, arith):
     """C = tanh(A W^T + b) / C = A W on the matrix cores vs float64 on the CPU.  Exact fp32 instruction: 1e-6 of the largest |z|
     (products are exact fp32, the sums of k terms round in fp32).  Split f16 (three f16 products per product, 22 significant bits,
     what the forward GEMMs of the training-mode networks run on): the same 1e-6.  Split bf16 (16 significant bits with fp32's range,
-    the backward GEMMs): 3e-5 — and, scaled down by 1e-6 like a gradient, still 3e-5 of ITS largest entry (no underflow).
+    16 bits): 3e-5 — and, scaled down by 1e-6 like a gradient, still 3e-5 of ITS largest entry (no underflow).  bf16 in three parts (six
+    products, 24 bits: the backward GEMMs of the split mode): 1e-6 at any scale.
     Column sums of z and z^2 within 1e-5 / the arithmetic's own bound."""
     torch.manual_seed(m + k + n)
     kp, ldc = (k + 7) & ~7, (n + 7) & ~7
@@ -30,7 +31,7 @@ def test_linear_rows_against_float64(m, k, n, transpose, arith):
     c = torch.full((m, ldc), 7.0, device=DEV)
     parts = lib.linear_rows_stat_parts(m)
     part = torch.empty(parts, 2, n, device=DEV)
-    mode = {"exact": lib.GEMM_EXACT, "split_f16": lib.GEMM_SPLIT_F16, "split_bf16": lib.GEMM_SPLIT_BF16}[arith]
+    mode = {"exact": lib.GEMM_EXACT, "split_f16": lib.GEMM_SPLIT_F16, "split_bf16": lib.GEMM_SPLIT_BF16, "bf16x6": lib.GEMM_BF16X6}[arith]
     tol = 3e-5 if arith == "split_bf16" else 1e-6
     lib.linear_rows(a.to(DEV), w.to(DEV), None if b is None else b.to(DEV), m, n, k, c, act=lib.ACT_NONE if transpose else lib.ACT_TANH,
                     transpose_w=transpose, stats_part=part, arith=mode)
@@ -46,7 +47,7 @@ def test_linear_rows_against_float64(m, k, n, transpose, arith):
     s = sums.cpu().view(2, n)
     assert float((s[0] - z.sum(0)).abs().max()) <= max(1e-5, 10 * tol) * float(z.abs().sum(0).max())
     assert float((s[1] - (z * z).sum(0)).abs().max()) <= max(1e-5, 10 * tol) * float((z * z).sum(0).max())
-    if arith == "split_bf16" and transpose:          # gradient-sized operands: bf16 halves keep fp32's exponent range
+    if arith in ("split_bf16", "bf16x6") and transpose:          # gradient-sized operands: bf16 parts keep fp32's exponent range
         c2 = torch.zeros((m, ldc), device=DEV)
         lib.linear_rows((a * 1e-6).to(DEV), w.to(DEV), None, m, n, k, c2, transpose_w=True, arith=mode)
         assert float((c2.cpu()[:, :n].double() - 1e-6 * z).abs().max()) <= tol * 1e-6 * max(1.0, float(z.abs().max()))
@@ -148,11 +149,15 @@ def test_render_training_mode_against_reference():
             continue
         e = grad_rel_err(got, want)
         worst = max(worst, e)
-        assert e <= 2e-3, (net, key, e)
+        # (no masks pinned here: one ReLU unit of this 312-row batch on the other side of zero moves a layer's gradient by 0.3-1 %.  The
+        # exact fp32 GEMMs land at 1.7e-3 of the reference's gradients, the split ones — fp32-equivalent products, another rounding, other
+        # units on the edge — at 1e-2 on the skip layer's weight; the bound is the one test_hip_backward.py uses for <= 4 flipped units.  The
+        # comparison with THIS implementation's masks pinned (test_training_mode_gradients_against_oracle_all_parameters) holds both arithmetics to 2e-3)
+        assert e <= 2e-2, (net, key, e)
     for name, p in model.density.named_parameters():
         e = grad_rel_err(p.grad.cpu().reshape(1), d[f"grad.density.{name}"])
         worst = max(worst, e)
-        assert e <= 2e-3, (name, e)
+        assert e <= 2e-2, (name, e)
     print(f"train-mode gradients vs reference: worst rel err {worst:.2e}")
     for net, i in (("vf", 0), ("vf", 3), ("vf", 7), ("rn", 0), ("rn", 3)):
         bn = nets[net].layers[i][1]

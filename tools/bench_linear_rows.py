@@ -11,7 +11,8 @@ from vf_nerf_amd import lib  # noqa: E402
 
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 524288
 dev = "cuda:0"
-for arith_name, arith in (("exact fp32", lib.GEMM_EXACT), ("split f16", lib.GEMM_SPLIT_F16), ("split bf16", lib.GEMM_SPLIT_BF16)):
+for arith_name, arith in (("exact fp32", lib.GEMM_EXACT), ("split f16", lib.GEMM_SPLIT_F16), ("split bf16", lib.GEMM_SPLIT_BF16),
+                          ("bf16 in three parts (six products)", lib.GEMM_BF16X6)):
   print(f"--- {arith_name}")
   for name, k, n, trans, stats in (("fwd 256->256 + stats", 256, 256, False, True), ("fwd 256->256", 256, 256, False, False),
                                  ("dX 256<-256", 256, 256, True, False), ("fwd 40->256 + stats", 39, 256, False, True),

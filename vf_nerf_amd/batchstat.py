@@ -63,20 +63,20 @@ def _running_coef(bn) -> torch.Tensor:
 
 
 def _arith(net, backward: bool) -> int:
-    """Arithmetic of the layer GEMMs (csrc/vfn_bstat.hip): ``net.gemm_arithmetic`` = "fp32" (default: the exact fp32 matrix
-    instruction) or "split" (opt-in: three f16 products per product in the forward GEMMs — 22 significant bits, like the fused f16x3
-    kernels — and three bf16 products in the backward GEMMs dX = dZ W, whose operands have any magnitude: 16 bits, the fused dX
-    chain's split; the 256 x 256 weight gradients on the bf16 cores as well).  Measured (round 4, profiles/r04/linear_rows_microbench.txt):
-    the split GEMM runs 0.66 ms against 0.80-0.87 ms at M = 524 288 — 1.25x, not the 5x of its matrix cycles, because the kernel is
-    bound by how it fetches its A operand (32-byte pieces of rows 1 KiB apart), not by the matrix pipe — and the training-mode step
-    79 ms against 92 ms, while the bf16 backward moves the worst parameter gradient from 1.7e-3 to 2.5e-3 of the reference's.  Not
-    worth the default; the lever that is left is staging A through LDS with whole-line loads."""
-    mode = getattr(net, "gemm_arithmetic", "fp32")
+    """Arithmetic of the layer GEMMs (csrc/vfn_bstat.hip): ``net.gemm_arithmetic`` = "split" (default since round 4) or "fp32" (the exact
+    fp32 matrix instruction).  Split: the forward GEMMs on three f16 products per product (22 significant bits, like the fused f16x3
+    kernels), the backward GEMMs dX = dZ W — operands of any magnitude — on bf16 in THREE parts (six products, 24 bits at fp32's exponent
+    range), the full 256 x 256 weight gradients on the bf16 cores.  Both fp32-equivalent: the training-mode fixture's outputs stay inside
+    the same bounds (normals 7e-5, directional derivatives 7e-5), the gradients with pinned ReLU masks inside 2e-3.  Measured
+    (profiles/r04/linear_rows_microbench.txt): 0.43 ms (f16x3) / 0.53 ms (bf16x6) against 0.81-0.87 ms per 524 288 x 256 x 256 GEMM once the
+    A operand goes through LDS in whole cache lines (the first split kernel fetched 32-byte pieces of 1-KiB-strided rows and was bound by
+    that at 0.66 ms); the training-mode step 69 ms against 92 ms."""
+    mode = getattr(net, "gemm_arithmetic", "split")
     if mode == "fp32":
         return lib.GEMM_EXACT
     if mode != "split":
         raise ValueError(f"gemm_arithmetic must be 'split' or 'fp32', got {mode!r}")
-    return lib.GEMM_SPLIT_BF16 if backward else lib.GEMM_SPLIT_F16
+    return lib.GEMM_BF16X6 if backward else lib.GEMM_SPLIT_F16
 
 
 def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, update_running: bool = True,
@@ -159,7 +159,7 @@ class _ParamGrads:
         lin = self.net._linear(i)
         n, k = lin.out_features, lin.in_features
         dev, G, m = dz.device, self.G, self.m
-        split = getattr(self.net, "gemm_arithmetic", "fp32") == "split"
+        split = getattr(self.net, "gemm_arithmetic", "split") == "split"
         row_blocks = []
         if n % 256 != 0 and n % 256 <= 32 and n > 32:     # 259 = 3 + 256: rows 0..2 as the narrow head, the rest as one block
             row_blocks.append((0, n % 256, 2))

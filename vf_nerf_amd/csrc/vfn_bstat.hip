@@ -195,32 +195,48 @@ typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 constexpr int GM_LDH = 40;      // LDS row stride of a 16-bit W plane (elements): 80 bytes, 16-byte aligned
 
-template <bool BF>
-__device__ __forceinline__ void split2(float v, unsigned short& hi, unsigned short& lo) {
-    if constexpr (BF) {
+// ARITH: 0 = split f16 (3 products, 22 bits), 1 = split bf16 (3 products, 16 bits), 2 = bf16 in THREE parts (hi | mid | lo = 24 bits,
+// six products hh hm mh hl lh mm: fp32-equivalent at fp32's exponent range, 192 instead of 512 matrix cycles per K = 16)
+template <int ARITH>
+__device__ __forceinline__ void split3(float v, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+    if constexpr (ARITH == 0) {
+        const _Float16 h = (_Float16)v;
+        hi = __builtin_bit_cast(unsigned short, h);
+        mid = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)h));
+        lo = 0;
+    } else {
         const unsigned u = __builtin_bit_cast(unsigned, v);
         hi = (unsigned short)(u >> 16);
         const float r = v - __builtin_bit_cast(float, u & 0xffff0000u);
-        lo = __builtin_bit_cast(unsigned short, (__bf16)r);
-    } else {
-        const _Float16 h = (_Float16)v;
-        hi = __builtin_bit_cast(unsigned short, h);
-        lo = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)h));
+        if constexpr (ARITH == 1) {
+            mid = __builtin_bit_cast(unsigned short, (__bf16)r);
+            lo = 0;
+        } else {
+            const unsigned ur = __builtin_bit_cast(unsigned, r);
+            mid = (unsigned short)(ur >> 16);
+            lo = __builtin_bit_cast(unsigned short, (__bf16)(r - __builtin_bit_cast(float, ur & 0xffff0000u)));
+        }
     }
 }
 
-template <int NT, bool TRANS, bool BF>
+template <int NT, bool TRANS, int ARITH>
 __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short s_hi[NT * 32 * GM_LDH];
-    __shared__ __attribute__((aligned(16))) unsigned short s_lo[NT * 32 * GM_LDH];
-    __shared__ float s_red[2][4][NT * 32];
+    constexpr bool THREE = ARITH == 2;
+    constexpr int NCOL = NT * 32;
+    constexpr int A_LD = 36;                     // floats per staged A row (32 k + 4): conflict-free 16-byte fragment reads
+    __shared__ __attribute__((aligned(16))) unsigned short s_hi[NCOL * GM_LDH];
+    __shared__ __attribute__((aligned(16))) unsigned short s_mid[NCOL * GM_LDH];
+    __shared__ __attribute__((aligned(16))) unsigned short s_lo[THREE ? NCOL * GM_LDH : 8];
+    __shared__ __attribute__((aligned(16))) float s_a[GM_ROWS * A_LD];
+    // (the column-sum partials of the epilogue reuse the A tile: 8 KiB of its 18; with three weight planes two workgroups still fit a CU)
+    static_assert(2 * 4 * NCOL <= GM_ROWS * A_LD, "s_red must fit into the A tile");
+    float (*s_red)[4][NCOL] = reinterpret_cast<float (*)[4][NCOL]>(s_a);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, g = lane >> 5;
-    constexpr int NCOL = NT * 32;
     constexpr int PER = NCOL * 16 / 256;         // PAIRS of consecutive k each thread stages per chunk of 32 k
     constexpr unsigned OOB = 0x7fffffffu;
-    constexpr float A_SCALE = BF ? 1.0f : 64.0f;
+    constexpr float A_SCALE = ARITH == 0 ? 64.0f : 1.0f;
 
     const long long blk_row0 = (long long)blockIdx.x * GM_ROWS;
     const long long blk_rows = min((long long)GM_ROWS, a.m - blk_row0);
@@ -228,7 +244,6 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
         const_cast<float*>(a.a + (size_t)blk_row0 * a.lda), 0, (int)(blk_rows * a.lda * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.w), 0, (int)((long long)(TRANS ? a.k_in : a.n_out) * a.ldw * 4), 0x00020000);
-    const unsigned a_row_off = (unsigned)(32 * wave + c) * (unsigned)a.lda * 4u;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -236,8 +251,6 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    // pair e of the chunk -> (column n, first contraction index kk of the pair).  Plain: consecutive lanes walk k (coalesced 8-byte
-    // reads of W[n][k]).  Transposed: consecutive lanes walk n (coalesced rows of W[k][n]), two rows per pair.
     auto stage_index = [&](int e, int& n, int& kk) {
         if (!TRANS) { kk = 2 * (e & 15); n = e >> 4; }
         else { n = e % NCOL; kk = 2 * (e / NCOL); }
@@ -263,61 +276,79 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
         for (int r = 0; r < PER; ++r) {
             int n, kk;
             stage_index(tid + 256 * r, n, kk);
-            unsigned short h0, l0, h1, l1;
-            split2<BF>(wreg[r][0], h0, l0);
-            split2<BF>(wreg[r][1], h1, l1);
+            unsigned short h0, m0, l0, h1, m1, l1;
+            split3<ARITH>(wreg[r][0], h0, m0, l0);
+            split3<ARITH>(wreg[r][1], h1, m1, l1);
             *reinterpret_cast<unsigned*>(s_hi + n * GM_LDH + kk) = (unsigned)h0 | ((unsigned)h1 << 16);
-            *reinterpret_cast<unsigned*>(s_lo + n * GM_LDH + kk) = (unsigned)l0 | ((unsigned)l1 << 16);
+            *reinterpret_cast<unsigned*>(s_mid + n * GM_LDH + kk) = (unsigned)m0 | ((unsigned)m1 << 16);
+            if constexpr (THREE) *reinterpret_cast<unsigned*>(s_lo + n * GM_LDH + kk) = (unsigned)l0 | ((unsigned)l1 << 16);
         }
     };
+    // A: the workgroup's 128 rows x 32 k of a chunk through LDS.  Eight consecutive lanes fetch one row's 128 bytes (whole cache
+    // lines; 32 rows per pass, four passes), instead of every lane fetching 32-byte pieces of its own row 1 KiB from its
+    // neighbour's — that pattern, not the matrix pipe, bounded the first version of this kernel at 1.6 TB/s.
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    f32x4 av[2][2];          // [K step of 16][first / second group of four k of this lane's eight]
+    u32x4 areg[4];
+    const int a_r = tid >> 3, a_q = tid & 7;     // row within a pass, 16-byte piece of the row's chunk
     auto fetch_a = [&](int kc) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = 32 * ps + a_r, k = kc + 4 * a_q;
+            areg[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, k < a.k_pad ? ((unsigned)row * (unsigned)a.lda + (unsigned)k) * 4u : OOB, 0, 0);
+        }
+    };
+    auto stage_a = [&]() {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int k = kc + 16 * ks + 8 * g + 4 * q;
-                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs_a, k < a.k_pad ? a_row_off + (unsigned)k * 4u : OOB, 0, 0);
-                av[ks][q] = __builtin_bit_cast(f32x4, raw);
-            }
+        for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<u32x4*>(s_a + (32 * ps + a_r) * A_LD + 4 * a_q) = areg[ps];
     };
 
     fetch_w(0);
+    fetch_a(0);
     for (int kc = 0; kc < a.k_pad; kc += GM_KC) {
         __syncthreads();               // every wave is done with the previous chunk
         stage_w();
+        stage_a();
         __syncthreads();
-        fetch_a(kc);
-        if (kc + GM_KC < a.k_pad) fetch_w(kc + GM_KC);
+        if (kc + GM_KC < a.k_pad) { fetch_w(kc + GM_KC); fetch_a(kc + GM_KC); }       // in flight underneath this chunk's matrix work
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if (kc + 16 * ks >= a.k_pad) break;
-            u16x8 ah, al;
+            const float* ap = s_a + (32 * wave + c) * A_LD + 16 * ks + 8 * g;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
+            u16x8 ah, am, al;
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                unsigned short h, l;
-                split2<BF>(av[ks][t >> 2][t & 3] * A_SCALE, h, l);
-                ah[t] = h; al[t] = l;
+                unsigned short h, m, l;
+                split3<ARITH>((t < 4 ? a0[t & 3] : a1[t & 3]) * A_SCALE, h, m, l);
+                ah[t] = h; am[t] = m; al[t] = l;
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const u16x8 bh = *reinterpret_cast<const u16x8*>(s_hi + (32 * j + c) * GM_LDH + 16 * ks + 8 * g);
-                const u16x8 bl = *reinterpret_cast<const u16x8*>(s_lo + (32 * j + c) * GM_LDH + 16 * ks + 8 * g);
-                if constexpr (BF) {
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, ah), __builtin_bit_cast(b8, bh), acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, ah), __builtin_bit_cast(b8, bl), acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, al), __builtin_bit_cast(b8, bh), acc[j], 0, 0, 0);
-                } else {
+                const int o = (32 * j + c) * GM_LDH + 16 * ks + 8 * g;
+                const u16x8 bh = *reinterpret_cast<const u16x8*>(s_hi + o);
+                const u16x8 bm = *reinterpret_cast<const u16x8*>(s_mid + o);
+                if constexpr (ARITH == 0) {
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ah), __builtin_bit_cast(h8, bh), acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ah), __builtin_bit_cast(h8, bl), acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, al), __builtin_bit_cast(h8, bh), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, ah), __builtin_bit_cast(h8, bm), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, am), __builtin_bit_cast(h8, bh), acc[j], 0, 0, 0);
+                } else {
+                    // smallest terms first
+                    if constexpr (THREE) {
+                        const u16x8 bl = *reinterpret_cast<const u16x8*>(s_lo + o);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, am), __builtin_bit_cast(b8, bm), acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, ah), __builtin_bit_cast(b8, bl), acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, al), __builtin_bit_cast(b8, bh), acc[j], 0, 0, 0);
+                    }
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, ah), __builtin_bit_cast(b8, bm), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, am), __builtin_bit_cast(b8, bh), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, ah), __builtin_bit_cast(b8, bh), acc[j], 0, 0, 0);
                 }
             }
         }
     }
 
     // epilogue: D row = (r&3) + 8 (r>>2) + 4 g, col = c  (as the exact kernel; the f16 form undoes A's scale first)
+    if (a.stats_part) __syncthreads();          // every wave has read its last A fragments: the tile becomes s_red
     const long long row0 = (long long)blockIdx.x * GM_ROWS + 32 * wave;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -357,16 +388,16 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
     }
 }
 
-template <bool TRANS, bool BF>
+template <bool TRANS, int ARITH>
 void launch_gemm16(GemmArgs a, hipStream_t s) {
     const unsigned blocks = (unsigned)((a.m + GM_ROWS - 1) / GM_ROWS);
     for (int n0 = 0; n0 < a.n_out; n0 += 256) {
         a.n0 = n0;
         const int tiles = (min(a.n_out - n0, 256) + 31) / 32;
-        if (tiles > 4) hipLaunchKernelGGL((vfn_linear_rows16_kernel<8, TRANS, BF>), dim3(blocks), dim3(256), 0, s, a);
-        else if (tiles > 2) hipLaunchKernelGGL((vfn_linear_rows16_kernel<4, TRANS, BF>), dim3(blocks), dim3(256), 0, s, a);
-        else if (tiles > 1) hipLaunchKernelGGL((vfn_linear_rows16_kernel<2, TRANS, BF>), dim3(blocks), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((vfn_linear_rows16_kernel<1, TRANS, BF>), dim3(blocks), dim3(256), 0, s, a);
+        if (tiles > 4) hipLaunchKernelGGL((vfn_linear_rows16_kernel<8, TRANS, ARITH>), dim3(blocks), dim3(256), 0, s, a);
+        else if (tiles > 2) hipLaunchKernelGGL((vfn_linear_rows16_kernel<4, TRANS, ARITH>), dim3(blocks), dim3(256), 0, s, a);
+        else if (tiles > 1) hipLaunchKernelGGL((vfn_linear_rows16_kernel<2, TRANS, ARITH>), dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((vfn_linear_rows16_kernel<1, TRANS, ARITH>), dim3(blocks), dim3(256), 0, s, a);
     }
 }
 
@@ -546,12 +577,13 @@ extern "C" int vfn_linear_rows(int32_t transpose_w, const float* a, int32_t lda,
     GemmArgs g = {};
     g.a = a; g.w = w; g.bias = bias; g.c = c; g.stats_part = stats_part; g.m = m; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
     g.n_out = n_out; g.k_in = k_in; g.k_pad = k_pad; g.act = act; g.stats_ld = n_out;
-    const int arith = transpose_w & 6;           // bit 1: split f16 (forward magnitudes), bit 2: split bf16 (any magnitude); neither: exact fp32
-    VFN_REQUIRE(arith != 6, "vfn_linear_rows: both split arithmetics requested");
+    const int arith = transpose_w & 6;           // 2: split f16 (22 bits); 4: split bf16 (16 bits); 6: bf16 in three parts (24 bits); 0: exact fp32
     hipStream_t s = (hipStream_t)stream;
-    if (arith == 2) { if (transpose_w & 1) launch_gemm16<true, false>(g, s); else launch_gemm16<false, false>(g, s); }
-    else if (arith == 4) { if (transpose_w & 1) launch_gemm16<true, true>(g, s); else launch_gemm16<false, true>(g, s); }
-    else if (transpose_w & 1) launch_gemm<true>(g, s);
+    const bool tr = (transpose_w & 1) != 0;
+    if (arith == 2) { if (tr) launch_gemm16<true, 0>(g, s); else launch_gemm16<false, 0>(g, s); }
+    else if (arith == 4) { if (tr) launch_gemm16<true, 1>(g, s); else launch_gemm16<false, 1>(g, s); }
+    else if (arith == 6) { if (tr) launch_gemm16<true, 2>(g, s); else launch_gemm16<false, 2>(g, s); }
+    else if (tr) launch_gemm<true>(g, s);
     else launch_gemm<false>(g, s);
     return vfn_check_launch("vfn_linear_rows");
 }

@@ -1184,13 +1184,14 @@ def bstat_row_parts(m: int) -> int:
     return int(load().vfn_bstat_row_parts(m))
 
 
-GEMM_EXACT, GEMM_SPLIT_F16, GEMM_SPLIT_BF16 = 0, 2, 4      # arithmetic of vfn_linear_rows (bits 1-2 of its first argument)
+GEMM_EXACT, GEMM_SPLIT_F16, GEMM_SPLIT_BF16, GEMM_BF16X6 = 0, 2, 4, 6      # arithmetic of vfn_linear_rows (bits 1-2 of its first argument)
 
 
 def linear_rows(a, w: torch.Tensor, bias, m: int, n_out: int, k_in: int, c, act: int = ACT_NONE, transpose_w: bool = False,
                 stats_part=None, arith: int = GEMM_EXACT) -> None:
     """``arith``: GEMM_EXACT (fp32 matrix instruction), GEMM_SPLIT_F16 (three f16 products per product, 22 bits: forward GEMMs on
-    normalised activations) or GEMM_SPLIT_BF16 (three bf16 products, 16 bits with fp32's exponent range: backward GEMMs)."""
+    normalised activations), GEMM_SPLIT_BF16 (three bf16 products, 16 bits with fp32's exponent range) or GEMM_BF16X6 (operands in three
+    bf16 parts, six products: 24 bits at fp32's exponent range, fp32-equivalent — backward GEMMs on gradients of any magnitude)."""
     a, c = _cols(a), _cols(c)
     _check(load().vfn_linear_rows(C.c_int32(int(transpose_w) | int(arith)), a.ptr, C.c_int32(a.ld), _ptr(w, "w"), C.c_int32(w.shape[1]),
                                   _ptr(bias, "bias"), C.c_int64(m), C.c_int32(n_out), C.c_int32(k_in), C.c_int32(act), c.ptr,
