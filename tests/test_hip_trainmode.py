@@ -53,6 +53,46 @@ def test_linear_rows_against_float64(m, k, n, transpose, arith):
         assert float((c2.cpu()[:, :n].double() - 1e-6 * z).abs().max()) <= tol * 1e-6 * max(1.0, float(z.abs().max()))
 
 
+@pytest.mark.parametrize("m,k_out,n,n_prev", [(4096, 256, 256, 256), (4096, 259 + 5, 259, 256), (5000, 295, 256, 217), (4096, 256, 256, 217),
+                                              (130, 256, 256, 64), (1, 289, 256, 256)])
+def test_dx_product_with_the_batchnorm_backward_sums(m, k_out, n, n_prev):
+    """vfn_linear_rows_dx_sums: C = dZ W bit-identical to vfn_linear_rows (the same kernel body), and the two column sums of the previous
+    layer's BatchNorm backward, taken from C in registers, equal the pass of their own (vfn_bstat_relu_bwd_sums) and float64 within 1e-6
+    of the largest sum (fp32 partial sums of 128 / 64 rows, finished in double by both).  Shapes: a hidden layer, the last Linear
+    (259 outputs), the skip layer (295 inputs of which 217 come from the BatchNorm'ed layer), ragged row counts."""
+    torch.manual_seed(m + k_out + n_prev)
+    up8 = lambda v: (v + 7) & ~7
+    dz = torch.zeros(m, up8(n), device=DEV)
+    dz[:, :n] = torch.randn(m, n, device=DEV)
+    w = torch.randn(n, k_out, device=DEV) * 0.1
+    zp = torch.randn(m, up8(n_prev), device=DEV)
+    coef = torch.stack([torch.rand(n_prev, device=DEV) + 0.5, torch.randn(n_prev, device=DEV) * 0.3, torch.randn(n_prev, device=DEV) * 0.1,
+                        torch.rand(n_prev, device=DEV) + 0.5]).contiguous()
+    post = 0.7
+    g1 = torch.zeros(m, up8(k_out), device=DEV)
+    g2 = torch.zeros_like(g1)
+    lib.linear_rows(dz, w, None, m, k_out, n, g1, transpose_w=True, arith=lib.GEMM_BF16X6)
+    p1 = lib.bstat_row_parts(m)
+    part1 = torch.empty(p1, 2, n_prev, device=DEV)
+    lib.bstat_relu_bwd_sums(g1, zp, coef, m, n_prev, post, part1)
+    s1 = torch.empty(2, n_prev, dtype=torch.float64, device=DEV)
+    lib.colsum_finish(part1, p1, 2 * n_prev, s1)
+    p2 = lib.linear_rows_stat_parts(m)
+    part2 = torch.empty(p2, 2, n_prev, device=DEV)
+    lib.linear_rows_dx_sums(dz, w, m, k_out, n, g2, zp, coef, n_prev, post, part2)
+    s2 = torch.empty(2, n_prev, dtype=torch.float64, device=DEV)
+    lib.colsum_finish(part2, p2, 2 * n_prev, s2)
+    assert torch.equal(g1, g2)
+    gd, zd, c = g1[:, :n_prev].double(), zp[:, :n_prev].double(), coef.double()
+    mask = torch.addcmul(coef[1], zp[:, :n_prev], coef[0]) > 0          # (fp32, like the kernels; ties at exactly 0 have measure zero here)
+    gp = torch.where(mask, post * gd, torch.zeros_like(gd))
+    want = torch.stack([gp.sum(0), (gp * ((zd - c[2]) * c[3])).sum(0)])
+    scale = float(want.abs().max())
+    e_fused, e_pass = float((s2 - want).abs().max()) / scale, float((s1 - want).abs().max()) / scale
+    print(f"column sums vs float64: fused {e_fused:.2e}, pass of its own {e_pass:.2e}")
+    assert e_fused <= 1e-6 and e_pass <= 1e-6
+
+
 def test_embed_rows_and_its_derivative():
     """Positional encoding rows (and the scaled copy the skip layer reads) bit-match the oracle's; the backward is the
     analytic derivative (checked against float64 autograd, 1e-5 of the largest entry)."""

@@ -18,6 +18,7 @@ one with ``create_graph=True`` but never differentiates it: render() uses them u
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -26,6 +27,8 @@ from . import lib
 from .lib import Cols
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+# the BatchNorm backward's column sums from the dX product's registers (VFN_FUSE_BN_SUMS=0: the pass of its own, for A/B runs)
+FUSE_BACKWARD_SUMS = os.environ.get("VFN_FUSE_BN_SUMS", "1") != "0"
 INV_SQRT2 = 1.0 / math.sqrt(2.0)
 
 
@@ -235,18 +238,26 @@ def _backward(net, st: _State, dz_last: torch.Tensor, pg: Optional[_ParamGrads],
         if i == 0 and not want_dx0:
             return None, skip_piece
         g = torch.zeros(m, _up8(k), device=dev) if k % 8 else torch.empty(m, _up8(k), device=dev)
-        lib.linear_rows(dz, lin.weight.detach(), None, m, k, n, g, transpose_w=True, arith=_arith(net, True))      # dX = dZ W
         if i == 0:
+            lib.linear_rows(dz, lin.weight.detach(), None, m, k, n, g, transpose_w=True, arith=_arith(net, True))      # dX = dZ W
             return g, skip_piece
         # BatchNorm + ReLU of layer i-1, whose (scaled) output is columns [0, n_prev) of x[i]
         n_prev = net._linear(i - 1).out_features
         post = INV_SQRT2 if i == skip else 1.0
+        z, coef = st.z[i - 1], st.coef[i - 1]
+        if FUSE_BACKWARD_SUMS and _arith(net, True) == lib.GEMM_BF16X6 and n_prev <= 256:
+            # dX = dZ W and, from the product while it is in registers, the two column sums of the BatchNorm backward (the separate pass
+            # over g and z that computed them was 16 % of a training-mode step)
+            parts = lib.linear_rows_stat_parts(m)
+            part = torch.empty(parts, 2, n_prev, device=dev)
+            lib.linear_rows_dx_sums(dz, lin.weight.detach(), m, k, n, g, z, coef, n_prev, post, part)
+        else:
+            lib.linear_rows(dz, lin.weight.detach(), None, m, k, n, g, transpose_w=True, arith=_arith(net, True))
+            parts = lib.bstat_row_parts(m)
+            part = torch.empty(parts, 2, n_prev, device=dev)
+            lib.bstat_relu_bwd_sums(g, z, coef, m, n_prev, post, part)
         if i == skip:
             skip_piece = (Cols(g, n_prev), INV_SQRT2)
-        parts = lib.bstat_row_parts(m)
-        part = torch.empty(parts, 2, n_prev, device=dev)
-        z, coef = st.z[i - 1], st.coef[i - 1]
-        lib.bstat_relu_bwd_sums(g, z, coef, m, n_prev, post, part)
         sums = torch.empty(2, n_prev, dtype=torch.float64, device=dev)
         lib.colsum_finish(part, parts, 2 * n_prev, sums)
         if pg is not None:

@@ -43,6 +43,11 @@ struct GemmArgs {
     int n0;         // first output column of this launch
     int act;
     int stats_ld;   // = n_out
+    // vfn_linear_rows_dx_sums (the split kernels with SUMS): stats_part = per-block partials of the NEXT BatchNorm backward's two column sums
+    // over the first stats_ld columns of C, from that layer's pre-BatchNorm outputs zp and coefficients coef_p [4][stats_ld]
+    const float* zp; const float* coef_p;
+    int ldzp;
+    float post_p;
 };
 
 // TRANS = false: B(k, n) = W[n][k]  (nn.Linear weight, C = A W^T);  TRANS = true: B(k, n) = W[k][n]  (C = A W).
@@ -219,7 +224,10 @@ __device__ __forceinline__ void split3(float v, unsigned short& hi, unsigned sho
     }
 }
 
-template <int NT, bool TRANS, int ARITH>
+// SUMS (vfn_linear_rows_dx_sums): C is the gradient wrt the previous layer's activated output; the per-block partials of sum g' and
+// sum g' x_hat of that layer's BatchNorm backward (g' = post g [z scale + shift > 0], x_hat = (z - mean) rstd) are taken from C while it is
+// in registers — what vfn_bstat_relu_bwd_sums computes in a pass of its own over g and z (2.3 TB/s, 16 % of a training-mode step).
+template <int NT, bool TRANS, int ARITH, bool SUMS = false>
 __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArgs a) {
     constexpr bool THREE = ARITH == 2;
     constexpr int NCOL = NT * 32;
@@ -350,12 +358,54 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
     // epilogue: D row = (r&3) + 8 (r>>2) + 4 g, col = c  (as the exact kernel; the f16 form undoes A's scale first)
     if (a.stats_part) __syncthreads();          // every wave has read its last A fragments: the tile becomes s_red
     const long long row0 = (long long)blockIdx.x * GM_ROWS + 32 * wave;
+    [[maybe_unused]] const int live = (int)min((long long)32, a.m - row0);            // rows of this wave inside the matrix
+    [[maybe_unused]] float znext[16];
+    [[maybe_unused]] auto fetch_z = [&](int j) {     // the previous layer's pre-BatchNorm outputs under tile j of C (the accumulators' rows)
+        const int col = a.n0 + 32 * j + c;
+        const float* zp0 = a.zp + (size_t)row0 * a.ldzp + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = (r & 3) + 8 * (r >> 2) + 4 * g;
+            znext[r] = (lr < live && col < a.stats_ld) ? zp0[lr * a.ldzp] : 0.f;
+        }
+    };
+    if constexpr (SUMS) {
+        if (a.stats_part) fetch_z(0);
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int col = a.n0 + 32 * j + c;
         const bool col_ok = col < a.n_out;
         const float b = (a.bias && col_ok) ? a.bias[col] : 0.f;
         float s1 = 0.f, s2 = 0.f;
+        if constexpr (SUMS) {
+            if (a.stats_part) {
+                // (tile j's z values are fetched while tile j - 1 is summed: see the loop head below)
+                const bool st_ok = col < a.stats_ld;
+                const float sc = st_ok ? a.coef_p[col] : 0.f, sh = st_ok ? a.coef_p[a.stats_ld + col] : 0.f;
+                const float mean = st_ok ? a.coef_p[2 * a.stats_ld + col] : 0.f, rstd = st_ok ? a.coef_p[3 * a.stats_ld + col] : 0.f;
+                float* c0 = a.c + (size_t)row0 * a.ldc + col;
+                float zq[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zq[r] = znext[r];
+                if (j + 1 < NT) fetch_z(j + 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = (r & 3) + 8 * (r >> 2) + 4 * g;
+                    const float v = acc[j][r] * (1.0f / A_SCALE);
+                    if (lr < live && col_ok) c0[lr * a.ldc] = v;
+                    if (lr < live && st_ok) {
+                        const float g1 = fmaf(zq[r], sc, sh) > 0.f ? a.post_p * v : 0.f;
+                        s1 += g1;
+                        s2 += g1 * ((zq[r] - mean) * rstd);
+                    }
+                }
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (g == 0) { s_red[0][wave][32 * j + c] = s1; s_red[1][wave][32 * j + c] = s2; }
+                continue;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * g;
@@ -380,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
         for (int i = tid; i < 2 * NCOL; i += 256) {
             const int which = i / NCOL, n = i - which * NCOL;
             const int col = a.n0 + n;
-            if (col < a.n_out) {
+            if (col < a.stats_ld) {          // (= n_out, or the summed layer's width in the SUMS form)
                 const float s = s_red[which][0][n] + s_red[which][1][n] + s_red[which][2][n] + s_red[which][3][n];
                 a.stats_part[((size_t)blockIdx.x * 2 + which) * a.stats_ld + col] = s;
             }
@@ -388,16 +438,18 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
     }
 }
 
-template <bool TRANS, int ARITH>
+template <bool TRANS, int ARITH, bool SUMS = false>
 void launch_gemm16(GemmArgs a, hipStream_t s) {
     const unsigned blocks = (unsigned)((a.m + GM_ROWS - 1) / GM_ROWS);
+    float* const stats = a.stats_part;
     for (int n0 = 0; n0 < a.n_out; n0 += 256) {
         a.n0 = n0;
+        if (SUMS) a.stats_part = n0 == 0 ? stats : nullptr;      // the summed columns (<= 256) all sit in the first launch
         const int tiles = (min(a.n_out - n0, 256) + 31) / 32;
-        if (tiles > 4) hipLaunchKernelGGL((vfn_linear_rows16_kernel<8, TRANS, ARITH>), dim3(blocks), dim3(256), 0, s, a);
-        else if (tiles > 2) hipLaunchKernelGGL((vfn_linear_rows16_kernel<4, TRANS, ARITH>), dim3(blocks), dim3(256), 0, s, a);
-        else if (tiles > 1) hipLaunchKernelGGL((vfn_linear_rows16_kernel<2, TRANS, ARITH>), dim3(blocks), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((vfn_linear_rows16_kernel<1, TRANS, ARITH>), dim3(blocks), dim3(256), 0, s, a);
+        if (tiles > 4) hipLaunchKernelGGL((vfn_linear_rows16_kernel<8, TRANS, ARITH, SUMS>), dim3(blocks), dim3(256), 0, s, a);
+        else if (tiles > 2) hipLaunchKernelGGL((vfn_linear_rows16_kernel<4, TRANS, ARITH, SUMS>), dim3(blocks), dim3(256), 0, s, a);
+        else if (tiles > 1) hipLaunchKernelGGL((vfn_linear_rows16_kernel<2, TRANS, ARITH, SUMS>), dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((vfn_linear_rows16_kernel<1, TRANS, ARITH, SUMS>), dim3(blocks), dim3(256), 0, s, a);
     }
 }
 
@@ -456,6 +508,50 @@ __global__ void vfn_bstat_finalize_kernel(const double* sums, long long m, int n
 // row-wise kernels: one thread per column (consecutive lanes = consecutive columns), EW_ROWS rows per workgroup
 // ------------------------------------------------------------------------------------------------
 constexpr int EW_ROWS = 64;
+
+// 16-byte form of the two passes that only map rows (n a multiple of 4, 16-byte aligned rows): a lane owns four consecutive columns, the
+// lanes of a workgroup cover 1024 / n... rows at a time; every access is a whole b128 (the one-column-per-thread forms reach 3.3-4 TB/s)
+__global__ __launch_bounds__(256) void vfn_bstat_relu_rows4_kernel(const float* z, int ldz, const float* coef, long long m, int n,
+                                                                    float post, float* h, int ldh) {
+    const int q = n >> 2;                                   // 16-byte pieces per row
+    const long long r0 = (long long)blockIdx.x * EW_ROWS, r1 = min(m, r0 + EW_ROWS);
+    const int piece = threadIdx.x % q, rsub = threadIdx.x / q, rstep = 256 / q;
+    if (rsub >= rstep) return;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(coef + 4 * piece), sh = *reinterpret_cast<const f32x4*>(coef + n + 4 * piece);
+    for (long long r = r0 + rsub; r < r1; r += rstep) {
+        const f32x4 zv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + (size_t)r * ldz + 4 * piece));
+        f32x4 o;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = post * fmaxf(fmaf(zv[t], sc[t], sh[t]), 0.f);
+        *reinterpret_cast<f32x4*>(h + (size_t)r * ldh + 4 * piece) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void vfn_bstat_relu_bwd_rows4_kernel(const float* gr, int ldg, const float* z, int ldz, const float* coef,
+                                                                        const double* sums, long long m, int n, float post, float* dz,
+                                                                        int lddz) {
+    const int q = n >> 2;
+    const long long r0 = (long long)blockIdx.x * EW_ROWS, r1 = min(m, r0 + EW_ROWS);
+    const int piece = threadIdx.x % q, rsub = threadIdx.x / q, rstep = 256 / q;
+    if (rsub >= rstep) return;
+    const int c0 = 4 * piece;
+    const f32x4 scale = *reinterpret_cast<const f32x4*>(coef + c0), sh = *reinterpret_cast<const f32x4*>(coef + n + c0);
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(coef + 2 * n + c0), rstd = *reinterpret_cast<const f32x4*>(coef + 3 * n + c0);
+    f32x4 ga, gb;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { ga[t] = (float)(sums[c0 + t] / (double)m); gb[t] = (float)(sums[n + c0 + t] / (double)m); }
+    for (long long r = r0 + rsub; r < r1; r += rstep) {
+        const f32x4 zv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + (size_t)r * ldz + c0));
+        const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gr + (size_t)r * ldg + c0));
+        f32x4 o;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float g1 = fmaf(zv[t], scale[t], sh[t]) > 0.f ? post * gv[t] : 0.f;
+            o[t] = scale[t] * (g1 - ga[t] - (zv[t] - mean[t]) * rstd[t] * gb[t]);
+        }
+        *reinterpret_cast<f32x4*>(dz + (size_t)r * lddz + c0) = o;
+    }
+}
 
 __global__ __launch_bounds__(256) void vfn_bstat_relu_rows_kernel(const float* z, int ldz, const float* coef, long long m, int n,
                                                                    float post, float* h, int ldh) {
@@ -560,6 +656,8 @@ __global__ __launch_bounds__(256) void vfn_embed_rows_bwd_kernel(const float* sr
 }
 
 inline unsigned ew_blocks(long long m) { return (unsigned)((m + EW_ROWS - 1) / EW_ROWS); }
+// rows of `ld` floats from a 16-byte aligned base, every row 16-byte aligned (the b128 forms of the row passes)
+inline bool rows16(const void* p, int ld) { return ((uintptr_t)p & 15) == 0 && (ld & 3) == 0; }
 
 }  // namespace
 
@@ -588,6 +686,27 @@ extern "C" int vfn_linear_rows(int32_t transpose_w, const float* a, int32_t lda,
     return vfn_check_launch("vfn_linear_rows");
 }
 
+extern "C" int vfn_linear_rows_dx_sums(const float* dz, int32_t lddz, const float* w, int32_t ldw, int64_t m, int32_t n_out, int32_t k_in, float* c,
+                                       int32_t ldc, const float* z_prev, int32_t ldz_prev, const float* coef_prev, int32_t n_prev, float post_prev,
+                                       float* sums_part, void* stream) {
+    VFN_REQUIRE(dz && w && c && z_prev && coef_prev && sums_part, "vfn_linear_rows_dx_sums: NULL argument");
+    VFN_REQUIRE(n_out >= 1 && k_in >= 1, "vfn_linear_rows_dx_sums: n_out=%d k_in=%d", n_out, k_in);
+    const int k_pad = (k_in + 7) & ~7;
+    VFN_REQUIRE((lddz & 3) == 0 && lddz >= k_pad && ((uintptr_t)dz & 15) == 0,
+                "vfn_linear_rows_dx_sums: dz needs 16-byte aligned rows with lddz (%d) >= %d (k rounded up to 8; pad columns zero)", lddz, k_pad);
+    VFN_REQUIRE(ldc >= n_out && ldw >= n_out, "vfn_linear_rows_dx_sums: ldc=%d ldw=%d too small", ldc, ldw);
+    VFN_REQUIRE((long long)k_in * ldw * 4 < (1ll << 31), "vfn_linear_rows_dx_sums: W larger than 2 GiB");
+    VFN_REQUIRE(n_prev >= 1 && n_prev <= n_out && n_prev <= 256 && ldz_prev >= n_prev,
+                "vfn_linear_rows_dx_sums: the summed columns are the first n_prev (%d) <= min(n_out, 256) of C", n_prev);
+    if (m <= 0) return VFN_OK;
+    GemmArgs g = {};
+    g.a = dz; g.w = w; g.c = c; g.m = m; g.lda = lddz; g.ldw = ldw; g.ldc = ldc;
+    g.n_out = n_out; g.k_in = k_in; g.k_pad = k_pad; g.act = ACT_NONE;
+    g.stats_part = sums_part; g.stats_ld = n_prev; g.zp = z_prev; g.ldzp = ldz_prev; g.coef_p = coef_prev; g.post_p = post_prev;
+    launch_gemm16<true, 2, true>(g, (hipStream_t)stream);
+    return vfn_check_launch("vfn_linear_rows_dx_sums");
+}
+
 extern "C" int64_t vfn_linear_rows_stat_parts(int64_t m) { return m <= 0 ? 0 : (m + GM_ROWS - 1) / GM_ROWS; }
 extern "C" int64_t vfn_bstat_row_parts(int64_t m) { return m <= 0 ? 0 : (m + EW_ROWS - 1) / EW_ROWS; }
 
@@ -609,8 +728,12 @@ extern "C" int vfn_bstat_relu_rows(const float* z, int32_t ldz, const float* coe
                                    int32_t ldh, void* stream) {
     VFN_REQUIRE(z && coef && h && n >= 1 && ldz >= n && ldh >= n, "vfn_bstat_relu_rows: bad argument");
     if (m <= 0) return VFN_OK;
-    hipLaunchKernelGGL(vfn_bstat_relu_rows_kernel, dim3(ew_blocks(m)), dim3(256), 0, (hipStream_t)stream, z, ldz, coef, (long long)m, n,
-                       post_scale, h, ldh);
+    if (rows16(z, ldz) && rows16(h, ldh) && rows16(coef, n) && n <= 1024)
+        hipLaunchKernelGGL(vfn_bstat_relu_rows4_kernel, dim3(ew_blocks(m)), dim3(256), 0, (hipStream_t)stream, z, ldz, coef, (long long)m, n,
+                           post_scale, h, ldh);
+    else
+        hipLaunchKernelGGL(vfn_bstat_relu_rows_kernel, dim3(ew_blocks(m)), dim3(256), 0, (hipStream_t)stream, z, ldz, coef, (long long)m, n,
+                           post_scale, h, ldh);
     return vfn_check_launch("vfn_bstat_relu_rows");
 }
 
@@ -627,8 +750,12 @@ extern "C" int vfn_bstat_relu_bwd_rows(const float* g, int32_t ldg, const float*
                                        int64_t m, int32_t n, float post_scale, float* dz, int32_t lddz, void* stream) {
     VFN_REQUIRE(g && z && coef && sums && dz && n >= 1, "vfn_bstat_relu_bwd_rows: bad argument");
     if (m <= 0) return VFN_OK;
-    hipLaunchKernelGGL(vfn_bstat_relu_bwd_rows_kernel, dim3(ew_blocks(m)), dim3(256), 0, (hipStream_t)stream, g, ldg, z, ldz,
-                       coef, sums, (long long)m, n, post_scale, dz, lddz);
+    if (rows16(g, ldg) && rows16(z, ldz) && rows16(dz, lddz) && rows16(coef, n) && n <= 1024)
+        hipLaunchKernelGGL(vfn_bstat_relu_bwd_rows4_kernel, dim3(ew_blocks(m)), dim3(256), 0, (hipStream_t)stream, g, ldg, z, ldz,
+                           coef, sums, (long long)m, n, post_scale, dz, lddz);
+    else
+        hipLaunchKernelGGL(vfn_bstat_relu_bwd_rows_kernel, dim3(ew_blocks(m)), dim3(256), 0, (hipStream_t)stream, g, ldg, z, ldz,
+                           coef, sums, (long long)m, n, post_scale, dz, lddz);
     return vfn_check_launch("vfn_bstat_relu_bwd_rows");
 }
 

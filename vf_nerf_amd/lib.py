@@ -35,6 +35,7 @@ EXPORTS = (
     "vfn_weight_grad_groups", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax", "vfn_merge_sort_depths",
     "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_f16x3_set_clock_probe", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step", "vfn_unfold_weight_grads_acc", "vfn_render_fwd", "vfn_render_fwd_workspace_bytes",
     "vfn_vf_loss_workspace_bytes", "vfn_vf_loss_fwd", "vfn_vf_loss_bwd", "vfn_train_step", "vfn_train_step_workspace_bytes",
+    "vfn_linear_rows_dx_sums",
 )
 
 
@@ -1196,6 +1197,16 @@ def linear_rows(a, w: torch.Tensor, bias, m: int, n_out: int, k_in: int, c, act:
     _check(load().vfn_linear_rows(C.c_int32(int(transpose_w) | int(arith)), a.ptr, C.c_int32(a.ld), _ptr(w, "w"), C.c_int32(w.shape[1]),
                                   _ptr(bias, "bias"), C.c_int64(m), C.c_int32(n_out), C.c_int32(k_in), C.c_int32(act), c.ptr,
                                   C.c_int32(c.ld), _ptr(stats_part, "stats_part"), _stream()), "vfn_linear_rows")
+
+
+def linear_rows_dx_sums(dz, w: torch.Tensor, m: int, n_out: int, k_in: int, c, z_prev, coef_prev: torch.Tensor, n_prev: int, post_prev: float,
+                        part: torch.Tensor) -> None:
+    """C = dZ W (bf16 in three parts) + the per-workgroup partials of the previous layer's BatchNorm-backward column sums, taken from C
+    in registers (include/vfn.h, vfn_linear_rows_dx_sums); ``part`` [linear_rows_stat_parts(m), 2, n_prev]."""
+    dz, c, z_prev = _cols(dz), _cols(c), _cols(z_prev)
+    _check(load().vfn_linear_rows_dx_sums(dz.ptr, C.c_int32(dz.ld), _ptr(w, "w"), C.c_int32(w.shape[1]), C.c_int64(m), C.c_int32(n_out),
+                                          C.c_int32(k_in), c.ptr, C.c_int32(c.ld), z_prev.ptr, C.c_int32(z_prev.ld), _ptr(coef_prev, "coef_prev"),
+                                          C.c_int32(n_prev), C.c_float(post_prev), _ptr(part, "part"), _stream()), "vfn_linear_rows_dx_sums")
 
 
 def colsum_finish(part: torch.Tensor, n_parts: int, width: int, sums: torch.Tensor) -> None:

@@ -252,7 +252,8 @@ class OneCallStep:
             views.append(flat[o:o + k])
             o += k
         ray_dirs, z, pts, normals, colors, weights, rgb, depth, out_terms, out_norm = views
-        io.uv, io.pose, io.intrinsics = _p(pixels.float().contiguous()), _p(pose), _p(intrinsics)
+        uv = pixels.float().contiguous()
+        io.uv, io.pose, io.intrinsics = _p(uv), _p(pose), _p(intrinsics)
         io.t_vals = _p(model._linspace(s_c, dev))
         io.far_coarse_per_ray, io.far_fine_per_ray = _p(far_ct), _p(far_ft)
         io.u_coarse, io.u_fine, io.u_add = _p(u_c), _p(u_f), _p(u_a)
@@ -262,7 +263,7 @@ class OneCallStep:
         io.ray_dirs, io.z_vals, io.points, io.normals, io.colors, io.weights, io.rgb, io.depth = (_p(t) for t in views[:8])
         io.out_terms, io.out_norm = _p(out_terms), _p(out_norm)
         io.out_counts = out_norm.data_ptr() + 8           # [2:4] of the same little tensor: samples the colour branch ran on, all samples
-        keep_alive = (pixels, pose, intrinsics, u_c, u_f, u_a, replay, rgb_gt, depth_gt, far_ct, far_ft)     # until the call has been issued
+        keep_alive = (uv, pose, intrinsics, u_c, u_f, u_a, replay, rgb_gt, depth_gt, far_ct, far_ft)     # until the call has been issued
 
         # ---- the call(s) --------------------------------------------------------------------------------------------------------------
         guard = model.range_guard
