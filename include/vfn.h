@@ -364,6 +364,10 @@ int vfn_f16x3_set_clock_probe(uint64_t* stamps, int64_t slots);
  * (`groups` slabs [groups][256][256] and [groups][256]).  ~2^-16 relative error per product under the sum over points. */
 int vfn_weight_grad_partials_bf16(const float* dy, const float* x, int64_t n_points, int32_t groups, float* dw_part,
                                   float* db_part, int32_t x_f16, void* stream);
+/* The same over 256 columns of wider matrices: rows ld_dy / ld_x floats apart (>= 256, multiples of 4, 16-byte aligned bases) — a
+ * 256-column block of the rendering net's 289-wide input or of the vector-field net's 259-wide output gradient (batchstat.py). */
+int vfn_weight_grad_partials_bf16_ld(const float* dy, int32_t ld_dy, const float* x, int32_t ld_x, int64_t n_points, int32_t groups,
+                                     float* dw_part, float* db_part, int32_t x_f16, void* stream);
 
 /* vfn_mlp_bwd_chain on the bf16 matrix cores (split operands, three products per K-block, fp32 accumulation; shipped layer
  * shapes only, others return VFN_ERR_UNSUPPORTED).  Takes its own TRANSPOSED bf16 packs (vfn_pack_weights_bwd16; re-run

@@ -164,7 +164,12 @@ class _ParamGrads:
         dev, G, m = dz.device, self.G, self.m
         split = getattr(self.net, "gemm_arithmetic", "split") == "split"
         row_blocks = []
-        if n % 256 != 0 and n % 256 <= 32 and n > 32:     # 259 = 3 + 256: rows 0..2 as the narrow head, the rest as one block
+        if n % 256 != 0 and n % 256 <= 32 and n > 32 and split:
+            # 259 = 256 + 3: any partition of the rows is valid; this one keeps the wide block at column 0 of dZ (16-byte aligned rows: the
+            # bf16 product), the last three rows go through the narrow-head shape
+            row_blocks += [(r, 256, 0) for r in range(0, n - n % 256, 256)]
+            row_blocks.append((n - n % 256, n % 256, 2))
+        elif n % 256 != 0 and n % 256 <= 32 and n > 32:   # 259 = 3 + 256: rows 0..2 as the narrow head, the rest as one block
             row_blocks.append((0, n % 256, 2))
             row_blocks += [(r, 256, 0) for r in range(n % 256, n, 256)]
         elif n <= 32:
@@ -176,6 +181,8 @@ class _ParamGrads:
             col_blocks = [("aux", 0, k)]
         elif k == 256:
             col_blocks = [("act", 0, 256)]
+        elif 256 < k <= 320 and split:
+            col_blocks = [("act", 0, 256), ("aux", 256, k - 256)]          # (any partition of the columns is valid: the aligned one)
         elif 256 < k <= 320:
             col_blocks = [("aux", 0, k - 256), ("act", k - 256, 256)]      # rendering net: [p, PE(d), n | 256 features]
         else:
@@ -197,10 +204,13 @@ class _ParamGrads:
                     u.update(dw_act=part, act_c0=c0, act_nc=nc)
                 elif kind == "act":
                     part = torch.empty(G, 256, 256, device=dev)
-                    if split and rows == 256 and nc == 256 and r0 == 0 and c0 == 0 and dzv.ld == 256 and xv.ld == 256:
-                        # a full 256 x 256 product of two dense [M,256] matrices: the bf16 matrix cores (three products on split operands,
-                        # csrc/vfn_dw16.hip — what the fused path's row-major backward uses), 4x the fp32 matrix instruction's rate
-                        lib.weight_grad_partials_bf16(dz, x, m, G, part, db_part if first else None)
+                    # 256 columns of dZ from r0 on: all valid, or the last block of a layer whose dZ was allocated 256 wide with zero pad
+                    # columns (`_backward`: 217 outputs in front of the skip layer)
+                    dz_ok = r0 % 4 == 0 and r0 + 256 <= dzv.ld and (rows == 256 or r0 + rows == n)
+                    if split and dz_ok and nc == 256 and c0 % 4 == 0 and c0 + 256 <= xv.ld:
+                        # a 256 x 256 product over whole 16-byte pieces of both matrices' rows: the bf16 matrix cores (three products on split
+                        # operands, csrc/vfn_dw16.hip — what the fused path's row-major backward uses), 4x the fp32 matrix instruction's rate
+                        lib.weight_grad_partials_bf16_cols(dzv, xv, m, G, part, db_part if first else None)
                     else:
                         lib.weight_grad_partials(0, dzv, dzv.ld, rows, xv, xv.ld, nc, m, G, part, db_part if first else None)
                     u.update(dw_act=part, act_c0=c0, act_nc=nc)
@@ -262,7 +272,10 @@ def _backward(net, st: _State, dz_last: torch.Tensor, pg: Optional[_ParamGrads],
         lib.colsum_finish(part, parts, 2 * n_prev, sums)
         if pg is not None:
             pg.batchnorm(i - 1, sums)
-        dz = torch.zeros(m, _up8(n_prev), device=dev) if n_prev % 8 else torch.empty(m, _up8(n_prev), device=dev)
+        if 192 < n_prev < 256 and getattr(net, "gemm_arithmetic", "split") == "split":
+            dz = torch.zeros(m, 256, device=dev)          # (zero pad columns up to 256: the bf16 weight-gradient product reads whole blocks)
+        else:
+            dz = torch.zeros(m, _up8(n_prev), device=dev) if n_prev % 8 else torch.empty(m, _up8(n_prev), device=dev)
         # batch statistics: dz = gamma rstd (g' - mean g' - x_hat mean(g' x_hat)); running statistics: dz = gamma rstd g'
         lib.bstat_relu_bwd_rows(g, z, coef, sums if st.batch_stats else torch.zeros_like(sums), m, n_prev, post, dz)
     raise AssertionError("unreachable")

@@ -46,6 +46,7 @@ struct Dw16Args {
     float* dw_part;       // [G][256][256]
     float* db_part;       // [G][256] or NULL
     long long n_points;
+    int ld_dy, ld_x;      // floats between rows (>= 256, multiples of 4: whole 16-byte pieces); 256 for the dense matrices
 };
 
 typedef __attribute__((address_space(3))) s4 lds_s4;
@@ -95,22 +96,23 @@ __global__ __launch_bounds__(256, 1) void vfn_dw16_kernel(const Dw16Args a) {
     // slab-relative descriptors: rows past the end of the batch read as zero
     const long long r_base = s0 * DW_STEP;
     const long long rows_slab = max(0LL, min((s1 - s0) * DW_STEP, a.n_points - r_base));
-    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + (size_t)r_base * 256), 0,
-                                                                           (int)(rows_slab * 1024), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)r_base * 256), 0,
-                                                                          (int)(rows_slab * 1024), 0x00020000);
+    const int sdy = a.ld_dy * 4, sx = a.ld_x * 4;            // bytes between rows
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + (size_t)r_base * a.ld_dy), 0,
+                                                                           (int)(rows_slab * sdy), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)r_base * a.ld_x), 0,
+                                                                          (int)(rows_slab * sx), 0x00020000);
     u32x4 ld_dy[8], ld_x[8];                                 // this wave's 8 rows of the step in flight
     auto issue = [&](long long s) {
         const int row0 = (int)(s - s0) * DW_STEP + 8 * wave;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            ld_dy[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, lane * 16, (row0 + r) * 1024, 0);
+            ld_dy[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, lane * 16, (row0 + r) * sdy, 0);
             if (XH) {
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rs_x, lane * 8, (row0 + r) * 1024, 0);
+                const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rs_x, lane * 8, (row0 + r) * sx, 0);
                 ld_x[r] = u32x4{h[0], h[1], 0u, 0u};
             } else {
-                ld_x[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, lane * 16, (row0 + r) * 1024, 0);
+                ld_x[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, lane * 16, (row0 + r) * sx, 0);
             }
         }
     };
@@ -204,11 +206,20 @@ __global__ __launch_bounds__(256, 1) void vfn_dw16_kernel(const Dw16Args a) {
 
 extern "C" int vfn_weight_grad_partials_bf16(const float* dy, const float* x, int64_t n_points, int32_t groups,
                                              float* dw_part, float* db_part, int32_t x_f16, void* stream) {
+    return vfn_weight_grad_partials_bf16_ld(dy, 256, x, 256, n_points, groups, dw_part, db_part, x_f16, stream);
+}
+
+extern "C" int vfn_weight_grad_partials_bf16_ld(const float* dy, int32_t ld_dy, const float* x, int32_t ld_x, int64_t n_points, int32_t groups,
+                                                float* dw_part, float* db_part, int32_t x_f16, void* stream) {
     VFN_REQUIRE(dy && x && dw_part, "vfn_weight_grad_partials_bf16: NULL argument");
     VFN_REQUIRE(groups >= 1 && groups <= 4096, "vfn_weight_grad_partials_bf16: groups=%d", groups);
-    VFN_REQUIRE(n_points >= 0 && n_points < (1ll << 21) * groups, "vfn_weight_grad_partials_bf16: slab larger than 2 GiB");
+    VFN_REQUIRE(ld_dy >= 256 && ld_x >= 256 && (ld_dy & 3) == 0 && (ld_x & 3) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)x & 15) == 0,
+                "vfn_weight_grad_partials_bf16: 256 columns in whole 16-byte pieces of every row (ld_dy=%d, ld_x=%d)", ld_dy, ld_x);
+    VFN_REQUIRE(!x_f16 || ld_x == 256, "vfn_weight_grad_partials_bf16: the f16 rows of X are 1 KiB apart");
+    VFN_REQUIRE(n_points >= 0 && n_points * (int64_t)(ld_dy > ld_x ? ld_dy : ld_x) * 4 < (int64_t)groups << 31,
+                "vfn_weight_grad_partials_bf16: slab larger than 2 GiB");
     Dw16Args a = {};
-    a.dy = dy; a.x = x; a.dw_part = dw_part; a.db_part = db_part; a.n_points = n_points;
+    a.dy = dy; a.x = x; a.dw_part = dw_part; a.db_part = db_part; a.n_points = n_points; a.ld_dy = ld_dy; a.ld_x = ld_x;
     if (x_f16) hipLaunchKernelGGL(vfn_dw16_kernel<true>, dim3(groups), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(vfn_dw16_kernel<false>, dim3(groups), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_weight_grad_partials_bf16");

@@ -35,7 +35,7 @@ EXPORTS = (
     "vfn_weight_grad_groups", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax", "vfn_merge_sort_depths",
     "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_f16x3_set_clock_probe", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step", "vfn_unfold_weight_grads_acc", "vfn_render_fwd", "vfn_render_fwd_workspace_bytes",
     "vfn_vf_loss_workspace_bytes", "vfn_vf_loss_fwd", "vfn_vf_loss_bwd", "vfn_train_step", "vfn_train_step_workspace_bytes",
-    "vfn_linear_rows_dx_sums",
+    "vfn_linear_rows_dx_sums", "vfn_weight_grad_partials_bf16_ld",
 )
 
 
@@ -891,6 +891,14 @@ def weight_grad_partials_bf16(dy, x, n_points: int, groups: int, dw_part, db_par
     _check(load().vfn_weight_grad_partials_bf16(_ptr(dy, "dy"), _ptr(x, "x"), C.c_int64(n_points), C.c_int32(groups),
                                                 _ptr(dw_part, "dw_part"), _ptr(db_part, "db_part"), C.c_int32(int(x_f16)), _stream()),
            "vfn_weight_grad_partials_bf16")
+
+
+def weight_grad_partials_bf16_cols(dy, x, n_points: int, groups: int, dw_part, db_part=None):
+    """The same over 256 columns of wider matrices (``Cols`` views: 16-byte aligned column offsets, leading dimensions >= 256)."""
+    dy, x = _cols(dy), _cols(x)
+    _check(load().vfn_weight_grad_partials_bf16_ld(dy.ptr, C.c_int32(dy.ld), x.ptr, C.c_int32(x.ld), C.c_int64(n_points), C.c_int32(groups),
+                                                   _ptr(dw_part, "dw_part"), _ptr(db_part, "db_part"), C.c_int32(0), _stream()),
+           "vfn_weight_grad_partials_bf16_ld")
 
 
 def ray_density_weights_bwd(dp: DensityParams, normals, ray_dirs, z_vals, scalars, colors, d_rgb, d_depth, d_weights,
