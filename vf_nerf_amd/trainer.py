@@ -103,8 +103,10 @@ class TrainStep:
                 sup.append(net(both, vector_only=True))
             else:
                 # training mode: BatchNorm normalises every batch with ITS statistics and advances the running ones once per call, so
-                # the two batches go through two calls exactly as the reference makes them (:201,213)
-                sup.append(torch.cat([net(p)[:, :3] for p in pts]) if len(pts) > 1 else net(pts[0])[:, :3])
+                # the two batches go through two calls exactly as the reference makes them (:201,213).  The nine Jacobian columns the
+                # reference's training-mode forward appends are sliced away there (`[:, :3]`); they change no state, so they are not
+                # computed here (three backward passes through the batch statistics per call: ~10 % of a training-mode step).
+                sup.append(torch.cat([net(p, jacobian=False)[:, :3] for p in pts]) if len(pts) > 1 else net(pts[0], jacobian=False)[:, :3])
             sup_gt.append(torch.cat(gts) if len(gts) > 1 else gts[0])
         predictions = {"rgb": outputs.coarse_rgb_values, "depth": outputs.coarse_depth_map,
                        "normals": outputs.coarse_normals.reshape(-1, 3),
