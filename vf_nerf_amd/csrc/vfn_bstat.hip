@@ -20,6 +20,7 @@
 //
 // Roofline: the fp32 matrix pipe (32x32x2: 64 cycles per MFMA per SIMD, 157 TFLOP/s nominal) bounds the GEMM; all other
 // kernels are one pass over [M, n] fp32 and HBM-bound.
+#include <stdlib.h>
 #include "vfn_common.h"
 
 namespace {
@@ -48,6 +49,7 @@ struct GemmArgs {
     const float* zp; const float* coef_p;
     int ldzp;
     float post_p;
+    unsigned long long* probe;      // VFN_GEMM_PROBE: per-workgroup cycle counts of the phases of the chunk loop (debug)
 };
 
 // TRANS = false: B(k, n) = W[n][k]  (nn.Linear weight, C = A W^T);  TRANS = true: B(k, n) = W[k][n]  (C = A W).
@@ -246,7 +248,9 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
     constexpr unsigned OOB = 0x7fffffffu;
     constexpr float A_SCALE = ARITH == 0 ? 64.0f : 1.0f;
 
-    const long long blk_row0 = (long long)blockIdx.x * GM_ROWS;
+    const unsigned rb = blockIdx.x;          // this workgroup's block of 128 rows
+    const int n0 = a.n0;
+    const long long blk_row0 = (long long)rb * GM_ROWS;
     const long long blk_rows = min((long long)GM_ROWS, a.m - blk_row0);
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.a + (size_t)blk_row0 * a.lda), 0, (int)(blk_rows * a.lda * 4), 0x00020000);
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
         for (int r = 0; r < PER; ++r) {
             int n, kk;
             stage_index(tid + 256 * r, n, kk);
-            const int col = a.n0 + n;
+            const int col = n0 + n;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int k = kc + kk + q;
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             const int row = 32 * ps + a_r, k = kc + 4 * a_q;
-            areg[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, k < a.k_pad ? ((unsigned)row * (unsigned)a.lda + (unsigned)k) * 4u : OOB, 0, 0);
+            areg[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, k < a.k_pad ? ((unsigned)row * (unsigned)a.lda + (unsigned)k) * 4u : OOB, 0, 2);
         }
     };
     auto stage_a = [&]() {
@@ -312,12 +316,28 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
 
     fetch_w(0);
     fetch_a(0);
+    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, t_prev = a.probe ? __builtin_amdgcn_s_memtime() : 0;
+    auto mark = [&](int which) {
+        if (a.probe) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            ph[which] += t - t_prev;
+            t_prev = t;
+        }
+    };
     for (int kc = 0; kc < a.k_pad; kc += GM_KC) {
         __syncthreads();               // every wave is done with the previous chunk
+        mark(0);
+        if (a.probe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mark(1); }
         stage_w();
         stage_a();
+        mark(2);
         __syncthreads();
+        mark(3);
         if (kc + GM_KC < a.k_pad) { fetch_w(kc + GM_KC); fetch_a(kc + GM_KC); }       // in flight underneath this chunk's matrix work
+        mark(4);
+        // (Hand-pipelining this section — B fragments one tile ahead, the second K-block's A fragment split behind the first's last tile —
+        // was tried and bought 2 %: the launch is bound by its HBM streams, see the phase table in profiles/r04/linear_rows_microbench.txt,
+        // and the eight-tile forms have no registers for the extra fragments.)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if (kc + 16 * ks >= a.k_pad) break;
@@ -353,15 +373,16 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
                 }
             }
         }
+        mark(5);
     }
 
     // epilogue: D row = (r&3) + 8 (r>>2) + 4 g, col = c  (as the exact kernel; the f16 form undoes A's scale first)
     if (a.stats_part) __syncthreads();          // every wave has read its last A fragments: the tile becomes s_red
-    const long long row0 = (long long)blockIdx.x * GM_ROWS + 32 * wave;
+    const long long row0 = (long long)rb * GM_ROWS + 32 * wave;
     [[maybe_unused]] const int live = (int)min((long long)32, a.m - row0);            // rows of this wave inside the matrix
     [[maybe_unused]] float znext[16];
     [[maybe_unused]] auto fetch_z = [&](int j) {     // the previous layer's pre-BatchNorm outputs under tile j of C (the accumulators' rows)
-        const int col = a.n0 + 32 * j + c;
+        const int col = n0 + 32 * j + c;
         const float* zp0 = a.zp + (size_t)row0 * a.ldzp + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -374,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int col = a.n0 + 32 * j + c;
+        const int col = n0 + 32 * j + c;
         const bool col_ok = col < a.n_out;
         const float b = (a.bias && col_ok) ? a.bias[col] : 0.f;
         float s1 = 0.f, s2 = 0.f;
@@ -393,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
                 for (int r = 0; r < 16; ++r) {
                     const int lr = (r & 3) + 8 * (r >> 2) + 4 * g;
                     const float v = acc[j][r] * (1.0f / A_SCALE);
-                    if (lr < live && col_ok) c0[lr * a.ldc] = v;
+                    if (lr < live && col_ok) __builtin_nontemporal_store(v, &c0[lr * a.ldc]);
                     if (lr < live && st_ok) {
                         const float g1 = fmaf(zq[r], sc, sh) > 0.f ? a.post_p * v : 0.f;
                         s1 += g1;
@@ -416,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
                 float y = z;
                 if (a.act == ACT_TANH) y = tanhf(z);
                 else if (a.act == ACT_SIGMOID) y = 1.0f / (1.0f + expf(-z));
-                a.c[(size_t)row * a.ldc + col] = y;
+                __builtin_nontemporal_store(y, &a.c[(size_t)row * a.ldc + col]);
             }
         }
         if (a.stats_part) {
@@ -429,17 +450,51 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
         __syncthreads();
         for (int i = tid; i < 2 * NCOL; i += 256) {
             const int which = i / NCOL, n = i - which * NCOL;
-            const int col = a.n0 + n;
+            const int col = n0 + n;
             if (col < a.stats_ld) {          // (= n_out, or the summed layer's width in the SUMS form)
                 const float s = s_red[which][0][n] + s_red[which][1][n] + s_red[which][2][n] + s_red[which][3][n];
-                a.stats_part[((size_t)blockIdx.x * 2 + which) * a.stats_ld + col] = s;
+                a.stats_part[((size_t)rb * 2 + which) * a.stats_ld + col] = s;
             }
         }
     }
+    if (a.probe && tid == 0 && rb < 4096) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        mark(6);          // (the epilogue)
+#pragma unroll
+        for (int q = 0; q < 7; ++q) a.probe[rb * 8 + q] = ph[q];
+    }
+}
+
+// VFN_GEMM_PROBE=1 (debugging aid, single-threaded use): wave 0 of every workgroup of the split kernels adds up the shader cycles
+// (s_memtime) it spends in each phase of the chunk loop; every launch is then followed by a synchronisation and one line on stderr.
+// This is what showed the launch to be bound by its HBM streams (profiles/r04/linear_rows_microbench.txt).
+constexpr unsigned PROBE_BLOCKS = 4096;
+unsigned long long* gemm_probe_buffer(hipStream_t s) {
+    static const bool on = getenv("VFN_GEMM_PROBE") != nullptr;
+    static unsigned long long* buf = nullptr;
+    if (!on) return nullptr;
+    if (!buf && hipMalloc(&buf, PROBE_BLOCKS * 8 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+    (void)hipMemsetAsync(buf, 0, PROBE_BLOCKS * 8 * sizeof(unsigned long long), s);
+    return buf;
+}
+void gemm_probe_report(const GemmArgs& a, unsigned blocks, int trans, int arith, int sums, hipStream_t s) {
+    unsigned long long* host = (unsigned long long*)malloc(PROBE_BLOCKS * 8 * sizeof(unsigned long long));
+    if (!host) return;
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(host, a.probe, PROBE_BLOCKS * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+    const unsigned nb = blocks < PROBE_BLOCKS ? blocks : PROBE_BLOCKS;
+    for (unsigned b = 0; b < nb; ++b)
+        for (int q = 0; q < 7; ++q) sum[q] += (double)host[b * 8 + q];
+    fprintf(stderr, "gemm16 probe (TRANS=%d ARITH=%d SUMS=%d m=%lld n=%d k=%d): cycles per workgroup: barrier1 %.0f  wait_loads %.0f  "
+            "stage %.0f  barrier2 %.0f  fetch_issue %.0f  compute %.0f  epilogue %.0f\n", trans, arith, sums, a.m, a.n_out, a.k_in,
+            sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[4] / nb, sum[5] / nb, sum[6] / nb);
+    free(host);
 }
 
 template <bool TRANS, int ARITH, bool SUMS = false>
 void launch_gemm16(GemmArgs a, hipStream_t s) {
+    a.probe = gemm_probe_buffer(s);
     const unsigned blocks = (unsigned)((a.m + GM_ROWS - 1) / GM_ROWS);
     float* const stats = a.stats_part;
     for (int n0 = 0; n0 < a.n_out; n0 += 256) {
@@ -451,6 +506,7 @@ void launch_gemm16(GemmArgs a, hipStream_t s) {
         else if (tiles > 1) hipLaunchKernelGGL((vfn_linear_rows16_kernel<2, TRANS, ARITH, SUMS>), dim3(blocks), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((vfn_linear_rows16_kernel<1, TRANS, ARITH, SUMS>), dim3(blocks), dim3(256), 0, s, a);
     }
+    if (a.probe) gemm_probe_report(a, blocks, (int)TRANS, ARITH, (int)SUMS, s);
 }
 
 template <bool TRANS>
