@@ -674,13 +674,17 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
     rec = {"metric": "training rays/sec (4096-ray batch, 128 samples/ray, fwd+bwd+clip+Adam)",
            "value": round(args.rays * args.steps * world / elapsed, 1), "unit": "rays/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": train_dtype_label(model),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": train_dtype_label(model) if not model.vector_field_network.training else
+           ("f16x3 forward products + bf16 in three parts (six products) dX + bf16x3 dW; f32 accumulate and fp32 activations in HBM"
+            if getattr(model.vector_field_network, "gemm_arithmetic", "split") == "split" else "f32 (exact fp32 matrix instruction)"),
            "data": "synthetic", "final_loss": round(float(loss), 5), "per_rank_rays_per_s": rates,
            "bucket_allreduce_ms": round(bucket_ms, 4) if bucket_ms is not None else None,
            "bucket_elements": bucket.numel() if bucket is not None else None,
            "activation_storage": model.activation_storage, "gradient_storage": model.gradient_storage,
            "workspace_layout": model.workspace_layout, "training_products": int(getattr(model, "training_products", 3)),
-           "networks": "training mode (batch-statistics BatchNorm, layer-at-a-time fp32 kernels)"
+           "networks": "training mode (batch-statistics BatchNorm: one product per layer with the statistics / the BatchNorm backward's sums in its "
+                       "epilogue, HBM-bound row passes in between; csrc/vfn_bstat.hip)"
            if model.vector_field_network.training else "eval mode (the shipped regime, fused kernels)",
            # per GPU: algorithmic FLOPs of a step / its duration against the f16 / 3 matrix ceiling, and the workspace bytes the
            # step has to move against the HBM peak (it sits between the two roofs)
