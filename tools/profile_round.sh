@@ -22,7 +22,7 @@ cd "$R"
 python3 tools/topk.py gpurun_out/prof_train/kt_results.db 30 > "$OUT/train_kernel_stats.txt"
 python3 tools/topk.py gpurun_out/prof_train1024/kt_results.db 30 > "$OUT/train1024_kernel_stats.txt"
 python3 tools/topk.py gpurun_out/prof_grid/kt_results.db 30 > "$OUT/grid_stage_stats.txt"
-tail -1 gpurun_out/prof_train.log > "$OUT/bench_train_profiled.json"
+grep '^{"metric"' gpurun_out/prof_train.log | tail -1 > "$OUT/bench_train_profiled.json"     # (the bench line of the profiled run, among the profiler's own log lines)
 ls -la "$OUT"
 # the raw rocprofv3 outputs are scratch (and would push gpurun_out/ past what is merged back)
 rm -rf gpurun_out/prof_kt gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/pmc_mfma gpurun_out/prof_train gpurun_out/prof_train1024 gpurun_out/prof_grid

@@ -74,12 +74,18 @@ def _arith(net, backward: bool) -> int:
     (profiles/r04/linear_rows_microbench.txt): 0.43 ms (f16x3) / 0.53 ms (bf16x6) against 0.81-0.87 ms per 524 288 x 256 x 256 GEMM once the
     A operand goes through LDS in whole cache lines (the first split kernel fetched 32-byte pieces of 1-KiB-strided rows and was bound by
     that at 0.66 ms); the training-mode step 69 ms against 92 ms."""
-    mode = getattr(net, "gemm_arithmetic", "split")
-    if mode == "fp32":
+    if not _split(net):
         return lib.GEMM_EXACT
-    if mode != "split":
-        raise ValueError(f"gemm_arithmetic must be 'split' or 'fp32', got {mode!r}")
     return lib.GEMM_BF16X6 if backward else lib.GEMM_SPLIT_F16
+
+
+def _split(net) -> bool:
+    """Split-operand products on the 16-bit matrix cores?  Not when the facade asks for the exact kernels (``model.precision = "fp32"``,
+    also what the range guard switches to) or the net itself does (``net.gemm_arithmetic = "fp32"``)."""
+    mode = getattr(net, "gemm_arithmetic", "split")
+    if mode not in ("split", "fp32"):
+        raise ValueError(f"gemm_arithmetic must be 'split' or 'fp32', got {mode!r}")
+    return mode == "split" and getattr(net, "precision", "f16x3") != "fp32"
 
 
 def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, update_running: bool = True,
@@ -162,7 +168,7 @@ class _ParamGrads:
         lin = self.net._linear(i)
         n, k = lin.out_features, lin.in_features
         dev, G, m = dz.device, self.G, self.m
-        split = getattr(self.net, "gemm_arithmetic", "split") == "split"
+        split = _split(self.net)
         row_blocks = []
         if n % 256 != 0 and n % 256 <= 32 and n > 32 and split:
             # 259 = 256 + 3: any partition of the rows is valid; this one keeps the wide block at column 0 of dZ (16-byte aligned rows: the
@@ -272,7 +278,7 @@ def _backward(net, st: _State, dz_last: torch.Tensor, pg: Optional[_ParamGrads],
         lib.colsum_finish(part, parts, 2 * n_prev, sums)
         if pg is not None:
             pg.batchnorm(i - 1, sums)
-        if 192 < n_prev < 256 and getattr(net, "gemm_arithmetic", "split") == "split":
+        if 192 < n_prev < 256 and _split(net):
             dz = torch.zeros(m, 256, device=dev)          # (zero pad columns up to 256: the bf16 weight-gradient product reads whole blocks)
         else:
             dz = torch.zeros(m, _up8(n_prev), device=dev) if n_prev % 8 else torch.empty(m, _up8(n_prev), device=dev)

@@ -296,7 +296,9 @@ class VectorFieldNerf:
         if value not in ("f16x3", "fp32"):
             raise ValueError(f"precision must be 'f16x3' or 'fp32', got {value!r}")
         self._precision = value
-        self.vector_field_network.precision = value
+        for net in (self.vector_field_network, getattr(self, "fine_vector_field_network", None), getattr(self, "rendering_network", None)):
+            if net is not None:
+                net.precision = value      # (the layer-at-a-time paths of batchstat.py read it too: "fp32" = the exact matrix instruction)
 
     @property
     def activation_storage(self) -> str:
