@@ -607,3 +607,23 @@ def test_training_products_knob_and_what_it_selects():
     assert ws.single and ws.dy16 == "f16" and ws.fwd_flags() == (lib.WS_F16 | lib.WS_FRAG | lib.WS_P1) and ws.dy_flags() == (lib.DY_FRAG | lib.DY_F16S | lib.DY_P1)
     ws3 = backward._Workspace(64, 13, torch.device("cpu"), f16=True, frag=True, dy16="f16")
     assert not ws3.single and ws3.fwd_flags() == (lib.WS_F16 | lib.WS_FRAG) and ws3.dy_flags() == (lib.DY_FRAG | lib.DY_F16S)
+
+
+def test_layer_product_arithmetic_follows_precision_and_the_net_knob():
+    """batchstat._arith: split-operand products on the 16-bit matrix cores by default (forward f16x3, backward bf16 in three parts); the exact
+    fp32 matrix instruction when the net asks for it (``gemm_arithmetic = "fp32"``) or the facade does (``precision = "fp32"`` — what the range
+    guard switches a model to); anything else is refused."""
+    import types
+    from vf_nerf_amd import batchstat, lib
+    net = types.SimpleNamespace()
+    assert batchstat._arith(net, False) == lib.GEMM_SPLIT_F16 and batchstat._arith(net, True) == lib.GEMM_BF16X6
+    net.precision = "fp32"
+    assert batchstat._arith(net, False) == batchstat._arith(net, True) == lib.GEMM_EXACT
+    net.precision, net.gemm_arithmetic = "f16x3", "fp32"
+    assert batchstat._arith(net, False) == batchstat._arith(net, True) == lib.GEMM_EXACT
+    net.gemm_arithmetic = "tf32"
+    with pytest.raises(ValueError):
+        batchstat._arith(net, False)
+    model = vf_nerf_amd.VectorFieldNerf(vf_nerf_amd.shipped_config(torch.device("cpu"), n_samples=8, n_importance=8))
+    model.precision = "fp32"
+    assert model.vector_field_network.precision == model.rendering_network.precision == "fp32"
