@@ -241,6 +241,8 @@ class OneCallStep:
         key = (n, s_c, n_f, n_sup, pr.border, pr.center, pr.sparse_colours, str(dev))
         ws = self._ws.get(key)
         if ws is None:
+            # ONE workspace stays alive: ~34 KiB per sample dense, ~61 KiB with the sparse colour branch (region 2 is sized for every sample
+            # being selected: 17 / 30 GiB at 4096 x 128 of the 288 GB) — the reference's trainer draws batches of one size
             self._ws.clear()
             need = lib.train_step_workspace_bytes(pr, model.vector_field_network.geometry(), model.rendering_network.geometry())
             ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=dev)
