@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: rays/s of ``VectorFieldNerf.render`` (forward, eval mode) on 4096-ray chunks with
-128 samples per ray (S_c = N_f = 64), synthetic random-weight scene, one process per GPU.
+128 samples per ray (S_c = N_f = 64), one process per GPU; the scene carries weights the reference's own trainer arrived at
+(tests/golden/trained_far.npz: data, not code) on synthetic rays; --weights random = the random-weight scene of rounds 1-3.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python bench.py --gpus 8 --steps 20 --warmup 3          # starts its own 8 ranks (torch.distributed.run as a CHILD process)
@@ -18,7 +19,9 @@ Extra objects on the line:
                     of one launch (SURVEY.md §8d per-point figures x its points) / its average duration measured with
                     HIP events on the launch stream inside the timed region; peak = dense f16 MFMA 2500 TFLOP/s / 3 (three
                     f16 products per fp32-equivalent product), or 157.3 TFLOP/s fp32 matrix with --precision fp32;
-                    traffic from the committed PMC passes (profiles/).
+                    traffic = FETCH_SIZE x 2 + WRITE_SIZE of that kernel from two rocprofv3 --pmc child runs of this command made on
+                    this box before the timed run (live_hbm_traffic; the committed passes of profiles/ are the fallback);
+                    effective_clock_ghz from in-kernel s_memtime / s_memrealtime stamps.
   cpu_baseline      the CPU oracle (torch fp32, 32 host threads) on a bounded sample of the same workload.
   parity_vs_oracle  the "PSNR vs ref" half of the metric: the HIP path against the oracle on those sample rays.
 
@@ -56,10 +59,14 @@ def kernel_sources_sha16() -> str:
 
 
 def hbm_traffic(f16: bool, kernel_class: str = "fused16", colour_products: int = 3):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside the benchmark; its
-    counters need their own passes): FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md section HBM) + WRITE_SIZE, in
+    """HBM bytes per launch of the dominant kernel: from THIS run's own PMC passes when main() made them (live_hbm_traffic: two
+    rocprofv3 child runs before the timed run), else from the committed passes of profiles/rNN/ (the counters need their own passes
+    either way): FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md section HBM) + WRITE_SIZE, in
     bytes -> (bytes | None, provenance).  The provenance names the file and says whether the kernel sources have changed since the
     counters were collected (tools/export_profiles.py stores a fingerprint of them)."""
+    if _LIVE_TRAFFIC is not None and kernel_class == "fused16" and f16:
+        if _LIVE_TRAFFIC[0] is not None:
+            return _LIVE_TRAFFIC
     syms = {"vf_feat16": ("vfn_mlp16_kernel<9>",), "render16": ("vfn_mlp16_kernel<18>",),
             "fused16": ("vfn_mlp16_kernel<35>",) if colour_products == 2 else ("vfn_mlp16_kernel<3>",)}.get(kernel_class, ())
     # newest round first; a round's file is used when it holds BOTH counters of the kernel in question (the 128-ray self-check
@@ -79,11 +86,76 @@ def hbm_traffic(f16: bool, kernel_class: str = "fused16", colour_products: int =
     sha = t.get("kernel_sources_sha16")
     prov = {"file": os.path.relpath(path, REPO), "collected_with": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)",
             "kernel_sources_unchanged_since": (sha == kernel_sources_sha16()) if sha else None}
+    if _LIVE_TRAFFIC is not None and kernel_class == "fused16":
+        prov["live_pass"] = _LIVE_TRAFFIC[1]         # (why this run's own passes did not give the figure)
     for sym in syms:
         fetch, write = t["all_kernels"].get(f"FETCH_SIZE|{sym}"), t["all_kernels"].get(f"WRITE_SIZE|{sym}")
         if fetch is not None and write is not None:
             return int((2.0 * fetch + write) * 1024), prov
     return None, prov
+
+
+_LIVE_TRAFFIC = None      # (bytes per launch, provenance) measured by live_hbm_traffic() in THIS run, or None
+
+
+def under_profiler() -> bool:
+    return any("rocprof" in (os.environ.get(k) or "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_PATH")) or \
+        any(k.startswith("ROCPROF") for k in os.environ)
+
+
+def live_hbm_traffic(args, timeout_s: float = 150.0):
+    """The PMC passes of profiles/rNN/traffic_f16x3.json made HERE, on the box the line is measured on: two child processes
+    (`rocprofv3 --pmc FETCH_SIZE -- python3 bench.py ...`, then WRITE_SIZE: each counter in its own pass, no trace domains, as
+    MI355X_MICROARCH.md prescribes) that run the headline render for a few steps, started before this process makes any GPU call;
+    FETCH_SIZE x 2 (the gfx950 correction) + WRITE_SIZE, KB -> bytes, averaged over the launches of the dominant kernel.
+    -> (bytes, provenance) or (None, why not)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, {"live": False, "why": "rocprofv3 is not on PATH"}
+    sym = "vfn_mlp16_kernel<35>" if args.colour_products == 2 else "vfn_mlp16_kernel<3>"
+    tmp = tempfile.mkdtemp(prefix="vfn_traffic_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--no-live-traffic", "--no-cpu-baseline", "--no-train", "--no-two-product-leg",
+             "--no-random-weight-leg", "--steps", "5", "--warmup", "2", "--sustain-seconds", "0", "--rays", str(args.rays), "--coarse",
+             str(args.coarse), "--fine", str(args.fine), "--weights", args.weights] + \
+            (["--colour-products", str(args.colour_products)] if args.colour_products else [])
+    kb = {}
+    t0 = time.perf_counter()
+    try:
+        for counter, stem in (("FETCH_SIZE", "pf"), ("WRITE_SIZE", "pw")):
+            out_dir = os.path.join(tmp, stem)
+            r = subprocess.run([exe, "--pmc", counter, "-d", out_dir, "-o", stem, "--"] + child, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            db = None
+            for root, _, files in os.walk(out_dir):
+                for f in files:
+                    if f.endswith("_results.db"):
+                        db = os.path.join(root, f)
+            if r.returncode != 0 or db is None:
+                return None, {"live": False, "why": f"the {counter} pass failed (exit {r.returncode}): {r.stderr.decode(errors='replace')[-200:]}"}
+            con = sqlite3.connect(db)
+            rows = list(con.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? group by kernel_name",
+                                    (counter,)))
+            con.close()
+            for name, val, n in rows:
+                short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+                if short == sym:
+                    kb[counter] = (float(val), int(n))
+            if counter not in kb:
+                return None, {"live": False, "why": f"no {sym} launch in the {counter} pass"}
+    except Exception as e:      # a timeout, a profiler that cannot start here: the committed file stays the source
+        return None, {"live": False, "why": f"{type(e).__name__}: {e}"[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = int((2.0 * kb["FETCH_SIZE"][0] + kb["WRITE_SIZE"][0]) * 1024)
+    return total, {"live": True, "collected_with": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child runs of this command on this box before "
+                                                   "the timed run (separate passes, no trace domains)",
+                   "kernel": sym, "launches_averaged": {"FETCH_SIZE": kb["FETCH_SIZE"][1], "WRITE_SIZE": kb["WRITE_SIZE"][1]},
+                   "fetch_kb_x2_gfx950": round(2.0 * kb["FETCH_SIZE"][0], 1), "write_kb": round(kb["WRITE_SIZE"][0], 1),
+                   "seconds": round(time.perf_counter() - t0, 1)}
 
 
 def build_scene(dev, n_rays, s_c, n_f, seed, perturb=True, weight_seed=0):
@@ -858,6 +930,9 @@ def main() -> None:
     ap.add_argument("--no-train", action="store_true", help="skip the training-step sub-object of the default line")
     ap.add_argument("--no-two-product-leg", action="store_true", help="skip the timed region of the opt-in two-product colour branch")
     ap.add_argument("--no-random-weight-leg", action="store_true", help="skip the timed region on the synthetic random-weight scene")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed profiles/rNN/traffic_f16x3.json instead of two rocprofv3 --pmc child runs of "
+                         "this command on this box (+25 s; render workload, one GPU, not under a profiler)")
     ap.add_argument("--weights", choices=("trained", "random"), default="trained",
                     help="render workload: trained = weights the reference's own trainer arrived at (tests/golden/trained_far.npz), the "
                          "default; random = the synthetic random-weight scene")
@@ -940,6 +1015,10 @@ def main() -> None:
     if args.dry_run:
         dry_run(args, rank, world, dist)
         return
+    if world == 1 and not force_dist and not args.train and args.workload == "render" and args.precision == "f16x3" and \
+            not args.no_live_traffic and not under_profiler():
+        global _LIVE_TRAFFIC
+        _LIVE_TRAFFIC = live_hbm_traffic(args)          # (children; before this process touches the GPU)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 

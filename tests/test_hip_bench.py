@@ -46,7 +46,13 @@ def test_default_line_has_the_contract_keys_and_consistent_arithmetic():
     assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) < 1e-2 * r["achieved"]
     assert 2 * r["avg_launch_ms"] <= d["ms_per_step"] * 1.02, "two launches of the dominant kernel fit in a step"
     assert 0.3 < r["frac"] < 1.0 and r["traffic"] is None or r["traffic"] > r["algorithmic_bytes"]
-    assert r["traffic_source"] is None or "file" in r["traffic_source"]
+    # the HBM counters come from two rocprofv3 --pmc child runs on THIS box, or — when the profiler cannot run here — from the committed
+    # file, with the reason beside it
+    src = r["traffic_source"]
+    print("roofline.traffic:", r["traffic"], json.dumps(src)[:400])
+    assert src is not None and (src.get("live") is True or ("file" in src and src["live_pass"]["live"] is False and src["live_pass"]["why"]))
+    if src.get("live"):
+        assert src["launches_averaged"]["FETCH_SIZE"] >= 10 and 2e7 < r["traffic"] < 2e8
     assert 1.0 < r["effective_clock_ghz"] < 2.6 and r["effective_clock"]["workgroups"] >= 1024
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "rays/s" and c["cores"] >= 1 and 0 < c["value"] < d["value"] / 100

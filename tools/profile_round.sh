@@ -7,7 +7,7 @@ R=$(pwd)
 OUT=${1:-gpurun_out/export}
 mkdir -p "$R/$OUT" "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-train --no-two-product-leg --no-random-weight-leg"
+B="python3 $R/bench.py --no-cpu-baseline --no-train --no-two-product-leg --no-random-weight-leg --no-live-traffic"
 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_kt" -o kt -- $B --steps 20 > "$R/gpurun_out/prof_kt.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE -d "$R/gpurun_out/prof_fetch" -o pf -- $B --steps 5 > "$R/gpurun_out/prof_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE -d "$R/gpurun_out/prof_write" -o pw -- $B --steps 5 > "$R/gpurun_out/prof_write.log" 2>&1
