@@ -103,7 +103,7 @@ def under_profiler() -> bool:
         any(k.startswith("ROCPROF") for k in os.environ)
 
 
-def live_hbm_traffic(args, timeout_s: float = 150.0):
+def live_hbm_traffic(args, timeout_s: float = 60.0):
     """The PMC passes of profiles/rNN/traffic_f16x3.json made HERE, on the box the line is measured on: two child processes
     (`rocprofv3 --pmc FETCH_SIZE -- python3 bench.py ...`, then WRITE_SIZE: each counter in its own pass, no trace domains, as
     MI355X_MICROARCH.md prescribes) that run the headline render for a few steps, started before this process makes any GPU call;
