@@ -268,22 +268,57 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
         else { n = e % NCOL; kk = 2 * (e / NCOL); }
     };
     float wreg[PER][2];
+    // W: the per-thread part of an element's address is the same for all PER x 2 loads of a chunk (TRANS: the thread's column and its
+    // first k; else its first row and its k pair) and goes into the buffer instruction's vector offset once; what changes from load to
+    // load is uniform and rides in the scalar offset.  (With the whole address recomputed and range-checked per load in vector
+    // instructions, ISSUING the 32 loads of a chunk took 2 500 cycles per workgroup — as long as its matrix instructions.)
+    static_assert(256 % NCOL == 0, "a thread keeps its column over the passes");
+    const int w_kk = TRANS ? 2 * (tid / NCOL) : 2 * (tid & 15);      // this thread's k within a chunk (plus the uniform part, TRANS)
+    const int w_n = TRANS ? tid % NCOL : tid >> 4;                  // its column (plus 16 r without TRANS)
+    const unsigned w_voff = TRANS ? ((unsigned)w_kk * (unsigned)a.ldw + (unsigned)(n0 + w_n)) * 4u
+                                  : ((unsigned)(n0 + w_n) * (unsigned)a.ldw + (unsigned)w_kk) * 4u;
     auto fetch_w = [&](int kc) {
 #pragma unroll
         for (int r = 0; r < PER; ++r) {
-            int n, kk;
-            stage_index(tid + 256 * r, n, kk);
-            const int col = n0 + n;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int k = kc + kk + q;
-                const unsigned off = (col < a.n_out && k < a.k_in)
-                    ? (TRANS ? ((unsigned)k * (unsigned)a.ldw + (unsigned)col) * 4u : ((unsigned)col * (unsigned)a.ldw + (unsigned)k) * 4u) : OOB;
-                wreg[r][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, off, 0, 0));
+                bool ok;
+                unsigned soff;
+                if constexpr (TRANS) {
+                    const int ku = kc + 2 * r * (256 / NCOL) + q;      // uniform part of k
+                    ok = n0 + w_n < a.n_out && w_kk + ku < a.k_in;
+                    soff = (unsigned)ku * (unsigned)a.ldw * 4u;
+                } else {
+                    ok = n0 + w_n + 16 * r < a.n_out && w_kk + kc + q < a.k_in;
+                    soff = ((unsigned)(16 * r) * (unsigned)a.ldw + (unsigned)(kc + q)) * 4u;
+                }
+                // (the range check of a raw buffer access covers the vector offset only: invalid elements get the out-of-range one)
+                wreg[r][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, ok ? w_voff : OOB, soff, 0));
             }
         }
     };
     auto stage_w = [&]() {
+        if constexpr (TRANS && NCOL == 256) {
+            // the thread holds the chunk's 32 k of ONE column: 64 bytes per plane, four 16-byte stores instead of sixteen 4-byte ones
+            typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32x4w ph, pm, pl;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    unsigned short h0, m0, l0, h1, m1, l1;
+                    split3<ARITH>(wreg[4 * i + t][0], h0, m0, l0);
+                    split3<ARITH>(wreg[4 * i + t][1], h1, m1, l1);
+                    ph[t] = (unsigned)h0 | ((unsigned)h1 << 16);
+                    pm[t] = (unsigned)m0 | ((unsigned)m1 << 16);
+                    pl[t] = (unsigned)l0 | ((unsigned)l1 << 16);
+                }
+                *reinterpret_cast<u32x4w*>(s_hi + w_n * GM_LDH + 8 * i) = ph;
+                *reinterpret_cast<u32x4w*>(s_mid + w_n * GM_LDH + 8 * i) = pm;
+                if constexpr (THREE) *reinterpret_cast<u32x4w*>(s_lo + w_n * GM_LDH + 8 * i) = pl;
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < PER; ++r) {
             int n, kk;
