@@ -93,6 +93,28 @@ def test_dx_product_with_the_batchnorm_backward_sums(m, k_out, n, n_prev):
     assert e_fused <= 1e-6 and e_pass <= 1e-6
 
 
+@pytest.mark.parametrize("m,ld_dy,c_dy,ld_x,c_x", [(4096, 256, 0, 256, 0), (3000, 264, 0, 256, 0), (4096, 256, 0, 296, 0), (1000, 264, 0, 296, 32),
+                                                     (33, 256, 0, 256, 0)])
+def test_weight_gradient_blocks_of_wider_matrices_on_the_bf16_cores(m, ld_dy, c_dy, ld_x, c_x):
+    """vfn_weight_grad_partials_bf16_ld: dW[n][k] = sum_m dY[m][c_dy + n] X[m][c_x + k] over 256 x 256 column blocks of matrices whose rows
+    are wider than 256 floats (the 259-wide output gradient, the 289-wide rendering-net input), and db = column sums of the dY block, vs
+    float64: 3e-5 of the largest entry (bf16 split operands, three products: 16 significant bits per operand under a sum over m)."""
+    torch.manual_seed(m + ld_dy + ld_x)
+    dy = torch.randn(m, ld_dy, device=DEV) * 1e-3
+    x = torch.randn(m, ld_x, device=DEV)
+    G = 4
+    part = torch.empty(G, 256, 256, device=DEV)
+    db = torch.empty(G, 256, device=DEV)
+    lib.weight_grad_partials_bf16_cols(lib.Cols(dy, c_dy), lib.Cols(x, c_x), m, G, part, db)
+    got_w, got_b = part.double().sum(0).cpu(), db.double().sum(0).cpu()
+    dyb, xb = dy[:, c_dy:c_dy + 256].double().cpu(), x[:, c_x:c_x + 256].double().cpu()
+    want_w, want_b = dyb.t() @ xb, dyb.sum(0)
+    e_w = float((got_w - want_w).abs().max() / want_w.abs().max())
+    e_b = float((got_b - want_b).abs().max() / want_b.abs().max())
+    print(f"dW block rel err {e_w:.2e}, db {e_b:.2e}")
+    assert e_w <= 3e-5 and e_b <= 1e-5
+
+
 def test_embed_rows_and_its_derivative():
     """Positional encoding rows (and the scaled copy the skip layer reads) bit-match the oracle's; the backward is the
     analytic derivative (checked against float64 autograd, 1e-5 of the largest entry)."""
