@@ -627,3 +627,20 @@ def test_layer_product_arithmetic_follows_precision_and_the_net_knob():
     model = vf_nerf_amd.VectorFieldNerf(vf_nerf_amd.shipped_config(torch.device("cpu"), n_samples=8, n_importance=8))
     model.precision = "fp32"
     assert model.vector_field_network.precision == model.rendering_network.precision == "fp32"
+
+
+def test_live_traffic_pass_reports_why_it_could_not_run(monkeypatch):
+    """bench.live_hbm_traffic: without rocprofv3 on PATH (this container's case on a CPU-only run is simulated here) it returns no figure and the
+    reason; bench.hbm_traffic then falls back to the committed PMC file and carries that reason beside the file's provenance."""
+    import shutil
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    args = type("A", (), dict(colour_products=None, rays=4096, coarse=64, fine=64, weights="trained"))()
+    got = bench.live_hbm_traffic(args)
+    assert got[0] is None and got[1]["live"] is False and "rocprofv3" in got[1]["why"]
+    monkeypatch.setattr(bench, "_LIVE_TRAFFIC", got)
+    total, prov = bench.hbm_traffic(True, "fused16", 3)
+    assert total is not None and total > 10485760 and prov["file"].startswith("profiles/") and prov["live_pass"]["live"] is False
+    assert bench.under_profiler() in (False, True)
