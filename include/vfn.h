@@ -754,7 +754,7 @@ int vfn_train_step(const vfn_train_step_params* p, const vfn_train_step_io* io, 
  * transpose_w = 0: C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]), W = nn.Linear weight [n_out][ldw], k_in columns
  *                  (torch.nn.functional.linear); act 0 none / 1 tanh / 2 sigmoid.
  * transpose_w = 1: C[m][j] = sum_k A[m][k] W[k][j], W [k_in][ldw], j < n_out  (the input gradient dX = dZ W).
- * A is read over k rounded up to a multiple of 8 (lda must cover it, pad columns zero).  Exact fp32 (v_mfma_f32_32x32x2f32).
+ * A is read over k rounded up to a multiple of 8 (lda must cover it, pad columns zero).
  * stats_part (or NULL): [vfn_linear_rows_stat_parts(m)][2][n_out] per-workgroup column sums of the pre-activation z and
  * of z^2 — the batch statistics, finished by vfn_colsum_finish. */
 int vfn_linear_rows(int32_t transpose_w, const float* a, int32_t lda, const float* w, int32_t ldw, const float* bias,
