@@ -117,7 +117,10 @@ def live_hbm_traffic(args, timeout_s: float = 60.0):
     if exe is None:
         return None, {"live": False, "why": "rocprofv3 is not on PATH"}
     sym = "vfn_mlp16_kernel<35>" if args.colour_products == 2 else "vfn_mlp16_kernel<3>"
-    tmp = tempfile.mkdtemp(prefix="vfn_traffic_", dir="/tmp")
+    try:
+        tmp = tempfile.mkdtemp(prefix="vfn_traffic_", dir="/tmp")
+    except OSError as e:
+        return None, {"live": False, "why": f"no scratch directory under /tmp: {e}"[:300]}
     child = [sys.executable, os.path.abspath(__file__), "--no-live-traffic", "--no-cpu-baseline", "--no-train", "--no-two-product-leg",
              "--no-random-weight-leg", "--steps", "5", "--warmup", "2", "--sustain-seconds", "0", "--rays", str(args.rays), "--coarse",
              str(args.coarse), "--fine", str(args.fine), "--weights", args.weights] + \
