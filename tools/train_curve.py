@@ -9,11 +9,11 @@ kernels; f16x3 with fp32-equivalent storage; f16x3 with the default 16-bit stora
 small batch through the CPU oracle's trainer (oracle.trainer_epoch: torch autograd + torch.optim.Adam on the host) with the
 same draws, beside the HIP runs.
 
-    python tools/train_curve.py [steps] > profiles/r03/train_curve.json
+    python tools/train_curve.py [steps] > profiles/r04/train_curve.json
 
 The runs are chaotic in the usual sense (a ReLU unit or an argmax landing on the other side flips a discrete event and the
 trajectories part), so the comparison is of where the runs END UP — loss and PSNR bands — not step by step."""
-import json, math, sys, time
+import json, math, os, sys, time
 import torch
 sys.path.insert(0, '.')
 import bench
@@ -32,6 +32,10 @@ def student(precision, activations, gradients, stream=0):
     """Same initial weights always; ``stream`` moves the random streams (stratified jitter, supervision points) only."""
     model, _, _, _ = bench.build_scene(dev, 16, s_c, n_f, seed=0, weight_seed=0)
     model.precision, model.activation_storage, model.gradient_storage = precision, activations, gradients
+    # A/B of the step's issue paths on the same streams: VFN_ONE_CALL=0 the launch-by-launch Python path, VFN_SPARSE_COLOURS=0 the dense C call
+    model.one_call_train_step = os.environ.get("VFN_ONE_CALL", "1") != "0"
+    model.sparse_colour_training = os.environ.get("VFN_SPARSE_COLOURS", "1") != "0"
+    model.train_step_streams = int(os.environ.get("VFN_TRAIN_STREAMS", "2"))
     model.rng_seed, model._rng_offset = 11 + 1000 * stream, 0
     supervision.manual_seed(3 + 1000 * stream)
     return model
@@ -56,6 +60,8 @@ def run(precision, activations="fp32", gradients="fp32", stream=0):
             "depth_loss_last_25_mean": sum(t["depth_loss"] for t in terms[-25:]) / 25,
             "supervision_loss_last_25_mean": sum(t["supervision_loss"] for t in terms[-25:]) / 25,
             "psnr_vs_teacher_before_after_db": [round(psnr0, 3), round(pool.psnr(model), 3)],
+            "largest_single_step_loss_after_step_100": [round(max(losses[100:]), 4), 100 + max(range(len(losses) - 100), key=lambda i: losses[100 + i])] if steps > 100 else None,
+            "step_issued_as": "one C call (vfn_train_step, sparse colour branch)" if step.one_call.why_not is None else f"launch by launch from Python ({step.one_call.why_not})",
             "guard_switched_to_fp32": model.f16x3_disabled, "colour_products_reason": model.range_guard.colour_products_reason,
             "two_product_check_after_training": bench.two_product_check(model, *[pool.batch(777_000, 1024)[i] for i in (1, 0, 2)]) if model.uses_f16x3() else None,
             "loss_mean_per_25_steps": [round(sum(losses[i:i + 25]) / len(losses[i:i + 25]), 5) for i in range(0, steps, 25)]}
@@ -64,8 +70,21 @@ def run(precision, activations="fp32", gradients="fp32", stream=0):
 # Every run is chaotic (see the module docstring): what two ARITHMETICS may differ by is only meaningful beside what two runs of
 # the SAME arithmetic differ by when nothing but the random streams (jitter, supervision points) moves.  So: three streams each for
 # the exact-fp32 kernels and for the default 16-bit path, one each for the other storages.
-STREAMS = (0, 1, 2)
+STREAMS = tuple(range(int(os.environ.get("VFN_CURVE_STREAMS", "3"))))
 results = {}
+if os.environ.get("VFN_CURVE_ONLY_DEFAULT") == "1":        # just the default family (the A/B of issue paths): one line, then stop
+    for st in STREAMS:
+        results[f"stream {st}"] = run("f16x3", "f16", "f16", stream=st)
+    print(json.dumps({"one_call": os.environ.get("VFN_ONE_CALL", "1"), "sparse": os.environ.get("VFN_SPARSE_COLOURS", "1"),
+                      "streams": os.environ.get("VFN_TRAIN_STREAMS", "2"),
+                      "final_loss": [round(r["loss_last_25_mean"], 4) for r in results.values()],
+                      "worst_25_step_mean_in_second_half": [max(r["loss_mean_per_25_steps"][len(r["loss_mean_per_25_steps"]) // 2:]) for r in results.values()],
+                      "guard": [r["guard_switched_to_fp32"] for r in results.values()],
+                      "largest_single_step_loss_after_step_100": [r["largest_single_step_loss_after_step_100"] for r in results.values()],
+                      "last_8_means_of_the_worst_run": max(results.values(), key=lambda r: r["loss_last_25_mean"])["loss_mean_per_25_steps"][-8:],
+                      "final_psnr_db": [r["psnr_vs_teacher_before_after_db"][1] for r in results.values()],
+                      "ms_per_step": [r["ms_per_step"] for r in results.values()], "issued_as": [r["step_issued_as"][:40] for r in results.values()]}))
+    sys.exit(0)
 for st in STREAMS:
     results[f"fp32 kernels, stream {st}"] = run("fp32", stream=st)
 for st in STREAMS:
