@@ -36,6 +36,10 @@ def student(precision, activations, gradients, stream=0):
     model.one_call_train_step = os.environ.get("VFN_ONE_CALL", "1") != "0"
     model.sparse_colour_training = os.environ.get("VFN_SPARSE_COLOURS", "1") != "0"
     model.train_step_streams = int(os.environ.get("VFN_TRAIN_STREAMS", "2"))
+    if os.environ.get("VFN_BATCH_STATISTICS") == "1":       # networks in training mode (batch-statistics BatchNorm); VFN_GEMM=fp32: exact layer products
+        model.train()
+        for net in (model.vector_field_network, model.rendering_network):
+            net.gemm_arithmetic = os.environ.get("VFN_GEMM", "split")
     model.rng_seed, model._rng_offset = 11 + 1000 * stream, 0
     supervision.manual_seed(3 + 1000 * stream)
     return model
@@ -76,6 +80,7 @@ if os.environ.get("VFN_CURVE_ONLY_DEFAULT") == "1":        # just the default fa
     for st in STREAMS:
         results[f"stream {st}"] = run("f16x3", "f16", "f16", stream=st)
     print(json.dumps({"one_call": os.environ.get("VFN_ONE_CALL", "1"), "sparse": os.environ.get("VFN_SPARSE_COLOURS", "1"),
+                      "batch_statistics": os.environ.get("VFN_BATCH_STATISTICS", "0"), "layer_products": os.environ.get("VFN_GEMM", "split"),
                       "streams": os.environ.get("VFN_TRAIN_STREAMS", "2"),
                       "final_loss": [round(r["loss_last_25_mean"], 4) for r in results.values()],
                       "worst_25_step_mean_in_second_half": [max(r["loss_mean_per_25_steps"][len(r["loss_mean_per_25_steps"]) // 2:]) for r in results.values()],
