@@ -747,7 +747,9 @@ int vfn_train_step(const vfn_train_step_params* p, const vfn_train_step_io* io, 
  * ============================================================================================= */
 /* (transpose_w is a bit field: bit 0 = the transposition below; bits 1-2 = the arithmetic — 0: exact fp32 (v_mfma_f32_32x32x2f32); 2: SPLIT
  *  f16, every operand as two f16 halves and a product as a_hi b_hi + a_hi b_lo + a_lo b_hi on v_mfma_f32_32x32x16_f16 with fp32
- *  accumulation, 22 significant bits, for forward GEMMs on normalised activations; 4: SPLIT bf16, the same with bf16 halves, 16 significant
+ *  accumulation, 22 significant bits, for forward GEMMs on normalised activations (A rides at 64x its value so that its low halves stay
+ *  out of the f16 denormals: |A| must stay below 1023, |W| below 65504 — batch-normalised activations, encodings, points and weights
+ *  do; gradients do not, hence form 6 for the backward products); 4: SPLIT bf16, the same with bf16 halves, 16 significant
  *  bits and fp32's exponent range; 6: bf16 in THREE parts (hi | mid | lo = 24 bits), six products: fp32-equivalent at fp32's exponent
  *  range, for backward GEMMs on gradients of any magnitude.  5.3x / 5.3x / 2.7x fewer matrix cycles than the exact form; A goes through LDS
  *  in whole cache lines in these forms.)
