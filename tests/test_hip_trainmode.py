@@ -115,6 +115,33 @@ def test_weight_gradient_blocks_of_wider_matrices_on_the_bf16_cores(m, ld_dy, c_
     assert e_w <= 3e-5 and e_b <= 1e-5
 
 
+def test_split_f16_layer_product_reports_operands_outside_its_range():
+    """The split f16 form carries A at 64x its value as two f16 halves: |a| >= 1023 overflows the high half.  Like the fused f16x3
+    kernels the launch then sets bit 0 of the calling thread's range-report word (vfn_f16x3_set_status), which the facade's range guard
+    turns into a move to the exact products (guard.py; batchstat._split reads model.precision); in range, the word stays clear; the
+    bf16 and exact forms do not report (they have fp32's range)."""
+    torch.manual_seed(0)
+    m, k, n = 300, 256, 256
+    a = torch.randn(m, k, device=DEV)
+    w = torch.randn(n, k, device=DEV) * 0.1
+    c = torch.empty(m, n, device=DEV)
+    word = torch.zeros(4, dtype=torch.int32, device=DEV)
+    lib.f16x3_set_status(word)
+    try:
+        lib.linear_rows(a, w, None, m, n, k, c, arith=lib.GEMM_SPLIT_F16)
+        assert int(word[0]) == 0
+        a[137, 200] = 1500.0
+        lib.linear_rows(a, w, None, m, n, k, c, arith=lib.GEMM_BF16X6)
+        lib.linear_rows(a, w, None, m, n, k, c, arith=lib.GEMM_EXACT)
+        assert int(word[0]) == 0
+        want = a.double() @ w.double().t()
+        assert float((c.double() - want).abs().max() / want.abs().max()) <= 1e-6          # (the exact form's result, the last one written)
+        lib.linear_rows(a, w, None, m, n, k, c, arith=lib.GEMM_SPLIT_F16)
+        assert int(word[0]) & lib.STATUS_ACT_SATURATED
+    finally:
+        lib.f16x3_set_status(None)
+
+
 def test_embed_rows_and_its_derivative():
     """Positional encoding rows (and the scaled copy the skip layer reads) bit-match the oracle's; the backward is the
     analytic derivative (checked against float64 autograd, 1e-5 of the largest entry)."""
@@ -144,6 +171,35 @@ def _train_model(fx, d):
     model.train()
     assert model.vector_field_network.training and model.rendering_network.training
     return model
+
+
+def test_training_mode_render_far_from_the_origin_moves_to_the_exact_products():
+    """A camera 5 000 units from the origin puts raw coordinates beyond the split f16 form's 1 023 into the first layer's operand.  With
+    the strict range guard, render() in training mode reports it, repeats the call on the exact fp32 products (model.precision = "fp32",
+    which batchstat._split honours) and returns finite values equal to what a model set to the exact products from the start returns."""
+    import warnings
+    fx, d = load_fixture("train_mode")
+    pose = d["pose"].clone()
+    pose[..., :3, 3] += 5000.0
+    uni = {k: d[k].to(DEV) for k in ("u_coarse", "u_fine", "u_add")}
+
+    def render(model):
+        with torch.no_grad():
+            return model.render(pose.to(DEV), d["uv"].to(DEV), d["intrinsics"].to(DEV), 0, False, uniforms=uni)
+
+    exact = _train_model(fx, d)
+    exact.precision = "fp32"
+    want = render(exact)
+    model = _train_model(fx, d)
+    model.f16x3_guard = "strict"
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        got = render(model)
+    assert model.precision == "fp32" and model.f16x3_disabled is not None and any("f16x3" in str(w.message) for w in caught)
+    assert bool(torch.isfinite(got.coarse_rgb_values).all()) and bool(torch.isfinite(got.coarse_normals).all())
+    assert torch.equal(got.z_vals, want.z_vals)
+    assert float((got.coarse_rgb_values - want.coarse_rgb_values).abs().max()) <= 1e-6
+    assert float((got.coarse_normals - want.coarse_normals).abs().max()) <= 1e-6
 
 
 def test_vf_forward_training_mode_against_oracle_and_reference():

@@ -50,6 +50,7 @@ struct GemmArgs {
     int ldzp;
     float post_p;
     unsigned long long* probe;      // VFN_GEMM_PROBE: per-workgroup cycle counts of the phases of the chunk loop (debug)
+    uint32_t* status;               // split f16 form: bit 0 is set when an element of A leaves the range its scaled halves cover (|a| >= 1023)
 };
 
 // TRANS = false: B(k, n) = W[n][k]  (nn.Linear weight, C = A W^T);  TRANS = true: B(k, n) = W[k][n]  (C = A W).
@@ -344,9 +345,16 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
             areg[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, k < a.k_pad ? ((unsigned)row * (unsigned)a.lda + (unsigned)k) * 4u : OOB, 0, 2);
         }
     };
+    [[maybe_unused]] float a_max = 0.f;       // split f16 form: largest |A| this thread staged (the range report at the end)
     auto stage_a = [&]() {
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<u32x4*>(s_a + (32 * ps + a_r) * A_LD + 4 * a_q) = areg[ps];
+        for (int ps = 0; ps < 4; ++ps) {
+            *reinterpret_cast<u32x4*>(s_a + (32 * ps + a_r) * A_LD + 4 * a_q) = areg[ps];
+            if constexpr (ARITH == 0) {
+                const f32x4 v = __builtin_bit_cast(f32x4, areg[ps]);
+                a_max = fmaxf(fmaxf(a_max, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            }
+        }
     };
 
     fetch_w(0);
@@ -492,6 +500,11 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
             }
         }
     }
+    if constexpr (ARITH == 0) {
+        // A rides at 64x its value as two f16 halves: from |a| = 1023.5 on the high half is infinite.  Report it like the fused f16x3
+        // kernels report a saturated activation (vfn_f16x3_set_status): the facade's range guard then moves the model to the exact products.
+        if (a.status && !(a_max < 1023.0f)) atomicOr(a.status, 1u);         // (also true for NaN)
+    }
     if (a.probe && tid == 0 && rb < 4096) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         mark(6);          // (the epilogue)
@@ -530,6 +543,7 @@ void gemm_probe_report(const GemmArgs& a, unsigned blocks, int trans, int arith,
 template <bool TRANS, int ARITH, bool SUMS = false>
 void launch_gemm16(GemmArgs a, hipStream_t s) {
     a.probe = gemm_probe_buffer(s);
+    a.status = ARITH == 0 ? vfn_internal_f16x3_status() : nullptr;
     const unsigned blocks = (unsigned)((a.m + GM_ROWS - 1) / GM_ROWS);
     float* const stats = a.stats_part;
     for (int n0 = 0; n0 < a.n_out; n0 += 256) {

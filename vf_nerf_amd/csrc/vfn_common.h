@@ -71,3 +71,5 @@ int vfn_internal_rows3_by_index(const float* a, const int32_t* index, const int3
 int vfn_internal_fused16_products_dev(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom, const void* rn_packed16,
                                       const float* points, const float* ray_dirs, int64_t n_points, const int32_t* n_dev, int32_t samples_per_ray,
                                       const int32_t* out_index, int32_t colour_products, float* normals, float* colors, void* stream);
+// csrc/vfn_mlp16.hip: the calling thread's range-report word (vfn_f16x3_set_status), or NULL
+uint32_t* vfn_internal_f16x3_status();

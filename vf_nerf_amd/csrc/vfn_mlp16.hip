@@ -1208,6 +1208,9 @@ static int check_kind16(int net_kind, const Plan16& p, const char* what) {
 // Where the f16x3 launches of THIS thread report operands outside the split-f16 range (NULL: nowhere).
 static thread_local uint32_t* t_status_word = nullptr;
 
+// (csrc/vfn_bstat.hip: the split-f16 layer products report into the same word)
+uint32_t* vfn_internal_f16x3_status() { return t_status_word; }
+
 extern "C" int vfn_f16x3_set_status(uint32_t* status_word) {
     t_status_word = status_word;
     return VFN_OK;
