@@ -65,7 +65,7 @@ def _running_coef(bn) -> torch.Tensor:
     return torch.stack([scale, bn.bias.detach() - bn.running_mean.detach() * scale, bn.running_mean.detach(), rstd]).contiguous()
 
 
-def _arith(net, backward: bool) -> int:
+def _arith(net, backward: bool, first_layer: bool = False) -> int:
     """Arithmetic of the layer GEMMs (csrc/vfn_bstat.hip): ``net.gemm_arithmetic`` = "split" (default since round 4) or "fp32" (the exact
     fp32 matrix instruction).  Split: the forward GEMMs on three f16 products per product (22 significant bits, like the fused f16x3
     kernels), the backward GEMMs dX = dZ W — operands of any magnitude — on bf16 in THREE parts (six products, 24 bits at fp32's exponent
@@ -76,7 +76,10 @@ def _arith(net, backward: bool) -> int:
     that at 0.66 ms); the training-mode step 69 ms against 92 ms."""
     if not _split(net):
         return lib.GEMM_EXACT
-    return lib.GEMM_BF16X6 if backward else lib.GEMM_SPLIT_F16
+    # The FIRST layer (and the skip layer, which re-reads the encoded input) reads raw inputs — coordinates of any scale beside the
+    # encodings: its forward product runs in the form with fp32's exponent range too.  Later layers read BatchNorm'ed activations, inside the split f16 form's |x| < 1 023 (the launch reports
+    # operands beyond it to the range guard, csrc/vfn_bstat.hip).
+    return lib.GEMM_BF16X6 if (backward or first_layer) else lib.GEMM_SPLIT_F16
 
 
 def _split(net) -> bool:
@@ -110,7 +113,7 @@ def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, upda
         if batch_stats:
             parts = lib.linear_rows_stat_parts(m)
             part = torch.empty(parts, 2, n, device=dev)
-            lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, stats_part=part, arith=_arith(net, False))
+            lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, stats_part=part, arith=_arith(net, False, i == 0 or i == skip))
             sums = torch.empty(2, n, dtype=torch.float64, device=dev)
             lib.colsum_finish(part, parts, 2 * n, sums)
             coef = torch.empty(4, n, device=dev)
@@ -119,7 +122,7 @@ def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, upda
             if update_running:
                 bn.num_batches_tracked += 1
         else:
-            lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, arith=_arith(net, False))
+            lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, arith=_arith(net, False, i == 0 or i == skip))
             coef = _running_coef(bn)
         st.z.append(z)
         st.coef.append(coef)
@@ -134,7 +137,7 @@ def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, upda
     last = net._linear(L - 1)
     st.x.append(x)
     y = torch.zeros(m, _up8(last.out_features), device=dev)
-    lib.linear_rows(x, last.weight.detach(), last.bias.detach(), m, last.out_features, last.in_features, y, act=final_act, arith=_arith(net, False))
+    lib.linear_rows(x, last.weight.detach(), last.bias.detach(), m, last.out_features, last.in_features, y, act=final_act, arith=_arith(net, False, L == 1))
     st.y = y
     if batch_stats and update_running:
         # vfn_bstat_finalize advanced running_mean / running_var through raw pointers: their _version did not move, so the
