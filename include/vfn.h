@@ -20,8 +20,10 @@ extern "C" {
 #endif
 
 /* Bumped whenever a POD struct's layout or an entry point's signature changes (2: vfn_render_params.timing_events,
- * vfn_abi_struct_bytes; 3: vfn_f16x3_set_clock_probe, vfn_train_step, vfn_linear_rows_dx_sums).  The Python binding reads this constant from this file and refuses a library that reports another. */
-#define VFN_ABI_VERSION 3
+ * vfn_abi_struct_bytes; 3: vfn_f16x3_set_clock_probe, vfn_train_step, vfn_linear_rows_dx_sums; 4: the session form of vfn_train_step —
+ * VFN_TRAIN_RENDER / VFN_TRAIN_BACKWARD, vfn_train_step_workspace_layout, vfn_train_step_supervision_points / _forward / _backward).  The Python
+ * binding reads this constant from this file and refuses a library that reports another. */
+#define VFN_ABI_VERSION 4
 
 typedef enum vfn_status {
     VFN_OK = 0,
@@ -690,9 +692,40 @@ int vfn_flat_adam_step(float* param, const float* grad, float* exp_avg, float* e
  * Outputs of phase 1 (caller-allocated, the NerfOutput of the step's render): ray_dirs[N,3], z_vals[N,S_t], points[N,S_t,3],
  * normals[N S_t,3], colors[N S_t,3], weights[N,S_t], rgb[N,3], depth[N]; out_terms[8] as vfn_vf_loss_fwd; out_counts[2] (optional) =
  * the number of samples the colour branch was evaluated for (sparse_colours: those with w > 0) and N S_t.  Phase 2: out_norm[2] as
- * vfn_flat_clip_grad_norm.  No allocation, no synchronisation, no host read-back. */
+ * vfn_flat_clip_grad_norm.  No allocation, no synchronisation, no host read-back.
+ *
+ * SESSION FORM (ABI 4): the same step for a caller that makes the reference trainer's calls ONE BY ONE — render(), the two supervision
+ * forwards, the loss, backward(), clip, step (train/vector_field_nerf_train.py:177-260 unchanged, through vf_nerf_amd.dropin) — and still wants
+ * the step's launches: same workspace, same kernels, the caller's own loss in the middle.
+ *   VFN_TRAIN_RENDER    the render() part of phase 1 alone (prep, rays, saving forwards, selection, composite).  sup_rows_reserved (a
+ *                       multiple of 32) rows of the workspace are set aside for supervision batches appended later; their points and
+ *                       upstream-gradient rows are zeroed.
+ *   vfn_train_step_supervision_points / _forward: one supervision batch into rows [row0, row0 + count) of that region (sampled by the call as
+ *                       phase 1 samples them) and its vector-only saving forward over rows [row0, pad32(row0 + count)) (row0 a multiple of 32).
+ *                       With render.streams >= 2 they run on the calling thread's side stream, ordered after this step's prep launch, beside
+ *                       the render's launches, and are joined into `stream` before the call returns.  The caller reads predictions / ground
+ *                       truth / points at the offsets vfn_train_step_workspace_layout reports and leaves the loss's gradient with respect to the
+ *                       predictions in the D_SUP rows.
+ *   VFN_TRAIN_BACKWARD  the backward part of phase 1 alone, from upstream gradients the caller supplies: io->d_rgb_in[N,3], io->d_depth_in[N]
+ *                       (or NULL), io->d_normals_in[N S_t,3] over the SORTED samples (copied into the workspace's DN rows unless it already is
+ *                       that address) and the D_SUP rows.  Gradients are ADDED into flat_grad / g_beta / g_mean / g_scale (the caller's
+ *                       zero_grad() decides what they start from).
+ * vfn_train_step_workspace_layout: out[VFN_TWS_*] for the given sizes — byte offsets into the workspace, or counts. */
 #define VFN_TRAIN_FORWARD_BACKWARD 1
 #define VFN_TRAIN_OPTIMIZER 2
+#define VFN_TRAIN_RENDER 4
+#define VFN_TRAIN_BACKWARD 8
+#define VFN_TRAIN_CLIP 16         /* the two halves of VFN_TRAIN_OPTIMIZER: clip_grad_norm_ (out_norm) ...                 */
+#define VFN_TRAIN_ADAM 32         /* ... and optimizer.step (+ the re-pack), for a caller that makes them as two calls */
+#define VFN_TWS_SUP_PTS 0        /* float[rows][3]  supervision points                                            */
+#define VFN_TWS_SUP_GT 1         /* float[rows][3]  their radial ground truth                                     */
+#define VFN_TWS_SUP_PRED 2       /* float[rows][3]  vector head of the supervision rows                           */
+#define VFN_TWS_D_SUP 3          /* float[rows][3]  upstream gradient of those predictions                        */
+#define VFN_TWS_DN 4             /* float[N S_t][3] upstream gradient of the sorted normals                       */
+#define VFN_TWS_SUP_ROWS 5       /* count: rows of the supervision region                                         */
+#define VFN_TWS_TOTAL_ROWS 6     /* count: points of one fragment-ordered slot                                    */
+#define VFN_TWS_BYTES 7          /* = vfn_train_step_workspace_bytes                                              */
+#define VFN_TWS_COUNT 8
 typedef struct vfn_train_step_params {
     vfn_render_params render;
     vfn_loss_params loss;
@@ -714,6 +747,7 @@ typedef struct vfn_train_step_params {
     float max_norm;
     int32_t sparse_colours;             /* != 0: the colour branch (feature block + rendering net) is evaluated, differentiated and summed into the
                                          * weight gradients only for the samples whose weight is non-zero (see below) */
+    int64_t sup_rows_reserved;          /* session form: rows (a multiple of 32) of the supervision region; 0: pad32(n_sup (border + center)) */
 } vfn_train_step_params;
 typedef struct vfn_train_step_io {
     const vfn_net_geom* vf_geom; const vfn_net_geom* rn_geom;
@@ -734,9 +768,25 @@ typedef struct vfn_train_step_io {
     float* ray_dirs; float* z_vals; float* points; float* normals; float* colors; float* weights; float* rgb; float* depth;
     float* out_terms; float* out_norm;
     float* out_counts;                                                                        /* optional [2]: samples the colour branch ran on, all samples */
+    const float* d_rgb_in; const float* d_depth_in; const float* d_normals_in;                /* VFN_TRAIN_BACKWARD: the caller's upstream gradients */
 } vfn_train_step_io;
 int64_t vfn_train_step_workspace_bytes(const vfn_train_step_params* p, const vfn_net_geom* vf_geom, const vfn_net_geom* rn_geom);
 int vfn_train_step(const vfn_train_step_params* p, const vfn_train_step_io* io, void* stream);
+int vfn_train_step_workspace_layout(const vfn_train_step_params* p, const vfn_net_geom* vf_geom, const vfn_net_geom* rn_geom, int64_t* out, int32_t n_out);
+/* vfn_sample_sphere_shell into rows [row0, row0 + count) of the open step's supervision region (points and ground truth).  The centre is
+ * given BY VALUE (cx, cy, cz) — then, with Philox draws (u == NULL), the launch depends on nothing the caller's stream produced after the
+ * step's prep and runs on the side stream — or as a device pointer centroid_dev / with supplied draws u[count,3], and then on `stream`.
+ * Returns 1 (not an error) when it ran on the side stream, 0 when on `stream`: pass that as on_side to the forward of the same rows.
+ * vfn_train_step_supervision_forward: the vector-only saving forward over rows [row0, pad32(row0 + count)), predictions into the SUP_PRED rows. */
+int vfn_train_step_supervision_points(const vfn_train_step_params* p, const vfn_train_step_io* io, int32_t inward, float r_min, float r_max,
+                                      float cx, float cy, float cz, const float* centroid_dev, int64_t row0, int64_t count, const float* u,
+                                      uint64_t seed, uint64_t offset, void* stream);
+int vfn_train_step_supervision_forward(const vfn_train_step_params* p, const vfn_train_step_io* io, int64_t row0, int64_t count, int32_t on_side,
+                                       void* stream);
+/* The backward of supervision rows [row0, pad32(row0 + count)) ALONE (their upstream gradient in the D_SUP rows): the vector-only chain and the
+ * vector-field net's weight gradients of those rows, added into flat_grad; the D_SUP rows are zeroed afterwards.  For a backward pass that
+ * never reaches VFN_TRAIN_BACKWARD (a loss that uses the supervision predictions only). */
+int vfn_train_step_supervision_backward(const vfn_train_step_params* p, const vfn_train_step_io* io, int64_t row0, int64_t count, void* stream);
 
 /* =============================================================================================
  * Networks in TRAINING mode: nn.BatchNorm1d with batch statistics (vector_field_network.py:146-208 and

@@ -195,6 +195,66 @@ def test_one_call_step_replays_the_reference_trainer_steps(colours):
     assert abs(model.optimizer.param_groups[0]["lr"] - float(d["final_lr"])) < 1e-15
 
 
+@pytest.mark.parametrize("colours", ["sparse", "dense"])
+def test_reference_call_sequence_replays_the_reference_trainer_steps(colours):
+    """VERDICT r04 next 1(a).  The reference's OWN train_epoch call sequence — render, functions.sample_border_points,
+    vector_field_network(points)[:, :3], functions.get_center_indices_and_gt, functions.sample_center_points, the second network call, the
+    torch.cat's, VFLoss, optimizer.zero_grad, backward, torch.nn.utils.clip_grad_norm_(model.parameters(), clip), optimizer.step,
+    scheduler.step, loss.item() (train/vector_field_nerf_train.py:177-275, restated call for call in tools/reference_sequence.py on the
+    names vf_nerf_amd.dropin installs) — replayed on the steps recorded from the reference's trainer (tests/golden/trainer_steps.npz),
+    and it must TAKE THE STEP SESSION: the render and the backward one C call each on the training step's workspace (with the sparse
+    colour branch by default), the supervision forwards on that workspace's rows, the centre-ball rows selected inside the loss kernels.
+    Held to the bounds of the one-call replay above."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from reference_sequence import ReferenceLoop, StandInDataset
+    from vf_nerf_amd import stepengine
+    fx, d = load_trainer_fixture()
+    model = build_model(fx, d, device=DEV)
+    model.sparse_colour_training = colours == "sparse"
+    model.scheduler = torch.optim.lr_scheduler.ExponentialLR(model.optimizer, lr_gamma(fx))
+    crit = vloss.VFLoss(SimpleNamespace(depth_loss_clamp=0.5, norm_smaller_than_one_start=11000, directional_derivatives_start=100),
+                        SimpleNamespace(rgb=2.0, depth=0.5, unit_norm=0.1, supervision=1.0, norm_smaller_than_one=0.1, directional_derivatives=0.0))
+    loop = ReferenceLoop(model, crit, StandInDataset(fx["centroid"], fx["far"]), fx["border_radius"])
+    _, oracle_grads = _oracle_run(fx, d)
+    lr = fx["lr"]
+    eng = stepengine.StepEngine.of(model)
+    for t, b in enumerate(trainer_batches(fx, d, device=DEV)):
+        supervision.replay_uniforms(b["border_u"], b["center_u"])
+        loop.render_uniforms = {k: b[k] for k in ("u_coarse", "u_fine", "u_add")}
+        lr_now = model.optimizer.param_groups[0]["lr"]
+        data = {"uv": b["uv"].unsqueeze(0), "intrinsics": b["intrinsics"].unsqueeze(0), "pose": b["pose"].unsqueeze(0),
+                "rgb": b["rgb_gt"].unsqueeze(0), "depth": b["depth_gt"].unsqueeze(0)}
+        loss, terms = loop(data, fx["epoch"])
+        session = eng.session
+        assert eng.why_not is None and session is not None and session.backward_done, eng.why_not
+        assert len(session.regions) == 2 and all(r["forwarded"] and not r["pending"] for r in session.regions.values())
+        assert session.ray_centre is not None and session.ray_centre["consumed"]
+        out = loop.last_outputs
+        same_z = bool(torch.equal(out.z_vals.cpu(), d[f"s{t}.out.z_vals"]))
+        e_terms = float((torch.tensor([terms[k] for k in vloss._NAMES], dtype=torch.float64) - d[f"s{t}.loss_terms"]).abs().max())
+        e_loss = abs(float(loss) - float(d[f"s{t}.loss"])) / max(1.0, float(d[f"s{t}.loss"]))
+        e_clip = abs(float(loop.last_total_norm) - float(d[f"s{t}.clip_total_norm"])) / float(d[f"s{t}.clip_total_norm"])
+        nets = {"vf": model.vector_field_network, "rn": model.rendering_network}
+        worst_w = 0.0
+        for net, key, how in TRAINER_WATCH:
+            got = watched_slice(dict(nets[net].named_parameters())[key].detach().cpu(), how)
+            g = oracle_grads[t][f"{net}.{key}"]
+            sig = g.abs() > 1e-2 * g.abs().max()
+            worst_w = max(worst_w, float((got - d[f"s{t}.after.{net}.{key}"]).abs()[sig].max()))
+        print(f"[reference call sequence, {colours} colours] step {t}: depths identical {same_z}; loss terms |d| {e_terms:.2e}; total rel {e_loss:.2e}; "
+              f"clip norm rel {e_clip:.2e}; watched weights (significant gradients) off by {worst_w / lr:.3f} lr")
+        assert abs(lr_now - float(d[f"s{t}.lr"])) < 1e-12
+        if t == 0:
+            assert same_z and e_terms < 1e-4 and e_loss < 1e-4 and e_clip < 1e-3 and worst_w < 0.02 * lr + 1e-7
+        elif t == 1:
+            assert same_z and e_terms < 1e-3 and e_clip < 0.5 and worst_w < 4.0 * lr
+        else:
+            assert e_loss < 0.1
+    assert float(model.optimizer.state[model.vector_field_network.layers[8].weight]["step"]) == 2 * fx["steps"]
+    assert abs(model.optimizer.param_groups[0]["lr"] - float(d["final_lr"])) < 1e-15
+
+
 def test_dropin_wraps_clip_grad_norm_for_the_duplicated_list():
     """`import vf_nerf_amd.dropin` leaves the trainer's own `torch.nn.utils.clip_grad_norm_(model.parameters(), c)` line
     (train/vector_field_nerf_train.py:254-255) correct on the GPU: duplicated device parameters go through the sequential

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     handle = lib.load()
     for name in declared:
         assert hasattr(handle, name), name
-    assert handle.vfn_abi_version() == lib.ABI_VERSION == 3
+    assert handle.vfn_abi_version() == lib.ABI_VERSION == 4
 
 
 def test_binding_signatures_come_from_the_header():

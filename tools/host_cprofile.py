@@ -1,22 +1,53 @@
-"""cProfile of 100 training steps (trainer.TrainStep, 1 024 rays x 128): where the HOST time of a step goes, function by function
-(tools/host_profile.py has the per-phase view).  `run_backward` carrying ~1 ms of its own means the host is waiting for the device
-there, i.e. the step is device-bound:    python tools/host_cprofile.py"""
-import sys, cProfile, pstats, torch
-sys.path.insert(0, '.')
-import bench
-from vf_nerf_amd import trainer, supervision
-dev = torch.device("cuda:0")
-model, uv, pose, K = bench.build_scene(dev, 1024, 64, 64, 0)
-teacher, _, _, _ = bench.build_scene(dev, 16, 64, 64, seed=0, perturb=False, weight_seed=1)
-teacher.precision = "fp32"
-with torch.no_grad():
-    t = teacher.render(pose, uv, K, 0)
-rgb_gt, depth_gt = t.coarse_rgb_values.clone(), t.coarse_depth_map.clone()
-step = trainer.TrainStep(model, (0.0, 0.0, 0.6), border_radius=0.05, far=1.0)
-for _ in range(10): step(pose, uv, K, rgb_gt, depth_gt)
+#!/usr/bin/env python3
+"""cProfile of the host side of a training step issued as the reference trainer's own call sequence (tools/reference_sequence.py) or as
+trainer.TrainStep's one C call: where the Python-side time of a step goes.
+
+    python tools/host_cprofile.py [rays] [steps] [drop_in|one_call] [top]"""
+import cProfile
+import io
+import os
+import pstats
+import sys
+from types import SimpleNamespace
+
+rays = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+mode = sys.argv[3] if len(sys.argv) > 3 else "drop_in"
+top = int(sys.argv[4]) if len(sys.argv) > 4 else 45
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import reference_sequence  # noqa: E402
+from vf_nerf_amd import loss as vloss, supervision, trainer  # noqa: E402
+
+dev = torch.device("cuda", 0)
+built = bench.build_trained_scene(dev, rays, 64, 64, seed=0)
+model, uv, pose, K, info = built
+model._bench_trained_weights = info
+rgb_gt, depth_gt, centroid, radius = bench.training_targets(model, uv, pose, K, dev, 64, 64)
+supervision.manual_seed(7)
+if mode == "drop_in":
+    crit = vloss.VFLoss(SimpleNamespace(**trainer.SHIPPED_LOSS_CONFIG), SimpleNamespace(**trainer.SHIPPED_LOSS_WEIGHTS))
+    loop = reference_sequence.ReferenceLoop(model, crit, reference_sequence.StandInDataset(centroid, 1.0), radius, sync_each_step=False)
+    data = {"uv": uv.unsqueeze(0), "intrinsics": K.unsqueeze(0), "pose": pose.unsqueeze(0), "rgb": rgb_gt.unsqueeze(0), "depth": depth_gt.unsqueeze(0)}
+    fn = lambda: loop(data, 0)  # noqa: E731
+else:
+    step = trainer.TrainStep(model, centroid, border_radius=radius, far=1.0)
+    fn = lambda: step(pose, uv, K, rgb_gt, depth_gt, epoch=0)  # noqa: E731
+for _ in range(10):
+    fn()
 torch.cuda.synchronize()
-pr = cProfile.Profile(); pr.enable()
-for _ in range(100): step(pose, uv, K, rgb_gt, depth_gt)
+prof = cProfile.Profile()
+prof.enable()
+for _ in range(steps):
+    torch.cuda.synchronize()          # empty queue: the time below is issue time, not back-pressure
+    fn()
+prof.disable()
 torch.cuda.synchronize()
-pr.disable()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+for key in ("tottime", "cumulative"):
+    buf = io.StringIO()
+    pstats.Stats(prof, stream=buf).sort_stats(key).print_stats(top)
+    print(f"==== {mode}, {rays} rays, {steps} steps, sorted by {key} (divide by {steps} for per-step) ====")
+    print(buf.getvalue())

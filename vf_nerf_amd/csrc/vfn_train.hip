@@ -102,6 +102,10 @@ int carve(void* workspace, const vfn_train_step_params* p, const vfn_net_geom* v
     w->m_c = n * sc; w->m = n * st;
     w->m_sup = (long long)p->n_sup * ((p->border ? 1 : 0) + (p->center ? 1 : 0));
     w->m_sup_pad = pad32(w->m_sup);
+    if (p->sup_rows_reserved > 0) {            // session form: the caller appends its batches to a region of this many rows
+        if (p->sup_rows_reserved % 32) { vfn_set_error("vfn_train_step: sup_rows_reserved must be a multiple of 32"); return VFN_ERR_INVALID; }
+        w->m_sup = w->m_sup_pad = p->sup_rows_reserved;
+    }
     // sparse colour branch: region 2 can hold every sample (the count of samples with w > 0 is known to the device only)
     w->cap = p->sparse_colours ? pad32(w->m) : 0;
     w->r2_first = w->m + w->m_sup_pad;
@@ -189,9 +193,9 @@ __global__ void vfn_train_scalar_grads_kernel(const float* dscal, float* g_beta,
 // one side stream (+ fork / join events) per host thread and device, made on first use: the supervision batch's forward and
 // chain are independent of the fine pass until the loss / the weight gradients, and at the reference's batch size they are
 // 0.8-round launches that leave the chip mostly idle when they run alone
-struct Side { hipStream_t s; hipEvent_t fork, join; int dev; };
+struct Side { hipStream_t s; hipEvent_t fork, join; int dev; const void* armed_ws; };
 Side* side_stream() {
-    static thread_local Side side = {nullptr, nullptr, nullptr, -1};
+    static thread_local Side side = {nullptr, nullptr, nullptr, -1, nullptr};
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     if (side.dev != dev) {
@@ -224,6 +228,224 @@ int join_into(Side* sd, hipStream_t into) {
         if (rc != VFN_OK) return rc;     \
     } while (0)
 
+
+// ---- the parts of a step (shared by vfn_train_step's whole-step phases and the session form) ------------------------------------------------
+struct StepCtx {
+    const vfn_train_step_params* p;
+    const vfn_train_step_io* io;
+    Ws w;
+    hipStream_t s, ss;            // the caller's stream; the side stream (== s without one)
+    Side* sd;
+    int n, sc, nf, st;
+    bool sparse;
+    float* saved_f;
+    vfn_density_params dp;        // n_samples = S_t after the render part
+};
+
+int step_open(StepCtx& c, const vfn_train_step_params* p, const vfn_train_step_io* io, void* stream, bool want_side) {
+    int rc;
+    c.p = p; c.io = io; c.s = (hipStream_t)stream;
+    c.n = p->render.n_rays; c.sc = p->render.n_coarse; c.nf = p->render.n_fine; c.st = c.sc + c.nf;
+    STEP(carve(io->workspace, p, io->vf_geom, io->rn_geom, &c.w));
+    VFN_REQUIRE(c.w.total < (1ll << 21), "vfn_train_step: at most 2097151 workspace points per step (%lld)", c.w.total);
+    c.sd = (want_side && p->render.streams >= 2) ? side_stream() : nullptr;
+    c.ss = c.sd ? c.sd->s : c.s;
+    c.sparse = p->sparse_colours != 0;
+    c.saved_f = reinterpret_cast<float*>(c.w.saved);
+    c.dp = p->render.density;
+    c.dp.n_rays = c.n; c.dp.n_samples = c.st;
+    return VFN_OK;
+}
+
+int step_prep(StepCtx& c, bool session) {
+    const vfn_train_step_params* p = c.p; const vfn_train_step_io* io = c.io; Ws& w = c.w;
+    int rc;
+    const int pad_floats = session ? 0 : (int)((w.m_sup_pad - w.m_sup) * 3);
+    PrepArgs pa{io->beta, io->mean, io->scale, w.scal, w.dscal, w.centroid, p->sup_centroid[0], p->sup_centroid[1], p->sup_centroid[2],
+                w.sup_pts + w.m_sup * 3, w.sup_gt + w.m_sup * 3, w.d_sup + w.m_sup * 3, pad_floats};
+    hipLaunchKernelGGL(vfn_train_prep_kernel, dim3(1), dim3(128), 0, c.s, pa);
+    STEP(vfn_check_launch("vfn_train_step (prep)"));
+    if (session && w.m_sup_pad > 0) {
+        // the caller appends batches of any size: every row it does not fill is a point at the origin with a zero upstream gradient
+        if (hipMemsetAsync(w.sup_pts, 0, (size_t)w.m_sup_pad * 3 * sizeof(float), c.s) != hipSuccess ||
+            hipMemsetAsync(w.d_sup, 0, (size_t)w.m_sup_pad * 3 * sizeof(float), c.s) != hipSuccess) {
+            vfn_set_error("vfn_train_step: could not clear the supervision rows");
+            return VFN_ERR_LAUNCH;
+        }
+    }
+    return VFN_OK;
+}
+
+// the supervision batch of the whole-step form: both shells sampled here, one vector-only saving forward (on c.ss)
+int step_supervision(StepCtx& c) {
+    const vfn_train_step_params* p = c.p; const vfn_train_step_io* io = c.io; Ws& w = c.w;
+    int rc;
+    long long row = 0;
+    if (p->border && p->n_sup > 0) {
+        STEP(vfn_sample_sphere_shell(p->n_sup, p->border_r_min, p->border_r_max, w.centroid, 1, io->sup_u_border, p->sup_seed, p->sup_offset,
+                                     w.sup_pts, w.sup_gt, c.ss));
+        row += p->n_sup;
+    }
+    if (p->center && p->n_sup > 0) {
+        STEP(vfn_sample_sphere_shell(p->n_sup, 0.0f, p->sup_radius, w.centroid, 0, io->sup_u_center, p->sup_seed,
+                                     p->sup_offset + (io->sup_u_border || !p->border ? 0 : (uint64_t)p->n_sup), w.sup_pts + row * 3,
+                                     w.sup_gt + row * 3, c.ss));
+        row += p->n_sup;
+    }
+    if (w.m_sup_pad > 0)
+        STEP(vfn_vf_mlp16_fwd_train_at(io->vf_geom, io->vf_packed16, w.sup_pts, w.m_sup_pad, 0, w.sup_pred, c.saved_f, w.aux_vf, w.masks,
+                                       p->save_flags, w.m, w.total, c.ss));
+    return VFN_OK;
+}
+
+// render() under autograd: one vector-field evaluation per distinct sample (backward.StoredFinePass)
+int step_render(StepCtx& c) {
+    const vfn_train_step_params* p = c.p; const vfn_train_step_io* io = c.io; Ws& w = c.w;
+    const vfn_render_params& r = p->render;
+    const int n = c.n, sc = c.sc, nf = c.nf, st = c.st;
+    hipStream_t s = c.s;
+    float* saved_f = c.saved_f;
+    int rc;
+    const int gen_c = r.perturb_coarse && !io->u_coarse, gen_f = r.perturb_fine && !io->u_fine, gen_a = !io->u_add;
+    const long long base_f = gen_c ? (long long)n * sc : 0, base_a = base_f + (gen_f ? (long long)n * nf : 0);
+    vfn_raygen_params rq = {n, sc, r.pose_is_quat, r.near_coarse, r.far_coarse};
+    STEP(vfn_internal_raygen(&rq, io->uv, io->pose, io->intrinsics, io->intrinsics, io->t_vals, io->far_coarse_per_ray,
+                             r.perturb_coarse ? io->u_coarse : nullptr, gen_c, 0, r.seed, r.offset, w.directions, io->ray_dirs, w.cam_loc, w.z_c,
+                             w.pts_c, s));
+    const bool sparse = c.sparse;
+    if (sparse)      // region 1: the vector-field net alone (vector head, no feature block) on every sample
+        STEP(vfn_vf_mlp16_fwd_train_at(io->vf_geom, io->vf_packed16, w.pts_c, w.m_c, 0, w.normals_s, saved_f, w.aux_vf, w.masks, p->save_flags, 0,
+                                       w.total, s));
+    else
+        STEP(vfn_vf_render_fused16_fwd_train_at(io->vf_geom, io->vf_packed16, io->rn_geom, io->rn_packed16, w.pts_c, io->ray_dirs, w.m_c, sc,
+                                                w.normals_s, w.colors_s, saved_f, w.aux_vf, w.aux_rn, w.masks, p->save_flags, 0, w.total,
+                                                p->forward_products, s));
+    vfn_density_params dp = r.density;
+    dp.n_rays = n; dp.n_samples = sc;
+    vfn_fine_params fp = {n, sc, nf, r.near_fine, r.far_fine, r.fine_range, r.window_step, r.span};
+    STEP(vfn_internal_density_fine(&dp, w.normals_s, io->ray_dirs, w.z_c, w.scal, &fp, w.directions, w.cam_loc, io->far_fine_per_ray,
+                                   r.perturb_fine ? io->u_fine : nullptr, io->u_add, gen_f, gen_a, base_f, base_a, r.seed, r.offset, io->z_vals,
+                                   io->points, w.src, w.new_pts, w.dst, w.m_c, s));
+    dp.n_samples = st;
+    if (sparse) {
+        STEP(vfn_vf_mlp16_fwd_train_at(io->vf_geom, io->vf_packed16, w.new_pts, w.m - w.m_c, 0, w.normals_s + w.m_c * 3, saved_f, w.aux_vf, w.masks,
+                                       p->save_flags, w.m_c, w.total, s));
+        // normals to their sorted positions, weights (no colours yet)
+        STEP(vfn_scatter_rows3(w.normals_s, nullptr, w.dst, w.m, io->normals, nullptr, s));
+        STEP(vfn_ray_density_weights(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, nullptr, nullptr, io->weights, nullptr, nullptr, nullptr, s));
+        // the samples with w > 0, compacted in ray order; their count stays on the device
+        STEP(vfn_internal_select_positive(io->weights, n, st, io->points, io->ray_dirs, w.cnt, w.off, w.k_dev, w.sel_sorted, w.pts_sel, w.dirs_sel, s));
+        // region 2: the fused saving forward (vector-field net + rendering net) on the selected samples only
+        STEP(vfn_internal_fused16_fwd_train_at(io->vf_geom, io->vf_packed16, io->rn_geom, io->rn_packed16, w.pts_sel, w.dirs_sel, w.cap, w.k_dev, 1,
+                                               w.normals_sel, w.colors_sel, saved_f, w.aux_vf, w.aux_rn, w.masks, p->save_flags, w.r2_first, w.total,
+                                               p->forward_products, s));
+        // colours: zero where w = 0 (they multiply a zero weight), the selected ones at their sorted positions; composite
+        if (hipMemsetAsync(io->colors, 0, (size_t)w.m * 3 * sizeof(float), s) != hipSuccess) {
+            vfn_set_error("vfn_train_step: could not clear the colours");
+            return VFN_ERR_LAUNCH;
+        }
+        STEP(vfn_internal_rows3_by_index(w.colors_sel, w.sel_sorted, w.k_dev, w.cap, io->colors, 0, s));
+        STEP(vfn_ray_density_weights(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, nullptr, io->weights, nullptr, io->rgb, io->depth, s));
+    } else {
+        STEP(vfn_vf_render_fused16_fwd_train_at(io->vf_geom, io->vf_packed16, io->rn_geom, io->rn_packed16, w.new_pts, io->ray_dirs, w.m - w.m_c, nf,
+                                                w.normals_s + w.m_c * 3, w.colors_s + w.m_c * 3, saved_f, w.aux_vf, w.aux_rn, w.masks, p->save_flags,
+                                                w.m_c, w.total, p->forward_products, s));
+        // every sample (proposal and new) moves from storage order to its sorted position on the way into the composite launch
+        STEP(vfn_internal_composite_gather(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, w.src, w.normals_s, w.colors_s, w.m,
+                                           io->weights, io->rgb, io->depth, s));
+    }
+    return VFN_OK;
+}
+
+// backward: supervision chain, per-ray backward, fine chain, weight gradients, the density's scalar gradients; the loss's d normals is in
+// w.dn (where the per-ray backward ADDS the density path's share), its d supervision predictions in w.d_sup
+int step_backward(StepCtx& c, const float* d_rgb, const float* d_depth) {
+    const vfn_train_step_params* p = c.p; const vfn_train_step_io* io = c.io; Ws& w = c.w;
+    hipStream_t s = c.s, ss = c.ss;
+    Side* sd = c.sd;
+    const bool sparse = c.sparse;
+    float* saved_f = c.saved_f;
+    const vfn_density_params& dp = c.dp;
+    int rc;
+    const float* feats = saved_f + (size_t)(w.vf_h - 1) * (w.slot_bytes / 4);           // the tanh'ed feature slot, row-major fp32
+    const size_t rn_off = (size_t)w.vf_h * w.slot_bytes;
+    if (sparse) {
+        // per-ray backward on the sorted samples: d colours = w d rgb (zero wherever w is), d normals += the density path's share
+        STEP(vfn_ray_density_weights_bwd(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, d_rgb, d_depth, nullptr, w.dn, w.dc, w.dscal, s));
+        STEP(vfn_scatter_rows3(w.dn, nullptr, w.src, w.m, w.dn_s, nullptr, s));       // row src[i] of region 1 is sorted sample i
+        STEP(vfn_internal_rows3_by_index(w.dc, w.sel_sorted, w.k_dev, w.cap, w.dc_sel, 1, s));
+        if (hipMemsetAsync(w.zero3, 0, (size_t)w.cap * 3 * sizeof(float), s) != hipSuccess) {
+            vfn_set_error("vfn_train_step: could not clear the zero rows");
+            return VFN_ERR_LAUNCH;
+        }
+        // Region 2's chain and the rendering net's weight gradients are small launches (a few percent of the samples: 0.6 rounds of
+        // workgroups at 4096 rays) that touch nothing region 1's chain and weight gradients touch (other rows of the workspace, other
+        // parameters' gradients, their own scratch): they run on the side stream beside them.
+        const size_t r2_off = (size_t)(w.r2_first / 32) * GROUP_BYTES;
+        if (sd) STEP(fork_to(sd, s));
+        // the fused chain over region 2: d colours in, no gradient at the vector head (region 1 carries it)
+        STEP(vfn_internal_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, io->rn_geom, io->rn_packed_bwd16, io->rn_head_w, feats,
+                                               w.masks, w.dy, p->dy_flags, w.dc_sel, w.colors_sel, w.zero3, w.normals_sel, nullptr, 3, w.cap, w.k_dev,
+                                               w.dz_rgb, w.dz_vec, w.r2_first, w.total, ss));
+        // weight gradients: the rendering net over region 2; the vector-field net's hidden layers + head over region 1 and the
+        // supervision rows, its hidden layers + feature block over region 2 (the head's gradient there is zero)
+        STEP(vfn_internal_net_weight_grads_frag_part(VFN_NET_RENDER, io->rn_geom, io->rn_wgrad, w.saved + rn_off + r2_off, w.dy + rn_off + r2_off,
+                                                     (int64_t)w.slot_bytes, p->dy_form, p->x_form, feats + w.r2_first * 256, w.aux_rn + w.r2_first * 40,
+                                                     w.dz_rgb + w.r2_first * 4, w.cap, w.k_dev, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD, 1,
+                                                     w.scratch_rn, ss));
+        // ONE vector-only chain over region 1 and the supervision rows (d normals | d supervision predictions)
+        STEP(vfn_mlp_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, nullptr, nullptr, nullptr, feats, w.masks, w.dy, p->dy_flags,
+                                          nullptr, nullptr, w.dn_s, w.normals_s, nullptr, 3, w.m + w.m_sup_pad, nullptr, w.dz_vec, 0, w.total, s));
+        STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form, nullptr,
+                                            w.aux_vf, w.dz_vec, w.m + w.m_sup_pad, VFN_WGRAD_LAYERS | VFN_WGRAD_HEAD, 1, w.scratch_vf, s));
+        // (the vector-field net's gradients of region 2 are ADDED to the same tensors: after both of the above)
+        if (sd) STEP(join_into(sd, s));
+        STEP(vfn_internal_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved + r2_off, w.dy + r2_off, (int64_t)w.slot_bytes,
+                                                     p->dy_form, p->x_form, nullptr, w.aux_vf + w.r2_first * 40, w.dz_vec + w.r2_first * 4, w.cap,
+                                                     w.k_dev, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES, 1, w.scratch_vf, s));
+    } else {
+        if (w.m_sup_pad > 0) {
+            // (beside the per-ray backward and the fine pass's chain when there is a side stream; joined in front of the weight gradients)
+            if (sd) STEP(fork_to(sd, s));
+            STEP(vfn_mlp_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, nullptr, nullptr, nullptr, feats, w.masks, w.dy,
+                                              p->dy_flags, nullptr, nullptr, w.d_sup, w.sup_pred, nullptr, 3, w.m_sup_pad, nullptr, w.dz_vec, w.m,
+                                              w.total, ss));
+        }
+        STEP(vfn_ray_density_weights_bwd(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, d_rgb, d_depth, nullptr, w.dn, w.dc, w.dscal, s));
+        // row src[i] of the workspace is sorted sample i: gradients to storage order
+        STEP(vfn_scatter_rows3(w.dn, w.dc, w.src, w.m, w.dn_s, w.dc_s, s));
+        STEP(vfn_mlp_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, io->rn_geom, io->rn_packed_bwd16, io->rn_head_w, feats,
+                                          w.masks, w.dy, p->dy_flags, w.dc_s, w.colors_s, w.dn_s, w.normals_s, nullptr, 3, w.m, w.dz_rgb, w.dz_vec, 0,
+                                          w.total, s));
+        STEP(vfn_net_weight_grads_frag_part(VFN_NET_RENDER, io->rn_geom, io->rn_wgrad, w.saved + rn_off, w.dy + rn_off, (int64_t)w.slot_bytes,
+                                            p->dy_form, p->x_form, feats, w.aux_rn, w.dz_rgb, w.m,
+                                            VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD, 1, w.scratch_rn, s));
+        // vector-field net: hidden layers + head over ALL rows (fine pass + supervision), the feature block over the fine pass's rows
+        if (sd && w.m_sup_pad > 0) STEP(join_into(sd, s));
+        if (w.m_sup_pad > 0) {
+            STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form,
+                                                nullptr, w.aux_vf, w.dz_vec, w.m + w.m_sup_pad, VFN_WGRAD_LAYERS | VFN_WGRAD_HEAD, 1, w.scratch_vf, s));
+            STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form,
+                                                nullptr, w.aux_vf, w.dz_vec, w.m, VFN_WGRAD_FEATURES, 1, w.scratch_vf, s));
+        } else {
+            STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form,
+                                                nullptr, w.aux_vf, w.dz_vec, w.m, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD, 1,
+                                                w.scratch_vf, s));
+        }
+    }
+    hipLaunchKernelGGL(vfn_train_scalar_grads_kernel, dim3(1), dim3(64), 0, s, w.dscal, io->g_beta, io->g_mean, io->g_scale,
+                       sparse ? w.k_dev : nullptr, (float)w.m, io->out_counts);
+    return vfn_check_launch("vfn_train_step (density scalar gradients)");
+}
+
+bool forward_pointers_ok(const vfn_train_step_io* io) {
+    return io->workspace && io->vf_packed16 && io->rn_packed16 && io->beta && io->mean && io->scale && io->uv && io->pose && io->intrinsics &&
+           io->t_vals && io->ray_dirs && io->z_vals && io->points && io->normals && io->colors && io->weights && io->rgb && io->depth;
+}
+bool backward_pointers_ok(const vfn_train_step_io* io) {
+    return io->workspace && io->vf_packed_bwd16 && io->rn_packed_bwd16 && io->vf_wgrad && io->rn_wgrad && io->vf_head_w && io->rn_head_w && io->g_beta &&
+           io->g_mean && io->g_scale && io->flat_grad && io->ray_dirs && io->z_vals && io->normals && io->colors;
+}
 }  // namespace
 
 extern "C" int64_t vfn_train_step_workspace_bytes(const vfn_train_step_params* p, const vfn_net_geom* vf_geom, const vfn_net_geom* rn_geom) {
@@ -233,113 +455,148 @@ extern "C" int64_t vfn_train_step_workspace_bytes(const vfn_train_step_params* p
     return rc != VFN_OK ? rc : (int64_t)w.bytes;
 }
 
+extern "C" int vfn_train_step_workspace_layout(const vfn_train_step_params* p, const vfn_net_geom* vf_geom, const vfn_net_geom* rn_geom, int64_t* out,
+                                               int32_t n_out) {
+    VFN_REQUIRE(p && vf_geom && rn_geom && out && n_out >= VFN_TWS_COUNT, "vfn_train_step_workspace_layout: NULL argument or fewer than %d outputs",
+                VFN_TWS_COUNT);
+    VFN_REQUIRE(p->render.n_rays >= 1 && p->render.n_coarse >= 1 && p->render.n_fine >= 2 && p->n_sup >= 0, "vfn_train_step_workspace_layout: bad sizes");
+    // carve() hands out NULL pointers for a NULL base: the offsets are taken against a dummy base that is never dereferenced
+    unsigned char* base = reinterpret_cast<unsigned char*>(uintptr_t(1) << 40);
+    Ws v;
+    const int rc = carve(base, p, vf_geom, rn_geom, &v);
+    if (rc != VFN_OK) return rc;
+    auto off = [&](const void* q) { return (int64_t)(reinterpret_cast<const unsigned char*>(q) - base); };
+    out[VFN_TWS_SUP_PTS] = off(v.sup_pts);
+    out[VFN_TWS_SUP_GT] = off(v.sup_gt);
+    out[VFN_TWS_SUP_PRED] = off(v.sup_pred);
+    out[VFN_TWS_D_SUP] = off(v.d_sup);
+    out[VFN_TWS_DN] = off(v.dn);
+    out[VFN_TWS_SUP_ROWS] = v.m_sup_pad;
+    out[VFN_TWS_TOTAL_ROWS] = v.total;
+    out[VFN_TWS_BYTES] = (int64_t)v.bytes;
+    return VFN_OK;
+}
+
+// Which of the calling thread's side-stream state belongs to the step that is open on `workspace` (the session form's later calls)
+static Side* armed_side(const vfn_train_step_params* p, const void* workspace) {
+    if (p->render.streams < 2) return nullptr;
+    Side* sd = side_stream();
+    return (sd && sd->armed_ws == workspace) ? sd : nullptr;
+}
+
+__global__ void vfn_train_set3_kernel(float* dst, float x, float y, float z) {
+    if (threadIdx.x == 0) { dst[0] = x; dst[1] = y; dst[2] = z; }
+}
+
+extern "C" int vfn_train_step_supervision_points(const vfn_train_step_params* p, const vfn_train_step_io* io, int32_t inward, float r_min, float r_max,
+                                                 float cx, float cy, float cz, const float* centroid_dev, int64_t row0, int64_t count, const float* u,
+                                                 uint64_t seed, uint64_t offset, void* stream) {
+    VFN_REQUIRE(p && io && io->vf_geom && io->rn_geom && io->workspace, "vfn_train_step_supervision_points: NULL argument");
+    Ws w;
+    int rc;
+    STEP(carve(io->workspace, p, io->vf_geom, io->rn_geom, &w));
+    VFN_REQUIRE(row0 >= 0 && count >= 0 && row0 + count <= w.m_sup_pad, "vfn_train_step_supervision_points: rows [%lld, %lld) of %lld", (long long)row0,
+                (long long)(row0 + count), w.m_sup_pad);
+    if (count == 0) return VFN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    // operands the caller's stream may have produced after the step's prep (a device centroid, supplied draws): on the caller's stream
+    Side* sd = (centroid_dev || u) ? nullptr : armed_side(p, io->workspace);
+    hipStream_t ss = sd ? sd->s : s;
+    const float* c = centroid_dev;
+    if (!c) {
+        float* slot = w.centroid + 4;           // (the carve rounds the centroid block up to 256 bytes: slot 1 of it)
+        hipLaunchKernelGGL(vfn_train_set3_kernel, dim3(1), dim3(64), 0, ss, slot, cx, cy, cz);
+        STEP(vfn_check_launch("vfn_train_step_supervision_points (centre)"));
+        c = slot;
+    }
+    STEP(vfn_sample_sphere_shell(count, r_min, r_max, c, inward ? 1 : 0, u, seed, offset, w.sup_pts + row0 * 3, w.sup_gt + row0 * 3, ss));
+    if (sd) { STEP(join_into(sd, s)); return 1; }
+    return VFN_OK;
+}
+
+extern "C" int vfn_train_step_supervision_forward(const vfn_train_step_params* p, const vfn_train_step_io* io, int64_t row0, int64_t count, int32_t on_side,
+                                                  void* stream) {
+    VFN_REQUIRE(p && io && io->vf_geom && io->rn_geom && io->workspace && io->vf_packed16, "vfn_train_step_supervision_forward: NULL argument");
+    VFN_REQUIRE(p->save_flags & 2, "vfn_train_step_supervision_forward: the fragment-ordered workspace only (save_flags bit 1)");
+    Ws w;
+    int rc;
+    STEP(carve(io->workspace, p, io->vf_geom, io->rn_geom, &w));
+    const long long rows = pad32(count);
+    VFN_REQUIRE(row0 >= 0 && row0 % 32 == 0 && count >= 0 && row0 + rows <= w.m_sup_pad,
+                "vfn_train_step_supervision_forward: rows [%lld, %lld) of %lld (row0 must be a multiple of 32)", (long long)row0, (long long)(row0 + rows),
+                w.m_sup_pad);
+    if (count == 0) return VFN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    Side* sd = on_side ? armed_side(p, io->workspace) : nullptr;
+    hipStream_t ss = sd ? sd->s : s;
+    STEP(vfn_vf_mlp16_fwd_train_at(io->vf_geom, io->vf_packed16, w.sup_pts + row0 * 3, rows, 0, w.sup_pred + row0 * 3, reinterpret_cast<float*>(w.saved),
+                                   w.aux_vf, w.masks, p->save_flags, w.m + row0, w.total, ss));
+    if (sd) STEP(join_into(sd, s));
+    return VFN_OK;
+}
+
+extern "C" int vfn_train_step_supervision_backward(const vfn_train_step_params* p, const vfn_train_step_io* io, int64_t row0, int64_t count, void* stream) {
+    VFN_REQUIRE(p && io && io->vf_geom && io->rn_geom && io->workspace && io->vf_packed_bwd16 && io->vf_wgrad && io->vf_head_w && io->flat_grad,
+                "vfn_train_step_supervision_backward: NULL argument");
+    Ws w;
+    int rc;
+    STEP(carve(io->workspace, p, io->vf_geom, io->rn_geom, &w));
+    const long long rows = pad32(count);
+    VFN_REQUIRE(row0 >= 0 && row0 % 32 == 0 && count >= 0 && row0 + rows <= w.m_sup_pad,
+                "vfn_train_step_supervision_backward: rows [%lld, %lld) of %lld (row0 must be a multiple of 32)", (long long)row0, (long long)(row0 + rows),
+                w.m_sup_pad);
+    if (count == 0) return VFN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const float* feats = reinterpret_cast<float*>(w.saved) + (size_t)(w.vf_h - 1) * (w.slot_bytes / 4);
+    const long long first = w.m + row0;
+    const size_t g_off = (size_t)(first / 32) * GROUP_BYTES;
+    STEP(vfn_mlp_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, nullptr, nullptr, nullptr, feats, w.masks, w.dy, p->dy_flags, nullptr,
+                                      nullptr, w.d_sup + row0 * 3, w.sup_pred + row0 * 3, nullptr, 3, rows, nullptr, w.dz_vec, first, w.total, s));
+    STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved + g_off, w.dy + g_off, (int64_t)w.slot_bytes, p->dy_form, p->x_form,
+                                        nullptr, w.aux_vf + first * 40, w.dz_vec + first * 4, rows, VFN_WGRAD_LAYERS | VFN_WGRAD_HEAD, 1, w.scratch_vf, s));
+    if (hipMemsetAsync(w.d_sup + row0 * 3, 0, (size_t)rows * 3 * sizeof(float), s) != hipSuccess) {
+        vfn_set_error("vfn_train_step_supervision_backward: could not clear the upstream rows");
+        return VFN_ERR_LAUNCH;
+    }
+    return VFN_OK;
+}
+
 extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_step_io* io, void* stream) {
     VFN_REQUIRE(p && io && io->vf_geom && io->rn_geom, "vfn_train_step: NULL argument");
     const vfn_render_params& r = p->render;
     VFN_REQUIRE(r.n_rays > 0 && r.n_coarse >= 1 && r.n_fine >= 2, "vfn_train_step: bad sizes (n_rays=%d, n_coarse=%d, n_fine=%d)", r.n_rays,
                 r.n_coarse, r.n_fine);
-    VFN_REQUIRE(p->phases & (VFN_TRAIN_FORWARD_BACKWARD | VFN_TRAIN_OPTIMIZER), "vfn_train_step: phases = %d selects nothing", p->phases);
+    const int all = VFN_TRAIN_FORWARD_BACKWARD | VFN_TRAIN_OPTIMIZER | VFN_TRAIN_RENDER | VFN_TRAIN_BACKWARD | VFN_TRAIN_CLIP | VFN_TRAIN_ADAM;
+    VFN_REQUIRE((p->phases & all) && !(p->phases & ~all), "vfn_train_step: phases = %d selects nothing", p->phases);
+    VFN_REQUIRE(!((p->phases & VFN_TRAIN_FORWARD_BACKWARD) && (p->phases & (VFN_TRAIN_RENDER | VFN_TRAIN_BACKWARD))),
+                "vfn_train_step: VFN_TRAIN_FORWARD_BACKWARD already contains the render and the backward part (phases = %d)", p->phases);
     const int n = r.n_rays, sc = r.n_coarse, nf = r.n_fine, st = sc + nf;
     hipStream_t s = (hipStream_t)stream;
     int rc;
 
-    if (p->phases & VFN_TRAIN_FORWARD_BACKWARD) {
-        VFN_REQUIRE(io->workspace && io->vf_packed16 && io->rn_packed16 && io->vf_packed_bwd16 && io->rn_packed_bwd16 && io->vf_wgrad && io->rn_wgrad &&
-                    io->vf_head_w && io->rn_head_w && io->beta && io->mean && io->scale && io->g_beta && io->g_mean && io->g_scale && io->flat_grad &&
-                    io->uv && io->pose && io->intrinsics && io->t_vals && io->rgb_gt && io->out_terms && io->ray_dirs && io->z_vals && io->points &&
-                    io->normals && io->colors && io->weights && io->rgb && io->depth, "vfn_train_step: NULL argument");
+    if (p->phases & (VFN_TRAIN_FORWARD_BACKWARD | VFN_TRAIN_RENDER | VFN_TRAIN_BACKWARD)) {
+        VFN_REQUIRE(io->workspace, "vfn_train_step: NULL workspace");
         VFN_REQUIRE(((long long)n * sc) % 32 == 0 && ((long long)n * st) % 32 == 0,
                     "vfn_train_step: the proposal samples and all samples must be whole groups of 32 points (%d rays x %d + %d)", n, sc, nf);
         VFN_REQUIRE(p->save_flags & 2, "vfn_train_step: the fragment-ordered workspace only (save_flags bit 1)");
-        VFN_REQUIRE(!p->loss.has_depth || io->depth_gt, "vfn_train_step: has_depth without depth_gt");
-        Ws w;
-        STEP(carve(io->workspace, p, io->vf_geom, io->rn_geom, &w));
-        VFN_REQUIRE(w.total < (1ll << 21), "vfn_train_step: at most 2097151 workspace points per step (%lld)", w.total);
-        const int pad_floats = (int)((w.m_sup_pad - w.m_sup) * 3);
-        PrepArgs pa{io->beta, io->mean, io->scale, w.scal, w.dscal, w.centroid, p->sup_centroid[0], p->sup_centroid[1], p->sup_centroid[2],
-                    w.sup_pts + w.m_sup * 3, w.sup_gt + w.m_sup * 3, w.d_sup + w.m_sup * 3, pad_floats};
-        hipLaunchKernelGGL(vfn_train_prep_kernel, dim3(1), dim3(128), 0, s, pa);
-        STEP(vfn_check_launch("vfn_train_step (prep)"));
+    }
 
+    if (p->phases & VFN_TRAIN_FORWARD_BACKWARD) {
+        VFN_REQUIRE(forward_pointers_ok(io) && backward_pointers_ok(io) && io->rgb_gt && io->out_terms, "vfn_train_step: NULL argument");
+        VFN_REQUIRE(!p->loss.has_depth || io->depth_gt, "vfn_train_step: has_depth without depth_gt");
+        VFN_REQUIRE(p->sup_rows_reserved == 0, "vfn_train_step: sup_rows_reserved belongs to the session form (VFN_TRAIN_RENDER)");
+        StepCtx c;
+        STEP(step_open(c, p, io, stream, true));
+        Ws& w = c.w;
+        if (w.m_sup_pad == 0) { c.sd = nullptr; c.ss = s; }
+        STEP(step_prep(c, false));
         // the supervision batch runs on a side stream beside the render (render.streams >= 2; joined in front of the loss): its points
         // depend on nothing but the prep launch
-        Side* sd = (r.streams >= 2 && w.m_sup_pad > 0) ? side_stream() : nullptr;
-        hipStream_t ss = sd ? sd->s : s;
-        if (sd) STEP(fork_to(sd, s));
-        float* saved_f = reinterpret_cast<float*>(w.saved);
-        auto supervision_forward = [&]() -> int {
-            long long row = 0;
-            if (p->border && p->n_sup > 0) {
-                STEP(vfn_sample_sphere_shell(p->n_sup, p->border_r_min, p->border_r_max, w.centroid, 1, io->sup_u_border, p->sup_seed, p->sup_offset,
-                                             w.sup_pts, w.sup_gt, ss));
-                row += p->n_sup;
-            }
-            if (p->center && p->n_sup > 0) {
-                STEP(vfn_sample_sphere_shell(p->n_sup, 0.0f, p->sup_radius, w.centroid, 0, io->sup_u_center, p->sup_seed,
-                                             p->sup_offset + (io->sup_u_border || !p->border ? 0 : (uint64_t)p->n_sup), w.sup_pts + row * 3,
-                                             w.sup_gt + row * 3, ss));
-                row += p->n_sup;
-            }
-            if (w.m_sup_pad > 0)
-                STEP(vfn_vf_mlp16_fwd_train_at(io->vf_geom, io->vf_packed16, w.sup_pts, w.m_sup_pad, 0, w.sup_pred, saved_f, w.aux_vf, w.masks,
-                                               p->save_flags, w.m, w.total, ss));
-            return VFN_OK;
-        };
-        if (sd) STEP(supervision_forward());
-
-        // ---- render() under autograd: one vector-field evaluation per distinct sample (backward.StoredFinePass) -----------------------
-        const int gen_c = r.perturb_coarse && !io->u_coarse, gen_f = r.perturb_fine && !io->u_fine, gen_a = !io->u_add;
-        const long long base_f = gen_c ? (long long)n * sc : 0, base_a = base_f + (gen_f ? (long long)n * nf : 0);
-        vfn_raygen_params rq = {n, sc, r.pose_is_quat, r.near_coarse, r.far_coarse};
-        STEP(vfn_internal_raygen(&rq, io->uv, io->pose, io->intrinsics, io->intrinsics, io->t_vals, io->far_coarse_per_ray,
-                                 r.perturb_coarse ? io->u_coarse : nullptr, gen_c, 0, r.seed, r.offset, w.directions, io->ray_dirs, w.cam_loc, w.z_c,
-                                 w.pts_c, s));
-        const bool sparse = p->sparse_colours != 0;
-        if (sparse)      // region 1: the vector-field net alone (vector head, no feature block) on every sample
-            STEP(vfn_vf_mlp16_fwd_train_at(io->vf_geom, io->vf_packed16, w.pts_c, w.m_c, 0, w.normals_s, saved_f, w.aux_vf, w.masks, p->save_flags, 0,
-                                           w.total, s));
-        else
-            STEP(vfn_vf_render_fused16_fwd_train_at(io->vf_geom, io->vf_packed16, io->rn_geom, io->rn_packed16, w.pts_c, io->ray_dirs, w.m_c, sc,
-                                                    w.normals_s, w.colors_s, saved_f, w.aux_vf, w.aux_rn, w.masks, p->save_flags, 0, w.total,
-                                                    p->forward_products, s));
-        vfn_density_params dp = r.density;
-        dp.n_rays = n; dp.n_samples = sc;
-        vfn_fine_params fp = {n, sc, nf, r.near_fine, r.far_fine, r.fine_range, r.window_step, r.span};
-        STEP(vfn_internal_density_fine(&dp, w.normals_s, io->ray_dirs, w.z_c, w.scal, &fp, w.directions, w.cam_loc, io->far_fine_per_ray,
-                                       r.perturb_fine ? io->u_fine : nullptr, io->u_add, gen_f, gen_a, base_f, base_a, r.seed, r.offset, io->z_vals,
-                                       io->points, w.src, w.new_pts, w.dst, w.m_c, s));
-        dp.n_samples = st;
-        if (sparse) {
-            STEP(vfn_vf_mlp16_fwd_train_at(io->vf_geom, io->vf_packed16, w.new_pts, w.m - w.m_c, 0, w.normals_s + w.m_c * 3, saved_f, w.aux_vf, w.masks,
-                                           p->save_flags, w.m_c, w.total, s));
-            // normals to their sorted positions, weights (no colours yet)
-            STEP(vfn_scatter_rows3(w.normals_s, nullptr, w.dst, w.m, io->normals, nullptr, s));
-            STEP(vfn_ray_density_weights(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, nullptr, nullptr, io->weights, nullptr, nullptr, nullptr, s));
-            // the samples with w > 0, compacted in ray order; their count stays on the device
-            STEP(vfn_internal_select_positive(io->weights, n, st, io->points, io->ray_dirs, w.cnt, w.off, w.k_dev, w.sel_sorted, w.pts_sel, w.dirs_sel, s));
-            // region 2: the fused saving forward (vector-field net + rendering net) on the selected samples only
-            STEP(vfn_internal_fused16_fwd_train_at(io->vf_geom, io->vf_packed16, io->rn_geom, io->rn_packed16, w.pts_sel, w.dirs_sel, w.cap, w.k_dev, 1,
-                                                   w.normals_sel, w.colors_sel, saved_f, w.aux_vf, w.aux_rn, w.masks, p->save_flags, w.r2_first, w.total,
-                                                   p->forward_products, s));
-            // colours: zero where w = 0 (they multiply a zero weight), the selected ones at their sorted positions; composite
-            if (hipMemsetAsync(io->colors, 0, (size_t)w.m * 3 * sizeof(float), s) != hipSuccess) {
-                vfn_set_error("vfn_train_step: could not clear the colours");
-                return VFN_ERR_LAUNCH;
-            }
-            STEP(vfn_internal_rows3_by_index(w.colors_sel, w.sel_sorted, w.k_dev, w.cap, io->colors, 0, s));
-            STEP(vfn_ray_density_weights(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, nullptr, io->weights, nullptr, io->rgb, io->depth, s));
-        } else {
-            STEP(vfn_vf_render_fused16_fwd_train_at(io->vf_geom, io->vf_packed16, io->rn_geom, io->rn_packed16, w.new_pts, io->ray_dirs, w.m - w.m_c, nf,
-                                                    w.normals_s + w.m_c * 3, w.colors_s + w.m_c * 3, saved_f, w.aux_vf, w.aux_rn, w.masks, p->save_flags,
-                                                    w.m_c, w.total, p->forward_products, s));
-            // every sample (proposal and new) moves from storage order to its sorted position on the way into the composite launch
-            STEP(vfn_internal_composite_gather(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, w.src, w.normals_s, w.colors_s, w.m,
-                                               io->weights, io->rgb, io->depth, s));
-        }
-
+        if (c.sd) { STEP(fork_to(c.sd, s)); STEP(step_supervision(c)); }
+        STEP(step_render(c));
         // ---- supervision points and their vector-only forward (train.py:186-216) -----------------------------------------------------
-        if (sd) STEP(join_into(sd, s));
-        else STEP(supervision_forward());
+        if (c.sd) STEP(join_into(c.sd, s));
+        else STEP(step_supervision(c));
 
         // ---- VFLoss forward / backward (vf_loss.py:34-87; the centre-ball rows of functions.py:137-157 inside the launches) -------------
         vfn_loss_params lp = p->loss;
@@ -358,86 +615,51 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
         // d normals of the loss lands in `dn`, where the per-ray backward ADDS the density path's share
         STEP(vfn_vf_loss_bwd(&lp, io->rgb, io->rgb_gt, lp.has_depth ? io->depth : nullptr, lp.has_depth ? io->depth_gt : nullptr, io->normals,
                              loss_points, sup_pred, sup_gt, w.loss_ws, nullptr, w.d_rgb, lp.has_depth ? w.d_depth : nullptr, w.dn, d_sup, s));
-
-        // ---- backward: supervision chain, per-ray backward, fine chain, weight gradients -------------------------------------------------
-        const float* feats = saved_f + (size_t)(w.vf_h - 1) * (w.slot_bytes / 4);           // the tanh'ed feature slot, row-major fp32
-        const size_t rn_off = (size_t)w.vf_h * w.slot_bytes;
-        if (sparse) {
-            // per-ray backward on the sorted samples: d colours = w d rgb (zero wherever w is), d normals += the density path's share
-            STEP(vfn_ray_density_weights_bwd(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, w.d_rgb, lp.has_depth ? w.d_depth : nullptr,
-                                             nullptr, w.dn, w.dc, w.dscal, s));
-            STEP(vfn_scatter_rows3(w.dn, nullptr, w.src, w.m, w.dn_s, nullptr, s));       // row src[i] of region 1 is sorted sample i
-            STEP(vfn_internal_rows3_by_index(w.dc, w.sel_sorted, w.k_dev, w.cap, w.dc_sel, 1, s));
-            if (hipMemsetAsync(w.zero3, 0, (size_t)w.cap * 3 * sizeof(float), s) != hipSuccess) {
-                vfn_set_error("vfn_train_step: could not clear the zero rows");
-                return VFN_ERR_LAUNCH;
-            }
-            // Region 2's chain and the rendering net's weight gradients are small launches (a few percent of the samples: 0.6 rounds of
-            // workgroups at 4096 rays) that touch nothing region 1's chain and weight gradients touch (other rows of the workspace, other
-            // parameters' gradients, their own scratch): they run on the side stream beside them.
-            const size_t r2_off = (size_t)(w.r2_first / 32) * GROUP_BYTES;
-            if (sd) STEP(fork_to(sd, s));
-            // the fused chain over region 2: d colours in, no gradient at the vector head (region 1 carries it)
-            STEP(vfn_internal_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, io->rn_geom, io->rn_packed_bwd16, io->rn_head_w, feats,
-                                                   w.masks, w.dy, p->dy_flags, w.dc_sel, w.colors_sel, w.zero3, w.normals_sel, nullptr, 3, w.cap, w.k_dev,
-                                                   w.dz_rgb, w.dz_vec, w.r2_first, w.total, ss));
-            // weight gradients: the rendering net over region 2; the vector-field net's hidden layers + head over region 1 and the
-            // supervision rows, its hidden layers + feature block over region 2 (the head's gradient there is zero)
-            STEP(vfn_internal_net_weight_grads_frag_part(VFN_NET_RENDER, io->rn_geom, io->rn_wgrad, w.saved + rn_off + r2_off, w.dy + rn_off + r2_off,
-                                                         (int64_t)w.slot_bytes, p->dy_form, p->x_form, feats + w.r2_first * 256, w.aux_rn + w.r2_first * 40,
-                                                         w.dz_rgb + w.r2_first * 4, w.cap, w.k_dev, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD, 1,
-                                                         w.scratch_rn, ss));
-            // ONE vector-only chain over region 1 and the supervision rows (d normals | d supervision predictions)
-            STEP(vfn_mlp_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, nullptr, nullptr, nullptr, feats, w.masks, w.dy, p->dy_flags,
-                                              nullptr, nullptr, w.dn_s, w.normals_s, nullptr, 3, w.m + w.m_sup_pad, nullptr, w.dz_vec, 0, w.total, s));
-            STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form, nullptr,
-                                                w.aux_vf, w.dz_vec, w.m + w.m_sup_pad, VFN_WGRAD_LAYERS | VFN_WGRAD_HEAD, 1, w.scratch_vf, s));
-            // (the vector-field net's gradients of region 2 are ADDED to the same tensors: after both of the above)
-            if (sd) STEP(join_into(sd, s));
-            STEP(vfn_internal_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved + r2_off, w.dy + r2_off, (int64_t)w.slot_bytes,
-                                                         p->dy_form, p->x_form, nullptr, w.aux_vf + w.r2_first * 40, w.dz_vec + w.r2_first * 4, w.cap,
-                                                         w.k_dev, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES, 1, w.scratch_vf, s));
-        } else {
-        if (w.m_sup_pad > 0) {
-            // (beside the per-ray backward and the fine pass's chain when there is a side stream; joined in front of the weight gradients)
-            if (sd) STEP(fork_to(sd, s));
-            STEP(vfn_mlp_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, nullptr, nullptr, nullptr, feats, w.masks, w.dy,
-                                              p->dy_flags, nullptr, nullptr, w.d_sup, w.sup_pred, nullptr, 3, w.m_sup_pad, nullptr, w.dz_vec, w.m,
-                                              w.total, ss));
-        }
-        STEP(vfn_ray_density_weights_bwd(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, w.d_rgb, lp.has_depth ? w.d_depth : nullptr,
-                                         nullptr, w.dn, w.dc, w.dscal, s));
-        // row src[i] of the workspace is sorted sample i: gradients to storage order
-        STEP(vfn_scatter_rows3(w.dn, w.dc, w.src, w.m, w.dn_s, w.dc_s, s));
-        STEP(vfn_mlp_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, io->rn_geom, io->rn_packed_bwd16, io->rn_head_w, feats,
-                                          w.masks, w.dy, p->dy_flags, w.dc_s, w.colors_s, w.dn_s, w.normals_s, nullptr, 3, w.m, w.dz_rgb, w.dz_vec, 0,
-                                          w.total, s));
-        STEP(vfn_net_weight_grads_frag_part(VFN_NET_RENDER, io->rn_geom, io->rn_wgrad, w.saved + rn_off, w.dy + rn_off, (int64_t)w.slot_bytes,
-                                            p->dy_form, p->x_form, feats, w.aux_rn, w.dz_rgb, w.m,
-                                            VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD, 1, w.scratch_rn, s));
-        // vector-field net: hidden layers + head over ALL rows (fine pass + supervision), the feature block over the fine pass's rows
-        if (sd) STEP(join_into(sd, s));
-        if (w.m_sup_pad > 0) {
-            STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form,
-                                                nullptr, w.aux_vf, w.dz_vec, w.m + w.m_sup_pad, VFN_WGRAD_LAYERS | VFN_WGRAD_HEAD, 1, w.scratch_vf, s));
-            STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form,
-                                                nullptr, w.aux_vf, w.dz_vec, w.m, VFN_WGRAD_FEATURES, 1, w.scratch_vf, s));
-        } else {
-            STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form,
-                                                nullptr, w.aux_vf, w.dz_vec, w.m, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD, 1,
-                                                w.scratch_vf, s));
-        }
-        }
-        hipLaunchKernelGGL(vfn_train_scalar_grads_kernel, dim3(1), dim3(64), 0, s, w.dscal, io->g_beta, io->g_mean, io->g_scale,
-                           sparse ? w.k_dev : nullptr, (float)w.m, io->out_counts);
-        STEP(vfn_check_launch("vfn_train_step (density scalar gradients)"));
+        STEP(step_backward(c, w.d_rgb, lp.has_depth ? w.d_depth : nullptr));
     }
 
-    if (p->phases & VFN_TRAIN_OPTIMIZER) {
-        VFN_REQUIRE(io->flat_param && io->flat_grad && io->exp_avg && io->exp_avg_sq && io->clip_workspace && io->out_norm && io->n_flat > 0 &&
-                    p->n_regions >= 1 && p->n_regions <= 4, "vfn_train_step: optimizer phase without its buffers");
+    if (p->phases & VFN_TRAIN_RENDER) {
+        VFN_REQUIRE(forward_pointers_ok(io), "vfn_train_step: NULL argument (render part)");
+        StepCtx c;
+        STEP(step_open(c, p, io, stream, true));
+        STEP(step_prep(c, true));
+        if (c.sd) {
+            // the supervision calls that follow (vfn_train_step_supervision_points / _forward) run on the side stream, after this step's prep
+            STEP(fork_to(c.sd, s));
+            c.sd->armed_ws = io->workspace;
+        }
+        STEP(step_render(c));
+    }
+
+    if (p->phases & VFN_TRAIN_BACKWARD) {
+        VFN_REQUIRE(backward_pointers_ok(io) && io->d_rgb_in && io->d_normals_in, "vfn_train_step: NULL argument (backward part)");
+        StepCtx c;
+        STEP(step_open(c, p, io, stream, true));
+        Ws& w = c.w;
+        if (io->d_normals_in != w.dn &&
+            hipMemcpyAsync(w.dn, io->d_normals_in, (size_t)w.m * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            vfn_set_error("vfn_train_step: could not copy the upstream gradient of the normals");
+            return VFN_ERR_LAUNCH;
+        }
+        if (hipMemsetAsync(w.dscal, 0, 4 * sizeof(float), s) != hipSuccess) {
+            vfn_set_error("vfn_train_step: could not clear the scalar gradients");
+            return VFN_ERR_LAUNCH;
+        }
+        STEP(step_backward(c, io->d_rgb_in, io->d_depth_in));
+        if (c.sd) c.sd->armed_ws = nullptr;
+    }
+
+    // VFN_TRAIN_OPTIMIZER = VFN_TRAIN_CLIP then VFN_TRAIN_ADAM (the session form's caller makes them as two calls: clip_grad_norm_, optimizer.step)
+    const bool clip = (p->phases & (VFN_TRAIN_OPTIMIZER | VFN_TRAIN_CLIP)) != 0, adam = (p->phases & (VFN_TRAIN_OPTIMIZER | VFN_TRAIN_ADAM)) != 0;
+    if (clip || adam)
+        VFN_REQUIRE(io->flat_grad && io->n_flat > 0 && p->n_regions >= 1 && p->n_regions <= 4, "vfn_train_step: optimizer phase without its buffers");
+    if (clip) {
+        VFN_REQUIRE(io->clip_workspace && io->out_norm, "vfn_train_step: clip without its workspace / output");
         STEP(vfn_flat_clip_grad_norm(io->flat_grad, io->n_flat, p->n_regions, p->starts, p->ends, p->mults, p->max_norm, io->clip_workspace,
                                      io->out_norm, s));
+    }
+    if (adam) {
+        VFN_REQUIRE(io->flat_param && io->exp_avg && io->exp_avg_sq, "vfn_train_step: Adam without its buffers");
         STEP(vfn_flat_adam_step(io->flat_param, io->flat_grad, io->exp_avg, io->exp_avg_sq, io->n_flat, p->n_regions, p->starts, p->ends, p->mults,
                                 p->step_size, p->bc2_sqrt, p->beta1, p->beta2, p->eps, p->weight_decay, s));
         if (p->repack) {

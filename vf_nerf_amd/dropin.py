@@ -67,8 +67,19 @@ def install() -> None:
         fn = importlib.import_module("models.helpers.functions")
         fn.sample_border_points = supervision.sample_border_points
         fn.sample_center_points = supervision.sample_center_points
+        # functions.py:137-157 compacts the centre-ball rows with boolean-mask indexing (a device synchronisation in the middle of every
+        # step); inside an open training step the same rows are selected by the fused loss kernels instead (supervision.py)
+        fn.get_center_indices_and_gt = supervision.get_center_indices_and_gt
     except Exception:
         pass
+    # the datasets' get_centroid(device) uploads the same three floats five times per step (train/vector_field_nerf_train.py:186-214);
+    # cached per device, and the cached tensor carries its host values so that the samplers above need no read-back
+    for mod, cls in (("datasets.normal_datasets.base_dataset", "BaseDataset"), ("datasets.normal_datasets.replica_dataset", "ReplicaDataset"),
+                     ("datasets.normal_datasets.scannet_dataset", "ScanNetDataset")):
+        try:
+            cache_centroid(getattr(importlib.import_module(mod), cls))
+        except Exception:
+            pass
     # the loss with one device read-back per step instead of six
     try:
         importlib.import_module("models.losses.vf_loss").VFLoss = loss.VFLoss
@@ -77,6 +88,33 @@ def install() -> None:
 
 
     _patch_clip_grad_norm()
+
+
+def cache_centroid(cls) -> None:
+    """Wrap ``cls.get_centroid(self, device)`` (datasets/normal_datasets/*_dataset.py: ``self.gt_mesh_centroid.to(device)``) so that it
+    returns ONE tensor per device for as long as the source tensor is unchanged, with the three host values attached as ``_vfn_host``
+    (read once, when the cache is filled).  The values are the dataset's; only the repeated uploads go away."""
+    orig = cls.__dict__.get("get_centroid")
+    if orig is None or getattr(orig, "_vfn_cached", False):
+        return
+
+    def get_centroid(self, device):
+        cache = self.__dict__.setdefault("_vfn_centroid_cache", {})
+        src = getattr(self, "gt_mesh_centroid", None)
+        key = (str(device), id(src), getattr(src, "_version", 0))
+        hit = cache.get(key)
+        if hit is None:
+            hit = orig(self, device)
+            host = hit.detach().reshape(-1).tolist()
+            if len(host) == 3:
+                hit._vfn_host = tuple(float(v) for v in host)
+            cache.clear()
+            cache[key] = hit
+        return hit
+
+    get_centroid._vfn_cached = True
+    get_centroid.__wrapped__ = orig
+    cls.get_centroid = get_centroid
 
 
 _torch_clip = None
@@ -98,10 +136,13 @@ def _patch_clip_grad_norm() -> None:
 
     def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=False, foreach=None):
         plist = [parameters] if isinstance(parameters, torch.Tensor) else list(parameters)
-        ids = [id(p) for p in plist]
-        if len(set(ids)) != len(ids) and float(norm_type) == 2.0 and not error_if_nonfinite and \
-                all(p.is_cuda for p in plist if p.grad is not None):
-            return optim.clip_grad_norm_(plist, max_norm, 2.0)
+        if float(norm_type) == 2.0 and not error_if_nonfinite and plist:
+            owner = optim.owner_of(plist[0])
+            if owner is not None and owner.regions_for(plist):     # the flat optimizer's own list (duplicates and all): two launches
+                return optim.clip_grad_norm_(plist, max_norm, 2.0)
+            ids = [id(p) for p in plist]
+            if len(set(ids)) != len(ids) and all(p.is_cuda for p in plist if p.grad is not None):
+                return optim.clip_grad_norm_(plist, max_norm, 2.0)
         return _torch_clip(plist, max_norm, norm_type, error_if_nonfinite, foreach)
 
     clip_grad_norm_.__wrapped__ = _torch_clip

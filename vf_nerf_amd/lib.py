@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Optional, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 
@@ -35,6 +35,7 @@ EXPORTS = (
     "vfn_weight_grad_groups", "vfn_scatter_rows3", "vfn_uniform_sample", "vfn_rows_argmax", "vfn_merge_sort_depths",
     "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_f16x3_set_clock_probe", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step", "vfn_unfold_weight_grads_acc", "vfn_render_fwd", "vfn_render_fwd_workspace_bytes",
     "vfn_vf_loss_workspace_bytes", "vfn_vf_loss_fwd", "vfn_vf_loss_bwd", "vfn_train_step", "vfn_train_step_workspace_bytes",
+    "vfn_train_step_workspace_layout", "vfn_train_step_supervision_points", "vfn_train_step_supervision_forward", "vfn_train_step_supervision_backward",
     "vfn_linear_rows_dx_sums", "vfn_weight_grad_partials_bf16_ld",
 )
 
@@ -96,7 +97,7 @@ class TrainStepParams(C.Structure):
                 ("x_form", C.c_int32), ("forward_products", C.c_int32), ("repack", C.c_int32), ("n_regions", C.c_int32), ("mults", C.c_int32 * 4),
                 ("starts", C.c_int64 * 4), ("ends", C.c_int64 * 4), ("step_size", C.c_double * 8), ("bc2_sqrt", C.c_double * 8),
                 ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double), ("max_norm", C.c_float),
-                ("sparse_colours", C.c_int32)]
+                ("sparse_colours", C.c_int32), ("sup_rows_reserved", C.c_int64)]
 
 
 class TrainStepIO(C.Structure):
@@ -106,10 +107,12 @@ class TrainStepIO(C.Structure):
                                           "flat_param", "flat_grad", "exp_avg", "exp_avg_sq")] + [("n_flat", C.c_int64)] + \
                [(n, C.c_void_p) for n in ("clip_workspace", "uv", "pose", "intrinsics", "t_vals", "far_coarse_per_ray", "far_fine_per_ray", "u_coarse", "u_fine",
                                           "u_add", "sup_u_border", "sup_u_center", "rgb_gt", "depth_gt", "workspace", "ray_dirs", "z_vals", "points", "normals",
-                                          "colors", "weights", "rgb", "depth", "out_terms", "out_norm", "out_counts")]
+                                          "colors", "weights", "rgb", "depth", "out_terms", "out_norm", "out_counts", "d_rgb_in", "d_depth_in", "d_normals_in")]
 
 
-TRAIN_FORWARD_BACKWARD, TRAIN_OPTIMIZER = 1, 2
+TRAIN_FORWARD_BACKWARD, TRAIN_OPTIMIZER, TRAIN_RENDER, TRAIN_BACKWARD, TRAIN_CLIP, TRAIN_ADAM = 1, 2, 4, 8, 16, 32
+# indices of vfn_train_step_workspace_layout's output (VFN_TWS_* of include/vfn.h)
+TWS_SUP_PTS, TWS_SUP_GT, TWS_SUP_PRED, TWS_D_SUP, TWS_DN, TWS_SUP_ROWS, TWS_TOTAL_ROWS, TWS_BYTES, TWS_COUNT = range(9)
 
 _lib: Optional[C.CDLL] = None
 
@@ -285,7 +288,8 @@ def _ptr(t: Optional[torch.Tensor], name: str, dtype=torch.float32) -> C.c_void_
 
 
 def _stream() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # (the raw handle of the current stream of the current device: torch.cuda.current_stream() builds a Stream object around it, 13 us a call)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -933,8 +937,39 @@ def train_step_workspace_bytes(params: "TrainStepParams", vf_geom: NetGeom, rn_g
 
 
 def train_step(params: "TrainStepParams", io: "TrainStepIO") -> None:
-    """One training step (or one of its two phases) from C: vf_nerf_amd/onecall.py fills the structs."""
+    """One training step (or some of its phases) from C: vf_nerf_amd/stepengine.py fills the structs."""
     _check(load().vfn_train_step(C.byref(params), C.byref(io), _stream()), "vfn_train_step")
+
+
+def train_step_workspace_layout(params: "TrainStepParams", vf_geom: NetGeom, rn_geom: NetGeom) -> List[int]:
+    """[TWS_*]: byte offsets of the session form's regions inside the step workspace, and its counts."""
+    out = (C.c_int64 * TWS_COUNT)()
+    _check(load().vfn_train_step_workspace_layout(C.byref(params), C.byref(vf_geom), C.byref(rn_geom), out, TWS_COUNT), "vfn_train_step_workspace_layout")
+    return [int(v) for v in out]
+
+
+def train_step_supervision_points(params: "TrainStepParams", io: "TrainStepIO", inward: bool, r_min: float, r_max: float, cx: float, cy: float,
+                                  cz: float, centroid_dev: Optional[torch.Tensor], row0: int, count: int, u: Optional[torch.Tensor], seed: int,
+                                  offset: int) -> bool:
+    """Session form: one supervision batch sampled into rows [row0, row0 + count) of the open step.  -> True when it ran on the step's side
+    stream (pass it on to ``train_step_supervision_forward``)."""
+    rc = load().vfn_train_step_supervision_points(C.byref(params), C.byref(io), 1 if inward else 0, float(r_min), float(r_max), float(cx), float(cy),
+                                                  float(cz), _ptr(centroid_dev, "centroid"), row0, count, _ptr(u, "u"), C.c_uint64(seed & (2 ** 64 - 1)),
+                                                  C.c_uint64(offset & (2 ** 64 - 1)), _stream())
+    if rc < 0:
+        _check(rc, "vfn_train_step_supervision_points")
+    return rc == 1
+
+
+def train_step_supervision_forward(params: "TrainStepParams", io: "TrainStepIO", row0: int, count: int, on_side: bool) -> None:
+    """Session form: the vector-only saving forward over supervision rows [row0, pad32(row0 + count)) of the open step."""
+    _check(load().vfn_train_step_supervision_forward(C.byref(params), C.byref(io), row0, count, 1 if on_side else 0, _stream()),
+           "vfn_train_step_supervision_forward")
+
+
+def train_step_supervision_backward(params: "TrainStepParams", io: "TrainStepIO", row0: int, count: int) -> None:
+    """Session form: chain + weight gradients of supervision rows [row0, pad32(row0 + count)) alone (a backward pass that never reaches the render)."""
+    _check(load().vfn_train_step_supervision_backward(C.byref(params), C.byref(io), row0, count, _stream()), "vfn_train_step_supervision_backward")
 
 
 def f16x3_set_clock_probe(stamps: Optional[torch.Tensor]) -> None:

@@ -108,12 +108,14 @@ class _FusedLoss(torch.autograd.Function):
     segments as pred0, gt0, pred1, gt1, ... (at most three pairs)."""
 
     @staticmethod
-    def forward(ctx, lp, rgb, rgb_gt, depth, depth_gt, normals, points, *segs):
+    def forward(ctx, lp, dn_buffer, rgb, rgb_gt, depth, depth_gt, normals, points, *segs):
         from . import lib
         ws = lib.vf_loss_workspace(rgb.device)
         preds, gts = list(segs[0::2]), list(segs[1::2])
         out = lib.vf_loss_fwd(lp, rgb, rgb_gt, depth, depth_gt, normals, points, preds, gts, ws)
         ctx.lp, ctx.ws, ctx.n_seg = lp, ws, len(preds)
+        # (an open training step lends the rows its backward reads the normals' gradient from: written in place, no copy; stepengine.py)
+        ctx.dn_buffer = dn_buffer
         ctx.save_for_backward(rgb, rgb_gt, depth, depth_gt, normals, points, *segs)
         ctx.mark_non_differentiable(out)
         return out[6].clone(), out
@@ -123,14 +125,17 @@ class _FusedLoss(torch.autograd.Function):
         from . import lib
         rgb, rgb_gt, depth, depth_gt, normals, points, *segs = ctx.saved_tensors
         preds, gts = list(segs[0::2]), list(segs[1::2])
-        need = ctx.needs_input_grad            # (lp, rgb, rgb_gt, depth, depth_gt, normals, points, pred0, gt0, ...)
-        d_rgb = torch.empty_like(rgb) if need[1] else None
-        d_depth = torch.empty_like(depth) if (need[3] and depth is not None) else None
-        d_normals = torch.empty_like(normals) if need[5] else None
-        d_sup = [torch.empty_like(p) if need[7 + 2 * k] else None for k, p in enumerate(preds)]
+        need = ctx.needs_input_grad            # (lp, dn_buffer, rgb, rgb_gt, depth, depth_gt, normals, points, pred0, gt0, ...)
+        d_rgb = torch.empty_like(rgb) if need[2] else None
+        d_depth = torch.empty_like(depth) if (need[4] and depth is not None) else None
+        d_normals = None
+        if need[6]:
+            buf = ctx.dn_buffer
+            d_normals = buf if (buf is not None and buf.shape == normals.shape and buf.device == normals.device) else torch.empty_like(normals)
+        d_sup = [torch.empty_like(p) if need[8 + 2 * k] else None for k, p in enumerate(preds)]
         lib.vf_loss_bwd(ctx.lp, rgb, rgb_gt, depth, depth_gt, normals, points, preds, gts, ctx.ws, g_total.reshape(1).float().contiguous(),
                         d_rgb, d_depth, d_normals, d_sup)
-        grads = [None, d_rgb, None, d_depth, None, d_normals, None]
+        grads = [None, None, d_rgb, None, d_depth, None, d_normals, None]
         for k in range(ctx.n_seg):
             grads += [d_sup[k], None]
         return tuple(grads)
@@ -170,13 +175,28 @@ class VFLoss(nn.Module):
         lp.depth_clamp = float(self.config.depth_loss_clamp)
         points = None
         rc = pred.get("ray_center")                # (points[N,S,3] | [M,3], centroid as three Python floats, radius): trainer.TrainStep
+        dn_buffer = None
+        if normals.requires_grad:
+            from .stepengine import current_session, find_marker
+            session = current_session()
+            if session is not None and normals.data_ptr() == session.normals.data_ptr() and normals.numel() == session.m * 3:
+                dn_buffer = session.dn
+            # the centre-ball rows supervision.get_center_indices_and_gt deferred to this loss (the reference trainer's call sequence)
+            marked = find_marker(pred["supervised_normals"]) if rc is None else None
+            if marked is not None:
+                info = marked.ray_centre
+                if marked is not session or dn_buffer is None or info is None:
+                    raise ValueError("VFLoss: the deferred centre-ball rows belong to another render() than pred['normals']")
+                rc = (marked.points, info["centroid"], info["radius"])
+                info["consumed"] = True
         if rc is not None:
             points = f32(rc[0].reshape(-1, 3))
             lp.ray_center, lp.radius = 1, float(rc[2])
             for i in range(3):
                 lp.centroid[i] = float(rc[1][i])
         flat = [t for pair in segments for t in pair]
-        total, out = _FusedLoss.apply(lp, f32(rgb.reshape(-1, 3)), f32(gt["rgb"].reshape(-1, 3)), f32(pred["depth"].reshape(-1)) if has_depth else None,
+        total, out = _FusedLoss.apply(lp, dn_buffer, f32(rgb.reshape(-1, 3)), f32(gt["rgb"].reshape(-1, 3)),
+                                      f32(pred["depth"].reshape(-1)) if has_depth else None,
                                       f32(gt["depth"].reshape(-1)) if has_depth else None, normals, points, *flat)
         terms = out[:6]
         dd = pred.get("directional_derivatives")

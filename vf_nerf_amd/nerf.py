@@ -184,6 +184,12 @@ class VectorFieldNerf:
         # it).  evaluator.render_view switches it on for its own calls; render() itself stays dense.
         self.sparse_colours = False
         self._render_ws: Dict[tuple, torch.Tensor] = {}
+        # A grad-mode render() in the shipped regime opens a STEP SESSION (stepengine.py): the render and, later, its backward are one C call
+        # each on the training step's workspace, with the sparse colour branch; the trainer's supervision forwards join that workspace.
+        # False: the launch-by-launch autograd path (backward.py).  ``defer_center_rows``: functions.get_center_indices_and_gt hands the
+        # centre-ball selection to the fused loss kernels instead of compacting rows (a device synchronisation) — needs loss.VFLoss.
+        self.step_sessions = True
+        self.defer_center_rows = True
 
     # ---------------------------------------------------------------------------------------------
     # module plumbing
@@ -545,6 +551,14 @@ class VectorFieldNerf:
         if self.one_call_render and self.reuse_proposal and self.uses_f16x3() and not self._needs_grad() and \
                 0 < n * (s_c + n_f) < (1 << 22) and not cfg.numerical_jacobian:
             return self._render_one_call(pose, pixels, intrinsics, uniforms, n, s_c, n_f, perturb_c, perturb_f, white)
+
+        # under autograd in the shipped regime: the render part of the training step from C, tied to ONE autograd node whose backward is
+        # one C call as well (stepengine.StepSession: what the reference trainer's own call sequence drives through the drop-in)
+        if pose.is_cuda and not white and self._needs_grad():
+            from .stepengine import StepEngine
+            out = StepEngine.of(self).open_session(pose, pixels, intrinsics, epoch, uniforms)
+            if out is not None:
+                return out
 
         # the draws that are not supplied come from ONE Philox launch (three contiguous segments of one buffer)
         wanted = [(name, shape) for name, shape, needed in (("u_coarse", (n, s_c), perturb_c), ("u_fine", (n, n_f), perturb_f),

@@ -223,6 +223,13 @@ class VectorFieldNetwork(_PackedMLP):
             from .batchstat import vf_forward_train_mode
             out = vf_forward_train_mode(self, points, want_jacobian=jacobian and not vector_only)
             return out[:, :3].contiguous() if vector_only else out
+        if points.is_cuda and torch.is_grad_enabled():
+            # points a sampler wrote into the open training step's supervision rows (stepengine.StepSession): the vector-only saving forward on
+            # those rows; [:, :3] of the result is all the trainer reads (train/vector_field_nerf_train.py:201,213)
+            from .stepengine import session_vf_forward
+            out = session_vf_forward(self, points)
+            if out is not None:
+                return out[:, :3] if vector_only else out
         from .autograd import vf_forward  # local import: autograd wrappers depend on this module
         return vf_forward(self, points, vector_only)
 

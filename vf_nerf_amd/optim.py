@@ -114,6 +114,7 @@ class FlatAdam(SequentialAdam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self._flat = None
         self.after_step = None
+        self.step_engine = None            # weakref to the owner's stepengine.StepEngine (set by it), or None
         for p in self.param_groups[0]["params"]:           # lets clip_grad_norm_ find the flat gradient buffer of a parameter list
             _register_owner(p, self)
 
@@ -145,8 +146,14 @@ class FlatAdam(SequentialAdam):
         f = self._flat
         if f is None:
             return False
-        base = f["param"].data_ptr()
-        return all(p.data_ptr() == base + 4 * off and p.requires_grad for p, off, _, _ in f["entries"])
+        pairs = f.get("bound_pairs")
+        if pairs is None:
+            base = f["param"].data_ptr()
+            pairs = f["bound_pairs"] = [(p, base + 4 * off) for p, off, _, _ in f["entries"]]
+        for p, want in pairs:
+            if p.data_ptr() != want or not p.requires_grad:
+                return False
+        return True
 
     def flat(self):
         """Build (or re-build, when something replaced a parameter's storage: .to(), .cuda()) the flat buffers; returns the
@@ -276,6 +283,11 @@ class FlatAdam(SequentialAdam):
                 loss = closure()
         from . import lib
         self._rebind_grads(f)
+        # the owning model's step engine (stepengine.py) applies the update and re-packs the weight packs in one C call when its structs
+        # describe these buffers (after a training render of the shipped regime they do)
+        eng = self.step_engine() if self.step_engine is not None else None
+        if eng is not None and eng.adam_step(f):
+            return loss
         group = self.param_groups[0]
         beta1, beta2, step_size, bc2_sqrt = self.step_scalars(f)
         lib.flat_adam_step(f["param"], f["grad"], f["exp_avg"], f["exp_avg_sq"], f["regions"], step_size, bc2_sqrt, beta1, beta2,
@@ -292,10 +304,16 @@ class FlatAdam(SequentialAdam):
         f = self.flat()
         if f is None:
             return False
+        ids = tuple(map(id, plist))
+        if f.get("regions_ok_ids") == ids:          # (the trainer passes the same list every step: one tuple comparison)
+            return True
         count = {}
-        for p in plist:
-            count[id(p)] = count.get(id(p), 0) + 1
-        return len(count) == len(f["entries"]) and all(count.get(id(p), 0) == m for p, _, _, m in f["entries"])
+        for i in ids:
+            count[i] = count.get(i, 0) + 1
+        ok = len(count) == len(f["entries"]) and all(count.get(id(p), 0) == m for p, _, _, m in f["entries"])
+        if ok:
+            f["regions_ok_ids"] = ids
+        return ok
 
 
 @torch.no_grad()

@@ -36,14 +36,30 @@ def replay_uniforms(*draws: torch.Tensor) -> None:
 
 def _shell(r_min: float, r_max: float, num_samples: int, centroid: torch.Tensor, device, inward: bool):
     global _offset
-    c = torch.as_tensor(centroid, dtype=torch.float32, device=device).reshape(3).contiguous()
+    n = int(num_samples)
+    u = None
     if _replay:
         u = _replay.pop(0)
-        if tuple(u.shape) != (int(num_samples), 3):
-            raise ValueError(f"replayed uniforms have shape {tuple(u.shape)}, the sampler needs {(int(num_samples), 3)}")
-        return lib.sample_sphere_shell(int(num_samples), float(r_min), float(r_max), c, inward, u=u.to(c.device).float().contiguous())
-    pts, gt = lib.sample_sphere_shell(int(num_samples), float(r_min), float(r_max), c, inward, _seed, _offset)
-    _offset += int(num_samples)
+        if tuple(u.shape) != (n, 3):
+            raise ValueError(f"replayed uniforms have shape {tuple(u.shape)}, the sampler needs {(n, 3)}")
+    # Inside an open training step (a grad-mode render() of the shipped regime, stepengine.StepSession) the points go straight into the
+    # step workspace's supervision rows: the vector-field forward the trainer runs on them next (train/vector_field_nerf_train.py:201,213)
+    # is then a vector-only saving forward on those rows, differentiated by the step's one chain.  Same kernel, same draws, same values.
+    if torch.is_grad_enabled() and n > 0:
+        from .stepengine import current_session
+        session = current_session()
+        if session is not None and torch.device(device) == session.ws.device:
+            got = session.sample(inward, float(r_min), float(r_max), centroid, n, None if u is None else u.to(session.ws.device).float().contiguous(),
+                                 _seed, _offset)
+            if got is not None:
+                if u is None:
+                    _offset += n
+                return got
+    c = torch.as_tensor(centroid, dtype=torch.float32, device=device).reshape(3).contiguous()
+    if u is not None:
+        return lib.sample_sphere_shell(n, float(r_min), float(r_max), c, inward, u=u.to(c.device).float().contiguous())
+    pts, gt = lib.sample_sphere_shell(n, float(r_min), float(r_max), c, inward, _seed, _offset)
+    _offset += n
     return pts, gt
 
 
@@ -72,7 +88,20 @@ def get_border_indices_and_gt(points: torch.Tensor, normals: torch.Tensor, far: 
 def get_center_indices_and_gt(points: torch.Tensor, normals: torch.Tensor, centroid: torch.Tensor,
                               radius: float) -> Tuple[torch.Tensor, torch.Tensor]:
     """Normals of the ray samples closer than ``radius`` to the centroid, and unit vectors from the centroid to them
-    (functions.py:137-157)."""
+    (functions.py:137-157).
+
+    Called on the outputs of an open training step (stepengine.StepSession) the rows are DEFERRED: both results are empty [0,3] tensors, the
+    prediction one carrying a marker node that ``loss.VFLoss`` finds behind ``pred["supervised_normals"]``; its fused kernels then select,
+    count and differentiate the same rows on the device (csrc/vfn_loss.hip: ray_center) — the same loss value and gradients without the
+    boolean-mask indexing, i.e. without a device synchronisation in the middle of the step.  A loss other than ``loss.VFLoss`` would see no
+    such rows: the step's backward refuses to run then (``model.defer_center_rows = False`` keeps the compaction)."""
+    if torch.is_grad_enabled() and points.is_cuda:
+        from .stepengine import centre_rows, current_session
+        session = current_session()
+        if session is not None and getattr(session.model, "defer_center_rows", True):
+            got = centre_rows(session, points, normals, centroid, radius)
+            if got is not None:
+                return got
     keep = torch.linalg.vector_norm(points - centroid, dim=2) < radius
     return normals.reshape(points.shape)[keep], F.normalize(points[keep] - centroid, dim=1)
 
