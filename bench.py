@@ -130,8 +130,21 @@ def live_hbm_traffic(args, timeout_s: float = 60.0):
     try:
         for counter, stem in (("FETCH_SIZE", "pf"), ("WRITE_SIZE", "pw")):
             out_dir = os.path.join(tmp, stem)
-            r = subprocess.run([exe, "--pmc", counter, "-d", out_dir, "-o", stem, "--"] + child, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
-                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            # the profiler and the profiled python are one process GROUP: a pass that outlives the cap is ended as a whole — killing
+            # rocprofv3 alone would leave its child rendering on the GPU while the timed region starts
+            proc = subprocess.Popen([exe, "--pmc", counter, "-d", out_dir, "-o", stem, "--"] + child, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
+                                    stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+            try:
+                _, err = proc.communicate(timeout=timeout_s)
+            except BaseException:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                raise
+            r = subprocess.CompletedProcess(proc.args, proc.returncode, None, err)
             db = None
             for root, _, files in os.walk(out_dir):
                 for f in files:
@@ -683,6 +696,37 @@ def training_targets(model, uv, pose, K, dev, s_c, n_f, rank=0):
     return t_out.coarse_rgb_values.clone(), t_out.coarse_depth_map.clone(), (0.0, 0.0, 0.6), 0.05
 
 
+def drop_in_sequence_timing(args, model, uv, pose, K, rgb_gt, depth_gt, centroid, radius, sync):
+    """The training step issued as the reference trainer's OWN call sequence (train/vector_field_nerf_train.py:177-275: render, the samplers,
+    the two network calls, VFLoss, zero_grad, backward, clip_grad_norm_, optimizer.step, scheduler.step, loss.item() — restated call for
+    call in tools/reference_sequence.py on the names vf_nerf_amd.dropin installs), timed like the one-call step above: it takes the step
+    session (stepengine.py), i.e. the same workspace and kernels, with ~15 Python-level calls around them.  ``ms_per_step`` includes the
+    loop's per-step loss.item() (a device synchronisation the reference's loop makes); ``ms_per_step_without_loss_item`` leaves it out."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    from types import SimpleNamespace
+    import reference_sequence
+    from vf_nerf_amd import loss as vloss, stepengine, trainer
+    crit = vloss.VFLoss(SimpleNamespace(**trainer.SHIPPED_LOSS_CONFIG), SimpleNamespace(**trainer.SHIPPED_LOSS_WEIGHTS))
+    data = {"uv": uv.unsqueeze(0), "intrinsics": K.unsqueeze(0), "pose": pose.unsqueeze(0), "rgb": rgb_gt.unsqueeze(0), "depth": depth_gt.unsqueeze(0)}
+    out = {}
+    eng = stepengine.StepEngine.of(model)
+    for name, item in (("ms_per_step", True), ("ms_per_step_without_loss_item", False)):
+        loop = reference_sequence.ReferenceLoop(model, crit, reference_sequence.StandInDataset(centroid, 1.0), radius, sync_each_step=item)
+        for _ in range(max(3, args.warmup)):
+            loop(data, 0)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loop(data, 0)
+        torch.cuda.synchronize()
+        out[name] = round((time.perf_counter() - t0) / args.steps * 1e3, 4)
+    out["took_the_step_session"] = eng.why_not is None and eng.session is not None
+    out["why_not"] = eng.why_not
+    out["call_sequence"] = "render | sample_border_points | vector_field_network(p)[:, :3] | get_center_indices_and_gt | sample_center_points | " \
+                           "vector_field_network(p)[:, :3] | VFLoss | zero_grad | backward | clip_grad_norm_ | optimizer.step | scheduler.step | loss.item()"
+    return out
+
+
 def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=True):
     """One step = what the reference trainer does per batch, with synthetic targets (config 3 of BASELINE.json)."""
     from vf_nerf_amd import distributed as vdist, supervision, trainer
@@ -731,6 +775,7 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
         e1.record()
         torch.cuda.synchronize()
         bucket_ms = e0.elapsed_time(e1) / 20.0
+    drop_in = drop_in_sequence_timing(args, model, uv, pose, K, rgb_gt, depth_gt, centroid, radius, sync) if (bucket is None and not model.vector_field_network.training) else None
     from vf_nerf_amd.backward import StoredFinePass
     stored = model.reuse_proposal and StoredFinePass.applicable(model, args.rays, args.coarse, s_t - args.coarse)
     flops, ws_bytes = train_step_accounting(args.rays, args.coarse, s_t, n_sup, model.activation_storage, model.gradient_storage,
@@ -764,6 +809,9 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
            # per GPU: algorithmic FLOPs of a step / its duration against the f16 / 3 matrix ceiling, and the workspace bytes the
            # step has to move against the HBM peak (it sits between the two roofs)
            "step_issued_as": "one C call (vfn_train_step)" if one_call else f"launch by launch from Python ({run_step.one_call.why_not})",
+           # the SAME step issued the way the reference's unchanged train_epoch issues it through vf_nerf_amd.dropin
+           "drop_in_sequence_ms": drop_in["ms_per_step"] if drop_in else None,
+           "drop_in_sequence": drop_in,
            "weights": trained if trained is not None else {"fixture": None, "trained_by": "nobody: synthetic random weights; targets rendered by a teacher of another seed"},
            "sparse_colour_branch": {"on": sparse, "samples_with_nonzero_weight": round(sel, 4) if sel is not None else None,
                                     "before_and_after_the_timed_steps": [round(c[0] / max(1.0, c[1]), 4) for c in counts] if sparse else None,

@@ -250,6 +250,12 @@ typedef struct vfn_render_params {
                                          * VF + rendering launches: [0] before / [1] after the one on the proposal samples, [2] / [3] the one
                                          * on the new samples (with `streams` > 1: around the FIRST range's launches).  bench.py times the
                                          * dominant kernel with these without leaving the one-call path. */
+    uint32_t* status_word;              /* optional (ABI 4): where the f16x3 launches of THIS call report operands outside their range (bit 0:
+                                         * a hidden activation reached the f16 clamp, bit 1: an input coordinate did) — per call, no hidden
+                                         * state; NULL: wherever vfn_f16x3_set_status (the ABI-3 setter, kept as a shim) pointed this thread */
+    uint64_t* clock_stamps;             /* optional (ABI 4): [clock_slots][2] per-workgroup (shader-clock cycles, 100 MHz ticks) of the fused
+                                         * launches of THIS call (vfn_f16x3_set_clock_probe is the ABI-3 shim) */
+    int64_t clock_slots;
 } vfn_render_params;
 int64_t vfn_render_fwd_workspace_bytes(const vfn_render_params* p);
 int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf_geom, const void* vf_packed16,
@@ -688,7 +694,10 @@ int vfn_flat_adam_step(float* param, const float* grad, float* exp_avg, float* e
  *           runs the fused saving forward, the fused chain and the colour branch's weight gradients on that compacted list only (region 2).
  *           The upstream gradient splits between the regions (d normals on region 1, d colours on region 2): the parameter gradients are
  *           the dense step's up to the order of their sums; rgb, depth, weights, normals are the dense step's bit for bit; the `colors`
- *           output holds zeros where w = 0.
+ *           output holds zeros where w = 0.  (One corner is not the dense step's: a sample with an OPEN density ReLU and non-zero
+ *           transmittance whose alpha = 1 - exp(-sigma delta) underflows to exactly 0 in fp32 (sigma delta < 3e-8) has w = 0 but
+ *           d w / d sigma = T delta != 0; the dense step adds (d rgb . c_s) T delta to that sample's d sigma, this selection drops it with
+ *           the colour.  Per sample the term is bounded by |d rgb| delta; such samples sit on the zero crossing of the density ReLU.)
  * Outputs of phase 1 (caller-allocated, the NerfOutput of the step's render): ray_dirs[N,3], z_vals[N,S_t], points[N,S_t,3],
  * normals[N S_t,3], colors[N S_t,3], weights[N,S_t], rgb[N,3], depth[N]; out_terms[8] as vfn_vf_loss_fwd; out_counts[2] (optional) =
  * the number of samples the colour branch was evaluated for (sparse_colours: those with w > 0) and N S_t.  Phase 2: out_norm[2] as

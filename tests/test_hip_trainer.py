@@ -930,6 +930,7 @@ def test_train_step_is_the_same_step_with_and_without_the_fused_loss():
     out = {}
     for mode in ("fused", "dense", "compact"):
         model = build_model(fx, d, device=DEV)
+        model.step_sessions = False              # (launch by launch: no step session behind render() either)
         model.one_call_train_step = False        # the three LOSS formulations through the same (launch-by-launch) step; the one-call step
         supervision.manual_seed(5)               # has its own comparisons (test_one_call_*)
         step = trainer.TrainStep(model, (0.0, 0.0, 0.55), border_radius=0.15, far=1.0, compact_selection=(mode == "compact"))
@@ -976,6 +977,7 @@ def test_one_call_training_step_equals_the_launch_by_launch_step(mode):
         elif mode == "single_product":
             model.training_products = 1
         model.one_call_train_step = path == "one_call"
+        model.step_sessions = path == "one_call"                    # (the launch-by-launch leg: no step session behind render() either)
         model.sparse_colour_training = mode != "dense_colours"      # (the C call's default: the colour branch only where w > 0; exact)
         model.rng_seed, model._rng_offset = 5, 0
         supervision.manual_seed(9)
@@ -1068,6 +1070,7 @@ def test_sparse_colour_branch_gives_the_dense_gradients():
             model, uv, pose, K = bench.build_scene(dev, 512, 64, 64, seed=0)
             model.activation_storage = model.gradient_storage = storages
             model.one_call_train_step, model.sparse_colour_training = one_call, sparse
+            model.step_sessions = one_call
             model.rng_seed, model._rng_offset = 3, 0
             supervision.manual_seed(21)
             gen = torch.Generator().manual_seed(2)
@@ -1128,6 +1131,7 @@ def test_sparse_colour_branch_edge_cases(case):
                 head.weight[:3].mul_(12.0)
         model.vector_field_network._invalidate_packs()
         model.one_call_train_step = path == "one_call"
+        model.step_sessions = path == "one_call"
         supervision.manual_seed(4)
         snap = Snapshot(model)
         step = trainer.TrainStep(model, (0.0, 0.0, 0.55), border_radius=0.15, far=1.0, bucket=snap)

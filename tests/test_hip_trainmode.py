@@ -220,6 +220,31 @@ def test_training_mode_render_outside_the_split_f16_range():
     assert bool(torch.isfinite(got.coarse_normals).all()) and torch.equal(got.z_vals, want.z_vals)
     assert float((got.coarse_normals - want.coarse_normals).abs().max()) <= 1e-6
     assert float((got.coarse_rgb_values - want.coarse_rgb_values).abs().max()) <= 1e-6
+    # ... and the flagged attempt left no trace in the BatchNorm running statistics: they are finite, they are the exact
+    # model's after its ONE call, and every layer counts the batches of one render, not of two
+    for net_e, net_g in ((exact.vector_field_network, model.vector_field_network), (exact.rendering_network, model.rendering_network)):
+        for i in range(net_g.num_layers):
+            bn_e, bn_g = net_e._bn(i), net_g._bn(i)
+            if bn_g is None:
+                continue
+            assert bool(torch.isfinite(bn_g.running_mean).all()) and bool(torch.isfinite(bn_g.running_var).all())
+            assert int(bn_g.num_batches_tracked) == int(bn_e.num_batches_tracked)
+            scale = float(bn_e.running_var.abs().max()) + float(bn_e.running_mean.abs().max()) + 1.0
+            assert float((bn_g.running_mean - bn_e.running_mean).abs().max()) <= 1e-5 * scale
+            assert float((bn_g.running_var - bn_e.running_var).abs().max()) <= 1e-5 * scale
+    # lazy mode: the flagged call returns clamped but FINITE values, and so are the statistics it advanced
+    lazy = _train_model(fx, d)
+    blow_up(lazy)
+    lazy.precision, lazy.f16x3_guard = "f16x3", "lazy"
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        got_lazy = render(lazy, d["pose"])
+    assert bool(torch.isfinite(got_lazy.coarse_normals).all())
+    for net in (lazy.vector_field_network, lazy.rendering_network):
+        for i in range(net.num_layers):
+            bn = net._bn(i)
+            if bn is not None:
+                assert bool(torch.isfinite(bn.running_mean).all()) and bool(torch.isfinite(bn.running_var).all())
 
 
 def test_vf_forward_training_mode_against_oracle_and_reference():

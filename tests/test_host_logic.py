@@ -519,7 +519,7 @@ def test_dense_centre_selection_gives_the_compacted_loss_and_gradient():
     assert abs(la - lb) < 1e-6 and abs(sa - sb) < 1e-6 and float((ga - gb).abs().max()) < 1e-7
 
 
-def _dp_step_worker(rank, world, port, result_dir):
+def _dp_step_worker(rank, world, port, result_dir, sequence="explicit"):
     """One data-parallel optimizer step on the CPU: this rank's shard of the fixture's rays through the ORACLE's render + autograd
     (there is no CPU backend of the product's kernels; the oracle is the checker's compute here), the gradients written into the
     flat bucket, ONE all-reduce, the clip over the duplicated parameter list, the optimizer's step — everything after the gradients
@@ -553,28 +553,36 @@ def _dp_step_worker(rank, world, port, result_dir):
     for p in model.unique_parameters():
         if id(p) in leaves and leaves[id(p)].grad is not None:
             p.grad.copy_(leaves[id(p)].grad)
-    bucket.all_reduce_mean()
-    norm = optim.clip_grad_norm_(model.parameters(), model.config.scheduler_config.clip_norm)
+    if sequence == "drop_in":
+        # the reference trainer's own lines (train/vector_field_nerf_train.py:254-258): the all-reduce sits inside the wrapped
+        # clip_grad_norm_ (vf_nerf_amd.dropin), i.e. still between backward() and the clip
+        import vf_nerf_amd.dropin  # noqa: F401
+        norm = torch.nn.utils.clip_grad_norm_(model.parameters(), model.config.scheduler_config.clip_norm)
+    else:
+        bucket.all_reduce_mean()
+        norm = optim.clip_grad_norm_(model.parameters(), model.config.scheduler_config.clip_norm)
     model.optimizer.step()
     watched = {k: dict(net.named_parameters())[k].detach().clone()
                for net, k in ((model.vector_field_network, "layers.5.0.weight"), (model.vector_field_network, "layers.8.weight"),
                               (model.rendering_network, "layers.2.0.weight"), (model.rendering_network, "layers.4.bias"))}
-    torch.save({"loss": float(loss), "norm": float(norm), "w": watched, "rays": hi - lo}, os.path.join(result_dir, f"dp_w{world}_r{rank}.pt"))
+    torch.save({"loss": float(loss), "norm": float(norm), "w": watched, "rays": hi - lo}, os.path.join(result_dir, f"dp_{sequence}_w{world}_r{rank}.pt"))
     if world > 1:
         dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_step_equals_the_single_process_step():
-    """BASELINE.json configs[3] in small, on the CPU: the rays of a batch sharded over two ranks, one all-reduce (mean) of the flat
+@pytest.mark.parametrize("sequence", ["explicit", "drop_in"])
+def test_two_rank_data_parallel_step_equals_the_single_process_step(sequence):
+    """("drop_in": the all-reduce where the reference's unchanged trainer reaches it — inside the wrapped clip_grad_norm_.)
+    BASELINE.json configs[3] in small, on the CPU: the rays of a batch sharded over two ranks, one all-reduce (mean) of the flat
     gradient bucket before the clip, then the optimizer's step — against ONE process taking the same step on the whole batch.  With
     equal shards the mean of the shard losses is the batch loss, so the clip norm and the weights after the step must agree (both
     ranks with each other exactly; with the single process up to the order of the sums)."""
-    port = 29700 + (os.getpid() % 2000)
+    port = 29700 + (os.getpid() % 2000) + (5000 if sequence == "drop_in" else 0)
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_dp_step_worker, args=(1, port, tmp), nprocs=1, join=True)      # (own process: the worker pins torch's thread count)
-        mp.spawn(_dp_step_worker, args=(2, port, tmp), nprocs=2, join=True)
-        one = torch.load(os.path.join(tmp, "dp_w1_r0.pt"))
-        two = [torch.load(os.path.join(tmp, f"dp_w2_r{r}.pt")) for r in range(2)]
+        mp.spawn(_dp_step_worker, args=(1, port, tmp, sequence), nprocs=1, join=True)      # (own process: the worker pins torch's thread count)
+        mp.spawn(_dp_step_worker, args=(2, port, tmp, sequence), nprocs=2, join=True)
+        one = torch.load(os.path.join(tmp, f"dp_{sequence}_w1_r0.pt"))
+        two = [torch.load(os.path.join(tmp, f"dp_{sequence}_w2_r{r}.pt")) for r in range(2)]
     assert one["rays"] == 48 and [t["rays"] for t in two] == [24, 24]
     assert abs(0.5 * (two[0]["loss"] + two[1]["loss"]) - one["loss"]) < 1e-6 * max(1.0, abs(one["loss"]))
     assert abs(two[0]["norm"] - two[1]["norm"]) == 0.0 and abs(two[0]["norm"] - one["norm"]) < 1e-4 * one["norm"]

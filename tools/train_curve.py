@@ -34,6 +34,7 @@ def student(precision, activations, gradients, stream=0):
     model.precision, model.activation_storage, model.gradient_storage = precision, activations, gradients
     # A/B of the step's issue paths on the same streams: VFN_ONE_CALL=0 the launch-by-launch Python path, VFN_SPARSE_COLOURS=0 the dense C call
     model.one_call_train_step = os.environ.get("VFN_ONE_CALL", "1") != "0"
+    model.step_sessions = model.one_call_train_step            # VFN_ONE_CALL=0: the launch-by-launch autograd path of rounds 1-3
     model.sparse_colour_training = os.environ.get("VFN_SPARSE_COLOURS", "1") != "0"
     model.train_step_streams = int(os.environ.get("VFN_TRAIN_STREAMS", "2"))
     if os.environ.get("VFN_BATCH_STATISTICS") == "1":       # networks in training mode (batch-statistics BatchNorm); VFN_GEMM=fp32: exact layer products

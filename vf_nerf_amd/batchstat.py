@@ -82,6 +82,31 @@ def _arith(net, backward: bool, first_layer: bool = False) -> int:
     return lib.GEMM_BF16X6 if (backward or first_layer) else lib.GEMM_SPLIT_F16
 
 
+def running_stats_snapshot(*nets):
+    """Copies of the BatchNorm running statistics (and batch counters) of the nets that are in batch-statistics mode: a guarded call that
+    ends FLAGGED (a split-f16 operand out of range; strict mode repeats it on the exact products) must not have advanced them — neither
+    with the flagged attempt's clamped values nor twice."""
+    snap = []
+    for net in nets:
+        if net is None or not net._batch_statistics():
+            continue
+        for i in range(net.num_layers):
+            bn = net._bn(i)
+            if bn is not None:
+                snap.append((net, bn, bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()))
+    return snap
+
+
+def running_stats_restore(snap) -> None:
+    with torch.no_grad():
+        for net, bn, mean, var, count in snap:
+            bn.running_mean.copy_(mean)
+            bn.running_var.copy_(var)
+            bn.num_batches_tracked.copy_(count)
+    for net in {id(e[0]): e[0] for e in snap}.values():
+        net._invalidate_packs()
+
+
 def _split(net) -> bool:
     """Split-operand products on the 16-bit matrix cores?  Not when the facade asks for the exact kernels (``model.precision = "fp32"``,
     also what the range guard switches to) or the net itself does (``net.gemm_arithmetic = "fp32"``)."""

@@ -390,7 +390,12 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 unsigned short h, m, l;
-                split3<ARITH>((t < 4 ? a0[t & 3] : a1[t & 3]) * A_SCALE, h, m, l);
+                float av = (t < 4 ? a0[t & 3] : a1[t & 3]) * A_SCALE;
+                // split f16 form: an element beyond the range (reported below) is SATURATED to the largest finite half, as the fused f16x3
+                // kernels saturate — the flagged call then returns clamped values, never inf - inf = NaN products (which the BatchNorm running
+                // statistics of a training-mode forward would keep)
+                if constexpr (ARITH == 0) av = __builtin_amdgcn_fmed3f(av, -65504.0f, 65504.0f);
+                split3<ARITH>(av, h, m, l);
                 ah[t] = h; am[t] = m; al[t] = l;
             }
 #pragma unroll

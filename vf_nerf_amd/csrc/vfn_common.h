@@ -73,3 +73,12 @@ int vfn_internal_fused16_products_dev(const vfn_net_geom* vf_geom, const void* v
                                       const int32_t* out_index, int32_t colour_products, float* normals, float* colors, void* stream);
 // csrc/vfn_mlp16.hip: the calling thread's range-report word (vfn_f16x3_set_status), or NULL
 uint32_t* vfn_internal_f16x3_status();
+// The report targets of ONE composite call (vfn_render_params.status_word / clock_stamps): in force for the f16x3 launches the call
+// issues, the thread's previous targets back in place when the scope ends.  NULL members leave the thread's targets as they are.
+struct VfnReportScope {
+    VfnReportScope(uint32_t* status_word, uint64_t* clock_stamps, int64_t clock_slots);
+    ~VfnReportScope();
+    VfnReportScope(const VfnReportScope&) = delete;
+    VfnReportScope& operator=(const VfnReportScope&) = delete;
+    uint32_t* old_status; unsigned long long* old_clock; long long old_slots;
+};

@@ -1227,6 +1227,13 @@ extern "C" int vfn_f16x3_set_clock_probe(uint64_t* stamps, int64_t slots) {
     return VFN_OK;
 }
 
+VfnReportScope::VfnReportScope(uint32_t* status_word, uint64_t* clock_stamps, int64_t clock_slots)
+    : old_status(t_status_word), old_clock(t_clock_probe), old_slots(t_clock_slots) {
+    if (status_word) t_status_word = status_word;
+    if (clock_stamps && clock_slots > 0) { t_clock_probe = reinterpret_cast<unsigned long long*>(clock_stamps); t_clock_slots = clock_slots; }
+}
+VfnReportScope::~VfnReportScope() { t_status_word = old_status; t_clock_probe = old_clock; t_clock_slots = old_slots; }
+
 extern "C" int vfn_vf_mlp16_fwd(const vfn_net_geom* geom, const void* packed16, const float* points, int64_t n_points,
                                  float* out_vec, void* stream) {
     Mlp16Args a = {};

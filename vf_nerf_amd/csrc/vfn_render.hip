@@ -104,6 +104,7 @@ extern "C" int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf
                               void* stream) {
     VFN_REQUIRE(p && vf_geom && rn_geom, "vfn_render_fwd: NULL argument");
     if (p->n_rays == 0) return VFN_OK;
+    VfnReportScope report(p->status_word, p->clock_stamps, p->clock_slots);
     VFN_REQUIRE(p->n_rays > 0 && p->n_coarse >= 1 && p->n_fine >= 2, "vfn_render_fwd: bad sizes (n_rays=%d, n_coarse=%d, n_fine=%d)",
                 p->n_rays, p->n_coarse, p->n_fine);
     VFN_REQUIRE(vf_packed16 && rn_packed16 && uv && pose && intrinsics && t_vals && density_scalars && workspace && ray_dirs && z_vals &&

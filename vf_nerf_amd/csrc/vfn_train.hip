@@ -518,6 +518,7 @@ extern "C" int vfn_train_step_supervision_forward(const vfn_train_step_params* p
                                                   void* stream) {
     VFN_REQUIRE(p && io && io->vf_geom && io->rn_geom && io->workspace && io->vf_packed16, "vfn_train_step_supervision_forward: NULL argument");
     VFN_REQUIRE(p->save_flags & 2, "vfn_train_step_supervision_forward: the fragment-ordered workspace only (save_flags bit 1)");
+    VfnReportScope report(p->render.status_word, nullptr, 0);
     Ws w;
     int rc;
     STEP(carve(io->workspace, p, io->vf_geom, io->rn_geom, &w));
@@ -573,6 +574,7 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
     const int n = r.n_rays, sc = r.n_coarse, nf = r.n_fine, st = sc + nf;
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    VfnReportScope report(r.status_word, nullptr, 0);
 
     if (p->phases & (VFN_TRAIN_FORWARD_BACKWARD | VFN_TRAIN_RENDER | VFN_TRAIN_BACKWARD)) {
         VFN_REQUIRE(io->workspace, "vfn_train_step: NULL workspace");

@@ -117,6 +117,46 @@ def cache_centroid(cls) -> None:
     cls.get_centroid = get_centroid
 
 
+# One process per GPU (vf_nerf_amd.distributed replaces the reference's nn.DataParallel, models/nerf/vector_field_nerf.py:70-75): the
+# unchanged trainer has no line for the gradient all-reduce, and the one place every replica passes between backward() and
+# optimizer.step() is its clip_grad_norm_ call (train/vector_field_nerf_train.py:254-255).  With a process group of more than one rank
+# the wrapped clip_grad_norm_ first averages the gradients of the list it was given over the ranks — ONE all-reduce of the flat gradient
+# buffer when the list is the flat optimizer's — so that every replica clips and steps identically.  False: the caller does it.
+data_parallel = True
+
+
+def all_reduce_gradients(plist) -> bool:
+    """Mean over the ranks of the gradients of ``plist`` (no-op without a process group of > 1 ranks).  -> whether a collective ran."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+        return False
+    from . import optim
+    world = dist.get_world_size()
+    owner = optim.owner_of(plist[0])
+    if owner is not None and owner.regions_for(plist):
+        f = owner.flat()
+        owner._rebind_grads(f)
+        dist.all_reduce(f["grad"], op=dist.ReduceOp.SUM)
+        f["grad"].div_(world)
+        return True
+    seen, grads = set(), []
+    for p in plist:
+        if id(p) not in seen and p.grad is not None:
+            seen.add(id(p))
+            grads.append(p.grad)
+    if not grads:
+        return False
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(world)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+    return True
+
+
 _torch_clip = None
 
 
@@ -136,6 +176,8 @@ def _patch_clip_grad_norm() -> None:
 
     def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=False, foreach=None):
         plist = [parameters] if isinstance(parameters, torch.Tensor) else list(parameters)
+        if data_parallel and plist:
+            all_reduce_gradients(plist)
         if float(norm_type) == 2.0 and not error_if_nonfinite and plist:
             owner = optim.owner_of(plist[0])
             if owner is not None and owner.regions_for(plist):     # the flat optimizer's own list (duplicates and all): two launches

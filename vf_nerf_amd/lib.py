@@ -79,7 +79,7 @@ class RenderParams(C.Structure):
                 ("perturb_coarse", C.c_int32), ("perturb_fine", C.c_int32), ("near_coarse", C.c_float), ("near_fine", C.c_float),
                 ("far_coarse", C.c_float), ("far_fine", C.c_float), ("fine_range", C.c_float), ("window_step", C.c_float), ("span", C.c_float),
                 ("density", DensityParams), ("seed", C.c_uint64), ("offset", C.c_uint64), ("colour_products", C.c_int32), ("separate_launches", C.c_int32), ("streams", C.c_int32), ("sparse_colours", C.c_int32),
-                ("timing_events", C.c_void_p * 4)]
+                ("timing_events", C.c_void_p * 4), ("status_word", C.c_void_p), ("clock_stamps", C.c_void_p), ("clock_slots", C.c_int64)]
 
 
 class LossParams(C.Structure):

@@ -512,11 +512,19 @@ class VectorFieldNerf:
         if not self.uses_f16x3():
             return self._render(pose, pixels, intrinsics, epoch, white, uniforms)
         rng_offset = self._rng_offset
+        snap = None
+        if guard.mode == "strict" and (self.vector_field_network._batch_statistics() or self.rendering_network._batch_statistics()):
+            # a training-mode forward advances the BatchNorm running statistics: a flagged first attempt must leave no trace in them
+            from .batchstat import running_stats_snapshot
+            snap = running_stats_snapshot(self.vector_field_network, self.rendering_network)
         with guard.watch(pose.device) as w:
             out = self._render(pose, pixels, intrinsics, epoch, white, uniforms)
             w.sample(out)                          # two-product colours: measured against three products on a few rays
         if w.flagged:                              # strict mode: repeat this call on the kernels the guard switched to, same draws
             self._rng_offset = rng_offset
+            if snap:
+                from .batchstat import running_stats_restore
+                running_stats_restore(snap)
             out = self._render(pose, pixels, intrinsics, epoch, white, uniforms)
         return out
 

@@ -125,7 +125,7 @@ class StepEngine:
             return "the optimizer is not the flat Adam over exactly model.parameters()"
         if not (_direct_ok(vf, pose.device) and _direct_ok(rn, pose.device)):
             return "a parameter is frozen, hooked or without a flat gradient view"
-        if any(not p.requires_grad for p in model.density.parameters()) or not hasattr(model.density, "scale"):
+        if any(not p.requires_grad for p in self._anchors()[2:]) or not hasattr(model.density, "scale"):
             return "density scalars frozen or absent"
         return None
 
@@ -219,6 +219,9 @@ class StepEngine:
         rp.span = (far_f - float(model.fine_sampler.near)) if far_ft is None else 0.0
         rp.density = model._density_params()
         rp.streams = int(streams)
+        # where this step's f16x3 forwards report operands outside their range: a field of the call's struct (no per-thread setter)
+        guard = model.range_guard
+        rp.status_word = _p(guard._state(dev)["status"]) if guard.active() else None
 
         def given(name, needed, shape):
             if not (needed and name in uniforms):
@@ -259,7 +262,7 @@ class StepEngine:
         self._single = single
         vf16, rn16, vfb, rnb = self.packs(single)
         io.vf_packed16, io.rn_packed16, io.vf_packed_bwd16, io.rn_packed_bwd16 = _p(vf16), _p(rn16), _p(vfb), _p(rnb)
-        # the colour branch only where a sample's weight is non-zero (exact: include/vfn.h, vfn_train_step); False: dense, as the Python path
+        # the colour branch only where a sample's weight is non-zero (the dense step up to one underflow corner: include/vfn.h, vfn_train_step); False: dense, as the Python path
         pr.sparse_colours = int(bool(getattr(model, "sparse_colour_training", True)))
         return single
 
@@ -333,6 +336,16 @@ class StepEngine:
         io.out_counts = views[9].data_ptr() + 8           # [2:4] of the same little tensor: samples the colour branch ran on, all samples
         return views
 
+    def _anchors(self):
+        """One parameter of each net and the density's scalars: what makes a step's outputs differentiable (their gradients are written in
+        place by the C call; the module tree is walked once)."""
+        a = getattr(self, "_anchor_cache", None)
+        if a is None or any(p.device != a[1] for p in a[0][:1]):
+            model = self.model
+            params = [next(iter(model.vector_field_network.parameters())), next(iter(model.rendering_network.parameters()))] + list(model.density.parameters())
+            a = self._anchor_cache = (params, params[0].device)
+        return a[0]
+
     def supersede(self) -> None:
         """The structs are about to describe another step: a session still open on them can no longer run its backward."""
         s = self.session
@@ -385,8 +398,7 @@ class StepEngine:
         io.rgb_gt = io.depth_gt = io.sup_u_border = io.sup_u_center = None
         io.d_rgb_in = io.d_depth_in = io.d_normals_in = None
         session = StepSession(self, n, s_c, n_f, sup_rows, ws, lay, views, f)
-        params = [next(iter(model.vector_field_network.parameters())), next(iter(model.rendering_network.parameters()))] + list(model.density.parameters())
-        rgb, depth, normals = _SessionRender.apply(session, *params)
+        rgb, depth, normals = _SessionRender.apply(session, *self._anchors())
         del keep_alive
         self.session = session
         _current = weakref.ref(session)
@@ -434,19 +446,13 @@ class StepSession:
             raise RuntimeError(f"{what}: a later render() or training step has reused this step's workspace (one open step per model; "
                                "set model.step_sessions = False to differentiate several renders in one backward)")
 
-    def _watch(self):
-        guard = self.model.range_guard
-        return guard.watch(self.ws.device) if guard.active() else _NoWatch()
-
     # -- forward side -----------------------------------------------------------------------------
     def render(self) -> None:
+        # (VectorFieldNerf.render holds the range guard's watch around this call; the supervision forwards that follow report into the same
+        # status word through the struct's status_word field, and the next guarded call's read-back sees what they left there)
         eng = self.engine
-        guard = self.model.range_guard
-        if guard.active():
-            guard.poll()
         eng.params.phases = lib.TRAIN_RENDER
-        with self._watch():
-            lib.train_step(eng.params, eng.io)
+        lib.train_step(eng.params, eng.io)
 
     def take(self, count: int) -> Optional[int]:
         """First row of a fresh supervision region of ``count`` points (whole groups of 32 are set aside), or None when there is no room."""
@@ -497,8 +503,7 @@ class StepSession:
     def forward_rows(self, row0: int) -> torch.Tensor:
         reg = self.regions[row0]
         eng = self.engine
-        with self._watch():
-            lib.train_step_supervision_forward(eng.params, eng.io, row0, reg["count"], reg["on_side"])
+        lib.train_step_supervision_forward(eng.params, eng.io, row0, reg["count"], reg["on_side"])
         reg["forwarded"] = True
         return self.sup_pred[row0:row0 + reg["count"]]
 
@@ -569,16 +574,6 @@ class StepSession:
         self.backward_done = True
         self.open = False
         self.model._last_colour_counts = self.out_norm[2:4]
-
-
-class _NoWatch:
-    flagged = False
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        return False
 
 
 class _SessionRender(torch.autograd.Function):
@@ -726,8 +721,7 @@ def session_vf_forward(net, points: torch.Tensor):
     row0 = session.region_of(points)
     if row0 is None:
         return None
-    anchor = next(iter(net.parameters()))
-    vec = _SessionVF.apply(session, row0, anchor)
+    vec = _SessionVF.apply(session, row0, session.engine._anchors()[0])
     pts = points
 
     def make_full():
