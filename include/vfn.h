@@ -757,6 +757,9 @@ typedef struct vfn_train_step_params {
     int32_t sparse_colours;             /* != 0: the colour branch (feature block + rendering net) is evaluated, differentiated and summed into the
                                          * weight gradients only for the samples whose weight is non-zero (see below) */
     int64_t sup_rows_reserved;          /* session form: rows (a multiple of 32) of the supervision region; 0: pad32(n_sup (border + center)) */
+    int64_t sup_rows_used;              /* session form, VFN_TRAIN_BACKWARD: the leading rows (a multiple of 32, <= sup_rows_reserved) of that region that
+                                         * supervision forwards have filled — the chain and the weight gradients walk these and no others (a row no
+                                         * forward has written holds no activations) */
 } vfn_train_step_params;
 typedef struct vfn_train_step_io {
     const vfn_net_geom* vf_geom; const vfn_net_geom* rn_geom;

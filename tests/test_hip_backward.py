@@ -692,6 +692,7 @@ def test_shared_step_workspace_gives_the_same_gradients(name):
     for shared in (True, False):
         model = build_model(fx, d, device="cuda:0")
         model.shared_step_workspace = shared
+        model.step_sessions = False                                   # (the pool of the launch-by-launch autograd path is what is tested here)
         vf = model.vector_field_network
         model.optimizer.zero_grad()                                   # gradient views exist: results are added in place
         out = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)

@@ -361,6 +361,13 @@ int step_render(StepCtx& c) {
 // w.dn (where the per-ray backward ADDS the density path's share), its d supervision predictions in w.d_sup
 int step_backward(StepCtx& c, const float* d_rgb, const float* d_depth) {
     const vfn_train_step_params* p = c.p; const vfn_train_step_io* io = c.io; Ws& w = c.w;
+    // supervision rows the chains and weight gradients walk: all of them in the whole-step form; in the session form those that forwards filled
+    long long sup_rows = w.m_sup_pad;
+    if (p->sup_rows_reserved > 0) {
+        VFN_REQUIRE(p->sup_rows_used >= 0 && p->sup_rows_used % 32 == 0 && p->sup_rows_used <= w.m_sup_pad,
+                    "vfn_train_step: sup_rows_used = %lld (a multiple of 32, at most %lld)", (long long)p->sup_rows_used, w.m_sup_pad);
+        sup_rows = p->sup_rows_used;
+    }
     hipStream_t s = c.s, ss = c.ss;
     Side* sd = c.sd;
     const bool sparse = c.sparse;
@@ -395,20 +402,20 @@ int step_backward(StepCtx& c, const float* d_rgb, const float* d_depth) {
                                                      w.scratch_rn, ss));
         // ONE vector-only chain over region 1 and the supervision rows (d normals | d supervision predictions)
         STEP(vfn_mlp_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, nullptr, nullptr, nullptr, feats, w.masks, w.dy, p->dy_flags,
-                                          nullptr, nullptr, w.dn_s, w.normals_s, nullptr, 3, w.m + w.m_sup_pad, nullptr, w.dz_vec, 0, w.total, s));
+                                          nullptr, nullptr, w.dn_s, w.normals_s, nullptr, 3, w.m + sup_rows, nullptr, w.dz_vec, 0, w.total, s));
         STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form, nullptr,
-                                            w.aux_vf, w.dz_vec, w.m + w.m_sup_pad, VFN_WGRAD_LAYERS | VFN_WGRAD_HEAD, 1, w.scratch_vf, s));
+                                            w.aux_vf, w.dz_vec, w.m + sup_rows, VFN_WGRAD_LAYERS | VFN_WGRAD_HEAD, 1, w.scratch_vf, s));
         // (the vector-field net's gradients of region 2 are ADDED to the same tensors: after both of the above)
         if (sd) STEP(join_into(sd, s));
         STEP(vfn_internal_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved + r2_off, w.dy + r2_off, (int64_t)w.slot_bytes,
                                                      p->dy_form, p->x_form, nullptr, w.aux_vf + w.r2_first * 40, w.dz_vec + w.r2_first * 4, w.cap,
                                                      w.k_dev, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES, 1, w.scratch_vf, s));
     } else {
-        if (w.m_sup_pad > 0) {
+        if (sup_rows > 0) {
             // (beside the per-ray backward and the fine pass's chain when there is a side stream; joined in front of the weight gradients)
             if (sd) STEP(fork_to(sd, s));
             STEP(vfn_mlp_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, nullptr, nullptr, nullptr, feats, w.masks, w.dy,
-                                              p->dy_flags, nullptr, nullptr, w.d_sup, w.sup_pred, nullptr, 3, w.m_sup_pad, nullptr, w.dz_vec, w.m,
+                                              p->dy_flags, nullptr, nullptr, w.d_sup, w.sup_pred, nullptr, 3, sup_rows, nullptr, w.dz_vec, w.m,
                                               w.total, ss));
         }
         STEP(vfn_ray_density_weights_bwd(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, d_rgb, d_depth, nullptr, w.dn, w.dc, w.dscal, s));
@@ -421,10 +428,10 @@ int step_backward(StepCtx& c, const float* d_rgb, const float* d_depth) {
                                             p->dy_form, p->x_form, feats, w.aux_rn, w.dz_rgb, w.m,
                                             VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD, 1, w.scratch_rn, s));
         // vector-field net: hidden layers + head over ALL rows (fine pass + supervision), the feature block over the fine pass's rows
-        if (sd && w.m_sup_pad > 0) STEP(join_into(sd, s));
-        if (w.m_sup_pad > 0) {
+        if (sd && sup_rows > 0) STEP(join_into(sd, s));
+        if (sup_rows > 0) {
             STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form,
-                                                nullptr, w.aux_vf, w.dz_vec, w.m + w.m_sup_pad, VFN_WGRAD_LAYERS | VFN_WGRAD_HEAD, 1, w.scratch_vf, s));
+                                                nullptr, w.aux_vf, w.dz_vec, w.m + sup_rows, VFN_WGRAD_LAYERS | VFN_WGRAD_HEAD, 1, w.scratch_vf, s));
             STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form,
                                                 nullptr, w.aux_vf, w.dz_vec, w.m, VFN_WGRAD_FEATURES, 1, w.scratch_vf, s));
         } else {

@@ -97,7 +97,7 @@ class TrainStepParams(C.Structure):
                 ("x_form", C.c_int32), ("forward_products", C.c_int32), ("repack", C.c_int32), ("n_regions", C.c_int32), ("mults", C.c_int32 * 4),
                 ("starts", C.c_int64 * 4), ("ends", C.c_int64 * 4), ("step_size", C.c_double * 8), ("bc2_sqrt", C.c_double * 8),
                 ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double), ("max_norm", C.c_float),
-                ("sparse_colours", C.c_int32), ("sup_rows_reserved", C.c_int64)]
+                ("sparse_colours", C.c_int32), ("sup_rows_reserved", C.c_int64), ("sup_rows_used", C.c_int64)]
 
 
 class TrainStepIO(C.Structure):

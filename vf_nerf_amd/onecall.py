@@ -59,9 +59,10 @@ class OneCallStep:
         # the all-reduce of a multi-rank step runs on the bucket's buffer; phase 2 clips and applies the optimizer's flat gradient: they
         # must be one buffer (a bucket built before the optimizer had its flat storage owns another one)
         bucket = step.bucket
-        if bucket is not None:
+        flat = getattr(bucket, "flat", None)            # (distributed.GradientBucket; a stand-in without a buffer of its own has nothing to diverge)
+        if flat is not None:
             f = model.optimizer.flat()
-            if f is None or bucket.flat.data_ptr() != f["grad"].data_ptr():
+            if f is None or flat.data_ptr() != f["grad"].data_ptr():
                 return no("the gradient bucket is not the optimizer's flat gradient buffer")
         self.why_not = None
         return True

@@ -226,6 +226,7 @@ class FlatAdam(SequentialAdam):
             if g is view:
                 continue
             if g is None:
+                view.zero_()                  # (None IS a zero gradient: the view must not bring back what an earlier step left in the buffer)
                 p.grad = view
             elif g.data_ptr() != view.data_ptr():
                 view.copy_(g)

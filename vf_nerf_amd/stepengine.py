@@ -77,7 +77,7 @@ def host_centroid(centroid) -> Optional[Tuple[float, float, float]]:
 
 class StepEngine:
     def __init__(self, model) -> None:
-        self.model = model
+        self._model_ref = weakref.ref(model)     # (the model owns the engine: no reference cycle keeps a 30 GB workspace waiting for the cyclic collector)
         self.params = lib.TrainStepParams()
         self.io = lib.TrainStepIO()
         self._built_for = None
@@ -86,6 +86,10 @@ class StepEngine:
         self._layouts: Dict[tuple, List[int]] = {}
         self.session: Optional[StepSession] = None
         self.why_not: Optional[str] = None  # the reason the last step did not take the C path (diagnostics / tests)
+
+    @property
+    def model(self):
+        return self._model_ref()
 
     @staticmethod
     def of(model) -> "StepEngine":
@@ -414,7 +418,7 @@ class StepSession:
     """One training step between a grad-mode render() and its backward (see the module docstring)."""
 
     def __init__(self, engine: StepEngine, n: int, s_c: int, n_f: int, sup_rows: int, ws: torch.Tensor, lay: List[int], views, flat) -> None:
-        self.engine, self.model = engine, engine.model
+        self.engine, self.model = engine, engine.model      # (a session lives for one step; the model holds the engine, which holds the last session)
         self.n, self.s_c, self.n_f, self.s_t, self.m = n, s_c, n_f, s_c + n_f, n * (s_c + n_f)
         self.sup_rows = sup_rows
         self.ws, self.flat = ws, flat
@@ -566,6 +570,15 @@ class StepSession:
             self.dn.zero_()
             d_normals = self.dn
         io.d_rgb_in, io.d_depth_in, io.d_normals_in = _p(d_rgb), _p(d_depth), _p(d_normals)
+        # the chain walks the supervision rows that forwards have filled, up to the last such region; a region below it that was sampled
+        # but never forwarded (its rows hold no activations) is forwarded now — its upstream gradient is zero, it adds exactly nothing
+        used = 0
+        for row0, reg in sorted(self.regions.items(), reverse=True):
+            if reg["forwarded"]:
+                used = max(used, row0 + _round32(reg["count"]))
+            elif row0 < used:
+                self.forward_rows(row0)
+        eng.params.sup_rows_used = used
         eng.params.phases = lib.TRAIN_BACKWARD
         lib.train_step(eng.params, eng.io)
         io.d_rgb_in = io.d_depth_in = io.d_normals_in = None
