@@ -122,7 +122,7 @@ def live_hbm_traffic(args, timeout_s: float = 60.0):
     except OSError as e:
         return None, {"live": False, "why": f"no scratch directory under /tmp: {e}"[:300]}
     child = [sys.executable, os.path.abspath(__file__), "--no-live-traffic", "--no-cpu-baseline", "--no-train", "--no-two-product-leg",
-             "--no-random-weight-leg", "--steps", "5", "--warmup", "2", "--sustain-seconds", "0", "--rays", str(args.rays), "--coarse",
+             "--no-random-weight-leg", "--no-shipped-rows", "--steps", "5", "--warmup", "2", "--sustain-seconds", "0", "--rays", str(args.rays), "--coarse",
              str(args.coarse), "--fine", str(args.fine), "--weights", args.weights] + \
             (["--colour-products", str(args.colour_products)] if args.colour_products else [])
     kb = {}
@@ -335,7 +335,55 @@ def ray_accounting(z, rgb, depth, ref_z, ref_rgb, ref_depth, tol=1e-4, z_tol=0.0
             "max_abs_rgb_err": float(e_rgb.max()), "mean_abs_depth_err": float(e_dep.mean())}
 
 
-def trained_weights_parity(dev, precision="f16x3"):
+def ray_error_sources(rgb_a, depth_a, normals_a, sigma_a, ref, settings, O, tol=1e-4):
+    """WHY a ray of side a (a HIP render) is outside the contract against side b (the oracle's dict ``ref`` on the same rays and draws).
+    The candidates: (1) a density decision that fell on the other side — the Laplace density's ReLU (density_functions.py:129-151) or the
+    mask of models/nerf/vector_field_nerf.py:463-469 — i.e. a sample with sigma == 0 on exactly one side ("flipped"); (2) the normals'
+    own error (|n_a - n_b|, contract 1e-4) amplified by the reference's function downstream of them (cosines of normalised neighbours
+    through an 11-sample window -> Laplace density of scale 100 -> transmittance scan -> weights normalised by their sum); (3) anything
+    else side a did differently (colours, density, scan, compositing).  Per ray outside ``tol``:
+      max_abs_normal_err   max over the ray's samples of |n_a - n_b|                     (what side a actually got wrong)
+      amplification        the ray's rgb / depth error over that
+      min_normal_length    shortest |n_b| among the samples that carry weight on either side
+      flipped_samples      samples with sigma == 0 on exactly one side
+      residual             |rgb, depth of side a - the ORACLE's density + weights + composite evaluated on side a's normals (oracle colours,
+                           oracle depths)|: what is left once the normals' difference is accounted for, i.e. source (3)
+    A ray is EXPLAINED BY ITS NORMALS when residual < tol / 2 and max_abs_normal_err < tol / 5: what side a did downstream of the normals
+    reproduces the oracle's own function to within half the contract (measured: 1e-7), the normals themselves are well inside the
+    contract, and the reference's function amplifies their difference past it on that ray.  Measured at view scale (profiles/r05/): no
+    ray has a flipped sample; the oracle's OWN fp32 evaluation against its float64 one shows the same rays with amplifications of
+    46-670x on normal differences of 3e-6, the f16x3 kernels 19-280x on 5-8e-6, the exact-fp32 kernels 19-150x on 4-6e-6: the number of
+    rays outside 1e-4 (6 / 14 / 10 of 12 750) follows the size of the normals' error, nothing else."""
+    rgb_b, depth_b = ref["rgb"].float(), ref["depth"].float().reshape(-1)
+    e_rgb = (rgb_a - rgb_b).abs().max(dim=1)[0]
+    e_dep = (depth_a.reshape(-1) - depth_b).abs()
+    bad = torch.nonzero((e_rgb >= tol) | (e_dep >= tol)).reshape(-1)
+    n, s_t = ref["z_vals"].shape
+    na, nb = normals_a.reshape(n, s_t, 3).float(), ref["normals"].reshape(n, s_t, 3).float()
+    # the oracle's own function downstream of the normals, on side a's normals
+    sig_x = O.ray_density(na, ref["ray_dirs"].float(), settings.n_window, settings.dir_to_normal_th, settings.density)
+    w_x = O.volsdf_weights(ref["z_vals"].float(), sig_x, settings.normalize)
+    rgb_x = torch.sum(w_x.unsqueeze(-1) * ref["colors"].float().reshape(n, s_t, 3), dim=1)
+    dep_x = torch.sum(w_x * ref["z_vals"].float(), dim=1)
+    res = torch.maximum((rgb_a - rgb_x).abs().max(dim=1)[0], (depth_a.reshape(-1) - dep_x).abs())
+    dn = (na - nb).norm(dim=2)
+    carries = (ref["weights"].float() > 0) | (w_x > 0)
+    length = torch.where(carries, nb.norm(dim=2), torch.full_like(dn, float("inf")))
+    flip = (sigma_a.reshape(n, s_t) == 0) != (ref["sigma"].reshape(n, s_t) == 0)
+    rows = []
+    for r in bad.tolist():
+        err = max(float(e_rgb[r]), float(e_dep[r]))
+        rows.append({"ray": r, "rgb_err": float(e_rgb[r]), "depth_err": float(e_dep[r]), "max_abs_normal_err": float(dn[r].max()),
+                     "amplification": round(err / max(float(dn[r].max()), 1e-30), 1), "min_normal_length": float(length[r].min()),
+                     "flipped_samples": int(flip[r].sum()), "residual": float(res[r])})
+    explained = sum(1 for q in rows if q["residual"] < tol / 2 and q["max_abs_normal_err"] < tol / 5)
+    return {"out_of_tolerance": len(rows), "explained_by_their_normals": explained, "unexplained": len(rows) - explained,
+            "max_abs_normal_err_all_rays": float(dn.max()), "largest_residual": max((q["residual"] for q in rows), default=None),
+            "rays_with_a_flipped_sample": sum(1 for q in rows if q["flipped_samples"]),
+            "rays": sorted(rows, key=lambda q: -max(q["rgb_err"], q["depth_err"]))}
+
+
+def trained_weights_parity(dev, precision="f16x3", fixture=None):
     """The DEFAULT render path on weights the reference's own trainer produced (tests/golden/trained_far.npz: 6 000 steps of
     train_epoch on 256-ray batches of a teacher-rendered target — far from the init family —, else trained_256.npz: 1 200 steps
     x 64 rays; stage outputs captured from the reference's render(); make_trained_golden.py)
@@ -345,18 +393,38 @@ def trained_weights_parity(dev, precision="f16x3"):
     import warnings
     import numpy as np
     import vf_nerf_amd
-    path = next((q for q in (os.path.join(REPO, "tests", "golden", f) for f in TRAINED_FIXTURES) if os.path.exists(q)), None)
+    golden = os.path.join(REPO, "tests", "golden")
+    path = next((q for q in (os.path.join(golden, f) for f in ((fixture,) if fixture else TRAINED_FIXTURES)) if os.path.exists(q)), None)
     if path is None:
         return None
     raw = np.load(path)
     fx = ast.literal_eval(str(raw["fixture"]))
-    recipe = ast.literal_eval(str(raw["train_recipe"]))
-    cfg = vf_nerf_amd.shipped_config(dev, n_samples=fx["n_samples"], n_importance=fx["n_importance"], perturb=fx["perturb"],
-                                     near=fx["near"], far=fx["far"], fine_range=fx["fine_range"], dir_to_normal_th=fx["th"],
-                                     n_window=fx["n_window"])
-    model = vf_nerf_amd.VectorFieldNerf(cfg)
-    for tag, mod in (("vf", model.vector_field_network), ("rn", model.rendering_network), ("density", model.density)):
-        mod.load_state_dict({k[len(f"w.{tag}."):]: torch.from_numpy(raw[k]) for k in raw.files if k.startswith(f"w.{tag}.")})
+    # (``fixture``: another reference-captured fixture — one that names the file its trained weights live in, or one on random weights
+    #  rebuilt from its recipe the way tests/helpers.build_model does)
+    src = np.load(os.path.join(golden, fx["weights_in"] + ".npz")) if "weights_in" in fx else raw
+    recipe = ast.literal_eval(str(src["train_recipe"])) if "train_recipe" in src.files else None
+    if fx.get("trained"):
+        cfg = vf_nerf_amd.shipped_config(dev, n_samples=fx["n_samples"], n_importance=fx["n_importance"], perturb=fx["perturb"],
+                                         near=fx["near"], far=fx["far"], fine_range=fx["fine_range"], dir_to_normal_th=fx["th"],
+                                         n_window=fx["n_window"])
+        model = vf_nerf_amd.VectorFieldNerf(cfg)
+        for tag, mod in (("vf", model.vector_field_network), ("rn", model.rendering_network), ("density", model.density)):
+            mod.load_state_dict({k[len(f"w.{tag}."):]: torch.from_numpy(src[k]) for k in src.files if k.startswith(f"w.{tag}.")})
+    else:
+        from vf_nerf_amd import synthetic
+        torch.manual_seed(fx["seed"])
+        cfg = vf_nerf_amd.shipped_config(torch.device("cpu"), n_samples=fx["n_samples"], n_importance=fx["n_importance"], perturb=fx["perturb"],
+                                         near=fx["near"], far=fx["far"], fine_range=fx["fine_range"], dir_to_normal_th=fx["th"],
+                                         n_window=fx["n_window"])
+        model = vf_nerf_amd.VectorFieldNerf(cfg)
+        synthetic.scale_hidden_weights(model.vector_field_network, model.rendering_network, fx["gain"])
+        with torch.no_grad():
+            last = model.vector_field_network.layers[8]
+            last.weight[:3] = torch.from_numpy(raw["head_weight"])
+            last.bias[:3] = torch.from_numpy(raw["head_bias"])
+        model.to(dev)
+        model.config.cuda_config.device = dev
+        model.config.cos_sim_weights = model.config.cos_sim_weights.to(dev)
     model.eval()
     model.precision = precision
     model.f16x3_guard = "strict"
@@ -366,8 +434,8 @@ def trained_weights_parity(dev, precision="f16x3"):
         warnings.simplefilter("always")
         with torch.no_grad():
             out = model.render(g("pose"), g("uv"), g("intrinsics"), epoch=0, uniforms=uni)
-    rec = {"fixture": f"tests/golden/{os.path.basename(path)} (reference train_epoch x {recipe['epochs'] * recipe['steps_per_epoch']} steps x "
-                      f"{recipe['n_rays']} rays; reference render() outputs)",
+    rec = {"fixture": f"tests/golden/{os.path.basename(path)} (" + (f"reference train_epoch x {recipe['epochs'] * recipe['steps_per_epoch']} steps x "
+                      f"{recipe['n_rays']} rays" if recipe else "random weights") + "; reference render() outputs)",
            "rays": fx["n_rays"], "samples": fx["n_samples"] + fx["n_importance"],
            "colour_products_ran": int(model.colour_products) if model.uses_f16x3() else None,
            "kernels": "f16x3" if model.uses_f16x3() else "fp32",
@@ -435,8 +503,10 @@ def view_bench(args, dev):
         g = torch.Generator().manual_seed(21)
         uni = {"u_add": torch.rand(ws * hs, n_f, generator=g)}
         o = model.render(pose_s, uv_s, K_s, epoch=0, uniforms=uni)
+        sig = model.get_density(o.coarse_normals, o.ray_dirs).cpu()          # the density kernel's own sigma on this render's normals
         model.precision = "fp32"                       # the exact-fp32 HIP kernels on the same rays: the second column of the accounting
         o32 = model.render(pose_s, uv_s, K_s, epoch=0, uniforms=uni)
+        sig32 = model.get_density(o32.coarse_normals, o32.ray_dirs).cpu()
         model.precision = args.precision
         torch.set_num_threads(min(32, os.cpu_count() or 1))
         settings = O.RenderSettings(n_samples=s_c, n_fine=n_f, perturb=False, dir_to_normal_th=-0.2, fine_range=0.3,
@@ -469,6 +539,12 @@ def view_bench(args, dev):
         f64 = {"oracle_f32_vs_oracle_f64": account(ref["z_vals"], ref["rgb"], ref["depth"], r64_z, r64_rgb, r64_dep, exact_z=False),
                "hip_default_vs_oracle_f64": account(o.z_vals.cpu(), rgb, depth, r64_z, r64_rgb, r64_dep, exact_z=False),
                "hip_exact_fp32_vs_oracle_f64": account(o32.z_vals.cpu(), rgb32, depth32, r64_z, r64_rgb, r64_dep, exact_z=False)}
+    # every ray outside the contract, with what puts it there
+    margins = {"hip_default_vs_oracle_f32": ray_error_sources(rgb, depth, o.coarse_normals.cpu(), sig, ref, settings, O),
+               "hip_exact_fp32_vs_oracle_f32": ray_error_sources(rgb32, depth32, o32.coarse_normals.cpu(), sig32, ref, settings, O)}
+    if ref64 is not None:     # the yardstick: the oracle's own fp32 evaluation against its float64 one, same accounting
+        ref64f = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in ref64.items()}
+        margins["oracle_f32_vs_oracle_f64"] = ray_error_sources(ref["rgb"], ref["depth"], ref["normals"], ref["sigma"], ref64f, settings, O)
     emit_line(({
         "metric": "rays/sec (full 1200x680 view, 1024-ray chunks, 128 samples/ray) + PSNR/depth vs ref",
         "value": round(n * args.steps / elapsed, 1), "unit": "rays/s", "n_gpus": 1, "steps": args.steps,
@@ -488,7 +564,9 @@ def view_bench(args, dev):
                              # who is how far from whom, per ray (contract: 1e-4)
                              "hip_default_vs_oracle_f32": account(o.z_vals.cpu(), rgb, depth, ref["z_vals"], ref["rgb"], ref["depth"]),
                              "hip_exact_fp32_vs_oracle_f32": account(o32.z_vals.cpu(), rgb32, depth32, ref["z_vals"], ref["rgb"], ref["depth"]),
-                             **f64}}))
+                             **f64,
+                             # ... and WHY the rays outside the contract are outside (ray_error_sources)
+                             "out_of_tolerance_rays": margins}}))
 
 
 def grid_bench(args, dev, rank, world, dist, sync):
@@ -981,6 +1059,7 @@ def main() -> None:
     ap.add_argument("--no-train", action="store_true", help="skip the training-step sub-object of the default line")
     ap.add_argument("--no-two-product-leg", action="store_true", help="skip the timed region of the opt-in two-product colour branch")
     ap.add_argument("--no-random-weight-leg", action="store_true", help="skip the timed region on the synthetic random-weight scene")
+    ap.add_argument("--no-shipped-rows", action="store_true", help="skip the extra rows at the shipped conf's sample counts (100 + 35, 100 + 100)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from the committed profiles/rNN/traffic_f16x3.json instead of two rocprofv3 --pmc child runs of "
                          "this command on this box (+25 s; render workload, one GPU, not under a profiler)")
@@ -1011,8 +1090,9 @@ def main() -> None:
                     help="MLP kernels: f16x3 = split-half products on the f16 matrix cores, fp32 accumulate (default, "
                          "fp32-equivalent accuracy); fp32 = exact fp32 MFMA")
     ap.add_argument("--colour-products", type=int, choices=(2, 3), default=None,
-                    help="f16 products per fp32-equivalent product in the colour branch of the f16x3 render (default: the model's, 2: "
-                         "weights of the feature block + rendering net as their f16 roundings, colours within 2e-5; 3: fp32-equivalent)")
+                    help="f16 products per fp32-equivalent product in the colour branch of the f16x3 render (default: the model's, 3: "
+                         "fp32-equivalent; 2 = the opt-in: weights of the feature block + rendering net as their f16 roundings, colours within "
+                         "2e-5 on near-init weights only)")
     ap.add_argument("--no-reuse", action="store_true",
                     help="evaluate the VF net on the proposal samples twice, as the reference does (one fused VF+rendering "
                          "launch over all S_c+N_f samples), instead of once")
@@ -1139,7 +1219,6 @@ def main() -> None:
         barrier + synchronize pairs -> (elapsed of this rank's own steps, elapsed including the closing barrier, last output).
         The kernel is power-limited: right after idle the chip boosts, and K = 20 steps are 40 ms, so the timed steps follow
         sustained work and `value` is a sustained figure whatever K the caller asks for."""
-        from vf_nerf_amd import lib as vlib
         o = None
         for _ in range(warmup):
             mdl.render(pose, uv, K, epoch=0)
@@ -1157,16 +1236,14 @@ def main() -> None:
             # step would be 8 more stream markers per step.)  The same steps leave their workgroups' clock stamps in `probe`.
             sampled = events is not None and i % 4 == 0
             mdl._kernel_events = events if sampled else None
-            if probe is not None:
-                vlib.f16x3_set_clock_probe(probe if sampled else None)
+            mdl._clock_probe = probe if sampled else None       # -> vfn_render_params.clock_stamps of that call (no per-thread setter)
             o = mdl.render(pose, uv, K, epoch=0)
         torch.cuda.synchronize()
         local = time.perf_counter() - t_a
         sync()
         total = time.perf_counter() - t_a
         mdl._kernel_events = None
-        if probe is not None:
-            vlib.f16x3_set_clock_probe(None)
+        mdl._clock_probe = None
         return local, total, o
 
     with torch.no_grad():
@@ -1175,8 +1252,8 @@ def main() -> None:
         probe = torch.zeros((args.rays * max(s_c, n_f) + 127) // 128, 2, dtype=torch.int64, device=dev) if args.precision == "f16x3" else None
         local_elapsed, elapsed, out = timed_region(model, args.steps, args.warmup, args.sustain_seconds, events, probe)
         clock = None
+        from vf_nerf_amd import lib as vlib
         if probe is not None:
-            from vf_nerf_amd import lib as vlib
             clock = vlib.clock_ghz_from_stamps(probe)
 
         # beside `value`, never instead: (a) the opt-in two-product colour branch on the same scene, with what the guard's measured
@@ -1189,16 +1266,37 @@ def main() -> None:
             model.f16x3_guard = "off"                      # timing of the opt-in itself; the check above says whether it would be kept
             _, elapsed2, _ = timed_region(model, args.steps, max(3, args.warmup), min(1.0, args.sustain_seconds))
             model.colour_products, model.f16x3_guard = 3, keep_guard
-        elapsed_rand = None
+        elapsed_rand, events_rand, clock_rand = None, [], None
         if scene_info is not None and not args.no_random_weight_leg:
             rmodel, uv_r, pose_r, K_r = build_scene(dev, args.rays, s_c, n_f, seed=rank)
             rmodel.precision, rmodel.reuse_proposal = args.precision, not args.no_reuse
             rmodel.colour_products = model.colour_products
             keep_inputs = (uv, pose, K)
             uv, pose, K = uv_r, pose_r, K_r
-            _, elapsed_rand, _ = timed_region(rmodel, args.steps, max(3, args.warmup), min(1.0, args.sustain_seconds))
+            probe_r = torch.zeros_like(probe) if probe is not None else None
+            # (the same sustain as the headline leg: the launch is power-limited, a shorter run-in would flatter this scene)
+            _, elapsed_rand, _ = timed_region(rmodel, args.steps, max(3, args.warmup), args.sustain_seconds, events_rand, probe_r)
             uv, pose, K = keep_inputs
+            if probe_r is not None:
+                clock_rand = vlib.clock_ghz_from_stamps(probe_r)
             del rmodel
+        # the SHIPPED sample counts (confs/vf_nerf.conf:40-48: 100 proposal samples, 35 fine samples growing to max_samples = 100) on the
+        # headline scene, as extra rows
+        shipped_rows = None
+        if args.precision == "f16x3" and not args.no_shipped_rows and args.workload == "render":
+            shipped_rows = []
+            keep_inputs = (uv, pose, K)
+            for sc2, nf2 in ((100, 35), (100, 100)):
+                built2 = build_trained_scene(dev, args.rays, sc2, nf2, seed=rank) if scene_info is not None else None
+                if built2 is not None:
+                    m2, uv, pose, K, _ = built2
+                else:
+                    m2, uv, pose, K = build_scene(dev, args.rays, sc2, nf2, seed=rank)
+                m2.precision, m2.reuse_proposal, m2.colour_products = args.precision, not args.no_reuse, model.colour_products
+                _, el2, _ = timed_region(m2, args.steps, max(3, args.warmup), min(1.0, args.sustain_seconds))
+                shipped_rows.append((sc2, nf2, el2))
+                del m2
+            uv, pose, K = keep_inputs
     model._kernel_events = None
     # dominant kernel class = the one with the largest share of the timed region (HIP events on the launch stream)
     per_class = {}
@@ -1210,10 +1308,12 @@ def main() -> None:
 
     _, rates = rank_rates(dist, local_elapsed, args.rays * args.steps, dev)
     if dist is not None:
-        t = torch.tensor([elapsed, elapsed2 or 0.0, elapsed_rand or 0.0], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, elapsed2 or 0.0, elapsed_rand or 0.0] + [r[2] for r in (shipped_rows or [])], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, elapsed2, elapsed_rand = float(t[0].item()), (float(t[1].item()) if elapsed2 is not None else None), \
             (float(t[2].item()) if elapsed_rand is not None else None)
+        if shipped_rows:
+            shipped_rows = [(a, b, float(t[3 + i].item())) for i, (a, b, _) in enumerate(shipped_rows)]
 
     if rank == 0:
         rays_per_s = args.rays * args.steps * world / elapsed
@@ -1263,6 +1363,21 @@ def main() -> None:
                 "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA, 4)}
         if f16:   # context, not the graded fraction: the power-limited MFMA rate measured on this chip
             roof["frac_of_measured_sustained_f16_mfma"] = round(achieved / (SUSTAINED_F16_MFMA / products), 4)
+        # the SAME accounting for the synthetic random-weight scene — the scene BASELINE.json's north_star names ("throughput on synthetic
+        # random-weight scenes"): its own event-timed launch duration, fraction and in-kernel clock
+        roof_rand = None
+        if events_rand:
+            pc = {}
+            for name, e0, e1 in events_rand:
+                pc.setdefault(name, []).append(e0.elapsed_time(e1))
+            if dom in pc:
+                k_ms = sum(pc[dom]) / len(pc[dom])
+                ach = flops_launch / (k_ms * 1e-3) / 1e12
+                roof_rand = {"bound": "mfma", "kernel": roof["kernel"], "avg_launch_ms": round(k_ms, 4), "achieved": round(ach, 2), "peak": round(peak, 1),
+                             "unit": "TFLOP/s", "frac": round(ach / peak, 4), "flops_per_launch": flops_launch,
+                             "executed_f16_tflops": round(ach * products, 1) if f16 else None,
+                             "effective_clock_ghz": clock_rand["median"] if clock_rand else None, "effective_clock": clock_rand,
+                             "sustained": f"timed steps follow {args.sustain_seconds:g} s of the same work without a gap (as the headline leg)"}
         line = {
             "metric": "rays/sec (4096-ray chunk, 128 samples/ray) + PSNR vs ref",
             "value": round(rays_per_s, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
@@ -1275,11 +1390,19 @@ def main() -> None:
             "value_fp32_equivalent": round(rays_per_s, 1) if (f16 and cp == 3) else None,
             "weights": scene_info if scene_info is not None else {"fixture": None, "trained_by": "nobody: synthetic random weights (seed + default init x gain 2 + recentred head)"},
             "value_random_weight_scene": round(args.rays * args.steps * world / elapsed_rand, 1) if elapsed_rand else None,
+            "roofline_random_weight_scene": roof_rand,
+            # SURVEY.md section 8d "extra row": the shipped conf's sample counts (confs/vf_nerf.conf:40-48), same scene, same default path;
+            # their per-ray parity against the reference's outputs at those sizes: parity_shipped_sizes below
+            "value_shipped_conf": ([{"samples": f"{a} + {b}", "rays_per_s": round(args.rays * args.steps * world / el, 1),
+                                     "ms_per_chunk": round(el / args.steps * 1e3, 4), "samples_per_s": round(args.rays * (a + b) * args.steps * world / el, 1)}
+                                    for a, b, el in shipped_rows] if shipped_rows else None),
             "value_two_product_opt_in": round(args.rays * args.steps * world / elapsed2, 1) if elapsed2 else None,
             "two_product_check": check2,
             "value_definition": ("value: the default path (three f16 products per fp32-equivalent product everywhere, colours 1e-7 from the exact-fp32 "
                                  "kernels) on TRAINED weights" + ("" if scene_info is not None else " — not available here: random weights") +
-                                 "; value_random_weight_scene: the same path on the synthetic random-weight scene of rounds 1-3; "
+                                 "; value_random_weight_scene (+ roofline_random_weight_scene): the same path on the synthetic random-weight scene — "
+                                 "the scene BASELINE.json's north_star names; the trained scene is what a user of the reference renders, and its "
+                                 "activations let the power-limited launch hold a higher clock (effective_clock_ghz of either roofline); "
                                  "value_two_product_opt_in: model.colour_products = 2 (colour-branch weights as f16 roundings) timed on the "
                                  "headline scene with the guard off — two_product_check says what it does to the colours there and whether the "
                                  "guard's measured self-check would keep it (on trained weights it does not)"),
@@ -1297,6 +1420,8 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["parity_vs_oracle"] = cpu_baseline(model, uv, pose, K, s_c, n_f)
             line["parity_trained_weights"] = trained_weights_parity(dev, args.precision)
+            # the shipped sample counts (100 + 35) against the reference's own outputs at those sizes: reference-trained weights and random ones
+            line["parity_shipped_sizes"] = [trained_weights_parity(dev, args.precision, fixture=name) for name in ("trained_256_shipped.npz", "shipped_sizes.npz")]
     # BASELINE.json configs[2] beside the headline line (outside its timed region): a few optimizer steps on the same batch
     # size, every rank, gradients all-reduced when there is more than one
     train_rec = None
@@ -1323,7 +1448,7 @@ def main() -> None:
             line["train"] = {k: train_rec[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "activation_storage", "gradient_storage", "workspace_layout",
                                                        "step_issued_as", "weights", "sparse_colour_branch", "algorithmic_tflop_per_step", "executed_tflop_per_step",
                                                        "executed_tflops", "frac_of_f16_mfma_div3_executed", "achieved_tflops", "frac_of_f16_mfma_div3",
-                                                       "workspace_gb_per_step", "workspace_tb_per_s", "frac_of_hbm_peak", "final_loss")}
+                                                       "workspace_gb_per_step", "workspace_tb_per_s", "frac_of_hbm_peak", "final_loss", "drop_in_sequence_ms", "drop_in_sequence")}
             line["train"]["workload"] = train_rec["config"]["workload"]
         emit_line((line))
     if dist is not None:

@@ -93,14 +93,30 @@ def test_single_product_line_says_what_it_is():
 def test_view_workload_per_ray_accounting_at_view_scale():
     """BASELINE.json configs[1] (`bench.py --workload view`): the 12 750 rays of the 150 x 85 parity image of the full view, HIP default
     path against the CPU oracle (fp32), accounted per ray.  Sample depths are bit-identical on EVERY ray; at least 99.8 % of the rays are
-    inside the 1e-4 contract in rgb and depth (observed 99.89 %: a handful of rays per ten thousand sit on a density threshold where the
-    reference's own fp32 arithmetic is 1e-3 from its float64 value — DESIGN.md section 4; the float64 yardstick itself is the tool's, not
-    this test's: --no-float64)."""
+    inside the 1e-4 contract in rgb and depth (bound 99.85 %, observed 99.89 %: on a handful of rays per ten thousand the reference's
+    function amplifies a 5e-6 difference in the normals past 1e-4 — its own fp32 arithmetic is 1e-3 from its float64 value there, DESIGN.md
+    section 4; the float64 yardstick itself is the tool's, not this test's: --no-float64)."""
     d = _run("--workload", "view", "--steps", "1", "--warmup", "3", "--no-float64", timeout=900)
     p = d["parity_vs_oracle"]
     a = p["hip_default_vs_oracle_f32"]
     print(f"view parity image {p['image']}: rays sampled identically {a['rays_sampled_bit_identically']}, inside 1e-4 {a['frac_all_rays_within_1e-4']}, "
           f"worst rgb {a['max_abs_rgb_err']:.2e}; exact-fp32 kernels: {p['hip_exact_fp32_vs_oracle_f32']['frac_all_rays_within_1e-4']}; PSNR {p['psnr_rgb_db']} dB")
     assert p["argmax_indices_equal"] and a["rays_with_different_z"] == 0 and a["rays_sampled_bit_identically"] == 1.0
-    assert a["frac_all_rays_within_1e-4"] >= 0.998 and p["hip_exact_fp32_vs_oracle_f32"]["frac_all_rays_within_1e-4"] >= 0.998
+    assert a["frac_all_rays_within_1e-4"] >= 0.9985 and p["hip_exact_fp32_vs_oracle_f32"]["frac_all_rays_within_1e-4"] >= 0.9985
     assert p["psnr_rgb_db"] > 90.0 and d["value"] > 1.0e6 and d["config"]["colour_products"] == 3
+    # WHY those few rays are outside (VERDICT r04 next 4).  NOT a density decision that fell on the other side: no ray has a sample whose
+    # sigma is zero on one side only.  It is the normals' own error — 4-8e-6, an order and more inside the 1e-4 contract — amplified 20-300x by
+    # the reference's function downstream of them (the oracle's own fp32-against-float64 comparison shows the same rays with the same
+    # amplifications; bench.ray_error_sources).  Pinned per ray: the ORACLE's density + weights + composite evaluated on the HIP normals
+    # reproduce the HIP output (residual < 5e-5; observed 1e-7 with the default kernels: nothing downstream of the normals differs), and the
+    # normals on that ray are within 2e-5 of the oracle's.
+    for who in ("hip_default_vs_oracle_f32", "hip_exact_fp32_vs_oracle_f32"):
+        m = p["out_of_tolerance_rays"][who]
+        print(f"{who}: {m['out_of_tolerance']} rays outside 1e-4, {m['explained_by_their_normals']} explained by their normals (largest residual "
+              f"{m['largest_residual']}), {m['rays_with_a_flipped_sample']} with a flipped density decision, {m['unexplained']} unexplained; max |dn| over "
+              f"all rays {m['max_abs_normal_err_all_rays']:.2e}")
+        for q in m["rays"]:
+            print(f"    ray {q['ray']:6d}: rgb err {q['rgb_err']:.2e}, depth err {q['depth_err']:.2e}, max |dn| {q['max_abs_normal_err']:.2e} (x{q['amplification']}), "
+                  f"shortest weighted normal {q['min_normal_length']:.2e}, flipped {q['flipped_samples']}, residual {q['residual']:.2e}")
+        assert m["unexplained"] == 0 and m["rays_with_a_flipped_sample"] == 0 and m["max_abs_normal_err_all_rays"] < 2e-5, \
+            [q for q in m["rays"] if q["residual"] >= 5e-5 or q["max_abs_normal_err"] >= 2e-5]

@@ -189,7 +189,7 @@ def _account(out, d, label):
 
 
 def test_render_end_to_end(case):
-    """Whole render() (the DEFAULT path: f16x3, two-product colours, one C call) with the reference's random draws replayed.
+    """Whole render() (the DEFAULT path: f16x3 with three products everywhere, one C call) with the reference's random draws replayed.
     A ray only counts as an outlier when a discontinuity (argmax / mask threshold) flipped.  Bounds are what is observed on
     these fixtures (every ray samples identically, every ray inside 1e-4), with one ray of slack on the larger fixtures."""
     from oracle import vfnerf_oracle as O
@@ -206,7 +206,7 @@ def test_render_end_to_end(case):
     r = _account(out, d, f"end-to-end {fx.get('n_rays')}x{s_t}")
     assert r["frac_same_z"] >= 0.99 or r["n_diff_z"] <= 1, "fp32 noise may move the argmax of one ray, not more"
     assert r["frac_within_tol"] >= 0.995 or (r["n_rays"] - r["n_diff_z"]) * (1 - r["frac_within_tol"]) <= 1.01
-    assert r["rel_rgb"] < 5e-4 and r["rel_depth"] < 5e-4, "element-wise relative error of entries with |ref| > 1e-2 (observed: <= 1e-4)"
+    assert r["rel_rgb"] < 2e-4 and r["rel_depth"] < 2e-4, "element-wise relative error of entries with |ref| > 1e-2 (observed: <= 1e-4)"
     good = (out.z_vals.cpu() == d["z_vals"]).all(dim=1)
     psnr = O.psnr(out.coarse_rgb_values.cpu()[good], d["rgb"][good])
     print(f"PSNR vs reference (matching rays): {psnr:.1f} dB")

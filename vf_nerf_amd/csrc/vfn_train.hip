@@ -170,16 +170,24 @@ struct PrepArgs {
     float cx, cy, cz;
     float *pad_pts, *pad_gt, *pad_dsup;       // rows [m_sup, m_sup_pad) of the supervision batch and of its upstream gradient
     int pad_floats;
+    float *zero_a, *zero_b;                   // session form: the whole supervision-point and upstream-gradient regions (zero_floats each)
+    long long zero_floats;
 };
 
 __global__ void vfn_train_prep_kernel(const PrepArgs a) {
     const int t = threadIdx.x;
-    if (t == 0) {
-        a.scal[0] = *a.beta; a.scal[1] = *a.mean; a.scal[2] = *a.scale;
-        a.dscal[0] = 0.f; a.dscal[1] = 0.f; a.dscal[2] = 0.f;
-        a.centroid[0] = a.cx; a.centroid[1] = a.cy; a.centroid[2] = a.cz;
+    if (blockIdx.x == 0) {
+        if (t == 0) {
+            a.scal[0] = *a.beta; a.scal[1] = *a.mean; a.scal[2] = *a.scale;
+            a.dscal[0] = 0.f; a.dscal[1] = 0.f; a.dscal[2] = 0.f;
+            a.centroid[0] = a.cx; a.centroid[1] = a.cy; a.centroid[2] = a.cz;
+        }
+        if (t < a.pad_floats) { a.pad_pts[t] = 0.f; a.pad_gt[t] = 0.f; a.pad_dsup[t] = 0.f; }
     }
-    if (t < a.pad_floats) { a.pad_pts[t] = 0.f; a.pad_gt[t] = 0.f; a.pad_dsup[t] = 0.f; }
+    for (long long i = (long long)blockIdx.x * blockDim.x + t; i < a.zero_floats; i += (long long)gridDim.x * blockDim.x) {
+        a.zero_a[i] = 0.f;
+        a.zero_b[i] = 0.f;
+    }
 }
 
 __global__ void vfn_train_scalar_grads_kernel(const float* dscal, float* g_beta, float* g_mean, float* g_scale, const int32_t* k_dev, float m,
@@ -261,18 +269,13 @@ int step_prep(StepCtx& c, bool session) {
     const vfn_train_step_params* p = c.p; const vfn_train_step_io* io = c.io; Ws& w = c.w;
     int rc;
     const int pad_floats = session ? 0 : (int)((w.m_sup_pad - w.m_sup) * 3);
+    // session form: the caller appends batches of any size — every row it does not fill is a point at the origin with a zero upstream gradient
+    const long long zero_floats = session ? w.m_sup_pad * 3 : 0;
     PrepArgs pa{io->beta, io->mean, io->scale, w.scal, w.dscal, w.centroid, p->sup_centroid[0], p->sup_centroid[1], p->sup_centroid[2],
-                w.sup_pts + w.m_sup * 3, w.sup_gt + w.m_sup * 3, w.d_sup + w.m_sup * 3, pad_floats};
-    hipLaunchKernelGGL(vfn_train_prep_kernel, dim3(1), dim3(128), 0, c.s, pa);
+                w.sup_pts + w.m_sup * 3, w.sup_gt + w.m_sup * 3, w.d_sup + w.m_sup * 3, pad_floats, w.sup_pts, w.d_sup, zero_floats};
+    const unsigned blocks = (unsigned)(zero_floats > 0 ? (zero_floats + 1023) / 1024 : 1);
+    hipLaunchKernelGGL(vfn_train_prep_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(128), 0, c.s, pa);
     STEP(vfn_check_launch("vfn_train_step (prep)"));
-    if (session && w.m_sup_pad > 0) {
-        // the caller appends batches of any size: every row it does not fill is a point at the origin with a zero upstream gradient
-        if (hipMemsetAsync(w.sup_pts, 0, (size_t)w.m_sup_pad * 3 * sizeof(float), c.s) != hipSuccess ||
-            hipMemsetAsync(w.d_sup, 0, (size_t)w.m_sup_pad * 3 * sizeof(float), c.s) != hipSuccess) {
-            vfn_set_error("vfn_train_step: could not clear the supervision rows");
-            return VFN_ERR_LAUNCH;
-        }
-    }
     return VFN_OK;
 }
 

@@ -476,6 +476,10 @@ class VectorFieldNerf:
             for i, e in enumerate(evs):
                 e.record()
                 rp.timing_events[i] = e.cuda_event
+        # bench.py hook: the per-workgroup clock stamps of this call's fused launches (a field of the call's struct since ABI 4)
+        probe = getattr(self, "_clock_probe", None)
+        if probe is not None:
+            rp.clock_stamps, rp.clock_slots = probe.data_ptr(), probe.numel() // 2
         o = lib.render_fwd(rp, vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(), pixels.float().contiguous(),
                            pose, intrinsics, self._linspace(s_c, dev), far_ct, far_ft, self.density.raw_scalars(), u_c, u_f, u_a, ws)
         if sink is not None:
