@@ -473,8 +473,17 @@ def view_bench(args, dev):
         # puts behind evaluation.methods.render_images); uploads and the download are inside the timed region
         uv_h, pose_h, K_h = uv.cpu(), pose.cpu(), K.cpu()
 
-        def full_view():
-            return evaluator.render_view(model, pose_h, uv_h, K_h, 0, split_size=chunk, n_streams=args.streams)
+        if args.unchanged_evaluator_loop:
+            # ... and with dropin.install(patch_evaluator=False): the reference's OWN loop body (evaluation/methods.py:507-540 restated call
+            # for call in tools/reference_sequence.py) — split_size rays per chunk, an upload, model.render and six .cpu() read-backs each
+            sys.path.insert(0, os.path.join(REPO, "tools"))
+            import reference_sequence
+
+            def full_view():
+                return reference_sequence.reference_render_view(model, pose_h, uv_h, K_h, (h, w), 0, split_size=chunk, device=dev)
+        else:
+            def full_view():
+                return evaluator.render_view(model, pose_h, uv_h, K_h, 0, split_size=chunk, n_streams=args.streams)
     else:
         def full_view():
             return model.render_chunked(pose, uv, K, epoch=0, chunk=chunk, n_streams=args.streams)
@@ -494,7 +503,9 @@ def view_bench(args, dev):
                         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16x3+f32acc" if args.precision == "f16x3" else "f32",
                         "data": "synthetic",
                         "config": {"workload": f"full view {w}x{h} in {chunk}-ray chunks x {s_c} + {n_f} samples, {args.streams} stream(s)" +
-                                               (f", as the evaluator runs it (host in / host out; grouped into >= {evaluator.MIN_CHUNK}-ray chunks)" if args.as_evaluator else "")}}))
+                                               ((f", the reference evaluator's UNCHANGED loop (dropin.install(patch_evaluator=False): per {chunk}-ray chunk an upload, "
+                                                 f"model.render and six .cpu() read-backs)" if args.unchanged_evaluator_loop else
+                                                 f", as the evaluator runs it (host in / host out; grouped into >= {evaluator.MIN_CHUNK}-ray chunks)") if args.as_evaluator else "")}}))
             return
 
         # parity image: same camera at 1/8 resolution on both sides, identical u_add draw (Q9)
@@ -1110,6 +1121,9 @@ def main() -> None:
     ap.add_argument("--as-evaluator", action="store_true",
                     help="view workload: time evaluator.render_view on HOST inputs (per-ray pose / intrinsics) with the download inside the "
                          "timed region — what the reference's evaluation/methods.py:render_images gets through vf_nerf_amd.dropin")
+    ap.add_argument("--unchanged-evaluator-loop", action="store_true",
+                    help="with --as-evaluator: the reference's own render_images loop body (what dropin.install(patch_evaluator=False) leaves in "
+                         "place) instead of evaluator.render_view")
     ap.add_argument("--streams", type=int, default=2,
                     help="view workload: HIP streams the consecutive ray chunks alternate over (1 = strictly one after the other)")
     ap.add_argument("--train", action="store_true",

@@ -401,7 +401,8 @@ int vfn_mlp_bwd_chain_bf16(const vfn_net_geom* vf_geom, const void* vf_packed_bw
 /* The same chain for the FRAGMENT-ORDERED workspace (below): `feats` = the tanh'ed features [M][256] row-major fp32 (the one
  * slot the chain reads as values), `dy` = the gradient slots it writes, dy_flags bit 1: fragment order, bit 2 (with bit 1):
  * as bf16, bit 3 (with bit 1, not with bit 2): as SCALED f16 (vfn_weight_grad_frag, dy_form 3).  dy_flags = 0 and feats =
- * slot 8 of saved[13][M][256] is vfn_mlp_bwd_chain_bf16.  n_points < 2^21 in fragment order.
+ * slot 8 of saved[13][M][256] is vfn_mlp_bwd_chain_bf16.  n_points < 2^21 per LAUNCH (32-bit offsets relative to the launch's first point);
+ * a workspace filled and walked by several launches (the _at forms) may hold up to 2^26 points.
  * dy_flags bit 4 (with bits 1 and 3; fused or vector-only chains): SINGLE-PRODUCT arithmetic — one bf16 product per K-block on
  * round-to-nearest operands (8 significant bits each) instead of three on split ones (16): the chain of the opt-in 16-bit-native
  * training mode (BASELINE.json configs[2], "bf16 MFMA MLPs" as written; vf_nerf_amd: model.training_products = 1).  Takes packs
@@ -587,7 +588,7 @@ int vfn_sample_sphere_shell(int64_t n, float r_min, float r_max, const float* ce
  * are stored as f16 — 256 values in the first 512 bytes of every 1 KiB row, the row stride does not change — which halves
  * what the forward writes and the weight-gradient kernels read, at 11 instead of 24 significant bits in the activations that
  * multiply dY (BASELINE.json configs[2] trains on bf16 matrix cores); the tanh'ed feature slot (8) stays fp32 row-major.
- * Bit 1: the ReLU slots are FRAGMENT-ORDERED (see vfn_weight_grad_frag; slot stride ceil(M/32) * 32 KiB, n_points < 2^21).
+ * Bit 1: the ReLU slots are FRAGMENT-ORDERED (see vfn_weight_grad_frag; slot stride ceil(M/32) * 32 KiB, n_points < 2^21 per launch, ws_points < 2^26).
  * Bit 2 (vfn_vf_mlp16_fwd_train[_at] with with_features = 0; the fused launch takes colour_products = 1 instead): SINGLE-PRODUCT
  * arithmetic — every K-block is ONE f16 product of the operands' f16 roundings (11 significant bits each, fp32 accumulation)
  * instead of three on split operands: the forward of the opt-in 16-bit-native training mode (BASELINE.json configs[2], "bf16

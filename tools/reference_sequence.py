@@ -120,3 +120,29 @@ class ReferenceLoop:
                     self.average_losses[key] += losses_dict[key]
             self._mark("loss.item()")
         return loss, losses_dict
+
+
+def reference_render_view(model, all_pose, all_pixels, all_intrinsics, image_size, epoch: int, split_size: int = 512, device="cuda", white: bool = False):
+    """The per-image body of the reference evaluator's loop, CALL FOR CALL (evaluation/methods.py:507-540): the view split into
+    ``split_size``-ray chunks, each uploaded, rendered with ``model.render`` and pulled back with ``.cpu().numpy()`` (rgb, depth, and the
+    pixel indices four times) — what runs when ``vf_nerf_amd.dropin.install(patch_evaluator=False)`` leaves ``render_images`` alone.
+    -> (rgb[H,W,3], depth[H,W,1]) numpy arrays."""
+    import numpy as np
+    num_pixels = all_pixels.shape[0]
+    num_batches = int(np.ceil(num_pixels / split_size))
+    pixels_split = torch.split(all_pixels, split_size, dim=0)
+    pose_split = torch.split(all_pose, split_size, dim=0)
+    intrinsics_split = torch.split(all_intrinsics, split_size, dim=0)
+    rgb = np.zeros((image_size[0], image_size[1], 3))
+    depth_map = np.zeros((image_size[0], image_size[1], 1))
+    with torch.no_grad():
+        for j in range(num_batches):
+            pixels = pixels_split[j].to(device)
+            pose = pose_split[j].to(device)
+            intrinsics = intrinsics_split[j].to(device)
+            output = model.render(pose, pixels, intrinsics, epoch, white)
+            rgb_values = output.coarse_rgb_values.cpu().numpy()
+            predicted_depth = output.coarse_depth_map.cpu().numpy()
+            rgb[pixels[:, 1].long().cpu().numpy(), pixels[:, 0].long().cpu().numpy(), :] = rgb_values
+            depth_map[pixels[:, 1].long().cpu().numpy(), pixels[:, 0].long().cpu().numpy(), :] = predicted_depth
+    return rgb, depth_map

@@ -607,13 +607,22 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
     p.dy16 = (MX & BM_F16S) ? 2 : ((frag && (a.dy_flags & 4)) ? 1 : 0);
     p.live = in ? 1 : 0;
     const long long mw = m + a.ws_first;          // this point's place in the workspace
-    p.evoff = (m & ~31ll) < n_live ? (uint32_t)((mw >> 5) * 32768 + 16384 + lane) : 0xc0000000u;
-    p.feats = a.feats; p.dy = a.dy; p.feat_bytes = (uint32_t)(a.ws_points * 1024);
+    // (descriptors of the dY slots and of the feature rows start at THIS LAUNCH's first point — 1 KiB per point in either order — and the
+    //  32-bit offsets are launch-relative: a launch covers < 2^21 points, the workspace may hold more; csrc/vfn_mlp16.hip does the same)
+    p.evoff = (m & ~31ll) < n_live ? (uint32_t)((m >> 5) * 32768 + 16384 + lane) : 0xc0000000u;
+    p.feats = a.feats + a.ws_first * 256; p.dy = a.dy + a.ws_first * 256;
+    {
+        const long long left = (a.ws_points - a.ws_first) * 1024;
+        p.feat_bytes = (uint32_t)(left < 0x7fffffffll ? left : 0x7fffffffll);
+    }
     p.slot_floats = frag ? ((a.ws_points + 31) >> 5) * 8192 : a.ws_points * 256;
-    p.slot_bytes = (uint32_t)(p.slot_floats * 4);
-    p.voff = in ? (uint32_t)(mw * 1024 + g * 16) : 0xfffffff0u;
-    // (fragment order adds scalar offsets of up to 32 KiB: the out-of-range value must not wrap; slots are limited to 2 GiB)
-    p.dvoff = !frag ? p.voff : (in ? (uint32_t)((mw >> 5) * 32768 + lane * (p.dy16 ? 8 : 16)) : 0xc0000000u);
+    {
+        const long long left = p.slot_floats * 4 - a.ws_first * 1024;
+        p.slot_bytes = (uint32_t)(left < 0x7fffffffll ? left : 0x7fffffffll);
+    }
+    p.voff = in ? (uint32_t)(m * 1024 + g * 16) : 0xfffffff0u;
+    // (fragment order adds scalar offsets of up to 32 KiB: the out-of-range value must not wrap; a launch is limited to 2 GiB per slot)
+    p.dvoff = !frag ? p.voff : (in ? (uint32_t)((m >> 5) * 32768 + lane * (p.dy16 ? 8 : 16)) : 0xc0000000u);
     p.st_tile = frag ? 4096u : 128u; p.st_q = frag ? 1024u : 32u;
     {   // sign bits of every ReLU layer this launch walks through: 16 bytes per slot, all requested now, in registers for good
         const unsigned mbytes = (unsigned)(a.ws_points * 32);
@@ -818,8 +827,8 @@ int vfn_internal_bwd_chain_bf16_ws_at(const vfn_net_geom* vf_geom, const void* v
     VFN_REQUIRE(ws_first >= 0 && ws_first + n_points <= ws_points, "vfn_mlp_bwd_chain_bf16: points %lld .. %lld outside a workspace of %lld",
                 (long long)ws_first, (long long)(ws_first + n_points), (long long)ws_points);
     VFN_REQUIRE(!(dy_flags & 2) || ws_first % 32 == 0, "vfn_mlp_bwd_chain_bf16: ws_first must be a multiple of 32 in fragment order");
-    VFN_REQUIRE(ws_points < ((dy_flags & 2) ? (1ll << 21) : (1ll << 22)), "vfn_mlp_bwd_chain_bf16: at most %lld points per workspace (32-bit slot offsets)",
-                ((dy_flags & 2) ? (1ll << 21) : (1ll << 22)) - 1);
+    VFN_REQUIRE(n_points < (1ll << 21) && ws_points < (1ll << 26), "vfn_mlp_bwd_chain_bf16: at most 2097151 points per launch (32-bit slot offsets) and "
+                "67108863 per workspace (got %lld in %lld)", (long long)n_points, (long long)ws_points);
     VFN_REQUIRE(!(dy_flags & 12) || (dy_flags & 2), "vfn_mlp_bwd_chain_bf16: 16-bit gradients need the fragment-ordered layout");
     VFN_REQUIRE((dy_flags & 12) != 12, "vfn_mlp_bwd_chain_bf16: dy_flags asks for bf16 AND scaled f16 gradients");
 #if !BW16_LATE_STORES

@@ -1072,15 +1072,21 @@ __global__ __launch_bounds__(256, 1) void vfn_mlp16_kernel(const Mlp16Args a) {
     p.rn_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>((MODE & M16_RENDER) ? a.rn_w : a.vf_w), 0,
                                                (int)((MODE & M16_RENDER) ? a.rn_bytes : a.vf_bytes), 0x00020000);
     const bool frag = (a.save_f16 & 2) != 0;          // fragment-ordered slots: groups of 32 points, 32 KiB each
-    p.saved = a.saved;
     const long long mw = m + a.ws_first;              // this point's place in the workspace
     p.slot_floats = frag ? ((a.ws_points + 31) >> 5) * 8192 : a.ws_points * 256;
-    p.slot_bytes = (uint32_t)(p.slot_floats * 4);
+    // The slot descriptors start at THIS LAUNCH's first point (1 KiB per point in either order; ws_first is a multiple of 32 in fragment
+    // order) and the 32-bit offsets below are launch-relative: a launch covers < 2^21 points, the workspace may hold any number
+    // (round 5: a step of 8 192 rays x 128 samples is 2.3 M workspace points).
+    p.saved = a.saved + a.ws_first * 256;
+    {
+        const long long left = p.slot_floats * 4 - a.ws_first * 1024;
+        p.slot_bytes = (uint32_t)(left < 0x7fffffffll ? left : 0x7fffffffll);
+    }
     // rows past the end get an offset beyond the descriptor's range (the store is dropped).  Fragment order adds scalar
-    // offsets of up to 32 KiB to it, so that value must not wrap: 3 GiB, with slots limited to 2 GiB (the host checks)
-    p.save_voff = !in ? (frag ? 0xc0000000u : 0xfffffff0u) : (frag ? (uint32_t)((mw >> 5) * 32768 + lane * 16) : (uint32_t)(mw * 1024 + g * 16));
-    p.save_voff16 = !in ? (frag ? 0xc0000000u : 0xfffffff0u) : (frag ? (uint32_t)((mw >> 5) * 32768 + lane * 8) : (uint32_t)(mw * 1024 + g * 8));
-    p.feat_voff = in ? (uint32_t)(mw * 1024 + g * 16) : 0xfffffff0u;
+    // offsets of up to 32 KiB to it, so that value must not wrap: 3 GiB, with a launch limited to 2 GiB per slot (the host checks)
+    p.save_voff = !in ? (frag ? 0xc0000000u : 0xfffffff0u) : (frag ? (uint32_t)((m >> 5) * 32768 + lane * 16) : (uint32_t)(m * 1024 + g * 16));
+    p.save_voff16 = !in ? (frag ? 0xc0000000u : 0xfffffff0u) : (frag ? (uint32_t)((m >> 5) * 32768 + lane * 8) : (uint32_t)(m * 1024 + g * 8));
+    p.feat_voff = in ? (uint32_t)(m * 1024 + g * 16) : 0xfffffff0u;
     p.st_tile = frag ? 4096u : 128u; p.st_q = frag ? 1024u : 32u;
     p.masks = a.save_masks; p.mask_bytes = (uint32_t)(a.ws_points * 32); p.mask_voff = in ? (uint32_t)((2 * mw + g) * 16) : 0xfffffff0u;
     p.save16 = a.save_f16 & 1;
@@ -1387,8 +1393,8 @@ extern "C" int vfn_vf_mlp16_fwd_train_at(const vfn_net_geom* geom, const void* p
     VFN_REQUIRE(ws_first >= 0 && ws_first + n_points <= ws_points, "vfn_vf_mlp16_fwd_train: points %lld .. %lld outside a workspace of %lld",
                 (long long)ws_first, (long long)(ws_first + n_points), (long long)ws_points);
     VFN_REQUIRE(!(save_f16 & 2) || ws_first % 32 == 0, "vfn_vf_mlp16_fwd_train: ws_first must be a multiple of 32 in fragment order");
-    VFN_REQUIRE(ws_points < ((save_f16 & 2) ? (1ll << 21) : (1ll << 22)), "vfn_vf_mlp16_fwd_train: at most %lld points per workspace (32-bit slot offsets)",
-                ((save_f16 & 2) ? (1ll << 21) : (1ll << 22)) - 1);
+    VFN_REQUIRE(n_points < (1ll << 21) && ws_points < (1ll << 26), "vfn_vf_mlp16_fwd_train: at most 2097151 points per launch (32-bit slot offsets) and 67108863 per "
+                "workspace (got %lld in %lld)", (long long)n_points, (long long)ws_points);
     a.vf_w = (const uint4*)packed16; a.points = points; a.out_vec = out_vec; a.n_points = n_points; a.dirs_div = 1;
     a.vf_multires = vf.multires; a.vf_bytes = vf.total_kb * 1024u; a.saved = saved; a.save_aux_vf = save_aux_vf;
     a.save_masks = save_masks; a.save_f16 = save_f16 & 3;
@@ -1448,8 +1454,8 @@ int vfn_internal_fused16_fwd_train_at(const vfn_net_geom* vf_geom, const void* v
     VFN_REQUIRE(ws_first >= 0 && ws_first + n_points <= ws_points, "vfn_vf_render_fused16_fwd_train: points %lld .. %lld outside a workspace of %lld",
                 (long long)ws_first, (long long)(ws_first + n_points), (long long)ws_points);
     VFN_REQUIRE(!(save_f16 & 2) || ws_first % 32 == 0, "vfn_vf_render_fused16_fwd_train: ws_first must be a multiple of 32 in fragment order");
-    VFN_REQUIRE(ws_points < ((save_f16 & 2) ? (1ll << 21) : (1ll << 22)), "vfn_vf_render_fused16_fwd_train: at most %lld points per workspace (32-bit slot offsets)",
-                ((save_f16 & 2) ? (1ll << 21) : (1ll << 22)) - 1);
+    VFN_REQUIRE(n_points < (1ll << 21) && ws_points < (1ll << 26), "vfn_vf_render_fused16_fwd_train: at most 2097151 points per launch (32-bit slot offsets) and 67108863 per "
+                "workspace (got %lld in %lld)", (long long)n_points, (long long)ws_points);
     a.ws_first = ws_first; a.ws_points = ws_points;
     a.vf_w = (const uint4*)vf_packed16; a.rn_w = (const uint4*)rn_packed16; a.points = points; a.ray_dirs = ray_dirs;
     a.out_vec = normals; a.out_colors = colors; a.n_points = n_points; a.dirs_div = samples_per_ray;

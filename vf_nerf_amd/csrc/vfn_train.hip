@@ -255,7 +255,10 @@ int step_open(StepCtx& c, const vfn_train_step_params* p, const vfn_train_step_i
     c.p = p; c.io = io; c.s = (hipStream_t)stream;
     c.n = p->render.n_rays; c.sc = p->render.n_coarse; c.nf = p->render.n_fine; c.st = c.sc + c.nf;
     STEP(carve(io->workspace, p, io->vf_geom, io->rn_geom, &c.w));
-    VFN_REQUIRE(c.w.total < (1ll << 21), "vfn_train_step: at most 2097151 workspace points per step (%lld)", c.w.total);
+    // a LAUNCH addresses its part of a slot with 32-bit offsets (< 2^21 points); the workspace itself may hold more (round 5)
+    VFN_REQUIRE(c.w.m + c.w.m_sup_pad < (1ll << 21) && c.w.total < (1ll << 26),
+                "vfn_train_step: at most 2097151 points per launch (%lld samples + %lld supervision rows) and 67108863 per workspace (%lld)", c.w.m,
+                c.w.m_sup_pad, c.w.total);
     c.sd = (want_side && p->render.streams >= 2) ? side_stream() : nullptr;
     c.ss = c.sd ? c.sd->s : c.s;
     c.sparse = p->sparse_colours != 0;

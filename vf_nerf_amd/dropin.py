@@ -36,7 +36,10 @@ def _ensure_package(name: str) -> None:
         sys.modules[name] = pkg
 
 
-def install() -> None:
+def install(patch_evaluator: bool = True) -> None:
+    """``patch_evaluator=False`` leaves ``evaluation.methods.render_images`` the reference's own loop (one upload, one ``model.render`` and
+    six ``.cpu()`` read-backs per 512-ray chunk): every call of it still lands on the HIP ``render()``; what it gives up is the grouping
+    into chip-filling chunks and the single download per image (profiles/r05/bench_view_as_evaluator.json: both loops timed)."""
     for dotted, module in _ALIASES.items():
         parts = dotted.split(".")
         for i in range(1, len(parts)):
@@ -58,7 +61,13 @@ def install() -> None:
     # the evaluator's image loop (evaluation/methods.py:472-545: one upload, one render() and four .cpu() synchronisations per
     # chunk) -> chunks on alternating streams, one download per image; same dataset, same files
     try:
-        importlib.import_module("evaluation.methods").render_images = evaluator.render_images
+        methods = importlib.import_module("evaluation.methods")
+        if patch_evaluator:
+            if not hasattr(methods, "_reference_render_images"):
+                methods._reference_render_images = methods.render_images
+            methods.render_images = evaluator.render_images
+        elif hasattr(methods, "_reference_render_images"):
+            methods.render_images = methods._reference_render_images
     except Exception:
         pass
     # models.helpers.functions stays the reference's module (the trainer uses more of it); only the two host-side numpy

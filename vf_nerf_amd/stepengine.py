@@ -120,9 +120,10 @@ class StepEngine:
         n_f = min(model.fine_sampler.N_samples, model.fine_sampler.max_samples)
         if not StoredFinePass.applicable(model, n, s_c, n_f) or (n * (s_c + n_f)) % 32 or n_f < 2:
             return "sample counts are not whole groups of 32 points"
-        sparse = bool(getattr(model, "sparse_colour_training", True))
-        if n * (s_c + n_f) * (2 if sparse else 1) + extra_rows >= (1 << 21):
-            return "too many points for one fragment-ordered workspace"
+        # (a launch addresses its part of a slot with 32-bit offsets: the samples + the supervision rows of one chain launch < 2^21 points;
+        #  the workspace itself — with the sparse colour branch's second region — may hold more since round 5)
+        if n * (s_c + n_f) + extra_rows >= (1 << 21):
+            return "too many points for one launch over a fragment-ordered slot"
         from .optim import FlatAdam
         opt = model.optimizer
         if not isinstance(opt, FlatAdam) or opt.flat() is None or not opt.regions_for(model.parameters()):
