@@ -213,8 +213,11 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
 
     u32x4 ld_a[A_FRAG ? 8 * GPS : 1], ld_b[(B_FRAG || XM == X_ROWS32) ? 8 * GPS : 2];
     unsigned ld_e[2 * GPS] = {};                                // form 3: this lane's exponent bytes of the wave's two tiles (2 wave, 2 wave + 1)
-    auto issue = [&](long long s) {
+    // ``part``: 1 = the dY pieces (and their exponent bytes), 2 = the X pieces, 3 = both.  The default training form (WIDE) requests and
+    // splits the two operands half a step apart (STAGGER below), every other form both together.
+    auto issue = [&](long long s, int part = 3) {
         const int st = (int)(s - s0) * GPS;                     // slab-relative group (a group past the slab's end reads as zero)
+        if (part & 1) {
         if constexpr (F16) {
 #pragma unroll
             for (int gq = 0; gq < GPS; ++gq) {
@@ -234,6 +237,8 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
         } else {
             ld_a[0] = tid < 32 ? __builtin_amdgcn_raw_buffer_load_b128(rs_a, tid * 16, st * F_STEP * 16, 0) : u32x4{0u, 0u, 0u, 0u};
         }
+        }
+        if (!(part & 2)) return;
         if constexpr (B_FRAG) {
 #pragma unroll
             for (int gq = 0; gq < GPS; ++gq)
@@ -256,14 +261,16 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
         }
     };
     const int gi = lane >> 5, pi = lane & 31;                   // fragment pieces: lane half (column group) and point inside the group
-    auto stage = [&](int buf, long long s) {                    // split + write what this thread loaded into the images of `buf`
+    auto stage = [&](int buf, long long s, int part = 3, bool valid = true) {      // split + write what this thread loaded into the images of `buf`
+                                                                                   // (valid = false: a step past the slab's end -> zeros)
         unsigned char* base = lds + buf * F_BUF;
+        if (part & 1) {
         if constexpr (A_FRAG) {
 #pragma unroll
             for (int gq = 0; gq < GPS; ++gq)
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const bool live = (s * GPS + gq) * F_STEP + pi < a.n_points;    // the last group may be partial: its missing points count as zero
+                const bool live = valid && (s * GPS + gq) * F_STEP + pi < a.n_points;    // the last group may be partial: its missing points count as zero
                 u32x4& la = ld_a[8 * gq + r];
                 const int pc = 8 * wave + r, t = pc >> 2, q = pc & 3;
                 f32x4v v;
@@ -301,12 +308,14 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) bsum[0][c] += v[c];
         }
+        }
+        if (!(part & 2)) return;
         if constexpr (B_FRAG) {
 #pragma unroll
             for (int gq = 0; gq < GPS; ++gq)
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const bool live = (s * GPS + gq) * F_STEP + pi < a.n_points;
+                const bool live = valid && (s * GPS + gq) * F_STEP + pi < a.n_points;
                 const u32x4 lb = ld_b[8 * gq + r];
                 const int pc = 8 * wave + r, t = pc >> 2, q = pc & 3;
                 f32x4v v;
@@ -384,6 +393,40 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
     // The pieces of step s + 1 are requested as soon as the registers are free — right after step s's pieces were split into LDS —
     // and not at the start of step s + 1's own trip: they then have the second K-block of this step, the barrier and the first K-block
     // of the next step to land in (two K-blocks of 16 MFMAs instead of one; the stream is latency-bound per CU).
+    // STAGGER (the default training form).  With both operands of a step requested together and split together, nothing is in flight
+    // between the arrival of a step's pieces and the end of their split, and every 64-KiB burst pays the memory latency in full: the
+    // launch streamed 3.9 TB/s where the same access pattern, kept continuously in flight, streams 5.7-5.9 (tools/micro/load_width.hip).
+    // Here the dY pieces of step s + 2 are requested in the MIDDLE of step s (after the dY pieces of s + 1 were split) and the X pieces at
+    // its END (after the X pieces of s + 1): one operand's pieces are always on their way, each with a whole step to arrive, out of the
+    // same registers.
+    constexpr bool STAGGER = WIDE;
+    if constexpr (STAGGER) {
+        // (no branch around a request or a split: at a join the compiler's s_waitcnt placement must be right for the path that issued nothing,
+        //  i.e. it would wait for the requests just made as well.  Steps past the slab's end read zeros — the descriptors are slab-relative
+        //  — and their split is masked.)
+        if (s0 < s1) {
+            issue(s0);
+            stage(0, s0);
+            issue(s0 + 1);
+            __syncthreads();
+        }
+        for (long long s = s0; s < s1; ++s) {
+            const int buf = (int)(s - s0) & 1;
+            const bool more = s + 1 < s1;
+#pragma unroll
+            for (int kb = 0; kb < GPS; ++kb) mma(buf, kb);
+            __builtin_amdgcn_sched_barrier(0);        // (fences: left alone the scheduler sinks the first requests to the end of the step)
+            stage(buf ^ 1, s + 1, 1, more);           // the other buffer was last read in step s-1; every wave passed that step's barrier
+            issue(s + 2, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = GPS; kb < 2 * GPS; ++kb) mma(buf, kb);
+            __builtin_amdgcn_sched_barrier(0);
+            stage(buf ^ 1, s + 1, 2, more);
+            issue(s + 2, 2);
+            __syncthreads();
+        }
+    } else {
     if (s0 < s1) {
         issue(s0);
         stage(0, s0);
@@ -400,6 +443,7 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
 #pragma unroll
         for (int kb = GPS; kb < 2 * GPS; ++kb) mma(buf, kb);
         __syncthreads();
+    }
     }
 
     // partial slab: D row = n (A operand's row), column = k (B operand's column)
