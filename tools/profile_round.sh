@@ -18,7 +18,15 @@ cd /tmp
 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_train" -o kt -- python3 $R/bench.py --workload train --steps 15 > "$R/gpurun_out/prof_train.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_train1024" -o kt -- python3 $R/bench.py --workload train --rays 1024 --steps 40 > "$R/gpurun_out/prof_train1024.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_grid" -o kt -- python3 $R/bench.py --workload grid-stages > "$R/gpurun_out/prof_grid.log" 2>&1
+# round 5: the step issued as the reference trainer's own call sequence, and the GPU's idle gaps under either issue path
+rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_dropin" -o kt -- python3 $R/tools/drive_step.py 1024 100 drop_in > "$R/gpurun_out/prof_dropin.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_onecall" -o kt -- python3 $R/tools/drive_step.py 1024 100 one_call > "$R/gpurun_out/prof_onecall.log" 2>&1
 cd "$R"
+for m in dropin onecall; do
+  db=$(find gpurun_out/prof_$m -name "*_results.db" | head -1)
+  { tail -1 gpurun_out/prof_$m.log; python3 tools/trace_gaps.py "$db" 600 12; python3 tools/topk.py "$db" 25; } > "$OUT/step1024_${m}_trace.txt"
+done
+rm -rf gpurun_out/prof_dropin gpurun_out/prof_onecall
 python3 tools/topk.py gpurun_out/prof_train/kt_results.db 30 > "$OUT/train_kernel_stats.txt"
 python3 tools/topk.py gpurun_out/prof_train1024/kt_results.db 30 > "$OUT/train1024_kernel_stats.txt"
 python3 tools/topk.py gpurun_out/prof_grid/kt_results.db 30 > "$OUT/grid_stage_stats.txt"

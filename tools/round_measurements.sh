@@ -15,5 +15,12 @@ python tools/host_profile.py 4096 60 2>/dev/null | last > "$OUT/host_profile_409
 VFN_SPARSE_COLOURS=0 python tools/host_profile.py 4096 40 2>/dev/null | last > "$OUT/host_profile_4096_dense.json"
 python bench.py --workload view 2>/dev/null | last > "$OUT/bench_view.json"
 python bench.py --workload view --as-evaluator --no-parity 2>/dev/null | last > "$OUT/bench_view_as_evaluator.json"
+# round 5: the reference evaluator's UNCHANGED loop (dropin.install(patch_evaluator=False)) at its own 512-ray chunks, the 8 192-ray step,
+# the weight-gradient launches alone, the step's idle gaps by call sequence
+python bench.py --workload view --as-evaluator --unchanged-evaluator-loop --rays 512 --no-parity --steps 3 2>/dev/null | last > "$OUT/bench_view_as_evaluator_unchanged_loop.json"
+python bench.py --workload view --as-evaluator --rays 512 --no-parity --steps 3 2>/dev/null | last > "$OUT/bench_view_as_evaluator_512.json"
+python tools/host_profile.py 8192 10 2>/dev/null | last > "$OUT/host_profile_8192.json"
+python tools/bench_dwf_shapes.py 2>/dev/null | tail -3 > "$OUT/dwf_shapes.txt"
+bash tools/micro_load_width.sh 2>/dev/null > "$OUT/load_width.txt" || true
 python tools/bench_forward_modes.py 2>/dev/null | grep "ms " > "$OUT/forward_modes.txt"
 ls -la "$OUT"

@@ -44,6 +44,7 @@
 // images — no lo halves — so a buffer holds 64 rows of each and a step takes TWO groups: 64 KiB per workgroup in flight out of the
 // same registers and LDS (WIDE in the kernel; 560 -> 512 us per batched 256 x 256 launch at 524 288 points).
 #include <string.h>
+#include <type_traits>
 #include "vfn_common.h"
 
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
@@ -211,11 +212,18 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
                                                 (size_t)r_base * (XM == X_AUX40 ? 160 : 1024), 0,
                                             (int)(rows_slab * (XM == X_AUX40 ? 160 : 1024)), 0x00020000);
 
-    u32x4 ld_a[A_FRAG ? 8 * GPS : 1], ld_b[(B_FRAG || XM == X_ROWS32) ? 8 * GPS : 2];
-    unsigned ld_e[2 * GPS] = {};                                // form 3: this lane's exponent bytes of the wave's two tiles (2 wave, 2 wave + 1)
+    // The thin shapes (the encoding tile's 256 x 64, the head's 32 x 256) move 16-20 KiB per step and workgroup and multiply for ~130
+    // cycles: with one step's pieces in flight they are latency-bound (the head's launch read its 322 MB at 1.1 TB/s).  Their accumulators
+    // are small, so they keep a RING of four register sets: three steps' pieces are on their way while one is split and multiplied.
+    constexpr int RING = SHAPE != 0 ? 4 : 1;
+    u32x4 ld_a_all[RING][A_FRAG ? 8 * GPS : 1], ld_b_all[RING][(B_FRAG || XM == X_ROWS32) ? 8 * GPS : 2];
+    unsigned ld_e_all[RING][2 * GPS] = {};                      // form 3: this lane's exponent bytes of the wave's two tiles (2 wave, 2 wave + 1)
     // ``part``: 1 = the dY pieces (and their exponent bytes), 2 = the X pieces, 3 = both.  The default training form (WIDE) requests and
-    // splits the two operands half a step apart (STAGGER below), every other form both together.
-    auto issue = [&](long long s, int part = 3) {
+    // splits the two operands half a step apart (STAGGER below), every other form both together.  ``setc``: which register set.
+    auto issue = [&](auto setc, long long s, int part = 3) {
+        auto& ld_a = ld_a_all[decltype(setc)::value];
+        auto& ld_b = ld_b_all[decltype(setc)::value];
+        auto& ld_e = ld_e_all[decltype(setc)::value];
         const int st = (int)(s - s0) * GPS;                     // slab-relative group (a group past the slab's end reads as zero)
         if (part & 1) {
         if constexpr (F16) {
@@ -261,8 +269,11 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
         }
     };
     const int gi = lane >> 5, pi = lane & 31;                   // fragment pieces: lane half (column group) and point inside the group
-    auto stage = [&](int buf, long long s, int part = 3, bool valid = true) {      // split + write what this thread loaded into the images of `buf`
-                                                                                   // (valid = false: a step past the slab's end -> zeros)
+    auto stage = [&](auto setc, int buf, long long s, int part = 3, bool valid = true) {      // split + write what this thread loaded into the images of `buf`
+                                                                                              // (valid = false: a step past the slab's end -> zeros)
+        auto& ld_a = ld_a_all[decltype(setc)::value];
+        auto& ld_b = ld_b_all[decltype(setc)::value];
+        auto& ld_e = ld_e_all[decltype(setc)::value];
         unsigned char* base = lds + buf * F_BUF;
         if (part & 1) {
         if constexpr (A_FRAG) {
@@ -400,14 +411,15 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
     // its END (after the X pieces of s + 1): one operand's pieces are always on their way, each with a whole step to arrive, out of the
     // same registers.
     constexpr bool STAGGER = WIDE;
+    typedef std::integral_constant<int, 0> S0;
     if constexpr (STAGGER) {
         // (no branch around a request or a split: at a join the compiler's s_waitcnt placement must be right for the path that issued nothing,
         //  i.e. it would wait for the requests just made as well.  Steps past the slab's end read zeros — the descriptors are slab-relative
         //  — and their split is masked.)
         if (s0 < s1) {
-            issue(s0);
-            stage(0, s0);
-            issue(s0 + 1);
+            issue(S0{}, s0);
+            stage(S0{}, 0, s0);
+            issue(S0{}, s0 + 1);
             __syncthreads();
         }
         for (long long s = s0; s < s1; ++s) {
@@ -416,21 +428,52 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
 #pragma unroll
             for (int kb = 0; kb < GPS; ++kb) mma(buf, kb);
             __builtin_amdgcn_sched_barrier(0);        // (fences: left alone the scheduler sinks the first requests to the end of the step)
-            stage(buf ^ 1, s + 1, 1, more);           // the other buffer was last read in step s-1; every wave passed that step's barrier
-            issue(s + 2, 1);
+            stage(S0{}, buf ^ 1, s + 1, 1, more);     // the other buffer was last read in step s-1; every wave passed that step's barrier
+            issue(S0{}, s + 2, 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kb = GPS; kb < 2 * GPS; ++kb) mma(buf, kb);
             __builtin_amdgcn_sched_barrier(0);
-            stage(buf ^ 1, s + 1, 2, more);
-            issue(s + 2, 2);
+            stage(S0{}, buf ^ 1, s + 1, 2, more);
+            issue(S0{}, s + 2, 2);
             __syncthreads();
+        }
+    } else if constexpr (RING == 4) {
+        // step j of the slab (j = s - s0) comes through register set j % 4 into LDS buffer j & 1.  Nothing below is conditional (see above):
+        // the slab is walked in whole groups of four steps, steps past its end read zeros and multiply zeros.
+        typedef std::integral_constant<int, 1> S1;
+        typedef std::integral_constant<int, 2> S2;
+        typedef std::integral_constant<int, 3> S3;
+        if (s0 < s1) {
+            issue(S0{}, s0); issue(S1{}, s0 + 1); issue(S2{}, s0 + 2); issue(S3{}, s0 + 3);
+            stage(S0{}, 0, s0);
+            issue(S0{}, s0 + 4);
+            __syncthreads();
+        }
+        const long long n_quads = (n_steps + 3) >> 2;
+        for (long long qd = 0; qd < n_quads; ++qd) {
+            const long long s = s0 + 4 * qd;
+            auto body = [&](auto nextc, int buf, long long sj) {      // step sj is in `buf`; the next step's pieces sit in set `nextc`
+#pragma unroll
+                for (int kb = 0; kb < GPS; ++kb) mma(buf, kb);
+                __builtin_amdgcn_sched_barrier(0);
+                stage(nextc, buf ^ 1, sj + 1, 3, sj + 1 < s1);
+                issue(nextc, sj + 5);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kb = GPS; kb < 2 * GPS; ++kb) mma(buf, kb);
+                __syncthreads();
+            };
+            body(S1{}, 0, s);
+            body(S2{}, 1, s + 1);
+            body(S3{}, 0, s + 2);
+            body(S0{}, 1, s + 3);
         }
     } else {
     if (s0 < s1) {
-        issue(s0);
-        stage(0, s0);
-        if (s0 + 1 < s1) issue(s0 + 1);
+        issue(S0{}, s0);
+        stage(S0{}, 0, s0);
+        if (s0 + 1 < s1) issue(S0{}, s0 + 1);
         __syncthreads();
     }
     for (long long s = s0; s < s1; ++s) {
@@ -438,8 +481,8 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
         const bool more = s + 1 < s1;
 #pragma unroll
         for (int kb = 0; kb < GPS; ++kb) mma(buf, kb);
-        if (more) stage(buf ^ 1, s + 1);      // the other buffer was last read in step s-1; every wave passed that step's barrier
-        if (s + 2 < s1) issue(s + 2);
+        if (more) stage(S0{}, buf ^ 1, s + 1);      // the other buffer was last read in step s-1; every wave passed that step's barrier
+        if (s + 2 < s1) issue(S0{}, s + 2);
 #pragma unroll
         for (int kb = GPS; kb < 2 * GPS; ++kb) mma(buf, kb);
         __syncthreads();
