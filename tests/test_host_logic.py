@@ -652,3 +652,23 @@ def test_live_traffic_pass_reports_why_it_could_not_run(monkeypatch):
     total, prov = bench.hbm_traffic(True, "fused16", 3)
     assert total is not None and total > 10485760 and prov["file"].startswith("profiles/") and prov["live_pass"]["live"] is False
     assert bench.under_profiler() in (False, True)
+
+
+def test_reference_sequence_is_the_reference_trainers_call_sequence():
+    """tools/reference_sequence.py (what the GPU tests, tools/host_profile.py and bench.py's ``train.drop_in_sequence`` run as "the
+    reference trainer's own call sequence") against the REFERENCE'S OWN ``VectorFieldNerfRunner.train_epoch``: both are run on the same
+    recording stand-ins (tests/trace_reference_loop.py, in a subprocess: it imports /root/reference) and must make the same calls with the
+    same argument shapes and scalars in the same order — render, sample_border_points, vector_field_network, get_center_indices_and_gt,
+    sample_center_points, vector_field_network, the loss, zero_grad, parameters, clip_grad_norm_, optimizer.step, scheduler.step.
+    Skipped where the reference is not present (the GPU box)."""
+    import json
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("no /root/reference here")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "trace_reference_loop.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["identical"] and rec["calls_reference"] == rec["calls_restatement"] == 24, rec
+    assert rec["sequence"][:7] == ["model.render", "functions.sample_border_points", "model.vector_field_network", "functions.get_center_indices_and_gt",
+                                   "functions.sample_center_points", "model.vector_field_network", "loss"]
