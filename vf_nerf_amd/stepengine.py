@@ -419,7 +419,9 @@ class StepSession:
     """One training step between a grad-mode render() and its backward (see the module docstring)."""
 
     def __init__(self, engine: StepEngine, n: int, s_c: int, n_f: int, sup_rows: int, ws: torch.Tensor, lay: List[int], views, flat) -> None:
-        self.engine, self.model = engine, engine.model      # (a session lives for one step; the model holds the engine, which holds the last session)
+        # (the engine holds its last session; the session reaches the engine — and through it the model — weakly: no cycle keeps a step's
+        #  30 GB workspace waiting for the cyclic collector once the model is gone)
+        self._engine_ref = weakref.ref(engine)
         self.n, self.s_c, self.n_f, self.s_t, self.m = n, s_c, n_f, s_c + n_f, n * (s_c + n_f)
         self.sup_rows = sup_rows
         self.ws, self.flat = ws, flat
@@ -427,19 +429,34 @@ class StepSession:
         self.ray_dirs, self.z, self.points, self.normals, self.colors, self.weights, self.rgb, self.depth, self.out_terms, self.out_norm = views
         self.normals = self.normals.view(self.m, 3)
 
-        def rows3(index: int, rows: int) -> torch.Tensor:
-            off = lay[index]
-            return ws[off:off + rows * 12].view(torch.float32).view(rows, 3)
+        # (views of the persistent workspace: the same five tensors step after step, made once per workspace)
+        cached = getattr(engine, "_region_views", None)
+        if cached is None or cached[0] != (ws.data_ptr(), sup_rows, self.m):
+            def rows3(index: int, rows: int) -> torch.Tensor:
+                off = lay[index]
+                return ws[off:off + rows * 12].view(torch.float32).view(rows, 3)
 
-        self.sup_pts, self.sup_gt = rows3(lib.TWS_SUP_PTS, sup_rows), rows3(lib.TWS_SUP_GT, sup_rows)
-        self.sup_pred, self.d_sup = rows3(lib.TWS_SUP_PRED, sup_rows), rows3(lib.TWS_D_SUP, sup_rows)
-        self.dn = rows3(lib.TWS_DN, self.m)
+            cached = engine._region_views = ((ws.data_ptr(), sup_rows, self.m),
+                                             (rows3(lib.TWS_SUP_PTS, sup_rows), rows3(lib.TWS_SUP_GT, sup_rows), rows3(lib.TWS_SUP_PRED, sup_rows),
+                                              rows3(lib.TWS_D_SUP, sup_rows), rows3(lib.TWS_DN, self.m)))
+        self.sup_pts, self.sup_gt, self.sup_pred, self.d_sup, self.dn = cached[1]
         self.next_row = 0
         self.regions: Dict[int, dict] = {}          # row0 -> {count, on_side, forwarded, pending}
         self.ray_centre: Optional[dict] = None      # the deferred centre-ball rows of functions.get_center_indices_and_gt
         self.open, self.stale, self.backward_done = True, False, False
         self.node_ref = None
         self._flush_queued = False
+
+    @property
+    def engine(self) -> "StepEngine":
+        eng = self._engine_ref()
+        if eng is None:
+            raise RuntimeError("the model this training step belongs to no longer exists")
+        return eng
+
+    @property
+    def model(self):
+        return self.engine.model
 
     # -- life cycle -------------------------------------------------------------------------------
     def abandoned(self) -> bool:

@@ -48,7 +48,8 @@ def _shell(r_min: float, r_max: float, num_samples: int, centroid: torch.Tensor,
     if torch.is_grad_enabled() and n > 0:
         from .stepengine import current_session
         session = current_session()
-        if session is not None and torch.device(device) == session.ws.device:
+        want = torch.device(device)
+        if session is not None and want.type == session.ws.device.type and want.index in (None, session.ws.device.index):
             got = session.sample(inward, float(r_min), float(r_max), centroid, n, None if u is None else u.to(session.ws.device).float().contiguous(),
                                  _seed, _offset)
             if got is not None:
