@@ -723,7 +723,7 @@ def grid_stages_bench(args, dev):
                       "stages": out}))
 
 
-def train_step_accounting(n_rays, s_c, s_t, n_sup, storage, gradients="fp32", separate_proposal=False):
+def train_step_accounting(n_rays, s_c, s_t, n_sup, storage, gradients="fp32", separate_proposal=False, selected=None):
     """ALGORITHMIC work and workspace traffic of one training step (DESIGN.md section 3 "Backward").
     FLOPs: the fine pass forward and twice that for its backward (VF + rendering, S_t samples) + forward and backward of the
     2 x n_sup supervision points through the VF net (+ the reference's separate vector-only proposal pass over the S_c samples
@@ -732,7 +732,11 @@ def train_step_accounting(n_rays, s_c, s_t, n_sup, storage, gradients="fp32", se
     point, 9 per supervision point; 1 KiB per slot and point as fp32, 512 B as f16 except the tanh'ed feature slot), their
     sign-bit words (32 B), the pre-activation gradients dY (1 KiB per slot and point, written by the chain, read by the
     weight-gradient kernels), the saved activations read once by the weight-gradient kernels, and the per-sample inputs and
-    outputs (point, normal, colour, their gradients)."""
+    outputs (point, normal, colour, their gradients).
+    ``selected`` (the sparse colour branch): the fraction of the samples with non-zero weight.  The bytes are then
+    what THAT step moves — every sample and supervision point through the vector-only launches (the 8 ReLU slots of the vector-field
+    net: no feature slot, no rendering-net slots), the selected samples once more through all 13 slots — while the FLOPs stay the
+    dense step's (algorithmic work; the caller prices what was executed separately)."""
     m_f, m_s = n_rays * s_t, 2 * n_sup
     # (supervision points: the three vector columns only — trainer.TrainStep's vector-only call; the 256 x 256 feature block of the
     # reference's full forward there is never read and is not counted)
@@ -742,6 +746,13 @@ def train_step_accounting(n_rays, s_c, s_t, n_sup, storage, gradients="fp32", se
     masks = 32 * (13 * m_f + 9 * m_s)
     dy = (512 if gradients in ("bf16", "f16") else 1024) * (13 * m_f + 9 * m_s)
     small = (12 + 12 + 12 + 4 + 12 + 12) * m_f + 2 * 160 * (m_f + m_s)        # points, normals, colours, z + grads, aux tiles
+    if selected is not None:
+        m_1, m_2 = m_f + m_s, selected * m_f                                   # region 1 (vector-only), region 2 (fused, the selected samples)
+        dy_slot = 512 if gradients in ("bf16", "f16") else 1024
+        saved = m_1 * 8 * relu_slot + m_2 * (12 * relu_slot + 1024)
+        masks = 32 * (8 * m_1 + 13 * m_2)
+        dy = dy_slot * (8 * m_1 + 13 * m_2)
+        small += (12 + 12 + 12 + 12) * m_2 + 2 * 160 * m_2
     total = 2 * saved + 2 * masks + 2 * dy + small                             # ... and read back once; dY written + read
     return flops, total
 
@@ -880,6 +891,10 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
     colour_share = 3.0 * args.rays * s_t * 2.0 * (256 * 256 + RN_MACS) / flops   # fraction of the step's dense FLOPs in the colour branch (feature block + rendering net)
     executed = flops * (1.0 - colour_share * (1.0 - sel)) + (3.0 * 2.0 * args.rays * s_t * sel * (VF_MACS - 256 * 256) if sel is not None else 0.0) \
         if sel is not None else flops
+    ws_dense = ws_bytes
+    if sel is not None:          # the bytes the sparse step moves (rounds 4's lines carried the DENSE step's accounting whatever ran)
+        ws_bytes = train_step_accounting(args.rays, args.coarse, s_t, n_sup, model.activation_storage, model.gradient_storage,
+                                         separate_proposal=not stored, selected=sel)[1]
     rec = {"metric": "training rays/sec (4096-ray batch, 128 samples/ray, fwd+bwd+clip+Adam)",
            "value": round(args.rays * args.steps * world / elapsed, 1), "unit": "rays/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -916,7 +931,11 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
            # whole peak and carries no div3 figure)
            "frac_of_f16_mfma_div3": round(flops / (ms * 1e-3) / 1e12 / (PEAK_F16_MFMA / 3.0), 4) if not train_dtype_label(model).startswith("16-bit-native") else None,
            "frac_of_f16_mfma": round(flops / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA, 4),
+           # bytes the step's launches move through the training workspace (accounted, not counted): with the sparse colour branch the
+           # vector-only slots of every point + all slots of the selected samples; `_dense_step` = what the dense step moves (the figure
+           # rounds 3-4 quoted for every step)
            "workspace_gb_per_step": round(ws_bytes / 1e9, 2),
+           "workspace_gb_per_step_dense_step": round(ws_dense / 1e9, 2),
            "workspace_tb_per_s": round(ws_bytes / (ms * 1e-3) / 1e12, 3),
            "frac_of_hbm_peak": round(ws_bytes / (ms * 1e-3) / 8e12, 4),
            # what the opt-in two-product colour branch would do on the weights these steps arrived at (raw difference to three products,
@@ -1462,7 +1481,7 @@ def main() -> None:
             line["train"] = {k: train_rec[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "activation_storage", "gradient_storage", "workspace_layout",
                                                        "step_issued_as", "weights", "sparse_colour_branch", "algorithmic_tflop_per_step", "executed_tflop_per_step",
                                                        "executed_tflops", "frac_of_f16_mfma_div3_executed", "achieved_tflops", "frac_of_f16_mfma_div3",
-                                                       "workspace_gb_per_step", "workspace_tb_per_s", "frac_of_hbm_peak", "final_loss", "drop_in_sequence_ms", "drop_in_sequence")}
+                                                       "workspace_gb_per_step", "workspace_gb_per_step_dense_step", "workspace_tb_per_s", "frac_of_hbm_peak", "final_loss", "drop_in_sequence_ms", "drop_in_sequence")}
             line["train"]["workload"] = train_rec["config"]["workload"]
         emit_line((line))
     if dist is not None:

@@ -61,7 +61,7 @@ int vfn_internal_bwd_chain_bf16_ws_at(const vfn_net_geom* vf_geom, const void* v
 int vfn_internal_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_geom* geom, const vfn_wgrad_layer* layers, const void* saved,
                                             const void* dy, int64_t slot_bytes, int32_t dy_form, int32_t x_form, const float* feats,
                                             const float* aux, const float* dz_head, int64_t n_points, const int32_t* n_dev, uint32_t parts,
-                                            int32_t accumulate, void* scratch, void* stream);
+                                            int32_t accumulate, void* scratch, void* stream, int32_t stages = 3);
 
 // csrc/vfn_rays.hip: the samples with non-zero weight, compacted on the device (the sparse colour branch of vfn_train_step / vfn_render_fwd)
 int vfn_internal_select_positive(const float* weights, int n_rays, int n_samples, const float* points, const float* ray_dirs, int32_t* cnt,

@@ -71,7 +71,7 @@ struct Ws {
     unsigned char *saved, *dy;
     uint32_t* masks;
     float *aux_vf, *aux_rn, *dz_vec, *dz_rgb;
-    void *scratch_vf, *scratch_rn;
+    void *scratch_vf, *scratch_rn, *scratch_vf2;      // (vf2: region 2's vector-field products, beside region 1's on the side stream)
     // sparse colour branch (region 2 = the samples with non-zero weight, compacted): selection and per-selected-sample buffers
     int32_t *cnt, *off, *k_dev, *sel_sorted;
     float *pts_sel, *dirs_sel, *normals_sel, *colors_sel, *dc_sel, *zero3;
@@ -160,6 +160,9 @@ int carve(void* workspace, const vfn_train_step_params* p, const vfn_net_geom* v
     if (s_vf < 0 || s_rn < 0) return VFN_ERR_UNSUPPORTED;
     w->scratch_vf = c.take<unsigned char>((size_t)s_vf);
     w->scratch_rn = c.take<unsigned char>((size_t)s_rn);
+    const int64_t s_vf2 = p->sparse_colours ? vfn_net_weight_grads_scratch_bytes(VFN_NET_VF, vf_geom, w->cap) : 0;
+    if (s_vf2 < 0) return VFN_ERR_UNSUPPORTED;
+    w->scratch_vf2 = c.take<unsigned char>((size_t)s_vf2);
     w->bytes = c.off;
     return VFN_OK;
 }
@@ -201,16 +204,21 @@ __global__ void vfn_train_scalar_grads_kernel(const float* dscal, float* g_beta,
 // one side stream (+ fork / join events) per host thread and device, made on first use: the supervision batch's forward and
 // chain are independent of the fine pass until the loss / the weight gradients, and at the reference's batch size they are
 // 0.8-round launches that leave the chip mostly idle when they run alone
-struct Side { hipStream_t s; hipEvent_t fork, join; int dev; const void* armed_ws; };
+struct Side { hipStream_t s; hipEvent_t fork, join, after_fine; int dev; const void* armed_ws; const void* gated_ws; };
 Side* side_stream() {
-    static thread_local Side side = {nullptr, nullptr, nullptr, -1, nullptr};
+    static thread_local Side side = {nullptr, nullptr, nullptr, nullptr, -1, nullptr, nullptr};
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     if (side.dev != dev) {
-        if (side.dev >= 0) { (void)hipStreamDestroy(side.s); (void)hipEventDestroy(side.fork); (void)hipEventDestroy(side.join); side.dev = -1; }
+        if (side.dev >= 0) {
+            (void)hipStreamDestroy(side.s); (void)hipEventDestroy(side.fork); (void)hipEventDestroy(side.join); (void)hipEventDestroy(side.after_fine);
+            side.dev = -1;
+        }
         if (hipStreamCreateWithFlags(&side.s, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&side.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&side.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+            hipEventCreateWithFlags(&side.join, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&side.after_fine, hipEventDisableTiming) != hipSuccess) return nullptr;
+        side.armed_ws = side.gated_ws = nullptr;
         side.dev = dev;
     }
     return &side;
@@ -246,6 +254,8 @@ struct StepCtx {
     Side* sd;
     int n, sc, nf, st;
     bool sparse;
+    int sup_mode;                 // what step_render does once the fine pass's forward is launched: 0 nothing, 1 fork the side stream and issue the
+                                  // supervision batch there (whole-step form), 2 record Side::after_fine (session form: gates the caller's forwards)
     float* saved_f;
     vfn_density_params dp;        // n_samples = S_t after the render part
 };
@@ -262,6 +272,7 @@ int step_open(StepCtx& c, const vfn_train_step_params* p, const vfn_train_step_i
     c.sd = (want_side && p->render.streams >= 2) ? side_stream() : nullptr;
     c.ss = c.sd ? c.sd->s : c.s;
     c.sparse = p->sparse_colours != 0;
+    c.sup_mode = 0;
     c.saved_f = reinterpret_cast<float*>(c.w.saved);
     c.dp = p->render.density;
     c.dp.n_rays = c.n; c.dp.n_samples = c.st;
@@ -336,6 +347,14 @@ int step_render(StepCtx& c) {
     if (sparse) {
         STEP(vfn_vf_mlp16_fwd_train_at(io->vf_geom, io->vf_packed16, w.new_pts, w.m - w.m_c, 0, w.normals_s + w.m_c * 3, saved_f, w.aux_vf, w.masks,
                                        p->save_flags, w.m_c, w.total, s));
+        // The supervision batch's forward goes HERE (round 5): what follows the fine pass's forward on this stream — the weights, the selection,
+        // region 2's forward of under one round of workgroups, the composite, the loss — leaves the chip mostly idle for ~0.3 ms at 4096 rays,
+        // which is what that forward needs; beside the proposal pass (where rounds 4 put it) it shared a chip that was already full.
+        if (c.sd && c.sup_mode == 1) { STEP(fork_to(c.sd, s)); STEP(step_supervision(c)); }
+        if (c.sd && c.sup_mode == 2) {
+            if (hipEventRecord(c.sd->after_fine, s) != hipSuccess) { vfn_set_error("vfn_train_step: could not record the fine pass's event"); return VFN_ERR_LAUNCH; }
+            c.sd->gated_ws = io->workspace;
+        }
         // normals to their sorted positions, weights (no colours yet)
         STEP(vfn_scatter_rows3(w.normals_s, nullptr, w.dst, w.m, io->normals, nullptr, s));
         STEP(vfn_ray_density_weights(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, nullptr, nullptr, io->weights, nullptr, nullptr, nullptr, s));
@@ -405,17 +424,25 @@ int step_backward(StepCtx& c, const float* d_rgb, const float* d_depth) {
         STEP(vfn_internal_net_weight_grads_frag_part(VFN_NET_RENDER, io->rn_geom, io->rn_wgrad, w.saved + rn_off + r2_off, w.dy + rn_off + r2_off,
                                                      (int64_t)w.slot_bytes, p->dy_form, p->x_form, feats + w.r2_first * 256, w.aux_rn + w.r2_first * 40,
                                                      w.dz_rgb + w.r2_first * 4, w.cap, w.k_dev, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD, 1,
-                                                     w.scratch_rn, ss));
+                                                     w.scratch_rn, ss, 1));
+        // ... and the vector-field net's products over region 2 (hidden layers + feature block; the head's gradient there is zero) into a scratch
+        // of their own; their un-fold ADDS to the tensors region 1's un-fold adds to, so it waits for the join below
+        STEP(vfn_internal_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved + r2_off, w.dy + r2_off, (int64_t)w.slot_bytes,
+                                                     p->dy_form, p->x_form, nullptr, w.aux_vf + w.r2_first * 40, w.dz_vec + w.r2_first * 4, w.cap,
+                                                     w.k_dev, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES, 1, w.scratch_vf2, ss, 1));
+        STEP(vfn_internal_net_weight_grads_frag_part(VFN_NET_RENDER, io->rn_geom, io->rn_wgrad, w.saved + rn_off + r2_off, w.dy + rn_off + r2_off,
+                                                     (int64_t)w.slot_bytes, p->dy_form, p->x_form, feats + w.r2_first * 256, w.aux_rn + w.r2_first * 40,
+                                                     w.dz_rgb + w.r2_first * 4, w.cap, w.k_dev, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES | VFN_WGRAD_HEAD, 1,
+                                                     w.scratch_rn, ss, 2));
         // ONE vector-only chain over region 1 and the supervision rows (d normals | d supervision predictions)
         STEP(vfn_mlp_bwd_chain_bf16_ws_at(io->vf_geom, io->vf_packed_bwd16, io->vf_head_w, nullptr, nullptr, nullptr, feats, w.masks, w.dy, p->dy_flags,
                                           nullptr, nullptr, w.dn_s, w.normals_s, nullptr, 3, w.m + sup_rows, nullptr, w.dz_vec, 0, w.total, s));
         STEP(vfn_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved, w.dy, (int64_t)w.slot_bytes, p->dy_form, p->x_form, nullptr,
                                             w.aux_vf, w.dz_vec, w.m + sup_rows, VFN_WGRAD_LAYERS | VFN_WGRAD_HEAD, 1, w.scratch_vf, s));
-        // (the vector-field net's gradients of region 2 are ADDED to the same tensors: after both of the above)
         if (sd) STEP(join_into(sd, s));
         STEP(vfn_internal_net_weight_grads_frag_part(VFN_NET_VF, io->vf_geom, io->vf_wgrad, w.saved + r2_off, w.dy + r2_off, (int64_t)w.slot_bytes,
                                                      p->dy_form, p->x_form, nullptr, w.aux_vf + w.r2_first * 40, w.dz_vec + w.r2_first * 4, w.cap,
-                                                     w.k_dev, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES, 1, w.scratch_vf, s));
+                                                     w.k_dev, VFN_WGRAD_LAYERS | VFN_WGRAD_FEATURES, 1, w.scratch_vf2, s, 2));
     } else {
         if (sup_rows > 0) {
             // (beside the per-ray backward and the fine pass's chain when there is a side stream; joined in front of the weight gradients)
@@ -543,6 +570,11 @@ extern "C" int vfn_train_step_supervision_forward(const vfn_train_step_params* p
     hipStream_t s = (hipStream_t)stream;
     Side* sd = on_side ? armed_side(p, io->workspace) : nullptr;
     hipStream_t ss = sd ? sd->s : s;
+    // (behind the fine pass's forward, where the chip has room for it: see step_render)
+    if (sd && sd->gated_ws == io->workspace && hipStreamWaitEvent(sd->s, sd->after_fine, 0) != hipSuccess) {
+        vfn_set_error("vfn_train_step_supervision_forward: could not wait for the fine pass");
+        return VFN_ERR_LAUNCH;
+    }
     STEP(vfn_vf_mlp16_fwd_train_at(io->vf_geom, io->vf_packed16, w.sup_pts + row0 * 3, rows, 0, w.sup_pred + row0 * 3, reinterpret_cast<float*>(w.saved),
                                    w.aux_vf, w.masks, p->save_flags, w.m + row0, w.total, ss));
     if (sd) STEP(join_into(sd, s));
@@ -607,7 +639,8 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
         STEP(step_prep(c, false));
         // the supervision batch runs on a side stream beside the render (render.streams >= 2; joined in front of the loss): its points
         // depend on nothing but the prep launch
-        if (c.sd) { STEP(fork_to(c.sd, s)); STEP(step_supervision(c)); }
+        if (c.sd && c.sparse && p->render.streams != 3) c.sup_mode = 1;      // (streams = 3: beside the proposal pass as in round 4, for A/B)
+        else if (c.sd) { STEP(fork_to(c.sd, s)); STEP(step_supervision(c)); }
         STEP(step_render(c));
         // ---- supervision points and their vector-only forward (train.py:186-216) -----------------------------------------------------
         if (c.sd) STEP(join_into(c.sd, s));
@@ -642,6 +675,8 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
             // the supervision calls that follow (vfn_train_step_supervision_points / _forward) run on the side stream, after this step's prep
             STEP(fork_to(c.sd, s));
             c.sd->armed_ws = io->workspace;
+            c.sd->gated_ws = nullptr;
+            if (c.sparse && p->render.streams != 3) c.sup_mode = 2;
         }
         STEP(step_render(c));
     }
@@ -661,7 +696,7 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
             return VFN_ERR_LAUNCH;
         }
         STEP(step_backward(c, io->d_rgb_in, io->d_depth_in));
-        if (c.sd) c.sd->armed_ws = nullptr;
+        if (c.sd) c.sd->armed_ws = c.sd->gated_ws = nullptr;
     }
 
     // VFN_TRAIN_OPTIMIZER = VFN_TRAIN_CLIP then VFN_TRAIN_ADAM (the session form's caller makes them as two calls: clip_grad_norm_, optimizer.step)
@@ -680,10 +715,15 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
         if (p->repack) {
             VFN_REQUIRE(io->vf_layers && io->rn_layers && io->vf_packed16 && io->rn_packed16 && io->vf_packed_bwd16 && io->rn_packed_bwd16,
                         "vfn_train_step: repack without the layer tables / packs");
+            // four small launches (+ two fills) that depend on Adam only: the rendering net's on the side stream beside the vector-field net's
+            Side* sd = p->render.streams >= 2 ? side_stream() : nullptr;
+            hipStream_t ss = sd ? sd->s : s;
+            if (sd) STEP(fork_to(sd, s));
+            STEP(vfn_pack16_weights(VFN_NET_RENDER, io->rn_geom, io->rn_layers, io->rn_packed16, ss));
+            STEP(vfn_pack_weights_bwd16_mode(VFN_NET_RENDER, io->rn_geom, io->rn_layers, p->forward_products == 1 ? 1 : 0, io->rn_packed_bwd16, ss));
             STEP(vfn_pack16_weights(VFN_NET_VF, io->vf_geom, io->vf_layers, io->vf_packed16, s));
-            STEP(vfn_pack16_weights(VFN_NET_RENDER, io->rn_geom, io->rn_layers, io->rn_packed16, s));
             STEP(vfn_pack_weights_bwd16_mode(VFN_NET_VF, io->vf_geom, io->vf_layers, p->forward_products == 1 ? 1 : 0, io->vf_packed_bwd16, s));
-            STEP(vfn_pack_weights_bwd16_mode(VFN_NET_RENDER, io->rn_geom, io->rn_layers, p->forward_products == 1 ? 1 : 0, io->rn_packed_bwd16, s));
+            if (sd) STEP(join_into(sd, s));
         }
     }
     return VFN_OK;

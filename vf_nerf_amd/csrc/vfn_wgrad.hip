@@ -115,7 +115,7 @@ extern "C" int vfn_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_ge
                                               const float* aux, const float* dz_head, int64_t n_points, uint32_t parts,
                                               int32_t accumulate, void* scratch, void* stream) {
     return vfn_internal_net_weight_grads_frag_part(net_kind, geom, layers, saved, dy, slot_bytes, dy_form, x_form, feats, aux, dz_head, n_points, nullptr,
-                                                   parts, accumulate, scratch, stream);
+                                                   parts, accumulate, scratch, stream, 3);
 }
 
 // ... over min(n_points, *n_dev) points when n_dev (device memory) is given: the slab count and the scratch are sized for n_points, every
@@ -123,12 +123,16 @@ extern "C" int vfn_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_ge
 int vfn_internal_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_geom* geom, const vfn_wgrad_layer* layers, const void* saved,
                                             const void* dy, int64_t slot_bytes, int32_t dy_form, int32_t x_form, const float* feats,
                                             const float* aux, const float* dz_head, int64_t n_points, const int32_t* n_dev, uint32_t parts,
-                                            int32_t accumulate, void* scratch, void* stream) {
+                                            int32_t accumulate, void* scratch, void* stream, int32_t stages) {
+    // stages: bit 0 the partial-slab products, bit 1 the un-fold launch — two calls with the same arguments otherwise, so that a caller can put
+    // the products of one row range on a side stream beside another range's and order only the un-folds (both ADD into the same tensors)
     const char* what = "vfn_net_weight_grads_frag";
     auto one = [&](int32_t shape, const void* dy1, int32_t dyf, const void* x1, int32_t xf, float* dw1, float* db1) -> int {
+        if (!(stages & 1)) return VFN_OK;
         return vfn_internal_weight_grad_frag_batch_dev(shape, dyf, xf, 1, &dy1, &x1, &dw1, &db1, n_points, n_dev, groups_for(n_points), stream);
     };
     VFN_REQUIRE(geom && layers && saved && dy && aux && dz_head && scratch, "%s: NULL argument", what);
+    VFN_REQUIRE(stages & 3, "%s: stages = 0", what);
     if (n_points <= 0) return VFN_OK;
     Entry e[VFN_MAX_LAYERS + 1];
     int head_slot;
@@ -157,7 +161,8 @@ int vfn_internal_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_geom
         if (b.n == 0) return VFN_OK;
         int gb = G / b.n;
         gb = gb < 1 ? 1 : gb;
-        int rc = vfn_internal_weight_grad_frag_batch_dev(shape, dy_form, xf, b.n, b.dy, b.x, b.dw, b.db, n_points, n_dev, gb, stream);
+        int rc = (stages & 1) ? vfn_internal_weight_grad_frag_batch_dev(shape, dy_form, xf, b.n, b.dy, b.x, b.dw, b.db, n_points, n_dev, gb, stream)
+                              : VFN_OK;
         for (int i = 0; i < b.n; ++i) {
             vfn_unfold_entry& o = u[b.unfold_idx[i]];
             if (shape == 0) { o.groups_act = gb; o.groups_db = gb; }
@@ -221,6 +226,6 @@ int vfn_internal_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_geom
         o.dw_act = part; o.db = dbp; o.w = q.weight; o.b_lin = q.bias; o.g_w = q.g_weight; o.g_b = q.g_bias;
         o.rows = 3; o.row_off = 0; o.in_dim = geom->in_dims[L - 1]; o.slab_rows = 32; o.act_c0 = 0; o.act_nc = VFN_HIDDEN; o.scale = 1.0f;
     }
-    if (nu == 0) return VFN_OK;
+    if (nu == 0 || !(stages & 2)) return VFN_OK;
     return vfn_unfold_weight_grads_acc(u, nu, G, accumulate ? (1u << nu) - 1u : 0u, stream);
 }
