@@ -175,6 +175,10 @@ struct PrepArgs {
     int pad_floats;
     float *zero_a, *zero_b;                   // session form: the whole supervision-point and upstream-gradient regions (zero_floats each)
     long long zero_floats;
+    // buffers a later launch of the step expects cleared (the colours outside the selection, the zero rows region 2's chain reads as its
+    // vector gradient, the flat gradient in the whole-step form): cleared HERE instead of by three fill launches on the step's critical path
+    float* clear[3];
+    long long clear_floats[3];
 };
 
 __global__ void vfn_train_prep_kernel(const PrepArgs a) {
@@ -187,9 +191,23 @@ __global__ void vfn_train_prep_kernel(const PrepArgs a) {
         }
         if (t < a.pad_floats) { a.pad_pts[t] = 0.f; a.pad_gt[t] = 0.f; a.pad_dsup[t] = 0.f; }
     }
-    for (long long i = (long long)blockIdx.x * blockDim.x + t; i < a.zero_floats; i += (long long)gridDim.x * blockDim.x) {
+    const long long first = (long long)blockIdx.x * blockDim.x + t, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = first; i < a.zero_floats; i += stride) {
         a.zero_a[i] = 0.f;
         a.zero_b[i] = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float* base = a.clear[r];
+        const long long n = a.clear_floats[r];
+        if (n <= 0) continue;
+        long long head = (long long)((16u - (unsigned)(reinterpret_cast<uintptr_t>(base) & 15u)) & 15u) / 4;      // floats in front of the first 16-byte line
+        head = head < n ? head : n;
+        float4* p4 = reinterpret_cast<float4*>(base + head);
+        const long long n4 = (n - head) / 4;
+        for (long long i = first; i < n4; i += stride) p4[i] = float4{0.f, 0.f, 0.f, 0.f};
+        if (first < head) base[first] = 0.f;
+        for (long long i = head + 4 * n4 + first; i < n; i += stride) base[i] = 0.f;
     }
 }
 
@@ -203,7 +221,9 @@ __global__ void vfn_train_scalar_grads_kernel(const float* dscal, float* g_beta,
 
 // one side stream (+ fork / join events) per host thread and device, made on first use: the supervision batch's forward and
 // chain are independent of the fine pass until the loss / the weight gradients, and at the reference's batch size they are
-// 0.8-round launches that leave the chip mostly idle when they run alone
+// 0.8-round launches that leave the chip mostly idle when they run alone.  (A lowest-priority side stream was measured in round 5 — the
+// supervision forward forked at the start of the step and left to fill whatever the main stream leaves idle: no gain over the explicit
+// placement behind the fine pass, 1-2 % worse at 1 024 rays.)
 struct Side { hipStream_t s; hipEvent_t fork, join, after_fine; int dev; const void* armed_ws; const void* gated_ws; };
 Side* side_stream() {
     static thread_local Side side = {nullptr, nullptr, nullptr, nullptr, -1, nullptr, nullptr};
@@ -286,9 +306,19 @@ int step_prep(StepCtx& c, bool session) {
     // session form: the caller appends batches of any size — every row it does not fill is a point at the origin with a zero upstream gradient
     const long long zero_floats = session ? w.m_sup_pad * 3 : 0;
     PrepArgs pa{io->beta, io->mean, io->scale, w.scal, w.dscal, w.centroid, p->sup_centroid[0], p->sup_centroid[1], p->sup_centroid[2],
-                w.sup_pts + w.m_sup * 3, w.sup_gt + w.m_sup * 3, w.d_sup + w.m_sup * 3, pad_floats, w.sup_pts, w.d_sup, zero_floats};
-    const unsigned blocks = (unsigned)(zero_floats > 0 ? (zero_floats + 1023) / 1024 : 1);
-    hipLaunchKernelGGL(vfn_train_prep_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(128), 0, c.s, pa);
+                w.sup_pts + w.m_sup * 3, w.sup_gt + w.m_sup * 3, w.d_sup + w.m_sup * 3, pad_floats, w.sup_pts, w.d_sup, zero_floats,
+                {nullptr, nullptr, nullptr}, {0, 0, 0}};
+    long long most = zero_floats;
+    int nc = 0;
+    auto clear = [&](float* ptr, long long floats) {
+        if (!ptr || floats <= 0) return;
+        pa.clear[nc] = ptr; pa.clear_floats[nc] = floats; ++nc;
+        most = floats / 4 > most ? floats / 4 : most;
+    };
+    if (c.sparse) { clear(io->colors, w.m * 3); clear(w.zero3, w.cap * 3); }
+    if (!session) clear(io->flat_grad, io->n_flat);
+    const unsigned blocks = (unsigned)(most > 0 ? (most + 1023) / 1024 : 1);
+    hipLaunchKernelGGL(vfn_train_prep_kernel, dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, c.s, pa);
     STEP(vfn_check_launch("vfn_train_step (prep)"));
     return VFN_OK;
 }
@@ -365,10 +395,6 @@ int step_render(StepCtx& c) {
                                                w.normals_sel, w.colors_sel, saved_f, w.aux_vf, w.aux_rn, w.masks, p->save_flags, w.r2_first, w.total,
                                                p->forward_products, s));
         // colours: zero where w = 0 (they multiply a zero weight), the selected ones at their sorted positions; composite
-        if (hipMemsetAsync(io->colors, 0, (size_t)w.m * 3 * sizeof(float), s) != hipSuccess) {
-            vfn_set_error("vfn_train_step: could not clear the colours");
-            return VFN_ERR_LAUNCH;
-        }
         STEP(vfn_internal_rows3_by_index(w.colors_sel, w.sel_sorted, w.k_dev, w.cap, io->colors, 0, s));
         STEP(vfn_ray_density_weights(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, nullptr, io->weights, nullptr, io->rgb, io->depth, s));
     } else {
@@ -406,10 +432,6 @@ int step_backward(StepCtx& c, const float* d_rgb, const float* d_depth) {
         STEP(vfn_ray_density_weights_bwd(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, io->colors, d_rgb, d_depth, nullptr, w.dn, w.dc, w.dscal, s));
         STEP(vfn_scatter_rows3(w.dn, nullptr, w.src, w.m, w.dn_s, nullptr, s));       // row src[i] of region 1 is sorted sample i
         STEP(vfn_internal_rows3_by_index(w.dc, w.sel_sorted, w.k_dev, w.cap, w.dc_sel, 1, s));
-        if (hipMemsetAsync(w.zero3, 0, (size_t)w.cap * 3 * sizeof(float), s) != hipSuccess) {
-            vfn_set_error("vfn_train_step: could not clear the zero rows");
-            return VFN_ERR_LAUNCH;
-        }
         // Region 2's chain and the rendering net's weight gradients are small launches (a few percent of the samples: 0.6 rounds of
         // workgroups at 4096 rays) that touch nothing region 1's chain and weight gradients touch (other rows of the workspace, other
         // parameters' gradients, their own scratch): they run on the side stream beside them.
@@ -656,10 +678,6 @@ extern "C" int vfn_train_step(const vfn_train_step_params* p, const vfn_train_st
         const float* loss_points = lp.ray_center ? io->points : nullptr;
         STEP(vfn_vf_loss_fwd(&lp, io->rgb, io->rgb_gt, lp.has_depth ? io->depth : nullptr, lp.has_depth ? io->depth_gt : nullptr, io->normals,
                              loss_points, sup_pred, sup_gt, w.loss_ws, io->out_terms, s));
-        if (hipMemsetAsync(io->flat_grad, 0, (size_t)io->n_flat * sizeof(float), s) != hipSuccess) {
-            vfn_set_error("vfn_train_step: could not zero the flat gradient");
-            return VFN_ERR_LAUNCH;
-        }
         // d normals of the loss lands in `dn`, where the per-ray backward ADDS the density path's share
         STEP(vfn_vf_loss_bwd(&lp, io->rgb, io->rgb_gt, lp.has_depth ? io->depth : nullptr, lp.has_depth ? io->depth_gt : nullptr, io->normals,
                              loss_points, sup_pred, sup_gt, w.loss_ws, nullptr, w.d_rgb, lp.has_depth ? w.d_depth : nullptr, w.dn, d_sup, s));
