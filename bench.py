@@ -801,7 +801,10 @@ def drop_in_sequence_timing(args, model, uv, pose, K, rgb_gt, depth_gt, centroid
     the two network calls, VFLoss, zero_grad, backward, clip_grad_norm_, optimizer.step, scheduler.step, loss.item() — restated call for
     call in tools/reference_sequence.py on the names vf_nerf_amd.dropin installs), timed like the one-call step above: it takes the step
     session (stepengine.py), i.e. the same workspace and kernels, with ~15 Python-level calls around them.  ``ms_per_step`` includes the
-    loop's per-step loss.item() (a device synchronisation the reference's loop makes); ``ms_per_step_without_loss_item`` leaves it out."""
+    loop's per-step ``loss.item()`` / ``losses_dict[key]`` reads and its running sums, exactly as train_epoch keeps them — on the HIP path
+    those are deferred scalars (vf_nerf_amd/deferred.py: added on the device, read once per epoch), so the loop no longer synchronises per
+    step; ``ms_per_step_without_loss_item`` leaves the reads out; ``ms_per_step_with_a_synchronising_item`` is the same loop with plain
+    floats (``loss.DEFERRED_SCALARS = False``: rounds 1-4's behaviour, a device synchronisation per step)."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
     from types import SimpleNamespace
     import reference_sequence
@@ -810,16 +813,25 @@ def drop_in_sequence_timing(args, model, uv, pose, K, rgb_gt, depth_gt, centroid
     data = {"uv": uv.unsqueeze(0), "intrinsics": K.unsqueeze(0), "pose": pose.unsqueeze(0), "rgb": rgb_gt.unsqueeze(0), "depth": depth_gt.unsqueeze(0)}
     out = {}
     eng = stepengine.StepEngine.of(model)
-    for name, item in (("ms_per_step", True), ("ms_per_step_without_loss_item", False)):
-        loop = reference_sequence.ReferenceLoop(model, crit, reference_sequence.StandInDataset(centroid, 1.0), radius, sync_each_step=item)
-        for _ in range(max(3, args.warmup)):
-            loop(data, 0)
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loop(data, 0)
-        torch.cuda.synchronize()
-        out[name] = round((time.perf_counter() - t0) / args.steps * 1e3, 4)
+    keep = vloss.DEFERRED_SCALARS
+    for name, item, deferred in (("ms_per_step", True, True), ("ms_per_step_without_loss_item", False, True),
+                                 ("ms_per_step_with_a_synchronising_item", True, False)):
+        vloss.DEFERRED_SCALARS = deferred
+        try:
+            loop = reference_sequence.ReferenceLoop(model, crit, reference_sequence.StandInDataset(centroid, 1.0), radius, sync_each_step=item)
+            for _ in range(max(3, args.warmup)):
+                loop(data, 0)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                loop(data, 0)
+            torch.cuda.synchronize()
+            out[name] = round((time.perf_counter() - t0) / args.steps * 1e3, 4)
+            if item and deferred:       # the epoch's end: the division that turns the running sums into floats (train.py:277-280)
+                avg = loop.average_losses
+                out["running_loss_mean_read_at_the_end"] = round(float(avg["loss"]) / (max(3, args.warmup) + args.steps), 6)
+        finally:
+            vloss.DEFERRED_SCALARS = keep
     out["took_the_step_session"] = eng.why_not is None and eng.session is not None
     out["why_not"] = eng.why_not
     out["call_sequence"] = "render | sample_border_points | vector_field_network(p)[:, :3] | get_center_indices_and_gt | sample_center_points | " \

@@ -222,6 +222,7 @@ def test_reference_call_sequence_replays_the_reference_trainer_steps(colours):
     _, oracle_grads = _oracle_run(fx, d)
     lr = fx["lr"]
     eng = stepengine.StepEngine.of(model)
+    seen_losses, seen_terms = [], []
     for t, b in enumerate(trainer_batches(fx, d, device=DEV)):
         supervision.replay_uniforms(b["border_u"], b["center_u"])
         loop.render_uniforms = {k: b[k] for k in ("u_coarse", "u_fine", "u_add")}
@@ -237,6 +238,11 @@ def test_reference_call_sequence_replays_the_reference_trainer_steps(colours):
         same_z = bool(torch.equal(out.z_vals.cpu(), d[f"s{t}.out.z_vals"]))
         e_terms = float((torch.tensor([terms[k] for k in vloss._NAMES], dtype=torch.float64) - d[f"s{t}.loss_terms"]).abs().max())
         e_loss = abs(float(loss) - float(d[f"s{t}.loss"])) / max(1.0, float(d[f"s{t}.loss"]))
+        # the loop's own `loss.item()` / `losses_dict[key]` reads (train.py:262-275) are deferred scalars: numbers that equal the tensor's value
+        from vf_nerf_amd.deferred import DeferredScalar
+        assert isinstance(loss.item(), DeferredScalar) and loss.item() == float(loss) and isinstance(terms["rgb_loss"], DeferredScalar)
+        seen_losses.append(float(loss))
+        seen_terms.append([float(terms[k]) for k in vloss._NAMES])
         e_clip = abs(float(loop.last_total_norm) - float(d[f"s{t}.clip_total_norm"])) / float(d[f"s{t}.clip_total_norm"])
         nets = {"vf": model.vector_field_network, "rn": model.rendering_network}
         worst_w = 0.0
@@ -256,6 +262,11 @@ def test_reference_call_sequence_replays_the_reference_trainer_steps(colours):
             assert e_loss < 0.1
     assert float(model.optimizer.state[model.vector_field_network.layers[8].weight]["step"]) == 2 * fx["steps"]
     assert abs(model.optimizer.param_groups[0]["lr"] - float(d["final_lr"])) < 1e-15
+    # the running sums the loop kept the way train_epoch keeps them (added on the device, step after step) are the sums of the steps' values
+    avg = loop.average_losses
+    assert abs(float(avg["loss"]) - sum(seen_losses)) < 1e-6 * max(1.0, sum(seen_losses))
+    for j, k in enumerate(vloss._NAMES):
+        assert abs(float(avg[k]) - sum(row[j] for row in seen_terms)) < 1e-6 * max(1.0, sum(row[j] for row in seen_terms)), k
 
 
 def test_dropin_wraps_clip_grad_norm_for_the_duplicated_list():

@@ -672,3 +672,59 @@ def test_reference_sequence_is_the_reference_trainers_call_sequence():
     assert rec["identical"] and rec["calls_reference"] == rec["calls_restatement"] == 24, rec
     assert rec["sequence"][:7] == ["model.render", "functions.sample_border_points", "model.vector_field_network", "functions.get_center_indices_and_gt",
                                    "functions.sample_center_points", "model.vector_field_network", "loss"]
+
+
+def test_deferred_scalars_carry_the_reference_loops_running_sums():
+    """vf_nerf_amd/deferred.py: ``loss.item()`` and ``losses_dict[key]`` as numbers that stay on the device while they are only ADDED (the
+    reference trainer's per-step accumulation, train/vector_field_nerf_train.py:262-275) and are plain floats on any other use.  Here on
+    CPU tensors (the mechanics are device-independent): the reference's own accumulation code, then its division at the end of the epoch."""
+    import json
+    import math
+
+    from vf_nerf_amd import loss as vloss
+    from vf_nerf_amd.deferred import DeferredScalar, DeviceScalars, as_loss
+
+    g = torch.Generator().manual_seed(3)
+    steps = [torch.rand(8, generator=g) for _ in range(5)]
+    average_losses = None
+    reads = []
+    for vec in steps:
+        holder = DeviceScalars(vec.clone())
+        loss = as_loss(vec[6].clone().requires_grad_(True) * 1.0, holder, 6)
+        losses_dict = vloss._LazyTerms(vloss._NAMES, None, holder=holder)
+        assert list(losses_dict.keys()) == list(vloss._NAMES) and len(losses_dict) == 6
+        loss.backward()                                   # a tensor like any other
+        if average_losses is None:                        # (the reference's code, verbatim in structure)
+            average_losses = losses_dict
+            average_losses["loss"] = loss.item()
+        else:
+            average_losses["loss"] += loss.item()
+            for key in losses_dict.keys():
+                average_losses[key] += losses_dict[key]
+        reads.append(holder)
+    # nothing has been read back so far: every per-step vector still sits on its "device"
+    assert all(h._host is None for h in reads[1:]) and isinstance(dict.__getitem__(average_losses, "loss"), DeferredScalar)
+    for key in average_losses.keys():
+        average_losses[key] /= len(steps)
+    want = torch.stack(steps).double().mean(dim=0)
+    assert all(type(v) is float for v in dict.values(average_losses))
+    for j, name in enumerate(vloss._NAMES):
+        assert abs(average_losses[name] - float(want[j])) < 1e-12
+    assert abs(average_losses["loss"] - float(want[6])) < 1e-12
+    # any other use is the float: arithmetic with numbers, comparison, formatting, math functions, json through items()
+    h = DeviceScalars(torch.tensor([0.25, 2.0]))
+    a, b = DeferredScalar(h, 0), DeferredScalar(h, 1)
+    assert a * 4 == 1.0 and 1 - a == 0.75 and b / a == 8.0 and a < b and f"{b:.1f}" == "2.0" and math.isfinite(a) and float(a) == 0.25
+    assert a + 1 == 1.25 and 1 + a == 1.25 and type(a + 1) is float and repr(b) == "2.0" and round(b) == 2 and a + b == 2.25
+    import numbers
+    assert isinstance(a, numbers.Real)
+    keep = vloss.DEFERRED_SCALARS
+    try:
+        vloss.DEFERRED_SCALARS = False
+        d = vloss._LazyTerms(vloss._NAMES, None, holder=DeviceScalars(steps[0]))
+        assert type(d["rgb_loss"]) is float
+    finally:
+        vloss.DEFERRED_SCALARS = keep
+    d = vloss._LazyTerms(vloss._NAMES, None, holder=DeviceScalars(steps[0]))
+    assert isinstance(d["rgb_loss"], DeferredScalar) and type(d.get("rgb_loss")) is float and type(d["rgb_loss"]) is float   # get() read it back
+    assert json.loads(json.dumps(d)) == {k: float(steps[0][j]) for j, k in enumerate(vloss._NAMES)}

@@ -3,7 +3,9 @@
 wall time of the same steps, for three ways of issuing it: trainer.TrainStep as ONE C call (vfn_train_step, the default), the reference
 trainer's OWN call sequence (train/vector_field_nerf_train.py:177-275 restated call for call in tools/reference_sequence.py: render, the
 samplers, the two network calls, VFLoss, zero_grad, backward, clip_grad_norm_, optimizer.step — what a reference user drives through
-vf_nerf_amd.dropin; "drop_in_sequence", with and without the loop's per-step loss.item()), and the launch-by-launch autograd path of round 4
+vf_nerf_amd.dropin; "drop_in_sequence": with the loop's per-step loss.item() / running sums, which the HIP path serves as deferred scalars
+(vf_nerf_amd/deferred.py: no synchronisation); "_no_item": without those reads; "_sync_item": with plain floats, a synchronisation per step as
+in rounds 1-4), and the launch-by-launch autograd path of round 4
 ("python": model.step_sessions = False, model.one_call_train_step = False).  The reference's batch size (1 024 rays) is the launch-bound
 regime.
 
@@ -58,7 +60,7 @@ def measure(step_fn, steps):
             "host_issue_ms_per_step_empty_queue": round(iso / min(steps, 30) * 1e3, 4)}
 
 
-for path in ("one_call", "drop_in_sequence", "drop_in_sequence_no_item", "python"):
+for path in ("one_call", "drop_in_sequence", "drop_in_sequence_no_item", "drop_in_sequence_sync_item", "python"):
     built = bench.build_trained_scene(dev, rays, 64, 64, seed=0)             # trained weights, targets = the model's own render (bench.training_targets)
     if built is not None:
         model, uv, pose, K, info = built
@@ -76,6 +78,7 @@ for path in ("one_call", "drop_in_sequence", "drop_in_sequence_no_item", "python
         from types import SimpleNamespace
         from vf_nerf_amd import loss as vloss
         crit = vloss.VFLoss(SimpleNamespace(**trainer.SHIPPED_LOSS_CONFIG), SimpleNamespace(**trainer.SHIPPED_LOSS_WEIGHTS))
+        vloss.DEFERRED_SCALARS = not path.endswith("sync_item")
         loop = reference_sequence.ReferenceLoop(model, crit, reference_sequence.StandInDataset(centroid, 1.0), radius,
                                                 sync_each_step=not path.endswith("no_item"))
         # what the reference's DataLoader hands over: host tensors with a leading batch dimension of one (train.py:172-177) — here already on
@@ -95,7 +98,8 @@ for path in ("one_call", "drop_in_sequence", "drop_in_sequence_no_item", "python
         rec.update({"took_the_step_session": eng.why_not is None and eng.session is not None, "why_not": eng.why_not,
                     "sparse_colour_branch": bool(model.sparse_colour_training) and eng.why_not is None,
                     "samples_with_nonzero_weight": round(sel[0] / sel[1], 4) if sel else None,
-                    "loss_item_every_step": loop.sync_each_step})
+                    "loss_item_every_step": loop.sync_each_step, "deferred_scalars": vloss.DEFERRED_SCALARS})
+        vloss.DEFERRED_SCALARS = True
         out[path] = rec
         continue
     step = trainer.TrainStep(model, centroid, border_radius=radius, far=1.0)

@@ -18,50 +18,43 @@ _NAMES = ("rgb_loss", "depth_loss", "unit_norm_loss", "supervision_loss", "norm_
           "directional_derivatives_loss")
 
 
+DEFERRED_SCALARS = True        # loss.item() and losses_dict[key] as deferred scalars (deferred.py): the reference loop's running sums without a sync
+
+
 class _LazyTerms(dict):
     """{name: float} whose values arrive from the device on first read.  Keys, length and iteration order are available at
-    once; every way of reading a value (indexing, get, values, items, pop, copy, repr, comparison) waits for the copy first."""
+    once.  Indexing a value that has not arrived gives a ``deferred.DeferredScalar`` (a number that stays on the device while it is only
+    added to other such numbers — the reference trainer's running sums, train.py:262-275 — and is the float on any other use); every
+    other way of reading (get, values, items, pop, copy, repr, comparison) waits for the device and holds plain floats from then on."""
 
-    _ring = []            # [pinned host buffer, weak reference to the dict that last used it], reused round-robin (a fresh pinned
-    _next = 0             # allocation per step costs more than the step's loss)
-
-    def _host(self, n: int) -> torch.Tensor:
-        import weakref
-        cls = _LazyTerms
-        if len(cls._ring) < 64:
-            cls._ring.append([torch.empty(16, dtype=torch.float32, pin_memory=True), None])
-        slot = cls._ring[cls._next % len(cls._ring)]
-        cls._next += 1
-        prev = slot[1]() if slot[1] is not None else None
-        if prev is not None and prev is not self:
-            prev._fetch()                      # 64 dicts later somebody still has not read this one: read it before its buffer goes
-        slot[1] = weakref.ref(self)
-        return slot[0][:n]
-
-    def __init__(self, names, stacked: torch.Tensor) -> None:
+    def __init__(self, names, stacked: torch.Tensor, holder=None, first: int = 0) -> None:
         super().__init__((n, None) for n in names)
         self._pending = None
-        if stacked.is_cuda:
-            host = self._host(stacked.numel())
-            host.copy_(stacked.float(), non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(stacked.device))
-            self._pending = (host, ev, tuple(names))
-        else:
+        if stacked is not None and not stacked.is_cuda:
             dict.update(self, zip(names, stacked.tolist()))
+            return
+        from .deferred import DeviceScalars
+        # ``holder``: a DeviceScalars whose entries first .. first + len(names) - 1 are these terms (the loss's total sits in the same vector)
+        self._pending = (holder if holder is not None else DeviceScalars(stacked.detach().float()), tuple(names), int(first))
 
     def _fetch(self) -> None:
         if self._pending is not None:
-            host, ev, names = self._pending
+            holder, names, first = self._pending
             self._pending = None
-            ev.synchronize()
-            for n, v in zip(names, host.tolist()):
+            host = holder.values()
+            for j, n in enumerate(names):
                 if dict.__getitem__(self, n) is None:          # (a value the caller has overwritten meanwhile stays)
-                    dict.__setitem__(self, n, v)
+                    dict.__setitem__(self, n, host[first + j])
 
     def __getitem__(self, k):
-        self._fetch()
-        return dict.__getitem__(self, k)
+        v = dict.__getitem__(self, k)
+        if v is None and self._pending is not None:
+            if DEFERRED_SCALARS and k in self._pending[1]:
+                from .deferred import DeferredScalar
+                return DeferredScalar(self._pending[0], self._pending[2] + self._pending[1].index(k))
+            self._fetch()
+            return dict.__getitem__(self, k)
+        return v
 
     def __iter__(self):          # (an overridden __iter__ also keeps dict(terms) / {**terms} off CPython's raw-copy fast path)
         return dict.__iter__(self)
@@ -205,7 +198,12 @@ class VFLoss(nn.Module):
             total = total + w.directional_derivatives * dd_loss
             terms = terms.clone()
             terms[5] = dd_loss.detach()
-        return total, _LazyTerms(_NAMES, terms)
+            return total, _LazyTerms(_NAMES, terms)
+        # the total (entry 6) and the six terms are ONE device vector: loss.item() and losses_dict[key] of a step add to the trainer's
+        # running sums as one vector addition, with no synchronisation (deferred.py)
+        from .deferred import DeviceScalars, as_loss
+        holder = DeviceScalars(out)
+        return (as_loss(total, holder, 6) if DEFERRED_SCALARS else total), _LazyTerms(_NAMES, None, holder=holder)
 
     @staticmethod
     def _fused_shapes_ok(pred, gt) -> Optional[str]:
