@@ -21,7 +21,12 @@ rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_grid" -o kt -- python3 $
 # round 5: the step issued as the reference trainer's own call sequence, and the GPU's idle gaps under either issue path
 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_dropin" -o kt -- python3 $R/tools/drive_step.py 1024 100 drop_in > "$R/gpurun_out/prof_dropin.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_onecall" -o kt -- python3 $R/tools/drive_step.py 1024 100 one_call > "$R/gpurun_out/prof_onecall.log" 2>&1
+# ... and ONE 4096-ray step on a time axis (start, end, queue of every kernel: what runs beside what)
+rocprofv3 --kernel-trace -d "$R/gpurun_out/prof_tl4096" -o kt -- python3 $R/tools/drive_step.py 4096 30 one_call > "$R/gpurun_out/prof_tl4096.log" 2>&1
 cd "$R"
+db=$(find gpurun_out/prof_tl4096 -name "*_results.db" | head -1)
+{ tail -1 gpurun_out/prof_tl4096.log; python3 tools/trace_timeline.py "$db" vfn_train_prep 0; } > "$OUT/step4096_onecall_timeline.txt"
+rm -rf gpurun_out/prof_tl4096
 for m in dropin onecall; do
   db=$(find gpurun_out/prof_$m -name "*_results.db" | head -1)
   { tail -1 gpurun_out/prof_$m.log; python3 tools/trace_gaps.py "$db" 600 12; python3 tools/topk.py "$db" 25; } > "$OUT/step1024_${m}_trace.txt"

@@ -23,4 +23,5 @@ python tools/host_profile.py 8192 10 2>/dev/null | last > "$OUT/host_profile_819
 python tools/bench_dwf_shapes.py 2>/dev/null | tail -3 > "$OUT/dwf_shapes.txt"
 bash tools/micro_load_width.sh 2>/dev/null > "$OUT/load_width.txt" || true
 python tools/bench_forward_modes.py 2>/dev/null | grep "ms " > "$OUT/forward_modes.txt"
+bash tools/ab_sup_window.sh > "$OUT/ab_supervision_forward_placement.txt" 2>/dev/null
 ls -la "$OUT"
