@@ -250,8 +250,14 @@ __device__ __forceinline__ f32x4v load_group(const Pipe& p, int q) {
 template <int SLOT, int TILE, int MASK>
 __device__ __forceinline__ f32x4v mask_group(const Pipe& p, int q) {
     if constexpr (MASK == MASK_RELU) {
-        const unsigned bits = p.mw[SLOT][TILE >> 1] >> (16 * (TILE & 1) + 4 * q);
-        return f32x4v{(bits & 1u) ? 1.f : 0.f, (bits & 2u) ? 1.f : 0.f, (bits & 4u) ? 1.f : 0.f, (bits & 8u) ? 1.f : 0.f};
+        // all-ones / zero WORDS (one v_bfe_i32 per value), ANDed onto the gradient in epi_pair: two VALU instructions per value and no SGPR
+        // pair in between — as 1.f / 0.f selected by compares it was five, with the wait states of the VALU-writes-SGPR hazard (round 5)
+        const int w = (int)p.mw[SLOT][TILE >> 1];
+        constexpr int b0 = 16 * (TILE & 1);
+        int m0 = __builtin_amdgcn_sbfe(w, b0 + 4 * q, 1), m1 = __builtin_amdgcn_sbfe(w, b0 + 4 * q + 1, 1),
+            m2 = __builtin_amdgcn_sbfe(w, b0 + 4 * q + 2, 1), m3 = __builtin_amdgcn_sbfe(w, b0 + 4 * q + 3, 1);
+        asm("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3));       // (opaque: or the AND below is folded back into compare + select)
+        return f32x4v{__builtin_bit_cast(float, m0), __builtin_bit_cast(float, m1), __builtin_bit_cast(float, m2), __builtin_bit_cast(float, m3)};
     } else {
         return load_group<SLOT, TILE>(p, q);
     }
@@ -284,7 +290,9 @@ __device__ __forceinline__ void store_group(const Pipe& p, const f32x16& v, int 
         typedef _Float16 half4 __attribute__((ext_vector_type(4)));
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
         const half4 h = __builtin_convertvector(g * scale, half4);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rs, (int)p.dvoff, (int)((TILE * p.st_tile + q * p.st_q) >> 1), BW16_STORE_AUX);
+        // (scaled f16 exists in fragment order only: tile stride 4096 B, quad stride 1024 B as fp32, half that here — a CONSTANT scalar offset;
+        //  through the runtime strides of `p` hipcc took it for a divergent value and wrapped every store in a waterfall loop, see below)
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rs, (int)p.dvoff, (TILE * 4096 + q * 1024) / 2, BW16_STORE_AUX);
     } else if (p.dy16) {              // bf16 (round to nearest even): half the bytes, 8 significant bits in ONE factor of dW = dY^T X
         typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -311,9 +319,13 @@ __device__ __forceinline__ void store_tile_f16s(const Pipe& p, int b, const u32x
 #ifdef BW16_ABL_NOSTORE      // timing only: the encode stays, the pieces do not leave
     asm volatile("" :: "v"(eq[0]), "v"(eq[1]), "v"(eq[2]), "v"(eq[3]));
 #else
+    // Round 5: the scalar offsets are compile-time constants (scaled f16 = fragment order: 2048 B per tile, 512 B per register quad).  They
+    // used to come from the Pipe's runtime strides, which hipcc did not know to be uniform: each of the four stores of every tile sat in a
+    // waterfall loop (v_readfirstlane / v_cmp / s_and_saveexec / store / s_cbranch_execnz: 245 loops in the vector-only kernel), i.e. four
+    // basic-block boundaries at the end of every chunk with their conservative s_waitcnt's and no scheduling across them.
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-        __builtin_amdgcn_raw_buffer_store_b64(eq[q], rs, (int)p.dvoff, (int)((TILE * p.st_tile + q * p.st_q) >> 1), BW16_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(eq[q], rs, (int)p.dvoff, (TILE * 4096 + q * 1024) / 2, BW16_STORE_AUX);
 #endif
 }
 // a whole finished tile: (scaled f16: the lane's exponent byte first, so that the four piece stores stay the youngest
@@ -350,7 +362,10 @@ __device__ __forceinline__ void epi_pair(f32x16& pend, const f32x4v (&mask)[4], 
         }
     }
     const float s0 = mask[pr >> 1][(2 * pr) & 3], s1 = mask[pr >> 1][(2 * pr + 1) & 3];
-    if (MASK == MASK_RELU) { v0 = s0 > 0.f ? v0 : 0.f; v1 = s1 > 0.f ? v1 : 0.f; }
+    if (MASK == MASK_RELU) {
+        v0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v0) & __builtin_bit_cast(unsigned, s0));
+        v1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v1) & __builtin_bit_cast(unsigned, s1));
+    }
     else { v0 *= 1.0f - s0 * s0; v1 *= 1.0f - s1 * s1; }
     pend[2 * pr] = v0; pend[2 * pr + 1] = v1;
     if constexpr (P1) {          // single product: the bf16 rounding (to nearest even) is the operand
@@ -623,7 +638,8 @@ __global__ __launch_bounds__(256, 1) void vfn_bwd16_kernel(const Bwd16Args a) {
     p.voff = in ? (uint32_t)(m * 1024 + g * 16) : 0xfffffff0u;
     // (fragment order adds scalar offsets of up to 32 KiB: the out-of-range value must not wrap; a launch is limited to 2 GiB per slot)
     p.dvoff = !frag ? p.voff : (in ? (uint32_t)((m >> 5) * 32768 + lane * (p.dy16 ? 8 : 16)) : 0xc0000000u);
-    p.st_tile = frag ? 4096u : 128u; p.st_q = frag ? 1024u : 32u;
+    // (readfirstlane: the strides become scalar offsets of the dY stores — as values hipcc knows to be uniform, or every store is a waterfall loop)
+    p.st_tile = (uint32_t)__builtin_amdgcn_readfirstlane(frag ? 4096 : 128); p.st_q = (uint32_t)__builtin_amdgcn_readfirstlane(frag ? 1024 : 32);
     {   // sign bits of every ReLU layer this launch walks through: 16 bytes per slot, all requested now, in registers for good
         const unsigned mbytes = (unsigned)(a.ws_points * 32);
         const unsigned mvoff = in ? (unsigned)((2 * mw + g) * 16) : 0xfffffff0u;

@@ -314,7 +314,11 @@ enum : int { EPI_RELU = 0, EPI_TANH = 1, EPI_HEAD_TANH = 2, EPI_HEAD_SIGMOID = 3
 //   operand) — the opt-in 16-bit-native TRAINING forward (BASELINE.json configs[2], "bf16 MFMA MLPs" as written; f16 has three
 //   more bits at the same matrix rate and the range guard covers its exponent range).  Same pack: only the hi planes and the
 //   bias block of a chunk are fetched.  Outside the 1e-4 contract by construction; never the default.
-enum : int { M16_FEAT = 1, M16_RENDER = 2, M16_TRAIN = 4, M16_BLKOUT = 8, M16_BLKIN = 16, M16_C2 = 32, M16_P1 = 64,
+// M16_SF16 (training modes): the ReLU slots are f16 in FRAGMENT ORDER — the default storage — as a compile-time fact.  The stores of a tile
+// then are four straight-line instructions with constant scalar offsets; with the storage form read from the Pipe at run time every register
+// quad of every tile went through two or three uniform branches (f16? fragment order?): ~1 500 branches in the vector-only kernel, four
+// basic-block boundaries per K step that no instruction could be scheduled across (round 5; the saving forward's "cost of the stores").
+enum : int { M16_FEAT = 1, M16_RENDER = 2, M16_TRAIN = 4, M16_BLKOUT = 8, M16_BLKIN = 16, M16_C2 = 32, M16_P1 = 64, M16_SF16 = 128,
              M16_VF_VEC = 0, M16_FUSED = M16_FEAT | M16_RENDER, M16_VF_BLK = M16_FEAT | M16_BLKOUT, M16_RN_BLK = M16_RENDER | M16_BLKIN,
              M16_VF_VEC_TRAIN = M16_TRAIN, M16_VF_FULL_TRAIN = M16_FEAT | M16_TRAIN, M16_FUSED_TRAIN = M16_FUSED | M16_TRAIN };
 
@@ -572,12 +576,19 @@ __device__ __forceinline__ void epi_pair(f32x16& pend, unsigned long long& sat, 
 
 // Training: registers 4q..4q+3 of a finished tile = 4 consecutive columns (32 TILE + 8 q + 4 (lane >> 5)) of this lane's
 // point -> one 16-byte buffer store into slot SLOT (rows beyond M are dropped by the range check).
-template <int SLOT, int TILE>
+template <int SLOT, int TILE, bool SF16 = false>
 __device__ __forceinline__ void save_group(const Pipe16& p, const f32x16& v, int q) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.saved + (long long)SLOT * p.slot_floats, 0,
                                                                         (int)p.slot_bytes, 0x00020000);
     const f32x4v g = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    if constexpr (SF16 && SLOT != 8) {   // f16 values, fragment order (2048 B per tile, 512 B per register quad): no run-time form
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const half4 h = __builtin_convertvector(g, half4);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rs, (int)p.save_voff16, (TILE * 4096 + q * 1024) / 2, VFN16_SAVE_AUX);
+        return;
+    }
 #if defined(ABL_SAVE_COALESCED)
     // timing only (WRONG layout): the same bytes as one 1-KiB run per instruction, to price the row-major store pattern
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g), rs, (int)(((p.save_voff >> 15) << 15) + (threadIdx.x & 63) * 16),
@@ -610,9 +621,12 @@ __device__ __forceinline__ void collect_mask(Carry16& cy) {
     if constexpr (EPI == EPI_RELU) {      // values are >= +0 here: positive <=> a non-zero bit pattern (two VALU ops per value)
         typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
         const u32x16 u = __builtin_bit_cast(u32x16, cy.pend);
+        // (two VALU instructions per value; from `min(u, 1) << r` hipcc made v_cmp_class + v_cndmask + v_or3 through an SGPR pair per value,
+        //  with the wait states that hazard costs — 55 issue slots per tile instead of 32)
+        // u + 0x7fffffff has its top bit set exactly for u != 0 (u < 0x7f800000 here); a funnel shift moves it into the word: b = b << 1 | top
         unsigned b = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) b |= min(u[r], 1u) << r;
+        for (int r = 15; r >= 0; --r) b = __builtin_amdgcn_alignbit(b, u[r] + 0x7fffffffu, 31);
         cy.lm[TILE >> 1] |= b << (16 * (TILE & 1));
     }                                     // the tanh'ed feature block has no mask: the chain reads its values
 }
@@ -796,8 +810,8 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
 #endif
 #pragma unroll
                 for (int q = (st - SBEG) * 4 / SSTEPS; q < (st - SBEG + 1) * 4 / SSTEPS; ++q) {
-                    if (ch > 0) save_group<(SLOT >= 0 ? SLOT : 0), (ch > 0 ? ch - 1 : 0)>(p, cy.pend, q);
-                    else save_group<(PSLOT >= 0 ? PSLOT : 0), PKB / 2>(p, cy.pend, q);
+                    if (ch > 0) save_group<(SLOT >= 0 ? SLOT : 0), (ch > 0 ? ch - 1 : 0), (MODE & M16_SF16) != 0>(p, cy.pend, q);
+                    else save_group<(PSLOT >= 0 ? PSLOT : 0), PKB / 2, (MODE & M16_SF16) != 0>(p, cy.pend, q);
                 }
             }
             // -- split launches: a finished feature tile leaves as operand blocks, after the hand-over like the stores above
@@ -1406,7 +1420,9 @@ extern "C" int vfn_vf_mlp16_fwd_train_at(const vfn_net_geom* geom, const void* p
         VFN_REQUIRE(!with_features, "vfn_vf_mlp16_fwd_train: the single-product forward computes the vector columns only");
         hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_VEC_TRAIN | M16_P1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     }
+    else if (with_features && (save_f16 & 3) == 3) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_FULL_TRAIN | M16_SF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else if (with_features) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_FULL_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else if ((save_f16 & 3) == 3) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_VEC_TRAIN | M16_SF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);   // the default storages
     else hipLaunchKernelGGL(vfn_mlp16_kernel<M16_VF_VEC_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_mlp16_fwd_train");
 }
@@ -1467,6 +1483,7 @@ int vfn_internal_fused16_fwd_train_at(const vfn_net_geom* vf_geom, const void* v
     VFN_REQUIRE(colour_products >= 1 && colour_products <= 3, "vfn_vf_render_fused16_fwd_train: colour_products must be 1, 2 or 3 (got %d)", colour_products);
     if (colour_products == 1) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED_TRAIN | M16_P1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);   // one product EVERYWHERE
     else if (colour_products == 2) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED_TRAIN | M16_C2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else if ((save_f16 & 3) == 3) hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED_TRAIN | M16_SF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(vfn_mlp16_kernel<M16_FUSED_TRAIN>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return vfn_check_launch("vfn_vf_render_fused16_fwd_train");
 }
