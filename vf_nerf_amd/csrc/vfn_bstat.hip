@@ -438,6 +438,74 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
             znext[r] = (lr < live && col < a.stats_ld) ? zp0[lr * a.ldzp] : 0.f;
         }
     };
+    // FAST epilogue (round 5): a wave whose 32 rows and whose NCOL columns all exist, no activation — every 256-wide layer product of a
+    // training-mode step.  C leaves through range-checked buffer stores whose per-lane offsets are computed ONCE (16 registers: the
+    // accumulator rows; the tile's column block rides in the instruction's immediate offset), the previous layer's z arrives the same way.
+    // The general path below guards every one of a lane's 128 values with its own row / column test and forms a 64-bit address for it:
+    // ~2 000 instructions and 250 divergent branches per wave, half the life of a workgroup (profiles/r04/linear_rows_microbench.txt
+    // took that for store bandwidth).
+    const bool whole = live == 32 && n0 + NCOL <= a.n_out && a.act == ACT_NONE;
+    if (whole && (!SUMS || !a.stats_part || n0 + NCOL <= a.stats_ld)) {
+        const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(a.c + (size_t)row0 * a.ldc, 0, (int)(32u * (unsigned)a.ldc * 4u), 0x00020000);
+        unsigned voff[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) voff[r] = ((unsigned)((r & 3) + 8 * (r >> 2) + 4 * g) * (unsigned)a.ldc + (unsigned)(n0 + c)) * 4u;
+        if constexpr (SUMS) {
+            if (a.stats_part) {
+                const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.zp) + (size_t)row0 * a.ldzp, 0,
+                                                                                      (int)(32u * (unsigned)a.ldzp * 4u), 0x00020000);
+                unsigned zoff[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zoff[r] = ((unsigned)((r & 3) + 8 * (r >> 2) + 4 * g) * (unsigned)a.ldzp + (unsigned)(n0 + c)) * 4u;
+                float zq[2][16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zq[0][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_z, zoff[r], 0, 0));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int col = n0 + 32 * j + c;
+                    const float sc = a.coef_p[col], sh = a.coef_p[a.stats_ld + col], mean = a.coef_p[2 * a.stats_ld + col], rstd = a.coef_p[3 * a.stats_ld + col];
+                    if (j + 1 < NT) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            zq[(j + 1) & 1][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_z, zoff[r] + 128u * (unsigned)(j + 1), 0, 0));
+                    }
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[j][r] * (1.0f / A_SCALE);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_c, voff[r] + 128u * (unsigned)j, 0, 2);
+                        const float z = zq[j & 1][r];
+                        const float g1 = fmaf(z, sc, sh) > 0.f ? a.post_p * v : 0.f;
+                        s1 += g1;
+                        s2 += g1 * ((z - mean) * rstd);
+                    }
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    if (g == 0) { s_red[0][wave][32 * j + c] = s1; s_red[1][wave][32 * j + c] = s2; }
+                }
+            }
+        }
+        if (!SUMS || !a.stats_part) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = n0 + 32 * j + c;
+                const float b = a.bias ? a.bias[col] : 0.f;
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float z = acc[j][r] * (1.0f / A_SCALE) + b;
+                    s1 += z;
+                    s2 += z * z;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, z), rs_c, voff[r] + 128u * (unsigned)j, 0, 2);
+                }
+                if (a.stats_part) {
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    if (g == 0) { s_red[0][wave][32 * j + c] = s1; s_red[1][wave][32 * j + c] = s2; }
+                }
+            }
+        }
+    } else {
     if constexpr (SUMS) {
         if (a.stats_part) fetch_z(0);
     }
@@ -494,6 +562,7 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
             if (g == 0) { s_red[0][wave][32 * j + c] = s1; s_red[1][wave][32 * j + c] = s2; }
         }
     }
+    }       // (general epilogue)
     if (a.stats_part) {
         __syncthreads();
         for (int i = tid; i < 2 * NCOL; i += 256) {

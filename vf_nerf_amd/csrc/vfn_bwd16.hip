@@ -274,13 +274,16 @@ __device__ __forceinline__ float tile_scale(const f32x16& v, int& b, bool live =
     // lane left as "all zero".  Its values now leave as NaN under byte 239 (which does not move the slab's common scale), so the weight
     // gradients they enter come out non-finite as the reference's fp32 products would.  (Lanes past the last point may hold anything;
     // their byte is 255 and the consumer zeroes them.)
+    // Bit arithmetic, no selects: as `if (biased == 255) return ...` — and as ternaries alike — hipcc made divergent (EXEC-masked) blocks of
+    // it in the middle of every chunk's K loop.  zm / im: all ones when the lane's maximum is zero (or subnormal) / non-finite.
     const int biased = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu);
-    if (biased == 255) {
-        b = live ? 239 : 255;
-        return live ? __builtin_bit_cast(float, 0x7fc00000u) : 0.f;
-    }
-    b = biased == 0 ? 255 : min(254 - biased, 239);       // k + 113: every normal fp32 magnitude has its byte (below 2^-112 the scale saturates)
-    return biased == 0 ? 0.f : __builtin_bit_cast(float, (unsigned)(b + 14) << 23);
+    const int bn = min(254 - biased, 239);                 // k + 113: every normal fp32 magnitude has its byte (below 2^-112 the scale saturates)
+    const int zm = (biased - 1) >> 31, im = (254 - biased) >> 31;
+    const int b_fin = bn | (zm & 255);                                      // zero -> 255 ("all zero")
+    const int s_fin = (int)((unsigned)(bn + 14) << 23) & ~zm;               // zero -> scale 0
+    const int b_inf = live ? 239 : 255, s_inf = live ? 0x7fc00000 : 0;      // (uniform per lane for the whole launch)
+    b = (b_fin & ~im) | (b_inf & im);
+    return __builtin_bit_cast(float, (s_fin & ~im) | (s_inf & im));
 }
 template <int SLOT, int TILE>
 __device__ __forceinline__ void store_group(const Pipe& p, const f32x16& v, int q, float scale = 1.0f) {

@@ -795,7 +795,12 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
 #pragma unroll
                 for (int i = (st - H) * PM / DST; i < (st - H + 1) * PM / DST; ++i) {
                     if (VFN16_WAVES * i + VFN16_WAVES <= DPIECES) dma_piece<ddma.net, ddma.off_kb, slot_base(MODE, C + RING - 1)>(p, piece_blk(wave + VFN16_WAVES * i), lane, P1 ? wave + VFN16_WAVES * i : -1);
-                    else if (VFN16_WAVES * i < DPIECES) { if (wave + VFN16_WAVES * i < DPIECES) dma_piece<ddma.net, ddma.off_kb, slot_base(MODE, C + RING - 1)>(p, piece_blk(wave + VFN16_WAVES * i), lane, P1 ? wave + VFN16_WAVES * i : -1); }
+                    else if (VFN16_WAVES * i < DPIECES) {
+                        // the last, partial round of pieces (a 33-block chunk: its bias block): EVERY wave issues one — the waves past the end
+                        // repeat the last piece (same bytes, same place) — instead of a uniform branch in the middle of this K step
+                        const int idx = min(wave + VFN16_WAVES * i, DPIECES - 1);
+                        dma_piece<ddma.net, ddma.off_kb, slot_base(MODE, C + RING - 1)>(p, piece_blk(idx), lane, P1 ? idx : -1);
+                    }
                 }
             }
 #endif
