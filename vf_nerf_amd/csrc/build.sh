@@ -60,7 +60,7 @@ fi
 spilled=$(python3 - "$OBJDIR" <<'PY'
 import re, sys, os
 bad = []
-for unit in ("vfn_mlp16", "vfn_bwd16", "vfn_dwf", "vfn_dw16"):
+for unit in ("vfn_mlp16", "vfn_bwd16", "vfn_dwf", "vfn_dw16", "vfn_bstat"):
     path = os.path.join(sys.argv[1], unit + ".remarks")
     name = None
     for line in open(path, errors="replace"):

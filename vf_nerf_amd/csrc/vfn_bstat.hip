@@ -359,9 +359,16 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
 
     fetch_w(0);
     fetch_a(0);
-    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, t_prev = a.probe ? __builtin_amdgcn_s_memtime() : 0;
+    // The phase probe is a BUILD option (tools/build_unit_variant.sh probe vfn_bstat -DVFN_GEMM_PROBE_BUILD, then VFN_GEMM_PROBE=1): as a
+    // run-time switch its seven uniform branches cut every iteration of the chunk loop into seven scheduling regions (round 5).
+#ifdef VFN_GEMM_PROBE_BUILD
+    constexpr bool PROBE = true;
+#else
+    constexpr bool PROBE = false;
+#endif
+    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, t_prev = (PROBE && a.probe) ? __builtin_amdgcn_s_memtime() : 0;
     auto mark = [&](int which) {
-        if (a.probe) {
+        if (PROBE && a.probe) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             ph[which] += t - t_prev;
             t_prev = t;
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
     for (int kc = 0; kc < a.k_pad; kc += GM_KC) {
         __syncthreads();               // every wave is done with the previous chunk
         mark(0);
-        if (a.probe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mark(1); }
+        if (PROBE && a.probe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mark(1); }
         stage_w();
         stage_a();
         mark(2);
@@ -383,7 +390,10 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
         // and the eight-tile forms have no registers for the extra fragments.)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            if (kc + 16 * ks >= a.k_pad) break;
+            // (no early exit for a chunk that holds 16 k or fewer: A beyond k_pad is staged as zeros — out-of-range loads — and the branch
+            //  kept the second K-block's operand split from being scheduled under the first one's matrix instructions)
+            // (the bf16 forms keep three operand planes per K-block: with both blocks' splits in flight they spill — fenced apart)
+            if constexpr (ARITH != 0) __builtin_amdgcn_sched_barrier(0);
             const float* ap = s_a + (32 * wave + c) * A_LD + 16 * ks + 8 * g;
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
             u16x8 ah, am, al;
@@ -447,19 +457,20 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
     const bool whole = live == 32 && n0 + NCOL <= a.n_out && a.act == ACT_NONE;
     if (whole && (!SUMS || !a.stats_part || n0 + NCOL <= a.stats_ld)) {
         const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(a.c + (size_t)row0 * a.ldc, 0, (int)(32u * (unsigned)a.ldc * 4u), 0x00020000);
-        unsigned voff[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) voff[r] = ((unsigned)((r & 3) + 8 * (r >> 2) + 4 * g) * (unsigned)a.ldc + (unsigned)(n0 + c)) * 4u;
+        // (per lane: its column and the 4 g rows; the accumulator's row — uniform — rides in the scalar offset, the tile's column block in the
+        //  immediate: no register per row.  A buffer's range check does not see the scalar offset: it is not needed, the wave's 32 rows exist.)
+        const unsigned vbase = ((unsigned)(4 * g) * (unsigned)a.ldc + (unsigned)(n0 + c)) * 4u;
+        const unsigned ldc4 = (unsigned)a.ldc * 4u;
+        auto srow = [](int r) -> unsigned { return (unsigned)((r & 3) + 8 * (r >> 2)); };
         if constexpr (SUMS) {
             if (a.stats_part) {
                 const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.zp) + (size_t)row0 * a.ldzp, 0,
                                                                                       (int)(32u * (unsigned)a.ldzp * 4u), 0x00020000);
-                unsigned zoff[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) zoff[r] = ((unsigned)((r & 3) + 8 * (r >> 2) + 4 * g) * (unsigned)a.ldzp + (unsigned)(n0 + c)) * 4u;
+                const unsigned zbase = ((unsigned)(4 * g) * (unsigned)a.ldzp + (unsigned)(n0 + c)) * 4u;
+                const unsigned ldz4 = (unsigned)a.ldzp * 4u;
                 float zq[2][16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) zq[0][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_z, zoff[r], 0, 0));
+                for (int r = 0; r < 16; ++r) zq[0][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_z, zbase, srow(r) * ldz4, 0));
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int col = n0 + 32 * j + c;
@@ -467,13 +478,13 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
                     if (j + 1 < NT) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            zq[(j + 1) & 1][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_z, zoff[r] + 128u * (unsigned)(j + 1), 0, 0));
+                            zq[(j + 1) & 1][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_z, zbase + 128u * (unsigned)(j + 1), srow(r) * ldz4, 0));
                     }
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float v = acc[j][r] * (1.0f / A_SCALE);
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_c, voff[r] + 128u * (unsigned)j, 0, 2);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_c, vbase + 128u * (unsigned)j, srow(r) * ldc4, 2);
                         const float z = zq[j & 1][r];
                         const float g1 = fmaf(z, sc, sh) > 0.f ? a.post_p * v : 0.f;
                         s1 += g1;
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
                     const float z = acc[j][r] * (1.0f / A_SCALE) + b;
                     s1 += z;
                     s2 += z * z;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, z), rs_c, voff[r] + 128u * (unsigned)j, 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, z), rs_c, vbase + 128u * (unsigned)j, srow(r) * ldc4, 2);
                 }
                 if (a.stats_part) {
                     s1 += __shfl_xor(s1, 32, 64);
@@ -579,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
         // kernels report a saturated activation (vfn_f16x3_set_status): the facade's range guard then moves the model to the exact products.
         if (a.status && !(a_max < 1023.0f)) atomicOr(a.status, 1u);         // (also true for NaN)
     }
-    if (a.probe && tid == 0 && rb < 4096) {
+    if (PROBE && a.probe && tid == 0 && rb < 4096) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         mark(6);          // (the epilogue)
 #pragma unroll
@@ -592,7 +603,11 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
 // This is what showed the launch to be bound by its HBM streams (profiles/r04/linear_rows_microbench.txt).
 constexpr unsigned PROBE_BLOCKS = 4096;
 unsigned long long* gemm_probe_buffer(hipStream_t s) {
+    #ifdef VFN_GEMM_PROBE_BUILD
     static const bool on = getenv("VFN_GEMM_PROBE") != nullptr;
+#else
+    static const bool on = false;
+#endif
     static unsigned long long* buf = nullptr;
     if (!on) return nullptr;
     if (!buf && hipMalloc(&buf, PROBE_BLOCKS * 8 * sizeof(unsigned long long)) != hipSuccess) return nullptr;

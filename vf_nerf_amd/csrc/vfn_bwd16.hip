@@ -566,6 +566,9 @@ __device__ __forceinline__ void step16(const X16& xin, X16& xout, X16& xpend, Ca
                 }
             }
 #endif
+            // (Explicit instruction groups here — one MFMA, then n VALU instructions in its shadow, as the forward kernel's K steps have them —
+            //  were measured in round 5 with n = 6, 8, 12: the vector-only chain within 0.5 % of the compiler's own order, the fused one 1-3 %
+            //  slower.  Not the lever.)
             __builtin_amdgcn_sched_barrier(0);
         }
         cy.pend = acc;
