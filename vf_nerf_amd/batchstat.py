@@ -107,6 +107,15 @@ def running_stats_restore(snap) -> None:
         net._invalidate_packs()
 
 
+def _padded(m: int, n: int, width: int, dev) -> torch.Tensor:
+    """An [m, width] matrix whose columns [n, width) are zero and whose first n columns the caller's kernel writes in full: only the pad
+    columns are cleared (a whole-matrix fill is a 0.6 GB write at 524 288 rows, ~1.2 ms of a training-mode step over all layers)."""
+    t = torch.empty(m, width, device=dev)
+    if width > n:
+        t[:, n:].zero_()
+    return t
+
+
 def _split(net) -> bool:
     """Split-operand products on the 16-bit matrix cores?  Not when the facade asks for the exact kernels (``model.precision = "fp32"``,
     also what the range guard switches to) or the net itself does (``net.gemm_arithmetic = "fp32"``)."""
@@ -130,11 +139,12 @@ def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, upda
     L = net.num_layers
     skip = net._skip_layer()
     x = x0
+    counted = []              # the BatchNorm layers' batch counters: advanced in ONE launch at the end (a launch each was 5 us x 32 per step)
     for i in range(L - 1):
         lin, bn = net._linear(i), net._bn(i)
         n, k = lin.out_features, lin.in_features
         st.x.append(x)
-        z = torch.empty(m, _up8(n), device=dev) if n % 8 == 0 else torch.zeros(m, _up8(n), device=dev)
+        z = _padded(m, n, _up8(n), dev)
         if batch_stats:
             parts = lib.linear_rows_stat_parts(m)
             part = torch.empty(parts, 2, n, device=dev)
@@ -145,7 +155,7 @@ def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, upda
             lib.bstat_finalize(sums, m, n, bn.weight.detach(), bn.bias.detach(), BN_EPS, BN_MOMENTUM,
                                bn.running_mean if update_running else None, bn.running_var if update_running else None, coef)
             if update_running:
-                bn.num_batches_tracked += 1
+                counted.append(bn.num_batches_tracked)
         else:
             lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, arith=_arith(net, False, i == 0 or i == skip))
             coef = _running_coef(bn)
@@ -153,17 +163,19 @@ def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, upda
         st.coef.append(coef)
         nxt_k = net._linear(i + 1).in_features
         if i + 1 == skip:        # next input = cat([h, pe]) / sqrt(2)  (vector_field_network.py:192-193)
-            x = torch.zeros(m, _up8(nxt_k), device=dev)
+            x = _padded(m, nxt_k, _up8(nxt_k), dev)      # (columns [0, n) by the row pass, [n, nxt_k) by fill_skip)
             lib.bstat_relu_rows(z, coef, m, n, INV_SQRT2, x)
             fill_skip(Cols(x, n), INV_SQRT2)
         else:
-            x = torch.empty(m, _up8(nxt_k), device=dev) if (nxt_k % 8 == 0 and nxt_k == n) else torch.zeros(m, _up8(nxt_k), device=dev)
+            x = _padded(m, n, _up8(nxt_k), dev)          # (the row pass writes columns [0, n))
             lib.bstat_relu_rows(z, coef, m, n, 1.0, x)
     last = net._linear(L - 1)
     st.x.append(x)
-    y = torch.zeros(m, _up8(last.out_features), device=dev)
+    y = _padded(m, last.out_features, _up8(last.out_features), dev)
     lib.linear_rows(x, last.weight.detach(), last.bias.detach(), m, last.out_features, last.in_features, y, act=final_act, arith=_arith(net, False, L == 1))
     st.y = y
+    if counted:
+        torch._foreach_add_(counted, 1)
     if batch_stats and update_running:
         # vfn_bstat_finalize advanced running_mean / running_var through raw pointers: their _version did not move, so the
         # folded-BatchNorm packs keyed on (data_ptr, _version) would survive into a later eval()/render() with stale statistics
@@ -281,7 +293,7 @@ def _backward(net, st: _State, dz_last: torch.Tensor, pg: Optional[_ParamGrads],
             pg.linear(i, dz, st.x[i])
         if i == 0 and not want_dx0:
             return None, skip_piece
-        g = torch.zeros(m, _up8(k), device=dev) if k % 8 else torch.empty(m, _up8(k), device=dev)
+        g = _padded(m, k, _up8(k), dev)
         if i == 0:
             lib.linear_rows(dz, lin.weight.detach(), None, m, k, n, g, transpose_w=True, arith=_arith(net, True))      # dX = dZ W
             return g, skip_piece
@@ -306,10 +318,8 @@ def _backward(net, st: _State, dz_last: torch.Tensor, pg: Optional[_ParamGrads],
         lib.colsum_finish(part, parts, 2 * n_prev, sums)
         if pg is not None:
             pg.batchnorm(i - 1, sums)
-        if 192 < n_prev < 256 and _split(net):
-            dz = torch.zeros(m, 256, device=dev)          # (zero pad columns up to 256: the bf16 weight-gradient product reads whole blocks)
-        else:
-            dz = torch.zeros(m, _up8(n_prev), device=dev) if n_prev % 8 else torch.empty(m, _up8(n_prev), device=dev)
+        # (zero pad columns — up to 256 where the bf16 weight-gradient product reads whole blocks)
+        dz = _padded(m, n_prev, 256 if (192 < n_prev < 256 and _split(net)) else _up8(n_prev), dev)
         # batch statistics: dz = gamma rstd (g' - mean g' - x_hat mean(g' x_hat)); running statistics: dz = gamma rstd g'
         lib.bstat_relu_bwd_rows(g, z, coef, sums if st.batch_stats else torch.zeros_like(sums), m, n_prev, post, dz)
     raise AssertionError("unreachable")
