@@ -630,6 +630,20 @@ __device__ __forceinline__ void collect_mask(Carry16& cy) {
         cy.lm[TILE >> 1] |= b << (16 * (TILE & 1));
     }                                     // the tanh'ed feature block has no mask: the chain reads its values
 }
+// ... in PARTS pieces over as many K steps (16 / PARTS values each, highest registers first; `b` is carried by the caller): the whole
+// collection in ONE step was 32 VALU instructions between three matrix instructions that cover 24
+template <int TILE, int EPI, int PART, int PARTS>
+__device__ __forceinline__ void collect_mask_part(Carry16& cy, unsigned& b) {
+    if constexpr (EPI == EPI_RELU) {
+        typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
+        const u32x16 u = __builtin_bit_cast(u32x16, cy.pend);
+        constexpr int N = 16 / PARTS;
+        if constexpr (PART == 0) b = 0;
+#pragma unroll
+        for (int r = 15 - PART * N; r > 15 - (PART + 1) * N; --r) b = __builtin_amdgcn_alignbit(b, u[r] + 0x7fffffffu, 31);
+        if constexpr (PART == PARTS - 1) cy.lm[TILE >> 1] |= b << (16 * (TILE & 1));
+    }
+}
 template <int SLOT>
 __device__ __forceinline__ void store_mask(const Pipe16& p, Carry16& cy) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -686,6 +700,9 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
     constexpr int SBEG = LATE ? DEND : H;
     constexpr int SSTEPS = LATE ? (NKB - DEND > 0 ? NKB - DEND : 1) : (DSPAN < 4 ? DSPAN : 4);      // steps that carry the 4 stores of a tile
     constexpr int DST = LATE ? (DEND - H > 0 ? DEND - H : 1) : DSTEPS;                             // steps that carry DMA pieces
+    // late stores: the sign-bit collection of the pending tile in MPARTS pieces over the steps [H, H + MPARTS) in front of its stores
+    // (the epilogue pairs are done by step E <= H; 0: in one piece at the first store step)
+    constexpr int MPARTS = (LATE && E <= H) ? (DEND - H >= 4 ? 4 : (DEND - H >= 2 ? 2 : (DEND - H >= 1 ? 1 : 0))) : 0;
     static_for<NCH>([&](auto ich) {
         constexpr int ch = decltype(ich)::value;
         constexpr int C = C0 + ch;
@@ -715,6 +732,7 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
             if (!W2 && !P1) fl[1] = __builtin_bit_cast(half8, cb[3 * 64 + lane]);
         }
         half8 ehi[2], elo[2];
+        [[maybe_unused]] unsigned mbits = 0;
 #pragma unroll
         for (int st = 0; st < NKB; ++st) {
             constexpr int AHEAD = VFN16_FDEPTH - 1;
@@ -806,11 +824,27 @@ __device__ __forceinline__ void layer16(const X16& xin, const A16& aux, X16& xou
 #endif
             // -- training: the finished (activated) pending tile goes out after the hand-over, so that the stores have
             // half a chunk to retire before the next vmcnt(0)
+#ifndef ABL_NOMASK
+            // (late stores: the pending tile's sign bits are collected in the DMA steps, a quarter per step, ahead of its stores)
+            if (TRAIN && MPARTS > 0 && st >= H && st < H + MPARTS && (ch > 0 || PEPI >= 0)) {
+                static_for<MPARTS>([&](auto ip) {
+                    constexpr int part = decltype(ip)::value;
+                    if (st - H == part) {
+                        if (ch > 0) collect_mask_part<(ch > 0 ? ch - 1 : 0), EPI, part, (MPARTS > 0 ? MPARTS : 1)>(cy, mbits);
+                        else collect_mask_part<PKB / 2, (PEPI >= 0 ? PEPI : 0), part, (MPARTS > 0 ? MPARTS : 1)>(cy, mbits);
+                    }
+                });
+            }
+#endif
             if (TRAIN && st >= SBEG && st < SBEG + SSTEPS && (ch > 0 || PEPI >= 0)) {
 #ifndef ABL_NOMASK
                 if (st == (LATE ? SBEG : VFN16_MASK_STEP(H, NKB))) {       // its sign bits; the pending tile (ch == 0) is the last one of the previous layer
-                    if (ch > 0) collect_mask<(ch > 0 ? ch - 1 : 0), EPI>(cy);
-                    else { collect_mask<PKB / 2, (PEPI >= 0 ? PEPI : 0)>(cy); store_mask<(PSLOT >= 0 ? PSLOT : 0)>(p, cy); }
+                    if constexpr (MPARTS > 0) {
+                        if (ch == 0) store_mask<(PSLOT >= 0 ? PSLOT : 0)>(p, cy);
+                    } else {
+                        if (ch > 0) collect_mask<(ch > 0 ? ch - 1 : 0), EPI>(cy);
+                        else { collect_mask<PKB / 2, (PEPI >= 0 ? PEPI : 0)>(cy); store_mask<(PSLOT >= 0 ? PSLOT : 0)>(p, cy); }
+                    }
                 }
 #endif
 #pragma unroll
