@@ -912,8 +912,9 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": train_dtype_label(model) if not model.vector_field_network.training else
-           ("f16x3 forward products + bf16 in three parts (six products) dX + bf16x3 dW; f32 accumulate and fp32 activations in HBM"
-            if getattr(model.vector_field_network, "gemm_arithmetic", "split") == "split" else "f32 (exact fp32 matrix instruction)"),
+           ({"split": "f16x3 forward products + bf16x3 dX + bf16x3 dW; f32 accumulate and fp32 activations in HBM",
+             "split24": "f16x3 forward products + bf16 in three parts (six products) dX + bf16x3 dW; f32 accumulate and fp32 activations in HBM"}
+            .get(getattr(model.vector_field_network, "gemm_arithmetic", "split"), "f32 (exact fp32 matrix instruction)")),
            "data": "synthetic", "final_loss": round(float(loss), 5), "per_rank_rays_per_s": rates,
            "bucket_allreduce_ms": round(bucket_ms, 4) if bucket_ms is not None else None,
            "bucket_elements": bucket.numel() if bucket is not None else None,

@@ -53,9 +53,10 @@ def test_linear_rows_against_float64(m, k, n, transpose, arith):
         assert float((c2.cpu()[:, :n].double() - 1e-6 * z).abs().max()) <= tol * 1e-6 * max(1.0, float(z.abs().max()))
 
 
+@pytest.mark.parametrize("arith", [lib.GEMM_SPLIT_BF16, lib.GEMM_BF16X6], ids=["bf16x3", "bf16x6"])
 @pytest.mark.parametrize("m,k_out,n,n_prev", [(4096, 256, 256, 256), (4096, 259 + 5, 259, 256), (5000, 295, 256, 217), (4096, 256, 256, 217),
                                               (130, 256, 256, 64), (1, 289, 256, 256)])
-def test_dx_product_with_the_batchnorm_backward_sums(m, k_out, n, n_prev):
+def test_dx_product_with_the_batchnorm_backward_sums(m, k_out, n, n_prev, arith):
     """vfn_linear_rows_dx_sums: C = dZ W bit-identical to vfn_linear_rows (the same kernel body), and the two column sums of the previous
     layer's BatchNorm backward, taken from C in registers, equal the pass of their own (vfn_bstat_relu_bwd_sums) and float64 within 1e-6
     of the largest sum (fp32 partial sums of 128 / 64 rows, finished in double by both).  Shapes: a hidden layer, the last Linear
@@ -71,7 +72,7 @@ def test_dx_product_with_the_batchnorm_backward_sums(m, k_out, n, n_prev):
     post = 0.7
     g1 = torch.zeros(m, up8(k_out), device=DEV)
     g2 = torch.zeros_like(g1)
-    lib.linear_rows(dz, w, None, m, k_out, n, g1, transpose_w=True, arith=lib.GEMM_BF16X6)
+    lib.linear_rows(dz, w, None, m, k_out, n, g1, transpose_w=True, arith=arith)
     p1 = lib.bstat_row_parts(m)
     part1 = torch.empty(p1, 2, n_prev, device=DEV)
     lib.bstat_relu_bwd_sums(g1, zp, coef, m, n_prev, post, part1)
@@ -79,7 +80,7 @@ def test_dx_product_with_the_batchnorm_backward_sums(m, k_out, n, n_prev):
     lib.colsum_finish(part1, p1, 2 * n_prev, s1)
     p2 = lib.linear_rows_stat_parts(m)
     part2 = torch.empty(p2, 2, n_prev, device=DEV)
-    lib.linear_rows_dx_sums(dz, w, m, k_out, n, g2, zp, coef, n_prev, post, part2)
+    lib.linear_rows_dx_sums(dz, w, m, k_out, n, g2, zp, coef, n_prev, post, part2, arith=arith)
     s2 = torch.empty(2, n_prev, dtype=torch.float64, device=DEV)
     lib.colsum_finish(part2, p2, 2 * n_prev, s2)
     assert torch.equal(g1, g2)

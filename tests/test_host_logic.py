@@ -618,13 +618,18 @@ def test_training_products_knob_and_what_it_selects():
 
 
 def test_layer_product_arithmetic_follows_precision_and_the_net_knob():
-    """batchstat._arith: split-operand products on the 16-bit matrix cores by default (forward f16x3, backward bf16 in three parts); the exact
-    fp32 matrix instruction when the net asks for it (``gemm_arithmetic = "fp32"``) or the facade does (``precision = "fp32"`` — what the range
+    """batchstat._arith: split-operand products on the 16-bit matrix cores by default (forward f16x3, the first layer on bf16 in three parts,
+    backward three bf16 products — bf16 in three parts with ``gemm_arithmetic = "split24"``); the exact fp32 matrix instruction when the net
+    asks for it (``gemm_arithmetic = "fp32"``) or the facade does (``precision = "fp32"`` — what the range
     guard switches a model to); anything else is refused."""
     import types
     from vf_nerf_amd import batchstat, lib
     net = types.SimpleNamespace()
+    assert batchstat._arith(net, False) == lib.GEMM_SPLIT_F16 and batchstat._arith(net, True) == lib.GEMM_SPLIT_BF16
+    assert batchstat._arith(net, False, first_layer=True) == lib.GEMM_BF16X6
+    net.gemm_arithmetic = "split24"
     assert batchstat._arith(net, False) == lib.GEMM_SPLIT_F16 and batchstat._arith(net, True) == lib.GEMM_BF16X6
+    del net.gemm_arithmetic
     net.precision = "fp32"
     assert batchstat._arith(net, False) == batchstat._arith(net, True) == lib.GEMM_EXACT
     net.precision, net.gemm_arithmetic = "f16x3", "fp32"

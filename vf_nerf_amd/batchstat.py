@@ -76,6 +76,11 @@ def _arith(net, backward: bool, first_layer: bool = False) -> int:
     that at 0.66 ms); the training-mode step 69 ms against 92 ms."""
     if not _split(net):
         return lib.GEMM_EXACT
+    if backward:
+        # Round 5: dX = dZ W on THREE bf16 products (16 significant bits at fp32's exponent range: the arithmetic of the eval-mode dX chain,
+        # csrc/vfn_bwd16.hip) by default; "split24" keeps bf16 in three parts (six products, 24 bits: rounds 4's).  The training-mode gradients
+        # against the oracle: worst 9.5e-5 against 8.4e-5 of a tensor's largest entry (bound 2e-3), the layer product 0.31 against 0.42 ms.
+        return lib.GEMM_BF16X6 if getattr(net, "gemm_arithmetic", "split") == "split24" else lib.GEMM_SPLIT_BF16
     # The FIRST layer (and the skip layer, which re-reads the encoded input) reads raw inputs — coordinates of any scale beside the
     # encodings: its forward product runs in the form with fp32's exponent range too.  Later layers read BatchNorm'ed activations, inside the split f16 form's |x| < 1 023 (the launch reports
     # operands beyond it to the range guard, csrc/vfn_bstat.hip).
@@ -120,9 +125,9 @@ def _split(net) -> bool:
     """Split-operand products on the 16-bit matrix cores?  Not when the facade asks for the exact kernels (``model.precision = "fp32"``,
     also what the range guard switches to) or the net itself does (``net.gemm_arithmetic = "fp32"``)."""
     mode = getattr(net, "gemm_arithmetic", "split")
-    if mode not in ("split", "fp32"):
-        raise ValueError(f"gemm_arithmetic must be 'split' or 'fp32', got {mode!r}")
-    return mode == "split" and getattr(net, "precision", "f16x3") != "fp32"
+    if mode not in ("split", "split24", "fp32"):
+        raise ValueError(f"gemm_arithmetic must be 'split', 'split24' or 'fp32', got {mode!r}")
+    return mode != "fp32" and getattr(net, "precision", "f16x3") != "fp32"
 
 
 def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, update_running: bool = True,
@@ -301,12 +306,12 @@ def _backward(net, st: _State, dz_last: torch.Tensor, pg: Optional[_ParamGrads],
         n_prev = net._linear(i - 1).out_features
         post = INV_SQRT2 if i == skip else 1.0
         z, coef = st.z[i - 1], st.coef[i - 1]
-        if FUSE_BACKWARD_SUMS and _arith(net, True) == lib.GEMM_BF16X6 and n_prev <= 256:
+        if FUSE_BACKWARD_SUMS and _arith(net, True) in (lib.GEMM_SPLIT_BF16, lib.GEMM_BF16X6) and n_prev <= 256:
             # dX = dZ W and, from the product while it is in registers, the two column sums of the BatchNorm backward (the separate pass
             # over g and z that computed them was 16 % of a training-mode step)
             parts = lib.linear_rows_stat_parts(m)
             part = torch.empty(parts, 2, n_prev, device=dev)
-            lib.linear_rows_dx_sums(dz, lin.weight.detach(), m, k, n, g, z, coef, n_prev, post, part)
+            lib.linear_rows_dx_sums(dz, lin.weight.detach(), m, k, n, g, z, coef, n_prev, post, part, arith=_arith(net, True))
         else:
             lib.linear_rows(dz, lin.weight.detach(), None, m, k, n, g, transpose_w=True, arith=_arith(net, True))
             parts = lib.bstat_row_parts(m)

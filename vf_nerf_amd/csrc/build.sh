@@ -18,7 +18,7 @@ extra_flags() {
     vfn_bwd16)  echo "$MFMA16 ${VFN_BWD16_EXTRA:-}" ;;
     vfn_dw16)   echo "${VFN_DW16_EXTRA:-}" ;;
     vfn_rays|vfn_grid) echo "-ffp-contract=off" ;;
-    *) echo "" ;;
+    *) v="VFN_$(echo "${1#vfn_}" | tr a-z A-Z)_EXTRA"; echo "${!v:-}" ;;      # (any other unit: VFN_<UNIT>_EXTRA, e.g. tools/build_unit_variant.sh)
   esac
 }
 

@@ -882,7 +882,8 @@ extern "C" int vfn_linear_rows(int32_t transpose_w, const float* a, int32_t lda,
 
 extern "C" int vfn_linear_rows_dx_sums(const float* dz, int32_t lddz, const float* w, int32_t ldw, int64_t m, int32_t n_out, int32_t k_in, float* c,
                                        int32_t ldc, const float* z_prev, int32_t ldz_prev, const float* coef_prev, int32_t n_prev, float post_prev,
-                                       float* sums_part, void* stream) {
+                                       float* sums_part, int32_t arith, void* stream) {
+    VFN_REQUIRE(arith == 4 || arith == 6, "vfn_linear_rows_dx_sums: arith = %d (4: three bf16 products, 6: bf16 in three parts)", arith);
     VFN_REQUIRE(dz && w && c && z_prev && coef_prev && sums_part, "vfn_linear_rows_dx_sums: NULL argument");
     VFN_REQUIRE(n_out >= 1 && k_in >= 1, "vfn_linear_rows_dx_sums: n_out=%d k_in=%d", n_out, k_in);
     const int k_pad = (k_in + 7) & ~7;
@@ -897,7 +898,8 @@ extern "C" int vfn_linear_rows_dx_sums(const float* dz, int32_t lddz, const floa
     g.a = dz; g.w = w; g.c = c; g.m = m; g.lda = lddz; g.ldw = ldw; g.ldc = ldc;
     g.n_out = n_out; g.k_in = k_in; g.k_pad = k_pad; g.act = ACT_NONE;
     g.stats_part = sums_part; g.stats_ld = n_prev; g.zp = z_prev; g.ldzp = ldz_prev; g.coef_p = coef_prev; g.post_p = post_prev;
-    launch_gemm16<true, 2, true>(g, (hipStream_t)stream);
+    if (arith == 4) launch_gemm16<true, 1, true>(g, (hipStream_t)stream);
+    else launch_gemm16<true, 2, true>(g, (hipStream_t)stream);
     return vfn_check_launch("vfn_linear_rows_dx_sums");
 }
 

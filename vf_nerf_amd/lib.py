@@ -1243,13 +1243,13 @@ def linear_rows(a, w: torch.Tensor, bias, m: int, n_out: int, k_in: int, c, act:
 
 
 def linear_rows_dx_sums(dz, w: torch.Tensor, m: int, n_out: int, k_in: int, c, z_prev, coef_prev: torch.Tensor, n_prev: int, post_prev: float,
-                        part: torch.Tensor) -> None:
-    """C = dZ W (bf16 in three parts) + the per-workgroup partials of the previous layer's BatchNorm-backward column sums, taken from C
+                        part: torch.Tensor, arith: int = 4) -> None:
+    """C = dZ W (``arith``: GEMM_SPLIT_BF16 = three bf16 products, GEMM_BF16X6 = bf16 in three parts) + the per-workgroup partials of the previous layer's BatchNorm-backward column sums, taken from C
     in registers (include/vfn.h, vfn_linear_rows_dx_sums); ``part`` [linear_rows_stat_parts(m), 2, n_prev]."""
     dz, c, z_prev = _cols(dz), _cols(c), _cols(z_prev)
     _check(load().vfn_linear_rows_dx_sums(dz.ptr, C.c_int32(dz.ld), _ptr(w, "w"), C.c_int32(w.shape[1]), C.c_int64(m), C.c_int32(n_out),
                                           C.c_int32(k_in), c.ptr, C.c_int32(c.ld), z_prev.ptr, C.c_int32(z_prev.ld), _ptr(coef_prev, "coef_prev"),
-                                          C.c_int32(n_prev), C.c_float(post_prev), _ptr(part, "part"), _stream()), "vfn_linear_rows_dx_sums")
+                                          C.c_int32(n_prev), C.c_float(post_prev), _ptr(part, "part"), C.c_int32(int(arith)), _stream()), "vfn_linear_rows_dx_sums")
 
 
 def colsum_finish(part: torch.Tensor, n_parts: int, width: int, sums: torch.Tensor) -> None:
