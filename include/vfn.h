@@ -825,6 +825,13 @@ int vfn_train_step_supervision_backward(const vfn_train_step_params* p, const vf
 int vfn_linear_rows(int32_t transpose_w, const float* a, int32_t lda, const float* w, int32_t ldw, const float* bias,
                     int64_t m, int32_t n_out, int32_t k_in, int32_t act, float* c, int32_t ldc, float* stats_part,
                     void* stream);
+/* vfn_linear_rows with a scratch for W's 16-bit planes (vfn_linear_rows_wplanes_bytes(n_out, k_in) bytes, 16-byte aligned; NULL: as
+ * vfn_linear_rows).  The split arithmetics with two planes (transpose_w & 6 = 2, 4) then split W ONCE per call — one small launch in front of
+ * the product — instead of once per workgroup and chunk; same values bit for bit.  The scratch is free again when the call's launches have run. */
+int vfn_linear_rows_ws(int32_t transpose_w, const float* a, int32_t lda, const float* w, int32_t ldw, const float* bias,
+                       int64_t m, int32_t n_out, int32_t k_in, int32_t act, float* c, int32_t ldc, float* stats_part,
+                       void* wplanes, void* stream);
+int64_t vfn_linear_rows_wplanes_bytes(int32_t n_out, int32_t k_in);
 int64_t vfn_linear_rows_stat_parts(int64_t m);
 /* The input-gradient product C[m][n_out] = dZ[m][k_in] W[k_in][n_out] (vfn_linear_rows with transpose_w = 1 | arith; arith = 4: three
  * bf16 products, 16 significant bits at fp32's exponent range — the arithmetic of the eval-mode dX chain, the default since round 5 — or
@@ -832,11 +839,11 @@ int64_t vfn_linear_rows_stat_parts(int64_t m);
  * also leaves, while C is in registers, the per-workgroup partials sums_part[vfn_linear_rows_stat_parts(m)][2][n_prev] of sum g' and
  * sum g' x_hat of the PREVIOUS layer's BatchNorm backward over the first n_prev (<= 256) columns of C — g' = post_prev C [z_prev scale +
  * shift > 0], x_hat = (z_prev - mean) rstd with coef_prev [4][n_prev] = scale, shift, mean, rstd — i.e. what vfn_bstat_relu_bwd_sums
- * computes in a pass of its own; finished by vfn_colsum_finish(sums_part, parts, 2 n_prev).
+ * computes in a pass of its own; finished by vfn_colsum_finish(sums_part, parts, 2 n_prev).  wplanes: as vfn_linear_rows_ws (or NULL).
  * Reference: the autograd of nn.Linear + nn.BatchNorm1d (training) + ReLU, models/vector_field/vector_field_network.py:176-208. */
 int vfn_linear_rows_dx_sums(const float* dz, int32_t lddz, const float* w, int32_t ldw, int64_t m, int32_t n_out, int32_t k_in, float* c,
                             int32_t ldc, const float* z_prev, int32_t ldz_prev, const float* coef_prev, int32_t n_prev, float post_prev,
-                            float* sums_part, int32_t arith, void* stream);
+                            float* sums_part, int32_t arith, void* wplanes, void* stream);
 /* Partials per workgroup of the row-wise kernels below (vfn_bstat_relu_bwd_sums). */
 int64_t vfn_bstat_row_parts(int64_t m);
 /* part[n_parts][width] fp32 -> sums[width] double. */

@@ -53,6 +53,28 @@ def test_linear_rows_against_float64(m, k, n, transpose, arith):
         assert float((c2.cpu()[:, :n].double() - 1e-6 * z).abs().max()) <= tol * 1e-6 * max(1.0, float(z.abs().max()))
 
 
+@pytest.mark.parametrize("arith", [lib.GEMM_SPLIT_F16, lib.GEMM_SPLIT_BF16], ids=["f16x3", "bf16x3"])
+@pytest.mark.parametrize("m,k,n,transpose", [(4096, 256, 256, False), (5000, 256, 256, True), (300, 289, 256, False), (4096, 256, 259, False),
+                                             (1000, 295, 256, True), (130, 39, 256, False), (4096, 256, 512, False)])
+def test_layer_product_with_presplit_weight_planes_is_bit_identical(m, k, n, transpose, arith):
+    """vfn_linear_rows_ws: W split ONCE per call into its 16-bit planes (one small launch) instead of by every workgroup for every chunk —
+    the same operands, hence the same C bit for bit and the same column-sum partials; shapes with ragged rows, a K that is not a whole number
+    of chunks, more than one block of 256 output columns, both orientations of W."""
+    torch.manual_seed(m + k + n)
+    kp = (k + 7) & ~7
+    a = torch.zeros(m, kp, device=DEV)
+    a[:, :k] = torch.randn(m, k, device=DEV) * (1e-4 if transpose else 1.0)
+    w = (torch.randn(k, n, device=DEV) if transpose else torch.randn(n, k, device=DEV)) * 0.1
+    bias = None if transpose else torch.randn(n, device=DEV)
+    ldc = (n + 7) & ~7
+    c1, c2 = torch.zeros(m, ldc, device=DEV), torch.zeros(m, ldc, device=DEV)
+    parts = lib.linear_rows_stat_parts(m)
+    p1, p2 = torch.zeros(parts, 2, n, device=DEV), torch.zeros(parts, 2, n, device=DEV)
+    lib.linear_rows(a, w, bias, m, n, k, c1, transpose_w=transpose, stats_part=p1, arith=arith)
+    lib.linear_rows(a, w, bias, m, n, k, c2, transpose_w=transpose, stats_part=p2, arith=arith, planes=lib.wplanes(n, k, DEV))
+    assert torch.equal(c1, c2) and torch.equal(p1, p2) and float(c1.abs().max()) > 0
+
+
 @pytest.mark.parametrize("arith", [lib.GEMM_SPLIT_BF16, lib.GEMM_BF16X6], ids=["bf16x3", "bf16x6"])
 @pytest.mark.parametrize("m,k_out,n,n_prev", [(4096, 256, 256, 256), (4096, 259 + 5, 259, 256), (5000, 295, 256, 217), (4096, 256, 256, 217),
                                               (130, 256, 256, 64), (1, 289, 256, 256)])
@@ -80,7 +102,8 @@ def test_dx_product_with_the_batchnorm_backward_sums(m, k_out, n, n_prev, arith)
     lib.colsum_finish(part1, p1, 2 * n_prev, s1)
     p2 = lib.linear_rows_stat_parts(m)
     part2 = torch.empty(p2, 2, n_prev, device=DEV)
-    lib.linear_rows_dx_sums(dz, w, m, k_out, n, g2, zp, coef, n_prev, post, part2, arith=arith)
+    lib.linear_rows_dx_sums(dz, w, m, k_out, n, g2, zp, coef, n_prev, post, part2, arith=arith,
+                            planes=lib.wplanes(k_out, n, DEV) if arith == lib.GEMM_SPLIT_BF16 else None)
     s2 = torch.empty(2, n_prev, dtype=torch.float64, device=DEV)
     lib.colsum_finish(part2, p2, 2 * n_prev, s2)
     assert torch.equal(g1, g2)

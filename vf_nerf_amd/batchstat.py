@@ -29,6 +29,7 @@ from .lib import Cols
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 # the BatchNorm backward's column sums from the dX product's registers (VFN_FUSE_BN_SUMS=0: the pass of its own, for A/B runs)
 FUSE_BACKWARD_SUMS = os.environ.get("VFN_FUSE_BN_SUMS", "1") != "0"
+PRESPLIT_W = os.environ.get("VFN_PRESPLIT_W", "1") != "0"      # W's 16-bit planes split once per layer product (vfn_linear_rows_ws) instead of per workgroup
 INV_SQRT2 = 1.0 / math.sqrt(2.0)
 
 
@@ -112,6 +113,11 @@ def running_stats_restore(snap) -> None:
         net._invalidate_packs()
 
 
+def _planes(arith: int, n_out: int, k_in: int, dev):
+    """The scratch for W's pre-split planes (lib.wplanes) where the product's arithmetic has two of them; None otherwise."""
+    return lib.wplanes(n_out, k_in, dev) if (PRESPLIT_W and arith in (lib.GEMM_SPLIT_F16, lib.GEMM_SPLIT_BF16)) else None
+
+
 def _padded(m: int, n: int, width: int, dev) -> torch.Tensor:
     """An [m, width] matrix whose columns [n, width) are zero and whose first n columns the caller's kernel writes in full: only the pad
     columns are cleared (a whole-matrix fill is a 0.6 GB write at 524 288 rows, ~1.2 ms of a training-mode step over all layers)."""
@@ -153,7 +159,8 @@ def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, upda
         if batch_stats:
             parts = lib.linear_rows_stat_parts(m)
             part = torch.empty(parts, 2, n, device=dev)
-            lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, stats_part=part, arith=_arith(net, False, i == 0 or i == skip))
+            ar = _arith(net, False, i == 0 or i == skip)
+            lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, stats_part=part, arith=ar, planes=_planes(ar, n, k, dev))
             sums = torch.empty(2, n, dtype=torch.float64, device=dev)
             lib.colsum_finish(part, parts, 2 * n, sums)
             coef = torch.empty(4, n, device=dev)
@@ -162,7 +169,8 @@ def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, upda
             if update_running:
                 counted.append(bn.num_batches_tracked)
         else:
-            lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, arith=_arith(net, False, i == 0 or i == skip))
+            ar = _arith(net, False, i == 0 or i == skip)
+            lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, arith=ar, planes=_planes(ar, n, k, dev))
             coef = _running_coef(bn)
         st.z.append(z)
         st.coef.append(coef)
@@ -177,7 +185,9 @@ def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, upda
     last = net._linear(L - 1)
     st.x.append(x)
     y = _padded(m, last.out_features, _up8(last.out_features), dev)
-    lib.linear_rows(x, last.weight.detach(), last.bias.detach(), m, last.out_features, last.in_features, y, act=final_act, arith=_arith(net, False, L == 1))
+    ar = _arith(net, False, L == 1)
+    lib.linear_rows(x, last.weight.detach(), last.bias.detach(), m, last.out_features, last.in_features, y, act=final_act, arith=ar,
+                    planes=_planes(ar, last.out_features, last.in_features, dev))
     st.y = y
     if counted:
         torch._foreach_add_(counted, 1)
@@ -300,7 +310,8 @@ def _backward(net, st: _State, dz_last: torch.Tensor, pg: Optional[_ParamGrads],
             return None, skip_piece
         g = _padded(m, k, _up8(k), dev)
         if i == 0:
-            lib.linear_rows(dz, lin.weight.detach(), None, m, k, n, g, transpose_w=True, arith=_arith(net, True))      # dX = dZ W
+            lib.linear_rows(dz, lin.weight.detach(), None, m, k, n, g, transpose_w=True, arith=_arith(net, True),
+                            planes=_planes(_arith(net, True), k, n, dev))                                         # dX = dZ W
             return g, skip_piece
         # BatchNorm + ReLU of layer i-1, whose (scaled) output is columns [0, n_prev) of x[i]
         n_prev = net._linear(i - 1).out_features
@@ -311,9 +322,11 @@ def _backward(net, st: _State, dz_last: torch.Tensor, pg: Optional[_ParamGrads],
             # over g and z that computed them was 16 % of a training-mode step)
             parts = lib.linear_rows_stat_parts(m)
             part = torch.empty(parts, 2, n_prev, device=dev)
-            lib.linear_rows_dx_sums(dz, lin.weight.detach(), m, k, n, g, z, coef, n_prev, post, part, arith=_arith(net, True))
+            lib.linear_rows_dx_sums(dz, lin.weight.detach(), m, k, n, g, z, coef, n_prev, post, part, arith=_arith(net, True),
+                                    planes=_planes(_arith(net, True), k, n, dev))
         else:
-            lib.linear_rows(dz, lin.weight.detach(), None, m, k, n, g, transpose_w=True, arith=_arith(net, True))
+            lib.linear_rows(dz, lin.weight.detach(), None, m, k, n, g, transpose_w=True, arith=_arith(net, True),
+                            planes=_planes(_arith(net, True), k, n, dev))
             parts = lib.bstat_row_parts(m)
             part = torch.empty(parts, 2, n_prev, device=dev)
             lib.bstat_relu_bwd_sums(g, z, coef, m, n_prev, post, part)

@@ -51,6 +51,10 @@ struct GemmArgs {
     float post_p;
     unsigned long long* probe;      // VFN_GEMM_PROBE: per-workgroup cycle counts of the phases of the chunk loop (debug)
     uint32_t* status;               // split f16 form: bit 0 is set when an element of A leaves the range its scaled halves cover (|a| >= 1023)
+    // W split ONCE per call into its two 16-bit planes by vfn_gemm_split_w_kernel (the two-plane arithmetics; caller's scratch): per block of
+    // 256 output columns and chunk of 32 k, [plane hi | mid][256 n][32 k] u16 — what a workgroup stages, in the order it stages it
+    const unsigned short* wp;
+    int wp_chunks;
 };
 
 // TRANS = false: B(k, n) = W[n][k]  (nn.Linear weight, C = A W^T);  TRANS = true: B(k, n) = W[k][n]  (C = A W).
@@ -230,9 +234,12 @@ __device__ __forceinline__ void split3(float v, unsigned short& hi, unsigned sho
 // SUMS (vfn_linear_rows_dx_sums): C is the gradient wrt the previous layer's activated output; the per-block partials of sum g' and
 // sum g' x_hat of that layer's BatchNorm backward (g' = post g [z scale + shift > 0], x_hat = (z - mean) rstd) are taken from C while it is
 // in registers — what vfn_bstat_relu_bwd_sums computes in a pass of its own over g and z (2.3 TB/s, 16 % of a training-mode step).
-template <int NT, bool TRANS, int ARITH, bool SUMS = false>
+// PK: W arrives as pre-split planes (GemmArgs::wp): every workgroup used to fetch all of W as fp32 dwords and split it again — 32 loads and
+// ~300 VALU instructions per thread and chunk, 40 % of a workgroup's cycles (round 5 phase probe) — for values that are the same for all of them.
+template <int NT, bool TRANS, int ARITH, bool SUMS = false, bool PK = false>
 __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArgs a) {
     constexpr bool THREE = ARITH == 2;
+    static_assert(!(PK && THREE), "pre-split planes exist for the two-plane arithmetics");
     constexpr int NCOL = NT * 32;
     constexpr int A_LD = 36;                     // floats per staged A row (32 k + 4): conflict-free 16-byte fragment reads
     __shared__ __attribute__((aligned(16))) unsigned short s_hi[NCOL * GM_LDH];
@@ -332,6 +339,33 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
             if constexpr (THREE) *reinterpret_cast<unsigned*>(s_lo + n * GM_LDH + kk) = (unsigned)l0 | ((unsigned)l1 << 16);
         }
     };
+    // PK: the chunk's two planes as 16-byte pieces (8 k of one column), NCOL * 4 per plane, straight from the planes to LDS rows
+    typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
+    constexpr int WPIECES = PK ? (NCOL * 4 + 255) / 256 : 1;
+    [[maybe_unused]] u32x4p preg[2][WPIECES];
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_wp = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(PK ? a.wp + (size_t)(n0 / 256) * a.wp_chunks * 2 * 8192 : nullptr), 0,
+        PK ? a.wp_chunks * 2 * 8192 * 2 : 0, 0x00020000);
+    [[maybe_unused]] auto fetch_wp = [&](int kc) {
+        const unsigned soff = (unsigned)(kc / GM_KC) * 2u * 8192u * 2u;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int i = 0; i < WPIECES; ++i) {
+                const int q = tid + 256 * i;                    // piece: column q >> 2, k 8 (q & 3) ..
+                preg[pl][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wp, q < NCOL * 4 ? (unsigned)q * 16u : OOB, soff + (unsigned)pl * 8192u * 2u, 0);
+            }
+    };
+    [[maybe_unused]] auto stage_wp = [&]() {
+#pragma unroll
+        for (int i = 0; i < WPIECES; ++i) {
+            const int q = tid + 256 * i;
+            if (q < NCOL * 4) {
+                *reinterpret_cast<u32x4p*>(s_hi + (q >> 2) * GM_LDH + 8 * (q & 3)) = preg[0][i];
+                *reinterpret_cast<u32x4p*>(s_mid + (q >> 2) * GM_LDH + 8 * (q & 3)) = preg[1][i];
+            }
+        }
+    };
     // A: the workgroup's 128 rows x 32 k of a chunk through LDS.  Eight consecutive lanes fetch one row's 128 bytes (whole cache
     // lines; 32 rows per pass, four passes), instead of every lane fetching 32-byte pieces of its own row 1 KiB from its
     // neighbour's — that pattern, not the matrix pipe, bounded the first version of this kernel at 1.6 TB/s.
@@ -357,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
         }
     };
 
-    fetch_w(0);
+    if constexpr (PK) fetch_wp(0); else fetch_w(0);
     fetch_a(0);
     // The phase probe is a BUILD option (tools/build_unit_variant.sh probe vfn_bstat -DVFN_GEMM_PROBE_BUILD, then VFN_GEMM_PROBE=1): as a
     // run-time switch its seven uniform branches cut every iteration of the chunk loop into seven scheduling regions (round 5).
@@ -378,12 +412,15 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
         __syncthreads();               // every wave is done with the previous chunk
         mark(0);
         if (PROBE && a.probe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mark(1); }
-        stage_w();
+        if constexpr (PK) stage_wp(); else stage_w();
         stage_a();
         mark(2);
         __syncthreads();
         mark(3);
-        if (kc + GM_KC < a.k_pad) { fetch_w(kc + GM_KC); fetch_a(kc + GM_KC); }       // in flight underneath this chunk's matrix work
+        if (kc + GM_KC < a.k_pad) {                                                   // in flight underneath this chunk's matrix work
+            if constexpr (PK) fetch_wp(kc + GM_KC); else fetch_w(kc + GM_KC);
+            fetch_a(kc + GM_KC);
+        }
         mark(4);
         // (Hand-pipelining this section — B fragments one tile ahead, the second K-block's A fragment split behind the first's last tile —
         // was tried and bought 2 %: the launch is bound by its HBM streams, see the phase table in profiles/r04/linear_rows_microbench.txt,
@@ -629,16 +666,48 @@ void gemm_probe_report(const GemmArgs& a, unsigned blocks, int trans, int arith,
     free(host);
 }
 
+// W -> its two 16-bit planes, once per call: out[block of 256 columns][chunk of 32 k][plane][256 n][32 k] (zeros past n_out / k_in)
+template <int ARITH>
+__global__ __launch_bounds__(256) void vfn_gemm_split_w_kernel(const float* w, int ldw, int trans, int n_out, int k_in, int chunks, unsigned short* out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;            // one (column, k) of one block and chunk
+    const int k = idx & 31, n = (idx >> 5) & 255, bc = idx >> 13;
+    const int ci = bc % chunks, nb = bc / chunks;
+    const int col = nb * 256 + n, kk = ci * 32 + k;
+    float v = 0.f;
+    if (col < n_out && kk < k_in) v = trans ? w[(size_t)kk * ldw + col] : w[(size_t)col * ldw + kk];
+    unsigned short hi, mid, lo;
+    split3<ARITH>(v, hi, mid, lo);
+    unsigned short* o = out + (size_t)bc * 2 * 8192 + n * 32 + k;
+    o[0] = hi;
+    o[8192] = mid;
+}
+
 template <bool TRANS, int ARITH, bool SUMS = false>
 void launch_gemm16(GemmArgs a, hipStream_t s) {
     a.probe = gemm_probe_buffer(s);
     a.status = ARITH == 0 ? vfn_internal_f16x3_status() : nullptr;
     const unsigned blocks = (unsigned)((a.m + GM_ROWS - 1) / GM_ROWS);
     float* const stats = a.stats_part;
+    if constexpr (ARITH != 2) {
+        if (a.wp) {         // (the caller's scratch: vfn_linear_rows_wplanes_bytes)
+            a.wp_chunks = (a.k_pad + GM_KC - 1) / GM_KC;
+            const int nblocks = (a.n_out + 255) / 256;
+            hipLaunchKernelGGL((vfn_gemm_split_w_kernel<ARITH>), dim3((unsigned)(nblocks * a.wp_chunks * 32)), dim3(256), 0, s, a.w, a.ldw, (int)TRANS,
+                               a.n_out, a.k_in, a.wp_chunks, const_cast<unsigned short*>(a.wp));
+        }
+    } else {
+        a.wp = nullptr;
+    }
     for (int n0 = 0; n0 < a.n_out; n0 += 256) {
         a.n0 = n0;
         if (SUMS) a.stats_part = n0 == 0 ? stats : nullptr;      // the summed columns (<= 256) all sit in the first launch
         const int tiles = (min(a.n_out - n0, 256) + 31) / 32;
+        if constexpr (ARITH != 2) {
+            if (a.wp && tiles > 4) {       // the 256-column launches read the planes; narrower ones split on the fly as before
+                hipLaunchKernelGGL((vfn_linear_rows16_kernel<8, TRANS, ARITH, SUMS, true>), dim3(blocks), dim3(256), 0, s, a);
+                continue;
+            }
+        }
         if (tiles > 4) hipLaunchKernelGGL((vfn_linear_rows16_kernel<8, TRANS, ARITH, SUMS>), dim3(blocks), dim3(256), 0, s, a);
         else if (tiles > 2) hipLaunchKernelGGL((vfn_linear_rows16_kernel<4, TRANS, ARITH, SUMS>), dim3(blocks), dim3(256), 0, s, a);
         else if (tiles > 1) hipLaunchKernelGGL((vfn_linear_rows16_kernel<2, TRANS, ARITH, SUMS>), dim3(blocks), dim3(256), 0, s, a);
@@ -855,9 +924,21 @@ inline bool rows16(const void* p, int ld) { return ((uintptr_t)p & 15) == 0 && (
 
 }  // namespace
 
+extern "C" int64_t vfn_linear_rows_wplanes_bytes(int32_t n_out, int32_t k_in) {
+    if (n_out < 1 || k_in < 1) return VFN_ERR_INVALID;
+    const long long k_pad = (k_in + 7) & ~7;
+    return ((long long)(n_out + 255) / 256) * ((k_pad + GM_KC - 1) / GM_KC) * 2 * 8192 * 2;
+}
+
 extern "C" int vfn_linear_rows(int32_t transpose_w, const float* a, int32_t lda, const float* w, int32_t ldw, const float* bias,
                                int64_t m, int32_t n_out, int32_t k_in, int32_t act, float* c, int32_t ldc, float* stats_part,
                                void* stream) {
+    return vfn_linear_rows_ws(transpose_w, a, lda, w, ldw, bias, m, n_out, k_in, act, c, ldc, stats_part, nullptr, stream);
+}
+
+extern "C" int vfn_linear_rows_ws(int32_t transpose_w, const float* a, int32_t lda, const float* w, int32_t ldw, const float* bias,
+                                  int64_t m, int32_t n_out, int32_t k_in, int32_t act, float* c, int32_t ldc, float* stats_part,
+                                  void* wplanes, void* stream) {
     VFN_REQUIRE(a && w && c, "vfn_linear_rows: NULL argument");
     VFN_REQUIRE(n_out >= 1 && k_in >= 1 && act >= 0 && act <= 2, "vfn_linear_rows: n_out=%d k_in=%d act=%d", n_out, k_in, act);
     const int k_pad = (k_in + 7) & ~7;
@@ -869,6 +950,7 @@ extern "C" int vfn_linear_rows(int32_t transpose_w, const float* a, int32_t lda,
     GemmArgs g = {};
     g.a = a; g.w = w; g.bias = bias; g.c = c; g.stats_part = stats_part; g.m = m; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
     g.n_out = n_out; g.k_in = k_in; g.k_pad = k_pad; g.act = act; g.stats_ld = n_out;
+    g.wp = static_cast<const unsigned short*>(wplanes);
     const int arith = transpose_w & 6;           // 2: split f16 (22 bits); 4: split bf16 (16 bits); 6: bf16 in three parts (24 bits); 0: exact fp32
     hipStream_t s = (hipStream_t)stream;
     const bool tr = (transpose_w & 1) != 0;
@@ -882,7 +964,7 @@ extern "C" int vfn_linear_rows(int32_t transpose_w, const float* a, int32_t lda,
 
 extern "C" int vfn_linear_rows_dx_sums(const float* dz, int32_t lddz, const float* w, int32_t ldw, int64_t m, int32_t n_out, int32_t k_in, float* c,
                                        int32_t ldc, const float* z_prev, int32_t ldz_prev, const float* coef_prev, int32_t n_prev, float post_prev,
-                                       float* sums_part, int32_t arith, void* stream) {
+                                       float* sums_part, int32_t arith, void* wplanes, void* stream) {
     VFN_REQUIRE(arith == 4 || arith == 6, "vfn_linear_rows_dx_sums: arith = %d (4: three bf16 products, 6: bf16 in three parts)", arith);
     VFN_REQUIRE(dz && w && c && z_prev && coef_prev && sums_part, "vfn_linear_rows_dx_sums: NULL argument");
     VFN_REQUIRE(n_out >= 1 && k_in >= 1, "vfn_linear_rows_dx_sums: n_out=%d k_in=%d", n_out, k_in);
@@ -898,6 +980,7 @@ extern "C" int vfn_linear_rows_dx_sums(const float* dz, int32_t lddz, const floa
     g.a = dz; g.w = w; g.c = c; g.m = m; g.lda = lddz; g.ldw = ldw; g.ldc = ldc;
     g.n_out = n_out; g.k_in = k_in; g.k_pad = k_pad; g.act = ACT_NONE;
     g.stats_part = sums_part; g.stats_ld = n_prev; g.zp = z_prev; g.ldzp = ldz_prev; g.coef_p = coef_prev; g.post_p = post_prev;
+    g.wp = static_cast<const unsigned short*>(wplanes);
     if (arith == 4) launch_gemm16<true, 1, true>(g, (hipStream_t)stream);
     else launch_gemm16<true, 2, true>(g, (hipStream_t)stream);
     return vfn_check_launch("vfn_linear_rows_dx_sums");

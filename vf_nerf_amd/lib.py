@@ -36,7 +36,7 @@ EXPORTS = (
     "vfn_ray_density_sigma_bwd", "vfn_weight_grad_frag", "vfn_mlp_bwd_chain_bf16_ws", "vfn_f16x3_set_status", "vfn_f16x3_set_clock_probe", "vfn_flat_clip_workspace_bytes", "vfn_flat_clip_grad_norm", "vfn_flat_adam_step", "vfn_unfold_weight_grads_acc", "vfn_render_fwd", "vfn_render_fwd_workspace_bytes",
     "vfn_vf_loss_workspace_bytes", "vfn_vf_loss_fwd", "vfn_vf_loss_bwd", "vfn_train_step", "vfn_train_step_workspace_bytes",
     "vfn_train_step_workspace_layout", "vfn_train_step_supervision_points", "vfn_train_step_supervision_forward", "vfn_train_step_supervision_backward",
-    "vfn_linear_rows_dx_sums", "vfn_weight_grad_partials_bf16_ld",
+    "vfn_linear_rows_dx_sums", "vfn_weight_grad_partials_bf16_ld", "vfn_linear_rows_ws", "vfn_linear_rows_wplanes_bytes",
 )
 
 
@@ -1231,25 +1231,40 @@ def bstat_row_parts(m: int) -> int:
 GEMM_EXACT, GEMM_SPLIT_F16, GEMM_SPLIT_BF16, GEMM_BF16X6 = 0, 2, 4, 6      # arithmetic of vfn_linear_rows (bits 1-2 of its first argument)
 
 
+_wplanes_cache: dict = {}
+
+
+def wplanes(n_out: int, k_in: int, device) -> torch.Tensor:
+    """The scratch the split layer products put W's 16-bit planes into (vfn_linear_rows_ws): one buffer per device, grown on demand —
+    calls on one stream use it one after the other."""
+    need = int(load().vfn_linear_rows_wplanes_bytes(C.c_int32(n_out), C.c_int32(k_in)))
+    buf = _wplanes_cache.get(str(device))
+    if buf is None or buf.numel() < need:
+        buf = _wplanes_cache[str(device)] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+    return buf
+
+
 def linear_rows(a, w: torch.Tensor, bias, m: int, n_out: int, k_in: int, c, act: int = ACT_NONE, transpose_w: bool = False,
-                stats_part=None, arith: int = GEMM_EXACT) -> None:
+                stats_part=None, arith: int = GEMM_EXACT, planes=None) -> None:
     """``arith``: GEMM_EXACT (fp32 matrix instruction), GEMM_SPLIT_F16 (three f16 products per product, 22 bits: forward GEMMs on
     normalised activations), GEMM_SPLIT_BF16 (three bf16 products, 16 bits with fp32's exponent range) or GEMM_BF16X6 (operands in three
     bf16 parts, six products: 24 bits at fp32's exponent range, fp32-equivalent — backward GEMMs on gradients of any magnitude)."""
     a, c = _cols(a), _cols(c)
-    _check(load().vfn_linear_rows(C.c_int32(int(transpose_w) | int(arith)), a.ptr, C.c_int32(a.ld), _ptr(w, "w"), C.c_int32(w.shape[1]),
-                                  _ptr(bias, "bias"), C.c_int64(m), C.c_int32(n_out), C.c_int32(k_in), C.c_int32(act), c.ptr,
-                                  C.c_int32(c.ld), _ptr(stats_part, "stats_part"), _stream()), "vfn_linear_rows")
+    _check(load().vfn_linear_rows_ws(C.c_int32(int(transpose_w) | int(arith)), a.ptr, C.c_int32(a.ld), _ptr(w, "w"), C.c_int32(w.shape[1]),
+                                     _ptr(bias, "bias"), C.c_int64(m), C.c_int32(n_out), C.c_int32(k_in), C.c_int32(act), c.ptr,
+                                     C.c_int32(c.ld), _ptr(stats_part, "stats_part"), _ptr(planes, "planes", torch.uint8), _stream()),
+           "vfn_linear_rows")
 
 
 def linear_rows_dx_sums(dz, w: torch.Tensor, m: int, n_out: int, k_in: int, c, z_prev, coef_prev: torch.Tensor, n_prev: int, post_prev: float,
-                        part: torch.Tensor, arith: int = 4) -> None:
+                        part: torch.Tensor, arith: int = 4, planes=None) -> None:
     """C = dZ W (``arith``: GEMM_SPLIT_BF16 = three bf16 products, GEMM_BF16X6 = bf16 in three parts) + the per-workgroup partials of the previous layer's BatchNorm-backward column sums, taken from C
     in registers (include/vfn.h, vfn_linear_rows_dx_sums); ``part`` [linear_rows_stat_parts(m), 2, n_prev]."""
     dz, c, z_prev = _cols(dz), _cols(c), _cols(z_prev)
     _check(load().vfn_linear_rows_dx_sums(dz.ptr, C.c_int32(dz.ld), _ptr(w, "w"), C.c_int32(w.shape[1]), C.c_int64(m), C.c_int32(n_out),
                                           C.c_int32(k_in), c.ptr, C.c_int32(c.ld), z_prev.ptr, C.c_int32(z_prev.ld), _ptr(coef_prev, "coef_prev"),
-                                          C.c_int32(n_prev), C.c_float(post_prev), _ptr(part, "part"), C.c_int32(int(arith)), _stream()), "vfn_linear_rows_dx_sums")
+                                          C.c_int32(n_prev), C.c_float(post_prev), _ptr(part, "part"), C.c_int32(int(arith)),
+                                          _ptr(planes, "planes", torch.uint8), _stream()), "vfn_linear_rows_dx_sums")
 
 
 def colsum_finish(part: torch.Tensor, n_parts: int, width: int, sums: torch.Tensor) -> None:
