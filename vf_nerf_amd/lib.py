@@ -1235,12 +1235,13 @@ _wplanes_cache: dict = {}
 
 
 def wplanes(n_out: int, k_in: int, device) -> torch.Tensor:
-    """The scratch the split layer products put W's 16-bit planes into (vfn_linear_rows_ws): one buffer per device, grown on demand —
-    calls on one stream use it one after the other."""
+    """The scratch the split layer products put W's 16-bit planes into (vfn_linear_rows_ws): one buffer per device AND stream, grown on
+    demand — calls on one stream use it one after the other; calls on different streams must not share it."""
     need = int(load().vfn_linear_rows_wplanes_bytes(C.c_int32(n_out), C.c_int32(k_in)))
-    buf = _wplanes_cache.get(str(device))
+    key = (str(device), int(_stream().value or 0))
+    buf = _wplanes_cache.get(key)
     if buf is None or buf.numel() < need:
-        buf = _wplanes_cache[str(device)] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+        buf = _wplanes_cache[key] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
     return buf
 
 
