@@ -127,9 +127,10 @@ int vfn_internal_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_geom
     // stages: bit 0 the partial-slab products, bit 1 the un-fold launch — two calls with the same arguments otherwise, so that a caller can put
     // the products of one row range on a side stream beside another range's and order only the un-folds (both ADD into the same tensors)
     const char* what = "vfn_net_weight_grads_frag";
+    const int slabs = n_dev ? (groups_for(n_points) < 64 ? groups_for(n_points) : 64) : groups_for(n_points);      // (see G below)
     auto one = [&](int32_t shape, const void* dy1, int32_t dyf, const void* x1, int32_t xf, float* dw1, float* db1) -> int {
         if (!(stages & 1)) return VFN_OK;
-        return vfn_internal_weight_grad_frag_batch_dev(shape, dyf, xf, 1, &dy1, &x1, &dw1, &db1, n_points, n_dev, groups_for(n_points), stream);
+        return vfn_internal_weight_grad_frag_batch_dev(shape, dyf, xf, 1, &dy1, &x1, &dw1, &db1, n_points, n_dev, slabs, stream);
     };
     VFN_REQUIRE(geom && layers && saved && dy && aux && dz_head && scratch, "%s: NULL argument", what);
     VFN_REQUIRE(stages & 3, "%s: stages = 0", what);
@@ -141,7 +142,11 @@ int vfn_internal_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_geom
     VFN_REQUIRE(n + 1 <= 12, "%s: %d entries (the un-fold launch takes 12)", what, n + 1);
     VFN_REQUIRE(net_kind == VFN_NET_VF || feats, "%s: the rendering net's first layer reads the fp32 feature rows", what);
     VFN_REQUIRE(slot_bytes > 0 && slot_bytes % 1024 == 0, "%s: slot_bytes = %lld", what, (long long)slot_bytes);
-    const int G = groups_for(n_points);
+    // Slabs: one per 256 points, at most 256 — but a launch over a device-side count (region 2 of a training step: a few percent of its
+    // capacity) spreads the LIVE points over all of them, and every slab costs 256 KiB of partial sums written and read back whatever it
+    // holds: with 256 slabs those launches moved 64 MB each for ~5 000 points of work (0.5 GB per step at 1 024 rays, a third of what the
+    // step's real weight-gradient launches move).  64 slabs there.
+    const int G = slabs;
     const unsigned char* sv = static_cast<const unsigned char*>(saved);
     const unsigned char* dyb = static_cast<const unsigned char*>(dy);
     Carve c{static_cast<unsigned char*>(scratch), 0};
