@@ -166,8 +166,7 @@ class OneCallStep:
                                        coarse_rgb_values=rgb.view(n, 3), coarse_depth_map=depth.view(n, 1), fine_normals=None, fine_rgb_values=None,
                                        fine_depth_map=None, z_vals=z.view(n, s_t), directional_derivtives=None, ray_dirs=rep_dirs,
                                        coarse_colors=colors.view(m, 3))
-        # (the outputs' buffer is reused by the next step: this step's seven scalars leave as one small copy on the stream — read back only
-        # when somebody needs a value, deferred.py)
+        # (a fresh little tensor per step, stepengine.outputs: this step's seven scalars are read back only when somebody needs a value)
         from .deferred import DeviceScalars, as_loss
-        holder = DeviceScalars(out_terms.clone())
+        holder = DeviceScalars(out_terms)
         return (as_loss(holder.dev[6], holder, 6) if vloss.DEFERRED_SCALARS else holder.dev[6]), vloss._LazyTerms(vloss._NAMES, None, holder=holder)

@@ -327,14 +327,18 @@ class StepEngine:
         return lay
 
     def outputs(self, n: int, s_t: int, dev):
-        """The step's outputs: one allocation, sliced (ray_dirs, z_vals, points, normals, colors, weights, rgb, depth, out_terms, out_norm)."""
+        """The step's outputs: one allocation, sliced (ray_dirs, z_vals, points, normals, colors, weights, rgb, depth) + (out_terms, out_norm)."""
         m = n * s_t
-        sizes = (n * 3, n * s_t, m * 3, m * 3, m * 3, n * s_t, n * 3, n, 8, 4)
+        sizes = (n * 3, n * s_t, m * 3, m * 3, m * 3, n * s_t, n * 3, n)
         flat = torch.empty(sum(sizes), device=dev)
         views, o = [], 0
         for k in sizes:
             views.append(flat[o:o + k])
             o += k
+        # (the step's scalars — loss terms, clip norm, counts — in a little tensor of their own: whoever keeps a step's terms, e.g. the
+        #  trainer's running sums, keeps 48 bytes alive and not the step's outputs)
+        small = torch.empty(12, device=dev)
+        views += [small[:8], small[8:]]
         io = self.io
         io.ray_dirs, io.z_vals, io.points, io.normals, io.colors, io.weights, io.rgb, io.depth = (_p(t) for t in views[:8])
         io.out_terms, io.out_norm = _p(views[8]), _p(views[9])
