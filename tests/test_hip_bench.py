@@ -62,6 +62,15 @@ def test_default_line_has_the_contract_keys_and_consistent_arithmetic():
     assert t["frac_rays_within_1e-4"] == 1.0 and t["rays_with_different_z"] == 0 and t["guard"]["switched_to_fp32"] is None
     tr = d["train"]
     assert tr["unit"] == "rays/s" and abs(tr["value"] - 4096 * 1000.0 / tr["ms_per_step"]) < 2e-3 * tr["value"] and 0.2 < tr["frac_of_f16_mfma_div3"] < 1.0
+    # the SAME step as the reference trainer's own call sequence: it took the step session; with the loop's per-step
+    # reads as deferred scalars it costs what it costs with those reads left out, and no more than with a synchronising item() (20 timed
+    # steps each: generous slack for the run-to-run spread)
+    seq = tr["drop_in_sequence"]
+    assert seq["took_the_step_session"] and seq["why_not"] is None and tr["drop_in_sequence_ms"] == seq["ms_per_step"]
+    assert seq["ms_per_step"] <= 1.15 * seq["ms_per_step_without_loss_item"] and seq["ms_per_step"] <= 1.05 * seq["ms_per_step_with_a_synchronising_item"]
+    assert seq["ms_per_step"] < 1.25 * tr["ms_per_step"] and abs(seq["running_loss_mean_read_at_the_end"]) < 10.0
+    # bytes of the step that ran (sparse colour branch) next to the dense step's accounting
+    assert tr["workspace_gb_per_step"] < 0.8 * tr["workspace_gb_per_step_dense_step"]
 
 
 def test_rccl_process_group_with_one_rank_keeps_stdout_to_the_json_line():
