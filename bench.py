@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: rays/s of ``VectorFieldNerf.render`` (forward, eval mode) on 4096-ray chunks with
-128 samples per ray (S_c = N_f = 64), one process per GPU; the scene carries weights the reference's own trainer arrived at
-(tests/golden/trained_far.npz: data, not code) on synthetic rays; --weights random = the random-weight scene of rounds 1-3.
+128 samples per ray (S_c = N_f = 64), one process per GPU, on the synthetic random-weight scene BASELINE.json's north_star names
+(`value`, `roofline`); the same path on weights the reference's own trainer arrived at (tests/golden/trained_far.npz: data, not code)
+is timed beside it (`value_trained_weights`, `roofline_trained_weights`); --weights trained swaps the two.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python bench.py --gpus 8 --steps 20 --warmup 3          # starts its own 8 ranks (torch.distributed.run as a CHILD process)
@@ -71,8 +72,8 @@ def hbm_traffic(f16: bool, kernel_class: str = "fused16", colour_products: int =
             "fused16": ("vfn_mlp16_kernel<35>",) if colour_products == 2 else ("vfn_mlp16_kernel<3>",)}.get(kernel_class, ())
     # newest round first; a round's file is used when it holds BOTH counters of the kernel in question (the 128-ray self-check
     # launches of the other product count also appear in a file: their averages are not what a full launch moves)
-    cands = [os.path.join(REPO, "profiles", r, n) for r in ("r04", "r03", "r02")
-             for n in (("traffic_f16x3.json",) if (colour_products == 2 or r == "r04") else ("traffic_f16x3_3products.json",))]
+    cands = [os.path.join(REPO, "profiles", r, n) for r in ("r06", "r05", "r04", "r03", "r02")
+             for n in (("traffic_f16x3.json",) if (colour_products == 2 or r >= "r04") else ("traffic_f16x3_3products.json",))]
     path = t = None
     for cand in cands:
         if f16 and os.path.exists(cand):
@@ -122,7 +123,7 @@ def live_hbm_traffic(args, timeout_s: float = 60.0):
     except OSError as e:
         return None, {"live": False, "why": f"no scratch directory under /tmp: {e}"[:300]}
     child = [sys.executable, os.path.abspath(__file__), "--no-live-traffic", "--no-cpu-baseline", "--no-train", "--no-two-product-leg",
-             "--no-random-weight-leg", "--no-shipped-rows", "--steps", "5", "--warmup", "2", "--sustain-seconds", "0", "--rays", str(args.rays), "--coarse",
+             "--no-other-scene-leg", "--no-shipped-rows", "--steps", "5", "--warmup", "2", "--sustain-seconds", "0", "--rays", str(args.rays), "--coarse",
              str(args.coarse), "--fine", str(args.fine), "--weights", args.weights] + \
             (["--colour-products", str(args.colour_products)] if args.colour_products else [])
     kb = {}
@@ -939,11 +940,10 @@ def train_bench(args, model, uv, pose, K, dev, dist, rank, world, sync, emit=Tru
            "executed_tflop_per_step": round(executed / 1e12, 4),
            "executed_tflops": round(executed / (ms * 1e-3) / 1e12, 1),
            "frac_of_f16_mfma_div3_executed": round(executed / (ms * 1e-3) / 1e12 / (PEAK_F16_MFMA / 3.0), 4),
-           "achieved_tflops": round(flops / (ms * 1e-3) / 1e12, 1),
-           # (three matrix products per algorithmic one on the default path; the opt-in single-product mode is priced against the
-           # whole peak and carries no div3 figure)
-           "frac_of_f16_mfma_div3": round(flops / (ms * 1e-3) / 1e12 / (PEAK_F16_MFMA / 3.0), 4) if not train_dtype_label(model).startswith("16-bit-native") else None,
-           "frac_of_f16_mfma": round(flops / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA, 4),
+           # (a fraction is quoted for EXECUTED work only: pricing the dense step's algorithmic FLOPs — the reference's dense colour branch,
+           # 1.5 VF evaluations per sample — against the roof would be a fraction of work the step does not do.  The opt-in single-product
+           # mode runs one matrix product per algorithmic one: its ceiling is the whole f16 peak.)
+           "frac_of_f16_mfma_executed_single_product": round(executed / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA, 4) if train_dtype_label(model).startswith("16-bit-native") else None,
            # bytes the step's launches move through the training workspace (accounted, not counted): with the sparse colour branch the
            # vector-only slots of every point + all slots of the selected samples; `_dense_step` = what the dense step moves (the figure
            # rounds 3-4 quoted for every step)
@@ -1101,14 +1101,19 @@ def main() -> None:
                     help="untimed run of the same work right before the timed steps (the chip's clock settles under load)")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step sub-object of the default line")
     ap.add_argument("--no-two-product-leg", action="store_true", help="skip the timed region of the opt-in two-product colour branch")
-    ap.add_argument("--no-random-weight-leg", action="store_true", help="skip the timed region on the synthetic random-weight scene")
+    ap.add_argument("--no-other-scene-leg", "--no-random-weight-leg", dest="no_other_scene_leg", action="store_true",
+                    help="skip the timed region on the OTHER scene (trained weights when --weights random, and the reverse)")
     ap.add_argument("--no-shipped-rows", action="store_true", help="skip the extra rows at the shipped conf's sample counts (100 + 35, 100 + 100)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from the committed profiles/rNN/traffic_f16x3.json instead of two rocprofv3 --pmc child runs of "
                          "this command on this box (+25 s; render workload, one GPU, not under a profiler)")
-    ap.add_argument("--weights", choices=("trained", "random"), default="trained",
-                    help="render workload: trained = weights the reference's own trainer arrived at (tests/golden/trained_far.npz), the "
-                         "default; random = the synthetic random-weight scene")
+    ap.add_argument("--weights", choices=("trained", "random"), default="random",
+                    help="render workload: random = the synthetic random-weight scene BASELINE.json's north_star names (the default: `value` "
+                         "and `roofline` are measured on it); trained = weights the reference's own trainer arrived at "
+                         "(tests/golden/trained_far.npz).  The other scene is timed beside it (value_trained_weights / value_random_weight_scene)")
+    ap.add_argument("--train-weights", choices=("trained", "random"), default="trained",
+                    help="the training sub-object of the default line (BASELINE.json configs[2]): trained = steps at the state a long run of the "
+                         "reference's trainer sits in (the scene keeps its surfaces); random = the synthetic scene (loses them within two Adam steps)")
     ap.add_argument("--train-steps", type=int, default=12, help="optimizer steps timed for the training sub-object")
     ap.add_argument("--activations", choices=("fp32", "f16"), default="f16",
                     help="training: storage of the hidden activations for the weight-gradient kernels (f16 = the default, "
@@ -1228,7 +1233,8 @@ def main() -> None:
     # state train/vector_field_nerf_train.py:136-292 arrived at); --weights random = the synthetic random-weight scene of rounds 1-3.
     # The training workload takes them too (its targets: the model's own render, train_bench).
     scene_info = None
-    built = build_trained_scene(dev, args.rays, s_c, n_f, seed=rank) if (args.weights == "trained" and args.workload in ("render", "train")) else None
+    want_trained = (args.weights if args.workload == "render" else args.train_weights) == "trained"
+    built = build_trained_scene(dev, args.rays, s_c, n_f, seed=rank) if (want_trained and args.workload in ("render", "train")) else None
     if built is not None:
         model, uv, pose, K, scene_info = built
         model._bench_trained_weights = scene_info
@@ -1312,20 +1318,29 @@ def main() -> None:
             model.f16x3_guard = "off"                      # timing of the opt-in itself; the check above says whether it would be kept
             _, elapsed2, _ = timed_region(model, args.steps, max(3, args.warmup), min(1.0, args.sustain_seconds))
             model.colour_products, model.f16x3_guard = 3, keep_guard
-        elapsed_rand, events_rand, clock_rand = None, [], None
-        if scene_info is not None and not args.no_random_weight_leg:
-            rmodel, uv_r, pose_r, K_r = build_scene(dev, args.rays, s_c, n_f, seed=rank)
-            rmodel.precision, rmodel.reuse_proposal = args.precision, not args.no_reuse
-            rmodel.colour_products = model.colour_products
-            keep_inputs = (uv, pose, K)
-            uv, pose, K = uv_r, pose_r, K_r
-            probe_r = torch.zeros_like(probe) if probe is not None else None
-            # (the same sustain as the headline leg: the launch is power-limited, a shorter run-in would flatter this scene)
-            _, elapsed_rand, _ = timed_region(rmodel, args.steps, max(3, args.warmup), args.sustain_seconds, events_rand, probe_r)
-            uv, pose, K = keep_inputs
-            if probe_r is not None:
-                clock_rand = vlib.clock_ghz_from_stamps(probe_r)
-            del rmodel
+        # the OTHER scene, same path, same run-in: trained weights beside the random-weight headline (or the reverse with --weights trained)
+        elapsed_rand, events_rand, clock_rand, other_info = None, [], None, None
+        if not args.no_other_scene_leg:
+            if scene_info is not None:
+                rmodel, uv_r, pose_r, K_r = build_scene(dev, args.rays, s_c, n_f, seed=rank)
+                other = (rmodel, uv_r, pose_r, K_r)
+            else:
+                built_o = build_trained_scene(dev, args.rays, s_c, n_f, seed=rank)
+                other = built_o[:4] if built_o is not None else None
+                other_info = built_o[4] if built_o is not None else None
+            if other is not None:
+                rmodel, uv_r, pose_r, K_r = other
+                rmodel.precision, rmodel.reuse_proposal = args.precision, not args.no_reuse
+                rmodel.colour_products = model.colour_products
+                keep_inputs = (uv, pose, K)
+                uv, pose, K = uv_r, pose_r, K_r
+                probe_r = torch.zeros_like(probe) if probe is not None else None
+                # (the same sustain as the headline leg: the launch is power-limited, a shorter run-in would flatter this scene)
+                _, elapsed_rand, _ = timed_region(rmodel, args.steps, max(3, args.warmup), args.sustain_seconds, events_rand, probe_r)
+                uv, pose, K = keep_inputs
+                if probe_r is not None:
+                    clock_rand = vlib.clock_ghz_from_stamps(probe_r)
+                del rmodel, other
         # the SHIPPED sample counts (confs/vf_nerf.conf:40-48: 100 proposal samples, 35 fine samples growing to max_samples = 100) on the
         # headline scene, as extra rows
         shipped_rows = None
@@ -1409,8 +1424,8 @@ def main() -> None:
                 "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA, 4)}
         if f16:   # context, not the graded fraction: the power-limited MFMA rate measured on this chip
             roof["frac_of_measured_sustained_f16_mfma"] = round(achieved / (SUSTAINED_F16_MFMA / products), 4)
-        # the SAME accounting for the synthetic random-weight scene — the scene BASELINE.json's north_star names ("throughput on synthetic
-        # random-weight scenes"): its own event-timed launch duration, fraction and in-kernel clock
+        # the SAME accounting for the other scene (trained weights beside the random-weight headline): its own event-timed launch
+        # duration, fraction and in-kernel clock
         roof_rand = None
         if events_rand:
             pc = {}
@@ -1435,8 +1450,12 @@ def main() -> None:
             # three products everywhere IS the default now: `value` is the fp32-equivalent figure (kept under its round-3 name too)
             "value_fp32_equivalent": round(rays_per_s, 1) if (f16 and cp == 3) else None,
             "weights": scene_info if scene_info is not None else {"fixture": None, "trained_by": "nobody: synthetic random weights (seed + default init x gain 2 + recentred head)"},
-            "value_random_weight_scene": round(args.rays * args.steps * world / elapsed_rand, 1) if elapsed_rand else None,
-            "roofline_random_weight_scene": roof_rand,
+            # the other scene: value_trained_weights / roofline_trained_weights beside the random-weight headline (BASELINE.json's scene),
+            # value_random_weight_scene / roofline_random_weight_scene beside a --weights trained one
+            ("value_random_weight_scene" if scene_info is not None else "value_trained_weights"):
+                round(args.rays * args.steps * world / elapsed_rand, 1) if elapsed_rand else None,
+            ("roofline_random_weight_scene" if scene_info is not None else "roofline_trained_weights"): roof_rand,
+            "other_scene_weights": other_info,
             # SURVEY.md section 8d "extra row": the shipped conf's sample counts (confs/vf_nerf.conf:40-48), same scene, same default path;
             # their per-ray parity against the reference's outputs at those sizes: parity_shipped_sizes below
             "value_shipped_conf": ([{"samples": f"{a} + {b}", "rays_per_s": round(args.rays * args.steps * world / el, 1),
@@ -1444,12 +1463,15 @@ def main() -> None:
                                     for a, b, el in shipped_rows] if shipped_rows else None),
             "value_two_product_opt_in": round(args.rays * args.steps * world / elapsed2, 1) if elapsed2 else None,
             "two_product_check": check2,
-            "value_definition": ("value: the default path (three f16 products per fp32-equivalent product everywhere, colours 1e-7 from the exact-fp32 "
-                                 "kernels) on TRAINED weights" + ("" if scene_info is not None else " — not available here: random weights") +
-                                 "; value_random_weight_scene (+ roofline_random_weight_scene): the same path on the synthetic random-weight scene — "
-                                 "the scene BASELINE.json's north_star names; the trained scene is what a user of the reference renders, and its "
-                                 "activations let the power-limited launch hold a higher clock (effective_clock_ghz of either roofline); "
-                                 "value_two_product_opt_in: model.colour_products = 2 (colour-branch weights as f16 roundings) timed on the "
+            "value_definition": ("value / roofline: the default path (three f16 products per fp32-equivalent product everywhere, colours 1e-7 from the "
+                                 "exact-fp32 kernels) on " + ("TRAINED weights (--weights trained)" if scene_info is not None else
+                                                              "the synthetic RANDOM-weight scene BASELINE.json's north_star names") +
+                                 "; " + ("value_random_weight_scene (+ roofline_random_weight_scene): the same path on the synthetic random-weight scene"
+                                         if scene_info is not None else
+                                         "value_trained_weights (+ roofline_trained_weights): the same path, same run-in, on weights the reference's own "
+                                         "trainer arrived at (what a user of the reference renders; its activations let the power-limited launch hold a "
+                                         "higher clock: effective_clock_ghz of either roofline)") +
+                                 "; value_two_product_opt_in: model.colour_products = 2 (colour-branch weights as f16 roundings) timed on the "
                                  "headline scene with the guard off — two_product_check says what it does to the colours there and whether the "
                                  "guard's measured self-check would keep it (on trained weights it does not)"),
             "per_rank_rays_per_s": rates,
@@ -1476,7 +1498,7 @@ def main() -> None:
         targs.steps, targs.warmup = args.train_steps, 5      # (the first steps size the caching allocator's 15 GB of workspace)
         del out
         torch.cuda.empty_cache()
-        tbuilt = build_trained_scene(dev, args.rays, s_c, n_f, seed=rank) if args.weights == "trained" else None
+        tbuilt = build_trained_scene(dev, args.rays, s_c, n_f, seed=rank) if args.train_weights == "trained" else None
         if tbuilt is not None:
             tmodel, tuv, tpose, tK, tinfo = tbuilt
             tmodel._bench_trained_weights = tinfo
@@ -1493,7 +1515,7 @@ def main() -> None:
         if train_rec is not None:
             line["train"] = {k: train_rec[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "activation_storage", "gradient_storage", "workspace_layout",
                                                        "step_issued_as", "weights", "sparse_colour_branch", "algorithmic_tflop_per_step", "executed_tflop_per_step",
-                                                       "executed_tflops", "frac_of_f16_mfma_div3_executed", "achieved_tflops", "frac_of_f16_mfma_div3",
+                                                       "executed_tflops", "frac_of_f16_mfma_div3_executed",
                                                        "workspace_gb_per_step", "workspace_gb_per_step_dense_step", "workspace_tb_per_s", "frac_of_hbm_peak", "final_loss", "drop_in_sequence_ms", "drop_in_sequence")}
             line["train"]["workload"] = train_rec["config"]["workload"]
         emit_line((line))

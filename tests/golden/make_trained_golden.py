@@ -150,11 +150,14 @@ def make_batches(fx, teacher):
     return batches
 
 
-def train(fx):
+def train(fx, batches=None, torch_seed=None, numpy_seed=None, quiet=False):
+    """``batches`` / ``torch_seed`` / ``numpy_seed``: make_run_golden.py's further runs of the SAME task (same initial weights, same
+    batches) under other random streams — the reference trainer's own run-to-run spread."""
     student = mtg.build_reference_model(fx)
     mtg.own_model_matches(fx, student)
-    teacher = mtg.build_reference_model(dict(fx, seed=fx["teacher_seed"]))
-    batches = make_batches(fx, teacher)
+    if batches is None:
+        teacher = mtg.build_reference_model(dict(fx, seed=fx["teacher_seed"]))
+        batches = make_batches(fx, teacher)
     hit = float(np.mean([float((b["depth"] > 0.02).float().mean()) for b in batches]))
 
     runner = object.__new__(ref_train.VectorFieldNerfRunner)       # __init__ needs dataset files, an init .pth, wandb: bypassed
@@ -188,15 +191,16 @@ def train(fx):
     torch.nn.utils.clip_grad_norm_ = clip_spy
     t0 = time.time()
     try:
-        torch.manual_seed(fx["torch_seed"])
-        np.random.seed(fx["numpy_seed"])
+        torch.manual_seed(fx["torch_seed"] if torch_seed is None else torch_seed)
+        np.random.seed(fx["numpy_seed"] if numpy_seed is None else numpy_seed)
         for epoch in range(fx["epochs"]):
             runner.train_epoch(epoch)                               # <- the reference's own loop body
             gap = ""
             if (epoch + 1) % 4 == 0 or epoch + 1 == fx["epochs"]:
                 curve["colour_gap"].append([float((epoch + 1) * fx["steps_per_epoch"]), colour_gap(student)])
                 gap = f"  two-product colour gap {curve['colour_gap'][-1][1]:.2e}"
-            print(f"  epoch {epoch}: mean loss {np.mean(curve['loss'][-fx['steps_per_epoch']:]):.4f}  ({time.time() - t0:.0f} s){gap}", flush=True)
+            if not quiet:
+                print(f"  epoch {epoch}: mean loss {np.mean(curve['loss'][-fx['steps_per_epoch']:]):.4f}  ({time.time() - t0:.0f} s){gap}", flush=True)
     finally:
         torch.nn.utils.clip_grad_norm_ = real_clip
         hook.remove()

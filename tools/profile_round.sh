@@ -7,8 +7,13 @@ R=$(pwd)
 OUT=${1:-gpurun_out/export}
 mkdir -p "$R/$OUT" "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-train --no-two-product-leg --no-random-weight-leg --no-live-traffic"
+B="python3 $R/bench.py --no-cpu-baseline --no-train --no-two-product-leg --no-other-scene-leg --no-shipped-rows --no-live-traffic"
+# the SAME command un-profiled and under the kernel trace, back to back on this box: the line's event-timed launch
+# duration must follow from the profiler's table, or profiled_vs_unprofiled.md says why not (clock and cycle counts of both runs)
+$B --steps 20 > "$R/$OUT/bench_unprofiled_same_box.json" 2> "$R/gpurun_out/bench_unprofiled.err"
 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_kt" -o kt -- $B --steps 20 > "$R/gpurun_out/prof_kt.log" 2>&1
+grep '^{"metric"' "$R/gpurun_out/prof_kt.log" | tail -1 > "$R/$OUT/bench_profiled_same_box.json"
+(cd "$R" && python3 tools/profiled_vs_unprofiled.py "$OUT/bench_unprofiled_same_box.json" gpurun_out/prof_kt.log "$(find gpurun_out/prof_kt -name 'kt_results.db' | head -1)" > "$OUT/profiled_vs_unprofiled.md" 2> "$OUT/profiled_vs_unprofiled.err")
 rocprofv3 --pmc FETCH_SIZE -d "$R/gpurun_out/prof_fetch" -o pf -- $B --steps 5 > "$R/gpurun_out/prof_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE -d "$R/gpurun_out/prof_write" -o pw -- $B --steps 5 > "$R/gpurun_out/prof_write.log" 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$R/gpurun_out/pmc_mfma" -o pm -- $B --steps 5 > "$R/gpurun_out/pmc_mfma.log" 2>&1
