@@ -150,3 +150,115 @@ def test_batch_tensors_are_checked_before_their_pointers_are_used():
         model.render(g["pose"][:5], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
     with pytest.raises(lib.VfnError, match="shape"):
         model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms={k: v[:3] for k, v in uni.items()})
+
+
+def test_session_render_returns_every_samples_colour_like_the_reference():
+    """models/nerf/vector_field_nerf.py:315-338: ``coarse_colors`` is the rendering net's colour of EVERY sample.  A step session evaluates
+    the colour branch on the SELECTED samples only (the sparse colour branch) — the field is completed on first access by a dense
+    gradient-free launch (render_output.LazyColours), so a reader sees the reference's tensor: against the reference's own captured
+    colours (tests/golden/bench_sizes.npz) every row is inside 2e-5, selected or not; the rows the step computed are the step's values bit
+    for bit (the zeros elsewhere are what the C call left); reading the field does not disturb the step (gradients equal to a step whose
+    colours were never read); and after optimizer.step() — new weights — a first read raises instead of returning other weights' colours."""
+    fx, d, model, g, uni = _model_and_batch("bench_sizes", True)
+    n, s_t = d["z_vals"].shape
+    a, b, c = (t.to(DEV) for t in loss_coefficients(n, s_t))
+    model.optimizer.zero_grad()
+    out = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
+    eng = stepengine.StepEngine.of(model)
+    assert eng.session is not None and eng.why_not is None and eng.params.sparse_colours == 1
+    raw = eng.session.colors.view(n * s_t, 3).clone()                       # what the C call wrote: selected rows, zeros elsewhere
+    w = eng.session.weights.view(n, s_t)
+    ran = (raw != 0).any(dim=1)
+    positive = (w > 0).reshape(-1)
+    assert bool((ran | ~positive).all()), "a sample with w > 0 was not selected"
+    assert 0 < int(ran.sum()) < n * s_t // 2, "the selection is neither empty nor dense on this fixture"
+    colours = out.coarse_colors                                              # first access: the dense fill
+    assert type(colours) is torch.Tensor and tuple(colours.shape) == (n * s_t, 3)
+    assert torch.equal(colours[ran], raw[ran])
+    err = (colours.cpu() - d["colors"]).abs().max(dim=1)[0]
+    print(f"session coarse_colors vs the reference's: selected rows {int(ran.sum())} of {n * s_t}, worst error on selected rows "
+          f"{float(err[ran.cpu()].max()):.2e}, on the filled rows {float(err[~ran.cpu()].max()):.2e}")
+    assert float(err.max()) < 2e-5
+    assert out.coarse_colors is colours                                      # filled once
+    ((out.coarse_rgb_values * a).sum() + (out.coarse_depth_map * b).sum() + (out.coarse_normals * c).sum()).backward()
+    got = _grads(model)
+    fx, d, ref, g, uni = _model_and_batch("bench_sizes", True)
+    ref.optimizer.zero_grad()
+    o2 = ref.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
+    ((o2.coarse_rgb_values * a).sum() + (o2.coarse_depth_map * b).sum() + (o2.coarse_normals * c).sum()).backward()
+    # (equal up to the order of the atomic sums of two runs of the same step)
+    assert _worst(got, _grads(ref)) < 1e-4
+    torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+    ref.optimizer.step()
+    with pytest.raises(RuntimeError, match="before optimizer.step"):
+        o2.coarse_colors
+    # eager fill: the same tensor, made inside render()
+    fx, d, eager, g, uni = _model_and_batch("bench_sizes", True)
+    eager.eager_session_colours = True
+    o3 = eager.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
+    assert torch.equal(o3.coarse_colors, colours)
+    del o3
+
+
+def test_training_selection_keeps_samples_whose_weight_underflowed_but_whose_derivative_did_not():
+    """The sparse colour branch's selection (csrc/vfn_rays.hip, sel_predicate): w > 0, or w = 0 by an underflowed alpha alone (sigma > 0,
+    delta > 0, T > 0) — there d w / d sigma = T delta is not zero and the dense step's (d rgb . c) term needs the colour.  Constructed
+    directly: sigma tiny (sigma delta < 6e-8 rounds alpha to 0) on otherwise empty rays."""
+    n, s = 8, 64
+    z = torch.linspace(0.0, 1.0, s, device=DEV).repeat(n, 1).contiguous()
+    sigma = torch.zeros(n, s, device=DEV)
+    sigma[0, 10] = 1e-6                # alpha = 1 - exp(-1e-6 / 63) == 0 in fp32, T = 1
+    sigma[1, 5] = 1e4                  # opaque: everything behind it has T = 0
+    sigma[1, 20] = 1e-6                # ... so this one is NOT needed
+    sigma[2, 7] = 3.0                  # an ordinary surface sample: w > 0
+    delta = torch.cat([z[:, 1:] - z[:, :-1], torch.full((n, 1), 1e10, device=DEV)], 1)
+    e = sigma * delta
+    T = torch.exp(-(torch.cumsum(e.double(), 1) - e.double())).float()
+    w = (1.0 - torch.exp(-e)) * T
+    assert float(w[0, 10]) == 0.0 and float(w[2, 7]) > 0.0
+    pts = torch.rand(n, s, 3, device=DEV)
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, device=DEV), dim=1)
+    got_train = lib.select_samples(w, pts, dirs, sigma=sigma, z_vals=z)
+    got_fwd = lib.select_samples(w, pts, dirs)
+    want_fwd = sorted(int(i) for i in torch.nonzero(w.reshape(-1) > 0).reshape(-1))
+    assert got_fwd == want_fwd and 2 * s + 7 in got_fwd and 0 * s + 10 not in got_fwd
+    assert 0 * s + 10 in got_train and 1 * s + 20 not in got_train and set(got_fwd) <= set(got_train)
+    assert got_train == sorted(got_train)
+
+
+def test_clip_inside_optimizer_step_equals_the_wrapped_clip():
+    """``dropin.install(patch_clip=False)``: torch.nn.utils.clip_grad_norm_ is PyTorch's own function, a step session
+    parks its gradient (every param.grad None until the step), the trainer's clip call scales nothing, and optimizer.step() clips with the
+    configured norm before the update — the same parameters, bit for bit, as the default drop-in (wrapped clip, then step), SURVEY Q4's
+    double clip and double Adam update of the aliased vector-field parameters included."""
+    from vf_nerf_amd import dropin, optim
+    after = {}
+    for patched in (True, False):
+        try:
+            dropin.install(patch_clip=patched)
+            fx, d, model, g, uni = _model_and_batch("bench_sizes", True)
+            n, s_t = d["z_vals"].shape
+            a, b, c = (t.to(DEV) for t in loss_coefficients(n, s_t))
+            clip = float(model.config.scheduler_config.clip_norm)
+            for _ in range(2):                          # two steps: the second starts from re-bound gradient views
+                model.optimizer.zero_grad()
+                out = model.render(g["pose"], g["uv"], g["intrinsics"], epoch=0, uniforms=uni)
+                assert stepengine.StepEngine.of(model).why_not is None
+                ((out.coarse_rgb_values * a).sum() + (out.coarse_depth_map * b).sum() + (out.coarse_normals * c).sum()).backward()
+                if not patched:
+                    assert all(p.grad is None for p in model.unique_parameters()) and "parked_max_norm" in model.optimizer.flat()
+                norm = torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+                if not patched:
+                    assert float(norm) == 0.0          # PyTorch's function saw no gradient
+                model.optimizer.step()
+                model.scheduler.step()
+                assert all(p.grad is not None for p in model.unique_parameters()) and "parked_max_norm" not in model.optimizer.flat()
+            after[patched] = {k: p.detach().clone() for net in (model.vector_field_network, model.rendering_network, model.density)
+                              for k, p in net.named_parameters(prefix=type(net).__name__)}
+            step8 = float(model.optimizer.state[model.vector_field_network.layers[8].weight]["step"])
+            assert step8 == 4.0                         # Q4: two updates per step for the aliased net
+        finally:
+            dropin.install()
+    assert optim.CLIP_INSIDE_STEP is False
+    for k, v in after[True].items():
+        assert torch.equal(v, after[False][k]), k

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     handle = lib.load()
     for name in declared:
         assert hasattr(handle, name), name
-    assert handle.vfn_abi_version() == lib.ABI_VERSION == 4
+    assert handle.vfn_abi_version() == lib.ABI_VERSION == 5
 
 
 def test_binding_signatures_come_from_the_header():
@@ -733,3 +733,75 @@ def test_deferred_scalars_carry_the_reference_loops_running_sums():
     d = vloss._LazyTerms(vloss._NAMES, None, holder=DeviceScalars(steps[0]))
     assert isinstance(d["rgb_loss"], DeferredScalar) and type(d.get("rgb_loss")) is float and type(d["rgb_loss"]) is float   # get() read it back
     assert json.loads(json.dumps(d)) == {k: float(steps[0][j]) for j, k in enumerate(vloss._NAMES)}
+
+
+def test_deferred_scalars_in_a_per_step_logger():
+    """What a user's per-step logger does with ``loss.item()`` / ``losses_dict[key]``: a wandb-style payload
+    (dict -> json), pickling (a multiprocessing queue, ``torch.save`` of a metrics dict), ``copy.deepcopy``, numpy arrays of a history,
+    ``isinstance(x, float)`` after ``deferred.resolve``.  The value is always the float; the foreign type never leaves the process."""
+    import copy
+    import json
+    import pickle
+
+    import numpy as np
+
+    from vf_nerf_amd import deferred, dropin, loss as vloss
+    from vf_nerf_amd.deferred import DeferredScalar, DeviceScalars
+
+    vec = torch.tensor([0.5, 0.25, 0.125, 1.5, 0.0, 0.0, 2.375, 7.0])
+    terms = lambda: vloss._LazyTerms(vloss._NAMES, None, holder=DeviceScalars(vec.clone()))
+    d = terms()
+    item = DeferredScalar(DeviceScalars(vec.clone()), 6)
+    payload = {"train/loss": item, "train/terms": {k: d[k] for k in d.keys()}, "step": 3, "lr": 5e-4}
+    assert isinstance(payload["train/terms"]["rgb_loss"], DeferredScalar)
+    # json: with the encoder hook (either one), or resolved first for an encoder that takes no hook
+    want = {"train/loss": 2.375, "train/terms": {k: float(vec[j]) for j, k in enumerate(vloss._NAMES)}, "step": 3, "lr": 5e-4}
+    assert json.loads(json.dumps(payload, default=float)) == want
+    assert json.loads(json.dumps(payload, default=deferred.json_default)) == want
+    with pytest.raises(TypeError):
+        json.dumps({"x": object()}, default=deferred.json_default)
+    resolved = deferred.resolve(payload)
+    assert json.loads(json.dumps(resolved)) == want and type(resolved["train/loss"]) is float and isinstance(resolved["train/loss"], float)
+    assert all(type(v) is float for v in resolved["train/terms"].values()) and deferred.resolve([item, (item, 1)]) == [2.375, (2.375, 1)]
+    # pickle / deepcopy: the float travels, the device vector does not
+    back = pickle.loads(pickle.dumps({"loss": item, "history": [item, item]}))
+    assert back == {"loss": 2.375, "history": [2.375, 2.375]} and type(back["loss"]) is float
+    assert type(copy.deepcopy(item)) is float and type(copy.copy(item)) is float and copy.deepcopy({"a": [item]}) == {"a": [2.375]}
+    import io
+    buf = io.BytesIO()
+    torch.save({"loss": item}, buf)
+    buf.seek(0)
+    assert torch.load(buf, weights_only=False) == {"loss": 2.375}
+    # numpy: a history of per-step losses is a float64 array, not an object array
+    hist = [DeferredScalar(DeviceScalars(vec.clone() + k), 6) for k in range(4)]
+    arr = np.asarray(hist)
+    assert arr.dtype == np.float64 and arr.shape == (4,) and np.allclose(arr, [2.375, 3.375, 4.375, 5.375])
+    assert abs(float(np.mean(hist)) - 3.875) < 1e-12 and np.asarray(item).shape == () and np.float32(item) == np.float32(2.375)
+    assert np.array(hist, dtype=np.float32).dtype == np.float32 and torch.tensor(hist, dtype=torch.float32).tolist() == [2.375, 3.375, 4.375, 5.375]
+    # the switch for a logger that cannot be touched: plain floats at once (a synchronisation per step), through the drop-in's install()
+    keep = vloss.DEFERRED_SCALARS
+    try:
+        dropin.install(deferred_scalars=False)
+        assert vloss.DEFERRED_SCALARS is False and type(terms()["rgb_loss"]) is float
+        dropin.install(deferred_scalars=True)
+        assert isinstance(terms()["rgb_loss"], DeferredScalar)
+    finally:
+        vloss.DEFERRED_SCALARS = keep
+
+
+def test_install_can_leave_torchs_clip_grad_norm_alone():
+    """``dropin.install(patch_clip=False)``: ``torch.nn.utils.clip_grad_norm_`` is PyTorch's own function again and the flat optimizer clips
+    inside ``step()`` when a step session parked its gradient (optim.CLIP_INSIDE_STEP); ``install()`` puts the wrapper back."""
+    from vf_nerf_amd import dropin, optim
+    wrapped = torch.nn.utils.clip_grad_norm_
+    assert wrapped.__module__ == "vf_nerf_amd.dropin" and optim.CLIP_INSIDE_STEP is False
+    try:
+        dropin.install(patch_clip=False)
+        assert torch.nn.utils.clip_grad_norm_ is wrapped.__wrapped__ and optim.CLIP_INSIDE_STEP is True
+        assert torch.nn.utils.clip_grad_norm_.__module__.startswith("torch.")
+        # PyTorch's own function on parameters without gradients (what a parked step looks like to it): nothing to scale
+        p = torch.nn.Parameter(torch.ones(3))
+        assert float(torch.nn.utils.clip_grad_norm_([p, p], 0.5)) == 0.0
+    finally:
+        dropin.install()
+    assert torch.nn.utils.clip_grad_norm_.__module__ == "vf_nerf_amd.dropin" and optim.CLIP_INSIDE_STEP is False

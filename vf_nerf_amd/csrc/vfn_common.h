@@ -64,8 +64,10 @@ int vfn_internal_net_weight_grads_frag_part(int32_t net_kind, const vfn_net_geom
                                             int32_t accumulate, void* scratch, void* stream, int32_t stages = 3);
 
 // csrc/vfn_rays.hip: the samples with non-zero weight, compacted on the device (the sparse colour branch of vfn_train_step / vfn_render_fwd)
-int vfn_internal_select_positive(const float* weights, int n_rays, int n_samples, const float* points, const float* ray_dirs, int32_t* cnt,
-                                 int32_t* off, int32_t* k_dev, int32_t* sel_sorted, float* pts_sel, float* dirs_sel, void* stream);
+// (sigma / z_vals NULL: w > 0; given: also the samples whose weight is zero by an underflowed alpha alone — what a training step needs)
+int vfn_internal_select_positive(const float* weights, const float* sigma, const float* z_vals, int n_rays, int n_samples, const float* points,
+                                 const float* ray_dirs, int32_t* cnt, int32_t* off, int32_t* k_dev, int32_t* sel_sorted, float* pts_sel,
+                                 float* dirs_sel, void* stream);
 int vfn_internal_rows3_by_index(const float* a, const int32_t* index, const int32_t* k_dev, int64_t capacity, float* out, int gather, void* stream);
 // csrc/vfn_mlp16.hip: the gradient-free fused launch over min(n_points, *n_dev) points (outputs scattered through out_index when given)
 int vfn_internal_fused16_products_dev(const vfn_net_geom* vf_geom, const void* vf_packed16, const vfn_net_geom* rn_geom, const void* rn_packed16,

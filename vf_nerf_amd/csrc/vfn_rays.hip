@@ -1033,11 +1033,38 @@ int vfn_internal_composite_gather(const vfn_density_params* dp, float* normals, 
 namespace {
 // One wave per ray (4 rays per workgroup).  Pass 1 counts, a one-workgroup scan turns the counts into offsets (ray order: the
 // compacted list is deterministic), pass 2 writes, per selected sample, its sorted index, its point and its ray's direction.
-__global__ void vfn_sel_count_kernel(const float* w, int n_rays, int S, int32_t* cnt) {
+//
+// The predicate.  Forward-only callers (sigma == NULL) select w > 0: a colour enters a render through w c only.  A TRAINING step also
+// needs a sample's colour where its weight is zero but the weight's DERIVATIVE is not: d w_j / d sigma_j = T_j delta_j exp(-e_j) survives
+// an alpha that has underflowed (1 - exp(-e) == 0 for e < 6e-8 while sigma > 0), and the dense step's (d rgb . c_j) term of d sigma_j
+// with it.  With sigma and z given the predicate is therefore  w > 0  OR  (sigma > 0 AND delta > 0 AND T > 0)  — every sample whose
+// colour can reach any gradient or output.  T_j = exp(-sum_{i<j} e_i) is tested through its exponent (float exp underflows to zero past
+// 103.98; the sum is re-accumulated here in fp64, the bound 110 errs on the side of selecting).
+__device__ __forceinline__ bool sel_predicate(const float* w, const float* sigma, const float* z, int ray, int S, int j, int lane, double& carry) {
+    const size_t i = (size_t)ray * S + j;
+    const bool in = j < S;
+    const bool pos = in && w[i] > 0.f;
+    if (!sigma) return pos;
+    const float sg = in ? sigma[i] : 0.f;
+    const float delta = !in ? 0.f : (j < S - 1 ? z[i + 1] - z[i] : 1e10f);
+    const double e = (double)(sg * delta);
+    double incl = e;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    const double before = carry + (incl - e);
+    carry += __shfl(incl, 63, 64);
+    return pos || (in && sg > 0.f && delta > 0.f && before < 110.0);
+}
+
+__global__ void vfn_sel_count_kernel(const float* w, const float* sigma, const float* z, int n_rays, int S, int32_t* cnt) {
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (ray >= n_rays) return;
     int c = 0;
-    for (int j = lane; j < S; j += 64) c += w[(size_t)ray * S + j] > 0.f ? 1 : 0;
+    double carry = 0.0;
+    for (int j0 = 0; j0 < S; j0 += 64) c += sel_predicate(w, sigma, z, ray, S, j0 + lane, lane, carry) ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if (lane == 0) cnt[ray] = c;
@@ -1062,15 +1089,16 @@ __global__ __launch_bounds__(256) void vfn_sel_scan_kernel(const int32_t* cnt, i
     if (t == 255) k_dev[0] = s_sum[255];
 }
 
-__global__ void vfn_sel_compact_kernel(const float* w, int n_rays, int S, const int32_t* off, const float* points, const float* ray_dirs,
-                                       int32_t* sel_sorted, float* pts_sel, float* dirs_sel) {
+__global__ void vfn_sel_compact_kernel(const float* w, const float* sigma, const float* z, int n_rays, int S, const int32_t* off, const float* points,
+                                       const float* ray_dirs, int32_t* sel_sorted, float* pts_sel, float* dirs_sel) {
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (ray >= n_rays) return;
     int base = off[ray];
     const float dx = ray_dirs[(size_t)ray * 3 + 0], dy = ray_dirs[(size_t)ray * 3 + 1], dz = ray_dirs[(size_t)ray * 3 + 2];
+    double carry = 0.0;
     for (int j0 = 0; j0 < S; j0 += 64) {
         const int j = j0 + lane;
-        const bool sel = j < S && w[(size_t)ray * S + j] > 0.f;
+        const bool sel = sel_predicate(w, sigma, z, ray, S, j, lane, carry);
         const unsigned long long mask = __ballot(sel);
         if (sel) {
             const int k = base + __popcll(mask & ((1ull << lane) - 1ull));
@@ -1094,19 +1122,31 @@ __global__ void vfn_sel_rows3_kernel(const float* a, const int32_t* index, const
 
 }  // namespace
 
-// weights[N,S] (sorted order), points[N,S,3], ray_dirs[N,3] -> k_dev[0] = number K of samples with w > 0 (device memory; the host never
+// weights[N,S] (sorted order), points[N,S,3], ray_dirs[N,3] -> k_dev[0] = number K of selected samples (device memory; the host never
 // learns it), and for k < K, in ray order: sel_sorted[k] = the sample's index ray * S + j, pts_sel[k], dirs_sel[k].  cnt / off: [N] scratch.
-int vfn_internal_select_positive(const float* weights, int n_rays, int n_samples, const float* points, const float* ray_dirs, int32_t* cnt,
-                                 int32_t* off, int32_t* k_dev, int32_t* sel_sorted, float* pts_sel, float* dirs_sel, void* stream) {
+// sigma == z_vals == NULL: the samples with w > 0 (forward-only renders); with sigma[N,S] and z_vals[N,S]: also those whose weight is
+// zero by an underflowed alpha only (sel_predicate above: what a training step's gradients need).
+int vfn_internal_select_positive(const float* weights, const float* sigma, const float* z_vals, int n_rays, int n_samples, const float* points,
+                                 const float* ray_dirs, int32_t* cnt, int32_t* off, int32_t* k_dev, int32_t* sel_sorted, float* pts_sel,
+                                 float* dirs_sel, void* stream) {
+    VFN_REQUIRE((sigma == nullptr) == (z_vals == nullptr), "vfn_internal_select_positive: sigma and z_vals come together");
     VFN_REQUIRE(weights && points && ray_dirs && cnt && off && k_dev && sel_sorted && pts_sel && dirs_sel && n_rays > 0 && n_samples > 0,
                 "vfn_internal_select_positive: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const unsigned blocks = (unsigned)((n_rays + 3) / 4);
-    hipLaunchKernelGGL(vfn_sel_count_kernel, dim3(blocks), dim3(256), 0, s, weights, n_rays, n_samples, cnt);
+    hipLaunchKernelGGL(vfn_sel_count_kernel, dim3(blocks), dim3(256), 0, s, weights, sigma, z_vals, n_rays, n_samples, cnt);
     hipLaunchKernelGGL(vfn_sel_scan_kernel, dim3(1), dim3(256), 0, s, cnt, n_rays, off, k_dev);
-    hipLaunchKernelGGL(vfn_sel_compact_kernel, dim3(blocks), dim3(256), 0, s, weights, n_rays, n_samples, off, points, ray_dirs, sel_sorted, pts_sel,
-                       dirs_sel);
+    hipLaunchKernelGGL(vfn_sel_compact_kernel, dim3(blocks), dim3(256), 0, s, weights, sigma, z_vals, n_rays, n_samples, off, points, ray_dirs,
+                       sel_sorted, pts_sel, dirs_sel);
     return vfn_check_launch("sample selection (w > 0)");
+}
+
+extern "C" int vfn_select_samples(const float* weights, const float* sigma, const float* z_vals, int32_t n_rays, int32_t n_samples, const float* points,
+                                  const float* ray_dirs, int32_t* scratch, int32_t* count, int32_t* index, float* points_sel, float* dirs_sel,
+                                  void* stream) {
+    VFN_REQUIRE(scratch && count, "vfn_select_samples: NULL scratch / count");
+    return vfn_internal_select_positive(weights, sigma, z_vals, n_rays, n_samples, points, ray_dirs, scratch, scratch + n_rays, count, index, points_sel,
+                                        dirs_sel, stream);
 }
 
 // gather != 0: out[k] = a[index[k]]; else out[index[k]] = a[k]; for the k < *k_dev (<= capacity) selected rows of [., 3] arrays

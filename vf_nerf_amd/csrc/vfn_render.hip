@@ -146,7 +146,7 @@ extern "C" int vfn_render_fwd(const vfn_render_params* p, const vfn_net_geom* vf
         dq.n_samples = st;
         rc = vfn_ray_density_weights(&dq, normals, ray_dirs, z_vals, density_scalars, nullptr, nullptr, weights, nullptr, nullptr, nullptr, stream);
         if (rc != VFN_OK) return rc;
-        rc = vfn_internal_select_positive(weights, n, st, points, ray_dirs, w.cnt, w.off, w.k_dev, w.sel_sorted, w.pts_sel, w.dirs_sel, stream);
+        rc = vfn_internal_select_positive(weights, nullptr, nullptr, n, st, points, ray_dirs, w.cnt, w.off, w.k_dev, w.sel_sorted, w.pts_sel, w.dirs_sel, stream);
         if (rc != VFN_OK) return rc;
         if (hipMemsetAsync(colors, 0, (size_t)n * st * 3 * sizeof(float), (hipStream_t)stream) != hipSuccess) {
             vfn_set_error("vfn_render_fwd: could not clear the colours");

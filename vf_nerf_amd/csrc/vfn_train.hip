@@ -387,9 +387,12 @@ int step_render(StepCtx& c) {
         }
         // normals to their sorted positions, weights (no colours yet)
         STEP(vfn_scatter_rows3(w.normals_s, nullptr, w.dst, w.m, io->normals, nullptr, s));
-        STEP(vfn_ray_density_weights(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, nullptr, nullptr, io->weights, nullptr, nullptr, nullptr, s));
-        // the samples with w > 0, compacted in ray order; their count stays on the device
-        STEP(vfn_internal_select_positive(io->weights, n, st, io->points, io->ray_dirs, w.cnt, w.off, w.k_dev, w.sel_sorted, w.pts_sel, w.dirs_sel, s));
+        // (sigma for the selection below goes through w.dc: the sorted colour gradients, written by the backward only)
+        STEP(vfn_ray_density_weights(&dp, io->normals, io->ray_dirs, io->z_vals, w.scal, nullptr, w.dc, io->weights, nullptr, nullptr, nullptr, s));
+        // the samples whose colour can reach an output or a gradient — w > 0, or w = 0 by an underflowed alpha alone (sigma > 0, T > 0,
+        // delta > 0: d w / d sigma is not zero there) — compacted in ray order; their count stays on the device
+        STEP(vfn_internal_select_positive(io->weights, w.dc, io->z_vals, n, st, io->points, io->ray_dirs, w.cnt, w.off, w.k_dev, w.sel_sorted, w.pts_sel,
+                                          w.dirs_sel, s));
         // region 2: the fused saving forward (vector-field net + rendering net) on the selected samples only
         STEP(vfn_internal_fused16_fwd_train_at(io->vf_geom, io->vf_packed16, io->rn_geom, io->rn_packed16, w.pts_sel, w.dirs_sel, w.cap, w.k_dev, 1,
                                                w.normals_sel, w.colors_sel, saved_f, w.aux_vf, w.aux_rn, w.masks, p->save_flags, w.r2_first, w.total,

@@ -135,11 +135,55 @@ class DeferredScalar:
     def conjugate(self):
         return float(self)
 
+    # -- leaving the process / entering numpy: as the float ------------------------------------------
+    def __reduce__(self):
+        """pickle / copy.deepcopy / multiprocessing queues: the value travels as a plain ``float`` (the device vector does not)."""
+        return (float, (float(self),))
+
+    def __copy__(self):
+        return float(self)
+
+    def __deepcopy__(self, memo):
+        return float(self)
+
+    def __array__(self, dtype=None, copy=None):
+        """``np.asarray(x)``, ``np.asarray([x, y])``, ``np.mean([...])``: a float64 scalar array, so that a list of them becomes a float64
+        array and not an object array."""
+        import numpy as np
+        return np.asarray(float(self), dtype=dtype or np.float64)
+
+    def as_integer_ratio(self):
+        return float(self).as_integer_ratio()
+
+    def hex(self) -> str:
+        return float(self).hex()
+
 
 for _n in ("__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__", "__rtruediv__", "__floordiv__", "__rfloordiv__", "__mod__", "__rmod__",
            "__pow__", "__rpow__", "__divmod__", "__rdivmod__", "__eq__", "__ne__", "__lt__", "__le__", "__gt__", "__ge__"):
     setattr(DeferredScalar, _n, _binary(_n))
 numbers.Real.register(DeferredScalar)
+
+
+def resolve(obj):
+    """``obj`` with every deferred scalar inside it (dicts, lists, tuples, nested) replaced by its ``float`` — what a logger does before it
+    hands a step's numbers to code that insists on the exact type (``json.dumps`` without ``default=``, ``isinstance(x, float)``,
+    msgpack).  One device read-back per distinct step vector, however many entries are read."""
+    if isinstance(obj, DeferredScalar):
+        return float(obj)
+    if isinstance(obj, dict):
+        return {k: resolve(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(resolve(v) for v in obj)
+    return obj
+
+
+def json_default(obj):
+    """``json.dumps(payload, default=deferred.json_default)`` (``default=float`` works as well): the encoder's hook for types it does not
+    know; deferred scalars leave as floats, anything else is refused as json itself would."""
+    if isinstance(obj, DeferredScalar):
+        return float(obj)
+    raise TypeError(f"Object of type {type(obj).__name__} is not JSON serializable")
 
 
 class LossTensor(torch.Tensor):

@@ -36,8 +36,15 @@ def _ensure_package(name: str) -> None:
         sys.modules[name] = pkg
 
 
-def install(patch_evaluator: bool = True) -> None:
-    """``patch_evaluator=False`` leaves ``evaluation.methods.render_images`` the reference's own loop (one upload, one ``model.render`` and
+def install(patch_evaluator: bool = True, patch_clip: bool = True, deferred_scalars=None) -> None:
+    """``patch_clip=False`` leaves ``torch.nn.utils.clip_grad_norm_`` PyTorch's own function (no process-wide replacement): a step session then
+    parks its gradient in the optimizer's flat buffer with every ``param.grad`` None, the trainer's clip call finds nothing to scale, and
+    ``optimizer.step()`` all-reduces (more than one rank), clips with the model's ``scheduler_config.clip_norm`` — the value the trainer
+    passes — and updates (optim.CLIP_INSIDE_STEP; SURVEY Q4's double clip of the aliased parameters is kept: same kernel).
+    ``deferred_scalars`` (None: leave as is): False makes ``loss.item()`` / ``losses_dict[key]`` plain floats at once — a per-step logger
+    that needs the exact type (``json.dumps`` without ``default=``, ``isinstance(x, float)``) pays a device synchronisation per step for it;
+    ``vf_nerf_amd.deferred.resolve(payload)`` converts at the logger instead.
+    ``patch_evaluator=False`` leaves ``evaluation.methods.render_images`` the reference's own loop (one upload, one ``model.render`` and
     six ``.cpu()`` read-backs per 512-ray chunk): every call of it still lands on the HIP ``render()``; what it gives up is the grouping
     into chip-filling chunks and the single download per image (profiles/r05/bench_view_as_evaluator.json: both loops timed)."""
     for dotted, module in _ALIASES.items():
@@ -95,8 +102,15 @@ def install(patch_evaluator: bool = True) -> None:
     except Exception:
         pass
 
-
-    _patch_clip_grad_norm()
+    from . import optim
+    if patch_clip:
+        _patch_clip_grad_norm()
+        optim.CLIP_INSIDE_STEP = False
+    else:
+        uninstall_clip_grad_norm()
+        optim.CLIP_INSIDE_STEP = True
+    if deferred_scalars is not None:
+        loss.DEFERRED_SCALARS = bool(deferred_scalars)
 
 
 def cache_centroid(cls) -> None:
@@ -132,6 +146,22 @@ def cache_centroid(cls) -> None:
 # the wrapped clip_grad_norm_ first averages the gradients of the list it was given over the ranks — ONE all-reduce of the flat gradient
 # buffer when the list is the flat optimizer's — so that every replica clips and steps identically.  False: the caller does it.
 data_parallel = True
+
+
+def world_size() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def all_reduce_flat(f) -> bool:
+    """Mean over the ranks of a FlatAdam's flat gradient buffer (ONE all-reduce of 805 780 fp32 on the shipped geometry)."""
+    import torch.distributed as dist
+    world = world_size()
+    if world < 2:
+        return False
+    dist.all_reduce(f["grad"], op=dist.ReduceOp.SUM)
+    f["grad"].div_(world)
+    return True
 
 
 def all_reduce_gradients(plist) -> bool:

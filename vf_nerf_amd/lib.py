@@ -37,6 +37,7 @@ EXPORTS = (
     "vfn_vf_loss_workspace_bytes", "vfn_vf_loss_fwd", "vfn_vf_loss_bwd", "vfn_train_step", "vfn_train_step_workspace_bytes",
     "vfn_train_step_workspace_layout", "vfn_train_step_supervision_points", "vfn_train_step_supervision_forward", "vfn_train_step_supervision_backward",
     "vfn_linear_rows_dx_sums", "vfn_weight_grad_partials_bf16_ld", "vfn_linear_rows_ws", "vfn_linear_rows_wplanes_bytes",
+    "vfn_select_samples",
 )
 
 
@@ -1053,6 +1054,26 @@ def vf_render_fused16_scatter(vf_geom, vf_packed16, rn_geom, rn_packed16, points
                                                 C.c_int32(samples_per_ray), _ptr(out_index, "out_index", torch.int32),
                                                 _ptr(normals, "normals"), _ptr(colors, "colors"), _stream()),
            "vfn_vf_render_fused16_scatter")
+
+
+def select_samples(weights, points, ray_dirs, sigma=None, z_vals=None):
+    """The sparse colour branch's sample selection on its own (vfn_select_samples) -> the selected indices ray * S + j as a Python list
+    (synchronises: tests and diagnostics).  ``sigma`` / ``z_vals`` given: the training selection."""
+    n, s = weights.shape
+    dev = weights.device
+    scratch = torch.empty(2 * n, dtype=torch.int32, device=dev)
+    count = torch.zeros(4, dtype=torch.int32, device=dev)
+    index = torch.empty(n * s, dtype=torch.int32, device=dev)
+    pts_sel, dirs_sel = torch.empty(n * s, 3, device=dev), torch.empty(n * s, 3, device=dev)
+    _check(load().vfn_select_samples(_ptr(weights, "weights"), _ptr(sigma, "sigma"), _ptr(z_vals, "z_vals"), C.c_int32(n), C.c_int32(s),
+                                     _ptr(points, "points"), _ptr(ray_dirs, "ray_dirs"), _ptr(scratch, "scratch", torch.int32),
+                                     _ptr(count, "count", torch.int32), _ptr(index, "index", torch.int32), _ptr(pts_sel, "points_sel"),
+                                     _ptr(dirs_sel, "dirs_sel"), _stream()), "vfn_select_samples")
+    k = int(count[0])
+    got = index[:k].tolist()
+    flat = points.reshape(-1, 3)
+    assert torch.equal(pts_sel[:k], flat[index[:k].long()]) and torch.equal(dirs_sel[:k], ray_dirs[(index[:k] // s).long()])
+    return got
 
 
 def scatter_rows3(a, b, index, out_a, out_b) -> None:

@@ -23,7 +23,7 @@ from torch import nn
 from . import lib
 from .density import LaplaceDensity
 from .networks import RenderingNetwork, VectorFieldNetwork
-from .render_output import NerfOutput, RepeatedRows
+from .render_output import LazyColours, NerfOutput, RepeatedRows
 from .samplers import RangeFineSampler, UniformSampler
 
 
@@ -180,8 +180,8 @@ class VectorFieldNerf:
         # Sparse colours (opt-in; gradient-free one-call renders): rgb = sum_s w_s c_s needs a colour only where w_s != 0 — 3-7 % of the
         # samples — so the vector-field net runs on every sample with its vector-only launch and the fused VF + rendering launch on the
         # compacted list of samples with w > 0 only (csrc/vfn_render.hip).  rgb, depth, weights, normals, z_vals, points: bit-identical;
-        # ``coarse_colors`` holds zeros where w = 0 (the reference has no consumer of that field: only vector_field_nerf.py:338 writes
-        # it).  evaluator.render_view switches it on for its own calls; render() itself stays dense.
+        # ``coarse_colors`` (no consumer in the reference: only vector_field_nerf.py:338 writes it) is completed on first access by a dense
+        # launch (render_output.LazyColours).  evaluator.render_view switches it on for its own calls; a gradient-free render() stays dense.
         self.sparse_colours = False
         self._render_ws: Dict[tuple, torch.Tensor] = {}
         # A grad-mode render() in the shipped regime opens a STEP SESSION (stepengine.py): the render and, later, its backward are one C call
@@ -490,10 +490,35 @@ class VectorFieldNerf:
         if white:
             rgb = rgb + (1. - o["weights"].sum(-1)[..., None])
         rep_dirs = RepeatedRows(o["ray_dirs"], s_t)            # [N * S_t, 3] on first access (nothing on the hot path reads it)
+        colours = o["colors"]
+        if rp.sparse_colours:      # the colours of the samples the sparse render skipped: evaluated if somebody reads the field
+            colours = LazyColours(colours, self._dense_colours_fill(o["points"], o["ray_dirs"], n, s_t, int(self.colour_products)))
         return NerfOutput(points_coarse=o["points"], points_fine=None, coarse_normals=o["normals"].view(n, s_t, 3),
                           coarse_rgb_values=rgb, coarse_depth_map=o["depth"], fine_normals=None, fine_rgb_values=None,
                           fine_depth_map=None, z_vals=o["z_vals"], directional_derivtives=None, ray_dirs=rep_dirs,
-                          coarse_colors=o["colors"])
+                          coarse_colors=colours)
+
+    def _dense_colours_fill(self, pts, ray_dirs, n: int, s_t: int, products: int):
+        """-> fill() for render_output.LazyColours: the dense gradient-free fused launch on a render's points, refusing weights newer than the render's."""
+        import weakref
+        vf, rn = self.vector_field_network, self.rendering_network
+        keys = (vf._pack_key()[1], rn._pack_key()[1])
+        model_ref = weakref.ref(self)
+
+        def fill():
+            m = model_ref()
+            if m is None:
+                raise RuntimeError("coarse_colors: the model of this render no longer exists")
+            vf, rn = m.vector_field_network, m.rendering_network
+            if (vf._pack_key()[1], rn._pack_key()[1]) != keys:
+                raise RuntimeError("coarse_colors of a training step's render is filled on first access with the weights the render saw: read it "
+                                   "before optimizer.step(), or set model.eager_session_colours = True (or model.sparse_colour_training = False)")
+            with torch.no_grad():
+                _, dense = lib.vf_render_fused16_fwd(vf.geometry(), vf.packed16_weights(), rn.geometry(), rn.packed16_weights(), pts.view(-1, 3),
+                                                     ray_dirs.view(n, 3), s_t, colour_products=products if products in (2, 3) else 3)
+            return dense
+
+        return fill
 
     # ---------------------------------------------------------------------------------------------
     # the hot path

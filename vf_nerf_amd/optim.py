@@ -23,6 +23,13 @@ from torch.optim.adam import adam as _functional_adam
 # optimizer); an entry whose parameter has died (its id may be reused) is recognised by the identity check and dropped.
 _OWNERS = {}
 
+# dropin.install(patch_clip=False): torch.nn.utils.clip_grad_norm_ stays PyTorch's own function.  A step session's backward then leaves
+# every ``param.grad`` None (the gradient sits in the flat buffer only), so the trainer's clip call (train/vector_field_nerf_train.py:
+# 254-255) finds nothing to scale, and FlatAdam.step() — the next call the trainer makes — all-reduces (more than one rank), clips with
+# the model's configured clip_norm (the value the trainer passes: config.vf_nerf_config.scheduler_config.clip_norm) and updates: the same
+# launches in the same order as the wrapped clip_grad_norm_ followed by step().
+CLIP_INSIDE_STEP = False
+
 
 def _register_owner(p: torch.nn.Parameter, opt) -> None:
     import weakref
@@ -240,6 +247,7 @@ class FlatAdam(SequentialAdam):
         if f is None:
             return super().zero_grad(set_to_none=set_to_none)
         f["grad"].zero_()
+        f.pop("parked_max_norm", None)
         for (p, off, n, _), view in zip(f["entries"], self._grad_views(f)):     # (keeps the views: setting .grad to None would detach them from the buffer)
             if p.grad is not view:
                 p.grad = view
@@ -283,7 +291,28 @@ class FlatAdam(SequentialAdam):
             with torch.enable_grad():
                 loss = closure()
         from . import lib
-        self._rebind_grads(f)
+        parked = f.pop("parked_max_norm", None)
+        if parked is not None:
+            # CLIP_INSIDE_STEP: the session's backward parked the gradient in the flat buffer with every param.grad None — here a parked
+            # gradient, NOT the zero gradient _rebind_grads takes a None for.  All-reduce | clip | update, as the wrapped clip + step() do.
+            for (p, off, n, _), view in zip(f["entries"], self._grad_views(f)):
+                if p.grad is None:
+                    p.grad = view
+                elif p.grad is not view:              # the caller put a gradient of its own there after the backward: it joins the parked one
+                    view.add_(p.grad)
+                    p.grad = view
+            from . import dropin
+            if dropin.data_parallel:
+                dropin.all_reduce_flat(f)
+            lib.flat_clip_grad_norm(f["grad"], f["regions"], float(parked), f["workspace"], f["out2"])
+        else:
+            self._rebind_grads(f)
+            if CLIP_INSIDE_STEP:
+                from . import dropin
+                if dropin.data_parallel and dropin.world_size() > 1:
+                    raise RuntimeError("dropin.install(patch_clip=False) with more than one rank: the gradient all-reduce rides on the step session's "
+                                       "optimizer.step(); this step did not go through a session (stepengine.StepEngine.of(model).why_not) — "
+                                       "use install(patch_clip=True) or all-reduce model.optimizer's flat gradient yourself")
         # the owning model's step engine (stepengine.py) applies the update and re-packs the weight packs in one C call when its structs
         # describe these buffers (after a training render of the shipped regime they do)
         eng = self.step_engine() if self.step_engine is not None else None

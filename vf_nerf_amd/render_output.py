@@ -51,11 +51,31 @@ class RepeatedRows:
         return self.rows.reshape(n, 1, 3).expand(n, self.times, 3).reshape(-1, 3)
 
 
+class LazyColours:
+    """``coarse_colors`` of a render that ran the rendering net on the SELECTED samples only (the sparse colour branch of a training step's
+    render, or ``model.sparse_colours``): ``sparse[M,3]`` holds the selected samples' colours and zeros elsewhere.  The reference returns the
+    rendering net's colour of EVERY sample (models/nerf/vector_field_nerf.py:315-338) although nothing in its trainer, evaluator or loss reads
+    the field; so the other rows are evaluated when — and only when — somebody does: ``fill()`` runs the dense gradient-free fused launch on
+    the render's points with the weights the render saw and returns [M,3]; rows the render computed keep the render's values."""
+
+    def __init__(self, sparse: torch.Tensor, fill) -> None:
+        self.sparse, self._fill = sparse, fill
+
+    def materialise(self) -> torch.Tensor:
+        dense = self._fill()
+        self._fill = None
+        ran = (self.sparse != 0).any(dim=-1, keepdim=True)       # (a sigmoid is never exactly 0: a zero row was not evaluated)
+        return torch.where(ran, self.sparse, dense)
+
+
 def _getattribute(self, name):
     value = object.__getattribute__(self, name)
     if name == "ray_dirs" and isinstance(value, RepeatedRows):
         value = value.materialise()
         object.__setattr__(self, "ray_dirs", value)
+    elif name == "coarse_colors" and isinstance(value, LazyColours):
+        value = value.materialise()
+        object.__setattr__(self, "coarse_colors", value)
     return value
 
 

@@ -23,7 +23,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import lib
-from .render_output import NerfOutput, RepeatedRows
+from .render_output import LazyColours, NerfOutput, RepeatedRows
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -413,10 +413,18 @@ class StepEngine:
         _current = weakref.ref(session)
         model.vector_field_network._step_ws = None      # (later vector-field forwards that do not join the session stand alone)
         ray_dirs, z, pts, _, colors, weights = views[:6]
+        colours_out = colors.view(n * s_t, 3)
+        if pr.sparse_colours:
+            # the reference returns every sample's colour (vector_field_nerf.py:338); the step evaluated the selected ones.  The others are
+            # filled on first access (render_output.LazyColours) by the dense gradient-free launch — with THIS step's weights, so before
+            # optimizer.step(); model.eager_session_colours = True fills them here (one more fused forward per step)
+            colours_out = LazyColours(colours_out, model._dense_colours_fill(pts, ray_dirs, n, s_t, int(pr.forward_products)))
+            if getattr(model, "eager_session_colours", False):
+                colours_out = colours_out.materialise()
         return NerfOutput(points_coarse=pts.view(n, s_t, 3), points_fine=None, coarse_normals=normals.view(n, s_t, 3),
                           coarse_rgb_values=rgb.view(n, 3), coarse_depth_map=depth.view(n, 1), fine_normals=None, fine_rgb_values=None,
                           fine_depth_map=None, z_vals=z.view(n, s_t), directional_derivtives=None, ray_dirs=RepeatedRows(ray_dirs.view(n, 3), s_t),
-                          coarse_colors=colors.view(n * s_t, 3))
+                          coarse_colors=colours_out)
 
 
 class StepSession:
@@ -609,6 +617,13 @@ class StepSession:
         self.backward_done = True
         self.open = False
         self.model._last_colour_counts = self.out_norm[2:4]
+        from . import optim
+        if optim.CLIP_INSIDE_STEP:
+            # torch.nn.utils.clip_grad_norm_ is PyTorch's own (dropin.install(patch_clip=False)): the gradient stays parked in the flat
+            # buffer, invisible to it; optimizer.step() all-reduces, clips with the configured norm and updates (optim.FlatAdam.step)
+            for p, _, _, _ in self.flat["entries"]:
+                p.grad = None
+            self.flat["parked_max_norm"] = float(self.model.config.scheduler_config.clip_norm)
 
 
 class _SessionRender(torch.autograd.Function):
