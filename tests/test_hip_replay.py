@@ -1,0 +1,79 @@
+"""The reference trainer's RECORDED run replayed on the HIP path ("loss-curve agreement over
+>= 100 steps").
+
+``tests/golden/trained_256_run.npz`` = the task of the run recorded in ``trained_256.npz`` (batches, targets, initial vector head) and the
+curves of the reference's own ``train_epoch`` (train/vector_field_nerf_train.py:161-292) on it: the recorded run — reproduced bit for bit
+when the fixture was generated — and four more under other torch / numpy random streams.  ``tools/replay_reference_run.py`` runs the same
+1 200 steps through ``tools/reference_sequence.ReferenceLoop`` (the trainer's loop body call for call through the drop-in: the step session)
+over device random streams.  Training is chaotic, so the comparison is of FAMILIES of runs: the replays' mean per 100-step window against
+the envelope of the reference's own runs.  The written report of the same comparison: profiles/r06/replay_reference_run.md."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "tools"))
+
+
+def _family(kernels, streams):
+    import replay_reference_run as rr
+    raw, recipe = rr.load_task()
+    runs = [rr.replay(s, kernels) for s in range(streams)]
+    return rr, raw, runs, rr.compare(rr.reference_curves(raw), runs)
+
+
+def _report(tag, runs, cmp):
+    p, c = cmp["psnr_vs_teacher_db"], cmp["clip_norm_median"]
+    print(f"{tag}: {len(runs)} streams, {runs[0]['issued_as']}, {1e3 * sum(r['seconds'] for r in runs) / sum(r['steps'] for r in runs):.2f} ms/step; "
+          f"worst window {cmp['worst_window_outside_in_widths']} widths outside the reference envelope; final PSNR {p['replay_after']} "
+          f"(mean {p['replay_after_mean']}; reference runs {p['reference_after']}, mean {p['reference_after_mean']}); "
+          f"median clip norm ratio {c['ratio_of_family_means']}")
+    for k, q in cmp["quantities"].items():
+        print(f"   {k:18s} ratio of window means (replay / reference): " + " ".join(f"{r:.2f}" for r in q["ratio_of_means"]))
+
+
+def _assert_family_matches(cmp, runs, widths):
+    steps = runs[0]["steps"]
+    assert steps == 1200 and all(np.isfinite(r["loss"]).all() and np.isfinite(r["terms"]).all() for r in runs)
+    # the task IS the recorded one: the untrained student renders the teacher's targets at the reference's PSNR
+    p = cmp["psnr_vs_teacher_db"]
+    assert abs(p["replay_before"][0] - p["reference_before"]) < 0.02
+    # per 100-step window and quantity (total, rgb, depth, unit norm, supervision): the replays' mean inside the envelope of the reference's
+    # own runs, give or take `widths` envelope widths
+    for k, q in cmp["quantities"].items():
+        worst = max(q["replay_mean_outside_reference_envelope_in_widths"])
+        assert worst <= widths, (k, q["replay_mean_outside_reference_envelope_in_widths"])
+        # ... and over the whole run no systematic offset: the mean of the window ratios within 10 % (total, rgb, depth) / 20 % (the two
+        # small terms, whose reference runs differ by +- 30 % per window among themselves)
+        ratio = float(np.mean(q["ratio_of_means"]))
+        assert abs(ratio - 1.0) < (0.10 if k in ("loss", "rgb_loss", "depth_loss") else 0.20), (k, ratio)
+    # the loss falls as the reference's does (first window / last window)
+    q = cmp["quantities"]["loss"]
+    assert q["replay_mean"][-1] < 0.45 * q["replay_mean"][0] and abs(q["replay_mean"][-1] / q["reference_mean"][-1] - 1.0) < 0.10
+    # final PSNR against the teacher: the family mean within 0.7 dB of the reference family's, every run inside the reference's range +- 0.7 dB
+    lo, hi = p["reference_after_min_max"]
+    assert abs(p["replay_after_mean"] - p["reference_after_mean"]) < 0.7
+    assert all(lo - 0.7 <= v <= hi + 0.7 for v in p["replay_after"]), p["replay_after"]
+    # clip_grad_norm_'s value (Q4: the aliased parameters counted twice): median over the run, family means within 10 %
+    assert abs(cmp["clip_norm_median"]["ratio_of_family_means"] - 1.0) < 0.10
+
+
+def test_recorded_reference_run_replays_on_the_default_kernels():
+    rr, raw, runs, cmp = _family("default", 6)
+    _report("default kernels (f16x3, 16-bit storages)", runs, cmp)
+    assert all(r["issued_as"] == "step session" and r["guard_switched_to_fp32"] is None for r in runs)
+    assert float(raw["runs.reproduces_recorded"][0]) == 0.0          # (the fixture's own pin: row 0 IS trained_256.npz's recorded curve)
+    assert np.array_equal(raw["runs.loss"][0], np.load(os.path.join(REPO, "tests", "golden", "trained_256.npz"))["curve.loss"])
+    _assert_family_matches(cmp, runs, widths=0.5)
+
+
+def test_recorded_reference_run_replays_on_the_exact_fp32_kernels():
+    """The control: exact-fp32 MFMA kernels with fp32 storages, launch-by-launch autograd — what the default family may differ from the
+    reference by is what THIS family differs by (both are families of chaotic runs around the same curves)."""
+    rr, raw, runs, cmp = _family("fp32", 4)
+    _report("exact-fp32 kernels, fp32 storages", runs, cmp)
+    assert all(r["issued_as"].startswith("launch by launch") for r in runs)
+    _assert_family_matches(cmp, runs, widths=0.75)
