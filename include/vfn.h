@@ -22,7 +22,7 @@ extern "C" {
 /* Bumped whenever a POD struct's layout or an entry point's signature changes (2: vfn_render_params.timing_events,
  * vfn_abi_struct_bytes; 3: vfn_f16x3_set_clock_probe, vfn_train_step, vfn_linear_rows_dx_sums; 4: the session form of vfn_train_step —
  * VFN_TRAIN_RENDER / VFN_TRAIN_BACKWARD, vfn_train_step_workspace_layout, vfn_train_step_supervision_points / _forward / _backward; 5: vfn_select_samples,
- * the training selection of vfn_train_step's sparse colour branch).  The Python binding reads this constant from this file and refuses a library
+ * the training selection of vfn_train_step's sparse colour branch, vfn_grid_lattice_points).  The Python binding reads this constant from this file and refuses a library
  * that reports another. */
 #define VFN_ABI_VERSION 5
 
@@ -634,6 +634,13 @@ int vfn_vf_render_fused16_fwd_train_at(const vfn_net_geom* vf_geom, const void* 
  * Dense-grid stages between the vector-field queries and the mesh triangulation (evaluation/utils/mc_utils.py,
  * evaluation/utils/guassian_smoothing.py).  Grid cell (i,j,k) -> (i n + j) n + k; field vt[n^3,3]; n <= 1024.
  * ============================================================================================= */
+/* evaluation/methods.py:194-208 fills samples[n^3,3] on the host with a SEPARABLE lattice: column 0 of cell (i,j,k) depends on i alone,
+ * column 1 on j, column 2 on k (index * voxel_size + origin + translation + centroid, in fp32).  Given the three axis tables
+ * axis0[n], axis1[n], axis2[n] (device; the caller reads them off the host tensor's first row / column / plane), writes
+ * points[count,3] = rows [row0, row0 + count) of that grid — the caller's values bit for bit — so the 12 B per point of
+ * mc_utils.get_set_predictions' upload (mc_utils.py:96-97) never crosses PCIe.  n <= 2048. */
+int vfn_grid_lattice_points(const float* axis0, const float* axis1, const float* axis2, int32_t n, int64_t row0, int64_t count,
+                            float* points, void* stream);
 /* mc_utils.py:34-86: out[n^3] = 1 where the flux of the normalised field through the cell's 8 corners is <= threshold
  * (-0.5 in the reference), else 0; cells of the last planes are 0. */
 int vfn_grid_divergence(const float* vt, int32_t n, float threshold, float* out, void* stream);

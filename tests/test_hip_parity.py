@@ -348,6 +348,46 @@ def test_grid_query_matches_full_forward():
     assert float(parts[0][3000:6000].abs().max()) == 0.0 and float(parts[1][:3000].abs().max()) == 0.0
 
 
+def test_grid_query_of_the_reference_lattice_needs_no_upload():
+    """evaluation/methods.py:190-208 builds the query grid on the host as a separable lattice; ``get_set_predictions`` regenerates it on the
+    device from its three axis tables (``vfn_grid_lattice_points``) while the host verifies the rows: the points are the host tensor's bit
+    for bit, so the predictions are the upload path's bit for bit — with a translation and a centroid in the grid, for one rank and for two.
+    A grid that only LOOKS like the lattice (one coordinate moved) is noticed and evaluated from the caller's tensor."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from vf_nerf_amd import grid, lib
+    fx, d = load_fixture("w1_det")
+    model = build_model(fx, d, device="cuda:0")
+    dec = model.fine_vector_field_network
+    res = 40
+    samples = bench.reference_lattice(res, scale=0.9, translation=(0.05, -0.1, 0.02), centroid=(0.0, 0.1, 0.45))
+    lat = grid.lattice_axes(samples)
+    pts = lib.grid_lattice_points(tuple(a.to(dev()) for a in lat[1:]), res, 12345, 30001)
+    assert torch.equal(pts.cpu(), samples[12345:12345 + 30001])               # the kernel: rows of the caller's grid, bit for bit
+    keep = grid.LATTICE_FAST_PATH
+    try:
+        grid.LATTICE_FAST_PATH = False
+        want = grid.get_set_predictions(dec, samples, 3000, dev())
+        assert grid.last_path == "upload"
+        grid.LATTICE_FAST_PATH = True
+        got = grid.get_set_predictions(dec, samples, 3000, dev())
+        assert grid.last_path == "lattice" and torch.equal(got, want)
+        parts = [grid.get_set_predictions(dec, samples, 3000, dev(), rank=r, world_size=2) for r in range(2)]
+        assert grid.last_path == "lattice" and torch.equal(parts[0] + parts[1], want)
+        cpu_sd = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
+        assert rel_err(got[::17], O.vf_mlp(samples[::17], cpu_sd, 6, (4,))[:, :3]) < 2e-5
+        almost = samples.clone()
+        almost[res ** 3 // 2 + 11, 0] += 1e-3
+        got2 = grid.get_set_predictions(dec, almost, 3000, dev())
+        assert grid.last_path == "upload"
+        grid.LATTICE_FAST_PATH = False
+        assert torch.equal(got2, grid.get_set_predictions(dec, almost, 3000, dev())) and not torch.equal(got2, want)
+    finally:
+        grid.LATTICE_FAST_PATH = keep
+
+
 def test_quaternion_pose_rays():
     """pose[N,7] = (qr,qi,qj,qk,tx,ty,tz): utils/rendering.py:27-33 + pinhole_model.quat_to_rot (CUDA-only in the
     reference, Q13), against the oracle's device-free restatement."""

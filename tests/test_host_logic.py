@@ -805,3 +805,36 @@ def test_install_can_leave_torchs_clip_grad_norm_alone():
     finally:
         dropin.install()
     assert torch.nn.utils.clip_grad_norm_.__module__ == "vf_nerf_amd.dropin" and optim.CLIP_INSIDE_STEP is False
+
+
+def test_separable_lattice_is_recognised_row_by_row():
+    """grid.lattice_axes / lattice_rows_match (the host side of get_set_predictions' lattice path): the grid evaluation/methods.py:190-208
+    builds — here with its own operations, a translation and a centroid — is recognised from its axis tables and verified bit for bit;
+    one perturbed coordinate, a NaN, another row order or another shape is refused; a rank verifies exactly the rows it evaluates."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from vf_nerf_amd import grid
+    res = 24
+    s = bench.reference_lattice(res, scale=1.3, translation=(0.1, -0.2, 0.05), centroid=(0.01, 0.3, 0.55))
+    lat = grid.lattice_axes(s)
+    assert lat is not None and lat[0] == res and all(a.shape == (res,) for a in lat[1:])
+    # the tables ARE the grid: cell (i, j, k) at row (i res + j) res + k
+    i, j, k = 5, 17, 3
+    assert torch.equal(s[(i * res + j) * res + k], torch.stack([lat[1][i], lat[2][j], lat[3][k]]))
+    all_rows = grid._rank_runs(res ** 3, 1000, 0, 1)
+    assert grid.lattice_rows_match(s, res, lat[1:], all_rows) and grid.lattice_rows_match(s, res, lat[1:], all_rows, workers=3)
+    covered = sorted(r for w in range(4) for r in grid._rank_runs(res ** 3, 1000, w, 4))
+    assert covered[0][0] == 0 and covered[-1][1] == res ** 3 and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    bad = s.clone()
+    bad[res ** 3 // 3, 1] += 1e-6                                   # one coordinate of one row, off by an ulp or so
+    assert grid.lattice_axes(bad) is not None and not grid.lattice_rows_match(bad, res, lat[1:], all_rows)
+    owner = (res ** 3 // 3) // 1000 % 4                             # only the rank that evaluates that row needs to refuse it
+    for w in range(4):
+        assert grid.lattice_rows_match(bad, res, lat[1:], grid._rank_runs(res ** 3, 1000, w, 4)) == (w != owner)
+    nan = s.clone()
+    nan[77, 2] = float("nan")
+    assert not grid.lattice_rows_match(nan, res, lat[1:], all_rows)
+    assert grid.lattice_axes(s[:-1]) is None and grid.lattice_axes(s.double()) is None and grid.lattice_axes(torch.rand(res ** 3, 3)) is None
+    assert grid.lattice_axes(s.reshape(res, res, res, 3).permute(2, 1, 0, 3).reshape(-1, 3).contiguous()) is None      # k-major order
+    assert grid.lattice_axes(torch.cat([s, torch.ones(res ** 3, 1)], 1)) is None

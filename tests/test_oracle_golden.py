@@ -266,3 +266,33 @@ def test_attached_normals_gradients_match_reference():
     _, detached = oracle_gradients(dict(fx, detach_normals=True), d, model)
     k = "vf.layers.7.1.weight"
     assert grad_rel_err(detached[k], d[f"grad.{k}"]) > 1e-3, "the fixture must tell the two settings apart"
+
+
+def test_recorded_run_fixture_is_the_recorded_run():
+    """tests/golden/trained_256_run.npz (make_run_golden.py): the task of the run recorded in trained_256.npz.  Row 0 of its reference curves
+    IS the recorded curve (the reference trainer re-run on the regenerated batches reproduced it bit for bit), the initial weights rebuild
+    from the recipe + the stored vector head to the reference model's checksum, and the targets are what the teacher rendered (hit fraction
+    of the recorded run)."""
+    import ast
+    import os
+    import sys
+
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    run = np.load(os.path.join(here, "golden", "trained_256_run.npz"))
+    rec = np.load(os.path.join(here, "golden", "trained_256.npz"))
+    assert float(run["runs.reproduces_recorded"][0]) == 0.0 and np.array_equal(run["runs.loss"][0], rec["curve.loss"])
+    assert np.array_equal(run["runs.terms"][0], rec["curve.terms"]) and np.array_equal(run["runs.clip"][0], rec["curve.clip"])
+    assert np.array_equal(run["runs.psnr_before_after"][0], rec["curve.psnr_before_after"])
+    recipe = ast.literal_eval(str(run["train_recipe"]))
+    assert recipe == ast.literal_eval(str(rec["train_recipe"]))
+    r, steps = run["runs.loss"].shape
+    assert r >= 4 and steps == recipe["epochs"] * recipe["steps_per_epoch"] and len({tuple(s) for s in run["runs.seeds"].tolist()}) == r
+    assert run["batch.uv"].shape == (recipe["steps_per_epoch"], recipe["n_rays"], 2) and run["batch.rgb"].shape == (recipe["steps_per_epoch"], recipe["n_rays"], 3)
+    hit = float((run["batch.depth"] > 0.02).mean())
+    assert abs(hit - float(rec["curve.target_hit_fraction"][0])) < 1e-6
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "tools"))
+    import replay_reference_run as rr
+    import torch
+    model = rr.build_student(run, recipe, torch.device("cpu"))      # (asserts the checksum of the reference model the run started from)
+    assert model.ray_sampler.N_samples == recipe["n_samples"]

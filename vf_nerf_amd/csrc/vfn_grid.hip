@@ -410,6 +410,44 @@ int launch_smooth(const SmoothArgs& a, hipStream_t s) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------------------------
+// lattice points: rows [row0, row0 + count) of the n^3 x 3 grid evaluation/methods.py:194-208 fills on the host, from its three AXIS
+// TABLES (the lattice is separable: column 0 depends on i alone, column 1 on j, column 2 on k — whatever fp32 expression filled
+// them, so the points are the caller's bit for bit).  12 B per point written, the tables (3 n floats) stay in L2.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void vfn_lattice_points_kernel(const float* __restrict__ ax0, const float* __restrict__ ax1,
+                                                                 const float* __restrict__ ax2, int n, long long row0, long long count,
+                                                                 float* __restrict__ out) {
+    // a lane owns four consecutive FLOATS of the [count, 3] output (16-byte stores): float f -> row f / 3, column f % 3
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long f0 = q * 4, total = count * 3;
+    if (f0 >= total) return;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long long f = f0 + e;
+        const long long row = row0 + f / 3;
+        const int c = (int)(f % 3);
+        const int k = (int)(row % n), j = (int)((row / n) % n), i = (int)(row / ((long long)n * n));
+        v[e] = f < total ? (c == 0 ? ax0[i] : (c == 1 ? ax1[j] : ax2[k])) : 0.f;
+    }
+    if (f0 + 4 <= total) *reinterpret_cast<float4*>(out + f0) = float4{v[0], v[1], v[2], v[3]};
+    else for (int e = 0; e < 4 && f0 + e < total; ++e) out[f0 + e] = v[e];
+}
+}  // namespace
+
+extern "C" int vfn_grid_lattice_points(const float* axis0, const float* axis1, const float* axis2, int32_t n, int64_t row0, int64_t count,
+                                       float* points, void* stream) {
+    VFN_REQUIRE(axis0 && axis1 && axis2 && points && n > 0 && n <= 2048 && row0 >= 0 && count >= 0 && row0 + count <= (int64_t)n * n * n,
+                "vfn_grid_lattice_points: bad argument (n = %d, rows [%lld, %lld))", n, (long long)row0, (long long)(row0 + count));
+    if (count == 0) return VFN_OK;
+    const long long quads = (count * 3 + 3) / 4;
+    hipLaunchKernelGGL(vfn_lattice_points_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, axis0, axis1, axis2, n,
+                       (long long)row0, (long long)count, points);
+    return vfn_check_launch("vfn_grid_lattice_points");
+}
+
 extern "C" int vfn_grid_divergence(const float* vt, int32_t n, float threshold, float* out, void* stream) {
     if (n <= 0) return VFN_OK;
     VFN_REQUIRE(vt && out, "vfn_grid_divergence: NULL argument");

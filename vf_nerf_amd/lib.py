@@ -37,7 +37,7 @@ EXPORTS = (
     "vfn_vf_loss_workspace_bytes", "vfn_vf_loss_fwd", "vfn_vf_loss_bwd", "vfn_train_step", "vfn_train_step_workspace_bytes",
     "vfn_train_step_workspace_layout", "vfn_train_step_supervision_points", "vfn_train_step_supervision_forward", "vfn_train_step_supervision_backward",
     "vfn_linear_rows_dx_sums", "vfn_weight_grad_partials_bf16_ld", "vfn_linear_rows_ws", "vfn_linear_rows_wplanes_bytes",
-    "vfn_select_samples",
+    "vfn_select_samples", "vfn_grid_lattice_points",
 )
 
 
@@ -1159,6 +1159,16 @@ def vf_render_fused16_fwd(vf_geom, vf_packed16, rn_geom, rn_packed16, points, ra
 # ------------------------------------------------------------------------------------------------
 # dense-grid stages (mesh extraction)
 # ------------------------------------------------------------------------------------------------
+def grid_lattice_points(axes, n: int, row0: int, count: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Rows [row0, row0 + count) of the separable n^3 lattice with axis tables ``axes`` = (a0[n], a1[n], a2[n]) -> points[count,3]."""
+    a0, a1, a2 = axes
+    if out is None:
+        out = torch.empty(count, 3, device=a0.device)
+    _check(load().vfn_grid_lattice_points(_ptr(a0, "axis0"), _ptr(a1, "axis1"), _ptr(a2, "axis2"), C.c_int32(n), C.c_int64(row0), C.c_int64(count),
+                                          _ptr(out, "points"), _stream()), "vfn_grid_lattice_points")
+    return out
+
+
 def grid_divergence(vt: torch.Tensor, n: int, threshold: float = -0.5) -> torch.Tensor:
     out = torch.empty(n, n, n, device=vt.device)
     _check(load().vfn_grid_divergence(_ptr(vt, "vt"), C.c_int32(n), C.c_float(threshold), _ptr(out, "out"), _stream()),
