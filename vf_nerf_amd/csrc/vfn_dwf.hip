@@ -239,6 +239,11 @@ __global__ __launch_bounds__(256, 1) void vfn_dwf_kernel(const DwfBatch batch) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int pc = 8 * wave + r;
+#ifdef VFN_DWF_PROBE_HALF_DY
+                // TIMING PROBE (tools/probe_dwf_half_dy.sh; never in the product build): every second dY piece is not requested at all — the bytes
+                // an ideal, decode-free compaction of the ReLU-masked half of dY would save.  Results are wrong by construction.
+                if (r & 1) { ld_a[8 * gq + r] = u32x4{0u, 0u, 0u, 0u}; continue; }
+#endif
                 if (DM == DY_FRAG32) ld_a[8 * gq + r] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, lane * 16, (st + gq) * F_GROUP + pc * 1024, 0);
                 else { const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rs_a, lane * 8, (st + gq) * F_GROUP + pc * 512, 0); ld_a[8 * gq + r] = u32x4{h[0], h[1], 0u, 0u}; }
             }
