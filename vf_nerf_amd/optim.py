@@ -228,12 +228,14 @@ class FlatAdam(SequentialAdam):
     def _rebind_grads(self, f) -> None:
         """Every ``param.grad`` is (again) its view of the flat gradient buffer; a gradient that autograd or the caller put
         somewhere else is copied in.  The views are made once: the common case is fifty identity checks."""
+        parked = "parked_max_norm" in f           # CLIP_INSIDE_STEP: a None gradient is the PARKED one (the buffer holds it), not a zero one
         for (p, off, n, _), view in zip(f["entries"], self._grad_views(f)):
             g = p.grad
             if g is view:
                 continue
             if g is None:
-                view.zero_()                  # (None IS a zero gradient: the view must not bring back what an earlier step left in the buffer)
+                if not parked:
+                    view.zero_()              # (None IS a zero gradient: the view must not bring back what an earlier step left in the buffer)
                 p.grad = view
             elif g.data_ptr() != view.data_ptr():
                 view.copy_(g)
