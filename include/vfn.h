@@ -22,7 +22,7 @@ extern "C" {
 /* Bumped whenever a POD struct's layout or an entry point's signature changes (2: vfn_render_params.timing_events,
  * vfn_abi_struct_bytes; 3: vfn_f16x3_set_clock_probe, vfn_train_step, vfn_linear_rows_dx_sums; 4: the session form of vfn_train_step —
  * VFN_TRAIN_RENDER / VFN_TRAIN_BACKWARD, vfn_train_step_workspace_layout, vfn_train_step_supervision_points / _forward / _backward; 5: vfn_select_samples,
- * the training selection of vfn_train_step's sparse colour branch, vfn_grid_lattice_points).  The Python binding reads this constant from this file and refuses a library
+ * the training selection of vfn_train_step's sparse colour branch, vfn_grid_lattice_points, vfn_linear_rows_fold, vfn_weight_grad_partials_bf16_fold).  The Python binding reads this constant from this file and refuses a library
  * that reports another. */
 #define VFN_ABI_VERSION 5
 
@@ -387,6 +387,14 @@ int vfn_weight_grad_partials_bf16(const float* dy, const float* x, int64_t n_poi
  * 256-column block of the rendering net's 289-wide input or of the vector-field net's 259-wide output gradient (batchstat.py). */
 int vfn_weight_grad_partials_bf16_ld(const float* dy, int32_t ld_dy, const float* x, int32_t ld_x, int64_t n_points, int32_t groups,
                                      float* dw_part, float* db_part, int32_t x_f16, void* stream);
+/* The same with the ACTIVATION folded into the X operand's read (round 6, ABI 5): z_prev[M, ldz] is the previous layer's pre-BatchNorm
+ * output and the operand is post_prev * max(z * scale + shift, 0) on the first n_prev of the 256 columns (coef_prev = [4][n_prev]: scale |
+ * shift | mean | rstd, as vfn_bstat_finalize writes them) and post_prev * z on the others (the skip layer's re-injected encoding,
+ * vector_field_network.py:192-193) — vfn_bstat_relu_rows' expression value for value, so the activated matrix of a training-mode
+ * layer (vector_field_network.py:146-173 under model.train()) need not exist in HBM. */
+int vfn_weight_grad_partials_bf16_fold(const float* dy, int32_t ld_dy, const float* z_prev, int32_t ldz, const float* coef_prev,
+                                       int32_t n_prev, float post_prev, int64_t n_points, int32_t groups, float* dw_part,
+                                       float* db_part, void* stream);
 
 /* vfn_mlp_bwd_chain on the bf16 matrix cores (split operands, three products per K-block, fp32 accumulation; shipped layer
  * shapes only, others return VFN_ERR_UNSUPPORTED).  Takes its own TRANSPOSED bf16 packs (vfn_pack_weights_bwd16; re-run
@@ -851,6 +859,14 @@ int vfn_linear_rows_ws(int32_t transpose_w, const float* a, int32_t lda, const f
                        void* wplanes, void* stream);
 int64_t vfn_linear_rows_wplanes_bytes(int32_t n_out, int32_t k_in);
 int64_t vfn_linear_rows_stat_parts(int64_t m);
+/* A forward layer product with the PREVIOUS layer's BatchNorm + ReLU folded into its operand read (round 6, ABI 5):
+ * C[M, n_out] = act(z_prev) W^T + bias with act(z)[k] = post_prev * max(z[k] * scale[k] + shift[k], 0) for k < n_prev (coef_prev =
+ * [4][n_prev]) and post_prev * z[k] for n_prev <= k < k_in; arith 2 (three f16 products on split operands); 129 <= n_out <= 256;
+ * stats_part as vfn_linear_rows_ws; wplanes (its scratch for W's planes) is required.  Replaces the vfn_bstat_relu_rows pass + vfn_linear_rows_ws pair of a training-mode layer
+ * (models/vector_field/vector_field_network.py:177-208 with batch statistics): same operand values, one [M, 256] write and read less. */
+int vfn_linear_rows_fold(int32_t arith, const float* z_prev, int32_t ldz, const float* coef_prev, int32_t n_prev, float post_prev,
+                         const float* w, int32_t ldw, const float* bias, int64_t m, int32_t n_out, int32_t k_in, float* c, int32_t ldc,
+                         float* stats_part, void* wplanes, void* stream);
 /* The input-gradient product C[m][n_out] = dZ[m][k_in] W[k_in][n_out] (vfn_linear_rows with transpose_w = 1 | arith; arith = 4: three
  * bf16 products, 16 significant bits at fp32's exponent range — the arithmetic of the eval-mode dX chain, the default since round 5 — or
  * 6: bf16 in three parts, six products, 24 bits) that

@@ -49,6 +49,32 @@ class _State:
         self.batch_stats = True                # False: eval-mode BatchNorm (running statistics), rows are independent
 
 
+# Round 6: a hidden layer's activated input x = post * relu(BatchNorm(z_prev)) is never written to HBM where both of its readers can form it
+# from z_prev themselves — the next layer's forward product (vfn_linear_rows_fold) and that layer's weight-gradient product
+# (vfn_weight_grad_partials_bf16_fold): same values bit for bit (the row pass's own expression), one [M, 256] write and two reads less per
+# layer.  Applies to the 256-wide hidden layers on the split-f16 forward product: 6 of the vector-field net's 8, 3 of the rendering net's 4;
+# the skip layer (six-product form: no registers for the coefficients), the last layer's input (narrow-head weight gradients) and every
+# layer of a net on the exact kernels keep the row pass.  False: the row pass everywhere (rounds 3-5).
+FOLD_ACTIVATIONS = os.environ.get("VFN_FOLD_ACTIVATIONS", "1") != "0"        # (the environment switch: same-box A/B, tools/ab_fold.sh)
+
+
+class Folded:
+    """The input of a layer as (z_prev, coef_prev, n_prev, post): act(z)[k] = post * max(z[k] * scale[k] + shift[k], 0) for k < n_prev,
+    post * z[k] behind them (the skip layer's encoding columns, stored UNscaled in z_prev's buffer)."""
+
+    def __init__(self, z: torch.Tensor, coef: torch.Tensor, n_prev: int, post: float) -> None:
+        self.z, self.coef, self.n_prev, self.post = z, coef, int(n_prev), float(post)
+
+    def materialise(self) -> torch.Tensor:
+        """The activated matrix after all (a reader that cannot fold)."""
+        m, width = self.z.shape
+        x = torch.empty(m, width, device=self.z.device)
+        lib.bstat_relu_rows(self.z, self.coef, m, self.n_prev, self.post, x)
+        if width > self.n_prev:
+            x[:, self.n_prev:] = self.z[:, self.n_prev:] * self.post
+        return x
+
+
 def _bn_layers(net) -> int:
     return sum(1 for i in range(net.num_layers) if net._bn(i) is not None)
 
@@ -150,17 +176,32 @@ def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, upda
     L = net.num_layers
     skip = net._skip_layer()
     x = x0
+    # (the test hook reads the activated matrices; the folding product takes W from its pre-split planes)
+    fold = FOLD_ACTIVATIONS and PRESPLIT_W and _split(net) and not getattr(net, "_keep_state", False)
     counted = []              # the BatchNorm layers' batch counters: advanced in ONE launch at the end (a launch each was 5 us x 32 per step)
     for i in range(L - 1):
         lin, bn = net._linear(i), net._bn(i)
         n, k = lin.out_features, lin.in_features
         st.x.append(x)
-        z = _padded(m, n, _up8(n), dev)
+        ar = _arith(net, False, i == 0 or i == skip)
+        # will the NEXT layer read this layer's z through the fold?  (then, in front of the skip layer, z's buffer is as wide as that layer's
+        # input and takes the re-injected encoding behind its n columns)
+        nxt_k = net._linear(i + 1).in_features
+        fold_next = fold and i + 1 <= L - 2 and nxt_k == 256 and 128 < net._linear(i + 1).out_features <= 256 and \
+            _arith(net, False, i + 1 == skip) == lib.GEMM_SPLIT_F16      # (the skip layer's six-product form keeps the row pass)
+        z = _padded(m, n, nxt_k if (fold_next and i + 1 == skip) else _up8(n), dev)
+
+        def product(stats_part):
+            if isinstance(x, Folded):
+                lib.linear_rows_fold(x.z, x.coef, x.n_prev, x.post, lin.weight.detach(), lin.bias.detach(), m, n, k, z, stats_part=stats_part,
+                                     arith=ar, planes=_planes(ar, n, k, dev))
+            else:
+                lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, stats_part=stats_part, arith=ar, planes=_planes(ar, n, k, dev))
+
         if batch_stats:
             parts = lib.linear_rows_stat_parts(m)
             part = torch.empty(parts, 2, n, device=dev)
-            ar = _arith(net, False, i == 0 or i == skip)
-            lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, stats_part=part, arith=ar, planes=_planes(ar, n, k, dev))
+            product(part)
             sums = torch.empty(2, n, dtype=torch.float64, device=dev)
             lib.colsum_finish(part, parts, 2 * n, sums)
             coef = torch.empty(4, n, device=dev)
@@ -169,13 +210,15 @@ def _forward(net, x0: torch.Tensor, m: int, final_act: int, fill_skip=None, upda
             if update_running:
                 counted.append(bn.num_batches_tracked)
         else:
-            ar = _arith(net, False, i == 0 or i == skip)
-            lib.linear_rows(x, lin.weight.detach(), lin.bias.detach(), m, n, k, z, arith=ar, planes=_planes(ar, n, k, dev))
+            product(None)
             coef = _running_coef(bn)
         st.z.append(z)
         st.coef.append(coef)
-        nxt_k = net._linear(i + 1).in_features
-        if i + 1 == skip:        # next input = cat([h, pe]) / sqrt(2)  (vector_field_network.py:192-193)
+        if fold_next:            # the next product (and its weight gradients) form the activation from z themselves
+            if i + 1 == skip:
+                fill_skip(Cols(z, n), 1.0)                   # (unscaled: the fold multiplies every column by 1 / sqrt(2))
+            x = Folded(z, coef, n, INV_SQRT2 if i + 1 == skip else 1.0)
+        elif i + 1 == skip:        # next input = cat([h, pe]) / sqrt(2)  (vector_field_network.py:192-193)
             x = _padded(m, nxt_k, _up8(nxt_k), dev)      # (columns [0, n) by the row pass, [n, nxt_k) by fill_skip)
             lib.bstat_relu_rows(z, coef, m, n, INV_SQRT2, x)
             fill_skip(Cols(x, n), INV_SQRT2)
@@ -248,6 +291,13 @@ class _ParamGrads:
             col_blocks = [("aux", 0, k - 256), ("act", k - 256, 256)]      # rendering net: [p, PE(d), n | 256 features]
         else:
             raise NotImplementedError(f"weight gradients for in_features={k}")
+        folded = x if isinstance(x, Folded) else None
+        if folded is not None:
+            foldable = split and k == 256 and all(not head for _, _, head in row_blocks) and folded.z.shape[1] >= 256
+            if not foldable:
+                x, folded = folded.materialise(), None
+            else:
+                x = folded.z
         for r0, rows, head in row_blocks:
             slab_rows = 32 if head else 256
             u = dict(w=lin.weight.detach(), b_lin=lin.bias.detach(), g_w=self._out(lin.weight), g_b=self._out(lin.bias),
@@ -268,7 +318,11 @@ class _ParamGrads:
                     # 256 columns of dZ from r0 on: all valid, or the last block of a layer whose dZ was allocated 256 wide with zero pad
                     # columns (`_backward`: 217 outputs in front of the skip layer)
                     dz_ok = r0 % 4 == 0 and r0 + 256 <= dzv.ld and (rows == 256 or r0 + rows == n)
-                    if split and dz_ok and nc == 256 and c0 % 4 == 0 and c0 + 256 <= xv.ld:
+                    if folded is not None:
+                        if not (dz_ok and c0 == 0):
+                            raise lib.VfnError(f"layer {i}: a folded input needs the aligned 256-column weight-gradient product")
+                        lib.weight_grad_partials_bf16_fold(dzv, xv, folded.coef, folded.n_prev, folded.post, m, G, part, db_part if first else None)
+                    elif split and dz_ok and nc == 256 and c0 % 4 == 0 and c0 + 256 <= xv.ld:
                         # a 256 x 256 product over whole 16-byte pieces of both matrices' rows: the bf16 matrix cores (three products on split
                         # operands, csrc/vfn_dw16.hip — what the fused path's row-major backward uses), 4x the fp32 matrix instruction's rate
                         lib.weight_grad_partials_bf16_cols(dzv, xv, m, G, part, db_part if first else None)

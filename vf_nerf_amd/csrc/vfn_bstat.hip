@@ -55,6 +55,13 @@ struct GemmArgs {
     // 256 output columns and chunk of 32 k, [plane hi | mid][256 n][32 k] u16 — what a workgroup stages, in the order it stages it
     const unsigned short* wp;
     int wp_chunks;
+    // FOLD (vfn_linear_rows_fold, round 6): A is the PREVIOUS layer's pre-BatchNorm output z; the operand the product multiplies is
+    // fold_post * max(z * scale + shift, 0) for the first fold_n columns (fold_coef = that layer's [4][fold_n] coefficients) and
+    // fold_post * z for the others (the skip layer's re-injected encoding) — formed when the A fragment is read, so the activated
+    // matrix is never written to or read from HBM.
+    const float* fold_coef;
+    int fold_n;
+    float fold_post;
 };
 
 // TRANS = false: B(k, n) = W[n][k]  (nn.Linear weight, C = A W^T);  TRANS = true: B(k, n) = W[k][n]  (C = A W).
@@ -236,9 +243,10 @@ __device__ __forceinline__ void split3(float v, unsigned short& hi, unsigned sho
 // in registers — what vfn_bstat_relu_bwd_sums computes in a pass of its own over g and z (2.3 TB/s, 16 % of a training-mode step).
 // PK: W arrives as pre-split planes (GemmArgs::wp): every workgroup used to fetch all of W as fp32 dwords and split it again — 32 loads and
 // ~300 VALU instructions per thread and chunk, 40 % of a workgroup's cycles (round 5 phase probe) — for values that are the same for all of them.
-template <int NT, bool TRANS, int ARITH, bool SUMS = false, bool PK = false>
+template <int NT, bool TRANS, int ARITH, bool SUMS = false, bool PK = false, bool FOLD = false>
 __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArgs a) {
     constexpr bool THREE = ARITH == 2;
+    static_assert(!FOLD || (!TRANS && !SUMS), "the fold is a forward product's");
     static_assert(!(PK && THREE), "pre-split planes exist for the two-plane arithmetics");
     constexpr int NCOL = NT * 32;
     constexpr int A_LD = 36;                     // floats per staged A row (32 k + 4): conflict-free 16-byte fragment reads
@@ -246,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
     __shared__ __attribute__((aligned(16))) unsigned short s_mid[NCOL * GM_LDH];
     __shared__ __attribute__((aligned(16))) unsigned short s_lo[THREE ? NCOL * GM_LDH : 8];
     __shared__ __attribute__((aligned(16))) float s_a[GM_ROWS * A_LD];
+    __shared__ __attribute__((aligned(16))) float s_fold[FOLD ? 3 * GM_KC : 4];      // the chunk's scale | shift | lower bound per k
     // (the column-sum partials of the epilogue reuse the A tile: 8 KiB of its 18; with three weight planes two workgroups still fit a CU)
     static_assert(2 * 4 * NCOL <= GM_ROWS * A_LD, "s_red must fit into the A tile");
     float (*s_red)[4][NCOL] = reinterpret_cast<float (*)[4][NCOL]>(s_a);
@@ -372,19 +381,32 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 areg[4];
     const int a_r = tid >> 3, a_q = tid & 7;     // row within a pass, 16-byte piece of the row's chunk
+    [[maybe_unused]] float freg = 0.f;           // FOLD: this thread's entry of the chunk's coefficient table (threads 0 .. 95)
     auto fetch_a = [&](int kc) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             const int row = 32 * ps + a_r, k = kc + 4 * a_q;
             areg[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, k < a.k_pad ? ((unsigned)row * (unsigned)a.lda + (unsigned)k) * 4u : OOB, 0, 2);
         }
+        if constexpr (FOLD) {
+            if (tid < 3 * GM_KC) {
+                const int which = tid / GM_KC, k = kc + tid % GM_KC;
+                const bool bn = k < a.fold_n;
+                // scale | shift of the BatchNorm'ed columns; identity without a ReLU (lower bound -inf) for the columns behind them
+                freg = which == 0 ? (bn ? a.fold_coef[k] : 1.0f) : (which == 1 ? (bn ? a.fold_coef[a.fold_n + k] : 0.0f) : (bn ? 0.0f : -__builtin_inff()));
+            }
+        }
     };
     [[maybe_unused]] float a_max = 0.f;       // split f16 form: largest |A| this thread staged (the range report at the end)
+    [[maybe_unused]] const bool fold_row_ok = 32 * wave + c < blk_rows;       // FOLD: this lane's fragment row exists
     auto stage_a = [&]() {
+        if constexpr (FOLD) {
+            if (tid < 3 * GM_KC) s_fold[tid] = freg;
+        }
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             *reinterpret_cast<u32x4*>(s_a + (32 * ps + a_r) * A_LD + 4 * a_q) = areg[ps];
-            if constexpr (ARITH == 0) {
+            if constexpr (ARITH == 0 && !FOLD) {      // (FOLD: the range report looks at the ACTIVATED operand, below)
                 const f32x4 v = __builtin_bit_cast(f32x4, areg[ps]);
                 a_max = fmaxf(fmaxf(a_max, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
             }
@@ -434,10 +456,26 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
             const float* ap = s_a + (32 * wave + c) * A_LD + 16 * ks + 8 * g;
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
             u16x8 ah, am, al;
+            [[maybe_unused]] f32x4 fs0, fs1, fh0, fh1, fl0, fl1;
+            if constexpr (FOLD) {
+                const float* fp = s_fold + 16 * ks + 8 * g;
+                fs0 = *reinterpret_cast<const f32x4*>(fp); fs1 = *reinterpret_cast<const f32x4*>(fp + 4);
+                fh0 = *reinterpret_cast<const f32x4*>(fp + GM_KC); fh1 = *reinterpret_cast<const f32x4*>(fp + GM_KC + 4);
+                fl0 = *reinterpret_cast<const f32x4*>(fp + 2 * GM_KC); fl1 = *reinterpret_cast<const f32x4*>(fp + 2 * GM_KC + 4);
+            }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 unsigned short h, m, l;
-                float av = (t < 4 ? a0[t & 3] : a1[t & 3]) * A_SCALE;
+                float av = (t < 4 ? a0[t & 3] : a1[t & 3]);
+                if constexpr (FOLD) {
+                    // the expression of vfn_bstat_relu_rows (post * max(fma(z, scale, shift), 0)): the operand is that pass's output, bit for bit
+                    av = a.fold_post * fmaxf(fmaf(av, t < 4 ? fs0[t & 3] : fs1[t & 3], t < 4 ? fh0[t & 3] : fh1[t & 3]), t < 4 ? fl0[t & 3] : fl1[t & 3]);
+                    // (a row past the end of the matrix reads z = 0, i.e. max(shift, 0) — any size: it must neither reach the range report nor
+                    //  the product as anything but the zero an unfolded operand reads there)
+                    av = fold_row_ok ? av : 0.f;
+                    if constexpr (ARITH == 0) a_max = fmaxf(a_max, fabsf(av));
+                }
+                av *= A_SCALE;
                 // split f16 form: an element beyond the range (reported below) is SATURATED to the largest finite half, as the fused f16x3
                 // kernels saturate — the flagged call then returns clamped values, never inf - inf = NaN products (which the BatchNorm running
                 // statistics of a training-mode forward would keep)
@@ -702,6 +740,13 @@ void launch_gemm16(GemmArgs a, hipStream_t s) {
         a.n0 = n0;
         if (SUMS) a.stats_part = n0 == 0 ? stats : nullptr;      // the summed columns (<= 256) all sit in the first launch
         const int tiles = (min(a.n_out - n0, 256) + 31) / 32;
+        if constexpr (!TRANS && !SUMS && ARITH == 0) {
+            if (a.fold_coef) {             // (vfn_linear_rows_fold has checked: more than four tiles of output columns)
+                // (W from its pre-split planes only: the form that fetches and splits W itself has no registers left for the coefficients)
+                hipLaunchKernelGGL((vfn_linear_rows16_kernel<8, false, 0, false, true, true>), dim3(blocks), dim3(256), 0, s, a);
+                continue;
+            }
+        }
         if constexpr (ARITH != 2) {
             if (a.wp && tiles > 4) {       // the 256-column launches read the planes; narrower ones split on the fly as before
                 hipLaunchKernelGGL((vfn_linear_rows16_kernel<8, TRANS, ARITH, SUMS, true>), dim3(blocks), dim3(256), 0, s, a);
@@ -960,6 +1005,30 @@ extern "C" int vfn_linear_rows_ws(int32_t transpose_w, const float* a, int32_t l
     else if (tr) launch_gemm<true>(g, s);
     else launch_gemm<false>(g, s);
     return vfn_check_launch("vfn_linear_rows");
+}
+
+// The forward product of a training-mode layer with the previous layer's BatchNorm + ReLU folded into its operand read (GemmArgs::fold_coef).
+extern "C" int vfn_linear_rows_fold(int32_t arith, const float* z_prev, int32_t ldz, const float* coef_prev, int32_t n_prev, float post_prev,
+                                    const float* w, int32_t ldw, const float* bias, int64_t m, int32_t n_out, int32_t k_in, float* c, int32_t ldc,
+                                    float* stats_part, void* wplanes, void* stream) {
+    // (the bf16-in-three-parts form keeps three operand planes per K-block: with the fold's coefficients beside them it spills — a layer on
+    //  that arithmetic, the skip layer, keeps the row pass)
+    VFN_REQUIRE(arith == 2, "vfn_linear_rows_fold: arith = %d (2: three f16 products)", arith);
+    VFN_REQUIRE(z_prev && coef_prev && w && c && wplanes, "vfn_linear_rows_fold: NULL argument (the scratch for W's planes is required)");
+    VFN_REQUIRE(n_out > 128 && n_out <= 256 && k_in >= 1 && n_prev >= 1 && n_prev <= k_in,
+                "vfn_linear_rows_fold: n_out = %d (129 .. 256), n_prev = %d (1 .. k_in = %d)", n_out, n_prev, k_in);
+    const int k_pad = (k_in + 7) & ~7;
+    VFN_REQUIRE((ldz & 3) == 0 && ldz >= k_pad && ((uintptr_t)z_prev & 15) == 0,
+                "vfn_linear_rows_fold: z needs 16-byte aligned rows with ldz (%d) >= %d (k rounded up to 8; pad columns zero)", ldz, k_pad);
+    VFN_REQUIRE(ldc >= n_out && ldw >= k_in, "vfn_linear_rows_fold: ldc=%d ldw=%d too small", ldc, ldw);
+    if (m <= 0) return VFN_OK;
+    GemmArgs g = {};
+    g.a = z_prev; g.w = w; g.bias = bias; g.c = c; g.stats_part = stats_part; g.m = m; g.lda = ldz; g.ldw = ldw; g.ldc = ldc;
+    g.n_out = n_out; g.k_in = k_in; g.k_pad = k_pad; g.act = ACT_NONE; g.stats_ld = n_out;
+    g.wp = static_cast<const unsigned short*>(wplanes);
+    g.fold_coef = coef_prev; g.fold_n = n_prev; g.fold_post = post_prev;
+    launch_gemm16<false, 0>(g, (hipStream_t)stream);
+    return vfn_check_launch("vfn_linear_rows_fold");
 }
 
 extern "C" int vfn_linear_rows_dx_sums(const float* dz, int32_t lddz, const float* w, int32_t ldw, int64_t m, int32_t n_out, int32_t k_in, float* c,

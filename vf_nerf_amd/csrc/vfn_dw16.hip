@@ -47,6 +47,11 @@ struct Dw16Args {
     float* db_part;       // [G][256] or NULL
     long long n_points;
     int ld_dy, ld_x;      // floats between rows (>= 256, multiples of 4: whole 16-byte pieces); 256 for the dense matrices
+    // FOLD (vfn_weight_grad_partials_bf16_fold): x is the previous layer's pre-BatchNorm output z; the operand is
+    // fold_post * max(z * scale + shift, 0) on the first fold_n of the 256 columns (fold_coef = [4][fold_n]: scale | shift | ..), fold_post * z behind them
+    const float* fold_coef;
+    int fold_n;
+    float fold_post;
 };
 
 typedef __attribute__((address_space(3))) s4 lds_s4;
@@ -72,8 +77,9 @@ __device__ __forceinline__ void split4(const f32x4v v, uint2& hi, uint2& lo) {
     lo.y = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf2));
 }
 
-template <bool XH>
+template <bool XH, bool FOLD = false>
 __global__ __launch_bounds__(256, 1) void vfn_dw16_kernel(const Dw16Args a) {
+    static_assert(!(XH && FOLD), "the fold reads fp32 pre-activations");
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * DW_BUF];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -101,6 +107,17 @@ __global__ __launch_bounds__(256, 1) void vfn_dw16_kernel(const Dw16Args a) {
                                                                            (int)(rows_slab * sdy), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)r_base * a.ld_x), 0,
                                                                           (int)(rows_slab * sx), 0x00020000);
+    [[maybe_unused]] f32x4v f_sc = {1.f, 1.f, 1.f, 1.f}, f_sh = {0.f, 0.f, 0.f, 0.f}, f_lo = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (FOLD) {                                    // a lane stages columns 4 lane .. 4 lane + 3 of every row: its coefficients once
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = 4 * lane + c;
+            const bool bn = k < a.fold_n;
+            f_sc[c] = bn ? a.fold_coef[k] : 1.0f;
+            f_sh[c] = bn ? a.fold_coef[a.fold_n + k] : 0.0f;
+            f_lo[c] = bn ? 0.0f : -__builtin_inff();
+        }
+    }
     u32x4 ld_dy[8], ld_x[8];                                 // this wave's 8 rows of the step in flight
     auto issue = [&](long long s) {
         const int row0 = (int)(s - s0) * DW_STEP + 8 * wave;
@@ -129,6 +146,10 @@ __global__ __launch_bounds__(256, 1) void vfn_dw16_kernel(const Dw16Args a) {
                 vx = __builtin_convertvector(__builtin_bit_cast(half4, h), f32x4v);
             } else {
                 vx = __builtin_bit_cast(f32x4v, ld_x[r]);
+            }
+            if constexpr (FOLD) {     // the expression of vfn_bstat_relu_rows, per value (rows past the slab's end read z = 0: their dY is zero)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) vx[c] = a.fold_post * fmaxf(fmaf(vx[c], f_sc[c], f_sh[c]), f_lo[c]);
             }
             uint2 hi, lo;
             split4(vd, hi, lo);
@@ -203,6 +224,22 @@ __global__ __launch_bounds__(256, 1) void vfn_dw16_kernel(const Dw16Args a) {
 }
 
 }  // namespace
+
+extern "C" int vfn_weight_grad_partials_bf16_fold(const float* dy, int32_t ld_dy, const float* z_prev, int32_t ldz, const float* coef_prev,
+                                                  int32_t n_prev, float post_prev, int64_t n_points, int32_t groups, float* dw_part,
+                                                  float* db_part, void* stream) {
+    VFN_REQUIRE(dy && z_prev && coef_prev && dw_part, "vfn_weight_grad_partials_bf16_fold: NULL argument");
+    VFN_REQUIRE(groups >= 1 && groups <= 4096 && n_prev >= 1 && n_prev <= 256, "vfn_weight_grad_partials_bf16_fold: groups=%d n_prev=%d", groups, n_prev);
+    VFN_REQUIRE(ld_dy >= 256 && ldz >= 256 && (ld_dy & 3) == 0 && (ldz & 3) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)z_prev & 15) == 0,
+                "vfn_weight_grad_partials_bf16_fold: 256 columns in whole 16-byte pieces of every row (ld_dy=%d, ldz=%d)", ld_dy, ldz);
+    VFN_REQUIRE(n_points >= 0 && n_points * (int64_t)(ld_dy > ldz ? ld_dy : ldz) * 4 < (int64_t)groups << 31,
+                "vfn_weight_grad_partials_bf16_fold: slab larger than 2 GiB");
+    Dw16Args a = {};
+    a.dy = dy; a.x = z_prev; a.dw_part = dw_part; a.db_part = db_part; a.n_points = n_points; a.ld_dy = ld_dy; a.ld_x = ldz;
+    a.fold_coef = coef_prev; a.fold_n = n_prev; a.fold_post = post_prev;
+    hipLaunchKernelGGL((vfn_dw16_kernel<false, true>), dim3(groups), dim3(256), 0, (hipStream_t)stream, a);
+    return vfn_check_launch("vfn_weight_grad_partials_bf16_fold");
+}
 
 extern "C" int vfn_weight_grad_partials_bf16(const float* dy, const float* x, int64_t n_points, int32_t groups,
                                              float* dw_part, float* db_part, int32_t x_f16, void* stream) {

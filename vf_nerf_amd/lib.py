@@ -37,7 +37,7 @@ EXPORTS = (
     "vfn_vf_loss_workspace_bytes", "vfn_vf_loss_fwd", "vfn_vf_loss_bwd", "vfn_train_step", "vfn_train_step_workspace_bytes",
     "vfn_train_step_workspace_layout", "vfn_train_step_supervision_points", "vfn_train_step_supervision_forward", "vfn_train_step_supervision_backward",
     "vfn_linear_rows_dx_sums", "vfn_weight_grad_partials_bf16_ld", "vfn_linear_rows_ws", "vfn_linear_rows_wplanes_bytes",
-    "vfn_select_samples", "vfn_grid_lattice_points",
+    "vfn_select_samples", "vfn_grid_lattice_points", "vfn_linear_rows_fold", "vfn_weight_grad_partials_bf16_fold",
 )
 
 
@@ -906,6 +906,15 @@ def weight_grad_partials_bf16_cols(dy, x, n_points: int, groups: int, dw_part, d
            "vfn_weight_grad_partials_bf16_ld")
 
 
+def weight_grad_partials_bf16_fold(dy, z_prev, coef_prev: torch.Tensor, n_prev: int, post_prev: float, n_points: int, groups: int, dw_part, db_part=None):
+    """dW = dY^T act(z_prev) over 256 columns with the activation formed in the operand read (vfn_weight_grad_partials_bf16_fold)."""
+    dy, z_prev = _cols(dy), _cols(z_prev)
+    _check(load().vfn_weight_grad_partials_bf16_fold(dy.ptr, C.c_int32(dy.ld), z_prev.ptr, C.c_int32(z_prev.ld), _ptr(coef_prev, "coef_prev"),
+                                                     C.c_int32(n_prev), C.c_float(post_prev), C.c_int64(n_points), C.c_int32(groups),
+                                                     _ptr(dw_part, "dw_part"), _ptr(db_part, "db_part"), _stream()),
+           "vfn_weight_grad_partials_bf16_fold")
+
+
 def ray_density_weights_bwd(dp: DensityParams, normals, ray_dirs, z_vals, scalars, colors, d_rgb, d_depth, d_weights,
                             d_normals, d_colors, d_scalars):
     n, s = z_vals.shape
@@ -1286,6 +1295,17 @@ def linear_rows(a, w: torch.Tensor, bias, m: int, n_out: int, k_in: int, c, act:
                                      _ptr(bias, "bias"), C.c_int64(m), C.c_int32(n_out), C.c_int32(k_in), C.c_int32(act), c.ptr,
                                      C.c_int32(c.ld), _ptr(stats_part, "stats_part"), _ptr(planes, "planes", torch.uint8), _stream()),
            "vfn_linear_rows")
+
+
+def linear_rows_fold(z_prev, coef_prev: torch.Tensor, n_prev: int, post_prev: float, w: torch.Tensor, bias, m: int, n_out: int, k_in: int, c,
+                     stats_part=None, arith: int = GEMM_SPLIT_F16, planes=None) -> None:
+    """The forward product of a layer whose input is act(z_prev) — the previous layer's BatchNorm + ReLU (+ the skip layer's encoding
+    columns behind the first ``n_prev``) — formed inside the product's operand read (include/vfn.h, vfn_linear_rows_fold)."""
+    z_prev, c = _cols(z_prev), _cols(c)
+    _check(load().vfn_linear_rows_fold(C.c_int32(int(arith)), z_prev.ptr, C.c_int32(z_prev.ld), _ptr(coef_prev, "coef_prev"), C.c_int32(n_prev),
+                                       C.c_float(post_prev), _ptr(w, "w"), C.c_int32(w.shape[1]), _ptr(bias, "bias"), C.c_int64(m), C.c_int32(n_out),
+                                       C.c_int32(k_in), c.ptr, C.c_int32(c.ld), _ptr(stats_part, "stats_part"), _ptr(planes, "planes", torch.uint8),
+                                       _stream()), "vfn_linear_rows_fold")
 
 
 def linear_rows_dx_sums(dz, w: torch.Tensor, m: int, n_out: int, k_in: int, c, z_prev, coef_prev: torch.Tensor, n_prev: int, post_prev: float,
