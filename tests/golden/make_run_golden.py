@@ -13,9 +13,10 @@ curves is the yardstick a statistical comparison of another implementation's cur
 
 Runs only in the build container (needs /root/reference, read-only); nothing of the reference's source travels.
 
-    python tests/golden/make_run_golden.py [--streams 4]          # ~4 minutes per stream on 8 cores
+    python tests/golden/make_run_golden.py [--streams 4]          # ~2 minutes per stream on 8 cores
+    python tests/golden/make_run_golden.py --far [--streams 3]    # the 8 000-step run of trained_far.npz (256-ray batches): ~1 hour per stream
 
-Writes ``trained_256_run.npz``:
+Writes ``trained_256_run.npz`` (``--far``: ``trained_far_run.npz``, the task and reference runs of ``trained_far.npz``'s recorded run):
 * ``batch.uv [100,64,2]``, ``batch.pose [100,4,4]``, ``batch.intrinsics [100,4,4]`` (one per batch: every ray of a batch shares them),
   ``batch.rgb [100,64,3]``, ``batch.depth [100,64,1]``;
 * ``init.head_weight [3,256]``, ``init.head_bias [3]``: the recentred vector head of the student (everything else of the initial state is
@@ -55,8 +56,10 @@ EXTRA_SEEDS = ((4100, 3025), (5100, 4025), (6100, 5025), (7100, 6025), (8100, 70
 def main() -> None:
     torch.set_num_threads(8)
     streams = int(sys.argv[sys.argv.index("--streams") + 1]) if "--streams" in sys.argv else 4
-    fx = mt.TRAIN
-    recorded = np.load(os.path.join(HERE, "trained_256.npz"))
+    far = "--far" in sys.argv
+    fx = mt.TRAIN_FAR if far else mt.TRAIN
+    recorded = np.load(os.path.join(HERE, "trained_far.npz" if far else "trained_256.npz"))
+    assert repr(fx) == str(recorded["train_recipe"]), "the recipe in make_trained_golden.py is not the recorded run's"
     teacher = mtg.build_reference_model(dict(fx, seed=fx["teacher_seed"]))
     batches = mt.make_batches(fx, teacher)
     student0 = mtg.build_reference_model(fx)
@@ -95,7 +98,7 @@ def main() -> None:
     arrays["runs.seeds"] = np.array(seeds, dtype=np.int64)
     arrays["runs.term_names"] = np.array(["rgb_loss", "depth_loss", "unit_norm_loss", "supervision_loss", "norm_smaller_than_one_loss", "directional_derivatives_loss"])
     arrays["train_recipe"] = np.array(repr(fx))
-    path = os.path.join(HERE, "trained_256_run.npz")
+    path = os.path.join(HERE, "trained_far_run.npz" if far else "trained_256_run.npz")
     np.savez_compressed(path, **arrays)
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB), {len(seeds)} reference runs")
 

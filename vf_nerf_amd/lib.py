@@ -909,6 +909,8 @@ def weight_grad_partials_bf16_cols(dy, x, n_points: int, groups: int, dw_part, d
 def weight_grad_partials_bf16_fold(dy, z_prev, coef_prev: torch.Tensor, n_prev: int, post_prev: float, n_points: int, groups: int, dw_part, db_part=None):
     """dW = dY^T act(z_prev) over 256 columns with the activation formed in the operand read (vfn_weight_grad_partials_bf16_fold)."""
     dy, z_prev = _cols(dy), _cols(z_prev)
+    if coef_prev.numel() < 2 * n_prev:
+        raise VfnError(f"weight_grad_partials_bf16_fold: coefficients of {coef_prev.numel()} floats for n_prev = {n_prev} (needs scale | shift rows)")
     _check(load().vfn_weight_grad_partials_bf16_fold(dy.ptr, C.c_int32(dy.ld), z_prev.ptr, C.c_int32(z_prev.ld), _ptr(coef_prev, "coef_prev"),
                                                      C.c_int32(n_prev), C.c_float(post_prev), C.c_int64(n_points), C.c_int32(groups),
                                                      _ptr(dw_part, "dw_part"), _ptr(db_part, "db_part"), _stream()),
@@ -1302,6 +1304,8 @@ def linear_rows_fold(z_prev, coef_prev: torch.Tensor, n_prev: int, post_prev: fl
     """The forward product of a layer whose input is act(z_prev) — the previous layer's BatchNorm + ReLU (+ the skip layer's encoding
     columns behind the first ``n_prev``) — formed inside the product's operand read (include/vfn.h, vfn_linear_rows_fold)."""
     z_prev, c = _cols(z_prev), _cols(c)
+    if coef_prev.numel() < 2 * n_prev or n_prev > k_in:
+        raise VfnError(f"linear_rows_fold: coefficients of {coef_prev.numel()} floats for n_prev = {n_prev} (needs scale | shift rows), k_in = {k_in}")
     _check(load().vfn_linear_rows_fold(C.c_int32(int(arith)), z_prev.ptr, C.c_int32(z_prev.ld), _ptr(coef_prev, "coef_prev"), C.c_int32(n_prev),
                                        C.c_float(post_prev), _ptr(w, "w"), C.c_int32(w.shape[1]), _ptr(bias, "bias"), C.c_int64(m), C.c_int32(n_out),
                                        C.c_int32(k_in), c.ptr, C.c_int32(c.ld), _ptr(stats_part, "stats_part"), _ptr(planes, "planes", torch.uint8),
