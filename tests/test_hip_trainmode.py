@@ -477,3 +477,86 @@ def test_standalone_rendering_net_is_differentiable_in_eval_mode():
     for k in keys:
         got = dict(rn.named_parameters())[k].grad
         assert grad_rel_err(got, sd[k].grad) <= 1e-3, (k, grad_rel_err(got, sd[k].grad))
+
+
+@pytest.mark.parametrize("n_prev,post,m", [(256, 1.0, 5000), (217, 2 ** -0.5, 4133)])
+def test_folded_products_equal_the_row_pass_then_the_product(n_prev, post, m):
+    """``vfn_linear_rows_fold`` / ``vfn_weight_grad_partials_bf16_fold`` (round 6): the previous layer's BatchNorm + ReLU formed inside the
+    operand read — against the row pass ``vfn_bstat_relu_rows`` followed by the plain product: the SAME operand values (the row pass's own
+    expression), hence outputs, column statistics and weight-gradient slabs bit for bit.  (217, 1/sqrt 2): the skip layer's shape — 217
+    BatchNorm'ed columns and 39 re-injected encoding columns behind them that pass through scaled, without a ReLU; m is not a multiple of
+    the 128-row blocks (rows past the end must neither be stored nor reach the range report: a first version flagged max(shift, 0) there)."""
+    from vf_nerf_amd import batchstat
+    torch.manual_seed(5)
+    k, n = 256, 256
+    z_prev = torch.randn(m, k, device=DEV) * 3.0
+    coef = torch.stack([torch.rand(n_prev, device=DEV) + 0.5, torch.randn(n_prev, device=DEV) * 40.0, torch.zeros(n_prev, device=DEV),
+                        torch.ones(n_prev, device=DEV)]).contiguous()               # (shifts of +-40: a row of zeros would activate to 40)
+    w, b = torch.randn(n, k, device=DEV) * 0.1, torch.randn(n, device=DEV)
+    # the materialised operand
+    x = torch.zeros(m, k, device=DEV)
+    lib.bstat_relu_rows(z_prev, coef, m, n_prev, post, x)
+    if n_prev < k:
+        x[:, n_prev:] = z_prev[:, n_prev:] * post
+    parts = lib.linear_rows_stat_parts(m)
+    outs = []
+    for folded in (False, True):
+        z, part = torch.empty(m, n, device=DEV), torch.empty(parts, 2, n, device=DEV)
+        planes = lib.wplanes(n, k, torch.device(DEV))
+        if folded:
+            lib.linear_rows_fold(z_prev, coef, n_prev, post, w, b, m, n, k, z, stats_part=part, arith=lib.GEMM_SPLIT_F16, planes=planes)
+        else:
+            lib.linear_rows(x, w, b, m, n, k, z, stats_part=part, arith=lib.GEMM_SPLIT_F16, planes=planes)
+        outs.append((z, part))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    want = x.double() @ w.double().t() + b.double()
+    assert float((outs[1][0].double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    # the weight-gradient product with the same fold on its X operand
+    dy = torch.randn(m, n, device=DEV) * 1e-3
+    G = batchstat._groups(m)
+    slabs = []
+    for folded in (False, True):
+        dw, db = torch.empty(G, 256, 256, device=DEV), torch.empty(G, 256, device=DEV)
+        if folded:
+            lib.weight_grad_partials_bf16_fold(dy, z_prev, coef, n_prev, post, m, G, dw, db)
+        else:
+            lib.weight_grad_partials_bf16_cols(dy, x, m, G, dw, db)
+        slabs.append((dw, db))
+    assert torch.equal(slabs[0][0], slabs[1][0]) and torch.equal(slabs[0][1], slabs[1][1])
+    want_dw = dy.double().t() @ x.double()
+    got_dw = slabs[1][0].double().sum(0)
+    assert float((got_dw - want_dw).abs().max()) <= 1e-4 * float(want_dw.abs().max())
+    with pytest.raises(lib.VfnError, match="coefficients"):
+        lib.linear_rows_fold(z_prev, coef[:1], n_prev, post, w, b, m, n, k, outs[0][0], arith=lib.GEMM_SPLIT_F16, planes=lib.wplanes(n, k, torch.device(DEV)))
+
+
+def test_training_mode_step_is_the_same_with_and_without_the_activation_fold():
+    """batchstat.FOLD_ACTIVATIONS: a training-mode render + backward with the fold and with the row pass everywhere — outputs and every
+    parameter gradient bit for bit (the folded operands ARE the row pass's values; nothing else changes)."""
+    from vf_nerf_amd import batchstat
+    fx, d = load_fixture("train_mode")
+    uni = {k: d[k].to(DEV) for k in ("u_coarse", "u_fine", "u_add")}
+    got = {}
+    keep = batchstat.FOLD_ACTIVATIONS
+    try:
+        for fold in (True, False):
+            batchstat.FOLD_ACTIVATIONS = fold
+            model = _train_model(fx, d)
+            model.optimizer.zero_grad()
+            out = model.render(d["pose"].to(DEV), d["uv"].to(DEV), d["intrinsics"].to(DEV), 0, False, uniforms=uni)
+            loss = out.coarse_rgb_values.abs().mean() + out.coarse_depth_map.mean() + 0.1 * out.coarse_normals.pow(2).mean() + \
+                0.05 * out.directional_derivtives.mean()
+            loss.backward()
+            got[fold] = (out, {k: p.grad.detach().clone() for net in (model.vector_field_network, model.rendering_network)
+                               for k, p in net.named_parameters(prefix=type(net).__name__) if p.grad is not None},
+                         {k: v.detach().clone() for k, v in model.vector_field_network.state_dict().items() if "running" in k})
+    finally:
+        batchstat.FOLD_ACTIVATIONS = keep
+    (o1, g1, r1), (o0, g0, r0) = got[True], got[False]
+    for f in ("coarse_rgb_values", "coarse_depth_map", "coarse_normals", "directional_derivtives", "coarse_colors"):
+        assert torch.equal(getattr(o1, f), getattr(o0, f)), f
+    assert g1.keys() == g0.keys() and len(g1) > 40
+    for k in g1:
+        assert torch.equal(g1[k], g0[k]), k
+    for k in r1:
+        assert torch.equal(r1[k], r0[k]), k

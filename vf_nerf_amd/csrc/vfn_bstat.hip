@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void vfn_linear_rows16_kernel(const GemmArg
                 float av = (t < 4 ? a0[t & 3] : a1[t & 3]);
                 if constexpr (FOLD) {
                     // the expression of vfn_bstat_relu_rows (post * max(fma(z, scale, shift), 0)): the operand is that pass's output, bit for bit
-                    av = a.fold_post * fmaxf(fmaf(av, t < 4 ? fs0[t & 3] : fs1[t & 3], t < 4 ? fh0[t & 3] : fh1[t & 3]), t < 4 ? fl0[t & 3] : fl1[t & 3]);
+                    av = __fmul_rn(a.fold_post, fmaxf(fmaf(av, t < 4 ? fs0[t & 3] : fs1[t & 3], t < 4 ? fh0[t & 3] : fh1[t & 3]), t < 4 ? fl0[t & 3] : fl1[t & 3]));
                     // (a row past the end of the matrix reads z = 0, i.e. max(shift, 0) — any size: it must neither reach the range report nor
                     //  the product as anything but the zero an unfolded operand reads there)
                     av = fold_row_ok ? av : 0.f;

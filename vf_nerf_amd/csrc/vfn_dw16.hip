@@ -148,8 +148,14 @@ __global__ __launch_bounds__(256, 1) void vfn_dw16_kernel(const Dw16Args a) {
                 vx = __builtin_bit_cast(f32x4v, ld_x[r]);
             }
             if constexpr (FOLD) {     // the expression of vfn_bstat_relu_rows, per value (rows past the slab's end read z = 0: their dY is zero)
+                // (the product must be ROUNDED to fp32 before the split below, as the stored activation is: left to -ffp-contract the multiply
+                //  fuses into split4's  v - hi  — an fma on the unrounded product — and the low halves differ.  The empty asm pins the value.)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) vx[c] = a.fold_post * fmaxf(fmaf(vx[c], f_sc[c], f_sh[c]), f_lo[c]);
+                for (int c = 0; c < 4; ++c) {
+                    float t = a.fold_post * fmaxf(fmaf(vx[c], f_sc[c], f_sh[c]), f_lo[c]);
+                    asm volatile("" : "+v"(t));
+                    vx[c] = t;
+                }
             }
             uint2 hi, lo;
             split4(vd, hi, lo);
