@@ -77,3 +77,26 @@ def test_recorded_reference_run_replays_on_the_exact_fp32_kernels():
     _report("exact-fp32 kernels, fp32 storages", runs, cmp)
     assert all(r["issued_as"].startswith("launch by launch") for r in runs)
     _assert_family_matches(cmp, runs, widths=0.75)
+
+
+def test_recorded_far_run_replays_on_the_default_kernels():
+    """The same comparison on the LONG run: the 8 000 steps on 256-ray batches that produced ``trained_far.npz`` (the state the headline's
+    trained scene and the two-product colour analysis use), against the reference's own runs of that task
+    (``tests/golden/trained_far_run.npz``: ``make_run_golden.py --far``, about an hour of CPU per reference run).  500-step windows."""
+    import replay_reference_run as rr
+    if not rr.task_available("far"):
+        pytest.skip("tests/golden/trained_far_run.npz has not been generated")
+    raw, recipe = rr.load_task("far")
+    runs = [rr.replay(s, "default", task="far") for s in range(3)]
+    cmp = rr.compare(rr.reference_curves(raw), runs, window=500)
+    _report("far run, default kernels", runs, cmp)
+    assert all(r["issued_as"] == "step session" and r["guard_switched_to_fp32"] is None and r["steps"] == 8000 for r in runs)
+    assert np.array_equal(raw["runs.loss"][0][:100], np.load(os.path.join(REPO, "tests", "golden", "trained_far.npz"))["curve.loss"][:100])
+    p = cmp["psnr_vs_teacher_db"]
+    assert abs(p["replay_before"][0] - p["reference_before"]) < 0.02
+    for k, q in cmp["quantities"].items():
+        assert max(q["replay_mean_outside_reference_envelope_in_widths"]) <= 1.0, (k, q["replay_mean_outside_reference_envelope_in_widths"])
+        assert abs(float(np.mean(q["ratio_of_means"])) - 1.0) < (0.10 if k in ("loss", "rgb_loss", "depth_loss") else 0.25), (k, q["ratio_of_means"])
+    lo, hi = p["reference_after_min_max"]
+    assert abs(p["replay_after_mean"] - p["reference_after_mean"]) < 1.0 and all(lo - 1.0 <= v <= hi + 1.0 for v in p["replay_after"])
+    assert abs(cmp["clip_norm_median"]["ratio_of_family_means"] - 1.0) < 0.10

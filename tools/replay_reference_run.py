@@ -35,10 +35,16 @@ for p in (REPO, HERE, os.path.join(REPO, "tests")):
 
 TERMS = ("rgb_loss", "depth_loss", "unit_norm_loss", "supervision_loss")       # the active ones (norm_smaller_than_one starts at epoch 11 000)
 WINDOW = 100
+TASKS = {"256": "trained_256_run.npz",      # 12 epochs x 100 batches of 64 rays (the run recorded in trained_256.npz)
+         "far": "trained_far_run.npz"}      # 80 epochs x 100 batches of 256 rays (trained_far.npz): make_run_golden.py --far
 
 
-def load_task():
-    raw = np.load(os.path.join(REPO, "tests", "golden", "trained_256_run.npz"))
+def task_available(task: str = "256") -> bool:
+    return os.path.exists(os.path.join(REPO, "tests", "golden", TASKS[task]))
+
+
+def load_task(task: str = "256"):
+    raw = np.load(os.path.join(REPO, "tests", "golden", TASKS[task]))
     recipe = ast.literal_eval(str(raw["train_recipe"]))
     return raw, recipe
 
@@ -83,13 +89,13 @@ def psnr(model, batches, first=16) -> float:
     return float(-10.0 * np.log10(se / n))
 
 
-def replay(stream: int, kernels: str = "default", dev=None, epochs=None):
+def replay(stream: int, kernels: str = "default", dev=None, epochs=None, task: str = "256"):
     """One run of the recorded task -> dict(loss[steps], terms[steps,4], clip[steps], psnr_before_after, issued_as, seconds).
     ``kernels``: "default" (f16x3, 16-bit storages, step session) or "fp32" (exact-fp32 MFMA kernels, fp32 storages, launch by launch)."""
     import reference_sequence
     from vf_nerf_amd import loss as vloss, stepengine, supervision, trainer
     dev = dev or torch.device("cuda:0")
-    raw, recipe = load_task()
+    raw, recipe = load_task(task)
     model = build_student(raw, recipe, dev)
     batches = batches_on(raw, dev)
     if kernels == "fp32":
@@ -123,21 +129,21 @@ def replay(stream: int, kernels: str = "default", dev=None, epochs=None):
             "guard_switched_to_fp32": model.f16x3_disabled, "seconds": round(seconds, 1), "steps": steps}
 
 
-def windows(x: np.ndarray) -> np.ndarray:
-    """[..., steps(, k)] -> means over consecutive 100-step windows along the steps axis (axis 1 of a [runs, steps, ...] array)."""
+def windows(x: np.ndarray, window: int = WINDOW) -> np.ndarray:
+    """[runs, steps(, k)] -> means over consecutive ``window``-step windows along the steps axis."""
     runs, steps = x.shape[:2]
-    return x[:, :steps // WINDOW * WINDOW].reshape(runs, steps // WINDOW, WINDOW, *x.shape[2:]).mean(axis=2)
+    return x[:, :steps // window * window].reshape(runs, steps // window, window, *x.shape[2:]).mean(axis=2)
 
 
-def compare(ref: dict, runs: list) -> dict:
+def compare(ref: dict, runs: list, window: int = WINDOW) -> dict:
     """Reference curves (``runs.*`` of the fixture) against a family of replays.  Per quantity and 100-step window: the reference runs'
     envelope [min, max] and spread, the replays' mean, and where that mean sits — ``outside`` = distance outside the envelope in units of
     the envelope's width (0 inside)."""
-    out = {"quantities": {}}
+    out = {"quantities": {}, "window": window}
     names = ("loss",) + TERMS
-    ref_w = {"loss": windows(ref["loss"])}
-    hip_w = {"loss": windows(np.stack([r["loss"] for r in runs]))}
-    rt, ht = windows(ref["terms"]), windows(np.stack([r["terms"] for r in runs]))
+    ref_w = {"loss": windows(ref["loss"], window)}
+    hip_w = {"loss": windows(np.stack([r["loss"] for r in runs]), window)}
+    rt, ht = windows(ref["terms"], window), windows(np.stack([r["terms"] for r in runs]), window)
     for j, k in enumerate(TERMS):
         ref_w[k], hip_w[k] = rt[:, :, j], ht[:, :, j]
     worst = 0.0
@@ -174,9 +180,10 @@ def reference_curves(raw) -> dict:
 
 
 def markdown(report: dict) -> str:
-    lines = ["# The reference trainer's recorded 1 200-step run, replayed on the HIP path\n",
+    W = report.get("window", WINDOW)
+    lines = [f"# The reference trainer's recorded {report.get('steps', 1200)}-step run, replayed on the HIP path\n",
              report["task"] + "\n",
-             "Per 100-step window: mean over the reference's runs [min .. max of its runs] | mean over the replays [min .. max].\n"]
+             f"Per {W}-step window: mean over the reference's runs [min .. max of its runs] | mean over the replays [min .. max].\n"]
     for fam in ("default", "fp32"):
         if fam not in report:
             continue
@@ -187,7 +194,7 @@ def markdown(report: dict) -> str:
             lines.append("| window | reference | replay | outside envelope (widths) | ratio of means |")
             lines.append("|---|---|---|---|---|")
             for w in range(len(q["reference_mean"])):
-                lines.append(f"| {w * WINDOW}-{(w + 1) * WINDOW - 1} | {q['reference_mean'][w]:.4f} [{q['reference_min'][w]:.4f} .. {q['reference_max'][w]:.4f}] | "
+                lines.append(f"| {w * W}-{(w + 1) * W - 1} | {q['reference_mean'][w]:.4f} [{q['reference_min'][w]:.4f} .. {q['reference_max'][w]:.4f}] | "
                              f"{q['replay_mean'][w]:.4f} [{q['replay_min'][w]:.4f} .. {q['replay_max'][w]:.4f}] | "
                              f"{q['replay_mean_outside_reference_envelope_in_widths'][w]:.2f} | {q['ratio_of_means'][w]:.3f} |")
             lines.append("")
@@ -201,18 +208,24 @@ def markdown(report: dict) -> str:
 
 def main() -> None:
     streams = int(sys.argv[sys.argv.index("--streams") + 1]) if "--streams" in sys.argv else 4
-    out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(REPO, "gpurun_out", "replay_reference_run")
-    raw, recipe = load_task()
+    task = sys.argv[sys.argv.index("--task") + 1] if "--task" in sys.argv else "256"
+    control = int(sys.argv[sys.argv.index("--control-streams") + 1]) if "--control-streams" in sys.argv else streams
+    out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(REPO, "gpurun_out", "replay_reference_run" + ("" if task == "256" else "_" + task))
+    raw, recipe = load_task(task)
     ref = reference_curves(raw)
-    report = {"task": f"{recipe['epochs']} epochs x {recipe['steps_per_epoch']} fixed batches of {recipe['n_rays']} rays x ({recipe['n_samples']} + {recipe['n_importance']}) "
+    steps = recipe["epochs"] * recipe["steps_per_epoch"]
+    window = WINDOW if steps <= 2000 else 500
+    report = {"steps": steps, "window": window, "task": f"{recipe['epochs']} epochs x {recipe['steps_per_epoch']} fixed batches of {recipe['n_rays']} rays x ({recipe['n_samples']} + {recipe['n_importance']}) "
                       f"samples, 8 orbit views, targets rendered by the reference from a teacher of another seed; the reference's own train_epoch ran it "
-                      f"{ref['loss'].shape[0]} times (row 0 = the run recorded in tests/golden/trained_256.npz, reproduced to {float(raw['runs.reproduces_recorded'][0]):.1e} when the "
+                      f"{ref['loss'].shape[0]} times (row 0 = the run recorded in tests/golden/{TASKS[task].replace('_run', '')}, reproduced to {float(raw['runs.reproduces_recorded'][0]):.1e} when the "
                       f"fixture was made; the others under other torch / numpy seeds)."}
     for fam, what in (("default", "default kernels (f16x3, 16-bit storages)"), ("fp32", "exact-fp32 kernels, fp32 storages (control)")):
-        runs = [replay(s, fam) for s in range(streams)]
+        runs = [replay(s, fam, task=task) for s in range(streams if fam == "default" else control)]
+        if not runs:
+            continue
         report[fam] = {"what": what, "runs": len(runs), "issued_as": runs[0]["issued_as"], "ms_per_step": round(1e3 * sum(r["seconds"] for r in runs) / sum(r["steps"] for r in runs), 3),
-                       "guard_switched_to_fp32": [r["guard_switched_to_fp32"] for r in runs], "comparison": compare(ref, runs),
-                       "loss_window_means_per_run": windows(np.stack([r["loss"] for r in runs])).round(5).tolist()}
+                       "guard_switched_to_fp32": [r["guard_switched_to_fp32"] for r in runs], "comparison": compare(ref, runs, window),
+                       "loss_window_means_per_run": windows(np.stack([r["loss"] for r in runs]), window).round(5).tolist()}
         print(f"{fam}: {len(runs)} runs, {report[fam]['ms_per_step']} ms/step, final PSNR {report[fam]['comparison']['psnr_vs_teacher_db']['replay_after']}, worst window "
               f"{report[fam]['comparison']['worst_window_outside_in_widths']} widths outside", flush=True)
     os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
