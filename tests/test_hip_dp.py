@@ -101,3 +101,60 @@ def test_two_rank_step_on_the_hip_path_equals_the_single_process_step(patched):
     frac = float((moved > 0.05 * 5e-4).float().mean())
     print(f"parameters after the step: {frac:.4f} of the entries differ by more than a twentieth of an update")
     assert frac < 0.02
+
+
+def _loop_worker(rank, world, port, out_dir):
+    """Ten steps of the reference trainer's loop body (tools/reference_sequence.ReferenceLoop: render, both supervision batches with THIS
+    rank's own random points, VFLoss with its data-dependent centre-ball rows, zero_grad, backward, clip_grad_norm_ — where the drop-in
+    all-reduces —, optimizer.step, scheduler.step) on this rank's 64-ray shard of the recorded run's first batches."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    from types import SimpleNamespace
+    import torch.distributed as dist
+    import reference_sequence
+    import replay_reference_run as rr
+    from vf_nerf_amd import distributed as vdist, loss as vloss, stepengine, trainer
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        raw, recipe = rr.load_task("256")
+        model = rr.build_student(raw, recipe, dev)
+        vdist.broadcast_parameters(model, src=0)
+        vdist.seed_rank_streams(model, rank, base_seed=3)                   # every rank its own jitter and supervision points
+        batches = rr.batches_on(raw, dev)
+        crit = vloss.VFLoss(SimpleNamespace(**trainer.SHIPPED_LOSS_CONFIG), SimpleNamespace(**trainer.SHIPPED_LOSS_WEIGHTS))
+        loop = reference_sequence.ReferenceLoop(model, crit, reference_sequence.StandInDataset(recipe["centroid"], recipe["far"], recipe["near"]),
+                                                recipe["border_radius"], clip_norm=recipe["clip_norm"], sync_each_step=True)
+        losses = []
+        for t in range(10):
+            # a global batch of 128 rays = two recorded 64-ray batches; this rank takes one of them
+            b = batches[2 * t + rank]
+            loss, _ = loop(b, 0)
+            eng = stepengine.StepEngine.of(model)
+            assert eng.why_not is None and eng.session is not None, eng.why_not
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        f = model.optimizer.flat()
+        torch.save({"params": f["param"].detach().cpu().clone(), "exp_avg": f["exp_avg"].detach().cpu().clone(), "losses": losses,
+                    "running_loss": float(loop.average_losses["loss"])}, os.path.join(out_dir, f"loop_r{rank}.pt"))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_through_the_reference_loop_stay_identical_replicas():
+    """The data-parallel invariant over several steps of the UNCHANGED loop body: ranks see different rays, draw different jitter and
+    supervision points, select different numbers of centre-ball rows — and after every step hold the SAME parameters and Adam moments,
+    because the one all-reduce (inside the wrapped clip_grad_norm_) hands every rank the same gradient before the clip and the update."""
+    port = 31800 + (os.getpid() % 1500)
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_loop_worker, args=(2, port, tmp), nprocs=2, join=True)
+        a, b = (torch.load(os.path.join(tmp, f"loop_r{r}.pt")) for r in range(2))
+    assert torch.equal(a["params"], b["params"]) and torch.equal(a["exp_avg"], b["exp_avg"])
+    assert a["losses"] != b["losses"] and all(l == l and l < 10.0 for l in a["losses"] + b["losses"])      # different shards, finite
+    assert abs(a["running_loss"] - sum(a["losses"])) < 1e-4 * abs(sum(a["losses"]))                        # the loop's deferred running sum
+    print(f"two ranks, ten steps of the reference loop: losses rank 0 {a['losses'][0]:.4f} -> {a['losses'][-1]:.4f}, rank 1 {b['losses'][0]:.4f} -> {b['losses'][-1]:.4f}; "
+          "parameters and first moments bit-identical")
