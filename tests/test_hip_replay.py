@@ -81,8 +81,13 @@ def test_recorded_reference_run_replays_on_the_exact_fp32_kernels():
 
 def test_recorded_far_run_replays_on_the_default_kernels():
     """The same comparison on the LONG run: the 8 000 steps on 256-ray batches that produced ``trained_far.npz`` (the state the headline's
-    trained scene and the two-product colour analysis use), against the reference's own runs of that task
-    (``tests/golden/trained_far_run.npz``: ``make_run_golden.py --far``, about an hour of CPU per reference run).  500-step windows."""
+    trained scene and the two-product colour analysis use), against the reference's own three runs of that task
+    (``tests/golden/trained_far_run.npz``: ``make_run_golden.py --far``, half an hour of CPU per reference run; the recorded one reproduced
+    bit for bit over all 8 000 steps).  500-step windows.  Three reference runs make a narrow envelope (+- 1-3 % per window), so the
+    yardstick here is the RATIO of the family means per window.  What 4 + 4 + 4 replays measured (profiles/r06/replay_reference_run_far.md):
+    default kernels and storages 1.04 over the run (twice, on different realisations: the 11-bit activation / gradient storages cost 3-4 %
+    of loss at equal step count, not visible in the final PSNR), the same kernels with fp32 storages 1.01, the exact-fp32 kernels 0.98;
+    single runs of one family differ by +- 4 % in a late window (the sums' order differs from run to run: the trajectories are chaotic)."""
     import replay_reference_run as rr
     if not rr.task_available("far"):
         pytest.skip("tests/golden/trained_far_run.npz has not been generated")
@@ -91,12 +96,16 @@ def test_recorded_far_run_replays_on_the_default_kernels():
     cmp = rr.compare(rr.reference_curves(raw), runs, window=500)
     _report("far run, default kernels", runs, cmp)
     assert all(r["issued_as"] == "step session" and r["guard_switched_to_fp32"] is None and r["steps"] == 8000 for r in runs)
-    assert np.array_equal(raw["runs.loss"][0][:100], np.load(os.path.join(REPO, "tests", "golden", "trained_far.npz"))["curve.loss"][:100])
+    rec = np.load(os.path.join(REPO, "tests", "golden", "trained_far.npz"))
+    assert float(raw["runs.reproduces_recorded"][0]) == 0.0 and np.array_equal(raw["runs.loss"][0], rec["curve.loss"])
     p = cmp["psnr_vs_teacher_db"]
-    assert abs(p["replay_before"][0] - p["reference_before"]) < 0.02
+    assert abs(p["replay_before"][0] - p["reference_before"]) < 0.06
     for k, q in cmp["quantities"].items():
-        assert max(q["replay_mean_outside_reference_envelope_in_widths"]) <= 1.0, (k, q["replay_mean_outside_reference_envelope_in_widths"])
-        assert abs(float(np.mean(q["ratio_of_means"])) - 1.0) < (0.10 if k in ("loss", "rgb_loss", "depth_loss") else 0.25), (k, q["ratio_of_means"])
-    lo, hi = p["reference_after_min_max"]
-    assert abs(p["replay_after_mean"] - p["reference_after_mean"]) < 1.0 and all(lo - 1.0 <= v <= hi + 1.0 for v in p["replay_after"])
+        big = k in ("loss", "rgb_loss", "depth_loss")
+        ratios = np.array(q["ratio_of_means"])
+        assert float(np.abs(ratios - 1.0).max()) < (0.15 if big else 0.30), (k, q["ratio_of_means"])          # every window
+        assert abs(float(ratios.mean()) - 1.0) < (0.08 if big else 0.15), (k, float(ratios.mean()))            # the run as a whole
+    q = cmp["quantities"]["loss"]
+    assert q["replay_mean"][-1] < 0.35 * q["replay_mean"][0]                                                   # 0.43 -> 0.13, as the reference's
+    assert abs(p["replay_after_mean"] - p["reference_after_mean"]) < 0.7 and all(17.0 <= v <= 18.6 for v in p["replay_after"]), p["replay_after"]
     assert abs(cmp["clip_norm_median"]["ratio_of_family_means"] - 1.0) < 0.10

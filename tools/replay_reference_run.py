@@ -100,6 +100,8 @@ def replay(stream: int, kernels: str = "default", dev=None, epochs=None, task: s
     batches = batches_on(raw, dev)
     if kernels == "fp32":
         model.precision, model.activation_storage, model.gradient_storage = "fp32", "fp32", "fp32"
+    elif kernels == "fp32_storages":      # the default f16x3 kernels through the session, activations and gradients stored as fp32
+        model.activation_storage, model.gradient_storage = "fp32", "fp32"
     model.rng_seed, model._rng_offset = 9000 + 101 * stream, 0
     supervision.manual_seed(7000 + 53 * stream)
     crit = vloss.VFLoss(SimpleNamespace(**trainer.SHIPPED_LOSS_CONFIG), SimpleNamespace(**trainer.SHIPPED_LOSS_WEIGHTS))
@@ -184,7 +186,7 @@ def markdown(report: dict) -> str:
     lines = [f"# The reference trainer's recorded {report.get('steps', 1200)}-step run, replayed on the HIP path\n",
              report["task"] + "\n",
              f"Per {W}-step window: mean over the reference's runs [min .. max of its runs] | mean over the replays [min .. max].\n"]
-    for fam in ("default", "fp32"):
+    for fam in ("default", "fp32_storages", "fp32"):
         if fam not in report:
             continue
         c = report[fam]["comparison"]
@@ -219,8 +221,11 @@ def main() -> None:
                       f"samples, 8 orbit views, targets rendered by the reference from a teacher of another seed; the reference's own train_epoch ran it "
                       f"{ref['loss'].shape[0]} times (row 0 = the run recorded in tests/golden/{TASKS[task].replace('_run', '')}, reproduced to {float(raw['runs.reproduces_recorded'][0]):.1e} when the "
                       f"fixture was made; the others under other torch / numpy seeds)."}
-    for fam, what in (("default", "default kernels (f16x3, 16-bit storages)"), ("fp32", "exact-fp32 kernels, fp32 storages (control)")):
-        runs = [replay(s, fam, task=task) for s in range(streams if fam == "default" else control)]
+    families = [("default", "default kernels (f16x3, 16-bit storages)"), ("fp32", "exact-fp32 kernels, fp32 storages (control)")]
+    if "--fp32-storages" in sys.argv:
+        families.insert(1, ("fp32_storages", "default f16x3 kernels, activations and gradients stored as fp32"))
+    for fam, what in families:
+        runs = [replay(s, fam, task=task) for s in range(control if fam == "fp32" else streams)]
         if not runs:
             continue
         report[fam] = {"what": what, "runs": len(runs), "issued_as": runs[0]["issued_as"], "ms_per_step": round(1e3 * sum(r["seconds"] for r in runs) / sum(r["steps"] for r in runs), 3),
