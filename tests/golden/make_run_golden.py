@@ -14,7 +14,8 @@ curves is the yardstick a statistical comparison of another implementation's cur
 Runs only in the build container (needs /root/reference, read-only); nothing of the reference's source travels.
 
     python tests/golden/make_run_golden.py [--streams 4]          # ~2 minutes per stream on 8 cores
-    python tests/golden/make_run_golden.py --far [--streams 3]    # the 8 000-step run of trained_far.npz (256-ray batches): ~1 hour per stream
+    python tests/golden/make_run_golden.py --far [--streams 3]    # the 8 000-step run of trained_far.npz (256-ray batches): ~half an hour per stream
+    python tests/golden/make_run_golden.py --far --append 4       # four MORE reference runs appended to the existing fixture (its task is re-checked)
 
 Writes ``trained_256_run.npz`` (``--far``: ``trained_far_run.npz``, the task and reference runs of ``trained_far.npz``'s recorded run):
 * ``batch.uv [100,64,2]``, ``batch.pose [100,4,4]``, ``batch.intrinsics [100,4,4]`` (one per batch: every ray of a batch shares them),
@@ -50,7 +51,8 @@ mt = _load("make_trained_golden")
 mtg = mt.mtg
 from vf_nerf_amd import synthetic  # noqa: E402
 
-EXTRA_SEEDS = ((4100, 3025), (5100, 4025), (6100, 5025), (7100, 6025), (8100, 7025))     # (torch, numpy) of the further streams
+EXTRA_SEEDS = ((4100, 3025), (5100, 4025), (6100, 5025), (7100, 6025), (8100, 7025), (9100, 8025), (10100, 9025), (11100, 10025),
+               (12100, 11025), (13100, 12025))     # (torch, numpy) of the further streams
 
 
 def main() -> None:
@@ -76,9 +78,24 @@ def main() -> None:
     arrays["batch.rgb"] = np.stack([b["rgb"][0].numpy() for b in batches])
     arrays["batch.depth"] = np.stack([b["depth"][0].numpy() for b in batches])
 
-    seeds = [(fx["torch_seed"], fx["numpy_seed"])] + list(EXTRA_SEEDS[:streams - 1])
+    path = os.path.join(HERE, "trained_far_run.npz" if far else "trained_256_run.npz")
+    append = int(sys.argv[sys.argv.index("--append") + 1]) if "--append" in sys.argv else 0
     runs = {"loss": [], "terms": [], "clip": [], "psnr_before_after": []}
-    for r, (ts, ns) in enumerate(seeds):
+    if append:
+        have = np.load(path)
+        for k in ("batch.uv", "batch.pose", "batch.intrinsics", "batch.rgb", "batch.depth", "init.head_weight", "init.head_bias", "init.checksum"):
+            assert np.array_equal(have[k], arrays[k]), f"the regenerated task differs from the fixture's at {k}"
+        done = [tuple(int(v) for v in row) for row in have["runs.seeds"]]
+        for k in runs:
+            runs[k] = [row for row in have[f"runs.{k}"]]
+        arrays["runs.reproduces_recorded"] = have["runs.reproduces_recorded"]
+        todo = [sd for sd in EXTRA_SEEDS if sd not in done][:append]
+        seeds = done + todo
+    else:
+        done = []
+        seeds = todo = [(fx["torch_seed"], fx["numpy_seed"])] + list(EXTRA_SEEDS[:streams - 1])
+    for ts, ns in todo:
+        r = len(runs["loss"])
         t0 = time.time()
         _, stats = mt.train(fx, batches=batches, torch_seed=ts, numpy_seed=ns, quiet=True)
         for k in runs:
@@ -93,12 +110,19 @@ def main() -> None:
             # later steps may part through thread-order rounding of the CPU GEMMs — reported, not required
             assert float(np.abs(stats["curve.loss"][:100] - recorded["curve.loss"][:100]).max()) < 1e-3, "the regenerated task is not the recorded run's"
             arrays["runs.reproduces_recorded"] = np.array([gap, gap_psnr])
+        # (written after every run: a half-hour run is not lost to an interruption)
+        snap = dict(arrays)
+        for k, v in runs.items():
+            snap[f"runs.{k}"] = np.stack(v)
+        snap["runs.seeds"] = np.array(seeds[:len(runs["loss"])], dtype=np.int64)
+        snap["runs.term_names"] = np.array(["rgb_loss", "depth_loss", "unit_norm_loss", "supervision_loss", "norm_smaller_than_one_loss", "directional_derivatives_loss"])
+        snap["train_recipe"] = np.array(repr(fx))
+        np.savez_compressed(path, **snap)
     for k, v in runs.items():
         arrays[f"runs.{k}"] = np.stack(v)
     arrays["runs.seeds"] = np.array(seeds, dtype=np.int64)
     arrays["runs.term_names"] = np.array(["rgb_loss", "depth_loss", "unit_norm_loss", "supervision_loss", "norm_smaller_than_one_loss", "directional_derivatives_loss"])
     arrays["train_recipe"] = np.array(repr(fx))
-    path = os.path.join(HERE, "trained_far_run.npz" if far else "trained_256_run.npz")
     np.savez_compressed(path, **arrays)
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB), {len(seeds)} reference runs")
 

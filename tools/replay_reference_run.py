@@ -102,6 +102,8 @@ def replay(stream: int, kernels: str = "default", dev=None, epochs=None, task: s
         model.precision, model.activation_storage, model.gradient_storage = "fp32", "fp32", "fp32"
     elif kernels == "fp32_storages":      # the default f16x3 kernels through the session, activations and gradients stored as fp32
         model.activation_storage, model.gradient_storage = "fp32", "fp32"
+    elif kernels.startswith("storages:"):      # "storages:<activations>,<gradients>", e.g. storages:f16,fp32
+        model.activation_storage, model.gradient_storage = kernels.split(":", 1)[1].split(",")
     model.rng_seed, model._rng_offset = 9000 + 101 * stream, 0
     supervision.manual_seed(7000 + 53 * stream)
     crit = vloss.VFLoss(SimpleNamespace(**trainer.SHIPPED_LOSS_CONFIG), SimpleNamespace(**trainer.SHIPPED_LOSS_WEIGHTS))
