@@ -102,6 +102,13 @@ def replay(stream: int, kernels: str = "default", dev=None, epochs=None, task: s
         model.precision, model.activation_storage, model.gradient_storage = "fp32", "fp32", "fp32"
     elif kernels == "fp32_storages":      # the default f16x3 kernels through the session, activations and gradients stored as fp32
         model.activation_storage, model.gradient_storage = "fp32", "fp32"
+    elif kernels == "default_lbl":          # the default kernels and storages WITHOUT the step session: launch-by-launch autograd (backward.py), dense colours
+        model.step_sessions = False
+    elif kernels == "fp32_backward":        # the f16x3 FORWARD kernels with the exact-fp32 BACKWARD kernels (a diagnostic knob: launch by launch)
+        model.backward_kernels = "fp32"
+        model.vector_field_network.backward_kernels = model.rendering_network.backward_kernels = "fp32"
+    elif kernels == "default_dense":        # the step session with the DENSE colour branch
+        model.sparse_colour_training = False
     elif kernels.startswith("storages:"):      # "storages:<activations>,<gradients>", e.g. storages:f16,fp32
         model.activation_storage, model.gradient_storage = kernels.split(":", 1)[1].split(",")
     model.rng_seed, model._rng_offset = 9000 + 101 * stream, 0
