@@ -81,13 +81,13 @@ def test_recorded_reference_run_replays_on_the_exact_fp32_kernels():
 
 def test_recorded_far_run_replays_on_the_default_kernels():
     """The same comparison on the LONG run: the 8 000 steps on 256-ray batches that produced ``trained_far.npz`` (the state the headline's
-    trained scene and the two-product colour analysis use), against the reference's own three runs of that task
+    trained scene and the two-product colour analysis use), against the reference's own EIGHT runs of that task
     (``tests/golden/trained_far_run.npz``: ``make_run_golden.py --far``, half an hour of CPU per reference run; the recorded one reproduced
     bit for bit over all 8 000 steps).  500-step windows.  A handful of reference runs make a narrow envelope (+- 1-3 % per window) while
     single runs of ANY family sit +- 1.5-5 % from their family's mean (chaotic, and not reproducible run to run: the order of the atomic
     sums differs), so the yardstick here is the RATIO of the family means per window, with bounds a three-run family keeps.  What many
-    runs measured (profiles/r06/replay_far_families.txt): default path 1.020 +- 0.009 (24 runs), exact-fp32 kernels 1.018 +- 0.011 (14),
-    fp32 storages / no session / dense colours / exact backward 1.02-1.03 — indistinguishable from each other and from the reference."""
+    runs measured (profiles/r06/replay_far_families.txt): default path 1.010 +- 0.009 (24 runs), exact-fp32 kernels 0.998 +- 0.010 (12)
+    of the eight reference runs' mean; fp32 storages / no session / dense colours / exact backward: indistinguishable as well."""
     import replay_reference_run as rr
     if not rr.task_available("far"):
         pytest.skip("tests/golden/trained_far_run.npz has not been generated")
