@@ -268,7 +268,8 @@ def test_attached_normals_gradients_match_reference():
     assert grad_rel_err(detached[k], d[f"grad.{k}"]) > 1e-3, "the fixture must tell the two settings apart"
 
 
-def test_recorded_run_fixture_is_the_recorded_run():
+@pytest.mark.parametrize("task,recorded", [("trained_256_run", "trained_256"), ("trained_far_run", "trained_far")])
+def test_recorded_run_fixture_is_the_recorded_run(task, recorded):
     """tests/golden/trained_256_run.npz (make_run_golden.py): the task of the run recorded in trained_256.npz.  Row 0 of its reference curves
     IS the recorded curve (the reference trainer re-run on the regenerated batches reproduced it bit for bit), the initial weights rebuild
     from the recipe + the stored vector head to the reference model's checksum, and the targets are what the teacher rendered (hit fraction
@@ -279,8 +280,8 @@ def test_recorded_run_fixture_is_the_recorded_run():
 
     import numpy as np
     here = os.path.dirname(os.path.abspath(__file__))
-    run = np.load(os.path.join(here, "golden", "trained_256_run.npz"))
-    rec = np.load(os.path.join(here, "golden", "trained_256.npz"))
+    run = np.load(os.path.join(here, "golden", f"{task}.npz"))
+    rec = np.load(os.path.join(here, "golden", f"{recorded}.npz"))
     assert float(run["runs.reproduces_recorded"][0]) == 0.0 and np.array_equal(run["runs.loss"][0], rec["curve.loss"])
     assert np.array_equal(run["runs.terms"][0], rec["curve.terms"]) and np.array_equal(run["runs.clip"][0], rec["curve.clip"])
     assert np.array_equal(run["runs.psnr_before_after"][0], rec["curve.psnr_before_after"])
